@@ -1,0 +1,85 @@
+"""Synthetic tet meshes of the reference's own shapes (host-side input generators).
+
+``truth_cube`` follows ``VolMeshSamples::CreateTruthCube`` (reference
+src/deformable/VolMeshSamples.cpp:67-130): nodes in i-major order ``i*ny*nz + j*nz + k`` starting at
+``(-nx/2, 0, -nz/2) * cellsize``, six tets per cell in the fixed corner pattern
+(LBN,LTN,RBN,LBF) (RTN,LTN,LBF,RBN) (RTN,LTN,LTF,LBF) (RTN,RBN,LBF,RBF) (RTN,LBF,LTF,RBF) (RTN,LTF,RTF,RBF).
+"""
+import numpy as np
+
+
+def truth_cube(nx, ny, nz, cellsize=0.1):
+    """Returns (verts float64 [n,3], tets int32 [m,4])."""
+    if nx < 2 or ny < 2 or nz < 2:
+        raise ValueError("truth cube needs at least 2 nodes per axis")
+    i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    start = np.array([-float(nx) / 2.0, 0.0, -float(nz) / 2.0]) * cellsize
+    verts = start[None, :] + np.stack([i.ravel(), j.ravel(), k.ravel()], axis=1).astype(np.float64) * cellsize
+    ci, cj, ck = np.meshgrid(np.arange(nx - 1), np.arange(ny - 1), np.arange(nz - 1), indexing="ij")
+    ci, cj, ck = ci.ravel(), cj.ravel(), ck.ravel()
+
+    def nid(di, dj, dk):
+        return (ci + di) * ny * nz + (cj + dj) * nz + (ck + dk)
+
+    LBN, LBF, LTN, LTF = nid(0, 0, 0), nid(0, 0, 1), nid(0, 1, 0), nid(0, 1, 1)
+    RBN, RBF, RTN, RTF = nid(1, 0, 0), nid(1, 0, 1), nid(1, 1, 0), nid(1, 1, 1)
+    six = [(LBN, LTN, RBN, LBF), (RTN, LTN, LBF, RBN), (RTN, LTN, LTF, LBF),
+           (RTN, RBN, LBF, RBF), (RTN, LBF, LTF, RBF), (RTN, LTF, RTF, RBF)]
+    tets = np.stack([np.stack(t, axis=1) for t in six], axis=1).reshape(-1, 4)
+    return np.ascontiguousarray(verts), np.ascontiguousarray(tets.astype(np.int32))
+
+
+def cube_fixed_plane_i0(ny, nz):
+    """Node ids of the i = 0 plane (the cantilever's clamped face)."""
+    return np.arange(ny * nz, dtype=np.int32)
+
+
+def fixed_vertices_to_dofs(fixed_vertices):
+    """``Deformable::FixedVerticesToFixedDOF`` (reference src/deformable/Deformable.cpp:294-314): sort, x3."""
+    v = np.sort(np.asarray(fixed_vertices, dtype=np.int32))
+    return (3 * v[:, None] + np.arange(3, dtype=np.int32)[None, :]).reshape(-1).astype(np.int32)
+
+
+def read_veg(path):
+    """Minimal Vega .veg reader (``*VERTICES`` / ``*ELEMENTS TET``, 1- or 0-indexed as the header row says).
+
+    Format as in reference data/models/beam3/beam3_tet.veg and src/deformable/VolMeshIO.cpp.
+    """
+    verts, tets = [], []
+    mode = None
+    with open(path, "r") as f:
+        lines = [ln.strip() for ln in f]
+    idx = 0
+    while idx < len(lines):
+        ln = lines[idx]
+        idx += 1
+        if not ln or ln.startswith("#"):
+            continue
+        if ln.startswith("*"):
+            key = ln.upper()
+            if key.startswith("*VERTICES"):
+                mode = "v"
+                while not lines[idx] or lines[idx].startswith("#"):
+                    idx += 1
+                idx += 1  # "<n> 3 0 0"
+            elif key.startswith("*ELEMENTS"):
+                mode = "e"
+                while not lines[idx] or lines[idx].startswith("#"):
+                    idx += 1
+                if lines[idx].upper().startswith("TET"):
+                    idx += 1
+                while not lines[idx] or lines[idx].startswith("#"):
+                    idx += 1
+                idx += 1  # "<m> 4 0"
+            else:
+                mode = None
+            continue
+        parts = ln.replace(",", " ").split()
+        if mode == "v" and len(parts) >= 4:
+            verts.append((int(parts[0]), float(parts[1]), float(parts[2]), float(parts[3])))
+        elif mode == "e" and len(parts) >= 5:
+            tets.append(tuple(int(p) for p in parts[:5]))
+    v = np.array(verts, dtype=np.float64)
+    e = np.array(tets, dtype=np.int64)
+    base = int(v[:, 0].min()) if len(v) else 1
+    return np.ascontiguousarray(v[:, 1:4]), np.ascontiguousarray((e[:, 1:5] - base).astype(np.int32))
