@@ -1,0 +1,79 @@
+// Shared host-side helpers of libfembrain_hip.so (error text, device buffers, timing).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fembrain_hip.h"
+
+namespace fb {
+
+std::string& last_error();
+int fail(int code, const char* fmt, ...);
+
+#define FB_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      return fb::fail(FB_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+#define FB_TRY(expr)            \
+  do {                          \
+    int _r = (expr);            \
+    if (_r != FB_OK) return _r; \
+  } while (0)
+
+// device array owned by a handle
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  int alloc(size_t count) {
+    if (count == n && p) return FB_OK;
+    release();
+    if (count == 0) return FB_OK;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) return fail(FB_ENOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    n = count;
+    return FB_OK;
+  }
+  int zero(hipStream_t s) {
+    if (n) FB_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
+    return FB_OK;
+  }
+  int upload(const T* host, size_t count, hipStream_t s) {
+    FB_TRY(alloc(count));
+    if (count) {
+      FB_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+      FB_HIP(hipStreamSynchronize(s));
+    }
+    return FB_OK;
+  }
+  int upload(const std::vector<T>& v, hipStream_t s) { return upload(v.data(), v.size(), s); }
+  int download(T* host, size_t count, hipStream_t s, size_t offset = 0) const {
+    if (count) {
+      FB_HIP(hipMemcpyAsync(host, p + offset, count * sizeof(T), hipMemcpyDeviceToHost, s));
+      FB_HIP(hipStreamSynchronize(s));
+    }
+    return FB_OK;
+  }
+};
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace fb

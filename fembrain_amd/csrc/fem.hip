@@ -1,0 +1,710 @@
+// C-ABI of the FEM hot path (include/fembrain_hip.h): handle life cycle, the per-step driver and the
+// inspection entry points.  Kernels live in fem_device.hip.h, the host-side plan in fem_plan.cpp.
+#include <algorithm>
+#include <cmath>
+
+#include "comm.h"
+#include "common.h"
+#include "fem_device.hip.h"
+#include "fem_plan.h"
+
+using namespace fb;
+
+struct fb_fem_s {
+  fb_fem_params prm;
+  hipStream_t stream = nullptr;
+  fb_comm_s* comm = nullptr;  // not owned
+  FemPlan plan;
+  double lambda = 0, mu = 0;
+  int grid = 8;
+  bool f64 = false;
+  // mesh
+  DevBuf<int4> tets;
+  DevBuf<double> x0, rest, fe;
+  DevBuf<char> rec;  // MT[16] per tet
+  // matrix
+  DevBuf<int> slice_off, colidx, slot_coff, slot_ccnt, send_local;
+  DevBuf<uint32_t> contrib;
+  DevBuf<uint8_t> dofmask;
+  DevBuf<char> vals;  // MT[n_slots][9][64]
+  DevBuf<double> mblk;
+  // vectors (3*n_local each)
+  DevBuf<double> q, qvel, fext, fint, rhs, x, r, d, Ad, invdiag, tmp, sendbuf;
+  DevBuf<double> part_a, part_b, scal;
+  DevBuf<CGState> st;
+  DevBuf<int> counter;
+  CGState* st_host = nullptr;  // pinned, 2 slots
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr}, ev_batch[2] = {nullptr, nullptr};
+  bool system_valid = false;
+  double last_assembly_s = 0, last_solve_s = 0;
+};
+
+namespace {
+
+size_t mt_size(const fb_fem_s* h) { return h->f64 ? sizeof(double) : sizeof(float); }
+
+SellView sell_view(const fb_fem_s* h) {
+  SellView sv;
+  sv.slice_off = h->slice_off.p; sv.colidx = h->colidx.p; sv.n_slices = h->plan.n_slices; sv.n_owned = h->plan.n_owned;
+  return sv;
+}
+
+int upload_plan(fb_fem_s* h, const double* xyz_global) {
+  const FemPlan& P = h->plan;
+  hipStream_t s = h->stream;
+  std::vector<int4> t4(P.n_tets);
+  for (int e = 0; e < P.n_tets; e++) t4[e] = make_int4(P.tets[4 * (size_t)e], P.tets[4 * (size_t)e + 1], P.tets[4 * (size_t)e + 2], P.tets[4 * (size_t)e + 3]);
+  FB_TRY(h->tets.upload(t4, s));
+  std::vector<double> x0((size_t)3 * P.n_local);
+  for (int l = 0; l < P.n_local; l++)
+    for (int k = 0; k < 3; k++) x0[3 * (size_t)l + k] = xyz_global[3 * (size_t)P.local2global[l] + k];
+  FB_TRY(h->x0.upload(x0, s));
+  FB_TRY(h->rest.alloc((size_t)16 * P.n_tets));
+  FB_TRY(h->fe.alloc((size_t)12 * P.n_tets));
+  FB_TRY(h->rec.alloc((size_t)16 * P.n_tets * mt_size(h)));
+  FB_TRY(h->slice_off.upload(P.slice_off, s));
+  FB_TRY(h->colidx.upload(P.colidx, s));
+  FB_TRY(h->slot_coff.upload(P.slot_coff, s));
+  FB_TRY(h->slot_ccnt.upload(P.slot_ccnt, s));
+  FB_TRY(h->contrib.upload(P.contrib, s));
+  FB_TRY(h->dofmask.upload(P.dofmask, s));
+  if (!P.send_local.empty()) FB_TRY(h->send_local.upload(P.send_local, s));
+  FB_TRY(h->sendbuf.alloc(std::max<size_t>(1, (size_t)3 * P.send_local.size())));
+  FB_TRY(h->vals.alloc((size_t)P.n_slots * 9 * 64 * mt_size(h)));
+  FB_TRY(h->vals.zero(s));
+  FB_TRY(h->mblk.alloc((size_t)P.n_slots * 64));
+  FB_TRY(h->mblk.zero(s));
+  const size_t nv = (size_t)3 * P.n_local;
+  DevBuf<double>* vecs[] = {&h->q, &h->qvel, &h->fext, &h->fint, &h->rhs, &h->x, &h->r, &h->d, &h->Ad, &h->invdiag, &h->tmp};
+  for (auto* v : vecs) {
+    FB_TRY(v->alloc(nv));
+    FB_TRY(v->zero(s));
+  }
+  const int chunk = ceil_div(P.n_slices, 8);
+  const int per = std::max(1, std::min(kMaxPartials / 8, ceil_div(chunk, kWavesPerBlock)));
+  h->grid = 8 * per;
+  FB_TRY(h->part_a.alloc(kMaxPartials));
+  FB_TRY(h->part_b.alloc(kMaxPartials));
+  FB_TRY(h->scal.alloc(4));
+  FB_TRY(h->st.alloc(1));
+  FB_TRY(h->st.zero(s));
+  FB_TRY(h->counter.alloc(1));
+  FB_HIP(hipStreamSynchronize(s));
+  h->system_valid = false;
+  return FB_OK;
+}
+
+int launch_rest(fb_fem_s* h) {
+  const int nt = h->plan.n_tets;
+  hipLaunchKernelGGL(k_tet_rest, dim3(ceil_div(nt, kBlock)), dim3(kBlock), 0, h->stream, nt, h->tets.p, h->x0.p, h->rest.p);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+// halo refresh of a node vector (3 doubles per node); no-op for an unsharded handle
+__global__ __launch_bounds__(kBlock) void k_pack_nodes(int n, const int* __restrict__ ids, const double* __restrict__ v,
+                                                       double* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const size_t s = 3 * (size_t)ids[i];
+  out[3 * (size_t)i] = v[s]; out[3 * (size_t)i + 1] = v[s + 1]; out[3 * (size_t)i + 2] = v[s + 2];
+}
+
+int halo_exchange(fb_fem_s* h, double* vec) {
+  if (!h->comm || h->comm->n_ranks == 1) return FB_OK;
+  const FemPlan& P = h->plan;
+  const int ns = (int)P.send_local.size();
+  if (ns > 0) {
+    hipLaunchKernelGGL(k_pack_nodes, dim3(ceil_div(ns, kBlock)), dim3(kBlock), 0, h->stream, ns, h->send_local.p, vec, h->sendbuf.p);
+    FB_HIP(hipGetLastError());
+  }
+  return comm_exchange_nodes(h->comm, h->sendbuf.p, P.send_off.data(), vec + 3 * (size_t)P.n_owned, P.halo_off.data(), h->stream);
+}
+
+template <typename MT>
+int launch_warp(fb_fem_s* h, const double* u, double* rot) {
+  const int nt = h->plan.n_tets;
+  hipLaunchKernelGGL(k_tet_warp<MT>, dim3(ceil_div(nt, kBlock)), dim3(kBlock), 0, h->stream, nt, h->tets.p, h->x0.p, u, h->rest.p,
+                     (MT*)h->rec.p, h->fe.p, rot, h->lambda, h->mu);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+template <typename MT>
+int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const double* fext, double* mblk_out, double* fint_out,
+                double* rhs, double* invdiag) {
+  hipLaunchKernelGGL(k_assemble_rows<MT>, dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), h->slot_coff.p, h->slot_ccnt.p,
+                     h->contrib.p, (const MT*)h->rec.p, h->fe.p, h->dofmask.p, qvel, fext, (MT*)h->vals.p, mblk_out, fint_out, rhs,
+                     invdiag, ap);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+// pass 1 + pass 2 of the system of the current state (Keff, rhs, invdiag)
+int assemble_system(fb_fem_s* h) {
+  const double hh = h->prm.timestep, cM = h->prm.damping_mass, cK = h->prm.damping_stiffness;
+  FB_TRY(halo_exchange(h, h->q.p));
+  FB_TRY(halo_exchange(h, h->qvel.p));
+  AsmParams ap;
+  ap.lambda = h->lambda; ap.mu = h->mu; ap.rho20 = h->prm.rho / 20.0;
+  ap.s_k = hh * (hh + cK); ap.s_m = 1.0 + hh * cM;   // Keff = M + h D + h^2 K, D = cK K + cM M
+  ap.g_k = hh + cK; ap.g_m = cM;                     // (h K + D) qvel
+  ap.h = hh; ap.apply_mask = 1;
+  if (h->f64) {
+    FB_TRY(launch_warp<double>(h, h->q.p, nullptr));
+    FB_TRY(launch_rows<double>(h, ap, h->qvel.p, h->fext.p, nullptr, h->fint.p, h->rhs.p, h->invdiag.p));
+  } else {
+    FB_TRY(launch_warp<float>(h, h->q.p, nullptr));
+    FB_TRY(launch_rows<float>(h, ap, h->qvel.p, h->fext.p, nullptr, h->fint.p, h->rhs.p, h->invdiag.p));
+  }
+  h->system_valid = true;
+  return FB_OK;
+}
+
+template <typename MT, int MODE>
+int launch_spmv(fb_fem_s* h, const double* x, double* y, const double* b, double* partial, int parity) {
+  hipLaunchKernelGGL((k_spmv<MT, MODE>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, x, y, b,
+                     h->invdiag.p, partial, h->st.p, parity);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+template <int MODE>
+int spmv(fb_fem_s* h, const double* x, double* y, const double* b, double* partial, int parity) {
+  return h->f64 ? launch_spmv<double, MODE>(h, x, y, b, partial, parity) : launch_spmv<float, MODE>(h, x, y, b, partial, parity);
+}
+
+// multi-GPU: fold the per-block partials into one scalar and all-reduce it; returns the device scalar pointer
+// the consumer kernels should read, or nullptr (single GPU: consumers sum the partials themselves)
+__global__ __launch_bounds__(kBlock) void k_fold_partials(const double* partial, int n, double* out, const CGState* st) {
+  __shared__ double lds[4];
+  if (st && st->done) return;
+  const double s = sum_partials(partial, n, lds);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+int global_scalar(fb_fem_s* h, const double* partial, double** out, bool check_done) {
+  *out = nullptr;
+  if (!h->comm || h->comm->n_ranks == 1) return FB_OK;
+  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(kBlock), 0, h->stream, partial, h->grid, h->scal.p, check_done ? h->st.p : nullptr);
+  FB_HIP(hipGetLastError());
+  // a converged solve leaves the previous (identical on every rank) value in place; the all-reduce still runs on
+  // every rank so the collective sequence stays matched, and its result is ignored by the done-checking consumers
+  FB_TRY(comm_allreduce_sum(h->comm, h->scal.p, 1, h->stream));
+  *out = h->scal.p;
+  return FB_OK;
+}
+
+int pcg_iteration(fb_fem_s* h, int it, const double* b) {
+  const FemPlan& P = h->plan;
+  const int parity = (it - 1) & 1;
+  const bool refresh = (it % 30 == 0);
+  double* sc = nullptr;
+  FB_TRY(halo_exchange(h, h->d.p));
+  FB_TRY(spmv<1>(h, h->d.p, h->Ad.p, nullptr, h->part_a.p, parity));
+  FB_TRY(global_scalar(h, h->part_a.p, &sc, true));
+  if (!refresh) {
+    hipLaunchKernelGGL(k_cg_update<false>, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity,
+                       h->part_a.p, h->grid, sc, h->d.p, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->part_b.p);
+    FB_HIP(hipGetLastError());
+  } else {
+    hipLaunchKernelGGL(k_cg_update<true>, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity,
+                       h->part_a.p, h->grid, sc, h->d.p, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->part_b.p);
+    FB_HIP(hipGetLastError());
+    FB_TRY(halo_exchange(h, h->x.p));
+    FB_TRY(spmv<2>(h, h->x.p, h->r.p, b, h->part_b.p, parity));
+  }
+  FB_TRY(global_scalar(h, h->part_b.p, &sc, true));
+  hipLaunchKernelGGL(k_cg_direction, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_b.p,
+                     h->grid, sc, h->r.p, h->invdiag.p, h->d.p);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+bool host_finished(const CGState& s) {
+  if (s.done) return true;
+  const double rho = s.rho[s.iter & 1];
+  return !(rho > s.eps2 * s.rho0) || s.iter >= s.max_iter;
+}
+
+// Jacobi-PCG on the assembled system, rhs b -> h->x.  iters_out: + converged / - not (CGSolver.cpp:189).
+int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state) {
+  const FemPlan& P = h->plan;
+  hipStream_t s = h->stream;
+  hipLaunchKernelGGL(k_cg_init, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, b, h->invdiag.p, h->x.p, h->r.p, h->d.p,
+                     h->part_b.p);
+  FB_HIP(hipGetLastError());
+  double* sc = nullptr;
+  FB_TRY(global_scalar(h, h->part_b.p, &sc, false));
+  hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, s, h->st.p, h->part_b.p, h->grid, sc, eps, max_iter);
+  FB_HIP(hipGetLastError());
+  const int kBatch = 30;
+  int it = 1, slot = 0;
+  bool pending[2] = {false, false};
+  CGState fin;
+  memset(&fin, 0, sizeof fin);
+  bool finished = false;
+  while (!finished) {
+    const int n = std::min(kBatch, max_iter - it + 1);
+    for (int k = 0; k < n; k++, it++) FB_TRY(pcg_iteration(h, it, b));
+    FB_HIP(hipMemcpyAsync(&h->st_host[slot], h->st.p, sizeof(CGState), hipMemcpyDeviceToHost, s));
+    FB_HIP(hipEventRecord(h->ev_batch[slot], s));
+    pending[slot] = true;
+    const int prev = slot ^ 1;
+    if (pending[prev]) {  // look one batch behind so the queue never drains
+      FB_HIP(hipEventSynchronize(h->ev_batch[prev]));
+      pending[prev] = false;
+      if (host_finished(h->st_host[prev])) finished = true;
+    }
+    if (it > max_iter) finished = true;
+    slot ^= 1;
+  }
+  FB_HIP(hipStreamSynchronize(s));
+  // the newest snapshot is in the slot written last
+  fin = h->st_host[slot ^ 1];
+  if (!host_finished(fin)) return fail(FB_EDEVICE, "internal: PCG batches ended without a terminal state (iter %d)", fin.iter);
+  const double rho = fin.rho[fin.iter & 1];
+  const bool converged = !(rho > fin.eps2 * fin.rho0);
+  if (iters_out) *iters_out = converged ? fin.iter : -fin.iter;
+  if (final_state) *final_state = fin;
+  return FB_OK;
+}
+
+int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed, const int* fixed, int n_ranks,
+          int rank, const int* splits) {
+  FB_TRY(build_fem_plan(h->plan, n_nodes, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits));
+  FB_TRY(upload_plan(h, xyz));
+  FB_TRY(launch_rest(h));
+  FB_HIP(hipStreamSynchronize(h->stream));
+  return FB_OK;
+}
+
+int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed, const int* fixed,
+                  const fb_fem_params* params, int n_ranks, int rank, const int* splits, fb_comm_t comm) {
+  if (!out || !xyz || !tets || !params) return fail(FB_EINVAL, "null argument");
+  if (n_fixed < 0 || (n_fixed > 0 && !fixed)) return fail(FB_EINVAL, "bad constrained DOF list");
+  if (!(params->timestep > 0) || !(params->E > 0) || !(params->rho > 0) || !(params->nu > -1.0 && params->nu < 0.5))
+    return fail(FB_EINVAL, "bad material / timestep parameters");
+  if (n_ranks > 1 && (!comm || comm->n_ranks != n_ranks || comm->rank != rank)) return fail(FB_EINVAL, "sharded handle needs a matching communicator");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(FB_EDEVICE, "no HIP device visible");
+  if (params->device < 0 || params->device >= ndev) return fail(FB_EINVAL, "device %d out of range (%d visible)", params->device, ndev);
+  FB_HIP(hipSetDevice(params->device));
+  fb_fem_s* h = new fb_fem_s;
+  h->prm = *params;
+  h->comm = (n_ranks > 1) ? comm : nullptr;
+  h->f64 = params->matrix_precision == FB_MATRIX_F64;
+  h->lambda = (params->nu * params->E) / ((1 + params->nu) * (1 - 2 * params->nu));
+  h->mu = params->E / (2 * (1 + params->nu));
+  int rc = FB_OK;
+  do {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(FB_EDEVICE, "hipStreamCreate failed"); break; }
+    for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) rc = fail(FB_EDEVICE, "hipEventCreate failed");
+    for (auto& e : h->ev_batch) if (hipEventCreate(&e) != hipSuccess) rc = fail(FB_EDEVICE, "hipEventCreate failed");
+    if (rc != FB_OK) break;
+    if (hipHostMalloc((void**)&h->st_host, 2 * sizeof(CGState), hipHostMallocDefault) != hipSuccess) { rc = fail(FB_ENOMEM, "hipHostMalloc failed"); break; }
+    rc = build(h, n_nodes, xyz, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits);
+  } while (0);
+  if (rc != FB_OK) {
+    std::string keep = last_error();
+    fb_fem_destroy(h);
+    last_error() = keep;
+    return rc;
+  }
+  *out = h;
+  return FB_OK;
+}
+
+#define CHECK_HANDLE(h)                                   \
+  if (!(h)) return fail(FB_EINVAL, "null FEM handle");   \
+  FB_HIP(hipSetDevice((h)->prm.device))
+
+// global-length host vector -> local device vector (owned + halo)
+int upload_global_vec(fb_fem_s* h, const double* g, DevBuf<double>& dst) {
+  const FemPlan& P = h->plan;
+  if (P.n_ranks == 1) {
+    FB_HIP(hipMemcpyAsync(dst.p, g, sizeof(double) * 3 * (size_t)P.n_local, hipMemcpyHostToDevice, h->stream));
+    FB_HIP(hipStreamSynchronize(h->stream));
+    return FB_OK;
+  }
+  std::vector<double> loc((size_t)3 * P.n_local);
+  for (int l = 0; l < P.n_local; l++)
+    for (int k = 0; k < 3; k++) loc[3 * (size_t)l + k] = g[3 * (size_t)P.local2global[l] + k];
+  FB_HIP(hipMemcpyAsync(dst.p, loc.data(), sizeof(double) * loc.size(), hipMemcpyHostToDevice, h->stream));
+  FB_HIP(hipStreamSynchronize(h->stream));
+  return FB_OK;
+}
+
+// owned part of a device vector -> its range of a global-length host vector
+int download_owned(fb_fem_s* h, const DevBuf<double>& src, double* g) {
+  const FemPlan& P = h->plan;
+  return src.download(g + 3 * (size_t)P.node_lo, (size_t)3 * P.n_owned, h->stream);
+}
+
+// SELL device values -> 9 doubles per block in CSR (fb_fem_pattern) order
+int download_blocks(fb_fem_s* h, double* out) {
+  const FemPlan& P = h->plan;
+  const size_t n = (size_t)P.n_slots * 9 * 64;
+  std::vector<double> host(n);
+  if (h->f64) {
+    FB_HIP(hipMemcpyAsync(host.data(), h->vals.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    FB_HIP(hipStreamSynchronize(h->stream));
+  } else {
+    std::vector<float> hf(n);
+    FB_HIP(hipMemcpyAsync(hf.data(), h->vals.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    FB_HIP(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < n; i++) host[i] = hf[i];
+  }
+  for (int a = 0; a < P.n_owned; a++)
+    for (int p = P.bptr[a]; p < P.bptr[a + 1]; p++)
+      for (int v = 0; v < 9; v++) out[9 * (size_t)p + v] = host[((size_t)P.blk_slot[p] * 9 + v) * 64 + (a & 63)];
+  return FB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fb_last_error(void) { return last_error().c_str(); }
+
+int fb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int fb_device_info(int dev, char* name, int name_len, char* arch, int arch_len, int* n_cu) {
+  hipDeviceProp_t p;
+  FB_HIP(hipGetDeviceProperties(&p, dev));
+  if (name && name_len > 0) snprintf(name, name_len, "%s", p.name);
+  if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", p.gcnArchName);
+  if (n_cu) *n_cu = p.multiProcessorCount;
+  return FB_OK;
+}
+
+void fb_fem_default_params(fb_fem_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof *p);
+  p->E = 1e7; p->nu = 0.46; p->rho = 1000.0;
+  p->timestep = 0.0333; p->damping_mass = 0.0; p->damping_stiffness = 0.01;
+  p->cg_eps = 1e-6; p->cg_max_iter = 10000;
+  p->matrix_precision = FB_MATRIX_F32; p->device = 0;
+}
+
+int fb_fem_create(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed_dofs,
+                  const int* fixed_dofs, const fb_fem_params* params) {
+  return create_common(out, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs, params, 1, 0, nullptr, nullptr);
+}
+
+int fb_fem_create_sharded(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed_dofs,
+                          const int* fixed_dofs, const fb_fem_params* params, int n_ranks, int rank, const int* node_splits,
+                          fb_comm_t comm) {
+  return create_common(out, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs, params, n_ranks, rank, node_splits, comm);
+}
+
+int fb_fem_destroy(fb_fem_t h) {
+  if (!h) return FB_OK;
+  (void)hipSetDevice(h->prm.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->ev_batch) if (e) (void)hipEventDestroy(e);
+  if (h->st_host) (void)hipHostFree(h->st_host);
+  DevBuf<double>* vecs[] = {&h->q, &h->qvel, &h->fext, &h->fint, &h->rhs, &h->x, &h->r, &h->d, &h->Ad, &h->invdiag, &h->tmp};
+  for (auto* v : vecs) v->release();
+  hipStream_t s = h->stream;
+  delete h;  // frees the remaining device buffers
+  if (s) (void)hipStreamDestroy(s);
+  return FB_OK;
+}
+
+int fb_fem_resync(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed_dofs, const int* fixed_dofs) {
+  CHECK_HANDLE(h);
+  if (!xyz || !tets) return fail(FB_EINVAL, "null mesh");
+  if (h->plan.n_ranks > 1) return fail(FB_EINVAL, "resync of a sharded handle: destroy and create it again on every rank");
+  FB_HIP(hipStreamSynchronize(h->stream));
+  return build(h, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs, 1, 0, nullptr);
+}
+
+int fb_fem_rebuild_elements(fb_fem_t h) {
+  CHECK_HANDLE(h);
+  h->system_valid = false;
+  return launch_rest(h);
+}
+
+int fb_fem_set_external_forces(fb_fem_t h, const double* f) {
+  CHECK_HANDLE(h);
+  if (!f) return fail(FB_EINVAL, "null force vector");
+  return upload_global_vec(h, f, h->fext);
+}
+
+int fb_fem_add_external_forces(fb_fem_t h, const double* f) {
+  CHECK_HANDLE(h);
+  if (!f) return fail(FB_EINVAL, "null force vector");
+  FB_TRY(upload_global_vec(h, f, h->tmp));
+  const int n = 3 * h->plan.n_local;
+  hipLaunchKernelGGL(k_axpy, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, h->stream, n, 1.0, h->tmp.p, h->fext.p);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int fb_fem_set_external_forces_zero(fb_fem_t h) {
+  CHECK_HANDLE(h);
+  return h->fext.zero(h->stream);
+}
+
+int fb_fem_set_uniform_force(fb_fem_t h, int axis, double value) {
+  CHECK_HANDLE(h);
+  if (axis < 0 || axis > 2) return fail(FB_EINVAL, "axis %d", axis);
+  const int n = h->plan.n_local;
+  hipLaunchKernelGGL(k_fill_axis, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, h->stream, n, axis, value, h->fext.p);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int fb_fem_step(fb_fem_t h, fb_step_info* info) {
+  CHECK_HANDLE(h);
+  hipStream_t s = h->stream;
+  FB_HIP(hipEventRecord(h->ev[0], s));
+  FB_TRY(assemble_system(h));
+  FB_HIP(hipEventRecord(h->ev[1], s));
+  int iters = 0;
+  CGState fin;
+  FB_TRY(pcg_solve(h, h->rhs.p, h->prm.cg_eps, h->prm.cg_max_iter, &iters, &fin));
+  FB_HIP(hipEventRecord(h->ev[2], s));
+  const bool ok = iters >= 0;
+  if (ok) {
+    const int n = 3 * h->plan.n_owned;
+    hipLaunchKernelGGL(k_state_update, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, s, n, h->x.p, h->dofmask.p, h->prm.timestep, h->q.p,
+                       h->qvel.p);
+    FB_HIP(hipGetLastError());
+  }
+  FB_HIP(hipStreamSynchronize(s));
+  float ms_a = 0, ms_s = 0;
+  FB_HIP(hipEventElapsedTime(&ms_a, h->ev[0], h->ev[1]));
+  FB_HIP(hipEventElapsedTime(&ms_s, h->ev[1], h->ev[2]));
+  h->last_assembly_s = ms_a * 1e-3; h->last_solve_s = ms_s * 1e-3;
+  if (info) {
+    info->cg_iterations = std::abs(iters);
+    info->converged = ok ? 1 : 0;
+    info->assembly_seconds = h->last_assembly_s;
+    info->solve_seconds = h->last_solve_s;
+    info->rho0 = fin.rho0;
+    info->rho = fin.rho[fin.iter & 1];
+  }
+  if (!ok) return fail(FB_ESOLVER, "PCG sparse solver returned non-zero exit status %d", iters);
+  return FB_OK;
+}
+
+int fb_fem_get_state(fb_fem_t h, double* q, double* qvel, double* qaccel) {
+  CHECK_HANDLE(h);
+  if (q) FB_TRY(download_owned(h, h->q, q));
+  if (qvel) FB_TRY(download_owned(h, h->qvel, qvel));
+  if (qaccel) memset(qaccel + 3 * (size_t)h->plan.node_lo, 0, sizeof(double) * 3 * (size_t)h->plan.n_owned);  // forced 0, PS_VolumeConservingIntegrator.cpp:55
+  return FB_OK;
+}
+
+int fb_fem_set_state(fb_fem_t h, const double* q, const double* qvel, const double* qaccel) {
+  CHECK_HANDLE(h);
+  (void)qaccel;
+  if (!q) return fail(FB_EINVAL, "q must not be null (IntegratorBase::SetqState)");
+  FB_TRY(upload_global_vec(h, q, h->q));
+  if (qvel) FB_TRY(upload_global_vec(h, qvel, h->qvel));
+  h->system_valid = false;
+  return FB_OK;
+}
+
+int fb_fem_reset(fb_fem_t h) {
+  CHECK_HANDLE(h);
+  FB_TRY(h->q.zero(h->stream));
+  FB_TRY(h->qvel.zero(h->stream));
+  h->system_valid = false;
+  return FB_OK;
+}
+
+int fb_fem_set_timestep(fb_fem_t h, double timestep) {
+  CHECK_HANDLE(h);
+  if (!(timestep > 0)) return fail(FB_EINVAL, "timestep must be positive");
+  h->prm.timestep = timestep;
+  h->system_valid = false;
+  return FB_OK;
+}
+
+int fb_fem_set_damping(fb_fem_t h, double damping_mass, double damping_stiffness) {
+  CHECK_HANDLE(h);
+  h->prm.damping_mass = damping_mass; h->prm.damping_stiffness = damping_stiffness;
+  h->system_valid = false;
+  return FB_OK;
+}
+
+int fb_fem_set_cg(fb_fem_t h, double eps, int max_iter) {
+  CHECK_HANDLE(h);
+  if (!(eps > 0) || max_iter < 0) return fail(FB_EINVAL, "bad PCG parameters");
+  h->prm.cg_eps = eps; h->prm.cg_max_iter = max_iter;
+  return FB_OK;
+}
+
+int fb_fem_set_constrained_dofs(fb_fem_t h, int n_fixed_dofs, const int* fixed_dofs) {
+  CHECK_HANDLE(h);
+  if (n_fixed_dofs < 0 || (n_fixed_dofs > 0 && !fixed_dofs)) return fail(FB_EINVAL, "bad constrained DOF list");
+  FB_TRY(plan_set_constraints(h->plan, n_fixed_dofs, fixed_dofs));
+  FB_TRY(h->dofmask.upload(h->plan.dofmask, h->stream));
+  h->system_valid = false;
+  return FB_OK;
+}
+
+int fb_fem_floor_collision(fb_fem_t h, double floor_y, double restitution, int* n_collided) {
+  CHECK_HANDLE(h);
+  FB_TRY(h->counter.zero(h->stream));
+  const int n = h->plan.n_owned;
+  hipLaunchKernelGGL(k_floor, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, h->stream, n, h->x0.p, floor_y, restitution, h->q.p,
+                     h->qvel.p, h->counter.p);
+  FB_HIP(hipGetLastError());
+  int c = 0;
+  FB_TRY(h->counter.download(&c, 1, h->stream));
+  if (n_collided) *n_collided = c;
+  h->system_valid = false;
+  return FB_OK;
+}
+
+int fb_fem_num_nodes(fb_fem_t h) { return h ? h->plan.n_global : 0; }
+int fb_fem_num_tets(fb_fem_t h) { return h ? h->plan.n_tets : 0; }
+int fb_fem_num_blocks(fb_fem_t h) { return h ? h->plan.n_blocks : 0; }
+
+int fb_fem_pattern(fb_fem_t h, int* bptr, int* bcol) {
+  if (!h || !bptr || !bcol) return fail(FB_EINVAL, "null argument");
+  const FemPlan& P = h->plan;
+  memcpy(bptr, P.bptr.data(), sizeof(int) * (P.n_owned + 1));
+  for (int p = 0; p < P.n_blocks; p++) bcol[p] = P.local2global[P.bcol[p]];
+  return FB_OK;
+}
+
+int fb_fem_element_stiffness(fb_fem_t h, int first, int count, double* K0, double* Minv) {
+  CHECK_HANDLE(h);
+  if (first < 0 || count < 0 || first + count > h->plan.n_tets || !K0) return fail(FB_EINVAL, "element range [%d,%d) outside [0,%d)", first, first + count, h->plan.n_tets);
+  const int kChunk = 1 << 16;
+  DevBuf<double> dK, dM;
+  FB_TRY(dK.alloc((size_t)144 * std::min(count, kChunk)));
+  if (Minv) FB_TRY(dM.alloc((size_t)16 * std::min(count, kChunk)));
+  for (int done = 0; done < count; done += kChunk) {
+    const int n = std::min(kChunk, count - done);
+    hipLaunchKernelGGL(k_element_K0_mfma, dim3(ceil_div(n, kWavesPerBlock)), dim3(kBlock), 0, h->stream, first + done, n, h->rest.p,
+                       h->lambda, h->mu, dK.p, Minv ? dM.p : nullptr, h->x0.p, h->tets.p);
+    FB_HIP(hipGetLastError());
+    FB_TRY(dK.download(K0 + (size_t)144 * done, (size_t)144 * n, h->stream));
+    if (Minv) FB_TRY(dM.download(Minv + (size_t)16 * done, (size_t)16 * n, h->stream));
+  }
+  return FB_OK;
+}
+
+int fb_fem_assemble(fb_fem_t h, const double* u, double* f, double* K_blocks) {
+  CHECK_HANDLE(h);
+  if (!u) return fail(FB_EINVAL, "null displacement");
+  FB_TRY(upload_global_vec(h, u, h->tmp));
+  FB_TRY(h->Ad.zero(h->stream));  // stands in for qvel and fext (both unused in raw mode)
+  AsmParams ap;
+  ap.lambda = h->lambda; ap.mu = h->mu; ap.rho20 = h->prm.rho / 20.0;
+  ap.s_k = 1.0; ap.s_m = 0.0; ap.g_k = 0.0; ap.g_m = 0.0; ap.h = 0.0; ap.apply_mask = 0;
+  if (h->f64) {
+    FB_TRY(launch_warp<double>(h, h->tmp.p, nullptr));
+    FB_TRY(launch_rows<double>(h, ap, h->Ad.p, h->Ad.p, h->mblk.p, h->r.p, nullptr, nullptr));
+  } else {
+    FB_TRY(launch_warp<float>(h, h->tmp.p, nullptr));
+    FB_TRY(launch_rows<float>(h, ap, h->Ad.p, h->Ad.p, h->mblk.p, h->r.p, nullptr, nullptr));
+  }
+  h->system_valid = false;
+  if (f) FB_TRY(download_owned(h, h->r, f));
+  if (K_blocks) FB_TRY(download_blocks(h, K_blocks));
+  return FB_OK;
+}
+
+int fb_fem_system(fb_fem_t h, double* Keff_blocks, double* rhs) {
+  CHECK_HANDLE(h);
+  FB_TRY(assemble_system(h));
+  if (rhs) FB_TRY(download_owned(h, h->rhs, rhs));
+  if (Keff_blocks) FB_TRY(download_blocks(h, Keff_blocks));
+  return FB_OK;
+}
+
+int fb_fem_mass(fb_fem_t h, double* m_blocks) {
+  CHECK_HANDLE(h);
+  if (!m_blocks) return fail(FB_EINVAL, "null output");
+  std::vector<double> u((size_t)3 * h->plan.n_global, 0.0);
+  FB_TRY(fb_fem_assemble(h, u.data(), nullptr, nullptr));
+  const FemPlan& P = h->plan;
+  std::vector<double> host((size_t)P.n_slots * 64);
+  FB_TRY(h->mblk.download(host.data(), host.size(), h->stream));
+  for (int a = 0; a < P.n_owned; a++)
+    for (int p = P.bptr[a]; p < P.bptr[a + 1]; p++) m_blocks[p] = host[(size_t)P.blk_slot[p] * 64 + (a & 63)];
+  return FB_OK;
+}
+
+int fb_fem_spmv(fb_fem_t h, const double* x, double* y) {
+  CHECK_HANDLE(h);
+  if (!x || !y) return fail(FB_EINVAL, "null vector");
+  if (!h->system_valid) FB_TRY(assemble_system(h));
+  FB_TRY(upload_global_vec(h, x, h->tmp));
+  FB_TRY(halo_exchange(h, h->tmp.p));
+  FB_TRY(spmv<0>(h, h->tmp.p, h->Ad.p, nullptr, nullptr, 0));
+  return download_owned(h, h->Ad, y);
+}
+
+int fb_fem_pcg(fb_fem_t h, const double* rhs, double* x, double eps, int max_iter, int* iterations_out) {
+  CHECK_HANDLE(h);
+  if (!rhs || !x) return fail(FB_EINVAL, "null vector");
+  if (!(eps > 0) || max_iter < 0) return fail(FB_EINVAL, "bad PCG parameters");
+  if (!h->system_valid) FB_TRY(assemble_system(h));
+  FB_TRY(upload_global_vec(h, rhs, h->tmp));
+  int iters = 0;
+  FB_TRY(pcg_solve(h, h->tmp.p, eps, max_iter, &iters, nullptr));
+  if (iterations_out) *iterations_out = iters;
+  return download_owned(h, h->x, x);
+}
+
+int fb_fem_time_spmv(fb_fem_t h, int reps, double* seconds_per_spmv) {
+  CHECK_HANDLE(h);
+  if (reps < 1 || !seconds_per_spmv) return fail(FB_EINVAL, "bad arguments");
+  if (!h->system_valid) FB_TRY(assemble_system(h));
+  FB_TRY(spmv<0>(h, h->rhs.p, h->Ad.p, nullptr, nullptr, 0));  // warm
+  FB_HIP(hipEventRecord(h->ev[0], h->stream));
+  for (int i = 0; i < reps; i++) FB_TRY(spmv<0>(h, h->rhs.p, h->Ad.p, nullptr, nullptr, 0));
+  FB_HIP(hipEventRecord(h->ev[1], h->stream));
+  FB_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0;
+  FB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  *seconds_per_spmv = ms * 1e-3 / reps;
+  return FB_OK;
+}
+
+int fb_fem_time_assembly(fb_fem_t h, int reps, double* seconds_per_assembly) {
+  CHECK_HANDLE(h);
+  if (reps < 1 || !seconds_per_assembly) return fail(FB_EINVAL, "bad arguments");
+  FB_TRY(assemble_system(h));
+  FB_HIP(hipEventRecord(h->ev[0], h->stream));
+  for (int i = 0; i < reps; i++) FB_TRY(assemble_system(h));
+  FB_HIP(hipEventRecord(h->ev[1], h->stream));
+  FB_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0;
+  FB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  *seconds_per_assembly = ms * 1e-3 / reps;
+  return FB_OK;
+}
+
+int fb_fem_spmv_bytes(fb_fem_t h, double* bytes) {
+  if (!h || !bytes) return fail(FB_EINVAL, "null argument");
+  const FemPlan& P = h->plan;
+  // SURVEY.md 8d BSR figure: nnzb*(9 values + 4 B index) + (rows+1)*4 + x read once + y written once (fp64 vectors)
+  *bytes = (double)P.n_blocks * (9.0 * mt_size(h) + 4.0) + (P.n_owned + 1) * 4.0 + 3.0 * P.n_owned * 8.0 * 2.0;
+  return FB_OK;
+}
+
+int fb_fem_assembly_bytes(fb_fem_t h, double* bytes) {
+  if (!h || !bytes) return fail(FB_EINVAL, "null argument");
+  const FemPlan& P = h->plan;
+  // pass 1: tet ids 16 + rest record 128 + 4 nodes * (x0 + u) 48 + rotated record 16*MT + element force 96
+  // pass 2: contribution words 16*4 per tet + Keff values 9*MT per block + index 4 per block + 5 node vectors
+  *bytes = (double)P.n_tets * (16.0 + 128.0 + 192.0 + 16.0 * mt_size(h) + 96.0 + 64.0) + (double)P.n_blocks * (9.0 * mt_size(h) + 4.0) +
+           3.0 * P.n_owned * 8.0 * 5.0;
+  return FB_OK;
+}
+
+}  // extern "C"

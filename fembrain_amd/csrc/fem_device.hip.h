@@ -1,0 +1,568 @@
+// FEM device kernels (included by fem.hip only).
+#pragma once
+#include "fem_kernels.h"
+
+namespace fb {
+
+// ------------------------------------------------------------------------------------------------------
+// a1 (rest state): per tet shape-function gradients b_k (rows of M^-1, vegafem corotationalLinearFEM.cpp:66-90)
+// and volume |det|/6 (tetMesh.cpp:184-188).  rest[16*e + 3*k + d] = b_k[d], rest[16*e + 12] = V,
+// rest[16*e + 13 + ...] unused.  One thread per tet.
+// ------------------------------------------------------------------------------------------------------
+__device__ inline void inv3x3(const double* A, double* I) {
+  const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+  const double id = 1.0 / (A[0] * c00 + A[1] * c01 + A[2] * c02);
+  I[0] = c00 * id; I[1] = (A[2] * A[7] - A[1] * A[8]) * id; I[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  I[3] = c01 * id; I[4] = (A[0] * A[8] - A[2] * A[6]) * id; I[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  I[6] = c02 * id; I[7] = (A[1] * A[6] - A[0] * A[7]) * id; I[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+__global__ __launch_bounds__(kBlock) void k_tet_rest(int nt, const int4* __restrict__ tets, const double* __restrict__ x0,
+                                                     double* __restrict__ rest) {
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= nt) return;
+  const int4 t = tets[e];
+  const int id[4] = {t.x, t.y, t.z, t.w};
+  double p[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int d = 0; d < 3; d++) p[k][d] = x0[3 * (size_t)id[k] + d];
+  double Dm[9], Di[9];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    Dm[3 * d + 0] = p[1][d] - p[0][d];
+    Dm[3 * d + 1] = p[2][d] - p[0][d];
+    Dm[3 * d + 2] = p[3][d] - p[0][d];
+  }
+  inv3x3(Dm, Di);
+  double* r = rest + 16 * (size_t)e;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    r[3 + d] = Di[d];
+    r[6 + d] = Di[3 + d];
+    r[9 + d] = Di[6 + d];
+    r[d] = -(Di[d] + Di[3 + d] + Di[6 + d]);
+  }
+  // volume = 1/6 |(a-d).((b-d)x(c-d))|
+  const double u[3] = {p[0][0] - p[3][0], p[0][1] - p[3][1], p[0][2] - p[3][2]};
+  const double v[3] = {p[1][0] - p[3][0], p[1][1] - p[3][1], p[1][2] - p[3][2]};
+  const double w[3] = {p[2][0] - p[3][0], p[2][1] - p[3][1], p[2][2] - p[3][2]};
+  const double cx = v[1] * w[2] - v[2] * w[1], cy = v[2] * w[0] - v[0] * w[2], cz = v[0] * w[1] - v[1] * w[0];
+  r[12] = (1.0 / 6) * fabs(u[0] * cx + u[1] * cy + u[2] * cz);
+  r[13] = r[14] = r[15] = 0.0;
+}
+
+// scaled-Newton polar decomposition of F (row-major), R out; returns last determinant
+// (vegafem polarDecomposition.cpp:37-108; the iteration is data dependent, capped for safety)
+__device__ inline double one_norm3(const double* A) {
+  return fmax(fmax(fabs(A[0]) + fabs(A[3]) + fabs(A[6]), fabs(A[1]) + fabs(A[4]) + fabs(A[7])), fabs(A[2]) + fabs(A[5]) + fabs(A[8]));
+}
+__device__ inline double inf_norm3(const double* A) {
+  return fmax(fmax(fabs(A[0]) + fabs(A[1]) + fabs(A[2]), fabs(A[3]) + fabs(A[4]) + fabs(A[5])), fabs(A[6]) + fabs(A[7]) + fabs(A[8]));
+}
+
+__device__ inline double polar_rotation(const double* F, double* R, double tol) {
+  double Mk[9], A[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) Mk[3 * i + j] = F[3 * j + i];
+  double M1 = one_norm3(Mk), Mi = inf_norm3(Mk), det = 0.0, E1;
+  int guard = 0;
+  do {
+    A[0] = Mk[4] * Mk[8] - Mk[5] * Mk[7]; A[1] = Mk[5] * Mk[6] - Mk[3] * Mk[8]; A[2] = Mk[3] * Mk[7] - Mk[4] * Mk[6];
+    A[3] = Mk[7] * Mk[2] - Mk[8] * Mk[1]; A[4] = Mk[8] * Mk[0] - Mk[6] * Mk[2]; A[5] = Mk[6] * Mk[1] - Mk[7] * Mk[0];
+    A[6] = Mk[1] * Mk[5] - Mk[2] * Mk[4]; A[7] = Mk[2] * Mk[3] - Mk[0] * Mk[5]; A[8] = Mk[0] * Mk[4] - Mk[1] * Mk[3];
+    det = Mk[0] * A[0] + Mk[1] * A[1] + Mk[2] * A[2];
+    if (det == 0.0) break;
+    const double A1 = one_norm3(A), Ai = inf_norm3(A);
+    const double gamma = sqrt(sqrt((A1 * Ai) / (M1 * Mi)) / fabs(det));
+    const double g1 = gamma * 0.5, g2 = 0.5 / (gamma * det);
+    double Ek[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      Ek[i] = Mk[i];
+      Mk[i] = g1 * Mk[i] + g2 * A[i];
+      Ek[i] -= Mk[i];
+    }
+    E1 = one_norm3(Ek);
+    M1 = one_norm3(Mk);
+    Mi = inf_norm3(Mk);
+  } while (E1 > M1 * tol && ++guard < 64);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Mk[3 * j + i];
+  return det;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a3/a4 pass 1, one thread per tet: F = P M^-1, R = polar(F) (flipped if det < 0), rotated gradients
+// c_k = R b_k and the element force f_e = R K0 (R^T x - x0) in closed form
+//   f_e,i = V R [lambda tr(H) I + mu (H + H^T)] b_i,   H = sum_j (R^T x_j - x0_j) b_j^T
+// (equal to corotationalLinearFEM.cpp:238-286 with K0 = V B^T E B, whose 3x3 blocks are
+//   K0[ij] = V [lambda b_i b_j^T + mu b_j b_i^T + mu (b_i.b_j) I]).
+// rec[16*e + 3*k + d] = c_k[d] (MT), rec[16*e+12] = V; fe[12*e + 3*k + d] fp64.
+// ------------------------------------------------------------------------------------------------------
+template <typename MT>
+__global__ __launch_bounds__(kBlock) void k_tet_warp(int nt, const int4* __restrict__ tets, const double* __restrict__ x0,
+                                                     const double* __restrict__ u, const double* __restrict__ rest,
+                                                     MT* __restrict__ rec, double* __restrict__ fe, double* __restrict__ rot,
+                                                     double lambda, double mu) {
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= nt) return;
+  const int4 t = tets[e];
+  const int id[4] = {t.x, t.y, t.z, t.w};
+  double b[4][3], X0[4][3], P[4][3];
+  const double* r = rest + 16 * (size_t)e;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      b[k][d] = r[3 * k + d];
+      X0[k][d] = x0[3 * (size_t)id[k] + d];
+      P[k][d] = X0[k][d] + u[3 * (size_t)id[k] + d];
+    }
+  const double V = r[12];
+  double F[9], R[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) F[3 * i + j] = P[0][i] * b[0][j] + P[1][i] * b[1][j] + P[2][i] * b[2][j] + P[3][i] * b[3][j];
+  const double det = polar_rotation(F, R, 1e-6);
+  if (det < 0) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = -R[i];
+  }
+  // H = sum_j y_j b_j^T with y_j = R^T P_j - X0_j
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    double y[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) y[a] = R[a] * P[j][0] + R[3 + a] * P[j][1] + R[6 + a] * P[j][2] - X0[j][a];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) H[3 * a + c] += y[a] * b[j][c];
+  }
+  const double tr = H[0] + H[4] + H[8];
+  double S[9];  // lambda tr I + mu (H + H^T)
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) S[3 * a + c] = mu * (H[3 * a + c] + H[3 * c + a]) + (a == c ? lambda * tr : 0.0);
+  MT* rc = rec + 16 * (size_t)e;
+  double* f = fe + 12 * (size_t)e;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    double sb[3], c[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      sb[a] = S[3 * a] * b[k][0] + S[3 * a + 1] * b[k][1] + S[3 * a + 2] * b[k][2];
+      c[a] = R[3 * a] * b[k][0] + R[3 * a + 1] * b[k][1] + R[3 * a + 2] * b[k][2];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      f[3 * k + a] = V * (R[3 * a] * sb[0] + R[3 * a + 1] * sb[1] + R[3 * a + 2] * sb[2]);
+      rc[3 * k + a] = (MT)c[a];
+    }
+  }
+  rc[12] = (MT)V;
+  rc[13] = rc[14] = rc[15] = (MT)0;
+  if (rot) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) rot[9 * (size_t)e + i] = R[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a3 scatter + a7 algebra, pass 2 ("row-gather"): lane = block row a.  For every slot (a,b) the lane sums its
+// element contributions in ascending element order
+//   K_ab = sum_e V_e [lambda c_i c_j^T + mu c_j c_i^T + mu (c_i.c_j) I],   m_ab = sum_e rho V_e/20 (1 + delta_ij)
+// and writes, in one pass and with no atomics (deterministic):
+//   vals   <- s_k K_ab + s_m m_ab I      (Keff = h(h+cK) K + (1+h cM) M; raw mode: s_k=1, s_m=0)
+//             with constrained rows/columns replaced by identity rows (the reference removes them,
+//             sparseMatrix.cpp:1296-1358 + :993-1002; identical solution, same arithmetic on the free DOFs)
+//   t_a    += (g_k K_ab + g_m m_ab I) qvel_b      ((hK + D) qvel of PS_VolumeConservingIntegrator.cpp:114)
+//   fint_a  = sum over the diagonal list of f_e,i  (the element-force scatter of corotationalLinearFEM.cpp:289-293)
+//   rhs_a   = -h (t_a + fint_a - fext_a) on free DOFs, 0 on constrained ones;   invdiag_a = 1 / diag(vals_aa)
+// ------------------------------------------------------------------------------------------------------
+struct AsmParams {
+  double lambda, mu, rho20;  // rho/20
+  double s_k, s_m;           // stored matrix = s_k K + s_m M
+  double g_k, g_m;           // rhs operator  = g_k K + g_m M
+  double h;
+  int apply_mask;
+};
+
+template <typename MT>
+__global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int* __restrict__ slot_coff,
+                                                          const int* __restrict__ slot_ccnt, const uint32_t* __restrict__ contrib,
+                                                          const MT* __restrict__ rec, const double* __restrict__ fe,
+                                                          const uint8_t* __restrict__ dofmask, const double* __restrict__ qvel,
+                                                          const double* __restrict__ fext, MT* __restrict__ vals,
+                                                          double* __restrict__ mblk_out, double* __restrict__ fint_out,
+                                                          double* __restrict__ rhs, double* __restrict__ invdiag, AsmParams ap) {
+  const int lane = threadIdx.x & 63;
+  for (SliceWalk w(sv.n_slices); w.valid(); w.next()) {
+    const int s = w.s;
+    const int row = s * 64 + lane;
+    const bool rvalid = row < sv.n_owned;
+    const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
+    double ta[3] = {0, 0, 0}, fi[3] = {0, 0, 0}, dg[3] = {1, 1, 1};
+    uint8_t ma[3] = {1, 1, 1};
+    if (rvalid && ap.apply_mask) {
+      ma[0] = dofmask[3 * (size_t)row];
+      ma[1] = dofmask[3 * (size_t)row + 1];
+      ma[2] = dofmask[3 * (size_t)row + 2];
+    }
+    bool seen_diag = false;
+    for (int k = 0; k < width; k++) {
+      const int slot = so + k;
+      const int col = sv.colidx[(size_t)slot * 64 + lane];
+      const int coff = slot_coff[slot], ccnt = slot_ccnt[slot];
+      // the true diagonal block is the first slot whose column is the row itself (padding slots repeat the row id)
+      const bool diag = rvalid && (col == row) && !seen_diag;
+      seen_diag = seen_diag || diag;
+      double K[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      double m = 0.0;
+      for (int t = 0; t < ccnt; t++) {
+        const uint32_t c = contrib[((size_t)coff + t) * 64 + lane];
+        if (c == 0xFFFFFFFFu) continue;
+        const uint32_t e = c >> 4;
+        const int i = (c >> 2) & 3, j = c & 3;
+        const MT* r = rec + 16 * (size_t)e;
+        const double ci[3] = {(double)r[3 * i], (double)r[3 * i + 1], (double)r[3 * i + 2]};
+        const double cj[3] = {(double)r[3 * j], (double)r[3 * j + 1], (double)r[3 * j + 2]};
+        const double V = (double)r[12];
+        const double dij = ci[0] * cj[0] + ci[1] * cj[1] + ci[2] * cj[2];
+        const double vl = V * ap.lambda, vm = V * ap.mu;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b = 0; b < 3; b++) K[3 * a + b] += vl * ci[a] * cj[b] + vm * cj[a] * ci[b];
+        K[0] += vm * dij; K[4] += vm * dij; K[8] += vm * dij;
+        m += ap.rho20 * V * (i == j ? 2.0 : 1.0);
+        if (diag) {
+          const double* f = fe + 12 * (size_t)e + 3 * i;
+          fi[0] += f[0]; fi[1] += f[1]; fi[2] += f[2];
+        }
+      }
+      // rhs operator on qvel (unmasked, as the reference multiplies the full matrix with the full qvel)
+      const double qv[3] = {qvel[3 * (size_t)col], qvel[3 * (size_t)col + 1], qvel[3 * (size_t)col + 2]};
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+        ta[a] += ap.g_k * (K[3 * a] * qv[0] + K[3 * a + 1] * qv[1] + K[3 * a + 2] * qv[2]) + ap.g_m * m * qv[a];
+      uint8_t mb[3] = {1, 1, 1};
+      if (ap.apply_mask) {
+        mb[0] = dofmask[3 * (size_t)col];
+        mb[1] = dofmask[3 * (size_t)col + 1];
+        mb[2] = dofmask[3 * (size_t)col + 2];
+      }
+      MT* out = vals + (size_t)slot * 9 * 64 + lane;
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          double v = ap.s_k * K[3 * a + b] + (a == b ? ap.s_m * m : 0.0);
+          if (!(ma[a] && mb[b])) v = (diag && a == b) ? 1.0 : 0.0;
+          const MT sv_ = (MT)v;
+          out[(3 * a + b) * 64] = sv_;
+          if (diag && a == b) dg[a] = (double)sv_;
+        }
+      if (mblk_out && rvalid) mblk_out[(size_t)slot * 64 + lane] = m;
+    }
+    if (rvalid) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const size_t d = 3 * (size_t)row + a;
+        if (fint_out) fint_out[d] = fi[a];
+        if (rhs) rhs[d] = ma[a] ? -ap.h * (ta[a] + fi[a] - fext[d]) : 0.0;
+        if (invdiag) invdiag[d] = 1.0 / dg[a];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a9 SpMV on the SELL-64 3x3-block matrix (SparseMatrix::MultiplyVector, sparseMatrix.cpp:405-413), fused
+// with the reduction its caller needs:
+//   MODE 0: y = A x                                    (plain)
+//   MODE 1: q = A d,  partial[b] = sum d.q             (PCG direction product, CGSolver.cpp:149-150)
+//   MODE 2: r = b - A x, partial[b] = sum r^2 invdiag   (exact residual every 30th iteration, CGSolver.cpp:161-171)
+// ------------------------------------------------------------------------------------------------------
+template <typename MT, int MODE>
+__global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restrict__ vals, const double* __restrict__ x,
+                                                 double* __restrict__ y, const double* __restrict__ bvec,
+                                                 const double* __restrict__ invdiag, double* __restrict__ partial,
+                                                 CGState* __restrict__ st, int parity) {
+  __shared__ double lds[4];
+  if (MODE != 0 && st->done) return;
+  if (MODE == 1) {
+    // the while-condition of CGSolver.cpp:147, evaluated by every block from the same published scalars at the
+    // head of each iteration; `done` is sticky so that every later launch of the batch is a no-op
+    if (!(st->rho[parity] > st->eps2 * st->rho0) || st->iter >= st->max_iter) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) st->done = 1;
+      return;
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (SliceWalk w(sv.n_slices); w.valid(); w.next()) {
+    const int s = w.s;
+    const int row = s * 64 + lane;
+    const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
+    const MT* v = vals + (size_t)so * 9 * 64 + lane;
+    const int* ci = sv.colidx + (size_t)so * 64 + lane;
+    double y0 = 0, y1 = 0, y2 = 0;
+#pragma unroll 4
+    for (int k = 0; k < width; k++) {
+      const int col = ci[(size_t)k * 64];
+      const double* xp = x + 3 * (size_t)col;
+      const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+      const MT* vk = v + (size_t)k * 9 * 64;
+      y0 += (double)vk[0 * 64] * x0 + (double)vk[1 * 64] * x1 + (double)vk[2 * 64] * x2;
+      y1 += (double)vk[3 * 64] * x0 + (double)vk[4 * 64] * x1 + (double)vk[5 * 64] * x2;
+      y2 += (double)vk[6 * 64] * x0 + (double)vk[7 * 64] * x1 + (double)vk[8 * 64] * x2;
+    }
+    if (row < sv.n_owned) {
+      const size_t d = 3 * (size_t)row;
+      if (MODE == 0) {
+        y[d] = y0; y[d + 1] = y1; y[d + 2] = y2;
+      } else if (MODE == 1) {
+        y[d] = y0; y[d + 1] = y1; y[d + 2] = y2;
+        acc += x[d] * y0 + x[d + 1] * y1 + x[d + 2] * y2;
+      } else {
+        const double r0 = bvec[d] - y0, r1 = bvec[d + 1] - y1, r2 = bvec[d + 2] - y2;
+        y[d] = r0; y[d + 1] = r1; y[d + 2] = r2;
+        acc += r0 * r0 * invdiag[d] + r1 * r1 * invdiag[d + 1] + r2 * r2 * invdiag[d + 2];
+      }
+    }
+  }
+  if (MODE != 0) {
+    const double tot = block_sum(acc, lds);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// PCG vector kernels (CGSolver.cpp:129-190).  Same lane<->row map and XCD slabs as the SpMV so each XCD's L2
+// keeps its share of x, r, d, q, invdiag between kernels.  `sc` (when non-null) holds an already
+// all-reduced scalar {dq, rho_new} (multi-GPU); otherwise the per-block partials are summed in fixed order.
+// ------------------------------------------------------------------------------------------------------
+// x = 0, r = b, d = invdiag r, partial = sum r^2 invdiag
+__global__ __launch_bounds__(kBlock) void k_cg_init(int n_slices, int n_owned, const double* __restrict__ b,
+                                                    const double* __restrict__ invdiag, double* __restrict__ x,
+                                                    double* __restrict__ r, double* __restrict__ d, double* __restrict__ partial) {
+  __shared__ double lds[4];
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (SliceWalk w(n_slices); w.valid(); w.next()) {
+    const int row = w.s * 64 + lane;
+    if (row < n_owned) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const size_t i = 3 * (size_t)row + a;
+        const double ri = b[i], di = invdiag[i];
+        x[i] = 0.0; r[i] = ri; d[i] = di * ri;
+        acc += ri * ri * di;
+      }
+    }
+  }
+  const double tot = block_sum(acc, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// one block: rho0 from the partials (or the all-reduced scalar), initial state
+__global__ __launch_bounds__(kBlock) void k_cg_begin(CGState* st, const double* partial, int n_partial, const double* sc,
+                                                     double eps, int max_iter) {
+  __shared__ double lds[4];
+  const double rho0 = sc ? sc[0] : sum_partials(partial, n_partial, lds);
+  if (threadIdx.x == 0) {
+    st->rho[0] = rho0; st->rho[1] = rho0; st->rho0 = rho0; st->eps2 = eps * eps;
+    st->iter = 0; st->max_iter = max_iter; st->done = 0; st->pad = 0;
+  }
+}
+
+// alpha = rho / (d.q);  x += alpha d;  REFRESH ? nothing more : (r -= alpha q, partial = sum r^2 invdiag)
+template <bool REFRESH>
+__global__ __launch_bounds__(kBlock) void k_cg_update(int n_slices, int n_owned, const CGState* __restrict__ st, int parity,
+                                                      const double* __restrict__ part_dq, int n_partial, const double* sc,
+                                                      const double* __restrict__ d, const double* __restrict__ q,
+                                                      const double* __restrict__ invdiag, double* __restrict__ x,
+                                                      double* __restrict__ r, double* __restrict__ part_rho) {
+  __shared__ double lds[4];
+  if (st->done) return;
+  const double dq = sc ? sc[0] : sum_partials(part_dq, n_partial, lds);
+  const double alpha = st->rho[parity] / dq;
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (SliceWalk w(n_slices); w.valid(); w.next()) {
+    const int row = w.s * 64 + lane;
+    if (row < n_owned) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const size_t i = 3 * (size_t)row + a;
+        x[i] += alpha * d[i];
+        if (!REFRESH) {
+          const double ri = r[i] - alpha * q[i];
+          r[i] = ri;
+          acc += ri * ri * invdiag[i];
+        }
+      }
+    }
+  }
+  if (!REFRESH) {
+    const double tot = block_sum(acc, lds);
+    if (threadIdx.x == 0) part_rho[blockIdx.x] = tot;
+  }
+}
+
+// beta = rho_new / rho;  d = invdiag r + beta d;  block 0 publishes rho_new, iteration count and the exit test
+__global__ __launch_bounds__(kBlock) void k_cg_direction(int n_slices, int n_owned, CGState* st, int parity,
+                                                         const double* __restrict__ part_rho, int n_partial, const double* sc,
+                                                         const double* __restrict__ r, const double* __restrict__ invdiag,
+                                                         double* __restrict__ d) {
+  __shared__ double lds[4];
+  if (st->done) return;
+  const double rho_new = sc ? sc[0] : sum_partials(part_rho, n_partial, lds);
+  const double beta = rho_new / st->rho[parity];
+  const int lane = threadIdx.x & 63;
+  for (SliceWalk w(n_slices); w.valid(); w.next()) {
+    const int row = w.s * 64 + lane;
+    if (row < n_owned) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const size_t i = 3 * (size_t)row + a;
+        d[i] = invdiag[i] * r[i] + beta * d[i];
+      }
+    }
+  }
+  // single writer; rho[1-parity] and iter are read only by later launches (this launch reads done, rho[parity])
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->rho[1 - parity] = rho_new;
+    st->iter = st->iter + 1;
+  }
+}
+
+// state update of PS_VolumeConservingIntegrator.cpp:229-237: qvel += dv, q += h qvel, constrained -> 0
+__global__ __launch_bounds__(kBlock) void k_state_update(int n, const double* __restrict__ dv, const uint8_t* __restrict__ mask,
+                                                         double h, double* __restrict__ q, double* __restrict__ qvel) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  if (mask[i]) {
+    const double v = qvel[i] + dv[i];
+    qvel[i] = v;
+    q[i] += h * v;
+  } else {
+    q[i] = 0.0;
+    qvel[i] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_axis(int n_nodes, int axis, double value, double* __restrict__ f) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_nodes) return;
+  f[3 * (size_t)i] = axis == 0 ? value : 0.0;
+  f[3 * (size_t)i + 1] = axis == 1 ? value : 0.0;
+  f[3 * (size_t)i + 2] = axis == 2 ? value : 0.0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_axpy(int n, double a, const double* __restrict__ x, double* __restrict__ y) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) y[i] += a * x[i];
+}
+
+// floor collision of Deformable::timestep (Deformable.cpp:350-400)
+__global__ __launch_bounds__(kBlock) void k_floor(int n_nodes, const double* __restrict__ x0, double floor_y, double rest,
+                                                  double* __restrict__ q, double* __restrict__ qvel, int* __restrict__ n_collided) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  int hit = 0;
+  if (i < n_nodes) {
+    const size_t d = 3 * (size_t)i;
+    const double pry = x0[d + 1];
+    const double pcy = pry + q[d + 1];
+    // v = (0,1,0): vn = (0, vy, 0); vr = (v - vn) - rest * vn
+    qvel[d + 1] = -rest * qvel[d + 1];
+    if (pcy <= floor_y) {
+      hit = 1;
+      q[d + 1] = floor_y - pry;
+    }
+  }
+  const unsigned long long b = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_collided, __popcll(b));
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a1 batched element stiffness K0 = V B^T (E B) on the matrix cores: one wavefront per element, the 12x12
+// product padded into one 16x16 tile, K = 6 strain rows padded to 8 = two v_mfma_f64_16x16x4_f64 steps
+// (A = B^T: 12x6, B-operand = E B: 6x12).  fp64 MFMA keeps this inspection path within 1e-12 of the oracle.
+// Operand lane maps (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+// D: col = lane&15, row = (lane>>4) + 4*reg.
+// ------------------------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ inline double strainB(const double* b, int s, int col) {
+  // B (6 x 12) entry: strain row s, dof col = 3*v + d, from the gradients b[v][*]  (corotationalLinearFEM.cpp:107-114)
+  const int v = col / 3, d = col - 3 * v;
+  const double bx = b[3 * v], by = b[3 * v + 1], bz = b[3 * v + 2];
+  switch (s) {
+    case 0: return d == 0 ? bx : 0.0;
+    case 1: return d == 1 ? by : 0.0;
+    case 2: return d == 2 ? bz : 0.0;
+    case 3: return d == 0 ? by : (d == 1 ? bx : 0.0);
+    case 4: return d == 1 ? bz : (d == 2 ? by : 0.0);
+    default: return d == 0 ? bz : (d == 2 ? bx : 0.0);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_element_K0_mfma(int first, int count, const double* __restrict__ rest,
+                                                            double lambda, double mu, double* __restrict__ K0,
+                                                            double* __restrict__ Minv, const double* __restrict__ x0,
+                                                            const int4* __restrict__ tets) {
+  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (wave >= count) return;  // wave-uniform
+  const int e = first + wave;
+  const int lane = threadIdx.x & 63;
+  const double* r = rest + 16 * (size_t)e;
+  const double V = r[12];
+  const int ij = lane & 15, kq = lane >> 4;  // kq = k index inside a 4-deep step
+  v4d acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int step = 0; step < 2; step++) {
+    const int s = 4 * step + kq;  // strain row 0..7 (6,7 are padding)
+    double a = 0.0, bb = 0.0;
+    if (s < 6 && ij < 12) {
+      a = strainB(r, s, ij);  // A[i][k] = B^T[i][s] = B[s][i]
+      // (E B)[s][j] = sum_t E[s][t] B[t][j]
+      if (s < 3) {
+        bb = lambda * (strainB(r, 0, ij) + strainB(r, 1, ij) + strainB(r, 2, ij)) + 2.0 * mu * strainB(r, s, ij);
+      } else {
+        bb = mu * strainB(r, s, ij);
+      }
+    }
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+  }
+  if (ij < 12) {
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      const int row = kq + 4 * reg;
+      if (row < 12) K0[144 * (size_t)wave + 12 * row + ij] = acc[reg] * V;
+    }
+  }
+  if (Minv && lane < 16) {
+    // row k = lane>>2: [b_k | N_k(0)], N_k(0) = delta_k0 - b_k . x_0
+    const int k = lane >> 2, d = lane & 3;
+    double val;
+    if (d < 3) val = r[3 * k + d];
+    else {
+      const int n0 = tets[e].x;
+      val = (k == 0 ? 1.0 : 0.0) - (r[3 * k] * x0[3 * (size_t)n0] + r[3 * k + 1] * x0[3 * (size_t)n0 + 1] + r[3 * k + 2] * x0[3 * (size_t)n0 + 2]);
+    }
+    Minv[16 * (size_t)wave + lane] = val;
+  }
+}
+
+}  // namespace fb

@@ -1,0 +1,60 @@
+// Host-side plan of one rank's share of the FEM system: local numbering, halo lists, the 3x3-block
+// sparsity pattern, its SELL-64 device layout and the per-(row,slot) element contribution lists that the
+// row-gather assembly kernel walks.  No HIP calls in here -- the plan is exercised on CPU by the tests
+// (including the world_size-2 gloo tests of the halo lists).
+//
+// Reference semantics restated: the pattern is every vertex pair of every tet with ascending columns
+// (vegafem/corotationalLinearFEM/corotationalLinearFEM.cpp:163-186, sparseMatrix/sparseMatrix.cpp:238-262);
+// the contribution lists replace the per-element rowIndices/columnIndices scatter caches
+// (corotationalLinearFEM.cpp:482-502) by their transpose: for each matrix block, the (tet, i, j) that add to it,
+// in ascending element order (the order the reference's element loop accumulates them, :230-469).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace fb {
+
+constexpr int kSliceRows = 64;             // one wavefront lane per block row
+constexpr uint32_t kNoContrib = 0xFFFFFFFFu;
+
+struct FemPlan {
+  // --- partition ---
+  int n_global = 0, n_ranks = 1, rank = 0;
+  std::vector<int> splits;                 // n_ranks+1 node range boundaries
+  int node_lo = 0, node_hi = 0;
+  int n_owned = 0, n_halo = 0, n_local = 0;
+  std::vector<int> local2global;           // n_local: owned (ascending) then halo (ascending => grouped by owner)
+  std::vector<int> halo_off;               // n_ranks+1: halo nodes owned by rank q are local ids n_owned+[halo_off[q],halo_off[q+1])
+  std::vector<int> send_off;               // n_ranks+1
+  std::vector<int> send_local;             // owned local ids to pack for rank q: [send_off[q], send_off[q+1]), ascending
+  // --- local elements ---
+  int n_tets = 0;                          // tets with at least one owned node
+  std::vector<int> tet_global;             // n_tets global element ids (ascending)
+  std::vector<int> tets;                   // 4*n_tets local node ids
+  // --- block pattern of owned rows (CSR, ascending global column order) ---
+  std::vector<int> bptr;                   // n_owned+1
+  std::vector<int> bcol;                   // local column ids
+  int n_blocks = 0;
+  // --- SELL-64 layout ---
+  int n_slices = 0;
+  std::vector<int> slice_off;              // n_slices+1, in slots
+  int n_slots = 0;                         // sum of slice widths
+  std::vector<int> colidx;                 // n_slots*64 local column ids (padding: the row itself / 0)
+  std::vector<int> blk_slot;               // n_blocks: global slot index (slice_off[s]+k) of CSR block p
+  // --- contribution lists, [slot][t][lane] ---
+  std::vector<int> slot_coff;              // n_slots: first contribution "row" of the slot
+  std::vector<int> slot_ccnt;              // n_slots: max contributions over the 64 lanes
+  int n_crows = 0;                         // sum of slot_ccnt
+  std::vector<uint32_t> contrib;           // n_crows*64, (tet<<4 | i<<2 | j) or kNoContrib
+  // --- constraints ---
+  std::vector<uint8_t> dofmask;            // 3*n_local: 1 free, 0 constrained
+  int n_fixed_owned = 0;
+};
+
+// Builds the plan of `rank`.  tets: 4*n_tets global node ids.  fixed_dofs ascending global DOF ids.
+// Returns 0 or a negative FB_E* code (text via fb::last_error()).
+int build_fem_plan(FemPlan& plan, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed_dofs,
+                   int n_ranks, int rank, const int* splits);
+int plan_set_constraints(FemPlan& plan, int n_fixed, const int* fixed_dofs);
+
+}  // namespace fb

@@ -1,0 +1,263 @@
+"""Host-side mirror of the reference's FEM class surface over the C ABI.
+
+``FemIntegrator`` plays the role of ``VolumeConservingIntegrator`` + ``CorotationalLinearFEMForceModel``
+(reference src/deformable/PS_VolumeConservingIntegrator.{h,cpp}, vegafem/integrator/integratorBase*.h): same
+method names in snake_case, same argument meaning, same error behaviour except that a failed solve raises
+``FbError(FB_ESOLVER)`` instead of ``exit(-1)``.  ``Deformable`` mirrors the per-step driver of
+``Deformable::timestep`` (reference src/deformable/Deformable.cpp:318-420).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _l
+from .meshgen import fixed_vertices_to_dofs
+
+
+class FemIntegrator:
+    def __init__(self, verts, tets, fixed_dofs=(), E=1e7, nu=0.46, rho=1000.0, timestep=0.0333,
+                 damping_mass=0.0, damping_stiffness=0.01, cg_eps=1e-6, cg_max_iter=10000,
+                 matrix_precision=_l.FB_MATRIX_F32, device=0, shard=None):
+        """shard = (n_ranks, rank, node_splits or None, comm_handle) for a domain-decomposed handle."""
+        L = _l.lib()
+        self._L = L
+        self.verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+        self.tets = np.ascontiguousarray(tets, dtype=np.int32).reshape(-1, 4)
+        self.n_nodes, self.n_tets_global = len(self.verts), len(self.tets)
+        self.r = 3 * self.n_nodes
+        fd = _l.as_i32(fixed_dofs)
+        p = _l.FemParams()
+        L.fb_fem_default_params(C.byref(p))
+        p.E, p.nu, p.rho, p.timestep = E, nu, rho, timestep
+        p.damping_mass, p.damping_stiffness = damping_mass, damping_stiffness
+        p.cg_eps, p.cg_max_iter, p.matrix_precision, p.device = cg_eps, cg_max_iter, matrix_precision, device
+        self.params = p
+        self.h = C.c_void_p()
+        self.node_lo, self.node_hi = 0, self.n_nodes
+        if shard is None:
+            _l.check(L.fb_fem_create(C.byref(self.h), self.n_nodes, _l.dptr(self.verts), self.n_tets_global,
+                                     _l.iptr(self.tets), len(fd), _l.iptr(fd), C.byref(p)))
+        else:
+            n_ranks, rank, splits, comm = shard
+            sp = None if splits is None else _l.as_i32(splits)
+            _l.check(L.fb_fem_create_sharded(C.byref(self.h), self.n_nodes, _l.dptr(self.verts), self.n_tets_global,
+                                             _l.iptr(self.tets), len(fd), _l.iptr(fd), C.byref(p), n_ranks, rank,
+                                             _l.iptr(sp), comm))
+            if sp is None:
+                sp = np.array([self.n_nodes * i // n_ranks for i in range(n_ranks + 1)], dtype=np.int32)
+            self.node_lo, self.node_hi = int(sp[rank]), int(sp[rank + 1])
+        self.last = _l.StepInfo()
+
+    # -- life cycle --
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.fb_fem_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def resync(self, verts, tets, fixed_dofs=()):
+        """Deformable::syncForceModel after a cut."""
+        self.verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+        self.tets = np.ascontiguousarray(tets, dtype=np.int32).reshape(-1, 4)
+        self.n_nodes, self.r = len(self.verts), 3 * len(self.verts)
+        self.node_lo, self.node_hi = 0, self.n_nodes
+        fd = _l.as_i32(fixed_dofs)
+        _l.check(self._L.fb_fem_resync(self.h, self.n_nodes, _l.dptr(self.verts), len(self.tets), _l.iptr(self.tets),
+                                       len(fd), _l.iptr(fd)))
+
+    def rebuild_elements(self):
+        _l.check(self._L.fb_fem_rebuild_elements(self.h))
+
+    # -- IntegratorBase surface --
+    def set_external_forces(self, f):
+        _l.check(self._L.fb_fem_set_external_forces(self.h, _l.dptr(_l.as_f64(f, self.r))))
+
+    def add_external_forces(self, f):
+        _l.check(self._L.fb_fem_add_external_forces(self.h, _l.dptr(_l.as_f64(f, self.r))))
+
+    def set_external_forces_to_zero(self):
+        _l.check(self._L.fb_fem_set_external_forces_zero(self.h))
+
+    def set_uniform_force(self, axis, value):
+        _l.check(self._L.fb_fem_set_uniform_force(self.h, axis, value))
+
+    def do_timestep(self):
+        """Returns the PCG iteration count; raises FbError(FB_ESOLVER) when the solve fails."""
+        _l.check(self._L.fb_fem_step(self.h, C.byref(self.last)))
+        return self.last.cg_iterations
+
+    def get_q_state(self):
+        q, qv, qa = np.zeros(self.r), np.zeros(self.r), np.zeros(self.r)
+        _l.check(self._L.fb_fem_get_state(self.h, _l.dptr(q), _l.dptr(qv), _l.dptr(qa)))
+        return q, qv, qa
+
+    def set_q_state(self, q, qvel=None, qaccel=None):
+        qv = None if qvel is None else _l.as_f64(qvel, self.r)
+        qa = None if qaccel is None else _l.as_f64(qaccel, self.r)
+        _l.check(self._L.fb_fem_set_state(self.h, _l.dptr(_l.as_f64(q, self.r)), _l.dptr(qv), _l.dptr(qa)))
+
+    def reset_to_rest(self):
+        _l.check(self._L.fb_fem_reset(self.h))
+
+    def set_timestep(self, h):
+        _l.check(self._L.fb_fem_set_timestep(self.h, h))
+
+    def set_damping(self, mass_coef, stiffness_coef):
+        _l.check(self._L.fb_fem_set_damping(self.h, mass_coef, stiffness_coef))
+
+    def set_cg(self, eps, max_iter):
+        _l.check(self._L.fb_fem_set_cg(self.h, eps, max_iter))
+
+    def set_constrained_dofs(self, fixed_dofs):
+        fd = _l.as_i32(fixed_dofs)
+        _l.check(self._L.fb_fem_set_constrained_dofs(self.h, len(fd), _l.iptr(fd)))
+
+    def get_force_assembly_time(self):
+        return self.last.assembly_seconds
+
+    def get_system_solve_time(self):
+        return self.last.solve_seconds
+
+    def floor_collision(self, floor_y, restitution=0.4):
+        n = C.c_int(0)
+        _l.check(self._L.fb_fem_floor_collision(self.h, floor_y, restitution, C.byref(n)))
+        return n.value
+
+    # -- inspection (parity tests) --
+    def num_tets(self):
+        return self._L.fb_fem_num_tets(self.h)
+
+    def num_blocks(self):
+        return self._L.fb_fem_num_blocks(self.h)
+
+    def pattern(self):
+        n_owned = self.node_hi - self.node_lo
+        bptr, bcol = np.empty(n_owned + 1, np.int32), np.empty(self.num_blocks(), np.int32)
+        _l.check(self._L.fb_fem_pattern(self.h, _l.iptr(bptr), _l.iptr(bcol)))
+        return bptr, bcol
+
+    def element_stiffness(self, first, count):
+        K0, Mi = np.empty((count, 12, 12)), np.empty((count, 4, 4))
+        _l.check(self._L.fb_fem_element_stiffness(self.h, first, count, _l.dptr(K0), _l.dptr(Mi)))
+        return K0, Mi
+
+    def assemble(self, u):
+        f, K = np.zeros(self.r), np.empty((self.num_blocks(), 3, 3))
+        _l.check(self._L.fb_fem_assemble(self.h, _l.dptr(_l.as_f64(u, self.r)), _l.dptr(f), _l.dptr(K)))
+        return f, K
+
+    def system(self):
+        rhs, K = np.zeros(self.r), np.empty((self.num_blocks(), 3, 3))
+        _l.check(self._L.fb_fem_system(self.h, _l.dptr(K), _l.dptr(rhs)))
+        return K, rhs
+
+    def mass(self):
+        m = np.empty(self.num_blocks())
+        _l.check(self._L.fb_fem_mass(self.h, _l.dptr(m)))
+        return m
+
+    def spmv(self, x):
+        y = np.zeros(self.r)
+        _l.check(self._L.fb_fem_spmv(self.h, _l.dptr(_l.as_f64(x, self.r)), _l.dptr(y)))
+        return y
+
+    def pcg(self, rhs, eps=1e-6, max_iter=10000):
+        x, it = np.zeros(self.r), C.c_int(0)
+        _l.check(self._L.fb_fem_pcg(self.h, _l.dptr(_l.as_f64(rhs, self.r)), _l.dptr(x), eps, max_iter, C.byref(it)))
+        return it.value, x
+
+    def time_spmv(self, reps=50):
+        s = C.c_double(0)
+        _l.check(self._L.fb_fem_time_spmv(self.h, reps, C.byref(s)))
+        return s.value
+
+    def time_assembly(self, reps=10):
+        s = C.c_double(0)
+        _l.check(self._L.fb_fem_time_assembly(self.h, reps, C.byref(s)))
+        return s.value
+
+    def spmv_bytes(self):
+        b = C.c_double(0)
+        _l.check(self._L.fb_fem_spmv_bytes(self.h, C.byref(b)))
+        return b.value
+
+    def assembly_bytes(self):
+        b = C.c_double(0)
+        _l.check(self._L.fb_fem_assembly_bytes(self.h, C.byref(b)))
+        return b.value
+
+
+def bsr_to_scipy(bptr, bcol, blocks, n_cols_nodes=None):
+    """3x3-block CSR (fb_fem_pattern order) -> scipy CSR, for comparisons in the tests."""
+    import scipy.sparse as sp
+    n_rows = len(bptr) - 1
+    n_cols = n_cols_nodes if n_cols_nodes is not None else n_rows
+    return sp.bsr_matrix((np.asarray(blocks).reshape(-1, 3, 3), bcol, bptr), shape=(3 * n_rows, 3 * n_cols)).tocsr()
+
+
+class Deformable:
+    """Per-step driver of ``Deformable::timestep`` (reference src/deformable/Deformable.cpp:318-420) without the
+    scene-graph / GL parts: external forces (gravity -10000 per y-DOF unless a collision happened in the previous
+    step, haptic forces), DoTimestep, floor collision with velocity rewrite, deformation callback."""
+
+    GRAVITY_FORCE = -10000.0  # Deformable.cpp:335
+
+    def __init__(self, verts, tets, fixed_vertices=(), floor_y=None, gravity=True, **kw):
+        self.fixed_vertices = sorted(int(v) for v in fixed_vertices)
+        fd = fixed_vertices_to_dofs(self.fixed_vertices) if len(self.fixed_vertices) else np.zeros(0, np.int32)
+        self.integrator = FemIntegrator(verts, tets, fd, **kw)
+        self.dof = self.integrator.r
+        self.gravity = bool(gravity)
+        self.floor_y = floor_y
+        self.ct_collided = 0
+        self.ct_timestep = 0
+        self.haptic_indices, self.haptic_forces = [], []
+        self.haptic_in_progress = False
+        self.on_deform = None  # FOnApplyDeformations(dof, q), Deformable.h:46
+
+    def set_deform_callback(self, fn):
+        self.on_deform = fn
+
+    def haptic_set_current_forces(self, indices, forces):
+        self.haptic_indices, self.haptic_forces = list(indices), [tuple(f) for f in forces]
+
+    def haptic_start(self, index):
+        self.haptic_in_progress = True
+
+    def haptic_end(self):
+        self.haptic_in_progress = False
+        self.haptic_indices, self.haptic_forces = [], []
+
+    def timestep(self):
+        it = self.integrator
+        apply_gravity = self.gravity and self.ct_collided == 0
+        if self.haptic_in_progress and self.haptic_indices:
+            f = np.zeros(self.dof)
+            if apply_gravity:
+                f[1::3] += self.GRAVITY_FORCE
+            for idx, frc in zip(self.haptic_indices, self.haptic_forces):
+                f[3 * idx:3 * idx + 3] += frc
+            it.set_external_forces(f)
+        elif apply_gravity:
+            it.set_uniform_force(1, self.GRAVITY_FORCE)
+        else:
+            it.set_external_forces_to_zero()
+        iters = it.do_timestep()
+        if self.floor_y is not None:
+            self.ct_collided = it.floor_collision(self.floor_y, 0.4)
+        self.ct_timestep += 1
+        if self.on_deform is not None:
+            q, _, _ = it.get_q_state()
+            self.on_deform(self.dof, q)
+        return iters
+
+    def get_solver_time(self):
+        return self.integrator.get_system_solve_time()
+
+    def reset_deformations(self):
+        self.integrator.reset_to_rest()

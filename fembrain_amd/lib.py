@@ -1,0 +1,171 @@
+"""ctypes binding of libfembrain_hip.so (the C ABI of include/fembrain_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this module raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfembrain_hip.so")
+
+FB_OK, FB_EINVAL, FB_EDEVICE, FB_ENOMEM, FB_ESOLVER, FB_ECOMM = 0, -1, -2, -3, -4, -5
+FB_MATRIX_F32, FB_MATRIX_F64 = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_up = C.POINTER(C.c_uint)
+_bp = C.POINTER(C.c_ubyte)
+
+
+class FbError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("fembrain_hip error %d: %s" % (code, text))
+        self.code = code
+
+
+class FemParams(C.Structure):
+    _fields_ = [("E", C.c_double), ("nu", C.c_double), ("rho", C.c_double), ("timestep", C.c_double),
+                ("damping_mass", C.c_double), ("damping_stiffness", C.c_double), ("cg_eps", C.c_double),
+                ("cg_max_iter", C.c_int), ("matrix_precision", C.c_int), ("device", C.c_int),
+                ("reserved", C.c_int * 5)]
+
+
+class StepInfo(C.Structure):
+    _fields_ = [("cg_iterations", C.c_int), ("converged", C.c_int), ("assembly_seconds", C.c_double),
+                ("solve_seconds", C.c_double), ("rho0", C.c_double), ("rho", C.c_double)]
+
+
+class PolyCounts(C.Structure):
+    _fields_ = [("grid", C.c_int * 3), ("n_points", C.c_int), ("n_cells", C.c_int), ("n_crossed_edges", C.c_int),
+                ("n_surface_cells", C.c_int), ("n_mc_indices", C.c_int), ("n_included_cells", C.c_int),
+                ("n_tet_vertices", C.c_int), ("n_tets", C.c_int)]
+
+
+def build(force=False):
+    """Compile libfembrain_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    mk = os.path.join(_HERE, "csrc", "Makefile")
+    if force:
+        subprocess.check_call(["make", "-s", "-f", mk, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-f", mk])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FbError(FB_EDEVICE, "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                  "(there is no CPU fallback for the HIP path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.fb_last_error.restype = C.c_char_p
+    vp = C.c_void_p
+    sig = {
+        "fb_device_count": (C.c_int, []),
+        "fb_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, _ip]),
+        "fb_fem_default_params": (None, [C.POINTER(FemParams)]),
+        "fb_fem_create": (C.c_int, [C.POINTER(vp), C.c_int, _dp, C.c_int, _ip, C.c_int, _ip, C.POINTER(FemParams)]),
+        "fb_fem_create_sharded": (C.c_int, [C.POINTER(vp), C.c_int, _dp, C.c_int, _ip, C.c_int, _ip, C.POINTER(FemParams),
+                                            C.c_int, C.c_int, _ip, vp]),
+        "fb_fem_destroy": (C.c_int, [vp]),
+        "fb_fem_resync": (C.c_int, [vp, C.c_int, _dp, C.c_int, _ip, C.c_int, _ip]),
+        "fb_fem_rebuild_elements": (C.c_int, [vp]),
+        "fb_fem_set_external_forces": (C.c_int, [vp, _dp]),
+        "fb_fem_add_external_forces": (C.c_int, [vp, _dp]),
+        "fb_fem_set_external_forces_zero": (C.c_int, [vp]),
+        "fb_fem_set_uniform_force": (C.c_int, [vp, C.c_int, C.c_double]),
+        "fb_fem_step": (C.c_int, [vp, C.POINTER(StepInfo)]),
+        "fb_fem_get_state": (C.c_int, [vp, _dp, _dp, _dp]),
+        "fb_fem_set_state": (C.c_int, [vp, _dp, _dp, _dp]),
+        "fb_fem_reset": (C.c_int, [vp]),
+        "fb_fem_set_timestep": (C.c_int, [vp, C.c_double]),
+        "fb_fem_set_damping": (C.c_int, [vp, C.c_double, C.c_double]),
+        "fb_fem_set_cg": (C.c_int, [vp, C.c_double, C.c_int]),
+        "fb_fem_set_constrained_dofs": (C.c_int, [vp, C.c_int, _ip]),
+        "fb_fem_floor_collision": (C.c_int, [vp, C.c_double, C.c_double, _ip]),
+        "fb_fem_num_nodes": (C.c_int, [vp]),
+        "fb_fem_num_tets": (C.c_int, [vp]),
+        "fb_fem_num_blocks": (C.c_int, [vp]),
+        "fb_fem_pattern": (C.c_int, [vp, _ip, _ip]),
+        "fb_fem_element_stiffness": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp]),
+        "fb_fem_assemble": (C.c_int, [vp, _dp, _dp, _dp]),
+        "fb_fem_system": (C.c_int, [vp, _dp, _dp]),
+        "fb_fem_mass": (C.c_int, [vp, _dp]),
+        "fb_fem_spmv": (C.c_int, [vp, _dp, _dp]),
+        "fb_fem_pcg": (C.c_int, [vp, _dp, _dp, C.c_double, C.c_int, _ip]),
+        "fb_fem_time_spmv": (C.c_int, [vp, C.c_int, _dp]),
+        "fb_fem_time_assembly": (C.c_int, [vp, C.c_int, _dp]),
+        "fb_fem_spmv_bytes": (C.c_int, [vp, _dp]),
+        "fb_fem_assembly_bytes": (C.c_int, [vp, _dp]),
+        "fb_comm_unique_id": (C.c_int, [_bp]),
+        "fb_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _bp, C.c_int]),
+        "fb_comm_destroy": (C.c_int, [vp]),
+        "fb_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int, C.c_int, _ip]),
+        "fb_plan_destroy": (C.c_int, [vp]),
+        "fb_plan_info": (C.c_int, [vp, _ip]),
+        "fb_plan_get": (C.c_int, [vp, C.c_char_p, _ip, C.c_size_t]),
+    }
+    poly_sig = {
+        "fb_poly_create": (C.c_int, [C.POINTER(vp), C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp]),
+        "fb_poly_destroy": (C.c_int, [vp]),
+        "fb_poly_field_array": (C.c_int, [vp, C.c_int, _fp]),
+        "fb_poly_sweep": (C.c_int, [vp, C.c_float, _ip]),
+        "fb_poly_sweep_grid": (C.c_int, [vp, _fp, C.c_float, _ip]),
+        "fb_poly_read_grid": (C.c_int, [vp, _fp]),
+        "fb_poly_classify": (C.c_int, [vp, C.POINTER(PolyCounts)]),
+        "fb_poly_read_classification": (C.c_int, [vp, _bp, _up, _bp]),
+        "fb_poly_tetrahedralize": (C.c_int, [vp, C.POINTER(PolyCounts)]),
+        "fb_poly_read_tetmesh": (C.c_int, [vp, _fp, _up]),
+        "fb_poly_surface": (C.c_int, [vp, _fp, _fp, _up]),
+        "fb_poly_apply_displacements": (C.c_int, [vp, C.c_int, _dp]),
+        "fb_poly_time_pipeline": (C.c_int, [vp, C.c_int, _dp, _dp]),
+    }
+    sig.update({k: v for k, v in poly_sig.items() if hasattr(L, k)})  # TEMP until poly.hip lands
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = the library does not match include/fembrain_hip.h
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != FB_OK:
+        raise FbError(code, lib().fb_last_error().decode("utf-8", "replace"))
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def fptr(a):
+    return None if a is None else a.ctypes.data_as(_fp)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def uptr(a):
+    return None if a is None else a.ctypes.data_as(_up)
+
+
+def bptr(a):
+    return None if a is None else a.ctypes.data_as(_bp)
+
+
+def as_f64(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+    if n is not None and a.size != n:
+        raise ValueError("expected %d values, got %d" % (n, a.size))
+    return a
+
+
+def as_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32).reshape(-1)

@@ -1,0 +1,223 @@
+/* fembrain_hip.h -- C ABI of libfembrain_hip.so: the MI355X (gfx950) implementation of FemBrain's per-step
+ * deformable hot path (element stiffness, sparse assembly, Keff/rhs algebra, Jacobi-PCG) and of the BlobTree
+ * field sweep / cell classification / tetrahedral polygonizer.
+ *
+ * Conventions: plain pointers and sizes, caller-owned host buffers (copied during the call), device memory
+ * owned by the handle, one caller thread per handle, no exceptions across the boundary.  Every function
+ * returns FB_OK (0) or a negative FB_E* code; fb_last_error() gives the text of the last failure on the
+ * calling thread.  Paths cited below are relative to the reference tree's src/ directory.
+ */
+#ifndef FEMBRAIN_HIP_H
+#define FEMBRAIN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FB_OK 0
+#define FB_EINVAL (-1)   /* bad argument (size, index range, unsorted constrained DOFs, ...) */
+#define FB_EDEVICE (-2)  /* HIP runtime error / no gfx950 device */
+#define FB_ENOMEM (-3)
+#define FB_ESOLVER (-4)  /* PCG did not converge (reference: printf + exit(-1), PS_VolumeConservingIntegrator.cpp:203-209) */
+#define FB_ECOMM (-5)    /* RCCL not available / communicator error */
+
+/* matrix storage precision (vectors, dot products and all per-element geometry are always fp64) */
+#define FB_MATRIX_F32 0 /* default: north-star fp32 stiffness storage */
+#define FB_MATRIX_F64 1 /* reference-width storage, used by the tight parity tests */
+
+const char* fb_last_error(void);
+int fb_device_count(void);
+/* name/arch of device `dev` into caller buffers (may be NULL) */
+int fb_device_info(int dev, char* name, int name_len, char* arch, int arch_len, int* n_cu);
+
+/* ------------------------------------------------------------------------------------------------------
+ * FEM handle.  One handle = what Deformable::syncForceModel builds (deformable/Deformable.cpp:127-220):
+ * TetMesh + CorotationalLinearFEM (3rdparty/vegafem/corotationalLinearFEM/corotationalLinearFEM.cpp:40-146)
+ * + consistent mass (volumetricMesh/generateMassMatrix.cpp:33-76) + the integrator state of
+ * ImplicitNewmarkSparse / VolumeConservingIntegrator (integrator/implicitNewmarkSparse.cpp:39-83,
+ * deformable/PS_VolumeConservingIntegrator.cpp:17-28).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct fb_fem_s* fb_fem_t;
+
+typedef struct fb_fem_params {
+  double E, nu, rho;            /* Deformable.cpp:178 uses 1e7, 0.46, 1000 */
+  double timestep;              /* Deformable.cpp:113: 0.0333 */
+  double damping_mass;          /* Rayleigh c_M, Deformable.cpp:107: 0 */
+  double damping_stiffness;     /* Rayleigh c_K, Deformable.cpp:110: 0.01 */
+  double cg_eps;                /* PS_VolumeConservingIntegrator.cpp:196: 1e-6 */
+  int cg_max_iter;              /* PS_VolumeConservingIntegrator.cpp:197: 10000 */
+  int matrix_precision;         /* FB_MATRIX_F32 / FB_MATRIX_F64 */
+  int device;                   /* HIP device ordinal */
+  int reserved[5];
+} fb_fem_params;
+
+/* fills the reference's defaults listed above */
+void fb_fem_default_params(fb_fem_params* p);
+
+/* xyz: n_nodes*3 rest positions (fp64); tets: n_tets*4 node ids (0-based);
+ * fixed_dofs: ascending, 0-based constrained DOFs (implicitNewmarkSparse.h:78-80), copied. */
+int fb_fem_create(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, const int* tets,
+                  int n_fixed_dofs, const int* fixed_dofs, const fb_fem_params* params);
+
+/* Domain-decomposed variant: rank `rank` of `n_ranks` owns the contiguous node range
+ * [node_splits[rank], node_splits[rank+1]) of the SAME global mesh every rank passes in (node_splits has
+ * n_ranks+1 ascending entries covering [0, n_nodes); NULL = equal split); it assembles every tet touching an
+ * owned node and keeps only owned rows, so no force/stiffness reduction is needed.
+ * Per PCG iteration: one halo exchange of the search direction and two fp64 scalar all-reduces over `comm`
+ * (RCCL); `comm` may be NULL when n_ranks == 1. */
+typedef struct fb_comm_s* fb_comm_t;
+int fb_fem_create_sharded(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, const int* tets,
+                          int n_fixed_dofs, const int* fixed_dofs, const fb_fem_params* params,
+                          int n_ranks, int rank, const int* node_splits, fb_comm_t comm);
+int fb_fem_destroy(fb_fem_t h);
+
+/* Rebuild after a topology change (Deformable::syncForceModel after CuttableMesh::cut, main.cpp:614-617):
+ * same semantics as destroy + create but keeps the device, parameters and constraints. State is reset. */
+int fb_fem_resync(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const int* tets,
+                  int n_fixed_dofs, const int* fixed_dofs);
+
+/* Per-element rest-state rebuild on the device (M^-1 rows / volume, corotationalLinearFEM.cpp:66-90 and
+ * tetMesh.cpp:184-188) -- the per-step "K0 rebuild" of BASELINE config 4. */
+int fb_fem_rebuild_elements(fb_fem_t h);
+
+/* IntegratorBase::SetExternalForces / AddExternalForces / SetExternalForcesToZero (integratorBase.cpp:84-103);
+ * f has 3*n_nodes entries (global numbering; a sharded handle reads its owned range). */
+int fb_fem_set_external_forces(fb_fem_t h, const double* f);
+int fb_fem_add_external_forces(fb_fem_t h, const double* f);
+int fb_fem_set_external_forces_zero(fb_fem_t h);
+/* constant force on one axis of every node, generated on the device: axis 1, value -10000 is the gravity
+ * load of Deformable::timestep (Deformable.cpp:331-338) */
+int fb_fem_set_uniform_force(fb_fem_t h, int axis, double value);
+
+typedef struct fb_step_info {
+  int cg_iterations;      /* |return value| of CGSolver::SolveLinearSystemWithJacobiPreconditioner (CGSolver.cpp:189) */
+  int converged;          /* 1 / 0 */
+  double assembly_seconds;/* IntegratorBaseSparse::GetForceAssemblyTime (integratorBaseSparse.h:66), hipEvent-timed */
+  double solve_seconds;   /* IntegratorBaseSparse::GetSystemSolveTime (integratorBaseSparse.h:67) */
+  double rho0, rho;       /* initial / final sum r^2 / diag */
+} fb_step_info;
+
+/* VolumeConservingIntegrator::DoTimestep (PS_VolumeConservingIntegrator.cpp:46-260): assembly, Keff/rhs, PCG,
+ * state update.  Returns FB_OK, or FB_ESOLVER when PCG hit cg_max_iter (state is then left unchanged). */
+int fb_fem_step(fb_fem_t h, fb_step_info* info);
+
+/* IntegratorBase::GetqState / SetqState / ResetToRest (integratorBase.cpp:105-131); any pointer may be NULL.
+ * Arrays are 3*n_nodes long, global numbering; a sharded handle fills / reads only its owned range. */
+int fb_fem_get_state(fb_fem_t h, double* q, double* qvel, double* qaccel);
+int fb_fem_set_state(fb_fem_t h, const double* q, const double* qvel, const double* qaccel);
+int fb_fem_reset(fb_fem_t h);
+int fb_fem_set_timestep(fb_fem_t h, double timestep);
+int fb_fem_set_damping(fb_fem_t h, double damping_mass, double damping_stiffness);
+int fb_fem_set_cg(fb_fem_t h, double eps, int max_iter);
+/* IntegratorBaseSparse::setConstrainedDOF (integratorBaseSparse.cpp:73-87) -- takes effect at the next step
+ * (the mask is applied when Keff is formed, so unlike the reference no stale systemMatrix can survive) */
+int fb_fem_set_constrained_dofs(fb_fem_t h, int n_fixed_dofs, const int* fixed_dofs);
+
+/* Floor-plane collision + velocity rewrite of Deformable::timestep (Deformable.cpp:350-402), on the device:
+ * v <- v_t - restitution * v_n for every node (n = +y), q_y clamped so rest_y + q_y >= floor_y.
+ * n_collided (may be NULL) counts nodes with rest_y + q_y <= floor_y before the clamp. */
+int fb_fem_floor_collision(fb_fem_t h, double floor_y, double restitution, int* n_collided);
+
+/* ---- inspection entry points (what the parity tests compare against the oracle) ---- */
+int fb_fem_num_nodes(fb_fem_t h);   /* global */
+int fb_fem_num_tets(fb_fem_t h);    /* local (all for an unsharded handle) */
+int fb_fem_num_blocks(fb_fem_t h);  /* 3x3 blocks of the stiffness pattern (owned rows) */
+/* node-level pattern, ascending columns per row (corotationalLinearFEM.cpp:163-186, sparseMatrix.cpp:238-262):
+ * bptr[n_owned+1], bcol[num_blocks] (global node ids) */
+int fb_fem_pattern(fb_fem_t h, int* bptr, int* bcol);
+/* per-element K0 = V B^T E B (144 fp64, row-major 12x12) and M^-1 (16 fp64, rows = [grad N_k | N_k(0)]) for
+ * elements [first, first+count), computed by the batched MFMA kernel (corotationalLinearFEM.cpp:99-145) */
+int fb_fem_element_stiffness(fb_fem_t h, int first, int count, double* K0, double* Minv);
+/* raw corotational assembly at displacement u (3*n_nodes): internal force f (3*n_nodes, owned range filled) and
+ * K as 9 values per block in fb_fem_pattern order (corotationalLinearFEM.cpp:219-470, warp = 1) */
+int fb_fem_assemble(fb_fem_t h, const double* u, double* f, double* K_blocks);
+/* Keff (blocks, constrained rows/cols replaced by identity) and right-hand side of the current state, as the
+ * next fb_fem_step would solve them (PS_VolumeConservingIntegrator.cpp:84-123,160-162) */
+int fb_fem_system(fb_fem_t h, double* Keff_blocks, double* rhs);
+/* consistent mass scalar per block (generateMassMatrix.cpp:33-76, tetMesh.cpp:150-182) */
+int fb_fem_mass(fb_fem_t h, double* m_blocks);
+/* y = Keff x with the device SpMV kernel on the last assembled system (x, y: 3*n_nodes) */
+int fb_fem_spmv(fb_fem_t h, const double* x, double* y);
+/* Jacobi-PCG (CGSolver.cpp:129-190) on the last assembled system with a caller right-hand side; x starts at 0.
+ * iterations_out: + converged / - not converged, as the reference returns. */
+int fb_fem_pcg(fb_fem_t h, const double* rhs, double* x, double eps, int max_iter, int* iterations_out);
+
+/* timing helpers for bench.py: run `iters` PCG iterations (no convergence exit) / `reps` SpMVs / assemblies on
+ * the current system and return the average device time of the named kernel in seconds, measured with HIP
+ * events on the handle's stream. */
+int fb_fem_time_spmv(fb_fem_t h, int reps, double* seconds_per_spmv);
+int fb_fem_time_assembly(fb_fem_t h, int reps, double* seconds_per_assembly);
+/* algorithmic bytes moved by one SpMV launch / one assembly on this handle */
+int fb_fem_spmv_bytes(fb_fem_t h, double* bytes);
+int fb_fem_assembly_bytes(fb_fem_t h, double* bytes);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Communicator for sharded handles: RCCL over xGMI, loaded lazily (a 1-GPU process never needs librccl).
+ * unique_id: 128 bytes produced by fb_comm_unique_id on rank 0 and broadcast by the launcher.
+ * ---------------------------------------------------------------------------------------------------- */
+int fb_comm_unique_id(unsigned char id[128]);
+int fb_comm_create(fb_comm_t* out, int rank, int n_ranks, const unsigned char id[128], int device);
+int fb_comm_destroy(fb_comm_t c);
+
+/* ------------------------------------------------------------------------------------------------------
+ * BlobTree field / polygonizer handle = the GPU side of PS::SKETCH::GPUPoly (implicit/OclPolygonizer.h:45-231)
+ * and PS::SKETCH::FieldComputer (implicit/FieldComputer.h:31-70).  Input is the LinearBlobTree flat layout
+ * (implicit/LinearBlobTree.h:20-82): header 12 floats, 16 per operator, 20 per primitive, 12 per matrix.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct fb_poly_s* fb_poly_t;
+
+/* GPUPoly::setBlob (OclPolygonizer.cpp:1602-1648): deep copy of the four arrays */
+int fb_poly_create(fb_poly_t* out, int device, const float* header12, int n_ops, const float* ops16,
+                   int n_prims, const float* prims20, int n_mtx, const float* mtx12);
+int fb_poly_destroy(fb_poly_t h);
+
+/* GPUPoly::computeFieldArray / FieldComputer::field(n,4,xyzf) (OclPolygonizer.cpp:943-986): xyzf is n*4 floats,
+ * .w overwritten with the field value */
+int fb_poly_field_array(fb_poly_t h, int n, float* xyzf);
+
+/* GPUPoly::computeAllFields (OclPolygonizer.cpp:1358-1426): sweeps the voxel grid of the model's bounding box at
+ * `cellsize` (points per axis = ceil(extent/cellsize)+2), keeps the float4 (x,y,z,f) grid on the device.
+ * dims_out[3] = grid points per axis.  `extra_points` = 0 for GPUPoly, 0 for FieldComputer as well (its +2 is
+ * the same count, FieldComputer.cpp:157-161). */
+int fb_poly_sweep(fb_poly_t h, float cellsize, int dims_out[3]);
+/* explicit grid (lower corner, cellsize, point counts) -- used by benches that name the grid size */
+int fb_poly_sweep_grid(fb_poly_t h, const float lower[3], float cellsize, const int dims[3]);
+/* GPUPoly::readBackVoxelGridSamples (OclPolygonizer.cpp:916-940): xyzf = 4 floats per grid point,
+ * index = iz*gx*gy + iy*gx + ix */
+int fb_poly_read_grid(fb_poly_t h, float* xyzf);
+
+typedef struct fb_poly_counts {
+  int grid[3];
+  int n_points, n_cells;
+  int n_crossed_edges;    /* = surface vertices, sum of ComputeEdgeTable counts (Polygonizer.cl:1353-1415) */
+  int n_surface_cells;    /* cells with 0 < config < 255 */
+  int n_mc_indices;       /* triangle indices from the compact tables (Polygonizer.cl:1564-1607) */
+  int n_included_cells;   /* config != 0 (Tetrahedralizer.cl:3-35) */
+  int n_tet_vertices;     /* grid points touched by an included cell */
+  int n_tets;             /* 6 per included cell */
+} fb_poly_counts;
+
+/* ComputeEdgeTable + ComputeCellConfigs + TetMeshCells + the exclusive scans, all on the device
+ * (OclPolygonizer.cpp:644-757 steps 2,3,5,6 and :762-819) */
+int fb_poly_classify(fb_poly_t h, fb_poly_counts* counts);
+/* per-point crossing flags (X=4,Y=2,Z=1) / counts and per-cell 8-bit configs, for parity tests; any may be NULL */
+int fb_poly_read_classification(fb_poly_t h, unsigned char* edge_flags, unsigned int* edge_counts,
+                                unsigned char* cell_configs);
+/* GPUPoly::runTetrahedralizer (OclPolygonizer.cpp:762-819; Tetrahedralizer.cl:39-132): compacts the included grid
+ * points in grid order and emits 6 tets per included cell; results stay on the device until read back. */
+int fb_poly_tetrahedralize(fb_poly_t h, fb_poly_counts* counts);
+/* xyz: 3 floats per tet-mesh vertex, tets: 4 uint32 per tet (both sized from fb_poly_counts) */
+int fb_poly_read_tetmesh(fb_poly_t h, float* xyz, unsigned int* tets);
+/* marching-cubes surface of GPUPoly::run (ComputeVertexAttribs / ComputeElements, Polygonizer.cl:1429-1670):
+ * vertices (xyz + normal, 6 floats) and triangle indices; sizes from fb_poly_counts */
+int fb_poly_surface(fb_poly_t h, float* vertices_xyz, float* normals_xyz, unsigned int* indices);
+/* ApplyVertexDeformations (Polygonizer.cl:1417-1426; OclPolygonizer.cpp:1543-1596): surface vertex i moves by
+ * displacement[3i..3i+2] (the reference's surface-vertex-id indexing) */
+int fb_poly_apply_displacements(fb_poly_t h, int dof, const double* displacements);
+/* average device seconds of one sweep / one classify+tetrahedralize pipeline on the current grid */
+int fb_poly_time_pipeline(fb_poly_t h, int reps, double* sweep_seconds, double* pipeline_seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEMBRAIN_HIP_H */

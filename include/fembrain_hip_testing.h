@@ -1,0 +1,29 @@
+/* fembrain_hip_testing.h -- host-only inspection hooks of libfembrain_hip.so used by the CPU test-suite
+ * (no device call is made by any function in this header).  They expose the per-rank plan that
+ * fb_fem_create[_sharded] builds -- local numbering, halo/send lists, 3x3-block pattern, SELL-64 layout and the
+ * element contribution lists -- so that the partition logic can be checked without a GPU, including with
+ * world_size-2 gloo runs.  Not part of the reference-facing surface. */
+#ifndef FEMBRAIN_HIP_TESTING_H
+#define FEMBRAIN_HIP_TESTING_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fb_plan_s* fb_plan_t;
+
+int fb_plan_create(fb_plan_t* out, int n_nodes, int n_tets, const int* tets, int n_fixed_dofs, const int* fixed_dofs,
+                   int n_ranks, int rank, const int* node_splits);
+int fb_plan_destroy(fb_plan_t p);
+/* info[0..11] = n_owned, n_halo, n_tets, n_blocks, n_slices, n_slots, n_crows, n_send, node_lo, node_hi,
+ * n_fixed_owned, n_ranks */
+int fb_plan_info(fb_plan_t p, int info[12]);
+/* copies the named int32 array into out (capacity in elements); returns the element count or a negative code.
+ * names: local2global, halo_off, send_off, send_local, tets, tet_global, bptr, bcol, slice_off, colidx, blk_slot,
+ *        slot_coff, slot_ccnt, contrib (uint32 bits), dofmask (one int per DOF) */
+int fb_plan_get(fb_plan_t p, const char* name, int* out, size_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
