@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FEM steps/s (element rebuild + assembly + Jacobi-PCG) on the synthetic 1M-tet cantilever,
+and BlobTree field Mvoxels/s on a 256^3 grid (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+One JSON line on rank 0.  A "step" is one pass of the hot path: fb_fem_rebuild_elements (per-element rest state,
+the cutting path's K0 rebuild), corotational assembly of Keff/rhs and the PCG solve to the reference tolerance
+(eps 1e-6, max 10000), followed by the state update -- all inputs resident in HBM.  For N > 1 the SAME mesh is
+slab-decomposed over the ranks (strong scaling): one process per GPU, RCCL all-reduce for the PCG dots and
+ncclSend/Recv halo exchange of the search direction.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (nodes per side, text)
+    "cube27": (27, "truth cube 27^3 nodes / 105,456 tets (BASELINE config 2 canonical mesh)"),
+    "cube56": (56, "truth cube 56^3 nodes / 998,250 tets, plane i=0 clamped, -10000 per y DOF, per-step re-assembly (BASELINE config 4)"),
+    "cube111": (111, "truth cube 111^3 nodes / 7,986,000 tets (BASELINE config 5 mesh)"),
+}
+
+
+def cpu_baseline(n, cg_iterations, sample_iters=40):
+    """Oracle (our fp64 CSR restatement of the reference path, 1 core) on the same workload: one full assembly +
+    system build and `sample_iters` PCG iterations are timed; the step time is extrapolated with the GPU-measured
+    iteration count."""
+    from oracle.pyoracle import OrcFem
+    from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
+    v, t = truth_cube(n, n, n, 0.1)
+    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    o = OrcFem(v, t)
+    o.integrator(fixed)
+    f = np.zeros(o.r)
+    f[1::3] = -10000.0
+    o.set_external_forces(f)
+    t0 = time.perf_counter()
+    o.step_prepare()  # assembly + Keff/rhs algebra + constrained system
+    t_asm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    it = abs(o.pcg_bounded(1e-30, sample_iters))
+    t_it = (time.perf_counter() - t0) / max(it, 1)
+    step_s = t_asm + cg_iterations * t_it
+    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": "oracle/fem_oracle.c on the same mesh: 1 assembly+system build (%.2f s) + %d PCG iterations (%.2f ms each), "
+                      "extrapolated to the %d iterations the GPU run needed" % (t_asm, it, t_it * 1e3, cg_iterations)}
+
+
+def field_bench(device):
+    """256^3 sweep + classify + tetrahedralize of sphere.blob (BASELINE config 3); returns extra JSON keys."""
+    try:
+        from fembrain_amd.poly import GpuPoly, sphere_blob
+    except Exception:
+        return {}
+    p = GpuPoly(sphere_blob(), device=device)
+    dims = p.sweep_grid((-0.5, -0.5, -0.5), 1.0 / 254.0, (256, 256, 256))
+    p.classify()
+    p.tetrahedralize()
+    sweep_s, pipe_s = p.time_pipeline(5)
+    npts = dims[0] * dims[1] * dims[2]
+    return {"field_mvoxels_per_s": npts / pipe_s / 1e6, "field_sweep_mvoxels_per_s": npts / sweep_s / 1e6,
+            "field_grid": list(dims), "field_sweep_gbs": npts * 16 / sweep_s / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cube56", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-field", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    from fembrain_amd import lib as fl
+    from fembrain_amd.fem import FemIntegrator
+    from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device visible (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    shard = None
+    comm = None
+    if world > 1:
+        import ctypes as C
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf = (C.c_ubyte * 128)()
+            fl.check(fl.lib().fb_comm_unique_id(buf))
+            uid = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        idb = (C.c_ubyte * 128)(*uid.cpu().tolist())
+        comm = C.c_void_p()
+        fl.check(fl.lib().fb_comm_create(C.byref(comm), rank, world, idb, local_rank))
+
+    n, text = WORKLOADS[args.workload]
+    v, t = truth_cube(n, n, n, 0.1)
+    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    if world > 1:
+        # slabs of whole i-planes (node index = i*n*n + j*n + k): <= 2 neighbours per rank
+        planes = [n * r // world for r in range(world + 1)]
+        splits = np.array([p * n * n for p in planes], dtype=np.int32)
+        shard = (world, rank, splits, comm)
+    prec = fl.FB_MATRIX_F64 if args.precision == "f64" else fl.FB_MATRIX_F32
+    g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=local_rank, shard=shard)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        g.rebuild_elements()
+        g.set_uniform_force(1, -10000.0)
+        return g.do_timestep()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    iters, asm_s, solve_s = [], 0.0, 0.0
+    for _ in range(args.steps):
+        iters.append(one_step())
+        asm_s += g.last.assembly_seconds
+        solve_s += g.last.solve_seconds
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # dominant kernel: the PCG SpMV.  Average launch duration measured with HIP events on the handle's stream.
+    spmv_s = g.time_spmv(200)
+    spmv_bytes = g.spmv_bytes()
+    asm_k_s = g.time_assembly(10)
+    out = None
+    if rank == 0:
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "spmv_pmc.json")
+        if os.path.exists(pmc) and args.workload == "cube56" and world == 1 and args.precision == "f32":
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "FEM steps/sec (assemble+PCG) at 1M tets", "value": args.steps / dt, "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 matrix, f64 vectors/accumulators" if args.precision == "f32" else "f64", "data": "synthetic",
+            "config": {"workload": text, "nodes": int(len(v)), "tets": int(len(t)), "partition": "i-plane slabs x%d" % world,
+                       "cg_eps": 1e-6, "cg_max_iter": 10000},
+            "cg_iterations_per_step": float(np.mean(iters)), "assembly_ms_per_step": asm_s / args.steps * 1e3,
+            "solve_ms_per_step": solve_s / args.steps * 1e3, "us_per_cg_iteration": solve_s / max(sum(iters), 1) * 1e6,
+            "assembly_kernels_us": asm_k_s * 1e6, "assembly_gbs": g.assembly_bytes() / asm_k_s / 1e9,
+            "roofline": {"kernel": "k_spmv (SELL-64 3x3-block SpMV of the PCG)", "bound": "hbm",
+                         "achieved": spmv_bytes / spmv_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": spmv_bytes / spmv_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": spmv_bytes, "us_per_launch": spmv_s * 1e6},
+        }
+    if world == 1 and not args.no_field:
+        extra = field_bench(local_rank)
+        if out is not None:
+            out.update(extra)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n, int(round(np.mean(iters))))
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    g.close()
+    if world > 1:
+        fl.lib().fb_comm_destroy(comm)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
