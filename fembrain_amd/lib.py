@@ -41,7 +41,7 @@ class StepInfo(C.Structure):
 
 class PolyCounts(C.Structure):
     _fields_ = [("grid", C.c_int * 3), ("n_points", C.c_int), ("n_cells", C.c_int), ("n_crossed_edges", C.c_int),
-                ("n_surface_cells", C.c_int), ("n_mc_indices", C.c_int), ("n_included_cells", C.c_int),
+                ("n_surface_cells", C.c_int), ("n_included_cells", C.c_int),
                 ("n_tet_vertices", C.c_int), ("n_tets", C.c_int)]
 
 
@@ -122,11 +122,9 @@ def lib():
         "fb_poly_read_classification": (C.c_int, [vp, _bp, _up, _bp]),
         "fb_poly_tetrahedralize": (C.c_int, [vp, C.POINTER(PolyCounts)]),
         "fb_poly_read_tetmesh": (C.c_int, [vp, _fp, _up]),
-        "fb_poly_surface": (C.c_int, [vp, _fp, _fp, _up]),
-        "fb_poly_apply_displacements": (C.c_int, [vp, C.c_int, _dp]),
         "fb_poly_time_pipeline": (C.c_int, [vp, C.c_int, _dp, _dp]),
     }
-    sig.update({k: v for k, v in poly_sig.items() if hasattr(L, k)})  # TEMP until poly.hip lands
+    sig.update(poly_sig)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the library does not match include/fembrain_hip.h
         fn.restype = res

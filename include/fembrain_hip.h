@@ -175,10 +175,10 @@ int fb_poly_destroy(fb_poly_t h);
  * .w overwritten with the field value */
 int fb_poly_field_array(fb_poly_t h, int n, float* xyzf);
 
-/* GPUPoly::computeAllFields (OclPolygonizer.cpp:1358-1426): sweeps the voxel grid of the model's bounding box at
- * `cellsize` (points per axis = ceil(extent/cellsize)+2), keeps the float4 (x,y,z,f) grid on the device.
- * dims_out[3] = grid points per axis.  `extra_points` = 0 for GPUPoly, 0 for FieldComputer as well (its +2 is
- * the same count, FieldComputer.cpp:157-161). */
+/* GPUPoly::computeAllFields (OclPolygonizer.cpp:1358-1426) / FieldComputer::fieldsForVoxelGrid
+ * (FieldComputer.cpp:143-231): sweeps the voxel grid of the model's bounding box (header[0..2] .. header[4..6]) at
+ * `cellsize` -- points per axis = ceil(extent/cellsize)+2, origin = bbox lower -- and keeps the float4 (x,y,z,f)
+ * grid on the device.  dims_out[3] = grid points per axis.  cellsize < 0.01 is refused as GPUPoly::run does. */
 int fb_poly_sweep(fb_poly_t h, float cellsize, int dims_out[3]);
 /* explicit grid (lower corner, cellsize, point counts) -- used by benches that name the grid size */
 int fb_poly_sweep_grid(fb_poly_t h, const float lower[3], float cellsize, const int dims[3]);
@@ -191,7 +191,6 @@ typedef struct fb_poly_counts {
   int n_points, n_cells;
   int n_crossed_edges;    /* = surface vertices, sum of ComputeEdgeTable counts (Polygonizer.cl:1353-1415) */
   int n_surface_cells;    /* cells with 0 < config < 255 */
-  int n_mc_indices;       /* triangle indices from the compact tables (Polygonizer.cl:1564-1607) */
   int n_included_cells;   /* config != 0 (Tetrahedralizer.cl:3-35) */
   int n_tet_vertices;     /* grid points touched by an included cell */
   int n_tets;             /* 6 per included cell */
@@ -208,12 +207,6 @@ int fb_poly_read_classification(fb_poly_t h, unsigned char* edge_flags, unsigned
 int fb_poly_tetrahedralize(fb_poly_t h, fb_poly_counts* counts);
 /* xyz: 3 floats per tet-mesh vertex, tets: 4 uint32 per tet (both sized from fb_poly_counts) */
 int fb_poly_read_tetmesh(fb_poly_t h, float* xyz, unsigned int* tets);
-/* marching-cubes surface of GPUPoly::run (ComputeVertexAttribs / ComputeElements, Polygonizer.cl:1429-1670):
- * vertices (xyz + normal, 6 floats) and triangle indices; sizes from fb_poly_counts */
-int fb_poly_surface(fb_poly_t h, float* vertices_xyz, float* normals_xyz, unsigned int* indices);
-/* ApplyVertexDeformations (Polygonizer.cl:1417-1426; OclPolygonizer.cpp:1543-1596): surface vertex i moves by
- * displacement[3i..3i+2] (the reference's surface-vertex-id indexing) */
-int fb_poly_apply_displacements(fb_poly_t h, int dof, const double* displacements);
 /* average device seconds of one sweep / one classify+tetrahedralize pipeline on the current grid */
 int fb_poly_time_pipeline(fb_poly_t h, int reps, double* sweep_seconds, double* pipeline_seconds);
 

@@ -1,0 +1,107 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-end of oracle/field_oracle.c (libfem_oracle.so).
+
+``OrcPoly`` runs the reference pipeline pass by pass on the host (sweep, edge table, cell configs, included cells
+with scatter-marked vertices, exclusive scans, vertex compaction, 6 tets per cell).  Never import from fembrain_amd/.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .pyoracle import _load
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_up = C.POINTER(C.c_uint)
+_bp = C.POINTER(C.c_ubyte)
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _lib():
+    lib = _load("orc")
+    if getattr(lib, "_field_bound", False):
+        return lib
+    tree = [C.c_int, _fp, C.c_int, _fp, C.c_int, _fp]
+    lib.orc_field_array.argtypes = tree + [C.c_int, _fp]
+    lib.orc_sweep.argtypes = tree + [_fp, C.c_float, _ip, _fp]
+    lib.orc_sweep_f.argtypes = tree + [_fp, C.c_float, _ip, C.c_int, C.c_int, _fp]
+    lib.orc_edge_table.argtypes = [_fp, _ip, _up, _bp]
+    lib.orc_cell_configs.argtypes = [_fp, _ip, _bp]
+    lib.orc_tet_cells.argtypes = [_bp, _ip, _up, _up]
+    lib.orc_scan.restype = C.c_uint
+    lib.orc_scan.argtypes = [_up, _up, C.c_size_t]
+    lib.orc_tet_vertices.argtypes = [_fp, _up, _up, C.c_size_t, _fp]
+    lib.orc_tet_elements.argtypes = [_up, _up, _up, _ip, _up]
+    lib._field_bound = True
+    return lib
+
+
+class OrcPoly:
+    def __init__(self, blob):
+        self.blob = blob
+        self.lib = _lib()
+        ops = blob.ops if blob.n_ops else np.zeros((1, 16), np.float32)
+        self._ops = np.ascontiguousarray(ops, np.float32)
+        self._tree = (blob.n_ops, _f(self._ops), blob.n_prims, _f(blob.prims), len(blob.mtx), _f(blob.mtx))
+
+    def field_array(self, xyzf):
+        a = np.ascontiguousarray(xyzf, dtype=np.float32).reshape(-1, 4).copy()
+        self.lib.orc_field_array(*self._tree, len(a), _f(a))
+        return a
+
+    def grid_dims(self, cellsize):
+        lo, hi = self.blob.bbox
+        ext = (hi - lo).astype(np.float32)
+        return tuple(int(np.ceil(np.float32(e) / np.float32(cellsize))) + 2 for e in ext)
+
+    def sweep_grid(self, lower, cellsize, dims):
+        self.lo = np.asarray(lower, np.float32)
+        self.g = np.asarray(dims, np.int32)
+        self.cellsize = cellsize
+        n = int(np.prod(self.g.astype(np.int64)))
+        self.xyzf = np.empty((n, 4), np.float32)
+        self.lib.orc_sweep(*self._tree, _f(self.lo), cellsize, self.g.ctypes.data_as(_ip), _f(self.xyzf))
+        return self.xyzf
+
+    def sweep(self, cellsize):
+        return self.sweep_grid(self.blob.bbox[0], cellsize, self.grid_dims(cellsize))
+
+    def sweep_f_slab(self, lower, cellsize, dims, z0, z1):
+        lo, g = np.asarray(lower, np.float32), np.asarray(dims, np.int32)
+        f = np.empty(int(g[0]) * int(g[1]) * (z1 - z0), np.float32)
+        self.lib.orc_sweep_f(*self._tree, _f(lo), cellsize, g.ctypes.data_as(_ip), z0, z1, _f(f))
+        return f
+
+    def classify(self):
+        g = self.g
+        npts = len(self.xyzf)
+        ncells = int((g[0] - 1) * (g[1] - 1) * (g[2] - 1))
+        gp = g.ctypes.data_as(_ip)
+        self.edge_count, self.edge_flags = np.empty(npts, np.uint32), np.empty(npts, np.uint8)
+        self.lib.orc_edge_table(_f(self.xyzf), gp, self.edge_count.ctypes.data_as(_up), self.edge_flags.ctypes.data_as(_bp))
+        self.config = np.empty(ncells, np.uint8)
+        self.lib.orc_cell_configs(_f(self.xyzf), gp, self.config.ctypes.data_as(_bp))
+        self.inc_cells, self.inc_verts = np.empty(ncells, np.uint32), np.empty(npts, np.uint32)
+        self.lib.orc_tet_cells(self.config.ctypes.data_as(_bp), gp, self.inc_cells.ctypes.data_as(_up), self.inc_verts.ctypes.data_as(_up))
+        return {"n_crossed_edges": int(self.edge_count.sum()), "n_surface_cells": int(((self.config != 0) & (self.config != 255)).sum()),
+                "n_included_cells": int(self.inc_cells.sum()), "n_tet_vertices": int(self.inc_verts.sum())}
+
+    def tetrahedralize(self):
+        npts, ncells = len(self.xyzf), len(self.config)
+        voff, coff = np.empty(npts, np.uint32), np.empty(ncells, np.uint32)
+        nv = self.lib.orc_scan(self.inc_verts.ctypes.data_as(_up), voff.ctypes.data_as(_up), npts)
+        nc = self.lib.orc_scan(self.inc_cells.ctypes.data_as(_up), coff.ctypes.data_as(_up), ncells)
+        xyz = np.empty((nv, 3), np.float32)
+        tets = np.empty((6 * nc, 4), np.uint32)
+        self.lib.orc_tet_vertices(_f(self.xyzf), self.inc_verts.ctypes.data_as(_up), voff.ctypes.data_as(_up), npts, _f(xyz))
+        self.lib.orc_tet_elements(voff.ctypes.data_as(_up), coff.ctypes.data_as(_up), self.inc_cells.ctypes.data_as(_up),
+                                  self.g.ctypes.data_as(_ip), tets.ctypes.data_as(_up))
+        return xyz, tets
+
+    def run_tetrahedralizer(self, cellsize):
+        self.sweep(cellsize)
+        counts = self.classify()
+        xyz, tets = self.tetrahedralize()
+        return xyz, tets, counts

@@ -1,0 +1,134 @@
+"""Parity of the HIP field / classification / tetrahedralizer path (through the C ABI) against the CPU oracle and
+the reference's golden sphere mesh.  Integer outputs (flags, configs, tet connectivity) and fp32 field values of
+sqrt-free primitives are compared bit-exactly; primitives that go through sqrt / pow are compared to 1e-6."""
+import os
+
+import numpy as np
+import pytest
+
+from fembrain_amd.blobtree import make_tree, read_blob, sphere_blob
+from fembrain_amd.poly import GpuPoly
+from oracle.pyfield import OrcPoly
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+OF_RIGHT_OP, OF_LEFT_OP, OF_RANGE, OF_UNARY = 1, 2, 4, 8
+
+
+def _trees():
+    pts = [(0, (0.1 * i - 0.3, 0.05 * i, 0.02 * i * i), (0, 0, 0), (0, 0, 0)) for i in range(6)]
+    mixed = [(0, (0, 0, 0), (0, 0, 0), (0, 0, 0)), (1, (-0.5, 0.2, 0), (0.6, 0.3, 0.1), (0, 0, 0)), (5, (0.3, -0.4, 0.2), (0, 0, 0), (0.25, 0, 0)),
+             (2, (0, 0, -0.6), (0, 1, 0), (0.2, 0.7, 0)), (3, (0.5, 0.5, 0.5), (0, 0, 1), (0.3, 0, 0)), (4, (-0.5, -0.5, 0.4), (1, 0, 0), (0.3, 0, 0)),
+             (7, (0.2, 0.7, -0.3), (1.0, 0.8, 0.64), (1.0 / 0.8 ** 4, -2.0 / 0.64, 1.0))]
+    return {
+        "sphere": sphere_blob(),
+        "blend6_noops": make_tree(pts),
+        "range_blend": make_tree(pts, [(4, 0, 5, OF_RANGE, 0, 0)]),
+        # op0 = union(op1, op2); op1 = dif(prim0, prim1); op2 = smoothdif(op3, prim2); op3 = range(3..6)
+        "nested": make_tree(mixed, [(0, 1, 2, OF_LEFT_OP | OF_RIGHT_OP, 0, 0), (2, 0, 1, 0, 0, 0), (3, 3, 2, OF_LEFT_OP, 0, 0), (4, 3, 6, OF_RANGE, 0, 0)]),
+        # two range operators under an intersection: the second range inherits the first one's running field
+        "two_ranges": make_tree(pts, [(1, 1, 2, OF_LEFT_OP | OF_RIGHT_OP, 0, 0), (4, 0, 2, OF_RANGE, 0, 0), (4, 3, 5, OF_RANGE, 0, 0)]),
+        "ricci": make_tree(pts[:2], [(5, 0, 1, 0, 2.0, 0.5)]),
+    }
+
+
+@pytest.mark.parametrize("name", ["sphere", "blend6_noops", "range_blend", "nested", "two_ranges", "ricci"])
+def test_field_array_matches_oracle(gpu, name):
+    blob = _trees()[name]
+    rng = np.random.default_rng(3)
+    pts = np.zeros((5000, 4), np.float32)
+    pts[:, :3] = rng.uniform(-1.2, 1.2, size=(5000, 3)).astype(np.float32)
+    g = GpuPoly(blob)
+    got = g.compute_field_array(pts)
+    want = OrcPoly(blob).field_array(pts)
+    assert np.array_equal(got[:, :3], pts[:, :3])
+    if name in ("nested", "ricci"):  # cylinder/disc/ring use sqrt, Ricci uses pow: last-ulp differences allowed
+        assert np.abs(got[:, 3] - want[:, 3]).max() <= 2e-6
+    else:
+        assert np.array_equal(got[:, 3], want[:, 3])
+    if name == "sphere":
+        assert g.field((0.25, 0, 0)) == np.float32((1 - 0.0625) ** 3)  # SURVEY.md 8c known answer
+
+
+def test_sphere_tetmesh_matches_reference_golden(gpu):
+    gold = np.load(os.path.join(GOLD, "sphere_tets_c0.1.npz"))
+    g = GpuPoly(sphere_blob())
+    xyz, tets = g.run_tetrahedralizer(0.1)
+    assert g.dims == (12, 12, 12) and len(tets) == 3744 == 6 * len(gold["cell_ijk"])
+    # bit-exact against the oracle (welded numbering: exclusive scan in grid order)
+    o = OrcPoly(sphere_blob())
+    oxyz, otets, oc = o.run_tetrahedralizer(0.1)
+    assert np.array_equal(tets, otets) and np.array_equal(xyz, oxyz)
+    c = g.counts
+    assert (c.n_crossed_edges, c.n_surface_cells, c.n_included_cells, c.n_tet_vertices) == \
+        (oc["n_crossed_edges"], oc["n_surface_cells"], oc["n_included_cells"], oc["n_tet_vertices"])
+    # against the reference's own file: same cells in the same order, same 6-tet corner pattern, same positions
+    cell_lo = np.rint((xyz[tets.reshape(-1, 6, 4)[:, 0, 0]] + 0.5) / 0.1).astype(np.int32)  # LBN of every cell
+    assert np.array_equal(cell_lo, gold["cell_ijk"])
+    for n, key in ((0, "first_cell_xyz"), (len(gold["cell_ijk"]) - 1, "last_cell_xyz")):
+        corners = gold[key]  # 8 un-welded corners of that cell in the file
+        for ti in range(6):
+            want = corners[gold["pattern"][ti]]
+            got = xyz[tets[6 * n + ti]]
+            assert np.abs(got - want).max() < 1e-6  # the old kernel forms +1 corners as lower+cellsize (7.45e-9 vs 0)
+
+
+@pytest.mark.parametrize("name,cellsize", [("nested", 0.09), ("two_ranges", 0.07), ("tumor.blob", 0.15), ("complex.blob", 0.12)])
+def test_grid_classification_bit_exact(gpu, name, cellsize):
+    blob = read_blob(os.path.join(GOLD, "blob", name)) if name.endswith(".blob") else _trees()[name]
+    g = GpuPoly(blob)
+    dims = g.sweep(cellsize)
+    o = OrcPoly(blob)
+    assert dims == o.grid_dims(cellsize)
+    ogrid = o.sweep(cellsize)
+    grid = g.read_grid()
+    assert np.array_equal(grid[:, :3], ogrid[:, :3])
+    assert np.abs(grid[:, 3] - ogrid[:, 3]).max() <= 2e-6
+    # classification is compared on points whose field is not within rounding of the iso value
+    oc = o.classify()
+    c = g.classify()
+    flags, cnt, cfg = g.read_classification()
+    safe = np.abs(ogrid[:, 3] - 0.5) > 1e-5
+    if safe.all():
+        assert np.array_equal(flags, o.edge_flags) and np.array_equal(cnt, o.edge_count) and np.array_equal(cfg, o.config)
+        assert c.n_crossed_edges == oc["n_crossed_edges"] and c.n_surface_cells == oc["n_surface_cells"]
+        assert c.n_included_cells == oc["n_included_cells"] and c.n_tet_vertices == oc["n_tet_vertices"]
+        g.tetrahedralize()
+        xyz, tets = g.read_tetmesh()
+        oxyz, otets = o.tetrahedralize()
+        assert np.array_equal(tets, otets) and np.array_equal(xyz, oxyz)
+    else:
+        assert (flags != o.edge_flags).sum() <= 8 * (~safe).sum()
+
+
+def test_sphere_256_properties(gpu):
+    """BASELINE config 3 at full size: known counts (6,557,600 included cells -> 39,345,600 tets) and
+    size-independent invariants of the emitted mesh."""
+    g = GpuPoly(sphere_blob())
+    dims = g.sweep_grid((-0.5, -0.5, -0.5), 1.0 / 254.0, (256, 256, 256))
+    assert dims == (256, 256, 256)
+    c = g.classify()
+    assert c.n_points == 256 ** 3 and c.n_cells == 255 ** 3
+    assert c.n_included_cells == 6557600
+    g.tetrahedralize()
+    assert g.counts.n_tets == 39345600
+    xyz, tets = g.read_tetmesh()
+    assert tets.max() == len(xyz) - 1 and tets.min() == 0
+    used = np.zeros(len(xyz), bool)
+    used[tets.reshape(-1)] = True
+    assert used.all()  # every compacted vertex belongs to a tet
+    # vertices come out in grid order (z slowest): lexicographic in (z, y, x)
+    key = np.rint((xyz + 0.5) * 254).astype(np.int64)
+    lin = key[:, 2] * 65536 + key[:, 1] * 256 + key[:, 0]
+    assert (np.diff(lin) > 0).all()
+    # every tet of a cell has positive or negative but never zero volume, and the 6 tets fill the cell
+    sample = tets[:: 4099][:2000]
+    p = xyz[sample].astype(np.float64)
+    vol = np.abs(np.einsum("ij,ij->i", p[:, 0] - p[:, 3], np.cross(p[:, 1] - p[:, 3], p[:, 2] - p[:, 3]))) / 6
+    assert np.allclose(vol, (1.0 / 254) ** 3 / 6, rtol=1e-3)
+    # all samples of the stored grid obey inside <=> |p| <= iso distance 0.4542 up to one cell
+    grid = g.read_grid()
+    rr = np.sqrt((grid[:, :3].astype(np.float64) ** 2).sum(1))
+    inside = grid[:, 3] >= 0.5
+    assert inside[rr < 0.45].all() and not inside[rr > 0.46].any()
