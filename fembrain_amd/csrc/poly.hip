@@ -236,7 +236,7 @@ __device__ inline int bit_at(const unsigned long long* __restrict__ m, long long
 // corner c = 4*dx + 2*dy + dz; included = config != 0.  One thread per cell, linear cell index cz*cx*cy + cy*cx + cx.
 __global__ __launch_bounds__(kPB) void k_cells(Grid G, const unsigned long long* __restrict__ inside, unsigned char* __restrict__ config,
                                                unsigned long long* __restrict__ cinc, unsigned int* __restrict__ cinc_pop,
-                                               unsigned int* __restrict__ totals) {
+                                               unsigned int* __restrict__ surf_pop) {
   const long long cid = (long long)blockIdx.x * kPB + threadIdx.x;
   int cfg = 0;
   if (cid < G.n_cells) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kPB) void k_cells(Grid G, const unsigned long long*
   if ((threadIdx.x & 63) == 0 && cid < ((G.n_cells + 63) & ~63LL)) {
     cinc[cid >> 6] = inc;
     cinc_pop[cid >> 6] = __popcll(inc);
-    if (surf) atomicAdd(&totals[1], (unsigned int)__popcll(surf));
+    surf_pop[cid >> 6] = __popcll(surf);  // summed by the scan pass: no same-address atomics on the hot path
   }
 }
 
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kPB) void k_cells(Grid G, const unsigned long long*
 __global__ __launch_bounds__(kPB) void k_points(Grid G, const unsigned long long* __restrict__ inside,
                                                 const unsigned long long* __restrict__ cinc, unsigned char* __restrict__ flags,
                                                 unsigned long long* __restrict__ vinc, unsigned int* __restrict__ vinc_pop,
-                                                unsigned int* __restrict__ totals) {
+                                                unsigned int* __restrict__ edge_pop) {
   const long long gid = (long long)blockIdx.x * kPB + threadIdx.x;
   int fl = 0, inc = 0;
   if (gid < G.n_points) {
@@ -303,38 +303,84 @@ __global__ __launch_bounds__(kPB) void k_points(Grid G, const unsigned long long
   if ((threadIdx.x & 63) == 0 && gid < ((G.n_points + 63) & ~63LL)) {
     vinc[gid >> 6] = vb;
     vinc_pop[gid >> 6] = __popcll(vb);
-    if (s) atomicAdd(&totals[0], (unsigned int)s);
+    edge_pop[gid >> 6] = (unsigned int)s;
   }
 }
 
-// single-block exclusive scan of n (<= a few million) u32 counts; total -> *total_out
-__global__ __launch_bounds__(1024) void k_scan_words(const unsigned int* __restrict__ in, unsigned int* __restrict__ out, int n,
-                                                     unsigned int* __restrict__ total_out) {
-  __shared__ unsigned int wsum[16];
-  __shared__ unsigned int carry_s;
+// Exclusive scan of the per-word popcounts in three small passes (n = points/64): per-chunk sums (kChunk words per
+// block), one block scanning the chunk sums, per-chunk local scans.  `aux` (same length) is only summed.
+constexpr int kChunk = 4096;  // words per block: 16 per thread
+
+__device__ inline unsigned int block_excl_scan256(unsigned int v, unsigned int* total, unsigned int* sh) {
+  // exclusive scan of one value per thread over a 256-thread block; *total = block sum
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + threadIdx.x;
-    const unsigned int v = i < n ? in[i] : 0u;
-    unsigned int incl = v;
+  unsigned int incl = v;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned int t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
-    }
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    unsigned int woff = 0;
-    for (int k = 0; k < w; k++) woff += wsum[k];
-    const unsigned int carry = carry_s;
-    if (i < n) out[i] = carry + woff + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) sh[w] = incl;
+  __syncthreads();
+  unsigned int woff = 0;
+  for (int k = 0; k < w; k++) woff += sh[k];
+  *total = sh[0] + sh[1] + sh[2] + sh[3];
+  return woff + incl - v;
+}
+
+__global__ __launch_bounds__(kPB) void k_chunk_sums(const unsigned int* __restrict__ in, const unsigned int* __restrict__ aux, int n,
+                                                    unsigned int* __restrict__ sums, unsigned int* __restrict__ aux_sums) {
+  __shared__ unsigned int sh[4];
+  const int base = blockIdx.x * kChunk;
+  unsigned int a = 0, b = 0;
+  for (int k = 0; k < kChunk / kPB; k++) {
+    const int i = base + k * kPB + threadIdx.x;
+    if (i < n) { a += in[i]; b += aux[i]; }
+  }
+  unsigned int ta, tb;
+  block_excl_scan256(a, &ta, sh);
+  block_excl_scan256(b, &tb, sh);
+  if (threadIdx.x == 0) { sums[blockIdx.x] = ta; aux_sums[blockIdx.x] = tb; }
+}
+
+// one block: exclusive scan of up to 16*kPB chunk sums in place; totals out
+__global__ __launch_bounds__(kPB) void k_scan_chunks(unsigned int* __restrict__ sums, const unsigned int* __restrict__ aux_sums, int nchunks,
+                                                     unsigned int* __restrict__ total_out, unsigned int* __restrict__ aux_total_out) {
+  __shared__ unsigned int sh[4];
+  unsigned int carry = 0, aux = 0;
+  for (int base = 0; base < nchunks; base += kPB) {
+    const int i = base + threadIdx.x;
+    const unsigned int v = i < nchunks ? sums[i] : 0u;
+    aux += i < nchunks ? aux_sums[i] : 0u;
+    unsigned int tot;
+    const unsigned int ex = block_excl_scan256(v, &tot, sh);
+    if (i < nchunks) sums[i] = carry + ex;
+    carry += tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *total_out = carry_s;
+  unsigned int auxtot;
+  block_excl_scan256(aux, &auxtot, sh);
+  if (threadIdx.x == 0) { *total_out = carry; *aux_total_out = auxtot; }
+}
+
+__global__ __launch_bounds__(kPB) void k_chunk_scan(const unsigned int* __restrict__ in, int n, const unsigned int* __restrict__ chunk_base,
+                                                    unsigned int* __restrict__ out) {
+  __shared__ unsigned int sh[4];
+  const int base = blockIdx.x * kChunk + threadIdx.x * (kChunk / kPB);  // 16 consecutive words per thread
+  unsigned int v[kChunk / kPB], s = 0;
+#pragma unroll
+  for (int k = 0; k < kChunk / kPB; k++) {
+    v[k] = (base + k) < n ? in[base + k] : 0u;
+    s += v[k];
+  }
+  unsigned int tot;
+  unsigned int run = chunk_base[blockIdx.x] + block_excl_scan256(s, &tot, sh);
+#pragma unroll
+  for (int k = 0; k < kChunk / kPB; k++) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
 }
 
 __device__ inline unsigned int rank_of(const unsigned long long* __restrict__ mask, const unsigned int* __restrict__ base, long long i) {
@@ -357,35 +403,51 @@ __global__ __launch_bounds__(kPB) void k_tet_vertices(Grid G, const unsigned lon
   xyz[o + 2] = G.lo[2] + G.cellsize * (float)iz;
 }
 
-// TetMeshElements (Tetrahedralizer.cl:67-132): 6 tets per included cell, corners LBN,LBF,LTN,LTF,RBN,RBF,RTN,RTF = 0..7
+// TetMeshElements (Tetrahedralizer.cl:67-132): 6 tets per included cell, corners LBN,LBF,LTN,LTF,RBN,RBF,RTN,RTF = 0..7.
+// A wavefront covers exactly one 64-cell word of the included mask, so its output is the contiguous range
+// [6*cbase[word], 6*(cbase[word]+popc)) of uint4 records: lanes stage their 6 records in LDS at their rank inside the
+// word and the wave then streams the range out with lane-contiguous 16-byte stores.
 __global__ __launch_bounds__(kPB) void k_tet_elements(Grid G, const unsigned long long* __restrict__ cinc,
                                                       const unsigned int* __restrict__ cbase, const unsigned long long* __restrict__ vinc,
                                                       const unsigned int* __restrict__ vbase, uint4* __restrict__ tets) {
+  __shared__ uint4 stage[kPB / 64][64 * 6];
   const long long cid = (long long)blockIdx.x * kPB + threadIdx.x;
-  if (cid >= G.n_cells || !bit_at(cinc, cid)) return;
-  const int cxy = G.c[0] * G.c[1];
-  const int z = (int)(cid / cxy);
-  const int rem = (int)(cid - (long long)z * cxy);
-  const int y = rem / G.c[0], x = rem - y * G.c[0];
-  const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
-  const long long p = z * gxy + y * gx + x;
-  unsigned int c[8];
-  c[0] = rank_of(vinc, vbase, p);
-  c[1] = rank_of(vinc, vbase, p + gxy);
-  c[2] = rank_of(vinc, vbase, p + gx);
-  c[3] = rank_of(vinc, vbase, p + gx + gxy);
-  c[4] = rank_of(vinc, vbase, p + 1);
-  c[5] = rank_of(vinc, vbase, p + 1 + gxy);
-  c[6] = rank_of(vinc, vbase, p + 1 + gx);
-  c[7] = rank_of(vinc, vbase, p + 1 + gx + gxy);
-  enum { LBN, LBF, LTN, LTF, RBN, RBF, RTN, RTF };
-  uint4* o = tets + 6 * (size_t)rank_of(cinc, cbase, cid);
-  o[0] = make_uint4(c[LBN], c[LTN], c[RBN], c[LBF]);
-  o[1] = make_uint4(c[RTN], c[LTN], c[LBF], c[RBN]);
-  o[2] = make_uint4(c[RTN], c[LTN], c[LTF], c[LBF]);
-  o[3] = make_uint4(c[RTN], c[RBN], c[LBF], c[RBF]);
-  o[4] = make_uint4(c[RTN], c[LBF], c[LTF], c[RBF]);
-  o[5] = make_uint4(c[RTN], c[LTF], c[RTF], c[RBF]);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long word = cid >> 6;
+  if (word >= ((G.n_cells + 63) >> 6)) return;  // wave-uniform
+  const unsigned long long mask = cinc[word];
+  if (mask == 0ULL) return;                     // wave-uniform
+  const bool inc = (mask >> lane) & 1ULL;
+  if (inc) {
+    const int cxy = G.c[0] * G.c[1];
+    const int z = (int)(cid / cxy);
+    const int rem = (int)(cid - (long long)z * cxy);
+    const int y = rem / G.c[0], x = rem - y * G.c[0];
+    const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
+    const long long p = z * gxy + y * gx + x;
+    unsigned int c[8];
+    c[0] = rank_of(vinc, vbase, p);
+    c[1] = rank_of(vinc, vbase, p + gxy);
+    c[2] = rank_of(vinc, vbase, p + gx);
+    c[3] = rank_of(vinc, vbase, p + gx + gxy);
+    c[4] = rank_of(vinc, vbase, p + 1);
+    c[5] = rank_of(vinc, vbase, p + 1 + gxy);
+    c[6] = rank_of(vinc, vbase, p + 1 + gx);
+    c[7] = rank_of(vinc, vbase, p + 1 + gx + gxy);
+    enum { LBN, LBF, LTN, LTF, RBN, RBF, RTN, RTF };
+    uint4* o = &stage[wv][6 * __popcll(mask & ((1ULL << lane) - 1ULL))];
+    o[0] = make_uint4(c[LBN], c[LTN], c[RBN], c[LBF]);
+    o[1] = make_uint4(c[RTN], c[LTN], c[LBF], c[RBN]);
+    o[2] = make_uint4(c[RTN], c[LTN], c[LTF], c[LBF]);
+    o[3] = make_uint4(c[RTN], c[RBN], c[LBF], c[RBF]);
+    o[4] = make_uint4(c[RTN], c[LBF], c[LTF], c[RBF]);
+    o[5] = make_uint4(c[RTN], c[LTF], c[RTF], c[RBF]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int total = 6 * __popcll(mask);
+  uint4* out = tets + 6 * (size_t)cbase[word];
+  for (int i = lane; i < total; i += 64) out[i] = stage[wv][i];
 }
 
 }  // namespace
@@ -404,7 +466,8 @@ struct fb_poly_s {
   DevBuf<float4> grid;
   DevBuf<unsigned long long> inside, cinc, vinc;
   DevBuf<unsigned char> config, flags;
-  DevBuf<unsigned int> cinc_pop, vinc_pop, cbase, vbase, totals;  // totals: [0] crossed edges [1] surface cells [2] incl cells [3] verts
+  DevBuf<unsigned int> cinc_pop, vinc_pop, surf_pop, edge_pop, cbase, vbase, csum, vsum, csum_aux, vsum_aux;
+  DevBuf<unsigned int> totals;  // [0] crossed edges [1] surface cells [2] included cells [3] tet vertices
   DevBuf<float> tv;
   DevBuf<uint4> tt;
   fb_poly_counts counts;
@@ -503,6 +566,14 @@ int set_grid(fb_poly_s* h, const float lo[3], float cellsize, const int dims[3])
   FB_TRY(h->vbase.alloc(pw));
   FB_TRY(h->cinc_pop.alloc(cw));
   FB_TRY(h->cbase.alloc(cw));
+  FB_TRY(h->surf_pop.alloc(cw));
+  FB_TRY(h->edge_pop.alloc(pw));
+  const size_t pch = (pw + kChunk - 1) / kChunk, cch = (cw + kChunk - 1) / kChunk;
+  if (pch > 16 * kPB) return fail(FB_EINVAL, "grid too large for the chunked scan");
+  FB_TRY(h->vsum.alloc(pch));
+  FB_TRY(h->vsum_aux.alloc(pch));
+  FB_TRY(h->csum.alloc(cch));
+  FB_TRY(h->csum_aux.alloc(cch));
   FB_TRY(h->config.alloc((size_t)G.n_cells));
   FB_TRY(h->flags.alloc((size_t)G.n_points));
   FB_TRY(h->totals.alloc(4));
@@ -514,13 +585,18 @@ int do_classify(fb_poly_s* h) {
   const Grid& G = h->G;
   FB_TRY(h->totals.zero(h->stream));
   const int cb = (int)((G.n_cells + kPB - 1) / kPB), pb = (int)((G.n_points + kPB - 1) / kPB);
-  hipLaunchKernelGGL(k_cells, dim3(cb), dim3(kPB), 0, h->stream, G, h->inside.p, h->config.p, h->cinc.p, h->cinc_pop.p, h->totals.p);
+  hipLaunchKernelGGL(k_cells, dim3(cb), dim3(kPB), 0, h->stream, G, h->inside.p, h->config.p, h->cinc.p, h->cinc_pop.p, h->surf_pop.p);
   FB_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_points, dim3(pb), dim3(kPB), 0, h->stream, G, h->inside.p, h->cinc.p, h->flags.p, h->vinc.p, h->vinc_pop.p, h->totals.p);
+  hipLaunchKernelGGL(k_points, dim3(pb), dim3(kPB), 0, h->stream, G, h->inside.p, h->cinc.p, h->flags.p, h->vinc.p, h->vinc_pop.p, h->edge_pop.p);
   FB_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_scan_words, dim3(1), dim3(1024), 0, h->stream, h->cinc_pop.p, h->cbase.p, (int)h->cinc_pop.n, h->totals.p + 2);
-  FB_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_scan_words, dim3(1), dim3(1024), 0, h->stream, h->vinc_pop.p, h->vbase.p, (int)h->vinc_pop.n, h->totals.p + 3);
+  const int cw = (int)h->cinc_pop.n, pw = (int)h->vinc_pop.n;
+  const int cch = (int)h->csum.n, pch = (int)h->vsum.n;
+  hipLaunchKernelGGL(k_chunk_sums, dim3(cch), dim3(kPB), 0, h->stream, h->cinc_pop.p, h->surf_pop.p, cw, h->csum.p, h->csum_aux.p);
+  hipLaunchKernelGGL(k_chunk_sums, dim3(pch), dim3(kPB), 0, h->stream, h->vinc_pop.p, h->edge_pop.p, pw, h->vsum.p, h->vsum_aux.p);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kPB), 0, h->stream, h->csum.p, h->csum_aux.p, cch, h->totals.p + 2, h->totals.p + 1);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kPB), 0, h->stream, h->vsum.p, h->vsum_aux.p, pch, h->totals.p + 3, h->totals.p + 0);
+  hipLaunchKernelGGL(k_chunk_scan, dim3(cch), dim3(kPB), 0, h->stream, h->cinc_pop.p, cw, h->csum.p, h->cbase.p);
+  hipLaunchKernelGGL(k_chunk_scan, dim3(pch), dim3(kPB), 0, h->stream, h->vinc_pop.p, pw, h->vsum.p, h->vbase.p);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }

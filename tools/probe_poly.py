@@ -1,0 +1,14 @@
+"""Quick performance probe of the field path on the 256^3 sphere grid (development aid)."""
+import sys
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from fembrain_amd.poly import GpuPoly, sphere_blob
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+p = GpuPoly(sphere_blob())
+dims = p.sweep_grid((-0.5, -0.5, -0.5), 1.0 / (n - 2), (n, n, n))
+c = p.classify()
+p.tetrahedralize()
+s, t = p.time_pipeline(5)
+npts = n ** 3
+print("grid %d^3: sweep %.1f us (%.0f GB/s), pipeline %.1f us -> %.0f Mvoxels/s; tets %d verts %d" %
+      (n, s * 1e6, npts * 16 / s / 1e9, t * 1e6, npts / t / 1e6, c.n_included_cells * 6, p.counts.n_tet_vertices))
