@@ -1,0 +1,91 @@
+"""Generates the FEM golden vectors under tests/golden/ by running the REFERENCE's own translation units
+(oracle/_ref/libfem_ref.so = VegaFEM from /root/reference compiled where it lies, driven by oracle/ref_harness.cpp).
+Run here once (`python tests/golden/make_fem_golden.py`); the .npz files are committed, the reference is not needed
+at test time.
+
+  fem_cube5.npz   truth cube 5^3 (125 nodes / 384 tets, plane i=0 clamped): per-element K0 / M^-1, stiffness pattern,
+                  assembled f and K at a seeded displacement, Keff / rhs / PCG solution of one step from a seeded
+                  state, q and qvel after 3 steps under the reference load (-10000/y-DOF) and a gentle one (-10)
+  fem_beam3.npz   data/models/beam3/beam3_tet.veg (208 nodes / 450 tets, Vega's own sample) with beam3.bou clamps:
+                  mesh, the reference's consistent mass matrix file beam3_tet.mass (a known answer shipped by the
+                  reference), and q after 3 steps with -10 per y-DOF
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, read_veg, truth_cube
+from oracle.pyoracle import RefFem
+
+REF = "/root/reference/data/models"
+
+
+def steps(v, t, fixed, load, n=3, eps=1e-6):
+    r = RefFem(v, t)
+    r.integrator(fixed)
+    f = np.zeros(r.r)
+    f[1::3] = load
+    qs, vs, its = [], [], []
+    for _ in range(n):
+        r.set_external_forces(f)
+        its.append(r.step(cg_eps=eps))
+        q, qv = r.get_state()
+        qs.append(q)
+        vs.append(qv)
+    return np.array(qs), np.array(vs), np.array(its)
+
+
+def cube5():
+    n = 5
+    v, t = truth_cube(n, n, n, 0.1)
+    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    r = RefFem(v, t)
+    els = np.array([0, 1, 2, 3, 4, 5, 100, 383])
+    K0 = np.array([r.K0(int(e)) for e in els])
+    Mi = np.array([r.Minv(int(e)) for e in els])
+    ia, ja = r.csr()
+    mia, mja, ma = r.mass_csr()
+    rng = np.random.default_rng(12345)
+    u = rng.normal(size=r.r) * 0.01
+    f, K = r.assemble(u)
+    r.integrator(fixed)
+    q0 = rng.normal(size=r.r) * 0.004
+    v0 = rng.normal(size=r.r) * 0.1
+    q0[fixed] = 0
+    v0[fixed] = 0
+    fext = np.zeros(r.r)
+    fext[1::3] = -10.0
+    r.set_state(q0, v0)
+    r.set_external_forces(fext)
+    info, keff, rhs, dv = r.step(cg_eps=1e-12, cg_maxiter=20000, want=True)
+    q1, v1 = r.get_state()
+    qa, va, ia_ = steps(v, t, fixed, -10000.0)
+    qb, vb, ib_ = steps(v, t, fixed, -10.0)
+    np.savez_compressed(os.path.join(HERE, "fem_cube5.npz"), n=n, fixed=fixed, els=els, K0=K0, Minv=Mi, ia=ia, ja=ja,
+                        mass_ia=mia, mass_ja=mja, mass_a=ma, u=u, f=f, K=K, q0=q0, v0=v0, keff=keff, rhs=rhs, dv=dv, cg_info=info,
+                        q1=q1, v1=v1, q_ref_load=qa, v_ref_load=va, it_ref_load=ia_, q_gentle=qb, v_gentle=vb, it_gentle=ib_)
+    print("cube5: nnz", len(ja), "cg", info, "iters", ia_, ib_)
+
+
+def beam3():
+    v, t = read_veg(os.path.join(REF, "beam3", "beam3_tet.veg"))
+    bou = [int(x) for x in open(os.path.join(REF, "beam3", "beam3.bou")).read().replace("\n", "").split(",") if x.strip()]
+    fixed_vertices = np.array(sorted(b - 1 for b in bou), np.int32)  # .bou is 1-indexed
+    fixed = fixed_vertices_to_dofs(fixed_vertices)
+    rows = []
+    with open(os.path.join(REF, "beam3", "beam3_tet.mass")) as fh:
+        toks = fh.read().split()
+    nr, nc = int(toks[0]), int(toks[1])
+    tri = np.array(toks[2:], dtype=np.float64).reshape(-1, 3)
+    q, qv, its = steps(v, t, fixed, -10.0, n=3)
+    np.savez_compressed(os.path.join(HERE, "fem_beam3.npz"), verts=v, tets=t, fixed_vertices=fixed_vertices, mass_n=nr,
+                        mass_i=tri[:, 0].astype(np.int32), mass_j=tri[:, 1].astype(np.int32), mass_v=tri[:, 2], q=q, qvel=qv, iters=its)
+    print("beam3:", v.shape, t.shape, "fixed", fixed_vertices, "iters", its, "mass entries", len(tri))
+
+
+if __name__ == "__main__":
+    cube5()
+    beam3()

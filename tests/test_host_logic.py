@@ -1,0 +1,181 @@
+"""CPU: host-side logic of the product -- the C-ABI library loads and exports every symbol the headers declare,
+the per-rank plan (pattern, SELL-64 layout, contribution lists, halo/send lists), mesh generators and readers."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from fembrain_amd import lib as fl
+from fembrain_amd.blobtree import read_blob, sphere_blob
+from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, read_veg, truth_cube
+from oracle.pyoracle import OrcFem
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(fl.LIB_PATH)
+    names = set()
+    for hdr in ("fembrain_hip.h", "fembrain_hip_testing.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(fb_[a-z0-9_]+)\s*\(", text))
+    assert len(names) >= 50
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+    fl.lib()  # binds argument types for all of them
+
+
+def test_no_device_is_reported_not_faked():
+    L = fl.lib()
+    if L.fb_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from fembrain_amd.fem import FemIntegrator
+    v, t = truth_cube(3, 3, 3)
+    with pytest.raises(fl.FbError) as ei:
+        FemIntegrator(v, t, [])
+    assert ei.value.code == fl.FB_EDEVICE  # the product path fails loudly, there is no CPU fallback
+
+
+def test_truth_cube_matches_reference_layout():
+    v, t = truth_cube(3, 4, 5, 0.1)
+    assert v.shape == (60, 3) and t.shape == (6 * 2 * 3 * 4, 4)
+    assert np.allclose(v[0], [-0.15, 0, -0.25]) and np.allclose(v[1] - v[0], [0, 0, 0.1])  # k fastest
+    # first cell: LBN=0, LBF=1 (k+1), LTN=nz (j+1), RBN=ny*nz (i+1)
+    assert t[0].tolist() == [0, 5, 20, 1] and t[1].tolist() == [25, 5, 1, 20]
+    vol = np.abs(np.einsum("ij,ij->i", v[t[:, 0]] - v[t[:, 3]], np.cross(v[t[:, 1]] - v[t[:, 3]], v[t[:, 2]] - v[t[:, 3]]))) / 6
+    assert np.allclose(vol.sum(), 0.2 * 0.3 * 0.4)
+    assert fixed_vertices_to_dofs([2, 0]).tolist() == [0, 1, 2, 6, 7, 8]
+
+
+def _plan(v, t, fixed, n_ranks=1, rank=0, splits=None):
+    L = fl.lib()
+    h = C.c_void_p()
+    sp = None if splits is None else np.asarray(splits, np.int32)
+    tt = np.ascontiguousarray(t, np.int32).reshape(-1)
+    fd = np.ascontiguousarray(fixed, np.int32)
+    fl.check(L.fb_plan_create(C.byref(h), len(v), len(t), fl.iptr(tt), len(fd), fl.iptr(fd), n_ranks, rank, fl.iptr(sp)))
+    info = np.zeros(12, np.int32)
+    L.fb_plan_info(h, fl.iptr(info))
+
+    def get(name):
+        cnt = L.fb_plan_get(h, name.encode(), None, 0)
+        assert cnt >= 0
+        a = np.zeros(cnt, np.int32)
+        assert L.fb_plan_get(h, name.encode(), fl.iptr(a), cnt) == cnt
+        return a
+    keys = ["n_owned", "n_halo", "n_tets", "n_blocks", "n_slices", "n_slots", "n_crows", "n_send", "node_lo", "node_hi", "n_fixed_owned", "n_ranks"]
+    return dict(zip(keys, info.tolist())), get, (L, h)
+
+
+def test_plan_pattern_and_contributions_match_oracle():
+    n = 6
+    v, t = truth_cube(n, n, n)
+    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    info, get, (L, h) = _plan(v, t, fixed)
+    o = OrcFem(v, t)
+    obptr, obcol = o.blocks()
+    assert np.array_equal(get("bptr"), obptr) and np.array_equal(get("bcol"), obcol)
+    assert info["n_fixed_owned"] == len(fixed) and info["n_halo"] == 0 and info["n_tets"] == len(t)
+    # SELL layout reproduces the CSR pattern
+    so, colidx, blk_slot, bptr, bcol = get("slice_off"), get("colidx"), get("blk_slot"), get("bptr"), get("bcol")
+    for a in (0, 1, 63, 64, 100, len(v) - 1):
+        for k, p in enumerate(range(bptr[a], bptr[a + 1])):
+            assert blk_slot[p] == so[a // 64] + k and colidx[blk_slot[p] * 64 + a % 64] == bcol[p]
+    # every (tet, i, j) appears exactly once, in the list of block (tet[i], tet[j]), in ascending element order
+    contrib = get("contrib").view(np.uint32)
+    coff, ccnt = get("slot_coff"), get("slot_ccnt")
+    valid = contrib[contrib != 0xFFFFFFFF]
+    assert len(valid) == 16 * len(t) and len(np.unique(valid)) == len(valid)
+    for a in (0, 70, 129):
+        for k, p in enumerate(range(bptr[a], bptr[a + 1])):
+            slot = blk_slot[p]
+            lst = [int(contrib[(coff[slot] + r) * 64 + a % 64]) for r in range(ccnt[slot])]
+            lst = [c for c in lst if c != 0xFFFFFFFF]
+            assert lst == sorted(lst) and lst
+            for c in lst:
+                e, i, j = c >> 4, (c >> 2) & 3, c & 3
+                assert t[e][i] == a and t[e][j] == bcol[p]
+    L.fb_plan_destroy(h)
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_sharded_plans_cover_the_mesh_consistently(n_ranks):
+    n = 7
+    v, t = truth_cube(n, n, n)
+    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    planes = [n * r // n_ranks for r in range(n_ranks + 1)]
+    splits = [p * n * n for p in planes]
+    plans = [_plan(v, t, fixed, n_ranks, r, splits) for r in range(n_ranks)]
+    o = OrcFem(v, t)
+    obptr, obcol = o.blocks()
+    owned_total, fixed_total = 0, 0
+    for r, (info, get, _) in enumerate(plans):
+        l2g = get("local2global")
+        lo, hi = splits[r], splits[r + 1]
+        assert info["node_lo"] == lo and info["node_hi"] == hi and np.array_equal(l2g[:hi - lo], np.arange(lo, hi))
+        owned_total += info["n_owned"]
+        fixed_total += info["n_fixed_owned"]
+        # owned rows carry exactly the global pattern (columns translated back to global ids)
+        bptr, bcol = get("bptr"), get("bcol")
+        for a in (0, info["n_owned"] // 2, info["n_owned"] - 1):
+            assert np.array_equal(l2g[bcol[bptr[a]:bptr[a + 1]]], obcol[obptr[lo + a]:obptr[lo + a + 1]])
+        # halo = exactly the non-owned columns, sorted, grouped by owner; send lists mirror the neighbours' halos
+        halo = l2g[hi - lo:]
+        assert np.array_equal(halo, np.unique(halo)) and not ((halo >= lo) & (halo < hi)).any()
+        cols = np.unique(l2g[bcol])
+        assert np.array_equal(np.sort(np.concatenate([halo, np.arange(lo, hi)])), np.union1d(cols, np.arange(lo, hi)))
+        hoff = get("halo_off")
+        for q in range(n_ranks):
+            seg = halo[hoff[q]:hoff[q + 1]]
+            assert ((seg >= splits[q]) & (seg < splits[q + 1])).all()
+            if q != r:
+                qinfo, qget, _ = plans[q]
+                soff, sloc = qget("send_off"), qget("send_local")
+                sent = splits[q] + sloc[soff[r]:soff[r + 1]]  # what q packs for r, as global ids
+                assert np.array_equal(sent, seg)
+    assert owned_total == len(v) and fixed_total == len(fixed)
+    for _, _, (L, h) in plans:
+        L.fb_plan_destroy(h)
+
+
+def test_plan_rejects_bad_input():
+    v, t = truth_cube(3, 3, 3)
+    L = fl.lib()
+    h = C.c_void_p()
+    tt = np.ascontiguousarray(t, np.int32).reshape(-1)
+    bad = np.array([5, 3], np.int32)
+    assert L.fb_plan_create(C.byref(h), len(v), len(t), fl.iptr(tt), 2, fl.iptr(bad), 1, 0, None) == fl.FB_EINVAL
+    assert b"ascending" in L.fb_last_error()
+    tt2 = tt.copy()
+    tt2[7] = 999
+    assert L.fb_plan_create(C.byref(h), len(v), len(t), fl.iptr(tt2), 0, None, 1, 0, None) == fl.FB_EINVAL
+    assert L.fb_plan_create(C.byref(h), len(v), len(t), fl.iptr(tt), 0, None, 2, 2, None) == fl.FB_EINVAL
+
+
+def test_blob_reader_and_veg_reader():
+    b = read_blob(os.path.join(GOLD, "blob", "sphere.blob"))
+    s = sphere_blob()
+    assert np.array_equal(b.header, s.header) and b.n_ops == 0 and b.n_prims == 1
+    t = read_blob(os.path.join(GOLD, "blob", "tumor.blob"))
+    assert (t.n_prims, t.n_ops, len(t.mtx)) == (10, 1, 11)
+    assert int(t.ops[0, 0]) == 4 and int(t.ops[0, 7]) & 4  # BLEND over a primitive range
+    assert (t.header[0:3] < t.header[4:7]).all()
+    c = read_blob(os.path.join(GOLD, "blob", "complex.blob"))
+    assert (c.n_prims, c.n_ops) == (12, 11)
+    # every operator is referenced once (the reference's CheckForBlobTreeErrors rule)
+    refs = []
+    for o in c.ops:
+        fl_ = int(o[7])
+        if fl_ & 4:
+            continue
+        if fl_ & 2:
+            refs.append(int(o[1]))
+        if fl_ & 1:
+            refs.append(int(o[2]))
+    assert sorted(refs) == list(range(1, c.n_ops))
+    g = np.load(os.path.join(GOLD, "fem_beam3.npz"))
+    assert g["verts"].shape == (208, 3) and g["tets"].max() == 207 and g["tets"].min() == 0

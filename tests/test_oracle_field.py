@@ -1,0 +1,72 @@
+"""CPU: the field / tetrahedralizer restatement (oracle/field_oracle.c) against the reference's golden sphere mesh
+(data/models/sphere/implicit_sphere.veg via tests/golden/sphere_tets_c0.1.npz) and analytic field values."""
+import os
+
+import numpy as np
+
+from fembrain_amd.blobtree import make_tree, read_blob, sphere_blob
+from oracle.pyfield import OrcPoly
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_sphere_golden_cells_pattern_positions():
+    g = np.load(os.path.join(GOLD, "sphere_tets_c0.1.npz"))
+    o = OrcPoly(sphere_blob())
+    assert o.grid_dims(0.1) == (12, 12, 12)
+    xyz, tets, counts = o.run_tetrahedralizer(0.1)
+    assert counts["n_included_cells"] == 624 and len(tets) == 3744
+    inc = np.nonzero(o.inc_cells)[0]
+    ijk = np.stack([inc % 11, (inc // 11) % 11, inc // 121], 1)
+    assert np.array_equal(ijk, g["cell_ijk"])  # same cells, same (linear) order as the reference file
+    # the 6-tet corner pattern: corner k of a cell = 4*dx + 2*dy + dz
+    cell0 = tets[:6]
+    lo = xyz[cell0[0, 0]]
+    corner_of = {}
+    for vid in np.unique(cell0):
+        d = np.rint((xyz[vid] - lo) / 0.1).astype(int)
+        corner_of[int(vid)] = 4 * d[0] + 2 * d[1] + d[2]
+    assert [[corner_of[int(x)] for x in row] for row in cell0] == g["pattern"].tolist()
+    assert np.abs(xyz[cell0[0]] - g["first_cell_xyz"][g["pattern"][0]]).max() < 1e-6
+
+
+def test_wyvill_known_answers():
+    o = OrcPoly(sphere_blob())
+    pts = np.array([[0.25, 0, 0, 0], [0, 0, 0, 0], [1.0, 0, 0, 0], [0.3, 0.4, 0, 0], [2, 2, 2, 0]], np.float32)
+    f = o.field_array(pts)[:, 3]
+    assert f[0] == np.float32((1 - 0.0625) ** 3) == np.float32(0.823974609)
+    assert f[1] == 1.0 and f[2] == 0.0 and f[4] == 0.0
+    assert abs(f[3] - (1 - 0.25) ** 3) < 1e-6
+
+
+def test_operator_semantics():
+    pts = [(0, (0.0, 0, 0), (0, 0, 0), (0, 0, 0)), (0, (0.6, 0, 0), (0, 0, 0), (0, 0, 0)), (0, (0, 0.6, 0), (0, 0, 0), (0, 0, 0))]
+    q = np.array([[0.3, 0.1, 0, 0]], np.float32)
+    single = [OrcPoly(make_tree([p])).field_array(q)[0, 3] for p in pts]
+    assert OrcPoly(make_tree(pts[:2], [(0, 0, 1, 0, 0, 0)])).field_array(q)[0, 3] == max(single[0], single[1])
+    assert OrcPoly(make_tree(pts[:2], [(1, 0, 1, 0, 0, 0)])).field_array(q)[0, 3] == min(single[0], single[1])
+    assert OrcPoly(make_tree(pts[:2], [(4, 0, 1, 0, 0, 0)])).field_array(q)[0, 3] == single[0] + single[1]
+    assert OrcPoly(make_tree(pts[:2], [(2, 0, 1, 0, 0, 0)])).field_array(q)[0, 3] == min(single[0], np.float32(1) - single[1])
+    # a range operator sums its primitives whatever its type (reference CPU path, Polygonizer.cpp:1968-1983)
+    assert OrcPoly(make_tree(pts, [(0, 0, 2, 4, 0, 0)])).field_array(q)[0, 3] == (single[0] + single[1]) + single[2]
+    # no operators: blend of everything
+    assert OrcPoly(make_tree(pts)).field_array(q)[0, 3] == (single[0] + single[1]) + single[2]
+
+
+def test_classification_definitions_on_a_blob_file():
+    o = OrcPoly(read_blob(os.path.join(GOLD, "blob", "peanut.blob")))
+    o.sweep(0.2)
+    c = o.classify()
+    g = o.g
+    f = o.xyzf[:, 3].reshape(g[2], g[1], g[0])
+    ins = f >= 0.5
+    nx = (ins[:, :, :-1] ^ ins[:, :, 1:]).sum() + (ins[:, :-1, :] ^ ins[:, 1:, :]).sum() + (ins[:-1] ^ ins[1:]).sum()
+    assert c["n_crossed_edges"] == nx
+    cells = np.zeros((g[2] - 1, g[1] - 1, g[0] - 1), int)
+    for k in range(8):
+        dx, dy, dz = (k >> 2) & 1, (k >> 1) & 1, k & 1
+        cells += ins[dz:g[2] - 1 + dz, dy:g[1] - 1 + dy, dx:g[0] - 1 + dx].astype(int) << k
+    assert np.array_equal(cells.reshape(-1), o.config)
+    assert c["n_included_cells"] == (cells != 0).sum()
+    xyz, tets = o.tetrahedralize()
+    assert len(tets) == 6 * c["n_included_cells"] and tets.max() == len(xyz) - 1
