@@ -74,7 +74,7 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
   FB_TRY(h->vals.zero(s));
   FB_TRY(h->mblk.alloc((size_t)P.n_slots * 64));
   FB_TRY(h->mblk.zero(s));
-  const size_t nv = (size_t)3 * P.n_local;
+  const size_t nv = (size_t)3 * P.n_local + 2;  // spare doubles: the vector kernels walk owned rows in 16-byte pairs
   DevBuf<double>* vecs[] = {&h->q, &h->qvel, &h->fext, &h->fint, &h->rhs, &h->x, &h->r, &h->d, &h->Ad, &h->invdiag, &h->tmp};
   for (auto* v : vecs) {
     FB_TRY(v->alloc(nv));
@@ -83,7 +83,7 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
   const int chunk = ceil_div(P.n_slices, 8);
   const int per = std::max(1, std::min(kMaxPartials / 8, ceil_div(chunk, kWavesPerBlock)));
   h->grid = 8 * per;
-  FB_TRY(h->part_a.alloc(kMaxPartials));
+  FB_TRY(h->part_a.alloc(3 * kMaxPartials));
   FB_TRY(h->part_b.alloc(kMaxPartials));
   FB_TRY(h->scal.alloc(4));
   FB_TRY(h->st.alloc(1));
@@ -176,21 +176,23 @@ int spmv(fb_fem_s* h, const double* x, double* y, const double* b, double* parti
 
 // multi-GPU: fold the per-block partials into one scalar and all-reduce it; returns the device scalar pointer
 // the consumer kernels should read, or nullptr (single GPU: consumers sum the partials themselves)
-__global__ __launch_bounds__(kBlock) void k_fold_partials(const double* partial, int n, double* out, const CGState* st) {
+__global__ __launch_bounds__(kBlock) void k_fold_partials(const double* partial, int n, int count, double* out, const CGState* st) {
   __shared__ double lds[4];
   if (st && st->done) return;
-  const double s = sum_partials(partial, n, lds);
-  if (threadIdx.x == 0) out[0] = s;
+  for (int c = 0; c < count; c++) {
+    const double s = sum_partials(partial + (size_t)c * n, n, lds);
+    if (threadIdx.x == 0) out[c] = s;
+  }
 }
 
-int global_scalar(fb_fem_s* h, const double* partial, double** out, bool check_done) {
+int global_scalar(fb_fem_s* h, const double* partial, double** out, bool check_done, int count = 1) {
   *out = nullptr;
   if (!h->comm || h->comm->n_ranks == 1) return FB_OK;
-  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(kBlock), 0, h->stream, partial, h->grid, h->scal.p, check_done ? h->st.p : nullptr);
+  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(kBlock), 0, h->stream, partial, h->grid, count, h->scal.p, check_done ? h->st.p : nullptr);
   FB_HIP(hipGetLastError());
-  // a converged solve leaves the previous (identical on every rank) value in place; the all-reduce still runs on
+  // a converged solve leaves the previous (identical on every rank) values in place; the all-reduce still runs on
   // every rank so the collective sequence stays matched, and its result is ignored by the done-checking consumers
-  FB_TRY(comm_allreduce_sum(h->comm, h->scal.p, 1, h->stream));
+  FB_TRY(comm_allreduce_sum(h->comm, h->scal.p, count, h->stream));
   *out = h->scal.p;
   return FB_OK;
 }
@@ -201,6 +203,15 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b) {
   const bool refresh = (it % 30 == 0);
   double* sc = nullptr;
   FB_TRY(halo_exchange(h, h->d.p));
+  if (!refresh && h->prm.pcg_variant == FB_PCG_MERGED) {
+    // merged-reduction iteration: SpMV with the three sums, then one fused vector pass (one reduction / all-reduce)
+    FB_TRY(spmv<3>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity));
+    FB_TRY(global_scalar(h, h->part_a.p, &sc, true, 3));
+    hipLaunchKernelGGL(k_cg_fused, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->grid,
+                       sc, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->d.p);
+    FB_HIP(hipGetLastError());
+    return FB_OK;
+  }
   FB_TRY(spmv<1>(h, h->d.p, h->Ad.p, nullptr, h->part_a.p, parity));
   FB_TRY(global_scalar(h, h->part_a.p, &sc, true));
   if (!refresh) {

@@ -292,6 +292,8 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
 //   MODE 0: y = A x                                    (plain)
 //   MODE 1: q = A d,  partial[b] = sum d.q             (PCG direction product, CGSolver.cpp:149-150)
 //   MODE 2: r = b - A x, partial[b] = sum r^2 invdiag   (exact residual every 30th iteration, CGSolver.cpp:161-171)
+//   MODE 3: q = A d with the three sums of the merged-reduction iteration: partial[b] = sum d.q,
+//           partial[G+b] = sum invdiag r q, partial[2G+b] = sum invdiag q^2 (bvec carries r)
 // ------------------------------------------------------------------------------------------------------
 template <typename MT, int MODE>
 __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restrict__ vals, const double* __restrict__ x,
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
                                                  CGState* __restrict__ st, int parity) {
   __shared__ double lds[4];
   if (MODE != 0 && st->done) return;
-  if (MODE == 1) {
+  if (MODE == 1 || MODE == 3) {
     // the while-condition of CGSolver.cpp:147, evaluated by every block from the same published scalars at the
     // head of each iteration; `done` is sticky so that every later launch of the batch is a no-op
     if (!(st->rho[parity] > st->eps2 * st->rho0) || st->iter >= st->max_iter) {
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
     }
   }
   const int lane = threadIdx.x & 63;
-  double acc = 0.0;
+  double acc = 0.0, acc1 = 0.0, acc2 = 0.0;
   for (SliceWalk w(sv.n_slices); w.valid(); w.next()) {
     const int s = w.s;
     const int row = s * 64 + lane;
@@ -334,6 +336,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
       } else if (MODE == 1) {
         y[d] = y0; y[d + 1] = y1; y[d + 2] = y2;
         acc += x[d] * y0 + x[d + 1] * y1 + x[d + 2] * y2;
+      } else if (MODE == 3) {
+        y[d] = y0; y[d + 1] = y1; y[d + 2] = y2;
+        acc += x[d] * y0 + x[d + 1] * y1 + x[d + 2] * y2;
+        const double i0 = invdiag[d], i1 = invdiag[d + 1], i2 = invdiag[d + 2];
+        acc1 += i0 * bvec[d] * y0 + i1 * bvec[d + 1] * y1 + i2 * bvec[d + 2] * y2;
+        acc2 += i0 * y0 * y0 + i1 * y1 * y1 + i2 * y2 * y2;
       } else {
         const double r0 = bvec[d] - y0, r1 = bvec[d + 1] - y1, r2 = bvec[d + 2] - y2;
         y[d] = r0; y[d + 1] = r1; y[d + 2] = r2;
@@ -345,6 +353,15 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
     const double tot = block_sum(acc, lds);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
   }
+  if (MODE == 3) {
+    const double t1 = block_sum(acc1, lds);
+    const double t2 = block_sum(acc2, lds);
+    if (threadIdx.x == 0) {
+      partial[gridDim.x + blockIdx.x] = t1;
+      partial[2 * gridDim.x + blockIdx.x] = t2;
+    }
+  }
+  (void)acc1; (void)acc2;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -441,6 +458,83 @@ __global__ __launch_bounds__(kBlock) void k_cg_direction(int n_slices, int n_own
     }
   }
   // single writer; rho[1-parity] and iter are read only by later launches (this launch reads done, rho[parity])
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->rho[1 - parity] = rho_new;
+    st->iter = st->iter + 1;
+  }
+}
+
+// Merged-reduction iteration, vector half: with S0 = d.q, S1 = sum invdiag r q, S2 = sum invdiag q^2 from the SpMV launch,
+//   alpha = rho / S0,   rho_new = sum invdiag (r - alpha q)^2 = rho - 2 alpha S1 + alpha^2 S2,   beta = rho_new / rho
+// so x, r and the next direction are updated in ONE pass with no second reduction (same iterates as CGSolver.cpp:149-182
+// up to rounding; the exact residual and its exactly summed rho are restored every 30th iteration by the reference path).
+// Flat element walk for the vector kernels: each XCD keeps the SAME contiguous slab of rows it owns in the SpMV
+// (chunk slices * 192 doubles), walked in 16-byte double2 pieces (192 doubles per slice keep every slab 16-B aligned).
+struct PairWalk {
+  size_t i, hi, stride;
+  __device__ PairWalk(int n_slices, int n_owned) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int chunk = (n_slices + 7) >> 3;
+    const size_t lo = (size_t)xcd * chunk * 96;  // in double2 units: 64 rows * 3 / 2
+    hi = min((size_t)(xcd + 1) * chunk * 96, ((size_t)3 * n_owned + 1) / 2);
+    i = lo + (size_t)j * kBlock + threadIdx.x;
+    stride = (size_t)per * kBlock;
+  }
+  __device__ bool valid() const { return i < hi; }
+  __device__ void next() { i += stride; }
+};
+
+__global__ __launch_bounds__(kBlock) void k_cg_fused(int n_slices, int n_owned, CGState* st, int parity,
+                                                     const double* __restrict__ part, int n_partial, const double* sc,
+                                                     const double* __restrict__ q, const double* __restrict__ invdiag,
+                                                     double* __restrict__ x, double* __restrict__ r, double* __restrict__ d) {
+  __shared__ double lds[12];
+  if (st->done) return;
+  const size_t n3 = 3 * (size_t)n_owned;  // an odd count ends in a half pair: loads stay in bounds (vectors carry 2 spare
+                                          // doubles, see upload_plan), only the owned component is stored
+  PairWalk w(n_slices, n_owned);
+  // first piece of own operands is requested before the scalar prologue so its latency overlaps the partial sums
+  double2 d0 = make_double2(0, 0), r0 = d0, q0 = d0, i0 = d0, x0 = d0;
+  const bool first = w.valid();
+  if (first) {
+    d0 = ((const double2*)d)[w.i]; r0 = ((const double2*)r)[w.i]; q0 = ((const double2*)q)[w.i];
+    i0 = ((const double2*)invdiag)[w.i]; x0 = ((const double2*)x)[w.i];
+  }
+  double s0, s1, s2;
+  if (sc) {
+    s0 = sc[0]; s1 = sc[1]; s2 = sc[2];
+  } else {
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int k = threadIdx.x; k < n_partial; k += kBlock) { a0 += part[k]; a1 += part[n_partial + k]; a2 += part[2 * n_partial + k]; }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { lds[wv] = a0; lds[4 + wv] = a1; lds[8 + wv] = a2; }
+    __syncthreads();
+    s0 = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    s1 = (lds[4] + lds[5]) + (lds[6] + lds[7]);
+    s2 = (lds[8] + lds[9]) + (lds[10] + lds[11]);
+  }
+  const double rho = st->rho[parity];
+  const double alpha = rho / s0;
+  const double rho_new = fmax(rho - 2.0 * alpha * s1 + alpha * alpha * s2, 0.0);
+  const double beta = rho_new / rho;
+  if (first) {
+    for (;;) {
+      double2 xn, rn, dn;
+      xn.x = x0.x + alpha * d0.x; xn.y = x0.y + alpha * d0.y;
+      rn.x = r0.x - alpha * q0.x; rn.y = r0.y - alpha * q0.y;
+      dn.x = i0.x * rn.x + beta * d0.x; dn.y = i0.y * rn.y + beta * d0.y;
+      if (2 * w.i + 1 < n3) {
+        ((double2*)x)[w.i] = xn; ((double2*)r)[w.i] = rn; ((double2*)d)[w.i] = dn;
+      } else {
+        x[2 * w.i] = xn.x; r[2 * w.i] = rn.x; d[2 * w.i] = dn.x;
+      }
+      w.next();
+      if (!w.valid()) break;
+      d0 = ((const double2*)d)[w.i]; r0 = ((const double2*)r)[w.i]; q0 = ((const double2*)q)[w.i];
+      i0 = ((const double2*)invdiag)[w.i]; x0 = ((const double2*)x)[w.i];
+    }
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->rho[1 - parity] = rho_new;
     st->iter = st->iter + 1;

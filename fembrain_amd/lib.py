@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libfembrain_hip.so")
 
 FB_OK, FB_EINVAL, FB_EDEVICE, FB_ENOMEM, FB_ESOLVER, FB_ECOMM = 0, -1, -2, -3, -4, -5
 FB_MATRIX_F32, FB_MATRIX_F64 = 0, 1
+FB_PCG_MERGED, FB_PCG_REFERENCE = 0, 1
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
@@ -31,7 +32,7 @@ class FemParams(C.Structure):
     _fields_ = [("E", C.c_double), ("nu", C.c_double), ("rho", C.c_double), ("timestep", C.c_double),
                 ("damping_mass", C.c_double), ("damping_stiffness", C.c_double), ("cg_eps", C.c_double),
                 ("cg_max_iter", C.c_int), ("matrix_precision", C.c_int), ("device", C.c_int),
-                ("reserved", C.c_int * 5)]
+                ("pcg_variant", C.c_int), ("reserved", C.c_int * 4)]
 
 
 class StepInfo(C.Structure):

@@ -25,6 +25,13 @@ extern "C" {
 #define FB_MATRIX_F32 0 /* default: north-star fp32 stiffness storage */
 #define FB_MATRIX_F64 1 /* reference-width storage, used by the tight parity tests */
 
+/* PCG formulation.  Both run the Jacobi-PCG of CGSolver.cpp:129-190 with the exact-residual refresh every 30th
+ * iteration.  REFERENCE performs its two reductions per iteration literally (d.q, then sum r^2/diag).  MERGED obtains
+ * rho_new = rho - 2 alpha S1 + alpha^2 S2 from sums taken in the SpMV launch, so an iteration is two kernels and one
+ * reduction (one RCCL all-reduce when sharded); iterates agree to rounding, checked by the parity tests. */
+#define FB_PCG_MERGED 0
+#define FB_PCG_REFERENCE 1
+
 const char* fb_last_error(void);
 int fb_device_count(void);
 /* name/arch of device `dev` into caller buffers (may be NULL) */
@@ -48,7 +55,8 @@ typedef struct fb_fem_params {
   int cg_max_iter;              /* PS_VolumeConservingIntegrator.cpp:197: 10000 */
   int matrix_precision;         /* FB_MATRIX_F32 / FB_MATRIX_F64 */
   int device;                   /* HIP device ordinal */
-  int reserved[5];
+  int pcg_variant;              /* FB_PCG_MERGED (default) / FB_PCG_REFERENCE */
+  int reserved[4];
 } fb_fem_params;
 
 /* fills the reference's defaults listed above */

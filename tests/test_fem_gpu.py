@@ -106,14 +106,22 @@ def test_system_spmv_pcg(gpu, prec, tol):
     x = rng.normal(size=o.r)
     y = g.spmv(x)
     assert np.abs(y - Kgs @ x).max() <= 1e-12 * np.abs(Kgs @ x).max()
-    # a8: PCG with a tight tolerance reproduces the oracle's solution
+    # a8: PCG with a tight tolerance reproduces the oracle's solution, in both formulations
     it, xg = g.pcg(rhs_g, eps=1e-12, max_iter=20000)
     assert it > 0
     assert np.abs(xg - dv).max() <= max(50 * tol, 1e-8) * np.abs(dv).max()
+    g2 = FemIntegrator(v, t, fixed, matrix_precision=prec, pcg_variant=fl.FB_PCG_REFERENCE)
+    g2.set_q_state(q0, v0)
+    g2.set_external_forces(fext)
+    g2.system()
+    it2, xg2 = g2.pcg(rhs_g, eps=1e-12, max_iter=20000)
+    assert abs(it2 - it) <= max(2, 0.02 * it)
+    assert np.abs(xg2 - xg).max() <= 1e-8 * np.abs(xg).max()
 
 
+@pytest.mark.parametrize("variant", [fl.FB_PCG_MERGED, fl.FB_PCG_REFERENCE])
 @pytest.mark.parametrize("prec", [fl.FB_MATRIX_F64, fl.FB_MATRIX_F32])
-def test_three_steps_reference_load(gpu, prec):
+def test_three_steps_reference_load(gpu, prec, variant):
     """q, qvel after 3 steps under the reference load (-10000 per y DOF, plane i=0 clamped, CG eps 1e-6).
 
     Stated tolerance: both solvers stop at a 1e-6 relative (Jacobi-weighted) residual, so the two converged
@@ -124,7 +132,7 @@ def test_three_steps_reference_load(gpu, prec):
     v, t, fixed = _cube(n)
     o = OrcFem(v, t)
     o.integrator(fixed)
-    g = FemIntegrator(v, t, fixed, matrix_precision=prec)
+    g = FemIntegrator(v, t, fixed, matrix_precision=prec, pcg_variant=variant)
     fext = np.zeros(o.r)
     fext[1::3] = -10000.0
     tol = 2e-5 if prec == fl.FB_MATRIX_F64 else 2e-4
