@@ -1,0 +1,242 @@
+// C++ adaptors with the reference's class surfaces over the C ABI (fembrain_hip.h).  Header-only; link with
+// -lfembrain_hip.  Scene-graph / GL members of the originals (SGMesh base, draw(), pickVertex, Bullet shapes) stay in
+// the host application: these classes carry the simulation state and the per-step hot path only.
+//
+//   PS::FEM::HipIntegrator  <-> VolumeConservingIntegrator / ImplicitNewmarkSparse / IntegratorBaseSparse
+//                               (reference src/deformable/PS_VolumeConservingIntegrator.h:15-37,
+//                                vegafem/integrator/integratorBase.h:107-205, integratorBaseSparse.h:45-84)
+//   PS::FEM::Deformable     <-> class Deformable (reference src/deformable/Deformable.h:63-235): same method names,
+//                               argument meaning and callback type; timestep() follows Deformable.cpp:318-420.
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../fembrain_hip.h"
+
+namespace PS {
+namespace FEM {
+
+typedef unsigned int U32;
+// same signature as the reference's FOnApplyDeformations (Deformable.h:46): borrowed pointer, dof = 3 * nodes
+typedef void (*FOnApplyDeformations)(U32 dof, double* displacements);
+
+struct vec3d {
+  double x, y, z;
+  vec3d(double x_ = 0, double y_ = 0, double z_ = 0) : x(x_), y(y_), z(z_) {}
+};
+
+class HipIntegrator {
+ public:
+  // constrainedDOFs: 0-indexed, ascending, copied (implicitNewmarkSparse.h:78-80)
+  HipIntegrator(int numVertices, const double* restPositions, int numElements, const int* elements, int numConstrainedDOFs,
+                const int* constrainedDOFs, double timestep = 0.0333, double dampingMassCoef = 0.0, double dampingStiffnessCoef = 0.01,
+                double E = 1e7, double nu = 0.46, double density = 1000.0, int device = 0)
+      : r_(3 * numVertices), h_(nullptr) {
+    fb_fem_default_params(&prm_);
+    prm_.E = E; prm_.nu = nu; prm_.rho = density;
+    prm_.timestep = timestep; prm_.damping_mass = dampingMassCoef; prm_.damping_stiffness = dampingStiffnessCoef;
+    prm_.device = device;
+    check(fb_fem_create(&h_, numVertices, restPositions, numElements, elements, numConstrainedDOFs, constrainedDOFs, &prm_));
+    std::memset(&info_, 0, sizeof info_);
+  }
+  ~HipIntegrator() { fb_fem_destroy(h_); }
+  HipIntegrator(const HipIntegrator&) = delete;
+  HipIntegrator& operator=(const HipIntegrator&) = delete;
+
+  int Getr() const { return r_; }
+  // 0 = ok, 1 = solver failed (the reference prints and exit(-1)s, PS_VolumeConservingIntegrator.cpp:203-209)
+  int DoTimestep() {
+    const int rc = fb_fem_step(h_, &info_);
+    if (rc == FB_ESOLVER) return 1;
+    check(rc);
+    return 0;
+  }
+  void SetExternalForces(double* f) { check(fb_fem_set_external_forces(h_, f)); }
+  void AddExternalForces(double* f) { check(fb_fem_add_external_forces(h_, f)); }
+  void SetExternalForcesToZero() { check(fb_fem_set_external_forces_zero(h_)); }
+  void SetUniformForce(int axis, double value) { check(fb_fem_set_uniform_force(h_, axis, value)); }
+  void SetqState(const double* q, const double* qvel = nullptr, const double* qaccel = nullptr) { check(fb_fem_set_state(h_, q, qvel, qaccel)); }
+  void GetqState(double* q, double* qvel = nullptr, double* qaccel = nullptr) { check(fb_fem_get_state(h_, q, qvel, qaccel)); }
+  int SetState(double* q, double* qvel = nullptr) { check(fb_fem_set_state(h_, q, qvel, nullptr)); return 0; }
+  void ResetToRest() { check(fb_fem_reset(h_)); }
+  void SetTimestep(double t) { prm_.timestep = t; check(fb_fem_set_timestep(h_, t)); }
+  double GetTimestep() const { return prm_.timestep; }
+  void SetDampingMassCoef(double c) { prm_.damping_mass = c; check(fb_fem_set_damping(h_, prm_.damping_mass, prm_.damping_stiffness)); }
+  void SetDampingStiffnessCoef(double c) { prm_.damping_stiffness = c; check(fb_fem_set_damping(h_, prm_.damping_mass, prm_.damping_stiffness)); }
+  bool setConstrainedDOF(int num, int* arr) {
+    if (num == 0 || arr == nullptr) return false;  // integratorBaseSparse.cpp:73-75
+    check(fb_fem_set_constrained_dofs(h_, num, arr));
+    return true;
+  }
+  double GetForceAssemblyTime() const { return info_.assembly_seconds; }
+  double GetSystemSolveTime() const { return info_.solve_seconds; }
+  int GetLastIterations() const { return info_.cg_iterations; }
+  int FloorCollision(double floorY, double restitution) {
+    int n = 0;
+    check(fb_fem_floor_collision(h_, floorY, restitution, &n));
+    return n;
+  }
+  void RebuildElements() { check(fb_fem_rebuild_elements(h_)); }
+  void Resync(int numVertices, const double* rest, int numElements, const int* elements, int nFixed, const int* fixed) {
+    check(fb_fem_resync(h_, numVertices, rest, numElements, elements, nFixed, fixed));
+    r_ = 3 * numVertices;
+  }
+  fb_fem_t handle() const { return h_; }
+
+ private:
+  static void check(int rc) {
+    if (rc != FB_OK) throw std::runtime_error(std::string("fembrain_hip: ") + fb_last_error());
+  }
+  int r_;
+  fb_fem_t h_;
+  fb_fem_params prm_;
+  fb_step_info info_;
+};
+
+class Deformable {
+ public:
+  Deformable(int numVertices, const double* restPositions, int numElements, const int* elements,
+             const std::vector<int>& vFixedVertices = std::vector<int>(), int device = 0)
+      : m_rest(restPositions, restPositions + 3 * (size_t)numVertices), m_elements(elements, elements + 4 * (size_t)numElements),
+        m_vFixedVertices(vFixedVertices), m_device(device) {
+    init();
+    syncForceModel();
+  }
+  ~Deformable() { delete m_lpIntegrator; }
+
+  // Deformable::timestep (Deformable.cpp:318-420)
+  void timestep() {
+    if (m_lpIntegrator == nullptr) return;
+    const bool applyGravity = m_bApplyGravity && (m_ctCollided == 0);
+    if (m_bHapticInProgress && !m_vHapticIndices.empty()) {
+      std::fill(m_arrExtForces.begin(), m_arrExtForces.end(), 0.0);
+      if (applyGravity)
+        for (U32 i = 1; i < m_dof; i += 3) m_arrExtForces[i] += -10000.0;
+      for (size_t i = 0; i < m_vHapticIndices.size(); i++) {
+        const int v = m_vHapticIndices[i];
+        m_arrExtForces[3 * v + 0] += m_vHapticForces[i].x;
+        m_arrExtForces[3 * v + 1] += m_vHapticForces[i].y;
+        m_arrExtForces[3 * v + 2] += m_vHapticForces[i].z;
+      }
+      m_lpIntegrator->SetExternalForces(m_arrExtForces.data());
+    } else if (applyGravity) {
+      m_lpIntegrator->SetUniformForce(1, -10000.0);
+    } else {
+      m_lpIntegrator->SetExternalForcesToZero();
+    }
+    m_lpIntegrator->DoTimestep();
+    if (m_hasFloor) m_ctCollided = (U32)m_lpIntegrator->FloorCollision(m_floorY, 0.4);
+    if (m_fOnDeform) {
+      m_lpIntegrator->GetqState(m_q.data(), m_qVel.data(), nullptr);
+      m_fOnDeform(m_dof, m_q.data());
+    }
+    m_ctTimeStep++;
+  }
+
+  // rebuild after a topology change (Deformable.cpp:127-220)
+  bool syncForceModel() {
+    const int n = (int)(m_rest.size() / 3), m = (int)(m_elements.size() / 4);
+    m_dof = 3 * n;
+    FixedVerticesToFixedDOF(m_vFixedVertices, m_vFixedDofs);
+    if (m_lpIntegrator) m_lpIntegrator->Resync(n, m_rest.data(), m, m_elements.data(), (int)m_vFixedDofs.size(), m_vFixedDofs.data());
+    else m_lpIntegrator = new HipIntegrator(n, m_rest.data(), m, m_elements.data(), (int)m_vFixedDofs.size(), m_vFixedDofs.data(),
+                                            m_timeStep, m_dampingMassCoeff, m_dampingStiffnessCoeff, 1e7, 0.46, 1000.0, m_device);
+    m_q.assign(m_dof, 0.0); m_qVel.assign(m_dof, 0.0); m_arrExtForces.assign(m_dof, 0.0);
+    return true;
+  }
+  void setMesh(int numVertices, const double* rest, int numElements, const int* elements) {
+    m_rest.assign(rest, rest + 3 * (size_t)numVertices);
+    m_elements.assign(elements, elements + 4 * (size_t)numElements);
+  }
+
+  // Deformable::FixedVerticesToFixedDOF (Deformable.cpp:294-314)
+  static int FixedVerticesToFixedDOF(std::vector<int>& arrInFixedVertices, std::vector<int>& arrOutFixedDOF) {
+    arrOutFixedDOF.clear();
+    if (arrInFixedVertices.empty()) return 0;
+    std::sort(arrInFixedVertices.begin(), arrInFixedVertices.end());
+    arrOutFixedDOF.resize(arrInFixedVertices.size() * 3);
+    for (size_t i = 0; i < arrInFixedVertices.size(); i++)
+      for (int k = 0; k < 3; k++) arrOutFixedDOF[3 * i + k] = arrInFixedVertices[i] * 3 + k;
+    return (int)arrOutFixedDOF.size();
+  }
+
+  bool addFixedVertex(int index) {
+    if (std::find(m_vFixedVertices.begin(), m_vFixedVertices.end(), index) != m_vFixedVertices.end()) return false;
+    m_vFixedVertices.push_back(index);
+    return updateFixedVertices();
+  }
+  bool removeFixedVertex(int index) {
+    std::vector<int>::iterator it = std::find(m_vFixedVertices.begin(), m_vFixedVertices.end(), index);
+    if (it == m_vFixedVertices.end()) return false;
+    m_vFixedVertices.erase(it);
+    return updateFixedVertices();
+  }
+  bool setFixedVertices(const std::vector<int>& v) { m_vFixedVertices = v; return updateFixedVertices(); }
+  int getFixedVertices(std::vector<int>& v) { v = m_vFixedVertices; return (int)v.size(); }
+  bool updateFixedVertices() {
+    FixedVerticesToFixedDOF(m_vFixedVertices, m_vFixedDofs);
+    return m_lpIntegrator->setConstrainedDOF((int)m_vFixedDofs.size(), m_vFixedDofs.data());
+  }
+
+  void setPulledVertex(int index) { m_idxPulledVertex = index; }
+  bool hapticStart(int index) { m_idxPulledVertex = index; m_bHapticInProgress = true; m_vHapticIndices.clear(); return true; }
+  void hapticEnd() { m_bHapticInProgress = false; m_idxPulledVertex = -1; m_vHapticIndices.clear(); }
+  bool isHapticInProgress() const { return m_bHapticInProgress; }
+  void hapticSetCurrentForces(const std::vector<int>& indices, const std::vector<vec3d>& forces) { m_vHapticIndices = indices; m_vHapticForces = forces; }
+  void setDampingStiffnessCoeff(double s) { m_dampingStiffnessCoeff = s; m_lpIntegrator->SetDampingStiffnessCoef(s); }
+  double getDampingStiffnessCoeff() const { return m_dampingStiffnessCoeff; }
+  void setDampingMassCoeff(double m) { m_dampingMassCoeff = m; m_lpIntegrator->SetDampingMassCoef(m); }
+  double getDampingMassCoeff() const { return m_dampingMassCoeff; }
+  void setGravity(bool g) { m_bApplyGravity = g; }
+  bool getGravity() const { return m_bApplyGravity; }
+  void setFloor(double y) { m_hasFloor = true; m_floorY = y; }  // stands in for setCollisionObject(SGNode*): the floor plane height
+  void resetDeformations() { m_lpIntegrator->ResetToRest(); m_vHapticForces.clear(); }
+  void setDeformCallback(FOnApplyDeformations fOnDeform) { m_fOnDeform = fOnDeform; }
+  double getSolverTime() const { return m_lpIntegrator->GetSystemSolveTime(); }
+  U32 getDof() const { return m_dof; }
+  U32 getCollidedCount() const { return m_ctCollided; }
+  HipIntegrator* integrator() { return m_lpIntegrator; }
+  // Deformable::computeVolume (Deformable.cpp:260-279) on the current displaced positions
+  double computeVolume(double* arrStore = nullptr, U32 count = 0) {
+    m_lpIntegrator->GetqState(m_q.data(), nullptr, nullptr);
+    const U32 m = (U32)(m_elements.size() / 4);
+    const bool store = arrStore != nullptr && count == m;
+    double vol = 0.0;
+    for (U32 e = 0; e < m; e++) {
+      double p[4][3];
+      for (int k = 0; k < 4; k++)
+        for (int d = 0; d < 3; d++) p[k][d] = m_rest[3 * (size_t)m_elements[4 * e + k] + d] + m_q[3 * (size_t)m_elements[4 * e + k] + d];
+      const double u[3] = {p[0][0] - p[3][0], p[0][1] - p[3][1], p[0][2] - p[3][2]}, v[3] = {p[1][0] - p[3][0], p[1][1] - p[3][1], p[1][2] - p[3][2]},
+                   w[3] = {p[2][0] - p[3][0], p[2][1] - p[3][1], p[2][2] - p[3][2]};
+      const double cur = std::abs(u[0] * (v[1] * w[2] - v[2] * w[1]) + u[1] * (v[2] * w[0] - v[0] * w[2]) + u[2] * (v[0] * w[1] - v[1] * w[0])) / 6.0;
+      if (store) arrStore[e] = cur;
+      vol += cur;
+    }
+    return vol;
+  }
+
+ private:
+  void init() {  // Deformable::init (Deformable.cpp:85-124)
+    m_ctCollided = 0; m_fOnDeform = nullptr; m_idxPulledVertex = -1; m_bHapticInProgress = false;
+    m_dampingMassCoeff = 0.0; m_dampingStiffnessCoeff = 0.01; m_timeStep = 0.0333; m_ctTimeStep = 0;
+    m_bApplyGravity = true;  // left uninitialised by the reference's init(); true is what its .sim files set
+    m_lpIntegrator = nullptr; m_hasFloor = false; m_floorY = 0.0; m_dof = 0;
+  }
+  std::vector<double> m_rest;
+  std::vector<int> m_elements;
+  std::vector<int> m_vFixedVertices, m_vFixedDofs, m_vHapticIndices;
+  std::vector<vec3d> m_vHapticForces;
+  std::vector<double> m_q, m_qVel, m_arrExtForces;
+  HipIntegrator* m_lpIntegrator;
+  FOnApplyDeformations m_fOnDeform;
+  U32 m_dof, m_ctCollided, m_ctTimeStep;
+  int m_idxPulledVertex, m_device;
+  bool m_bHapticInProgress, m_bApplyGravity, m_hasFloor;
+  double m_dampingMassCoeff, m_dampingStiffnessCoeff, m_timeStep, m_floorY;
+};
+
+}  // namespace FEM
+}  // namespace PS

@@ -1,0 +1,70 @@
+// Host program over the C++ class surfaces (include/fembrain/Deformable.h, GPUPoly.h): a truth cube stepped through
+// PS::FEM::Deformable with a deformation callback, then sphere.blob polygonized through PS::SKETCH::GPUPoly and the
+// resulting tet mesh fed back into a Deformable -- the reference's main.cpp flow (src/main.cpp:782-886) without GL.
+// Prints one KEY=VALUE line per fact for tests/test_cpp_host.py.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "fembrain/Deformable.h"
+#include "fembrain/GPUPoly.h"
+
+static unsigned g_calls = 0;
+static double g_maxq = 0;
+static void onDeform(PS::FEM::U32 dof, double* q) {
+  g_calls++;
+  g_maxq = 0;
+  for (unsigned i = 0; i < dof; i++) g_maxq = std::fmax(g_maxq, std::fabs(q[i]));
+}
+
+int main() {
+  // CreateTruthCube(5,5,5,0.1), src/deformable/VolMeshSamples.cpp:67-130
+  const int n = 5;
+  std::vector<double> v;
+  std::vector<int> t;
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) for (int k = 0; k < n; k++) {
+    v.push_back((-n / 2.0 + i) * 0.1); v.push_back(j * 0.1); v.push_back((-n / 2.0 + k) * 0.1);
+  }
+  for (int i = 0; i < n - 1; i++) for (int j = 0; j < n - 1; j++) for (int k = 0; k < n - 1; k++) {
+    int c[8];
+    for (int q = 0; q < 8; q++) c[q] = (i + ((q >> 2) & 1)) * n * n + (j + ((q >> 1) & 1)) * n + k + (q & 1);
+    const int pat[6][4] = {{0, 2, 4, 1}, {6, 2, 1, 4}, {6, 2, 3, 1}, {6, 4, 1, 5}, {6, 1, 3, 5}, {6, 3, 7, 5}};
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 4; b++) t.push_back(c[pat[a][b]]);
+  }
+  std::vector<int> fixed;
+  for (int a = 0; a < n * n; a++) fixed.push_back(a);
+  PS::FEM::Deformable d(n * n * n, v.data(), (int)t.size() / 4, t.data(), fixed);
+  d.setDeformCallback(onDeform);
+  const double vol0 = d.computeVolume();
+  d.timestep();
+  d.timestep();
+  std::printf("CUBE_DOF=%u\nCUBE_CALLBACKS=%u\nCUBE_MAXQ=%.9g\nCUBE_VOL0=%.9g\nCUBE_VOL=%.9g\nCUBE_ITERS=%d\nCUBE_SOLVE_S=%.6g\n", d.getDof(), g_calls, g_maxq,
+              vol0, d.computeVolume(), d.integrator()->GetLastIterations(), d.getSolverTime());
+
+  // sphere.blob -> GPUPoly -> tet mesh -> Deformable
+  PS::SKETCH::LinearBlobTreeData blob;
+  const float hdr[12] = {-0.5f, -0.5f, -0.5f, 1, 0.5f, 0.5f, 0.5f, 1, 1, 0, 1, 65535.0f};
+  blob.header.assign(hdr, hdr + 12);
+  blob.prims.assign(20, 0.0f);
+  const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  blob.mtx.assign(ident, ident + 12);
+  PS::SKETCH::GPUPoly poly(blob);
+  poly.setCellSize(0.1f);
+  const int ok = poly.run();
+  const int ntets = poly.runTetrahedralizer();
+  PS::SKETCH::U32 nv, nt;
+  std::vector<float> xyz;
+  std::vector<PS::SKETCH::U32> el;
+  poly.readbackTetMesh(nv, xyz, nt, el);
+  std::printf("POLY_RUN=%d\nPOLY_TETS=%d\nPOLY_VERTS=%u\n", ok, ntets, nv);
+  PS::SKETCH::FieldComputer fc(blob);
+  std::printf("FIELD_025=%.9g\nGRID_POINTS=%d\n", fc.field(0.25f, 0, 0), fc.fieldsForVoxelGrid(0.1f));
+  std::vector<double> xv(xyz.begin(), xyz.end());
+  std::vector<int> ev(el.begin(), el.end());
+  std::vector<int> low;
+  for (unsigned i = 0; i < nv; i++) if (xyz[3 * i + 1] < -0.35f) low.push_back((int)i);  // BASELINE config 1 clamp
+  PS::FEM::Deformable ball((int)nv, xv.data(), (int)nt, ev.data(), low);
+  ball.timestep();
+  std::printf("BALL_FIXED=%zu\nBALL_ITERS=%d\n", low.size(), ball.integrator()->GetLastIterations());
+  return 0;
+}

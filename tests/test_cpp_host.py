@@ -1,0 +1,51 @@
+"""The C++ class surfaces (include/fembrain/*.h) compile against the C ABI with a plain host compiler (CPU test) and a
+host program using them produces the oracle's numbers on the GPU (gpu test)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "host_classes")
+
+
+def _build():
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "host_classes.cpp"),
+           "-o", EXE, "-L", os.path.join(ROOT, "fembrain_amd"), "-lfembrain_hip", "-Wl,-rpath," + os.path.join(ROOT, "fembrain_amd")]
+    subprocess.check_call(cmd)
+
+
+def test_cpp_adaptors_compile_and_link_with_gxx():
+    _build()  # a C++11 host compiler and the C ABI are all the host application needs
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_cpp_host_program_matches_oracle(gpu):
+    from fembrain_amd.blobtree import sphere_blob
+    from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
+    from oracle.pyfield import OrcPoly
+    from oracle.pyoracle import OrcFem
+    if not os.path.exists(EXE):
+        _build()
+    out = subprocess.check_output([EXE], text=True)
+    kv = dict(line.split("=", 1) for line in out.strip().splitlines())
+    n = 5
+    v, t = truth_cube(n, n, n, 0.1)
+    o = OrcFem(v, t)
+    o.integrator(fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n)))
+    f = np.zeros(o.r)
+    f[1::3] = -10000.0
+    for _ in range(2):
+        o.set_external_forces(f)
+        it = abs(o.step())
+    q, _ = o.get_state()
+    assert int(kv["CUBE_DOF"]) == o.r and int(kv["CUBE_CALLBACKS"]) == 2
+    assert abs(float(kv["CUBE_MAXQ"]) - np.abs(q).max()) <= 2e-4 * np.abs(q).max()
+    assert abs(int(kv["CUBE_ITERS"]) - it) <= 3
+    assert abs(float(kv["CUBE_VOL0"]) - 0.4 ** 3) < 1e-12
+    ox, ot, oc = OrcPoly(sphere_blob()).run_tetrahedralizer(0.1)
+    assert int(kv["POLY_RUN"]) == 1 and int(kv["POLY_TETS"]) == len(ot) == 3744 and int(kv["POLY_VERTS"]) == len(ox)
+    assert np.float32(kv["FIELD_025"]) == np.float32((1 - 0.0625) ** 3) and int(kv["GRID_POINTS"]) == 12 ** 3
+    assert int(kv["BALL_FIXED"]) == int((ox[:, 1] < -0.35).sum()) and int(kv["BALL_ITERS"]) > 0
