@@ -102,7 +102,10 @@ def main():
     torch.cuda.set_device(local_rank)
     shard = None
     comm = None
-    if world > 1:
+    # FEMBRAIN_BENCH_FORCE_DIST=1 runs the one-process-per-GPU plumbing (process group, unique-id broadcast, RCCL
+    # communicator, sharded handle) even at world size 1 -- the rehearsal available on a one-GPU box
+    dist_mode = world > 1 or os.environ.get("FEMBRAIN_BENCH_FORCE_DIST") == "1"
+    if dist_mode:
         import ctypes as C
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -120,7 +123,7 @@ def main():
     n, text = WORKLOADS[args.workload]
     v, t = truth_cube(n, n, n, 0.1)
     fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
-    if world > 1:
+    if dist_mode:
         # slabs of whole i-planes (node index = i*n*n + j*n + k): <= 2 neighbours per rank
         planes = [n * r // world for r in range(world + 1)]
         splits = np.array([p * n * n for p in planes], dtype=np.int32)
@@ -129,7 +132,7 @@ def main():
     g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=local_rank, shard=shard)
 
     def barrier():
-        if world > 1:
+        if dist_mode:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -149,7 +152,7 @@ def main():
         solve_s += g.last.solve_seconds
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_mode:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -192,7 +195,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     g.close()
-    if world > 1:
+    if dist_mode:
         fl.lib().fb_comm_destroy(comm)
         dist.barrier()
         dist.destroy_process_group()

@@ -87,8 +87,8 @@ int fb_comm_create(fb_comm_t* out, int rank, int n_ranks, const unsigned char id
   if (!out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fb::fail(FB_EINVAL, "bad communicator arguments");
   fb_comm_s* c = new fb_comm_s;
   c->rank = rank; c->n_ranks = n_ranks; c->device = device;
-  if (n_ranks > 1) {
-    if (!id) { delete c; return fb::fail(FB_EINVAL, "null unique id"); }
+  if (n_ranks > 1 && !id) { delete c; return fb::fail(FB_EINVAL, "null unique id"); }
+  if (id) {  // a unique id with n_ranks == 1 builds a real one-rank communicator (used to test the RCCL plumbing on one GPU)
     int r = load_rccl();
     if (r != FB_OK) { delete c; return r; }
     hipError_t e = hipSetDevice(device);
@@ -116,14 +116,14 @@ int fb_comm_destroy(fb_comm_t c) {
 namespace fb {
 
 int comm_allreduce_sum(fb_comm_s* c, double* dev_buf, int count, hipStream_t s) {
-  if (!c || c->n_ranks == 1) return FB_OK;
+  if (!c || !c->nccl) return FB_OK;
   FB_NCCL(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)c->nccl, s));
   return FB_OK;
 }
 
 int comm_exchange_nodes(fb_comm_s* c, const double* sendbuf, const int* send_off, double* recv_base, const int* recv_off,
                         hipStream_t s) {
-  if (!c || c->n_ranks == 1) return FB_OK;
+  if (!c || !c->nccl || c->n_ranks == 1) return FB_OK;
   FB_NCCL(g_rccl.GroupStart());
   for (int q = 0; q < c->n_ranks; q++) {
     if (q == c->rank) continue;

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void k_fold_partials(const double* partial,
 
 int global_scalar(fb_fem_s* h, const double* partial, double** out, bool check_done, int count = 1) {
   *out = nullptr;
-  if (!h->comm || h->comm->n_ranks == 1) return FB_OK;
+  if (!h->comm || !h->comm->nccl) return FB_OK;
   hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(kBlock), 0, h->stream, partial, h->grid, count, h->scal.p, check_done ? h->st.p : nullptr);
   FB_HIP(hipGetLastError());
   // a converged solve leaves the previous (identical on every rank) values in place; the all-reduce still runs on
@@ -296,14 +296,15 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
   if (n_fixed < 0 || (n_fixed > 0 && !fixed)) return fail(FB_EINVAL, "bad constrained DOF list");
   if (!(params->timestep > 0) || !(params->E > 0) || !(params->rho > 0) || !(params->nu > -1.0 && params->nu < 0.5))
     return fail(FB_EINVAL, "bad material / timestep parameters");
-  if (n_ranks > 1 && (!comm || comm->n_ranks != n_ranks || comm->rank != rank)) return fail(FB_EINVAL, "sharded handle needs a matching communicator");
+  if (n_ranks > 1 && !comm) return fail(FB_EINVAL, "sharded handle needs a communicator");
+  if (comm && (comm->n_ranks != n_ranks || comm->rank != rank)) return fail(FB_EINVAL, "communicator rank/size does not match the handle");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(FB_EDEVICE, "no HIP device visible");
   if (params->device < 0 || params->device >= ndev) return fail(FB_EINVAL, "device %d out of range (%d visible)", params->device, ndev);
   FB_HIP(hipSetDevice(params->device));
   fb_fem_s* h = new fb_fem_s;
   h->prm = *params;
-  h->comm = (n_ranks > 1) ? comm : nullptr;
+  h->comm = comm;  // a one-rank communicator with a live RCCL handle still runs the collectives (plumbing test)
   h->f64 = params->matrix_precision == FB_MATRIX_F64;
   h->lambda = (params->nu * params->E) / ((1 + params->nu) * (1 - 2 * params->nu));
   h->mu = params->E / (2 * (1 + params->nu));

@@ -185,3 +185,27 @@ def test_bad_arguments(gpu):
     bad[0, 0] = len(v)
     with pytest.raises(fl.FbError):
         FemIntegrator(v, bad, fixed)
+
+
+def test_one_rank_rccl_communicator_runs_the_collective_path(gpu):
+    """RCCL plumbing on one GPU: a real one-rank communicator (dlopen, unique id, ncclCommInitRank) drives the sharded
+    code path -- partial fold kernel + ncclAllReduce on the handle's stream every iteration -- and must reproduce the
+    unsharded result bit for bit (a one-rank all-reduce is the identity)."""
+    import ctypes as C
+    L = fl.lib()
+    buf = (C.c_ubyte * 128)()
+    fl.check(L.fb_comm_unique_id(buf))
+    comm = C.c_void_p()
+    fl.check(L.fb_comm_create(C.byref(comm), 0, 1, buf, 0))
+    n = 8
+    v, t, fixed = _cube(n)
+    a = FemIntegrator(v, t, fixed)
+    b = FemIntegrator(v, t, fixed, shard=(1, 0, None, comm))
+    for g in (a, b):
+        g.set_uniform_force(1, -10000.0)
+    ia = [a.do_timestep() for _ in range(2)]
+    ib = [b.do_timestep() for _ in range(2)]
+    assert ia == ib
+    assert np.array_equal(a.get_q_state()[0], b.get_q_state()[0])
+    b.close()
+    fl.check(L.fb_comm_destroy(comm))
