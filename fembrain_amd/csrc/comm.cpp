@@ -121,15 +121,15 @@ int comm_allreduce_sum(fb_comm_s* c, double* dev_buf, int count, hipStream_t s) 
   return FB_OK;
 }
 
-int comm_exchange_nodes(fb_comm_s* c, const double* sendbuf, const int* send_off, double* recv_base, const int* recv_off,
+int comm_exchange_nodes(fb_comm_s* c, const double* sendbuf, const int* send_off, double* recv_base, const int* recv_off, int width,
                         hipStream_t s) {
   if (!c || !c->nccl || c->n_ranks == 1) return FB_OK;
   FB_NCCL(g_rccl.GroupStart());
   for (int q = 0; q < c->n_ranks; q++) {
     if (q == c->rank) continue;
     const int ns = send_off[q + 1] - send_off[q], nr = recv_off[q + 1] - recv_off[q];
-    if (ns > 0) FB_NCCL(g_rccl.Send(sendbuf + 3 * (size_t)send_off[q], 3 * (size_t)ns, ncclFloat64, q, (ncclComm_t)c->nccl, s));
-    if (nr > 0) FB_NCCL(g_rccl.Recv(recv_base + 3 * (size_t)recv_off[q], 3 * (size_t)nr, ncclFloat64, q, (ncclComm_t)c->nccl, s));
+    if (ns > 0) FB_NCCL(g_rccl.Send(sendbuf + (size_t)width * send_off[q], (size_t)width * ns, ncclFloat64, q, (ncclComm_t)c->nccl, s));
+    if (nr > 0) FB_NCCL(g_rccl.Recv(recv_base + (size_t)width * recv_off[q], (size_t)width * nr, ncclFloat64, q, (ncclComm_t)c->nccl, s));
   }
   FB_NCCL(g_rccl.GroupEnd());
   return FB_OK;

@@ -12,7 +12,8 @@ struct fb_comm_s {
 
 namespace fb {
 int comm_allreduce_sum(fb_comm_s* c, double* dev_buf, int count, hipStream_t s);
-// send_off/recv_off: n_ranks+1 offsets in NODES; sendbuf packed by destination; recv lands at recv_base + 3*recv_off[q]
-int comm_exchange_nodes(fb_comm_s* c, const double* sendbuf, const int* send_off, double* recv_base, const int* recv_off,
+// send_off/recv_off: n_ranks+1 offsets in NODES of `width` doubles; sendbuf packed by destination; recv lands at
+// recv_base + width*recv_off[q]
+int comm_exchange_nodes(fb_comm_s* c, const double* sendbuf, const int* send_off, double* recv_base, const int* recv_off, int width,
                         hipStream_t s);
 }  // namespace fb

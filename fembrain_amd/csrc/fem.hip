@@ -27,10 +27,12 @@ struct fb_fem_s {
   DevBuf<uint32_t> contrib;
   DevBuf<uint8_t> dofmask;
   DevBuf<char> vals;  // MT[n_slots][9][64]
+  DevBuf<char> dlo;   // MT[n_slices][9][64]: low part of every row's diagonal block
   DevBuf<double> mblk;
   // vectors (3*n_local each)
   DevBuf<double> q, qvel, fext, fint, rhs, x, r, d, Ad, invdiag, tmp, sendbuf;
-  DevBuf<double> part_a, part_b, scal;
+  DevBuf<double> part_a, part_b, part_c, scal;
+  DevBuf<double> rec_s[2];  // FB_PCG_FUSED: 12 doubles per local node, double buffered
   DevBuf<CGState> st;
   DevBuf<int> counter;
   CGState* st_host = nullptr;  // pinned, 2 slots
@@ -69,9 +71,11 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
   FB_TRY(h->contrib.upload(P.contrib, s));
   FB_TRY(h->dofmask.upload(P.dofmask, s));
   if (!P.send_local.empty()) FB_TRY(h->send_local.upload(P.send_local, s));
-  FB_TRY(h->sendbuf.alloc(std::max<size_t>(1, (size_t)3 * P.send_local.size())));
+  FB_TRY(h->sendbuf.alloc(std::max<size_t>(1, (size_t)12 * P.send_local.size())));
   FB_TRY(h->vals.alloc((size_t)P.n_slots * 9 * 64 * mt_size(h)));
   FB_TRY(h->vals.zero(s));
+  FB_TRY(h->dlo.alloc((size_t)P.n_slices * 9 * 64 * mt_size(h)));
+  FB_TRY(h->dlo.zero(s));
   FB_TRY(h->mblk.alloc((size_t)P.n_slots * 64));
   FB_TRY(h->mblk.zero(s));
   const size_t nv = (size_t)3 * P.n_local + 2;  // spare doubles: the vector kernels walk owned rows in 16-byte pairs
@@ -85,7 +89,12 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
   h->grid = 8 * per;
   FB_TRY(h->part_a.alloc(3 * kMaxPartials));
   FB_TRY(h->part_b.alloc(kMaxPartials));
-  FB_TRY(h->scal.alloc(4));
+  FB_TRY(h->part_c.alloc(3 * kMaxPartials));
+  for (auto& r : h->rec_s) {
+    FB_TRY(r.alloc((size_t)12 * P.n_local + 2));
+    FB_TRY(r.zero(s));
+  }
+  FB_TRY(h->scal.alloc(8));
   FB_TRY(h->st.alloc(1));
   FB_TRY(h->st.zero(s));
   FB_TRY(h->counter.alloc(1));
@@ -101,24 +110,24 @@ int launch_rest(fb_fem_s* h) {
   return FB_OK;
 }
 
-// halo refresh of a node vector (3 doubles per node); no-op for an unsharded handle
-__global__ __launch_bounds__(kBlock) void k_pack_nodes(int n, const int* __restrict__ ids, const double* __restrict__ v,
+// halo refresh of a per-node array (`width` doubles per node: 3 for vectors, 12 for PCG records); no-op when unsharded
+__global__ __launch_bounds__(kBlock) void k_pack_nodes(int n, int width, const int* __restrict__ ids, const double* __restrict__ v,
                                                        double* __restrict__ out) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const size_t s = 3 * (size_t)ids[i];
-  out[3 * (size_t)i] = v[s]; out[3 * (size_t)i + 1] = v[s + 1]; out[3 * (size_t)i + 2] = v[s + 2];
+  if (i >= n * width) return;
+  const int node = i / width, c = i - node * width;
+  out[i] = v[(size_t)width * ids[node] + c];
 }
 
-int halo_exchange(fb_fem_s* h, double* vec) {
+int halo_exchange(fb_fem_s* h, double* vec, int width = 3) {
   if (!h->comm || h->comm->n_ranks == 1) return FB_OK;
   const FemPlan& P = h->plan;
   const int ns = (int)P.send_local.size();
   if (ns > 0) {
-    hipLaunchKernelGGL(k_pack_nodes, dim3(ceil_div(ns, kBlock)), dim3(kBlock), 0, h->stream, ns, h->send_local.p, vec, h->sendbuf.p);
+    hipLaunchKernelGGL(k_pack_nodes, dim3(ceil_div(ns * width, kBlock)), dim3(kBlock), 0, h->stream, ns, width, h->send_local.p, vec, h->sendbuf.p);
     FB_HIP(hipGetLastError());
   }
-  return comm_exchange_nodes(h->comm, h->sendbuf.p, P.send_off.data(), vec + 3 * (size_t)P.n_owned, P.halo_off.data(), h->stream);
+  return comm_exchange_nodes(h->comm, h->sendbuf.p, P.send_off.data(), vec + (size_t)width * P.n_owned, P.halo_off.data(), width, h->stream);
 }
 
 template <typename MT>
@@ -134,7 +143,7 @@ template <typename MT>
 int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const double* fext, double* mblk_out, double* fint_out,
                 double* rhs, double* invdiag) {
   hipLaunchKernelGGL(k_assemble_rows<MT>, dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), h->slot_coff.p, h->slot_ccnt.p,
-                     h->contrib.p, (const MT*)h->rec.p, h->fe.p, h->dofmask.p, qvel, fext, (MT*)h->vals.p, mblk_out, fint_out, rhs,
+                     h->contrib.p, (const MT*)h->rec.p, h->fe.p, h->dofmask.p, qvel, fext, (MT*)h->vals.p, (MT*)h->dlo.p, mblk_out, fint_out, rhs,
                      invdiag, ap);
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -163,7 +172,7 @@ int assemble_system(fb_fem_s* h) {
 
 template <typename MT, int MODE>
 int launch_spmv(fb_fem_s* h, const double* x, double* y, const double* b, double* partial, int parity) {
-  hipLaunchKernelGGL((k_spmv<MT, MODE>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, x, y, b,
+  hipLaunchKernelGGL((k_spmv<MT, MODE>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y, b,
                      h->invdiag.p, partial, h->st.p, parity);
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -185,15 +194,15 @@ __global__ __launch_bounds__(kBlock) void k_fold_partials(const double* partial,
   }
 }
 
-int global_scalar(fb_fem_s* h, const double* partial, double** out, bool check_done, int count = 1) {
+int global_scalar(fb_fem_s* h, const double* partial, double** out, bool check_done, int count = 1, int slot = 0) {
   *out = nullptr;
   if (!h->comm || !h->comm->nccl) return FB_OK;
-  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(kBlock), 0, h->stream, partial, h->grid, count, h->scal.p, check_done ? h->st.p : nullptr);
+  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(kBlock), 0, h->stream, partial, h->grid, count, h->scal.p + slot, check_done ? h->st.p : nullptr);
   FB_HIP(hipGetLastError());
   // a converged solve leaves the previous (identical on every rank) values in place; the all-reduce still runs on
   // every rank so the collective sequence stays matched, and its result is ignored by the done-checking consumers
-  FB_TRY(comm_allreduce_sum(h->comm, h->scal.p, count, h->stream));
-  *out = h->scal.p;
+  FB_TRY(comm_allreduce_sum(h->comm, h->scal.p + slot, count, h->stream));
+  *out = h->scal.p;  // consumers index the scalar block themselves ([0..2] pending sums, [3] exact rho)
   return FB_OK;
 }
 
@@ -239,7 +248,10 @@ bool host_finished(const CGState& s) {
 }
 
 // Jacobi-PCG on the assembled system, rhs b -> h->x.  iters_out: + converged / - not (CGSolver.cpp:189).
+int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state);
+
 int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state) {
+  if (h->prm.pcg_variant == FB_PCG_FUSED) return pcg_solve_fused(h, b, eps, max_iter, iters_out, final_state);
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
   hipLaunchKernelGGL(k_cg_init, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, b, h->invdiag.p, h->x.p, h->r.p, h->d.p,
@@ -278,6 +290,91 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
   const bool converged = !(rho > fin.eps2 * fin.rho0);
   if (iters_out) *iters_out = converged ? fin.iter : -fin.iter;
   if (final_state) *final_state = fin;
+  return FB_OK;
+}
+
+template <typename MT, bool FIRST>
+int launch_mega(fb_fem_s* h, int cur, const double* sc, int k) {
+  // partial sums ping-pong with the records: a block may publish its new sums while another still reads the old ones
+  double* pin = cur ? h->part_c.p : h->part_a.p;
+  double* pout = cur ? h->part_a.p : h->part_c.p;
+  hipLaunchKernelGGL((k_cg_mega<MT, FIRST>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, h->rec_s[cur].p,
+                     h->rec_s[cur ^ 1].p, h->x.p, pin, h->grid, sc, pout, h->st.p, k);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+template <bool FIRST>
+int mega(fb_fem_s* h, int cur, const double* sc, int k) {
+  return h->f64 ? launch_mega<double, FIRST>(h, cur, sc, k) : launch_mega<float, FIRST>(h, cur, sc, k);
+}
+
+// FB_PCG_FUSED: one launch per iteration (see k_cg_mega).  Launch j computes q_j; the launch after it completes
+// iteration j, so n iterations take n+1 launches; every 30th iteration is completed by the exact-residual sequence.
+int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state) {
+  const FemPlan& P = h->plan;
+  hipStream_t s = h->stream;
+  int cur = 0;
+  hipLaunchKernelGGL(k_rec_init, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, b, h->invdiag.p, h->x.p, h->rec_s[0].p, h->part_b.p);
+  FB_HIP(hipGetLastError());
+  double* sc = nullptr;
+  FB_TRY(global_scalar(h, h->part_b.p, &sc, false));
+  hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, s, h->st.p, h->part_b.p, h->grid, sc, eps, max_iter);
+  FB_HIP(hipGetLastError());
+  // launch 0: q_1 = A d_1
+  FB_TRY(halo_exchange(h, h->rec_s[cur].p, 12));
+  FB_TRY(mega<true>(h, cur, nullptr, 0));
+  cur ^= 1;
+  auto pending_sums = [&]() { return cur ? h->part_c.p : h->part_a.p; };  // what the launch that produced rec_s[cur] wrote
+  FB_TRY(global_scalar(h, pending_sums(), &sc, true, 3));
+  const int kBatch = 30;
+  int k = 1, slot = 0;
+  bool pending[2] = {false, false}, finished = false;
+  while (!finished) {
+    for (int n = 0; n < kBatch && k <= max_iter; n++, k++) {  // k = iteration being completed
+      if (k % 30 == 0) {
+        hipLaunchKernelGGL(k_rec_apply_x, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->rec_s[cur].p, h->x.p, pending_sums(), h->grid,
+                           sc, h->st.p, k);
+        FB_HIP(hipGetLastError());
+        FB_TRY(halo_exchange(h, h->x.p));
+        FB_TRY(spmv<2>(h, h->x.p, h->r.p, b, h->part_b.p, 0));
+        double* sc2 = nullptr;
+        FB_TRY(global_scalar(h, h->part_b.p, &sc2, true, 1, 3));
+        hipLaunchKernelGGL(k_rec_refresh, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->rec_s[cur].p, h->rec_s[cur ^ 1].p, h->r.p,
+                           h->part_b.p, h->grid, sc2, h->st.p, k);
+        FB_HIP(hipGetLastError());
+        cur ^= 1;
+        FB_TRY(halo_exchange(h, h->rec_s[cur].p, 12));
+        FB_TRY(mega<true>(h, cur, nullptr, k));
+      } else {
+        FB_TRY(halo_exchange(h, h->rec_s[cur].p, 12));
+        FB_TRY(mega<false>(h, cur, sc, k));
+      }
+      cur ^= 1;
+      FB_TRY(global_scalar(h, pending_sums(), &sc, true, 3));
+    }
+    FB_HIP(hipMemcpyAsync(&h->st_host[slot], h->st.p, sizeof(CGState), hipMemcpyDeviceToHost, s));
+    FB_HIP(hipEventRecord(h->ev_batch[slot], s));
+    pending[slot] = true;
+    const int prev = slot ^ 1;
+    if (pending[prev]) {
+      FB_HIP(hipEventSynchronize(h->ev_batch[prev]));
+      pending[prev] = false;
+      if (h->st_host[prev].done) finished = true;
+    }
+    if (k > max_iter) finished = true;
+    slot ^= 1;
+  }
+  FB_HIP(hipStreamSynchronize(s));
+  const CGState fin = h->st_host[slot ^ 1];
+  if (!fin.done) return fail(FB_EDEVICE, "internal: fused PCG ended without a terminal state (iter %d)", fin.iter);
+  const double rho = fin.rho[(fin.iter + 1) & 1];
+  const bool converged = !(rho > fin.eps2 * fin.rho0);
+  if (iters_out) *iters_out = converged ? fin.iter : -fin.iter;
+  if (final_state) {
+    *final_state = fin;
+    final_state->rho[fin.iter & 1] = rho;  // callers read rho[iter & 1] (the literal solver's convention)
+  }
   return FB_OK;
 }
 
@@ -353,23 +450,30 @@ int download_owned(fb_fem_s* h, const DevBuf<double>& src, double* g) {
   return src.download(g + 3 * (size_t)P.node_lo, (size_t)3 * P.n_owned, h->stream);
 }
 
-// SELL device values -> 9 doubles per block in CSR (fb_fem_pattern) order
+// SELL device values -> 9 doubles per block in CSR (fb_fem_pattern) order (diagonal blocks: hi + lo)
 int download_blocks(fb_fem_s* h, double* out) {
   const FemPlan& P = h->plan;
-  const size_t n = (size_t)P.n_slots * 9 * 64;
-  std::vector<double> host(n);
+  const size_t n = (size_t)P.n_slots * 9 * 64, nl = (size_t)P.n_slices * 9 * 64;
+  std::vector<double> host(n), lo(nl);
   if (h->f64) {
     FB_HIP(hipMemcpyAsync(host.data(), h->vals.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    FB_HIP(hipMemcpyAsync(lo.data(), h->dlo.p, nl * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     FB_HIP(hipStreamSynchronize(h->stream));
   } else {
-    std::vector<float> hf(n);
+    std::vector<float> hf(n), lf(nl);
     FB_HIP(hipMemcpyAsync(hf.data(), h->vals.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    FB_HIP(hipMemcpyAsync(lf.data(), h->dlo.p, nl * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     FB_HIP(hipStreamSynchronize(h->stream));
     for (size_t i = 0; i < n; i++) host[i] = hf[i];
+    for (size_t i = 0; i < nl; i++) lo[i] = lf[i];
   }
   for (int a = 0; a < P.n_owned; a++)
     for (int p = P.bptr[a]; p < P.bptr[a + 1]; p++)
-      for (int v = 0; v < 9; v++) out[9 * (size_t)p + v] = host[((size_t)P.blk_slot[p] * 9 + v) * 64 + (a & 63)];
+      for (int v = 0; v < 9; v++) {
+        double x = host[((size_t)P.blk_slot[p] * 9 + v) * 64 + (a & 63)];
+        if (P.bcol[p] == a) x += lo[((size_t)(a >> 6) * 9 + v) * 64 + (a & 63)];
+        out[9 * (size_t)p + v] = x;
+      }
   return FB_OK;
 }
 
@@ -705,7 +809,8 @@ int fb_fem_spmv_bytes(fb_fem_t h, double* bytes) {
   if (!h || !bytes) return fail(FB_EINVAL, "null argument");
   const FemPlan& P = h->plan;
   // SURVEY.md 8d BSR figure: nnzb*(9 values + 4 B index) + (rows+1)*4 + x read once + y written once (fp64 vectors)
-  *bytes = (double)P.n_blocks * (9.0 * mt_size(h) + 4.0) + (P.n_owned + 1) * 4.0 + 3.0 * P.n_owned * 8.0 * 2.0;
+  // + the low part of each row's diagonal block (9 values per row)
+  *bytes = (double)P.n_blocks * (9.0 * mt_size(h) + 4.0) + (P.n_owned + 1) * 4.0 + 3.0 * P.n_owned * 8.0 * 2.0 + 9.0 * mt_size(h) * P.n_owned;
   return FB_OK;
 }
 

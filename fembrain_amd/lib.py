@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libfembrain_hip.so")
 
 FB_OK, FB_EINVAL, FB_EDEVICE, FB_ENOMEM, FB_ESOLVER, FB_ECOMM = 0, -1, -2, -3, -4, -5
 FB_MATRIX_F32, FB_MATRIX_F64 = 0, 1
-FB_PCG_MERGED, FB_PCG_REFERENCE = 0, 1
+FB_PCG_MERGED, FB_PCG_REFERENCE, FB_PCG_FUSED = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)

@@ -31,6 +31,11 @@ extern "C" {
  * reduction (one RCCL all-reduce when sharded); iterates agree to rounding, checked by the parity tests. */
 #define FB_PCG_MERGED 0
 #define FB_PCG_REFERENCE 1
+/* FUSED (experimental): the merged recurrence with the vector update folded into the SpMV launch: each gathered column
+ * recomputes its new search-direction entry from a 96-byte per-node record {d, r, q, 1/diag}, so one launch is one
+ * iteration.  Correct (same iteration counts), but measured 1.8x SLOWER than MERGED on MI355X at 1M tets (51 vs 28 us per
+ * iteration): the 6 x 16-byte gathers per neighbour cost more than the vector pass they remove.  Kept for reference. */
+#define FB_PCG_FUSED 2
 
 const char* fb_last_error(void);
 int fb_device_count(void);

@@ -94,6 +94,7 @@ def test_system_spmv_pcg(gpu, prec, tol):
     Ko = sp.csr_matrix((keff, ja, ia), shape=(o.r, o.r))
     bptr, bcol = g.pattern()
     Kgs = bsr_to_scipy(bptr, bcol, Kg)
+    assert abs(Kgs - Kgs.T).max() == 0  # stored operator exactly symmetric (fp32 rounding included): CG needs A = A^T
     D = (Kgs - Ko)[free][:, free]
     assert abs(D).max() <= tol * abs(Ko).max()
     # in fp32 mode the (hK+D)qvel term sees the rotated gradients through their fp32 record
@@ -110,16 +111,21 @@ def test_system_spmv_pcg(gpu, prec, tol):
     it, xg = g.pcg(rhs_g, eps=1e-12, max_iter=20000)
     assert it > 0
     assert np.abs(xg - dv).max() <= max(50 * tol, 1e-8) * np.abs(dv).max()
-    g2 = FemIntegrator(v, t, fixed, matrix_precision=prec, pcg_variant=fl.FB_PCG_REFERENCE)
-    g2.set_q_state(q0, v0)
-    g2.set_external_forces(fext)
-    g2.system()
-    it2, xg2 = g2.pcg(rhs_g, eps=1e-12, max_iter=20000)
-    assert abs(it2 - it) <= max(2, 0.02 * it)
-    assert np.abs(xg2 - xg).max() <= 1e-8 * np.abs(xg).max()
+    for variant in (fl.FB_PCG_REFERENCE, fl.FB_PCG_FUSED):
+        g2 = FemIntegrator(v, t, fixed, matrix_precision=prec, pcg_variant=variant)
+        g2.set_q_state(q0, v0)
+        g2.set_external_forces(fext)
+        g2.system()
+        it2, xg2 = g2.pcg(rhs_g, eps=1e-12, max_iter=20000)
+        assert abs(it2 - it) <= max(2, 0.02 * it), variant
+        assert np.abs(xg2 - xg).max() <= 1e-8 * np.abs(xg).max(), variant
+        itz, xz = g2.pcg(np.zeros(o.r), eps=1e-6, max_iter=100)   # zero right-hand side: no iteration, x = 0
+        assert itz == 0 and not xz.any()
+        itm, _ = g2.pcg(rhs_g, eps=1e-12, max_iter=7)             # iteration cap: -7 as the reference returns
+        assert itm == -7, (variant, itm)
 
 
-@pytest.mark.parametrize("variant", [fl.FB_PCG_MERGED, fl.FB_PCG_REFERENCE])
+@pytest.mark.parametrize("variant", [fl.FB_PCG_MERGED, fl.FB_PCG_REFERENCE, fl.FB_PCG_FUSED])
 @pytest.mark.parametrize("prec", [fl.FB_MATRIX_F64, fl.FB_MATRIX_F32])
 def test_three_steps_reference_load(gpu, prec, variant):
     """q, qvel after 3 steps under the reference load (-10000 per y DOF, plane i=0 clamped, CG eps 1e-6).
@@ -209,3 +215,104 @@ def test_one_rank_rccl_communicator_runs_the_collective_path(gpu):
     assert np.array_equal(a.get_q_state()[0], b.get_q_state()[0])
     b.close()
     fl.check(L.fb_comm_destroy(comm))
+
+
+def test_config1_sphere_tetmesh_one_step(gpu):
+    """BASELINE config 1: sphere.blob polygonized at cellsize 0.1 (3,744 tets, the golden-pinned mesh), nodes with
+    y < -0.35 clamped, reference gravity, one step -- an UNSTRUCTURED pattern (ragged rows, SELL padding)."""
+    from fembrain_amd.blobtree import sphere_blob
+    from fembrain_amd.poly import GpuPoly
+    xyz, tets = GpuPoly(sphere_blob()).run_tetrahedralizer(0.1)
+    assert len(tets) == 3744
+    v = xyz.astype(np.float64)
+    t = tets.astype(np.int32)
+    fixed = fixed_vertices_to_dofs(np.nonzero(v[:, 1] < -0.35)[0])
+    o = OrcFem(v, t)
+    o.integrator(fixed)
+    g = FemIntegrator(v, t, fixed)
+    obptr, obcol = o.blocks()
+    bptr, bcol = g.pattern()
+    assert np.array_equal(bptr, obptr) and np.array_equal(bcol, obcol)
+    f = np.zeros(o.r)
+    f[1::3] = -10000.0
+    o.set_external_forces(f)
+    g.set_external_forces(f)
+    io, ig = abs(o.step()), g.do_timestep()
+    qo, _ = o.get_state()
+    qg, _, _ = g.get_q_state()
+    assert abs(io - ig) <= max(3, 0.02 * io)
+    assert np.abs(qg - qo).max() <= 2e-4 * np.abs(qo).max()
+
+
+def test_beam3_against_reference_golden(gpu):
+    """Vega's own beam (208 nodes / 450 tets, TetGen-style unstructured) with the reference build's q after 3 steps."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "fem_beam3.npz"))
+    fixed = fixed_vertices_to_dofs(gold["fixed_vertices"])
+    for prec, tol in ((fl.FB_MATRIX_F64, 2e-5), (fl.FB_MATRIX_F32, 3e-4)):
+        g = FemIntegrator(gold["verts"], gold["tets"], fixed, matrix_precision=prec)
+        f = np.zeros(g.r)
+        f[1::3] = -10.0
+        for k in range(3):
+            g.set_external_forces(f)
+            it = g.do_timestep()
+            q, _, _ = g.get_q_state()
+            assert abs(it - int(gold["iters"][k])) <= max(5, 0.03 * int(gold["iters"][k]))
+            assert np.abs(q - gold["q"][k]).max() <= tol * np.abs(gold["q"][k]).max()
+        # mass against the matrix file the reference ships (beam3_tet.mass)
+        bptr, bcol = g.pattern()
+        m = g.mass()
+        import scipy.sparse as sp
+        M = sp.csr_matrix((m, bcol, bptr), shape=(len(gold["verts"]),) * 2)
+        Mref = sp.csr_matrix((gold["mass_v"], (gold["mass_i"], gold["mass_j"])), shape=M.shape)
+        assert abs(M - Mref).max() <= (1e-12 if prec == fl.FB_MATRIX_F64 else 1e-7) * abs(Mref).max()
+
+
+def test_ragged_inputs(gpu):
+    """Edge cases: a node no element references (kept at rest), a single tet, no constraints at all (singular K but
+    Keff = M + ... is SPD), arbitrary (not node-aligned) constrained DOFs."""
+    v, t, fixed = _cube(4)
+    v2 = np.vstack([v, [[9.0, 9.0, 9.0]]])  # isolated extra node
+    g = FemIntegrator(v2, t, fixed)
+    g.set_uniform_force(1, -100.0)
+    it = g.do_timestep()
+    q, qv, _ = g.get_q_state()
+    assert it > 0 and np.isfinite(q).all() and np.isfinite(qv).all()
+    o = OrcFem(v, t)
+    o.integrator(fixed)
+    f = np.zeros(o.r)
+    f[1::3] = -100.0
+    o.set_external_forces(f)
+    o.step()
+    qo, _ = o.get_state()
+    assert np.abs(q[:-3] - qo).max() <= 2e-4 * np.abs(qo).max()
+    # single tet, free floating
+    v1 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float) * 0.1
+    t1 = np.array([[0, 1, 2, 3]], np.int32)
+    g1 = FemIntegrator(v1, t1, [])
+    g1.set_uniform_force(1, -1.0)
+    assert g1.do_timestep() > 0
+    o1 = OrcFem(v1, t1)
+    o1.integrator(np.zeros(0, np.int32))
+    f1 = np.zeros(12)
+    f1[1::3] = -1.0
+    o1.set_external_forces(f1)
+    o1.step()
+    assert np.abs(g1.get_q_state()[0] - o1.get_state()[0]).max() <= 1e-6 * np.abs(o1.get_state()[0]).max()
+    # constrained DOFs that do not cover whole nodes
+    odd = np.array([0, 4, 5, 17, 30], np.int32)
+    g3 = FemIntegrator(v, t, odd)
+    o3 = OrcFem(v, t)
+    o3.integrator(odd)
+    g3.set_external_forces(f)
+    o3.set_external_forces(f)
+    g3.do_timestep()
+    o3.step()
+    q3 = g3.get_q_state()[0]
+    assert np.all(q3[odd] == 0) and np.abs(q3 - o3.get_state()[0]).max() <= 2e-4 * np.abs(q3).max()
+    # changing the constraints later takes effect at the next step
+    g3.set_constrained_dofs(fixed)
+    g3.reset_to_rest()
+    g3.set_external_forces(f)
+    g3.do_timestep()
+    assert np.abs(g3.get_q_state()[0] - qo).max() <= 2e-4 * np.abs(qo).max()

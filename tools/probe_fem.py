@@ -13,11 +13,12 @@ from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, tr
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 56
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 prec = fl.FB_MATRIX_F64 if (len(sys.argv) > 3 and sys.argv[3] == "f64") else fl.FB_MATRIX_F32
+variant = int(sys.argv[4]) if len(sys.argv) > 4 else fl.FB_PCG_MERGED
 t0 = time.time()
 v, t = truth_cube(n, n, n, 0.1)
 fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
 t1 = time.time()
-g = FemIntegrator(v, t, fixed, matrix_precision=prec)
+g = FemIntegrator(v, t, fixed, matrix_precision=prec, pcg_variant=variant)
 t2 = time.time()
 print("mesh %d nodes %d tets: gen %.2fs create %.2fs blocks %d" % (len(v), len(t), t1 - t0, t2 - t1, g.num_blocks()), flush=True)
 g.set_uniform_force(1, -10000.0)
