@@ -232,78 +232,106 @@ __global__ __launch_bounds__(kPB) void k_field_array(int n, const Instr* __restr
 
 __device__ inline int bit_at(const unsigned long long* __restrict__ m, long long i) { return (int)((m[i >> 6] >> (i & 63)) & 1ULL); }
 
-// ComputeCellConfigs (Polygonizer.cl:1564-1607) + TetMeshCells' included test (Tetrahedralizer.cl:3-35):
-// corner c = 4*dx + 2*dy + dz; included = config != 0.  One thread per cell, linear cell index cz*cx*cy + cy*cx + cx.
-__global__ __launch_bounds__(kPB) void k_cells(Grid G, const unsigned long long* __restrict__ inside, unsigned char* __restrict__ config,
-                                               unsigned long long* __restrict__ cinc, unsigned int* __restrict__ cinc_pop,
-                                               unsigned int* __restrict__ surf_pop) {
-  const long long cid = (long long)blockIdx.x * kPB + threadIdx.x;
-  int cfg = 0;
-  if (cid < G.n_cells) {
-    const int cxy = G.c[0] * G.c[1];
-    const int z = (int)(cid / cxy);
-    const int rem = (int)(cid - (long long)z * cxy);
-    const int y = rem / G.c[0], x = rem - y * G.c[0];
-    const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
-    const long long p = z * gxy + y * gx + x;
-    cfg = bit_at(inside, p) | (bit_at(inside, p + gxy) << 1) | (bit_at(inside, p + gx) << 2) | (bit_at(inside, p + gx + gxy) << 3) |
-          (bit_at(inside, p + 1) << 4) | (bit_at(inside, p + 1 + gxy) << 5) | (bit_at(inside, p + 1 + gx) << 6) |
-          (bit_at(inside, p + 1 + gx + gxy) << 7);
-    config[cid] = (unsigned char)cfg;
-  }
-  const unsigned long long inc = __ballot(cfg != 0);
-  const unsigned long long surf = __ballot(cfg != 0 && cfg != 255);
-  if ((threadIdx.x & 63) == 0 && cid < ((G.n_cells + 63) & ~63LL)) {
-    cinc[cid >> 6] = inc;
-    cinc_pop[cid >> 6] = __popcll(inc);
-    surf_pop[cid >> 6] = __popcll(surf);  // summed by the scan pass: no same-address atomics on the hot path
-  }
+// ---- classification on the inside bitmask, 64 grid points per thread -----------------------------------------
+// Point p = iz*gx*gy + iy*gx + ix is bit p of `inside`.  A cell is addressed by its lower-corner point (cells keep the
+// reference's linear order: the valid lower corners in increasing p), so every per-cell quantity is a bit array over
+// points as well and the reference's per-item passes become shifts of the bit array by 1, gx and gx*gy:
+//   cell config != 0   (Tetrahedralizer.cl:3-35, included)  = OR  of inside over the 8 corners   -> cinc
+//   cell config == 255 (Polygonizer.cl:1564-1607)           = AND of inside over the 8 corners   -> surface = cinc & ~all
+//   edge flags X/Y/Z   (Polygonizer.cl:1353-1415)           = inside ^ inside(+1 / +gx / +gx*gy), masked at the last x/y/z
+//   included vertices  (TetMeshCells' scatter-marks)        = OR of cinc over the 8 cells around the point -> vinc
+// word w of A shifted so that bit p holds A[p + k] (fwd) or A[p - k] (bwd); bits past either end read 0
+__device__ inline unsigned long long fwd_word(const unsigned long long* __restrict__ a, long long nwords, long long w, long long k) {
+  const long long q = w + (k >> 6);
+  const int r = (int)(k & 63);
+  unsigned long long lo = q < nwords ? a[q] : 0ULL;
+  if (r == 0) return lo;
+  const unsigned long long hi = (q + 1) < nwords ? a[q + 1] : 0ULL;
+  return (lo >> r) | (hi << (64 - r));
+}
+__device__ inline unsigned long long bwd_word(const unsigned long long* __restrict__ a, long long nwords, long long w, long long k) {
+  const long long q = w - (k >> 6);
+  const int r = (int)(k & 63);
+  unsigned long long hi = (q >= 0 && q < nwords) ? a[q] : 0ULL;
+  if (r == 0) return hi;
+  const unsigned long long lo = (q - 1 >= 0) ? a[q - 1] : 0ULL;
+  return (hi << r) | (lo >> (64 - r));
 }
 
-// ComputeEdgeTable (Polygonizer.cl:1353-1415): flags X=4, Y=2, Z=1 for the +x/+y/+z edges whose ends differ in
-// (f >= iso); plus TetMeshCells' vertex marking restated as a gather: a grid point is a tet-mesh vertex when one of
-// the (up to 8) cells it is a corner of is included.
-__global__ __launch_bounds__(kPB) void k_points(Grid G, const unsigned long long* __restrict__ inside,
-                                                const unsigned long long* __restrict__ cinc, unsigned char* __restrict__ flags,
-                                                unsigned long long* __restrict__ vinc, unsigned int* __restrict__ vinc_pop,
-                                                unsigned int* __restrict__ edge_pop) {
+// one-time per grid: bits of the points with ix == gx-1 / iy == gy-1 / iz == gz-1 and of the points inside the grid
+__global__ __launch_bounds__(kPB) void k_grid_masks(Grid G, unsigned long long* __restrict__ lastx, unsigned long long* __restrict__ lasty,
+                                                    unsigned long long* __restrict__ lastz, unsigned long long* __restrict__ valid) {
   const long long gid = (long long)blockIdx.x * kPB + threadIdx.x;
-  int fl = 0, inc = 0;
+  bool lx = false, ly = false, lz = false, in = false;
   if (gid < G.n_points) {
     const int gxy = G.g[0] * G.g[1];
     const int z = (int)(gid / gxy);
     const int rem = (int)(gid - (long long)z * gxy);
     const int y = rem / G.g[0], x = rem - y * G.g[0];
-    const int me = bit_at(inside, gid);
-    if (x + 1 < G.g[0] && (me ^ bit_at(inside, gid + 1))) fl |= 4;
-    if (y + 1 < G.g[1] && (me ^ bit_at(inside, gid + G.g[0]))) fl |= 2;
-    if (z + 1 < G.g[2] && (me ^ bit_at(inside, gid + gxy))) fl |= 1;
-    flags[gid] = (unsigned char)fl;
-    const long long cxy = (long long)G.c[0] * G.c[1];
-    for (int dz = 0; dz < 2; dz++) {
-      const int cz = z - dz;
-      if (cz < 0 || cz >= G.c[2]) continue;
-      for (int dy = 0; dy < 2; dy++) {
-        const int cy = y - dy;
-        if (cy < 0 || cy >= G.c[1]) continue;
-        for (int dx = 0; dx < 2; dx++) {
-          const int cx = x - dx;
-          if (cx < 0 || cx >= G.c[0]) continue;
-          inc |= bit_at(cinc, cz * cxy + (long long)cy * G.c[0] + cx);
-        }
-      }
-    }
+    lx = x == G.g[0] - 1; ly = y == G.g[1] - 1; lz = z == G.g[2] - 1; in = true;
   }
-  const unsigned long long vb = __ballot(inc);
-  const int nf = __popc(fl);
-  // wave total of crossed edges
-  int s = nf;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  const unsigned long long bx = __ballot(lx), by = __ballot(ly), bz = __ballot(lz), bv = __ballot(in);
   if ((threadIdx.x & 63) == 0 && gid < ((G.n_points + 63) & ~63LL)) {
-    vinc[gid >> 6] = vb;
-    vinc_pop[gid >> 6] = __popcll(vb);
-    edge_pop[gid >> 6] = (unsigned int)s;
+    lastx[gid >> 6] = bx; lasty[gid >> 6] = by; lastz[gid >> 6] = bz; valid[gid >> 6] = bv;
+  }
+}
+
+__global__ __launch_bounds__(kPB) void k_classify_bits(Grid G, long long nwords, const unsigned long long* __restrict__ inside,
+                                                       const unsigned long long* __restrict__ lastx, const unsigned long long* __restrict__ lasty,
+                                                       const unsigned long long* __restrict__ lastz, const unsigned long long* __restrict__ valid,
+                                                       unsigned long long* __restrict__ cinc, unsigned long long* __restrict__ crossx,
+                                                       unsigned long long* __restrict__ crossy, unsigned long long* __restrict__ crossz,
+                                                       unsigned int* __restrict__ cinc_pop, unsigned int* __restrict__ aux_pop) {
+  const long long w = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (w >= nwords) return;
+  const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
+  const unsigned long long c0 = inside[w];
+  const unsigned long long cx = fwd_word(inside, nwords, w, 1), cy = fwd_word(inside, nwords, w, gx), cz = fwd_word(inside, nwords, w, gxy);
+  const unsigned long long cxy = fwd_word(inside, nwords, w, gx + 1), cxz = fwd_word(inside, nwords, w, gxy + 1),
+                           cyz = fwd_word(inside, nwords, w, gxy + gx), cxyz = fwd_word(inside, nwords, w, gxy + gx + 1);
+  const unsigned long long lx = lastx[w], ly = lasty[w], lz = lastz[w], vd = valid[w];
+  const unsigned long long cellok = vd & ~(lx | ly | lz);
+  const unsigned long long any = (c0 | cx | cy | cz | cxy | cxz | cyz | cxyz) & cellok;
+  const unsigned long long all = (c0 & cx & cy & cz & cxy & cxz & cyz & cxyz) & cellok;
+  const unsigned long long ex = (c0 ^ cx) & vd & ~lx, ey = (c0 ^ cy) & vd & ~ly, ez = (c0 ^ cz) & vd & ~lz;
+  cinc[w] = any; crossx[w] = ex; crossy[w] = ey; crossz[w] = ez;
+  cinc_pop[w] = (unsigned int)__popcll(any);
+  // two counters packed for the sum pass: crossed edges (low 16 bits: <= 192) and surface cells (high bits: <= 64)
+  aux_pop[w] = (unsigned int)(__popcll(ex) + __popcll(ey) + __popcll(ez)) | ((unsigned int)__popcll(any & ~all) << 16);
+}
+
+__global__ __launch_bounds__(kPB) void k_vertex_bits(Grid G, long long nwords, const unsigned long long* __restrict__ cinc,
+                                                     unsigned long long* __restrict__ vinc, unsigned int* __restrict__ vinc_pop) {
+  const long long w = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (w >= nwords) return;
+  const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
+  // cinc is 0 at every invalid lower corner (last x / y / z), so the backward shifts cannot leak across rows or planes
+  const unsigned long long v = cinc[w] | bwd_word(cinc, nwords, w, 1) | bwd_word(cinc, nwords, w, gx) | bwd_word(cinc, nwords, w, gxy) |
+                               bwd_word(cinc, nwords, w, gx + 1) | bwd_word(cinc, nwords, w, gxy + 1) | bwd_word(cinc, nwords, w, gxy + gx) |
+                               bwd_word(cinc, nwords, w, gxy + gx + 1);
+  vinc[w] = v;
+  vinc_pop[w] = (unsigned int)__popcll(v);
+}
+
+// on-demand materialisation of the reference's per-item outputs for read-back: edge flags (X=4,Y=2,Z=1) per point and
+// the 8-bit configuration per cell (corner c = 4*dx + 2*dy + dz, cell index cz*cx*cy + cy*cx + cx)
+__global__ __launch_bounds__(kPB) void k_materialize(Grid G, const unsigned long long* __restrict__ inside,
+                                                     const unsigned long long* __restrict__ crossx, const unsigned long long* __restrict__ crossy,
+                                                     const unsigned long long* __restrict__ crossz, unsigned char* __restrict__ flags,
+                                                     unsigned char* __restrict__ config) {
+  const long long gid = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (gid >= G.n_points) return;
+  const int gxy = G.g[0] * G.g[1];
+  const int z = (int)(gid / gxy);
+  const int rem = (int)(gid - (long long)z * gxy);
+  const int y = rem / G.g[0], x = rem - y * G.g[0];
+  flags[gid] = (unsigned char)((bit_at(crossx, gid) << 2) | (bit_at(crossy, gid) << 1) | bit_at(crossz, gid));
+  if (x < G.c[0] && y < G.c[1] && z < G.c[2]) {
+    const long long gx = G.g[0], gxyl = (long long)gxy, p = gid;
+    const int cfg = bit_at(inside, p) | (bit_at(inside, p + gxyl) << 1) | (bit_at(inside, p + gx) << 2) | (bit_at(inside, p + gx + gxyl) << 3) |
+                    (bit_at(inside, p + 1) << 4) | (bit_at(inside, p + 1 + gxyl) << 5) | (bit_at(inside, p + 1 + gx) << 6) |
+                    (bit_at(inside, p + 1 + gx + gxyl) << 7);
+    config[(long long)z * G.c[0] * G.c[1] + (long long)y * G.c[0] + x] = (unsigned char)cfg;
   }
 }
 
@@ -333,35 +361,47 @@ __global__ __launch_bounds__(kPB) void k_chunk_sums(const unsigned int* __restri
                                                     unsigned int* __restrict__ sums, unsigned int* __restrict__ aux_sums) {
   __shared__ unsigned int sh[4];
   const int base = blockIdx.x * kChunk;
-  unsigned int a = 0, b = 0;
+  unsigned int a = 0, b = 0, c = 0;
   for (int k = 0; k < kChunk / kPB; k++) {
     const int i = base + k * kPB + threadIdx.x;
-    if (i < n) { a += in[i]; b += aux[i]; }
+    if (i < n) {
+      a += in[i];
+      if (aux) { const unsigned int v = aux[i]; b += v & 0xFFFFu; c += v >> 16; }
+    }
   }
-  unsigned int ta, tb;
+  unsigned int ta, tb, tc;
   block_excl_scan256(a, &ta, sh);
   block_excl_scan256(b, &tb, sh);
-  if (threadIdx.x == 0) { sums[blockIdx.x] = ta; aux_sums[blockIdx.x] = tb; }
+  block_excl_scan256(c, &tc, sh);
+  if (threadIdx.x == 0) {
+    sums[blockIdx.x] = ta;
+    if (aux) { aux_sums[2 * blockIdx.x] = tb; aux_sums[2 * blockIdx.x + 1] = tc; }
+  }
 }
 
 // one block: exclusive scan of up to 16*kPB chunk sums in place; totals out
 __global__ __launch_bounds__(kPB) void k_scan_chunks(unsigned int* __restrict__ sums, const unsigned int* __restrict__ aux_sums, int nchunks,
                                                      unsigned int* __restrict__ total_out, unsigned int* __restrict__ aux_total_out) {
+  // aux_sums: two counters per chunk (may be null); aux_total_out[0], [1] receive their totals
   __shared__ unsigned int sh[4];
-  unsigned int carry = 0, aux = 0;
+  unsigned int carry = 0, aux = 0, aux2 = 0;
   for (int base = 0; base < nchunks; base += kPB) {
     const int i = base + threadIdx.x;
     const unsigned int v = i < nchunks ? sums[i] : 0u;
-    aux += i < nchunks ? aux_sums[i] : 0u;
+    if (aux_sums && i < nchunks) { aux += aux_sums[2 * i]; aux2 += aux_sums[2 * i + 1]; }
     unsigned int tot;
     const unsigned int ex = block_excl_scan256(v, &tot, sh);
     if (i < nchunks) sums[i] = carry + ex;
     carry += tot;
     __syncthreads();
   }
-  unsigned int auxtot;
+  unsigned int auxtot, auxtot2;
   block_excl_scan256(aux, &auxtot, sh);
-  if (threadIdx.x == 0) { *total_out = carry; *aux_total_out = auxtot; }
+  block_excl_scan256(aux2, &auxtot2, sh);
+  if (threadIdx.x == 0) {
+    *total_out = carry;
+    if (aux_sums) { aux_total_out[0] = auxtot; aux_total_out[1] = auxtot2; }
+  }
 }
 
 __global__ __launch_bounds__(kPB) void k_chunk_scan(const unsigned int* __restrict__ in, int n, const unsigned int* __restrict__ chunk_base,
@@ -404,27 +444,22 @@ __global__ __launch_bounds__(kPB) void k_tet_vertices(Grid G, const unsigned lon
 }
 
 // TetMeshElements (Tetrahedralizer.cl:67-132): 6 tets per included cell, corners LBN,LBF,LTN,LTF,RBN,RBF,RTN,RTF = 0..7.
-// A wavefront covers exactly one 64-cell word of the included mask, so its output is the contiguous range
+// A wavefront covers exactly one 64-bit word of the included-cell mask (cells addressed by their lower-corner point), so its output is the contiguous range
 // [6*cbase[word], 6*(cbase[word]+popc)) of uint4 records: lanes stage their 6 records in LDS at their rank inside the
 // word and the wave then streams the range out with lane-contiguous 16-byte stores.
 __global__ __launch_bounds__(kPB) void k_tet_elements(Grid G, const unsigned long long* __restrict__ cinc,
                                                       const unsigned int* __restrict__ cbase, const unsigned long long* __restrict__ vinc,
                                                       const unsigned int* __restrict__ vbase, uint4* __restrict__ tets) {
   __shared__ uint4 stage[kPB / 64][64 * 6];
-  const long long cid = (long long)blockIdx.x * kPB + threadIdx.x;
+  const long long p = (long long)blockIdx.x * kPB + threadIdx.x;  // lower-corner grid point of the cell
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long long word = cid >> 6;
-  if (word >= ((G.n_cells + 63) >> 6)) return;  // wave-uniform
+  const long long word = p >> 6;
+  if (word >= ((G.n_points + 63) >> 6)) return;  // wave-uniform
   const unsigned long long mask = cinc[word];
-  if (mask == 0ULL) return;                     // wave-uniform
+  if (mask == 0ULL) return;                      // wave-uniform
   const bool inc = (mask >> lane) & 1ULL;
   if (inc) {
-    const int cxy = G.c[0] * G.c[1];
-    const int z = (int)(cid / cxy);
-    const int rem = (int)(cid - (long long)z * cxy);
-    const int y = rem / G.c[0], x = rem - y * G.c[0];
     const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
-    const long long p = z * gxy + y * gx + x;
     unsigned int c[8];
     c[0] = rank_of(vinc, vbase, p);
     c[1] = rank_of(vinc, vbase, p + gxy);
@@ -462,11 +497,11 @@ struct fb_poly_s {
   DevBuf<Instr> d_prog;
   DevBuf<float> d_prims, d_mtx;
   Grid G;
-  bool have_grid = false, classified = false, tetra = false;
+  bool have_grid = false, classified = false, tetra = false, materialized = false;
   DevBuf<float4> grid;
-  DevBuf<unsigned long long> inside, cinc, vinc;
+  DevBuf<unsigned long long> inside, cinc, vinc, lastx, lasty, lastz, valid, crossx, crossy, crossz;
   DevBuf<unsigned char> config, flags;
-  DevBuf<unsigned int> cinc_pop, vinc_pop, surf_pop, edge_pop, cbase, vbase, csum, vsum, csum_aux, vsum_aux;
+  DevBuf<unsigned int> cinc_pop, vinc_pop, aux_pop, cbase, vbase, csum, vsum, csum_aux;
   DevBuf<unsigned int> totals;  // [0] crossed edges [1] surface cells [2] included cells [3] tet vertices
   DevBuf<float> tv;
   DevBuf<uint4> tt;
@@ -557,47 +592,46 @@ int set_grid(fb_poly_s* h, const float lo[3], float cellsize, const int dims[3])
   }
   if (G.n_points >= (1LL << 31)) return fail(FB_EINVAL, "grid too large");
   h->G = G;
-  const size_t pw = (size_t)((G.n_points + 63) / 64), cw = (size_t)((G.n_cells + 63) / 64);
+  const size_t pw = (size_t)((G.n_points + 63) / 64);
   FB_TRY(h->grid.alloc((size_t)G.n_points));
-  FB_TRY(h->inside.alloc(pw + 1));
-  FB_TRY(h->vinc.alloc(pw + 1));
-  FB_TRY(h->cinc.alloc(cw + 1));
+  DevBuf<unsigned long long>* masks[] = {&h->inside, &h->cinc, &h->vinc, &h->lastx, &h->lasty, &h->lastz, &h->valid, &h->crossx, &h->crossy, &h->crossz};
+  for (auto* m : masks) FB_TRY(m->alloc(pw + 1));
   FB_TRY(h->vinc_pop.alloc(pw));
   FB_TRY(h->vbase.alloc(pw));
-  FB_TRY(h->cinc_pop.alloc(cw));
-  FB_TRY(h->cbase.alloc(cw));
-  FB_TRY(h->surf_pop.alloc(cw));
-  FB_TRY(h->edge_pop.alloc(pw));
-  const size_t pch = (pw + kChunk - 1) / kChunk, cch = (cw + kChunk - 1) / kChunk;
+  FB_TRY(h->cinc_pop.alloc(pw));
+  FB_TRY(h->cbase.alloc(pw));
+  FB_TRY(h->aux_pop.alloc(pw));
+  const size_t pch = (pw + kChunk - 1) / kChunk;
   if (pch > 16 * kPB) return fail(FB_EINVAL, "grid too large for the chunked scan");
   FB_TRY(h->vsum.alloc(pch));
-  FB_TRY(h->vsum_aux.alloc(pch));
-  FB_TRY(h->csum.alloc(cch));
-  FB_TRY(h->csum_aux.alloc(cch));
+  FB_TRY(h->csum.alloc(pch));
+  FB_TRY(h->csum_aux.alloc(2 * pch));
   FB_TRY(h->config.alloc((size_t)G.n_cells));
   FB_TRY(h->flags.alloc((size_t)G.n_points));
   FB_TRY(h->totals.alloc(4));
+  hipLaunchKernelGGL(k_grid_masks, dim3((int)((G.n_points + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, G, h->lastx.p, h->lasty.p, h->lastz.p, h->valid.p);
+  FB_HIP(hipGetLastError());
+  h->materialized = false;
   h->have_grid = h->classified = h->tetra = false;
   return FB_OK;
 }
 
 int do_classify(fb_poly_s* h) {
   const Grid& G = h->G;
-  FB_TRY(h->totals.zero(h->stream));
-  const int cb = (int)((G.n_cells + kPB - 1) / kPB), pb = (int)((G.n_points + kPB - 1) / kPB);
-  hipLaunchKernelGGL(k_cells, dim3(cb), dim3(kPB), 0, h->stream, G, h->inside.p, h->config.p, h->cinc.p, h->cinc_pop.p, h->surf_pop.p);
+  const long long pw = (long long)h->vinc_pop.n;
+  const int wb = (int)((pw + kPB - 1) / kPB), pch = (int)h->vsum.n;
+  hipLaunchKernelGGL(k_classify_bits, dim3(wb), dim3(kPB), 0, h->stream, G, pw, h->inside.p, h->lastx.p, h->lasty.p, h->lastz.p, h->valid.p, h->cinc.p,
+                     h->crossx.p, h->crossy.p, h->crossz.p, h->cinc_pop.p, h->aux_pop.p);
+  hipLaunchKernelGGL(k_vertex_bits, dim3(wb), dim3(kPB), 0, h->stream, G, pw, h->cinc.p, h->vinc.p, h->vinc_pop.p);
+  hipLaunchKernelGGL(k_chunk_sums, dim3(pch), dim3(kPB), 0, h->stream, h->cinc_pop.p, h->aux_pop.p, (int)pw, h->csum.p, h->csum_aux.p);
+  hipLaunchKernelGGL(k_chunk_sums, dim3(pch), dim3(kPB), 0, h->stream, h->vinc_pop.p, (const unsigned int*)nullptr, (int)pw, h->vsum.p, h->csum_aux.p);
+  // totals: [0] crossed edges, [1] surface cells (the two packed counters), [2] included cells, [3] tet vertices
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kPB), 0, h->stream, h->csum.p, h->csum_aux.p, pch, h->totals.p + 2, h->totals.p + 0);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kPB), 0, h->stream, h->vsum.p, (const unsigned int*)nullptr, pch, h->totals.p + 3, h->totals.p + 0);
+  hipLaunchKernelGGL(k_chunk_scan, dim3(pch), dim3(kPB), 0, h->stream, h->cinc_pop.p, (int)pw, h->csum.p, h->cbase.p);
+  hipLaunchKernelGGL(k_chunk_scan, dim3(pch), dim3(kPB), 0, h->stream, h->vinc_pop.p, (int)pw, h->vsum.p, h->vbase.p);
   FB_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_points, dim3(pb), dim3(kPB), 0, h->stream, G, h->inside.p, h->cinc.p, h->flags.p, h->vinc.p, h->vinc_pop.p, h->edge_pop.p);
-  FB_HIP(hipGetLastError());
-  const int cw = (int)h->cinc_pop.n, pw = (int)h->vinc_pop.n;
-  const int cch = (int)h->csum.n, pch = (int)h->vsum.n;
-  hipLaunchKernelGGL(k_chunk_sums, dim3(cch), dim3(kPB), 0, h->stream, h->cinc_pop.p, h->surf_pop.p, cw, h->csum.p, h->csum_aux.p);
-  hipLaunchKernelGGL(k_chunk_sums, dim3(pch), dim3(kPB), 0, h->stream, h->vinc_pop.p, h->edge_pop.p, pw, h->vsum.p, h->vsum_aux.p);
-  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kPB), 0, h->stream, h->csum.p, h->csum_aux.p, cch, h->totals.p + 2, h->totals.p + 1);
-  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kPB), 0, h->stream, h->vsum.p, h->vsum_aux.p, pch, h->totals.p + 3, h->totals.p + 0);
-  hipLaunchKernelGGL(k_chunk_scan, dim3(cch), dim3(kPB), 0, h->stream, h->cinc_pop.p, cw, h->csum.p, h->cbase.p);
-  hipLaunchKernelGGL(k_chunk_scan, dim3(pch), dim3(kPB), 0, h->stream, h->vinc_pop.p, pw, h->vsum.p, h->vbase.p);
-  FB_HIP(hipGetLastError());
+  h->materialized = false;
   return FB_OK;
 }
 
@@ -616,10 +650,10 @@ int fetch_counts(fb_poly_s* h) {
 
 int do_emit(fb_poly_s* h) {
   const Grid& G = h->G;
-  const int cb = (int)((G.n_cells + kPB - 1) / kPB), pb = (int)((G.n_points + kPB - 1) / kPB);
+  const int pb = (int)((G.n_points + kPB - 1) / kPB);
   hipLaunchKernelGGL(k_tet_vertices, dim3(pb), dim3(kPB), 0, h->stream, G, h->vinc.p, h->vbase.p, h->tv.p);
   FB_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_tet_elements, dim3(cb), dim3(kPB), 0, h->stream, G, h->cinc.p, h->cbase.p, h->vinc.p, h->vbase.p, h->tt.p);
+  hipLaunchKernelGGL(k_tet_elements, dim3(pb), dim3(kPB), 0, h->stream, G, h->cinc.p, h->cbase.p, h->vinc.p, h->vbase.p, h->tt.p);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -737,6 +771,12 @@ int fb_poly_read_classification(fb_poly_t h, unsigned char* edge_flags, unsigned
   CHECK_POLY(h);
   if (!h->classified) return fail(FB_EINVAL, "classify first");
   const size_t np = (size_t)h->G.n_points;
+  if (!h->materialized) {
+    hipLaunchKernelGGL(k_materialize, dim3((int)((np + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, h->G, h->inside.p, h->crossx.p, h->crossy.p,
+                       h->crossz.p, h->flags.p, h->config.p);
+    FB_HIP(hipGetLastError());
+    h->materialized = true;
+  }
   if (edge_flags || edge_counts) {
     std::vector<unsigned char> f(np);
     FB_TRY(h->flags.download(f.data(), np, h->stream));
