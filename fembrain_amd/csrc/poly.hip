@@ -202,10 +202,9 @@ __global__ __launch_bounds__(kPB) void k_sweep(Grid G, const Instr* __restrict__
   const long long gid = (long long)blockIdx.x * kPB + threadIdx.x;
   bool in = false;
   if (gid < G.n_points) {
-    const int gxy = G.g[0] * G.g[1];
-    const int iz = (int)(gid / gxy);
-    const int rem = (int)(gid - (long long)iz * gxy);
-    const int iy = rem / G.g[0], ix = rem - iy * G.g[0];
+    const unsigned int g32 = (unsigned int)gid, gx = (unsigned int)G.g[0], gxy = gx * (unsigned int)G.g[1];  // n_points < 2^31
+    const unsigned int iz = g32 / gxy, rem = g32 - iz * gxy;
+    const unsigned int iy = rem / gx, ix = rem - iy * gx;
     const float x = G.lo[0] + G.cellsize * (float)ix;
     const float y = G.lo[1] + G.cellsize * (float)iy;
     const float z = G.lo[2] + G.cellsize * (float)iz;
@@ -428,19 +427,35 @@ __device__ inline unsigned int rank_of(const unsigned long long* __restrict__ ma
   return base[i >> 6] + (unsigned int)__popcll(w & ((1ULL << (i & 63)) - 1ULL));
 }
 
-// TetMeshVertices (Tetrahedralizer.cl:39-64): included grid points compacted in grid order, xyz = the sweep's positions
+// TetMeshVertices (Tetrahedralizer.cl:39-64): included grid points compacted in grid order, xyz = the sweep's positions.
+// One wavefront = one 64-point word of the included-vertex mask: its output is the contiguous float range
+// [3*vbase[word], 3*(vbase[word]+popc)), staged in LDS and written with lane-contiguous stores.
 __global__ __launch_bounds__(kPB) void k_tet_vertices(Grid G, const unsigned long long* __restrict__ vinc,
                                                       const unsigned int* __restrict__ vbase, float* __restrict__ xyz) {
-  const long long gid = (long long)blockIdx.x * kPB + threadIdx.x;
-  if (gid >= G.n_points || !bit_at(vinc, gid)) return;
-  const int gxy = G.g[0] * G.g[1];
-  const int iz = (int)(gid / gxy);
-  const int rem = (int)(gid - (long long)iz * gxy);
-  const int iy = rem / G.g[0], ix = rem - iy * G.g[0];
-  const size_t o = 3 * (size_t)rank_of(vinc, vbase, gid);
-  xyz[o] = G.lo[0] + G.cellsize * (float)ix;
-  xyz[o + 1] = G.lo[1] + G.cellsize * (float)iy;
-  xyz[o + 2] = G.lo[2] + G.cellsize * (float)iz;
+  __shared__ float stage[kPB / 64][64 * 3];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long nwords = (G.n_points + 63) >> 6;
+  const long long nwaves = (long long)gridDim.x * (kPB / 64);
+  for (long long word = (long long)blockIdx.x * (kPB / 64) + wv; word < nwords; word += nwaves) {  // wave-uniform loop
+    const unsigned long long mask = vinc[word];
+    if (mask == 0ULL) continue;
+    if ((mask >> lane) & 1ULL) {
+      const unsigned int g32 = (unsigned int)(word * 64 + lane), gx = (unsigned int)G.g[0], gxy = gx * (unsigned int)G.g[1];
+      const unsigned int iz = g32 / gxy, rem = g32 - iz * gxy;
+      const unsigned int iy = rem / gx, ix = rem - iy * gx;
+      float* o = &stage[wv][3 * __popcll(mask & ((1ULL << lane) - 1ULL))];
+      o[0] = G.lo[0] + G.cellsize * (float)ix;
+      o[1] = G.lo[1] + G.cellsize * (float)iy;
+      o[2] = G.lo[2] + G.cellsize * (float)iz;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int total = 3 * __popcll(mask);
+    float* out = xyz + 3 * (size_t)vbase[word];
+    for (int i = lane; i < total; i += 64) out[i] = stage[wv][i];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
 }
 
 // TetMeshElements (Tetrahedralizer.cl:67-132): 6 tets per included cell, corners LBN,LBF,LTN,LTF,RBN,RBF,RTN,RTF = 0..7.
@@ -451,38 +466,41 @@ __global__ __launch_bounds__(kPB) void k_tet_elements(Grid G, const unsigned lon
                                                       const unsigned int* __restrict__ cbase, const unsigned long long* __restrict__ vinc,
                                                       const unsigned int* __restrict__ vbase, uint4* __restrict__ tets) {
   __shared__ uint4 stage[kPB / 64][64 * 6];
-  const long long p = (long long)blockIdx.x * kPB + threadIdx.x;  // lower-corner grid point of the cell
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long long word = p >> 6;
-  if (word >= ((G.n_points + 63) >> 6)) return;  // wave-uniform
-  const unsigned long long mask = cinc[word];
-  if (mask == 0ULL) return;                      // wave-uniform
-  const bool inc = (mask >> lane) & 1ULL;
-  if (inc) {
-    const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
-    unsigned int c[8];
-    c[0] = rank_of(vinc, vbase, p);
-    c[1] = rank_of(vinc, vbase, p + gxy);
-    c[2] = rank_of(vinc, vbase, p + gx);
-    c[3] = rank_of(vinc, vbase, p + gx + gxy);
-    c[4] = rank_of(vinc, vbase, p + 1);
-    c[5] = rank_of(vinc, vbase, p + 1 + gxy);
-    c[6] = rank_of(vinc, vbase, p + 1 + gx);
-    c[7] = rank_of(vinc, vbase, p + 1 + gx + gxy);
-    enum { LBN, LBF, LTN, LTF, RBN, RBF, RTN, RTF };
-    uint4* o = &stage[wv][6 * __popcll(mask & ((1ULL << lane) - 1ULL))];
-    o[0] = make_uint4(c[LBN], c[LTN], c[RBN], c[LBF]);
-    o[1] = make_uint4(c[RTN], c[LTN], c[LBF], c[RBN]);
-    o[2] = make_uint4(c[RTN], c[LTN], c[LTF], c[LBF]);
-    o[3] = make_uint4(c[RTN], c[RBN], c[LBF], c[RBF]);
-    o[4] = make_uint4(c[RTN], c[LBF], c[LTF], c[RBF]);
-    o[5] = make_uint4(c[RTN], c[LTF], c[RTF], c[RBF]);
+  const long long nwords = (G.n_points + 63) >> 6;
+  const long long nwaves = (long long)gridDim.x * (kPB / 64);
+  const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
+  for (long long word = (long long)blockIdx.x * (kPB / 64) + wv; word < nwords; word += nwaves) {  // wave-uniform loop
+    const unsigned long long mask = cinc[word];
+    if (mask == 0ULL) continue;
+    if ((mask >> lane) & 1ULL) {
+      const long long p = word * 64 + lane;  // lower-corner grid point of the cell
+      unsigned int c[8];
+      c[0] = rank_of(vinc, vbase, p);
+      c[1] = rank_of(vinc, vbase, p + gxy);
+      c[2] = rank_of(vinc, vbase, p + gx);
+      c[3] = rank_of(vinc, vbase, p + gx + gxy);
+      c[4] = rank_of(vinc, vbase, p + 1);
+      c[5] = rank_of(vinc, vbase, p + 1 + gxy);
+      c[6] = rank_of(vinc, vbase, p + 1 + gx);
+      c[7] = rank_of(vinc, vbase, p + 1 + gx + gxy);
+      enum { LBN, LBF, LTN, LTF, RBN, RBF, RTN, RTF };
+      uint4* o = &stage[wv][6 * __popcll(mask & ((1ULL << lane) - 1ULL))];
+      o[0] = make_uint4(c[LBN], c[LTN], c[RBN], c[LBF]);
+      o[1] = make_uint4(c[RTN], c[LTN], c[LBF], c[RBN]);
+      o[2] = make_uint4(c[RTN], c[LTN], c[LTF], c[LBF]);
+      o[3] = make_uint4(c[RTN], c[RBN], c[LBF], c[RBF]);
+      o[4] = make_uint4(c[RTN], c[LBF], c[LTF], c[RBF]);
+      o[5] = make_uint4(c[RTN], c[LTF], c[RTF], c[RBF]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int total = 6 * __popcll(mask);
+    uint4* out = tets + 6 * (size_t)cbase[word];
+    for (int i = lane; i < total; i += 64) out[i] = stage[wv][i];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  const int total = 6 * __popcll(mask);
-  uint4* out = tets + 6 * (size_t)cbase[word];
-  for (int i = lane; i < total; i += 64) out[i] = stage[wv][i];
 }
 
 }  // namespace
@@ -650,7 +668,7 @@ int fetch_counts(fb_poly_s* h) {
 
 int do_emit(fb_poly_s* h) {
   const Grid& G = h->G;
-  const int pb = (int)((G.n_points + kPB - 1) / kPB);
+  const int pb = (int)std::min<long long>((G.n_points + kPB - 1) / kPB, 4096);  // waves stride over the mask words
   hipLaunchKernelGGL(k_tet_vertices, dim3(pb), dim3(kPB), 0, h->stream, G, h->vinc.p, h->vbase.p, h->tv.p);
   FB_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_tet_elements, dim3(pb), dim3(kPB), 0, h->stream, G, h->cinc.p, h->cbase.p, h->vinc.p, h->vbase.p, h->tt.p);
