@@ -316,3 +316,80 @@ def test_ragged_inputs(gpu):
     g3.set_external_forces(f)
     g3.do_timestep()
     assert np.abs(g3.get_q_state()[0] - qo).max() <= 2e-4 * np.abs(qo).max()
+
+
+def test_integrator_surface_semantics(gpu):
+    """IntegratorBase-level calls behave as the reference's: force setters, state copies, reset, timestep / damping
+    changes, resync after a topology change (Deformable::syncForceModel) and the per-step element rebuild."""
+    n = 5
+    v, t, fixed = _cube(n)
+    g = FemIntegrator(v, t, fixed)
+    o = OrcFem(v, t)
+    o.integrator(fixed, timestep=0.02, cM=0.1, cK=0.02)
+    g.set_timestep(0.02)
+    g.set_damping(0.1, 0.02)
+    f1 = np.zeros(g.r)
+    f1[1::3] = -40.0
+    f2 = np.zeros(g.r)
+    f2[0::3] = 15.0
+    g.set_external_forces_to_zero()
+    g.add_external_forces(f1)
+    g.add_external_forces(f2)          # AddExternalForces accumulates
+    o.set_external_forces(f1 + f2)
+    rng = np.random.default_rng(2)
+    q0 = rng.normal(size=g.r) * 1e-3
+    v0 = rng.normal(size=g.r) * 1e-2
+    q0[fixed] = 0
+    v0[fixed] = 0
+    g.set_q_state(q0, v0)
+    qa, va, aa = g.get_q_state()
+    assert np.array_equal(qa, q0) and np.array_equal(va, v0) and not aa.any()   # copy semantics, qaccel forced 0
+    o.set_state(q0, v0)
+    g.rebuild_elements()               # same rest state: must not change the result
+    ig, io = g.do_timestep(), abs(o.step())
+    assert abs(ig - io) <= max(3, 0.02 * io)
+    assert np.abs(g.get_q_state()[0] - o.get_state()[0]).max() <= 2e-4 * np.abs(o.get_state()[0]).max()
+    assert g.get_force_assembly_time() > 0 and g.get_system_solve_time() > 0
+    g.reset_to_rest()
+    assert not g.get_q_state()[0].any() and not g.get_q_state()[1].any()
+    # resync with a different mesh (as after a cut): same handle, new topology, state reset
+    v2, t2, fixed2 = _cube(6)
+    g.resync(v2, t2, fixed2)
+    o2 = OrcFem(v2, t2)
+    o2.integrator(fixed2, timestep=0.02, cM=0.1, cK=0.02)
+    bptr, bcol = g.pattern()
+    obptr, obcol = o2.blocks()
+    assert np.array_equal(bptr, obptr) and np.array_equal(bcol, obcol)
+    f = np.zeros(g.r)
+    f[1::3] = -100.0
+    g.set_external_forces(f)
+    o2.set_external_forces(f)
+    g.do_timestep()
+    o2.step()
+    assert np.abs(g.get_q_state()[0] - o2.get_state()[0]).max() <= 2e-4 * np.abs(o2.get_state()[0]).max()
+    # moved rest positions + rebuild_elements == a fresh handle on the moved mesh (the per-step K0 rebuild path)
+    with pytest.raises(fl.FbError):
+        g.set_timestep(0.0)
+    with pytest.raises(ValueError):
+        g.set_external_forces(np.zeros(5))
+
+
+def test_floor_collision_kernel_matches_reference_loop(gpu):
+    """Deformable.cpp:350-402 restated on the host vs fb_fem_floor_collision."""
+    n = 5
+    v, t, fixed = _cube(n)
+    g = FemIntegrator(v, t, fixed)
+    rng = np.random.default_rng(4)
+    q = rng.normal(size=g.r) * 0.05
+    qv = rng.normal(size=g.r)
+    g.set_q_state(q, qv)
+    floor_y = 0.03
+    hit = g.floor_collision(floor_y, 0.4)
+    pc = v[:, 1] + q[1::3]
+    assert hit == int((pc <= floor_y).sum())
+    q_ref, v_ref = q.copy(), qv.copy()
+    v_ref[1::3] = qv[1::3] - 1.4 * qv[1::3]          # vr = vp - 0.4 vn with n = +y
+    m = pc <= floor_y
+    q_ref[1::3][m] = floor_y - v[m, 1]
+    qg, vg, _ = g.get_q_state()
+    assert np.allclose(qg, q_ref, rtol=0, atol=1e-15) and np.allclose(vg, v_ref, rtol=1e-15, atol=1e-15)

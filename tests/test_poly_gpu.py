@@ -132,3 +132,74 @@ def test_sphere_256_properties(gpu):
     rr = np.sqrt((grid[:, :3].astype(np.float64) ** 2).sum(1))
     inside = grid[:, 3] >= 0.5
     assert inside[rr < 0.45].all() and not inside[rr > 0.46].any()
+
+
+def test_poly_error_paths_and_order(gpu):
+    from fembrain_amd import lib as fl
+    g = GpuPoly(sphere_blob())
+    with pytest.raises(fl.FbError):
+        g.classify()                        # nothing swept yet
+    with pytest.raises(fl.FbError):
+        g.sweep(0.001)                      # GPUPoly::run refuses cellsize < 0.01
+    g.sweep(0.2)
+    with pytest.raises(fl.FbError):
+        g.tetrahedralize()                  # classify first
+    c = g.classify()
+    assert c.n_points == int(np.prod(g.dims)) and c.n_cells == int(np.prod(np.array(g.dims) - 1))
+    g.tetrahedralize()
+    assert g.compute_field_array(np.zeros((0, 4), np.float32)).shape == (0, 4)
+    bad = sphere_blob()
+    bad.prims[0, 1] = 7                     # matrix index out of range
+    with pytest.raises(fl.FbError):
+        GpuPoly(bad)
+    loop = make_tree([(0, (0, 0, 0), (0, 0, 0), (0, 0, 0))] * 2, [(0, 0, 0, OF_LEFT_OP, 0, 0)])  # operator is its own child
+    with pytest.raises(fl.FbError):
+        GpuPoly(loop)
+
+
+def test_far_empty_grid_and_full_grid(gpu):
+    """Grids with no surface at all: everything outside (no tets) and everything inside (all cells, config 255)."""
+    g = GpuPoly(sphere_blob())
+    g.sweep_grid((5.0, 5.0, 5.0), 0.1, (9, 8, 7))
+    c = g.classify()
+    assert (c.n_crossed_edges, c.n_surface_cells, c.n_included_cells, c.n_tet_vertices) == (0, 0, 0, 0)
+    g.tetrahedralize()
+    xyz, tets = g.read_tetmesh()
+    assert len(xyz) == 0 and len(tets) == 0
+    g.sweep_grid((-0.05, -0.05, -0.05), 0.02, (6, 5, 7))
+    c = g.classify()
+    assert c.n_crossed_edges == 0 and c.n_surface_cells == 0
+    assert c.n_included_cells == 5 * 4 * 6 and c.n_tet_vertices == 6 * 5 * 7
+    flags, cnt, cfg = g.read_classification()
+    assert not flags.any() and (cfg == 255).all()
+    o = OrcPoly(sphere_blob())
+    o.sweep_grid((-0.05, -0.05, -0.05), 0.02, (6, 5, 7))
+    o.classify()
+    g.tetrahedralize()
+    xyz, tets = g.read_tetmesh()
+    oxyz, otets = o.tetrahedralize()
+    assert np.array_equal(tets, otets) and np.array_equal(xyz, oxyz)
+
+
+def test_non_multiple_of_64_row_length_grid(gpu):
+    """gx not a multiple of 64 and a total that is not a multiple of 64: words straddle rows and planes."""
+    blob = _trees()["nested"]
+    lo = np.array([-1.1, -0.9, -1.0], np.float32)
+    g = GpuPoly(blob)
+    g.sweep_grid(lo, 0.061, (37, 29, 33))
+    o = OrcPoly(blob)
+    og = o.sweep_grid(lo, 0.061, (37, 29, 33))
+    grid = g.read_grid()
+    safe = np.abs(og[:, 3] - 0.5) > 1e-5
+    assert np.abs(grid[:, 3] - og[:, 3]).max() <= 2e-6
+    oc = o.classify()
+    c = g.classify()
+    if safe.all():
+        flags, cnt, cfg = g.read_classification()
+        assert np.array_equal(flags, o.edge_flags) and np.array_equal(cfg, o.config)
+        assert (c.n_crossed_edges, c.n_surface_cells, c.n_included_cells, c.n_tet_vertices) == \
+            (oc["n_crossed_edges"], oc["n_surface_cells"], oc["n_included_cells"], oc["n_tet_vertices"])
+        g.tetrahedralize()
+        xyz, tets = g.read_tetmesh()
+        oxyz, otets = o.tetrahedralize()
+        assert np.array_equal(tets, otets) and np.array_equal(xyz, oxyz)
