@@ -103,7 +103,7 @@ __device__ inline double polar_rotation(const double* F, double* R, double tol) 
 //   f_e,i = V R [lambda tr(H) I + mu (H + H^T)] b_i,   H = sum_j (R^T x_j - x0_j) b_j^T
 // (equal to corotationalLinearFEM.cpp:238-286 with K0 = V B^T E B, whose 3x3 blocks are
 //   K0[ij] = V [lambda b_i b_j^T + mu b_j b_i^T + mu (b_i.b_j) I]).
-// rec[16*e + 3*k + d] = c_k[d] (MT), rec[16*e+12] = V; fe[12*e + 3*k + d] fp64.
+// rec[16*e + 4*k + d] = c_k[d] (MT), rec[16*e + 4*k + 3] = V; fe[12*e + 3*k + d] fp64.
 // ------------------------------------------------------------------------------------------------------
 template <typename MT>
 __global__ __launch_bounds__(kBlock) void k_tet_warp(int nt, const int4* __restrict__ tets, const double* __restrict__ x0,
@@ -166,11 +166,10 @@ __global__ __launch_bounds__(kBlock) void k_tet_warp(int nt, const int4* __restr
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       f[3 * k + a] = V * (R[3 * a] * sb[0] + R[3 * a + 1] * sb[1] + R[3 * a + 2] * sb[2]);
-      rc[3 * k + a] = (MT)c[a];
+      rc[4 * k + a] = (MT)c[a];
     }
+    rc[4 * k + 3] = (MT)V;  // V rides in the 4th lane of every gradient: one 4-wide load gives (c_k, V)
   }
-  rc[12] = (MT)V;
-  rc[13] = rc[14] = rc[15] = (MT)0;
   if (rot) {
 #pragma unroll
     for (int i = 0; i < 9; i++) rot[9 * (size_t)e + i] = R[i];
@@ -238,10 +237,12 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
         nc++;
         const uint32_t e = c >> 4;
         const int i = (c >> 2) & 3, j = c & 3;
-        const MT* r = rec + 16 * (size_t)e;
-        const double ci[3] = {(double)r[3 * i], (double)r[3 * i + 1], (double)r[3 * i + 2]};
-        const double cj[3] = {(double)r[3 * j], (double)r[3 * j + 1], (double)r[3 * j + 2]};
-        const double V = (double)r[12];
+        typedef MT mt4 __attribute__((ext_vector_type(4)));
+        const mt4* r = (const mt4*)(rec + 16 * (size_t)e);
+        const mt4 ri = r[i], rj = r[j];
+        const double ci[3] = {(double)ri.x, (double)ri.y, (double)ri.z};
+        const double cj[3] = {(double)rj.x, (double)rj.y, (double)rj.z};
+        const double V = (double)ri.w;
         const double dij = ci[0] * cj[0] + ci[1] * cj[1] + ci[2] * cj[2];
         const double vl = V * ap.lambda, vm = V * ap.mu;
 #pragma unroll

@@ -179,3 +179,48 @@ def test_blob_reader_and_veg_reader():
     assert sorted(refs) == list(range(1, c.n_ops))
     g = np.load(os.path.join(GOLD, "fem_beam3.npz"))
     assert g["verts"].shape == (208, 3) and g["tets"].max() == 207 and g["tets"].min() == 0
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 3])
+def test_contribution_lists_reassemble_the_oracle_matrix(n_ranks):
+    """Host emulation of the row-gather assembly (k_assemble_rows) from the plan's contribution lists: for every rank
+    and a sample of its owned rows, summing the oracle's element blocks K_e[i][j] over the listed (tet, i, j) gives the
+    oracle's assembled global rows -- checks local tet numbering, tet_global and the lists of sharded plans."""
+    n = 6
+    v, t = truth_cube(n, n, n)
+    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    o = OrcFem(v, t)
+    rng = np.random.default_rng(8)
+    u = rng.normal(size=o.r) * 0.01
+    _, Kglob = o.assemble(u)
+    ia, ja = o.csr()
+    obptr, obcol = o.blocks()
+    planes = [n * r // n_ranks for r in range(n_ranks + 1)]
+    splits = [p * n * n for p in planes]
+    total_valid = 0
+    for r in range(n_ranks):
+        info, get, (L, h) = _plan(v, t, fixed, n_ranks, r, splits)
+        l2g, tg, lt = get("local2global"), get("tet_global"), get("tets").reshape(-1, 4)
+        assert np.array_equal(l2g[lt], t[tg])  # local tets are the global ones, renumbered
+        contrib = get("contrib").view(np.uint32)
+        total_valid += int((contrib != 0xFFFFFFFF).sum())
+        coff, ccnt, bptr, bcol, blk_slot = get("slot_coff"), get("slot_ccnt"), get("bptr"), get("bcol"), get("blk_slot")
+        lo = splits[r]
+        for a in sorted(set([0, 1, info["n_owned"] // 3, info["n_owned"] - 1])):
+            ga = lo + a
+            for p in range(bptr[a], bptr[a + 1]):
+                slot = blk_slot[p]
+                blk = np.zeros((3, 3))
+                for rr in range(ccnt[slot]):
+                    c = int(contrib[(coff[slot] + rr) * 64 + a % 64])
+                    if c == 0xFFFFFFFF:
+                        continue
+                    e, i, j = c >> 4, (c >> 2) & 3, c & 3
+                    _, Ke, _ = o.element(int(tg[e]), u)
+                    blk += Ke[3 * i:3 * i + 3, 3 * j:3 * j + 3]
+                gb = l2g[bcol[p]]
+                pos = int(np.nonzero(obcol[obptr[ga]:obptr[ga + 1]] == gb)[0][0])
+                want = np.stack([Kglob[ia[3 * ga + k] + 3 * pos: ia[3 * ga + k] + 3 * pos + 3] for k in range(3)])
+                assert np.abs(blk - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
+        L.fb_plan_destroy(h)
+    assert total_valid == 16 * len(t)  # every (tet, i, j) is assembled by exactly one rank: the owner of node t[i]
