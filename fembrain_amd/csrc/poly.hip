@@ -29,6 +29,7 @@ namespace {
 
 constexpr int kPB = 256;  // threads per block
 constexpr float kIso = 0.5f;
+constexpr int kSweepPts = 4;  // 256-point runs per sweep block
 
 enum PrimType { primPoint, primLine, primCylinder, primDisc, primRing, primCube, primTriangle, primQuadricPoint, primNULL, primInstance, primRBF };
 enum OpType { opUnion, opIntersect, opDif, opSmoothDif, opBlend, opRicciBlend, opGradientBlend, opFastQuadricPointSet, opCache,
@@ -199,22 +200,28 @@ __global__ __launch_bounds__(kPB) void k_sweep(Grid G, const Instr* __restrict__
                                                const float* __restrict__ prims, const float* __restrict__ mtx,
                                                float4* __restrict__ grid, unsigned long long* __restrict__ inside) {
   extern __shared__ float stack[];
-  const long long gid = (long long)blockIdx.x * kPB + threadIdx.x;
-  bool in = false;
-  if (gid < G.n_points) {
-    const unsigned int g32 = (unsigned int)gid, gx = (unsigned int)G.g[0], gxy = gx * (unsigned int)G.g[1];  // n_points < 2^31
-    const unsigned int iz = g32 / gxy, rem = g32 - iz * gxy;
-    const unsigned int iy = rem / gx, ix = rem - iy * gx;
-    const float x = G.lo[0] + G.cellsize * (float)ix;
-    const float y = G.lo[1] + G.cellsize * (float)iy;
-    const float z = G.lo[2] + G.cellsize * (float)iz;
-    const float f = eval_field(prog, n_instr, n_prims, prims, mtx, x, y, z, stack + threadIdx.x);
-    if (grid) grid[gid] = make_float4(x, y, z, f);
-    in = f >= kIso;  // inside test of Polygonizer.cl:1367,1599 and Polygonizer.cpp:1052
+  // kSweepPts consecutive 256-point runs per block: every store instruction of a wave is still one contiguous 1 KiB
+  // float4 segment and every ballot one aligned 64-point word of the inside mask
+  const unsigned int gx = (unsigned int)G.g[0], gxy = gx * (unsigned int)G.g[1];  // n_points < 2^31
+#pragma unroll
+  for (int k = 0; k < kSweepPts; k++) {
+    const long long gid = ((long long)blockIdx.x * kSweepPts + k) * kPB + threadIdx.x;
+    bool in = false;
+    if (gid < G.n_points) {
+      const unsigned int g32 = (unsigned int)gid;
+      const unsigned int iz = g32 / gxy, rem = g32 - iz * gxy;
+      const unsigned int iy = rem / gx, ix = rem - iy * gx;
+      const float x = G.lo[0] + G.cellsize * (float)ix;
+      const float y = G.lo[1] + G.cellsize * (float)iy;
+      const float z = G.lo[2] + G.cellsize * (float)iz;
+      const float f = eval_field(prog, n_instr, n_prims, prims, mtx, x, y, z, stack + threadIdx.x);
+      if (grid) grid[gid] = make_float4(x, y, z, f);
+      in = f >= kIso;  // inside test of Polygonizer.cl:1367,1599 and Polygonizer.cpp:1052
+    }
+    const unsigned long long b = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && gid < ((G.n_points + 63) & ~63LL)) inside[gid >> 6] = b;
   }
   (void)depth;
-  const unsigned long long b = __ballot(in);
-  if ((threadIdx.x & 63) == 0 && gid < ((G.n_points + 63) & ~63LL)) inside[gid >> 6] = b;
 }
 
 // ComputeFieldArray (Polygonizer.cl:1262-1286)
@@ -476,14 +483,13 @@ __global__ __launch_bounds__(kPB) void k_tet_elements(Grid G, const unsigned lon
     if ((mask >> lane) & 1ULL) {
       const long long p = word * 64 + lane;  // lower-corner grid point of the cell
       unsigned int c[8];
+      // all 8 corners of an included cell are included vertices, and a rank is a prefix count in grid order, so the
+      // +x corner of each of the 4 (y,z) rows is simply the next rank
       c[0] = rank_of(vinc, vbase, p);
       c[1] = rank_of(vinc, vbase, p + gxy);
       c[2] = rank_of(vinc, vbase, p + gx);
       c[3] = rank_of(vinc, vbase, p + gx + gxy);
-      c[4] = rank_of(vinc, vbase, p + 1);
-      c[5] = rank_of(vinc, vbase, p + 1 + gxy);
-      c[6] = rank_of(vinc, vbase, p + 1 + gx);
-      c[7] = rank_of(vinc, vbase, p + 1 + gx + gxy);
+      c[4] = c[0] + 1; c[5] = c[1] + 1; c[6] = c[2] + 1; c[7] = c[3] + 1;
       enum { LBN, LBF, LTN, LTF, RBN, RBF, RTN, RTF };
       uint4* o = &stage[wv][6 * __popcll(mask & ((1ULL << lane) - 1ULL))];
       o[0] = make_uint4(c[LBN], c[LTN], c[RBN], c[LBF]);
@@ -591,7 +597,7 @@ size_t stack_bytes(const fb_poly_s* h) { return (size_t)std::max(1, h->depth) * 
 
 int do_sweep(fb_poly_s* h, bool store_grid) {
   const Grid& G = h->G;
-  const int blocks = (int)((G.n_points + kPB - 1) / kPB);
+  const int blocks = (int)((G.n_points + (long long)kPB * kSweepPts - 1) / ((long long)kPB * kSweepPts));
   hipLaunchKernelGGL(k_sweep, dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, h->d_prog.p, (int)h->prog.size(), h->n_prims, h->depth,
                      h->d_prims.p, h->d_mtx.p, store_grid ? h->grid.p : nullptr, h->inside.p);
   FB_HIP(hipGetLastError());
