@@ -57,20 +57,35 @@ def cpu_baseline(n, cg_iterations, sample_iters=40):
                       "extrapolated to the %d iterations the GPU run needed" % (t_asm, it, t_it * 1e3, cg_iterations)}
 
 
-def field_bench(device):
+def field_bench(device, cpu=True):
     """256^3 sweep + classify + tetrahedralize of sphere.blob (BASELINE config 3); returns extra JSON keys."""
-    try:
-        from fembrain_amd.poly import GpuPoly, sphere_blob
-    except Exception:
-        return {}
-    p = GpuPoly(sphere_blob(), device=device)
-    dims = p.sweep_grid((-0.5, -0.5, -0.5), 1.0 / 254.0, (256, 256, 256))
-    p.classify()
+    from fembrain_amd.poly import GpuPoly, sphere_blob
+    blob = sphere_blob()
+    lower, cell, dims = (-0.5, -0.5, -0.5), 1.0 / 254.0, (256, 256, 256)
+    p = GpuPoly(blob, device=device)
+    p.sweep_grid(lower, cell, dims)
+    c = p.classify()
     p.tetrahedralize()
-    sweep_s, pipe_s = p.time_pipeline(5)
+    sweep_s, pipe_s = p.time_pipeline(10)
     npts = dims[0] * dims[1] * dims[2]
-    return {"field_mvoxels_per_s": npts / pipe_s / 1e6, "field_sweep_mvoxels_per_s": npts / sweep_s / 1e6,
-            "field_grid": list(dims), "field_sweep_gbs": npts * 16 / sweep_s / 1e9}
+    out = {"field_mvoxels_per_s": npts / pipe_s / 1e6, "field_sweep_mvoxels_per_s": npts / sweep_s / 1e6, "field_grid": list(dims),
+           "field_sweep_gbs": npts * 16 / sweep_s / 1e9, "field_pipeline_us": pipe_s * 1e6, "field_tets": int(p.counts.n_tets),
+           "field_pipeline": "sweep (float4 per point) + edge/cell classification + scans + tet-mesh vertices and 6 tets per included cell"}
+    if cpu:
+        # bounded CPU sample: the oracle's scalar sweep + classification + tet emission on a 256x256x24 slab through the
+        # sphere's equator (1 core), scaled to points/s; the reference CPU polygonizer is TBB-parallel over cores
+        from oracle.pyfield import OrcPoly
+        o = OrcPoly(blob)
+        zs = 24
+        t0 = time.perf_counter()
+        o.sweep_grid((lower[0], lower[1], lower[2] + cell * 116), cell, (dims[0], dims[1], zs))
+        o.classify()
+        o.tetrahedralize()
+        dt = time.perf_counter() - t0
+        out["field_cpu_baseline"] = {"value": dims[0] * dims[1] * zs / dt / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+                                     "sample": "oracle/field_oracle.c, 256x256x%d slab of the same grid through the sphere, sweep+classify+tets" % zs}
+    p.close()
+    return out
 
 
 def main():
@@ -186,7 +201,7 @@ def main():
                          "algorithmic_bytes_per_launch": spmv_bytes, "us_per_launch": spmv_s * 1e6},
         }
     if world == 1 and not args.no_field:
-        extra = field_bench(local_rank)
+        extra = field_bench(local_rank, cpu=not args.no_cpu_baseline)
         if out is not None:
             out.update(extra)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -393,3 +393,60 @@ def test_floor_collision_kernel_matches_reference_loop(gpu):
     q_ref[1::3][m] = floor_y - v[m, 1]
     qg, vg, _ = g.get_q_state()
     assert np.allclose(qg, q_ref, rtol=0, atol=1e-15) and np.allclose(vg, v_ref, rtol=1e-15, atol=1e-15)
+
+
+def test_config2_105k_tets_one_step(gpu):
+    """BASELINE config 2 canonical mesh (27^3 nodes, 105,456 tets): one reference-load step against the oracle."""
+    n = 27
+    v, t, fixed = _cube(n)
+    o = OrcFem(v, t)
+    o.integrator(fixed)
+    g = FemIntegrator(v, t, fixed)
+    f = np.zeros(o.r)
+    f[1::3] = -10000.0
+    o.set_external_forces(f)
+    g.set_uniform_force(1, -10000.0)
+    io, ig = abs(o.step()), g.do_timestep()
+    qo, vo = o.get_state()
+    qg, vg, _ = g.get_q_state()
+    assert abs(io - ig) <= max(3, 0.02 * io), (io, ig)      # 1029 iterations in the reference build
+    assert abs(np.linalg.norm(qg) - 730.25) < 0.05          # SURVEY.md 8c: |q|_2 after step 1 of the full reference
+    assert np.abs(qg - qo).max() <= 2e-4 * np.abs(qo).max()
+    assert np.abs(vg - vo).max() <= 2e-3 * np.abs(vo).max()
+
+
+def test_full_size_1M_tet_properties(gpu):
+    """BASELINE config 4 mesh (998,250 tets): size-independent properties of the assembled operator and the solve."""
+    n = 56
+    v, t, fixed = _cube(n)
+    g = FemIntegrator(v, t, fixed)
+    assert g.num_blocks() == 2559646                        # SURVEY.md section 8 table
+    rng = np.random.default_rng(11)
+    # mass: sum over all blocks = rho * volume (each tet contributes rho V /20 * (4*2 + 12*1) = rho V)
+    assert abs(g.mass().sum() - 1000.0 * (0.1 * (n - 1)) ** 3) <= 1e-6 * 1000.0 * (0.1 * (n - 1)) ** 3
+    # internal forces of any displacement field sum to zero (translation invariance of every element)
+    u = rng.normal(size=g.r) * 1e-3
+    fint, _ = g.assemble(u)
+    assert np.abs(fint.reshape(-1, 3).sum(0)).max() <= 1e-9 * np.abs(fint).sum()
+    # a rigid translation produces no internal force at all
+    ft, _ = g.assemble(np.tile([0.3, -0.2, 0.1], len(v)))
+    assert np.abs(ft).max() <= 1e-6 * np.abs(fint).max()
+    # SpMV of the assembled Keff: linear and symmetric
+    g.set_uniform_force(1, -10000.0)
+    g.system()
+    x, y = rng.normal(size=g.r), rng.normal(size=g.r)
+    Ax, Ay = g.spmv(x), g.spmv(y)
+    assert np.abs(g.spmv(2.0 * x - 3.0 * y) - (2.0 * Ax - 3.0 * Ay)).max() <= 1e-12 * np.abs(Ax).max()
+    assert abs(y @ Ax - x @ Ay) <= 1e-12 * abs(y @ Ax)
+    assert np.array_equal(Ax[fixed], x[fixed])              # identity rows on the clamped plane
+    # one full step: converged, and the returned dv really solves the system to the reference tolerance
+    K, rhs = g.system()
+    it, dv = g.pcg(rhs, eps=1e-6, max_iter=10000)
+    assert 1000 < it < 3000
+    res = rhs - g.spmv(dv)
+    bptr, bcol = g.pattern()
+    diag = np.empty(g.r)
+    isdiag = bcol == np.repeat(np.arange(len(v)), np.diff(bptr))
+    diag.reshape(-1, 3)[:] = np.stack([K[isdiag][:, k, k] for k in range(3)], 1)
+    assert (res * res / diag).sum() <= 1.5e-12 * (rhs * rhs / diag).sum()   # sum r^2/D <= eps^2 sum r0^2/D
+    assert not dv[fixed].any()
