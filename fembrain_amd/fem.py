@@ -201,6 +201,32 @@ def bsr_to_scipy(bptr, bcol, blocks, n_cols_nodes=None):
     return sp.bsr_matrix((np.asarray(blocks).reshape(-1, 3, 3), bcol, bptr), shape=(3 * n_rows, 3 * n_cols)).tocsr()
 
 
+def spread_haptic_forces(bptr, bcol, indices, forces, neighborhood_size, ext_forces):
+    """``Deformable::applyHapticForces`` (reference src/deformable/Deformable.cpp:634-706): the force of each haptic
+    vertex is added to it and, with the linear fall-off (size - j) / size, to the vertices first reached in ring
+    j = 1 .. size-1 of a breadth-first walk over mesh edges.  Node neighbours are the off-diagonal columns of the
+    stiffness pattern (= vertices sharing a tet edge; the reference's ``VolMesh::get_node_neighbors`` intends exactly
+    that set -- its ``const_edgeAt(i)`` indexing slip, VolMesh.cpp:1346-1363, is not reproduced).  Adds in place."""
+    for idx, frc in zip(indices, forces):
+        ext_forces[3 * idx:3 * idx + 3] += frc
+    for idx, frc in zip(indices, forces):
+        affected, last = {int(idx)}, {int(idx)}
+        for j in range(1, neighborhood_size):
+            mag = 1.0 * (neighborhood_size - j) / float(neighborhood_size)
+            new = set()
+            for vtx in last:
+                for nb in bcol[bptr[vtx]:bptr[vtx + 1]]:
+                    nb = int(nb)
+                    if nb != vtx and nb not in affected:
+                        new.add(nb)
+            last = set()
+            for nb in sorted(new):
+                ext_forces[3 * nb:3 * nb + 3] += mag * np.asarray(frc, dtype=np.float64)
+                last.add(nb)
+                affected.add(nb)
+    return ext_forces
+
+
 class Deformable:
     """Per-step driver of ``Deformable::timestep`` (reference src/deformable/Deformable.cpp:318-420) without the
     scene-graph / GL parts: external forces (gravity -10000 per y-DOF unless a collision happened in the previous
@@ -219,6 +245,8 @@ class Deformable:
         self.ct_timestep = 0
         self.haptic_indices, self.haptic_forces = [], []
         self.haptic_in_progress = False
+        self.haptic_force_neighborhood_size = 5  # DEFAULT_FORCE_NEIGHBORHOOD_SIZE, Deformable.h:41
+        self._pattern = None
         self.on_deform = None  # FOnApplyDeformations(dof, q), Deformable.h:46
 
     def set_deform_callback(self, fn):
@@ -226,6 +254,12 @@ class Deformable:
 
     def haptic_set_current_forces(self, indices, forces):
         self.haptic_indices, self.haptic_forces = list(indices), [tuple(f) for f in forces]
+
+    def set_haptic_force_radius(self, radius):
+        self.haptic_force_neighborhood_size = int(radius)
+
+    def get_haptic_force_radius(self):
+        return self.haptic_force_neighborhood_size
 
     def haptic_start(self, index):
         self.haptic_in_progress = True
@@ -241,8 +275,10 @@ class Deformable:
             f = np.zeros(self.dof)
             if apply_gravity:
                 f[1::3] += self.GRAVITY_FORCE
-            for idx, frc in zip(self.haptic_indices, self.haptic_forces):
-                f[3 * idx:3 * idx + 3] += frc
+            if self._pattern is None:
+                self._pattern = it.pattern()
+            spread_haptic_forces(self._pattern[0], self._pattern[1], self.haptic_indices, self.haptic_forces,
+                                 self.haptic_force_neighborhood_size, f)
             it.set_external_forces(f)
         elif apply_gravity:
             it.set_uniform_force(1, self.GRAVITY_FORCE)

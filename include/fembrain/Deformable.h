@@ -115,12 +115,7 @@ class Deformable {
       std::fill(m_arrExtForces.begin(), m_arrExtForces.end(), 0.0);
       if (applyGravity)
         for (U32 i = 1; i < m_dof; i += 3) m_arrExtForces[i] += -10000.0;
-      for (size_t i = 0; i < m_vHapticIndices.size(); i++) {
-        const int v = m_vHapticIndices[i];
-        m_arrExtForces[3 * v + 0] += m_vHapticForces[i].x;
-        m_arrExtForces[3 * v + 1] += m_vHapticForces[i].y;
-        m_arrExtForces[3 * v + 2] += m_vHapticForces[i].z;
-      }
+      applyHapticForces();
       m_lpIntegrator->SetExternalForces(m_arrExtForces.data());
     } else if (applyGravity) {
       m_lpIntegrator->SetUniformForce(1, -10000.0);
@@ -145,6 +140,7 @@ class Deformable {
     else m_lpIntegrator = new HipIntegrator(n, m_rest.data(), m, m_elements.data(), (int)m_vFixedDofs.size(), m_vFixedDofs.data(),
                                             m_timeStep, m_dampingMassCoeff, m_dampingStiffnessCoeff, 1e7, 0.46, 1000.0, m_device);
     m_q.assign(m_dof, 0.0); m_qVel.assign(m_dof, 0.0); m_arrExtForces.assign(m_dof, 0.0);
+    m_bptr.clear(); m_bcol.clear();
     return true;
   }
   void setMesh(int numVertices, const double* rest, int numElements, const int* elements) {
@@ -181,6 +177,49 @@ class Deformable {
     return m_lpIntegrator->setConstrainedDOF((int)m_vFixedDofs.size(), m_vFixedDofs.data());
   }
 
+  // Deformable::applyHapticForces (Deformable.cpp:634-706): each haptic force acts on its vertex and, with the linear
+  // fall-off (size - j)/size, on the vertices first reached in ring j of a breadth-first walk over mesh edges.  Vertex
+  // neighbours are the off-diagonal columns of the stiffness pattern (vertices sharing a tet edge).
+  bool applyHapticForces() {
+    if (m_vHapticIndices.empty() || !m_bHapticInProgress) return false;
+    if (m_bptr.empty()) {
+      m_bptr.resize(m_rest.size() / 3 + 1);
+      m_bcol.resize(fb_fem_num_blocks(m_lpIntegrator->handle()));
+      if (fb_fem_pattern(m_lpIntegrator->handle(), m_bptr.data(), m_bcol.data()) != FB_OK) return false;
+    }
+    for (size_t i = 0; i < m_vHapticIndices.size(); i++) {
+      const int v = m_vHapticIndices[i];
+      m_arrExtForces[3 * v + 0] += m_vHapticForces[i].x;
+      m_arrExtForces[3 * v + 1] += m_vHapticForces[i].y;
+      m_arrExtForces[3 * v + 2] += m_vHapticForces[i].z;
+    }
+    for (size_t iv = 0; iv < m_vHapticIndices.size(); iv++) {
+      std::vector<char> affected(m_rest.size() / 3, 0);
+      std::vector<int> last(1, m_vHapticIndices[iv]);
+      affected[m_vHapticIndices[iv]] = 1;
+      const vec3d f = m_vHapticForces[iv];
+      for (int j = 1; j < m_hapticForceNeighorhoodSize; j++) {
+        const double mag = 1.0 * (m_hapticForceNeighorhoodSize - j) / static_cast<double>(m_hapticForceNeighorhoodSize);
+        std::vector<int> fresh;
+        for (size_t a = 0; a < last.size(); a++)
+          for (int p = m_bptr[last[a]]; p < m_bptr[last[a] + 1]; p++) {
+            const int nb = m_bcol[p];
+            if (!affected[nb]) { affected[nb] = 2; fresh.push_back(nb); }  // 2 = discovered in this ring
+          }
+        std::sort(fresh.begin(), fresh.end());
+        for (size_t a = 0; a < fresh.size(); a++) {
+          m_arrExtForces[3 * fresh[a] + 0] += mag * f.x;
+          m_arrExtForces[3 * fresh[a] + 1] += mag * f.y;
+          m_arrExtForces[3 * fresh[a] + 2] += mag * f.z;
+          affected[fresh[a]] = 1;
+        }
+        last.swap(fresh);
+      }
+    }
+    return true;
+  }
+  int getHapticForceRadius() const { return m_hapticForceNeighorhoodSize; }
+  void setHapticForceRadius(int radius) { m_hapticForceNeighorhoodSize = radius; }
   void setPulledVertex(int index) { m_idxPulledVertex = index; }
   bool hapticStart(int index) { m_idxPulledVertex = index; m_bHapticInProgress = true; m_vHapticIndices.clear(); return true; }
   void hapticEnd() { m_bHapticInProgress = false; m_idxPulledVertex = -1; m_vHapticIndices.clear(); }
@@ -222,18 +261,19 @@ class Deformable {
   void init() {  // Deformable::init (Deformable.cpp:85-124)
     m_ctCollided = 0; m_fOnDeform = nullptr; m_idxPulledVertex = -1; m_bHapticInProgress = false;
     m_dampingMassCoeff = 0.0; m_dampingStiffnessCoeff = 0.01; m_timeStep = 0.0333; m_ctTimeStep = 0;
+    m_hapticForceNeighorhoodSize = 5;  // DEFAULT_FORCE_NEIGHBORHOOD_SIZE, Deformable.h:41
     m_bApplyGravity = true;  // left uninitialised by the reference's init(); true is what its .sim files set
     m_lpIntegrator = nullptr; m_hasFloor = false; m_floorY = 0.0; m_dof = 0;
   }
   std::vector<double> m_rest;
   std::vector<int> m_elements;
-  std::vector<int> m_vFixedVertices, m_vFixedDofs, m_vHapticIndices;
+  std::vector<int> m_vFixedVertices, m_vFixedDofs, m_vHapticIndices, m_bptr, m_bcol;
   std::vector<vec3d> m_vHapticForces;
   std::vector<double> m_q, m_qVel, m_arrExtForces;
   HipIntegrator* m_lpIntegrator;
   FOnApplyDeformations m_fOnDeform;
   U32 m_dof, m_ctCollided, m_ctTimeStep;
-  int m_idxPulledVertex, m_device;
+  int m_idxPulledVertex, m_device, m_hapticForceNeighorhoodSize;
   bool m_bHapticInProgress, m_bApplyGravity, m_hasFloor;
   double m_dampingMassCoeff, m_dampingStiffnessCoeff, m_timeStep, m_floorY;
 };

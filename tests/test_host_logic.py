@@ -224,3 +224,29 @@ def test_contribution_lists_reassemble_the_oracle_matrix(n_ranks):
                 assert np.abs(blk - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
         L.fb_plan_destroy(h)
     assert total_valid == 16 * len(t)  # every (tet, i, j) is assembled by exactly one rank: the owner of node t[i]
+
+
+def test_haptic_force_spreading_rings():
+    """Deformable::applyHapticForces: ring j of the breadth-first walk over mesh edges gets (size - j)/size of the force."""
+    from fembrain_amd.fem import spread_haptic_forces
+    n = 7
+    v, t = truth_cube(n, n, n)
+    o = OrcFem(v, t)
+    bptr, bcol = o.blocks()
+    centre = 3 * n * n + 3 * n + 3
+    f = np.zeros(3 * len(v))
+    spread_haptic_forces(bptr, bcol, [centre], [(0.0, 5.0, 0.0)], 3, f)
+    fy = f[1::3]
+    assert fy[centre] == 5.0
+    ring1 = set(int(b) for b in bcol[bptr[centre]:bptr[centre + 1]]) - {centre}
+    assert len(ring1) == 14 and all(abs(fy[b] - 5.0 * 2 / 3) < 1e-15 for b in ring1)   # 14 edge neighbours in the 6-tet cube
+    ring2 = set()
+    for b in ring1:
+        ring2 |= set(int(c) for c in bcol[bptr[b]:bptr[b + 1]])
+    ring2 -= ring1 | {centre}
+    assert ring2 and all(abs(fy[b] - 5.0 / 3) < 1e-15 for b in ring2)
+    assert np.count_nonzero(fy) == 1 + len(ring1) + len(ring2) and not f[0::3].any() and not f[2::3].any()
+    # two haptic vertices superpose
+    g = np.zeros(3 * len(v))
+    spread_haptic_forces(bptr, bcol, [centre, 0], [(0.0, 5.0, 0.0), (1.0, 0.0, 0.0)], 2, g)
+    assert g[3 * centre + 1] == 5.0 and g[0] == 1.0 and abs(g[3 * 1] - 0.5) < 1e-15
