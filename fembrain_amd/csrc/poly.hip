@@ -480,16 +480,27 @@ __global__ __launch_bounds__(kPB) void k_tet_elements(Grid G, const unsigned lon
   for (long long word = (long long)blockIdx.x * (kPB / 64) + wv; word < nwords; word += nwaves) {  // wave-uniform loop
     const unsigned long long mask = cinc[word];
     if (mask == 0ULL) continue;
+    // vertex ranks of the four (y,z) rows of corners: the 64 lanes of a row cover 64 consecutive points, i.e. at most two
+    // words of the vertex mask -- fetched once per wave through the scalar path instead of per lane
+    unsigned int c[8];
+    const long long rowoff[4] = {0, gxy, gx, gx + gxy};
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) {
+      const long long q0 = word * 64 + rowoff[r4];                       // wave-uniform
+      // clamped: rows past the grid end are only touched by lanes whose cell is not included (their ranks are unused)
+      const long long w0 = min(q0 >> 6, nwords - 1);
+      const long long w1 = min(w0 + 1, nwords - 1);
+      const unsigned long long m0 = vinc[w0], m1 = vinc[w1];
+      const unsigned int b0 = vbase[w0], b1 = vbase[w1];
+      const int bit = (int)(q0 & 63) + lane;                             // position inside the two-word window
+      const unsigned long long mm = bit < 64 ? m0 : m1;
+      const unsigned int bb = bit < 64 ? b0 : b1;
+      c[r4] = bb + (unsigned int)__popcll(mm & ((1ULL << (bit & 63)) - 1ULL));
+    }
+    // all 8 corners of an included cell are included vertices and a rank is a prefix count in grid order, so the +x
+    // corner of each row is simply the next rank
+    c[4] = c[0] + 1; c[5] = c[1] + 1; c[6] = c[2] + 1; c[7] = c[3] + 1;
     if ((mask >> lane) & 1ULL) {
-      const long long p = word * 64 + lane;  // lower-corner grid point of the cell
-      unsigned int c[8];
-      // all 8 corners of an included cell are included vertices, and a rank is a prefix count in grid order, so the
-      // +x corner of each of the 4 (y,z) rows is simply the next rank
-      c[0] = rank_of(vinc, vbase, p);
-      c[1] = rank_of(vinc, vbase, p + gxy);
-      c[2] = rank_of(vinc, vbase, p + gx);
-      c[3] = rank_of(vinc, vbase, p + gx + gxy);
-      c[4] = c[0] + 1; c[5] = c[1] + 1; c[6] = c[2] + 1; c[7] = c[3] + 1;
       enum { LBN, LBF, LTN, LTF, RBN, RBF, RTN, RTF };
       uint4* o = &stage[wv][6 * __popcll(mask & ((1ULL << lane) - 1ULL))];
       o[0] = make_uint4(c[LBN], c[LTN], c[RBN], c[LBF]);
