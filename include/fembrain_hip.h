@@ -155,9 +155,9 @@ int fb_fem_spmv(fb_fem_t h, const double* x, double* y);
  * iterations_out: + converged / - not converged, as the reference returns. */
 int fb_fem_pcg(fb_fem_t h, const double* rhs, double* x, double eps, int max_iter, int* iterations_out);
 
-/* timing helpers for bench.py: run `iters` PCG iterations (no convergence exit) / `reps` SpMVs / assemblies on
- * the current system and return the average device time of the named kernel in seconds, measured with HIP
- * events on the handle's stream. */
+/* timing helpers for bench.py: `reps` launches of the PCG loop's SpMV kernel (k_spmv<MT,3>: q = A d plus the three
+ * merged sums) / `reps` assemblies (k_tet_warp + k_assemble_rows) on the current system; average device seconds per
+ * launch measured with HIP events on the handle's stream. */
 int fb_fem_time_spmv(fb_fem_t h, int reps, double* seconds_per_spmv);
 int fb_fem_time_assembly(fb_fem_t h, int reps, double* seconds_per_assembly);
 /* algorithmic bytes moved by one SpMV launch / one assembly on this handle */

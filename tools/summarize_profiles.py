@@ -1,0 +1,56 @@
+"""Turns raw rocprofv3 output under gpurun_out/ into the small summaries committed under profiles/ (development aid).
+
+usage: summarize_profiles.py <kernel_stats.csv> <fetch counter csv> <write counter csv> <tag>"""
+import collections
+import csv
+import json
+import re
+import statistics
+import sys
+
+stats, fetch, write, tag = sys.argv[1:5]
+rows = list(csv.DictReader(open(stats)))
+with open("profiles/%s_kernel_stats.csv" % tag, "w") as fh:
+    w = csv.writer(fh)
+    w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent", "min_us", "max_us"])
+    for r in rows:
+        m = re.search(r"(k_\w+(<[^>]*>)?|__amd\w+)", r["Name"])
+        name = m.group(1) if m else r["Name"][:40]
+        w.writerow([name, r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6), "%.2f" % (float(r["AverageNs"]) / 1e3), r["Percentage"],
+                    "%.2f" % (float(r["MinNs"]) / 1e3), "%.2f" % (float(r["MaxNs"]) / 1e3)])
+
+
+def agg(path):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        m = re.search(r"(k_\w+(<[^>]*>)?|__amd\w+)", r["Kernel_Name"])
+        d[m.group(1) if m else r["Kernel_Name"][:40]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+                                                                       int(r["VGPR_Count"]), int(r["SGPR_Count"]), int(r["LDS_Block_Size"])))
+    return d
+
+
+f, wv = agg(fetch), agg(write)
+out = []
+for k in f:
+    fv = [x for x in f[k] if x[1] > 3000]
+    ww = [x for x in wv.get(k, []) if x[1] > 3000]
+    if not fv:
+        continue
+    out.append(dict(kernel=k, launches=len(fv), FETCH_SIZE_KB_median=statistics.median(x[0] for x in fv),
+                    WRITE_SIZE_KB_median=statistics.median(x[0] for x in ww) if ww else None,
+                    duration_us_median=statistics.median(x[1] for x in fv) / 1e3, vgpr=fv[0][2], sgpr=fv[0][3], lds=fv[0][4]))
+with open("profiles/%s_pmc_summary.csv" % tag, "w") as fh:
+    wr = csv.DictWriter(fh, fieldnames=list(out[0].keys()))
+    wr.writeheader()
+    wr.writerows(out)
+sp = [r for r in out if r["kernel"] == "k_spmv<float, 3>"][0]
+hbm = (2 * sp["FETCH_SIZE_KB_median"] + sp["WRITE_SIZE_KB_median"]) * 1024
+json.dump({"kernel": "fb::k_spmv<float,3> (PCG SpMV with the merged sums)", "workload": "cube56 (998,250 tets), f32 matrix",
+           "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/probe_fem.py 56 1; per-launch medians over %d launches" % sp["launches"],
+           "FETCH_SIZE_KB": sp["FETCH_SIZE_KB_median"], "WRITE_SIZE_KB": sp["WRITE_SIZE_KB_median"],
+           "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM section); calibrated here against the known "
+                         "algorithmic read volume of this kernel; WRITE_SIZE exact (q = 4.21 MB)",
+           "hbm_bytes_per_launch": hbm}, open("profiles/spmv_pmc.json", "w"), indent=1)
+print(open("profiles/spmv_pmc.json").read())
+for r in out:
+    print(r["kernel"][:40], r["launches"], "F %.0f KB W %s KB %.1f us" % (r["FETCH_SIZE_KB_median"], r["WRITE_SIZE_KB_median"], r["duration_us_median"]))
