@@ -53,13 +53,13 @@ struct Grid {
   long long n_points, n_cells;
 };
 
-__device__ inline float wyvill(float dd) {
+__device__ __forceinline__ float wyvill(float dd) {
   const float t = 1.0f - dd;
   return fmaxf(0.0f, (t * t) * t);  // Polygonizer.h:519-529
 }
 
 // computePrimitiveField (Polygonizer.cpp:1544-1908), scalar fp32, no bounding-box cull
-__device__ inline float prim_field(const float* __restrict__ prims, const float* __restrict__ mtx, int i, float pX, float pY, float pZ) {
+__device__ __forceinline__ float prim_field(const float* __restrict__ prims, const float* __restrict__ mtx, int i, float pX, float pY, float pZ) {
   const float* P = prims + 20 * i;
   const int type = (int)P[0];
   const int im = (int)P[1];
@@ -153,7 +153,7 @@ __device__ inline float prim_field(const float* __restrict__ prims, const float*
   return wyvill(dist2);
 }
 
-__device__ inline float apply_op(int optype, float lf, float rf, float p0, float p1, float keep) {
+__device__ __forceinline__ float apply_op(int optype, float lf, float rf, float p0, float p1, float keep) {
   switch (optype) {
     case opBlend: return lf + rf;
     case opRicciBlend: return powf(powf(lf, p0) + powf(rf, p0), p1);
@@ -168,7 +168,7 @@ __device__ inline float apply_op(int optype, float lf, float rf, float p0, float
 
 // FieldComputer::fieldValue (Polygonizer.cpp:1913-2108) through the compiled order.  `stk` is this thread's
 // column of an LDS stack [depth][kPB].
-__device__ inline float eval_field(const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
+__device__ __forceinline__ float eval_field(const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
                                    const float* __restrict__ mtx, float x, float y, float z, float* stk) {
   float out = 0.0f;
   if (n_instr == 0) {  // no operators: blend of all primitives (:2085-2096)

@@ -8,7 +8,7 @@ p = GpuPoly(sphere_blob())
 dims = p.sweep_grid((-0.5, -0.5, -0.5), 1.0 / (n - 2), (n, n, n))
 c = p.classify()
 p.tetrahedralize()
-s, t = p.time_pipeline(5)
+s, t = p.time_pipeline(30)
 npts = n ** 3
 print("grid %d^3: sweep %.1f us (%.0f GB/s), pipeline %.1f us -> %.0f Mvoxels/s; tets %d verts %d" %
       (n, s * 1e6, npts * 16 / s / 1e9, t * 1e6, npts / t / 1e6, c.n_included_cells * 6, p.counts.n_tet_vertices))
