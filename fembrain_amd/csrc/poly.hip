@@ -443,7 +443,10 @@ __global__ __launch_bounds__(kPB) void k_tet_vertices(Grid G, const unsigned lon
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long long nwords = (G.n_points + 63) >> 6;
   const long long nwaves = (long long)gridDim.x * (kPB / 64);
-  for (long long word = (long long)blockIdx.x * (kPB / 64) + wv; word < nwords; word += nwaves) {  // wave-uniform loop
+  // each wave owns a CONTIGUOUS run of mask words, so neighbouring output ranges (which share cache lines at their
+  // 96-/12-byte-granular ends) are written by the same CU instead of by waves on different XCDs
+  const long long per = (nwords + nwaves - 1) / nwaves, wid = (long long)blockIdx.x * (kPB / 64) + wv;
+  for (long long word = wid * per; word < min((wid + 1) * per, nwords); word++) {  // wave-uniform loop
     const unsigned long long mask = vinc[word];
     if (mask == 0ULL) continue;
     if ((mask >> lane) & 1ULL) {
@@ -477,7 +480,10 @@ __global__ __launch_bounds__(kPB) void k_tet_elements(Grid G, const unsigned lon
   const long long nwords = (G.n_points + 63) >> 6;
   const long long nwaves = (long long)gridDim.x * (kPB / 64);
   const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
-  for (long long word = (long long)blockIdx.x * (kPB / 64) + wv; word < nwords; word += nwaves) {  // wave-uniform loop
+  // each wave owns a CONTIGUOUS run of mask words, so neighbouring output ranges (which share cache lines at their
+  // 96-/12-byte-granular ends) are written by the same CU instead of by waves on different XCDs
+  const long long per = (nwords + nwaves - 1) / nwaves, wid = (long long)blockIdx.x * (kPB / 64) + wv;
+  for (long long word = wid * per; word < min((wid + 1) * per, nwords); word++) {  // wave-uniform loop
     const unsigned long long mask = cinc[word];
     if (mask == 0ULL) continue;
     // vertex ranks of the four (y,z) rows of corners: the 64 lanes of a row cover 64 consecutive points, i.e. at most two
@@ -685,7 +691,8 @@ int fetch_counts(fb_poly_s* h) {
 
 int do_emit(fb_poly_s* h) {
   const Grid& G = h->G;
-  const int pb = (int)std::min<long long>((G.n_points + kPB - 1) / kPB, 4096);  // waves stride over the mask words
+  static const int emit_blocks = getenv("FB_EMIT_BLOCKS") ? atoi(getenv("FB_EMIT_BLOCKS")) : 4096;  // tuning knob (development)
+  const int pb = (int)std::min<long long>((G.n_points + kPB - 1) / kPB, emit_blocks);  // each wave owns a run of mask words
   hipLaunchKernelGGL(k_tet_vertices, dim3(pb), dim3(kPB), 0, h->stream, G, h->vinc.p, h->vbase.p, h->tv.p);
   FB_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_tet_elements, dim3(pb), dim3(kPB), 0, h->stream, G, h->cinc.p, h->cbase.p, h->vinc.p, h->vbase.p, h->tt.p);
