@@ -250,3 +250,23 @@ def test_haptic_force_spreading_rings():
     g = np.zeros(3 * len(v))
     spread_haptic_forces(bptr, bcol, [centre, 0], [(0.0, 5.0, 0.0), (1.0, 0.0, 0.0)], 2, g)
     assert g[3 * centre + 1] == 5.0 and g[0] == 1.0 and abs(g[3 * 1] - 0.5) < 1e-15
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under fembrain_amd/ or include/ may import, include or link it."""
+    import subprocess
+    bad = []
+    for base in ("fembrain_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            if "build" in dirpath or "__pycache__" in dirpath:
+                continue
+            for fn in files:
+                if not fn.endswith((".py", ".h", ".hip", ".cpp", ".c")) and fn != "Makefile":
+                    continue
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                for pat in (r"^\s*(from|import)\s+oracle", r"#include\s+[\"<].*oracle", r"libfem_oracle", r"libfem_ref", r"oracle/"):
+                    if re.search(pat, text, flags=re.M):
+                        bad.append((os.path.join(dirpath, fn), pat))
+    assert not bad, bad
+    needed = subprocess.check_output(["readelf", "-d", fl.LIB_PATH], text=True)
+    assert "oracle" not in needed and "fem_ref" not in needed
