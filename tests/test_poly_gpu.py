@@ -74,7 +74,7 @@ def test_sphere_tetmesh_matches_reference_golden(gpu):
             assert np.abs(got - want).max() < 1e-6  # the old kernel forms +1 corners as lower+cellsize (7.45e-9 vs 0)
 
 
-@pytest.mark.parametrize("name,cellsize", [("nested", 0.09), ("two_ranges", 0.07), ("tumor.blob", 0.15), ("complex.blob", 0.12)])
+@pytest.mark.parametrize("name,cellsize", [("nested", 0.09), ("two_ranges", 0.07), ("tumor.blob", 0.15), ("complex.blob", 0.12), ("ventricle.blob", 0.11), ("3slabs.blob", 0.13), ("CylinderWithHoles.blob", 0.17)])
 def test_grid_classification_bit_exact(gpu, name, cellsize):
     blob = read_blob(os.path.join(GOLD, "blob", name)) if name.endswith(".blob") else _trees()[name]
     g = GpuPoly(blob)
