@@ -450,3 +450,11 @@ def test_full_size_1M_tet_properties(gpu):
     diag.reshape(-1, 3)[:] = np.stack([K[isdiag][:, k, k] for k in range(3)], 1)
     assert (res * res / diag).sum() <= 1.5e-12 * (rhs * rhs / diag).sum()   # sum r^2/D <= eps^2 sum r0^2/D
     assert not dv[fixed].any()
+
+
+def test_device_is_an_mi355x(gpu):
+    import ctypes as C
+    L = fl.lib()
+    name, arch, ncu = C.create_string_buffer(128), C.create_string_buffer(64), C.c_int(0)
+    fl.check(L.fb_device_info(0, name, 128, arch, 64, C.byref(ncu)))
+    assert arch.value.decode().startswith("gfx950") and ncu.value == 256, (name.value, arch.value, ncu.value)
