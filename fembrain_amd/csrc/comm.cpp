@@ -3,6 +3,11 @@
 #include "comm.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
 
 #include "common.h"
 
@@ -70,6 +75,79 @@ int load_rccl() {
     if (_r != ncclSuccess) return fb::fail(FB_ECOMM, "%s failed: %s", #expr, g_rccl.GetErrorString(_r)); \
   } while (0)
 
+// ---- host-staged shared-memory transport (TEST HOOK) -----------------------------------------------------------
+// Lets several processes that share ONE GPU run the sharded solver against each other: every collective synchronises
+// the stream, stages through a POSIX shared-memory segment and meets the peers at a process barrier.  Same call
+// sequence and data movement as the RCCL path (fixed rank-order sums, owner-grouped halo segments), none of its speed.
+constexpr int kLocalMaxRanks = 8;
+struct LocalShm {
+  std::atomic<int> count;
+  std::atomic<int> sense;
+  double scal[kLocalMaxRanks][8];
+  int send_off[kLocalMaxRanks][kLocalMaxRanks + 1];
+  size_t outbox_bytes;
+  // followed by n_ranks outboxes of outbox_bytes each
+};
+struct LocalComm {
+  LocalShm* shm = nullptr;
+  size_t map_bytes = 0;
+  int local_sense = 0;
+  std::string name;
+  char* outbox(int r) const { return (char*)(shm + 1) + (size_t)r * shm->outbox_bytes; }
+};
+
+void local_barrier(LocalComm* L, int n_ranks) {
+  L->local_sense ^= 1;
+  if (L->shm->count.fetch_add(1) == n_ranks - 1) {
+    L->shm->count.store(0);
+    L->shm->sense.store(L->local_sense);
+  } else {
+    while (L->shm->sense.load() != L->local_sense) usleep(20);
+  }
+}
+
+int local_allreduce(fb_comm_s* c, double* dev_buf, int count, hipStream_t s) {
+  LocalComm* L = (LocalComm*)c->local;
+  if (count > 8) return fb::fail(FB_EINVAL, "local transport: at most 8 scalars");
+  double v[8];
+  FB_HIP(hipMemcpyAsync(v, dev_buf, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+  FB_HIP(hipStreamSynchronize(s));
+  memcpy(L->shm->scal[c->rank], v, sizeof(double) * count);
+  local_barrier(L, c->n_ranks);
+  for (int k = 0; k < count; k++) {
+    double t = 0.0;
+    for (int r = 0; r < c->n_ranks; r++) t += L->shm->scal[r][k];  // fixed rank order: identical on every rank
+    v[k] = t;
+  }
+  local_barrier(L, c->n_ranks);  // everyone has read before the slots are reused
+  FB_HIP(hipMemcpyAsync(dev_buf, v, sizeof(double) * count, hipMemcpyHostToDevice, s));
+  FB_HIP(hipStreamSynchronize(s));
+  return FB_OK;
+}
+
+int local_exchange(fb_comm_s* c, const double* sendbuf, const int* send_off, double* recv_base, const int* recv_off, int width, hipStream_t s) {
+  LocalComm* L = (LocalComm*)c->local;
+  const int n = c->n_ranks, me = c->rank;
+  const size_t bytes = sizeof(double) * (size_t)width * send_off[n];
+  if (bytes > L->shm->outbox_bytes) return fb::fail(FB_EINVAL, "local transport: outbox too small (%zu > %zu)", bytes, L->shm->outbox_bytes);
+  if (bytes) FB_HIP(hipMemcpyAsync(L->outbox(me), sendbuf, bytes, hipMemcpyDeviceToHost, s));
+  FB_HIP(hipStreamSynchronize(s));
+  memcpy(L->shm->send_off[me], send_off, sizeof(int) * (n + 1));
+  local_barrier(L, n);
+  for (int q = 0; q < n; q++) {
+    if (q == me) continue;
+    const int nr = recv_off[q + 1] - recv_off[q];
+    if (nr <= 0) continue;
+    const int* so = L->shm->send_off[q];
+    if (so[me + 1] - so[me] != nr) return fb::fail(FB_ECOMM, "local transport: rank %d sends %d nodes to rank %d, which expects %d", q, so[me + 1] - so[me], me, nr);
+    FB_HIP(hipMemcpyAsync(recv_base + (size_t)width * recv_off[q], L->outbox(q) + sizeof(double) * (size_t)width * so[me], sizeof(double) * (size_t)width * nr,
+                          hipMemcpyHostToDevice, s));
+  }
+  FB_HIP(hipStreamSynchronize(s));
+  local_barrier(L, n);  // outboxes may be overwritten again
+  return FB_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -104,8 +182,32 @@ int fb_comm_create(fb_comm_t* out, int rank, int n_ranks, const unsigned char id
   return FB_OK;
 }
 
+int fb_comm_create_local(fb_comm_t* out, int rank, int n_ranks, const char* shm_name, size_t outbox_bytes, int device) {
+  if (!out || !shm_name || n_ranks < 1 || n_ranks > kLocalMaxRanks || rank < 0 || rank >= n_ranks) return fb::fail(FB_EINVAL, "bad local communicator arguments");
+  const size_t total = sizeof(LocalShm) + (size_t)n_ranks * outbox_bytes;
+  int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) return fb::fail(FB_ECOMM, "shm_open(%s) failed", shm_name);
+  if (ftruncate(fd, (off_t)total) != 0) { close(fd); return fb::fail(FB_ECOMM, "ftruncate(%s) failed", shm_name); }
+  void* p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return fb::fail(FB_ECOMM, "mmap(%s) failed", shm_name);
+  LocalComm* L = new LocalComm;
+  L->shm = (LocalShm*)p; L->map_bytes = total; L->name = shm_name;
+  L->shm->outbox_bytes = outbox_bytes;  // same value from every rank; a fresh segment is zero-filled (count = sense = 0)
+  fb_comm_s* c = new fb_comm_s;
+  c->rank = rank; c->n_ranks = n_ranks; c->device = device; c->local = L;
+  *out = c;
+  return FB_OK;
+}
+
 int fb_comm_destroy(fb_comm_t c) {
   if (!c) return FB_OK;
+  if (c->local) {
+    LocalComm* L = (LocalComm*)c->local;
+    munmap(L->shm, L->map_bytes);
+    if (c->rank == 0) shm_unlink(L->name.c_str());
+    delete L;
+  }
   if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->nccl);
   delete c;
   return FB_OK;
@@ -116,6 +218,7 @@ int fb_comm_destroy(fb_comm_t c) {
 namespace fb {
 
 int comm_allreduce_sum(fb_comm_s* c, double* dev_buf, int count, hipStream_t s) {
+  if (c && c->local) return local_allreduce(c, dev_buf, count, s);
   if (!c || !c->nccl) return FB_OK;
   FB_NCCL(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)c->nccl, s));
   return FB_OK;
@@ -123,6 +226,7 @@ int comm_allreduce_sum(fb_comm_s* c, double* dev_buf, int count, hipStream_t s) 
 
 int comm_exchange_nodes(fb_comm_s* c, const double* sendbuf, const int* send_off, double* recv_base, const int* recv_off, int width,
                         hipStream_t s) {
+  if (c && c->local) return c->n_ranks == 1 ? FB_OK : local_exchange(c, sendbuf, send_off, recv_base, recv_off, width, s);
   if (!c || !c->nccl || c->n_ranks == 1) return FB_OK;
   FB_NCCL(g_rccl.GroupStart());
   for (int q = 0; q < c->n_ranks; q++) {

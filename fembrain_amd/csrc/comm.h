@@ -7,7 +7,8 @@
 
 struct fb_comm_s {
   int rank = 0, n_ranks = 1, device = 0;
-  void* nccl = nullptr;  // ncclComm_t
+  void* nccl = nullptr;   // ncclComm_t
+  void* local = nullptr;  // host-staged shared-memory transport (test hook, fb_comm_create_local)
 };
 
 namespace fb {

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_fold_partials(const double* partial,
 
 int global_scalar(fb_fem_s* h, const double* partial, double** out, bool check_done, int count = 1, int slot = 0) {
   *out = nullptr;
-  if (!h->comm || !h->comm->nccl) return FB_OK;
+  if (!h->comm || (!h->comm->nccl && !h->comm->local)) return FB_OK;
   hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(kBlock), 0, h->stream, partial, h->grid, count, h->scal.p + slot, check_done ? h->st.p : nullptr);
   FB_HIP(hipGetLastError());
   // a converged solve leaves the previous (identical on every rank) values in place; the all-reduce still runs on

@@ -107,6 +107,7 @@ def lib():
         "fb_comm_unique_id": (C.c_int, [_bp]),
         "fb_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _bp, C.c_int]),
         "fb_comm_destroy": (C.c_int, [vp]),
+        "fb_comm_create_local": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_int]),
         "fb_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int, C.c_int, _ip]),
         "fb_plan_destroy": (C.c_int, [vp]),
         "fb_plan_info": (C.c_int, [vp, _ip]),

@@ -23,6 +23,13 @@ int fb_plan_info(fb_plan_t p, int info[12]);
  *        slot_coff, slot_ccnt, contrib (uint32 bits), dofmask (one int per DOF) */
 int fb_plan_get(fb_plan_t p, const char* name, int* out, size_t capacity);
 
+/* Host-staged communicator for tests: processes sharing ONE GPU (or none of them owning more than one) exchange through
+ * the POSIX shared-memory segment `shm_name` with a process barrier per collective.  It drives exactly the sharded
+ * solver path of fb_fem_create_sharded (halo lists, packing, rank-ordered sums) without RCCL, so the N > 1 path can be
+ * run on a one-GPU box.  Every rank passes the same name, n_ranks and outbox_bytes; destroy with fb_comm_destroy. */
+struct fb_comm_s;
+int fb_comm_create_local(struct fb_comm_s** out, int rank, int n_ranks, const char* shm_name, size_t outbox_bytes, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,85 @@
+"""GPU: the sharded FEM handle run by several PROCESSES on the one GPU of the box.  The ranks talk through the
+host-staged shared-memory communicator (fb_comm_create_local), which drives exactly the code path of the RCCL
+communicator -- per-rank plans, halo packing and exchange of q / qvel / the PCG search direction / x, rank-ordered
+all-reduce of the merged PCG sums, identical termination on every rank -- so the N > 1 solver is exercised on hardware
+even though RCCL itself refuses two ranks on one device.  The gathered state must match the unsharded handle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, shm_name, n, variant, steps, q):
+    try:
+        from fembrain_amd import lib as fl
+        from fembrain_amd.fem import FemIntegrator
+        from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
+        L = fl.lib()
+        comm = C.c_void_p()
+        fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
+        v, t = truth_cube(n, n, n, 0.1)
+        fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+        planes = [n * r // world for r in range(world + 1)]
+        splits = np.array([p * n * n for p in planes], np.int32)
+        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), pcg_variant=variant)
+        f = np.zeros(g.r)
+        f[1::3] = -10000.0
+        f[0::3] = 300.0 * np.sin(np.arange(len(v)))   # not symmetric across the slabs
+        its = []
+        for _ in range(steps):
+            g.set_external_forces(f)
+            its.append(g.do_timestep())
+        qq, vv, _ = g.get_q_state()
+        lo, hi = 3 * int(splits[rank]), 3 * int(splits[rank + 1])
+        q.put((rank, its, qq[lo:hi].copy(), vv[lo:hi].copy(), lo, hi))
+        g.close()
+        L.fb_comm_destroy(comm)
+    except Exception as e:  # surface the failure instead of hanging the peers' barrier forever
+        q.put((rank, repr(e), None, None, 0, 0))
+        os._exit(1)
+
+
+@pytest.mark.parametrize("world,variant", [(2, 0), (3, 0), (2, 1), (4, 2)])
+def test_sharded_ranks_on_one_gpu_match_the_unsharded_handle(gpu, world, variant):
+    import multiprocessing as mp
+    from fembrain_amd.fem import FemIntegrator
+    from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
+    n, steps = 12, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "/fembrain_test_%d_%d_%d" % (os.getpid(), world, variant)
+    procs = [ctx.Process(target=_worker, args=(r, world, name, n, variant, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=240))
+            assert res[-1][2] is not None, res[-1]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    v, t = truth_cube(n, n, n, 0.1)
+    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    g = FemIntegrator(v, t, fixed, pcg_variant=variant)
+    f = np.zeros(g.r)
+    f[1::3] = -10000.0
+    f[0::3] = 300.0 * np.sin(np.arange(len(v)))
+    its = []
+    for _ in range(steps):
+        g.set_external_forces(f)
+        its.append(g.do_timestep())
+    qs, vs, _ = g.get_q_state()
+    qg, vg = np.zeros_like(qs), np.zeros_like(vs)
+    for rank, rits, qq, vv, lo, hi in res:
+        assert rits == res[0][1]                                  # every rank stopped at the same iteration
+        assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its))
+        qg[lo:hi], vg[lo:hi] = qq, vv
+    # rank-ordered partial sums instead of one block-ordered sum: same iterates up to rounding
+    assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
+    assert np.abs(vg - vs).max() <= 1e-5 * np.abs(vs).max()
