@@ -114,7 +114,12 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # FEMBRAIN_BENCH_LOCAL_COMM=1: rehearsal of the N > 1 flow on a ONE-GPU box -- every rank uses device 0, the process
+    # group is gloo and the solver talks through the host-staged shared-memory communicator (RCCL refuses two ranks on
+    # one device).  Numbers from this mode are meaningless; it exists to exercise the control flow.
+    local_comm = os.environ.get("FEMBRAIN_BENCH_LOCAL_COMM") == "1"
+    device = 0 if local_comm else local_rank
+    torch.cuda.set_device(device)
     shard = None
     comm = None
     # FEMBRAIN_BENCH_FORCE_DIST=1 runs the one-process-per-GPU plumbing (process group, unique-id broadcast, RCCL
@@ -124,16 +129,21 @@ def main():
         import ctypes as C
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            buf = (C.c_ubyte * 128)()
-            fl.check(fl.lib().fb_comm_unique_id(buf))
-            uid = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
-        dist.broadcast(uid, 0)
-        idb = (C.c_ubyte * 128)(*uid.cpu().tolist())
         comm = C.c_void_p()
-        fl.check(fl.lib().fb_comm_create(C.byref(comm), rank, world, idb, local_rank))
+        if local_comm:
+            dist.init_process_group("gloo")
+            name = "/fembrain_bench_%s" % os.environ.get("MASTER_PORT", "0")
+            fl.check(fl.lib().fb_comm_create_local(C.byref(comm), rank, world, name.encode(), 64 << 20, device))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                buf = (C.c_ubyte * 128)()
+                fl.check(fl.lib().fb_comm_unique_id(buf))
+                uid = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
+            dist.broadcast(uid, 0)
+            idb = (C.c_ubyte * 128)(*uid.cpu().tolist())
+            fl.check(fl.lib().fb_comm_create(C.byref(comm), rank, world, idb, device))
 
     n, text = WORKLOADS[args.workload]
     v, t = truth_cube(n, n, n, 0.1)
@@ -144,7 +154,7 @@ def main():
         splits = np.array([p * n * n for p in planes], dtype=np.int32)
         shard = (world, rank, splits, comm)
     prec = fl.FB_MATRIX_F64 if args.precision == "f64" else fl.FB_MATRIX_F32
-    g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=local_rank, shard=shard)
+    g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device, shard=shard)
 
     def barrier():
         if dist_mode:
@@ -168,7 +178,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist_mode:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if local_comm else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -201,7 +211,7 @@ def main():
                          "algorithmic_bytes_per_launch": spmv_bytes, "us_per_launch": spmv_s * 1e6},
         }
     if world == 1 and not args.no_field:
-        extra = field_bench(local_rank, cpu=not args.no_cpu_baseline)
+        extra = field_bench(device, cpu=not args.no_cpu_baseline)
         if out is not None:
             out.update(extra)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
