@@ -526,6 +526,219 @@ __global__ __launch_bounds__(kPB) void k_tet_elements(Grid G, const unsigned lon
   }
 }
 
+// ---- marching-cubes surface (GPUPoly::run steps 3,4,6,7: OclPolygonizer.cpp:663-757) ---------------------------------
+// Triangle table: the cube table of Bloomenthal's polygonizer ("An implicit surface polygonizer", Graphics Gems IV),
+// whose edge/corner/face naming the reference's _CellConfigTable.h carries: walk the crossed edges of each of the 256
+// sign configurations clockwise around the faces into polygons, then fan every polygon around its last vertex.
+// Generated at library load; tests pin it to the hash of the reference's own array (tests/golden/mc_table.json).
+enum { eLB, eLT, eLN, eLF, eRB, eRT, eRN, eRF, eBN, eBF, eTN, eTF };
+enum { fL, fR, fB, fT, fN, fF };
+// corner = 4*dx + 2*dy + dz (LBN LBF LTN LTF RBN RBF RTN RTF)
+const int kEdgeCorner1[12] = {0, 2, 0, 1, 4, 6, 4, 5, 0, 1, 2, 3};
+const int kEdgeCorner2[12] = {1, 3, 2, 3, 5, 7, 6, 7, 4, 5, 6, 7};
+const int kEdgeAxis[12] = {2, 2, 1, 1, 2, 2, 1, 1, 0, 0, 0, 0};
+
+struct CubeTable {
+  unsigned char tri[256][16];  // edge ids, 255 = end
+  unsigned char nvert[256];
+  // per edge: bits 0-2 first corner, bits 4-5 axis
+  unsigned char edge_info[16];
+};
+
+int next_cw_edge(int edge, int face) {
+  // the next edge clockwise around `face` (seen from outside the cube)
+  static const int on_first[12] = {fL, fL, fL, fL, fR, fR, fR, fR, fB, fB, fT, fT};
+  static const int if_first[12] = {eLF, eLN, eLB, eLT, eRN, eRF, eRT, eRB, eRB, eLB, eLT, eRT};
+  static const int if_other[12] = {eBN, eTF, eTN, eBF, eBF, eTN, eBN, eTF, eLN, eRF, eRN, eLF};
+  return face == on_first[edge] ? if_first[edge] : if_other[edge];
+}
+
+const CubeTable& cube_table() {
+  static const CubeTable T = [] {
+    static const int left_face[12] = {fB, fL, fL, fF, fR, fT, fN, fR, fN, fB, fT, fF};
+    static const int right_face[12] = {fL, fT, fN, fL, fB, fR, fR, fF, fB, fF, fN, fT};
+    CubeTable t;
+    memset(t.tri, 255, sizeof t.tri);
+    memset(t.edge_info, 0, sizeof t.edge_info);
+    for (int e = 0; e < 12; e++) t.edge_info[e] = (unsigned char)(kEdgeCorner1[e] | (kEdgeAxis[e] << 4));
+    for (int cfg = 0; cfg < 256; cfg++) {
+      auto in = [cfg](int corner) { return (cfg >> corner) & 1; };
+      bool done[12] = {false};
+      int n = 0;
+      for (int e0 = 0; e0 < 12; e0++) {
+        if (done[e0] || in(kEdgeCorner1[e0]) == in(kEdgeCorner2[e0])) continue;
+        int walk[12], nw = 0, e = e0, face = in(kEdgeCorner1[e0]) ? right_face[e0] : left_face[e0];
+        do {
+          e = next_cw_edge(e, face);
+          done[e] = true;
+          if (in(kEdgeCorner1[e]) != in(kEdgeCorner2[e])) {
+            walk[nw++] = e;
+            if (e != e0) face = face == left_face[e] ? right_face[e] : left_face[e];
+          }
+        } while (e != e0);
+        // Bloomenthal prepends to his polygon list, so list order = reverse walk order; the fan apex is the list's last
+        // entry (= first edge met) and the triangles come out from the far end of the list
+        for (int k = nw - 3; k >= 0; k--) {
+          t.tri[cfg][n++] = (unsigned char)walk[nw - 1 - k];
+          t.tri[cfg][n++] = (unsigned char)walk[nw - 2 - k];
+          t.tri[cfg][n++] = (unsigned char)walk[0];
+        }
+      }
+      t.nvert[cfg] = (unsigned char)n;
+    }
+    return t;
+  }();
+  return T;
+}
+
+// 8-bit configuration of the cell whose lower corner is bit b of the word, from the eight shifted inside words
+__device__ __forceinline__ int cfg_from_words(int b, unsigned long long c0, unsigned long long cz, unsigned long long cy, unsigned long long cyz,
+                                              unsigned long long cx, unsigned long long cxz, unsigned long long cxy, unsigned long long cxyz) {
+  return (int)(((c0 >> b) & 1ULL) | (((cz >> b) & 1ULL) << 1) | (((cy >> b) & 1ULL) << 2) | (((cyz >> b) & 1ULL) << 3) | (((cx >> b) & 1ULL) << 4) |
+               (((cxz >> b) & 1ULL) << 5) | (((cxy >> b) & 1ULL) << 6) | (((cxyz >> b) & 1ULL) << 7));
+}
+
+// per 64-point word: surface-cell mask, number of surface vertices (crossed edges) and of triangle indices
+__global__ __launch_bounds__(kPB) void k_surface_pops(Grid G, long long nwords, const unsigned long long* __restrict__ inside,
+                                                      const unsigned long long* __restrict__ lastx, const unsigned long long* __restrict__ lasty,
+                                                      const unsigned long long* __restrict__ lastz, const unsigned long long* __restrict__ valid,
+                                                      const unsigned int* __restrict__ aux_pop, const unsigned char* __restrict__ nvert,
+                                                      unsigned long long* __restrict__ surf, unsigned int* __restrict__ edge_pop,
+                                                      unsigned int* __restrict__ idx_pop) {
+  const long long w = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (w >= nwords) return;
+  const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
+  const unsigned long long c0 = inside[w];
+  const unsigned long long cx = fwd_word(inside, nwords, w, 1), cy = fwd_word(inside, nwords, w, gx), cz = fwd_word(inside, nwords, w, gxy);
+  const unsigned long long cxy = fwd_word(inside, nwords, w, gx + 1), cxz = fwd_word(inside, nwords, w, gxy + 1),
+                           cyz = fwd_word(inside, nwords, w, gxy + gx), cxyz = fwd_word(inside, nwords, w, gxy + gx + 1);
+  const unsigned long long cellok = valid[w] & ~(lastx[w] | lasty[w] | lastz[w]);
+  unsigned long long m = ((c0 | cx | cy | cz | cxy | cxz | cyz | cxyz) & ~(c0 & cx & cy & cz & cxy & cxz & cyz & cxyz)) & cellok;
+  surf[w] = m;
+  unsigned int n = 0;
+  while (m) {
+    const int b = __builtin_ctzll(m);
+    n += nvert[cfg_from_words(b, c0, cz, cy, cyz, cx, cxz, cxy, cxyz)];
+    m &= m - 1;
+  }
+  idx_pop[w] = n;
+  edge_pop[w] = aux_pop[w] & 0xFFFFu;
+}
+
+// first surface-vertex id of grid point q (exclusive scan of the per-point edge counts, OclPolygonizer.cpp:663-675)
+__device__ __forceinline__ unsigned int edge_offset(long long q, const unsigned long long* __restrict__ crossx, const unsigned long long* __restrict__ crossy,
+                                                    const unsigned long long* __restrict__ crossz, const unsigned int* __restrict__ ebase) {
+  const long long w = q >> 6;
+  const unsigned long long low = (1ULL << (q & 63)) - 1ULL;
+  return ebase[w] + (unsigned int)(__popcll(crossx[w] & low) + __popcll(crossy[w] & low) + __popcll(crossz[w] & low));
+}
+
+// ComputeVertexAttribs (Polygonizer.cl:1429-1561, linear root): one wavefront per 64-point word.  The word's crossed
+// edges are listed in LDS in output order (point-major, X Y Z) and then dealt to the lanes round-robin, so the four
+// field evaluations per vertex are spread over all 64 lanes however the crossings cluster.
+__global__ __launch_bounds__(kPB) void k_surface_vertices(Grid G, const Instr* __restrict__ prog, int n_instr, int n_prims,
+                                                          const float* __restrict__ prims, const float* __restrict__ mtx,
+                                                          const float4* __restrict__ grid, const unsigned long long* __restrict__ crossx,
+                                                          const unsigned long long* __restrict__ crossy, const unsigned long long* __restrict__ crossz,
+                                                          const unsigned int* __restrict__ ebase, float* __restrict__ pos, float* __restrict__ nrm) {
+  extern __shared__ float stack[];
+  __shared__ unsigned char list[kPB / 64][192];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long nwords = (G.n_points + 63) >> 6;
+  const long long nwaves = (long long)gridDim.x * (kPB / 64);
+  const long long stride[3] = {1, G.g[0], (long long)G.g[0] * G.g[1]};
+  const float delta = 0.0001f, dinv = 1.0f / 0.0001f;  // NORMAL_DELTA, Polygonizer.cl
+  for (long long word = (long long)blockIdx.x * (kPB / 64) + wv; word < nwords; word += nwaves) {  // wave-uniform
+    const unsigned long long mx = crossx[word], my = crossy[word], mz = crossz[word];
+    if ((mx | my | mz) == 0ULL) continue;
+    const unsigned long long low = (1ULL << lane) - 1ULL;
+    int r = __popcll(mx & low) + __popcll(my & low) + __popcll(mz & low);
+    if ((mx >> lane) & 1ULL) list[wv][r++] = (unsigned char)(lane << 2);
+    if ((my >> lane) & 1ULL) list[wv][r++] = (unsigned char)((lane << 2) | 1);
+    if ((mz >> lane) & 1ULL) list[wv][r++] = (unsigned char)((lane << 2) | 2);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int total = __popcll(mx) + __popcll(my) + __popcll(mz);
+    const size_t first = ebase[word];
+    for (int j = lane; j < total; j += 64) {
+      const int ent = list[wv][j];
+      const long long p = word * 64 + (ent >> 2);
+      const float4 va = grid[p], vb = grid[p + stride[ent & 3]];
+      const float t = (kIso - va.w) / (vb.w - va.w);
+      const float x = va.x + t * (vb.x - va.x), y = va.y + t * (vb.y - va.y), z = va.z + t * (vb.z - va.z);
+      float* stk = stack + threadIdx.x;
+      const float f = eval_field(prog, n_instr, n_prims, prims, mtx, x, y, z, stk);
+      float gx = eval_field(prog, n_instr, n_prims, prims, mtx, x + delta, y, z, stk);
+      float gy = eval_field(prog, n_instr, n_prims, prims, mtx, x, y + delta, z, stk);
+      float gz = eval_field(prog, n_instr, n_prims, prims, mtx, x, y, z + delta, stk);
+      gx = -1.0f * (dinv * (gx - f)); gy = -1.0f * (dinv * (gy - f)); gz = -1.0f * (dinv * (gz - f));
+      const float len = sqrtf(gx * gx + gy * gy + gz * gz);
+      float* o = pos + 3 * (first + j);
+      o[0] = x; o[1] = y; o[2] = z;
+      o = nrm + 3 * (first + j);
+      o[0] = gx / len; o[1] = gy / len; o[2] = gz / len;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+
+// ComputeElements (Polygonizer.cl:1610-1670): one wavefront per word of the surface-cell mask; every lane stages its
+// cell's <= 15 indices in LDS behind the lanes before it and the wave streams the range out contiguously.
+__global__ __launch_bounds__(kPB) void k_surface_elements(Grid G, const unsigned long long* __restrict__ inside,
+                                                          const unsigned long long* __restrict__ surf, const unsigned int* __restrict__ ibase,
+                                                          const unsigned long long* __restrict__ crossx, const unsigned long long* __restrict__ crossy,
+                                                          const unsigned long long* __restrict__ crossz, const unsigned int* __restrict__ ebase,
+                                                          const unsigned char* __restrict__ tri, const unsigned char* __restrict__ nvert,
+                                                          const unsigned char* __restrict__ edge_info, unsigned int* __restrict__ indices) {
+  __shared__ unsigned int stage[kPB / 64][64 * 15];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long nwords = (G.n_points + 63) >> 6;
+  const long long nwaves = (long long)gridDim.x * (kPB / 64);
+  const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
+  for (long long word = (long long)blockIdx.x * (kPB / 64) + wv; word < nwords; word += nwaves) {  // wave-uniform
+    const unsigned long long mask = surf[word];
+    if (mask == 0ULL) continue;
+    const bool on = (mask >> lane) & 1ULL;
+    const long long p = word * 64 + lane;
+    int cfg = 0, cnt = 0;
+    if (on) {
+      cfg = bit_at(inside, p) | (bit_at(inside, p + gxy) << 1) | (bit_at(inside, p + gx) << 2) | (bit_at(inside, p + gx + gxy) << 3) |
+            (bit_at(inside, p + 1) << 4) | (bit_at(inside, p + 1 + gxy) << 5) | (bit_at(inside, p + 1 + gx) << 6) | (bit_at(inside, p + 1 + gx + gxy) << 7);
+      cnt = nvert[cfg];
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    const int total = __shfl(incl, 63, 64);
+    unsigned int* o = &stage[wv][incl - cnt];
+    for (int i = 0; i < cnt; i++) {
+      const int info = edge_info[tri[16 * cfg + i]];
+      const int c = info & 7, axis = info >> 4;
+      const long long q = p + ((c >> 2) & 1) + ((c >> 1) & 1) * gx + (c & 1) * gxy;
+      const unsigned int hasx = (unsigned int)bit_at(crossx, q), hasy = (unsigned int)bit_at(crossy, q);
+      o[i] = edge_offset(q, crossx, crossy, crossz, ebase) + (axis == 0 ? 0u : (axis == 1 ? hasx : hasx + hasy));
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    unsigned int* out = indices + (size_t)ibase[word];
+    for (int i = lane; i < total; i += 64) out[i] = stage[wv][i];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+
+// ApplyVertexDeformations (Polygonizer.cl:1417-1426) with the double -> float narrowing of GPUPoly::applyFemDisplacements
+// (OclPolygonizer.cpp:1559-1564) folded in
+__global__ __launch_bounds__(kPB) void k_apply_displacements(long long n, const float* __restrict__ rest, const double* __restrict__ u,
+                                                             float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (i < n) out[i] = rest[i] + (float)u[i];
+}
+
 }  // namespace
 
 struct fb_poly_s {
@@ -546,6 +759,14 @@ struct fb_poly_s {
   DevBuf<unsigned int> totals;  // [0] crossed edges [1] surface cells [2] included cells [3] tet vertices
   DevBuf<float> tv;
   DevBuf<uint4> tt;
+  // marching-cubes surface
+  bool surfaced = false;
+  DevBuf<unsigned char> d_tri, d_nvert, d_edge_info;
+  DevBuf<unsigned long long> surf;
+  DevBuf<unsigned int> edge_pop, idx_pop, ebase, ibase, esum, isum;
+  DevBuf<float> sv, sn, deformed;
+  DevBuf<unsigned int> si;
+  DevBuf<double> disp;
   fb_poly_counts counts;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
@@ -635,7 +856,8 @@ int set_grid(fb_poly_s* h, const float lo[3], float cellsize, const int dims[3])
   h->G = G;
   const size_t pw = (size_t)((G.n_points + 63) / 64);
   FB_TRY(h->grid.alloc((size_t)G.n_points));
-  DevBuf<unsigned long long>* masks[] = {&h->inside, &h->cinc, &h->vinc, &h->lastx, &h->lasty, &h->lastz, &h->valid, &h->crossx, &h->crossy, &h->crossz};
+  DevBuf<unsigned long long>* masks[] = {&h->inside, &h->cinc, &h->vinc, &h->lastx, &h->lasty, &h->lastz, &h->valid, &h->crossx, &h->crossy, &h->crossz,
+                                         &h->surf};
   for (auto* m : masks) FB_TRY(m->alloc(pw + 1));
   FB_TRY(h->vinc_pop.alloc(pw));
   FB_TRY(h->vbase.alloc(pw));
@@ -647,13 +869,17 @@ int set_grid(fb_poly_s* h, const float lo[3], float cellsize, const int dims[3])
   FB_TRY(h->vsum.alloc(pch));
   FB_TRY(h->csum.alloc(pch));
   FB_TRY(h->csum_aux.alloc(2 * pch));
+  DevBuf<unsigned int>* words[] = {&h->edge_pop, &h->idx_pop, &h->ebase, &h->ibase};
+  for (auto* m : words) FB_TRY(m->alloc(pw));
+  FB_TRY(h->esum.alloc(pch));
+  FB_TRY(h->isum.alloc(pch));
   FB_TRY(h->config.alloc((size_t)G.n_cells));
   FB_TRY(h->flags.alloc((size_t)G.n_points));
-  FB_TRY(h->totals.alloc(4));
+  FB_TRY(h->totals.alloc(6));
   hipLaunchKernelGGL(k_grid_masks, dim3((int)((G.n_points + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, G, h->lastx.p, h->lasty.p, h->lastz.p, h->valid.p);
   FB_HIP(hipGetLastError());
   h->materialized = false;
-  h->have_grid = h->classified = h->tetra = false;
+  h->have_grid = h->classified = h->tetra = h->surfaced = false;
   return FB_OK;
 }
 
@@ -673,6 +899,7 @@ int do_classify(fb_poly_s* h) {
   hipLaunchKernelGGL(k_chunk_scan, dim3(pch), dim3(kPB), 0, h->stream, h->vinc_pop.p, (int)pw, h->vsum.p, h->vbase.p);
   FB_HIP(hipGetLastError());
   h->materialized = false;
+  h->surfaced = false;
   return FB_OK;
 }
 
@@ -696,6 +923,37 @@ int do_emit(fb_poly_s* h) {
   hipLaunchKernelGGL(k_tet_vertices, dim3(pb), dim3(kPB), 0, h->stream, G, h->vinc.p, h->vbase.p, h->tv.p);
   FB_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_tet_elements, dim3(pb), dim3(kPB), 0, h->stream, G, h->cinc.p, h->cbase.p, h->vinc.p, h->vbase.p, h->tt.p);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+// scans + emission of the marching-cubes surface; totals[4] = surface vertices, totals[5] = triangle indices
+int do_surface_counts(fb_poly_s* h) {
+  const Grid& G = h->G;
+  const long long pw = (long long)h->vinc_pop.n;
+  const int wb = (int)((pw + kPB - 1) / kPB), pch = (int)h->vsum.n;
+  const unsigned int* none = nullptr;
+  hipLaunchKernelGGL(k_surface_pops, dim3(wb), dim3(kPB), 0, h->stream, G, pw, h->inside.p, h->lastx.p, h->lasty.p, h->lastz.p, h->valid.p, h->aux_pop.p,
+                     h->d_nvert.p, h->surf.p, h->edge_pop.p, h->idx_pop.p);
+  hipLaunchKernelGGL(k_chunk_sums, dim3(pch), dim3(kPB), 0, h->stream, h->edge_pop.p, none, (int)pw, h->esum.p, h->csum_aux.p);
+  hipLaunchKernelGGL(k_chunk_sums, dim3(pch), dim3(kPB), 0, h->stream, h->idx_pop.p, none, (int)pw, h->isum.p, h->csum_aux.p);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kPB), 0, h->stream, h->esum.p, none, pch, h->totals.p + 4, h->totals.p + 0);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kPB), 0, h->stream, h->isum.p, none, pch, h->totals.p + 5, h->totals.p + 0);
+  hipLaunchKernelGGL(k_chunk_scan, dim3(pch), dim3(kPB), 0, h->stream, h->edge_pop.p, (int)pw, h->esum.p, h->ebase.p);
+  hipLaunchKernelGGL(k_chunk_scan, dim3(pch), dim3(kPB), 0, h->stream, h->idx_pop.p, (int)pw, h->isum.p, h->ibase.p);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int do_surface_emit(fb_poly_s* h) {
+  const Grid& G = h->G;
+  const long long pw = (long long)h->vinc_pop.n;
+  const int blocks = (int)std::min<long long>((pw + kPB / 64 - 1) / (kPB / 64), 8192);
+  hipLaunchKernelGGL(k_surface_vertices, dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, h->d_prog.p, (int)h->prog.size(), h->n_prims, h->d_prims.p,
+                     h->d_mtx.p, h->grid.p, h->crossx.p, h->crossy.p, h->crossz.p, h->ebase.p, h->sv.p, h->sn.p);
+  FB_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_surface_elements, dim3(blocks), dim3(kPB), 0, h->stream, G, h->inside.p, h->surf.p, h->ibase.p, h->crossx.p, h->crossy.p, h->crossz.p,
+                     h->ebase.p, h->d_tri.p, h->d_nvert.p, h->d_edge_info.p, h->si.p);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -735,6 +993,10 @@ int fb_poly_create(fb_poly_t* out, int device, const float* header12, int n_ops,
   }
   if (rc == FB_OK) rc = h->d_prims.upload(h->prims, h->stream);
   if (rc == FB_OK) rc = h->d_mtx.upload(h->mtx, h->stream);
+  const CubeTable& ct = cube_table();
+  if (rc == FB_OK) rc = h->d_tri.upload(&ct.tri[0][0], sizeof ct.tri, h->stream);
+  if (rc == FB_OK) rc = h->d_nvert.upload(ct.nvert, sizeof ct.nvert, h->stream);
+  if (rc == FB_OK) rc = h->d_edge_info.upload(ct.edge_info, sizeof ct.edge_info, h->stream);
   if (rc != FB_OK) {
     std::string keep = last_error();
     fb_poly_destroy(h);
@@ -847,6 +1109,59 @@ int fb_poly_read_tetmesh(fb_poly_t h, float* xyz, unsigned int* tets) {
   if (!h->tetra) return fail(FB_EINVAL, "tetrahedralize first");
   if (xyz) FB_TRY(h->tv.download(xyz, 3 * (size_t)h->counts.n_tet_vertices, h->stream));
   if (tets) FB_TRY(h->tt.download((uint4*)tets, (size_t)h->counts.n_tets, h->stream));
+  return FB_OK;
+}
+
+int fb_poly_cube_table(unsigned char tri[4096], unsigned char nvert[256]) {
+  const CubeTable& ct = cube_table();
+  if (tri) memcpy(tri, ct.tri, sizeof ct.tri);
+  if (nvert) memcpy(nvert, ct.nvert, sizeof ct.nvert);
+  return FB_OK;
+}
+
+int fb_poly_surface(fb_poly_t h, fb_poly_counts* counts) {
+  CHECK_POLY(h);
+  if (!h->classified) return fail(FB_EINVAL, "classify first");
+  FB_TRY(do_surface_counts(h));
+  unsigned int t[2];
+  FB_TRY(h->totals.download(t, 2, h->stream, 4));
+  if ((int)t[0] != h->counts.n_crossed_edges) return fail(FB_EDEVICE, "surface vertex scan (%u) disagrees with the edge table (%d)", t[0], h->counts.n_crossed_edges);
+  h->counts.n_surface_vertices = (int)t[0];
+  h->counts.n_surface_indices = (int)t[1];
+  FB_TRY(h->sv.alloc(std::max<size_t>(1, 3 * (size_t)t[0])));
+  FB_TRY(h->sn.alloc(std::max<size_t>(1, 3 * (size_t)t[0])));
+  FB_TRY(h->si.alloc(std::max<size_t>(1, (size_t)t[1])));
+  FB_TRY(do_surface_emit(h));
+  FB_HIP(hipStreamSynchronize(h->stream));
+  h->surfaced = true;
+  if (counts) *counts = h->counts;
+  return FB_OK;
+}
+
+int fb_poly_read_surface(fb_poly_t h, float* xyz, float* normals, unsigned int* indices) {
+  CHECK_POLY(h);
+  if (!h->surfaced) return fail(FB_EINVAL, "run fb_poly_surface first");
+  const size_t nv = 3 * (size_t)h->counts.n_surface_vertices;
+  if (xyz) FB_TRY(h->sv.download(xyz, nv, h->stream));
+  if (normals) FB_TRY(h->sn.download(normals, nv, h->stream));
+  if (indices) FB_TRY(h->si.download(indices, (size_t)h->counts.n_surface_indices, h->stream));
+  return FB_OK;
+}
+
+int fb_poly_apply_displacements(fb_poly_t h, int mesh, int n_dof, const double* displacements, float* xyz_out) {
+  CHECK_POLY(h);
+  const bool tet = mesh == FB_MESH_TET;
+  if (mesh != FB_MESH_TET && mesh != FB_MESH_SURFACE) return fail(FB_EINVAL, "mesh must be FB_MESH_SURFACE or FB_MESH_TET");
+  if (tet ? !h->tetra : !h->surfaced) return fail(FB_EINVAL, "no valid vertex buffer: polygonize first");  // m_isValidVertex
+  const long long n = 3LL * (tet ? h->counts.n_tet_vertices : h->counts.n_surface_vertices);
+  if (n_dof != n || !displacements) return fail(FB_EINVAL, "displacement vector has %d entries, the mesh has %lld", n_dof, n);
+  if (n == 0) return FB_OK;
+  FB_TRY(h->disp.upload(displacements, (size_t)n, h->stream));
+  FB_TRY(h->deformed.alloc((size_t)n));
+  hipLaunchKernelGGL(k_apply_displacements, dim3((int)((n + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, n, tet ? h->tv.p : h->sv.p, h->disp.p, h->deformed.p);
+  FB_HIP(hipGetLastError());
+  if (xyz_out) return h->deformed.download(xyz_out, (size_t)n, h->stream);
+  FB_HIP(hipStreamSynchronize(h->stream));
   return FB_OK;
 }
 

@@ -43,7 +43,8 @@ class StepInfo(C.Structure):
 class PolyCounts(C.Structure):
     _fields_ = [("grid", C.c_int * 3), ("n_points", C.c_int), ("n_cells", C.c_int), ("n_crossed_edges", C.c_int),
                 ("n_surface_cells", C.c_int), ("n_included_cells", C.c_int),
-                ("n_tet_vertices", C.c_int), ("n_tets", C.c_int)]
+                ("n_tet_vertices", C.c_int), ("n_tets", C.c_int), ("n_surface_vertices", C.c_int),
+                ("n_surface_indices", C.c_int)]
 
 
 def build(force=False):
@@ -125,6 +126,10 @@ def lib():
         "fb_poly_tetrahedralize": (C.c_int, [vp, C.POINTER(PolyCounts)]),
         "fb_poly_read_tetmesh": (C.c_int, [vp, _fp, _up]),
         "fb_poly_time_pipeline": (C.c_int, [vp, C.c_int, _dp, _dp]),
+        "fb_poly_surface": (C.c_int, [vp, C.POINTER(PolyCounts)]),
+        "fb_poly_read_surface": (C.c_int, [vp, _fp, _fp, _up]),
+        "fb_poly_cube_table": (C.c_int, [_bp, _bp]),
+        "fb_poly_apply_displacements": (C.c_int, [vp, C.c_int, C.c_int, _dp, _fp]),
     }
     sig.update(poly_sig)
     for name, (res, args) in sig.items():

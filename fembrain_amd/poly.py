@@ -13,6 +13,16 @@ from . import lib as _l
 from .blobtree import BlobTree, read_blob, sphere_blob  # noqa: F401
 
 
+MESH_SURFACE, MESH_TET = 0, 1
+
+
+def cube_table():
+    """The marching-cubes triangle table (256 x 16 edge ids, 255 = end) and per-configuration index counts."""
+    tri, nvert = np.empty((256, 16), np.uint8), np.empty(256, np.uint8)
+    _l.check(_l.lib().fb_poly_cube_table(_l.bptr(tri), _l.bptr(nvert)))
+    return tri, nvert
+
+
 class GpuPoly:
     DEFAULT_CELL_SIZE = 0.14  # reference src/implicit/Polygonizer.h
 
@@ -98,6 +108,33 @@ class GpuPoly:
         self.classify()
         self.tetrahedralize()
         return self.read_tetmesh()
+
+    # GPUPoly::run (OclPolygonizer.cpp:616-760): marching-cubes surface of the current BlobTree
+    def surface(self):
+        c = _l.PolyCounts()
+        _l.check(self._L.fb_poly_surface(self.h, C.byref(c)))
+        self.counts = c
+        return c
+
+    # GPUPoly::readbackMeshV3T3
+    def read_surface(self):
+        nv, ni = self.counts.n_surface_vertices, self.counts.n_surface_indices
+        xyz, nrm, idx = np.empty((nv, 3), np.float32), np.empty((nv, 3), np.float32), np.empty((ni // 3, 3), np.uint32)
+        _l.check(self._L.fb_poly_read_surface(self.h, _l.fptr(xyz), _l.fptr(nrm), _l.uptr(idx)))
+        return xyz, nrm, idx
+
+    def run(self, cellsize=DEFAULT_CELL_SIZE):
+        self.sweep(cellsize)
+        self.classify()
+        self.surface()
+        return self.read_surface()
+
+    # GPUPoly::applyFemDisplacements
+    def apply_fem_displacements(self, displacements, mesh=MESH_SURFACE):
+        u = np.ascontiguousarray(displacements, dtype=np.float64).reshape(-1)
+        out = np.empty((len(u) // 3, 3), np.float32)
+        _l.check(self._L.fb_poly_apply_displacements(self.h, mesh, len(u), _l.dptr(u), _l.fptr(out)))
+        return out
 
     def time_pipeline(self, reps=5):
         a, b = C.c_double(0), C.c_double(0)

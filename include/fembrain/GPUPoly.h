@@ -50,12 +50,32 @@ class GPUPoly {
   void setCellSize(float c) { m_cellsize = c; }
   float cellsize() const { return m_cellsize; }
 
-  // field + classification of the voxel grid; 1 ok, -1 if cellsize < 0.01 or nothing crosses the surface (OclPolygonizer.cpp:644-757)
+  // field sweep, classification and the marching-cubes surface; 1 ok, -1 if cellsize < 0.01 or nothing crosses the
+  // surface (OclPolygonizer.cpp:644-757)
   int run() {
     int dims[3];
     if (fb_poly_sweep(h_, m_cellsize, dims) != FB_OK) return -1;
     if (fb_poly_classify(h_, &m_counts) != FB_OK) return -1;
-    return m_counts.n_crossed_edges > 0 ? 1 : -1;
+    if (m_counts.n_crossed_edges == 0) return -1;
+    return fb_poly_surface(h_, &m_counts) == FB_OK ? 1 : -1;
+  }
+  // GPUPoly::readbackMeshV3T3 (OclPolygonizer.cpp:1696-1744)
+  bool readbackMeshV3T3(U32& ctVertices, std::vector<float>& vertices, U32& ctTriangles, std::vector<U32>& elements) const {
+    ctVertices = (U32)m_counts.n_surface_vertices; ctTriangles = (U32)m_counts.n_surface_indices / 3;
+    vertices.resize(3 * (size_t)ctVertices); elements.resize(3 * (size_t)ctTriangles);
+    return fb_poly_read_surface(h_, vertices.data(), nullptr, elements.data()) == FB_OK;
+  }
+  // GPUPoly::readBackNormals
+  bool readBackNormals(U32& ctVertices, std::vector<float>& verticesXYZ, std::vector<float>& normals) const {
+    ctVertices = (U32)m_counts.n_surface_vertices;
+    verticesXYZ.resize(3 * (size_t)ctVertices); normals.resize(3 * (size_t)ctVertices);
+    return fb_poly_read_surface(h_, verticesXYZ.data(), normals.data(), nullptr) == FB_OK;
+  }
+  // GPUPoly::applyFemDisplacements (OclPolygonizer.cpp:1543-1596) on the surface mesh; `deformed` receives what the
+  // reference writes into its vertex VBO
+  bool applyFemDisplacements(U32 dof, const double* displacements, std::vector<float>* deformed = nullptr, int mesh = FB_MESH_SURFACE) {
+    if (deformed) deformed->resize(dof);
+    return fb_poly_apply_displacements(h_, mesh, (int)dof, displacements, deformed ? deformed->data() : nullptr) == FB_OK;
   }
   // OclPolygonizer.cpp:762-819: needs run() first; returns the number of tets or -1
   int runTetrahedralizer() {

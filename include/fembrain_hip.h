@@ -207,6 +207,8 @@ typedef struct fb_poly_counts {
   int n_included_cells;   /* config != 0 (Tetrahedralizer.cl:3-35) */
   int n_tet_vertices;     /* grid points touched by an included cell */
   int n_tets;             /* 6 per included cell */
+  int n_surface_vertices; /* set by fb_poly_surface: = n_crossed_edges (m_ctVertices of GPUPoly::run) */
+  int n_surface_indices;  /* set by fb_poly_surface: 3 per triangle (m_ctFaceElements) */
 } fb_poly_counts;
 
 /* ComputeEdgeTable + ComputeCellConfigs + TetMeshCells + the exclusive scans, all on the device
@@ -220,6 +222,28 @@ int fb_poly_read_classification(fb_poly_t h, unsigned char* edge_flags, unsigned
 int fb_poly_tetrahedralize(fb_poly_t h, fb_poly_counts* counts);
 /* xyz: 3 floats per tet-mesh vertex, tets: 4 uint32 per tet (both sized from fb_poly_counts) */
 int fb_poly_read_tetmesh(fb_poly_t h, float* xyz, unsigned int* tets);
+
+/* ---- marching-cubes surface: GPUPoly::run steps 3,4,6,7 (OclPolygonizer.cpp:663-757) ------------------------------
+ * Replaces ComputeVertexAttribs (data/opencl/Polygonizer.cl:1429-1561, linear root + forward-difference normal,
+ * 4 field evaluations per vertex), ComputeElements (:1610-1670) and the two host scans between them.  Needs
+ * fb_poly_classify on a grid swept WITH stored samples.  Vertex colours (ComputeFieldAndColor) are not produced. */
+int fb_poly_surface(fb_poly_t h, fb_poly_counts* counts);
+/* GPUPoly::readbackMeshV3T3 (OclPolygonizer.cpp:1696-1744): 3 floats per vertex / normal, 3 uint32 per triangle;
+ * any pointer may be NULL */
+int fb_poly_read_surface(fb_poly_t h, float* xyz, float* normals, unsigned int* indices);
+/* the 256 x 16 triangle table (edge ids, 255 = end) and vertex counts the surface pass uses -- the data of
+ * src/implicit/_CellConfigTable.h:58-317 / _CellConfigTableCompact.cpp, regenerated from Bloomenthal's cube-table
+ * procedure at load time; host only, needs no device */
+int fb_poly_cube_table(unsigned char tri[4096], unsigned char nvert[256]);
+
+#define FB_MESH_SURFACE 0
+#define FB_MESH_TET 1
+/* GPUPoly::applyFemDisplacements (OclPolygonizer.cpp:1543-1596; ApplyVertexDeformations, Polygonizer.cl:1417-1426):
+ * out = rest position + (float)displacement for every vertex of the surface or the tet mesh; the rest positions are
+ * kept.  n_dof must be 3 x the mesh's vertex count (FB_EINVAL otherwise -- the reference does not check).  The
+ * deformed positions stay on the device and are copied to xyz_out when it is not NULL. */
+int fb_poly_apply_displacements(fb_poly_t h, int mesh, int n_dof, const double* displacements, float* xyz_out);
+
 /* average device seconds of one sweep / one classify+tetrahedralize pipeline on the current grid */
 int fb_poly_time_pipeline(fb_poly_t h, int reps, double* sweep_seconds, double* pipeline_seconds);
 

@@ -34,8 +34,17 @@ def _lib():
     lib.orc_scan.argtypes = [_up, _up, C.c_size_t]
     lib.orc_tet_vertices.argtypes = [_fp, _up, _up, C.c_size_t, _fp]
     lib.orc_tet_elements.argtypes = [_up, _up, _up, _ip, _up]
+    lib.orc_cube_table.argtypes = [_bp, _bp]
+    lib.orc_vertex_attribs.argtypes = tree + [_fp, _ip, _up, _bp, _up, _fp, _fp]
+    lib.orc_cell_elements.argtypes = [_bp, _ip, _bp, _bp, _up, _up, _bp, _up]
     lib._field_bound = True
     return lib
+
+
+def cube_table():
+    tri, nvert = np.empty((256, 16), np.uint8), np.empty(256, np.uint8)
+    _lib().orc_cube_table(tri.ctypes.data_as(_bp), nvert.ctypes.data_as(_bp))
+    return tri, nvert
 
 
 class OrcPoly:
@@ -99,6 +108,22 @@ class OrcPoly:
         self.lib.orc_tet_elements(voff.ctypes.data_as(_up), coff.ctypes.data_as(_up), self.inc_cells.ctypes.data_as(_up),
                                   self.g.ctypes.data_as(_ip), tets.ctypes.data_as(_up))
         return xyz, tets
+
+    def surface(self):
+        """GPUPoly::run steps 3,4,6,7 after classify(): (xyz, normals, triangles)."""
+        npts, ncells = len(self.xyzf), len(self.config)
+        gp = self.g.ctypes.data_as(_ip)
+        tri, nvert = cube_table()
+        eoff, coff = np.empty(npts, np.uint32), np.empty(ncells, np.uint32)
+        nv = self.lib.orc_scan(self.edge_count.ctypes.data_as(_up), eoff.ctypes.data_as(_up), npts)
+        per_cell = nvert[self.config].astype(np.uint32)
+        ni = self.lib.orc_scan(per_cell.ctypes.data_as(_up), coff.ctypes.data_as(_up), ncells)
+        pos, nrm, idx = np.empty((nv, 3), np.float32), np.empty((nv, 3), np.float32), np.empty(ni, np.uint32)
+        self.lib.orc_vertex_attribs(*self._tree, _f(self.xyzf), gp, self.edge_count.ctypes.data_as(_up), self.edge_flags.ctypes.data_as(_bp),
+                                    eoff.ctypes.data_as(_up), _f(pos), _f(nrm))
+        self.lib.orc_cell_elements(self.config.ctypes.data_as(_bp), gp, tri.ctypes.data_as(_bp), nvert.ctypes.data_as(_bp), coff.ctypes.data_as(_up),
+                                   eoff.ctypes.data_as(_up), self.edge_flags.ctypes.data_as(_bp), idx.ctypes.data_as(_up))
+        return pos, nrm, idx.reshape(-1, 3)
 
     def run_tetrahedralizer(self, cellsize):
         self.sweep(cellsize)

@@ -57,6 +57,14 @@ int main() {
   std::vector<PS::SKETCH::U32> el;
   poly.readbackTetMesh(nv, xyz, nt, el);
   std::printf("POLY_RUN=%d\nPOLY_TETS=%d\nPOLY_VERTS=%u\n", ok, ntets, nv);
+  PS::SKETCH::U32 sv, st;
+  std::vector<float> sxyz, snrm, moved;
+  std::vector<PS::SKETCH::U32> sel;
+  poly.readbackMeshV3T3(sv, sxyz, st, sel);
+  poly.readBackNormals(sv, sxyz, snrm);
+  std::vector<double> shift(3 * (size_t)sv, 0.25);
+  const bool applied = poly.applyFemDisplacements(3 * sv, shift.data(), &moved);
+  std::printf("SURF_VERTS=%u\nSURF_TRIS=%u\nSURF_APPLIED=%d\nSURF_SHIFT=%.9g\n", sv, st, applied ? 1 : 0, sv ? moved[0] - sxyz[0] : 0.0f);
   PS::SKETCH::FieldComputer fc(blob);
   std::printf("FIELD_025=%.9g\nGRID_POINTS=%d\n", fc.field(0.25f, 0, 0), fc.fieldsForVoxelGrid(0.1f));
   std::vector<double> xv(xyz.begin(), xyz.end());

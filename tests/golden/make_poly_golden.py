@@ -30,3 +30,23 @@ np.savez_compressed(os.path.join(os.path.dirname(__file__), "sphere_tets_c0.1.np
                     first_cell_xyz=cells[0].astype(np.float32), last_cell_xyz=cells[-1].astype(np.float32),
                     grid=np.array([12, 12, 12], np.int32), cellsize=np.float32(0.1), lower=np.array([-0.5, -0.5, -0.5], np.float32))
 print("cells", len(cells), "pattern", local[0].tolist())
+
+# ---- marching-cubes tables: hashes only (the arrays themselves are reference source text and stay there) ----
+import hashlib
+import json
+import re
+
+src = open("/root/reference/src/implicit/_CellConfigTable.h").read()
+rows = re.findall(r"\{([^{}]*)\}", src[src.index("g_triTableCache[256][16]"):])[:256]
+tri = np.array([[255 if int(x) < 0 else int(x) for x in r.replace(" ", "").split(",") if x.strip()] for r in rows], np.uint8)
+assert tri.shape == (256, 16)
+src = open("/root/reference/src/implicit/_CellConfigTableCompact.cpp").read()
+src = src[src.index("g_numVerticesTableCompact[256]"):]
+nvert = np.array([int(x) for x in re.findall(r"\d+", src[src.index("{"):src.index("}")])], np.uint8)
+assert nvert.shape == (256,) and np.array_equal(nvert, (tri != 255).sum(1))
+json.dump({"tri_table_u8_256x16_sha256": hashlib.sha256(tri.tobytes()).hexdigest(),
+           "num_vertices_u8_256_sha256": hashlib.sha256(nvert.tobytes()).hexdigest(),
+           "total_indices": int(nvert.sum()),
+           "note": "-1 entries hashed as 255; source src/implicit/_CellConfigTable.h:58-317 and _CellConfigTableCompact.cpp"},
+          open(os.path.join(os.path.dirname(__file__), "mc_table.json"), "w"), indent=1)
+print("mc table hashed,", int(nvert.sum()), "indices")

@@ -7,6 +7,8 @@ import numpy as np
 from fembrain_amd.blobtree import make_tree, read_blob, sphere_blob
 from oracle.pyfield import OrcPoly
 
+from meshchecks import surface_mesh_checks
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -70,3 +72,44 @@ def test_classification_definitions_on_a_blob_file():
     assert c["n_included_cells"] == (cells != 0).sum()
     xyz, tets = o.tetrahedralize()
     assert len(tets) == 6 * c["n_included_cells"] and tets.max() == len(xyz) - 1
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_cube_table_equals_the_reference_table():
+    """Both regenerations of the marching-cubes table (oracle C, product host code; Bloomenthal's cube-table walk) hash to
+    the reference's own array (tests/golden/mc_table.json, made by make_poly_golden.py from _CellConfigTable.h)."""
+    import json
+    from fembrain_amd.poly import cube_table as product_table
+    from oracle.pyfield import cube_table as oracle_table
+    gold = json.load(open(os.path.join(GOLD, "mc_table.json")))
+    for tri, nvert in (oracle_table(), product_table()):
+        assert _sha(tri) == gold["tri_table_u8_256x16_sha256"]
+        assert _sha(nvert) == gold["num_vertices_u8_256_sha256"]
+        assert int(nvert.sum()) == gold["total_indices"]
+
+
+def test_surface_of_the_sphere_is_a_closed_oriented_manifold():
+    """parity unpinned by the reference (it holds no marching-cubes output); pinned by geometry instead."""
+    o = OrcPoly(sphere_blob())
+    o.sweep(0.1)
+    c = o.classify()
+    xyz, nrm, tri = o.surface()
+    assert len(xyz) == c["n_crossed_edges"]
+    # Wyvill (1 - r^2)^3 = 0.5
+    surface_mesh_checks(xyz, nrm, tri, radius=np.sqrt(1 - 0.5 ** (1 / 3)))
+    assert len(xyz) - 3 * len(tri) // 2 + len(tri) == 2  # Euler characteristic of a sphere
+    f = o.field_array(np.concatenate([xyz, np.zeros((len(xyz), 1), np.float32)], 1))[:, 3]
+    assert np.abs(f - 0.5).max() < 0.02
+
+
+def test_surface_of_blob_files_is_closed():
+    for name in ("peanut", "tumor"):
+        o = OrcPoly(read_blob(os.path.join(GOLD, "blob", name + ".blob")))
+        o.sweep(0.15)
+        o.classify()
+        xyz, nrm, tri = o.surface()
+        surface_mesh_checks(xyz, nrm, tri)

@@ -1,4 +1,4 @@
-"""Parity of the HIP field / classification / tetrahedralizer path (through the C ABI) against the CPU oracle and
+"""Parity of the HIP field / classification / tetrahedralizer / marching-cubes surface path (through the C ABI) against the CPU oracle and
 the reference's golden sphere mesh.  Integer outputs (flags, configs, tet connectivity) and fp32 field values of
 sqrt-free primitives are compared bit-exactly; primitives that go through sqrt / pow are compared to 1e-6."""
 import os
@@ -9,6 +9,8 @@ import pytest
 from fembrain_amd.blobtree import make_tree, read_blob, sphere_blob
 from fembrain_amd.poly import GpuPoly
 from oracle.pyfield import OrcPoly
+
+from meshchecks import surface_mesh_checks
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -203,3 +205,95 @@ def test_non_multiple_of_64_row_length_grid(gpu):
         xyz, tets = g.read_tetmesh()
         oxyz, otets = o.tetrahedralize()
         assert np.array_equal(tets, otets) and np.array_equal(xyz, oxyz)
+
+
+# ---- marching-cubes surface (GPUPoly::run) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,cellsize", [("sphere", 0.1), ("blend6_noops", 0.07), ("range_blend", 0.11), ("two_ranges", 0.09), ("nested", 0.08),
+                                           ("peanut.blob", 0.15), ("tumor.blob", 0.2)])
+def test_surface_matches_oracle(gpu, name, cellsize):
+    """Triangle indices bit-exact; vertex positions bit-exact (same fp32 operation order); normals to 1e-6 for sqrt-free
+    trees.  Trees with sqrt/pow primitives differ from the oracle by an ulp in the field, which the forward difference
+    over delta = 1e-4 amplifies 1e4-fold in the gradient, so their normals are held to 2e-2 only."""
+    blob = read_blob(os.path.join(GOLD, "blob", name)) if name.endswith(".blob") else _trees()[name]
+    g, o = GpuPoly(blob), OrcPoly(blob)
+    g.sweep(cellsize)
+    og = o.sweep(cellsize)
+    grid = g.read_grid()
+    c = g.classify()
+    oc = o.classify()
+    exact_field = np.array_equal(grid, og)
+    if not exact_field and (np.abs(og[:, 3] - 0.5) <= 1e-5).any():
+        pytest.skip("a grid sample within rounding of the iso value: the two classifications may differ")
+    assert c.n_crossed_edges == oc["n_crossed_edges"]
+    c = g.surface()
+    xyz, nrm, tri = g.read_surface()
+    oxyz, onrm, otri = o.surface()
+    assert c.n_surface_vertices == len(oxyz) == c.n_crossed_edges and c.n_surface_indices == 3 * len(otri)
+    assert np.array_equal(tri, otri)
+    if exact_field:
+        assert np.array_equal(xyz, oxyz)
+        assert np.abs(nrm - onrm).max() <= (1e-6 if name in ("sphere", "blend6_noops", "range_blend", "two_ranges") else 2e-2)
+    else:
+        assert np.abs(xyz - oxyz).max() <= 1e-5
+        assert np.abs(nrm - onrm).max() <= 2e-2
+    lo = np.asarray(blob.bbox[0], np.float64)
+    surface_mesh_checks(xyz, nrm, tri, box=None if name == "sphere" or name.endswith(".blob") else (lo, lo + cellsize * (np.array(g.dims) - 1)),
+                        smooth=name != "nested")
+
+
+def test_surface_sphere_256(gpu):
+    """BASELINE config 3 grid: the surface is a closed, consistently oriented 2-manifold of genus 0 on the iso-sphere."""
+    g = GpuPoly(sphere_blob())
+    g.sweep_grid((-0.5, -0.5, -0.5), 1.0 / 254.0, (256, 256, 256))
+    c = g.classify()
+    c = g.surface()
+    assert c.n_surface_vertices == c.n_crossed_edges and c.n_surface_indices % 3 == 0
+    xyz, nrm, tri = g.read_surface()
+    surface_mesh_checks(xyz, nrm, tri, radius=np.sqrt(1 - 0.5 ** (1 / 3)), tol=2e-4, ntol=5e-2)
+    assert len(xyz) - 3 * len(tri) // 2 + len(tri) == 2
+    f = g.compute_field_array(np.concatenate([xyz, np.zeros((len(xyz), 1), np.float32)], 1))[:, 3]
+    assert np.abs(f - 0.5).max() < 1e-3
+
+
+def test_surface_on_ragged_and_empty_grids(gpu):
+    blob = _trees()["two_ranges"]
+    lo = np.array([-1.1, -0.9, -1.0], np.float32)
+    g, o = GpuPoly(blob), OrcPoly(blob)
+    g.sweep_grid(lo, 0.061, (37, 29, 33))
+    og = o.sweep_grid(lo, 0.061, (37, 29, 33))
+    assert np.array_equal(g.read_grid(), og)
+    g.classify(); o.classify()
+    g.surface()
+    xyz, nrm, tri = g.read_surface()
+    oxyz, onrm, otri = o.surface()
+    assert np.array_equal(tri, otri) and np.array_equal(xyz, oxyz) and np.abs(nrm - onrm).max() <= 1e-6
+    # no surface at all
+    g.sweep_grid((5.0, 5.0, 5.0), 0.1, (9, 8, 7))
+    g.classify()
+    c = g.surface()
+    assert (c.n_surface_vertices, c.n_surface_indices) == (0, 0)
+    xyz, nrm, tri = g.read_surface()
+    assert xyz.shape == (0, 3) and tri.shape == (0, 3)
+
+
+def test_apply_fem_displacements(gpu):
+    from fembrain_amd import lib as fl
+    from fembrain_amd.poly import MESH_SURFACE, MESH_TET
+    g = GpuPoly(sphere_blob())
+    g.sweep(0.1)
+    g.classify()
+    with pytest.raises(fl.FbError):
+        g.apply_fem_displacements(np.zeros(3), MESH_SURFACE)   # m_isValidVertex is false before run()
+    g.surface()
+    g.tetrahedralize()
+    sxyz, _, _ = g.read_surface()
+    txyz, _ = g.read_tetmesh()
+    rng = np.random.default_rng(5)
+    for mesh, rest in ((MESH_SURFACE, sxyz), (MESH_TET, txyz)):
+        u = rng.normal(scale=0.01, size=rest.size)
+        out = g.apply_fem_displacements(u, mesh)
+        assert np.array_equal(out, rest + u.reshape(-1, 3).astype(np.float32))
+        with pytest.raises(fl.FbError):
+            g.apply_fem_displacements(u[:-3], mesh)
+    # rest positions are kept
+    assert np.array_equal(g.read_surface()[0], sxyz) and np.array_equal(g.read_tetmesh()[0], txyz)
