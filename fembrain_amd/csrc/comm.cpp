@@ -20,6 +20,7 @@ typedef int ncclResult_t;
 enum { ncclSuccess = 0 };
 enum { ncclSum = 0 };
 enum { ncclFloat64 = 8 };
+enum { ncclUint8 = 1 };
 
 struct Rccl {
   void* lib = nullptr;
@@ -27,6 +28,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -59,6 +61,7 @@ int load_rccl() {
   SYM(CommInitRank, "ncclCommInitRank");
   SYM(CommDestroy, "ncclCommDestroy");
   SYM(AllReduce, "ncclAllReduce");
+  SYM(AllGather, "ncclAllGather");
   SYM(Send, "ncclSend");
   SYM(Recv, "ncclRecv");
   SYM(GroupStart, "ncclGroupStart");
@@ -85,6 +88,7 @@ struct LocalShm {
   std::atomic<int> sense;
   double scal[kLocalMaxRanks][8];
   int send_off[kLocalMaxRanks][kLocalMaxRanks + 1];
+  char meta[kLocalMaxRanks][512];
   size_t outbox_bytes;
   // followed by n_ranks outboxes of outbox_bytes each
 };
@@ -148,6 +152,21 @@ int local_exchange(fb_comm_s* c, const double* sendbuf, const int* send_off, dou
   return FB_OK;
 }
 
+int local_allgather(fb_comm_s* c, const void* mine, void* all, size_t bytes) {
+  LocalComm* L = (LocalComm*)c->local;
+  if (bytes > sizeof L->shm->meta[0]) return fb::fail(FB_EINVAL, "local transport: all-gather item too large");
+  memcpy(L->shm->meta[c->rank], mine, bytes);
+  local_barrier(L, c->n_ranks);
+  for (int r = 0; r < c->n_ranks; r++) memcpy((char*)all + (size_t)r * bytes, L->shm->meta[r], bytes);
+  local_barrier(L, c->n_ranks);
+  return FB_OK;
+}
+
+bool env_flag(const char* name, bool dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) != 0 : dflt;
+}
+
 }  // namespace
 
 extern "C" {
@@ -177,6 +196,7 @@ int fb_comm_create(fb_comm_t* out, int rank, int n_ranks, const unsigned char id
     ncclResult_t nr = g_rccl.CommInitRank(&comm, n_ranks, u, rank);
     if (nr != ncclSuccess) { delete c; return fb::fail(FB_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(nr)); }
     c->nccl = comm;
+    c->want_p2p = env_flag("FEMBRAIN_P2P", true);  // direct xGMI mailboxes for the per-iteration exchanges (comm.h)
   }
   *out = c;
   return FB_OK;
@@ -196,6 +216,7 @@ int fb_comm_create_local(fb_comm_t* out, int rank, int n_ranks, const char* shm_
   L->shm->outbox_bytes = outbox_bytes;  // same value from every rank; a fresh segment is zero-filled (count = sense = 0)
   fb_comm_s* c = new fb_comm_s;
   c->rank = rank; c->n_ranks = n_ranks; c->device = device; c->local = L;
+  c->want_p2p = env_flag("FEMBRAIN_P2P", false);  // the test transport stays host-staged unless asked
   *out = c;
   return FB_OK;
 }
@@ -222,6 +243,17 @@ int comm_allreduce_sum(fb_comm_s* c, double* dev_buf, int count, hipStream_t s) 
   if (!c || !c->nccl) return FB_OK;
   FB_NCCL(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)c->nccl, s));
   return FB_OK;
+}
+
+int comm_allgather_bytes(fb_comm_s* c, const void* mine, void* all, size_t bytes, hipStream_t s) {
+  if (!c || c->n_ranks == 1) { memcpy(all, mine, bytes); return FB_OK; }
+  if (c->local) return local_allgather(c, mine, all, bytes);
+  if (!c->nccl) return fail(FB_ECOMM, "communicator has no transport");
+  DevBuf<unsigned char> in, out;
+  FB_TRY(in.upload((const unsigned char*)mine, bytes, s));
+  FB_TRY(out.alloc(bytes * (size_t)c->n_ranks));
+  FB_NCCL(g_rccl.AllGather(in.p, out.p, bytes, ncclUint8, (ncclComm_t)c->nccl, s));
+  return out.download((unsigned char*)all, bytes * (size_t)c->n_ranks, s);
 }
 
 int comm_exchange_nodes(fb_comm_s* c, const double* sendbuf, const int* send_off, double* recv_base, const int* recv_off, int width,

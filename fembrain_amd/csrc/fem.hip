@@ -14,6 +14,8 @@ struct fb_fem_s {
   fb_fem_params prm;
   hipStream_t stream = nullptr;
   fb_comm_s* comm = nullptr;  // not owned
+  P2P* p2p = nullptr;         // direct peer mailboxes for halo refresh and dots (comm.h); null = collective library
+  DevBuf<int> send_dest, send_off_dev, halo_off_dev;
   FemPlan plan;
   double lambda = 0, mu = 0;
   int grid = 8;
@@ -123,6 +125,9 @@ int halo_exchange(fb_fem_s* h, double* vec, int width = 3) {
   if (!h->comm || h->comm->n_ranks == 1) return FB_OK;
   const FemPlan& P = h->plan;
   const int ns = (int)P.send_local.size();
+  if (h->p2p)
+    return p2p_halo(h->p2p, width, ns, h->send_local.p, h->send_dest.p, h->send_off_dev.p, P.n_local - P.n_owned, h->halo_off_dev.p, P.n_owned, vec,
+                    h->stream);
   if (ns > 0) {
     hipLaunchKernelGGL(k_pack_nodes, dim3(ceil_div(ns * width, kBlock)), dim3(kBlock), 0, h->stream, ns, width, h->send_local.p, vec, h->sendbuf.p);
     FB_HIP(hipGetLastError());
@@ -197,6 +202,11 @@ __global__ __launch_bounds__(kBlock) void k_fold_partials(const double* partial,
 int global_scalar(fb_fem_s* h, const double* partial, double** out, bool check_done, int count = 1, int slot = 0) {
   *out = nullptr;
   if (!h->comm || (!h->comm->nccl && !h->comm->local)) return FB_OK;
+  if (h->p2p) {  // fold + exchange + rank-ordered sum in one single-block kernel
+    FB_TRY(p2p_reduce(h->p2p, partial, h->grid, count, h->scal.p + slot, h->stream));
+    *out = h->scal.p;
+    return FB_OK;
+  }
   hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(kBlock), 0, h->stream, partial, h->grid, count, h->scal.p + slot, check_done ? h->st.p : nullptr);
   FB_HIP(hipGetLastError());
   // a converged solve leaves the previous (identical on every rank) values in place; the all-reduce still runs on
@@ -283,6 +293,7 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
     slot ^= 1;
   }
   FB_HIP(hipStreamSynchronize(s));
+  if (h->p2p) FB_TRY(p2p_check(h->p2p, s));
   // the newest snapshot is in the slot written last
   fin = h->st_host[slot ^ 1];
   if (!host_finished(fin)) return fail(FB_EDEVICE, "internal: PCG batches ended without a terminal state (iter %d)", fin.iter);
@@ -366,6 +377,7 @@ int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int*
     slot ^= 1;
   }
   FB_HIP(hipStreamSynchronize(s));
+  if (h->p2p) FB_TRY(p2p_check(h->p2p, s));
   const CGState fin = h->st_host[slot ^ 1];
   if (!fin.done) return fail(FB_EDEVICE, "internal: fused PCG ended without a terminal state (iter %d)", fin.iter);
   const double rho = fin.rho[(fin.iter + 1) & 1];
@@ -384,6 +396,21 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
   FB_TRY(upload_plan(h, xyz));
   FB_TRY(launch_rest(h));
   FB_HIP(hipStreamSynchronize(h->stream));
+  return FB_OK;
+}
+
+// collective: every rank of the communicator creates its handle at the same point of its program
+int attach_p2p(fb_fem_s* h) {
+  const FemPlan& P = h->plan;
+  FB_TRY(p2p_attach(h->comm, P.n_local - P.n_owned, P.halo_off.data(), h->stream, &h->p2p));
+  if (!h->p2p) return FB_OK;
+  std::vector<int> dest(std::max<size_t>(1, P.send_local.size()), 0);
+  for (int q = 0; q < P.n_ranks; q++)
+    for (int i = P.send_off[q]; i < P.send_off[q + 1]; i++) dest[i] = q;
+  FB_TRY(h->send_dest.upload(dest, h->stream));
+  FB_TRY(h->send_off_dev.upload(P.send_off, h->stream));
+  FB_TRY(h->halo_off_dev.upload(P.halo_off, h->stream));
+  if (P.send_local.empty()) FB_TRY(h->send_local.alloc(1));
   return FB_OK;
 }
 
@@ -413,6 +440,7 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
     if (rc != FB_OK) break;
     if (hipHostMalloc((void**)&h->st_host, 2 * sizeof(CGState), hipHostMallocDefault) != hipSuccess) { rc = fail(FB_ENOMEM, "hipHostMalloc failed"); break; }
     rc = build(h, n_nodes, xyz, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits);
+    if (rc == FB_OK && comm && comm->n_ranks > 1) rc = attach_p2p(h);
   } while (0);
   if (rc != FB_OK) {
     std::string keep = last_error();
@@ -525,12 +553,19 @@ int fb_fem_destroy(fb_fem_t h) {
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->ev_batch) if (e) (void)hipEventDestroy(e);
   if (h->st_host) (void)hipHostFree(h->st_host);
+  if (h->p2p) p2p_detach(h->p2p);
   DevBuf<double>* vecs[] = {&h->q, &h->qvel, &h->fext, &h->fint, &h->rhs, &h->x, &h->r, &h->d, &h->Ad, &h->invdiag, &h->tmp};
   for (auto* v : vecs) v->release();
   hipStream_t s = h->stream;
   delete h;  // frees the remaining device buffers
   if (s) (void)hipStreamDestroy(s);
   return FB_OK;
+}
+
+int fb_fem_transport(fb_fem_t h) {
+  if (!h) return -1;
+  if (!h->comm || h->comm->n_ranks == 1) return 0;
+  return h->p2p ? 2 : 1;
 }
 
 int fb_fem_resync(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed_dofs, const int* fixed_dofs) {

@@ -1,0 +1,226 @@
+// Direct peer-to-peer exchange for the sharded PCG loop (see comm.h): inbox layout, the two exchange kernels and the
+// collective set-up over HIP IPC.
+#include "comm.h"
+#include "common.h"
+#include "fem_kernels.h"
+
+namespace fb {
+
+namespace {
+
+// inbox layout (bytes)
+constexpr size_t kOffHaloFlag = 0;     // u64[kP2PMaxRanks]   written by peer q at [q]
+constexpr size_t kOffRedFlag = 128;    // u64[kP2PMaxRanks]
+constexpr size_t kOffErr = 256;        // u64
+constexpr size_t kOffRed = 512;        // double[2][kP2PMaxRanks][8]
+constexpr size_t kOffHalo = 4096;      // double[2][cap * 12]
+constexpr int kMaxWidth = 12;
+
+struct Meta {  // what every rank publishes at attach time
+  hipIpcMemHandle_t handle;
+  long long cap;
+  int halo_off[kP2PMaxRanks + 1];
+  int ok;
+};
+
+__device__ __forceinline__ unsigned long long ld_acquire_sys(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_release_sys(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// spin until *flag >= seq; bounded by the wall clock.  A timeout anywhere poisons the inbox so that the queue drains.
+__device__ bool wait_flag(const P2PDev& c, const unsigned long long* flag, unsigned long long seq) {
+  unsigned long long* err = (unsigned long long*)(c.inbox + kOffErr);
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return false;
+  const long long t0 = wall_clock64();
+  while (ld_acquire_sys(flag) < seq) {
+    if (wall_clock64() - t0 > c.timeout_ticks) {
+      __hip_atomic_store(err, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return true;
+}
+
+// phase 1: every thread stores its share of my boundary values straight into the destination's inbox; the last block
+// to finish publishes the sequence number to the destinations.  phase 2: wait for the neighbours' numbers and copy
+// their values from my inbox into the halo part of the vector.  A block in phase 2 only depends on the peers' phase 1.
+__global__ __launch_bounds__(kBlock) void k_p2p_halo(P2PDev c, int width, unsigned long long seq, int n_send, const int* __restrict__ send_ids,
+                                                     const int* __restrict__ send_dest, const int* __restrict__ send_off, int n_halo,
+                                                     const int* __restrict__ halo_off, int n_owned, double* __restrict__ vec, int* __restrict__ counter) {
+  __shared__ int last;
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x, stride = (long long)gridDim.x * kBlock;
+  const int par = (int)(seq & 1ULL);
+  for (long long i = tid; i < (long long)n_send * width; i += stride) {
+    const int node = (int)(i / width), cc = (int)(i - (long long)node * width);
+    const int q = send_dest[node];
+    double* dst = (double*)(c.peer[q] + kOffHalo) + (size_t)par * c.peer_cap[q] * kMaxWidth + (size_t)(c.peer_seg[q] + node - send_off[q]) * width + cc;
+    *dst = vec[(size_t)width * send_ids[node] + cc];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (last) {
+    __threadfence();
+    if (threadIdx.x == 0) atomicExch(counter, 0);
+    const int q = threadIdx.x;
+    if (q < c.n_ranks && q != c.rank && send_off[q + 1] > send_off[q]) st_release_sys((unsigned long long*)(c.peer[q] + kOffHaloFlag) + c.rank, seq);
+  }
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < c.n_ranks; q++)
+      if (q != c.rank && halo_off[q + 1] > halo_off[q]) wait_flag(c, (const unsigned long long*)(c.inbox + kOffHaloFlag) + q, seq);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  const double* in = (const double*)(c.inbox + kOffHalo) + (size_t)par * c.cap * kMaxWidth;
+  double* out = vec + (size_t)width * n_owned;
+  for (long long i = tid; i < (long long)n_halo * width; i += stride) out[i] = __builtin_nontemporal_load(in + i);
+}
+
+// one block: fold my per-block partial sums, post them into every rank's inbox (mine included), wait for everybody's,
+// add in rank order.
+__global__ __launch_bounds__(kBlock) void k_p2p_reduce(P2PDev c, unsigned long long seq, const double* __restrict__ partial, int n, int count,
+                                                       double* __restrict__ out) {
+  __shared__ double lds[4];
+  __shared__ double mine[8];
+  for (int k = 0; k < count; k++) {
+    const double s = sum_partials(partial + (size_t)k * n, n, lds);
+    if (threadIdx.x == 0) mine[k] = s;
+  }
+  __syncthreads();
+  const int par = (int)(seq & 1ULL), t = threadIdx.x;
+  if (t < c.n_ranks) {
+    double* slot = (double*)(c.peer[t] + kOffRed) + ((size_t)par * kP2PMaxRanks + c.rank) * 8;
+    for (int k = 0; k < count; k++) slot[k] = mine[k];
+    __threadfence_system();
+    st_release_sys((unsigned long long*)(c.peer[t] + kOffRedFlag) + c.rank, seq);
+    wait_flag(c, (const unsigned long long*)(c.inbox + kOffRedFlag) + t, seq);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (t < count) {
+    const double* slots = (const double*)(c.inbox + kOffRed) + (size_t)par * kP2PMaxRanks * 8;
+    double tot = 0.0;
+    for (int r = 0; r < c.n_ranks; r++) tot += __builtin_nontemporal_load(slots + (size_t)r * 8 + t);
+    out[t] = tot;
+  }
+}
+
+}  // namespace
+
+struct P2P {
+  P2PDev dev;
+  fb_comm_s* comm = nullptr;
+  void* opened[kP2PMaxRanks] = {nullptr};
+  unsigned long long halo_seq = 0, red_seq = 0;
+  int* counter = nullptr;
+  double* probe = nullptr;  // 2 doubles of ordinary device memory
+  size_t inbox_bytes = 0;
+};
+
+void p2p_detach(P2P* p) {
+  if (!p) return;
+  (void)hipDeviceSynchronize();
+  for (int q = 0; q < p->dev.n_ranks; q++)
+    if (p->opened[q]) (void)hipIpcCloseMemHandle(p->opened[q]);
+  if (p->dev.inbox) (void)hipFree(p->dev.inbox);
+  if (p->counter) (void)hipFree(p->counter);
+  if (p->probe) (void)hipFree(p->probe);
+  delete p;
+}
+
+int p2p_reduce(P2P* p, const double* partial, int n, int count, double* out, hipStream_t s) {
+  if (count < 1 || count > 8 || n < 1 || n > kMaxPartials) return fail(FB_EINVAL, "p2p_reduce: bad sizes");
+  hipLaunchKernelGGL(k_p2p_reduce, dim3(1), dim3(kBlock), 0, s, p->dev, ++p->red_seq, partial, n, count, out);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int p2p_halo(P2P* p, int width, int n_send, const int* send_ids, const int* send_dest, const int* send_off_dev, int n_halo,
+             const int* halo_off_dev, int n_owned, double* vec, hipStream_t s) {
+  if (width < 1 || width > kMaxWidth || n_halo > p->dev.cap) return fail(FB_EINVAL, "p2p_halo: bad sizes");
+  const long long work = (long long)std::max(n_send, n_halo) * width;
+  const int blocks = (int)std::max<long long>(1, std::min<long long>((work + kBlock - 1) / kBlock, 256));  // all co-resident
+  hipLaunchKernelGGL(k_p2p_halo, dim3(blocks), dim3(kBlock), 0, s, p->dev, width, ++p->halo_seq, n_send, send_ids, send_dest, send_off_dev, n_halo,
+                     halo_off_dev, n_owned, vec, p->counter);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int p2p_check(P2P* p, hipStream_t s) {
+  unsigned long long err = 0;
+  FB_HIP(hipMemcpyAsync(&err, p->dev.inbox + kOffErr, sizeof err, hipMemcpyDeviceToHost, s));
+  FB_HIP(hipStreamSynchronize(s));
+  if (err) return fail(FB_ECOMM, "peer-to-peer exchange timed out on rank %d (a peer stopped or the mapping is broken)", p->dev.rank);
+  return FB_OK;
+}
+
+int p2p_attach(fb_comm_s* c, int n_halo_nodes, const int* halo_off, hipStream_t s, P2P** out) {
+  *out = nullptr;
+  if (!c || c->n_ranks < 2 || !c->want_p2p) return FB_OK;
+  if (c->n_ranks > kP2PMaxRanks) return FB_OK;
+  const int n = c->n_ranks, me = c->rank;
+  P2P* p = new P2P;
+  p->comm = c;
+  memset(&p->dev, 0, sizeof p->dev);
+  p->dev.rank = me; p->dev.n_ranks = n;
+  p->dev.cap = std::max(1, n_halo_nodes);
+  const char* te = getenv("FEMBRAIN_P2P_TIMEOUT_MS");
+  p->dev.timeout_ticks = (long long)(te ? atof(te) : 20000.0) * 100000LL;
+  p->inbox_bytes = kOffHalo + 2 * (size_t)p->dev.cap * kMaxWidth * sizeof(double);
+  Meta mine;
+  memset(&mine, 0, sizeof mine);
+  mine.cap = p->dev.cap;
+  for (int q = 0; q <= n; q++) mine.halo_off[q] = halo_off[q];
+  // local part; any failure is reported through mine.ok so that the ranks can agree to fall back together
+  bool ok = hipExtMallocWithFlags((void**)&p->dev.inbox, p->inbox_bytes, hipDeviceMallocFinegrained) == hipSuccess;
+  ok = ok && hipMemsetAsync(p->dev.inbox, 0, p->inbox_bytes, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  ok = ok && hipMalloc((void**)&p->counter, sizeof(int)) == hipSuccess && hipMemsetAsync(p->counter, 0, sizeof(int), s) == hipSuccess;
+  ok = ok && hipMalloc((void**)&p->probe, 2 * sizeof(double)) == hipSuccess;
+  ok = ok && hipIpcGetMemHandle(&mine.handle, p->dev.inbox) == hipSuccess;
+  (void)hipGetLastError();
+  mine.ok = ok ? 1 : 0;
+  std::vector<Meta> all(n);
+  int rc = comm_allgather_bytes(c, &mine, all.data(), sizeof(Meta), s);
+  if (rc != FB_OK) { p2p_detach(p); return rc; }
+  bool all_ok = true;
+  for (int q = 0; q < n; q++) all_ok = all_ok && all[q].ok;
+  int opened_ok = 1;
+  if (all_ok) {
+    for (int q = 0; q < n; q++) {
+      p->dev.peer_cap[q] = all[q].cap;
+      p->dev.peer_seg[q] = all[q].halo_off[me];
+      if (q == me) { p->dev.peer[q] = p->dev.inbox; continue; }
+      void* ptr = nullptr;
+      if (hipIpcOpenMemHandle(&ptr, all[q].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); opened_ok = 0; break; }
+      p->opened[q] = ptr;
+      p->dev.peer[q] = (char*)ptr;
+    }
+  }
+  // second agreement round: did everybody map everybody?
+  std::vector<int> oks(n);
+  rc = comm_allgather_bytes(c, &opened_ok, oks.data(), sizeof(int), s);
+  if (rc != FB_OK) { p2p_detach(p); return rc; }
+  for (int q = 0; q < n; q++) all_ok = all_ok && oks[q];
+  if (!all_ok) { p2p_detach(p); return FB_OK; }  // fall back to the collective library, on every rank alike
+  // handshake through the transport itself: the sum of ones must come back as n_ranks
+  const double one = 1.0;
+  bool good = hipMemcpyAsync(p->probe, &one, sizeof one, hipMemcpyHostToDevice, s) == hipSuccess;
+  good = good && p2p_reduce(p, p->probe, 1, 1, p->probe + 1, s) == FB_OK;
+  double got = 0.0;
+  good = good && hipMemcpyAsync(&got, p->probe + 1, sizeof got, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  good = good && p2p_check(p, s) == FB_OK && got == (double)n;
+  int g = good ? 1 : 0;
+  rc = comm_allgather_bytes(c, &g, oks.data(), sizeof(int), s);
+  if (rc != FB_OK) { p2p_detach(p); return rc; }
+  for (int q = 0; q < n; q++) good = good && oks[q];
+  if (!good) { p2p_detach(p); return FB_OK; }
+  *out = p;
+  return FB_OK;
+}
+
+}  // namespace fb

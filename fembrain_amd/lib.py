@@ -115,6 +115,7 @@ def lib():
         "fb_plan_get": (C.c_int, [vp, C.c_char_p, _ip, C.c_size_t]),
     }
     poly_sig = {
+        "fb_fem_transport": (C.c_int, [vp]),
         "fb_poly_create": (C.c_int, [C.POINTER(vp), C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp]),
         "fb_poly_destroy": (C.c_int, [vp]),
         "fb_poly_field_array": (C.c_int, [vp, C.c_int, _fp]),

@@ -83,6 +83,11 @@ int fb_fem_create_sharded(fb_fem_t* out, int n_nodes, const double* xyz, int n_t
                           int n_fixed_dofs, const int* fixed_dofs, const fb_fem_params* params,
                           int n_ranks, int rank, const int* node_splits, fb_comm_t comm);
 int fb_fem_destroy(fb_fem_t h);
+/* how a sharded handle exchanges halo values and PCG sums: 0 = unsharded (no exchange), 1 = collective library
+ * (RCCL all-reduce + send/recv; or the host-staged test communicator), 2 = direct peer-to-peer mailboxes over xGMI
+ * (HIP IPC mapped inboxes written by kernels; chosen at create time when every rank can map every peer, environment
+ * FEMBRAIN_P2P=0 forces 1) */
+int fb_fem_transport(fb_fem_t h);
 
 /* Rebuild after a topology change (Deformable::syncForceModel after CuttableMesh::cut, main.cpp:614-617):
  * same semantics as destroy + create but keeps the device, parameters and constraints. State is reset. */

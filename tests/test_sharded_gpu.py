@@ -12,8 +12,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, shm_name, n, variant, steps, q):
+def _worker(rank, world, shm_name, n, variant, steps, q, p2p=False, quit_early=False):
     try:
+        if p2p:
+            os.environ["FEMBRAIN_P2P"] = "1"
+            os.environ["FEMBRAIN_P2P_TIMEOUT_MS"] = "1500" if quit_early else "20000"
         from fembrain_amd import lib as fl
         from fembrain_amd.fem import FemIntegrator
         from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
@@ -25,6 +28,12 @@ def _worker(rank, world, shm_name, n, variant, steps, q):
         planes = [n * r // world for r in range(world + 1)]
         splits = np.array([p * n * n for p in planes], np.int32)
         g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), pcg_variant=variant)
+        assert L.fb_fem_transport(g.h) == (2 if p2p else 1), L.fb_fem_transport(g.h)
+        if quit_early and rank == world - 1:   # a rank that stops taking part: the others must time out, not hang
+            q.put((rank, "left", None, None, 0, 0))
+            q.close()
+            q.join_thread()   # flush the feeder thread before leaving without cleanup
+            os._exit(0)
         f = np.zeros(g.r)
         f[1::3] = -10000.0
         f[0::3] = 300.0 * np.sin(np.arange(len(v)))   # not symmetric across the slabs
@@ -39,19 +48,24 @@ def _worker(rank, world, shm_name, n, variant, steps, q):
         L.fb_comm_destroy(comm)
     except Exception as e:  # surface the failure instead of hanging the peers' barrier forever
         q.put((rank, repr(e), None, None, 0, 0))
+        q.close()
+        q.join_thread()
         os._exit(1)
 
 
-@pytest.mark.parametrize("world,variant", [(2, 0), (3, 0), (2, 1), (4, 2)])
-def test_sharded_ranks_on_one_gpu_match_the_unsharded_handle(gpu, world, variant):
+@pytest.mark.parametrize("world,variant,p2p", [(2, 0, False), (3, 0, False), (2, 1, False), (4, 2, False),
+                                               (2, 0, True), (4, 0, True), (3, 1, True), (3, 2, True)])
+def test_sharded_ranks_on_one_gpu_match_the_unsharded_handle(gpu, world, variant, p2p):
+    """p2p=True: the direct mailbox transport (HIP IPC mapped inboxes, kernels that store into the peer's inbox and
+    spin -- bounded -- on their own flags) between processes that share the GPU."""
     import multiprocessing as mp
     from fembrain_amd.fem import FemIntegrator
     from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
     n, steps = 12, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    name = "/fembrain_test_%d_%d_%d" % (os.getpid(), world, variant)
-    procs = [ctx.Process(target=_worker, args=(r, world, name, n, variant, steps, q)) for r in range(world)]
+    name = "/fembrain_test_%d_%d_%d_%d" % (os.getpid(), world, variant, int(p2p))
+    procs = [ctx.Process(target=_worker, args=(r, world, name, n, variant, steps, q, p2p)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
@@ -83,3 +97,30 @@ def test_sharded_ranks_on_one_gpu_match_the_unsharded_handle(gpu, world, variant
     # rank-ordered partial sums instead of one block-ordered sum: same iterates up to rounding
     assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
     assert np.abs(vg - vs).max() <= 1e-5 * np.abs(vs).max()
+
+
+def test_p2p_wait_is_bounded_when_a_peer_leaves(gpu):
+    """One rank exits after the collective set-up.  The survivor's exchange kernels give up at the wall-clock bound, poison
+    the inbox, drain the queue, and the step returns FB_ECOMM -- no hang."""
+    import multiprocessing as mp
+    import time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "/fembrain_test_%d_leave" % os.getpid()
+    procs = [ctx.Process(target=_worker, args=(r, 2, name, 8, 0, 1, q, True, True)) for r in range(2)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(2):
+            r = q.get(timeout=120)
+            res[r[0]] = r
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert res[1][1] == "left"
+    assert res[0][2] is None and "timed out" in res[0][1], res[0]
+    assert time.time() - t0 < 100
