@@ -201,6 +201,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 matrix, f64 vectors/accumulators" if args.precision == "f32" else "f64", "data": "synthetic",
             "config": {"workload": text, "nodes": int(len(v)), "tets": int(len(t)), "partition": "i-plane slabs x%d" % world,
+                       "exchange": ["none (one GPU)", "RCCL all-reduce + send/recv", "peer-to-peer inbox kernels over xGMI (HIP IPC)"][g.transport()],
                        "cg_eps": 1e-6, "cg_max_iter": 10000},
             "cg_iterations_per_step": float(np.mean(iters)), "assembly_ms_per_step": asm_s / args.steps * 1e3,
             "solve_ms_per_step": solve_s / args.steps * 1e3, "us_per_cg_iteration": solve_s / max(sum(iters), 1) * 1e6,

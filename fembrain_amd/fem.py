@@ -50,6 +50,10 @@ class FemIntegrator:
         self.last = _l.StepInfo()
 
     # -- life cycle --
+    def transport(self):
+        """0 unsharded, 1 collective library (RCCL / test communicator), 2 direct peer-to-peer mailboxes."""
+        return int(self._L.fb_fem_transport(self.h))
+
     def close(self):
         if getattr(self, "h", None):
             self._L.fb_fem_destroy(self.h)
