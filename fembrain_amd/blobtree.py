@@ -6,8 +6,13 @@ inverse affine matrix per primitive), src/implicit/Polygonizer.cpp:210-540 (``Pr
 boxes with offset ISO_VALUE = 0.5, operator boxes, model box) and src/implicit/LinearBlobTree.cpp:43-167
 (``LinearBlobTree::load``: header 12 floats, 16 per operator, 20 per primitive, 12 per matrix node).
 
+Instanced nodes (``PrimitiveType=INSTANCE``): res = (array index of the original node, its script id, original is an
+operator), dir.x = the original's type code (ReadSceneModel.cpp:649-668, ``setAllInstancedNodes`` :214-236); boxes as
+``PrepareAllBoxes`` orders them (Polygonizer.cpp:210-263): primitives, operators, instanced nodes (the original's box
+mapped -- lo and hi corner only, as the reference does -- by the instance's forward matrix), operators again.
+
 Not restated: the traversal-route links of ``LinearBlobTree::setTraversalRoute`` (the HIP evaluator compiles its
-own evaluation order from lc/rc/flags; the ``next`` field is left at NULL_BLOB) and instanced-node boxes.
+own evaluation order from lc/rc/flags; the ``next`` field is left at NULL_BLOB).
 """
 import re
 
@@ -139,6 +144,7 @@ def read_blob(path):
     if not roots:
         raise ValueError("%s: no RootIDs" % path)
     prims, ops, mtx, boxm = [], [], [np.eye(4, dtype=f32)[:3].reshape(12)], [np.eye(4, dtype=f32)]
+    script2array = {}
 
     def read_node(nid):
         sec = ini.get("BLOBNODE %d" % nid)
@@ -147,6 +153,7 @@ def read_blob(path):
         is_op = sec.get("IsOperator", "0").strip() in ("1", "true", "True", "TRUE")
         if is_op:
             idx = len(ops)
+            script2array.setdefault(nid, idx)
             op = {"type": OP_TYPES.get(sec.get("OperatorType", ""), 0), "flags": 0, "lc": 0, "rc": 0, "res": [0.0, 0.0, 0.0, 0.0]}
             ops.append(op)
             t = op["type"]
@@ -208,7 +215,10 @@ def read_blob(path):
         elif pt == 6:
             pos, dirv, res = _vec(sec.get("corner0"), 3), _vec(sec.get("corner1"), 3), _vec(sec.get("corner2"), 3)
         elif pt == 9:
-            res = [0.0, float(sec.get("OriginalNodeIndex", 0)), float(sec.get("OriginalNodeIsOp", 0))]
+            is_op = int(sec.get("OriginalNodeIsOp", 0))
+            res = [0.0, float(sec.get("OriginalNodeIndex", 0)), float(is_op)]
+            oname = sec.get("OriginalNodeType", "").strip()
+            dirv = [float((OP_TYPES if is_op else PRIM_TYPES).get(oname, 0)), 0.0, 0.0]
         color = _vec(sec.get("MtrlDiffused"), 4)
         fwd = _affine(sec)
         im = 0
@@ -218,11 +228,21 @@ def read_blob(path):
             mtx.append(inv[:3].reshape(12))
             boxm.append(fwd)
         prims.append({"type": pt, "im": im, "pos": pos, "dir": dirv, "res": res, "color": color[:3]})
+        script2array.setdefault(nid, idx)
         return idx, False
 
     read_node(roots[0])
     if not prims:
         raise ValueError("%s: no primitives" % path)
+    for p in prims:  # setAllInstancedNodes: script id -> array index of the original
+        if p["type"] == 9:
+            sid = int(p["res"][1])
+            if sid not in script2array:
+                raise ValueError("%s: instance of unknown node %d" % (path, sid))
+            p["res"][0] = float(script2array[sid])
+            n_target = len(ops) if int(p["res"][2]) else len(prims)
+            if not 0 <= script2array[sid] < n_target:
+                raise ValueError("%s: instance of node %d: original index out of range" % (path, sid))
     # primitive boxes (PrepareAllPrimBBoxes) and model box (PrepareAllBoxes tail: hi starts at FLT_MIN, sic)
     pboxes = []
     for p in prims:
@@ -233,10 +253,6 @@ def read_blob(path):
             b = (M[:3, :3] @ hi + M[:3, 3]).astype(f32)
             lo, hi = np.minimum(a, b), np.maximum(a, b)
         pboxes.append((lo, hi))
-    mlo, mhi = np.full(3, FLT_MAX, f32), np.full(3, FLT_MIN, f32)
-    for lo, hi in pboxes:
-        mlo, mhi = np.minimum(mlo, lo), np.maximum(mhi, hi)
-
     def op_box(i):
         op = ops[i]
         if op["flags"] & OF_RANGE:
@@ -253,6 +269,21 @@ def read_blob(path):
 
     if ops:
         op_box(0)
+    if any(p["type"] == 9 for p in prims):  # PrepareAllInstancedNodesBBoxes, then the operator boxes once more
+        for i, p in enumerate(prims):
+            if p["type"] != 9:
+                continue
+            origin = int(p["res"][0])
+            lo, hi = ops[origin]["box"] if int(p["res"][2]) else pboxes[origin]
+            M = boxm[p["im"]]
+            a = (M[:3, :3] @ lo + M[:3, 3]).astype(f32)
+            b = (M[:3, :3] @ hi + M[:3, 3]).astype(f32)
+            pboxes[i] = (np.minimum(a, b), np.maximum(a, b))
+        if ops:
+            op_box(0)
+    mlo, mhi = np.full(3, FLT_MAX, f32), np.full(3, FLT_MIN, f32)
+    for lo, hi in pboxes:
+        mlo, mhi = np.minimum(mlo, lo), np.maximum(mhi, hi)
     header = np.zeros(12, f32)
     header[0:3], header[3], header[4:7], header[7] = mlo, 1.0, mhi, 1.0
     header[8], header[9], header[10], header[11] = len(prims), len(ops), len(mtx), NULL_BLOB

@@ -36,13 +36,18 @@ enum OpType { opUnion, opIntersect, opDif, opSmoothDif, opBlend, opRicciBlend, o
               opWarpTwist, opWarpTaper, opWarpBend, opWarpShear };
 enum OpFlags { ofRightChildIsOp = 1, ofLeftChildIsOp = 2, ofChildIndexIsRange = 4, ofIsUnaryOp = 8, ofIsRightOp = 16, ofBreak = 32 };
 
-// one step of the compiled evaluation order
+// one step of the compiled evaluation order.  Values live in numbered slots of a per-thread LDS column; the running
+// field `out` and the query point are registers.
 struct Instr {
-  int kind;    // 0 = RANGE (sum prims a..b onto the running field), 1 = BINARY/UNARY operator
-  int a, b;    // RANGE: first/last prim.  OP: left / right source: >= 0 primitive index, -1 = pop an operator result
+  int kind;    // 0 RANGE: out += prims a..b.  1 OP.  2 ENTER an instanced subtree.  3 LEAVE it.  4 ADDSLOT: out += slot a
+  int a, b;    // OP: left / right operand, >= 0 primitive index, < 0 slot -1-k.  ENTER: a = matrix node, b = first of the
+               // 5 frame slots (x, y, z, out, inside).  LEAVE: a = frame slots
   int optype;  // OP only
   int unary;
+  int dst;     // slot that receives the result (RANGE, OP, LEAVE); -1 = only `out`
+  int skip;    // ENTER: index of the matching LEAVE (taken when the mapped point is outside the box)
   float p0, p1;
+  float lo[3], hi[3];  // ENTER: box of the original operator (isOutsideOp, Polygonizer.cpp:1464-1483)
 };
 
 struct Grid {
@@ -61,14 +66,22 @@ __device__ __forceinline__ float wyvill(float dd) {
 // computePrimitiveField (Polygonizer.cpp:1544-1908), scalar fp32, no bounding-box cull
 __device__ __forceinline__ float prim_field(const float* __restrict__ prims, const float* __restrict__ mtx, int i, float pX, float pY, float pZ) {
   const float* P = prims + 20 * i;
-  const int type = (int)P[0];
-  const int im = (int)P[1];
+  int type = (int)P[0];
   float x = pX, y = pY, z = pZ;
-  if (im != 0) {
-    const float* m = mtx + 12 * im;
-    x = m[0] * pX + m[1] * pY + m[2] * pZ + m[3];
-    y = m[4] * pX + m[5] * pY + m[6] * pZ + m[7];
-    z = m[8] * pX + m[9] * pY + m[10] * pZ + m[11];
+  for (int hop = 0;; hop++) {
+    const int im = (int)P[1];
+    if (im != 0) {
+      const float* m = mtx + 12 * im;
+      const float tx = m[0] * x + m[1] * y + m[2] * z + m[3];
+      const float ty = m[4] * x + m[5] * y + m[6] * z + m[7];
+      const float tz = m[8] * x + m[9] * y + m[10] * z + m[11];
+      x = tx; y = ty; z = tz;
+    }
+    // an instance of a PRIMITIVE is that primitive at the mapped point (Polygonizer.cpp:1879-1901); instances of
+    // operators never get here: compile_tree expands them into ENTER .. LEAVE blocks
+    if (type != primInstance || hop == 8 || (int)P[14] != 0) break;
+    P = prims + 20 * (int)P[12];
+    type = (int)P[0];
   }
   const float posX = P[4], posY = P[5], posZ = P[6];
   const float dirX = P[8], dirY = P[9], dirZ = P[10];
@@ -167,7 +180,7 @@ __device__ __forceinline__ float apply_op(int optype, float lf, float rf, float 
 }
 
 // FieldComputer::fieldValue (Polygonizer.cpp:1913-2108) through the compiled order.  `stk` is this thread's
-// column of an LDS stack [depth][kPB].
+// column of an LDS slot array [depth][kPB].
 __device__ __forceinline__ float eval_field(const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
                                    const float* __restrict__ mtx, float x, float y, float z, float* stk) {
   float out = 0.0f;
@@ -175,22 +188,47 @@ __device__ __forceinline__ float eval_field(const Instr* __restrict__ prog, int 
     for (int i = 0; i < n_prims; i++) out = out + prim_field(prims, mtx, i, x, y, z);
     return out;
   }
-  int sp = 0;
   for (int k = 0; k < n_instr; k++) {
-    const Instr in = prog[k];
-    if (in.kind == 0) {
-      for (int i = in.a; i <= in.b; i++) out = out + prim_field(prims, mtx, i, x, y, z);
-    } else {
-      float lf, rf = 0.0f;
-      if (in.a >= 0) lf = prim_field(prims, mtx, in.a, x, y, z);
-      else lf = stk[(--sp) * kPB];
-      if (!in.unary) {
-        if (in.b >= 0) rf = prim_field(prims, mtx, in.b, x, y, z);
-        else rf = stk[(--sp) * kPB];
-      }
-      out = apply_op(in.optype, lf, rf, in.p0, in.p1, out);
+    const Instr& in = prog[k];
+    switch (in.kind) {
+      case 0:
+        for (int i = in.a; i <= in.b; i++) out = out + prim_field(prims, mtx, i, x, y, z);
+        break;
+      case 1: {
+        const int a = in.a, b = in.b;
+        const float lf = a >= 0 ? prim_field(prims, mtx, a, x, y, z) : stk[(-1 - a) * kPB];
+        float rf = 0.0f;
+        if (!in.unary) rf = b >= 0 ? prim_field(prims, mtx, b, x, y, z) : stk[(-1 - b) * kPB];
+        out = apply_op(in.optype, lf, rf, in.p0, in.p1, out);
+      } break;
+      case 2: {  // computePrimitiveField of an operator instance: map the point, cull against the original's box
+        float* f = stk + in.b * kPB;
+        f[0] = x; f[kPB] = y; f[2 * kPB] = z; f[3 * kPB] = out;
+        if (in.a != 0) {
+          const float* m = mtx + 12 * in.a;
+          const float tx = m[0] * x + m[1] * y + m[2] * z + m[3];
+          const float ty = m[4] * x + m[5] * y + m[6] * z + m[7];
+          const float tz = m[8] * x + m[9] * y + m[10] * z + m[11];
+          x = tx; y = ty; z = tz;
+        }
+        out = 0.0f;
+        const bool inside = x >= in.lo[0] && in.hi[0] >= x && y >= in.lo[1] && in.hi[1] >= y && z >= in.lo[2] && in.hi[2] >= z;
+        f[4 * kPB] = inside ? 1.0f : 0.0f;
+        // the program counter stays wave-uniform (scalar instruction fetch): the block is skipped only when every lane
+        // is outside; a lane that is outside while a neighbour is inside runs along and gets its 0 at the LEAVE
+        if (__ballot(inside) == 0ULL) k = in.skip - 1;
+      } continue;
+      case 3: {
+        const float* f = stk + in.a * kPB;
+        const float v = f[4 * kPB] != 0.0f ? out : 0.0f;
+        x = f[0]; y = f[kPB]; z = f[2 * kPB]; out = f[3 * kPB];
+        stk[in.dst * kPB] = v;
+      } continue;
+      default:
+        out = out + stk[in.a * kPB];
+        continue;
     }
-    stk[(sp++) * kPB] = out;
+    if (in.dst >= 0) stk[in.dst * kPB] = out;
   }
   return out;
 }
@@ -777,57 +815,186 @@ namespace {
   if (!(h)) return fail(FB_EINVAL, "null poly handle"); \
   FB_HIP(hipSetDevice((h)->device))
 
-// Emulates the operator stack walk of FieldComputer::fieldValue (Polygonizer.cpp:1938-2080) once on the host and
-// records the order in which operators get evaluated; results are consumed LIFO, which the walk below verifies.
+// Emulates the operator stack walk of FieldComputer::fieldValue (Polygonizer.cpp:1938-2080) once on the host and records
+// the order in which operators get evaluated.  Operator results go to numbered slots (the reference keeps one float per
+// operator; here a slot is recycled as soon as its consumer has been emitted).  An instance of an operator
+// (computePrimitiveField :1879-1901 calls fieldValue on the original subtree at the mapped point) is expanded in place:
+// ENTER (save point and running field, map the point, cull against the original's box) .. subtree .. LEAVE (result to a
+// slot, restore).  Instances of primitives are followed by prim_field on the device.
+struct TreeCompiler {
+  fb_poly_s* h;
+  std::vector<Instr> prog;
+  std::vector<char> used;
+  int depth = 1, nest = 0;
+
+  int alloc(int n) {
+    for (int base = 0;; base++) {
+      bool ok = true;
+      for (int k = 0; k < n && ok; k++) ok = base + k >= (int)used.size() || !used[base + k];
+      if (!ok) continue;
+      if ((int)used.size() < base + n) used.resize(base + n, 0);
+      for (int k = 0; k < n; k++) used[base + k] = 1;
+      depth = std::max(depth, base + n);
+      return base;
+    }
+  }
+  void release(int base, int n) { for (int k = 0; k < n; k++) used[base + k] = 0; }
+  const float* prim(int i) const { return h->prims.data() + 20 * (size_t)i; }
+  const float* op(int i) const { return h->ops.data() + 16 * (size_t)i; }
+
+  // does primitive i, followed through instances of primitives, end in an instance of an operator?
+  int resolves_to_op(int i, bool* yes) const {
+    for (int hop = 0; hop < 8; hop++) {
+      const float* P = prim(i);
+      if ((int)P[0] != primInstance) { *yes = false; return FB_OK; }
+      const int origin = (int)P[12], is_op = (int)P[14];
+      if (is_op) {
+        if (origin < 0 || origin >= h->n_ops) return fail(FB_EINVAL, "primitive %d instances operator %d of %d", i, origin, h->n_ops);
+        *yes = true;
+        return FB_OK;
+      }
+      if (origin < 0 || origin >= h->n_prims) return fail(FB_EINVAL, "primitive %d instances primitive %d of %d", i, origin, h->n_prims);
+      i = origin;
+    }
+    return fail(FB_EINVAL, "instance chain of primitive %d does not end", i);
+  }
+
+  // value of primitive i (known to resolve to an operator instance) -> new slot
+  int emit_instance(int i, int* slot) {
+    if (++nest > 8) return fail(FB_EINVAL, "instanced subtrees nest deeper than 8 (primitive %d): an instance of its own ancestor?", i);
+    const float* P = prim(i);
+    const int origin = (int)P[12], is_op = (int)P[14];
+    Instr in;
+    memset(&in, 0, sizeof in);
+    in.kind = 2; in.a = (int)P[1]; in.b = alloc(5); in.dst = -1;
+    for (int a = 0; a < 3; a++) { in.lo[a] = -FLT_MAX; in.hi[a] = FLT_MAX; }
+    if (is_op)
+      for (int a = 0; a < 3; a++) { in.lo[a] = op(origin)[8 + a]; in.hi[a] = op(origin)[12 + a]; }
+    const size_t enter = prog.size();
+    const int frame = in.b;
+    prog.push_back(in);
+    if (is_op) {
+      FB_TRY(subtree(origin));
+    } else {  // instance of a primitive that is itself an instance of an operator
+      int inner = -1;
+      FB_TRY(emit_instance(origin, &inner));
+      Instr add;
+      memset(&add, 0, sizeof add);
+      add.kind = 4; add.a = inner; add.dst = -1;
+      prog.push_back(add);
+      release(inner, 1);
+    }
+    Instr out;
+    memset(&out, 0, sizeof out);
+    out.kind = 3; out.a = frame;
+    release(frame, 5);
+    out.dst = *slot = alloc(1);
+    prog[enter].skip = (int)prog.size();
+    prog.push_back(out);
+    if (prog.size() > (1u << 20)) return fail(FB_EINVAL, "instanced BlobTree expands to more than 2^20 evaluation steps");
+    --nest;
+    return FB_OK;
+  }
+
+  // operand reference of a primitive child: the primitive itself, or the slot of its expanded instance
+  int operand(int i, int* ref, int* slot) {
+    bool yes = false;
+    FB_TRY(resolves_to_op(i, &yes));
+    *slot = -1;
+    if (!yes) { *ref = i; return FB_OK; }
+    FB_TRY(emit_instance(i, slot));
+    *ref = -1 - *slot;
+    return FB_OK;
+  }
+
+  // the walk of fieldValue(.., idxRootNode = root); on return the root's value is the running field
+  int subtree(int root) {
+    const int nops = h->n_ops;
+    std::vector<char> computed(nops, 0);
+    std::vector<int> where(nops, -1);  // slot of a computed operator
+    std::vector<int> stk{root};
+    size_t guard = 0;
+    while (!stk.empty()) {
+      if (++guard > (size_t)4 * nops + 16) return fail(FB_EINVAL, "BlobTree operator graph is not a tree");
+      const int n = stk.back();
+      const float* o = op(n);
+      const int type = (int)o[0], lc = (int)o[1], rc = (int)o[2], fl = (int)o[7];
+      const bool unary = fl & ofIsUnaryOp, range = fl & ofChildIndexIsRange, lop = fl & ofLeftChildIsOp, rop = fl & ofRightChildIsOp;
+      Instr in;
+      memset(&in, 0, sizeof in);
+      in.dst = -1;
+      if (range) {
+        if (lc < 0 || rc >= h->n_prims || lc > rc) return fail(FB_EINVAL, "operator %d: bad primitive range [%d,%d]", n, lc, rc);
+        stk.pop_back();
+        int first = lc;  // runs of plain primitives, split at operator instances (same summation order)
+        for (int i = lc; i <= rc; i++) {
+          bool yes = false;
+          FB_TRY(resolves_to_op(i, &yes));
+          if (!yes) continue;
+          if (first < i) { in.kind = 0; in.a = first; in.b = i - 1; prog.push_back(in); }
+          int s = -1;
+          FB_TRY(emit_instance(i, &s));
+          Instr add;
+          memset(&add, 0, sizeof add);
+          add.kind = 4; add.a = s; add.dst = -1;
+          prog.push_back(add);
+          release(s, 1);
+          first = i + 1;
+        }
+        if (first <= rc) { in.kind = 0; in.a = first; in.b = rc; prog.push_back(in); }
+      } else {
+        if ((lop && (lc < 0 || lc >= nops)) || (!lop && (lc < 0 || lc >= h->n_prims))) return fail(FB_EINVAL, "operator %d: bad left child %d", n, lc);
+        if (!unary && ((rop && (rc < 0 || rc >= nops)) || (!rop && (rc < 0 || rc >= h->n_prims)))) return fail(FB_EINVAL, "operator %d: bad right child %d", n, rc);
+        const bool ready = unary ? !(lop && !computed[lc]) : !((lop && !computed[lc]) || (rop && !computed[rc]));
+        if (!ready) {
+          if (lop && !computed[lc]) stk.push_back(lc);
+          if (!unary && rop && !computed[rc]) stk.push_back(rc);
+          continue;
+        }
+        stk.pop_back();
+        int sa = -1, sb = -1;
+        if (lop) { in.a = -1 - where[lc]; sa = where[lc]; } else FB_TRY(operand(lc, &in.a, &sa));
+        if (unary) in.b = 0;
+        else if (rop) { in.b = -1 - where[rc]; sb = where[rc]; } else FB_TRY(operand(rc, &in.b, &sb));
+        in.kind = 1; in.optype = type; in.unary = unary ? 1 : 0;
+        in.p0 = o[4]; in.p1 = o[5];
+        if (sa >= 0) release(sa, 1);
+        if (sb >= 0 && sb != sa) release(sb, 1);
+        prog.push_back(in);
+      }
+      computed[n] = 1;
+      if (n != root) {  // the result of an inner operator is kept for its parent
+        where[n] = alloc(1);
+        prog.back().dst = where[n];
+        // a RANGE that ended in an instance has an ADDSLOT last: give the store its own step
+        if (prog.back().kind == 4) {
+          prog.back().dst = -1;
+          Instr keep;
+          memset(&keep, 0, sizeof keep);
+          keep.kind = 0; keep.a = 0; keep.b = -1; keep.dst = where[n];  // empty range: only stores the running field
+          prog.push_back(keep);
+        }
+      }
+    }
+    return FB_OK;
+  }
+};
+
 int compile_tree(fb_poly_s* h) {
   h->prog.clear();
   h->depth = 1;
-  const int nops = h->n_ops;
-  if (nops == 0) return FB_OK;
-  std::vector<char> computed(nops, 0);
-  std::vector<int> stk{0}, vals;
-  size_t guard = 0;
-  while (!stk.empty()) {
-    if (++guard > (size_t)4 * nops + 16) return fail(FB_EINVAL, "BlobTree operator graph is not a tree");
-    const int n = stk.back();
-    const float* o = h->ops.data() + 16 * (size_t)n;
-    const int type = (int)o[0], lc = (int)o[1], rc = (int)o[2], fl = (int)o[7];
-    const bool unary = fl & ofIsUnaryOp, range = fl & ofChildIndexIsRange, lop = fl & ofLeftChildIsOp, rop = fl & ofRightChildIsOp;
-    Instr in;
-    memset(&in, 0, sizeof in);
-    if (range) {
-      if (lc < 0 || rc >= h->n_prims || lc > rc) return fail(FB_EINVAL, "operator %d: bad primitive range [%d,%d]", n, lc, rc);
-      stk.pop_back();
-      in.kind = 0; in.a = lc; in.b = rc;
-    } else {
-      if ((lop && (lc < 0 || lc >= nops)) || (!lop && (lc < 0 || lc >= h->n_prims))) return fail(FB_EINVAL, "operator %d: bad left child %d", n, lc);
-      if (!unary && ((rop && (rc < 0 || rc >= nops)) || (!rop && (rc < 0 || rc >= h->n_prims)))) return fail(FB_EINVAL, "operator %d: bad right child %d", n, rc);
-      const bool ready = unary ? !(lop && !computed[lc]) : !((lop && !computed[lc]) || (rop && !computed[rc]));
-      if (!ready) {
-        if (lop && !computed[lc]) stk.push_back(lc);
-        if (!unary && rop && !computed[rc]) stk.push_back(rc);
-        continue;
-      }
-      stk.pop_back();
-      in.kind = 1; in.optype = type; in.unary = unary ? 1 : 0;
-      in.p0 = o[4]; in.p1 = o[5];
-      in.a = lop ? -1 : lc;
-      in.b = unary ? 0 : (rop ? -1 : rc);
-      if (lop) {
-        if (vals.empty() || vals.back() != lc) return fail(FB_EINVAL, "operator %d: left operand is not on top of the value stack", n);
-        vals.pop_back();
-      }
-      if (!unary && rop) {
-        if (vals.empty() || vals.back() != rc) return fail(FB_EINVAL, "operator %d: right operand is not on top of the value stack", n);
-        vals.pop_back();
-      }
-    }
-    computed[n] = 1;
-    vals.push_back(n);
-    h->depth = std::max(h->depth, (int)vals.size());
-    h->prog.push_back(in);
+  for (int i = 0; i < h->n_prims; i++) {  // validates every instance chain, used or not
+    bool yes = false;
+    TreeCompiler probe{h};
+    FB_TRY(probe.resolves_to_op(i, &yes));
+    if (yes && h->n_ops == 0) return fail(FB_EINVAL, "primitive %d instances an operator but the tree has none", i);
   }
-  if (h->depth > 64) return fail(FB_EINVAL, "BlobTree too deep (%d)", h->depth);
+  if (h->n_ops == 0) return FB_OK;
+  TreeCompiler c{h};
+  FB_TRY(c.subtree(0));
+  h->prog = std::move(c.prog);
+  h->depth = c.depth;
+  if (h->depth > 60) return fail(FB_EINVAL, "BlobTree needs %d value slots per point (limit 60)", h->depth);
   return FB_OK;
 }
 
@@ -1004,6 +1171,18 @@ int fb_poly_create(fb_poly_t* out, int device, const float* header12, int n_ops,
     return rc;
   }
   *out = h;
+  return FB_OK;
+}
+
+int fb_poly_compile_info(int n_ops, const float* ops16, int n_prims, const float* prims20, int* n_steps, int* n_slots) {
+  if (n_prims < 1 || !prims20 || n_ops < 0 || (n_ops > 0 && !ops16)) return fail(FB_EINVAL, "bad BlobTree arrays");
+  fb_poly_s h;
+  h.ops.assign(ops16, ops16 + 16 * (size_t)n_ops);
+  h.prims.assign(prims20, prims20 + 20 * (size_t)n_prims);
+  h.n_ops = n_ops; h.n_prims = n_prims;
+  FB_TRY(compile_tree(&h));
+  if (n_steps) *n_steps = (int)h.prog.size();
+  if (n_slots) *n_slots = h.depth;
   return FB_OK;
 }
 

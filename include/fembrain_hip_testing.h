@@ -30,6 +30,11 @@ int fb_plan_get(fb_plan_t p, const char* name, int* out, size_t capacity);
 struct fb_comm_s;
 int fb_comm_create_local(struct fb_comm_s** out, int rank, int n_ranks, const char* shm_name, size_t outbox_bytes, int device);
 
+/* Host-only: compiles a BlobTree (operator walk order, slot allocation, expansion of instanced subtrees) exactly as
+ * fb_poly_create does and reports the number of evaluation steps and of per-point value slots; needs no device.
+ * Lets the CPU suite check every reference model's tree, including the instanced ones. */
+int fb_poly_compile_info(int n_ops, const float* ops16, int n_prims, const float* prims20, int* n_steps, int* n_slots);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,3 +113,49 @@ def test_surface_of_blob_files_is_closed():
         o.classify()
         xyz, nrm, tri = o.surface()
         surface_mesh_checks(xyz, nrm, tri)
+
+
+def test_instanced_nodes_reader_and_field():
+    """peanutInstanced.blob: union(blend(p0, p1), INSTANCE of that blend moved by t).  The instance is the original
+    subtree evaluated at the mapped point (Polygonizer.cpp:1879-1901), so the field is invariant under the shift by t.
+    No reference output exists for instanced models: parity unpinned, pinned by this symmetry."""
+    b = read_blob(os.path.join(GOLD, "blob", "peanutInstanced.blob"))
+    inst = b.prims[2]
+    assert inst[0] == 9 and (inst[12], inst[13], inst[14]) == (1.0, 3.0, 1.0) and inst[8] == 4.0  # op #1 (script id 3), BLEND
+    t = np.array([-2.522842, -1.193464, -1.396770], np.float32)
+    assert np.allclose(b.mtx[int(inst[1])].reshape(3, 4)[:, 3], -t)          # inverse matrix of the translation
+    # instance box = the blend's box moved by t; model box = union over primitives
+    assert np.allclose(b.prim_boxes[2][0], b.op_boxes[1][0] + t, atol=1e-6) and np.allclose(b.header[0:3], b.prim_boxes[2][0])
+    o = OrcPoly(b)
+    rng = np.random.default_rng(11)
+    lo, hi = b.op_boxes[1]
+    p = np.zeros((400, 4), np.float32)
+    p[:, :3] = rng.uniform(lo + 0.2, hi - 0.2, size=(400, 3)).astype(np.float32)
+    q = p.copy()
+    q[:, :3] = p[:, :3] + t
+    fp, fq = o.field_array(p)[:, 3], o.field_array(q)[:, 3]
+    assert (fp > 0).any()
+    assert np.abs(fp - fq).max() < 2e-6          # q - t is p up to fp32 rounding of the shift
+    # outside the original's box the instance contributes nothing (isOutsideOp cull), although the Wyvill support
+    # (radius 1) reaches beyond the box (offset 0.5): 0.2 outside the low-x face, level with the leftmost point primitive
+    c0 = -b.mtx[1].reshape(3, 4)[:, 3] + t     # centre of the instanced copy of primitive 0
+    cut = np.array([[lo[0] + t[0] - 0.2, c0[1], c0[2], 0], [lo[0] + t[0] + 0.01, c0[1], c0[2], 0]], np.float32)
+    f = o.field_array(cut)[:, 3]
+    assert f[0] == 0.0 and f[1] > 0.1
+
+
+def test_instanced_models_compile_for_the_device():
+    import ctypes as C
+    from fembrain_amd import lib as fl
+    L = fl.lib()
+    for name, n_inst in (("peanutInstanced", 1), ("pizaL2P4", 1), ("piza4x4", 16), ("complex", 0)):
+        b = read_blob(os.path.join(GOLD, "blob", name + ".blob"))
+        assert int((b.prims[:, 0] == 9).sum()) == n_inst
+        steps, slots = C.c_int(0), C.c_int(0)
+        fl.check(L.fb_poly_compile_info(b.n_ops, fl.fptr(b.ops), b.n_prims, fl.fptr(b.prims), C.byref(steps), C.byref(slots)))
+        assert steps.value >= b.n_ops and 1 <= slots.value <= 16
+    # an instance of its own ancestor must be refused, not expanded for ever
+    b = read_blob(os.path.join(GOLD, "blob", "peanutInstanced.blob"))
+    b.prims[2, 12] = 0.0   # the instance now points at the root union, which contains it
+    steps, slots = C.c_int(0), C.c_int(0)
+    assert L.fb_poly_compile_info(b.n_ops, fl.fptr(b.ops), b.n_prims, fl.fptr(b.prims), C.byref(steps), C.byref(slots)) != 0

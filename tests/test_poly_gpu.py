@@ -297,3 +297,38 @@ def test_apply_fem_displacements(gpu):
             g.apply_fem_displacements(u[:-3], mesh)
     # rest positions are kept
     assert np.array_equal(g.read_surface()[0], sxyz) and np.array_equal(g.read_tetmesh()[0], txyz)
+
+
+# ---- instanced nodes -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,cellsize", [("peanutInstanced", 0.12), ("pizaL2P4", 0.45), ("piza4x4", 1.1)])
+def test_instanced_models_match_oracle(gpu, name, cellsize):
+    """Reference models built from INSTANCE nodes (copies of an operator subtree under another affine map): expanded at
+    tree-compile time into ENTER .. LEAVE blocks on the device, recursion in the oracle.  Point primitives only ->
+    field values, classification, tet mesh and surface indices bit-exact."""
+    blob = read_blob(os.path.join(GOLD, "blob", name + ".blob"))
+    g, o = GpuPoly(blob), OrcPoly(blob)
+    rng = np.random.default_rng(5)
+    lo, hi = blob.bbox
+    pts = np.zeros((20000, 4), np.float32)
+    pts[:, :3] = rng.uniform(lo - 0.3, hi + 0.3, size=(20000, 3)).astype(np.float32)
+    got, want = g.compute_field_array(pts)[:, 3], o.field_array(pts)[:, 3]
+    assert (want > 0.5).sum() > 20
+    exact = np.array_equal(got, want)
+    assert exact or np.abs(got - want).max() <= 2e-6
+    g.sweep(cellsize)
+    og = o.sweep(cellsize)
+    grid = g.read_grid()
+    assert np.array_equal(grid, og) if exact else np.abs(grid[:, 3] - og[:, 3]).max() <= 2e-6
+    if not np.array_equal(grid, og):
+        return
+    c, oc = g.classify(), o.classify()
+    flags, cnt, cfg = g.read_classification()
+    assert np.array_equal(flags, o.edge_flags) and np.array_equal(cfg, o.config)
+    g.tetrahedralize()
+    xyz, tets = g.read_tetmesh()
+    oxyz, otets = o.tetrahedralize()
+    assert np.array_equal(tets, otets) and np.array_equal(xyz, oxyz)
+    g.surface()
+    sx, sn, st = g.read_surface()
+    ox, on, ot = o.surface()
+    assert np.array_equal(st, ot) and np.array_equal(sx, ox) and np.abs(sn - on).max() <= 2e-2
