@@ -678,7 +678,9 @@ __global__ __launch_bounds__(kPB) void k_surface_vertices(Grid G, const Instr* _
                                                           const float* __restrict__ prims, const float* __restrict__ mtx,
                                                           const float4* __restrict__ grid, const unsigned long long* __restrict__ crossx,
                                                           const unsigned long long* __restrict__ crossy, const unsigned long long* __restrict__ crossz,
-                                                          const unsigned int* __restrict__ ebase, float* __restrict__ pos, float* __restrict__ nrm) {
+                                                          const unsigned int* __restrict__ ebase, const unsigned long long* __restrict__ vinc,
+                                                          const unsigned int* __restrict__ vbase, float* __restrict__ pos, float* __restrict__ nrm,
+                                                          uint2* __restrict__ ends, float* __restrict__ frac) {
   extern __shared__ float stack[];
   __shared__ unsigned char list[kPB / 64][192];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -715,6 +717,10 @@ __global__ __launch_bounds__(kPB) void k_surface_vertices(Grid G, const Instr* _
       o[0] = x; o[1] = y; o[2] = z;
       o = nrm + 3 * (first + j);
       o[0] = gx / len; o[1] = gy / len; o[2] = gz / len;
+      // the two grid points of the edge are vertices of the tet mesh of the same grid (a crossed edge belongs to a cell
+      // with config != 0): remember their tet-mesh ids and the interpolation weight for fb_poly_interpolate_displacements
+      ends[first + j] = make_uint2(rank_of(vinc, vbase, p), rank_of(vinc, vbase, p + stride[ent & 3]));
+      frac[first + j] = t;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -769,6 +775,19 @@ __global__ __launch_bounds__(kPB) void k_surface_elements(Grid G, const unsigned
   }
 }
 
+// surface vertex = rest + da + t (db - da): the FEM displacements of the two tet-mesh nodes of its grid edge, weighted as
+// the vertex itself was placed on the edge
+__global__ __launch_bounds__(kPB) void k_interpolate_displacements(long long nv, const float* __restrict__ rest, const uint2* __restrict__ ends,
+                                                                   const float* __restrict__ frac, const double* __restrict__ u, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (i >= 3 * nv) return;
+  const long long v = i / 3;
+  const int c = (int)(i - 3 * v);
+  const uint2 e = ends[v];
+  const float da = (float)u[3 * (size_t)e.x + c], db = (float)u[3 * (size_t)e.y + c];
+  out[i] = rest[i] + (da + frac[v] * (db - da));
+}
+
 // ApplyVertexDeformations (Polygonizer.cl:1417-1426) with the double -> float narrowing of GPUPoly::applyFemDisplacements
 // (OclPolygonizer.cpp:1559-1564) folded in
 __global__ __launch_bounds__(kPB) void k_apply_displacements(long long n, const float* __restrict__ rest, const double* __restrict__ u,
@@ -802,7 +821,8 @@ struct fb_poly_s {
   DevBuf<unsigned char> d_tri, d_nvert, d_edge_info;
   DevBuf<unsigned long long> surf;
   DevBuf<unsigned int> edge_pop, idx_pop, ebase, ibase, esum, isum;
-  DevBuf<float> sv, sn, deformed;
+  DevBuf<float> sv, sn, deformed, sfrac;
+  DevBuf<uint2> sends;
   DevBuf<unsigned int> si;
   DevBuf<double> disp;
   fb_poly_counts counts;
@@ -1117,7 +1137,7 @@ int do_surface_emit(fb_poly_s* h) {
   const long long pw = (long long)h->vinc_pop.n;
   const int blocks = (int)std::min<long long>((pw + kPB / 64 - 1) / (kPB / 64), 8192);
   hipLaunchKernelGGL(k_surface_vertices, dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, h->d_prog.p, (int)h->prog.size(), h->n_prims, h->d_prims.p,
-                     h->d_mtx.p, h->grid.p, h->crossx.p, h->crossy.p, h->crossz.p, h->ebase.p, h->sv.p, h->sn.p);
+                     h->d_mtx.p, h->grid.p, h->crossx.p, h->crossy.p, h->crossz.p, h->ebase.p, h->vinc.p, h->vbase.p, h->sv.p, h->sn.p, h->sends.p, h->sfrac.p);
   FB_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_surface_elements, dim3(blocks), dim3(kPB), 0, h->stream, G, h->inside.p, h->surf.p, h->ibase.p, h->crossx.p, h->crossy.p, h->crossz.p,
                      h->ebase.p, h->d_tri.p, h->d_nvert.p, h->d_edge_info.p, h->si.p);
@@ -1310,6 +1330,8 @@ int fb_poly_surface(fb_poly_t h, fb_poly_counts* counts) {
   FB_TRY(h->sv.alloc(std::max<size_t>(1, 3 * (size_t)t[0])));
   FB_TRY(h->sn.alloc(std::max<size_t>(1, 3 * (size_t)t[0])));
   FB_TRY(h->si.alloc(std::max<size_t>(1, (size_t)t[1])));
+  FB_TRY(h->sends.alloc(std::max<size_t>(1, (size_t)t[0])));
+  FB_TRY(h->sfrac.alloc(std::max<size_t>(1, (size_t)t[0])));
   FB_TRY(do_surface_emit(h));
   FB_HIP(hipStreamSynchronize(h->stream));
   h->surfaced = true;
@@ -1340,6 +1362,32 @@ int fb_poly_apply_displacements(fb_poly_t h, int mesh, int n_dof, const double* 
   hipLaunchKernelGGL(k_apply_displacements, dim3((int)((n + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, n, tet ? h->tv.p : h->sv.p, h->disp.p, h->deformed.p);
   FB_HIP(hipGetLastError());
   if (xyz_out) return h->deformed.download(xyz_out, (size_t)n, h->stream);
+  FB_HIP(hipStreamSynchronize(h->stream));
+  return FB_OK;
+}
+
+int fb_poly_read_surface_binding(fb_poly_t h, unsigned int* tet_vertex_pairs, float* weights) {
+  CHECK_POLY(h);
+  if (!h->surfaced) return fail(FB_EINVAL, "run fb_poly_surface first");
+  const size_t nv = (size_t)h->counts.n_surface_vertices;
+  if (tet_vertex_pairs) FB_TRY(h->sends.download((uint2*)tet_vertex_pairs, nv, h->stream));
+  if (weights) FB_TRY(h->sfrac.download(weights, nv, h->stream));
+  return FB_OK;
+}
+
+int fb_poly_interpolate_displacements(fb_poly_t h, int n_tet_dof, const double* tet_displacements, float* xyz_out) {
+  CHECK_POLY(h);
+  if (!h->surfaced) return fail(FB_EINVAL, "run fb_poly_surface first");
+  if (n_tet_dof != 3 * h->counts.n_tet_vertices || !tet_displacements)
+    return fail(FB_EINVAL, "displacement vector has %d entries, the tet mesh of this grid has %d DOF", n_tet_dof, 3 * h->counts.n_tet_vertices);
+  const long long nv = h->counts.n_surface_vertices;
+  if (nv == 0) return FB_OK;
+  FB_TRY(h->disp.upload(tet_displacements, (size_t)n_tet_dof, h->stream));
+  FB_TRY(h->deformed.alloc((size_t)(3 * nv)));
+  hipLaunchKernelGGL(k_interpolate_displacements, dim3((int)((3 * nv + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, nv, h->sv.p, h->sends.p, h->sfrac.p, h->disp.p,
+                     h->deformed.p);
+  FB_HIP(hipGetLastError());
+  if (xyz_out) return h->deformed.download(xyz_out, (size_t)(3 * nv), h->stream);
   FB_HIP(hipStreamSynchronize(h->stream));
   return FB_OK;
 }

@@ -136,6 +136,19 @@ class GpuPoly:
         _l.check(self._L.fb_poly_apply_displacements(self.h, mesh, len(u), _l.dptr(u), _l.fptr(out)))
         return out
 
+    def interpolate_displacements(self, tet_displacements):
+        """Deformed surface from the displacements of the tet mesh of the same grid (fb_poly_interpolate_displacements)."""
+        u = np.ascontiguousarray(tet_displacements, dtype=np.float64).reshape(-1)
+        out = np.empty((self.counts.n_surface_vertices, 3), np.float32)
+        _l.check(self._L.fb_poly_interpolate_displacements(self.h, len(u), _l.dptr(u), _l.fptr(out)))
+        return out
+
+    def read_surface_binding(self):
+        nv = self.counts.n_surface_vertices
+        pairs, w = np.empty((nv, 2), np.uint32), np.empty(nv, np.float32)
+        _l.check(self._L.fb_poly_read_surface_binding(self.h, _l.uptr(pairs), _l.fptr(w)))
+        return pairs, w
+
     def time_pipeline(self, reps=5):
         a, b = C.c_double(0), C.c_double(0)
         _l.check(self._L.fb_poly_time_pipeline(self.h, reps, C.byref(a), C.byref(b)))

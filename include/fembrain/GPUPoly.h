@@ -98,6 +98,12 @@ class GPUPoly {
     if (step != 4 || vertices.size() < 4 * (size_t)ctVertices) return -1;
     return fb_poly_field_array(h_, (int)ctVertices, vertices.data()) == FB_OK ? 1 : -1;
   }
+  // render-loop coupling when the FEM mesh is this grid's own tet mesh: surface vertices follow the displacements of
+  // the two tet-mesh nodes of their grid edge (fb_poly_interpolate_displacements)
+  bool applyTetMeshDisplacements(U32 tetDof, const double* displacements, std::vector<float>* deformed = nullptr) {
+    if (deformed) deformed->resize(3 * (size_t)m_counts.n_surface_vertices);
+    return fb_poly_interpolate_displacements(h_, (int)tetDof, displacements, deformed ? deformed->data() : nullptr) == FB_OK;
+  }
   vec4u voxelGridDim() const { vec4u d = {(U32)m_counts.grid[0], (U32)m_counts.grid[1], (U32)m_counts.grid[2], (U32)m_counts.n_points}; return d; }
   U32 countSurfaceVoxels() const { return (U32)m_counts.n_surface_cells; }
   const fb_poly_counts& counts() const { return m_counts; }

@@ -249,6 +249,15 @@ int fb_poly_cube_table(unsigned char tri[4096], unsigned char nvert[256]);
  * deformed positions stay on the device and are copied to xyz_out when it is not NULL. */
 int fb_poly_apply_displacements(fb_poly_t h, int mesh, int n_dof, const double* displacements, float* xyz_out);
 
+/* Render-loop coupling when the FEM mesh is the tet mesh of the SAME grid (fb_poly_tetrahedralize): every surface vertex
+ * lies on a grid edge whose two end points are tet-mesh vertices a, b, at the weight t the root finder placed it.
+ * out = rest + (float)u_a + t * ((float)u_b - (float)u_a).  (The reference indexes the FEM displacements by the
+ * surface-vertex id, OclPolygonizer.cpp:1559-1563, which is only meaningful when both meshes share their vertices;
+ * SURVEY 8f-2.)  n_tet_dof = 3 * n_tet_vertices; xyz_out (3 floats per surface vertex) may be NULL. */
+int fb_poly_interpolate_displacements(fb_poly_t h, int n_tet_dof, const double* tet_displacements, float* xyz_out);
+/* per surface vertex: the pair (a, b) of tet-mesh vertex ids and the weight t (either may be NULL) */
+int fb_poly_read_surface_binding(fb_poly_t h, unsigned int* tet_vertex_pairs, float* weights);
+
 /* average device seconds of one sweep / one classify+tetrahedralize pipeline on the current grid */
 int fb_poly_time_pipeline(fb_poly_t h, int reps, double* sweep_seconds, double* pipeline_seconds);
 

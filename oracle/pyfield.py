@@ -125,6 +125,32 @@ class OrcPoly:
                                    eoff.ctypes.data_as(_up), self.edge_flags.ctypes.data_as(_bp), idx.ctypes.data_as(_up))
         return pos, nrm, idx.reshape(-1, 3)
 
+    def surface_binding(self):
+        """Per surface vertex (output order: grid point, then X, Y, Z edge): tet-mesh ids of the edge's two grid points
+        (exclusive scan of the included-vertex marks, Tetrahedralizer.cl:39-64) and the root weight
+        t = (0.5 - fa) / (fb - fa) of ComputeVertexAttribs (Polygonizer.cl:1540-1543), fp32."""
+        gx, gy = int(self.g[0]), int(self.g[1])
+        voff = np.cumsum(self.inc_verts, dtype=np.int64) - self.inc_verts
+        pts, axes = [], []
+        has = np.nonzero(self.edge_count)[0]
+        for axis, bit in ((0, 4), (1, 2), (2, 1)):
+            sel = has[(self.edge_flags[has] & bit) != 0]
+            pts.append(sel)
+            axes.append(np.full(len(sel), axis))
+        pts, axes = np.concatenate(pts), np.concatenate(axes)
+        order = np.lexsort((axes, pts))
+        pts, axes = pts[order], axes[order]
+        nb = pts + np.array([1, gx, gx * gy], np.int64)[axes]
+        fa, fb = self.xyzf[pts, 3], self.xyzf[nb, 3]
+        t = (np.float32(0.5) - fa) / (fb - fa)
+        return np.stack([voff[pts], voff[nb]], 1).astype(np.uint32), t.astype(np.float32)
+
+    def interpolate_displacements(self, rest, tet_displacements):
+        pairs, t = self.surface_binding()
+        u = np.asarray(tet_displacements, np.float64).reshape(-1, 3).astype(np.float32)
+        da, db = u[pairs[:, 0]], u[pairs[:, 1]]
+        return rest + (da + t[:, None] * (db - da))
+
     def run_tetrahedralizer(self, cellsize):
         self.sweep(cellsize)
         counts = self.classify()

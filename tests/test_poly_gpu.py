@@ -332,3 +332,32 @@ def test_instanced_models_match_oracle(gpu, name, cellsize):
     sx, sn, st = g.read_surface()
     ox, on, ot = o.surface()
     assert np.array_equal(st, ot) and np.array_equal(sx, ox) and np.abs(sn - on).max() <= 2e-2
+
+
+def test_surface_follows_the_tet_mesh_displacements(gpu):
+    """fb_poly_interpolate_displacements: surface vertex = rest + da + t (db - da) with (a, b, t) of its grid edge.
+    Bit-exact against the oracle; exact for a rigid translation; an affine displacement field is reproduced."""
+    from fembrain_amd import lib as fl
+    blob = read_blob(os.path.join(GOLD, "blob", "peanut.blob"))
+    g, o = GpuPoly(blob), OrcPoly(blob)
+    g.sweep(0.1); o.sweep(0.1)
+    g.classify(); o.classify()
+    g.surface()
+    g.tetrahedralize()
+    sx, _, _ = g.read_surface()
+    tx, _ = g.read_tetmesh()
+    pairs, w = g.read_surface_binding()
+    opairs, ow = o.surface_binding()
+    assert np.array_equal(pairs, opairs) and np.array_equal(w, ow)
+    # the surface vertex really is the weighted point of its edge
+    assert np.abs(tx[pairs[:, 0]] + w[:, None] * (tx[pairs[:, 1]] - tx[pairs[:, 0]]) - sx).max() < 1e-6
+    rng = np.random.default_rng(9)
+    u = rng.normal(scale=0.02, size=tx.shape)
+    assert np.array_equal(g.interpolate_displacements(u), o.interpolate_displacements(sx, u))
+    shift = np.tile(np.array([0.25, -0.5, 0.125]), (len(tx), 1))
+    assert np.array_equal(g.interpolate_displacements(shift), sx + shift[0].astype(np.float32))
+    A = np.array([[0.02, 0.01, 0.0], [-0.01, 0.03, 0.005], [0.0, 0.004, -0.02]])
+    aff = tx.astype(np.float64) @ A.T + 0.1
+    assert np.abs(g.interpolate_displacements(aff) - (sx + (sx.astype(np.float64) @ A.T + 0.1))).max() < 2e-6
+    with pytest.raises(fl.FbError):
+        g.interpolate_displacements(u[:-1])
