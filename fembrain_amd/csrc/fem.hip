@@ -393,6 +393,17 @@ int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int*
 int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed, const int* fixed, int n_ranks,
           int rank, const int* splits) {
   FB_TRY(build_fem_plan(h->plan, n_nodes, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits));
+  // A flat element makes inverse4x4 (corotationalLinearFEM.cpp:529-572) divide by zero; the reference then carries
+  // inf/NaN into the step silently.  Refuse it here instead (checked on this rank's elements, rest geometry).
+  for (int e = 0; e < h->plan.n_tets; e++) {
+    const double* p[4];
+    for (int k = 0; k < 4; k++) p[k] = xyz + 3 * (size_t)h->plan.local2global[h->plan.tets[4 * (size_t)e + k]];
+    double a[3], b[3], c[3];
+    for (int k = 0; k < 3; k++) { a[k] = p[1][k] - p[0][k]; b[k] = p[2][k] - p[0][k]; c[k] = p[3][k] - p[0][k]; }
+    const double det = a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+    if (!(det != 0.0) || !std::isfinite(det))
+      return fail(FB_EINVAL, "element %d has zero (or non-finite) rest volume", h->plan.tet_global.empty() ? e : h->plan.tet_global[e]);
+  }
   FB_TRY(upload_plan(h, xyz));
   FB_TRY(launch_rest(h));
   FB_HIP(hipStreamSynchronize(h->stream));

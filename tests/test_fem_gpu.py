@@ -458,3 +458,53 @@ def test_device_is_an_mi355x(gpu):
     name, arch, ncu = C.create_string_buffer(128), C.create_string_buffer(64), C.c_int(0)
     fl.check(L.fb_device_info(0, name, 128, arch, 64, C.byref(ncu)))
     assert arch.value.decode().startswith("gfx950") and ncu.value == 256, (name.value, arch.value, ncu.value)
+
+
+def test_inverted_and_strongly_rotated_elements(gpu):
+    """a3/a4 edge cases: elements turned inside out (det F < 0: the reference flips the polar factors,
+    corotationalLinearFEM.cpp:270-283) and a rigid rotation by 170 degrees (R far from I, zero elastic force)."""
+    n = 4
+    v, t, fixed = _cube(n)
+    o = OrcFem(v, t)
+    g = FemIntegrator(v, t, fixed, matrix_precision=fl.FB_MATRIX_F64)
+    conv = _oracle_bsr(o)
+    # push one interior node through the opposite faces of the tets around it
+    u = np.zeros(o.r)
+    node = (1 * n + 1) * n + 1
+    u[3 * node:3 * node + 3] = [0.25, 0.22, 0.27]
+    x = v + u.reshape(-1, 3)
+    vol = np.einsum("ij,ij->i", x[t[:, 1]] - x[t[:, 0]], np.cross(x[t[:, 2]] - x[t[:, 0]], x[t[:, 3]] - x[t[:, 0]]))
+    vol0 = np.einsum("ij,ij->i", v[t[:, 1]] - v[t[:, 0]], np.cross(v[t[:, 2]] - v[t[:, 0]], v[t[:, 3]] - v[t[:, 0]]))
+    assert (np.sign(vol) != np.sign(vol0)).sum() >= 3   # several inverted elements
+    fo, Ko = o.assemble(u)
+    fg, Kg = g.assemble(u)
+    assert np.abs(Kg - conv(Ko)).max() <= 1e-9 * np.abs(Ko).max()
+    assert np.abs(fg - fo).max() <= 1e-9 * np.abs(fo).max()
+    # rigid rotation about the cube centre: internal forces vanish, K = R K0 R^T block-wise
+    a = np.deg2rad(170.0)
+    R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    c = v.mean(0)
+    u = ((v - c) @ R.T + c - v).reshape(-1)
+    fo, Ko = o.assemble(u)
+    fg, Kg = g.assemble(u)
+    assert np.abs(fg).max() <= 1e-6 * np.abs(Ko).max() * 0.1 and np.abs(fo).max() <= 1e-6 * np.abs(Ko).max() * 0.1
+    assert np.abs(Kg - conv(Ko)).max() <= 1e-9 * np.abs(Ko).max()
+    _, K0 = o.assemble(np.zeros(o.r))
+    K0 = conv(K0)
+    assert np.abs(Kg - np.einsum("ab,kbc,dc->kad", R, K0, R)).max() <= 1e-8 * np.abs(K0).max()
+
+
+def test_every_dof_constrained_and_degenerate_input(gpu):
+    v, t, _ = _cube(3)
+    allfixed = np.arange(3 * len(v), dtype=np.int32)
+    g = FemIntegrator(v, t, allfixed)
+    g.set_uniform_force(1, -1000.0)
+    it = g.do_timestep()                      # nothing to solve: x = 0 at once
+    q, qv, _ = g.get_q_state()
+    assert it >= 0 and not q.any() and not qv.any()
+    with pytest.raises(fl.FbError):
+        FemIntegrator(v, np.array([[0, 1, 2, 2]], np.int32), [])           # repeated vertex: zero volume
+    flat = v.copy()
+    flat[:, 2] = 0.0
+    with pytest.raises(fl.FbError):
+        FemIntegrator(flat, t, [])                                         # all elements flat
