@@ -186,6 +186,7 @@ def main():
     spmv_s = g.time_spmv(200)
     spmv_bytes = g.spmv_bytes()
     asm_k_s = g.time_assembly(10)
+    halo_s, sum_s = g.time_exchange(200) if dist_mode else (0.0, 0.0)
     out = None
     if rank == 0:
         traffic = None
@@ -201,10 +202,12 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 matrix, f64 vectors/accumulators" if args.precision == "f32" else "f64", "data": "synthetic",
             "config": {"workload": text, "nodes": int(len(v)), "tets": int(len(t)), "partition": "i-plane slabs x%d" % world,
-                       "exchange": ["none (one GPU)", "RCCL all-reduce + send/recv", "peer-to-peer inbox kernels over xGMI (HIP IPC)"][g.transport()],
+                       "exchange": ["none (one GPU)", "host-staged test communicator (rehearsal)" if local_comm else "RCCL all-reduce + send/recv",
+                                    "peer-to-peer inbox kernels over xGMI (HIP IPC)"][g.transport()],
                        "cg_eps": 1e-6, "cg_max_iter": 10000},
             "cg_iterations_per_step": float(np.mean(iters)), "assembly_ms_per_step": asm_s / args.steps * 1e3,
             "solve_ms_per_step": solve_s / args.steps * 1e3, "us_per_cg_iteration": solve_s / max(sum(iters), 1) * 1e6,
+            "exchange_us": {"halo_refresh": halo_s * 1e6, "global_sum_3": sum_s * 1e6},
             "assembly_kernels_us": asm_k_s * 1e6, "assembly_gbs": g.assembly_bytes() / asm_k_s / 1e9,
             "roofline": {"kernel": "k_spmv (SELL-64 3x3-block SpMV of the PCG)", "bound": "hbm",
                          "achieved": spmv_bytes / spmv_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -844,6 +844,31 @@ int fb_fem_time_spmv(fb_fem_t h, int reps, double* seconds_per_spmv) {
   return FB_OK;
 }
 
+int fb_fem_time_exchange(fb_fem_t h, int reps, double* seconds_per_halo, double* seconds_per_sum) {
+  CHECK_HANDLE(h);
+  if (reps < 1) return fail(FB_EINVAL, "bad arguments");
+  if (seconds_per_halo) *seconds_per_halo = 0.0;
+  if (seconds_per_sum) *seconds_per_sum = 0.0;
+  if (!h->comm || h->comm->n_ranks == 1) return FB_OK;
+  hipStream_t s = h->stream;
+  double* sc = nullptr;
+  FB_TRY(halo_exchange(h, h->tmp.p));  // warm, and lines the ranks up
+  FB_TRY(global_scalar(h, h->part_a.p, &sc, false, 3));
+  float ms = 0;
+  FB_HIP(hipEventRecord(h->ev[0], s));
+  for (int i = 0; i < reps; i++) FB_TRY(halo_exchange(h, h->tmp.p));
+  FB_HIP(hipEventRecord(h->ev[1], s));
+  for (int i = 0; i < reps; i++) FB_TRY(global_scalar(h, h->part_a.p, &sc, false, 3));
+  FB_HIP(hipEventRecord(h->ev[2], s));
+  FB_HIP(hipStreamSynchronize(s));
+  if (h->p2p) FB_TRY(p2p_check(h->p2p, s));
+  FB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  if (seconds_per_halo) *seconds_per_halo = ms * 1e-3 / reps;
+  FB_HIP(hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
+  if (seconds_per_sum) *seconds_per_sum = ms * 1e-3 / reps;
+  return FB_OK;
+}
+
 int fb_fem_time_assembly(fb_fem_t h, int reps, double* seconds_per_assembly) {
   CHECK_HANDLE(h);
   if (reps < 1 || !seconds_per_assembly) return fail(FB_EINVAL, "bad arguments");

@@ -50,6 +50,12 @@ class FemIntegrator:
         self.last = _l.StepInfo()
 
     # -- life cycle --
+    def time_exchange(self, reps=100):
+        """(seconds per halo refresh, seconds per 3-scalar global sum); collective on a sharded handle."""
+        a, b = C.c_double(0), C.c_double(0)
+        _l.check(self._L.fb_fem_time_exchange(self.h, reps, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def transport(self):
         """0 unsharded, 1 collective library (RCCL / test communicator), 2 direct peer-to-peer mailboxes."""
         return int(self._L.fb_fem_transport(self.h))

@@ -165,6 +165,10 @@ int fb_fem_pcg(fb_fem_t h, const double* rhs, double* x, double eps, int max_ite
  * launch measured with HIP events on the handle's stream. */
 int fb_fem_time_spmv(fb_fem_t h, int reps, double* seconds_per_spmv);
 int fb_fem_time_assembly(fb_fem_t h, int reps, double* seconds_per_assembly);
+/* COLLECTIVE on a sharded handle (every rank calls it with the same reps): average device seconds of one halo refresh of
+ * a 3-vector and of one 3-scalar global sum, back to back on the handle's stream -- the two exchanges of a PCG
+ * iteration, through whichever transport fb_fem_transport() reports.  Both 0 on an unsharded handle. */
+int fb_fem_time_exchange(fb_fem_t h, int reps, double* seconds_per_halo, double* seconds_per_sum);
 /* algorithmic bytes moved by one SpMV launch / one assembly on this handle */
 int fb_fem_spmv_bytes(fb_fem_t h, double* bytes);
 int fb_fem_assembly_bytes(fb_fem_t h, double* bytes);
