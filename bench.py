@@ -166,6 +166,24 @@ def main():
         g.set_uniform_force(1, -10000.0)
         return g.do_timestep()
 
+    # Sharded runs: the exchange modes give bitwise identical iterates, so the fastest one ON THIS MACHINE is picked by
+    # timing one step in each (max over ranks); untimed, before the warmup.
+    xch_trials = {}
+    if dist_mode and g.transport() >= fl.FB_XCH_P2P and os.environ.get("FEMBRAIN_XCH_MODE") is None:
+        names = {fl.FB_XCH_COLLECTIVE: "collective", fl.FB_XCH_P2P: "p2p", fl.FB_XCH_P2P_SUMS: "p2p_sums", fl.FB_XCH_P2P_FUSED: "p2p_fused"}
+        one_step()
+        for mode in (fl.FB_XCH_P2P, fl.FB_XCH_P2P_SUMS, fl.FB_XCH_P2P_FUSED):
+            g.set_exchange_mode(mode)
+            barrier()
+            ts = time.perf_counter()
+            one_step()
+            barrier()
+            tt = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cpu" if local_comm else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            xch_trials[names[mode]] = float(tt.item()) * 1e3
+        best = min(xch_trials, key=xch_trials.get)
+        g.set_exchange_mode({v: k for k, v in names.items()}[best])
+        g.reset_to_rest()   # the timed steps start from the same state as the one-GPU run's
     for _ in range(args.warmup):
         one_step()
     barrier()
@@ -203,7 +221,10 @@ def main():
             "dtype": "f32 matrix, f64 vectors/accumulators" if args.precision == "f32" else "f64", "data": "synthetic",
             "config": {"workload": text, "nodes": int(len(v)), "tets": int(len(t)), "partition": "i-plane slabs x%d" % world,
                        "exchange": ["none (one GPU)", "host-staged test communicator (rehearsal)" if local_comm else "RCCL all-reduce + send/recv",
-                                    "peer-to-peer inbox kernels over xGMI (HIP IPC)"][g.transport()],
+                                    "peer-to-peer inboxes over xGMI (HIP IPC), one kernel per exchange",
+                                    "peer-to-peer inboxes, sums inside the PCG kernels",
+                                    "peer-to-peer inboxes, sums and halo values inside the PCG kernels"][g.transport()],
+                       "exchange_trials_ms_per_step": xch_trials,
                        "cg_eps": 1e-6, "cg_max_iter": 10000},
             "cg_iterations_per_step": float(np.mean(iters)), "assembly_ms_per_step": asm_s / args.steps * 1e3,
             "solve_ms_per_step": solve_s / args.steps * 1e3, "us_per_cg_iteration": solve_s / max(sum(iters), 1) * 1e6,

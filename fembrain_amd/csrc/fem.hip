@@ -15,6 +15,8 @@ struct fb_fem_s {
   hipStream_t stream = nullptr;
   fb_comm_s* comm = nullptr;  // not owned
   P2P* p2p = nullptr;         // direct peer mailboxes for halo refresh and dots (comm.h); null = collective library
+  unsigned long long pending_halo = 0;  // sequence number under which the last vector pass sent the search direction (0 = none)
+  int xch_mode = FB_XCH_COLLECTIVE;     // how the exchanges of a sharded handle run (fb_fem_set_exchange_mode)
   DevBuf<int> send_dest, send_off_dev, halo_off_dev;
   FemPlan plan;
   double lambda = 0, mu = 0;
@@ -125,7 +127,7 @@ int halo_exchange(fb_fem_s* h, double* vec, int width = 3) {
   if (!h->comm || h->comm->n_ranks == 1) return FB_OK;
   const FemPlan& P = h->plan;
   const int ns = (int)P.send_local.size();
-  if (h->p2p)
+  if (h->xch_mode >= FB_XCH_P2P)
     return p2p_halo(h->p2p, width, ns, h->send_local.p, h->send_dest.p, h->send_off_dev.p, P.n_local - P.n_owned, h->halo_off_dev.p, P.n_owned, vec,
                     h->stream);
   if (ns > 0) {
@@ -178,7 +180,17 @@ int assemble_system(fb_fem_s* h) {
 template <typename MT, int MODE>
 int launch_spmv(fb_fem_s* h, const double* x, double* y, const double* b, double* partial, int parity) {
   hipLaunchKernelGGL((k_spmv<MT, MODE>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y, b,
-                     h->invdiag.p, partial, h->st.p, parity);
+                     h->invdiag.p, partial, h->st.p, parity, P2PArgs());
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+// the merged-iteration SpMV of a sharded handle on the peer-to-peer transport: its last block posts the three sums;
+// XCH = 2 also gathers the halo columns from the inbox (sent by the neighbours' previous vector pass)
+template <typename MT, int XCH>
+int launch_spmv_xch(fb_fem_s* h, const double* x, double* y, const double* b, double* partial, int parity, const P2PArgs& pa) {
+  hipLaunchKernelGGL((k_spmv<MT, 3, XCH>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y, b,
+                     h->invdiag.p, partial, h->st.p, parity, pa);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void k_fold_partials(const double* partial,
 int global_scalar(fb_fem_s* h, const double* partial, double** out, bool check_done, int count = 1, int slot = 0) {
   *out = nullptr;
   if (!h->comm || (!h->comm->nccl && !h->comm->local)) return FB_OK;
-  if (h->p2p) {  // fold + exchange + rank-ordered sum in one single-block kernel
+  if (h->xch_mode >= FB_XCH_P2P) {  // fold + exchange + rank-ordered sum in one single-block kernel
     FB_TRY(p2p_reduce(h->p2p, partial, h->grid, count, h->scal.p + slot, h->stream));
     *out = h->scal.p;
     return FB_OK;
@@ -221,13 +233,45 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b) {
   const int parity = (it - 1) & 1;
   const bool refresh = (it % 30 == 0);
   double* sc = nullptr;
-  FB_TRY(halo_exchange(h, h->d.p));
+  const unsigned long long have = h->pending_halo;  // the previous vector pass already sent d to the neighbours' inboxes
+  h->pending_halo = 0;
+  if (!refresh && h->prm.pcg_variant == FB_PCG_MERGED && h->xch_mode >= FB_XCH_P2P_SUMS) {
+    // Peer-to-peer transport: both exchanges ride inside the two kernels of the iteration.  The SpMV waits for the
+    // neighbours' halo post and gathers halo columns from the inbox, its last block posts the three sums; the vector
+    // pass waits for everybody's sums and its last block sends the new search direction for the next SpMV.
+    P2PArgs pa = p2p_next_sum(h->p2p);
+    pa.send_ids = h->send_local.p; pa.send_dest = h->send_dest.p; pa.send_off = h->send_off_dev.p; pa.halo_off = h->halo_off_dev.p;
+    pa.n_send = (int)P.send_local.size(); pa.n_owned = P.n_owned;
+    if (have) {
+      pa.halo_seq = have;
+      FB_TRY(h->f64 ? (launch_spmv_xch<double, 2>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity, pa))
+                    : (launch_spmv_xch<float, 2>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity, pa)));
+    } else {
+      FB_TRY(halo_exchange(h, h->d.p));
+      FB_TRY(h->f64 ? (launch_spmv_xch<double, 1>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity, pa))
+                    : (launch_spmv_xch<float, 1>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity, pa)));
+    }
+    if (h->xch_mode == FB_XCH_P2P_SUMS) {  // the halo refresh keeps its own kernel
+      hipLaunchKernelGGL((k_cg_fused<true, false>), dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p,
+                         h->grid, (const double*)nullptr, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->d.p, pa);
+      FB_HIP(hipGetLastError());
+      return FB_OK;
+    }
+    pa.halo_seq = p2p_next_halo(h->p2p);
+    hipLaunchKernelGGL((k_cg_fused<true, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->grid,
+                       (const double*)nullptr, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->d.p, pa);
+    FB_HIP(hipGetLastError());
+    h->pending_halo = pa.halo_seq;
+    return FB_OK;
+  }
+  if (have) FB_TRY(p2p_halo_unpack(h->p2p, have, 3, P.n_local - P.n_owned, h->halo_off_dev.p, P.n_owned, h->d.p, h->st.p, h->stream));
+  else FB_TRY(halo_exchange(h, h->d.p));
   if (!refresh && h->prm.pcg_variant == FB_PCG_MERGED) {
     // merged-reduction iteration: SpMV with the three sums, then one fused vector pass (one reduction / all-reduce)
     FB_TRY(spmv<3>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity));
     FB_TRY(global_scalar(h, h->part_a.p, &sc, true, 3));
-    hipLaunchKernelGGL(k_cg_fused, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->grid,
-                       sc, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->d.p);
+    hipLaunchKernelGGL((k_cg_fused<false, false>), dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->grid,
+                       sc, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->d.p, P2PArgs());
     FB_HIP(hipGetLastError());
     return FB_OK;
   }
@@ -261,6 +305,7 @@ bool host_finished(const CGState& s) {
 int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state);
 
 int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state) {
+  h->pending_halo = 0;  // a direction sent by the last vector pass of an earlier solve is never consumed
   if (h->prm.pcg_variant == FB_PCG_FUSED) return pcg_solve_fused(h, b, eps, max_iter, iters_out, final_state);
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
@@ -415,6 +460,11 @@ int attach_p2p(fb_fem_s* h) {
   const FemPlan& P = h->plan;
   FB_TRY(p2p_attach(h->comm, P.n_local - P.n_owned, P.halo_off.data(), h->stream, &h->p2p));
   if (!h->p2p) return FB_OK;
+  h->xch_mode = FB_XCH_P2P_FUSED;
+  if (const char* e = getenv("FEMBRAIN_XCH_MODE")) {  // 2 / 3 / 4: how much of the exchange rides inside the PCG kernels
+    const int m = atoi(e);
+    if (m >= FB_XCH_COLLECTIVE && m <= FB_XCH_P2P_FUSED) h->xch_mode = m;
+  }
   std::vector<int> dest(std::max<size_t>(1, P.send_local.size()), 0);
   for (int q = 0; q < P.n_ranks; q++)
     for (int i = P.send_off[q]; i < P.send_off[q + 1]; i++) dest[i] = q;
@@ -576,7 +626,19 @@ int fb_fem_destroy(fb_fem_t h) {
 int fb_fem_transport(fb_fem_t h) {
   if (!h) return -1;
   if (!h->comm || h->comm->n_ranks == 1) return 0;
-  return h->p2p ? 2 : 1;
+  return h->xch_mode;
+}
+
+int fb_fem_set_exchange_mode(fb_fem_t h, int mode) {
+  CHECK_HANDLE(h);
+  if (!h->comm || h->comm->n_ranks == 1) return fail(FB_EINVAL, "an unsharded handle has no exchange");
+  if (mode < FB_XCH_COLLECTIVE || mode > FB_XCH_P2P_FUSED) return fail(FB_EINVAL, "exchange mode %d", mode);
+  if (mode >= FB_XCH_P2P && !h->p2p) return fail(FB_ECOMM, "the peer-to-peer transport is not attached (mapping failed or FEMBRAIN_P2P=0)");
+  if (mode == FB_XCH_COLLECTIVE && !h->comm->nccl && !h->comm->local) return fail(FB_ECOMM, "the communicator has no collective library");
+  FB_HIP(hipStreamSynchronize(h->stream));
+  h->xch_mode = mode;
+  h->pending_halo = 0;
+  return FB_OK;
 }
 
 int fb_fem_resync(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed_dofs, const int* fixed_dofs) {

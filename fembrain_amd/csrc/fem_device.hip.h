@@ -1,6 +1,7 @@
 // FEM device kernels (included by fem.hip only).
 #pragma once
 #include "fem_kernels.h"
+#include "p2p_device.hip.h"
 
 namespace fb {
 
@@ -329,11 +330,14 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
 //   MODE 3: q = A d with the three sums of the merged-reduction iteration: partial[b] = sum d.q,
 //           partial[G+b] = sum invdiag r q, partial[2G+b] = sum invdiag q^2 (bvec carries r)
 // ------------------------------------------------------------------------------------------------------
-template <typename MT, int MODE>
+// XCH (sharded handles on the peer-to-peer transport, MODE 3 only): 1 = the last block to finish folds the block partials
+// and posts the three sums into every rank's inbox, so the global sum costs no launch of its own; 2 = in addition the
+// halo columns are gathered straight from the inbox, where the neighbours' previous vector pass put them.
+template <typename MT, int MODE, int XCH = 0>
 __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo, const double* __restrict__ x,
                                                  double* __restrict__ y, const double* __restrict__ bvec,
                                                  const double* __restrict__ invdiag, double* __restrict__ partial,
-                                                 CGState* __restrict__ st, int parity) {
+                                                 CGState* __restrict__ st, int parity, P2PArgs pa) {
   __shared__ double lds[4];
   if (MODE != 0 && st->done) return;
   if (MODE == 1 || MODE == 3) {
@@ -346,6 +350,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
   }
   const int lane = threadIdx.x & 63;
   double acc = 0.0, acc1 = 0.0, acc2 = 0.0;
+  const double* halo_in = nullptr;
+  if (XCH == 2) {
+    p2p_wait_halo(pa.dev, pa.halo_seq, pa.halo_off);
+    halo_in = p2p_halo_in(pa.dev, pa.halo_seq) - 3 * (size_t)sv.n_owned;
+  }
   for (SliceWalk w(sv.n_slices); w.valid(); w.next()) {
     const int s = w.s;
     const int row = s * 64 + lane;
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
 #pragma unroll 4
     for (int k = 0; k < width; k++) {
       const int col = ci[(size_t)k * 64];
-      const double* xp = x + 3 * (size_t)col;
+      const double* xp = ((XCH == 2 && col >= sv.n_owned) ? halo_in : x) + 3 * (size_t)col;
       const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
       const MT* vk = v + (size_t)k * 9 * 64;
       y0 += (double)vk[0 * 64] * x0 + (double)vk[1 * 64] * x1 + (double)vk[2 * 64] * x2;
@@ -400,6 +409,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
     if (threadIdx.x == 0) {
       partial[gridDim.x + blockIdx.x] = t1;
       partial[2 * gridDim.x + blockIdx.x] = t2;
+    }
+  }
+  if (XCH != 0 && MODE == 3) {
+    __shared__ int last;
+    __shared__ double mine[8];
+    __threadfence();
+    if (threadIdx.x == 0) last = atomicAdd(pa.ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (last) {  // block-uniform
+      if (threadIdx.x == 0) atomicExch(pa.ticket, 0);
+      __threadfence();
+      p2p_post_sums(pa.dev, pa.seq, partial, (int)gridDim.x, 3, lds, mine);
     }
   }
   (void)acc1; (void)acc2;
@@ -525,10 +546,13 @@ struct PairWalk {
   __device__ void next() { i += stride; }
 };
 
+// WAIT: the three sums arrive in this rank's inbox, posted by the last SpMV block of every rank (see k_spmv XCH).
+// SEND: the last block to finish stores the new search direction of the boundary nodes into the neighbours' inboxes.
+template <bool WAIT = false, bool SEND = false>
 __global__ __launch_bounds__(kBlock) void k_cg_fused(int n_slices, int n_owned, CGState* st, int parity,
                                                      const double* __restrict__ part, int n_partial, const double* sc,
                                                      const double* __restrict__ q, const double* __restrict__ invdiag,
-                                                     double* __restrict__ x, double* __restrict__ r, double* __restrict__ d) {
+                                                     double* __restrict__ x, double* __restrict__ r, double* __restrict__ d, P2PArgs pa) {
   __shared__ double lds[12];
   if (st->done) return;
   const size_t n3 = 3 * (size_t)n_owned;  // an odd count ends in a half pair: loads stay in bounds (vectors carry 2 spare
@@ -542,7 +566,10 @@ __global__ __launch_bounds__(kBlock) void k_cg_fused(int n_slices, int n_owned, 
     i0 = ((const double2*)invdiag)[w.i]; x0 = ((const double2*)x)[w.i];
   }
   double s0, s1, s2;
-  if (sc) {
+  if (WAIT) {
+    p2p_wait_sums(pa.dev, pa.seq, 3, lds);
+    s0 = lds[0]; s1 = lds[1]; s2 = lds[2];
+  } else if (sc) {
     s0 = sc[0]; s1 = sc[1]; s2 = sc[2];
   } else {
     double a0 = 0, a1 = 0, a2 = 0;
@@ -579,6 +606,17 @@ __global__ __launch_bounds__(kBlock) void k_cg_fused(int n_slices, int n_owned, 
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->rho[1 - parity] = rho_new;
     st->iter = st->iter + 1;
+  }
+  if (SEND) {
+    __shared__ int last;
+    __threadfence();
+    if (threadIdx.x == 0) last = atomicAdd(pa.ticket2, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (last) {  // block-uniform
+      if (threadIdx.x == 0) atomicExch(pa.ticket2, 0);
+      __threadfence();
+      p2p_send_halo3(pa.dev, pa.halo_seq, pa.n_send, pa.send_ids, pa.send_dest, pa.send_off, d);
+    }
   }
 }
 

@@ -3,18 +3,13 @@
 #include "comm.h"
 #include "common.h"
 #include "fem_kernels.h"
+#include "p2p_device.hip.h"
 
 namespace fb {
 
 namespace {
 
-// inbox layout (bytes)
-constexpr size_t kOffHaloFlag = 0;     // u64[kP2PMaxRanks]   written by peer q at [q]
-constexpr size_t kOffRedFlag = 128;    // u64[kP2PMaxRanks]
-constexpr size_t kOffErr = 256;        // u64
-constexpr size_t kOffRed = 512;        // double[2][kP2PMaxRanks][8]
-constexpr size_t kOffHalo = 4096;      // double[2][cap * 12]
-constexpr int kMaxWidth = 12;
+constexpr int kMaxWidth = kP2PMaxWidth;
 
 struct Meta {  // what every rank publishes at attach time
   hipIpcMemHandle_t handle;
@@ -22,28 +17,6 @@ struct Meta {  // what every rank publishes at attach time
   int halo_off[kP2PMaxRanks + 1];
   int ok;
 };
-
-__device__ __forceinline__ unsigned long long ld_acquire_sys(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ void st_release_sys(unsigned long long* p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// spin until *flag >= seq; bounded by the wall clock.  A timeout anywhere poisons the inbox so that the queue drains.
-__device__ bool wait_flag(const P2PDev& c, const unsigned long long* flag, unsigned long long seq) {
-  unsigned long long* err = (unsigned long long*)(c.inbox + kOffErr);
-  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return false;
-  const long long t0 = wall_clock64();
-  while (ld_acquire_sys(flag) < seq) {
-    if (wall_clock64() - t0 > c.timeout_ticks) {
-      __hip_atomic_store(err, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return false;
-    }
-    __builtin_amdgcn_s_sleep(4);
-  }
-  return true;
-}
 
 // phase 1: every thread stores its share of my boundary values straight into the destination's inbox; the last block
 // to finish publishes the sequence number to the destinations.  phase 2: wait for the neighbours' numbers and copy
@@ -72,11 +45,22 @@ __global__ __launch_bounds__(kBlock) void k_p2p_halo(P2PDev c, int width, unsign
   }
   if (threadIdx.x == 0) {
     for (int q = 0; q < c.n_ranks; q++)
-      if (q != c.rank && halo_off[q + 1] > halo_off[q]) wait_flag(c, (const unsigned long long*)(c.inbox + kOffHaloFlag) + q, seq);
+      if (q != c.rank && halo_off[q + 1] > halo_off[q]) p2p_wait_flag(c, (const unsigned long long*)(c.inbox + kOffHaloFlag) + q, seq);
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   const double* in = (const double*)(c.inbox + kOffHalo) + (size_t)par * c.cap * kMaxWidth;
+  double* out = vec + (size_t)width * n_owned;
+  for (long long i = tid; i < (long long)n_halo * width; i += stride) out[i] = __builtin_nontemporal_load(in + i);
+}
+
+// phase 2 alone: the values were sent by the neighbours' vector pass (k_cg_fused SEND)
+__global__ __launch_bounds__(kBlock) void k_p2p_unpack(P2PDev c, int width, unsigned long long seq, int n_halo, const int* __restrict__ halo_off,
+                                                       int n_owned, double* __restrict__ vec, const CGState* __restrict__ st) {
+  if (st->done) return;  // a finished solve: the vector pass that would have sent `seq` returned early on every rank
+  p2p_wait_halo(c, seq, halo_off);
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x, stride = (long long)gridDim.x * kBlock;
+  const double* in = (const double*)(c.inbox + kOffHalo) + (size_t)(seq & 1ULL) * c.cap * kMaxWidth;
   double* out = vec + (size_t)width * n_owned;
   for (long long i = tid; i < (long long)n_halo * width; i += stride) out[i] = __builtin_nontemporal_load(in + i);
 }
@@ -87,27 +71,10 @@ __global__ __launch_bounds__(kBlock) void k_p2p_reduce(P2PDev c, unsigned long l
                                                        double* __restrict__ out) {
   __shared__ double lds[4];
   __shared__ double mine[8];
-  for (int k = 0; k < count; k++) {
-    const double s = sum_partials(partial + (size_t)k * n, n, lds);
-    if (threadIdx.x == 0) mine[k] = s;
-  }
-  __syncthreads();
-  const int par = (int)(seq & 1ULL), t = threadIdx.x;
-  if (t < c.n_ranks) {
-    double* slot = (double*)(c.peer[t] + kOffRed) + ((size_t)par * kP2PMaxRanks + c.rank) * 8;
-    for (int k = 0; k < count; k++) slot[k] = mine[k];
-    __threadfence_system();
-    st_release_sys((unsigned long long*)(c.peer[t] + kOffRedFlag) + c.rank, seq);
-    wait_flag(c, (const unsigned long long*)(c.inbox + kOffRedFlag) + t, seq);
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  if (t < count) {
-    const double* slots = (const double*)(c.inbox + kOffRed) + (size_t)par * kP2PMaxRanks * 8;
-    double tot = 0.0;
-    for (int r = 0; r < c.n_ranks; r++) tot += __builtin_nontemporal_load(slots + (size_t)r * 8 + t);
-    out[t] = tot;
-  }
+  __shared__ double tot[8];
+  p2p_post_sums(c, seq, partial, n, count, lds, mine);
+  p2p_wait_sums(c, seq, count, tot);
+  if ((int)threadIdx.x < count) out[threadIdx.x] = tot[threadIdx.x];
 }
 
 }  // namespace
@@ -136,6 +103,27 @@ void p2p_detach(P2P* p) {
 int p2p_reduce(P2P* p, const double* partial, int n, int count, double* out, hipStream_t s) {
   if (count < 1 || count > 8 || n < 1 || n > kMaxPartials) return fail(FB_EINVAL, "p2p_reduce: bad sizes");
   hipLaunchKernelGGL(k_p2p_reduce, dim3(1), dim3(kBlock), 0, s, p->dev, ++p->red_seq, partial, n, count, out);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+P2PArgs p2p_next_sum(P2P* p) {
+  P2PArgs a;
+  memset(&a, 0, sizeof a);
+  a.dev = p->dev;
+  a.seq = ++p->red_seq;
+  a.ticket = p->counter + 1;
+  a.ticket2 = p->counter + 2;
+  return a;
+}
+
+unsigned long long p2p_next_halo(P2P* p) { return ++p->halo_seq; }
+
+int p2p_halo_unpack(P2P* p, unsigned long long seq, int width, int n_halo, const int* halo_off_dev, int n_owned, double* vec, const CGState* st,
+                    hipStream_t s) {
+  if (width < 1 || width > kMaxWidth || n_halo > p->dev.cap) return fail(FB_EINVAL, "p2p_halo_unpack: bad sizes");
+  const int blocks = (int)std::max<long long>(1, std::min<long long>(((long long)n_halo * width + kBlock - 1) / kBlock, 256));
+  hipLaunchKernelGGL(k_p2p_unpack, dim3(blocks), dim3(kBlock), 0, s, p->dev, width, seq, n_halo, halo_off_dev, n_owned, vec, st);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -179,7 +167,7 @@ int p2p_attach(fb_comm_s* c, int n_halo_nodes, const int* halo_off, hipStream_t 
   // local part; any failure is reported through mine.ok so that the ranks can agree to fall back together
   bool ok = hipExtMallocWithFlags((void**)&p->dev.inbox, p->inbox_bytes, hipDeviceMallocFinegrained) == hipSuccess;
   ok = ok && hipMemsetAsync(p->dev.inbox, 0, p->inbox_bytes, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-  ok = ok && hipMalloc((void**)&p->counter, sizeof(int)) == hipSuccess && hipMemsetAsync(p->counter, 0, sizeof(int), s) == hipSuccess;
+  ok = ok && hipMalloc((void**)&p->counter, 4 * sizeof(int)) == hipSuccess && hipMemsetAsync(p->counter, 0, 4 * sizeof(int), s) == hipSuccess;
   ok = ok && hipMalloc((void**)&p->probe, 2 * sizeof(double)) == hipSuccess;
   ok = ok && hipIpcGetMemHandle(&mine.handle, p->dev.inbox) == hipSuccess;
   (void)hipGetLastError();

@@ -1,0 +1,108 @@
+// Device side of the peer-to-peer transport (comm.h): inbox layout and the post / wait primitives shared by the
+// stand-alone exchange kernels (p2p.hip) and the PCG kernels that carry an exchange in their prologue / epilogue.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "comm.h"
+#include "fem_kernels.h"
+
+namespace fb {
+
+// inbox layout (bytes)
+constexpr size_t kOffHaloFlag = 0;     // u64[kP2PMaxRanks]   written by peer q at [q]
+constexpr size_t kOffRedFlag = 128;    // u64[kP2PMaxRanks]
+constexpr size_t kOffErr = 256;        // u64
+constexpr size_t kOffRed = 512;        // double[2][kP2PMaxRanks][8]
+constexpr size_t kOffHalo = 4096;      // double[2][cap * 12]
+constexpr int kP2PMaxWidth = 12;
+
+__device__ __forceinline__ unsigned long long ld_acquire_sys(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_release_sys(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// spin until *flag >= seq; bounded by the wall clock.  A timeout anywhere poisons the inbox so that the queue drains.
+__device__ inline bool p2p_wait_flag(const P2PDev& c, const unsigned long long* flag, unsigned long long seq) {
+  unsigned long long* err = (unsigned long long*)(c.inbox + kOffErr);
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return false;
+  const long long t0 = wall_clock64();
+  while (ld_acquire_sys(flag) < seq) {
+    if (wall_clock64() - t0 > c.timeout_ticks) {
+      __hip_atomic_store(err, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return true;
+}
+
+// ONE whole block, after every block's partial sums are visible: fold them in fixed order and post the `count` totals
+// into every rank's inbox (own included).  lds: 4 doubles, mine: 8 doubles of shared memory.
+__device__ inline void p2p_post_sums(const P2PDev& c, unsigned long long seq, const double* partial, int n, int count, double* lds, double* mine) {
+  for (int k = 0; k < count; k++) {
+    const double s = sum_partials(partial + (size_t)k * n, n, lds);
+    if (threadIdx.x == 0) mine[k] = s;
+  }
+  __syncthreads();
+  const int par = (int)(seq & 1ULL), t = threadIdx.x;
+  if (t < c.n_ranks) {
+    double* slot = (double*)(c.peer[t] + kOffRed) + ((size_t)par * kP2PMaxRanks + c.rank) * 8;
+    for (int k = 0; k < count; k++) slot[k] = mine[k];
+    __threadfence_system();
+    st_release_sys((unsigned long long*)(c.peer[t] + kOffRedFlag) + c.rank, seq);
+  }
+}
+
+// any block: wait for every rank's post of `seq` and add the slots in rank order; all threads return after the totals
+// are in tot[0..count) (shared memory, >= 8 doubles)
+__device__ inline void p2p_wait_sums(const P2PDev& c, unsigned long long seq, int count, double* tot) {
+  const int par = (int)(seq & 1ULL), t = threadIdx.x;
+  if (t == 0) {  // one poller per block keeps the pressure on the flag line low; later flags are normally set already
+    for (int r = 0; r < c.n_ranks; r++) p2p_wait_flag(c, (const unsigned long long*)(c.inbox + kOffRedFlag) + r, seq);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (t < count) {
+    const double* slots = (const double*)(c.inbox + kOffRed) + (size_t)par * kP2PMaxRanks * 8;
+    double s = 0.0;
+    for (int r = 0; r < c.n_ranks; r++) s += __builtin_nontemporal_load(slots + (size_t)r * 8 + t);
+    tot[t] = s;
+  }
+  __syncthreads();
+}
+
+// every block, before it gathers halo columns straight from the inbox: wait for the neighbours' halo post `seq`
+__device__ inline void p2p_wait_halo(const P2PDev& c, unsigned long long seq, const int* __restrict__ halo_off) {
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < c.n_ranks; q++)
+      if (q != c.rank && halo_off[q + 1] > halo_off[q]) p2p_wait_flag(c, (const unsigned long long*)(c.inbox + kOffHaloFlag) + q, seq);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+// where the 3-vector halo values posted under `seq` sit in my inbox (indexed by halo node: local id - n_owned)
+__device__ inline const double* p2p_halo_in(const P2PDev& c, unsigned long long seq) {
+  return (const double*)(c.inbox + kOffHalo) + (size_t)(seq & 1ULL) * c.cap * kP2PMaxWidth;
+}
+
+// ONE whole block, after every block's part of vec is visible: store my boundary 3-vectors into the neighbours' inboxes
+// and release `seq` to them
+__device__ inline void p2p_send_halo3(const P2PDev& c, unsigned long long seq, int n_send, const int* __restrict__ send_ids,
+                                      const int* __restrict__ send_dest, const int* __restrict__ send_off, const double* vec) {
+  const int par = (int)(seq & 1ULL);
+  for (int i = threadIdx.x; i < 3 * n_send; i += kBlock) {
+    const int node = i / 3, cc = i - 3 * node;
+    const int q = send_dest[node];
+    double* dst = (double*)(c.peer[q] + kOffHalo) + (size_t)par * c.peer_cap[q] * kP2PMaxWidth + (size_t)(c.peer_seg[q] + node - send_off[q]) * 3 + cc;
+    *dst = __builtin_nontemporal_load(vec + 3 * (size_t)send_ids[node] + cc);
+  }
+  __threadfence_system();
+  __syncthreads();
+  const int q = threadIdx.x;
+  if (q < c.n_ranks && q != c.rank && send_off[q + 1] > send_off[q]) st_release_sys((unsigned long long*)(c.peer[q] + kOffHaloFlag) + c.rank, seq);
+}
+
+}  // namespace fb

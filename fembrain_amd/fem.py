@@ -57,8 +57,12 @@ class FemIntegrator:
         return a.value, b.value
 
     def transport(self):
-        """0 unsharded, 1 collective library (RCCL / test communicator), 2 direct peer-to-peer mailboxes."""
+        """0 unsharded, else the exchange mode in use (lib.FB_XCH_*)."""
         return int(self._L.fb_fem_transport(self.h))
+
+    def set_exchange_mode(self, mode):
+        """Collective: every rank of a sharded handle switches between two solves."""
+        _l.check(self._L.fb_fem_set_exchange_mode(self.h, mode))
 
     def close(self):
         if getattr(self, "h", None):

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libfembrain_hip.so")
 
 FB_OK, FB_EINVAL, FB_EDEVICE, FB_ENOMEM, FB_ESOLVER, FB_ECOMM = 0, -1, -2, -3, -4, -5
 FB_MATRIX_F32, FB_MATRIX_F64 = 0, 1
+FB_XCH_COLLECTIVE, FB_XCH_P2P, FB_XCH_P2P_SUMS, FB_XCH_P2P_FUSED = 1, 2, 3, 4
 FB_PCG_MERGED, FB_PCG_REFERENCE, FB_PCG_FUSED = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
@@ -116,6 +117,7 @@ def lib():
     }
     poly_sig = {
         "fb_fem_transport": (C.c_int, [vp]),
+        "fb_fem_set_exchange_mode": (C.c_int, [vp, C.c_int]),
         "fb_fem_time_exchange": (C.c_int, [vp, C.c_int, _dp, _dp]),
         "fb_poly_create": (C.c_int, [C.POINTER(vp), C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp]),
         "fb_poly_destroy": (C.c_int, [vp]),

@@ -83,11 +83,20 @@ int fb_fem_create_sharded(fb_fem_t* out, int n_nodes, const double* xyz, int n_t
                           int n_fixed_dofs, const int* fixed_dofs, const fb_fem_params* params,
                           int n_ranks, int rank, const int* node_splits, fb_comm_t comm);
 int fb_fem_destroy(fb_fem_t h);
-/* how a sharded handle exchanges halo values and PCG sums: 0 = unsharded (no exchange), 1 = collective library
- * (RCCL all-reduce + send/recv; or the host-staged test communicator), 2 = direct peer-to-peer mailboxes over xGMI
- * (HIP IPC mapped inboxes written by kernels; chosen at create time when every rank can map every peer, environment
- * FEMBRAIN_P2P=0 forces 1) */
+/* How a sharded handle runs the two exchanges of a PCG iteration (halo refresh of the search direction, 3-scalar sum):
+ *   FB_XCH_COLLECTIVE  RCCL all-reduce + send/recv (or the host-staged test communicator)
+ *   FB_XCH_P2P         direct peer-to-peer inboxes over xGMI (HIP IPC), one small kernel per exchange
+ *   FB_XCH_P2P_SUMS    as above, but the sums are posted by the last SpMV block and awaited by the vector pass
+ *   FB_XCH_P2P_FUSED   both exchanges ride inside the two kernels of the iteration (default when every rank could map
+ *                      every peer; FEMBRAIN_P2P=0 keeps the collective library, FEMBRAIN_XCH_MODE=n picks a mode)
+ * All modes give bitwise identical iterates (fixed rank-order sums).  fb_fem_transport: 0 for an unsharded handle, else
+ * the mode in use.  fb_fem_set_exchange_mode is COLLECTIVE: every rank switches between two solves. */
+#define FB_XCH_COLLECTIVE 1
+#define FB_XCH_P2P 2
+#define FB_XCH_P2P_SUMS 3
+#define FB_XCH_P2P_FUSED 4
 int fb_fem_transport(fb_fem_t h);
+int fb_fem_set_exchange_mode(fb_fem_t h, int mode);
 
 /* Rebuild after a topology change (Deformable::syncForceModel after CuttableMesh::cut, main.cpp:614-617):
  * same semantics as destroy + create but keeps the device, parameters and constraints. State is reset. */

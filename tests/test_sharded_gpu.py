@@ -12,10 +12,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, shm_name, n, variant, steps, q, p2p=False, quit_early=False):
+def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False):
+    """p2p: 0 = host-staged test communicator, else the peer-to-peer exchange mode (lib.FB_XCH_P2P / _SUMS / _FUSED)."""
     try:
         if p2p:
             os.environ["FEMBRAIN_P2P"] = "1"
+            os.environ["FEMBRAIN_XCH_MODE"] = str(p2p)
             os.environ["FEMBRAIN_P2P_TIMEOUT_MS"] = "1500" if quit_early else "20000"
         from fembrain_amd import lib as fl
         from fembrain_amd.fem import FemIntegrator
@@ -28,7 +30,7 @@ def _worker(rank, world, shm_name, n, variant, steps, q, p2p=False, quit_early=F
         planes = [n * r // world for r in range(world + 1)]
         splits = np.array([p * n * n for p in planes], np.int32)
         g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), pcg_variant=variant)
-        assert L.fb_fem_transport(g.h) == (2 if p2p else 1), L.fb_fem_transport(g.h)
+        assert L.fb_fem_transport(g.h) == (p2p if p2p else 1), L.fb_fem_transport(g.h)
         if quit_early and rank == world - 1:   # a rank that stops taking part: the others must time out, not hang
             q.put((rank, "left", None, None, 0, 0))
             q.close()
@@ -53,11 +55,12 @@ def _worker(rank, world, shm_name, n, variant, steps, q, p2p=False, quit_early=F
         os._exit(1)
 
 
-@pytest.mark.parametrize("world,variant,p2p", [(2, 0, False), (3, 0, False), (2, 1, False), (4, 2, False),
-                                               (2, 0, True), (4, 0, True), (3, 1, True), (3, 2, True)])
+@pytest.mark.parametrize("world,variant,p2p", [(2, 0, 0), (3, 0, 0), (2, 1, 0), (4, 2, 0),
+                                               (2, 0, 2), (3, 0, 3), (2, 0, 4), (4, 0, 4), (3, 1, 4), (3, 2, 4)])
 def test_sharded_ranks_on_one_gpu_match_the_unsharded_handle(gpu, world, variant, p2p):
-    """p2p=True: the direct mailbox transport (HIP IPC mapped inboxes, kernels that store into the peer's inbox and
-    spin -- bounded -- on their own flags) between processes that share the GPU."""
+    """p2p != 0: the direct inbox transport (HIP IPC mapped inboxes, kernels that store into the peer's inbox and spin --
+    bounded -- on their own flags) between processes that share the GPU, in its three forms: an own kernel per exchange
+    (2), sums inside the PCG kernels (3), sums and halo values inside the PCG kernels (4)."""
     import multiprocessing as mp
     from fembrain_amd.fem import FemIntegrator
     from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
@@ -107,7 +110,7 @@ def test_p2p_wait_is_bounded_when_a_peer_leaves(gpu):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     name = "/fembrain_test_%d_leave" % os.getpid()
-    procs = [ctx.Process(target=_worker, args=(r, 2, name, 8, 0, 1, q, True, True)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, name, 8, 0, 1, q, 4, True)) for r in range(2)]
     t0 = time.time()
     for p in procs:
         p.start()

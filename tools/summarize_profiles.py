@@ -43,7 +43,7 @@ with open("profiles/%s_pmc_summary.csv" % tag, "w") as fh:
     wr = csv.DictWriter(fh, fieldnames=list(out[0].keys()))
     wr.writeheader()
     wr.writerows(out)
-sp = [r for r in out if r["kernel"] == "k_spmv<float, 3>"][0]
+sp = [r for r in out if r["kernel"].replace(" ", "").startswith("k_spmv<float,3")][0]
 hbm = (2 * sp["FETCH_SIZE_KB_median"] + sp["WRITE_SIZE_KB_median"]) * 1024
 json.dump({"kernel": "fb::k_spmv<float,3> (PCG SpMV with the merged sums)", "workload": "cube56 (998,250 tets), f32 matrix",
            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/probe_fem.py 56 1; per-launch medians over %d launches" % sp["launches"],
