@@ -172,7 +172,10 @@ def main():
     if dist_mode and g.transport() >= fl.FB_XCH_P2P and os.environ.get("FEMBRAIN_XCH_MODE") is None:
         names = {fl.FB_XCH_COLLECTIVE: "collective", fl.FB_XCH_P2P: "p2p", fl.FB_XCH_P2P_SUMS: "p2p_sums", fl.FB_XCH_P2P_FUSED: "p2p_fused"}
         one_step()
-        for mode in (fl.FB_XCH_P2P, fl.FB_XCH_P2P_SUMS, fl.FB_XCH_P2P_FUSED):
+        modes = (fl.FB_XCH_P2P, fl.FB_XCH_P2P_SUMS, fl.FB_XCH_P2P_FUSED)
+        if not local_comm and os.environ.get("FEMBRAIN_BENCH_SKIP_RCCL") != "1":
+            modes = (fl.FB_XCH_COLLECTIVE,) + modes   # the collective library, for the record
+        for mode in modes:
             g.set_exchange_mode(mode)
             barrier()
             ts = time.perf_counter()
