@@ -33,28 +33,48 @@ WORKLOADS = {
 
 
 def cpu_baseline(n, cg_iterations, sample_iters=40):
-    """Oracle (our fp64 CSR restatement of the reference path, 1 core) on the same workload: one full assembly +
-    system build and `sample_iters` PCG iterations are timed; the step time is extrapolated with the GPU-measured
-    iteration count."""
-    from oracle.pyoracle import OrcFem
+    """The reference's CPU path on the same workload, 1 core (it is serial: Deformable.cpp:182).  When the reference build
+    oracle/_ref/libfem_ref.so travelled with the snapshot ("reference": the reference's own CorotationalLinearFEM,
+    SparseMatrix and CGSolver objects driven through its step sequence) it is timed, otherwise the plain-C restatement
+    oracle/fem_oracle.c ("port").  Bounded sample: one step cut off after 1 PCG iteration and one cut off after
+    1 + sample_iters; the difference prices an iteration, the rest is assembly + system algebra; the step time is
+    extrapolated with the iteration count the GPU run needed.  Set-up is not timed."""
+    from oracle import pyoracle
     from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
     v, t = truth_cube(n, n, n, 0.1)
     fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
-    o = OrcFem(v, t)
-    o.integrator(fixed)
-    f = np.zeros(o.r)
-    f[1::3] = -10000.0
-    o.set_external_forces(f)
-    t0 = time.perf_counter()
-    o.step_prepare()  # assembly + Keff/rhs algebra + constrained system
-    t_asm = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    it = abs(o.pcg_bounded(1e-30, sample_iters))
-    t_it = (time.perf_counter() - t0) / max(it, 1)
+
+    def sample(cls):
+        o = cls(v, t)
+        o.integrator(fixed)
+        f = np.zeros(o.r)
+        f[1::3] = -10000.0
+        o.set_external_forces(f)
+        t0 = time.perf_counter()
+        o.step(cg_maxiter=1)
+        t1 = time.perf_counter()
+        o.step(cg_maxiter=1 + sample_iters)
+        t2 = time.perf_counter()
+        o.close()
+        t_it = max(((t2 - t1) - (t1 - t0)) / sample_iters, 1e-9)
+        t_asm = max((t1 - t0) - t_it, 0.0)
+        return t_asm, t_it
+
+    kind, cls = "port", pyoracle.OrcFem
+    if os.environ.get("FEMBRAIN_BENCH_CPU_KIND") != "port":
+        try:
+            pyoracle._load("ref")
+            kind, cls = "reference", pyoracle.RefFem
+        except Exception:
+            pass
+    t_asm, t_it = sample(cls)
     step_s = t_asm + cg_iterations * t_it
-    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": 1, "kind": "port",
-            "sample": "oracle/fem_oracle.c on the same mesh: 1 assembly+system build (%.2f s) + %d PCG iterations (%.2f ms each), "
-                      "extrapolated to the %d iterations the GPU run needed" % (t_asm, it, t_it * 1e3, cg_iterations)}
+    what = ("oracle/_ref/libfem_ref.so = the reference's VegaFEM translation units (CorotationalLinearFEM, SparseMatrix, CGSolver) built "
+            "from /root/reference by oracle/Makefile, driven through VolumeConservingIntegrator's step sequence") if kind == "reference" \
+        else "oracle/fem_oracle.c (plain-C restatement)"
+    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": 1, "kind": kind,
+            "sample": "%s on the same mesh: assembly + system algebra %.2f s, %d PCG iterations at %.2f ms each, extrapolated to the %d "
+                      "iterations per step of the GPU run; set-up excluded" % (what, t_asm, sample_iters, t_it * 1e3, cg_iterations)}
 
 
 def field_bench(device, cpu=True):
