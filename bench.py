@@ -87,9 +87,13 @@ def field_bench(device, cpu=True):
     c = p.classify()
     p.tetrahedralize()
     sweep_s, pipe_s = p.time_pipeline(10)
+    p.surface()
+    surf_s = p.time_surface(10)
     npts = dims[0] * dims[1] * dims[2]
     out = {"field_mvoxels_per_s": npts / pipe_s / 1e6, "field_sweep_mvoxels_per_s": npts / sweep_s / 1e6, "field_grid": list(dims),
            "field_sweep_gbs": npts * 16 / sweep_s / 1e9, "field_pipeline_us": pipe_s * 1e6, "field_tets": int(p.counts.n_tets),
+           "field_surface_us": surf_s * 1e6, "field_surface_vertices": int(p.counts.n_surface_vertices),
+           "field_surface_triangles": int(p.counts.n_surface_indices) // 3,
            "field_pipeline": "sweep (float4 per point) + edge/cell classification + scans + tet-mesh vertices and 6 tets per included cell"}
     if cpu:
         # bounded CPU sample: the oracle's scalar sweep + classification + tet emission on a 256x256x24 slab through the

@@ -401,8 +401,25 @@ __device__ inline unsigned int block_excl_scan256(unsigned int v, unsigned int* 
   return woff + incl - v;
 }
 
-__global__ __launch_bounds__(kPB) void k_chunk_sums(const unsigned int* __restrict__ in, const unsigned int* __restrict__ aux, int n,
-                                                    unsigned int* __restrict__ sums, unsigned int* __restrict__ aux_sums) {
+// two independent scans share every launch: blockIdx.y picks the job
+struct ScanJob {
+  const unsigned int* in;    // per-word counts
+  const unsigned int* aux;   // optional packed pair of counters (low 16 / high 16 bits), only summed
+  unsigned int* sums;        // per-chunk sums, scanned in place
+  unsigned int* aux_sums;    // 2 per chunk
+  unsigned int* out;         // exclusive scan of `in`
+  unsigned int* total;       // grand total of `in`
+  unsigned int* aux_total;   // 2 grand totals of the packed counters
+};
+struct ScanJobs {
+  ScanJob j[2];
+};
+
+__global__ __launch_bounds__(kPB) void k_chunk_sums(ScanJobs jobs, int n) {
+  const unsigned int* __restrict__ in = jobs.j[blockIdx.y].in;
+  const unsigned int* __restrict__ aux = jobs.j[blockIdx.y].aux;
+  unsigned int* __restrict__ sums = jobs.j[blockIdx.y].sums;
+  unsigned int* __restrict__ aux_sums = jobs.j[blockIdx.y].aux_sums;
   __shared__ unsigned int sh[4];
   const int base = blockIdx.x * kChunk;
   unsigned int a = 0, b = 0, c = 0;
@@ -424,8 +441,11 @@ __global__ __launch_bounds__(kPB) void k_chunk_sums(const unsigned int* __restri
 }
 
 // one block: exclusive scan of up to 16*kPB chunk sums in place; totals out
-__global__ __launch_bounds__(kPB) void k_scan_chunks(unsigned int* __restrict__ sums, const unsigned int* __restrict__ aux_sums, int nchunks,
-                                                     unsigned int* __restrict__ total_out, unsigned int* __restrict__ aux_total_out) {
+__global__ __launch_bounds__(kPB) void k_scan_chunks(ScanJobs jobs, int nchunks) {
+  unsigned int* __restrict__ sums = jobs.j[blockIdx.x].sums;
+  const unsigned int* __restrict__ aux_sums = jobs.j[blockIdx.x].aux ? jobs.j[blockIdx.x].aux_sums : nullptr;
+  unsigned int* __restrict__ total_out = jobs.j[blockIdx.x].total;
+  unsigned int* __restrict__ aux_total_out = jobs.j[blockIdx.x].aux_total;
   // aux_sums: two counters per chunk (may be null); aux_total_out[0], [1] receive their totals
   __shared__ unsigned int sh[4];
   unsigned int carry = 0, aux = 0, aux2 = 0;
@@ -448,8 +468,10 @@ __global__ __launch_bounds__(kPB) void k_scan_chunks(unsigned int* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(kPB) void k_chunk_scan(const unsigned int* __restrict__ in, int n, const unsigned int* __restrict__ chunk_base,
-                                                    unsigned int* __restrict__ out) {
+__global__ __launch_bounds__(kPB) void k_chunk_scan(ScanJobs jobs, int n) {
+  const unsigned int* __restrict__ in = jobs.j[blockIdx.y].in;
+  const unsigned int* __restrict__ chunk_base = jobs.j[blockIdx.y].sums;
+  unsigned int* __restrict__ out = jobs.j[blockIdx.y].out;
   __shared__ unsigned int sh[4];
   const int base = blockIdx.x * kChunk + threadIdx.x * (kChunk / kPB);  // 16 consecutive words per thread
   unsigned int v[kChunk / kPB], s = 0;
@@ -663,116 +685,115 @@ __global__ __launch_bounds__(kPB) void k_surface_pops(Grid G, long long nwords, 
   edge_pop[w] = aux_pop[w] & 0xFFFFu;
 }
 
-// first surface-vertex id of grid point q (exclusive scan of the per-point edge counts, OclPolygonizer.cpp:663-675)
-__device__ __forceinline__ unsigned int edge_offset(long long q, const unsigned long long* __restrict__ crossx, const unsigned long long* __restrict__ crossy,
-                                                    const unsigned long long* __restrict__ crossz, const unsigned int* __restrict__ ebase) {
-  const long long w = q >> 6;
-  const unsigned long long low = (1ULL << (q & 63)) - 1ULL;
-  return ebase[w] + (unsigned int)(__popcll(crossx[w] & low) + __popcll(crossy[w] & low) + __popcll(crossz[w] & low));
+// Work lists for the two emission kernels, one thread per 64-point word (after the scans): every crossed edge of the word
+// in output order (point-major, X Y Z) -> elist[first vertex id of the word + r] = point << 2 | axis, and every triangle
+// of every surface cell -> tlist[first triangle id of the word + r] = (lower-corner point, config | local triangle << 8).
+// Crossings are sparse and clustered (a sphere crosses a 64-point word of a grid row once or twice), so emission is
+// balanced by giving every vertex and every triangle its own lane instead of every word its own wavefront.
+__global__ __launch_bounds__(kPB) void k_surface_lists(Grid G, long long nwords, const unsigned long long* __restrict__ inside,
+                                                       const unsigned long long* __restrict__ surf, const unsigned long long* __restrict__ crossx,
+                                                       const unsigned long long* __restrict__ crossy, const unsigned long long* __restrict__ crossz,
+                                                       const unsigned int* __restrict__ ebase, const unsigned int* __restrict__ ibase,
+                                                       const unsigned char* __restrict__ nvert, unsigned long long* __restrict__ elist,
+                                                       uint2* __restrict__ tlist) {
+  const long long w = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (w >= nwords) return;
+  const unsigned long long mx = crossx[w], my = crossy[w], mz = crossz[w];
+  unsigned long long m = mx | my | mz;
+  if (m) {
+    unsigned long long* e = elist + ebase[w];
+    while (m) {
+      const int b = __builtin_ctzll(m);
+      m &= m - 1;
+      const unsigned long long p4 = (unsigned long long)(w * 64 + b) << 2;
+      if ((mx >> b) & 1ULL) *e++ = p4;
+      if ((my >> b) & 1ULL) *e++ = p4 | 1ULL;
+      if ((mz >> b) & 1ULL) *e++ = p4 | 2ULL;
+    }
+  }
+  unsigned long long sm = surf[w];
+  if (sm) {
+    const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
+    const unsigned long long c0 = inside[w];
+    const unsigned long long cx = fwd_word(inside, nwords, w, 1), cy = fwd_word(inside, nwords, w, gx), cz = fwd_word(inside, nwords, w, gxy);
+    const unsigned long long cxy = fwd_word(inside, nwords, w, gx + 1), cxz = fwd_word(inside, nwords, w, gxy + 1),
+                             cyz = fwd_word(inside, nwords, w, gxy + gx), cxyz = fwd_word(inside, nwords, w, gxy + gx + 1);
+    uint2* t = tlist + ibase[w] / 3;
+    while (sm) {
+      const int b = __builtin_ctzll(sm);
+      sm &= sm - 1;
+      const int cfg = cfg_from_words(b, c0, cz, cy, cyz, cx, cxz, cxy, cxyz);
+      const int ntri = nvert[cfg] / 3;
+      for (int k = 0; k < ntri; k++) *t++ = make_uint2((unsigned int)(w * 64 + b), (unsigned int)(cfg | (k << 8)));
+    }
+  }
 }
 
-// ComputeVertexAttribs (Polygonizer.cl:1429-1561, linear root): one wavefront per 64-point word.  The word's crossed
-// edges are listed in LDS in output order (point-major, X Y Z) and then dealt to the lanes round-robin, so the four
-// field evaluations per vertex are spread over all 64 lanes however the crossings cluster.
-__global__ __launch_bounds__(kPB) void k_surface_vertices(Grid G, const Instr* __restrict__ prog, int n_instr, int n_prims,
+// ComputeVertexAttribs (Polygonizer.cl:1429-1561, linear root), one lane per surface vertex: the 4 field evaluations
+// per vertex (root + forward-difference normal) are spread over full wavefronts and all stores are contiguous.
+__global__ __launch_bounds__(kPB) void k_surface_vertices(Grid G, long long nv, const unsigned long long* __restrict__ elist,
+                                                          const Instr* __restrict__ prog, int n_instr, int n_prims,
                                                           const float* __restrict__ prims, const float* __restrict__ mtx,
-                                                          const float4* __restrict__ grid, const unsigned long long* __restrict__ crossx,
-                                                          const unsigned long long* __restrict__ crossy, const unsigned long long* __restrict__ crossz,
-                                                          const unsigned int* __restrict__ ebase, const unsigned long long* __restrict__ vinc,
+                                                          const float4* __restrict__ grid, const unsigned long long* __restrict__ vinc,
                                                           const unsigned int* __restrict__ vbase, float* __restrict__ pos, float* __restrict__ nrm,
                                                           uint2* __restrict__ ends, float* __restrict__ frac) {
   extern __shared__ float stack[];
-  __shared__ unsigned char list[kPB / 64][192];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long long nwords = (G.n_points + 63) >> 6;
-  const long long nwaves = (long long)gridDim.x * (kPB / 64);
-  const long long stride[3] = {1, G.g[0], (long long)G.g[0] * G.g[1]};
+  const long long j = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (j >= nv) return;
   const float delta = 0.0001f, dinv = 1.0f / 0.0001f;  // NORMAL_DELTA, Polygonizer.cl
-  for (long long word = (long long)blockIdx.x * (kPB / 64) + wv; word < nwords; word += nwaves) {  // wave-uniform
-    const unsigned long long mx = crossx[word], my = crossy[word], mz = crossz[word];
-    if ((mx | my | mz) == 0ULL) continue;
-    const unsigned long long low = (1ULL << lane) - 1ULL;
-    int r = __popcll(mx & low) + __popcll(my & low) + __popcll(mz & low);
-    if ((mx >> lane) & 1ULL) list[wv][r++] = (unsigned char)(lane << 2);
-    if ((my >> lane) & 1ULL) list[wv][r++] = (unsigned char)((lane << 2) | 1);
-    if ((mz >> lane) & 1ULL) list[wv][r++] = (unsigned char)((lane << 2) | 2);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int total = __popcll(mx) + __popcll(my) + __popcll(mz);
-    const size_t first = ebase[word];
-    for (int j = lane; j < total; j += 64) {
-      const int ent = list[wv][j];
-      const long long p = word * 64 + (ent >> 2);
-      const float4 va = grid[p], vb = grid[p + stride[ent & 3]];
-      const float t = (kIso - va.w) / (vb.w - va.w);
-      const float x = va.x + t * (vb.x - va.x), y = va.y + t * (vb.y - va.y), z = va.z + t * (vb.z - va.z);
-      float* stk = stack + threadIdx.x;
-      const float f = eval_field(prog, n_instr, n_prims, prims, mtx, x, y, z, stk);
-      float gx = eval_field(prog, n_instr, n_prims, prims, mtx, x + delta, y, z, stk);
-      float gy = eval_field(prog, n_instr, n_prims, prims, mtx, x, y + delta, z, stk);
-      float gz = eval_field(prog, n_instr, n_prims, prims, mtx, x, y, z + delta, stk);
-      gx = -1.0f * (dinv * (gx - f)); gy = -1.0f * (dinv * (gy - f)); gz = -1.0f * (dinv * (gz - f));
-      const float len = sqrtf(gx * gx + gy * gy + gz * gz);
-      float* o = pos + 3 * (first + j);
-      o[0] = x; o[1] = y; o[2] = z;
-      o = nrm + 3 * (first + j);
-      o[0] = gx / len; o[1] = gy / len; o[2] = gz / len;
-      // the two grid points of the edge are vertices of the tet mesh of the same grid (a crossed edge belongs to a cell
-      // with config != 0): remember their tet-mesh ids and the interpolation weight for fb_poly_interpolate_displacements
-      ends[first + j] = make_uint2(rank_of(vinc, vbase, p), rank_of(vinc, vbase, p + stride[ent & 3]));
-      frac[first + j] = t;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  }
+  const unsigned long long ent = elist[j];
+  const long long p = (long long)(ent >> 2);
+  const int axis = (int)(ent & 3ULL);
+  const long long nb = p + (axis == 0 ? 1LL : (axis == 1 ? (long long)G.g[0] : (long long)G.g[0] * G.g[1]));
+  const float4 va = grid[p], vb = grid[nb];
+  const float t = (kIso - va.w) / (vb.w - va.w);
+  const float x = va.x + t * (vb.x - va.x), y = va.y + t * (vb.y - va.y), z = va.z + t * (vb.z - va.z);
+  float* stk = stack + threadIdx.x;
+  const float f = eval_field(prog, n_instr, n_prims, prims, mtx, x, y, z, stk);
+  float gx = eval_field(prog, n_instr, n_prims, prims, mtx, x + delta, y, z, stk);
+  float gy = eval_field(prog, n_instr, n_prims, prims, mtx, x, y + delta, z, stk);
+  float gz = eval_field(prog, n_instr, n_prims, prims, mtx, x, y, z + delta, stk);
+  gx = -1.0f * (dinv * (gx - f)); gy = -1.0f * (dinv * (gy - f)); gz = -1.0f * (dinv * (gz - f));
+  const float len = sqrtf(gx * gx + gy * gy + gz * gz);
+  float* o = pos + 3 * (size_t)j;
+  o[0] = x; o[1] = y; o[2] = z;
+  o = nrm + 3 * (size_t)j;
+  o[0] = gx / len; o[1] = gy / len; o[2] = gz / len;
+  // the two grid points of the edge are vertices of the tet mesh of the same grid (a crossed edge belongs to a cell
+  // with config != 0): remember their tet-mesh ids and the interpolation weight for fb_poly_interpolate_displacements
+  ends[j] = make_uint2(rank_of(vinc, vbase, p), rank_of(vinc, vbase, nb));
+  frac[j] = t;
 }
 
-// ComputeElements (Polygonizer.cl:1610-1670): one wavefront per word of the surface-cell mask; every lane stages its
-// cell's <= 15 indices in LDS behind the lanes before it and the wave streams the range out contiguously.
-__global__ __launch_bounds__(kPB) void k_surface_elements(Grid G, const unsigned long long* __restrict__ inside,
-                                                          const unsigned long long* __restrict__ surf, const unsigned int* __restrict__ ibase,
+// ComputeElements (Polygonizer.cl:1610-1670), one lane per triangle: three table entries, each resolved to the vertex id
+// of its grid edge = first id of the edge's lower grid point (exclusive scan of the edge counts, as rank of the point in
+// the three crossing masks) + X before Y before Z on that point.
+__global__ __launch_bounds__(kPB) void k_surface_elements(Grid G, long long ntri, const uint2* __restrict__ tlist,
                                                           const unsigned long long* __restrict__ crossx, const unsigned long long* __restrict__ crossy,
                                                           const unsigned long long* __restrict__ crossz, const unsigned int* __restrict__ ebase,
-                                                          const unsigned char* __restrict__ tri, const unsigned char* __restrict__ nvert,
-                                                          const unsigned char* __restrict__ edge_info, unsigned int* __restrict__ indices) {
-  __shared__ unsigned int stage[kPB / 64][64 * 15];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long long nwords = (G.n_points + 63) >> 6;
-  const long long nwaves = (long long)gridDim.x * (kPB / 64);
+                                                          const unsigned char* __restrict__ tri, const unsigned char* __restrict__ edge_info,
+                                                          unsigned int* __restrict__ indices) {
+  const long long t = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (t >= ntri) return;
+  const uint2 rec = tlist[t];
   const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
-  for (long long word = (long long)blockIdx.x * (kPB / 64) + wv; word < nwords; word += nwaves) {  // wave-uniform
-    const unsigned long long mask = surf[word];
-    if (mask == 0ULL) continue;
-    const bool on = (mask >> lane) & 1ULL;
-    const long long p = word * 64 + lane;
-    int cfg = 0, cnt = 0;
-    if (on) {
-      cfg = bit_at(inside, p) | (bit_at(inside, p + gxy) << 1) | (bit_at(inside, p + gx) << 2) | (bit_at(inside, p + gx + gxy) << 3) |
-            (bit_at(inside, p + 1) << 4) | (bit_at(inside, p + 1 + gxy) << 5) | (bit_at(inside, p + 1 + gx) << 6) | (bit_at(inside, p + 1 + gx + gxy) << 7);
-      cnt = nvert[cfg];
-    }
-    int incl = cnt;
+  const unsigned char* row = tri + 16 * (int)(rec.y & 255u) + 3 * (int)(rec.y >> 8);
+  unsigned int id[3];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
-    }
-    const int total = __shfl(incl, 63, 64);
-    unsigned int* o = &stage[wv][incl - cnt];
-    for (int i = 0; i < cnt; i++) {
-      const int info = edge_info[tri[16 * cfg + i]];
-      const int c = info & 7, axis = info >> 4;
-      const long long q = p + ((c >> 2) & 1) + ((c >> 1) & 1) * gx + (c & 1) * gxy;
-      const unsigned int hasx = (unsigned int)bit_at(crossx, q), hasy = (unsigned int)bit_at(crossy, q);
-      o[i] = edge_offset(q, crossx, crossy, crossz, ebase) + (axis == 0 ? 0u : (axis == 1 ? hasx : hasx + hasy));
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    unsigned int* out = indices + (size_t)ibase[word];
-    for (int i = lane; i < total; i += 64) out[i] = stage[wv][i];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int k = 0; k < 3; k++) {
+    const int info = edge_info[row[k]];
+    const int corner = info & 7, axis = info >> 4;
+    const long long q = (long long)rec.x + ((corner >> 2) & 1) + ((corner >> 1) & 1) * gx + (corner & 1) * gxy;
+    const long long qw = q >> 6;
+    const unsigned long long bit = 1ULL << (q & 63), low = bit - 1ULL;
+    const unsigned long long cx = crossx[qw], cy = crossy[qw], cz = crossz[qw];
+    unsigned int v = ebase[qw] + (unsigned int)(__popcll(cx & low) + __popcll(cy & low) + __popcll(cz & low));
+    if (axis >= 1) v += (cx & bit) ? 1u : 0u;
+    if (axis == 2) v += (cy & bit) ? 1u : 0u;
+    id[k] = v;
   }
+  unsigned int* o = indices + 3 * (size_t)t;
+  o[0] = id[0]; o[1] = id[1]; o[2] = id[2];
 }
 
 // surface vertex = rest + da + t (db - da): the FEM displacements of the two tet-mesh nodes of its grid edge, weighted as
@@ -822,7 +843,8 @@ struct fb_poly_s {
   DevBuf<unsigned long long> surf;
   DevBuf<unsigned int> edge_pop, idx_pop, ebase, ibase, esum, isum;
   DevBuf<float> sv, sn, deformed, sfrac;
-  DevBuf<uint2> sends;
+  DevBuf<uint2> sends, tlist;
+  DevBuf<unsigned long long> elist;
   DevBuf<unsigned int> si;
   DevBuf<double> disp;
   fb_poly_counts counts;
@@ -1077,16 +1099,15 @@ int do_classify(fb_poly_s* h) {
   hipLaunchKernelGGL(k_classify_bits, dim3(wb), dim3(kPB), 0, h->stream, G, pw, h->inside.p, h->lastx.p, h->lasty.p, h->lastz.p, h->valid.p, h->cinc.p,
                      h->crossx.p, h->crossy.p, h->crossz.p, h->cinc_pop.p, h->aux_pop.p);
   hipLaunchKernelGGL(k_vertex_bits, dim3(wb), dim3(kPB), 0, h->stream, G, pw, h->cinc.p, h->vinc.p, h->vinc_pop.p);
-  hipLaunchKernelGGL(k_chunk_sums, dim3(pch), dim3(kPB), 0, h->stream, h->cinc_pop.p, h->aux_pop.p, (int)pw, h->csum.p, h->csum_aux.p);
-  hipLaunchKernelGGL(k_chunk_sums, dim3(pch), dim3(kPB), 0, h->stream, h->vinc_pop.p, (const unsigned int*)nullptr, (int)pw, h->vsum.p, h->csum_aux.p);
   // totals: [0] crossed edges, [1] surface cells (the two packed counters), [2] included cells, [3] tet vertices
-  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kPB), 0, h->stream, h->csum.p, h->csum_aux.p, pch, h->totals.p + 2, h->totals.p + 0);
-  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kPB), 0, h->stream, h->vsum.p, (const unsigned int*)nullptr, pch, h->totals.p + 3, h->totals.p + 0);
-  hipLaunchKernelGGL(k_chunk_scan, dim3(pch), dim3(kPB), 0, h->stream, h->cinc_pop.p, (int)pw, h->csum.p, h->cbase.p);
-  hipLaunchKernelGGL(k_chunk_scan, dim3(pch), dim3(kPB), 0, h->stream, h->vinc_pop.p, (int)pw, h->vsum.p, h->vbase.p);
+  ScanJobs jobs;
+  jobs.j[0] = ScanJob{h->cinc_pop.p, h->aux_pop.p, h->csum.p, h->csum_aux.p, h->cbase.p, h->totals.p + 2, h->totals.p + 0};
+  jobs.j[1] = ScanJob{h->vinc_pop.p, nullptr, h->vsum.p, nullptr, h->vbase.p, h->totals.p + 3, nullptr};
+  hipLaunchKernelGGL(k_chunk_sums, dim3(pch, 2), dim3(kPB), 0, h->stream, jobs, (int)pw);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(2), dim3(kPB), 0, h->stream, jobs, pch);
+  hipLaunchKernelGGL(k_chunk_scan, dim3(pch, 2), dim3(kPB), 0, h->stream, jobs, (int)pw);
   FB_HIP(hipGetLastError());
   h->materialized = false;
-  h->surfaced = false;
   return FB_OK;
 }
 
@@ -1119,15 +1140,14 @@ int do_surface_counts(fb_poly_s* h) {
   const Grid& G = h->G;
   const long long pw = (long long)h->vinc_pop.n;
   const int wb = (int)((pw + kPB - 1) / kPB), pch = (int)h->vsum.n;
-  const unsigned int* none = nullptr;
   hipLaunchKernelGGL(k_surface_pops, dim3(wb), dim3(kPB), 0, h->stream, G, pw, h->inside.p, h->lastx.p, h->lasty.p, h->lastz.p, h->valid.p, h->aux_pop.p,
                      h->d_nvert.p, h->surf.p, h->edge_pop.p, h->idx_pop.p);
-  hipLaunchKernelGGL(k_chunk_sums, dim3(pch), dim3(kPB), 0, h->stream, h->edge_pop.p, none, (int)pw, h->esum.p, h->csum_aux.p);
-  hipLaunchKernelGGL(k_chunk_sums, dim3(pch), dim3(kPB), 0, h->stream, h->idx_pop.p, none, (int)pw, h->isum.p, h->csum_aux.p);
-  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kPB), 0, h->stream, h->esum.p, none, pch, h->totals.p + 4, h->totals.p + 0);
-  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kPB), 0, h->stream, h->isum.p, none, pch, h->totals.p + 5, h->totals.p + 0);
-  hipLaunchKernelGGL(k_chunk_scan, dim3(pch), dim3(kPB), 0, h->stream, h->edge_pop.p, (int)pw, h->esum.p, h->ebase.p);
-  hipLaunchKernelGGL(k_chunk_scan, dim3(pch), dim3(kPB), 0, h->stream, h->idx_pop.p, (int)pw, h->isum.p, h->ibase.p);
+  ScanJobs jobs;
+  jobs.j[0] = ScanJob{h->edge_pop.p, nullptr, h->esum.p, nullptr, h->ebase.p, h->totals.p + 4, nullptr};
+  jobs.j[1] = ScanJob{h->idx_pop.p, nullptr, h->isum.p, nullptr, h->ibase.p, h->totals.p + 5, nullptr};
+  hipLaunchKernelGGL(k_chunk_sums, dim3(pch, 2), dim3(kPB), 0, h->stream, jobs, (int)pw);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(2), dim3(kPB), 0, h->stream, jobs, pch);
+  hipLaunchKernelGGL(k_chunk_scan, dim3(pch, 2), dim3(kPB), 0, h->stream, jobs, (int)pw);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -1135,13 +1155,21 @@ int do_surface_counts(fb_poly_s* h) {
 int do_surface_emit(fb_poly_s* h) {
   const Grid& G = h->G;
   const long long pw = (long long)h->vinc_pop.n;
-  const int blocks = (int)std::min<long long>((pw + kPB / 64 - 1) / (kPB / 64), 8192);
-  hipLaunchKernelGGL(k_surface_vertices, dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, h->d_prog.p, (int)h->prog.size(), h->n_prims, h->d_prims.p,
-                     h->d_mtx.p, h->grid.p, h->crossx.p, h->crossy.p, h->crossz.p, h->ebase.p, h->vinc.p, h->vbase.p, h->sv.p, h->sn.p, h->sends.p, h->sfrac.p);
+  const long long nv = h->counts.n_surface_vertices, ntri = h->counts.n_surface_indices / 3;
+  if (nv == 0 && ntri == 0) return FB_OK;
+  hipLaunchKernelGGL(k_surface_lists, dim3((int)((pw + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, G, pw, h->inside.p, h->surf.p, h->crossx.p, h->crossy.p,
+                     h->crossz.p, h->ebase.p, h->ibase.p, h->d_nvert.p, h->elist.p, h->tlist.p);
   FB_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_surface_elements, dim3(blocks), dim3(kPB), 0, h->stream, G, h->inside.p, h->surf.p, h->ibase.p, h->crossx.p, h->crossy.p, h->crossz.p,
-                     h->ebase.p, h->d_tri.p, h->d_nvert.p, h->d_edge_info.p, h->si.p);
-  FB_HIP(hipGetLastError());
+  if (nv > 0) {
+    hipLaunchKernelGGL(k_surface_vertices, dim3((int)((nv + kPB - 1) / kPB)), dim3(kPB), stack_bytes(h), h->stream, G, nv, h->elist.p, h->d_prog.p,
+                       (int)h->prog.size(), h->n_prims, h->d_prims.p, h->d_mtx.p, h->grid.p, h->vinc.p, h->vbase.p, h->sv.p, h->sn.p, h->sends.p, h->sfrac.p);
+    FB_HIP(hipGetLastError());
+  }
+  if (ntri > 0) {
+    hipLaunchKernelGGL(k_surface_elements, dim3((int)((ntri + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, G, ntri, h->tlist.p, h->crossx.p, h->crossy.p,
+                       h->crossz.p, h->ebase.p, h->d_tri.p, h->d_edge_info.p, h->si.p);
+    FB_HIP(hipGetLastError());
+  }
   return FB_OK;
 }
 
@@ -1266,6 +1294,7 @@ int fb_poly_classify(fb_poly_t h, fb_poly_counts* counts) {
   FB_TRY(do_classify(h));
   FB_TRY(fetch_counts(h));
   h->classified = true;
+  h->surfaced = false;
   if (counts) *counts = h->counts;
   return FB_OK;
 }
@@ -1332,6 +1361,8 @@ int fb_poly_surface(fb_poly_t h, fb_poly_counts* counts) {
   FB_TRY(h->si.alloc(std::max<size_t>(1, (size_t)t[1])));
   FB_TRY(h->sends.alloc(std::max<size_t>(1, (size_t)t[0])));
   FB_TRY(h->sfrac.alloc(std::max<size_t>(1, (size_t)t[0])));
+  FB_TRY(h->elist.alloc(std::max<size_t>(1, (size_t)t[0])));
+  FB_TRY(h->tlist.alloc(std::max<size_t>(1, (size_t)t[1] / 3)));
   FB_TRY(do_surface_emit(h));
   FB_HIP(hipStreamSynchronize(h->stream));
   h->surfaced = true;
@@ -1363,6 +1394,22 @@ int fb_poly_apply_displacements(fb_poly_t h, int mesh, int n_dof, const double* 
   FB_HIP(hipGetLastError());
   if (xyz_out) return h->deformed.download(xyz_out, (size_t)n, h->stream);
   FB_HIP(hipStreamSynchronize(h->stream));
+  return FB_OK;
+}
+
+int fb_poly_time_surface(fb_poly_t h, int reps, double* seconds) {
+  CHECK_POLY(h);
+  if (!h->surfaced || reps < 1 || !seconds) return fail(FB_EINVAL, "run fb_poly_surface once first");
+  FB_HIP(hipEventRecord(h->ev[0], h->stream));
+  for (int r = 0; r < reps; r++) {
+    FB_TRY(do_surface_counts(h));
+    FB_TRY(do_surface_emit(h));  // same counts as the validated run: grid and tree are unchanged
+  }
+  FB_HIP(hipEventRecord(h->ev[1], h->stream));
+  FB_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0;
+  FB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  *seconds = ms * 1e-3 / reps;
   return FB_OK;
 }
 

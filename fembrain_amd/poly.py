@@ -149,6 +149,11 @@ class GpuPoly:
         _l.check(self._L.fb_poly_read_surface_binding(self.h, _l.uptr(pairs), _l.fptr(w)))
         return pairs, w
 
+    def time_surface(self, reps=5):
+        a = C.c_double(0)
+        _l.check(self._L.fb_poly_time_surface(self.h, reps, C.byref(a)))
+        return a.value
+
     def time_pipeline(self, reps=5):
         a, b = C.c_double(0), C.c_double(0)
         _l.check(self._L.fb_poly_time_pipeline(self.h, reps, C.byref(a), C.byref(b)))

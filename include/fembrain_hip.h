@@ -271,6 +271,8 @@ int fb_poly_interpolate_displacements(fb_poly_t h, int n_tet_dof, const double* 
 /* per surface vertex: the pair (a, b) of tet-mesh vertex ids and the weight t (either may be NULL) */
 int fb_poly_read_surface_binding(fb_poly_t h, unsigned int* tet_vertex_pairs, float* weights);
 
+/* average device seconds of the surface pass (counts + scans + vertex attributes + elements) on the current grid */
+int fb_poly_time_surface(fb_poly_t h, int reps, double* seconds);
 /* average device seconds of one sweep / one classify+tetrahedralize pipeline on the current grid */
 int fb_poly_time_pipeline(fb_poly_t h, int reps, double* sweep_seconds, double* pipeline_seconds);
 
