@@ -232,6 +232,12 @@ def main():
     spmv_bytes = g.spmv_bytes()
     asm_k_s = g.time_assembly(10)
     halo_s, sum_s = g.time_exchange(200) if dist_mode else (0.0, 0.0)
+    resync_ms = None
+    if not dist_mode:  # Deformable::syncForceModel after a cut: host plan (pattern, SELL, contribution lists) + upload + rest state
+        ts = time.perf_counter()
+        g.resync(v, t, fixed)
+        torch.cuda.synchronize()
+        resync_ms = (time.perf_counter() - ts) * 1e3
     out = None
     if rank == 0:
         traffic = None
@@ -255,6 +261,7 @@ def main():
                        "cg_eps": 1e-6, "cg_max_iter": 10000},
             "cg_iterations_per_step": float(np.mean(iters)), "assembly_ms_per_step": asm_s / args.steps * 1e3,
             "solve_ms_per_step": solve_s / args.steps * 1e3, "us_per_cg_iteration": solve_s / max(sum(iters), 1) * 1e6,
+            "resync_ms": resync_ms,
             "exchange_us": {"halo_refresh": halo_s * 1e6, "global_sum_3": sum_s * 1e6},
             "assembly_kernels_us": asm_k_s * 1e6, "assembly_gbs": g.assembly_bytes() / asm_k_s / 1e9,
             "roofline": {"kernel": "k_spmv (SELL-64 3x3-block SpMV of the PCG)", "bound": "hbm",
