@@ -46,6 +46,8 @@ struct fb_fem_s {
   // one batch of 30 PCG iterations (29 merged + the exact-residual one) captured once and replayed: the launch sequence
   // and every kernel argument repeat from batch to batch, and on meshes of ~100k tets the host's launch rate, not the
   // device, would otherwise bound the iteration time
+  bool split = false;  // small mesh: SpMV with one slice per block (k_spmv_split)
+  int sgrid = 8;       // blocks (= partial sums) of the SpMV launches; equals grid unless split
   hipGraphExec_t batch_graph = nullptr;
   const double* graph_rhs = nullptr;
   bool use_graph = true;
@@ -97,6 +99,11 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
   const int chunk = ceil_div(P.n_slices, 8);
   const int per = std::max(1, std::min(kMaxPartials / 8, ceil_div(chunk, kWavesPerBlock)));
   h->grid = 8 * per;
+  const int want = h->prm.spmv_kernel;
+  if (want == FB_SPMV_SPLIT && (8 * chunk > kMaxPartials || P.n_ranks > 1))
+    return fail(FB_EINVAL, "split SpMV needs an unsharded mesh of <= %d slices, this one has %d on %d ranks", kMaxPartials, P.n_slices, P.n_ranks);
+  h->split = want == FB_SPMV_SPLIT || (want == 0 && 8 * chunk <= kMaxPartials && P.n_ranks == 1);
+  h->sgrid = h->split ? 8 * chunk : h->grid;
   FB_TRY(h->part_a.alloc(3 * kMaxPartials));
   FB_TRY(h->part_b.alloc(kMaxPartials));
   FB_TRY(h->part_c.alloc(3 * kMaxPartials));
@@ -185,6 +192,12 @@ int assemble_system(fb_fem_s* h) {
 
 template <typename MT, int MODE>
 int launch_spmv(fb_fem_s* h, const double* x, double* y, const double* b, double* partial, int parity) {
+  if (h->split) {
+    hipLaunchKernelGGL((k_spmv_split<MT, MODE>), dim3(h->sgrid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
+                       b, h->invdiag.p, partial, h->st.p, parity);
+    FB_HIP(hipGetLastError());
+    return FB_OK;
+  }
   hipLaunchKernelGGL((k_spmv<MT, MODE>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y, b,
                      h->invdiag.p, partial, h->st.p, parity, P2PArgs());
   FB_HIP(hipGetLastError());
@@ -276,7 +289,7 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b) {
     // merged-reduction iteration: SpMV with the three sums, then one fused vector pass (one reduction / all-reduce)
     FB_TRY(spmv<3>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity));
     FB_TRY(global_scalar(h, h->part_a.p, &sc, true, 3));
-    hipLaunchKernelGGL((k_cg_fused<false, false>), dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->grid,
+    hipLaunchKernelGGL((k_cg_fused<false, false>), dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->sgrid,
                        sc, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->d.p, P2PArgs());
     FB_HIP(hipGetLastError());
     return FB_OK;
@@ -285,18 +298,19 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b) {
   FB_TRY(global_scalar(h, h->part_a.p, &sc, true));
   if (!refresh) {
     hipLaunchKernelGGL(k_cg_update<false>, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity,
-                       h->part_a.p, h->grid, sc, h->d.p, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->part_b.p);
+                       h->part_a.p, h->sgrid, sc, h->d.p, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->part_b.p);
     FB_HIP(hipGetLastError());
   } else {
     hipLaunchKernelGGL(k_cg_update<true>, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity,
-                       h->part_a.p, h->grid, sc, h->d.p, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->part_b.p);
+                       h->part_a.p, h->sgrid, sc, h->d.p, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->part_b.p);
     FB_HIP(hipGetLastError());
     FB_TRY(halo_exchange(h, h->x.p));
     FB_TRY(spmv<2>(h, h->x.p, h->r.p, b, h->part_b.p, parity));
   }
   FB_TRY(global_scalar(h, h->part_b.p, &sc, true));
+  // part_b comes from the exact-residual SpMV on refresh iterations, from the vector kernel otherwise
   hipLaunchKernelGGL(k_cg_direction, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_b.p,
-                     h->grid, sc, h->r.p, h->invdiag.p, h->d.p);
+                     refresh ? h->sgrid : h->grid, sc, h->r.p, h->invdiag.p, h->d.p);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -438,7 +452,7 @@ int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int*
         double* sc2 = nullptr;
         FB_TRY(global_scalar(h, h->part_b.p, &sc2, true, 1, 3));
         hipLaunchKernelGGL(k_rec_refresh, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->rec_s[cur].p, h->rec_s[cur ^ 1].p, h->r.p,
-                           h->part_b.p, h->grid, sc2, h->st.p, k);
+                           h->part_b.p, h->sgrid, sc2, h->st.p, k);
         FB_HIP(hipGetLastError());
         cur ^= 1;
         FB_TRY(halo_exchange(h, h->rec_s[cur].p, 12));

@@ -426,6 +426,91 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
   (void)acc1; (void)acc2;
 }
 
+// Small meshes (<= 1024 slices, ~350k tets): one slice per BLOCK, its slots dealt to the block's four wavefronts.  With
+// fewer slices than the chip has wave slots the row kernel above is bound by the latency of one wavefront walking all
+// ~15 slots of its slice (6.8 us at 105k tets for 13 MB); splitting the walk four ways shortens that chain.  The four
+// partial row sums are added in wave order (deterministic; rounding differs from the row kernel in the last bit).
+template <typename MT, int MODE>
+__global__ __launch_bounds__(kBlock) void k_spmv_split(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo,
+                                                       const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ bvec,
+                                                       const double* __restrict__ invdiag, double* __restrict__ partial,
+                                                       CGState* __restrict__ st, int parity) {
+  __shared__ double ylds[kWavesPerBlock][3][64];
+  if (MODE != 0 && st->done) return;
+  if (MODE == 1 || MODE == 3) {
+    if (!(st->rho[parity] > st->eps2 * st->rho0) || st->iter >= st->max_iter) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) st->done = 1;
+      return;
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int xcd = blockIdx.x & 7, chunk = (sv.n_slices + 7) >> 3;
+  const int s = xcd * chunk + (blockIdx.x >> 3);
+  const bool live = (int)(blockIdx.x >> 3) < chunk && s < sv.n_slices;  // block-uniform
+  double y0 = 0, y1 = 0, y2 = 0;
+  if (live) {
+    const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
+    const MT* v = vals + (size_t)so * 9 * 64 + lane;
+    const int* ci = sv.colidx + (size_t)so * 64 + lane;
+#pragma unroll 4
+    for (int k = wv; k < width; k += kWavesPerBlock) {
+      const int col = ci[(size_t)k * 64];
+      const double* xp = x + 3 * (size_t)col;
+      const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
+      const MT* vk = v + (size_t)k * 9 * 64;
+      y0 += (double)vk[0 * 64] * x0 + (double)vk[1 * 64] * x1 + (double)vk[2 * 64] * x2;
+      y1 += (double)vk[3 * 64] * x0 + (double)vk[4 * 64] * x1 + (double)vk[5 * 64] * x2;
+      y2 += (double)vk[6 * 64] * x0 + (double)vk[7 * 64] * x1 + (double)vk[8 * 64] * x2;
+    }
+  }
+  ylds[wv][0][lane] = y0; ylds[wv][1][lane] = y1; ylds[wv][2][lane] = y2;
+  __syncthreads();
+  if (wv != 0) return;
+  double acc = 0.0, acc1 = 0.0, acc2 = 0.0;
+  const int row = s * 64 + lane;
+  if (live && row < sv.n_owned) {
+    y0 = ((ylds[0][0][lane] + ylds[1][0][lane]) + ylds[2][0][lane]) + ylds[3][0][lane];
+    y1 = ((ylds[0][1][lane] + ylds[1][1][lane]) + ylds[2][1][lane]) + ylds[3][1][lane];
+    y2 = ((ylds[0][2][lane] + ylds[1][2][lane]) + ylds[2][2][lane]) + ylds[3][2][lane];
+    const size_t d = 3 * (size_t)row;
+    {
+      const MT* l = dlo + (size_t)s * 9 * 64 + lane;
+      const double o0 = x[d], o1 = x[d + 1], o2 = x[d + 2];
+      y0 += (double)l[0 * 64] * o0 + (double)l[1 * 64] * o1 + (double)l[2 * 64] * o2;
+      y1 += (double)l[3 * 64] * o0 + (double)l[4 * 64] * o1 + (double)l[5 * 64] * o2;
+      y2 += (double)l[6 * 64] * o0 + (double)l[7 * 64] * o1 + (double)l[8 * 64] * o2;
+    }
+    if (MODE == 0) {
+      y[d] = y0; y[d + 1] = y1; y[d + 2] = y2;
+    } else if (MODE == 1) {
+      y[d] = y0; y[d + 1] = y1; y[d + 2] = y2;
+      acc += x[d] * y0 + x[d + 1] * y1 + x[d + 2] * y2;
+    } else if (MODE == 3) {
+      y[d] = y0; y[d + 1] = y1; y[d + 2] = y2;
+      acc += x[d] * y0 + x[d + 1] * y1 + x[d + 2] * y2;
+      const double i0 = invdiag[d], i1 = invdiag[d + 1], i2 = invdiag[d + 2];
+      acc1 += i0 * bvec[d] * y0 + i1 * bvec[d + 1] * y1 + i2 * bvec[d + 2] * y2;
+      acc2 += i0 * y0 * y0 + i1 * y1 * y1 + i2 * y2 * y2;
+    } else {
+      const double r0 = bvec[d] - y0, r1 = bvec[d + 1] - y1, r2 = bvec[d + 2] - y2;
+      y[d] = r0; y[d + 1] = r1; y[d + 2] = r2;
+      acc += r0 * r0 * invdiag[d] + r1 * r1 * invdiag[d + 1] + r2 * r2 * invdiag[d + 2];
+    }
+  }
+  if (MODE != 0) {
+    const double tot = wave_sum(acc);
+    if (lane == 0) partial[blockIdx.x] = tot;
+  }
+  if (MODE == 3) {
+    const double t1 = wave_sum(acc1), t2 = wave_sum(acc2);
+    if (lane == 0) {
+      partial[gridDim.x + blockIdx.x] = t1;
+      partial[2 * gridDim.x + blockIdx.x] = t2;
+    }
+  }
+  (void)acc1; (void)acc2;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // PCG vector kernels (CGSolver.cpp:129-190).  Same lane<->row map and XCD slabs as the SpMV so each XCD's L2
 // keeps its share of x, r, d, q, invdiag between kernels.  `sc` (when non-null) holds an already

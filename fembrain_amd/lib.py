@@ -15,6 +15,7 @@ FB_OK, FB_EINVAL, FB_EDEVICE, FB_ENOMEM, FB_ESOLVER, FB_ECOMM = 0, -1, -2, -3, -
 FB_MATRIX_F32, FB_MATRIX_F64 = 0, 1
 FB_XCH_COLLECTIVE, FB_XCH_P2P, FB_XCH_P2P_SUMS, FB_XCH_P2P_FUSED = 1, 2, 3, 4
 FB_PCG_MERGED, FB_PCG_REFERENCE, FB_PCG_FUSED = 0, 1, 2
+FB_SPMV_AUTO, FB_SPMV_ROWS, FB_SPMV_SPLIT = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
@@ -33,7 +34,7 @@ class FemParams(C.Structure):
     _fields_ = [("E", C.c_double), ("nu", C.c_double), ("rho", C.c_double), ("timestep", C.c_double),
                 ("damping_mass", C.c_double), ("damping_stiffness", C.c_double), ("cg_eps", C.c_double),
                 ("cg_max_iter", C.c_int), ("matrix_precision", C.c_int), ("device", C.c_int),
-                ("pcg_variant", C.c_int), ("reserved", C.c_int * 4)]
+                ("pcg_variant", C.c_int), ("spmv_kernel", C.c_int), ("reserved", C.c_int * 3)]
 
 
 class StepInfo(C.Structure):

@@ -61,8 +61,11 @@ typedef struct fb_fem_params {
   int matrix_precision;         /* FB_MATRIX_F32 / FB_MATRIX_F64 */
   int device;                   /* HIP device ordinal */
   int pcg_variant;              /* FB_PCG_MERGED (default) / FB_PCG_REFERENCE */
-  int reserved[4];
+  int spmv_kernel;              /* 0 = choose by size, FB_SPMV_ROWS, FB_SPMV_SPLIT (small meshes: one slice per block) */
+  int reserved[3];
 } fb_fem_params;
+#define FB_SPMV_ROWS 1
+#define FB_SPMV_SPLIT 2
 
 /* fills the reference's defaults listed above */
 void fb_fem_default_params(fb_fem_params* p);

@@ -66,13 +66,14 @@ def test_pattern_elements_assembly(gpu, prec, tol):
     assert np.abs(fg - fo).max() <= 1e-9 * np.abs(fo).max()  # element forces never pass through the fp32 matrix
 
 
+@pytest.mark.parametrize("spmv", [fl.FB_SPMV_ROWS, fl.FB_SPMV_SPLIT])  # the row kernel of large meshes / the split kernel of small ones
 @pytest.mark.parametrize("prec,tol", [(fl.FB_MATRIX_F64, 1e-9), (fl.FB_MATRIX_F32, 5e-7)])
-def test_system_spmv_pcg(gpu, prec, tol):
+def test_system_spmv_pcg(gpu, prec, tol, spmv):
     n = 7
     v, t, fixed = _cube(n)
     o = OrcFem(v, t)
     o.integrator(fixed)
-    g = FemIntegrator(v, t, fixed, matrix_precision=prec)
+    g = FemIntegrator(v, t, fixed, matrix_precision=prec, spmv_kernel=spmv)
     rng = np.random.default_rng(7)
     q0 = rng.normal(size=o.r) * 0.005
     v0 = rng.normal(size=o.r) * 0.1
@@ -125,9 +126,10 @@ def test_system_spmv_pcg(gpu, prec, tol):
         assert itm == -7, (variant, itm)
 
 
+@pytest.mark.parametrize("spmv", [fl.FB_SPMV_ROWS, fl.FB_SPMV_SPLIT])
 @pytest.mark.parametrize("variant", [fl.FB_PCG_MERGED, fl.FB_PCG_REFERENCE, fl.FB_PCG_FUSED])
 @pytest.mark.parametrize("prec", [fl.FB_MATRIX_F64, fl.FB_MATRIX_F32])
-def test_three_steps_reference_load(gpu, prec, variant):
+def test_three_steps_reference_load(gpu, prec, variant, spmv):
     """q, qvel after 3 steps under the reference load (-10000 per y DOF, plane i=0 clamped, CG eps 1e-6).
 
     Stated tolerance: both solvers stop at a 1e-6 relative (Jacobi-weighted) residual, so the two converged
@@ -138,7 +140,7 @@ def test_three_steps_reference_load(gpu, prec, variant):
     v, t, fixed = _cube(n)
     o = OrcFem(v, t)
     o.integrator(fixed)
-    g = FemIntegrator(v, t, fixed, matrix_precision=prec, pcg_variant=variant)
+    g = FemIntegrator(v, t, fixed, matrix_precision=prec, pcg_variant=variant, spmv_kernel=spmv)
     fext = np.zeros(o.r)
     fext[1::3] = -10000.0
     tol = 2e-5 if prec == fl.FB_MATRIX_F64 else 2e-4
