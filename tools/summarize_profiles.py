@@ -46,7 +46,7 @@ with open("profiles/%s_pmc_summary.csv" % tag, "w") as fh:
 sp = [r for r in out if r["kernel"].replace(" ", "").startswith("k_spmv<float,3")][0]
 hbm = (2 * sp["FETCH_SIZE_KB_median"] + sp["WRITE_SIZE_KB_median"]) * 1024
 json.dump({"kernel": "fb::k_spmv<float,3> (PCG SpMV with the merged sums)", "workload": "cube56 (998,250 tets), f32 matrix",
-           "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/probe_fem.py 56 1; per-launch medians over %d launches" % sp["launches"],
+           "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-field` (tools/profile_round.sh); per-launch medians over %d launches" % sp["launches"],
            "FETCH_SIZE_KB": sp["FETCH_SIZE_KB_median"], "WRITE_SIZE_KB": sp["WRITE_SIZE_KB_median"],
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM section); calibrated here against the known "
                          "algorithmic read volume of this kernel; WRITE_SIZE exact (q = 4.21 MB)",
