@@ -46,7 +46,7 @@ struct fb_fem_s {
   // one batch of 30 PCG iterations (29 merged + the exact-residual one) captured once and replayed: the launch sequence
   // and every kernel argument repeat from batch to batch, and on meshes of ~100k tets the host's launch rate, not the
   // device, would otherwise bound the iteration time
-  bool split = false;  // small mesh: SpMV with one slice per block (k_spmv_split)
+  int split = 0;       // wavefronts per slice of the SpMV on small / mid-size meshes (k_spmv_split): 0 (row kernel), 2 or 4
   int sgrid = 8;       // blocks (= partial sums) of the SpMV launches; equals grid unless split
   hipGraphExec_t batch_graph = nullptr;
   const double* graph_rhs = nullptr;
@@ -100,10 +100,14 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
   const int per = std::max(1, std::min(kMaxPartials / 8, ceil_div(chunk, kWavesPerBlock)));
   h->grid = 8 * per;
   const int want = h->prm.spmv_kernel;
-  if (want == FB_SPMV_SPLIT && (8 * chunk > kMaxPartials || P.n_ranks > 1))
-    return fail(FB_EINVAL, "split SpMV needs an unsharded mesh of <= %d slices, this one has %d on %d ranks", kMaxPartials, P.n_slices, P.n_ranks);
-  h->split = want == FB_SPMV_SPLIT || (want == 0 && 8 * chunk <= kMaxPartials && P.n_ranks == 1);
-  h->sgrid = h->split ? 8 * chunk : h->grid;
+  if (want == FB_SPMV_SPLIT && (8 * ceil_div(chunk, 2) > kMaxPartials || P.n_ranks > 1))
+    return fail(FB_EINVAL, "split SpMV needs an unsharded mesh of <= %d slices, this one has %d on %d ranks", 2 * kMaxPartials, P.n_slices, P.n_ranks);
+  h->split = 0;
+  if (want == FB_SPMV_SPLIT || (want == 0 && P.n_ranks == 1)) {
+    if (8 * chunk <= kMaxPartials) h->split = 4;
+    else if (8 * ceil_div(chunk, 2) <= kMaxPartials) h->split = 2;
+  }
+  h->sgrid = h->split == 4 ? 8 * chunk : (h->split == 2 ? 8 * ceil_div(chunk, 2) : h->grid);
   FB_TRY(h->part_a.alloc(3 * kMaxPartials));
   FB_TRY(h->part_b.alloc(kMaxPartials));
   FB_TRY(h->part_c.alloc(3 * kMaxPartials));
@@ -192,8 +196,14 @@ int assemble_system(fb_fem_s* h) {
 
 template <typename MT, int MODE>
 int launch_spmv(fb_fem_s* h, const double* x, double* y, const double* b, double* partial, int parity) {
-  if (h->split) {
-    hipLaunchKernelGGL((k_spmv_split<MT, MODE>), dim3(h->sgrid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
+  if (h->split == 4) {
+    hipLaunchKernelGGL((k_spmv_split<MT, MODE, 4>), dim3(h->sgrid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
+                       b, h->invdiag.p, partial, h->st.p, parity);
+    FB_HIP(hipGetLastError());
+    return FB_OK;
+  }
+  if (h->split == 2) {
+    hipLaunchKernelGGL((k_spmv_split<MT, MODE, 2>), dim3(h->sgrid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
                        b, h->invdiag.p, partial, h->st.p, parity);
     FB_HIP(hipGetLastError());
     return FB_OK;

@@ -426,16 +426,19 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
   (void)acc1; (void)acc2;
 }
 
-// Small meshes (<= 1024 slices, ~350k tets): one slice per BLOCK, its slots dealt to the block's four wavefronts.  With
-// fewer slices than the chip has wave slots the row kernel above is bound by the latency of one wavefront walking all
-// ~15 slots of its slice (6.8 us at 105k tets for 13 MB); splitting the walk four ways shortens that chain.  The four
-// partial row sums are added in wave order (deterministic; rounding differs from the row kernel in the last bit).
-template <typename MT, int MODE>
+// Small and mid-size meshes: SPLIT wavefronts share one slice (SPLIT = 4: one slice per block, up to 1024 slices ~ 350k
+// tets; SPLIT = 2: two slices per block, up to 2048 slices ~ 750k tets).  With fewer slices than the chip has wave slots
+// the row kernel above is bound by the latency of one wavefront walking all ~15 slots of its slice (6.8 us at 105k tets
+// for 13 MB); dealing the slots to several wavefronts shortens that chain.  The partial row sums are added in wave order
+// through LDS (deterministic; rounding differs from the row kernel in the last bit).
+template <typename MT, int MODE, int SPLIT>
 __global__ __launch_bounds__(kBlock) void k_spmv_split(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo,
                                                        const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ bvec,
                                                        const double* __restrict__ invdiag, double* __restrict__ partial,
                                                        CGState* __restrict__ st, int parity) {
+  constexpr int kPerBlock = kWavesPerBlock / SPLIT;  // slices per block
   __shared__ double ylds[kWavesPerBlock][3][64];
+  __shared__ double red[3][kWavesPerBlock];
   if (MODE != 0 && st->done) return;
   if (MODE == 1 || MODE == 3) {
     if (!(st->rho[parity] > st->eps2 * st->rho0) || st->iter >= st->max_iter) {
@@ -444,16 +447,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv_split(SellView sv, const MT* __
     }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sub = wv % SPLIT, which = wv / SPLIT;
   const int xcd = blockIdx.x & 7, chunk = (sv.n_slices + 7) >> 3;
-  const int s = xcd * chunk + (blockIdx.x >> 3);
-  const bool live = (int)(blockIdx.x >> 3) < chunk && s < sv.n_slices;  // block-uniform
+  const int j = (int)(blockIdx.x >> 3) * kPerBlock + which;
+  const int s = xcd * chunk + j;
+  const bool live = j < chunk && s < sv.n_slices;  // wave-uniform
   double y0 = 0, y1 = 0, y2 = 0;
   if (live) {
     const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
     const MT* v = vals + (size_t)so * 9 * 64 + lane;
     const int* ci = sv.colidx + (size_t)so * 64 + lane;
 #pragma unroll 4
-    for (int k = wv; k < width; k += kWavesPerBlock) {
+    for (int k = sub; k < width; k += SPLIT) {
       const int col = ci[(size_t)k * 64];
       const double* xp = x + 3 * (size_t)col;
       const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
@@ -465,13 +470,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv_split(SellView sv, const MT* __
   }
   ylds[wv][0][lane] = y0; ylds[wv][1][lane] = y1; ylds[wv][2][lane] = y2;
   __syncthreads();
-  if (wv != 0) return;
   double acc = 0.0, acc1 = 0.0, acc2 = 0.0;
   const int row = s * 64 + lane;
-  if (live && row < sv.n_owned) {
-    y0 = ((ylds[0][0][lane] + ylds[1][0][lane]) + ylds[2][0][lane]) + ylds[3][0][lane];
-    y1 = ((ylds[0][1][lane] + ylds[1][1][lane]) + ylds[2][1][lane]) + ylds[3][1][lane];
-    y2 = ((ylds[0][2][lane] + ylds[1][2][lane]) + ylds[2][2][lane]) + ylds[3][2][lane];
+  if (sub == 0 && live && row < sv.n_owned) {  // the slice's first wavefront finishes the rows
+    y0 = ylds[wv][0][lane]; y1 = ylds[wv][1][lane]; y2 = ylds[wv][2][lane];
+#pragma unroll
+    for (int k = 1; k < SPLIT; k++) { y0 += ylds[wv + k][0][lane]; y1 += ylds[wv + k][1][lane]; y2 += ylds[wv + k][2][lane]; }
     const size_t d = 3 * (size_t)row;
     {
       const MT* l = dlo + (size_t)s * 9 * 64 + lane;
@@ -497,18 +501,17 @@ __global__ __launch_bounds__(kBlock) void k_spmv_split(SellView sv, const MT* __
       acc += r0 * r0 * invdiag[d] + r1 * r1 * invdiag[d + 1] + r2 * r2 * invdiag[d + 2];
     }
   }
-  if (MODE != 0) {
-    const double tot = wave_sum(acc);
-    if (lane == 0) partial[blockIdx.x] = tot;
-  }
-  if (MODE == 3) {
-    const double t1 = wave_sum(acc1), t2 = wave_sum(acc2);
-    if (lane == 0) {
-      partial[gridDim.x + blockIdx.x] = t1;
-      partial[2 * gridDim.x + blockIdx.x] = t2;
+  if (MODE != 0) {  // one partial per block: the finishing wavefronts' sums in wave order
+    const double t0 = wave_sum(acc), t1 = wave_sum(acc1), t2 = wave_sum(acc2);
+    if (lane == 0) { red[0][wv] = t0; red[1][wv] = t1; red[2][wv] = t2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double a = 0.0, b = 0.0, c = 0.0;
+      for (int k = 0; k < kWavesPerBlock; k += SPLIT) { a += red[0][k]; b += red[1][k]; c += red[2][k]; }
+      partial[blockIdx.x] = a;
+      if (MODE == 3) { partial[gridDim.x + blockIdx.x] = b; partial[2 * gridDim.x + blockIdx.x] = c; }
     }
   }
-  (void)acc1; (void)acc2;
 }
 
 // ------------------------------------------------------------------------------------------------------
