@@ -383,11 +383,18 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
   const bool graphable = h->use_graph && P.n_slices <= 4096 && (!h->comm || h->comm->n_ranks == 1);
   while (!finished) {
     const int n = std::min(kBatch, max_iter - it + 1);
-    if (graphable && n == kBatch && (it - 1) % kBatch == 0) {
-      FB_TRY(ensure_batch_graph(h, b, kBatch));
-      FB_HIP(hipGraphLaunch(h->batch_graph, s));
-      it += kBatch;
-    } else {
+    bool replayed = false;
+    if (graphable && h->use_graph && n == kBatch && (it - 1) % kBatch == 0) {
+      if (ensure_batch_graph(h, b, kBatch) == FB_OK && hipGraphLaunch(h->batch_graph, s) == hipSuccess) {
+        replayed = true;
+        it += kBatch;
+      } else {  // capture or replay unavailable: plain launches from now on
+        (void)hipGetLastError();
+        drop_graph(h);
+        h->use_graph = false;
+      }
+    }
+    if (!replayed) {
       for (int k = 0; k < n; k++, it++) FB_TRY(pcg_iteration(h, it, b));
     }
     FB_HIP(hipMemcpyAsync(&h->st_host[slot], h->st.p, sizeof(CGState), hipMemcpyDeviceToHost, s));
