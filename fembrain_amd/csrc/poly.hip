@@ -81,7 +81,7 @@ __device__ __forceinline__ float prim_field(const float* __restrict__ prims, con
     }
     // an instance of a PRIMITIVE is that primitive at the mapped point (Polygonizer.cpp:1879-1901); instances of
     // operators never get here: compile_tree expands them into ENTER .. LEAVE blocks
-    if (type != primInstance || hop == 8 || (int)P[14] != 0) break;
+    if (__builtin_expect(type != primInstance, 1) || hop == 8 || (int)P[14] != 0) break;
     P = prims + 20 * (int)P[12];
     type = (int)P[0];
   }
@@ -181,26 +181,49 @@ __device__ __forceinline__ float apply_op(int optype, float lf, float rf, float 
   }
 }
 
+// Wave-level culling of primitives in the sweep.  The 64 points of a wavefront are a run of consecutive grid points; its
+// bounding box is known from the run's first and last index alone (no cross-lane work).  A primitive whose SUPPORT box
+// (where its field can be non-zero at all: skeleton grown by the Wyvill radius 1, mapped to world space, padded against
+// rounding -- support_box() on the host) misses that box contributes exactly 0.0f to every lane, so skipping it leaves
+// every field value bit-identical.  (This is not the reference's bounding-box cull, whose boxes are tighter than the
+// support and whose outcome depends on the host SIMD width -- DESIGN.md section 2.)  Decisions are wave-uniform.
+struct SegBox {
+  float lo[3], hi[3];
+  const float* pbox;  // 6 floats per primitive: support lo, hi
+};
+
+template <bool CULL>
+__device__ __forceinline__ float prim_val(const float* __restrict__ prims, const float* __restrict__ mtx, int i, float x, float y, float z,
+                                          const SegBox& sb, int nest) {
+  if (CULL && nest == 0) {  // inside an instanced subtree the point has been mapped: no culling there
+    const float* b = sb.pbox + 6 * i;
+    if (sb.lo[0] > b[3] || sb.hi[0] < b[0] || sb.lo[1] > b[4] || sb.hi[1] < b[1] || sb.lo[2] > b[5] || sb.hi[2] < b[2]) return 0.0f;
+  }
+  return prim_field(prims, mtx, i, x, y, z);
+}
+
 // FieldComputer::fieldValue (Polygonizer.cpp:1913-2108) through the compiled order.  `stk` is this thread's
 // column of an LDS slot array [depth][kPB].
-__device__ __forceinline__ float eval_field(const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
-                                   const float* __restrict__ mtx, float x, float y, float z, float* stk) {
+template <bool CULL>
+__device__ __forceinline__ float eval_field_t(const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
+                                              const float* __restrict__ mtx, float x, float y, float z, float* stk, const SegBox& sb) {
   float out = 0.0f;
+  int nest = 0;
   if (n_instr == 0) {  // no operators: blend of all primitives (:2085-2096)
-    for (int i = 0; i < n_prims; i++) out = out + prim_field(prims, mtx, i, x, y, z);
+    for (int i = 0; i < n_prims; i++) out = out + prim_val<CULL>(prims, mtx, i, x, y, z, sb, nest);
     return out;
   }
   for (int k = 0; k < n_instr; k++) {
     const Instr& in = prog[k];
     switch (in.kind) {
       case 0:
-        for (int i = in.a; i <= in.b; i++) out = out + prim_field(prims, mtx, i, x, y, z);
+        for (int i = in.a; i <= in.b; i++) out = out + prim_val<CULL>(prims, mtx, i, x, y, z, sb, nest);
         break;
       case 1: {
         const int a = in.a, b = in.b;
-        const float lf = a >= 0 ? prim_field(prims, mtx, a, x, y, z) : stk[(-1 - a) * kPB];
+        const float lf = a >= 0 ? prim_val<CULL>(prims, mtx, a, x, y, z, sb, nest) : stk[(-1 - a) * kPB];
         float rf = 0.0f;
-        if (!in.unary) rf = b >= 0 ? prim_field(prims, mtx, b, x, y, z) : stk[(-1 - b) * kPB];
+        if (!in.unary) rf = b >= 0 ? prim_val<CULL>(prims, mtx, b, x, y, z, sb, nest) : stk[(-1 - b) * kPB];
         out = apply_op(in.optype, lf, rf, in.p0, in.p1, out);
       } break;
       case 2: {  // computePrimitiveField of an operator instance: map the point, cull against the original's box
@@ -214,6 +237,7 @@ __device__ __forceinline__ float eval_field(const Instr* __restrict__ prog, int 
           x = tx; y = ty; z = tz;
         }
         out = 0.0f;
+        nest++;
         const bool inside = x >= in.lo[0] && in.hi[0] >= x && y >= in.lo[1] && in.hi[1] >= y && z >= in.lo[2] && in.hi[2] >= z;
         f[4 * kPB] = inside ? 1.0f : 0.0f;
         // the program counter stays wave-uniform (scalar instruction fetch): the block is skipped only when every lane
@@ -225,6 +249,7 @@ __device__ __forceinline__ float eval_field(const Instr* __restrict__ prog, int 
         const float v = f[4 * kPB] != 0.0f ? out : 0.0f;
         x = f[0]; y = f[kPB]; z = f[2 * kPB]; out = f[3 * kPB];
         stk[in.dst * kPB] = v;
+        nest--;
       } continue;
       default:
         out = out + stk[in.a * kPB];
@@ -235,9 +260,17 @@ __device__ __forceinline__ float eval_field(const Instr* __restrict__ prog, int 
   return out;
 }
 
+__device__ __forceinline__ float eval_field(const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
+                                            const float* __restrict__ mtx, float x, float y, float z, float* stk) {
+  SegBox none;
+  none.pbox = nullptr;
+  return eval_field_t<false>(prog, n_instr, n_prims, prims, mtx, x, y, z, stk, none);
+}
+
 // ---- ComputeAllFields (Polygonizer.cl:1215-1236): v = lo + cellsize*(ix,iy,iz), index iz*gx*gy + iy*gx + ix ----
+template <bool CULL>
 __global__ __launch_bounds__(kPB) void k_sweep(Grid G, const Instr* __restrict__ prog, int n_instr, int n_prims, int depth,
-                                               const float* __restrict__ prims, const float* __restrict__ mtx,
+                                               const float* __restrict__ prims, const float* __restrict__ mtx, const float* __restrict__ pbox,
                                                float4* __restrict__ grid, unsigned long long* __restrict__ inside) {
   extern __shared__ float stack[];
   // kSweepPts consecutive 256-point runs per block: every store instruction of a wave is still one contiguous 1 KiB
@@ -247,14 +280,32 @@ __global__ __launch_bounds__(kPB) void k_sweep(Grid G, const Instr* __restrict__
   for (int k = 0; k < kSweepPts; k++) {
     const long long gid = ((long long)blockIdx.x * kSweepPts + k) * kPB + threadIdx.x;
     bool in = false;
+    // every lane's grid index (lanes past the end of the grid compute one too: harmless, they evaluate nothing)
+    const unsigned int g32 = (unsigned int)gid;
+    const unsigned int iz = g32 / gxy, rem = g32 - iz * gxy;
+    const unsigned int iy = rem / gx, ix = rem - iy * gx;
+    // bounding box of this wavefront's 64-point run from the indices of its first and last valid lane (scalar reads of
+    // values the lanes hold anyway)
+    SegBox sb;
+    sb.pbox = pbox;
+    if (CULL) {
+      const long long first = gid - (threadIdx.x & 63);
+      const int last_lane = __builtin_amdgcn_readfirstlane((int)min(63LL, G.n_points - 1 - first));
+      const int ll = last_lane < 0 ? 0 : last_lane;
+      const unsigned int ax = __builtin_amdgcn_readlane(ix, 0), ay = __builtin_amdgcn_readlane(iy, 0), az = __builtin_amdgcn_readlane(iz, 0);
+      const unsigned int bx = __builtin_amdgcn_readlane(ix, ll), by = __builtin_amdgcn_readlane(iy, ll), bz = __builtin_amdgcn_readlane(iz, ll);
+      const bool same_plane = az == bz, same_row = same_plane && ay == by;
+      const unsigned int x0 = same_row ? ax : 0u, x1 = same_row ? bx : gx - 1u;
+      const unsigned int y0 = same_plane ? ay : 0u, y1 = same_plane ? by : (unsigned int)G.g[1] - 1u;
+      sb.lo[0] = G.lo[0] + G.cellsize * (float)x0; sb.hi[0] = G.lo[0] + G.cellsize * (float)x1;
+      sb.lo[1] = G.lo[1] + G.cellsize * (float)y0; sb.hi[1] = G.lo[1] + G.cellsize * (float)y1;
+      sb.lo[2] = G.lo[2] + G.cellsize * (float)az; sb.hi[2] = G.lo[2] + G.cellsize * (float)bz;
+    }
     if (gid < G.n_points) {
-      const unsigned int g32 = (unsigned int)gid;
-      const unsigned int iz = g32 / gxy, rem = g32 - iz * gxy;
-      const unsigned int iy = rem / gx, ix = rem - iy * gx;
       const float x = G.lo[0] + G.cellsize * (float)ix;
       const float y = G.lo[1] + G.cellsize * (float)iy;
       const float z = G.lo[2] + G.cellsize * (float)iz;
-      const float f = eval_field(prog, n_instr, n_prims, prims, mtx, x, y, z, stack + threadIdx.x);
+      const float f = eval_field_t<CULL>(prog, n_instr, n_prims, prims, mtx, x, y, z, stack + threadIdx.x, sb);
       if (grid) { const v4f o = {x, y, z, f}; __builtin_nontemporal_store(o, (v4f*)&grid[gid]); }  // streamed once: 49 vs 56 us
       in = f >= kIso;  // inside test of Polygonizer.cl:1367,1599 and Polygonizer.cpp:1052
     }
@@ -829,7 +880,8 @@ struct fb_poly_s {
   std::vector<Instr> prog;
   int depth = 1;
   DevBuf<Instr> d_prog;
-  DevBuf<float> d_prims, d_mtx;
+  DevBuf<float> d_prims, d_mtx, d_pbox;
+  std::vector<float> pbox;  // support box of every primitive (support_boxes)
   Grid G;
   bool have_grid = false, classified = false, tetra = false, materialized = false;
   DevBuf<float4> grid;
@@ -1042,13 +1094,91 @@ int compile_tree(fb_poly_s* h) {
   return FB_OK;
 }
 
+// World-space box outside which primitive i contributes exactly 0.0f (see SegBox).  Local support = skeleton grown by the
+// Wyvill radius 1 (field = max(0, (1 - d^2)^3)); mapped with the forward matrix (inverse of the stored matrix node) and
+// padded generously against fp32 rounding of the distance and of the affine maps.  Anything not provably bounded
+// (infinite line, instances, non-unit directions, singular matrices) gets an infinite box = is never culled.
+void support_boxes(fb_poly_s* h) {
+  const float inf = FLT_MAX;
+  h->pbox.assign(6 * (size_t)h->n_prims, 0.0f);
+  for (int i = 0; i < h->n_prims; i++) {
+    const float* P = h->prims.data() + 20 * (size_t)i;
+    const int type = (int)P[0], im = (int)P[1];
+    const double pos[3] = {P[4], P[5], P[6]}, dir[3] = {P[8], P[9], P[10]};
+    const double r0 = P[12], r1 = P[13];
+    double lo[3], hi[3];
+    bool bounded = true, empty = false;
+    const double dlen = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    const bool unit = std::fabs(dlen - 1.0) < 1e-3;
+    auto ball = [&](double rad) { for (int a = 0; a < 3; a++) { lo[a] = pos[a] - rad; hi[a] = pos[a] + rad; } };
+    switch (type) {
+      case primPoint: ball(1.0); break;
+      case primCylinder:
+        if (!unit || !(r0 >= 0) || !(r1 >= 0)) { bounded = false; break; }
+        for (int a = 0; a < 3; a++) {
+          const double e0 = pos[a] - dir[a], e1 = pos[a] + dir[a] * (r1 + 1.0);
+          lo[a] = std::min(e0, e1) - (r0 + 1.0); hi[a] = std::max(e0, e1) + (r0 + 1.0);
+        }
+        break;
+      case primDisc: case primRing:
+        if (!unit || !(r0 >= 0)) { bounded = false; break; }
+        ball(r0 + 1.0);
+        break;
+      case primCube:
+        if (!(r0 >= 0)) { bounded = false; break; }
+        ball(r0 + 1.0);
+        break;
+      case primQuadricPoint:
+        if (!(P[10] >= 0)) { empty = true; break; }
+        ball(std::sqrt((double)P[10]));
+        break;
+      case primTriangle: case primNULL: empty = true; break;  // wyvill(FLT_MAX) = wyvill(10) = 0
+      case primLine: case primInstance: bounded = false; break;
+      default: empty = true; break;                           // unknown types evaluate to 0
+    }
+    float* out = h->pbox.data() + 6 * (size_t)i;
+    if (empty) { out[0] = out[1] = out[2] = inf; out[3] = out[4] = out[5] = -inf; continue; }
+    if (bounded && im != 0) {  // forward map of the 8 corners
+      const float* m = h->mtx.data() + 12 * (size_t)im;
+      const double A[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]}, t[3] = {m[3], m[7], m[11]};
+      const double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+      if (!(std::fabs(det) > 1e-12) || !std::isfinite(det)) bounded = false;
+      else {
+        double I[9];
+        I[0] = (A[4] * A[8] - A[5] * A[7]) / det; I[1] = (A[2] * A[7] - A[1] * A[8]) / det; I[2] = (A[1] * A[5] - A[2] * A[4]) / det;
+        I[3] = (A[5] * A[6] - A[3] * A[8]) / det; I[4] = (A[0] * A[8] - A[2] * A[6]) / det; I[5] = (A[2] * A[3] - A[0] * A[5]) / det;
+        I[6] = (A[3] * A[7] - A[4] * A[6]) / det; I[7] = (A[1] * A[6] - A[0] * A[7]) / det; I[8] = (A[0] * A[4] - A[1] * A[3]) / det;
+        double wlo[3] = {1e300, 1e300, 1e300}, whi[3] = {-1e300, -1e300, -1e300};
+        for (int c = 0; c < 8; c++) {
+          const double q[3] = {((c & 1) ? hi[0] : lo[0]) - t[0], ((c & 2) ? hi[1] : lo[1]) - t[1], ((c & 4) ? hi[2] : lo[2]) - t[2]};
+          for (int a = 0; a < 3; a++) {
+            const double w = I[3 * a] * q[0] + I[3 * a + 1] * q[1] + I[3 * a + 2] * q[2];  // world = A^-1 (local - t)
+            wlo[a] = std::min(wlo[a], w); whi[a] = std::max(whi[a], w);
+          }
+        }
+        for (int a = 0; a < 3; a++) { lo[a] = wlo[a]; hi[a] = whi[a]; }
+      }
+    }
+    for (int a = 0; a < 3; a++) {
+      if (!bounded || !std::isfinite(lo[a]) || !std::isfinite(hi[a])) { out[a] = -inf; out[3 + a] = inf; continue; }
+      const double pad = 1e-2 + 1e-4 * std::max(std::fabs(lo[a]), std::fabs(hi[a]));
+      out[a] = (float)(lo[a] - pad); out[3 + a] = (float)(hi[a] + pad);
+    }
+  }
+}
+
 size_t stack_bytes(const fb_poly_s* h) { return (size_t)std::max(1, h->depth) * kPB * sizeof(float); }
 
 int do_sweep(fb_poly_s* h, bool store_grid) {
   const Grid& G = h->G;
   const int blocks = (int)((G.n_points + (long long)kPB * kSweepPts - 1) / ((long long)kPB * kSweepPts));
-  hipLaunchKernelGGL(k_sweep, dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, h->d_prog.p, (int)h->prog.size(), h->n_prims, h->depth,
-                     h->d_prims.p, h->d_mtx.p, store_grid ? h->grid.p : nullptr, h->inside.p);
+  // with one or two primitives the box test costs more than it can save (sphere at 256^3: 66 vs 50 us)
+  if (h->n_prims > 2)
+    hipLaunchKernelGGL(k_sweep<true>, dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, h->d_prog.p, (int)h->prog.size(), h->n_prims, h->depth,
+                       h->d_prims.p, h->d_mtx.p, h->d_pbox.p, store_grid ? h->grid.p : nullptr, h->inside.p);
+  else
+    hipLaunchKernelGGL(k_sweep<false>, dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, h->d_prog.p, (int)h->prog.size(), h->n_prims, h->depth,
+                       h->d_prims.p, h->d_mtx.p, h->d_pbox.p, store_grid ? h->grid.p : nullptr, h->inside.p);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -1210,6 +1340,10 @@ int fb_poly_create(fb_poly_t* out, int device, const float* header12, int n_ops,
   }
   if (rc == FB_OK) rc = h->d_prims.upload(h->prims, h->stream);
   if (rc == FB_OK) rc = h->d_mtx.upload(h->mtx, h->stream);
+  if (rc == FB_OK) {
+    support_boxes(h);
+    rc = h->d_pbox.upload(h->pbox, h->stream);
+  }
   const CubeTable& ct = cube_table();
   if (rc == FB_OK) rc = h->d_tri.upload(&ct.tri[0][0], sizeof ct.tri, h->stream);
   if (rc == FB_OK) rc = h->d_nvert.upload(ct.nvert, sizeof ct.nvert, h->stream);

@@ -361,3 +361,27 @@ def test_surface_follows_the_tet_mesh_displacements(gpu):
     assert np.abs(g.interpolate_displacements(aff) - (sx + (sx.astype(np.float64) @ A.T + 0.1))).max() < 2e-6
     with pytest.raises(fl.FbError):
         g.interpolate_displacements(u[:-1])
+
+
+@pytest.mark.parametrize("name", ["ventricle", "complex", "CylinderWithHoles", "3slabs", "tumor", "pizaL2P4", "piza4x4"])
+def test_sweep_culling_changes_no_value(gpu, name):
+    """The sweep skips, per 64-point run, the primitives whose support box misses the run (poly.hip: SegBox, support_boxes);
+    computeFieldArray evaluates every primitive at every point.  Same device arithmetic otherwise, so the two must agree
+    BIT FOR BIT on every grid sample -- cylinders, discs, cubes, scaled / rotated / translated primitives and instanced
+    subtrees included."""
+    blob = read_blob(os.path.join(GOLD, "blob", name + ".blob"))
+    g = GpuPoly(blob)
+    lo, hi = blob.bbox
+    cell = float((hi - lo).max()) / 60.0
+    g.sweep(cell)
+    grid = g.read_grid()
+    again = g.compute_field_array(grid)
+    assert np.array_equal(again[:, :3], grid[:, :3])
+    assert np.array_equal(again[:, 3], grid[:, 3])
+    assert (grid[:, 3] > 0).any() and (grid[:, 3] == 0).any()
+    # and on a grid that reaches far outside the model, where nearly everything is culled
+    pad = np.float32(2.5)
+    dims = tuple(int(np.ceil((h - l + 2 * pad) / (2 * cell))) + 1 for l, h in zip(lo, hi))
+    g.sweep_grid(lo - pad, 2 * cell, dims)
+    grid = g.read_grid()
+    assert np.array_equal(g.compute_field_array(grid)[:, 3], grid[:, 3])
