@@ -510,3 +510,34 @@ def test_every_dof_constrained_and_degenerate_input(gpu):
     flat[:, 2] = 0.0
     with pytest.raises(fl.FbError):
         FemIntegrator(flat, t, [])                                         # all elements flat
+
+
+def test_config2_blobtree_model_100k_tets_end_to_end(gpu):
+    """BASELINE config 2 on a reference model (no brain BlobTree exists; ventricle.blob, 17 primitives, stands in):
+    field sweep -> tetrahedral polygonizer at the cellsize that gives 100k +- 10 % tets (0.115 -> 107,820) -> FEM handle
+    on that welded mesh, lowest 5 % of the nodes in y clamped, reference gravity, one step.  Tet mesh bit-exact against the
+    oracle; displacements within the stated fp32-matrix tolerance; PCG iteration count within 2 %."""
+    import os
+    from fembrain_amd.blobtree import read_blob
+    from fembrain_amd.poly import GpuPoly
+    from oracle.pyfield import OrcPoly
+    blob = read_blob(os.path.join(os.path.dirname(__file__), "golden", "blob", "ventricle.blob"))
+    xyz, tets = GpuPoly(blob).run_tetrahedralizer(0.115)
+    oxyz, otets, _ = OrcPoly(blob).run_tetrahedralizer(0.115)
+    assert 90000 <= len(tets) <= 110000
+    assert np.array_equal(tets, otets) and np.abs(xyz - oxyz).max() <= 1e-6
+    v, t = xyz.astype(np.float64), tets.astype(np.int32)
+    ycut = np.sort(v[:, 1])[len(v) // 20]
+    fixed = fixed_vertices_to_dofs(np.nonzero(v[:, 1] <= ycut)[0])
+    o = OrcFem(v, t)
+    o.integrator(fixed)
+    g = FemIntegrator(v, t, fixed)
+    f = np.zeros(o.r)
+    f[1::3] = -10000.0
+    o.set_external_forces(f)
+    g.set_external_forces(f)
+    io, ig = abs(o.step()), g.do_timestep()
+    qo, _ = o.get_state()
+    qg, _, _ = g.get_q_state()
+    assert abs(io - ig) <= max(3, 0.02 * io), (io, ig)
+    assert np.abs(qg - qo).max() <= 2e-4 * np.abs(qo).max()
