@@ -29,10 +29,30 @@ WORKLOADS = {
     "cube27": (27, "truth cube 27^3 nodes / 105,456 tets (BASELINE config 2 canonical mesh)"),
     "cube56": (56, "truth cube 56^3 nodes / 998,250 tets, plane i=0 clamped, -10000 per y DOF, per-step re-assembly (BASELINE config 4)"),
     "cube111": (111, "truth cube 111^3 nodes / 7,986,000 tets (BASELINE config 5 mesh)"),
+    # BASELINE config 2 on a reference model: ventricle.blob polygonized on the device at cellsize 0.115
+    "ventricle": (0, "ventricle.blob (17 primitives) -> tetrahedral polygonizer at cellsize 0.115 -> 107,820 tets, lowest 5 % of the nodes "
+                     "in y clamped, -10000 per y DOF (BASELINE config 2)"),
 }
 
 
-def cpu_baseline(n, cg_iterations, sample_iters=40):
+def workload_mesh(name, device=0):
+    """(vertices, tets, constrained DOFs) of a workload; the BlobTree model is polygonized by the HIP path itself."""
+    from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
+    n = WORKLOADS[name][0]
+    if n:
+        v, t = truth_cube(n, n, n, 0.1)
+        return v, t, fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    from fembrain_amd.blobtree import read_blob
+    from fembrain_amd.poly import GpuPoly
+    p = GpuPoly(read_blob(os.path.join(ROOT, "tests", "golden", "blob", "ventricle.blob")), device=device)
+    xyz, tets = p.run_tetrahedralizer(0.115)
+    p.close()
+    v, t = xyz.astype(np.float64), tets.astype(np.int32)
+    ycut = np.sort(v[:, 1])[len(v) // 20]
+    return v, t, fixed_vertices_to_dofs(np.nonzero(v[:, 1] <= ycut)[0])
+
+
+def cpu_baseline(mesh, cg_iterations, sample_iters=40):
     """The reference's CPU path on the same workload, 1 core (it is serial: Deformable.cpp:182).  When the reference build
     oracle/_ref/libfem_ref.so travelled with the snapshot ("reference": the reference's own CorotationalLinearFEM,
     SparseMatrix and CGSolver objects driven through its step sequence) it is timed, otherwise the plain-C restatement
@@ -40,9 +60,7 @@ def cpu_baseline(n, cg_iterations, sample_iters=40):
     1 + sample_iters; the difference prices an iteration, the rest is assembly + system algebra; the step time is
     extrapolated with the iteration count the GPU run needed.  Set-up is not timed."""
     from oracle import pyoracle
-    from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
-    v, t = truth_cube(n, n, n, 0.1)
-    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    v, t, fixed = mesh
 
     def sample(cls):
         o = cls(v, t)
@@ -170,12 +188,14 @@ def main():
             fl.check(fl.lib().fb_comm_create(C.byref(comm), rank, world, idb, device))
 
     n, text = WORKLOADS[args.workload]
-    v, t = truth_cube(n, n, n, 0.1)
-    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    v, t, fixed = workload_mesh(args.workload, device)
     if dist_mode:
         # slabs of whole i-planes (node index = i*n*n + j*n + k): <= 2 neighbours per rank
-        planes = [n * r // world for r in range(world + 1)]
-        splits = np.array([p * n * n for p in planes], dtype=np.int32)
+        if n:
+            planes = [n * r // world for r in range(world + 1)]
+            splits = np.array([p * n * n for p in planes], dtype=np.int32)
+        else:  # grid-ordered polygonizer mesh: equal node ranges (z slabs of the voxel grid)
+            splits = np.array([len(v) * r // world for r in range(world + 1)], dtype=np.int32)
         shard = (world, rank, splits, comm)
     prec = fl.FB_MATRIX_F64 if args.precision == "f64" else fl.FB_MATRIX_F32
     g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device, shard=shard)
@@ -248,7 +268,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "FEM steps/sec (assemble+PCG) at 1M tets", "value": args.steps / dt, "unit": "steps/s",
+            "metric": "FEM steps/sec (assemble+PCG) at 1M tets" if args.workload == "cube56" else "FEM steps/sec (assemble+PCG)", "value": args.steps / dt, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 matrix, f64 vectors/accumulators" if args.precision == "f32" else "f64", "data": "synthetic",
@@ -274,7 +294,7 @@ def main():
         if out is not None:
             out.update(extra)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(n, int(round(np.mean(iters))))
+        out["cpu_baseline"] = cpu_baseline((v, t, fixed), int(round(np.mean(iters))))
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     elif rank == 0:
         out["cpu_baseline"] = None
