@@ -541,3 +541,39 @@ def test_config2_blobtree_model_100k_tets_end_to_end(gpu):
     qg, _, _ = g.get_q_state()
     assert abs(io - ig) <= max(3, 0.02 * io), (io, ig)
     assert np.abs(qg - qo).max() <= 2e-4 * np.abs(qo).max()
+
+
+def test_random_delaunay_mesh(gpu):
+    """An unstructured mesh with no grid regularity at all: Delaunay tetrahedra of random points (slivers below 1e-7 volume
+    dropped), mixed orientations as scipy returns them, irregular valences (row lengths 5..40).  Pattern bit-exact, warped
+    assembly to the fp64 tolerance, two steps against the oracle."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(42)
+    pts = rng.uniform(0, 1, size=(400, 3))
+    t = Delaunay(pts).simplices.astype(np.int32)
+    vol = np.einsum("ij,ij->i", pts[t[:, 1]] - pts[t[:, 0]], np.cross(pts[t[:, 2]] - pts[t[:, 0]], pts[t[:, 3]] - pts[t[:, 0]])) / 6
+    t = np.ascontiguousarray(t[np.abs(vol) > 1e-7])
+    assert len(t) > 1500 and (vol > 0).any() and (vol < 0).any()
+    fixed = fixed_vertices_to_dofs(np.nonzero(pts[:, 0] < 0.1)[0])
+    o = OrcFem(pts, t)
+    o.integrator(fixed)
+    g = FemIntegrator(pts, t, fixed, matrix_precision=fl.FB_MATRIX_F64)
+    obptr, obcol = o.blocks()
+    bptr, bcol = g.pattern()
+    assert np.array_equal(bptr, obptr) and np.array_equal(bcol, obcol)
+    u = rng.normal(size=o.r) * 0.003
+    fo, Ko = o.assemble(u)
+    fg, Kg = g.assemble(u)
+    assert np.abs(Kg - _oracle_bsr(o)(Ko)).max() <= 1e-9 * np.abs(Ko).max()
+    assert np.abs(fg - fo).max() <= 1e-9 * np.abs(fo).max()
+    f = np.zeros(o.r)
+    f[1::3] = -200.0
+    for _ in range(2):
+        o.set_external_forces(f)
+        g.set_external_forces(f)
+        io, ig = abs(o.step()), g.do_timestep()
+        assert abs(io - ig) <= max(3, 0.02 * io), (io, ig)
+    qo, vo = o.get_state()
+    qg, vg, _ = g.get_q_state()
+    assert np.abs(qg - qo).max() <= 2e-5 * np.abs(qo).max()
+    assert np.abs(vg - vo).max() <= 2e-4 * np.abs(vo).max()
