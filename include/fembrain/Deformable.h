@@ -141,6 +141,7 @@ class Deformable {
                                             m_timeStep, m_dampingMassCoeff, m_dampingStiffnessCoeff, 1e7, 0.46, 1000.0, m_device);
     m_q.assign(m_dof, 0.0); m_qVel.assign(m_dof, 0.0); m_arrExtForces.assign(m_dof, 0.0);
     m_bptr.clear(); m_bcol.clear();
+    m_restVolume = -1.0;
     return true;
   }
   void setMesh(int numVertices, const double* rest, int numElements, const int* elements) {
@@ -235,19 +236,70 @@ class Deformable {
   void resetDeformations() { m_lpIntegrator->ResetToRest(); m_vHapticForces.clear(); }
   void setDeformCallback(FOnApplyDeformations fOnDeform) { m_fOnDeform = fOnDeform; }
   double getSolverTime() const { return m_lpIntegrator->GetSystemSolveTime(); }
+  // Deformable::pickVertex (Deformable.cpp:422-428): closest vertex of the displaced mesh to a world position
+  int pickVertex(const vec3d& wpos, vec3d& vertex) {
+    m_lpIntegrator->GetqState(m_q.data(), nullptr, nullptr);
+    int best = -1;
+    double bd = 0.0;
+    for (size_t i = 0; i < m_rest.size() / 3; i++) {
+      const double dx = m_rest[3 * i] + m_q[3 * i] - wpos.x, dy = m_rest[3 * i + 1] + m_q[3 * i + 1] - wpos.y, dz = m_rest[3 * i + 2] + m_q[3 * i + 2] - wpos.z;
+      const double d = dx * dx + dy * dy + dz * dz;
+      if (best < 0 || d < bd) { best = (int)i; bd = d; }
+    }
+    if (best >= 0) { vertex.x = m_rest[3 * (size_t)best] + m_q[3 * (size_t)best]; vertex.y = m_rest[3 * (size_t)best + 1] + m_q[3 * (size_t)best + 1]; vertex.z = m_rest[3 * (size_t)best + 2] + m_q[3 * (size_t)best + 2]; }
+    return best;
+  }
+  // Deformable::pickVertices (Deformable.cpp:430-448)
+  int pickVertices(const vec3d& boxLo, const vec3d& boxHi, std::vector<vec3d>& arrFoundCoords, std::vector<int>& arrFoundIndices) {
+    m_lpIntegrator->GetqState(m_q.data(), nullptr, nullptr);
+    arrFoundCoords.clear(); arrFoundIndices.clear();
+    for (size_t i = 0; i < m_rest.size() / 3; i++) {
+      vec3d v = {m_rest[3 * i] + m_q[3 * i], m_rest[3 * i + 1] + m_q[3 * i + 1], m_rest[3 * i + 2] + m_q[3 * i + 2]};
+      if (v.x >= boxLo.x && v.x <= boxHi.x && v.y >= boxLo.y && v.y <= boxHi.y && v.z >= boxLo.z && v.z <= boxHi.z) {
+        arrFoundCoords.push_back(v);
+        arrFoundIndices.push_back((int)i);
+      }
+    }
+    return (int)arrFoundCoords.size();
+  }
+  // Deformable::hapticStart(const vec3d&) (Deformable.cpp:519-532): refuses a clamped vertex
+  bool hapticStart(const vec3d& wpos) {
+    vec3d vertex;
+    const int idx = pickVertex(wpos, vertex);
+    for (size_t i = 0; i < m_vFixedVertices.size(); i++)
+      if (m_vFixedVertices[i] == idx) { m_idxPulledVertex = idx; return false; }
+    return hapticStart(idx);
+  }
+  // Deformable::isVolumeChanged (Deformable.h:128); the rest volume is taken at the first call after a (re)build
+  bool isVolumeChanged() {
+    if (m_restVolume < 0.0) {
+      std::vector<double> keep(m_q);
+      std::fill(m_q.begin(), m_q.end(), 0.0);
+      m_restVolume = volumeOf(m_q);
+      m_q.swap(keep);
+    }
+    return std::abs(computeVolume() - m_restVolume) > 0.0001;
+  }
+  std::string getModelName() const { return m_strModelName; }
+  void setModelName(const std::string& name) { m_strModelName = name; }
   U32 getDof() const { return m_dof; }
   U32 getCollidedCount() const { return m_ctCollided; }
   HipIntegrator* integrator() { return m_lpIntegrator; }
   // Deformable::computeVolume (Deformable.cpp:260-279) on the current displaced positions
   double computeVolume(double* arrStore = nullptr, U32 count = 0) {
     m_lpIntegrator->GetqState(m_q.data(), nullptr, nullptr);
+    return volumeOf(m_q, arrStore, count);
+  }
+
+ private:
+  double volumeOf(const std::vector<double>& q, double* arrStore = nullptr, U32 count = 0) const {
     const U32 m = (U32)(m_elements.size() / 4);
     const bool store = arrStore != nullptr && count == m;
     double vol = 0.0;
     for (U32 e = 0; e < m; e++) {
       double p[4][3];
       for (int k = 0; k < 4; k++)
-        for (int d = 0; d < 3; d++) p[k][d] = m_rest[3 * (size_t)m_elements[4 * e + k] + d] + m_q[3 * (size_t)m_elements[4 * e + k] + d];
+        for (int d = 0; d < 3; d++) p[k][d] = m_rest[3 * (size_t)m_elements[4 * e + k] + d] + q[3 * (size_t)m_elements[4 * e + k] + d];
       const double u[3] = {p[0][0] - p[3][0], p[0][1] - p[3][1], p[0][2] - p[3][2]}, v[3] = {p[1][0] - p[3][0], p[1][1] - p[3][1], p[1][2] - p[3][2]},
                    w[3] = {p[2][0] - p[3][0], p[2][1] - p[3][1], p[2][2] - p[3][2]};
       const double cur = std::abs(u[0] * (v[1] * w[2] - v[2] * w[1]) + u[1] * (v[2] * w[0] - v[0] * w[2]) + u[2] * (v[0] * w[1] - v[1] * w[0])) / 6.0;
@@ -256,14 +308,12 @@ class Deformable {
     }
     return vol;
   }
-
- private:
   void init() {  // Deformable::init (Deformable.cpp:85-124)
     m_ctCollided = 0; m_fOnDeform = nullptr; m_idxPulledVertex = -1; m_bHapticInProgress = false;
     m_dampingMassCoeff = 0.0; m_dampingStiffnessCoeff = 0.01; m_timeStep = 0.0333; m_ctTimeStep = 0;
     m_hapticForceNeighorhoodSize = 5;  // DEFAULT_FORCE_NEIGHBORHOOD_SIZE, Deformable.h:41
     m_bApplyGravity = true;  // left uninitialised by the reference's init(); true is what its .sim files set
-    m_lpIntegrator = nullptr; m_hasFloor = false; m_floorY = 0.0; m_dof = 0;
+    m_lpIntegrator = nullptr; m_hasFloor = false; m_floorY = 0.0; m_dof = 0; m_restVolume = -1.0;
   }
   std::vector<double> m_rest;
   std::vector<int> m_elements;
@@ -275,7 +325,8 @@ class Deformable {
   U32 m_dof, m_ctCollided, m_ctTimeStep;
   int m_idxPulledVertex, m_device, m_hapticForceNeighorhoodSize;
   bool m_bHapticInProgress, m_bApplyGravity, m_hasFloor;
-  double m_dampingMassCoeff, m_dampingStiffnessCoeff, m_timeStep, m_floorY;
+  double m_dampingMassCoeff, m_dampingStiffnessCoeff, m_timeStep, m_floorY, m_restVolume;
+  std::string m_strModelName;
 };
 
 }  // namespace FEM

@@ -41,6 +41,17 @@ int main() {
   std::printf("CUBE_DOF=%u\nCUBE_CALLBACKS=%u\nCUBE_MAXQ=%.9g\nCUBE_VOL0=%.9g\nCUBE_VOL=%.9g\nCUBE_ITERS=%d\nCUBE_SOLVE_S=%.6g\n", d.getDof(), g_calls, g_maxq,
               vol0, d.computeVolume(), d.integrator()->GetLastIterations(), d.getSolverTime());
 
+  // picking / volume check on the displaced mesh
+  PS::FEM::vec3d far = {10.0, 0.2, 10.0}, hit;
+  const int picked = d.pickVertex(far, hit);            // nearest vertex to a far +x,+z point: the (n-1, j, n-1) corner column
+  PS::FEM::vec3d boxLo = {-1.0, -1.0, -1.0}, boxHi = {-0.24, 1.0, 1.0};
+  std::vector<PS::FEM::vec3d> found;
+  std::vector<int> foundIdx;
+  const int nbox = d.pickVertices(boxLo, boxHi, found, foundIdx);   // the clamped plane i = 0 (x = -0.25)
+  std::printf("PICKED=%d\nPICK_BOX=%d\nVOL_CHANGED=%d\nHAPTIC_FIXED=%d\n", picked, nbox, d.isVolumeChanged() ? 1 : 0,
+              d.hapticStart(PS::FEM::vec3d{-0.25, 0.0, -0.25}) ? 1 : 0);
+  d.hapticEnd();
+
   // sphere.blob -> GPUPoly -> tet mesh -> Deformable
   PS::SKETCH::LinearBlobTreeData blob;
   const float hdr[12] = {-0.5f, -0.5f, -0.5f, 1, 0.5f, 0.5f, 0.5f, 1, 1, 0, 1, 65535.0f};

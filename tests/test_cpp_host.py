@@ -45,6 +45,11 @@ def test_cpp_host_program_matches_oracle(gpu):
     assert abs(float(kv["CUBE_MAXQ"]) - np.abs(q).max()) <= 2e-4 * np.abs(q).max()
     assert abs(int(kv["CUBE_ITERS"]) - it) <= 3
     assert abs(float(kv["CUBE_VOL0"]) - 0.4 ** 3) < 1e-12
+    cur = v + q.reshape(-1, 3)
+    assert int(kv["PICKED"]) == int(np.argmin(((cur - np.array([10.0, 0.2, 10.0])) ** 2).sum(1)))
+    inbox = ((cur >= np.array([-1.0, -1.0, -1.0])) & (cur <= np.array([-0.24, 1.0, 1.0]))).all(1)
+    assert int(kv["PICK_BOX"]) == int(inbox.sum()) >= n * n   # the clamped plane and whatever sagged into the box
+    assert int(kv["VOL_CHANGED"]) == 1 and int(kv["HAPTIC_FIXED"]) == 0   # a clamped vertex cannot be pulled
     op = OrcPoly(sphere_blob())
     ox, ot, oc = op.run_tetrahedralizer(0.1)
     sx, sn, st = op.surface()
