@@ -378,9 +378,9 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
   CGState fin;
   memset(&fin, 0, sizeof fin);
   bool finished = false;
-  // replay pays on small meshes (11.5 vs 12.1 us per iteration at 105k tets) and costs a little on large ones (29.4 vs 29.1 at
-  // 1M); sharded kernels carry sequence numbers and are launched one by one
-  const bool graphable = h->use_graph && P.n_slices <= 4096 && (!h->comm || h->comm->n_ranks == 1);
+  // replay pays on small meshes only (us per iteration, replay vs launches: 8.2 vs 9.6 at 22k tets, 9.4 vs 9.8 at 105k,
+  // 13.1 vs 12.9 at 257k, 29.4 vs 29.1 at 1M); sharded kernels carry sequence numbers and are launched one by one
+  const bool graphable = h->use_graph && P.n_slices <= 512 && (!h->comm || h->comm->n_ranks == 1);
   while (!finished) {
     const int n = std::min(kBatch, max_iter - it + 1);
     bool replayed = false;
