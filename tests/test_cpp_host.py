@@ -58,3 +58,36 @@ def test_cpp_host_program_matches_oracle(gpu):
     assert int(kv["POLY_RUN"]) == 1 and int(kv["POLY_TETS"]) == len(ot) == 3744 and int(kv["POLY_VERTS"]) == len(ox)
     assert np.float32(kv["FIELD_025"]) == np.float32((1 - 0.0625) ** 3) and int(kv["GRID_POINTS"]) == 12 ** 3
     assert int(kv["BALL_FIXED"]) == int((ox[:, 1] < -0.35).sum()) and int(kv["BALL_ITERS"]) > 0
+
+
+def test_cpp_blob_and_veg_readers_match_the_python_readers(tmp_path):
+    """include/fembrain/BlobReader.h (for C++ hosts that do not link the reference's ModelReader / VolMeshIO) against
+    fembrain_amd/blobtree.py and meshgen.read_veg on every fixture model, instanced ones included.  Host only."""
+    import glob
+    from fembrain_amd.blobtree import read_blob
+    from fembrain_amd.meshgen import read_veg, truth_cube
+    from fembrain_amd.poly import write_veg
+    exe = os.path.join(ROOT, "tests", "cpp", "read_models")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "read_models.cpp"),
+                           "-o", exe, "-L", os.path.join(ROOT, "fembrain_amd"), "-lfembrain_hip", "-Wl,-rpath," + os.path.join(ROOT, "fembrain_amd")])
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "blob", "*.blob")))
+    assert len(files) >= 10
+    for f in files:
+        out = subprocess.check_output([exe, "blob", f], text=True)
+        arr = {ln.split()[0]: np.array(ln.split()[2:], dtype=np.float32) for ln in out.strip().splitlines()}
+        b = read_blob(f)
+        for name, want in (("header", b.header), ("ops", b.ops), ("prims", b.prims), ("mtx", b.mtx)):
+            want = np.asarray(want, np.float32).reshape(-1)
+            assert arr[name].shape == want.shape, (f, name)
+            assert np.allclose(arr[name], want, rtol=2e-6, atol=2e-6), (f, name, np.abs(arr[name] - want).max())
+    v, t = truth_cube(4, 4, 4, 0.1)
+    p = str(tmp_path / "cube.veg")
+    write_veg(p, v, t)
+    out = subprocess.check_output([exe, "veg", p], text=True).strip().splitlines()
+    cv = np.array(out[0].split()[2:], dtype=np.float64).reshape(-1, 3)
+    ce = np.array(out[1].split()[2:], dtype=np.int32).reshape(-1, 4)
+    pv, pt = read_veg(p)
+    assert np.array_equal(ce, pt) and np.array_equal(ce, t) and np.allclose(cv, pv, rtol=0, atol=1e-12)
+    bad = tmp_path / "bad.blob"
+    bad.write_text("[Global]\nFileVersion=6\nRootIDs=(0)\n[BLOBNODE 0]\nIsOperator=0\nPrimitiveType=TORUS\n")
+    assert subprocess.run([exe, "blob", str(bad)], capture_output=True, text=True).returncode == 1
