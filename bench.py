@@ -252,6 +252,7 @@ def main():
     spmv_bytes = g.spmv_bytes()
     asm_k_s = g.time_assembly(10)
     halo_s, sum_s = g.time_exchange(200) if dist_mode else (0.0, 0.0)
+    k0_s = g.time_element_stiffness(3)
     resync_ms = None
     if not dist_mode:  # Deformable::syncForceModel after a cut: host plan (pattern, SELL, contribution lists) + upload + rest state
         ts = time.perf_counter()
@@ -282,6 +283,10 @@ def main():
             "cg_iterations_per_step": float(np.mean(iters)), "assembly_ms_per_step": asm_s / args.steps * 1e3,
             "solve_ms_per_step": solve_s / args.steps * 1e3, "us_per_cg_iteration": solve_s / max(sum(iters), 1) * 1e6,
             "resync_ms": resync_ms,
+            # informational (north star: MFMA only for the batched 12x12 element contractions): forming every K0 = V B^T E B on the
+            # fp64 matrix cores; 2*(6*6*12 + 12*6*12) flop and 1152 B written per element.  The per-step path never forms K0.
+            "element_k0_mfma": {"us_per_pass": k0_s * 1e6, "gflops": 2592.0 * len(t) / k0_s / 1e9 if shard is None else None,
+                                "write_gbs": 1152.0 * len(t) / k0_s / 1e9 if shard is None else None},
             "exchange_us": {"halo_refresh": halo_s * 1e6, "global_sum_3": sum_s * 1e6},
             "assembly_kernels_us": asm_k_s * 1e6, "assembly_gbs": g.assembly_bytes() / asm_k_s / 1e9,
             "roofline": {"kernel": "k_spmv (SELL-64 3x3-block SpMV of the PCG)", "bound": "hbm",

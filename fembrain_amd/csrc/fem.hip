@@ -895,6 +895,31 @@ int fb_fem_element_stiffness(fb_fem_t h, int first, int count, double* K0, doubl
   return FB_OK;
 }
 
+int fb_fem_time_element_stiffness(fb_fem_t h, int reps, double* seconds_per_pass) {
+  CHECK_HANDLE(h);
+  if (reps < 1 || !seconds_per_pass) return fail(FB_EINVAL, "bad arguments");
+  const int kChunk = 1 << 16, nt = h->plan.n_tets;
+  DevBuf<double> dK;
+  FB_TRY(dK.alloc((size_t)144 * std::min(nt, kChunk)));  // the 1.15 GB of a 1M-tet K0 set are produced chunk by chunk into the same scratch
+  auto pass = [&]() {
+    for (int done = 0; done < nt; done += kChunk) {
+      const int n = std::min(kChunk, nt - done);
+      hipLaunchKernelGGL(k_element_K0_mfma, dim3(ceil_div(n, kWavesPerBlock)), dim3(kBlock), 0, h->stream, done, n, h->rest.p, h->lambda, h->mu, dK.p,
+                         (double*)nullptr, h->x0.p, h->tets.p);
+    }
+  };
+  pass();
+  FB_HIP(hipEventRecord(h->ev[0], h->stream));
+  for (int r = 0; r < reps; r++) pass();
+  FB_HIP(hipEventRecord(h->ev[1], h->stream));
+  FB_HIP(hipStreamSynchronize(h->stream));
+  FB_HIP(hipGetLastError());
+  float ms = 0;
+  FB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  *seconds_per_pass = ms * 1e-3 / reps;
+  return FB_OK;
+}
+
 int fb_fem_assemble(fb_fem_t h, const double* u, double* f, double* K_blocks) {
   CHECK_HANDLE(h);
   if (!u) return fail(FB_EINVAL, "null displacement");

@@ -51,6 +51,12 @@ class FemIntegrator:
         self.last = _l.StepInfo()
 
     # -- life cycle --
+    def time_element_stiffness(self, reps=5):
+        """Seconds to form K0 = V B^T E B of every element with the fp64 MFMA kernel (inspection path)."""
+        a = C.c_double(0)
+        _l.check(self._L.fb_fem_time_element_stiffness(self.h, reps, C.byref(a)))
+        return a.value
+
     def time_exchange(self, reps=100):
         """(seconds per halo refresh, seconds per 3-scalar global sum); collective on a sharded handle."""
         a, b = C.c_double(0), C.c_double(0)

@@ -120,6 +120,7 @@ def lib():
         "fb_fem_transport": (C.c_int, [vp]),
         "fb_fem_set_exchange_mode": (C.c_int, [vp, C.c_int]),
         "fb_fem_time_exchange": (C.c_int, [vp, C.c_int, _dp, _dp]),
+        "fb_fem_time_element_stiffness": (C.c_int, [vp, C.c_int, _dp]),
         "fb_poly_create": (C.c_int, [C.POINTER(vp), C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp]),
         "fb_poly_destroy": (C.c_int, [vp]),
         "fb_poly_field_array": (C.c_int, [vp, C.c_int, _fp]),

@@ -181,6 +181,10 @@ int fb_fem_time_assembly(fb_fem_t h, int reps, double* seconds_per_assembly);
  * a 3-vector and of one 3-scalar global sum, back to back on the handle's stream -- the two exchanges of a PCG
  * iteration, through whichever transport fb_fem_transport() reports.  Both 0 on an unsharded handle. */
 int fb_fem_time_exchange(fb_fem_t h, int reps, double* seconds_per_halo, double* seconds_per_sum);
+/* average device seconds of forming K0 = V B^T E B for ALL elements with the fp64 MFMA kernel behind
+ * fb_fem_element_stiffness (results go to a device scratch, nothing is copied out): what materialising the reference's
+ * KElementUndeformed array would cost per rebuild; the per-step path never forms K0. */
+int fb_fem_time_element_stiffness(fb_fem_t h, int reps, double* seconds_per_pass);
 /* algorithmic bytes moved by one SpMV launch / one assembly on this handle */
 int fb_fem_spmv_bytes(fb_fem_t h, double* bytes);
 int fb_fem_assembly_bytes(fb_fem_t h, double* bytes);
