@@ -849,6 +849,23 @@ __global__ __launch_bounds__(kPB) void k_surface_elements(Grid G, long long ntri
   o[0] = id[0]; o[1] = id[1]; o[2] = id[2];
 }
 
+// ComputeOffSurfacePointsAndFields (Polygonizer.cl:1329-1350): v +- len * normal and the field there, (x, y, z, f) pairs
+__global__ __launch_bounds__(kPB) void k_off_surface(long long nv, float len, const float* __restrict__ pos, const float* __restrict__ nrm,
+                                                     const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
+                                                     const float* __restrict__ mtx, float4* __restrict__ out) {
+  extern __shared__ float stack[];
+  const long long j = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (j >= nv) return;
+  const float vx = pos[3 * j], vy = pos[3 * j + 1], vz = pos[3 * j + 2];
+  const float dx = len * nrm[3 * j], dy = len * nrm[3 * j + 1], dz = len * nrm[3 * j + 2];
+  float* stk = stack + threadIdx.x;
+  const float ox = vx + dx, oy = vy + dy, oz = vz + dz, ix = vx - dx, iy = vy - dy, iz = vz - dz;
+  const float fo = eval_field(prog, n_instr, n_prims, prims, mtx, ox, oy, oz, stk);
+  const float fi = eval_field(prog, n_instr, n_prims, prims, mtx, ix, iy, iz, stk);
+  out[2 * j] = make_float4(ox, oy, oz, fo);
+  out[2 * j + 1] = make_float4(ix, iy, iz, fi);
+}
+
 // surface vertex = rest + da + t (db - da): the FEM displacements of the two tet-mesh nodes of its grid edge, weighted as
 // the vertex itself was placed on the edge
 __global__ __launch_bounds__(kPB) void k_interpolate_displacements(long long nv, const float* __restrict__ rest, const uint2* __restrict__ ends,
@@ -1531,6 +1548,20 @@ int fb_poly_apply_displacements(fb_poly_t h, int mesh, int n_dof, const double* 
   if (xyz_out) return h->deformed.download(xyz_out, (size_t)n, h->stream);
   FB_HIP(hipStreamSynchronize(h->stream));
   return FB_OK;
+}
+
+int fb_poly_off_surface(fb_poly_t h, float len, float* xyzf_pairs) {
+  CHECK_POLY(h);
+  if (!h->surfaced) return fail(FB_EINVAL, "run fb_poly_surface first");
+  if (!xyzf_pairs) return fail(FB_EINVAL, "null output");
+  const long long nv = h->counts.n_surface_vertices;
+  if (nv == 0) return FB_OK;
+  DevBuf<float4> out;
+  FB_TRY(out.alloc((size_t)(2 * nv)));
+  hipLaunchKernelGGL(k_off_surface, dim3((int)((nv + kPB - 1) / kPB)), dim3(kPB), stack_bytes(h), h->stream, nv, len, h->sv.p, h->sn.p, h->d_prog.p,
+                     (int)h->prog.size(), h->n_prims, h->d_prims.p, h->d_mtx.p, out.p);
+  FB_HIP(hipGetLastError());
+  return out.download((float4*)xyzf_pairs, (size_t)(2 * nv), h->stream);
 }
 
 int fb_poly_time_surface(fb_poly_t h, int reps, double* seconds) {

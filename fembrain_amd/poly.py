@@ -149,6 +149,12 @@ class GpuPoly:
         _l.check(self._L.fb_poly_read_surface_binding(self.h, _l.uptr(pairs), _l.fptr(w)))
         return pairs, w
 
+    # GPUPoly::computeOffSurfacePointsAndFields
+    def compute_off_surface_points_and_fields(self, length):
+        out = np.empty((2 * self.counts.n_surface_vertices, 4), np.float32)
+        _l.check(self._L.fb_poly_off_surface(self.h, length, _l.fptr(out)))
+        return out
+
     def time_surface(self, reps=5):
         a = C.c_double(0)
         _l.check(self._L.fb_poly_time_surface(self.h, reps, C.byref(a)))

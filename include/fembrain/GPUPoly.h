@@ -71,6 +71,12 @@ class GPUPoly {
     verticesXYZ.resize(3 * (size_t)ctVertices); normals.resize(3 * (size_t)ctVertices);
     return fb_poly_read_surface(h_, verticesXYZ.data(), normals.data(), nullptr) == FB_OK;
   }
+  // GPUPoly::computeOffSurfacePointsAndFields (OclPolygonizer.cpp:1045-1107); `interval` is unused there as well
+  int computeOffSurfacePointsAndFields(U32 /*interval*/, float len, U32& ctOutVertices, std::vector<float>& outOffSurfacePoints) {
+    ctOutVertices = 2 * (U32)m_counts.n_surface_vertices;
+    outOffSurfacePoints.resize(4 * (size_t)ctOutVertices);
+    return fb_poly_off_surface(h_, len, outOffSurfacePoints.data()) == FB_OK ? 1 : -1;
+  }
   // GPUPoly::applyFemDisplacements (OclPolygonizer.cpp:1543-1596) on the surface mesh; `deformed` receives what the
   // reference writes into its vertex VBO
   bool applyFemDisplacements(U32 dof, const double* displacements, std::vector<float>* deformed = nullptr, int mesh = FB_MESH_SURFACE) {

@@ -278,6 +278,10 @@ int fb_poly_interpolate_displacements(fb_poly_t h, int n_tet_dof, const double* 
 /* per surface vertex: the pair (a, b) of tet-mesh vertex ids and the weight t (either may be NULL) */
 int fb_poly_read_surface_binding(fb_poly_t h, unsigned int* tet_vertex_pairs, float* weights);
 
+/* GPUPoly::computeOffSurfacePointsAndFields (OclPolygonizer.cpp:1045-1107; kernel Polygonizer.cl:1329-1350): for every
+ * surface vertex v with normal n the two points v + len n and v - len n with their field values; xyzf_pairs receives
+ * 8 floats per vertex (x, y, z, f outside then inside).  Needs fb_poly_surface. */
+int fb_poly_off_surface(fb_poly_t h, float len, float* xyzf_pairs);
 /* average device seconds of the surface pass (counts + scans + vertex attributes + elements) on the current grid */
 int fb_poly_time_surface(fb_poly_t h, int reps, double* seconds);
 /* average device seconds of one sweep / one classify+tetrahedralize pipeline on the current grid */

@@ -385,3 +385,20 @@ def test_sweep_culling_changes_no_value(gpu, name):
     g.sweep_grid(lo - pad, 2 * cell, dims)
     grid = g.read_grid()
     assert np.array_equal(g.compute_field_array(grid)[:, 3], grid[:, 3])
+
+
+def test_off_surface_points_and_fields(gpu):
+    """GPUPoly::computeOffSurfacePointsAndFields: v +- len n with the field there; against numpy fp32 + the oracle's field."""
+    blob = _trees()["two_ranges"]
+    g, o = GpuPoly(blob), OrcPoly(blob)
+    g.sweep(0.09)
+    g.classify()
+    g.surface()
+    xyz, nrm, _ = g.read_surface()
+    got = g.compute_off_surface_points_and_fields(0.05)
+    d = np.float32(0.05) * nrm
+    want = np.empty_like(got)
+    want[0::2, :3], want[1::2, :3] = xyz + d, xyz - d
+    want[:, 3] = o.field_array(np.concatenate([want[:, :3], np.zeros((len(want), 1), np.float32)], 1))[:, 3]
+    assert np.array_equal(got, want)
+    assert (got[0::2, 3] < 0.5).mean() > 0.95 and (got[1::2, 3] > 0.5).mean() > 0.95   # outside / inside of the iso-surface
