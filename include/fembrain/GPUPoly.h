@@ -112,6 +112,22 @@ class GPUPoly {
   }
   vec4u voxelGridDim() const { vec4u d = {(U32)m_counts.grid[0], (U32)m_counts.grid[1], (U32)m_counts.grid[2], (U32)m_counts.n_points}; return d; }
   U32 countSurfaceVoxels() const { return (U32)m_counts.n_surface_cells; }
+  // GPUPoly::surfaceVoxels (filled by run(), OclPolygonizer.cpp:698-721): lower corners (x, y, z) of the cells the surface
+  // crosses, in the reference's order (x outermost, z innermost); `lower` = model box lower corner (header[0..2])
+  std::vector<float> surfaceVoxels(const float lower[3]) const {
+    std::vector<float> out;
+    std::vector<U8> cfg((size_t)m_counts.n_cells);
+    if (cfg.empty() || fb_poly_read_classification(h_, nullptr, nullptr, cfg.data()) != FB_OK) return out;
+    const int cx = m_counts.grid[0] - 1, cy = m_counts.grid[1] - 1, cz = m_counts.grid[2] - 1;
+    out.reserve(3 * (size_t)m_counts.n_surface_cells);
+    for (int i = 0; i < cx; i++)
+      for (int j = 0; j < cy; j++)
+        for (int k = 0; k < cz; k++) {
+          const U8 c = cfg[(size_t)k * cx * cy + (size_t)j * cx + i];
+          if (c != 0 && c != 255) { out.push_back(lower[0] + i * m_cellsize); out.push_back(lower[1] + j * m_cellsize); out.push_back(lower[2] + k * m_cellsize); }
+        }
+    return out;
+  }
   const fb_poly_counts& counts() const { return m_counts; }
 
   // GPUPoly::storeTetMeshInVegaFormat (OclPolygonizer.cpp:1651-1694)

@@ -75,6 +75,9 @@ int main() {
   poly.readBackNormals(sv, sxyz, snrm);
   std::vector<double> shift(3 * (size_t)sv, 0.25);
   const bool applied = poly.applyFemDisplacements(3 * sv, shift.data(), &moved);
+  const float lower[3] = {hdr[0], hdr[1], hdr[2]};
+  const std::vector<float> vox = poly.surfaceVoxels(lower);
+  std::printf("SURF_VOXELS=%zu\nSURF_VOXELS_COUNT=%u\n", vox.size() / 3, poly.countSurfaceVoxels());
   std::printf("SURF_VERTS=%u\nSURF_TRIS=%u\nSURF_APPLIED=%d\nSURF_SHIFT=%.9g\n", sv, st, applied ? 1 : 0, sv ? moved[0] - sxyz[0] : 0.0f);
   PS::SKETCH::FieldComputer fc(blob);
   std::printf("FIELD_025=%.9g\nGRID_POINTS=%d\n", fc.field(0.25f, 0, 0), fc.fieldsForVoxelGrid(0.1f));

@@ -55,6 +55,7 @@ def test_cpp_host_program_matches_oracle(gpu):
     sx, sn, st = op.surface()
     assert int(kv["SURF_VERTS"]) == len(sx) and int(kv["SURF_TRIS"]) == len(st) and int(kv["SURF_APPLIED"]) == 1
     assert abs(float(kv["SURF_SHIFT"]) - 0.25) < 1e-6
+    assert int(kv["SURF_VOXELS"]) == int(kv["SURF_VOXELS_COUNT"]) == int(((op.config != 0) & (op.config != 255)).sum())
     assert int(kv["POLY_RUN"]) == 1 and int(kv["POLY_TETS"]) == len(ot) == 3744 and int(kv["POLY_VERTS"]) == len(ox)
     assert np.float32(kv["FIELD_025"]) == np.float32((1 - 0.0625) ** 3) and int(kv["GRID_POINTS"]) == 12 ** 3
     assert int(kv["BALL_FIXED"]) == int((ox[:, 1] < -0.35).sum()) and int(kv["BALL_ITERS"]) > 0
