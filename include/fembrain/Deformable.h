@@ -85,15 +85,65 @@ class HipIntegrator {
     r_ = 3 * numVertices;
   }
   fb_fem_t handle() const { return h_; }
-
- private:
   static void check(int rc) {
     if (rc != FB_OK) throw std::runtime_error(std::string("fembrain_hip: ") + fb_last_error());
   }
+
+ private:
   int r_;
   fb_fem_t h_;
   fb_fem_params prm_;
   fb_step_info info_;
+};
+
+// ---- the narrower VegaFEM seams, for hosts that keep their own integrator -------------------------
+// ForceModel (vegafem/forceModel/forceModel.h:42-67) over a HipIntegrator's handle: internal force and tangent stiffness
+// at a displacement u.  The matrix comes as 3x3 blocks on the node-level pattern (bptr / bcol, ascending columns per row
+// = the block rows of the reference's SparseMatrix, sparseMatrix.cpp:238-262), 9 row-major values per block.
+class HipForceModel {
+ public:
+  explicit HipForceModel(HipIntegrator* integrator) : in_(integrator) {}
+  int Getr() const { return in_->Getr(); }
+  void GetInternalForce(double* u, double* internalForces) { HipIntegrator::check(fb_fem_assemble(in_->handle(), u, internalForces, nullptr)); }
+  // GetTangentStiffnessMatrixTopology: callee-allocated in the reference; here the caller's vectors are filled
+  void GetTangentStiffnessMatrixTopology(std::vector<int>& bptr, std::vector<int>& bcol) {
+    bptr.resize((size_t)fb_fem_num_nodes(in_->handle()) + 1);
+    bcol.resize((size_t)fb_fem_num_blocks(in_->handle()));
+    HipIntegrator::check(fb_fem_pattern(in_->handle(), bptr.data(), bcol.data()));
+  }
+  void GetTangentStiffnessMatrix(double* u, std::vector<double>& blocks) {
+    blocks.resize(9 * (size_t)fb_fem_num_blocks(in_->handle()));
+    HipIntegrator::check(fb_fem_assemble(in_->handle(), u, nullptr, blocks.data()));
+  }
+  void GetForceAndMatrix(double* u, double* internalForces, std::vector<double>& blocks) {
+    blocks.resize(9 * (size_t)fb_fem_num_blocks(in_->handle()));
+    HipIntegrator::check(fb_fem_assemble(in_->handle(), u, internalForces, blocks.data()));
+  }
+
+ private:
+  HipIntegrator* in_;
+};
+
+// LinearSolver (vegafem/sparseSolver/linearSolver.h:44-53) + CGSolver's Jacobi-PCG entry (CGSolver.cpp:129-190) on the
+// system the handle assembled last (Keff of the current state): returns the reference's code, > 0 iterations when
+// converged, < 0 when not.
+class HipCGSolver {
+ public:
+  explicit HipCGSolver(HipIntegrator* integrator) : in_(integrator) {}
+  int SolveLinearSystemWithJacobiPreconditioner(double* x, const double* b, double eps, int maxIterations) {
+    int it = 0;
+    HipIntegrator::check(fb_fem_pcg(in_->handle(), b, x, eps, maxIterations, &it));
+    return it;
+  }
+  int SolveLinearSystem(double* x, const double* rhs) { return SolveLinearSystemWithJacobiPreconditioner(x, rhs, 1e-6, 10000) > 0 ? 0 : 1; }
+  // CGSolver's C hook `typedef void (*blackBoxProductType)(const void* data, const double* x, double* Ax)` (CGSolver.h:65-66):
+  // pass HipCGSolver::BlackBoxProduct with data = the HipIntegrator to run the reference's own CG on the device SpMV
+  static void BlackBoxProduct(const void* data, const double* x, double* Ax) {
+    HipIntegrator::check(fb_fem_spmv(static_cast<const HipIntegrator*>(data)->handle(), x, Ax));
+  }
+
+ private:
+  HipIntegrator* in_;
 };
 
 class Deformable {

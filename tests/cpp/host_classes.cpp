@@ -41,6 +41,28 @@ int main() {
   std::printf("CUBE_DOF=%u\nCUBE_CALLBACKS=%u\nCUBE_MAXQ=%.9g\nCUBE_VOL0=%.9g\nCUBE_VOL=%.9g\nCUBE_ITERS=%d\nCUBE_SOLVE_S=%.6g\n", d.getDof(), g_calls, g_maxq,
               vol0, d.computeVolume(), d.integrator()->GetLastIterations(), d.getSolverTime());
 
+  // the narrower VegaFEM seams on the same handle: force model, black-box product, CG solver
+  {
+    PS::FEM::HipForceModel fm(d.integrator());
+    PS::FEM::HipCGSolver cg(d.integrator());
+    const int r = fm.Getr();
+    std::vector<double> u(r, 0.0), f(r, 0.0), blocks, x(r, 0.0), ax(r, 0.0), b(r, 0.0);
+    std::vector<int> bptr, bcol;
+    for (int i = 0; i < r; i++) u[i] = 1e-3 * std::sin(0.37 * i);
+    fm.GetTangentStiffnessMatrixTopology(bptr, bcol);
+    fm.GetForceAndMatrix(u.data(), f.data(), blocks);
+    double fn = 0, kn = 0;
+    for (int i = 0; i < r; i++) fn += f[i] * f[i];
+    for (size_t i = 0; i < blocks.size(); i++) kn += blocks[i] * blocks[i];
+    for (int i = 0; i < r; i++) b[i] = std::cos(0.11 * i);
+    const int it = cg.SolveLinearSystemWithJacobiPreconditioner(x.data(), b.data(), 1e-8, 5000);   // Keff of the last step
+    PS::FEM::HipCGSolver::BlackBoxProduct(d.integrator(), x.data(), ax.data());
+    double res = 0, bn = 0;
+    for (int i = 0; i < r; i++) { res += (ax[i] - b[i]) * (ax[i] - b[i]); bn += b[i] * b[i]; }
+    std::printf("SEAM_BLOCKS=%zu\nSEAM_FNORM=%.12g\nSEAM_KNORM=%.12g\nSEAM_CG_ITERS=%d\nSEAM_RESIDUAL=%.3g\n", bcol.size(), std::sqrt(fn), std::sqrt(kn), it,
+                std::sqrt(res / bn));
+  }
+
   // picking / volume check on the displaced mesh
   PS::FEM::vec3d far = {10.0, 0.2, 10.0}, hit;
   const int picked = d.pickVertex(far, hit);            // nearest vertex to a far +x,+z point: the (n-1, j, n-1) corner column

@@ -45,6 +45,14 @@ def test_cpp_host_program_matches_oracle(gpu):
     assert abs(float(kv["CUBE_MAXQ"]) - np.abs(q).max()) <= 2e-4 * np.abs(q).max()
     assert abs(int(kv["CUBE_ITERS"]) - it) <= 3
     assert abs(float(kv["CUBE_VOL0"]) - 0.4 ** 3) < 1e-12
+    # ForceModel / CGSolver seams: force and stiffness norms at u = 1e-3 sin(0.37 i) against the oracle; the PCG solution
+    # of Keff x = b (constrained rows are identity) satisfies the system through the black-box product
+    uu = 1e-3 * np.sin(0.37 * np.arange(o.r))
+    fo, Ko = o.assemble(uu)
+    assert int(kv["SEAM_BLOCKS"]) == len(o.blocks()[1])
+    assert abs(float(kv["SEAM_FNORM"]) - np.linalg.norm(fo)) <= 1e-9 * np.linalg.norm(fo)
+    assert abs(float(kv["SEAM_KNORM"]) - np.linalg.norm(Ko)) <= 5e-7 * np.linalg.norm(Ko)
+    assert int(kv["SEAM_CG_ITERS"]) > 0 and float(kv["SEAM_RESIDUAL"]) < 1e-6
     cur = v + q.reshape(-1, 3)
     assert int(kv["PICKED"]) == int(np.argmin(((cur - np.array([10.0, 0.2, 10.0])) ** 2).sum(1)))
     inbox = ((cur >= np.array([-1.0, -1.0, -1.0])) & (cur <= np.array([-0.24, 1.0, 1.0]))).all(1)
