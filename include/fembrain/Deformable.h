@@ -71,6 +71,26 @@ class HipIntegrator {
     check(fb_fem_set_constrained_dofs(h_, num, arr));
     return true;
   }
+  // IntegratorBaseSparse::GetTotalMass / GetKineticEnergy (integratorBaseSparse.cpp:63-71): sum of the entries of the
+  // inflated consistent mass matrix, and 1/2 qvel^T M qvel -- host arithmetic on the mass blocks (not on the step path)
+  double GetTotalMass() {
+    loadMass();
+    double s = 0.0;
+    for (size_t k = 0; k < mass_.size(); k++) s += mass_[k];
+    return 3.0 * s;
+  }
+  double GetKineticEnergy() {
+    loadMass();
+    std::vector<double> v((size_t)r_);
+    check(fb_fem_get_state(h_, nullptr, v.data(), nullptr));
+    double e = 0.0;
+    for (size_t a = 0; a + 1 < bptr_.size(); a++)
+      for (int k = bptr_[a]; k < bptr_[a + 1]; k++) {
+        const size_t b = (size_t)bcol_[k];
+        e += mass_[k] * (v[3 * a] * v[3 * b] + v[3 * a + 1] * v[3 * b + 1] + v[3 * a + 2] * v[3 * b + 2]);
+      }
+    return 0.5 * e;
+  }
   double GetForceAssemblyTime() const { return info_.assembly_seconds; }
   double GetSystemSolveTime() const { return info_.solve_seconds; }
   int GetLastIterations() const { return info_.cg_iterations; }
@@ -81,6 +101,7 @@ class HipIntegrator {
   }
   void RebuildElements() { check(fb_fem_rebuild_elements(h_)); }
   void Resync(int numVertices, const double* rest, int numElements, const int* elements, int nFixed, const int* fixed) {
+    mass_.clear(); bptr_.clear(); bcol_.clear();
     check(fb_fem_resync(h_, numVertices, rest, numElements, elements, nFixed, fixed));
     r_ = 3 * numVertices;
   }
@@ -90,6 +111,16 @@ class HipIntegrator {
   }
 
  private:
+  void loadMass() {
+    if (!mass_.empty()) return;
+    bptr_.resize((size_t)fb_fem_num_nodes(h_) + 1);
+    bcol_.resize((size_t)fb_fem_num_blocks(h_));
+    mass_.resize(bcol_.size());
+    check(fb_fem_pattern(h_, bptr_.data(), bcol_.data()));
+    check(fb_fem_mass(h_, mass_.data()));
+  }
+  std::vector<int> bptr_, bcol_;
+  std::vector<double> mass_;
   int r_;
   fb_fem_t h_;
   fb_fem_params prm_;

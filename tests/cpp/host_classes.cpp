@@ -59,6 +59,7 @@ int main() {
     PS::FEM::HipCGSolver::BlackBoxProduct(d.integrator(), x.data(), ax.data());
     double res = 0, bn = 0;
     for (int i = 0; i < r; i++) { res += (ax[i] - b[i]) * (ax[i] - b[i]); bn += b[i] * b[i]; }
+    std::printf("TOTAL_MASS=%.12g\nKINETIC=%.12g\n", d.integrator()->GetTotalMass(), d.integrator()->GetKineticEnergy());
     std::printf("SEAM_BLOCKS=%zu\nSEAM_FNORM=%.12g\nSEAM_KNORM=%.12g\nSEAM_CG_ITERS=%d\nSEAM_RESIDUAL=%.3g\n", bcol.size(), std::sqrt(fn), std::sqrt(kn), it,
                 std::sqrt(res / bn));
   }

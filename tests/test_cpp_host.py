@@ -53,6 +53,14 @@ def test_cpp_host_program_matches_oracle(gpu):
     assert abs(float(kv["SEAM_FNORM"]) - np.linalg.norm(fo)) <= 1e-9 * np.linalg.norm(fo)
     assert abs(float(kv["SEAM_KNORM"]) - np.linalg.norm(Ko)) <= 5e-7 * np.linalg.norm(Ko)
     assert int(kv["SEAM_CG_ITERS"]) > 0 and float(kv["SEAM_RESIDUAL"]) < 1e-6
+    # IntegratorBaseSparse::GetTotalMass = 3 rho V (inflated consistent mass), GetKineticEnergy = 1/2 qvel^T M qvel
+    assert abs(float(kv["TOTAL_MASS"]) - 3 * 1000.0 * 0.4 ** 3) < 1e-6 * 192
+    import scipy.sparse as sp
+    ia, ja = o.csr()
+    M = sp.csr_matrix((o.mass_on_pattern(), ja, ia), shape=(o.r, o.r))
+    _, qv = o.get_state()
+    ke = 0.5 * qv @ (M @ qv)
+    assert abs(float(kv["KINETIC"]) - ke) <= 1e-3 * ke
     cur = v + q.reshape(-1, 3)
     assert int(kv["PICKED"]) == int(np.argmin(((cur - np.array([10.0, 0.2, 10.0])) ** 2).sum(1)))
     inbox = ((cur >= np.array([-1.0, -1.0, -1.0])) & (cur <= np.array([-0.24, 1.0, 1.0]))).all(1)
