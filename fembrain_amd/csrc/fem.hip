@@ -835,6 +835,18 @@ int fb_fem_set_damping(fb_fem_t h, double damping_mass, double damping_stiffness
   return FB_OK;
 }
 
+int fb_fem_set_internal_force_scaling(fb_fem_t h, double factor) {
+  CHECK_HANDLE(h);
+  if (!(factor > 0) || !std::isfinite(factor)) return fail(FB_EINVAL, "internal force scaling factor must be positive");
+  // f_int and K are linear in Young's modulus, so scaling both (integratorBase.cpp:46, implicitNewmarkSparse.cpp:200-204;
+  // PS_VolumeConservingIntegrator.cpp:84-90) is scaling the Lame parameters the element kernels use
+  const double E = h->prm.E * factor, nu = h->prm.nu;
+  h->lambda = (nu * E) / ((1 + nu) * (1 - 2 * nu));
+  h->mu = E / (2 * (1 + nu));
+  h->system_valid = false;
+  return FB_OK;
+}
+
 int fb_fem_set_cg(fb_fem_t h, double eps, int max_iter) {
   CHECK_HANDLE(h);
   if (!(eps > 0) || max_iter < 0) return fail(FB_EINVAL, "bad PCG parameters");

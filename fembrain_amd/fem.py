@@ -132,6 +132,9 @@ class FemIntegrator:
     def set_damping(self, mass_coef, stiffness_coef):
         _l.check(self._L.fb_fem_set_damping(self.h, mass_coef, stiffness_coef))
 
+    def set_internal_force_scaling_factor(self, factor):
+        _l.check(self._L.fb_fem_set_internal_force_scaling(self.h, factor))
+
     def set_cg(self, eps, max_iter):
         _l.check(self._L.fb_fem_set_cg(self.h, eps, max_iter))
 

@@ -90,6 +90,7 @@ def lib():
         "fb_fem_reset": (C.c_int, [vp]),
         "fb_fem_set_timestep": (C.c_int, [vp, C.c_double]),
         "fb_fem_set_damping": (C.c_int, [vp, C.c_double, C.c_double]),
+        "fb_fem_set_internal_force_scaling": (C.c_int, [vp, C.c_double]),
         "fb_fem_set_cg": (C.c_int, [vp, C.c_double, C.c_int]),
         "fb_fem_set_constrained_dofs": (C.c_int, [vp, C.c_int, _ip]),
         "fb_fem_floor_collision": (C.c_int, [vp, C.c_double, C.c_double, _ip]),

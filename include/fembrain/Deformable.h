@@ -66,6 +66,7 @@ class HipIntegrator {
   double GetTimestep() const { return prm_.timestep; }
   void SetDampingMassCoef(double c) { prm_.damping_mass = c; check(fb_fem_set_damping(h_, prm_.damping_mass, prm_.damping_stiffness)); }
   void SetDampingStiffnessCoef(double c) { prm_.damping_stiffness = c; check(fb_fem_set_damping(h_, prm_.damping_mass, prm_.damping_stiffness)); }
+  void SetInternalForceScalingFactor(double f) { check(fb_fem_set_internal_force_scaling(h_, f)); }
   bool setConstrainedDOF(int num, int* arr) {
     if (num == 0 || arr == nullptr) return false;  // integratorBaseSparse.cpp:73-75
     check(fb_fem_set_constrained_dofs(h_, num, arr));

@@ -138,6 +138,9 @@ int fb_fem_set_state(fb_fem_t h, const double* q, const double* qvel, const doub
 int fb_fem_reset(fb_fem_t h);
 int fb_fem_set_timestep(fb_fem_t h, double timestep);
 int fb_fem_set_damping(fb_fem_t h, double damping_mass, double damping_stiffness);
+/* IntegratorBase::SetInternalForceScalingFactor (integratorBase.h; default 1): internal forces and tangent stiffness
+ * are multiplied by `factor` from the next assembly on (both are linear in Young's modulus, which is what is scaled) */
+int fb_fem_set_internal_force_scaling(fb_fem_t h, double factor);
 int fb_fem_set_cg(fb_fem_t h, double eps, int max_iter);
 /* IntegratorBaseSparse::setConstrainedDOF (integratorBaseSparse.cpp:73-87) -- takes effect at the next step
  * (the mask is applied when Keff is formed, so unlike the reference no stale systemMatrix can survive) */

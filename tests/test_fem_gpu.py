@@ -577,3 +577,22 @@ def test_random_delaunay_mesh(gpu):
     qg, vg, _ = g.get_q_state()
     assert np.abs(qg - qo).max() <= 2e-5 * np.abs(qo).max()
     assert np.abs(vg - vo).max() <= 2e-4 * np.abs(vo).max()
+
+
+def test_internal_force_scaling_factor(gpu):
+    """IntegratorBase::SetInternalForceScalingFactor: f_int and K times s == a body of Young's modulus s E."""
+    v, t, fixed = _cube(5)
+    rng = np.random.default_rng(2)
+    u = rng.normal(size=3 * len(v)) * 0.004
+    g = FemIntegrator(v, t, fixed, matrix_precision=fl.FB_MATRIX_F64)
+    f1, K1 = g.assemble(u)
+    g.set_internal_force_scaling_factor(0.25)
+    f2, K2 = g.assemble(u)
+    assert np.abs(f2 - 0.25 * f1).max() <= 1e-12 * np.abs(f1).max() and np.abs(K2 - 0.25 * K1).max() <= 1e-12 * np.abs(K1).max()
+    soft = FemIntegrator(v, t, fixed, matrix_precision=fl.FB_MATRIX_F64, E=0.25e7)
+    for h in (g, soft):
+        h.set_uniform_force(1, -500.0)
+        h.do_timestep()
+    assert np.abs(g.get_q_state()[0] - soft.get_q_state()[0]).max() <= 1e-9 * np.abs(soft.get_q_state()[0]).max()
+    with pytest.raises(fl.FbError):
+        g.set_internal_force_scaling_factor(0.0)
