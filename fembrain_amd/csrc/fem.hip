@@ -80,7 +80,7 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
   FB_TRY(h->colidx.upload(P.colidx, s));
   FB_TRY(h->slot_coff.upload(P.slot_coff, s));
   FB_TRY(h->slot_ccnt.upload(P.slot_ccnt, s));
-  FB_TRY(h->contrib.upload(P.contrib, s));
+  FB_TRY(h->contrib.upload(P.contrib.data(), P.contrib.size(), s));
   FB_TRY(h->dofmask.upload(P.dofmask, s));
   if (!P.send_local.empty()) FB_TRY(h->send_local.upload(P.send_local, s));
   FB_TRY(h->sendbuf.alloc(std::max<size_t>(1, (size_t)12 * P.send_local.size())));

@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
+#include <thread>
 
 #include "../../include/fembrain_hip.h"
 
@@ -23,6 +25,24 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   last_error() = buf;
   return code;
+}
+
+// host threads for the row-parallel parts of the plan (FEMBRAIN_PLAN_THREADS overrides; at most 16)
+static int plan_threads(int n_rows) {
+  int t = (int)std::thread::hardware_concurrency();
+  if (const char* e = getenv("FEMBRAIN_PLAN_THREADS")) t = atoi(e);
+  t = std::max(1, std::min(t, 16));
+  return std::max(1, std::min(t, n_rows / 2048 + 1));
+}
+
+template <class F>
+static void parallel_for(int T, F f) {
+  if (T <= 1) { f(0); return; }
+  std::vector<std::thread> th;
+  th.reserve(T - 1);
+  for (int t = 1; t < T; t++) th.emplace_back(f, t);
+  f(0);
+  for (auto& x : th) x.join();
 }
 
 static int owner_of(const std::vector<int>& splits, int g) {
@@ -73,14 +93,19 @@ int build_fem_plan(FemPlan& P, int n_nodes, int n_tets, const int* tets, int n_f
 
   // local tets: any owned node
   auto owned = [&](int g) { return g >= P.node_lo && g < P.node_hi; };
-  for (int e = 0; e < n_tets; e++) {
-    const int* t = tets + 4 * (size_t)e;
-    if (owned(t[0]) || owned(t[1]) || owned(t[2]) || owned(t[3])) P.tet_global.push_back(e);
+  if (n_ranks == 1) {
+    P.tet_global.resize(n_tets);
+    for (int e = 0; e < n_tets; e++) P.tet_global[e] = e;
+  } else {
+    for (int e = 0; e < n_tets; e++) {
+      const int* t = tets + 4 * (size_t)e;
+      if (owned(t[0]) || owned(t[1]) || owned(t[2]) || owned(t[3])) P.tet_global.push_back(e);
+    }
   }
   P.n_tets = (int)P.tet_global.size();
   // halo = non-owned nodes of local tets
   std::vector<int> halo;
-  for (int le = 0; le < P.n_tets; le++) {
+  for (int le = 0; le < (n_ranks == 1 ? 0 : P.n_tets); le++) {
     const int* t = tets + 4 * (size_t)P.tet_global[le];
     for (int i = 0; i < 4; i++)
       if (!owned(t[i])) halo.push_back(t[i]);
@@ -99,14 +124,18 @@ int build_fem_plan(FemPlan& P, int n_nodes, int n_tets, const int* tets, int n_f
     if (owned(g)) return g - P.node_lo;
     return P.n_owned + int(std::lower_bound(halo.begin(), halo.end(), g) - halo.begin());
   };
-  P.tets.resize((size_t)4 * P.n_tets);
-  for (int le = 0; le < P.n_tets; le++)
-    for (int i = 0; i < 4; i++) P.tets[(size_t)4 * le + i] = to_local(tets[4 * (size_t)P.tet_global[le] + i]);
+  if (n_ranks == 1) {
+    P.tets.assign(tets, tets + (size_t)4 * n_tets);  // local ids are the global ones
+  } else {
+    P.tets.resize((size_t)4 * P.n_tets);
+    for (int le = 0; le < P.n_tets; le++)
+      for (int i = 0; i < 4; i++) P.tets[(size_t)4 * le + i] = to_local(tets[4 * (size_t)P.tet_global[le] + i]);
+  }
 
   // send lists: my owned nodes that share a tet with a node owned by q (that is exactly q's halo inside my range)
   {
     std::vector<std::vector<int>> snd(n_ranks);
-    for (int le = 0; le < P.n_tets; le++) {
+    for (int le = 0; le < (n_ranks == 1 ? 0 : P.n_tets); le++) {
       const int* t = tets + 4 * (size_t)P.tet_global[le];
       int own[4];
       for (int i = 0; i < 4; i++) own[i] = owned(t[i]) ? rank : owner_of(P.splits, t[i]);
@@ -124,36 +153,61 @@ int build_fem_plan(FemPlan& P, int n_nodes, int n_tets, const int* tets, int n_f
     }
   }
 
-  // block pattern of owned rows; columns ascending in GLOBAL id (the reference's order)
-  {
-    std::vector<int> deg(P.n_owned + 1, 0);
-    for (int le = 0; le < P.n_tets; le++)
-      for (int i = 0; i < 4; i++) {
-        int a = P.tets[(size_t)4 * le + i];
-        if (a < P.n_owned) deg[a + 1] += 4;
-      }
-    for (int a = 0; a < P.n_owned; a++) deg[a + 1] += deg[a];
-    std::vector<int> fill(deg.begin(), deg.end() - 1), raw((size_t)deg[P.n_owned]);
-    for (int le = 0; le < P.n_tets; le++)
-      for (int i = 0; i < 4; i++) {
-        int a = P.tets[(size_t)4 * le + i];
-        if (a >= P.n_owned) continue;
-        for (int j = 0; j < 4; j++) raw[fill[a]++] = P.local2global[P.tets[(size_t)4 * le + j]];
-      }
-    P.bptr.assign(P.n_owned + 1, 0);
-    std::vector<int> gcol;
-    gcol.reserve(raw.size() / 4);
-    for (int a = 0; a < P.n_owned; a++) {
-      auto b = raw.begin() + deg[a], e = raw.begin() + deg[a + 1];
-      std::sort(b, e);
-      e = std::unique(b, e);
-      if (b == e) { gcol.push_back(P.node_lo + a); }  // isolated node: keep a diagonal block so the row is solvable
-      else gcol.insert(gcol.end(), b, e);
-      P.bptr[a + 1] = (int)gcol.size();
+  // ---- pattern, SELL layout and contribution lists, row-parallel ------------------------------------------------------
+  // Everything below is independent per block row (= owned node), so the rows are dealt to host threads in contiguous
+  // ranges; the result does not depend on the number of threads.  (A re-sync after a cut rebuilds the whole plan: at
+  // 1M tets this part is what the application waits for.)
+  const int T = plan_threads(P.n_owned);
+  auto row_lo = [&](int t) { return (int)((long long)P.n_owned * t / T); };
+
+  // incidence lists: for every owned row the (tet << 2 | corner) pairs that touch it, ascending tet
+  std::vector<int> inc_ptr(P.n_owned + 1, 0);
+  for (int le = 0; le < P.n_tets; le++)
+    for (int i = 0; i < 4; i++) {
+      const int a = P.tets[(size_t)4 * le + i];
+      if (a < P.n_owned) inc_ptr[a + 1]++;
     }
-    P.n_blocks = (int)gcol.size();
+  for (int a = 0; a < P.n_owned; a++) inc_ptr[a + 1] += inc_ptr[a];
+  std::vector<uint32_t> inc((size_t)inc_ptr[P.n_owned]);
+  {
+    std::vector<int> fill(inc_ptr.begin(), inc_ptr.end() - 1);
+    for (int le = 0; le < P.n_tets; le++)
+      for (int i = 0; i < 4; i++) {
+        const int a = P.tets[(size_t)4 * le + i];
+        if (a < P.n_owned) inc[fill[a]++] = ((uint32_t)le << 2) | (uint32_t)i;
+      }
+  }
+
+  // block pattern of owned rows; columns ascending in GLOBAL id (the reference's order)
+  std::vector<int> gcol;  // global column id of every block
+  {
+    std::vector<std::vector<int>> part(T);
+    std::vector<int> ucnt(P.n_owned, 0);
+    parallel_for(T, [&](int t) {
+      std::vector<int> tmp;
+      std::vector<int>& out = part[t];
+      for (int a = row_lo(t); a < row_lo(t + 1); a++) {
+        tmp.clear();
+        for (int q = inc_ptr[a]; q < inc_ptr[a + 1]; q++) {
+          const int le = (int)(inc[q] >> 2);
+          for (int j = 0; j < 4; j++) tmp.push_back(P.local2global[P.tets[(size_t)4 * le + j]]);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        if (tmp.empty()) tmp.push_back(P.node_lo + a);  // isolated node: keep a diagonal block so the row is solvable
+        ucnt[a] = (int)tmp.size();
+        out.insert(out.end(), tmp.begin(), tmp.end());
+      }
+    });
+    P.bptr.assign(P.n_owned + 1, 0);
+    for (int a = 0; a < P.n_owned; a++) P.bptr[a + 1] = P.bptr[a] + ucnt[a];
+    P.n_blocks = P.bptr[P.n_owned];
+    gcol.resize(P.n_blocks);
     P.bcol.resize(P.n_blocks);
-    for (int p = 0; p < P.n_blocks; p++) P.bcol[p] = to_local(gcol[p]);
+    parallel_for(T, [&](int t) {
+      std::copy(part[t].begin(), part[t].end(), gcol.begin() + P.bptr[row_lo(t)]);
+      for (int p = P.bptr[row_lo(t)]; p < P.bptr[row_lo(t + 1)]; p++) P.bcol[p] = to_local(gcol[p]);
+    });
   }
 
   // SELL-64
@@ -170,63 +224,81 @@ int build_fem_plan(FemPlan& P, int n_nodes, int n_tets, const int* tets, int n_f
   P.n_slots = P.slice_off[P.n_slices];
   P.colidx.assign((size_t)P.n_slots * kSliceRows, 0);
   P.blk_slot.assign(P.n_blocks, 0);
-  for (int s = 0; s < P.n_slices; s++) {
-    int w = P.slice_off[s + 1] - P.slice_off[s];
-    for (int l = 0; l < kSliceRows; l++) {
-      int a = s * kSliceRows + l;
-      for (int k = 0; k < w; k++) {
-        size_t at = ((size_t)P.slice_off[s] + k) * kSliceRows + l;
-        if (a < P.n_owned && k < P.bptr[a + 1] - P.bptr[a]) {
-          P.colidx[at] = P.bcol[P.bptr[a] + k];
-          P.blk_slot[P.bptr[a] + k] = P.slice_off[s] + k;
-        } else {
-          P.colidx[at] = a < P.n_owned ? a : 0;  // padding: any valid column, its values stay zero
+  const int TS = std::min(T, std::max(1, P.n_slices));
+  auto slice_lo = [&](int t) { return (int)((long long)P.n_slices * t / TS); };
+  parallel_for(TS, [&](int t) {
+    for (int s = slice_lo(t); s < slice_lo(t + 1); s++) {
+      const int w = P.slice_off[s + 1] - P.slice_off[s];
+      for (int l = 0; l < kSliceRows; l++) {
+        const int a = s * kSliceRows + l;
+        for (int k = 0; k < w; k++) {
+          const size_t at = ((size_t)P.slice_off[s] + k) * kSliceRows + l;
+          if (a < P.n_owned && k < P.bptr[a + 1] - P.bptr[a]) {
+            P.colidx[at] = P.bcol[P.bptr[a] + k];
+            P.blk_slot[P.bptr[a] + k] = P.slice_off[s] + k;
+          } else {
+            P.colidx[at] = a < P.n_owned ? a : 0;  // padding: any valid column, its values stay zero
+          }
         }
       }
     }
-  }
+  });
 
   // contribution lists
   {
-    std::vector<int> cnt(P.n_blocks + 1, 0);
-    std::vector<int> elblk((size_t)16 * P.n_tets, -1);
-    for (int le = 0; le < P.n_tets; le++)
-      for (int i = 0; i < 4; i++) {
-        int a = P.tets[(size_t)4 * le + i];
-        if (a >= P.n_owned) continue;
-        for (int j = 0; j < 4; j++) {
-          int gb = P.local2global[P.tets[(size_t)4 * le + j]];
-          // binary search by global id inside row a
-          int lo = P.bptr[a], hi = P.bptr[a + 1] - 1, pos = -1;
-          while (lo <= hi) {
-            int m = (lo + hi) >> 1, gm = P.local2global[P.bcol[m]];
-            if (gm == gb) { pos = m; break; }
-            if (gm < gb) lo = m + 1; else hi = m - 1;
+    std::vector<int> cnt(P.n_blocks, 0);
+    std::vector<uint16_t> where((size_t)4 * inc.size());  // block of (incidence entry, j) as its offset inside the row
+    parallel_for(T, [&](int t) {
+      for (int a = row_lo(t); a < row_lo(t + 1); a++) {
+        const int* cb = gcol.data() + P.bptr[a];
+        const int* ce = gcol.data() + P.bptr[a + 1];
+        for (int q = inc_ptr[a]; q < inc_ptr[a + 1]; q++) {
+          const int le = (int)(inc[q] >> 2);
+          for (int j = 0; j < 4; j++) {
+            const int gb = P.local2global[P.tets[(size_t)4 * le + j]];
+            const int k = (int)(std::lower_bound(cb, ce, gb) - cb);
+            where[(size_t)4 * q + j] = (uint16_t)k;
+            cnt[P.bptr[a] + k]++;
           }
-          elblk[(size_t)16 * le + 4 * i + j] = pos;
-          cnt[pos + 1]++;
         }
       }
-    P.slot_ccnt.assign(P.n_slots, 0);
+    });
     for (int a = 0; a < P.n_owned; a++)
-      for (int p = P.bptr[a]; p < P.bptr[a + 1]; p++) P.slot_ccnt[P.blk_slot[p]] = std::max(P.slot_ccnt[P.blk_slot[p]], cnt[p + 1]);
+      if (P.bptr[a + 1] - P.bptr[a] > 65535) return fail(FB_EINVAL, "node %d has more than 65535 neighbours", P.node_lo + a);
+    P.slot_ccnt.assign(P.n_slots, 0);
+    parallel_for(TS, [&](int t) {
+      for (int s = slice_lo(t); s < slice_lo(t + 1); s++)
+        for (int l = 0; l < kSliceRows; l++) {
+          const int a = s * kSliceRows + l;
+          if (a >= P.n_owned) break;
+          for (int p = P.bptr[a]; p < P.bptr[a + 1]; p++) P.slot_ccnt[P.blk_slot[p]] = std::max(P.slot_ccnt[P.blk_slot[p]], cnt[p]);
+        }
+    });
     P.slot_coff.assign(P.n_slots, 0);
     long long tot = 0;
     for (int t = 0; t < P.n_slots; t++) { P.slot_coff[t] = (int)tot; tot += P.slot_ccnt[t]; }
     if (tot * kSliceRows >= (1LL << 31)) return fail(FB_EINVAL, "contribution table too large (%lld rows)", tot);
     P.n_crows = (int)tot;
-    P.contrib.assign((size_t)P.n_crows * kSliceRows, kNoContrib);
-    std::vector<int> used(P.n_blocks, 0);
-    for (int le = 0; le < P.n_tets; le++)  // ascending element order inside every block's list
-      for (int i = 0; i < 4; i++) {
-        int a = P.tets[(size_t)4 * le + i];
-        if (a >= P.n_owned) continue;
-        for (int j = 0; j < 4; j++) {
-          int p = elblk[(size_t)16 * le + 4 * i + j];
-          int slot = P.blk_slot[p], lane = a % kSliceRows;
-          P.contrib[((size_t)P.slot_coff[slot] + used[p]++) * kSliceRows + lane] = ((uint32_t)le << 4) | (uint32_t)(i << 2) | (uint32_t)j;
+    P.contrib.resize((size_t)P.n_crows * kSliceRows);
+    parallel_for(T, [&](int t) {  // pad first, every thread its share
+      const size_t n = P.contrib.size(), lo = n * t / T, hi = n * (t + 1) / T;
+      std::fill(P.contrib.begin() + lo, P.contrib.begin() + hi, kNoContrib);
+    });
+    parallel_for(T, [&](int t) {  // ascending element order inside every block's list (inc is ascending in the tet)
+      std::vector<int> used;
+      for (int a = row_lo(t); a < row_lo(t + 1); a++) {
+        used.assign(P.bptr[a + 1] - P.bptr[a], 0);
+        const int lane = a % kSliceRows;
+        for (int q = inc_ptr[a]; q < inc_ptr[a + 1]; q++) {
+          const uint32_t le = inc[q] >> 2, i = inc[q] & 3u;
+          for (uint32_t j = 0; j < 4; j++) {
+            const int k = where[(size_t)4 * q + j];
+            const int slot = P.blk_slot[P.bptr[a] + k];
+            P.contrib[((size_t)P.slot_coff[slot] + used[k]++) * kSliceRows + lane] = (le << 4) | (i << 2) | j;
+          }
         }
       }
+    });
   }
   return plan_set_constraints(P, n_fixed, fixed_dofs);
 }

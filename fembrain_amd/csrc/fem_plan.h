@@ -10,9 +10,23 @@
 // in ascending element order (the order the reference's element loop accumulates them, :230-469).
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <new>
+#include <utility>
 #include <vector>
 
 namespace fb {
+
+// vector whose resize() leaves new elements uninitialised: the 77 MB contribution table of a 1M-tet mesh is filled by the
+// builder's threads, not zeroed first by one
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+  template <class U> struct rebind { typedef default_init_allocator<U> other; };
+  default_init_allocator() = default;
+  template <class U> default_init_allocator(const default_init_allocator<U>&) {}
+  template <class U> void construct(U* p) { ::new (static_cast<void*>(p)) U; }
+  template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
 
 constexpr int kSliceRows = 64;             // one wavefront lane per block row
 constexpr uint32_t kNoContrib = 0xFFFFFFFFu;
@@ -45,7 +59,7 @@ struct FemPlan {
   std::vector<int> slot_coff;              // n_slots: first contribution "row" of the slot
   std::vector<int> slot_ccnt;              // n_slots: max contributions over the 64 lanes
   int n_crows = 0;                         // sum of slot_ccnt
-  std::vector<uint32_t> contrib;           // n_crows*64, (tet<<4 | i<<2 | j) or kNoContrib
+  std::vector<uint32_t, default_init_allocator<uint32_t>> contrib;  // n_crows*64, (tet<<4 | i<<2 | j) or kNoContrib
   // --- constraints ---
   std::vector<uint8_t> dofmask;            // 3*n_local: 1 free, 0 constrained
   int n_fixed_owned = 0;

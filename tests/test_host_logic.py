@@ -270,3 +270,23 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
     needed = subprocess.check_output(["readelf", "-d", fl.LIB_PATH], text=True)
     assert "oracle" not in needed and "fem_ref" not in needed
+
+
+def test_plan_is_independent_of_the_builder_threads(monkeypatch):
+    """The pattern / SELL / contribution-list phases of the host plan run row-parallel on host threads (a re-sync after a
+    cut waits for them); every array must come out identical for any thread count, sharded or not."""
+    n = 30   # 27,000 nodes: more than 2048 rows per thread for 7 threads
+    v, t = truth_cube(n, n, n, 0.1)
+    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    names = ["local2global", "halo_off", "send_off", "send_local", "tets", "tet_global", "bptr", "bcol", "slice_off", "colidx", "blk_slot",
+             "slot_coff", "slot_ccnt", "contrib", "dofmask"]
+    for n_ranks, rank in ((1, 0), (2, 1)):
+        got = []
+        for threads in ("1", "7"):
+            monkeypatch.setenv("FEMBRAIN_PLAN_THREADS", threads)
+            info, get, (L, h) = _plan(v, t, fixed, n_ranks, rank)
+            got.append((info, {k: get(k) for k in names}))
+            L.fb_plan_destroy(h)
+        assert got[0][0] == got[1][0]
+        for k in names:
+            assert np.array_equal(got[0][1][k], got[1][1][k]), k
