@@ -217,8 +217,9 @@ def main():
         names = {fl.FB_XCH_COLLECTIVE: "collective", fl.FB_XCH_P2P: "p2p", fl.FB_XCH_P2P_SUMS: "p2p_sums", fl.FB_XCH_P2P_FUSED: "p2p_fused"}
         one_step()
         modes = (fl.FB_XCH_P2P, fl.FB_XCH_P2P_SUMS, fl.FB_XCH_P2P_FUSED)
-        if not local_comm and os.environ.get("FEMBRAIN_BENCH_SKIP_RCCL") != "1":
-            modes = (fl.FB_XCH_COLLECTIVE,) + modes   # the collective library, for the record
+        if not local_comm and os.environ.get("FEMBRAIN_BENCH_TRY_RCCL") == "1":
+            modes = (fl.FB_XCH_COLLECTIVE,) + modes   # the collective library, for the record (opt-in: RCCL with N > 1 could not
+            #                                           be rehearsed on the one-GPU development box)
         for mode in modes:
             g.set_exchange_mode(mode)
             barrier()
