@@ -48,6 +48,7 @@ struct fb_fem_s {
   // device, would otherwise bound the iteration time
   int split = 0;       // wavefronts per slice of the SpMV on small / mid-size meshes (k_spmv_split): 0 (row kernel), 2 or 4
   int sgrid = 8;       // blocks (= partial sums) of the SpMV launches; equals grid unless split
+  int vgrid = 8;       // blocks of the merged vector pass: one 16-byte pair per thread
   hipGraphExec_t batch_graph = nullptr;
   const double* graph_rhs = nullptr;
   bool use_graph = true;
@@ -108,6 +109,9 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
     else if (8 * ceil_div(chunk, 2) <= kMaxPartials) h->split = 2;
   }
   h->sgrid = h->split == 4 ? 8 * chunk : (h->split == 2 ? 8 * ceil_div(chunk, 2) : h->grid);
+  // small meshes: one 16-byte pair per thread in the merged vector pass (8.9 vs 9.3 us per iteration at 105k tets; on the 1M-tet
+  // mesh the extra blocks cost more in the partial-sum prologue than they save: 29.9 vs 29.1)
+  h->vgrid = h->split == 4 ? 8 * std::max(1, ceil_div(chunk * 96, kBlock)) : h->grid;
   FB_TRY(h->part_a.alloc(3 * kMaxPartials));
   FB_TRY(h->part_b.alloc(kMaxPartials));
   FB_TRY(h->part_c.alloc(3 * kMaxPartials));
@@ -299,7 +303,7 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b) {
     // merged-reduction iteration: SpMV with the three sums, then one fused vector pass (one reduction / all-reduce)
     FB_TRY(spmv<3>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity));
     FB_TRY(global_scalar(h, h->part_a.p, &sc, true, 3));
-    hipLaunchKernelGGL((k_cg_fused<false, false>), dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->sgrid,
+    hipLaunchKernelGGL((k_cg_fused<false, false>), dim3(h->vgrid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->sgrid,
                        sc, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->d.p, P2PArgs());
     FB_HIP(hipGetLastError());
     return FB_OK;
