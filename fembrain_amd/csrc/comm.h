@@ -40,24 +40,15 @@ struct P2PDev {  // passed to kernels by value
   long long timeout_ticks;           // wall_clock64 ticks (100 MHz)
 };
 struct P2P;
-struct P2PArgs {  // what a PCG kernel that carries an exchange needs: the view, sequence numbers, block tickets
+struct P2PArgs {  // what a PCG kernel that carries an exchange in its prologue needs
   P2PDev dev;
-  unsigned long long seq;        // of the 3-scalar sum this iteration posts / awaits
-  unsigned long long halo_seq;   // SpMV: halo values to read from the inbox (0 = read the vector);  vector pass: number to send under
-  int* ticket;                   // SpMV's last-block ticket
-  int* ticket2;                  // vector pass's last-block ticket
-  const int *send_ids, *send_dest, *send_off, *halo_off;  // device copies of the plan's exchange lists
-  int n_send, n_owned;
+  unsigned long long seq;        // of the 3-scalar sum the vector pass posts and awaits
+  unsigned long long halo_seq;   // of the halo refresh the SpMV sends and awaits
+  const int *send_ids, *send_off, *halo_off;  // device copies of the plan's exchange lists
 };
-// next sequence number of the 3-scalar sum, for kernels that post it (last SpMV block) and wait for it (vector pass)
+// next sequence number of the 3-scalar sum / of the halo refresh, for kernels that carry the exchange themselves
 P2PArgs p2p_next_sum(P2P* p);
-// next halo sequence number, for a vector pass that sends the new search direction itself
 unsigned long long p2p_next_halo(P2P* p);
-// wait for halo values sent under `seq` by the neighbours' vector pass and copy them from the inbox behind the owned
-// part of vec (no send); a no-op once st->done, when that vector pass did not send
-struct CGState;
-int p2p_halo_unpack(P2P* p, unsigned long long seq, int width, int n_halo, const int* halo_off_dev, int n_owned, double* vec, const CGState* st,
-                    hipStream_t s);
 // collective over the communicator; *out == nullptr (and FB_OK) when the ranks agree that the transport is unavailable
 int p2p_attach(fb_comm_s* c, int n_halo_nodes, const int* halo_off, hipStream_t s, P2P** out);
 void p2p_detach(P2P* p);

@@ -15,7 +15,6 @@ struct fb_fem_s {
   hipStream_t stream = nullptr;
   fb_comm_s* comm = nullptr;  // not owned
   P2P* p2p = nullptr;         // direct peer mailboxes for halo refresh and dots (comm.h); null = collective library
-  unsigned long long pending_halo = 0;  // sequence number under which the last vector pass sent the search direction (0 = none)
   int xch_mode = FB_XCH_COLLECTIVE;     // how the exchanges of a sharded handle run (fb_fem_set_exchange_mode)
   DevBuf<int> send_dest, send_off_dev, halo_off_dev;
   FemPlan plan;
@@ -266,44 +265,31 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b) {
   const int parity = (it - 1) & 1;
   const bool refresh = (it % 30 == 0);
   double* sc = nullptr;
-  const unsigned long long have = h->pending_halo;  // the previous vector pass already sent d to the neighbours' inboxes
-  h->pending_halo = 0;
   if (!refresh && h->prm.pcg_variant == FB_PCG_MERGED && h->xch_mode >= FB_XCH_P2P_SUMS) {
-    // Peer-to-peer transport: both exchanges ride inside the two kernels of the iteration.  The SpMV waits for the
-    // neighbours' halo post and gathers halo columns from the inbox, its last block posts the three sums; the vector
-    // pass waits for everybody's sums and its last block sends the new search direction for the next SpMV.
+    // Peer-to-peer transport with the exchanges inside the iteration's own kernels: the vector pass posts (block 0) and
+    // awaits the three sums in its prologue; in FB_XCH_P2P_FUSED the SpMV also refreshes the halo in its prologue (a block
+    // per neighbour sends, every block waits and gathers halo columns from the inbox) -- two launches, as on one GPU.
     P2PArgs pa = p2p_next_sum(h->p2p);
-    pa.send_ids = h->send_local.p; pa.send_dest = h->send_dest.p; pa.send_off = h->send_off_dev.p; pa.halo_off = h->halo_off_dev.p;
-    pa.n_send = (int)P.send_local.size(); pa.n_owned = P.n_owned;
-    if (have) {
-      pa.halo_seq = have;
+    pa.send_ids = h->send_local.p; pa.send_off = h->send_off_dev.p; pa.halo_off = h->halo_off_dev.p;
+    if (h->xch_mode == FB_XCH_P2P_FUSED) {
+      pa.halo_seq = p2p_next_halo(h->p2p);
       FB_TRY(h->f64 ? (launch_spmv_xch<double, 2>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity, pa))
                     : (launch_spmv_xch<float, 2>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity, pa)));
     } else {
       FB_TRY(halo_exchange(h, h->d.p));
-      FB_TRY(h->f64 ? (launch_spmv_xch<double, 1>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity, pa))
-                    : (launch_spmv_xch<float, 1>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity, pa)));
+      FB_TRY(spmv<3>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity));
     }
-    if (h->xch_mode == FB_XCH_P2P_SUMS) {  // the halo refresh keeps its own kernel
-      hipLaunchKernelGGL((k_cg_fused<true, false>), dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p,
-                         h->grid, (const double*)nullptr, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->d.p, pa);
-      FB_HIP(hipGetLastError());
-      return FB_OK;
-    }
-    pa.halo_seq = p2p_next_halo(h->p2p);
-    hipLaunchKernelGGL((k_cg_fused<true, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->grid,
+    hipLaunchKernelGGL((k_cg_fused<true>), dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->sgrid,
                        (const double*)nullptr, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->d.p, pa);
     FB_HIP(hipGetLastError());
-    h->pending_halo = pa.halo_seq;
     return FB_OK;
   }
-  if (have) FB_TRY(p2p_halo_unpack(h->p2p, have, 3, P.n_local - P.n_owned, h->halo_off_dev.p, P.n_owned, h->d.p, h->st.p, h->stream));
-  else FB_TRY(halo_exchange(h, h->d.p));
+  FB_TRY(halo_exchange(h, h->d.p));
   if (!refresh && h->prm.pcg_variant == FB_PCG_MERGED) {
     // merged-reduction iteration: SpMV with the three sums, then one fused vector pass (one reduction / all-reduce)
     FB_TRY(spmv<3>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity));
     FB_TRY(global_scalar(h, h->part_a.p, &sc, true, 3));
-    hipLaunchKernelGGL((k_cg_fused<false, false>), dim3(h->vgrid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->sgrid,
+    hipLaunchKernelGGL((k_cg_fused<false>), dim3(h->vgrid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->sgrid,
                        sc, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->d.p, P2PArgs());
     FB_HIP(hipGetLastError());
     return FB_OK;
@@ -365,7 +351,6 @@ bool host_finished(const CGState& s) {
 int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state);
 
 int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state) {
-  h->pending_halo = 0;  // a direction sent by the last vector pass of an earlier solve is never consumed
   if (h->prm.pcg_variant == FB_PCG_FUSED) return pcg_solve_fused(h, b, eps, max_iter, iters_out, final_state);
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
@@ -716,7 +701,6 @@ int fb_fem_set_exchange_mode(fb_fem_t h, int mode) {
   if (mode == FB_XCH_COLLECTIVE && !h->comm->nccl && !h->comm->local) return fail(FB_ECOMM, "the communicator has no collective library");
   FB_HIP(hipStreamSynchronize(h->stream));
   h->xch_mode = mode;
-  h->pending_halo = 0;
   return FB_OK;
 }
 

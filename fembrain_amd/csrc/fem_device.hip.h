@@ -330,9 +330,11 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
 //   MODE 3: q = A d with the three sums of the merged-reduction iteration: partial[b] = sum d.q,
 //           partial[G+b] = sum invdiag r q, partial[2G+b] = sum invdiag q^2 (bvec carries r)
 // ------------------------------------------------------------------------------------------------------
-// XCH (sharded handles on the peer-to-peer transport, MODE 3 only): 1 = the last block to finish folds the block partials
-// and posts the three sums into every rank's inbox, so the global sum costs no launch of its own; 2 = in addition the
-// halo columns are gathered straight from the inbox, where the neighbours' previous vector pass put them.
+// XCH = 2 (sharded handles on the peer-to-peer transport, MODE 3 only): the halo refresh of x rides in the prologue.  Block
+// q (q < n_ranks) stores this rank's boundary values for neighbour q into q's inbox and releases the sequence number;
+// every block then waits for the neighbours' numbers and gathers halo columns straight from the own inbox.  No launch of
+// its own, no grid-wide ticket (same-address atomics cost ~12 ns each here) and no per-block fence (an agent-scope
+// release writes back the whole per-XCD L2): x was completed by the previous kernel.
 template <typename MT, int MODE, int XCH = 0>
 __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo, const double* __restrict__ x,
                                                  double* __restrict__ y, const double* __restrict__ bvec,
@@ -352,6 +354,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
   double acc = 0.0, acc1 = 0.0, acc2 = 0.0;
   const double* halo_in = nullptr;
   if (XCH == 2) {
+    for (int q = blockIdx.x; q < pa.dev.n_ranks; q += gridDim.x)  // block-uniform
+      if (q != pa.dev.rank) p2p_send_halo3_to(pa.dev, q, pa.halo_seq, pa.send_ids, pa.send_off, x);
     p2p_wait_halo(pa.dev, pa.halo_seq, pa.halo_off);
     halo_in = p2p_halo_in(pa.dev, pa.halo_seq) - 3 * (size_t)sv.n_owned;
   }
@@ -409,18 +413,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
     if (threadIdx.x == 0) {
       partial[gridDim.x + blockIdx.x] = t1;
       partial[2 * gridDim.x + blockIdx.x] = t2;
-    }
-  }
-  if (XCH != 0 && MODE == 3) {
-    __shared__ int last;
-    __shared__ double mine[8];
-    __threadfence();
-    if (threadIdx.x == 0) last = atomicAdd(pa.ticket, 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (last) {  // block-uniform
-      if (threadIdx.x == 0) atomicExch(pa.ticket, 0);
-      __threadfence();
-      p2p_post_sums(pa.dev, pa.seq, partial, (int)gridDim.x, 3, lds, mine);
     }
   }
   (void)acc1; (void)acc2;
@@ -634,9 +626,10 @@ struct PairWalk {
   __device__ void next() { i += stride; }
 };
 
-// WAIT: the three sums arrive in this rank's inbox, posted by the last SpMV block of every rank (see k_spmv XCH).
-// SEND: the last block to finish stores the new search direction of the boundary nodes into the neighbours' inboxes.
-template <bool WAIT = false, bool SEND = false>
+// WAIT (sharded handles on the peer-to-peer transport): the global sum rides in the prologue.  Block 0 folds this rank's
+// per-block partials (complete: the SpMV kernel has finished) and posts the three sums into every rank's inbox; every
+// block then waits for all ranks' posts and adds them in rank order.  The first operand loads are already in flight.
+template <bool WAIT = false>
 __global__ __launch_bounds__(kBlock) void k_cg_fused(int n_slices, int n_owned, CGState* st, int parity,
                                                      const double* __restrict__ part, int n_partial, const double* sc,
                                                      const double* __restrict__ q, const double* __restrict__ invdiag,
@@ -655,6 +648,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_fused(int n_slices, int n_owned, 
   }
   double s0, s1, s2;
   if (WAIT) {
+    __shared__ double mine[8];
+    if (blockIdx.x == 0) p2p_post_sums(pa.dev, pa.seq, part, n_partial, 3, lds, mine);
     p2p_wait_sums(pa.dev, pa.seq, 3, lds);
     s0 = lds[0]; s1 = lds[1]; s2 = lds[2];
   } else if (sc) {
@@ -694,17 +689,6 @@ __global__ __launch_bounds__(kBlock) void k_cg_fused(int n_slices, int n_owned, 
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->rho[1 - parity] = rho_new;
     st->iter = st->iter + 1;
-  }
-  if (SEND) {
-    __shared__ int last;
-    __threadfence();
-    if (threadIdx.x == 0) last = atomicAdd(pa.ticket2, 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (last) {  // block-uniform
-      if (threadIdx.x == 0) atomicExch(pa.ticket2, 0);
-      __threadfence();
-      p2p_send_halo3(pa.dev, pa.halo_seq, pa.n_send, pa.send_ids, pa.send_dest, pa.send_off, d);
-    }
   }
 }
 

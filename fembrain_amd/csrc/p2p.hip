@@ -54,17 +54,6 @@ __global__ __launch_bounds__(kBlock) void k_p2p_halo(P2PDev c, int width, unsign
   for (long long i = tid; i < (long long)n_halo * width; i += stride) out[i] = __builtin_nontemporal_load(in + i);
 }
 
-// phase 2 alone: the values were sent by the neighbours' vector pass (k_cg_fused SEND)
-__global__ __launch_bounds__(kBlock) void k_p2p_unpack(P2PDev c, int width, unsigned long long seq, int n_halo, const int* __restrict__ halo_off,
-                                                       int n_owned, double* __restrict__ vec, const CGState* __restrict__ st) {
-  if (st->done) return;  // a finished solve: the vector pass that would have sent `seq` returned early on every rank
-  p2p_wait_halo(c, seq, halo_off);
-  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x, stride = (long long)gridDim.x * kBlock;
-  const double* in = (const double*)(c.inbox + kOffHalo) + (size_t)(seq & 1ULL) * c.cap * kMaxWidth;
-  double* out = vec + (size_t)width * n_owned;
-  for (long long i = tid; i < (long long)n_halo * width; i += stride) out[i] = __builtin_nontemporal_load(in + i);
-}
-
 // one block: fold my per-block partial sums, post them into every rank's inbox (mine included), wait for everybody's,
 // add in rank order.
 __global__ __launch_bounds__(kBlock) void k_p2p_reduce(P2PDev c, unsigned long long seq, const double* __restrict__ partial, int n, int count,
@@ -112,21 +101,10 @@ P2PArgs p2p_next_sum(P2P* p) {
   memset(&a, 0, sizeof a);
   a.dev = p->dev;
   a.seq = ++p->red_seq;
-  a.ticket = p->counter + 1;
-  a.ticket2 = p->counter + 2;
   return a;
 }
 
 unsigned long long p2p_next_halo(P2P* p) { return ++p->halo_seq; }
-
-int p2p_halo_unpack(P2P* p, unsigned long long seq, int width, int n_halo, const int* halo_off_dev, int n_owned, double* vec, const CGState* st,
-                    hipStream_t s) {
-  if (width < 1 || width > kMaxWidth || n_halo > p->dev.cap) return fail(FB_EINVAL, "p2p_halo_unpack: bad sizes");
-  const int blocks = (int)std::max<long long>(1, std::min<long long>(((long long)n_halo * width + kBlock - 1) / kBlock, 256));
-  hipLaunchKernelGGL(k_p2p_unpack, dim3(blocks), dim3(kBlock), 0, s, p->dev, width, seq, n_halo, halo_off_dev, n_owned, vec, st);
-  FB_HIP(hipGetLastError());
-  return FB_OK;
-}
 
 int p2p_halo(P2P* p, int width, int n_send, const int* send_ids, const int* send_dest, const int* send_off_dev, int n_halo,
              const int* halo_off_dev, int n_owned, double* vec, hipStream_t s) {

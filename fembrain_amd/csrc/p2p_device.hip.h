@@ -88,21 +88,20 @@ __device__ inline const double* p2p_halo_in(const P2PDev& c, unsigned long long 
   return (const double*)(c.inbox + kOffHalo) + (size_t)(seq & 1ULL) * c.cap * kP2PMaxWidth;
 }
 
-// ONE whole block, after every block's part of vec is visible: store my boundary 3-vectors into the neighbours' inboxes
-// and release `seq` to them
-__device__ inline void p2p_send_halo3(const P2PDev& c, unsigned long long seq, int n_send, const int* __restrict__ send_ids,
-                                      const int* __restrict__ send_dest, const int* __restrict__ send_off, const double* vec) {
-  const int par = (int)(seq & 1ULL);
-  for (int i = threadIdx.x; i < 3 * n_send; i += kBlock) {
+// ONE whole block: store my boundary 3-vectors for neighbour q into q's inbox and release `seq` to it.  vec was completed by
+// an earlier kernel.
+__device__ inline void p2p_send_halo3_to(const P2PDev& c, int q, unsigned long long seq, const int* __restrict__ send_ids,
+                                         const int* __restrict__ send_off, const double* __restrict__ vec) {
+  const int first = send_off[q], n = send_off[q + 1] - first;
+  if (n <= 0) return;  // block-uniform
+  double* dst = (double*)(c.peer[q] + kOffHalo) + (size_t)(seq & 1ULL) * c.peer_cap[q] * kP2PMaxWidth + (size_t)c.peer_seg[q] * 3;
+  for (int i = threadIdx.x; i < 3 * n; i += kBlock) {
     const int node = i / 3, cc = i - 3 * node;
-    const int q = send_dest[node];
-    double* dst = (double*)(c.peer[q] + kOffHalo) + (size_t)par * c.peer_cap[q] * kP2PMaxWidth + (size_t)(c.peer_seg[q] + node - send_off[q]) * 3 + cc;
-    *dst = __builtin_nontemporal_load(vec + 3 * (size_t)send_ids[node] + cc);
+    dst[i] = vec[3 * (size_t)send_ids[first + node] + cc];
   }
   __threadfence_system();
   __syncthreads();
-  const int q = threadIdx.x;
-  if (q < c.n_ranks && q != c.rank && send_off[q + 1] > send_off[q]) st_release_sys((unsigned long long*)(c.peer[q] + kOffHaloFlag) + c.rank, seq);
+  if (threadIdx.x == 0) st_release_sys((unsigned long long*)(c.peer[q] + kOffHaloFlag) + c.rank, seq);
 }
 
 }  // namespace fb
