@@ -330,9 +330,9 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
 //   MODE 3: q = A d with the three sums of the merged-reduction iteration: partial[b] = sum d.q,
 //           partial[G+b] = sum invdiag r q, partial[2G+b] = sum invdiag q^2 (bvec carries r)
 // ------------------------------------------------------------------------------------------------------
-// XCH = 2 (sharded handles on the peer-to-peer transport, MODE 3 only): the halo refresh of x rides in the prologue.  Block
-// q (q < n_ranks) stores this rank's boundary values for neighbour q into q's inbox and releases the sequence number;
-// every block then waits for the neighbours' numbers and gathers halo columns straight from the own inbox.  No launch of
+// XCH = 2 (sharded handles on the peer-to-peer transport, MODE 3 only): the halo refresh of x rides in the prologue.  The
+// first blocks each store one chunk of this rank's boundary values into a neighbour's inbox and release that chunk's
+// flag; every block then waits for the neighbours' chunks and gathers halo columns straight from the own inbox.  No launch of
 // its own, no grid-wide ticket (same-address atomics cost ~12 ns each here) and no per-block fence (an agent-scope
 // release writes back the whole per-XCD L2): x was completed by the previous kernel.
 template <typename MT, int MODE, int XCH = 0>
@@ -354,9 +354,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
   double acc = 0.0, acc1 = 0.0, acc2 = 0.0;
   const double* halo_in = nullptr;
   if (XCH == 2) {
-    for (int q = blockIdx.x; q < pa.dev.n_ranks; q += gridDim.x)  // block-uniform
-      if (q != pa.dev.rank) p2p_send_halo3_to(pa.dev, q, pa.halo_seq, pa.send_ids, pa.send_off, x);
-    p2p_wait_halo(pa.dev, pa.halo_seq, pa.halo_off);
+    p2p_send_halo_jobs(pa.dev, pa.halo_seq, 3, pa.send_ids, pa.send_off, x);
+    p2p_wait_halo(pa.dev, pa.halo_seq, pa.halo_off, 3);
     halo_in = p2p_halo_in(pa.dev, pa.halo_seq) - 3 * (size_t)sv.n_owned;
   }
   for (SliceWalk w(sv.n_slices); w.valid(); w.next()) {

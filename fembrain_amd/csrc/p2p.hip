@@ -18,38 +18,16 @@ struct Meta {  // what every rank publishes at attach time
   int ok;
 };
 
-// phase 1: every thread stores its share of my boundary values straight into the destination's inbox; the last block
-// to finish publishes the sequence number to the destinations.  phase 2: wait for the neighbours' numbers and copy
-// their values from my inbox into the halo part of the vector.  A block in phase 2 only depends on the peers' phase 1.
-__global__ __launch_bounds__(kBlock) void k_p2p_halo(P2PDev c, int width, unsigned long long seq, int n_send, const int* __restrict__ send_ids,
-                                                     const int* __restrict__ send_dest, const int* __restrict__ send_off, int n_halo,
-                                                     const int* __restrict__ halo_off, int n_owned, double* __restrict__ vec, int* __restrict__ counter) {
-  __shared__ int last;
+// phase 1: the sender jobs (one per neighbour and chunk) are dealt to the blocks; phase 2: every block waits for the
+// neighbours' chunks and copies its share of their values from my inbox into the halo part of the vector.  A block in
+// phase 2 only depends on the peers' phase 1; no grid-wide ticket.
+__global__ __launch_bounds__(kBlock) void k_p2p_halo(P2PDev c, int width, unsigned long long seq, const int* __restrict__ send_ids,
+                                                     const int* __restrict__ send_off, int n_halo, const int* __restrict__ halo_off, int n_owned,
+                                                     double* __restrict__ vec) {
+  p2p_send_halo_jobs(c, seq, width, send_ids, send_off, vec);
+  p2p_wait_halo(c, seq, halo_off, width);
   const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x, stride = (long long)gridDim.x * kBlock;
-  const int par = (int)(seq & 1ULL);
-  for (long long i = tid; i < (long long)n_send * width; i += stride) {
-    const int node = (int)(i / width), cc = (int)(i - (long long)node * width);
-    const int q = send_dest[node];
-    double* dst = (double*)(c.peer[q] + kOffHalo) + (size_t)par * c.peer_cap[q] * kMaxWidth + (size_t)(c.peer_seg[q] + node - send_off[q]) * width + cc;
-    *dst = vec[(size_t)width * send_ids[node] + cc];
-  }
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (last) {
-    __threadfence();
-    if (threadIdx.x == 0) atomicExch(counter, 0);
-    const int q = threadIdx.x;
-    if (q < c.n_ranks && q != c.rank && send_off[q + 1] > send_off[q]) st_release_sys((unsigned long long*)(c.peer[q] + kOffHaloFlag) + c.rank, seq);
-  }
-  if (threadIdx.x == 0) {
-    for (int q = 0; q < c.n_ranks; q++)
-      if (q != c.rank && halo_off[q + 1] > halo_off[q]) p2p_wait_flag(c, (const unsigned long long*)(c.inbox + kOffHaloFlag) + q, seq);
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  const double* in = (const double*)(c.inbox + kOffHalo) + (size_t)par * c.cap * kMaxWidth;
+  const double* in = (const double*)(c.inbox + kOffHalo) + (size_t)(seq & 1ULL) * c.cap * kMaxWidth;
   double* out = vec + (size_t)width * n_owned;
   for (long long i = tid; i < (long long)n_halo * width; i += stride) out[i] = __builtin_nontemporal_load(in + i);
 }
@@ -109,10 +87,11 @@ unsigned long long p2p_next_halo(P2P* p) { return ++p->halo_seq; }
 int p2p_halo(P2P* p, int width, int n_send, const int* send_ids, const int* send_dest, const int* send_off_dev, int n_halo,
              const int* halo_off_dev, int n_owned, double* vec, hipStream_t s) {
   if (width < 1 || width > kMaxWidth || n_halo > p->dev.cap) return fail(FB_EINVAL, "p2p_halo: bad sizes");
-  const long long work = (long long)std::max(n_send, n_halo) * width;
-  const int blocks = (int)std::max<long long>(1, std::min<long long>((work + kBlock - 1) / kBlock, 256));  // all co-resident
-  hipLaunchKernelGGL(k_p2p_halo, dim3(blocks), dim3(kBlock), 0, s, p->dev, width, ++p->halo_seq, n_send, send_ids, send_dest, send_off_dev, n_halo,
-                     halo_off_dev, n_owned, vec, p->counter);
+  (void)n_send; (void)send_dest;
+  const long long work = (long long)n_halo * width;
+  const int blocks = (int)std::max<long long>(2 * kP2PChunks, std::min<long long>((work + kBlock - 1) / kBlock, 64));
+  hipLaunchKernelGGL(k_p2p_halo, dim3(blocks), dim3(kBlock), 0, s, p->dev, width, ++p->halo_seq, send_ids, send_off_dev, n_halo, halo_off_dev, n_owned,
+                     vec);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }

@@ -9,11 +9,12 @@
 namespace fb {
 
 // inbox layout (bytes)
-constexpr size_t kOffHaloFlag = 0;     // u64[kP2PMaxRanks]   written by peer q at [q]
-constexpr size_t kOffRedFlag = 128;    // u64[kP2PMaxRanks]
-constexpr size_t kOffErr = 256;        // u64
-constexpr size_t kOffRed = 512;        // double[2][kP2PMaxRanks][8]
-constexpr size_t kOffHalo = 4096;      // double[2][cap * 12]
+constexpr int kP2PChunks = 16;         // a neighbour's halo values arrive in up to 16 chunks, each from its own sender block
+constexpr size_t kOffHaloFlag = 0;     // u64[kP2PMaxRanks][kP2PChunks]   written by peer q at [q][chunk]
+constexpr size_t kOffRedFlag = 2048;   // u64[kP2PMaxRanks]
+constexpr size_t kOffErr = 2304;       // u64
+constexpr size_t kOffRed = 2560;       // double[2][kP2PMaxRanks][8]
+constexpr size_t kOffHalo = 8192;      // double[2][cap * 12]
 constexpr int kP2PMaxWidth = 12;
 
 __device__ __forceinline__ unsigned long long ld_acquire_sys(const unsigned long long* p) {
@@ -73,11 +74,20 @@ __device__ inline void p2p_wait_sums(const P2PDev& c, unsigned long long seq, in
   __syncthreads();
 }
 
-// every block, before it gathers halo columns straight from the inbox: wait for the neighbours' halo post `seq`
-__device__ inline void p2p_wait_halo(const P2PDev& c, unsigned long long seq, const int* __restrict__ halo_off) {
+// A neighbour's n nodes of `width` doubles travel in this many chunks (sender and receiver compute it alike): one sender
+// block per chunk keeps many stores in flight (a single block sending a whole 9k-node plane was 2.5x slower) and each
+// chunk has its own flag, so there is no grid-wide ticket.
+__device__ __forceinline__ int p2p_chunks(int n, int width) { return max(1, min(kP2PChunks, (n * width + 1023) / 1024)); }
+
+// every block, before it reads halo values from the inbox: wait for all chunks of the neighbours' post `seq`
+__device__ inline void p2p_wait_halo(const P2PDev& c, unsigned long long seq, const int* __restrict__ halo_off, int width) {
   if (threadIdx.x == 0) {
-    for (int q = 0; q < c.n_ranks; q++)
-      if (q != c.rank && halo_off[q + 1] > halo_off[q]) p2p_wait_flag(c, (const unsigned long long*)(c.inbox + kOffHaloFlag) + q, seq);
+    for (int q = 0; q < c.n_ranks; q++) {
+      const int n = halo_off[q + 1] - halo_off[q];
+      if (q == c.rank || n <= 0) continue;
+      const int nc = p2p_chunks(n, width);
+      for (int k = 0; k < nc; k++) p2p_wait_flag(c, (const unsigned long long*)(c.inbox + kOffHaloFlag) + q * kP2PChunks + k, seq);
+    }
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -88,20 +98,29 @@ __device__ inline const double* p2p_halo_in(const P2PDev& c, unsigned long long 
   return (const double*)(c.inbox + kOffHalo) + (size_t)(seq & 1ULL) * c.cap * kP2PMaxWidth;
 }
 
-// ONE whole block: store my boundary 3-vectors for neighbour q into q's inbox and release `seq` to it.  vec was completed by
-// an earlier kernel.
-__device__ inline void p2p_send_halo3_to(const P2PDev& c, int q, unsigned long long seq, const int* __restrict__ send_ids,
-                                         const int* __restrict__ send_off, const double* __restrict__ vec) {
-  const int first = send_off[q], n = send_off[q + 1] - first;
-  if (n <= 0) return;  // block-uniform
-  double* dst = (double*)(c.peer[q] + kOffHalo) + (size_t)(seq & 1ULL) * c.peer_cap[q] * kP2PMaxWidth + (size_t)c.peer_seg[q] * 3;
-  for (int i = threadIdx.x; i < 3 * n; i += kBlock) {
-    const int node = i / 3, cc = i - 3 * node;
-    dst[i] = vec[3 * (size_t)send_ids[first + node] + cc];
+// The sender jobs of a halo refresh -- one per (neighbour, chunk) -- are dealt round-robin to the blocks of the grid: a block
+// stores its chunk of my boundary values into the neighbour's inbox and releases `seq` on that chunk's flag.  vec was
+// completed by an earlier kernel, so the only fence is the sender's own.
+__device__ inline void p2p_send_halo_jobs(const P2PDev& c, unsigned long long seq, int width, const int* __restrict__ send_ids,
+                                          const int* __restrict__ send_off, const double* __restrict__ vec) {
+  int job = 0;
+  for (int q = 0; q < c.n_ranks; q++) {
+    const int first = send_off[q], n = send_off[q + 1] - first;
+    if (q == c.rank || n <= 0) continue;
+    const int nc = p2p_chunks(n, width);
+    for (int k = 0; k < nc; k++, job++) {
+      if (job % (int)gridDim.x != (int)blockIdx.x) continue;  // block-uniform
+      const int lo = (int)((long long)n * k / nc), hi = (int)((long long)n * (k + 1) / nc);
+      double* dst = (double*)(c.peer[q] + kOffHalo) + (size_t)(seq & 1ULL) * c.peer_cap[q] * kP2PMaxWidth + (size_t)c.peer_seg[q] * width;
+      for (int i = lo * width + threadIdx.x; i < hi * width; i += kBlock) {
+        const int node = i / width, cc = i - node * width;
+        dst[i] = vec[(size_t)width * send_ids[first + node] + cc];
+      }
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) st_release_sys((unsigned long long*)(c.peer[q] + kOffHaloFlag) + c.rank * kP2PChunks + k, seq);
+    }
   }
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) st_release_sys((unsigned long long*)(c.peer[q] + kOffHaloFlag) + c.rank, seq);
 }
 
 }  // namespace fb
