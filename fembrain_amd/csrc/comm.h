@@ -45,6 +45,7 @@ struct P2PArgs {  // what a PCG kernel that carries an exchange in its prologue 
   unsigned long long seq;        // of the 3-scalar sum the vector pass posts and awaits
   unsigned long long halo_seq;   // of the halo refresh the SpMV sends and awaits
   const int *send_ids, *send_off, *halo_off;  // device copies of the plan's exchange lists
+  const unsigned char* slice_halo;            // per SELL slice: 1 if any of its columns is a halo node
 };
 // next sequence number of the 3-scalar sum / of the halo refresh, for kernels that carry the exchange themselves
 P2PArgs p2p_next_sum(P2P* p);

@@ -17,6 +17,7 @@ struct fb_fem_s {
   P2P* p2p = nullptr;         // direct peer mailboxes for halo refresh and dots (comm.h); null = collective library
   int xch_mode = FB_XCH_COLLECTIVE;     // how the exchanges of a sharded handle run (fb_fem_set_exchange_mode)
   DevBuf<int> send_dest, send_off_dev, halo_off_dev;
+  DevBuf<unsigned char> slice_halo;
   FemPlan plan;
   double lambda = 0, mu = 0;
   int grid = 8;
@@ -270,7 +271,7 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b) {
     // awaits the three sums in its prologue; in FB_XCH_P2P_FUSED the SpMV also refreshes the halo in its prologue (a block
     // per neighbour sends, every block waits and gathers halo columns from the inbox) -- two launches, as on one GPU.
     P2PArgs pa = p2p_next_sum(h->p2p);
-    pa.send_ids = h->send_local.p; pa.send_off = h->send_off_dev.p; pa.halo_off = h->halo_off_dev.p;
+    pa.send_ids = h->send_local.p; pa.send_off = h->send_off_dev.p; pa.halo_off = h->halo_off_dev.p; pa.slice_halo = h->slice_halo.p;
     if (h->xch_mode == FB_XCH_P2P_FUSED) {
       pa.halo_seq = p2p_next_halo(h->p2p);
       FB_TRY(h->f64 ? (launch_spmv_xch<double, 2>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity, pa))
@@ -533,6 +534,10 @@ int attach_p2p(fb_fem_s* h) {
   FB_TRY(h->send_dest.upload(dest, h->stream));
   FB_TRY(h->send_off_dev.upload(P.send_off, h->stream));
   FB_TRY(h->halo_off_dev.upload(P.halo_off, h->stream));
+  std::vector<unsigned char> sh((size_t)std::max(1, P.n_slices), 0);  // slices with a halo column are done after the halo wait
+  for (int sl = 0; sl < P.n_slices; sl++)
+    for (size_t k = (size_t)P.slice_off[sl] * kSliceRows; k < (size_t)P.slice_off[sl + 1] * kSliceRows && !sh[sl]; k++) sh[sl] = P.colidx[k] >= P.n_owned;
+  FB_TRY(h->slice_halo.upload(sh, h->stream));
   if (P.send_local.empty()) FB_TRY(h->send_local.alloc(1));
   return FB_OK;
 }

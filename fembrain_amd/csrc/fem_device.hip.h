@@ -353,13 +353,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
   const int lane = threadIdx.x & 63;
   double acc = 0.0, acc1 = 0.0, acc2 = 0.0;
   const double* halo_in = nullptr;
-  if (XCH == 2) {
-    p2p_send_halo_jobs(pa.dev, pa.halo_seq, 3, pa.send_ids, pa.send_off, x);
-    p2p_wait_halo(pa.dev, pa.halo_seq, pa.halo_off, 3);
-    halo_in = p2p_halo_in(pa.dev, pa.halo_seq) - 3 * (size_t)sv.n_owned;
-  }
-  for (SliceWalk w(sv.n_slices); w.valid(); w.next()) {
-    const int s = w.s;
+  // one SELL slice (wave-uniform s): row products, diagonal low part, epilogue of the MODE
+  auto do_slice = [&](const int s) {
     const int row = s * 64 + lane;
     const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
     const MT* v = vals + (size_t)so * 9 * 64 + lane;
@@ -400,6 +395,26 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
         y[d] = r0; y[d + 1] = r1; y[d + 2] = r2;
         acc += r0 * r0 * invdiag[d] + r1 * r1 * invdiag[d + 1] + r2 * r2 * invdiag[d + 2];
       }
+    }
+  };
+  if (XCH != 2) {
+    for (SliceWalk w(sv.n_slices); w.valid(); w.next()) do_slice(w.s);
+  } else {
+    // The halo refresh rides here.  Sender jobs first; then two passes over this block's slices: the interior ones (no halo
+    // column, the bulk) before the wait for the neighbours' values, the boundary ones after it; a block without boundary
+    // slices never waits at all.
+    p2p_send_halo_jobs(pa.dev, pa.halo_seq, 3, pa.send_ids, pa.send_off, x);
+    for (SliceWalk w(sv.n_slices); w.valid(); w.next())
+      if (!pa.slice_halo[w.s]) do_slice(w.s);
+    bool mine = false;  // does any slice of this block touch the halo?  (block-uniform: every wave scans the block's slices)
+    for (int j = blockIdx.x >> 3, chunk = (sv.n_slices + 7) >> 3, lo = (blockIdx.x & 7) * chunk, hi = min(lo + chunk, sv.n_slices),
+             s0 = lo + j * kWavesPerBlock; s0 < hi; s0 += (gridDim.x >> 3) * kWavesPerBlock)
+      for (int k = 0; k < kWavesPerBlock && s0 + k < hi; k++) mine = mine || pa.slice_halo[s0 + k];
+    if (mine) {
+      p2p_wait_halo(pa.dev, pa.halo_seq, pa.halo_off, 3);
+      halo_in = p2p_halo_in(pa.dev, pa.halo_seq) - 3 * (size_t)sv.n_owned;
+      for (SliceWalk w(sv.n_slices); w.valid(); w.next())
+        if (pa.slice_halo[w.s]) do_slice(w.s);
     }
   }
   if (MODE != 0) {
