@@ -304,7 +304,49 @@ def main():
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     elif rank == 0:
         out["cpu_baseline"] = None
+    mode_used = g.transport()
     g.close()
+    # BASELINE config 5 in the same run: the 8M-tet cube (111^3 nodes) on the same ranks, 1 warm-up + 2 timed steps, so that
+    # the N = 1, 2, 4, 8 runs of this script also give the 8M-tet strong-scaling series of the north star.  Reported
+    # under "cube111"; never part of `value`.
+    if args.workload == "cube56" and os.environ.get("FEMBRAIN_BENCH_SKIP_8M") != "1":
+        big = None
+        try:
+            n8 = WORKLOADS["cube111"][0]
+            v8, t8, fixed8 = workload_mesh("cube111", device)
+            shard8 = None
+            if dist_mode:
+                planes = [n8 * r // world for r in range(world + 1)]
+                shard8 = (world, rank, np.array([p * n8 * n8 for p in planes], dtype=np.int32), comm)
+            g8 = FemIntegrator(v8, t8, fixed8, matrix_precision=prec, device=device, shard=shard8)
+            if dist_mode and mode_used != g8.transport() and mode_used >= fl.FB_XCH_P2P and g8.transport() >= fl.FB_XCH_P2P:
+                g8.set_exchange_mode(mode_used)
+
+            def step8():
+                g8.rebuild_elements()
+                g8.set_uniform_force(1, -10000.0)
+                return g8.do_timestep()
+            step8()
+            barrier()
+            ts = time.perf_counter()
+            it8, solve8 = [], 0.0
+            for _ in range(2):
+                it8.append(step8())
+                solve8 += g8.last.solve_seconds
+            barrier()
+            dt8 = time.perf_counter() - ts
+            if dist_mode:
+                tt = torch.tensor([dt8], dtype=torch.float64, device="cpu" if local_comm else "cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt8 = float(tt.item())
+            big = {"workload": WORKLOADS["cube111"][1], "tets": int(len(t8)), "steps": 2, "warmup": 1, "value": 2 / dt8, "unit": "steps/s",
+                   "ms_per_step": dt8 / 2 * 1e3, "cg_iterations_per_step": float(np.mean(it8)), "us_per_cg_iteration": solve8 / max(sum(it8), 1) * 1e6,
+                   "spmv_gbs": (g8.spmv_bytes() / g8.time_spmv(50) / 1e9) if not dist_mode else None}
+            g8.close()
+        except Exception as e:  # the headline line must survive whatever happens here
+            big = {"error": repr(e)}
+        if out is not None:
+            out["cube111"] = big
     if dist_mode:
         fl.lib().fb_comm_destroy(comm)
         dist.barrier()
