@@ -55,8 +55,8 @@ int p2p_attach(fb_comm_s* c, int n_halo_nodes, const int* halo_off, hipStream_t 
 void p2p_detach(P2P* p);
 // halo refresh of a per-node array of `width` doubles (<= 12): my send list goes into the peers' inboxes, theirs lands
 // in vec[width * n_owned ...]
-int p2p_halo(P2P* p, int width, int n_send, const int* send_ids, const int* send_dest, const int* send_off_dev, int n_halo,
-             const int* halo_off_dev, int n_owned, double* vec, hipStream_t s);
+int p2p_halo(P2P* p, int width, const int* send_ids, const int* send_off_dev, int n_halo, const int* halo_off_dev, int n_owned, double* vec,
+             hipStream_t s);
 // out[c] = sum over ranks (fixed rank order, bitwise identical everywhere) of sum_i partial[c * n + i], c < count <= 8
 int p2p_reduce(P2P* p, const double* partial, int n, int count, double* out, hipStream_t s);
 // FB_OK, or FB_ECOMM if any wait on this rank timed out since attach (synchronises the stream)

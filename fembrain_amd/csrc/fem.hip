@@ -16,7 +16,7 @@ struct fb_fem_s {
   fb_comm_s* comm = nullptr;  // not owned
   P2P* p2p = nullptr;         // direct peer mailboxes for halo refresh and dots (comm.h); null = collective library
   int xch_mode = FB_XCH_COLLECTIVE;     // how the exchanges of a sharded handle run (fb_fem_set_exchange_mode)
-  DevBuf<int> send_dest, send_off_dev, halo_off_dev;
+  DevBuf<int> send_off_dev, halo_off_dev;
   DevBuf<unsigned char> slice_halo;
   FemPlan plan;
   double lambda = 0, mu = 0;
@@ -149,8 +149,7 @@ int halo_exchange(fb_fem_s* h, double* vec, int width = 3) {
   const FemPlan& P = h->plan;
   const int ns = (int)P.send_local.size();
   if (h->xch_mode >= FB_XCH_P2P)
-    return p2p_halo(h->p2p, width, ns, h->send_local.p, h->send_dest.p, h->send_off_dev.p, P.n_local - P.n_owned, h->halo_off_dev.p, P.n_owned, vec,
-                    h->stream);
+    return p2p_halo(h->p2p, width, h->send_local.p, h->send_off_dev.p, P.n_local - P.n_owned, h->halo_off_dev.p, P.n_owned, vec, h->stream);
   if (ns > 0) {
     hipLaunchKernelGGL(k_pack_nodes, dim3(ceil_div(ns * width, kBlock)), dim3(kBlock), 0, h->stream, ns, width, h->send_local.p, vec, h->sendbuf.p);
     FB_HIP(hipGetLastError());
@@ -528,10 +527,6 @@ int attach_p2p(fb_fem_s* h) {
     const int m = atoi(e);
     if (m >= FB_XCH_COLLECTIVE && m <= FB_XCH_P2P_FUSED) h->xch_mode = m;
   }
-  std::vector<int> dest(std::max<size_t>(1, P.send_local.size()), 0);
-  for (int q = 0; q < P.n_ranks; q++)
-    for (int i = P.send_off[q]; i < P.send_off[q + 1]; i++) dest[i] = q;
-  FB_TRY(h->send_dest.upload(dest, h->stream));
   FB_TRY(h->send_off_dev.upload(P.send_off, h->stream));
   FB_TRY(h->halo_off_dev.upload(P.halo_off, h->stream));
   std::vector<unsigned char> sh((size_t)std::max(1, P.n_slices), 0);  // slices with a halo column are done after the halo wait

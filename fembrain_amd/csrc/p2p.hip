@@ -51,7 +51,6 @@ struct P2P {
   fb_comm_s* comm = nullptr;
   void* opened[kP2PMaxRanks] = {nullptr};
   unsigned long long halo_seq = 0, red_seq = 0;
-  int* counter = nullptr;
   double* probe = nullptr;  // 2 doubles of ordinary device memory
   size_t inbox_bytes = 0;
 };
@@ -62,7 +61,6 @@ void p2p_detach(P2P* p) {
   for (int q = 0; q < p->dev.n_ranks; q++)
     if (p->opened[q]) (void)hipIpcCloseMemHandle(p->opened[q]);
   if (p->dev.inbox) (void)hipFree(p->dev.inbox);
-  if (p->counter) (void)hipFree(p->counter);
   if (p->probe) (void)hipFree(p->probe);
   delete p;
 }
@@ -84,10 +82,9 @@ P2PArgs p2p_next_sum(P2P* p) {
 
 unsigned long long p2p_next_halo(P2P* p) { return ++p->halo_seq; }
 
-int p2p_halo(P2P* p, int width, int n_send, const int* send_ids, const int* send_dest, const int* send_off_dev, int n_halo,
-             const int* halo_off_dev, int n_owned, double* vec, hipStream_t s) {
+int p2p_halo(P2P* p, int width, const int* send_ids, const int* send_off_dev, int n_halo, const int* halo_off_dev, int n_owned, double* vec,
+             hipStream_t s) {
   if (width < 1 || width > kMaxWidth || n_halo > p->dev.cap) return fail(FB_EINVAL, "p2p_halo: bad sizes");
-  (void)n_send; (void)send_dest;
   const long long work = (long long)n_halo * width;
   const int blocks = (int)std::max<long long>(2 * kP2PChunks, std::min<long long>((work + kBlock - 1) / kBlock, 64));
   hipLaunchKernelGGL(k_p2p_halo, dim3(blocks), dim3(kBlock), 0, s, p->dev, width, ++p->halo_seq, send_ids, send_off_dev, n_halo, halo_off_dev, n_owned,
@@ -124,7 +121,6 @@ int p2p_attach(fb_comm_s* c, int n_halo_nodes, const int* halo_off, hipStream_t 
   // local part; any failure is reported through mine.ok so that the ranks can agree to fall back together
   bool ok = hipExtMallocWithFlags((void**)&p->dev.inbox, p->inbox_bytes, hipDeviceMallocFinegrained) == hipSuccess;
   ok = ok && hipMemsetAsync(p->dev.inbox, 0, p->inbox_bytes, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-  ok = ok && hipMalloc((void**)&p->counter, 4 * sizeof(int)) == hipSuccess && hipMemsetAsync(p->counter, 0, 4 * sizeof(int), s) == hipSuccess;
   ok = ok && hipMalloc((void**)&p->probe, 2 * sizeof(double)) == hipSuccess;
   ok = ok && hipIpcGetMemHandle(&mine.handle, p->dev.inbox) == hipSuccess;
   (void)hipGetLastError();

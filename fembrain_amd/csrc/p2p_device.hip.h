@@ -60,9 +60,8 @@ __device__ inline void p2p_post_sums(const P2PDev& c, unsigned long long seq, co
 // are in tot[0..count) (shared memory, >= 8 doubles)
 __device__ inline void p2p_wait_sums(const P2PDev& c, unsigned long long seq, int count, double* tot) {
   const int par = (int)(seq & 1ULL), t = threadIdx.x;
-  if (t == 0) {  // one poller per block keeps the pressure on the flag line low; later flags are normally set already
-    for (int r = 0; r < c.n_ranks; r++) p2p_wait_flag(c, (const unsigned long long*)(c.inbox + kOffRedFlag) + r, seq);
-  }
+  // lane r polls rank r's flag: the flags share one 128-byte row, so a block's poll is one request and one latency
+  if (t < c.n_ranks) p2p_wait_flag(c, (const unsigned long long*)(c.inbox + kOffRedFlag) + t, seq);
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   if (t < count) {
@@ -79,15 +78,15 @@ __device__ inline void p2p_wait_sums(const P2PDev& c, unsigned long long seq, in
 // chunk has its own flag, so there is no grid-wide ticket.
 __device__ __forceinline__ int p2p_chunks(int n, int width) { return max(1, min(kP2PChunks, (n * width + 1023) / 1024)); }
 
-// every block, before it reads halo values from the inbox: wait for all chunks of the neighbours' post `seq`
+// every block, before it reads halo values from the inbox: wait for all chunks of the neighbours' post `seq`.  Thread
+// 16 q + k polls chunk k of neighbour q, so all flags are polled side by side (one 128-byte flag row per neighbour) and
+// the wait costs one poll latency, not one per flag.
 __device__ inline void p2p_wait_halo(const P2PDev& c, unsigned long long seq, const int* __restrict__ halo_off, int width) {
-  if (threadIdx.x == 0) {
-    for (int q = 0; q < c.n_ranks; q++) {
-      const int n = halo_off[q + 1] - halo_off[q];
-      if (q == c.rank || n <= 0) continue;
-      const int nc = p2p_chunks(n, width);
-      for (int k = 0; k < nc; k++) p2p_wait_flag(c, (const unsigned long long*)(c.inbox + kOffHaloFlag) + q * kP2PChunks + k, seq);
-    }
+  static_assert(kP2PMaxRanks * kP2PChunks <= kBlock, "one polling thread per (neighbour, chunk)");
+  const int q = threadIdx.x / kP2PChunks, k = threadIdx.x % kP2PChunks;
+  if (q < c.n_ranks && q != c.rank) {
+    const int n = halo_off[q + 1] - halo_off[q];
+    if (n > 0 && k < p2p_chunks(n, width)) p2p_wait_flag(c, (const unsigned long long*)(c.inbox + kOffHaloFlag) + q * kP2PChunks + k, seq);
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
