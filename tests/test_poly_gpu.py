@@ -402,3 +402,114 @@ def test_off_surface_points_and_fields(gpu):
     want[:, 3] = o.field_array(np.concatenate([want[:, :3], np.zeros((len(want), 1), np.float32)], 1))[:, 3]
     assert np.array_equal(got, want)
     assert (got[0::2, 3] < 0.5).mean() > 0.95 and (got[1::2, 3] > 0.5).mean() > 0.95   # outside / inside of the iso-surface
+
+
+def _random_tree(rng, n_prims, with_instances):
+    """A random BlobTree in the flat layout: every primitive type with a field, random affine matrix nodes, a random binary /
+    unary / range operator structure over them, optionally instances of earlier subtrees and primitives."""
+    from fembrain_amd.blobtree import BlobTree, NULL_BLOB
+    mtx = [np.eye(4, dtype=np.float64)[:3].reshape(12)]
+    P, ops = [], []
+
+    def new_matrix():
+        a = rng.normal(size=(3, 3)) * 0.25 + np.eye(3) * rng.uniform(0.7, 1.4)
+        t = rng.uniform(-0.6, 0.6, size=3)
+        m = np.concatenate([a, t[:, None]], 1).reshape(12)
+        mtx.append(m)
+        return len(mtx) - 1
+
+    def new_prim():
+        t = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 7, 8, 6]))
+        p = np.zeros(20)
+        p[0] = t
+        p[1] = new_matrix() if rng.random() < 0.4 else 0
+        p[4:7] = rng.uniform(-0.8, 0.8, size=3)
+        d = rng.normal(size=3)
+        p[8:11] = d / np.linalg.norm(d)
+        if t == 1:
+            p[8:11] = p[4:7] + d * 0.6
+        p[12:15] = [rng.uniform(0.1, 0.5), rng.uniform(0.2, 0.9), 0.0]
+        if t == 7:
+            r = rng.uniform(0.5, 1.0)
+            p[8:11] = [1.0, r, r * r]
+            p[12:15] = [1.0 / r ** 4, -2.0 / r ** 2, 1.0]
+        P.append(p)
+        return len(P) - 1
+
+    def new_instance(origin, is_op):
+        p = np.zeros(20)
+        p[0], p[1] = 9, new_matrix()
+        p[12:15] = [origin, 0, 1.0 if is_op else 0.0]
+        P.append(p)
+        return len(P) - 1
+
+    def build(depth):
+        """returns (index, is_op)"""
+        if depth == 0 or rng.random() < 0.25:
+            if with_instances and ops and rng.random() < 0.2:
+                done = [i for i, o in enumerate(ops) if o["done"]]
+                if done:
+                    return new_instance(int(rng.choice(done)), True), False
+            if with_instances and P and rng.random() < 0.1:
+                plain = [i for i, p in enumerate(P) if p[0] != 9]
+                return new_instance(int(rng.choice(plain)), False), False
+            return new_prim(), False
+        idx = len(ops)
+        o = {"type": 0, "lc": 0, "rc": 0, "flags": 0, "res": [0.0, 0.0], "done": False}
+        ops.append(o)
+        kind = rng.random()
+        if kind < 0.2:      # range operator over freshly made consecutive primitives
+            first = new_prim()
+            last = first
+            for _ in range(int(rng.integers(1, 4))):
+                last = new_prim()
+            o.update(type=int(rng.choice([4, 0])), lc=first, rc=last, flags=4)
+        elif kind < 0.3:    # unary warp: passes its child through
+            c, cop = build(depth - 1)
+            o.update(type=int(rng.choice([9, 10, 11, 12])), lc=c, flags=8 | (2 if cop else 0))
+        else:
+            o["type"] = int(rng.choice([0, 1, 2, 3, 4, 5]))
+            if o["type"] == 5:
+                pw = float(rng.choice([2.0, 3.0]))
+                o["res"] = [pw, 1.0 / pw]
+            l, lop = build(depth - 1)
+            r, rop = build(depth - 1)
+            o.update(lc=l, rc=r, flags=(2 if lop else 0) | (1 if rop else 0))
+        o["done"] = True
+        return idx, True
+
+    root, is_op = build(4 if rng.random() < 0.5 else 3)
+    while not is_op or root != 0:   # the root must be operator 0
+        P.clear(); ops.clear(); del mtx[1:]
+        root, is_op = build(4 if rng.random() < 0.5 else 3)
+    O = np.zeros((len(ops), 16), np.float32)
+    for i, o in enumerate(ops):
+        O[i, 0:4] = [o["type"], o["lc"], o["rc"], NULL_BLOB]
+        O[i, 4:6], O[i, 7] = o["res"], o["flags"]
+        O[i, 8:11], O[i, 12:15] = -50.0, 50.0   # operator boxes: wide open (instance cull never triggers wrongly)
+    Pm = np.array(P, np.float32)
+    header = np.zeros(12, np.float32)
+    header[0:3], header[3], header[4:7], header[7] = -1.5, 1, 1.5, 1
+    header[8:12] = [len(P), len(ops), len(mtx), NULL_BLOB]
+    return BlobTree(header, O, Pm, np.array(mtx, np.float32))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_trees_match_oracle(gpu, seed):
+    """Randomised BlobTrees (all primitive types, affine matrices, nested binary / unary / range operators, Ricci blends;
+    odd seeds add instances of subtrees and of primitives): point fields and a swept grid against the oracle.  The sweep
+    runs the culled kernel, computeFieldArray the unculled one -- both must agree with each other bit for bit and with
+    the oracle to 4e-6 (sqrt / pow primitives differ by an ulp between the two libm's)."""
+    rng = np.random.default_rng(1000 + seed)
+    blob = _random_tree(rng, 0, with_instances=bool(seed & 1))
+    g, o = GpuPoly(blob), OrcPoly(blob)
+    pts = np.zeros((4000, 4), np.float32)
+    pts[:, :3] = rng.uniform(-1.6, 1.6, size=(4000, 3)).astype(np.float32)
+    got, want = g.compute_field_array(pts)[:, 3], o.field_array(pts)[:, 3]
+    assert np.isfinite(want).all()
+    assert np.abs(got - want).max() <= 4e-6 * max(1.0, np.abs(want).max())
+    g.sweep_grid((-1.5, -1.5, -1.5), 0.1, (31, 30, 29))
+    grid = g.read_grid()
+    assert np.array_equal(g.compute_field_array(grid)[:, 3], grid[:, 3])
+    og = o.sweep_grid((-1.5, -1.5, -1.5), 0.1, (31, 30, 29))
+    assert np.abs(grid[:, 3] - og[:, 3]).max() <= 4e-6 * max(1.0, np.abs(og[:, 3]).max())
