@@ -12,6 +12,25 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _mesh(n, world):
+    """n > 0: truth cube split into i-plane slabs; n < 0: Delaunay tetrahedra of |n| random points in RANDOM node order split
+    into equal index ranges -- every rank neighbours every other and the halos are large and irregular."""
+    from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
+    if n > 0:
+        v, t = truth_cube(n, n, n, 0.1)
+        fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+        planes = [n * r // world for r in range(world + 1)]
+        return v, t, fixed, np.array([p * n * n for p in planes], np.int32)
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(77)
+    v = rng.uniform(0, 1, size=(-n, 3))
+    t = Delaunay(v).simplices.astype(np.int32)
+    vol = np.einsum("ij,ij->i", v[t[:, 1]] - v[t[:, 0]], np.cross(v[t[:, 2]] - v[t[:, 0]], v[t[:, 3]] - v[t[:, 0]])) / 6
+    t = np.ascontiguousarray(t[np.abs(vol) > 1e-7])
+    fixed = fixed_vertices_to_dofs(np.nonzero(v[:, 0] < 0.12)[0])
+    return v, t, fixed, np.array([(-n) * r // world for r in range(world + 1)], np.int32)
+
+
 def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False):
     """p2p: 0 = host-staged test communicator, else the peer-to-peer exchange mode (lib.FB_XCH_P2P / _SUMS / _FUSED)."""
     try:
@@ -25,10 +44,7 @@ def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False
         L = fl.lib()
         comm = C.c_void_p()
         fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
-        v, t = truth_cube(n, n, n, 0.1)
-        fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
-        planes = [n * r // world for r in range(world + 1)]
-        splits = np.array([p * n * n for p in planes], np.int32)
+        v, t, fixed, splits = _mesh(n, world)
         g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), pcg_variant=variant)
         assert L.fb_fem_transport(g.h) == (p2p if p2p else 1), L.fb_fem_transport(g.h)
         if quit_early and rank == world - 1:   # a rank that stops taking part: the others must time out, not hang
@@ -37,8 +53,8 @@ def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False
             q.join_thread()   # flush the feeder thread before leaving without cleanup
             os._exit(0)
         f = np.zeros(g.r)
-        f[1::3] = -10000.0
-        f[0::3] = 300.0 * np.sin(np.arange(len(v)))   # not symmetric across the slabs
+        f[1::3] = -10000.0 if n > 0 else -200.0
+        f[0::3] = (300.0 if n > 0 else 20.0) * np.sin(np.arange(len(v)))   # not symmetric across the slabs
         its = []
         for _ in range(steps):
             g.set_external_forces(f)
@@ -58,13 +74,22 @@ def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False
 @pytest.mark.parametrize("world,variant,p2p", [(2, 0, 0), (3, 0, 0), (2, 1, 0), (4, 2, 0),
                                                (2, 0, 2), (3, 0, 3), (2, 0, 4), (4, 0, 4), (3, 1, 4), (3, 2, 4)])
 def test_sharded_ranks_on_one_gpu_match_the_unsharded_handle(gpu, world, variant, p2p):
+    _run_sharded(world, variant, p2p, 12)
+
+
+@pytest.mark.parametrize("world,p2p", [(2, 0), (3, 2), (3, 4), (4, 4)])
+def test_sharded_unstructured_mesh_all_to_all_halos(gpu, world, p2p):
+    """Delaunay mesh in random node order cut into equal index ranges: every rank is every other rank's neighbour."""
+    _run_sharded(world, 0, p2p, -900)
+
+
+def _run_sharded(world, variant, p2p, n):
     """p2p != 0: the direct inbox transport (HIP IPC mapped inboxes, kernels that store into the peer's inbox and spin --
     bounded -- on their own flags) between processes that share the GPU, in its three forms: an own kernel per exchange
     (2), sums inside the PCG kernels (3), sums and halo values inside the PCG kernels (4)."""
     import multiprocessing as mp
     from fembrain_amd.fem import FemIntegrator
-    from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
-    n, steps = 12, 2
+    steps = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     name = "/fembrain_test_%d_%d_%d_%d" % (os.getpid(), world, variant, int(p2p))
@@ -81,12 +106,11 @@ def test_sharded_ranks_on_one_gpu_match_the_unsharded_handle(gpu, world, variant
             p.join(timeout=30)
             if p.is_alive():
                 p.kill()
-    v, t = truth_cube(n, n, n, 0.1)
-    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    v, t, fixed, _ = _mesh(n, world)
     g = FemIntegrator(v, t, fixed, pcg_variant=variant)
     f = np.zeros(g.r)
-    f[1::3] = -10000.0
-    f[0::3] = 300.0 * np.sin(np.arange(len(v)))
+    f[1::3] = -10000.0 if n > 0 else -200.0
+    f[0::3] = (300.0 if n > 0 else 20.0) * np.sin(np.arange(len(v)))
     its = []
     for _ in range(steps):
         g.set_external_forces(f)
