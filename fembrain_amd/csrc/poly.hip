@@ -48,6 +48,8 @@ struct Instr {
   int unary;
   int dst;     // slot that receives the result (RANGE, OP, LEAVE); -1 = only `out`
   int skip;    // ENTER: index of the matching LEAVE (taken when the mapped point is outside the box)
+  int ca, cb;  // colour pass: OP: primitive whose colour a primitive operand carries (an instance of a primitive shows the
+               // original's colour).  ADDSLOT: ca = primitive whose colour weighs the slot, cb = 1 if the slot REPLACES the colour
   float p0, p1;
   float lo[3], hi[3];  // ENTER: box of the original operator (isOutsideOp, Polygonizer.cpp:1464-1483)
 };
@@ -849,6 +851,119 @@ __global__ __launch_bounds__(kPB) void k_surface_elements(Grid G, long long ntri
   o[0] = id[0]; o[1] = id[1]; o[2] = id[2];
 }
 
+// FieldComputer::fieldValueAndColor (Polygonizer.cpp:2110-2353) through the compiled order: the reference evaluates the field
+// once, keeping every primitive's and operator's value, and then walks the operators a second time IN THE SAME ORDER to
+// combine the colours; here both happen in one pass over the program.  Every value slot has five channels (field as the
+// operator sees it, field as the colour pass sees it, r, g, b) in a global scratch array [slot][channel][thread]; the
+// evaluation runs once per surface vertex, so its speed does not matter.  Rules: range operators add 2 f * colour of their
+// primitives onto the RUNNING colour; blend / Ricci 2 f_l c_l + 2 f_r c_r; union / intersection channel-wise max / min of
+// the weighted colours; (smooth) difference the child whose value the operator took; warps the child's colour; an
+// instanced subtree under a binary operator shows its own colour walk WITHOUT the box cull (computeInstancedNodeFieldAndColor,
+// :2355-2410), inside a range it counts with the instance node's colour and the culled field.
+__device__ float eval_field_color(const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
+                                  const float* __restrict__ mtx, float x, float y, float z, float* __restrict__ S, size_t nth, float rgb[3]) {
+  float out = 0.0f, col[3] = {0.0f, 0.0f, 0.0f};
+  auto at = [&](int slot, int ch) -> float& { return S[((size_t)slot * 5 + ch) * nth]; };
+  auto pcol = [&](int i, int k) { return prims[20 * i + 16 + k]; };
+  if (n_instr == 0) {
+    for (int i = 0; i < n_prims; i++) out = out + prim_field(prims, mtx, i, x, y, z);
+    for (int k = 0; k < 3; k++) rgb[k] = pcol(0, k);
+    return out;
+  }
+  for (int pc = 0; pc < n_instr; pc++) {
+    const Instr& in = prog[pc];
+    switch (in.kind) {
+      case 0:
+        for (int i = in.a; i <= in.b; i++) {
+          const float f = prim_field(prims, mtx, i, x, y, z);
+          out = out + f;
+          const float cur = 2.0f * (0.5f + f) - 1.0f;
+          for (int k = 0; k < 3; k++) col[k] = col[k] + cur * pcol(i, k);
+        }
+        break;
+      case 1: {
+        float lf, lfc, rf = 0.0f, rfc = 0.0f, lc[3], rc[3] = {0.0f, 0.0f, 0.0f};
+        if (in.a >= 0) { lf = lfc = prim_field(prims, mtx, in.a, x, y, z); for (int k = 0; k < 3; k++) lc[k] = pcol(in.ca, k); }
+        else { const int s = -1 - in.a; lf = at(s, 0); lfc = at(s, 1); for (int k = 0; k < 3; k++) lc[k] = at(s, 2 + k); }
+        if (!in.unary) {
+          if (in.b >= 0) { rf = rfc = prim_field(prims, mtx, in.b, x, y, z); for (int k = 0; k < 3; k++) rc[k] = pcol(in.cb, k); }
+          else { const int s = -1 - in.b; rf = at(s, 0); rfc = at(s, 1); for (int k = 0; k < 3; k++) rc[k] = at(s, 2 + k); }
+        }
+        out = apply_op(in.optype, lf, rf, in.p0, in.p1, out);
+        const float wa = 2.0f * (0.5f + lfc) - 1.0f, wb = 2.0f * (0.5f + rfc) - 1.0f;
+        switch (in.optype) {
+          case opBlend: case opRicciBlend: for (int k = 0; k < 3; k++) col[k] = wa * lc[k] + wb * rc[k]; break;
+          case opUnion: for (int k = 0; k < 3; k++) col[k] = fmaxf(wa * lc[k], wb * rc[k]); break;
+          case opIntersect: for (int k = 0; k < 3; k++) col[k] = fminf(wa * lc[k], wb * rc[k]); break;
+          case opDif: case opSmoothDif: {
+            const float a = (lfc == out) ? 1.0f : 0.0f, b = ((1.0f - rfc) == out) ? 1.0f : 0.0f;
+            for (int k = 0; k < 3; k++) col[k] = a * lc[k] + b * rc[k];
+          } break;
+          case opWarpBend: case opWarpTwist: case opWarpTaper: case opWarpShear: for (int k = 0; k < 3; k++) col[k] = lc[k]; break;
+          default: break;
+        }
+      } break;
+      case 2: {  // frame: x, y, z, out, inside in channel 0 of the 5 frame slots, the running colour in channel 1 of the first 3
+        at(in.b, 0) = x; at(in.b + 1, 0) = y; at(in.b + 2, 0) = z; at(in.b + 3, 0) = out;
+        for (int k = 0; k < 3; k++) at(in.b + k, 1) = col[k];
+        if (in.a != 0) {
+          const float* m = mtx + 12 * in.a;
+          const float tx = m[0] * x + m[1] * y + m[2] * z + m[3];
+          const float ty = m[4] * x + m[5] * y + m[6] * z + m[7];
+          const float tz = m[8] * x + m[9] * y + m[10] * z + m[11];
+          x = tx; y = ty; z = tz;
+        }
+        const bool inside = x >= in.lo[0] && in.hi[0] >= x && y >= in.lo[1] && in.hi[1] >= y && z >= in.lo[2] && in.hi[2] >= z;
+        at(in.b + 4, 0) = inside ? 1.0f : 0.0f;
+        out = 0.0f; col[0] = col[1] = col[2] = 0.0f;
+      } continue;
+      case 3: {
+        const float v = out, vc[3] = {col[0], col[1], col[2]};
+        const bool inside = at(in.a + 4, 0) != 0.0f;
+        x = at(in.a, 0); y = at(in.a + 1, 0); z = at(in.a + 2, 0); out = at(in.a + 3, 0);
+        for (int k = 0; k < 3; k++) col[k] = at(in.a + k, 1);
+        at(in.dst, 0) = inside ? v : 0.0f;   // what fieldValue saw (isOutsideOp cull)
+        at(in.dst, 1) = v;                   // what the colour pass re-evaluates
+        for (int k = 0; k < 3; k++) at(in.dst, 2 + k) = vc[k];
+      } continue;
+      default: {
+        const float f = at(in.a, 0);
+        out = out + f;
+        if (in.cb) { for (int k = 0; k < 3; k++) col[k] = pcol(in.ca, k); }
+        else { const float cur = 2.0f * (0.5f + f) - 1.0f; for (int k = 0; k < 3; k++) col[k] = col[k] + cur * pcol(in.ca, k); }
+      } continue;
+    }
+    if (in.dst >= 0) { at(in.dst, 0) = out; at(in.dst, 1) = out; for (int k = 0; k < 3; k++) at(in.dst, 2 + k) = col[k]; }
+  }
+  for (int k = 0; k < 3; k++) rgb[k] = col[k];
+  return out;
+}
+
+// vertex colours of the surface (ComputeVertexAttribs' ComputeFieldAndColor, Polygonizer.cl:1544-1553), RGBA with A = 1
+__global__ __launch_bounds__(kPB) void k_surface_colors(long long first, long long count, const float* __restrict__ pos,
+                                                        const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
+                                                        const float* __restrict__ mtx, float* __restrict__ scratch, long long nth, float4* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (t >= count) return;
+  const long long j = first + t;
+  float rgb[3];
+  (void)eval_field_color(prog, n_instr, n_prims, prims, mtx, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], scratch + t, (size_t)nth, rgb);
+  out[j] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+}
+
+// also: the field and colour of arbitrary points (FieldComputer::fieldValueAndColor), for the parity tests
+__global__ __launch_bounds__(kPB) void k_field_color_array(long long count, float4* __restrict__ pts, const Instr* __restrict__ prog, int n_instr,
+                                                           int n_prims, const float* __restrict__ prims, const float* __restrict__ mtx,
+                                                           float* __restrict__ scratch, long long nth, float* __restrict__ rgb_out) {
+  const long long t = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (t >= count) return;
+  float4 p = pts[t];
+  float rgb[3];
+  p.w = eval_field_color(prog, n_instr, n_prims, prims, mtx, p.x, p.y, p.z, scratch + t, (size_t)nth, rgb);
+  pts[t] = p;
+  rgb_out[3 * t] = rgb[0]; rgb_out[3 * t + 1] = rgb[1]; rgb_out[3 * t + 2] = rgb[2];
+}
+
 // ComputeOffSurfacePointsAndFields (Polygonizer.cl:1329-1350): v +- len * normal and the field there, (x, y, z, f) pairs
 __global__ __launch_bounds__(kPB) void k_off_surface(long long nv, float len, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                      const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
@@ -994,6 +1109,7 @@ struct TreeCompiler {
       Instr add;
       memset(&add, 0, sizeof add);
       add.kind = 4; add.a = inner; add.dst = -1;
+      add.ca = origin; add.cb = 1;  // computeInstancedNodeFieldAndColor: the colour of the original primitive node
       prog.push_back(add);
       release(inner, 1);
     }
@@ -1008,6 +1124,10 @@ struct TreeCompiler {
     --nest;
     return FB_OK;
   }
+
+  // primitive whose colour an operand primitive shows: itself, or -- for an instance of a primitive -- its immediate
+  // original (computeInstancedNodeFieldAndColor, Polygonizer.cpp:2403-2409)
+  int color_source(int i) const { return ((int)prim(i)[0] == primInstance && (int)prim(i)[14] == 0) ? (int)prim(i)[12] : i; }
 
   // operand reference of a primitive child: the primitive itself, or the slot of its expanded instance
   int operand(int i, int* ref, int* slot) {
@@ -1050,6 +1170,7 @@ struct TreeCompiler {
           Instr add;
           memset(&add, 0, sizeof add);
           add.kind = 4; add.a = s; add.dst = -1;
+          add.ca = i; add.cb = 0;  // inside a range the instance counts with its own node colour
           prog.push_back(add);
           release(s, 1);
           first = i + 1;
@@ -1071,6 +1192,8 @@ struct TreeCompiler {
         else if (rop) { in.b = -1 - where[rc]; sb = where[rc]; } else FB_TRY(operand(rc, &in.b, &sb));
         in.kind = 1; in.optype = type; in.unary = unary ? 1 : 0;
         in.p0 = o[4]; in.p1 = o[5];
+        in.ca = in.a >= 0 ? color_source(in.a) : 0;
+        in.cb = (!unary && in.b >= 0) ? color_source(in.b) : 0;
         if (sa >= 0) release(sa, 1);
         if (sb >= 0 && sb != sa) release(sb, 1);
         prog.push_back(in);
@@ -1548,6 +1671,42 @@ int fb_poly_apply_displacements(fb_poly_t h, int mesh, int n_dof, const double* 
   if (xyz_out) return h->deformed.download(xyz_out, (size_t)n, h->stream);
   FB_HIP(hipStreamSynchronize(h->stream));
   return FB_OK;
+}
+
+int fb_poly_read_surface_colors(fb_poly_t h, float* rgba) {
+  CHECK_POLY(h);
+  if (!h->surfaced) return fail(FB_EINVAL, "run fb_poly_surface first");
+  if (!rgba) return fail(FB_EINVAL, "null output");
+  const long long nv = h->counts.n_surface_vertices;
+  if (nv == 0) return FB_OK;
+  const long long kChunk = 1 << 16;
+  DevBuf<float> scratch;
+  DevBuf<float4> out;
+  FB_TRY(scratch.alloc((size_t)5 * std::max(1, h->depth) * (size_t)std::min(nv, kChunk)));
+  FB_TRY(out.alloc((size_t)nv));
+  for (long long first = 0; first < nv; first += kChunk) {
+    const long long n = std::min(kChunk, nv - first), nth = std::min(nv, kChunk);
+    hipLaunchKernelGGL(k_surface_colors, dim3((int)((n + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, first, n, h->sv.p, h->d_prog.p, (int)h->prog.size(),
+                       h->n_prims, h->d_prims.p, h->d_mtx.p, scratch.p, nth, out.p);
+    FB_HIP(hipGetLastError());
+  }
+  return out.download((float4*)rgba, (size_t)nv, h->stream);
+}
+
+int fb_poly_field_color_array(fb_poly_t h, int n, float* xyzf, float* rgb) {
+  CHECK_POLY(h);
+  if (n < 0 || (n > 0 && (!xyzf || !rgb))) return fail(FB_EINVAL, "bad point array");
+  if (n == 0) return FB_OK;
+  DevBuf<float4> pts;
+  DevBuf<float> scratch, col;
+  FB_TRY(pts.upload((const float4*)xyzf, (size_t)n, h->stream));
+  FB_TRY(scratch.alloc((size_t)5 * std::max(1, h->depth) * (size_t)n));
+  FB_TRY(col.alloc((size_t)3 * n));
+  hipLaunchKernelGGL(k_field_color_array, dim3(ceil_div(n, kPB)), dim3(kPB), 0, h->stream, (long long)n, pts.p, h->d_prog.p, (int)h->prog.size(), h->n_prims,
+                     h->d_prims.p, h->d_mtx.p, scratch.p, (long long)n, col.p);
+  FB_HIP(hipGetLastError());
+  FB_TRY(pts.download((float4*)xyzf, (size_t)n, h->stream));
+  return col.download(rgb, (size_t)3 * n, h->stream);
 }
 
 int fb_poly_off_surface(fb_poly_t h, float len, float* xyzf_pairs) {

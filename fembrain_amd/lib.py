@@ -138,6 +138,8 @@ def lib():
         "fb_poly_cube_table": (C.c_int, [_bp, _bp]),
         "fb_poly_time_surface": (C.c_int, [vp, C.c_int, _dp]),
         "fb_poly_off_surface": (C.c_int, [vp, C.c_float, _fp]),
+        "fb_poly_read_surface_colors": (C.c_int, [vp, _fp]),
+        "fb_poly_field_color_array": (C.c_int, [vp, C.c_int, _fp, _fp]),
         "fb_poly_interpolate_displacements": (C.c_int, [vp, C.c_int, _dp, _fp]),
         "fb_poly_read_surface_binding": (C.c_int, [vp, _up, _fp]),
         "fb_poly_compile_info": (C.c_int, [C.c_int, _fp, C.c_int, _fp, _ip, _ip]),

@@ -149,6 +149,19 @@ class GpuPoly:
         _l.check(self._L.fb_poly_read_surface_binding(self.h, _l.uptr(pairs), _l.fptr(w)))
         return pairs, w
 
+    def read_surface_colors(self):
+        """RGBA per surface vertex (ComputeVertexAttribs' colour output)."""
+        out = np.empty((self.counts.n_surface_vertices, 4), np.float32)
+        _l.check(self._L.fb_poly_read_surface_colors(self.h, _l.fptr(out)))
+        return out
+
+    def field_color_array(self, xyzf):
+        """FieldComputer::fieldValueAndColor: (xyzf with the field filled in, rgb)."""
+        a = np.ascontiguousarray(xyzf, dtype=np.float32).reshape(-1, 4).copy()
+        rgb = np.empty((len(a), 3), np.float32)
+        _l.check(self._L.fb_poly_field_color_array(self.h, len(a), _l.fptr(a), _l.fptr(rgb)))
+        return a, rgb
+
     # GPUPoly::computeOffSurfacePointsAndFields
     def compute_off_surface_points_and_fields(self, length):
         out = np.empty((2 * self.counts.n_surface_vertices, 4), np.float32)

@@ -71,6 +71,14 @@ class GPUPoly {
     verticesXYZ.resize(3 * (size_t)ctVertices); normals.resize(3 * (size_t)ctVertices);
     return fb_poly_read_surface(h_, verticesXYZ.data(), normals.data(), nullptr) == FB_OK;
   }
+  // the colour buffer of the surface mesh (m_outputMesh's vertex colours, written by ComputeVertexAttribs): RGBA per vertex
+  bool readBackColors(U32& ctVertices, std::vector<float>& colorsRGBA) const {
+    ctVertices = (U32)m_counts.n_surface_vertices;
+    colorsRGBA.resize(4 * (size_t)ctVertices);
+    return fb_poly_read_surface_colors(h_, colorsRGBA.data()) == FB_OK;
+  }
+  // FieldComputer::fieldValueAndColor for an array of points
+  bool computeFieldAndColorArray(U32 ctVertices, float* xyzf, float* rgb) const { return fb_poly_field_color_array(h_, (int)ctVertices, xyzf, rgb) == FB_OK; }
   // GPUPoly::computeOffSurfacePointsAndFields (OclPolygonizer.cpp:1045-1107); `interval` is unused there as well
   int computeOffSurfacePointsAndFields(U32 /*interval*/, float len, U32& ctOutVertices, std::vector<float>& outOffSurfacePoints) {
     ctOutVertices = 2 * (U32)m_counts.n_surface_vertices;

@@ -254,7 +254,7 @@ int fb_poly_read_tetmesh(fb_poly_t h, float* xyz, unsigned int* tets);
 /* ---- marching-cubes surface: GPUPoly::run steps 3,4,6,7 (OclPolygonizer.cpp:663-757) ------------------------------
  * Replaces ComputeVertexAttribs (data/opencl/Polygonizer.cl:1429-1561, linear root + forward-difference normal,
  * 4 field evaluations per vertex), ComputeElements (:1610-1670) and the two host scans between them.  Needs
- * fb_poly_classify on a grid swept WITH stored samples.  Vertex colours (ComputeFieldAndColor) are not produced. */
+ * fb_poly_classify on a grid swept WITH stored samples.  Vertex colours: fb_poly_read_surface_colors. */
 int fb_poly_surface(fb_poly_t h, fb_poly_counts* counts);
 /* GPUPoly::readbackMeshV3T3 (OclPolygonizer.cpp:1696-1744): 3 floats per vertex / normal, 3 uint32 per triangle;
  * any pointer may be NULL */
@@ -281,6 +281,11 @@ int fb_poly_interpolate_displacements(fb_poly_t h, int n_tet_dof, const double* 
 /* per surface vertex: the pair (a, b) of tet-mesh vertex ids and the weight t (either may be NULL) */
 int fb_poly_read_surface_binding(fb_poly_t h, unsigned int* tet_vertex_pairs, float* weights);
 
+/* Vertex colours of the surface mesh (the colour output of ComputeVertexAttribs / FieldComputer::fieldValueAndColor,
+ * src/implicit/Polygonizer.cpp:2110-2410): 4 floats (r, g, b, 1) per surface vertex.  Needs fb_poly_surface. */
+int fb_poly_read_surface_colors(fb_poly_t h, float* rgba);
+/* FieldComputer::fieldValueAndColor for n points: xyzf (x, y, z, f) gets f, rgb 3 floats per point */
+int fb_poly_field_color_array(fb_poly_t h, int n, float* xyzf, float* rgb);
 /* GPUPoly::computeOffSurfacePointsAndFields (OclPolygonizer.cpp:1045-1107; kernel Polygonizer.cl:1329-1350): for every
  * surface vertex v with normal n the two points v + len n and v - len n with their field values; xyzf_pairs receives
  * 8 floats per vertex (x, y, z, f outside then inside).  Needs fb_poly_surface. */

@@ -34,6 +34,7 @@ def _lib():
     lib.orc_scan.argtypes = [_up, _up, C.c_size_t]
     lib.orc_tet_vertices.argtypes = [_fp, _up, _up, C.c_size_t, _fp]
     lib.orc_tet_elements.argtypes = [_up, _up, _up, _ip, _up]
+    lib.orc_field_color_array.argtypes = tree + [C.c_int, _fp, _fp]
     lib.orc_cube_table.argtypes = [_bp, _bp]
     lib.orc_vertex_attribs.argtypes = tree + [_fp, _ip, _up, _bp, _up, _fp, _fp]
     lib.orc_cell_elements.argtypes = [_bp, _ip, _bp, _bp, _up, _up, _bp, _up]
@@ -59,6 +60,13 @@ class OrcPoly:
         a = np.ascontiguousarray(xyzf, dtype=np.float32).reshape(-1, 4).copy()
         self.lib.orc_field_array(*self._tree, len(a), _f(a))
         return a
+
+    def field_color_array(self, xyzf):
+        """FieldComputer::fieldValueAndColor at n points: (xyzf with the field filled in, rgb)."""
+        a = np.ascontiguousarray(xyzf, dtype=np.float32).reshape(-1, 4).copy()
+        rgb = np.empty((len(a), 3), np.float32)
+        self.lib.orc_field_color_array(*self._tree, len(a), _f(a), _f(rgb))
+        return a, rgb
 
     def grid_dims(self, cellsize):
         lo, hi = self.blob.bbox

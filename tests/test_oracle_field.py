@@ -159,3 +159,34 @@ def test_instanced_models_compile_for_the_device():
     b.prims[2, 12] = 0.0   # the instance now points at the root union, which contains it
     steps, slots = C.c_int(0), C.c_int(0)
     assert L.fb_poly_compile_info(b.n_ops, fl.fptr(b.ops), b.n_prims, fl.fptr(b.prims), C.byref(steps), C.byref(slots)) != 0
+
+
+def test_color_walk_known_answers():
+    """fieldValueAndColor (Polygonizer.cpp:2110-2353) on trees small enough to do by hand: a lone primitive shows its colour;
+    a blend of two points 2 f_l c_l + 2 f_r c_r; a union the channel-wise maximum; a difference the child it took."""
+    from fembrain_amd.blobtree import make_tree
+    a, b = (0, (-0.3, 0, 0), (0, 0, 0), (0, 0, 0)), (0, (0.3, 0, 0), (0, 0, 0), (0, 0, 0))
+    pts = np.float32([[0.0, 0.1, 0.0, 0], [-0.3, 0.05, 0.1, 0], [0.4, 0, 0, 0]])
+    ca, cb = np.float32([1, 0.25, 0]), np.float32([0, 0.5, 1])
+    for optype in (4, 0, 1, 2):   # opBlend, opUnion, opIntersect, opDif
+        blob = make_tree([a, b], [(optype, 0, 1, 0, 0, 0)])
+        blob.prims[0, 16:19], blob.prims[1, 16:19] = ca, cb
+        o = OrcPoly(blob)
+        f, c = o.field_color_array(pts)
+        assert np.array_equal(f[:, 3], o.field_array(pts)[:, 3])
+        one = OrcPoly(make_tree([a]))
+        two = OrcPoly(make_tree([b]))
+        fa, fb = one.field_array(pts)[:, 3], two.field_array(pts)[:, 3]
+        wa, wb = (np.float32(2) * (np.float32(0.5) + fa) - 1)[:, None] * ca, (np.float32(2) * (np.float32(0.5) + fb) - 1)[:, None] * cb
+        if optype == 4:
+            want = wa + wb
+        elif optype == 0:
+            want = np.maximum(wa, wb)
+        elif optype == 1:
+            want = np.minimum(wa, wb)
+        else:
+            want = np.where((fa == f[:, 3])[:, None], ca, 0) + np.where((1 - fb == f[:, 3])[:, None], cb, 0)
+        assert np.array_equal(c, want.astype(np.float32)), optype
+    lone = make_tree([a])
+    lone.prims[0, 16:19] = ca
+    assert np.array_equal(OrcPoly(lone).field_color_array(pts)[1], np.tile(ca, (3, 1)))

@@ -513,3 +513,63 @@ def test_random_trees_match_oracle(gpu, seed):
     assert np.array_equal(g.compute_field_array(grid)[:, 3], grid[:, 3])
     og = o.sweep_grid((-1.5, -1.5, -1.5), 0.1, (31, 30, 29))
     assert np.abs(grid[:, 3] - og[:, 3]).max() <= 4e-6 * max(1.0, np.abs(og[:, 3]).max())
+
+
+# ---- vertex colours (FieldComputer::fieldValueAndColor, Polygonizer.cpp:2110-2410) -------------------------------------------
+# Parity unpinned by reference outputs: the reference holds no colour fixtures; the oracle restates its two-pass walk.
+def _assert_colors(got_f, got_c, want_f, want_c):
+    """fields to the usual 4e-6; colours to 2e-5 of their scale, except where a (smooth) difference / union / intersection
+    picks the other child because the two candidates are an ulp apart between the two libm's (a handful of points at most)"""
+    assert np.isfinite(want_c).all()
+    assert np.abs(got_f - want_f).max() <= 4e-6 * max(1.0, np.abs(want_f).max())
+    bad = np.abs(got_c - want_c).max(axis=1) > 2e-5 * max(1.0, np.abs(want_c).max())
+    assert bad.mean() <= 2e-3, "%d of %d colours differ" % (bad.sum(), len(bad))
+
+
+@pytest.mark.parametrize("name", ["peanutInstanced", "complex", "pizaL2P4", "piza4x4", "tumor", "3slabs", "CylinderWithHoles"])
+def test_field_color_matches_oracle(gpu, name):
+    blob = read_blob(os.path.join(GOLD, "blob", name + ".blob"))
+    g, o = GpuPoly(blob), OrcPoly(blob)
+    lo, hi = blob.bbox
+    rng = np.random.default_rng(5)
+    pts = np.zeros((6000, 4), np.float32)
+    pts[:, :3] = (lo + (hi - lo) * rng.random((6000, 3))).astype(np.float32)
+    got, got_c = g.field_color_array(pts)
+    want, want_c = o.field_color_array(pts)
+    _assert_colors(got[:, 3], got_c, want[:, 3], want_c)
+    assert np.array_equal(got[:, 3], g.compute_field_array(pts)[:, 3])   # the colour walk leaves the field alone
+    assert np.abs(want_c).max() > 0.0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_field_color_random_trees(gpu, seed):
+    rng = np.random.default_rng(1000 + seed)
+    blob = _random_tree(rng, 0, with_instances=bool(seed & 1))
+    blob.prims[:, 16:19] = rng.random((blob.n_prims, 3)).astype(np.float32)
+    g, o = GpuPoly(blob), OrcPoly(blob)
+    pts = np.zeros((4000, 4), np.float32)
+    pts[:, :3] = rng.uniform(-1.6, 1.6, size=(4000, 3)).astype(np.float32)
+    got, got_c = g.field_color_array(pts)
+    want, want_c = o.field_color_array(pts)
+    _assert_colors(got[:, 3], got_c, want[:, 3], want_c)
+    assert np.array_equal(got[:, 3], g.compute_field_array(pts)[:, 3])
+
+
+def test_single_primitive_color(gpu):
+    blob = sphere_blob()
+    blob.prims[0, 16:19] = [0.25, 0.5, 0.75]
+    g = GpuPoly(blob)
+    _, c = g.field_color_array([[0.1, 0.2, 0.3, 0.0]])
+    assert np.array_equal(c[0], np.float32([0.25, 0.5, 0.75]))
+
+
+def test_surface_colors(gpu):
+    blob = read_blob(os.path.join(GOLD, "blob", "peanutInstanced.blob"))
+    g, o = GpuPoly(blob), OrcPoly(blob)
+    g.run(0.12)
+    v, _, _ = g.read_surface()
+    rgba = g.read_surface_colors()
+    assert rgba.shape == (len(v), 4) and np.all(rgba[:, 3] == 1.0) and len(v) > 1000
+    pts = np.concatenate([v, np.zeros((len(v), 1), np.float32)], axis=1)
+    f, want = o.field_color_array(pts)
+    _assert_colors(g.compute_field_array(pts)[:, 3], rgba[:, :3], f[:, 3], want)
