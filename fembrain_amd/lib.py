@@ -144,6 +144,16 @@ def lib():
         "fb_poly_read_surface_binding": (C.c_int, [vp, _up, _fp]),
         "fb_poly_compile_info": (C.c_int, [C.c_int, _fp, C.c_int, _fp, _ip, _ip]),
         "fb_poly_apply_displacements": (C.c_int, [vp, C.c_int, C.c_int, _dp, _fp]),
+        "fb_cut_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _dp, C.c_int, _up]),
+        "fb_cut_destroy": (None, [vp]),
+        "fb_cut_set_vertices": (C.c_int, [vp, C.c_int, _dp]),
+        "fb_cut_face_centroids": (C.c_int, [vp]),
+        "fb_cut_face_intersections": (C.c_int, [vp, _dp, _dp, _ip]),
+        "fb_cut_edge_intersections": (C.c_int, [vp, _dp, _ip]),
+        "fb_cut_read": (C.c_int, [vp, C.c_int, _up, _fp]),
+        "fb_cut_read_hits": (C.c_int, [vp, C.c_int, C.c_int, _up, _fp, _ip]),
+        "fb_cut_segment_triangles": (C.c_int, [C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
+        "fb_cut_time": (C.c_int, [vp, C.c_int, _dp, _dp, C.c_int, _dp]),
     }
     sig.update(poly_sig)
     for name, (res, args) in sig.items():

@@ -367,6 +367,17 @@ class Deformable {
   U32 getDof() const { return m_dof; }
   U32 getCollidedCount() const { return m_ctCollided; }
   HipIntegrator* integrator() { return m_lpIntegrator; }
+  // what getVolMesh()->countNodes() / countCells() / const_nodeAt(i).pos / const_cellAt(e).nodes give the cutting tool
+  // (Cutting.cpp:96-147): the current (displaced) node positions and the element list
+  U32 countNodes() const { return (U32)(m_rest.size() / 3); }
+  U32 countCells() const { return (U32)(m_elements.size() / 4); }
+  const std::vector<int>& cells() const { return m_elements; }
+  std::vector<double> currentPositions() {
+    if (m_lpIntegrator) m_lpIntegrator->GetqState(m_q.data(), nullptr, nullptr);
+    std::vector<double> p(m_rest);
+    for (size_t i = 0; i < p.size() && i < m_q.size(); i++) p[i] += m_q[i];
+    return p;
+  }
   // Deformable::computeVolume (Deformable.cpp:260-279) on the current displaced positions
   double computeVolume(double* arrStore = nullptr, U32 count = 0) {
     m_lpIntegrator->GetqState(m_q.data(), nullptr, nullptr);

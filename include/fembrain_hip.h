@@ -295,6 +295,42 @@ int fb_poly_time_surface(fb_poly_t h, int reps, double* seconds);
 /* average device seconds of one sweep / one classify+tetrahedralize pipeline on the current grid */
 int fb_poly_time_pipeline(fb_poly_t h, int reps, double* sweep_seconds, double* pipeline_seconds);
 
+/* ---- cutting tool: scalpel / tet-mesh intersection tests --------------------------------------------------------------------
+ * Replaces the device half of PS::FEM::Cutting (src/deformable/Cutting.cpp:87-497) and the four kernels of
+ * data/opencl/Cutting.cl (:158-341).  Face f of tet t is face 4 t + f with corners faceMask[f] = {0,1,2} {1,2,3} {2,3,0}
+ * {0,1,3}; edge e of tet t is edge 6 t + e with ends {0,1} {1,2} {2,0} {0,3} {1,3} {2,3} (Cutting.cl:174-176, :290-292).
+ * fp32 arithmetic, operation for operation that of the reference's IntersectSegmentTriangleF
+ * (src/graphics/Intersections.cpp:12-64). */
+typedef struct fb_cut_s* fb_cut_t;
+#define FB_CUT_FACES 0
+#define FB_CUT_EDGES 1
+/* Cutting::createMemBuffers (Cutting.cpp:87-167): node positions (3 doubles each, rounded to float as there) and the
+ * tets' node ids (4 each).  Ids are checked against n_vertices (FB_EINVAL; the reference does not check). */
+int fb_cut_create(fb_cut_t* out, int device, int n_vertices, const double* xyz, int n_tets, const unsigned int* tets);
+void fb_cut_destroy(fb_cut_t h);
+/* new positions of the same nodes (the deformed mesh) */
+int fb_cut_set_vertices(fb_cut_t h, int n_vertices, const double* xyz);
+/* Cutting::computeFaceCentroids (Cutting.cpp:253-322; kernel ComputePerTetCentroids): every face flag 1, point = centroid */
+int fb_cut_face_centroids(fb_cut_t h);
+/* Cutting::computeFaceIntersections (Cutting.cpp:169-251; kernel ComputePerTetFaceIntersections): flag = the scalpel edge
+ * s0-s1 (3 doubles each) crosses the face, point = the crossing (w = 1), the centroid otherwise; *n_hits = number of
+ * flagged faces (what the reference's sum scan returns).  n_hits may be NULL. */
+int fb_cut_face_intersections(fb_cut_t h, const double* s0, const double* s1, int* n_hits);
+/* Cutting::computeEdgeIntersections (Cutting.cpp:442-497; kernel ComputePerTetEdgeIntersections): quad12 = the swept quad
+ * q0..q3; an edge is tested against triangle (q0, q3, q1), then (q0, q2, q3).  Points of missed edges are (0, 0, 0, 1)
+ * (the reference leaves them unwritten). */
+int fb_cut_edge_intersections(fb_cut_t h, const double* quad12, int* n_hits);
+/* flags (4 or 6 per tet) and points (x, y, z, w per face / edge) of the last pass; either pointer may be NULL */
+int fb_cut_read(fb_cut_t h, int what, unsigned int* flags, float* points_xyzw);
+/* the flagged faces / edges of the last pass in ascending id order (the compaction the reference's scan prepares):
+ * ids and points (4 floats) of at most `capacity` hits, *n_out = number of hits.  ids / points may be NULL to query. */
+int fb_cut_read_hits(fb_cut_t h, int what, int capacity, unsigned int* ids, float* points_xyzw, int* n_out);
+/* kernel ComputeSegmentTriIntersections (Cutting.cl:321-341; Cutting::computeFaceSegmentIntersectionTest): loose
+ * triangles (3 x float4 each) against the segment s0-s1 (3 floats each); out = crossing or (-1, -1, -1, 1) */
+int fb_cut_segment_triangles(int device, int n_tris, const float* tri_xyzw, const float* s0, const float* s1, float* points_xyzw);
+/* average device milliseconds of one face pass (a = s0, b = s1) or one edge pass (a = quad12, b ignored) */
+int fb_cut_time(fb_cut_t h, int what, const double* a, const double* b, int reps, double* ms_per_pass);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "fembrain/Deformable.h"
+#include "fembrain/Cutting.h"
 #include "fembrain/GPUPoly.h"
 
 static unsigned g_calls = 0;
@@ -111,5 +112,25 @@ int main() {
   PS::FEM::Deformable ball((int)nv, xv.data(), (int)nt, ev.data(), low);
   ball.timestep();
   std::printf("BALL_FIXED=%zu\nBALL_ITERS=%d\n", low.size(), ball.integrator()->GetLastIterations());
+  // the cutting tool on the ball's current (deformed) mesh: a vertical needle through it, then a blade swept along x
+  PS::FEM::Cutting cut(&ball);
+  float known[4];
+  cut.computeFaceSegmentIntersectionTest(known);
+  std::printf("CUT_KNOWN=%g,%g,%g,%g\n", known[0], known[1], known[2], known[3]);
+  const int nface = cut.computeFaceIntersections(PS::FEM::vec3d(0.013, -2.0, 0.021), PS::FEM::vec3d(0.013, 2.0, 0.021));
+  std::vector<PS::FEM::U32> ids, flags;
+  std::vector<float> pts, all;
+  cut.readHits(FB_CUT_FACES, ids, pts);
+  cut.readFacePoints(flags, all);
+  std::printf("CUT_FACES=%d\nCUT_FACE_IDS=%zu\nCUT_FACE_FLAGS=%zu\n", nface, ids.size(), flags.size());
+  cut.performCut(PS::FEM::vec3d(-0.2, 0.05, -1.0), PS::FEM::vec3d(-0.2, 0.05, 1.0));
+  cut.performCut(PS::FEM::vec3d(-0.1, 0.05, -1.0), PS::FEM::vec3d(-0.1, 0.05, 1.0));
+  const bool before = cut.isSweptQuadValid();
+  cut.performCut(PS::FEM::vec3d(0.1, 0.05, -1.0), PS::FEM::vec3d(0.1, 0.05, 1.0));
+  std::printf("CUT_QUAD=%d%d\nCUT_EDGES=%u\nCUT_QUAD_X=%g\n", before ? 1 : 0, cut.isSweptQuadValid() ? 1 : 0, cut.countEdgePoints(), cut.sweptQuad()[2].x);
+  {
+    std::vector<double> cur = ball.currentPositions();
+    std::printf("CUT_NODES=%u\nCUT_CELLS=%u\nCUT_POS0=%.17g\n", ball.countNodes(), ball.countCells(), cur[1]);
+  }
   return 0;
 }

@@ -290,3 +290,19 @@ def test_plan_is_independent_of_the_builder_threads(monkeypatch):
         assert got[0][0] == got[1][0]
         for k in names:
             assert np.array_equal(got[0][1][k], got[1][1][k]), k
+
+
+def test_cut_create_validates_before_touching_a_device():
+    """fb_cut_create checks the tet indices (the reference's createMemBuffers does not) -- host logic, no GPU needed"""
+    import ctypes as C
+    from fembrain_amd import lib as fl
+    L = fl.lib()
+    v = np.zeros((4, 3))
+    h = C.c_void_p()
+    bad = np.array([[0, 1, 2, 4]], np.uint32)
+    assert L.fb_cut_create(C.byref(h), 0, 4, fl.dptr(v), 1, fl.uptr(bad)) == fl.FB_EINVAL
+    assert b"references vertex 4" in L.fb_last_error()
+    assert L.fb_cut_create(C.byref(h), 0, 0, fl.dptr(v), 1, fl.uptr(bad)) == fl.FB_EINVAL
+    assert L.fb_cut_create(None, 0, 4, fl.dptr(v), 1, fl.uptr(bad)) == fl.FB_EINVAL
+    assert L.fb_cut_face_centroids(None) == fl.FB_EINVAL
+    assert L.fb_cut_read(None, 0, None, None) == fl.FB_EINVAL
