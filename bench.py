@@ -213,24 +213,48 @@ def main():
     # Sharded runs: the exchange modes give bitwise identical iterates, so the fastest one ON THIS MACHINE is picked by
     # timing one step in each (max over ranks); untimed, before the warmup.
     xch_trials = {}
+    xch_note = None
+
+    def all_ok(ok):
+        """did the step succeed on EVERY rank?  (a peer-to-peer wait that times out returns FB_ECOMM after its bounded wait)"""
+        tt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cpu" if local_comm else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        return bool(tt.item() > 0.5)
+
+    def guarded_step():
+        try:
+            one_step()
+            return all_ok(True), None
+        except fl.FbError as e:
+            all_ok(False)
+            return False, str(e)
+
     if dist_mode and g.transport() >= fl.FB_XCH_P2P and os.environ.get("FEMBRAIN_XCH_MODE") is None:
         names = {fl.FB_XCH_COLLECTIVE: "collective", fl.FB_XCH_P2P: "p2p", fl.FB_XCH_P2P_SUMS: "p2p_sums", fl.FB_XCH_P2P_FUSED: "p2p_fused"}
-        one_step()
         modes = (fl.FB_XCH_P2P, fl.FB_XCH_P2P_SUMS, fl.FB_XCH_P2P_FUSED)
         if not local_comm and os.environ.get("FEMBRAIN_BENCH_TRY_RCCL") == "1":
             modes = (fl.FB_XCH_COLLECTIVE,) + modes   # the collective library, for the record (opt-in: RCCL with N > 1 could not
             #                                           be rehearsed on the one-GPU development box)
-        for mode in modes:
+        ok, why = guarded_step()
+        for mode in modes if ok else ():
             g.set_exchange_mode(mode)
             barrier()
             ts = time.perf_counter()
-            one_step()
+            ok, why = guarded_step()
+            if not ok:
+                break
             barrier()
             tt = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cpu" if local_comm else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             xch_trials[names[mode]] = float(tt.item()) * 1e3
-        best = min(xch_trials, key=xch_trials.get)
-        g.set_exchange_mode({v: k for k, v in names.items()}[best])
+        if ok:
+            best = min(xch_trials, key=xch_trials.get)
+            g.set_exchange_mode({v: k for k, v in names.items()}[best])
+        else:
+            # a peer-to-peer form failed on some rank (its inbox is poisoned from then on): the collective library carries
+            # the rest of the run, on every rank alike, and the line says so
+            xch_note = "peer-to-peer exchange failed in the trial step (%s); fell back to the collective library" % (why or "on another rank")
+            g.set_exchange_mode(fl.FB_XCH_COLLECTIVE)
         g.reset_to_rest()   # the timed steps start from the same state as the one-GPU run's
     for _ in range(args.warmup):
         one_step()
@@ -279,7 +303,7 @@ def main():
                                     "peer-to-peer inboxes over xGMI (HIP IPC), one kernel per exchange",
                                     "peer-to-peer inboxes, sums inside the PCG kernels",
                                     "peer-to-peer inboxes, sums and halo values inside the PCG kernels"][g.transport()],
-                       "exchange_trials_ms_per_step": xch_trials,
+                       "exchange_trials_ms_per_step": xch_trials, "exchange_note": xch_note,
                        "cg_eps": 1e-6, "cg_max_iter": 10000},
             "cg_iterations_per_step": float(np.mean(iters)), "assembly_ms_per_step": asm_s / args.steps * 1e3,
             "solve_ms_per_step": solve_s / args.steps * 1e3, "us_per_cg_iteration": solve_s / max(sum(iters), 1) * 1e6,
@@ -319,8 +343,8 @@ def main():
                 planes = [n8 * r // world for r in range(world + 1)]
                 shard8 = (world, rank, np.array([p * n8 * n8 for p in planes], dtype=np.int32), comm)
             g8 = FemIntegrator(v8, t8, fixed8, matrix_precision=prec, device=device, shard=shard8)
-            if dist_mode and mode_used != g8.transport() and mode_used >= fl.FB_XCH_P2P and g8.transport() >= fl.FB_XCH_P2P:
-                g8.set_exchange_mode(mode_used)
+            if dist_mode and mode_used != g8.transport() and g8.transport() >= fl.FB_XCH_P2P:
+                g8.set_exchange_mode(mode_used)   # the form picked (or fallen back to) above
 
             def step8():
                 g8.rebuild_elements()
