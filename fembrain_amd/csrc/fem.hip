@@ -48,6 +48,7 @@ struct fb_fem_s {
   // device, would otherwise bound the iteration time
   int split = 0;       // wavefronts per slice of the SpMV on small / mid-size meshes (k_spmv_split): 0 (row kernel), 2 or 4
   int sgrid = 8;       // blocks (= partial sums) of the SpMV launches; equals grid unless split
+  bool spmv_nt = false;  // stream the matrix values non-temporally (systems larger than the Infinity Cache, see k_spmv)
   int vgrid = 8;       // blocks of the merged vector pass: one 16-byte pair per thread
   hipGraphExec_t batch_graph = nullptr;
   const double* graph_rhs = nullptr;
@@ -109,6 +110,12 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
     else if (8 * ceil_div(chunk, 2) <= kMaxPartials) h->split = 2;
   }
   h->sgrid = h->split == 4 ? 8 * chunk : (h->split == 2 ? 8 * ceil_div(chunk, 2) : h->grid);
+  {
+    // bytes one PCG iteration moves: matrix values + indices + the 12 vector streams of the two kernels
+    const double iter_bytes = (double)P.n_slots * 64 * (9.0 * mt_size(h) + 4.0) + 12.0 * 24.0 * P.n_local;
+    const char* e = getenv("FEMBRAIN_SPMV_NT");
+    h->spmv_nt = e ? atoi(e) != 0 : iter_bytes > 384.0 * 1024 * 1024;  // measured: -2 % at 341 MB, +11 % at 469 MB, +15 % at 1.1 GB
+  }
   // small meshes: one 16-byte pair per thread in the merged vector pass (8.9 vs 9.3 us per iteration at 105k tets; on the 1M-tet
   // mesh the extra blocks cost more in the partial-sum prologue than they save: 29.9 vs 29.1)
   h->vgrid = h->split == 4 ? 8 * std::max(1, ceil_div(chunk * 96, kBlock)) : h->grid;
@@ -211,8 +218,12 @@ int launch_spmv(fb_fem_s* h, const double* x, double* y, const double* b, double
     FB_HIP(hipGetLastError());
     return FB_OK;
   }
-  hipLaunchKernelGGL((k_spmv<MT, MODE>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y, b,
-                     h->invdiag.p, partial, h->st.p, parity, P2PArgs());
+  if (h->spmv_nt)
+    hipLaunchKernelGGL((k_spmv<MT, MODE, 0, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
+                       b, h->invdiag.p, partial, h->st.p, parity, P2PArgs());
+  else
+    hipLaunchKernelGGL((k_spmv<MT, MODE>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y, b,
+                       h->invdiag.p, partial, h->st.p, parity, P2PArgs());
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -221,8 +232,12 @@ int launch_spmv(fb_fem_s* h, const double* x, double* y, const double* b, double
 // XCH = 2 also gathers the halo columns from the inbox (sent by the neighbours' previous vector pass)
 template <typename MT, int XCH>
 int launch_spmv_xch(fb_fem_s* h, const double* x, double* y, const double* b, double* partial, int parity, const P2PArgs& pa) {
-  hipLaunchKernelGGL((k_spmv<MT, 3, XCH>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y, b,
-                     h->invdiag.p, partial, h->st.p, parity, pa);
+  if (h->spmv_nt)
+    hipLaunchKernelGGL((k_spmv<MT, 3, XCH, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
+                       b, h->invdiag.p, partial, h->st.p, parity, pa);
+  else
+    hipLaunchKernelGGL((k_spmv<MT, 3, XCH>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y, b,
+                       h->invdiag.p, partial, h->st.p, parity, pa);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }

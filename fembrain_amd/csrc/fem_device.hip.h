@@ -351,7 +351,12 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
 // flag; every block then waits for the neighbours' chunks and gathers halo columns straight from the own inbox.  No launch of
 // its own, no grid-wide ticket (same-address atomics cost ~12 ns each here) and no per-block fence (an agent-scope
 // release writes back the whole per-XCD L2): x was completed by the previous kernel.
-template <typename MT, int MODE, int XCH = 0>
+// NT: the value stream is loaded non-temporally.  On a system whose per-iteration working set (matrix + vector passes)
+// exceeds the 256 MiB Infinity Cache the values can never be re-used from it, and loading them without allocating keeps
+// the vectors resident instead: 168 vs 206 us at 8M tets (5.9 vs 4.8 TB/s).  On a system that fits (1M tets, 160 MB)
+// the same hint evicts the matrix from the cache it would be served from: 24.7 vs 20.8 us -- so the host picks by size
+// (crossover measured between 341 MB and 469 MB per iteration; FEMBRAIN_SPMV_NT=0/1 overrides).
+template <typename MT, int MODE, int XCH = 0, bool NT = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo, const double* __restrict__ x,
                                                  double* __restrict__ y, const double* __restrict__ bvec,
                                                  const double* __restrict__ invdiag, double* __restrict__ partial,
@@ -382,9 +387,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
       const double* xp = ((XCH == 2 && col >= sv.n_owned) ? halo_in : x) + 3 * (size_t)col;
       const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
       const MT* vk = v + (size_t)k * 9 * 64;
-      y0 += (double)vk[0 * 64] * x0 + (double)vk[1 * 64] * x1 + (double)vk[2 * 64] * x2;
-      y1 += (double)vk[3 * 64] * x0 + (double)vk[4 * 64] * x1 + (double)vk[5 * 64] * x2;
-      y2 += (double)vk[6 * 64] * x0 + (double)vk[7 * 64] * x1 + (double)vk[8 * 64] * x2;
+      auto lv = [&](int j) { return NT ? __builtin_nontemporal_load(vk + j * 64) : vk[j * 64]; };
+      y0 += (double)lv(0) * x0 + (double)lv(1) * x1 + (double)lv(2) * x2;
+      y1 += (double)lv(3) * x0 + (double)lv(4) * x1 + (double)lv(5) * x2;
+      y2 += (double)lv(6) * x0 + (double)lv(7) * x1 + (double)lv(8) * x2;
     }
     if (row < sv.n_owned) {
       const size_t d = 3 * (size_t)row;

@@ -596,3 +596,21 @@ def test_internal_force_scaling_factor(gpu):
     assert np.abs(g.get_q_state()[0] - soft.get_q_state()[0]).max() <= 1e-9 * np.abs(soft.get_q_state()[0]).max()
     with pytest.raises(fl.FbError):
         g.set_internal_force_scaling_factor(0.0)
+
+
+def test_nontemporal_value_stream_gives_identical_iterates(gpu, monkeypatch):
+    """k_spmv<.., NT> (picked by size for systems beyond the Infinity Cache; forced here through FEMBRAIN_SPMV_NT) only
+    changes the cache policy of the matrix loads: states after 2 steps are bitwise those of the default kernel."""
+    v, t, fixed = _cube(12)
+    out = []
+    for nt in ("0", "1"):
+        monkeypatch.setenv("FEMBRAIN_SPMV_NT", nt)
+        g = FemIntegrator(v, t, fixed, spmv_kernel=fl.FB_SPMV_ROWS)
+        its = []
+        for _ in range(2):
+            g.set_uniform_force(1, -10000.0)
+            its.append(g.do_timestep())
+        q, qv, _ = g.get_q_state()
+        out.append((its, q, qv))
+        g.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
