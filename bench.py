@@ -256,6 +256,50 @@ def main():
             xch_note = "peer-to-peer exchange failed in the trial step (%s); fell back to the collective library" % (why or "on another rank")
             g.set_exchange_mode(fl.FB_XCH_COLLECTIVE)
         g.reset_to_rest()   # the timed steps start from the same state as the one-GPU run's
+    # Sharded runs check themselves before anything is timed: the first step from rest, gathered over the ranks, against
+    # the same step of an UNSHARDED handle on rank 0's GPU (iteration count within max(3, 2 %), displacements within 2e-4
+    # of max|q| -- the tolerance of the parity tests for two solves that both stop at a 1e-6 residual).  If a peer-to-peer
+    # form fails the check, the collective library takes over and is checked the same way.
+    sharded_check = None
+    if dist_mode and os.environ.get("FEMBRAIN_BENCH_NO_CHECK") != "1":
+        ref = None
+        if rank == 0:
+            g1 = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device)
+            g1.rebuild_elements()
+            g1.set_uniform_force(1, -10000.0)
+            it_ref = g1.do_timestep()
+            ref = (it_ref, g1.get_q_state()[0])
+            g1.close()
+
+        def check_once():
+            g.reset_to_rest()
+            ok, why = guarded_step()
+            its = g.last.cg_iterations if ok else -1
+            q = g.get_q_state()[0] if ok else np.zeros(g.r)
+            tq = torch.from_numpy(q.copy())
+            if not local_comm:
+                tq = tq.cuda()
+            dist.all_reduce(tq, op=dist.ReduceOp.SUM)   # every rank fills its owned range only
+            res = {"ok": False, "error": why} if not ok else None
+            good = torch.zeros(1, dtype=torch.float64, device=tq.device)
+            if rank == 0 and ok:
+                qa = tq.cpu().numpy()
+                diff = float(np.abs(qa - ref[1]).max() / np.abs(ref[1]).max())
+                res = {"iterations_sharded": int(its), "iterations_one_gpu": int(ref[0]), "max_rel_diff_q": diff,
+                       "ok": bool(abs(its - ref[0]) <= max(3, 0.02 * ref[0]) and diff <= 2e-4)}
+                good[0] = 1.0 if res["ok"] else 0.0
+            dist.broadcast(good, src=0)
+            return bool(good.item() > 0.5), res
+
+        passed, sharded_check = check_once()
+        if not passed and g.transport() >= fl.FB_XCH_P2P:
+            first = sharded_check
+            xch_note = ((xch_note + "; ") if xch_note else "") + "the peer-to-peer exchange failed the self-check, the collective library took over"
+            g.set_exchange_mode(fl.FB_XCH_COLLECTIVE)
+            passed, sharded_check = check_once()
+            if rank == 0 and sharded_check is not None:
+                sharded_check["peer_to_peer_attempt"] = first
+        g.reset_to_rest()
     for _ in range(args.warmup):
         one_step()
     barrier()
@@ -303,7 +347,7 @@ def main():
                                     "peer-to-peer inboxes over xGMI (HIP IPC), one kernel per exchange",
                                     "peer-to-peer inboxes, sums inside the PCG kernels",
                                     "peer-to-peer inboxes, sums and halo values inside the PCG kernels"][g.transport()],
-                       "exchange_trials_ms_per_step": xch_trials, "exchange_note": xch_note,
+                       "exchange_trials_ms_per_step": xch_trials, "exchange_note": xch_note, "sharded_self_check": sharded_check,
                        "cg_eps": 1e-6, "cg_max_iter": 10000},
             "cg_iterations_per_step": float(np.mean(iters)), "assembly_ms_per_step": asm_s / args.steps * 1e3,
             "solve_ms_per_step": solve_s / args.steps * 1e3, "us_per_cg_iteration": solve_s / max(sum(iters), 1) * 1e6,
