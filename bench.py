@@ -130,6 +130,31 @@ def field_bench(device, cpu=True):
     return out
 
 
+def field_bench_sharded(device, rank, world, allreduce):
+    """The same 256^3 grid dealt to the ranks as z-slabs: every rank sweeps, classifies and tetrahedralizes its
+    slab (one plane below, two above what it owns); the pieces are the single-GPU mesh bit for bit
+    (tests/test_poly_gpu.py).  Rate = grid points / slowest rank's pipeline time; the only exchange is the all-gather of
+    one vertex count.  allreduce(value, op) -> reduced float over the ranks."""
+    from fembrain_amd.poly import GpuPoly, slab_plan, sphere_blob
+    blob = sphere_blob()
+    lower, cell, dims = (-0.5, -0.5, -0.5), 1.0 / 254.0, (256, 256, 256)
+    p0, p1, z_first, z_count, own_planes, own_layers = slab_plan(dims[2], world, rank)
+    p = GpuPoly(blob, device=device)
+    p.sweep_slab(lower, cell, dims, z_first, z_count)
+    p.classify()
+    p.tetrahedralize()
+    nv, nt = p.slab_counts(p0, own_planes, own_layers)
+    sweep_s, pipe_s = p.time_pipeline(10)
+    p.close()
+    pipe = allreduce(pipe_s, "max")
+    sweep = allreduce(sweep_s, "max")
+    tets = int(round(allreduce(float(nt), "sum")))
+    npts = dims[0] * dims[1] * dims[2]
+    return {"field_mvoxels_per_s": npts / pipe / 1e6, "field_sweep_mvoxels_per_s": npts / sweep / 1e6, "field_grid": list(dims),
+            "field_pipeline_us": pipe * 1e6, "field_tets": tets, "field_tets_expected": 39345600, "field_scaling": "strong",
+            "field_partition": "z-slabs x%d, %d planes swept per rank for %d owned" % (world, z_count, own_planes)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -363,6 +388,17 @@ def main():
                          "frac": spmv_bytes / spmv_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": spmv_bytes, "us_per_launch": spmv_s * 1e6},
         }
+    if dist_mode and world > 1 and not args.no_field:
+        def allreduce(x, op):
+            tt = torch.tensor([x], dtype=torch.float64, device="cpu" if local_comm else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+            return float(tt.item())
+        try:
+            fs = field_bench_sharded(device, rank, world, allreduce)
+        except Exception as e:  # the headline line must survive
+            fs = {"field_error": repr(e)}
+        if out is not None:
+            out.update(fs)
     if world == 1 and not args.no_field:
         extra = field_bench(device, cpu=not args.no_cpu_baseline)
         if out is not None:

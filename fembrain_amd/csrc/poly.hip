@@ -60,6 +60,7 @@ struct Grid {
   int g[3];  // points per axis
   int c[3];  // cells per axis
   long long n_points, n_cells;
+  int z0;    // slab of a larger grid: global index of this grid's first point plane (positions are lo + cellsize * global index)
 };
 
 __device__ __forceinline__ float wyvill(float dd) {
@@ -301,12 +302,12 @@ __global__ __launch_bounds__(kPB) void k_sweep(Grid G, const Instr* __restrict__
       const unsigned int y0 = same_plane ? ay : 0u, y1 = same_plane ? by : (unsigned int)G.g[1] - 1u;
       sb.lo[0] = G.lo[0] + G.cellsize * (float)x0; sb.hi[0] = G.lo[0] + G.cellsize * (float)x1;
       sb.lo[1] = G.lo[1] + G.cellsize * (float)y0; sb.hi[1] = G.lo[1] + G.cellsize * (float)y1;
-      sb.lo[2] = G.lo[2] + G.cellsize * (float)az; sb.hi[2] = G.lo[2] + G.cellsize * (float)bz;
+      sb.lo[2] = G.lo[2] + G.cellsize * (float)(az + (unsigned int)G.z0); sb.hi[2] = G.lo[2] + G.cellsize * (float)(bz + (unsigned int)G.z0);
     }
     if (gid < G.n_points) {
       const float x = G.lo[0] + G.cellsize * (float)ix;
       const float y = G.lo[1] + G.cellsize * (float)iy;
-      const float z = G.lo[2] + G.cellsize * (float)iz;
+      const float z = G.lo[2] + G.cellsize * (float)(iz + (unsigned int)G.z0);
       const float f = eval_field_t<CULL>(prog, n_instr, n_prims, prims, mtx, x, y, z, stack + threadIdx.x, sb);
       if (grid) { const v4f o = {x, y, z, f}; __builtin_nontemporal_store(o, (v4f*)&grid[gid]); }  // streamed once: 49 vs 56 us
       in = f >= kIso;  // inside test of Polygonizer.cl:1367,1599 and Polygonizer.cpp:1052
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(kPB) void k_tet_vertices(Grid G, const unsigned lon
       float* o = &stage[wv][3 * __popcll(mask & ((1ULL << lane) - 1ULL))];
       o[0] = G.lo[0] + G.cellsize * (float)ix;
       o[1] = G.lo[1] + G.cellsize * (float)iy;
-      o[2] = G.lo[2] + G.cellsize * (float)iz;
+      o[2] = G.lo[2] + G.cellsize * (float)(iz + (unsigned int)G.z0);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1015,6 +1016,7 @@ struct fb_poly_s {
   DevBuf<float> d_prims, d_mtx, d_pbox;
   std::vector<float> pbox;  // support box of every primitive (support_boxes)
   Grid G;
+  int gz_total = 0;  // point planes of the whole grid this one is a slab of (= G.g[2] for a grid of its own)
   bool have_grid = false, classified = false, tetra = false, materialized = false;
   DevBuf<float4> grid;
   DevBuf<unsigned long long> inside, cinc, vinc, lastx, lasty, lastz, valid, crossx, crossy, crossz;
@@ -1323,10 +1325,12 @@ int do_sweep(fb_poly_s* h, bool store_grid) {
   return FB_OK;
 }
 
-int set_grid(fb_poly_s* h, const float lo[3], float cellsize, const int dims[3]) {
+int set_grid(fb_poly_s* h, const float lo[3], float cellsize, const int dims[3], int z0 = 0, int gz_total = 0) {
   if (!(cellsize > 0)) return fail(FB_EINVAL, "cellsize must be positive");
   Grid G;
   G.cellsize = cellsize;
+  G.z0 = z0;
+  h->gz_total = gz_total > 0 ? gz_total : dims[2];
   G.n_points = 1; G.n_cells = 1;
   for (int a = 0; a < 3; a++) {
     if (dims[a] < 2) return fail(FB_EINVAL, "grid needs at least 2 points per axis");
@@ -1541,6 +1545,87 @@ int fb_poly_sweep_grid(fb_poly_t h, const float lower[3], float cellsize, const 
   FB_TRY(do_sweep(h, true));
   FB_HIP(hipStreamSynchronize(h->stream));
   h->have_grid = true;
+  return FB_OK;
+}
+
+int fb_poly_sweep_slab(fb_poly_t h, const float lower[3], float cellsize, const int dims[3], int z_first, int z_count) {
+  CHECK_POLY(h);
+  if (!lower || !dims) return fail(FB_EINVAL, "null grid description");
+  if (z_first < 0 || z_count < 2 || z_first + z_count > dims[2]) return fail(FB_EINVAL, "slab planes [%d, %d) do not fit a grid of %d planes", z_first, z_first + z_count, dims[2]);
+  const int sub[3] = {dims[0], dims[1], z_count};
+  FB_TRY(set_grid(h, lower, cellsize, sub, z_first, dims[2]));
+  FB_TRY(do_sweep(h, true));
+  FB_HIP(hipStreamSynchronize(h->stream));
+  h->have_grid = true;
+  return FB_OK;
+}
+
+namespace {
+// number of set bits of a scanned mask below bit `bit` (base[w] = set bits before word w)
+int count_before(fb_poly_s* h, const DevBuf<unsigned long long>& mask, const DevBuf<unsigned int>& base, long long bit, unsigned int total, unsigned int* out) {
+  if (bit >= h->G.n_points) { *out = total; return FB_OK; }
+  unsigned long long w = 0;
+  unsigned int b = 0;
+  FB_TRY(mask.download(&w, 1, h->stream, (size_t)(bit >> 6)));
+  FB_TRY(base.download(&b, 1, h->stream, (size_t)(bit >> 6)));
+  *out = b + (unsigned int)__builtin_popcountll(w & ((1ULL << (bit & 63)) - 1ULL));
+  return FB_OK;
+}
+
+struct SlabRange { unsigned int v0, v1, c0, c1; };  // owned vertices [v0, v1) and included cells [c0, c1) in the slab's own numbering
+
+int slab_range(fb_poly_s* h, int own_first_plane, int own_planes, int own_layers, SlabRange* r) {
+  if (!h->tetra) return fail(FB_EINVAL, "tetrahedralize first");
+  const Grid& G = h->G;
+  const int p0 = own_first_plane - G.z0, p1 = p0 + own_planes, l1 = p0 + own_layers;
+  if (own_planes < 0 || own_layers < 0 || p0 < 0 || p1 > G.g[2] || l1 > G.c[2])
+    return fail(FB_EINVAL, "planes [%d, %d) / layers [%d, %d) are not inside the slab [%d, %d)", own_first_plane, own_first_plane + own_planes,
+                own_first_plane, own_first_plane + own_layers, G.z0, G.z0 + G.g[2]);
+  // the vertex marks of a plane are complete only if both cell layers next to it were classified here (or do not exist)
+  if (p0 == 0 && G.z0 > 0 && own_planes > 0) return fail(FB_EINVAL, "the slab must start one plane below the first owned plane %d", own_first_plane);
+  if (own_layers > 0 && l1 + 1 > G.c[2] && G.z0 + G.g[2] < h->gz_total)
+    return fail(FB_EINVAL, "the slab must reach two planes above the last owned cell layer %d", own_first_plane + own_layers - 1);
+  const long long gxy = (long long)G.g[0] * G.g[1];
+  const unsigned int nv = (unsigned int)h->counts.n_tet_vertices, nc = (unsigned int)(h->counts.n_tets / 6);
+  FB_TRY(count_before(h, h->vinc, h->vbase, p0 * gxy, nv, &r->v0));
+  FB_TRY(count_before(h, h->vinc, h->vbase, p1 * gxy, nv, &r->v1));
+  FB_TRY(count_before(h, h->cinc, h->cbase, p0 * gxy, nc, &r->c0));
+  FB_TRY(count_before(h, h->cinc, h->cbase, l1 * gxy, nc, &r->c1));
+  return FB_OK;
+}
+
+__global__ __launch_bounds__(kPB) void k_renumber_tets(long long n, const uint4* __restrict__ in, unsigned int delta, uint4* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (i >= n) return;
+  uint4 t = in[i];
+  t.x += delta; t.y += delta; t.z += delta; t.w += delta;
+  out[i] = t;
+}
+}  // namespace
+
+int fb_poly_slab_counts(fb_poly_t h, int own_first_plane, int own_planes, int own_layers, int* n_vertices, int* n_tets) {
+  CHECK_POLY(h);
+  SlabRange r;
+  FB_TRY(slab_range(h, own_first_plane, own_planes, own_layers, &r));
+  if (n_vertices) *n_vertices = (int)(r.v1 - r.v0);
+  if (n_tets) *n_tets = (int)(6 * (r.c1 - r.c0));
+  return FB_OK;
+}
+
+int fb_poly_read_tetmesh_slab(fb_poly_t h, int own_first_plane, int own_planes, int own_layers, unsigned int vertex_base, float* xyz, unsigned int* tets) {
+  CHECK_POLY(h);
+  SlabRange r;
+  FB_TRY(slab_range(h, own_first_plane, own_planes, own_layers, &r));
+  if (xyz && r.v1 > r.v0) FB_TRY(h->tv.download(xyz, 3 * (size_t)(r.v1 - r.v0), h->stream, 3 * (size_t)r.v0));
+  const long long nt = 6LL * (r.c1 - r.c0);
+  if (tets && nt > 0) {
+    DevBuf<uint4> out;
+    FB_TRY(out.alloc((size_t)nt));
+    // a vertex's number in the whole grid = its number here - (vertices of the planes below the owned ones) + vertex_base
+    hipLaunchKernelGGL(k_renumber_tets, dim3((unsigned)((nt + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, nt, h->tt.p + 6 * (size_t)r.c0, vertex_base - r.v0, out.p);
+    FB_HIP(hipGetLastError());
+    FB_TRY(out.download((uint4*)tets, (size_t)nt, h->stream));
+  }
   return FB_OK;
 }
 

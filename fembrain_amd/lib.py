@@ -144,6 +144,9 @@ def lib():
         "fb_poly_read_surface_binding": (C.c_int, [vp, _up, _fp]),
         "fb_poly_compile_info": (C.c_int, [C.c_int, _fp, C.c_int, _fp, _ip, _ip]),
         "fb_poly_apply_displacements": (C.c_int, [vp, C.c_int, C.c_int, _dp, _fp]),
+        "fb_poly_sweep_slab": (C.c_int, [vp, _fp, C.c_float, _ip, C.c_int, C.c_int]),
+        "fb_poly_slab_counts": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, _ip, _ip]),
+        "fb_poly_read_tetmesh_slab": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_uint, _fp, _up]),
         "fb_cut_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _dp, C.c_int, _up]),
         "fb_cut_destroy": (None, [vp]),
         "fb_cut_set_vertices": (C.c_int, [vp, C.c_int, _dp]),

@@ -71,6 +71,36 @@ class GpuPoly:
         self.dims = tuple(int(x) for x in dm)
         return self.dims
 
+    # ---- multi-GPU field path: one z-slab of a larger grid (fembrain_hip.h, "z-slabs of one grid") ----
+    def sweep_slab(self, lower, cellsize, dims, z_first, z_count):
+        lo = np.asarray(lower, dtype=np.float32)
+        dm = np.asarray(dims, dtype=np.int32)
+        _l.check(self._L.fb_poly_sweep_slab(self.h, _l.fptr(lo), cellsize, _l.iptr(dm), z_first, z_count))
+        self.dims = (int(dm[0]), int(dm[1]), int(z_count))
+        return self.dims
+
+    def slab_counts(self, own_first_plane, own_planes, own_layers):
+        a, b = C.c_int(), C.c_int()
+        _l.check(self._L.fb_poly_slab_counts(self.h, own_first_plane, own_planes, own_layers, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def read_tetmesh_slab(self, own_first_plane, own_planes, own_layers, vertex_base):
+        nv, nt = self.slab_counts(own_first_plane, own_planes, own_layers)
+        xyz, tets = np.empty((nv, 3), np.float32), np.empty((nt, 4), np.uint32)
+        _l.check(self._L.fb_poly_read_tetmesh_slab(self.h, own_first_plane, own_planes, own_layers, vertex_base, _l.fptr(xyz), _l.uptr(tets)))
+        return xyz, tets
+
+    def run_tetrahedralizer_slab(self, lower, cellsize, dims, rank, world, allgather):
+        """This rank's consecutive piece (vertices, tets with whole-grid vertex numbers) of the tet mesh of the grid `dims`.
+        allgather(int) -> list of every rank's int (e.g. torch.distributed.all_gather_object)."""
+        p0, p1, z_first, z_count, own_planes, own_layers = slab_plan(int(dims[2]), world, rank)
+        self.sweep_slab(lower, cellsize, dims, z_first, z_count)
+        self.classify()
+        self.tetrahedralize()
+        nv, _ = self.slab_counts(p0, own_planes, own_layers)
+        base = sum(allgather(nv)[:rank])
+        return self.read_tetmesh_slab(p0, own_planes, own_layers, base)
+
     # GPUPoly::readBackVoxelGridSamples
     def read_grid(self):
         n = self.dims[0] * self.dims[1] * self.dims[2]
@@ -177,6 +207,17 @@ class GpuPoly:
         a, b = C.c_double(0), C.c_double(0)
         _l.check(self._L.fb_poly_time_pipeline(self.h, reps, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+
+def slab_plan(planes, world, rank):
+    """z-slab of rank `rank`: owned point planes [p0, p1), the slab to sweep [z_first, z_first + z_count) (one plane below,
+    two above, clipped to the grid), and how many planes / cell layers the rank owns."""
+    if world < 1 or not 0 <= rank < world or planes < 2 * world:
+        raise ValueError("cannot deal %d planes to %d ranks" % (planes, world))
+    p0, p1 = planes * rank // world, planes * (rank + 1) // world
+    z_first, z_last = max(p0 - 1, 0), min(p1 + 1, planes - 1)
+    own_layers = min(p1, planes - 1) - p0
+    return p0, p1, z_first, z_last - z_first + 1, p1 - p0, own_layers
 
 
 def write_veg(path, xyz, tets, rho=1000.0, E=1e7, nu=0.45):

@@ -101,6 +101,27 @@ class GPUPoly {
     vertices.resize(3 * (size_t)ctVertices); elements.resize(4 * (size_t)ctTets);
     return fb_poly_read_tetmesh(h_, vertices.data(), elements.data()) == FB_OK;
   }
+  // Multi-GPU field path (one GPUPoly per rank; fembrain_hip.h "z-slabs of one grid"): this rank's z-slab of the grid
+  // `dims` through the tetrahedralizer.  allGatherVertexCounts(mine) must return the owned-vertex counts of ALL ranks in
+  // rank order (one all-gather of an int: RCCL, MPI, ...).  The pieces of all ranks in rank order are the one-GPU mesh.
+  template <typename AllGather>
+  bool runTetrahedralizerSlab(const float lower[3], const int dims[3], int rank, int world, AllGather allGatherVertexCounts, U32& ctVertices,
+                              std::vector<float>& vertices, U32& ctTets, std::vector<U32>& elements) {
+    if (world < 1 || rank < 0 || rank >= world || dims[2] < 2 * world) return false;
+    const int planes = dims[2], p0 = (int)((long long)planes * rank / world), p1 = (int)((long long)planes * (rank + 1) / world);
+    const int zFirst = p0 > 0 ? p0 - 1 : 0, zLast = p1 + 1 < planes - 1 ? p1 + 1 : planes - 1;
+    const int ownPlanes = p1 - p0, ownLayers = (p1 < planes - 1 ? p1 : planes - 1) - p0;
+    if (fb_poly_sweep_slab(h_, lower, m_cellsize, dims, zFirst, zLast - zFirst + 1) != FB_OK) return false;
+    if (fb_poly_classify(h_, &m_counts) != FB_OK || fb_poly_tetrahedralize(h_, &m_counts) != FB_OK) return false;
+    int nv = 0, nt = 0;
+    if (fb_poly_slab_counts(h_, p0, ownPlanes, ownLayers, &nv, &nt) != FB_OK) return false;
+    const std::vector<int> all = allGatherVertexCounts(nv);
+    unsigned int base = 0;
+    for (int r = 0; r < rank && r < (int)all.size(); r++) base += (unsigned int)all[r];
+    ctVertices = (U32)nv; ctTets = (U32)nt;
+    vertices.resize(3 * (size_t)nv); elements.resize(4 * (size_t)nt);
+    return fb_poly_read_tetmesh_slab(h_, p0, ownPlanes, ownLayers, base, vertices.data(), elements.data()) == FB_OK;
+  }
   // GPUPoly::readBackVoxelGridSamples (OclPolygonizer.cpp:916-940)
   bool readBackVoxelGridSamples(vec4u& dim, std::vector<float>& arrXYZF) const {
     dim.x = (U32)m_counts.grid[0]; dim.y = (U32)m_counts.grid[1]; dim.z = (U32)m_counts.grid[2]; dim.w = (U32)m_counts.n_points;

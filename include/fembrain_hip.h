@@ -295,6 +295,19 @@ int fb_poly_time_surface(fb_poly_t h, int reps, double* seconds);
 /* average device seconds of one sweep / one classify+tetrahedralize pipeline on the current grid */
 int fb_poly_time_pipeline(fb_poly_t h, int reps, double* sweep_seconds, double* pipeline_seconds);
 
+/* ---- multi-GPU field path: z-slabs of one grid ---------------------------------------------------------------------
+ * The grid's point planes are dealt to the ranks in contiguous runs.  A rank that owns planes [p0, p1) (and the cell layers
+ * [p0, min(p1, planes - 1))) sweeps the slab [max(p0 - 1, 0), min(p1 + 1, planes - 1)] -- one plane below and two above,
+ * so that the vertex marks of its own planes and of plane p1 are complete -- and runs fb_poly_classify and
+ * fb_poly_tetrahedralize on it unchanged.  Point positions are lower + cellsize * GLOBAL index, so field samples, marks
+ * and positions are bitwise those of the whole grid.  Vertices are numbered plane by plane: with vertex_base = the number
+ * of owned vertices of all lower ranks (one all-gather of fb_poly_slab_counts' first number), fb_poly_read_tetmesh_slab
+ * returns the rank's consecutive piece of the whole grid's tet mesh -- the pieces of all ranks concatenated ARE
+ * fb_poly_read_tetmesh of the single-GPU run, bit for bit. */
+int fb_poly_sweep_slab(fb_poly_t h, const float lower[3], float cellsize, const int dims[3], int z_first, int z_count);
+int fb_poly_slab_counts(fb_poly_t h, int own_first_plane, int own_planes, int own_layers, int* n_vertices, int* n_tets);
+int fb_poly_read_tetmesh_slab(fb_poly_t h, int own_first_plane, int own_planes, int own_layers, unsigned int vertex_base, float* xyz, unsigned int* tets);
+
 /* ---- cutting tool: scalpel / tet-mesh intersection tests --------------------------------------------------------------------
  * Replaces the device half of PS::FEM::Cutting (src/deformable/Cutting.cpp:87-497) and the four kernels of
  * data/opencl/Cutting.cl (:158-341).  Face f of tet t is face 4 t + f with corners faceMask[f] = {0,1,2} {1,2,3} {2,3,0}

@@ -112,6 +112,27 @@ int main() {
   PS::FEM::Deformable ball((int)nv, xv.data(), (int)nt, ev.data(), low);
   ball.timestep();
   std::printf("BALL_FIXED=%zu\nBALL_ITERS=%d\n", low.size(), ball.integrator()->GetLastIterations());
+  {  // the field path as two "ranks" run it (one after the other here): the pieces put together are the mesh above
+    const int dims[3] = {12, 12, 12};
+    std::vector<int> counts(2, 0);
+    size_t verts = 0, tets = 0;
+    bool same = true;
+    for (int pass = 0; pass < 2; pass++)      // pass 0 learns the counts an all-gather would deliver
+      for (int r = 0; r < 2; r++) {
+        PS::SKETCH::GPUPoly part(blob);
+        part.setCellSize(0.1f);
+        PS::SKETCH::U32 pv, pt;
+        std::vector<float> px;
+        std::vector<PS::SKETCH::U32> pe;
+        int mine = 0;
+        part.runTetrahedralizerSlab(hdr, dims, r, 2, [&](int n) { mine = n; return counts; }, pv, px, pt, pe);
+        if (pass == 0) { counts[r] = mine; continue; }
+        for (size_t i = 0; i < px.size(); i++) same = same && px[i] == xyz[3 * verts + i];
+        for (size_t i = 0; i < pe.size(); i++) same = same && pe[i] == el[4 * tets + i];
+        verts += pv; tets += pt;
+      }
+    std::printf("SLAB_VERTS=%zu\nSLAB_TETS=%zu\nSLAB_SAME=%d\n", verts, tets, same ? 1 : 0);
+  }
   // the cutting tool on the ball's current (deformed) mesh: a vertical needle through it, then a blade swept along x
   PS::FEM::Cutting cut(&ball);
   float known[4];

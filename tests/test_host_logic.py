@@ -306,3 +306,22 @@ def test_cut_create_validates_before_touching_a_device():
     assert L.fb_cut_create(None, 0, 4, fl.dptr(v), 1, fl.uptr(bad)) == fl.FB_EINVAL
     assert L.fb_cut_face_centroids(None) == fl.FB_EINVAL
     assert L.fb_cut_read(None, 0, None, None) == fl.FB_EINVAL
+
+
+def test_slab_plan_deals_every_plane_and_layer_once():
+    """fembrain_amd.poly.slab_plan: owned planes partition [0, planes), owned cell layers partition [0, planes - 1), every slab
+    holds one plane below and two above what it owns (clipped to the grid)"""
+    from fembrain_amd.poly import slab_plan
+    for planes in (4, 16, 17, 111, 256):
+        for world in (1, 2, 3, 8):
+            if planes < 2 * world:
+                with pytest.raises(ValueError):
+                    slab_plan(planes, world, 0)
+                continue
+            own_p, own_l = [], []
+            for r in range(world):
+                p0, p1, zf, zc, op, ol = slab_plan(planes, world, r)
+                assert op == p1 - p0 >= 2 and zf == max(p0 - 1, 0) and zf + zc - 1 == min(p1 + 1, planes - 1) and zc >= 2
+                own_p += list(range(p0, p0 + op))
+                own_l += list(range(p0, p0 + ol))
+            assert own_p == list(range(planes)) and own_l == list(range(planes - 1))

@@ -573,3 +573,67 @@ def test_surface_colors(gpu):
     pts = np.concatenate([v, np.zeros((len(v), 1), np.float32)], axis=1)
     f, want = o.field_color_array(pts)
     _assert_colors(g.compute_field_array(pts)[:, 3], rgba[:, :3], f[:, 3], want)
+
+
+# ---- multi-GPU field path: z-slabs of one grid -----------------------------------------------------------------------
+def _sharded_mesh(blob, lower, cell, dims, world):
+    """the ranks of a `world`-GPU run, played one after the other on this GPU: pieces of the tet mesh in rank order"""
+    from fembrain_amd.poly import slab_plan
+    polys, nvs = [], []
+    for rank in range(world):
+        g = GpuPoly(blob)
+        p0, p1, z_first, z_count, own_planes, own_layers = slab_plan(dims[2], world, rank)
+        g.sweep_slab(lower, cell, dims, z_first, z_count)
+        g.classify()
+        g.tetrahedralize()
+        nvs.append(g.slab_counts(p0, own_planes, own_layers)[0])
+        polys.append((g, p0, own_planes, own_layers))
+    pieces = [g.read_tetmesh_slab(p0, op, ol, sum(nvs[:r])) for r, (g, p0, op, ol) in enumerate(polys)]
+    return pieces
+
+
+@pytest.mark.parametrize("world", [2, 3, 5, 8])
+@pytest.mark.parametrize("name", ["sphere", "complex", "peanutInstanced"])
+def test_slab_pieces_concatenate_to_the_single_grid_mesh(gpu, name, world):
+    """positions, field samples and marks of a slab are computed from GLOBAL indices, so the pieces of all ranks put end to
+    end are bit for bit the tet mesh of the one-GPU run (vertex numbers included)"""
+    blob = sphere_blob() if name == "sphere" else read_blob(os.path.join(GOLD, "blob", name + ".blob"))
+    g = GpuPoly(blob)
+    dims = g.sweep(0.043 if name == "sphere" else 0.11)
+    lower, _ = blob.bbox
+    g.classify()
+    g.tetrahedralize()
+    xyz, tets = g.read_tetmesh()
+    assert dims[2] >= 2 * world and len(tets) > 1000
+    pieces = _sharded_mesh(blob, lower, 0.043 if name == "sphere" else 0.11, dims, world)
+    assert np.array_equal(np.concatenate([p[0] for p in pieces]), xyz)
+    assert np.array_equal(np.concatenate([p[1] for p in pieces]), tets)
+    assert sum(len(p[1]) for p in pieces) == g.counts.n_tets and min(len(p[1]) for p in pieces[1:-1] or pieces) >= 0
+
+
+def test_slab_grid_samples_equal_the_whole_grid(gpu):
+    blob = read_blob(os.path.join(GOLD, "blob", "tumor.blob"))
+    g = GpuPoly(blob)
+    dims = g.sweep(0.09)
+    whole = g.read_grid().reshape(dims[2], dims[1], dims[0], 4)
+    s = GpuPoly(blob)
+    s.sweep_slab(blob.bbox[0], 0.09, dims, 3, dims[2] - 5)
+    part = s.read_grid().reshape(dims[2] - 5, dims[1], dims[0], 4)
+    assert np.array_equal(part, whole[3:dims[2] - 2])
+
+
+def test_slab_argument_checks(gpu):
+    from fembrain_amd import lib as fl
+    blob = sphere_blob()
+    g = GpuPoly(blob)
+    dims = (12, 12, 12)
+    with pytest.raises(fl.FbError):
+        g.sweep_slab(blob.bbox[0], 0.1, dims, 5, 8)       # runs past the grid
+    g.sweep_slab(blob.bbox[0], 0.1, dims, 4, 6)           # planes 4..9
+    g.classify()
+    g.tetrahedralize()
+    with pytest.raises(fl.FbError):
+        g.slab_counts(4, 2, 2)                            # first owned plane needs the plane below it in the slab
+    with pytest.raises(fl.FbError):
+        g.slab_counts(5, 4, 4)                            # last owned layer 8 needs plane 10
+    assert g.slab_counts(5, 3, 3)[1] % 6 == 0

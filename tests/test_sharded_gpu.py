@@ -151,3 +151,60 @@ def test_p2p_wait_is_bounded_when_a_peer_leaves(gpu):
     assert res[1][1] == "left"
     assert res[0][2] is None and "timed out" in res[0][1], res[0]
     assert time.time() - t0 < 100
+
+
+def _field_worker(rank, world, port, q):
+    """one rank of the sharded field path: its z-slab through sweep / classify / tetrahedralize, vertex base from a real
+    all-gather (torch.distributed, gloo)"""
+    try:
+        import torch.distributed as dist
+        from fembrain_amd.blobtree import sphere_blob
+        from fembrain_amd.poly import GpuPoly
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+
+        def allgather(x):
+            out = [None] * world
+            dist.all_gather_object(out, int(x))
+            return out
+        blob = sphere_blob()
+        g = GpuPoly(blob)
+        xyz, tets = g.run_tetrahedralizer_slab(blob.bbox[0], 0.043, (26, 26, 26), rank, world, allgather)
+        q.put((rank, xyz, tets))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, repr(e), None))
+        q.close()
+        q.join_thread()
+        os._exit(1)
+
+
+def test_field_slabs_in_processes_concatenate_to_the_whole_mesh(gpu):
+    import multiprocessing as mp
+    from fembrain_amd.blobtree import sphere_blob
+    from fembrain_amd.poly import GpuPoly
+    world, port = 3, 29700 + os.getpid() % 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_field_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            r = q.get(timeout=240)
+            assert r[2] is not None, r
+            res[r[0]] = r
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    blob = sphere_blob()
+    g = GpuPoly(blob)
+    g.sweep_grid(blob.bbox[0], 0.043, (26, 26, 26))
+    g.classify()
+    g.tetrahedralize()
+    xyz, tets = g.read_tetmesh()
+    assert np.array_equal(np.concatenate([res[r][1] for r in range(world)]), xyz)
+    assert np.array_equal(np.concatenate([res[r][2] for r in range(world)]), tets) and len(tets) > 10000
