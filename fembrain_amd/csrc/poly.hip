@@ -550,9 +550,21 @@ __device__ inline unsigned int rank_of(const unsigned long long* __restrict__ ma
   return base[i >> 6] + (unsigned int)__popcll(w & ((1ULL << (i & 63)) - 1ULL));
 }
 
+// wave-uniform lane pick of a 64-bit / 32-bit register (j is the same in every lane)
+__device__ __forceinline__ unsigned long long pick64(unsigned long long v, int j) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, j);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), j);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned int pick32(unsigned int v, int j) { return (unsigned int)__builtin_amdgcn_readlane((int)v, j); }
+
+constexpr int kRun = 62;  // mask words a wave prefetches at once: lane j holds word j of the run (and j + 1 for the row windows)
+
 // TetMeshVertices (Tetrahedralizer.cl:39-64): included grid points compacted in grid order, xyz = the sweep's positions.
-// One wavefront = one 64-point word of the included-vertex mask: its output is the contiguous float range
-// [3*vbase[word], 3*(vbase[word]+popc)), staged in LDS and written with lane-contiguous stores.
+// One wavefront = one 64-point word of the included-vertex mask at a time: its output is the contiguous float range
+// [3*vbase[word], 3*(vbase[word]+popc)), staged in LDS and written with lane-contiguous stores.  The masks and bases of the
+// wave's whole run of words are fetched up front, one per lane, and picked with readlane inside the loop: with a load per
+// word in the loop the kernel was bound by that load's latency (40 us at 256^3 for 80 MB of output).
 __global__ __launch_bounds__(kPB) void k_tet_vertices(Grid G, const unsigned long long* __restrict__ vinc,
                                                       const unsigned int* __restrict__ vbase, float* __restrict__ xyz) {
   __shared__ float stage[kPB / 64][64 * 3];
@@ -562,32 +574,40 @@ __global__ __launch_bounds__(kPB) void k_tet_vertices(Grid G, const unsigned lon
   // each wave owns a CONTIGUOUS run of mask words, so neighbouring output ranges (which share cache lines at their
   // 96-/12-byte-granular ends) are written by the same CU instead of by waves on different XCDs
   const long long per = (nwords + nwaves - 1) / nwaves, wid = (long long)blockIdx.x * (kPB / 64) + wv;
-  for (long long word = wid * per; word < min((wid + 1) * per, nwords); word++) {  // wave-uniform loop
-    const unsigned long long mask = vinc[word];
-    if (mask == 0ULL) continue;
-    if ((mask >> lane) & 1ULL) {
-      const unsigned int g32 = (unsigned int)(word * 64 + lane), gx = (unsigned int)G.g[0], gxy = gx * (unsigned int)G.g[1];
-      const unsigned int iz = g32 / gxy, rem = g32 - iz * gxy;
-      const unsigned int iy = rem / gx, ix = rem - iy * gx;
-      float* o = &stage[wv][3 * __popcll(mask & ((1ULL << lane) - 1ULL))];
-      o[0] = G.lo[0] + G.cellsize * (float)ix;
-      o[1] = G.lo[1] + G.cellsize * (float)iy;
-      o[2] = G.lo[2] + G.cellsize * (float)(iz + (unsigned int)G.z0);
+  const long long end = min((wid + 1) * per, nwords);
+  for (long long first = wid * per; first < end; first += kRun) {  // wave-uniform loops
+    const int cnt = (int)min((long long)kRun, end - first);
+    const unsigned long long my_mask = lane < cnt ? vinc[first + lane] : 0ULL;
+    const unsigned int my_base = lane < cnt ? vbase[first + lane] : 0u;
+    for (int j = 0; j < cnt; j++) {
+      const unsigned long long mask = pick64(my_mask, j);
+      if (mask == 0ULL) continue;
+      if ((mask >> lane) & 1ULL) {
+        const unsigned int g32 = (unsigned int)((first + j) * 64 + lane), gx = (unsigned int)G.g[0], gxy = gx * (unsigned int)G.g[1];
+        const unsigned int iz = g32 / gxy, rem = g32 - iz * gxy;
+        const unsigned int iy = rem / gx, ix = rem - iy * gx;
+        float* o = &stage[wv][3 * __popcll(mask & ((1ULL << lane) - 1ULL))];
+        o[0] = G.lo[0] + G.cellsize * (float)ix;
+        o[1] = G.lo[1] + G.cellsize * (float)iy;
+        o[2] = G.lo[2] + G.cellsize * (float)(iz + (unsigned int)G.z0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int total = 3 * __popcll(mask);
+      float* out = xyz + 3 * (size_t)pick32(my_base, j);
+      for (int i = lane; i < total; i += 64) out[i] = stage[wv][i];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int total = 3 * __popcll(mask);
-    float* out = xyz + 3 * (size_t)vbase[word];
-    for (int i = lane; i < total; i += 64) out[i] = stage[wv][i];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
 }
 
 // TetMeshElements (Tetrahedralizer.cl:67-132): 6 tets per included cell, corners LBN,LBF,LTN,LTF,RBN,RBF,RTN,RTF = 0..7.
-// A wavefront covers exactly one 64-bit word of the included-cell mask (cells addressed by their lower-corner point), so its output is the contiguous range
-// [6*cbase[word], 6*(cbase[word]+popc)) of uint4 records: lanes stage their 6 records in LDS at their rank inside the
-// word and the wave then streams the range out with lane-contiguous 16-byte stores.
+// A wavefront covers one 64-bit word of the included-cell mask at a time (cells addressed by their lower-corner point), so its
+// output is the contiguous range [6*cbase[word], 6*(cbase[word]+popc)) of uint4 records: lanes stage their 6 records in LDS
+// at their rank inside the word and the wave then streams the range out with lane-contiguous 16-byte stores.  As in
+// k_tet_vertices everything the loop needs from memory -- the cell masks and bases of the run and the vertex-mask windows
+// of the four corner rows -- is fetched up front, one word per lane.
 __global__ __launch_bounds__(kPB) void k_tet_elements(Grid G, const unsigned long long* __restrict__ cinc,
                                                       const unsigned int* __restrict__ cbase, const unsigned long long* __restrict__ vinc,
                                                       const unsigned int* __restrict__ vbase, uint4* __restrict__ tets) {
@@ -596,49 +616,58 @@ __global__ __launch_bounds__(kPB) void k_tet_elements(Grid G, const unsigned lon
   const long long nwords = (G.n_points + 63) >> 6;
   const long long nwaves = (long long)gridDim.x * (kPB / 64);
   const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
-  // each wave owns a CONTIGUOUS run of mask words, so neighbouring output ranges (which share cache lines at their
-  // 96-/12-byte-granular ends) are written by the same CU instead of by waves on different XCDs
   const long long per = (nwords + nwaves - 1) / nwaves, wid = (long long)blockIdx.x * (kPB / 64) + wv;
-  for (long long word = wid * per; word < min((wid + 1) * per, nwords); word++) {  // wave-uniform loop
-    const unsigned long long mask = cinc[word];
-    if (mask == 0ULL) continue;
-    // vertex ranks of the four (y,z) rows of corners: the 64 lanes of a row cover 64 consecutive points, i.e. at most two
-    // words of the vertex mask -- fetched once per wave through the scalar path instead of per lane
-    unsigned int c[8];
-    const long long rowoff[4] = {0, gxy, gx, gx + gxy};
+  const long long end = min((wid + 1) * per, nwords);
+  const long long rowoff[4] = {0, gxy, gx, gx + gxy};
+  for (long long first = wid * per; first < end; first += kRun) {  // wave-uniform loops
+    const int cnt = (int)min((long long)kRun, end - first);
+    const unsigned long long my_mask = lane < cnt ? cinc[first + lane] : 0ULL;
+    const unsigned int my_base = lane < cnt ? cbase[first + lane] : 0u;
+    // vertex ranks of the four (y,z) rows of corners: the 64 lanes of a row cover 64 consecutive points, i.e. two words of
+    // the vertex mask, word j + off and the next one for the run's word j (clamped: rows past the grid end are only touched
+    // by lanes whose cell is not included, their ranks are unused)
+    unsigned long long rm[4];
+    unsigned int rb[4];
 #pragma unroll
     for (int r4 = 0; r4 < 4; r4++) {
-      const long long q0 = word * 64 + rowoff[r4];                       // wave-uniform
-      // clamped: rows past the grid end are only touched by lanes whose cell is not included (their ranks are unused)
-      const long long w0 = min(q0 >> 6, nwords - 1);
-      const long long w1 = min(w0 + 1, nwords - 1);
-      const unsigned long long m0 = vinc[w0], m1 = vinc[w1];
-      const unsigned int b0 = vbase[w0], b1 = vbase[w1];
-      const int bit = (int)(q0 & 63) + lane;                             // position inside the two-word window
-      const unsigned long long mm = bit < 64 ? m0 : m1;
-      const unsigned int bb = bit < 64 ? b0 : b1;
-      c[r4] = bb + (unsigned int)__popcll(mm & ((1ULL << (bit & 63)) - 1ULL));
+      const long long w = min(first + lane + (rowoff[r4] >> 6), nwords - 1);
+      rm[r4] = lane <= cnt ? vinc[w] : 0ULL;
+      rb[r4] = lane <= cnt ? vbase[w] : 0u;
     }
-    // all 8 corners of an included cell are included vertices and a rank is a prefix count in grid order, so the +x
-    // corner of each row is simply the next rank
-    c[4] = c[0] + 1; c[5] = c[1] + 1; c[6] = c[2] + 1; c[7] = c[3] + 1;
-    if ((mask >> lane) & 1ULL) {
-      enum { LBN, LBF, LTN, LTF, RBN, RBF, RTN, RTF };
-      uint4* o = &stage[wv][6 * __popcll(mask & ((1ULL << lane) - 1ULL))];
-      o[0] = make_uint4(c[LBN], c[LTN], c[RBN], c[LBF]);
-      o[1] = make_uint4(c[RTN], c[LTN], c[LBF], c[RBN]);
-      o[2] = make_uint4(c[RTN], c[LTN], c[LTF], c[LBF]);
-      o[3] = make_uint4(c[RTN], c[RBN], c[LBF], c[RBF]);
-      o[4] = make_uint4(c[RTN], c[LBF], c[LTF], c[RBF]);
-      o[5] = make_uint4(c[RTN], c[LTF], c[RTF], c[RBF]);
+    for (int j = 0; j < cnt; j++) {
+      const unsigned long long mask = pick64(my_mask, j);
+      if (mask == 0ULL) continue;
+      unsigned int c[8];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) {
+        const unsigned long long m0 = pick64(rm[r4], j), m1 = pick64(rm[r4], j + 1);
+        const unsigned int b0 = pick32(rb[r4], j), b1 = pick32(rb[r4], j + 1);
+        const int bit = (int)(rowoff[r4] & 63) + lane;                     // position inside the two-word window
+        const unsigned long long mm = bit < 64 ? m0 : m1;
+        const unsigned int bb = bit < 64 ? b0 : b1;
+        c[r4] = bb + (unsigned int)__popcll(mm & ((1ULL << (bit & 63)) - 1ULL));
+      }
+      // all 8 corners of an included cell are included vertices and a rank is a prefix count in grid order, so the +x
+      // corner of each row is simply the next rank
+      c[4] = c[0] + 1; c[5] = c[1] + 1; c[6] = c[2] + 1; c[7] = c[3] + 1;
+      if ((mask >> lane) & 1ULL) {
+        enum { LBN, LBF, LTN, LTF, RBN, RBF, RTN, RTF };
+        uint4* o = &stage[wv][6 * __popcll(mask & ((1ULL << lane) - 1ULL))];
+        o[0] = make_uint4(c[LBN], c[LTN], c[RBN], c[LBF]);
+        o[1] = make_uint4(c[RTN], c[LTN], c[LBF], c[RBN]);
+        o[2] = make_uint4(c[RTN], c[LTN], c[LTF], c[LBF]);
+        o[3] = make_uint4(c[RTN], c[RBN], c[LBF], c[RBF]);
+        o[4] = make_uint4(c[RTN], c[LBF], c[LTF], c[RBF]);
+        o[5] = make_uint4(c[RTN], c[LTF], c[RTF], c[RBF]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int total = 6 * __popcll(mask);
+      uint4* out = tets + 6 * (size_t)pick32(my_base, j);
+      for (int i = lane; i < total; i += 64) out[i] = stage[wv][i];  // (non-temporal stores measured slower here: 161 vs 140 us)
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int total = 6 * __popcll(mask);
-    uint4* out = tets + 6 * (size_t)cbase[word];
-    for (int i = lane; i < total; i += 64) out[i] = stage[wv][i];  // (non-temporal stores measured slower here: 161 vs 140 us)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
 }
 
