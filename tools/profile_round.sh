@@ -3,6 +3,7 @@
 # runs, no trace domains) of the default bench workload; raw output under gpurun_out/, summaries are made afterwards by
 # tools/kernel_stats.py and tools/summarize_profiles.py.
 set -e
+export FEMBRAIN_BENCH_SKIP_8M=${FEMBRAIN_BENCH_SKIP_8M:-1}   # the 8M-tet leg has its own kernels (k_spmv<..., true>); profile it with =0
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$R/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
