@@ -110,7 +110,7 @@ template <typename MT>
 __global__ __launch_bounds__(kBlock) void k_tet_warp(int nt, const int4* __restrict__ tets, const double* __restrict__ x0,
                                                      const double* __restrict__ u, const double* __restrict__ rest,
                                                      MT* __restrict__ rec, double* __restrict__ fe, double* __restrict__ rot,
-                                                     double lambda, double mu) {
+                                                     double lambda, double mu, int linear) {
   const int e = blockIdx.x * kBlock + threadIdx.x;
   if (e >= nt) return;
   const int4 t = tets[e];
@@ -131,10 +131,15 @@ __global__ __launch_bounds__(kBlock) void k_tet_warp(int nt, const int4* __restr
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) F[3 * i + j] = P[0][i] * b[0][j] + P[1][i] * b[1][j] + P[2][i] * b[2][j] + P[3][i] * b[3][j];
-  const double det = polar_rotation(F, R, 1e-6);
-  if (det < 0) {
+  if (linear) {  // warp = 0 (corotationalLinearFEM.cpp:429-453): R = I, so c_k = b_k and f_e = K0 u
 #pragma unroll
-    for (int i = 0; i < 9; i++) R[i] = -R[i];
+    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  } else {
+    const double det = polar_rotation(F, R, 1e-6);
+    if (det < 0) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) R[i] = -R[i];
+    }
   }
   // H = sum_j y_j b_j^T with y_j = R^T P_j - X0_j
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -17,7 +17,8 @@ from .meshgen import fixed_vertices_to_dofs
 class FemIntegrator:
     def __init__(self, verts, tets, fixed_dofs=(), E=1e7, nu=0.46, rho=1000.0, timestep=0.0333,
                  damping_mass=0.0, damping_stiffness=0.01, cg_eps=1e-6, cg_max_iter=10000,
-                 matrix_precision=_l.FB_MATRIX_F32, device=0, shard=None, pcg_variant=_l.FB_PCG_MERGED, spmv_kernel=_l.FB_SPMV_AUTO):
+                 matrix_precision=_l.FB_MATRIX_F32, device=0, shard=None, pcg_variant=_l.FB_PCG_MERGED, spmv_kernel=_l.FB_SPMV_AUTO,
+                 linear=False):
         """shard = (n_ranks, rank, node_splits or None, comm_handle) for a domain-decomposed handle."""
         L = _l.lib()
         self._L = L
@@ -33,6 +34,7 @@ class FemIntegrator:
         p.cg_eps, p.cg_max_iter, p.matrix_precision, p.device = cg_eps, cg_max_iter, matrix_precision, device
         p.pcg_variant = pcg_variant
         p.spmv_kernel = spmv_kernel
+        p.linear = 1 if linear else 0
         self.params = p
         self.h = C.c_void_p()
         self.node_lo, self.node_hi = 0, self.n_nodes

@@ -34,7 +34,7 @@ class FemParams(C.Structure):
     _fields_ = [("E", C.c_double), ("nu", C.c_double), ("rho", C.c_double), ("timestep", C.c_double),
                 ("damping_mass", C.c_double), ("damping_stiffness", C.c_double), ("cg_eps", C.c_double),
                 ("cg_max_iter", C.c_int), ("matrix_precision", C.c_int), ("device", C.c_int),
-                ("pcg_variant", C.c_int), ("spmv_kernel", C.c_int), ("reserved", C.c_int * 3)]
+                ("pcg_variant", C.c_int), ("spmv_kernel", C.c_int), ("linear", C.c_int), ("reserved", C.c_int * 2)]
 
 
 class StepInfo(C.Structure):

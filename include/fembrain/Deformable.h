@@ -33,9 +33,13 @@ class HipIntegrator {
   // constrainedDOFs: 0-indexed, ascending, copied (implicitNewmarkSparse.h:78-80)
   HipIntegrator(int numVertices, const double* restPositions, int numElements, const int* elements, int numConstrainedDOFs,
                 const int* constrainedDOFs, double timestep = 0.0333, double dampingMassCoef = 0.0, double dampingStiffnessCoef = 0.01,
-                double E = 1e7, double nu = 0.46, double density = 1000.0, int device = 0)
+                double E = 1e7, double nu = 0.46, double density = 1000.0, int device = 0, int warp = 1)
       : r_(3 * numVertices), h_(nullptr) {
+    // warp: the argument of CorotationalLinearFEMForceModel (corotationalLinearFEMForceModel.h:42): 1 = corotational (default,
+    // what FemBrain runs), 0 = linear elasticity; 2 (exact tangent) is not offered -- its Keff is not symmetric
+    if (warp != 0 && warp != 1) throw std::invalid_argument("warp must be 0 or 1");
     fb_fem_default_params(&prm_);
+    prm_.linear = warp == 0 ? 1 : 0;
     prm_.E = E; prm_.nu = nu; prm_.rho = density;
     prm_.timestep = timestep; prm_.damping_mass = dampingMassCoef; prm_.damping_stiffness = dampingStiffnessCoef;
     prm_.device = device;

@@ -62,7 +62,9 @@ typedef struct fb_fem_params {
   int device;                   /* HIP device ordinal */
   int pcg_variant;              /* FB_PCG_MERGED (default) / FB_PCG_REFERENCE */
   int spmv_kernel;              /* 0 = choose by size, FB_SPMV_ROWS, FB_SPMV_SPLIT (small meshes: one slice per block) */
-  int reserved[3];
+  int linear;                   /* non-zero: warp = 0 of CorotationalLinearFEMForceModel (corotationalLinearFEM.cpp:429-453): no rotation
+                                 * extraction, K = K0 and f = K0 u.  0 = the corotational model FemBrain uses (warp = 1, its default) */
+  int reserved[2];
 } fb_fem_params;
 #define FB_SPMV_ROWS 1
 #define FB_SPMV_SPLIT 2

@@ -30,6 +30,7 @@ typedef struct {
   double *Minv; /* 16 nt, row-major, rows = vertices: [b_k | c_k] */
   double *K0;   /* 144 nt, row-major 12x12 */
   double lambda, mu, rho;
+  int linear;   /* warp = 0: K = K0, f = K0 u (corotationalLinearFEM.cpp:429-453) */
   /* node-level block pattern */
   int *bptr, *bcol, nblk;
   /* scalar CSR */
@@ -214,6 +215,16 @@ void orc_fem_element(void *h, int e, const double *u, double *Rout, double *Ke, 
   double P[12], F[9], R[9], RK[144], KE[144];
   for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) P[4 * i + j] = s->x0[3 * t[j] + i] + u[3 * t[j] + i];
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double a = 0; for (int k = 0; k < 4; k++) a += P[4 * i + k] * Mi[4 * k + j]; F[3 * i + j] = a; }
+  if (s->linear) {  /* :429-446: KElement = KElementUndeformed, fElement = KElement u */
+    if (fe) for (int i = 0; i < 12; i++) {
+      double a = 0;
+      for (int j = 0; j < 4; j++) a += K0[12 * i + 3 * j + 0] * u[3 * t[j] + 0] + K0[12 * i + 3 * j + 1] * u[3 * t[j] + 1] + K0[12 * i + 3 * j + 2] * u[3 * t[j] + 2];
+      fe[i] = a;
+    }
+    if (Rout) { memset(Rout, 0, 9 * sizeof(double)); Rout[0] = Rout[4] = Rout[8] = 1.0; }
+    if (Ke) memcpy(Ke, K0, sizeof KE);
+    return;
+  }
   double det = orc_polar(F, R, NULL, 1e-6);
   if (det < 0) for (int i = 0; i < 9; i++) R[i] *= -1.0;
   memset(RK, 0, sizeof RK); memset(KE, 0, sizeof KE);
@@ -231,6 +242,8 @@ void orc_fem_element(void *h, int e, const double *u, double *Rout, double *Ke, 
   if (Rout) memcpy(Rout, R, sizeof R);
   if (Ke) memcpy(Ke, KE, sizeof KE);
 }
+
+void orc_fem_set_linear(void *h, int linear) { ((OrcFem *)h)->linear = linear; }
 
 /* f (may be NULL) and K values on the CSR pattern (may be NULL): zeroed, then accumulated in element order */
 void orc_fem_assemble(void *h, const double *u, double *f, double *Kv) {

@@ -54,6 +54,7 @@ def _load(kind):
     for name in ("fem_K0", "fem_Minv"):
         getattr(lib, p + name).argtypes = [C.c_void_p, C.c_int, _dp]
     getattr(lib, p + "fem_assemble").argtypes = [C.c_void_p, _dp, _dp, _dp]
+    getattr(lib, p + "fem_set_linear").argtypes = [C.c_void_p, C.c_int]
     g = getattr(lib, p + "integrator_create")
     g.argtypes = [C.c_void_p, C.c_int, _ip, C.c_double, C.c_double, C.c_double]
     getattr(lib, p + "set_state").argtypes = [C.c_void_p, _dp, _dp]
@@ -129,6 +130,10 @@ class _Fem:
         out = np.empty(16)
         getattr(self.lib, self.p + "fem_Minv")(self.h, el, _d(out))
         return out.reshape(4, 4)
+
+    def set_linear(self, linear=True):
+        """warp = 0 of ComputeForceAndStiffnessMatrix (corotationalLinearFEM.cpp:429-453) instead of FemBrain's warp = 1"""
+        getattr(self.lib, self.p + "fem_set_linear")(self.h, 1 if linear else 0)
 
     def assemble(self, u, want_K=True):
         u = np.ascontiguousarray(u, dtype=np.float64)

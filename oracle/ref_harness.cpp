@@ -51,8 +51,9 @@ struct RefFem {
   std::vector<double> q, qvel, qaccel, fext, fint, qres, qdelta, buf, bufc;
   double h, cM, cK, scale;
   int last_iters;
+  int warp;  // the `warp` argument of ComputeForceAndStiffnessMatrix: 1 (FemBrain's default) or 0 (linear)
   RefFem() : mesh(NULL), fem(NULL), mass(NULL), r(0), K(NULL), D(NULL), damp(NULL), sys(NULL), cg(NULL),
-             h(0.0333), cM(0.0), cK(0.01), scale(1.0), last_iters(0) {}
+             h(0.0333), cM(0.0), cK(0.01), scale(1.0), last_iters(0), warp(1) {}
 };
 
 }  // namespace
@@ -100,11 +101,13 @@ int ref_fem_mass(void* h, int* ia, int* ja, double* a) {
   return nnz;
 }
 
-// f_int and K values (CSR order of ref_fem_topology) for displacement u, warp=1
+void ref_fem_set_linear(void* h, int linear) { ((RefFem*)h)->warp = linear ? 0 : 1; }
+
+// f_int and K values (CSR order of ref_fem_topology) for displacement u (warp = 1 unless ref_fem_set_linear)
 void ref_fem_assemble(void* h, const double* u, double* f, double* Kvals) {
   RefFem* s = (RefFem*)h;
   SparseMatrix* T; s->fem->GetStiffnessMatrixTopology(&T);
-  s->fem->ComputeForceAndStiffnessMatrix(const_cast<double*>(u), f, T, 1);
+  s->fem->ComputeForceAndStiffnessMatrix(const_cast<double*>(u), f, T, s->warp);
   if (Kvals) T->GenerateCompressedRowMajorFormat(Kvals, NULL, NULL, 0, 0);
   delete T;
 }
@@ -158,7 +161,7 @@ int ref_step(void* hh, double cg_eps, int cg_maxiter, double* keff, double* rhs,
   RefFem* s = (RefFem*)hh;
   int r = s->r;
   for (int i = 0; i < r; i++) s->qaccel[i] = 0;
-  s->fem->ComputeForceAndStiffnessMatrix(s->q.data(), s->fint.data(), s->K, 1);
+  s->fem->ComputeForceAndStiffnessMatrix(s->q.data(), s->fint.data(), s->K, s->warp);
   for (int i = 0; i < r; i++) s->fint[i] *= s->scale;
   *s->K *= s->scale;
   memset(s->qres.data(), 0, sizeof(double) * r);

@@ -6,6 +6,7 @@ at test time.
   fem_cube5.npz   truth cube 5^3 (125 nodes / 384 tets, plane i=0 clamped): per-element K0 / M^-1, stiffness pattern,
                   assembled f and K at a seeded displacement, Keff / rhs / PCG solution of one step from a seeded
                   state, q and qvel after 3 steps under the reference load (-10000/y-DOF) and a gentle one (-10)
+  fem_cube5_linear.npz   the same cube with warp = 0 (linear elasticity): assembled f and K at a seeded displacement, q after 2 steps
   fem_beam3.npz   data/models/beam3/beam3_tet.veg (208 nodes / 450 tets, Vega's own sample) with beam3.bou clamps:
                   mesh, the reference's consistent mass matrix file beam3_tet.mass (a known answer shipped by the
                   reference), and q after 3 steps with -10 per y-DOF
@@ -70,6 +71,28 @@ def cube5():
     print("cube5: nnz", len(ja), "cg", info, "iters", ia_, ib_)
 
 
+def cube5_linear():
+    """warp = 0 (the linear branch of ComputeForceAndStiffnessMatrix): assembled f, K and 2 steps under the gentle load"""
+    n = 5
+    v, t = truth_cube(n, n, n, 0.1)
+    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    r = RefFem(v, t)
+    r.set_linear(True)
+    rng = np.random.default_rng(54321)
+    u = rng.normal(size=r.r) * 0.01
+    f, K = r.assemble(u)
+    r.integrator(fixed)
+    fext = np.zeros(r.r)
+    fext[1::3] = -10.0
+    qs, its = [], []
+    for _ in range(2):
+        r.set_external_forces(fext)
+        its.append(r.step(cg_eps=1e-6))
+        qs.append(r.get_state()[0])
+    np.savez_compressed(os.path.join(HERE, "fem_cube5_linear.npz"), n=n, fixed=fixed, u=u, f=f, K=K, q=np.array(qs), it=np.array(its))
+    print("cube5 linear: |f|", np.linalg.norm(f), "iters", its)
+
+
 def beam3():
     v, t = read_veg(os.path.join(REF, "beam3", "beam3_tet.veg"))
     bou = [int(x) for x in open(os.path.join(REF, "beam3", "beam3.bou")).read().replace("\n", "").split(",") if x.strip()]
@@ -87,5 +110,9 @@ def beam3():
 
 
 if __name__ == "__main__":
-    cube5()
-    beam3()
+    if len(sys.argv) > 1 and sys.argv[1] == "linear":
+        cube5_linear()   # added later: leaves the other two files as they are
+    else:
+        cube5()
+        cube5_linear()
+        beam3()

@@ -4,6 +4,8 @@ Tolerances (stated per test): FB_MATRIX_F64 storage reproduces the fp64 oracle u
 (<= 1e-9 relative); the default FB_MATRIX_F32 storage rounds every stiffness entry to fp32 (6e-8 relative),
 everything else (geometry, polar decomposition, vectors, dots) stays fp64.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -614,3 +616,35 @@ def test_nontemporal_value_stream_gives_identical_iterates(gpu, monkeypatch):
         out.append((its, q, qv))
         g.close()
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("prec,tol", [(fl.FB_MATRIX_F64, 1e-10), (fl.FB_MATRIX_F32, 5e-7)])
+def test_linear_elasticity_mode(gpu, prec, tol):
+    """fb_fem_params.linear = warp 0 of the reference's force model (corotationalLinearFEM.cpp:429-453): K = K0 whatever
+    the displacement, f = K0 u; assembled values and two steps against the oracle (pinned for this mode by
+    tests/golden/fem_cube5_linear.npz, vectors of the reference build) and against those vectors directly"""
+    g5 = np.load(os.path.join(os.path.dirname(__file__), "golden", "fem_cube5_linear.npz"))
+    n = int(g5["n"])
+    v, t, fixed = _cube(n)
+    o = OrcFem(v, t)
+    o.set_linear(True)
+    g = FemIntegrator(v, t, fixed, matrix_precision=prec, linear=True)
+    conv = _oracle_bsr(o)
+    fg, Kg = g.assemble(g5["u"])
+    assert np.abs(fg - g5["f"]).max() <= 1e-9 * np.abs(g5["f"]).max()
+    Kref = conv(g5["K"])
+    assert np.abs(Kg - Kref).max() <= tol * np.abs(Kref).max()
+    # a large rigid-looking displacement changes nothing in K (no rotation extraction in this mode)
+    big = np.tile([0.3, -0.2, 0.1], len(v)) + 0.5 * np.cross(v, [0.0, 0.0, 1.0]).reshape(-1)
+    _, K2 = g.assemble(big)
+    assert np.array_equal(K2, Kg)
+    o.integrator(fixed)
+    fext = np.zeros(o.r)
+    fext[1::3] = -10.0
+    for k in range(2):
+        o.set_external_forces(fext)
+        g.set_external_forces(fext)
+        io, ig = abs(o.step()), g.do_timestep()
+        qg = g.get_q_state()[0]
+        assert abs(ig - io) <= 3 and abs(ig - g5["it"][k]) <= 3
+        assert np.abs(qg - g5["q"][k]).max() <= (2e-5 if prec == fl.FB_MATRIX_F64 else 2e-4) * np.abs(g5["q"][k]).max()

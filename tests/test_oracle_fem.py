@@ -127,3 +127,28 @@ def test_live_reference_build_matches_and_survey_norms():
         r.step()
         q, _ = r.get_state()
         assert abs(np.linalg.norm(q) - want[k]) < 0.006
+
+
+def test_linear_elasticity_mode_against_reference_vectors():
+    """warp = 0 (corotationalLinearFEM.cpp:429-453): K = K0, f = K0 u -- golden vectors of the reference build with
+    ComputeForceAndStiffnessMatrix(.., warp = 0) (tests/golden/make_fem_golden.py linear)"""
+    g = np.load(os.path.join(GOLD, "fem_cube5_linear.npz"))
+    n = int(g["n"])
+    v, t = truth_cube(n, n, n, 0.1)
+    o = OrcFem(v, t)
+    o.set_linear(True)
+    f, K = o.assemble(g["u"])
+    assert np.abs(f - g["f"]).max() <= 1e-12 * np.abs(g["f"]).max()
+    assert np.abs(K - g["K"]).max() <= 1e-12 * np.abs(g["K"]).max()
+    # K does not depend on u, and f is linear in it
+    f2, K2 = o.assemble(2.0 * g["u"])
+    assert np.array_equal(K2, K) and np.abs(f2 - 2.0 * f).max() <= 1e-12 * np.abs(f).max()
+    o.integrator(g["fixed"])
+    fext = np.zeros(o.r)
+    fext[1::3] = -10.0
+    for k in range(2):
+        o.set_external_forces(fext)
+        it = o.step()
+        q, _ = o.get_state()
+        assert abs(abs(it) - g["it"][k]) <= 2
+        assert np.abs(q - g["q"][k]).max() <= 1e-5 * np.abs(g["q"][k]).max()
