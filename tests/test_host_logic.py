@@ -325,3 +325,17 @@ def test_slab_plan_deals_every_plane_and_layer_once():
                 own_p += list(range(p0, p0 + op))
                 own_l += list(range(p0, p0 + ol))
             assert own_p == list(range(planes)) and own_l == list(range(planes - 1))
+
+
+def test_c_abi_header_is_plain_c99(tmp_path):
+    """include/fembrain_hip.h is the drop-in boundary: a C99 compiler must accept it with -pedantic (no C++-isms) and a C
+    program must link against the library"""
+    import subprocess
+    src = tmp_path / "cabi.c"
+    src.write_text('#include "fembrain_hip.h"\n#include "fembrain_hip_testing.h"\n'
+                   'int main(void) { fb_fem_params p; fb_fem_default_params(&p); return (p.linear == 0 && fb_last_error() != 0) ? 0 : 1; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "cabi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", os.path.join(root, "fembrain_amd"), "-lfembrain_hip", "-Wl,-rpath," + os.path.join(root, "fembrain_amd")])
+    assert subprocess.call([str(exe)]) == 0
