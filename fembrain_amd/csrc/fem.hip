@@ -3,10 +3,13 @@
 #include <algorithm>
 #include <cmath>
 
+#include <chrono>
+
 #include "comm.h"
 #include "common.h"
 #include "fem_device.hip.h"
 #include "fem_plan.h"
+#include "plan_device.h"
 
 using namespace fb;
 
@@ -29,6 +32,8 @@ struct fb_fem_s {
   // matrix
   DevBuf<int> slice_off, colidx, slot_coff, slot_ccnt, send_local;
   DevBuf<uint32_t> contrib;
+  DevBuf<int> d_bptr, d_bcol, d_blk_slot;  // device-built plan only: pattern and slot table, fetched when an inspection entry point asks
+  bool device_plan = false, host_pattern = true;
   DevBuf<uint8_t> dofmask;
   DevBuf<char> vals;  // MT[n_slots][9][64]
   DevBuf<char> dlo;   // MT[n_slices][9][64]: low part of every row's diagonal block
@@ -68,9 +73,16 @@ SellView sell_view(const fb_fem_s* h) {
 int upload_plan(fb_fem_s* h, const double* xyz_global) {
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
-  std::vector<int4> t4(P.n_tets);
-  for (int e = 0; e < P.n_tets; e++) t4[e] = make_int4(P.tets[4 * (size_t)e], P.tets[4 * (size_t)e + 1], P.tets[4 * (size_t)e + 2], P.tets[4 * (size_t)e + 3]);
-  FB_TRY(h->tets.upload(t4, s));
+  if (!h->device_plan) {  // (the device builder has put the tets and the plan arrays in place already)
+    std::vector<int4> t4(P.n_tets);
+    for (int e = 0; e < P.n_tets; e++) t4[e] = make_int4(P.tets[4 * (size_t)e], P.tets[4 * (size_t)e + 1], P.tets[4 * (size_t)e + 2], P.tets[4 * (size_t)e + 3]);
+    FB_TRY(h->tets.upload(t4, s));
+    FB_TRY(h->slice_off.upload(P.slice_off, s));
+    FB_TRY(h->colidx.upload(P.colidx, s));
+    FB_TRY(h->slot_coff.upload(P.slot_coff, s));
+    FB_TRY(h->slot_ccnt.upload(P.slot_ccnt, s));
+    FB_TRY(h->contrib.upload(P.contrib.data(), P.contrib.size(), s));
+  }
   std::vector<double> x0((size_t)3 * P.n_local);
   for (int l = 0; l < P.n_local; l++)
     for (int k = 0; k < 3; k++) x0[3 * (size_t)l + k] = xyz_global[3 * (size_t)P.local2global[l] + k];
@@ -78,11 +90,6 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
   FB_TRY(h->rest.alloc((size_t)16 * P.n_tets));
   FB_TRY(h->fe.alloc((size_t)12 * P.n_tets));
   FB_TRY(h->rec.alloc((size_t)16 * P.n_tets * mt_size(h)));
-  FB_TRY(h->slice_off.upload(P.slice_off, s));
-  FB_TRY(h->colidx.upload(P.colidx, s));
-  FB_TRY(h->slot_coff.upload(P.slot_coff, s));
-  FB_TRY(h->slot_ccnt.upload(P.slot_ccnt, s));
-  FB_TRY(h->contrib.upload(P.contrib.data(), P.contrib.size(), s));
   FB_TRY(h->dofmask.upload(P.dofmask, s));
   if (!P.send_local.empty()) FB_TRY(h->send_local.upload(P.send_local, s));
   FB_TRY(h->sendbuf.alloc(std::max<size_t>(1, (size_t)12 * P.send_local.size())));
@@ -511,24 +518,94 @@ int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int*
   return FB_OK;
 }
 
+// The plan of an unsharded handle, built on the device (plan_device.hip).  The host keeps the scalars, the slice offsets,
+// the identity numbering and the constraint mask; the pattern arrays stay on the device until an inspection entry point
+// asks for them (ensure_host_pattern).
+int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed) {
+  if (n_nodes <= 0 || n_tets <= 0 || !tets) return fail(FB_EINVAL, "empty mesh (%d nodes, %d tets)", n_nodes, n_tets);
+  if ((long long)n_tets >= (1LL << 28)) return fail(FB_EINVAL, "too many tets for the packed contribution word");
+  for (long long k = 0; k < 4LL * n_tets; k++)
+    if (tets[k] < 0 || tets[k] >= n_nodes) return fail(FB_EINVAL, "tet %lld references node %d outside [0,%d)", k / 4, tets[k], n_nodes);
+  FemPlan& P = h->plan;
+  P = FemPlan();
+  P.n_global = n_nodes; P.n_ranks = 1; P.rank = 0;
+  P.splits = {0, n_nodes};
+  P.node_lo = 0; P.node_hi = n_nodes;
+  P.n_owned = P.n_local = n_nodes; P.n_halo = 0;
+  P.local2global.resize(n_nodes);
+  for (int l = 0; l < n_nodes; l++) P.local2global[l] = l;
+  P.halo_off.assign(2, 0);
+  P.send_off.assign(2, 0);
+  P.n_tets = n_tets;
+  FB_TRY(plan_set_constraints(P, n_fixed, fixed));
+  FB_TRY(h->tets.upload((const int4*)tets, (size_t)n_tets, h->stream));
+  DevicePlan D;
+  D.slice_off = &h->slice_off; D.colidx = &h->colidx; D.slot_coff = &h->slot_coff; D.slot_ccnt = &h->slot_ccnt; D.contrib = &h->contrib;
+  D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot;
+  FB_TRY(build_plan_device(h->stream, n_nodes, n_tets, h->tets.p, D));
+  P.n_blocks = D.n_blocks; P.n_slices = D.n_slices; P.n_slots = D.n_slots; P.n_crows = D.n_crows;
+  P.slice_off = D.slice_off_host;
+  return FB_OK;
+}
+
+// inspection entry points (pattern, block values, mass) index the CSR pattern on the host
+int ensure_host_pattern(fb_fem_s* h) {
+  if (h->host_pattern) return FB_OK;
+  FemPlan& P = h->plan;
+  P.bptr.resize((size_t)P.n_owned + 1);
+  P.bcol.resize((size_t)P.n_blocks);
+  P.blk_slot.resize((size_t)P.n_blocks);
+  FB_TRY(h->d_bptr.download(P.bptr.data(), P.bptr.size(), h->stream));
+  FB_TRY(h->d_bcol.download(P.bcol.data(), P.bcol.size(), h->stream));
+  FB_TRY(h->d_blk_slot.download(P.blk_slot.data(), P.blk_slot.size(), h->stream));
+  h->host_pattern = true;
+  return FB_OK;
+}
+
 int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed, const int* fixed, int n_ranks,
           int rank, const int* splits) {
   drop_graph(h);  // the buffers it refers to are about to be replaced
-  FB_TRY(build_fem_plan(h->plan, n_nodes, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits));
+  static const bool timing = getenv("FEMBRAIN_TIMING") != nullptr;  // development aid: where a (re)build spends its time
+  const auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (timing) fprintf(stderr, "[fembrain] build: %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  };
+  const bool want_device = !(getenv("FEMBRAIN_PLAN_DEVICE") && atoi(getenv("FEMBRAIN_PLAN_DEVICE")) == 0);
+  h->device_plan = want_device && n_ranks == 1;
+  h->host_pattern = !h->device_plan;
+  if (h->device_plan) {
+    const int rc = build_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed);
+    if (rc == FB_ENOMEM) {  // no room for the sort's temporaries: the host builder needs none on the device
+      (void)hipGetLastError();
+      h->device_plan = false;
+      h->host_pattern = true;
+    } else if (rc != FB_OK) {
+      return rc;
+    }
+    lap("device plan");
+  }
+  if (!h->device_plan) {
+    FB_TRY(build_fem_plan(h->plan, n_nodes, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits));
+    lap("host plan");
+  }
   // A flat element makes inverse4x4 (corotationalLinearFEM.cpp:529-572) divide by zero; the reference then carries
   // inf/NaN into the step silently.  Refuse it here instead (checked on this rank's elements, rest geometry).
   for (int e = 0; e < h->plan.n_tets; e++) {
     const double* p[4];
-    for (int k = 0; k < 4; k++) p[k] = xyz + 3 * (size_t)h->plan.local2global[h->plan.tets[4 * (size_t)e + k]];
+    for (int k = 0; k < 4; k++)
+      p[k] = xyz + 3 * (size_t)(h->device_plan ? tets[4 * (size_t)e + k] : h->plan.local2global[h->plan.tets[4 * (size_t)e + k]]);
     double a[3], b[3], c[3];
     for (int k = 0; k < 3; k++) { a[k] = p[1][k] - p[0][k]; b[k] = p[2][k] - p[0][k]; c[k] = p[3][k] - p[0][k]; }
     const double det = a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
     if (!(det != 0.0) || !std::isfinite(det))
       return fail(FB_EINVAL, "element %d has zero (or non-finite) rest volume", h->plan.tet_global.empty() ? e : h->plan.tet_global[e]);
   }
+  lap("volume check");
   FB_TRY(upload_plan(h, xyz));
+  lap("upload");
   FB_TRY(launch_rest(h));
   FB_HIP(hipStreamSynchronize(h->stream));
+  lap("rest state");
   return FB_OK;
 }
 
@@ -619,6 +696,7 @@ int download_owned(fb_fem_s* h, const DevBuf<double>& src, double* g) {
 
 // SELL device values -> 9 doubles per block in CSR (fb_fem_pattern) order (diagonal blocks: hi + lo)
 int download_blocks(fb_fem_s* h, double* out) {
+  FB_TRY(ensure_host_pattern(h));
   const FemPlan& P = h->plan;
   const size_t n = (size_t)P.n_slots * 9 * 64, nl = (size_t)P.n_slices * 9 * 64;
   std::vector<double> host(n), lo(nl);
@@ -880,12 +958,39 @@ int fb_fem_floor_collision(fb_fem_t h, double floor_y, double restitution, int* 
   return FB_OK;
 }
 
+int fb_fem_plan_on_device(fb_fem_t h) { return h && h->device_plan ? 1 : 0; }
+
+long long fb_fem_device_plan_get(fb_fem_t h, const char* name, int* out, long long capacity) {
+  CHECK_HANDLE(h);
+  if (!name) return fail(FB_EINVAL, "null name");
+  const FemPlan& P = h->plan;
+  const std::string n(name);
+  const void* src = nullptr;
+  long long cnt = 0;
+  if (n == "slice_off") { src = h->slice_off.p; cnt = P.n_slices + 1; }
+  else if (n == "colidx") { src = h->colidx.p; cnt = (long long)P.n_slots * kSliceRows; }
+  else if (n == "slot_coff") { src = h->slot_coff.p; cnt = P.n_slots; }
+  else if (n == "slot_ccnt") { src = h->slot_ccnt.p; cnt = P.n_slots; }
+  else if (n == "contrib") { src = h->contrib.p; cnt = (long long)P.n_crows * kSliceRows; }
+  else if (h->device_plan && n == "bptr") { src = h->d_bptr.p; cnt = P.n_owned + 1; }
+  else if (h->device_plan && n == "bcol") { src = h->d_bcol.p; cnt = P.n_blocks; }
+  else if (h->device_plan && n == "blk_slot") { src = h->d_blk_slot.p; cnt = P.n_blocks; }
+  else return fail(FB_EINVAL, "no device plan array '%s'", name);
+  if (out && capacity > 0 && cnt > 0) {
+    FB_HIP(hipMemcpyAsync(out, src, sizeof(int) * (size_t)std::min(cnt, capacity), hipMemcpyDeviceToHost, h->stream));
+    FB_HIP(hipStreamSynchronize(h->stream));
+  }
+  return cnt;
+}
+
 int fb_fem_num_nodes(fb_fem_t h) { return h ? h->plan.n_global : 0; }
 int fb_fem_num_tets(fb_fem_t h) { return h ? h->plan.n_tets : 0; }
 int fb_fem_num_blocks(fb_fem_t h) { return h ? h->plan.n_blocks : 0; }
 
 int fb_fem_pattern(fb_fem_t h, int* bptr, int* bcol) {
   if (!h || !bptr || !bcol) return fail(FB_EINVAL, "null argument");
+  FB_HIP(hipSetDevice(h->prm.device));
+  FB_TRY(ensure_host_pattern(h));
   const FemPlan& P = h->plan;
   memcpy(bptr, P.bptr.data(), sizeof(int) * (P.n_owned + 1));
   for (int p = 0; p < P.n_blocks; p++) bcol[p] = P.local2global[P.bcol[p]];
@@ -969,6 +1074,7 @@ int fb_fem_mass(fb_fem_t h, double* m_blocks) {
   if (!m_blocks) return fail(FB_EINVAL, "null output");
   std::vector<double> u((size_t)3 * h->plan.n_global, 0.0);
   FB_TRY(fb_fem_assemble(h, u.data(), nullptr, nullptr));
+  FB_TRY(ensure_host_pattern(h));
   const FemPlan& P = h->plan;
   std::vector<double> host((size_t)P.n_slots * 64);
   FB_TRY(h->mblk.download(host.data(), host.size(), h->stream));

@@ -1,0 +1,209 @@
+// Device-side builder of the unsharded FEM plan (the arrays of fem_plan.h that the per-step kernels read): block pattern,
+// SELL-64 layout and the per-(row, slot) element contribution lists, straight from the tet list in device memory.
+//
+// Deformable::syncForceModel (src/deformable/Deformable.cpp:127-220) rebuilds all of this after every cut; on the host
+// (fem_plan.cpp, 16 threads) that is 61-68 ms at 1M tets and was 90 % of a re-sync.  Here it is a handful of streaming
+// passes around one radix sort:
+//   1. every tet emits its 16 (row, col) vertex pairs, key = row << 32 | col, value = tet << 4 | i << 2 | j -- the
+//      contribution word of fem_plan.h -- and every node one marker pair (a, a) so that a node no element references
+//      still gets its diagonal block (fem_plan.cpp: "isolated node");
+//   2. a stable radix sort by key puts the pairs in pattern order: rows ascending, columns ascending inside a row, and
+//      inside one block the contributions in ascending (tet, i, j) order -- the order the reference's element loop
+//      accumulates them in (corotationalLinearFEM.cpp:230-469) -- with the marker last;
+//   3. run-length encoding of the keys gives the blocks (bptr / bcol) and their contribution counts; one wavefront per
+//      64-row slice then lays out SELL-64 (width = longest row, padding columns = the row itself), the slot table of the
+//      blocks and the per-slot list heights; two scans give the slot and list offsets; a last pass copies the sorted
+//      contribution words into the [slot][t][lane] table.
+// The result is bit for bit the host plan (tests/test_fem_gpu.py::test_device_plan_equals_host_plan).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+#include "fem_plan.h"
+#include "plan_device.h"
+
+namespace fb {
+namespace {
+
+constexpr int kB = 256;
+
+__global__ __launch_bounds__(kB) void k_plan_pairs(int n_tets, int n_nodes, const int4* __restrict__ tets, unsigned long long* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals) {
+  const long long i = (long long)blockIdx.x * kB + threadIdx.x;
+  const long long n_tp = 16LL * n_tets;
+  if (i < n_tp) {
+    const int e = (int)(i >> 4), ij = (int)(i & 15);
+    const int4 t = tets[e];
+    const int id[4] = {t.x, t.y, t.z, t.w};
+    keys[i] = ((unsigned long long)(unsigned int)id[ij >> 2] << 32) | (unsigned int)id[ij & 3];
+    vals[i] = ((uint32_t)e << 4) | (uint32_t)ij;
+  } else if (i < n_tp + n_nodes) {
+    const unsigned int a = (unsigned int)(i - n_tp);
+    keys[i] = ((unsigned long long)a << 32) | a;
+    vals[i] = kNoContrib;
+  }
+}
+
+// block p: row, column; bptr by binary search of the first block of every row
+__global__ __launch_bounds__(kB) void k_plan_rows(int n_nodes, int n_blocks, const unsigned long long* __restrict__ ukeys, int* __restrict__ bptr,
+                                                  int* __restrict__ bcol) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i < n_blocks) bcol[i] = (int)(unsigned int)(ukeys[i] & 0xffffffffULL);
+  if (i <= n_nodes) {
+    const unsigned long long want = (unsigned long long)(unsigned int)i << 32;
+    int lo = 0, hi = n_blocks;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (ukeys[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    bptr[i] = lo;
+  }
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// one wavefront per slice: width = longest row
+__global__ __launch_bounds__(kB) void k_plan_widths(int n_nodes, int n_slices, const int* __restrict__ bptr, int* __restrict__ width) {
+  const int s = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (s >= n_slices) return;
+  const int a = s * 64 + lane;
+  const int len = a < n_nodes ? bptr[a + 1] - bptr[a] : 0;
+  const int w = wave_max(len);
+  if (lane == 0) width[s] = w;
+}
+
+// one wavefront per slice: column ids, the slot of every block, and the height of every slot's contribution list
+__global__ __launch_bounds__(kB) void k_plan_sell(int n_nodes, int n_slices, const int* __restrict__ bptr, const int* __restrict__ bcol,
+                                                  const unsigned int* __restrict__ ucnt, const int* __restrict__ slice_off, int* __restrict__ colidx,
+                                                  int* __restrict__ blk_slot, int* __restrict__ slot_ccnt) {
+  const int s = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (s >= n_slices) return;
+  const int a = s * 64 + lane;
+  const int so = slice_off[s], w = slice_off[s + 1] - so;
+  const int first = a < n_nodes ? bptr[a] : 0, len = a < n_nodes ? bptr[a + 1] - first : 0;
+  for (int k = 0; k < w; k++) {
+    int c = 0;
+    if (k < len) {
+      colidx[((size_t)so + k) * 64 + lane] = bcol[first + k];
+      blk_slot[first + k] = so + k;
+      c = (int)ucnt[first + k] - (bcol[first + k] == a ? 1 : 0);  // the diagonal block's run ends with the marker pair
+    } else {
+      colidx[((size_t)so + k) * 64 + lane] = a < n_nodes ? a : 0;  // padding: any valid column, its values stay zero
+    }
+    const int m = wave_max(c);
+    if (lane == 0) slot_ccnt[so + k] = m;
+  }
+}
+
+// one wavefront per slice: the sorted contribution words of every block go to contrib[slot_coff[slot] + t][lane]
+__global__ __launch_bounds__(kB) void k_plan_contrib(int n_nodes, int n_slices, const int* __restrict__ bptr, const int* __restrict__ bcol,
+                                                     const unsigned int* __restrict__ ucnt,
+                                                     const unsigned int* __restrict__ cstart, const uint32_t* __restrict__ vals,
+                                                     const int* __restrict__ slice_off, const int* __restrict__ slot_coff,
+                                                     const int* __restrict__ slot_ccnt, uint32_t* __restrict__ contrib) {
+  const int s = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (s >= n_slices) return;
+  const int a = s * 64 + lane;
+  const int so = slice_off[s], w = slice_off[s + 1] - so;
+  const int first = a < n_nodes ? bptr[a] : 0, len = a < n_nodes ? bptr[a + 1] - first : 0;
+  for (int k = 0; k < w; k++) {
+    const int height = slot_ccnt[so + k];  // wave-uniform
+    const int cnt = k < len ? (int)ucnt[first + k] - (bcol[first + k] == a ? 1 : 0) : 0;
+    const unsigned int from = k < len ? cstart[first + k] : 0u;
+    uint32_t* out = contrib + (size_t)slot_coff[so + k] * 64 + lane;
+    for (int t = 0; t < height; t++) out[(size_t)t * 64] = t < cnt ? vals[from + t] : kNoContrib;
+  }
+}
+
+}  // namespace
+
+int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& D) {
+  const long long n_pairs = 16LL * n_tets + n_nodes;
+  if (n_pairs >= (1LL << 31)) return fail(FB_EINVAL, "mesh too large for the device plan builder (%lld pairs)", n_pairs);
+  DevBuf<unsigned long long> keys, keys_s, ukeys;
+  DevBuf<uint32_t> vals, vals_s;
+  DevBuf<unsigned int> ucnt, cstart, nruns;
+  DevBuf<int> width;
+  DevBuf<char> temp;
+  FB_TRY(keys.alloc((size_t)n_pairs));
+  FB_TRY(keys_s.alloc((size_t)n_pairs));
+  FB_TRY(vals.alloc((size_t)n_pairs));
+  FB_TRY(vals_s.alloc((size_t)n_pairs));
+  hipLaunchKernelGGL(k_plan_pairs, dim3((unsigned)((n_pairs + kB - 1) / kB)), dim3(kB), 0, s, n_tets, n_nodes, d_tets, keys.p, vals.p);
+  FB_HIP(hipGetLastError());
+  int row_bits = 1;
+  while ((1LL << row_bits) < n_nodes) row_bits++;
+  size_t bytes = 0;
+  FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, (unsigned)(32 + row_bits), s));
+  FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));
+  FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, (unsigned)(32 + row_bits), s));
+  // blocks = runs of equal keys
+  FB_TRY(ukeys.alloc((size_t)n_pairs));
+  FB_TRY(ucnt.alloc((size_t)n_pairs));
+  FB_TRY(nruns.alloc(1));
+  bytes = 0;
+  FB_HIP(rocprim::run_length_encode(nullptr, bytes, keys_s.p, (unsigned int)n_pairs, ukeys.p, ucnt.p, nruns.p, s));
+  FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));
+  FB_HIP(rocprim::run_length_encode(temp.p, bytes, keys_s.p, (unsigned int)n_pairs, ukeys.p, ucnt.p, nruns.p, s));
+  unsigned int nb = 0;
+  FB_TRY(nruns.download(&nb, 1, s));
+  D.n_blocks = (int)nb;
+  FB_TRY(cstart.alloc((size_t)nb));
+  bytes = 0;
+  FB_HIP(rocprim::exclusive_scan(nullptr, bytes, ucnt.p, cstart.p, 0u, (size_t)nb, rocprim::plus<unsigned int>(), s));
+  FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));
+  FB_HIP(rocprim::exclusive_scan(temp.p, bytes, ucnt.p, cstart.p, 0u, (size_t)nb, rocprim::plus<unsigned int>(), s));
+  FB_TRY(D.bptr->alloc((size_t)n_nodes + 1));
+  FB_TRY(D.bcol->alloc((size_t)nb));
+  FB_TRY(D.blk_slot->alloc((size_t)nb));
+  hipLaunchKernelGGL(k_plan_rows, dim3((unsigned)((std::max<long long>(nb, n_nodes + 1) + kB - 1) / kB)), dim3(kB), 0, s, n_nodes, (int)nb, ukeys.p, D.bptr->p,
+                     D.bcol->p);
+  FB_HIP(hipGetLastError());
+  // SELL-64
+  const int n_slices = (n_nodes + kSliceRows - 1) / kSliceRows;
+  D.n_slices = n_slices;
+  const dim3 sg((unsigned)((n_slices + kB / 64 - 1) / (kB / 64)));
+  FB_TRY(width.alloc((size_t)n_slices + 1));
+  FB_TRY(width.zero(s));
+  hipLaunchKernelGGL(k_plan_widths, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, width.p);
+  FB_HIP(hipGetLastError());
+  FB_TRY(D.slice_off->alloc((size_t)n_slices + 1));
+  bytes = 0;
+  FB_HIP(rocprim::exclusive_scan(nullptr, bytes, width.p, D.slice_off->p, 0, (size_t)n_slices + 1, rocprim::plus<int>(), s));
+  FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));
+  FB_HIP(rocprim::exclusive_scan(temp.p, bytes, width.p, D.slice_off->p, 0, (size_t)n_slices + 1, rocprim::plus<int>(), s));
+  D.slice_off_host.resize((size_t)n_slices + 1);
+  FB_TRY(D.slice_off->download(D.slice_off_host.data(), (size_t)n_slices + 1, s));
+  D.n_slots = D.slice_off_host[n_slices];
+  FB_TRY(D.colidx->alloc((size_t)D.n_slots * kSliceRows));
+  FB_TRY(D.slot_ccnt->alloc((size_t)D.n_slots + 1));
+  FB_TRY(D.slot_ccnt->zero(s));
+  FB_TRY(D.slot_coff->alloc((size_t)D.n_slots + 1));
+  hipLaunchKernelGGL(k_plan_sell, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, D.slice_off->p, D.colidx->p, D.blk_slot->p,
+                     D.slot_ccnt->p);
+  FB_HIP(hipGetLastError());
+  bytes = 0;
+  FB_HIP(rocprim::exclusive_scan(nullptr, bytes, D.slot_ccnt->p, D.slot_coff->p, 0, (size_t)D.n_slots + 1, rocprim::plus<int>(), s));
+  FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));
+  FB_HIP(rocprim::exclusive_scan(temp.p, bytes, D.slot_ccnt->p, D.slot_coff->p, 0, (size_t)D.n_slots + 1, rocprim::plus<int>(), s));
+  int crows = 0;
+  FB_TRY(D.slot_coff->download(&crows, 1, s, (size_t)D.n_slots));
+  if ((long long)crows * kSliceRows >= (1LL << 31)) return fail(FB_EINVAL, "contribution table too large (%d rows)", crows);
+  D.n_crows = crows;
+  FB_TRY(D.contrib->alloc(std::max<size_t>(1, (size_t)crows * kSliceRows)));
+  hipLaunchKernelGGL(k_plan_contrib, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, cstart.p, vals_s.p, D.slice_off->p, D.slot_coff->p,
+                     D.slot_ccnt->p, D.contrib->p);
+  FB_HIP(hipGetLastError());
+  FB_HIP(hipStreamSynchronize(s));  // the temporaries go out of scope
+  return FB_OK;
+}
+
+}  // namespace fb

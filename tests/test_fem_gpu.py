@@ -648,3 +648,78 @@ def test_linear_elasticity_mode(gpu, prec, tol):
         qg = g.get_q_state()[0]
         assert abs(ig - io) <= 3 and abs(ig - g5["it"][k]) <= 3
         assert np.abs(qg - g5["q"][k]).max() <= (2e-5 if prec == fl.FB_MATRIX_F64 else 2e-4) * np.abs(g5["q"][k]).max()
+
+
+def _device_plan(g, name):
+    L = fl.lib()
+    n = L.fb_fem_device_plan_get(g.h, name.encode(), None, 0)
+    assert n >= 0, (name, L.fb_last_error())
+    a = np.zeros(n, np.int32)
+    assert L.fb_fem_device_plan_get(g.h, name.encode(), fl.iptr(a), n) == n
+    return a
+
+
+def _host_plan(v, t, fixed):
+    import ctypes as C
+    L = fl.lib()
+    h = C.c_void_p()
+    tt = np.ascontiguousarray(t, np.int32).reshape(-1)
+    fd = np.ascontiguousarray(fixed, np.int32)
+    fl.check(L.fb_plan_create(C.byref(h), len(v), len(t), fl.iptr(tt), len(fd), fl.iptr(fd), 1, 0, None))
+
+    def get(name):
+        cnt = L.fb_plan_get(h, name.encode(), None, 0)
+        a = np.zeros(cnt, np.int32)
+        assert L.fb_plan_get(h, name.encode(), fl.iptr(a), cnt) == cnt
+        return a
+    return get, (L, h)
+
+
+@pytest.mark.parametrize("mesh", ["cube7", "cube20", "delaunay", "isolated"])
+def test_device_plan_equals_host_plan(gpu, mesh):
+    """plan_device.hip (radix sort of the 16 vertex pairs of every tet, run-length encoding, SELL-64 layout, contribution
+    lists) against fem_plan.cpp, array by array, bit for bit"""
+    if mesh.startswith("cube"):
+        n = int(mesh[4:])
+        v, t, fixed = _cube(n)
+    else:
+        from scipy.spatial import Delaunay
+        rng = np.random.default_rng(3)
+        v = rng.uniform(0, 1, size=(3000, 3))
+        t = Delaunay(v).simplices.astype(np.int32)
+        vol = np.einsum("ij,ij->i", v[t[:, 1]] - v[t[:, 0]], np.cross(v[t[:, 2]] - v[t[:, 0]], v[t[:, 3]] - v[t[:, 0]])) / 6
+        t = np.ascontiguousarray(t[np.abs(vol) > 1e-9])
+        rng.shuffle(t)   # element order is part of the contribution lists
+        fixed = fixed_vertices_to_dofs(np.nonzero(v[:, 0] < 0.1)[0])
+        if mesh == "isolated":   # nodes no element references (identity rows), in the middle and at the end
+            v = np.concatenate([v[:1500], rng.uniform(2, 3, size=(70, 3)), v[1500:], rng.uniform(2, 3, size=(5, 3))])
+            t = np.where(t >= 1500, t + 70, t).astype(np.int32)
+            fixed = fixed_vertices_to_dofs(np.nonzero(v[:, 0] < 0.1)[0])
+    g = FemIntegrator(v, t, fixed)
+    assert fl.lib().fb_fem_plan_on_device(g.h) == 1
+    get, (L, hp) = _host_plan(v, t, fixed)
+    for name in ("bptr", "bcol", "blk_slot", "slice_off", "colidx", "slot_coff", "slot_ccnt", "contrib"):
+        assert np.array_equal(_device_plan(g, name), get(name)), name
+    bptr, bcol = g.pattern()   # fetched from the device on demand
+    assert np.array_equal(bptr, get("bptr")) and np.array_equal(bcol, get("bcol"))
+    L.fb_plan_destroy(hp)
+    # and a handle on the host plan gives the same step, bit for bit
+    f = np.zeros(g.r)
+    f[1::3] = -50.0
+    g.set_external_forces(f)
+    it = g.do_timestep()
+    os.environ["FEMBRAIN_PLAN_DEVICE"] = "0"
+    try:
+        g2 = FemIntegrator(v, t, fixed)
+    finally:
+        del os.environ["FEMBRAIN_PLAN_DEVICE"]
+    assert fl.lib().fb_fem_plan_on_device(g2.h) == 0
+    g2.set_external_forces(f)
+    assert g2.do_timestep() == it > 0
+    assert np.array_equal(g2.get_q_state()[0], g.get_q_state()[0])
+    # a re-sync (Deformable::syncForceModel) with fewer elements goes through the device builder again
+    g.resync(v, t[: len(t) // 2], fixed)
+    get, (L, hp) = _host_plan(v, t[: len(t) // 2], fixed)
+    for name in ("bptr", "bcol", "slice_off", "colidx", "contrib"):
+        assert np.array_equal(_device_plan(g, name), get(name)), name
+    L.fb_plan_destroy(hp)
