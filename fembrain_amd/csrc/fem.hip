@@ -109,10 +109,10 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
   const int per = std::max(1, std::min(kMaxPartials / 8, ceil_div(chunk, kWavesPerBlock)));
   h->grid = 8 * per;
   const int want = h->prm.spmv_kernel;
-  if (want == FB_SPMV_SPLIT && (8 * ceil_div(chunk, 2) > kMaxPartials || P.n_ranks > 1))
-    return fail(FB_EINVAL, "split SpMV needs an unsharded mesh of <= %d slices, this one has %d on %d ranks", 2 * kMaxPartials, P.n_slices, P.n_ranks);
+  if (want == FB_SPMV_SPLIT && 8 * ceil_div(chunk, 2) > kMaxPartials)
+    return fail(FB_EINVAL, "split SpMV needs a mesh (or shard) of <= %d slices, this one has %d", 2 * kMaxPartials, P.n_slices);
   h->split = 0;
-  if (want == FB_SPMV_SPLIT || (want == 0 && P.n_ranks == 1)) {
+  if (want == FB_SPMV_SPLIT || want == 0) {
     if (8 * chunk <= kMaxPartials) h->split = 4;
     else if (8 * ceil_div(chunk, 2) <= kMaxPartials) h->split = 2;
   }
@@ -215,13 +215,13 @@ template <typename MT, int MODE>
 int launch_spmv(fb_fem_s* h, const double* x, double* y, const double* b, double* partial, int parity) {
   if (h->split == 4) {
     hipLaunchKernelGGL((k_spmv_split<MT, MODE, 4>), dim3(h->sgrid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
-                       b, h->invdiag.p, partial, h->st.p, parity);
+                       b, h->invdiag.p, partial, h->st.p, parity, P2PArgs());
     FB_HIP(hipGetLastError());
     return FB_OK;
   }
   if (h->split == 2) {
     hipLaunchKernelGGL((k_spmv_split<MT, MODE, 2>), dim3(h->sgrid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
-                       b, h->invdiag.p, partial, h->st.p, parity);
+                       b, h->invdiag.p, partial, h->st.p, parity, P2PArgs());
     FB_HIP(hipGetLastError());
     return FB_OK;
   }
@@ -239,6 +239,18 @@ int launch_spmv(fb_fem_s* h, const double* x, double* y, const double* b, double
 // XCH = 2 also gathers the halo columns from the inbox (sent by the neighbours' previous vector pass)
 template <typename MT, int XCH>
 int launch_spmv_xch(fb_fem_s* h, const double* x, double* y, const double* b, double* partial, int parity, const P2PArgs& pa) {
+  if (h->split == 4) {
+    hipLaunchKernelGGL((k_spmv_split<MT, 3, 4, XCH>), dim3(h->sgrid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x,
+                       y, b, h->invdiag.p, partial, h->st.p, parity, pa);
+    FB_HIP(hipGetLastError());
+    return FB_OK;
+  }
+  if (h->split == 2) {
+    hipLaunchKernelGGL((k_spmv_split<MT, 3, 2, XCH>), dim3(h->sgrid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x,
+                       y, b, h->invdiag.p, partial, h->st.p, parity, pa);
+    FB_HIP(hipGetLastError());
+    return FB_OK;
+  }
   if (h->spmv_nt)
     hipLaunchKernelGGL((k_spmv<MT, 3, XCH, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
                        b, h->invdiag.p, partial, h->st.p, parity, pa);
@@ -265,15 +277,18 @@ __global__ __launch_bounds__(kBlock) void k_fold_partials(const double* partial,
   }
 }
 
-int global_scalar(fb_fem_s* h, const double* partial, double** out, bool check_done, int count = 1, int slot = 0) {
+// n = number of per-block partials per sum: h->grid for the vector kernels, h->sgrid for the SpMV launches (they differ when
+// the split SpMV runs)
+int global_scalar(fb_fem_s* h, const double* partial, double** out, bool check_done, int count = 1, int slot = 0, int n = -1) {
   *out = nullptr;
   if (!h->comm || (!h->comm->nccl && !h->comm->local)) return FB_OK;
+  if (n < 0) n = h->grid;
   if (h->xch_mode >= FB_XCH_P2P) {  // fold + exchange + rank-ordered sum in one single-block kernel
-    FB_TRY(p2p_reduce(h->p2p, partial, h->grid, count, h->scal.p + slot, h->stream));
+    FB_TRY(p2p_reduce(h->p2p, partial, n, count, h->scal.p + slot, h->stream));
     *out = h->scal.p;
     return FB_OK;
   }
-  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(kBlock), 0, h->stream, partial, h->grid, count, h->scal.p + slot, check_done ? h->st.p : nullptr);
+  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(kBlock), 0, h->stream, partial, n, count, h->scal.p + slot, check_done ? h->st.p : nullptr);
   FB_HIP(hipGetLastError());
   // a converged solve leaves the previous (identical on every rank) values in place; the all-reduce still runs on
   // every rank so the collective sequence stays matched, and its result is ignored by the done-checking consumers
@@ -310,14 +325,14 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b) {
   if (!refresh && h->prm.pcg_variant == FB_PCG_MERGED) {
     // merged-reduction iteration: SpMV with the three sums, then one fused vector pass (one reduction / all-reduce)
     FB_TRY(spmv<3>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity));
-    FB_TRY(global_scalar(h, h->part_a.p, &sc, true, 3));
+    FB_TRY(global_scalar(h, h->part_a.p, &sc, true, 3, 0, h->sgrid));
     hipLaunchKernelGGL((k_cg_fused<false>), dim3(h->vgrid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->sgrid,
                        sc, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->d.p, P2PArgs());
     FB_HIP(hipGetLastError());
     return FB_OK;
   }
   FB_TRY(spmv<1>(h, h->d.p, h->Ad.p, nullptr, h->part_a.p, parity));
-  FB_TRY(global_scalar(h, h->part_a.p, &sc, true));
+  FB_TRY(global_scalar(h, h->part_a.p, &sc, true, 1, 0, h->sgrid));
   if (!refresh) {
     hipLaunchKernelGGL(k_cg_update<false>, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity,
                        h->part_a.p, h->sgrid, sc, h->d.p, h->Ad.p, h->invdiag.p, h->x.p, h->r.p, h->part_b.p);
@@ -329,7 +344,7 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b) {
     FB_TRY(halo_exchange(h, h->x.p));
     FB_TRY(spmv<2>(h, h->x.p, h->r.p, b, h->part_b.p, parity));
   }
-  FB_TRY(global_scalar(h, h->part_b.p, &sc, true));
+  FB_TRY(global_scalar(h, h->part_b.p, &sc, true, 1, 0, refresh ? h->sgrid : h->grid));
   // part_b comes from the exact-residual SpMV on refresh iterations, from the vector kernel otherwise
   hipLaunchKernelGGL(k_cg_direction, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_b.p,
                      refresh ? h->sgrid : h->grid, sc, h->r.p, h->invdiag.p, h->d.p);
@@ -478,7 +493,7 @@ int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int*
         FB_TRY(halo_exchange(h, h->x.p));
         FB_TRY(spmv<2>(h, h->x.p, h->r.p, b, h->part_b.p, 0));
         double* sc2 = nullptr;
-        FB_TRY(global_scalar(h, h->part_b.p, &sc2, true, 1, 3));
+        FB_TRY(global_scalar(h, h->part_b.p, &sc2, true, 1, 3, h->sgrid));
         hipLaunchKernelGGL(k_rec_refresh, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->rec_s[cur].p, h->rec_s[cur ^ 1].p, h->r.p,
                            h->part_b.p, h->sgrid, sc2, h->st.p, k);
         FB_HIP(hipGetLastError());

@@ -464,11 +464,14 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
 // the row kernel above is bound by the latency of one wavefront walking all ~15 slots of its slice (6.8 us at 105k tets
 // for 13 MB); dealing the slots to several wavefronts shortens that chain.  The partial row sums are added in wave order
 // through LDS (deterministic; rounding differs from the row kernel in the last bit).
-template <typename MT, int MODE, int SPLIT>
+// XCH = 2 (sharded handles, FB_XCH_P2P_FUSED): as in k_spmv the halo refresh rides in the prologue -- the sender jobs are dealt
+// to the first blocks, a block whose slice has a halo column waits for the neighbours' chunks and gathers those columns
+// from the inbox; blocks of interior slices never wait.
+template <typename MT, int MODE, int SPLIT, int XCH = 0>
 __global__ __launch_bounds__(kBlock) void k_spmv_split(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo,
                                                        const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ bvec,
                                                        const double* __restrict__ invdiag, double* __restrict__ partial,
-                                                       CGState* __restrict__ st, int parity) {
+                                                       CGState* __restrict__ st, int parity, P2PArgs pa) {
   constexpr int kPerBlock = kWavesPerBlock / SPLIT;  // slices per block
   __shared__ double ylds[kWavesPerBlock][3][64];
   __shared__ double red[3][kWavesPerBlock];
@@ -486,6 +489,19 @@ __global__ __launch_bounds__(kBlock) void k_spmv_split(SellView sv, const MT* __
   const int s = xcd * chunk + j;
   const bool live = j < chunk && s < sv.n_slices;  // wave-uniform
   double y0 = 0, y1 = 0, y2 = 0;
+  const double* halo_in = nullptr;
+  if (XCH == 2) {
+    p2p_send_halo_jobs(pa.dev, pa.halo_seq, 3, pa.send_ids, pa.send_off, x);
+    bool mine = false;  // block-uniform: does any slice of this block touch the halo?
+    for (int k = 0; k < kPerBlock; k++) {
+      const int jj = (int)(blockIdx.x >> 3) * kPerBlock + k, ss = xcd * chunk + jj;
+      if (jj < chunk && ss < sv.n_slices) mine = mine || pa.slice_halo[ss];
+    }
+    if (mine) {
+      p2p_wait_halo(pa.dev, pa.halo_seq, pa.halo_off, 3);
+      halo_in = p2p_halo_in(pa.dev, pa.halo_seq) - 3 * (size_t)sv.n_owned;
+    }
+  }
   if (live) {
     const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
     const MT* v = vals + (size_t)so * 9 * 64 + lane;
@@ -493,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_split(SellView sv, const MT* __
 #pragma unroll 4
     for (int k = sub; k < width; k += SPLIT) {
       const int col = ci[(size_t)k * 64];
-      const double* xp = x + 3 * (size_t)col;
+      const double* xp = ((XCH == 2 && col >= sv.n_owned) ? halo_in : x) + 3 * (size_t)col;
       const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
       const MT* vk = v + (size_t)k * 9 * 64;
       y0 += (double)vk[0 * 64] * x0 + (double)vk[1 * 64] * x1 + (double)vk[2 * 64] * x2;

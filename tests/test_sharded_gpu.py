@@ -31,7 +31,7 @@ def _mesh(n, world):
     return v, t, fixed, np.array([(-n) * r // world for r in range(world + 1)], np.int32)
 
 
-def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False):
+def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False, spmv=0):
     """p2p: 0 = host-staged test communicator, else the peer-to-peer exchange mode (lib.FB_XCH_P2P / _SUMS / _FUSED)."""
     try:
         if p2p:
@@ -45,7 +45,7 @@ def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False
         comm = C.c_void_p()
         fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
         v, t, fixed, splits = _mesh(n, world)
-        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), pcg_variant=variant)
+        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), pcg_variant=variant, spmv_kernel=spmv)
         assert L.fb_fem_transport(g.h) == (p2p if p2p else 1), L.fb_fem_transport(g.h)
         if quit_early and rank == world - 1:   # a rank that stops taking part: the others must time out, not hang
             q.put((rank, "left", None, None, 0, 0))
@@ -77,13 +77,20 @@ def test_sharded_ranks_on_one_gpu_match_the_unsharded_handle(gpu, world, variant
     _run_sharded(world, variant, p2p, 12)
 
 
+@pytest.mark.parametrize("world,variant,p2p", [(2, 0, 0), (3, 0, 2), (2, 0, 3), (3, 0, 4), (2, 1, 4)])
+def test_sharded_ranks_with_the_row_kernel(gpu, world, variant, p2p):
+    """small shards take the split SpMV by themselves (the tests above); the row kernel of large shards is forced here"""
+    from fembrain_amd import lib as fl
+    _run_sharded(world, variant, p2p, 12, spmv=fl.FB_SPMV_ROWS)
+
+
 @pytest.mark.parametrize("world,p2p", [(2, 0), (3, 2), (3, 4), (4, 4)])
 def test_sharded_unstructured_mesh_all_to_all_halos(gpu, world, p2p):
     """Delaunay mesh in random node order cut into equal index ranges: every rank is every other rank's neighbour."""
     _run_sharded(world, 0, p2p, -900)
 
 
-def _run_sharded(world, variant, p2p, n):
+def _run_sharded(world, variant, p2p, n, spmv=0):
     """p2p != 0: the direct inbox transport (HIP IPC mapped inboxes, kernels that store into the peer's inbox and spin --
     bounded -- on their own flags) between processes that share the GPU, in its three forms: an own kernel per exchange
     (2), sums inside the PCG kernels (3), sums and halo values inside the PCG kernels (4)."""
@@ -93,7 +100,7 @@ def _run_sharded(world, variant, p2p, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     name = "/fembrain_test_%d_%d_%d_%d" % (os.getpid(), world, variant, int(p2p))
-    procs = [ctx.Process(target=_worker, args=(r, world, name, n, variant, steps, q, p2p)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, name, n, variant, steps, q, p2p, False, spmv)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
