@@ -142,9 +142,9 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
   return FB_OK;
 }
 
-int launch_rest(fb_fem_s* h) {
+int launch_rest(fb_fem_s* h, int* first_flat = nullptr) {
   const int nt = h->plan.n_tets;
-  hipLaunchKernelGGL(k_tet_rest, dim3(ceil_div(nt, kBlock)), dim3(kBlock), 0, h->stream, nt, h->tets.p, h->x0.p, h->rest.p);
+  hipLaunchKernelGGL(k_tet_rest, dim3(ceil_div(nt, kBlock)), dim3(kBlock), 0, h->stream, nt, h->tets.p, h->x0.p, h->rest.p, first_flat);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -604,8 +604,9 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
     lap("host plan");
   }
   // A flat element makes inverse4x4 (corotationalLinearFEM.cpp:529-572) divide by zero; the reference then carries
-  // inf/NaN into the step silently.  Refuse it here instead (checked on this rank's elements, rest geometry).
-  for (int e = 0; e < h->plan.n_tets; e++) {
+  // inf/NaN into the step silently.  Refuse it here instead (checked on this rank's elements, rest geometry; a handle
+  // whose plan was built on the device lets the rest-state kernel look, below).
+  for (int e = 0; e < (h->device_plan ? 0 : h->plan.n_tets); e++) {
     const double* p[4];
     for (int k = 0; k < 4; k++)
       p[k] = xyz + 3 * (size_t)(h->device_plan ? tets[4 * (size_t)e + k] : h->plan.local2global[h->plan.tets[4 * (size_t)e + k]]);
@@ -618,8 +619,18 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
   lap("volume check");
   FB_TRY(upload_plan(h, xyz));
   lap("upload");
-  FB_TRY(launch_rest(h));
-  FB_HIP(hipStreamSynchronize(h->stream));
+  if (h->device_plan) {
+    DevBuf<int> flat;
+    const int none = 0x7fffffff;
+    FB_TRY(flat.upload(&none, 1, h->stream));
+    FB_TRY(launch_rest(h, flat.p));
+    int first = none;
+    FB_TRY(flat.download(&first, 1, h->stream));
+    if (first != none) return fail(FB_EINVAL, "element %d has zero (or non-finite) rest volume", first);
+  } else {
+    FB_TRY(launch_rest(h));
+    FB_HIP(hipStreamSynchronize(h->stream));
+  }
   lap("rest state");
   return FB_OK;
 }

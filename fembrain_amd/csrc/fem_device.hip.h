@@ -18,8 +18,10 @@ __device__ inline void inv3x3(const double* A, double* I) {
   I[6] = c02 * id; I[7] = (A[1] * A[6] - A[0] * A[7]) * id; I[8] = (A[0] * A[4] - A[1] * A[3]) * id;
 }
 
+// first_flat (may be null): receives the lowest index of an element whose rest volume is zero or not finite -- the check
+// build() otherwise makes on the host, same expression
 __global__ __launch_bounds__(kBlock) void k_tet_rest(int nt, const int4* __restrict__ tets, const double* __restrict__ x0,
-                                                     double* __restrict__ rest) {
+                                                     double* __restrict__ rest, int* __restrict__ first_flat) {
   const int e = blockIdx.x * kBlock + threadIdx.x;
   if (e >= nt) return;
   const int4 t = tets[e];
@@ -29,6 +31,12 @@ __global__ __launch_bounds__(kBlock) void k_tet_rest(int nt, const int4* __restr
   for (int k = 0; k < 4; k++)
 #pragma unroll
     for (int d = 0; d < 3; d++) p[k][d] = x0[3 * (size_t)id[k] + d];
+  if (first_flat) {
+    double a[3], b[3], c[3];
+    for (int k = 0; k < 3; k++) { a[k] = p[1][k] - p[0][k]; b[k] = p[2][k] - p[0][k]; c[k] = p[3][k] - p[0][k]; }
+    const double det = a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+    if (!(det != 0.0) || !isfinite(det)) atomicMin(first_flat, e);
+  }
   double Dm[9], Di[9];
 #pragma unroll
   for (int d = 0; d < 3; d++) {
