@@ -76,4 +76,9 @@ struct DevBuf {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// the tet mesh a polygonizer handle holds on its device after fb_poly_tetrahedralize (poly.hip -> fem.hip hand-off):
+// positions 3 floats per vertex, elements 4 vertex ids per tet; the handle's stream has been synchronised
+struct DeviceTetMesh { int device, n_vertices, n_tets; const float* xyz; const uint4* tets; };
+int poly_device_tetmesh(fb_poly_t h, DeviceTetMesh* out);
+
 }  // namespace fb

@@ -70,7 +70,12 @@ SellView sell_view(const fb_fem_s* h) {
   return sv;
 }
 
-int upload_plan(fb_fem_s* h, const double* xyz_global) {
+__global__ __launch_bounds__(kBlock) void k_widen_positions(long long n, const float* __restrict__ in, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = (double)in[i];
+}
+
+int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device = nullptr) {
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
   if (!h->device_plan) {  // (the device builder has put the tets and the plan arrays in place already)
@@ -83,10 +88,17 @@ int upload_plan(fb_fem_s* h, const double* xyz_global) {
     FB_TRY(h->slot_ccnt.upload(P.slot_ccnt, s));
     FB_TRY(h->contrib.upload(P.contrib.data(), P.contrib.size(), s));
   }
-  std::vector<double> x0((size_t)3 * P.n_local);
-  for (int l = 0; l < P.n_local; l++)
-    for (int k = 0; k < 3; k++) x0[3 * (size_t)l + k] = xyz_global[3 * (size_t)P.local2global[l] + k];
-  FB_TRY(h->x0.upload(x0, s));
+  if (xyz_device) {  // mesh handed over on the device (fb_fem_create_from_poly): float positions widened in place
+    const long long n3 = 3LL * P.n_local;
+    FB_TRY(h->x0.alloc((size_t)n3));
+    hipLaunchKernelGGL(k_widen_positions, dim3((unsigned)((n3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n3, xyz_device, h->x0.p);
+    FB_HIP(hipGetLastError());
+  } else {
+    std::vector<double> x0((size_t)3 * P.n_local);
+    for (int l = 0; l < P.n_local; l++)
+      for (int k = 0; k < 3; k++) x0[3 * (size_t)l + k] = xyz_global[3 * (size_t)P.local2global[l] + k];
+    FB_TRY(h->x0.upload(x0, s));
+  }
   FB_TRY(h->rest.alloc((size_t)16 * P.n_tets));
   FB_TRY(h->fe.alloc((size_t)12 * P.n_tets));
   FB_TRY(h->rec.alloc((size_t)16 * P.n_tets * mt_size(h)));
@@ -536,10 +548,11 @@ int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int*
 // The plan of an unsharded handle, built on the device (plan_device.hip).  The host keeps the scalars, the slice offsets,
 // the identity numbering and the constraint mask; the pattern arrays stay on the device until an inspection entry point
 // asks for them (ensure_host_pattern).
-int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed) {
-  if (n_nodes <= 0 || n_tets <= 0 || !tets) return fail(FB_EINVAL, "empty mesh (%d nodes, %d tets)", n_nodes, n_tets);
+// tets: host node ids, or -- d_tets non-null -- ids already on this device (the polygonizer's own output: in range by construction)
+int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed, const uint4* d_tets = nullptr) {
+  if (n_nodes <= 0 || n_tets <= 0 || (!tets && !d_tets)) return fail(FB_EINVAL, "empty mesh (%d nodes, %d tets)", n_nodes, n_tets);
   if ((long long)n_tets >= (1LL << 28)) return fail(FB_EINVAL, "too many tets for the packed contribution word");
-  for (long long k = 0; k < 4LL * n_tets; k++)
+  for (long long k = 0; k < (d_tets ? 0 : 4LL * n_tets); k++)
     if (tets[k] < 0 || tets[k] >= n_nodes) return fail(FB_EINVAL, "tet %lld references node %d outside [0,%d)", k / 4, tets[k], n_nodes);
   FemPlan& P = h->plan;
   P = FemPlan();
@@ -553,7 +566,12 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   P.send_off.assign(2, 0);
   P.n_tets = n_tets;
   FB_TRY(plan_set_constraints(P, n_fixed, fixed));
-  FB_TRY(h->tets.upload((const int4*)tets, (size_t)n_tets, h->stream));
+  if (d_tets) {
+    FB_TRY(h->tets.alloc((size_t)n_tets));
+    FB_HIP(hipMemcpyAsync(h->tets.p, d_tets, sizeof(int4) * (size_t)n_tets, hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    FB_TRY(h->tets.upload((const int4*)tets, (size_t)n_tets, h->stream));
+  }
   DevicePlan D;
   D.slice_off = &h->slice_off; D.colidx = &h->colidx; D.slot_coff = &h->slot_coff; D.slot_ccnt = &h->slot_ccnt; D.contrib = &h->contrib;
   D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot;
@@ -578,7 +596,7 @@ int ensure_host_pattern(fb_fem_s* h) {
 }
 
 int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed, const int* fixed, int n_ranks,
-          int rank, const int* splits) {
+          int rank, const int* splits, const DeviceTetMesh* dm = nullptr) {
   drop_graph(h);  // the buffers it refers to are about to be replaced
   static const bool timing = getenv("FEMBRAIN_TIMING") != nullptr;  // development aid: where a (re)build spends its time
   const auto t0 = std::chrono::steady_clock::now();
@@ -586,10 +604,11 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
     if (timing) fprintf(stderr, "[fembrain] build: %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   };
   const bool want_device = !(getenv("FEMBRAIN_PLAN_DEVICE") && atoi(getenv("FEMBRAIN_PLAN_DEVICE")) == 0);
-  h->device_plan = want_device && n_ranks == 1;
+  h->device_plan = (want_device || dm) && n_ranks == 1;
   h->host_pattern = !h->device_plan;
   if (h->device_plan) {
-    const int rc = build_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed);
+    const int rc = build_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, dm ? dm->tets : nullptr);
+    if (dm && rc != FB_OK) return rc;
     if (rc == FB_ENOMEM) {  // no room for the sort's temporaries: the host builder needs none on the device
       (void)hipGetLastError();
       h->device_plan = false;
@@ -617,7 +636,7 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
       return fail(FB_EINVAL, "element %d has zero (or non-finite) rest volume", h->plan.tet_global.empty() ? e : h->plan.tet_global[e]);
   }
   lap("volume check");
-  FB_TRY(upload_plan(h, xyz));
+  FB_TRY(upload_plan(h, xyz, dm ? dm->xyz : nullptr));
   lap("upload");
   if (h->device_plan) {
     DevBuf<int> flat;
@@ -656,8 +675,9 @@ int attach_p2p(fb_fem_s* h) {
 }
 
 int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed, const int* fixed,
-                  const fb_fem_params* params, int n_ranks, int rank, const int* splits, fb_comm_t comm) {
-  if (!out || !xyz || !tets || !params) return fail(FB_EINVAL, "null argument");
+                  const fb_fem_params* params, int n_ranks, int rank, const int* splits, fb_comm_t comm, const DeviceTetMesh* dm = nullptr) {
+  if (!out || (!dm && (!xyz || !tets)) || !params) return fail(FB_EINVAL, "null argument");
+  if (dm && dm->device != params->device) return fail(FB_EINVAL, "the polygonizer lives on device %d, the FEM handle is asked for device %d", dm->device, params->device);
   if (n_fixed < 0 || (n_fixed > 0 && !fixed)) return fail(FB_EINVAL, "bad constrained DOF list");
   if (!(params->timestep > 0) || !(params->E > 0) || !(params->rho > 0) || !(params->nu > -1.0 && params->nu < 0.5))
     return fail(FB_EINVAL, "bad material / timestep parameters");
@@ -681,7 +701,7 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
     if (rc != FB_OK) break;
     if (hipHostMalloc((void**)&h->st_host, 2 * sizeof(CGState), hipHostMallocDefault) != hipSuccess) { rc = fail(FB_ENOMEM, "hipHostMalloc failed"); break; }
     if (const char* e = getenv("FEMBRAIN_GRAPH")) h->use_graph = atoi(e) != 0;
-    rc = build(h, n_nodes, xyz, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits);
+    rc = build(h, n_nodes, xyz, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits, dm);
     if (rc == FB_OK && comm && comm->n_ranks > 1) rc = attach_p2p(h);
   } while (0);
   if (rc != FB_OK) {
@@ -781,6 +801,13 @@ void fb_fem_default_params(fb_fem_params* p) {
 int fb_fem_create(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed_dofs,
                   const int* fixed_dofs, const fb_fem_params* params) {
   return create_common(out, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs, params, 1, 0, nullptr, nullptr);
+}
+
+int fb_fem_create_from_poly(fb_fem_t* out, fb_poly_t poly, int n_fixed_dofs, const int* fixed_dofs, const fb_fem_params* params) {
+  DeviceTetMesh dm;
+  FB_TRY(poly_device_tetmesh(poly, &dm));
+  if (dm.n_tets < 1) return fail(FB_EINVAL, "the polygonizer holds no tets");
+  return create_common(out, dm.n_vertices, nullptr, dm.n_tets, nullptr, n_fixed_dofs, fixed_dofs, params, 1, 0, nullptr, nullptr, &dm);
 }
 
 int fb_fem_create_sharded(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed_dofs,

@@ -1725,6 +1725,19 @@ int fb_poly_tetrahedralize(fb_poly_t h, fb_poly_counts* counts) {
   return FB_OK;
 }
 
+extern "C++" {
+namespace fb {
+int poly_device_tetmesh(fb_poly_t h, DeviceTetMesh* out) {
+  CHECK_POLY(h);
+  if (!h->tetra) return fail(FB_EINVAL, "tetrahedralize first");
+  FB_HIP(hipStreamSynchronize(h->stream));
+  out->device = h->device; out->n_vertices = h->counts.n_tet_vertices; out->n_tets = h->counts.n_tets;
+  out->xyz = h->tv.p; out->tets = h->tt.p;
+  return FB_OK;
+}
+}  // namespace fb
+}  // extern "C++"
+
 int fb_poly_read_tetmesh(fb_poly_t h, float* xyz, unsigned int* tets) {
   CHECK_POLY(h);
   if (!h->tetra) return fail(FB_EINVAL, "tetrahedralize first");

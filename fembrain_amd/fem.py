@@ -52,6 +52,33 @@ class FemIntegrator:
             self.node_lo, self.node_hi = int(sp[rank]), int(sp[rank + 1])
         self.last = _l.StepInfo()
 
+    @classmethod
+    def from_poly(cls, poly, fixed_dofs=(), E=1e7, nu=0.46, rho=1000.0, timestep=0.0333, damping_mass=0.0, damping_stiffness=0.01,
+                  cg_eps=1e-6, cg_max_iter=10000, matrix_precision=_l.FB_MATRIX_F32, device=0, linear=False):
+        """The tet mesh a GpuPoly holds on the device (after tetrahedralize) as the FEM mesh, without a host copy
+        (fb_fem_create_from_poly).  verts / tets are read back only for the Python-side conveniences."""
+        self = cls.__new__(cls)
+        L = _l.lib()
+        self._L = L
+        xyz, tets = poly.read_tetmesh()
+        self.verts = xyz.astype(np.float64)
+        self.tets = tets.astype(np.int32)
+        self.n_nodes, self.n_tets_global = len(self.verts), len(self.tets)
+        self.r = 3 * self.n_nodes
+        fd = _l.as_i32(fixed_dofs)
+        p = _l.FemParams()
+        L.fb_fem_default_params(C.byref(p))
+        p.E, p.nu, p.rho, p.timestep = E, nu, rho, timestep
+        p.damping_mass, p.damping_stiffness = damping_mass, damping_stiffness
+        p.cg_eps, p.cg_max_iter, p.matrix_precision, p.device = cg_eps, cg_max_iter, matrix_precision, device
+        p.linear = 1 if linear else 0
+        self.params = p
+        self.h = C.c_void_p()
+        self.node_lo, self.node_hi = 0, self.n_nodes
+        _l.check(L.fb_fem_create_from_poly(C.byref(self.h), poly.h, len(fd), _l.iptr(fd), C.byref(p)))
+        self.last = _l.StepInfo()
+        return self
+
     # -- life cycle --
     def time_element_stiffness(self, reps=5):
         """Seconds to form K0 = V B^T E B of every element with the fp64 MFMA kernel (inspection path)."""

@@ -46,6 +46,19 @@ class HipIntegrator {
     check(fb_fem_create(&h_, numVertices, restPositions, numElements, elements, numConstrainedDOFs, constrainedDOFs, &prm_));
     std::memset(&info_, 0, sizeof info_);
   }
+  // the tet mesh a polygonizer handle (GPUPoly::handle()) holds on the device becomes the FEM mesh, no host copy
+  // (fb_fem_create_from_poly; field grid -> tets -> K0 on the device)
+  HipIntegrator(fb_poly_t poly, int numConstrainedDOFs, const int* constrainedDOFs, double timestep = 0.0333, double dampingMassCoef = 0.0,
+                double dampingStiffnessCoef = 0.01, double E = 1e7, double nu = 0.46, double density = 1000.0, int device = 0)
+      : r_(0), h_(nullptr) {
+    fb_fem_default_params(&prm_);
+    prm_.E = E; prm_.nu = nu; prm_.rho = density;
+    prm_.timestep = timestep; prm_.damping_mass = dampingMassCoef; prm_.damping_stiffness = dampingStiffnessCoef;
+    prm_.device = device;
+    check(fb_fem_create_from_poly(&h_, poly, numConstrainedDOFs, constrainedDOFs, &prm_));
+    r_ = 3 * fb_fem_num_nodes(h_);
+    std::memset(&info_, 0, sizeof info_);
+  }
   ~HipIntegrator() { fb_fem_destroy(h_); }
   HipIntegrator(const HipIntegrator&) = delete;
   HipIntegrator& operator=(const HipIntegrator&) = delete;

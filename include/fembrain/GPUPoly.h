@@ -176,6 +176,9 @@ class GPUPoly {
     return true;
   }
 
+  // the C handle, e.g. for PS::FEM::HipIntegrator(fb_poly_t, ...): the tet mesh goes to the FEM on the device
+  fb_poly_t handle() const { return h_; }
+
  private:
   fb_poly_t h_;
   float m_cellsize;

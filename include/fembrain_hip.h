@@ -303,6 +303,12 @@ int fb_poly_time_surface(fb_poly_t h, int reps, double* seconds);
 /* average device seconds of one sweep / one classify+tetrahedralize pipeline on the current grid */
 int fb_poly_time_pipeline(fb_poly_t h, int reps, double* sweep_seconds, double* pipeline_seconds);
 
+/* Field grid -> tets -> FEM with no host hop: the tet mesh fb_poly_tetrahedralize left on the device becomes
+ * the mesh of a new FEM handle -- node ids copied device to device, float positions widened to double, pattern / SELL-64
+ * layout / contribution lists built on the device.  Same result as fb_fem_create on fb_poly_read_tetmesh's arrays.
+ * params->device must be the polygonizer's device.  The constrained DOFs come from the host as for fb_fem_create. */
+int fb_fem_create_from_poly(fb_fem_t* out, fb_poly_t poly, int n_fixed_dofs, const int* fixed_dofs, const fb_fem_params* params);
+
 /* ---- multi-GPU field path: z-slabs of one grid ---------------------------------------------------------------------
  * The grid's point planes are dealt to the ranks in contiguous runs.  A rank that owns planes [p0, p1) (and the cell layers
  * [p0, min(p1, planes - 1))) sweeps the slab [max(p0 - 1, 0), min(p1 + 1, planes - 1)] -- one plane below and two above,

@@ -112,6 +112,16 @@ int main() {
   PS::FEM::Deformable ball((int)nv, xv.data(), (int)nt, ev.data(), low);
   ball.timestep();
   std::printf("BALL_FIXED=%zu\nBALL_ITERS=%d\n", low.size(), ball.integrator()->GetLastIterations());
+  {  // the same ball with the mesh handed over on the device (no host copy): one step must give the same iteration count
+    PS::FEM::HipIntegrator direct(poly.handle(), 0, nullptr);
+    std::vector<double> f((size_t)direct.Getr(), 0.0);
+    for (size_t i = 1; i < f.size(); i += 3) f[i] = -10.0;
+    direct.SetExternalForces(f.data());
+    PS::FEM::HipIntegrator staged((int)nv, xv.data(), (int)nt, ev.data(), 0, nullptr);
+    staged.SetExternalForces(f.data());
+    const int a = direct.DoTimestep(), b = staged.DoTimestep();
+    std::printf("DIRECT_R=%d\nDIRECT_SAME=%d\n", direct.Getr(), (a == b && direct.GetLastIterations() == staged.GetLastIterations()) ? 1 : 0);
+  }
   {  // the field path as two "ranks" run it (one after the other here): the pieces put together are the mesh above
     const int dims[3] = {12, 12, 12};
     std::vector<int> counts(2, 0);

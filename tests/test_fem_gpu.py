@@ -723,3 +723,41 @@ def test_device_plan_equals_host_plan(gpu, mesh):
     for name in ("bptr", "bcol", "slice_off", "colidx", "contrib"):
         assert np.array_equal(_device_plan(g, name), get(name)), name
     L.fb_plan_destroy(hp)
+
+
+def test_fem_handle_straight_from_the_polygonizer(gpu):
+    """fb_fem_create_from_poly: field grid -> tets -> FEM without a host copy.  Same plan, same steps (bit for bit) as
+    fb_fem_create on the arrays fb_poly_read_tetmesh returns."""
+    from fembrain_amd.blobtree import read_blob
+    from fembrain_amd.poly import GpuPoly
+    blob = read_blob(os.path.join(os.path.dirname(__file__), "golden", "blob", "tumor.blob"))
+    p = GpuPoly(blob)
+    xyz, tets = p.run_tetrahedralizer(0.11)
+    assert len(tets) > 3000
+    fixed = fixed_vertices_to_dofs(np.nonzero(xyz[:, 1] < np.percentile(xyz[:, 1], 10))[0])
+    a = FemIntegrator.from_poly(p, fixed)
+    b = FemIntegrator(xyz.astype(np.float64), tets.astype(np.int32), fixed)
+    assert fl.lib().fb_fem_plan_on_device(a.h) == 1
+    for name in ("bptr", "bcol", "slice_off", "colidx", "contrib"):
+        assert np.array_equal(_device_plan(a, name), _device_plan(b, name)), name
+    for g in (a, b):
+        g.set_uniform_force(1, -50.0)
+    for _ in range(2):
+        assert a.do_timestep() == b.do_timestep()
+    assert np.array_equal(a.get_q_state()[0], b.get_q_state()[0])
+    p.close()   # the FEM handle owns its copy of the mesh
+    a.set_uniform_force(1, -50.0)
+    assert a.do_timestep() > 0
+    # a polygonizer without a tet mesh is refused
+    q = GpuPoly(blob)
+    with pytest.raises(fl.FbError):
+        FemIntegrator.from_poly.__func__(FemIntegrator, _NoMesh(q))
+
+
+class _NoMesh:
+    """a GpuPoly stand-in whose read_tetmesh would fail: from_poly must fail in the C call, not earlier"""
+    def __init__(self, poly):
+        self.h = poly.h
+
+    def read_tetmesh(self):
+        return np.zeros((4, 3), np.float32), np.zeros((1, 4), np.uint32)
