@@ -4,7 +4,7 @@
 // Deformable::syncForceModel (src/deformable/Deformable.cpp:127-220) rebuilds all of this after every cut; on the host
 // (fem_plan.cpp, 16 threads) that is 61-68 ms at 1M tets and was 90 % of a re-sync.  Here it is a handful of streaming
 // passes around one radix sort:
-//   1. every tet emits its 16 (row, col) vertex pairs, key = row << 32 | col, value = tet << 4 | i << 2 | j -- the
+//   1. every tet emits its 16 (row, col) vertex pairs, key = row << b | col (b = bits of a node id, so the sort runs over 2 b bits only), value = tet << 4 | i << 2 | j -- the
 //      contribution word of fem_plan.h -- and every node one marker pair (a, a) so that a node no element references
 //      still gets its diagonal block (fem_plan.cpp: "isolated node");
 //   2. a stable radix sort by key puts the pairs in pattern order: rows ascending, columns ascending inside a row, and
@@ -31,30 +31,30 @@ namespace {
 
 constexpr int kB = 256;
 
-__global__ __launch_bounds__(kB) void k_plan_pairs(int n_tets, int n_nodes, const int4* __restrict__ tets, unsigned long long* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals) {
+__global__ __launch_bounds__(kB) void k_plan_pairs(int n_tets, int n_nodes, int row_bits, const int4* __restrict__ tets,
+                                                   unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
   const long long i = (long long)blockIdx.x * kB + threadIdx.x;
   const long long n_tp = 16LL * n_tets;
   if (i < n_tp) {
     const int e = (int)(i >> 4), ij = (int)(i & 15);
     const int4 t = tets[e];
     const int id[4] = {t.x, t.y, t.z, t.w};
-    keys[i] = ((unsigned long long)(unsigned int)id[ij >> 2] << 32) | (unsigned int)id[ij & 3];
+    keys[i] = ((unsigned long long)(unsigned int)id[ij >> 2] << row_bits) | (unsigned int)id[ij & 3];
     vals[i] = ((uint32_t)e << 4) | (uint32_t)ij;
   } else if (i < n_tp + n_nodes) {
     const unsigned int a = (unsigned int)(i - n_tp);
-    keys[i] = ((unsigned long long)a << 32) | a;
+    keys[i] = ((unsigned long long)a << row_bits) | a;
     vals[i] = kNoContrib;
   }
 }
 
 // block p: row, column; bptr by binary search of the first block of every row
-__global__ __launch_bounds__(kB) void k_plan_rows(int n_nodes, int n_blocks, const unsigned long long* __restrict__ ukeys, int* __restrict__ bptr,
-                                                  int* __restrict__ bcol) {
+__global__ __launch_bounds__(kB) void k_plan_rows(int n_nodes, int n_blocks, int row_bits, const unsigned long long* __restrict__ ukeys,
+                                                  int* __restrict__ bptr, int* __restrict__ bcol) {
   const int i = blockIdx.x * kB + threadIdx.x;
-  if (i < n_blocks) bcol[i] = (int)(unsigned int)(ukeys[i] & 0xffffffffULL);
+  if (i < n_blocks) bcol[i] = (int)(unsigned int)(ukeys[i] & ((1ULL << row_bits) - 1ULL));
   if (i <= n_nodes) {
-    const unsigned long long want = (unsigned long long)(unsigned int)i << 32;
+    const unsigned long long want = (unsigned long long)(unsigned int)i << row_bits;
     int lo = 0, hi = n_blocks;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
@@ -137,14 +137,14 @@ int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets
   FB_TRY(keys_s.alloc((size_t)n_pairs));
   FB_TRY(vals.alloc((size_t)n_pairs));
   FB_TRY(vals_s.alloc((size_t)n_pairs));
-  hipLaunchKernelGGL(k_plan_pairs, dim3((unsigned)((n_pairs + kB - 1) / kB)), dim3(kB), 0, s, n_tets, n_nodes, d_tets, keys.p, vals.p);
-  FB_HIP(hipGetLastError());
   int row_bits = 1;
   while ((1LL << row_bits) < n_nodes) row_bits++;
+  hipLaunchKernelGGL(k_plan_pairs, dim3((unsigned)((n_pairs + kB - 1) / kB)), dim3(kB), 0, s, n_tets, n_nodes, row_bits, d_tets, keys.p, vals.p);
+  FB_HIP(hipGetLastError());
   size_t bytes = 0;
-  FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, (unsigned)(32 + row_bits), s));
+  FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, (unsigned)(2 * row_bits), s));
   FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));
-  FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, (unsigned)(32 + row_bits), s));
+  FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, (unsigned)(2 * row_bits), s));
   // blocks = runs of equal keys
   FB_TRY(ukeys.alloc((size_t)n_pairs));
   FB_TRY(ucnt.alloc((size_t)n_pairs));
@@ -164,8 +164,8 @@ int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets
   FB_TRY(D.bptr->alloc((size_t)n_nodes + 1));
   FB_TRY(D.bcol->alloc((size_t)nb));
   FB_TRY(D.blk_slot->alloc((size_t)nb));
-  hipLaunchKernelGGL(k_plan_rows, dim3((unsigned)((std::max<long long>(nb, n_nodes + 1) + kB - 1) / kB)), dim3(kB), 0, s, n_nodes, (int)nb, ukeys.p, D.bptr->p,
-                     D.bcol->p);
+  hipLaunchKernelGGL(k_plan_rows, dim3((unsigned)((std::max<long long>(nb, n_nodes + 1) + kB - 1) / kB)), dim3(kB), 0, s, n_nodes, (int)nb, row_bits, ukeys.p,
+                     D.bptr->p, D.bcol->p);
   FB_HIP(hipGetLastError());
   // SELL-64
   const int n_slices = (n_nodes + kSliceRows - 1) / kSliceRows;
