@@ -126,6 +126,22 @@ def field_bench(device, cpu=True):
         dt = time.perf_counter() - t0
         out["field_cpu_baseline"] = {"value": dims[0] * dims[1] * zs / dt / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
                                      "sample": "oracle/field_oracle.c, 256x256x%d slab of the same grid through the sphere, sweep+classify+tets" % zs}
+        # the reference's CPU polygonizer is TBB-parallel over cores (Polygonizer.cpp:627-629): the same slab on every core of the
+        # box's share at once (threads; the C oracle runs outside the GIL), as a courtesy number
+        from concurrent.futures import ThreadPoolExecutor
+        cores = max(1, min(os.cpu_count() or 1, 16))
+
+        def one(i):
+            oo = OrcPoly(blob)
+            oo.sweep_grid((lower[0], lower[1], lower[2] + cell * (40 + (i * 11) % 160)), cell, (dims[0], dims[1], zs))
+            oo.classify()
+            oo.tetrahedralize()
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(one, range(cores)))
+        dta = time.perf_counter() - t0
+        out["field_cpu_baseline_all_cores"] = {"value": cores * dims[0] * dims[1] * zs / dta / 1e6, "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+                                               "sample": "%d threads, one 256x256x%d slab each" % (cores, zs)}
     p.close()
     return out
 
