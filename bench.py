@@ -382,8 +382,9 @@ def main():
             "metric": "FEM steps/sec (assemble+PCG) at 1M tets" if args.workload == "cube56" else "FEM steps/sec (assemble+PCG)", "value": args.steps / dt, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 matrix, f64 vectors/accumulators" if args.precision == "f32" else "f64", "data": "synthetic",
-            "config": {"workload": text, "nodes": int(len(v)), "tets": int(len(t)), "partition": "i-plane slabs x%d" % world,
+            # the arithmetic type of the path: every product, sum and vector is fp64; only the STORED matrix values are fp32 by default
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": text, "nodes": int(len(v)), "tets": int(len(t)), "partition": "i-plane slabs x%d" % world, "matrix_storage": args.precision,
                        "exchange": ["none (one GPU)", "host-staged test communicator (rehearsal)" if local_comm else "RCCL all-reduce + send/recv",
                                     "peer-to-peer inboxes over xGMI (HIP IPC), one kernel per exchange",
                                     "peer-to-peer inboxes, sums inside the PCG kernels",
