@@ -332,6 +332,28 @@ class Deformable {
   void setGravity(bool g) { m_bApplyGravity = g; }
   bool getGravity() const { return m_bApplyGravity; }
   void setFloor(double y) { m_hasFloor = true; m_floorY = y; }  // stands in for setCollisionObject(SGNode*): the floor plane height
+  // Deformable::collisionDetect (Deformable.cpp:541-600) against the floor plane set with setFloor: vertices at or below it are
+  // put back on it and their velocity reflected (the device pass timestep() also runs); true if any vertex was touched
+  bool collisionDetect() {
+    if (!m_hasFloor) return false;
+    m_ctCollided = (U32)m_lpIntegrator->FloorCollision(m_floorY, 0.4);
+    return m_ctCollided > 0;
+  }
+  // Deformable::statFillRecord (Deformable.cpp:225-258) without the sqlite logger: the same fields in a plain record
+  struct StatRecord {
+    U32 ctElements, ctVertices;
+    double restVolume, totalVolume, youngModulo, poissonRatio;
+    const char *xpElementType, *xpForceModel, *xpIntegrator;
+    std::string xpModelName;
+  };
+  void statFillRecord(StatRecord& rec) {
+    rec.ctElements = countCells(); rec.ctVertices = countNodes();
+    (void)isVolumeChanged();  // fills the rest volume on first use
+    rec.restVolume = m_restVolume; rec.totalVolume = computeVolume();
+    rec.youngModulo = 0.0; rec.poissonRatio = 0.0;  // as the reference leaves them
+    rec.xpElementType = "TET"; rec.xpForceModel = "COROTATIONAL LINEAR FEM"; rec.xpIntegrator = "JACOBI PRECONDITIONED CG";
+    rec.xpModelName = m_strModelName;
+  }
   void resetDeformations() { m_lpIntegrator->ResetToRest(); m_vHapticForces.clear(); }
   void setDeformCallback(FOnApplyDeformations fOnDeform) { m_fOnDeform = fOnDeform; }
   double getSolverTime() const { return m_lpIntegrator->GetSystemSolveTime(); }

@@ -75,6 +75,12 @@ int main() {
   std::printf("PICKED=%d\nPICK_BOX=%d\nVOL_CHANGED=%d\nHAPTIC_FIXED=%d\n", picked, nbox, d.isVolumeChanged() ? 1 : 0,
               d.hapticStart(PS::FEM::vec3d{-0.25, 0.0, -0.25}) ? 1 : 0);
   d.hapticEnd();
+  {
+    PS::FEM::Deformable::StatRecord rec;
+    d.statFillRecord(rec);
+    std::printf("STAT=%u,%u,%s,%s\nSTAT_VOL=%.9g\nCOLLIDE_NOFLOOR=%d\n", rec.ctElements, rec.ctVertices, rec.xpElementType, rec.xpIntegrator, rec.restVolume,
+                d.collisionDetect() ? 1 : 0);
+  }
 
   // sphere.blob -> GPUPoly -> tet mesh -> Deformable
   PS::SKETCH::LinearBlobTreeData blob;

@@ -75,6 +75,8 @@ def test_cpp_host_program_matches_oracle(gpu):
     assert int(kv["POLY_RUN"]) == 1 and int(kv["POLY_TETS"]) == len(ot) == 3744 and int(kv["POLY_VERTS"]) == len(ox)
     assert np.float32(kv["FIELD_025"]) == np.float32((1 - 0.0625) ** 3) and int(kv["GRID_POINTS"]) == 12 ** 3
     assert int(kv["BALL_FIXED"]) == int((ox[:, 1] < -0.35).sum()) and int(kv["BALL_ITERS"]) > 0
+    assert kv["STAT"] == "%d,%d,TET,JACOBI PRECONDITIONED CG" % (len(t), len(v)) and abs(float(kv["STAT_VOL"]) - 0.4 ** 3) < 1e-12
+    assert kv["COLLIDE_NOFLOOR"] == "0"
     assert int(kv["DIRECT_R"]) == 3 * len(ox) and kv["DIRECT_SAME"] == "1"
     assert int(kv["SLAB_VERTS"]) == len(ox) and int(kv["SLAB_TETS"]) == len(ot) and kv["SLAB_SAME"] == "1"
     # PS::FEM::Cutting on the ball: the reference's known answer, hit list = count, the swept quad closes at the third call
