@@ -78,6 +78,11 @@ class HipIntegrator {
   void SetqState(const double* q, const double* qvel = nullptr, const double* qaccel = nullptr) { check(fb_fem_set_state(h_, q, qvel, qaccel)); }
   void GetqState(double* q, double* qvel = nullptr, double* qaccel = nullptr) { check(fb_fem_get_state(h_, q, qvel, qaccel)); }
   int SetState(double* q, double* qvel = nullptr) { check(fb_fem_set_state(h_, q, qvel, nullptr)); return 0; }
+  // Getq / Getqvel / Getqaccel (integratorBase.h:139-141) hand out the integrator's own arrays in the reference; the state
+  // lives on the device here, so these return a host mirror refreshed by the call (borrowed, valid until the next call)
+  double* Getq() { mirror(); return mq_.data(); }
+  double* Getqvel() { mirror(); return mv_.data(); }
+  double* Getqaccel() { mirror(); return ma_.data(); }
   void ResetToRest() { check(fb_fem_reset(h_)); }
   void SetTimestep(double t) { prm_.timestep = t; check(fb_fem_set_timestep(h_, t)); }
   double GetTimestep() const { return prm_.timestep; }
@@ -140,6 +145,11 @@ class HipIntegrator {
   std::vector<int> bptr_, bcol_;
   std::vector<double> mass_;
   int r_;
+  void mirror() {
+    mq_.resize((size_t)r_); mv_.resize((size_t)r_); ma_.resize((size_t)r_);
+    check(fb_fem_get_state(h_, mq_.data(), mv_.data(), ma_.data()));
+  }
+  std::vector<double> mq_, mv_, ma_;
   fb_fem_t h_;
   fb_fem_params prm_;
   fb_step_info info_;

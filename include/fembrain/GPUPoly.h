@@ -176,6 +176,8 @@ class GPUPoly {
     return true;
   }
 
+  // GPUPoly::computeDevice() returned the OpenCL wrapper; there is none any more ("must become opaque/nullable")
+  void* computeDevice() const { return nullptr; }
   // the C handle, e.g. for PS::FEM::HipIntegrator(fb_poly_t, ...): the tet mesh goes to the FEM on the device
   fb_poly_t handle() const { return h_; }
 
