@@ -138,3 +138,32 @@ def test_perform_cut_path_logic(gpu):
     for _ in range(600):
         c.perform_cut(e1 * 0, e1)
     assert len(c._path0) == Cutting.MAX_PATH_NODES == len(c._path1)
+
+
+def test_unstructured_mesh_and_many_blades(gpu):
+    """Delaunay tetrahedra of random points (tets of every shape and orientation, shuffled), 40 random scalpel edges and
+    swept quads: flags, points, counts and hit lists against the oracle, bit for bit"""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(123)
+    v = rng.uniform(-1, 1, size=(4000, 3))
+    t = Delaunay(v).simplices.astype(np.uint32)
+    rng.shuffle(t)
+    c = Cutting(v, t)
+    seen_faces = seen_edges = 0
+    for k in range(40):
+        s0 = rng.uniform(-1.2, 1.2, 3)
+        s1 = s0 + rng.normal(size=3) * rng.choice([0.02, 0.3, 2.5])
+        n = c.compute_face_intersections(s0, s1)
+        flags, pts = c.read(FB_CUT_FACES)
+        on, oflags, opts = pycut.cut_faces(1, v, t, s0, s1)
+        assert n == on and np.array_equal(flags, oflags) and np.array_equal(pts, opts), k
+        quad = np.stack([s0, s1, s0 + rng.normal(size=3) * 0.4, s1 + rng.normal(size=3) * 0.4])   # not planar in general
+        n = c.compute_edge_intersections(quad)
+        flags, pts = c.read(FB_CUT_EDGES)
+        on, oflags, opts = pycut.cut_edges(v, t, quad)
+        assert n == on and np.array_equal(flags, oflags) and np.array_equal(pts, opts), k
+        ids, hp = c.read_hits(FB_CUT_EDGES)
+        assert np.array_equal(ids, np.nonzero(flags)[0]) and np.array_equal(hp, pts[flags == 1])
+        seen_faces += int(oflags.sum() > 0)
+        seen_edges += n
+    assert seen_edges > 1000
