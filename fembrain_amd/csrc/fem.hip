@@ -552,8 +552,7 @@ int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int*
 int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed, const uint4* d_tets = nullptr) {
   if (n_nodes <= 0 || n_tets <= 0 || (!tets && !d_tets)) return fail(FB_EINVAL, "empty mesh (%d nodes, %d tets)", n_nodes, n_tets);
   if ((long long)n_tets >= (1LL << 28)) return fail(FB_EINVAL, "too many tets for the packed contribution word");
-  for (long long k = 0; k < (d_tets ? 0 : 4LL * n_tets); k++)
-    if (tets[k] < 0 || tets[k] >= n_nodes) return fail(FB_EINVAL, "tet %lld references node %d outside [0,%d)", k / 4, tets[k], n_nodes);
+
   FemPlan& P = h->plan;
   P = FemPlan();
   P.n_global = n_nodes; P.n_ranks = 1; P.rank = 0;
@@ -575,7 +574,14 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   DevicePlan D;
   D.slice_off = &h->slice_off; D.colidx = &h->colidx; D.slot_coff = &h->slot_coff; D.slot_ccnt = &h->slot_ccnt; D.contrib = &h->contrib;
   D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot;
-  FB_TRY(build_plan_device(h->stream, n_nodes, n_tets, h->tets.p, D));
+  const int rc = build_plan_device(h->stream, n_nodes, n_tets, h->tets.p, D);
+  if (rc != FB_OK && D.first_bad_tet >= 0 && tets) {  // say which node, as the host builder does
+    for (int k = 0; k < 4; k++) {
+      const int id = tets[4 * (size_t)D.first_bad_tet + k];
+      if (id < 0 || id >= n_nodes) return fail(FB_EINVAL, "tet %d references node %d outside [0,%d)", D.first_bad_tet, id, n_nodes);
+    }
+  }
+  FB_TRY(rc);
   P.n_blocks = D.n_blocks; P.n_slices = D.n_slices; P.n_slots = D.n_slots; P.n_crows = D.n_crows;
   P.slice_off = D.slice_off_host;
   return FB_OK;

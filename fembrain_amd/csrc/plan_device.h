@@ -16,9 +16,10 @@ struct DevicePlan {
   DevBuf<int>*bptr = nullptr, *bcol = nullptr, *blk_slot = nullptr;  // CSR pattern and slot of every block (inspection entry points)
   int n_blocks = 0, n_slices = 0, n_slots = 0, n_crows = 0;
   std::vector<int> slice_off_host;
+  int first_bad_tet = -1;  // lowest tet with a node id outside [0, n_nodes), -1 if none (the build then fails with FB_EINVAL)
 };
 
-// d_tets: n_tets x int4 node ids (already range-checked on the host).  Synchronises the stream before it returns.
+// d_tets: n_tets x int4 node ids; their range is checked here (first_bad_tet).  Synchronises the stream before it returns.
 int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& out);
 
 }  // namespace fb

@@ -32,13 +32,14 @@ namespace {
 constexpr int kB = 256;
 
 __global__ __launch_bounds__(kB) void k_plan_pairs(int n_tets, int n_nodes, int row_bits, const int4* __restrict__ tets,
-                                                   unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                   unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, int* __restrict__ first_bad) {
   const long long i = (long long)blockIdx.x * kB + threadIdx.x;
   const long long n_tp = 16LL * n_tets;
   if (i < n_tp) {
     const int e = (int)(i >> 4), ij = (int)(i & 15);
     const int4 t = tets[e];
     const int id[4] = {t.x, t.y, t.z, t.w};
+    if ((unsigned int)id[ij & 3] >= (unsigned int)n_nodes) atomicMin(first_bad, e);  // the host reports it; the keys of this run are never used
     keys[i] = ((unsigned long long)(unsigned int)id[ij >> 2] << row_bits) | (unsigned int)id[ij & 3];
     vals[i] = ((uint32_t)e << 4) | (uint32_t)ij;
   } else if (i < n_tp + n_nodes) {
@@ -139,8 +140,15 @@ int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets
   FB_TRY(vals_s.alloc((size_t)n_pairs));
   int row_bits = 1;
   while ((1LL << row_bits) < n_nodes) row_bits++;
-  hipLaunchKernelGGL(k_plan_pairs, dim3((unsigned)((n_pairs + kB - 1) / kB)), dim3(kB), 0, s, n_tets, n_nodes, row_bits, d_tets, keys.p, vals.p);
+  DevBuf<int> bad;
+  const int none = 0x7fffffff;
+  FB_TRY(bad.upload(&none, 1, s));
+  hipLaunchKernelGGL(k_plan_pairs, dim3((unsigned)((n_pairs + kB - 1) / kB)), dim3(kB), 0, s, n_tets, n_nodes, row_bits, d_tets, keys.p, vals.p, bad.p);
   FB_HIP(hipGetLastError());
+  int first_bad = none;
+  FB_TRY(bad.download(&first_bad, 1, s));
+  D.first_bad_tet = first_bad == none ? -1 : first_bad;
+  if (D.first_bad_tet >= 0) return fail(FB_EINVAL, "tet %d references a node outside [0,%d)", D.first_bad_tet, n_nodes);
   size_t bytes = 0;
   FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, (unsigned)(2 * row_bits), s));
   FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));

@@ -193,7 +193,10 @@ def test_bad_arguments(gpu):
         FemIntegrator(v, t, fixed[::-1])  # not ascending
     bad = t.copy()
     bad[0, 0] = len(v)
-    with pytest.raises(fl.FbError):
+    with pytest.raises(fl.FbError, match="tet 0 references node %d outside" % len(v)):
+        FemIntegrator(v, bad, fixed)
+    bad[0, 0], bad[5, 2] = 0, -3
+    with pytest.raises(fl.FbError, match="tet 5 references node -3 outside"):
         FemIntegrator(v, bad, fixed)
 
 
