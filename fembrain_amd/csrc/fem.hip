@@ -32,6 +32,8 @@ struct fb_fem_s {
   // matrix
   DevBuf<int> slice_off, colidx, slot_coff, slot_ccnt, send_local;
   DevBuf<uint32_t> contrib;
+  DevBuf<short> coldelta;  // 16-bit column - row (device-built plans); c16 says whether the SpMV may use it
+  bool c16 = false;
   DevBuf<int> d_bptr, d_bcol, d_blk_slot;  // device-built plan only: pattern and slot table, fetched when an inspection entry point asks
   bool device_plan = false, host_pattern = true;
   DevBuf<uint8_t> dofmask;
@@ -67,6 +69,7 @@ size_t mt_size(const fb_fem_s* h) { return h->f64 ? sizeof(double) : sizeof(floa
 SellView sell_view(const fb_fem_s* h) {
   SellView sv;
   sv.slice_off = h->slice_off.p; sv.colidx = h->colidx.p; sv.n_slices = h->plan.n_slices; sv.n_owned = h->plan.n_owned;
+  sv.coldelta = h->c16 ? h->coldelta.p : nullptr;
   return sv;
 }
 
@@ -237,7 +240,13 @@ int launch_spmv(fb_fem_s* h, const double* x, double* y, const double* b, double
     FB_HIP(hipGetLastError());
     return FB_OK;
   }
-  if (h->spmv_nt)
+  if (h->c16 && h->spmv_nt)
+    hipLaunchKernelGGL((k_spmv<MT, MODE, 0, true, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x,
+                       y, b, h->invdiag.p, partial, h->st.p, parity, P2PArgs());
+  else if (h->c16)
+    hipLaunchKernelGGL((k_spmv<MT, MODE, 0, false, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x,
+                       y, b, h->invdiag.p, partial, h->st.p, parity, P2PArgs());
+  else if (h->spmv_nt)
     hipLaunchKernelGGL((k_spmv<MT, MODE, 0, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
                        b, h->invdiag.p, partial, h->st.p, parity, P2PArgs());
   else
@@ -573,7 +582,7 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   }
   DevicePlan D;
   D.slice_off = &h->slice_off; D.colidx = &h->colidx; D.slot_coff = &h->slot_coff; D.slot_ccnt = &h->slot_ccnt; D.contrib = &h->contrib;
-  D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot;
+  D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot; D.coldelta = &h->coldelta;
   const int rc = build_plan_device(h->stream, n_nodes, n_tets, h->tets.p, D);
   if (rc != FB_OK && D.first_bad_tet >= 0 && tets) {  // say which node, as the host builder does
     for (int k = 0; k < 4; k++) {
@@ -583,6 +592,7 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   }
   FB_TRY(rc);
   P.n_blocks = D.n_blocks; P.n_slices = D.n_slices; P.n_slots = D.n_slots; P.n_crows = D.n_crows;
+  h->c16 = D.deltas_fit16 && !(getenv("FEMBRAIN_SPMV_C16") && atoi(getenv("FEMBRAIN_SPMV_C16")) == 0);
   P.slice_off = D.slice_off_host;
   return FB_OK;
 }
@@ -625,6 +635,7 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
     lap("device plan");
   }
   if (!h->device_plan) {
+    h->c16 = false;
     FB_TRY(build_fem_plan(h->plan, n_nodes, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits));
     lap("host plan");
   }
@@ -1231,7 +1242,9 @@ int fb_fem_spmv_bytes(fb_fem_t h, double* bytes) {
   // SURVEY.md 8d BSR figure, for the launch the PCG loop makes (k_spmv<MT,3>): nnzb*(9 values + 4 B index) + (rows+1)*4
   // + the low part of each row's diagonal block (9 values per row) + fp64 vectors: d read once, q written once, and the
   // own-row r and 1/diag the merged sums need
-  *bytes = (double)P.n_blocks * (9.0 * mt_size(h) + 4.0) + (P.n_owned + 1) * 4.0 + 9.0 * mt_size(h) * P.n_owned + 3.0 * P.n_owned * 8.0 * 4.0;
+  // (the index is 2 bytes where the row kernel reads 16-bit column differences)
+  const double idx = (h->c16 && h->split == 0) ? 2.0 : 4.0;
+  *bytes = (double)P.n_blocks * (9.0 * mt_size(h) + idx) + (P.n_owned + 1) * 4.0 + 9.0 * mt_size(h) * P.n_owned + 3.0 * P.n_owned * 8.0 * 4.0;
   return FB_OK;
 }
 

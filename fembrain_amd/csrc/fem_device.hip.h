@@ -369,7 +369,9 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
 // the vectors resident instead: 168 vs 206 us at 8M tets (5.9 vs 4.8 TB/s).  On a system that fits (1M tets, 160 MB)
 // the same hint evicts the matrix from the cache it would be served from: 24.7 vs 20.8 us -- so the host picks by size
 // (crossover measured between 341 MB and 469 MB per iteration; FEMBRAIN_SPMV_NT=0/1 overrides).
-template <typename MT, int MODE, int XCH = 0, bool NT = false>
+// C16: column ids are read as 16-bit differences to the row (2 instead of 4 bytes per block; unsharded handles whose
+// plan was built on the device, when every difference fits) -- same columns, same products, 4 % fewer bytes.
+template <typename MT, int MODE, int XCH = 0, bool NT = false, bool C16 = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo, const double* __restrict__ x,
                                                  double* __restrict__ y, const double* __restrict__ bvec,
                                                  const double* __restrict__ invdiag, double* __restrict__ partial,
@@ -393,10 +395,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
     const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
     const MT* v = vals + (size_t)so * 9 * 64 + lane;
     const int* ci = sv.colidx + (size_t)so * 64 + lane;
+    const short* cd = C16 ? sv.coldelta + (size_t)so * 64 + lane : nullptr;
     double y0 = 0, y1 = 0, y2 = 0;
 #pragma unroll 4
     for (int k = 0; k < width; k++) {
-      const int col = ci[(size_t)k * 64];
+      const int col = C16 ? row + (int)cd[(size_t)k * 64] : ci[(size_t)k * 64];
       const double* xp = ((XCH == 2 && col >= sv.n_owned) ? halo_in : x) + 3 * (size_t)col;
       const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
       const MT* vk = v + (size_t)k * 9 * 64;

@@ -33,6 +33,7 @@ struct CGState {
 struct SellView {
   const int* slice_off;  // n_slices+1
   const int* colidx;     // n_slots*64
+  const short* coldelta; // n_slots*64: column - row where every such difference fits 16 bits (k_spmv<..., C16>), else null
   int n_slices;
   int n_owned;
 };

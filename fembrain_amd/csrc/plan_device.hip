@@ -84,21 +84,28 @@ __global__ __launch_bounds__(kB) void k_plan_widths(int n_nodes, int n_slices, c
 // one wavefront per slice: column ids, the slot of every block, and the height of every slot's contribution list
 __global__ __launch_bounds__(kB) void k_plan_sell(int n_nodes, int n_slices, const int* __restrict__ bptr, const int* __restrict__ bcol,
                                                   const unsigned int* __restrict__ ucnt, const int* __restrict__ slice_off, int* __restrict__ colidx,
-                                                  int* __restrict__ blk_slot, int* __restrict__ slot_ccnt) {
+                                                  int* __restrict__ blk_slot, int* __restrict__ slot_ccnt, short* __restrict__ coldelta,
+                                                  int* __restrict__ wide) {
   const int s = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (s >= n_slices) return;
   const int a = s * 64 + lane;
   const int so = slice_off[s], w = slice_off[s + 1] - so;
   const int first = a < n_nodes ? bptr[a] : 0, len = a < n_nodes ? bptr[a + 1] - first : 0;
   for (int k = 0; k < w; k++) {
-    int c = 0;
+    int c = 0, col;
     if (k < len) {
-      colidx[((size_t)so + k) * 64 + lane] = bcol[first + k];
+      col = bcol[first + k];
+      colidx[((size_t)so + k) * 64 + lane] = col;
       blk_slot[first + k] = so + k;
-      c = (int)ucnt[first + k] - (bcol[first + k] == a ? 1 : 0);  // the diagonal block's run ends with the marker pair
+      c = (int)ucnt[first + k] - (col == a ? 1 : 0);  // the diagonal block's run ends with the marker pair
     } else {
-      colidx[((size_t)so + k) * 64 + lane] = a < n_nodes ? a : 0;  // padding: any valid column, its values stay zero
+      col = a < n_nodes ? a : 0;
+      colidx[((size_t)so + k) * 64 + lane] = col;  // padding: any valid column, its values stay zero
+      if (a >= n_nodes) col = n_nodes - 1;       // (in the 16-bit form a lane past the last row points at the last row instead)
     }
+    const int delta = col - a;
+    if (delta < -32768 || delta > 32767) atomicOr(wide, 1);
+    coldelta[((size_t)so + k) * 64 + lane] = (short)delta;
     const int m = wave_max(c);
     if (lane == 0) slot_ccnt[so + k] = m;
   }
@@ -195,9 +202,16 @@ int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets
   FB_TRY(D.slot_ccnt->alloc((size_t)D.n_slots + 1));
   FB_TRY(D.slot_ccnt->zero(s));
   FB_TRY(D.slot_coff->alloc((size_t)D.n_slots + 1));
+  FB_TRY(D.coldelta->alloc(std::max<size_t>(1, (size_t)D.n_slots * kSliceRows)));
+  DevBuf<int> wide;
+  const int zero = 0;
+  FB_TRY(wide.upload(&zero, 1, s));
   hipLaunchKernelGGL(k_plan_sell, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, D.slice_off->p, D.colidx->p, D.blk_slot->p,
-                     D.slot_ccnt->p);
+                     D.slot_ccnt->p, D.coldelta->p, wide.p);
   FB_HIP(hipGetLastError());
+  int w = 0;
+  FB_TRY(wide.download(&w, 1, s));
+  D.deltas_fit16 = w == 0;
   bytes = 0;
   FB_HIP(rocprim::exclusive_scan(nullptr, bytes, D.slot_ccnt->p, D.slot_coff->p, 0, (size_t)D.n_slots + 1, rocprim::plus<int>(), s));
   FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));

@@ -764,3 +764,42 @@ class _NoMesh:
 
     def read_tetmesh(self):
         return np.zeros((4, 3), np.float32), np.zeros((1, 4), np.uint32)
+
+
+def test_16bit_column_differences_give_identical_iterates(gpu, monkeypatch):
+    """k_spmv<.., C16> reads column - row as 16-bit values (device-built plans whose differences all fit); the products are
+    the same, so are the states -- bit for bit against the 32-bit index kernel (FEMBRAIN_SPMV_C16=0); a mesh whose node
+    numbering makes a difference too wide falls back by itself"""
+    v, t, fixed = _cube(14)
+    out = []
+    for c16 in ("1", "0"):
+        monkeypatch.setenv("FEMBRAIN_SPMV_C16", c16)
+        g = FemIntegrator(v, t, fixed, spmv_kernel=fl.FB_SPMV_ROWS)
+        its = []
+        for _ in range(2):
+            g.set_uniform_force(1, -10000.0)
+            its.append(g.do_timestep())
+        out.append((its, g.get_q_state()[0], g.spmv_bytes()))
+        g.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    assert out[0][2] < out[1][2]    # 2 bytes less per block in the 16-bit form
+    monkeypatch.delenv("FEMBRAIN_SPMV_C16")
+    # 40,000 isolated nodes between two halves of the numbering: differences beyond 16 bits -> 32-bit kernel, same answer
+    half = len(v) // 2
+    pad = np.random.default_rng(1).uniform(5, 6, size=(40000, 3))
+    v2 = np.concatenate([v[:half], pad, v[half:]])
+    t2 = np.where(t >= half, t + 40000, t).astype(np.int32)
+    fixed2 = fixed_vertices_to_dofs(np.nonzero(v2[:, 0] < v[:, 0].min() + 1e-9)[0])
+    g2 = FemIntegrator(v2, t2, fixed2, spmv_kernel=fl.FB_SPMV_ROWS)
+
+    def index_bytes(g):
+        n, nb = g.n_nodes, g.num_blocks()
+        return (g.spmv_bytes() - (n + 1) * 4 - 36 * n - 96 * n) / nb - 36
+
+    assert index_bytes(g2) == 4.0
+    g3 = FemIntegrator(v, t, fixed, spmv_kernel=fl.FB_SPMV_ROWS)
+    assert index_bytes(g3) == 2.0
+    g2.set_uniform_force(1, -1000.0)
+    assert g2.do_timestep() > 0
+    q2 = g2.get_q_state()[0].reshape(-1, 3)
+    assert np.isfinite(q2).all() and np.abs(q2[:half]).max() > 0
