@@ -1244,7 +1244,8 @@ int fb_fem_spmv_bytes(fb_fem_t h, double* bytes) {
   // own-row r and 1/diag the merged sums need
   // (the index is 2 bytes where the row kernel reads 16-bit column differences)
   const double idx = (h->c16 && h->split == 0) ? 2.0 : 4.0;
-  *bytes = (double)P.n_blocks * (9.0 * mt_size(h) + idx) + (P.n_owned + 1) * 4.0 + 9.0 * mt_size(h) * P.n_owned + 3.0 * P.n_owned * 8.0 * 4.0;
+  // (6 of the 9 planes of the symmetric low part are read)
+  *bytes = (double)P.n_blocks * (9.0 * mt_size(h) + idx) + (P.n_owned + 1) * 4.0 + 6.0 * mt_size(h) * P.n_owned + 3.0 * P.n_owned * 8.0 * 4.0;
   return FB_OK;
 }
 

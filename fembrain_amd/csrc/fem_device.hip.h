@@ -413,9 +413,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
       {  // low part of the diagonal block (see k_assemble_rows)
         const MT* l = dlo + (size_t)s * 9 * 64 + lane;
         const double o0 = x[d], o1 = x[d + 1], o2 = x[d + 2];
-        y0 += (double)l[0 * 64] * o0 + (double)l[1 * 64] * o1 + (double)l[2 * 64] * o2;
-        y1 += (double)l[3 * 64] * o0 + (double)l[4 * 64] * o1 + (double)l[5 * 64] * o2;
-        y2 += (double)l[6 * 64] * o0 + (double)l[7 * 64] * o1 + (double)l[8 * 64] * o2;
+        // the low part is symmetric (k_assemble_rows forms it from the symmetric part of the block): 6 of its 9 planes are read
+        const double l01 = (double)l[1 * 64], l02 = (double)l[2 * 64], l12 = (double)l[5 * 64];
+        y0 += (double)l[0 * 64] * o0 + l01 * o1 + l02 * o2;
+        y1 += l01 * o0 + (double)l[4 * 64] * o1 + l12 * o2;
+        y2 += l02 * o0 + l12 * o1 + (double)l[8 * 64] * o2;
       }
       if (MODE == 0) {
         y[d] = y0; y[d + 1] = y1; y[d + 2] = y2;
@@ -540,9 +542,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv_split(SellView sv, const MT* __
     {
       const MT* l = dlo + (size_t)s * 9 * 64 + lane;
       const double o0 = x[d], o1 = x[d + 1], o2 = x[d + 2];
-      y0 += (double)l[0 * 64] * o0 + (double)l[1 * 64] * o1 + (double)l[2 * 64] * o2;
-      y1 += (double)l[3 * 64] * o0 + (double)l[4 * 64] * o1 + (double)l[5 * 64] * o2;
-      y2 += (double)l[6 * 64] * o0 + (double)l[7 * 64] * o1 + (double)l[8 * 64] * o2;
+      const double l01 = (double)l[1 * 64], l02 = (double)l[2 * 64], l12 = (double)l[5 * 64];  // symmetric, see k_spmv
+      y0 += (double)l[0 * 64] * o0 + l01 * o1 + l02 * o2;
+      y1 += l01 * o0 + (double)l[4 * 64] * o1 + l12 * o2;
+      y2 += l02 * o0 + l12 * o1 + (double)l[8 * 64] * o2;
     }
     if (MODE == 0) {
       y[d] = y0; y[d + 1] = y1; y[d + 2] = y2;

@@ -794,7 +794,7 @@ def test_16bit_column_differences_give_identical_iterates(gpu, monkeypatch):
 
     def index_bytes(g):
         n, nb = g.n_nodes, g.num_blocks()
-        return (g.spmv_bytes() - (n + 1) * 4 - 36 * n - 96 * n) / nb - 36
+        return (g.spmv_bytes() - (n + 1) * 4 - 24 * n - 96 * n) / nb - 36
 
     assert index_bytes(g2) == 4.0
     g3 = FemIntegrator(v, t, fixed, spmv_kernel=fl.FB_SPMV_ROWS)
