@@ -52,6 +52,11 @@ struct DevBuf {
     n = count;
     return FB_OK;
   }
+  // grow-only: keeps a larger allocation (workspaces that are reused with varying sizes)
+  int reserve(size_t count) {
+    if (p && n >= count) return FB_OK;
+    return alloc(count);
+  }
   int zero(hipStream_t s) {
     if (n) FB_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
     return FB_OK;

@@ -34,6 +34,7 @@ struct fb_fem_s {
   DevBuf<uint32_t> contrib;
   DevBuf<short> coldelta;  // 16-bit column - row (device-built plans); c16 says whether the SpMV may use it
   bool c16 = false;
+  PlanWorkspace plan_ws;  // the device plan builder's temporaries, kept for the next re-sync
   DevBuf<int> d_bptr, d_bcol, d_blk_slot;  // device-built plan only: pattern and slot table, fetched when an inspection entry point asks
   bool device_plan = false, host_pattern = true;
   DevBuf<uint8_t> dofmask;
@@ -583,7 +584,8 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   DevicePlan D;
   D.slice_off = &h->slice_off; D.colidx = &h->colidx; D.slot_coff = &h->slot_coff; D.slot_ccnt = &h->slot_ccnt; D.contrib = &h->contrib;
   D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot; D.coldelta = &h->coldelta;
-  const int rc = build_plan_device(h->stream, n_nodes, n_tets, h->tets.p, D);
+  const int rc = build_plan_device(h->stream, n_nodes, n_tets, h->tets.p, D, h->plan_ws);
+  if (h->plan_ws.bytes() > ((size_t)2 << 30)) h->plan_ws.release();  // kept for the next re-sync only while it is small change (0.8 GB at 1M tets)
   if (rc != FB_OK && D.first_bad_tet >= 0 && tets) {  // say which node, as the host builder does
     for (int k = 0; k < 4; k++) {
       const int id = tets[4 * (size_t)D.first_bad_tet + k];

@@ -9,6 +9,23 @@
 
 namespace fb {
 
+// temporaries of the builder, kept by the caller between builds (a re-sync after every cut would otherwise spend more time
+// in hipMalloc / hipFree of ~700 MB than in the kernels)
+struct PlanWorkspace {
+  DevBuf<unsigned long long> keys, keys_s, ukeys;
+  DevBuf<uint32_t> vals, vals_s;
+  DevBuf<unsigned int> ucnt, cstart, nruns;
+  DevBuf<int> width, flags;
+  DevBuf<char> temp;
+  size_t bytes() const {
+    return keys.n * 8 + keys_s.n * 8 + ukeys.n * 8 + vals.n * 4 + vals_s.n * 4 + ucnt.n * 4 + cstart.n * 4 + nruns.n * 4 + width.n * 4 + flags.n * 4 + temp.n;
+  }
+  void release() {
+    keys.release(); keys_s.release(); ukeys.release(); vals.release(); vals_s.release(); ucnt.release(); cstart.release(); nruns.release();
+    width.release(); flags.release(); temp.release();
+  }
+};
+
 struct DevicePlan {
   // outputs, allocated by the builder (the caller owns the buffers)
   DevBuf<int>*slice_off = nullptr, *colidx = nullptr, *slot_coff = nullptr, *slot_ccnt = nullptr;
@@ -22,6 +39,6 @@ struct DevicePlan {
 };
 
 // d_tets: n_tets x int4 node ids; their range is checked here (first_bad_tet).  Synchronises the stream before it returns.
-int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& out);
+int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& out, PlanWorkspace& ws);
 
 }  // namespace fb

@@ -133,48 +133,51 @@ __global__ __launch_bounds__(kB) void k_plan_contrib(int n_nodes, int n_slices, 
 
 }  // namespace
 
-int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& D) {
+int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& D, PlanWorkspace& W) {
   const long long n_pairs = 16LL * n_tets + n_nodes;
   if (n_pairs >= (1LL << 31)) return fail(FB_EINVAL, "mesh too large for the device plan builder (%lld pairs)", n_pairs);
-  DevBuf<unsigned long long> keys, keys_s, ukeys;
-  DevBuf<uint32_t> vals, vals_s;
-  DevBuf<unsigned int> ucnt, cstart, nruns;
-  DevBuf<int> width;
-  DevBuf<char> temp;
-  FB_TRY(keys.alloc((size_t)n_pairs));
-  FB_TRY(keys_s.alloc((size_t)n_pairs));
-  FB_TRY(vals.alloc((size_t)n_pairs));
-  FB_TRY(vals_s.alloc((size_t)n_pairs));
+  DevBuf<unsigned long long>&keys = W.keys, &keys_s = W.keys_s, &ukeys = W.ukeys;
+  DevBuf<uint32_t>&vals = W.vals, &vals_s = W.vals_s;
+  DevBuf<unsigned int>&ucnt = W.ucnt, &cstart = W.cstart, &nruns = W.nruns;
+  DevBuf<int>& width = W.width;
+  DevBuf<char>& temp = W.temp;
+  FB_TRY(W.flags.reserve(2));
+  FB_TRY(keys.reserve((size_t)n_pairs));
+  FB_TRY(keys_s.reserve((size_t)n_pairs));
+  FB_TRY(vals.reserve((size_t)n_pairs));
+  FB_TRY(vals_s.reserve((size_t)n_pairs));
   int row_bits = 1;
   while ((1LL << row_bits) < n_nodes) row_bits++;
-  DevBuf<int> bad;
-  const int none = 0x7fffffff;
-  FB_TRY(bad.upload(&none, 1, s));
+  const int init[2] = {0x7fffffff, 0};  // [0] lowest tet with a bad node id, [1] "a column difference does not fit 16 bits"
+  const int none = init[0];
+  FB_HIP(hipMemcpyAsync(W.flags.p, init, sizeof init, hipMemcpyHostToDevice, s));
+  struct { int* p; } bad = {W.flags.p};
   hipLaunchKernelGGL(k_plan_pairs, dim3((unsigned)((n_pairs + kB - 1) / kB)), dim3(kB), 0, s, n_tets, n_nodes, row_bits, d_tets, keys.p, vals.p, bad.p);
   FB_HIP(hipGetLastError());
   int first_bad = none;
-  FB_TRY(bad.download(&first_bad, 1, s));
+  FB_HIP(hipMemcpyAsync(&first_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  FB_HIP(hipStreamSynchronize(s));
   D.first_bad_tet = first_bad == none ? -1 : first_bad;
   if (D.first_bad_tet >= 0) return fail(FB_EINVAL, "tet %d references a node outside [0,%d)", D.first_bad_tet, n_nodes);
   size_t bytes = 0;
   FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, (unsigned)(2 * row_bits), s));
-  FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));
+  FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
   FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, (unsigned)(2 * row_bits), s));
   // blocks = runs of equal keys
-  FB_TRY(ukeys.alloc((size_t)n_pairs));
-  FB_TRY(ucnt.alloc((size_t)n_pairs));
-  FB_TRY(nruns.alloc(1));
+  FB_TRY(ukeys.reserve((size_t)n_pairs));
+  FB_TRY(ucnt.reserve((size_t)n_pairs));
+  FB_TRY(nruns.reserve(1));
   bytes = 0;
   FB_HIP(rocprim::run_length_encode(nullptr, bytes, keys_s.p, (unsigned int)n_pairs, ukeys.p, ucnt.p, nruns.p, s));
-  FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));
+  FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
   FB_HIP(rocprim::run_length_encode(temp.p, bytes, keys_s.p, (unsigned int)n_pairs, ukeys.p, ucnt.p, nruns.p, s));
   unsigned int nb = 0;
   FB_TRY(nruns.download(&nb, 1, s));
   D.n_blocks = (int)nb;
-  FB_TRY(cstart.alloc((size_t)nb));
+  FB_TRY(cstart.reserve((size_t)nb));
   bytes = 0;
   FB_HIP(rocprim::exclusive_scan(nullptr, bytes, ucnt.p, cstart.p, 0u, (size_t)nb, rocprim::plus<unsigned int>(), s));
-  FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));
+  FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
   FB_HIP(rocprim::exclusive_scan(temp.p, bytes, ucnt.p, cstart.p, 0u, (size_t)nb, rocprim::plus<unsigned int>(), s));
   FB_TRY(D.bptr->alloc((size_t)n_nodes + 1));
   FB_TRY(D.bcol->alloc((size_t)nb));
@@ -186,14 +189,14 @@ int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets
   const int n_slices = (n_nodes + kSliceRows - 1) / kSliceRows;
   D.n_slices = n_slices;
   const dim3 sg((unsigned)((n_slices + kB / 64 - 1) / (kB / 64)));
-  FB_TRY(width.alloc((size_t)n_slices + 1));
-  FB_TRY(width.zero(s));
+  FB_TRY(width.reserve((size_t)n_slices + 1));
+  FB_HIP(hipMemsetAsync(width.p, 0, sizeof(int) * ((size_t)n_slices + 1), s));
   hipLaunchKernelGGL(k_plan_widths, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, width.p);
   FB_HIP(hipGetLastError());
   FB_TRY(D.slice_off->alloc((size_t)n_slices + 1));
   bytes = 0;
   FB_HIP(rocprim::exclusive_scan(nullptr, bytes, width.p, D.slice_off->p, 0, (size_t)n_slices + 1, rocprim::plus<int>(), s));
-  FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));
+  FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
   FB_HIP(rocprim::exclusive_scan(temp.p, bytes, width.p, D.slice_off->p, 0, (size_t)n_slices + 1, rocprim::plus<int>(), s));
   D.slice_off_host.resize((size_t)n_slices + 1);
   FB_TRY(D.slice_off->download(D.slice_off_host.data(), (size_t)n_slices + 1, s));
@@ -203,18 +206,17 @@ int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets
   FB_TRY(D.slot_ccnt->zero(s));
   FB_TRY(D.slot_coff->alloc((size_t)D.n_slots + 1));
   FB_TRY(D.coldelta->alloc(std::max<size_t>(1, (size_t)D.n_slots * kSliceRows)));
-  DevBuf<int> wide;
-  const int zero = 0;
-  FB_TRY(wide.upload(&zero, 1, s));
+  struct { int* p; } wide = {W.flags.p + 1};
   hipLaunchKernelGGL(k_plan_sell, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, D.slice_off->p, D.colidx->p, D.blk_slot->p,
                      D.slot_ccnt->p, D.coldelta->p, wide.p);
   FB_HIP(hipGetLastError());
   int w = 0;
-  FB_TRY(wide.download(&w, 1, s));
+  FB_HIP(hipMemcpyAsync(&w, wide.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  FB_HIP(hipStreamSynchronize(s));
   D.deltas_fit16 = w == 0;
   bytes = 0;
   FB_HIP(rocprim::exclusive_scan(nullptr, bytes, D.slot_ccnt->p, D.slot_coff->p, 0, (size_t)D.n_slots + 1, rocprim::plus<int>(), s));
-  FB_TRY(temp.alloc(std::max<size_t>(bytes, 16)));
+  FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
   FB_HIP(rocprim::exclusive_scan(temp.p, bytes, D.slot_ccnt->p, D.slot_coff->p, 0, (size_t)D.n_slots + 1, rocprim::plus<int>(), s));
   int crows = 0;
   FB_TRY(D.slot_coff->download(&crows, 1, s, (size_t)D.n_slots));
