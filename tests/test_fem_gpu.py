@@ -803,3 +803,19 @@ def test_16bit_column_differences_give_identical_iterates(gpu, monkeypatch):
     assert g2.do_timestep() > 0
     q2 = g2.get_q_state()[0].reshape(-1, 3)
     assert np.isfinite(q2).all() and np.abs(q2[:half]).max() > 0
+
+
+def test_resync_through_meshes_of_different_sizes(gpu):
+    """Deformable::syncForceModel on one handle through meshes that grow and shrink (the plan builder's workspace is reused):
+    after every re-sync the handle steps exactly like a fresh one"""
+    meshes = [_cube(8), _cube(13), _cube(5), _cube(10)]
+    v0, t0, f0 = meshes[0]
+    g = FemIntegrator(v0, t0, f0)
+    for v, t, fixed in meshes[1:] + meshes[:2]:
+        g.resync(v, t, fixed)
+        fresh = FemIntegrator(v, t, fixed)
+        for h in (g, fresh):
+            h.set_uniform_force(1, -3000.0)
+        assert g.do_timestep() == fresh.do_timestep()
+        assert np.array_equal(g.get_q_state()[0], fresh.get_q_state()[0])
+        fresh.close()
