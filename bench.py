@@ -203,6 +203,7 @@ def main():
     local_comm = os.environ.get("FEMBRAIN_BENCH_LOCAL_COMM") == "1"
     device = 0 if local_comm else local_rank
     torch.cuda.set_device(device)
+    os.environ.setdefault("FEMBRAIN_P2P_TIMEOUT_MS", "5000")   # a healthy peer answers in microseconds; fail over to the collective library quickly
     shard = None
     comm = None
     # FEMBRAIN_BENCH_FORCE_DIST=1 runs the one-process-per-GPU plumbing (process group, unique-id broadcast, RCCL
