@@ -312,6 +312,7 @@ def main():
             it_ref = g1.do_timestep()
             ref = (it_ref, g1.get_q_state()[0])
             g1.close()
+        dist.barrier()   # the other ranks wait HERE for rank 0's reference step, not inside a bounded peer-to-peer wait
 
         def check_once():
             g.reset_to_rest()
