@@ -405,7 +405,11 @@ def main():
             "roofline": {"kernel": "k_spmv (SELL-64 3x3-block SpMV of the PCG)", "bound": "hbm",
                          "achieved": spmv_bytes / spmv_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": spmv_bytes / spmv_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": spmv_bytes, "us_per_launch": spmv_s * 1e6},
+                         "algorithmic_bytes_per_launch": spmv_bytes, "us_per_launch": spmv_s * 1e6,
+                         # for comparison, SURVEY 8d's plain BSR figure (4-byte column ids, x read once, y written once, here in fp64):
+                         # it leaves out what this fused launch also streams (own r and 1/diag for the merged sums, the low part of
+                         # the diagonal blocks) and what it saves (16-bit column differences)
+                         "survey_bsr_bytes_per_launch": (g.num_blocks() * 40.0 + (len(v) + 1) * 4.0 + 3.0 * len(v) * 16.0) if shard is None else None},
         }
     if dist_mode and world > 1 and not args.no_field:
         def allreduce(x, op):
