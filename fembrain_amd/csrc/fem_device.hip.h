@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
     const int* ci = sv.colidx + (size_t)so * 64 + lane;
     const short* cd = C16 ? sv.coldelta + (size_t)so * 64 + lane : nullptr;
     double y0 = 0, y1 = 0, y2 = 0;
-#pragma unroll 4
+#pragma unroll 2  // measured at 1M tets: 27.4 us per iteration with 2, 27.7 with 1, 28.1 with 3, 28.25 with 4, 41 with 8 (registers)
     for (int k = 0; k < width; k++) {
       const int col = C16 ? row + (int)cd[(size_t)k * 64] : ci[(size_t)k * 64];
       const double* xp = ((XCH == 2 && col >= sv.n_owned) ? halo_in : x) + 3 * (size_t)col;
