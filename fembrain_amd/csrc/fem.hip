@@ -130,7 +130,9 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   h->split = 0;
   if (want == FB_SPMV_SPLIT || want == 0) {
     if (8 * chunk <= kMaxPartials) h->split = 4;
-    else if (8 * ceil_div(chunk, 2) <= kMaxPartials) h->split = 2;
+    // two wavefronts per slice still pay up to ~1,700 slices (us per iteration, split vs rows: 17.5 / 18.1 at 1,158 slices,
+    // 19.1 / 19.5 at 1,521, 23.1 / 22.1 at 1,954); an explicit FB_SPMV_SPLIT is honoured up to the partial-sum limit
+    else if (8 * ceil_div(chunk, 2) <= kMaxPartials && (want == FB_SPMV_SPLIT || P.n_slices <= 1700)) h->split = 2;
   }
   h->sgrid = h->split == 4 ? 8 * chunk : (h->split == 2 ? 8 * ceil_div(chunk, 2) : h->grid);
   {
