@@ -38,8 +38,36 @@ def _lib():
     lib.orc_cube_table.argtypes = [_bp, _bp]
     lib.orc_vertex_attribs.argtypes = tree + [_fp, _ip, _up, _bp, _up, _fp, _fp]
     lib.orc_cell_elements.argtypes = [_bp, _ip, _bp, _bp, _up, _up, _bp, _up]
+    lib.orc_set_field_mode.argtypes = [C.c_int, C.c_int, _fp]
+    lib.orc_cl_has_route.argtypes = [C.c_int, _fp]
     lib._field_bound = True
     return lib
+
+
+FIELD_CPU, FIELD_CPU_BOX, FIELD_OPENCL = 0, 1, 2
+
+
+class field_mode:
+    """``with field_mode(FIELD_OPENCL): ...`` -- every oracle field evaluation inside follows that reference path (see the
+    header of field_oracle.c); FIELD_CPU_BOX needs the blob's primitive boxes (``blob.prim_boxes``, n x 6)."""
+
+    def __init__(self, mode, blob=None):
+        self.mode, self.blob = mode, blob
+
+    def __enter__(self):
+        box = None
+        if self.mode == FIELD_CPU_BOX:
+            box = np.ascontiguousarray(self.blob.prim_boxes, np.float32).reshape(-1, 6)
+        _lib().orc_set_field_mode(self.mode, 0 if box is None else len(box), None if box is None else _f(box))
+        return self
+
+    def __exit__(self, *a):
+        _lib().orc_set_field_mode(FIELD_CPU, 0, None)
+
+
+def cl_has_route(blob):
+    ops = np.ascontiguousarray(blob.ops, np.float32)
+    return bool(_lib().orc_cl_has_route(blob.n_ops, _f(ops))) if blob.n_ops else True
 
 
 def cube_table():

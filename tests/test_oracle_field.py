@@ -190,3 +190,77 @@ def test_color_walk_known_answers():
     lone = make_tree([a])
     lone.prims[0, 16:19] = ca
     assert np.array_equal(OrcPoly(lone).field_color_array(pts)[1], np.tile(ca, (3, 1)))
+
+
+# ---- the reference's own shipped polygonizer outputs (tests/golden/surface_*.npz, from data/models/blobtree/*.veg) ----
+SURFACE_FIXTURES = ("tumor", "peanut", "dumbel", "dumbelclose", "eggshell")
+
+
+def _fixture_check(pos, g, bbox_lo):
+    """every vertex, in the reference's output order, to the 6 significant digits the .veg files print; the grid origin
+    sits on the fixture's lattice"""
+    want = g["vertices"]
+    assert len(pos) == len(want), (len(pos), len(want))
+    tol = 6e-6 * np.maximum(1.0, np.abs(want))
+    assert (np.abs(pos - want) <= tol).all(), np.abs(pos - want).max()
+    r = (np.asarray(bbox_lo, np.float64) - g["lattice_phase"]) / float(g["cellsize"])
+    assert np.abs(r - np.rint(r)).max() * float(g["cellsize"]) < 2e-5
+
+
+def test_opencl_mode_reproduces_every_shipped_surface_vertex_in_order():
+    from oracle.pyfield import FIELD_OPENCL, field_mode
+    for name in SURFACE_FIXTURES:
+        g = np.load(os.path.join(GOLD, "surface_%s.npz" % name))
+        blob = read_blob(os.path.join(GOLD, "blob", name + ".blob"))
+        with field_mode(FIELD_OPENCL):
+            o = OrcPoly(blob)
+            o.sweep(float(g["cellsize"]))
+            o.classify()
+            pos, nrm, tri = o.surface()
+        _fixture_check(pos, g, blob.bbox[0])
+        surface_mesh_checks(pos, nrm, tri, smooth=False)
+
+
+def test_which_reference_path_wrote_the_shipped_files():
+    """tumor.blob (one range BLEND) is the same surface in every mode without the box cull; the four two-primitive trees are
+    reproduced ONLY by the OpenCL kernel's evaluation (binary operator evaluated as operator type := operator index,
+    data/opencl/Polygonizer.cl:825), neither by the CPU semantics nor by the CPU path's primitive box cull."""
+    from oracle.pyfield import FIELD_CPU, FIELD_CPU_BOX, FIELD_OPENCL, field_mode
+    match = {}
+    for name in SURFACE_FIXTURES:
+        g = np.load(os.path.join(GOLD, "surface_%s.npz" % name))
+        blob = read_blob(os.path.join(GOLD, "blob", name + ".blob"))
+        for mode in (FIELD_CPU, FIELD_CPU_BOX, FIELD_OPENCL):
+            with field_mode(mode, blob):
+                o = OrcPoly(blob)
+                o.sweep(float(g["cellsize"]))
+                o.classify()
+                pos, _, _ = o.surface()
+            want = g["vertices"]
+            match[name, mode] = len(pos) == len(want) and bool((np.abs(pos - want) <= 6e-6 * np.maximum(1.0, np.abs(want))).all())
+    assert all(match[n, FIELD_OPENCL] for n in SURFACE_FIXTURES)
+    assert match["tumor", FIELD_CPU] and not match["tumor", FIELD_CPU_BOX]
+    for n in ("peanut", "dumbel", "dumbelclose", "eggshell"):
+        assert not match[n, FIELD_CPU] and not match[n, FIELD_CPU_BOX]
+
+
+def test_opencl_mode_semantics():
+    from oracle.pyfield import FIELD_OPENCL, cl_has_route, field_mode
+    pts = [(0, (0.0, 0, 0), (0, 0, 0), (0, 0, 0)), (0, (0.6, 0, 0), (0, 0, 0), (0, 0, 0)), (0, (0, 0.6, 0), (0, 0, 0), (0, 0, 0))]
+    q = np.array([[0.3, 0.1, 0, 0]], np.float32)
+    single = [OrcPoly(make_tree([p])).field_array(q)[0, 3] for p in pts]
+    with field_mode(FIELD_OPENCL):
+        # operator 0 is evaluated as type 0 = UNION whatever it says (Polygonizer.cl:825)
+        for optype in (0, 1, 2, 3, 4, 5):
+            assert OrcPoly(make_tree(pts[:2], [(optype, 0, 1, 0, 0, 0)])).field_array(q)[0, 3] == max(single[0], single[1])
+        # range operators are evaluated by their own type (ComputeRangeField): blend sums, union is a max fold, intersection
+        # a min fold from 0, everything else 0
+        assert OrcPoly(make_tree(pts, [(4, 0, 2, 4, 0, 0)])).field_array(q)[0, 3] == (single[0] + single[1]) + single[2]
+        assert OrcPoly(make_tree(pts, [(0, 0, 2, 4, 0, 0)])).field_array(q)[0, 3] == max(single)
+        assert OrcPoly(make_tree(pts, [(1, 0, 2, 4, 0, 0)])).field_array(q)[0, 3] == 0.0
+        assert OrcPoly(make_tree(pts, [(2, 0, 2, 4, 0, 0)])).field_array(q)[0, 3] == 0.0
+        # no operators: primitive 0 only (ComputeField :884)
+        assert OrcPoly(make_tree(pts)).field_array(q)[0, 3] == single[0]
+    # LinearBlobTree::setTraversalRoute never ends on an operator with two operator children
+    assert cl_has_route(read_blob(os.path.join(GOLD, "blob", "CylinderWithHoles.blob")))
+    assert not cl_has_route(read_blob(os.path.join(GOLD, "blob", "complex.blob")))
