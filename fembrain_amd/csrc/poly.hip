@@ -16,7 +16,16 @@
 // range operators SUM their primitives, and the running `outField` is carried from one operator to the next
 // exactly as that code does.  Not reproduced (documented in DESIGN.md): its all-SIMD-lanes-outside bounding-box
 // cull (depends on the host SIMD width), the rsqrt+Newton approximation (1/sqrt here), the rational pow of the
-// Ricci blend (powf here); instanced primitives evaluate to 0 as in data/opencl/Polygonizer.cl:505-531.
+// Ricci blend (powf here).
+//
+// Field semantics are a property of the handle (fb_poly_set_field_semantics), compiled into the kernels as a template
+// parameter so that the default path is untouched:
+//   SEM_CPU (default)  the CPU path as described above, without computePrimitiveField's primitive box cull
+//   SEM_CPU_BOX        the same WITH that cull (isOutsidePrim, Polygonizer.cpp:1485-1505,1548-1552), tested per point
+//   SEM_OPENCL         the OpenCL kernel's evaluation (data/opencl/Polygonizer.cl:483-886) -- the path that wrote the .veg
+//                      files the reference ships: binary operators evaluated by ComputeOpField(operator INDEX, ..) (:825),
+//                      range operators by their own type, instanced nodes 0, over the `next` links of
+//                      LinearBlobTree::setTraversalRoute (LinearBlobTree.cpp:333-429)
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -37,11 +46,15 @@ enum PrimType { primPoint, primLine, primCylinder, primDisc, primRing, primCube,
 enum OpType { opUnion, opIntersect, opDif, opSmoothDif, opBlend, opRicciBlend, opGradientBlend, opFastQuadricPointSet, opCache,
               opWarpTwist, opWarpTaper, opWarpBend, opWarpShear };
 enum OpFlags { ofRightChildIsOp = 1, ofLeftChildIsOp = 2, ofChildIndexIsRange = 4, ofIsUnaryOp = 8, ofIsRightOp = 16, ofBreak = 32 };
+enum { SEM_CPU = FB_FIELD_CPU, SEM_CPU_BOX = FB_FIELD_CPU_BOX, SEM_OPENCL = FB_FIELD_OPENCL };
+constexpr int kNullBlob = 0xFFFF;         // NULL_BLOB, LinearBlobTree.h:18
+constexpr int kZeroOperand = -0x7fffffff;  // OpenCL program: an operand register that still holds its initial 0.0f
 
 // one step of the compiled evaluation order.  Values live in numbered slots of a per-thread LDS column; the running
 // field `out` and the query point are registers.
 struct Instr {
   int kind;    // 0 RANGE: out += prims a..b.  1 OP.  2 ENTER an instanced subtree.  3 LEAVE it.  4 ADDSLOT: out += slot a
+               // OpenCL program (SEM_OPENCL) only: 5 CL_RANGE: out = fold of prims a..b by optype.  6 CL_OP: out = op(a, b)
   int a, b;    // OP: left / right operand, >= 0 primitive index, < 0 slot -1-k.  ENTER: a = matrix node, b = first of the
                // 5 frame slots (x, y, z, out, inside).  LEAVE: a = frame slots
   int optype;  // OP only
@@ -50,6 +63,7 @@ struct Instr {
   int skip;    // ENTER: index of the matching LEAVE (taken when the mapped point is outside the box)
   int ca, cb;  // colour pass: OP: primitive whose colour a primitive operand carries (an instance of a primitive shows the
                // original's colour).  ADDSLOT: ca = primitive whose colour weighs the slot, cb = 1 if the slot REPLACES the colour
+               // ENTER: ca = the instance primitive itself (its own box is tested under SEM_CPU_BOX)
   float p0, p1;
   float lo[3], hi[3];  // ENTER: box of the original operator (isOutsideOp, Polygonizer.cpp:1464-1483)
 };
@@ -68,12 +82,23 @@ __device__ __forceinline__ float wyvill(float dd) {
   return fmaxf(0.0f, (t * t) * t);  // Polygonizer.h:519-529
 }
 
-// computePrimitiveField (Polygonizer.cpp:1544-1908), scalar fp32, no bounding-box cull
-__device__ __forceinline__ float prim_field(const float* __restrict__ prims, const float* __restrict__ mtx, int i, float pX, float pY, float pZ) {
+__device__ __forceinline__ bool in_box(const float* __restrict__ b, float x, float y, float z) {  // isOutsidePrim / isOutsideOp: inclusive bounds
+  return x >= b[0] && b[3] >= x && y >= b[1] && b[4] >= y && z >= b[2] && b[5] >= z;
+}
+
+// computePrimitiveField (Polygonizer.cpp:1544-1908), scalar fp32.  SEM_CPU: no bounding-box cull.  SEM_CPU_BOX: 0 outside
+// the primitive's box (cbox: lo, hi per primitive), tested with the incoming point at every level of an instance chain.
+// SEM_OPENCL: ComputePrimitiveField of the kernel (Polygonizer.cl:483-695) -- instanced nodes are 0, a quadric point falls
+// through to the Wyvill value outside its radius.
+template <int SEM>
+__device__ __forceinline__ float prim_field_t(const float* __restrict__ prims, const float* __restrict__ mtx, const float* __restrict__ cbox, int i,
+                                              float pX, float pY, float pZ) {
   const float* P = prims + 20 * i;
   int type = (int)P[0];
   float x = pX, y = pY, z = pZ;
+  if (SEM == SEM_OPENCL && type == primInstance) return 0.0f;  // Polygonizer.cl:505-531
   for (int hop = 0;; hop++) {
+    if (SEM == SEM_CPU_BOX && !in_box(cbox + 6 * i, x, y, z)) return 0.0f;
     const int im = (int)P[1];
     if (im != 0) {
       const float* m = mtx + 12 * im;
@@ -85,7 +110,8 @@ __device__ __forceinline__ float prim_field(const float* __restrict__ prims, con
     // an instance of a PRIMITIVE is that primitive at the mapped point (Polygonizer.cpp:1879-1901); instances of
     // operators never get here: compile_tree expands them into ENTER .. LEAVE blocks
     if (__builtin_expect(type != primInstance, 1) || hop == 8 || (int)P[14] != 0) break;
-    P = prims + 20 * (int)P[12];
+    i = (int)P[12];
+    P = prims + 20 * i;
     type = (int)P[0];
   }
   const float posX = P[4], posY = P[5], posZ = P[6];
@@ -160,6 +186,10 @@ __device__ __forceinline__ float prim_field(const float* __restrict__ prims, con
     case primQuadricPoint: {
       const float dX = x - posX, dY = y - posY, dZ = z - posZ;
       dist2 = dX * dX + dY * dY + dZ * dZ;
+      if (SEM == SEM_OPENCL) {  // Polygonizer.cl:672-683
+        if (dirZ > dist2) return dist2 * dist2 * resX + dist2 * resY + resZ;
+        break;
+      }
       return dirZ > dist2 ? (dist2 * dist2 * resX + dist2 * resY + resZ) : 0.0f;
     }
     case primNULL:
@@ -169,6 +199,10 @@ __device__ __forceinline__ float prim_field(const float* __restrict__ prims, con
       return 0.0f;
   }
   return wyvill(dist2);
+}
+
+__device__ __forceinline__ float prim_field(const float* __restrict__ prims, const float* __restrict__ mtx, int i, float pX, float pY, float pZ) {
+  return prim_field_t<SEM_CPU>(prims, mtx, nullptr, i, pX, pY, pZ);
 }
 
 __device__ __forceinline__ float apply_op(int optype, float lf, float rf, float p0, float p1, float keep) {
@@ -193,45 +227,94 @@ __device__ __forceinline__ float apply_op(int optype, float lf, float rf, float 
 struct SegBox {
   float lo[3], hi[3];
   const float* pbox;  // 6 floats per primitive: support lo, hi
+  const float* cbox;  // SEM_CPU_BOX: the reference's primitive boxes (PrepareAllBoxes), 6 floats per primitive
 };
 
-template <bool CULL>
+template <bool CULL, int SEM>
 __device__ __forceinline__ float prim_val(const float* __restrict__ prims, const float* __restrict__ mtx, int i, float x, float y, float z,
                                           const SegBox& sb, int nest) {
   if (CULL && nest == 0) {  // inside an instanced subtree the point has been mapped: no culling there
     const float* b = sb.pbox + 6 * i;
     if (sb.lo[0] > b[3] || sb.hi[0] < b[0] || sb.lo[1] > b[4] || sb.hi[1] < b[1] || sb.lo[2] > b[5] || sb.hi[2] < b[2]) return 0.0f;
   }
-  return prim_field(prims, mtx, i, x, y, z);
+  return prim_field_t<SEM>(prims, mtx, sb.cbox, i, x, y, z);
+}
+
+// ---- SEM_OPENCL: the kernel's operator functions ----
+__device__ __forceinline__ float cl_op_field(int optype, float lf, float rf, float p0, float p1) {  // ComputeOpField, Polygonizer.cl:697-729
+  switch (optype) {
+    case opUnion: return fmaxf(lf, rf);
+    case opIntersect: return fminf(lf, rf);
+    case opBlend: return lf + rf;
+    case opRicciBlend: return powf(powf(lf, p0) + powf(rf, p0), p1);
+    case opDif: return fminf(lf, 1.0f - rf);
+    case opSmoothDif: return lf * (1.0f - rf);
+    default: return 0.0f;
+  }
+}
+
+// ComputeField (Polygonizer.cl:848-886) over the program compile_tree_cl wrote: the control flow of the stackless walk does
+// not depend on the field values, so it is run once on the host and leaves a straight list of CL_RANGE / CL_OP steps whose
+// operands name a primitive, a value slot or the constant 0 a register still holds.
+template <bool CULL>
+__device__ __forceinline__ float eval_field_cl(const Instr* __restrict__ prog, int n_instr, const float* __restrict__ prims,
+                                               const float* __restrict__ mtx, float x, float y, float z, float* stk, const SegBox& sb) {
+  if (n_instr == 0) return prim_val<CULL, SEM_OPENCL>(prims, mtx, 0, x, y, z, sb, 0);  // no operators: primitive 0 alone (:884)
+  float out = 0.0f;
+  for (int k = 0; k < n_instr; k++) {
+    const Instr& in = prog[k];
+    float f = 0.0f;
+    if (in.kind == 5) {  // ComputeRangeField :731-770
+      switch (in.optype) {
+        case opUnion: for (int i = in.a; i <= in.b; i++) f = fmaxf(f, prim_val<CULL, SEM_OPENCL>(prims, mtx, i, x, y, z, sb, 0)); break;
+        case opIntersect: for (int i = in.a; i <= in.b; i++) f = fminf(f, prim_val<CULL, SEM_OPENCL>(prims, mtx, i, x, y, z, sb, 0)); break;
+        case opBlend: for (int i = in.a; i <= in.b; i++) f += prim_val<CULL, SEM_OPENCL>(prims, mtx, i, x, y, z, sb, 0); break;
+        case opRicciBlend:
+          for (int i = in.a; i <= in.b; i++) f = powf(powf(f, in.p0) + powf(prim_val<CULL, SEM_OPENCL>(prims, mtx, i, x, y, z, sb, 0), in.p0), in.p1);
+          break;
+        default: break;
+      }
+    } else {
+      const int a = in.a, b = in.b;
+      const float lf = a >= 0 ? prim_val<CULL, SEM_OPENCL>(prims, mtx, a, x, y, z, sb, 0) : (a == kZeroOperand ? 0.0f : stk[(-1 - a) * kPB]);
+      const float rf = b >= 0 ? prim_val<CULL, SEM_OPENCL>(prims, mtx, b, x, y, z, sb, 0) : (b == kZeroOperand ? 0.0f : stk[(-1 - b) * kPB]);
+      f = cl_op_field(in.optype, lf, rf, in.p0, in.p1);
+    }
+    out = f;
+    stk[in.dst * kPB] = f;
+  }
+  return out;
 }
 
 // FieldComputer::fieldValue (Polygonizer.cpp:1913-2108) through the compiled order.  `stk` is this thread's
 // column of an LDS slot array [depth][kPB].
-template <bool CULL>
+template <bool CULL, int SEM>
 __device__ __forceinline__ float eval_field_t(const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
                                               const float* __restrict__ mtx, float x, float y, float z, float* stk, const SegBox& sb) {
+  if (SEM == SEM_OPENCL) return eval_field_cl<CULL>(prog, n_instr, prims, mtx, x, y, z, stk, sb);
   float out = 0.0f;
   int nest = 0;
   if (n_instr == 0) {  // no operators: blend of all primitives (:2085-2096)
-    for (int i = 0; i < n_prims; i++) out = out + prim_val<CULL>(prims, mtx, i, x, y, z, sb, nest);
+    for (int i = 0; i < n_prims; i++) out = out + prim_val<CULL, SEM>(prims, mtx, i, x, y, z, sb, nest);
     return out;
   }
   for (int k = 0; k < n_instr; k++) {
     const Instr& in = prog[k];
     switch (in.kind) {
       case 0:
-        for (int i = in.a; i <= in.b; i++) out = out + prim_val<CULL>(prims, mtx, i, x, y, z, sb, nest);
+        for (int i = in.a; i <= in.b; i++) out = out + prim_val<CULL, SEM>(prims, mtx, i, x, y, z, sb, nest);
         break;
       case 1: {
         const int a = in.a, b = in.b;
-        const float lf = a >= 0 ? prim_val<CULL>(prims, mtx, a, x, y, z, sb, nest) : stk[(-1 - a) * kPB];
+        const float lf = a >= 0 ? prim_val<CULL, SEM>(prims, mtx, a, x, y, z, sb, nest) : stk[(-1 - a) * kPB];
         float rf = 0.0f;
-        if (!in.unary) rf = b >= 0 ? prim_val<CULL>(prims, mtx, b, x, y, z, sb, nest) : stk[(-1 - b) * kPB];
+        if (!in.unary) rf = b >= 0 ? prim_val<CULL, SEM>(prims, mtx, b, x, y, z, sb, nest) : stk[(-1 - b) * kPB];
         out = apply_op(in.optype, lf, rf, in.p0, in.p1, out);
       } break;
       case 2: {  // computePrimitiveField of an operator instance: map the point, cull against the original's box
         float* f = stk + in.b * kPB;
         f[0] = x; f[kPB] = y; f[2 * kPB] = z; f[3 * kPB] = out;
+        const bool own = SEM != SEM_CPU_BOX || in_box(sb.cbox + 6 * in.ca, x, y, z);  // the instance node's own box, incoming point
         if (in.a != 0) {
           const float* m = mtx + 12 * in.a;
           const float tx = m[0] * x + m[1] * y + m[2] * z + m[3];
@@ -241,7 +324,7 @@ __device__ __forceinline__ float eval_field_t(const Instr* __restrict__ prog, in
         }
         out = 0.0f;
         nest++;
-        const bool inside = x >= in.lo[0] && in.hi[0] >= x && y >= in.lo[1] && in.hi[1] >= y && z >= in.lo[2] && in.hi[2] >= z;
+        const bool inside = own && x >= in.lo[0] && in.hi[0] >= x && y >= in.lo[1] && in.hi[1] >= y && z >= in.lo[2] && in.hi[2] >= z;
         f[4 * kPB] = inside ? 1.0f : 0.0f;
         // the program counter stays wave-uniform (scalar instruction fetch): the block is skipped only when every lane
         // is outside; a lane that is outside while a neighbour is inside runs along and gets its 0 at the LEAVE
@@ -263,18 +346,20 @@ __device__ __forceinline__ float eval_field_t(const Instr* __restrict__ prog, in
   return out;
 }
 
+template <int SEM>
 __device__ __forceinline__ float eval_field(const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
-                                            const float* __restrict__ mtx, float x, float y, float z, float* stk) {
+                                            const float* __restrict__ mtx, const float* __restrict__ cbox, float x, float y, float z, float* stk) {
   SegBox none;
   none.pbox = nullptr;
-  return eval_field_t<false>(prog, n_instr, n_prims, prims, mtx, x, y, z, stk, none);
+  none.cbox = cbox;
+  return eval_field_t<false, SEM>(prog, n_instr, n_prims, prims, mtx, x, y, z, stk, none);
 }
 
 // ---- ComputeAllFields (Polygonizer.cl:1215-1236): v = lo + cellsize*(ix,iy,iz), index iz*gx*gy + iy*gx + ix ----
-template <bool CULL>
+template <bool CULL, int SEM>
 __global__ __launch_bounds__(kPB) void k_sweep(Grid G, const Instr* __restrict__ prog, int n_instr, int n_prims, int depth,
                                                const float* __restrict__ prims, const float* __restrict__ mtx, const float* __restrict__ pbox,
-                                               float4* __restrict__ grid, unsigned long long* __restrict__ inside) {
+                                               const float* __restrict__ cbox, float4* __restrict__ grid, unsigned long long* __restrict__ inside) {
   extern __shared__ float stack[];
   // kSweepPts consecutive 256-point runs per block: every store instruction of a wave is still one contiguous 1 KiB
   // float4 segment and every ballot one aligned 64-point word of the inside mask
@@ -291,6 +376,7 @@ __global__ __launch_bounds__(kPB) void k_sweep(Grid G, const Instr* __restrict__
     // values the lanes hold anyway)
     SegBox sb;
     sb.pbox = pbox;
+    sb.cbox = cbox;
     if (CULL) {
       const long long first = gid - (threadIdx.x & 63);
       const int last_lane = __builtin_amdgcn_readfirstlane((int)min(63LL, G.n_points - 1 - first));
@@ -308,7 +394,7 @@ __global__ __launch_bounds__(kPB) void k_sweep(Grid G, const Instr* __restrict__
       const float x = G.lo[0] + G.cellsize * (float)ix;
       const float y = G.lo[1] + G.cellsize * (float)iy;
       const float z = G.lo[2] + G.cellsize * (float)(iz + (unsigned int)G.z0);
-      const float f = eval_field_t<CULL>(prog, n_instr, n_prims, prims, mtx, x, y, z, stack + threadIdx.x, sb);
+      const float f = eval_field_t<CULL, SEM>(prog, n_instr, n_prims, prims, mtx, x, y, z, stack + threadIdx.x, sb);
       if (grid) { const v4f o = {x, y, z, f}; __builtin_nontemporal_store(o, (v4f*)&grid[gid]); }  // streamed once: 49 vs 56 us
       in = f >= kIso;  // inside test of Polygonizer.cl:1367,1599 and Polygonizer.cpp:1052
     }
@@ -319,14 +405,15 @@ __global__ __launch_bounds__(kPB) void k_sweep(Grid G, const Instr* __restrict__
 }
 
 // ComputeFieldArray (Polygonizer.cl:1262-1286)
+template <int SEM>
 __global__ __launch_bounds__(kPB) void k_field_array(int n, const Instr* __restrict__ prog, int n_instr, int n_prims,
-                                                     const float* __restrict__ prims, const float* __restrict__ mtx,
+                                                     const float* __restrict__ prims, const float* __restrict__ mtx, const float* __restrict__ cbox,
                                                      float4* __restrict__ pts) {
   extern __shared__ float stack[];
   const int i = blockIdx.x * kPB + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
-  p.w = eval_field(prog, n_instr, n_prims, prims, mtx, p.x, p.y, p.z, stack + threadIdx.x);
+  p.w = eval_field<SEM>(prog, n_instr, n_prims, prims, mtx, cbox, p.x, p.y, p.z, stack + threadIdx.x);
   pts[i] = p;
 }
 
@@ -816,9 +903,10 @@ __global__ __launch_bounds__(kPB) void k_surface_lists(Grid G, long long nwords,
 
 // ComputeVertexAttribs (Polygonizer.cl:1429-1561, linear root), one lane per surface vertex: the 4 field evaluations
 // per vertex (root + forward-difference normal) are spread over full wavefronts and all stores are contiguous.
+template <int SEM>
 __global__ __launch_bounds__(kPB) void k_surface_vertices(Grid G, long long nv, const unsigned long long* __restrict__ elist,
                                                           const Instr* __restrict__ prog, int n_instr, int n_prims,
-                                                          const float* __restrict__ prims, const float* __restrict__ mtx,
+                                                          const float* __restrict__ prims, const float* __restrict__ mtx, const float* __restrict__ cbox,
                                                           const float4* __restrict__ grid, const unsigned long long* __restrict__ vinc,
                                                           const unsigned int* __restrict__ vbase, float* __restrict__ pos, float* __restrict__ nrm,
                                                           uint2* __restrict__ ends, float* __restrict__ frac) {
@@ -834,10 +922,10 @@ __global__ __launch_bounds__(kPB) void k_surface_vertices(Grid G, long long nv, 
   const float t = (kIso - va.w) / (vb.w - va.w);
   const float x = va.x + t * (vb.x - va.x), y = va.y + t * (vb.y - va.y), z = va.z + t * (vb.z - va.z);
   float* stk = stack + threadIdx.x;
-  const float f = eval_field(prog, n_instr, n_prims, prims, mtx, x, y, z, stk);
-  float gx = eval_field(prog, n_instr, n_prims, prims, mtx, x + delta, y, z, stk);
-  float gy = eval_field(prog, n_instr, n_prims, prims, mtx, x, y + delta, z, stk);
-  float gz = eval_field(prog, n_instr, n_prims, prims, mtx, x, y, z + delta, stk);
+  const float f = eval_field<SEM>(prog, n_instr, n_prims, prims, mtx, cbox, x, y, z, stk);
+  float gx = eval_field<SEM>(prog, n_instr, n_prims, prims, mtx, cbox, x + delta, y, z, stk);
+  float gy = eval_field<SEM>(prog, n_instr, n_prims, prims, mtx, cbox, x, y + delta, z, stk);
+  float gz = eval_field<SEM>(prog, n_instr, n_prims, prims, mtx, cbox, x, y, z + delta, stk);
   gx = -1.0f * (dinv * (gx - f)); gy = -1.0f * (dinv * (gy - f)); gz = -1.0f * (dinv * (gz - f));
   const float len = sqrtf(gx * gx + gy * gy + gz * gz);
   float* o = pos + 3 * (size_t)j;
@@ -995,9 +1083,10 @@ __global__ __launch_bounds__(kPB) void k_field_color_array(long long count, floa
 }
 
 // ComputeOffSurfacePointsAndFields (Polygonizer.cl:1329-1350): v +- len * normal and the field there, (x, y, z, f) pairs
+template <int SEM>
 __global__ __launch_bounds__(kPB) void k_off_surface(long long nv, float len, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                      const Instr* __restrict__ prog, int n_instr, int n_prims, const float* __restrict__ prims,
-                                                     const float* __restrict__ mtx, float4* __restrict__ out) {
+                                                     const float* __restrict__ mtx, const float* __restrict__ cbox, float4* __restrict__ out) {
   extern __shared__ float stack[];
   const long long j = (long long)blockIdx.x * kPB + threadIdx.x;
   if (j >= nv) return;
@@ -1005,8 +1094,8 @@ __global__ __launch_bounds__(kPB) void k_off_surface(long long nv, float len, co
   const float dx = len * nrm[3 * j], dy = len * nrm[3 * j + 1], dz = len * nrm[3 * j + 2];
   float* stk = stack + threadIdx.x;
   const float ox = vx + dx, oy = vy + dy, oz = vz + dz, ix = vx - dx, iy = vy - dy, iz = vz - dz;
-  const float fo = eval_field(prog, n_instr, n_prims, prims, mtx, ox, oy, oz, stk);
-  const float fi = eval_field(prog, n_instr, n_prims, prims, mtx, ix, iy, iz, stk);
+  const float fo = eval_field<SEM>(prog, n_instr, n_prims, prims, mtx, cbox, ox, oy, oz, stk);
+  const float fi = eval_field<SEM>(prog, n_instr, n_prims, prims, mtx, cbox, ix, iy, iz, stk);
   out[2 * j] = make_float4(ox, oy, oz, fo);
   out[2 * j + 1] = make_float4(ix, iy, iz, fi);
 }
@@ -1042,8 +1131,10 @@ struct fb_poly_s {
   std::vector<Instr> prog;
   int depth = 1;
   DevBuf<Instr> d_prog;
-  DevBuf<float> d_prims, d_mtx, d_pbox;
+  DevBuf<float> d_prims, d_mtx, d_pbox, d_cbox;
   std::vector<float> pbox;  // support box of every primitive (support_boxes)
+  std::vector<float> cbox;  // SEM_CPU_BOX: the reference's primitive boxes, given by the caller (fb_poly_set_field_semantics)
+  int sem = SEM_CPU;
   Grid G;
   int gz_total = 0;  // point planes of the whole grid this one is a slab of (= G.g[2] for a grid of its own)
   bool have_grid = false, classified = false, tetra = false, materialized = false;
@@ -1125,7 +1216,7 @@ struct TreeCompiler {
     const int origin = (int)P[12], is_op = (int)P[14];
     Instr in;
     memset(&in, 0, sizeof in);
-    in.kind = 2; in.a = (int)P[1]; in.b = alloc(5); in.dst = -1;
+    in.kind = 2; in.a = (int)P[1]; in.b = alloc(5); in.dst = -1; in.ca = i;
     for (int a = 0; a < 3; a++) { in.lo[a] = -FLT_MAX; in.hi[a] = FLT_MAX; }
     if (is_op)
       for (int a = 0; a < 3; a++) { in.lo[a] = op(origin)[8 + a]; in.hi[a] = op(origin)[12 + a]; }
@@ -1247,7 +1338,118 @@ struct TreeCompiler {
   }
 };
 
+// LinearBlobTree::setTraversalRoute (LinearBlobTree.cpp:333-429): start operator and `next` links of the stackless walk.
+// The reference loop re-examines an operator after its operator children have been linked and pushes them again, so it
+// never ends on an operator with two operator children; that (and a malformed graph) is reported instead of spinning.
+int traversal_route(const fb_poly_s* h, std::vector<int>* next, int* start) {
+  const int n = h->n_ops;
+  next->assign(n, kNullBlob);
+  *start = kNullBlob;
+  std::vector<int> ops{0}, brk{kNullBlob};
+  auto flags = [&](int o) { return (int)h->ops[16 * (size_t)o + 7]; };
+  auto child = [&](int o, int k) { return (int)h->ops[16 * (size_t)o + 1 + k]; };
+  auto is_op_id = [&](int c) { return c >= 0 && c < n; };
+  size_t guard = 0;
+  while (!ops.empty()) {
+    if (++guard > (size_t)8 * n + 16) return fail(FB_EINVAL, "OpenCL field semantics: the reference's traversal-route builder does not terminate on this tree (an operator with two operator children)");
+    int o = ops.back(), fl = flags(o);
+    bool is_break = fl & ofBreak, lop = fl & ofLeftChildIsOp, rop = fl & ofRightChildIsOp;
+    if (!lop && !rop) {
+      if (brk.empty()) return fail(FB_EINVAL, "OpenCL field semantics: no traversal route (operator %d)", o);
+      ops.pop_back();
+      const int b = brk.back();
+      brk.pop_back();
+      if (b == kNullBlob) *start = o; else (*next)[b] = o;
+      if (is_break) brk.push_back(o);
+      while (!is_break && !ops.empty()) {
+        o = ops.back();
+        ops.pop_back();
+        fl = flags(o);
+        is_break = fl & ofBreak; lop = fl & ofLeftChildIsOp; rop = fl & ofRightChildIsOp;
+        if (is_break) brk.push_back(o);
+        if (lop) { if (!is_op_id(child(o, 0))) return fail(FB_EINVAL, "operator %d: bad left child", o); (*next)[child(o, 0)] = o; }
+        if (rop) { if (!is_op_id(child(o, 1))) return fail(FB_EINVAL, "operator %d: bad right child", o); (*next)[child(o, 1)] = o; }
+      }
+    } else {
+      if (lop) { if (!is_op_id(child(o, 0))) return fail(FB_EINVAL, "operator %d: bad left child", o); ops.push_back(child(o, 0)); }
+      if (rop) { if (!is_op_id(child(o, 1))) return fail(FB_EINVAL, "operator %d: bad right child", o); ops.push_back(child(o, 1)); }
+    }
+  }
+  if ((*next)[0] != kNullBlob) return fail(FB_EINVAL, "OpenCL field semantics: root operator has a next link (LinearBlobTree.cpp:408-412)");
+  for (int i = 1; i < n; i++)
+    if ((*next)[i] < 0 || (*next)[i] >= n) return fail(FB_EINVAL, "OpenCL field semantics: operator %d is not on the traversal route", i);
+  return FB_OK;
+}
+
+// SEM_OPENCL: runs ComputeField / ComputeBranchField (Polygonizer.cl:781-886) symbolically.  The kernel keeps the values of
+// finished subtrees in two registers per level (lf, rf: the outer pair of ComputeField, and the by-value copies of
+// ComputeBranchField); which register an operator reads and writes depends on flags alone.  A register holds the constant 0,
+// the value of a primitive at the query point (re-evaluated where it is read -- same value), or the result of an earlier step,
+// which then lives in a slot for as long as a register names it.
+int compile_tree_cl(fb_poly_s* h) {
+  h->prog.clear();
+  h->depth = 1;
+  if (h->n_ops == 0) return FB_OK;
+  std::vector<int> next;
+  int start = kNullBlob;
+  FB_TRY(traversal_route(h, &next, &start));
+  const int n = h->n_ops;
+  struct Val { int kind, id; };  // kind 0: constant 0, 1: primitive id, 2: slot id
+  auto ref = [](const Val& v) { return v.kind == 0 ? kZeroOperand : (v.kind == 1 ? v.id : -1 - v.id); };
+  Val OL{0, 0}, OR{0, 0}, IL{0, 0}, IR{0, 0};
+  std::vector<char> used;
+  auto new_slot = [&]() {
+    const Val* regs[4] = {&OL, &OR, &IL, &IR};
+    for (size_t k = 0; k < used.size(); k++) used[k] = 0;
+    for (auto* r : regs)
+      if (r->kind == 2) used[r->id] = 1;
+    for (size_t k = 0; k < used.size(); k++)
+      if (!used[k]) return (int)k;
+    used.push_back(1);
+    return (int)used.size() - 1;
+  };
+  size_t guard = 0;
+  for (int op = start; op != kNullBlob;) {
+    IL = OL; IR = OR;
+    int next_op = kNullBlob;
+    bool is_right = false;
+    Val field{0, 0};
+    for (int b = op; b != kNullBlob;) {
+      if (++guard > (size_t)4 * n + 16) return fail(FB_EINVAL, "OpenCL field semantics: traversal route does not end");
+      const float* o = h->ops.data() + 16 * (size_t)b;
+      const int type = (int)o[0], lc = (int)o[1], rc = (int)o[2], fl = (int)o[7];
+      next_op = next[b];
+      const bool is_break = fl & ofBreak, unary = fl & ofIsUnaryOp, range = fl & ofChildIndexIsRange, lop = fl & ofLeftChildIsOp, rop = fl & ofRightChildIsOp;
+      is_right = fl & ofIsRightOp;
+      Instr in;
+      memset(&in, 0, sizeof in);
+      in.p0 = o[4]; in.p1 = o[5];
+      if (range) {
+        if (lc < 0 || rc >= h->n_prims || lc > rc) return fail(FB_EINVAL, "operator %d: bad primitive range [%d,%d]", b, lc, rc);
+        in.kind = 5; in.optype = type; in.a = lc; in.b = rc;
+      } else {
+        if (!lop) { if (lc < 0 || lc >= h->n_prims) return fail(FB_EINVAL, "operator %d: bad left child %d", b, lc); IL = Val{1, lc}; }
+        if (!unary && !rop) { if (rc < 0 || rc >= h->n_prims) return fail(FB_EINVAL, "operator %d: bad right child %d", b, rc); IR = Val{1, rc}; }
+        in.kind = 6; in.optype = b;  // sic: ComputeOpField(idxBranchOp, ..), Polygonizer.cl:825
+        in.a = ref(IL); in.b = ref(IR);
+      }
+      in.dst = new_slot();
+      h->prog.push_back(in);
+      field = Val{2, in.dst};
+      if (is_right) IR = field; else IL = field;
+      if (is_break) break;
+      b = next_op;
+    }
+    if (is_right) OR = field; else OL = field;
+    IL = OL; IR = OR;  // the by-value copies of the finished branch are gone
+    op = next_op;
+  }
+  h->depth = std::max(1, (int)used.size());
+  return FB_OK;
+}
+
 int compile_tree(fb_poly_s* h) {
+  if (h->sem == SEM_OPENCL) return compile_tree_cl(h);
   h->prog.clear();
   h->depth = 1;
   for (int i = 0; i < h->n_prims; i++) {  // validates every instance chain, used or not
@@ -1300,11 +1502,15 @@ void support_boxes(fb_poly_s* h) {
         ball(r0 + 1.0);
         break;
       case primQuadricPoint:
+        if (h->sem == SEM_OPENCL) { ball(std::max(1.0, std::sqrt(std::max(0.0, (double)P[10])))); break; }  // Wyvill value outside the radius
         if (!(P[10] >= 0)) { empty = true; break; }
         ball(std::sqrt((double)P[10]));
         break;
       case primTriangle: case primNULL: empty = true; break;  // wyvill(FLT_MAX) = wyvill(10) = 0
-      case primLine: case primInstance: bounded = false; break;
+      case primInstance:
+        if (h->sem == SEM_OPENCL) empty = true; else bounded = false;  // the kernel returns 0 for instanced nodes
+        break;
+      case primLine: bounded = false; break;
       default: empty = true; break;                           // unknown types evaluate to 0
     }
     float* out = h->pbox.data() + 6 * (size_t)i;
@@ -1338,18 +1544,32 @@ void support_boxes(fb_poly_s* h) {
   }
 }
 
+// launches KERNEL<SEM> for the handle's field semantics
+#define FB_LAUNCH_SEM(h, KERNEL, grid, block, shmem, ...)                                                                        \
+  do {                                                                                                                           \
+    switch ((h)->sem) {                                                                                                          \
+      case SEM_CPU_BOX: hipLaunchKernelGGL((KERNEL<SEM_CPU_BOX>), grid, block, shmem, (h)->stream, __VA_ARGS__); break;           \
+      case SEM_OPENCL: hipLaunchKernelGGL((KERNEL<SEM_OPENCL>), grid, block, shmem, (h)->stream, __VA_ARGS__); break;             \
+      default: hipLaunchKernelGGL((KERNEL<SEM_CPU>), grid, block, shmem, (h)->stream, __VA_ARGS__); break;                        \
+    }                                                                                                                            \
+  } while (0)
+
 size_t stack_bytes(const fb_poly_s* h) { return (size_t)std::max(1, h->depth) * kPB * sizeof(float); }
 
 int do_sweep(fb_poly_s* h, bool store_grid) {
   const Grid& G = h->G;
   const int blocks = (int)((G.n_points + (long long)kPB * kSweepPts - 1) / ((long long)kPB * kSweepPts));
   // with one or two primitives the box test costs more than it can save (sphere at 256^3: 66 vs 50 us)
-  if (h->n_prims > 2)
-    hipLaunchKernelGGL(k_sweep<true>, dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, h->d_prog.p, (int)h->prog.size(), h->n_prims, h->depth,
-                       h->d_prims.p, h->d_mtx.p, h->d_pbox.p, store_grid ? h->grid.p : nullptr, h->inside.p);
-  else
-    hipLaunchKernelGGL(k_sweep<false>, dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, h->d_prog.p, (int)h->prog.size(), h->n_prims, h->depth,
-                       h->d_prims.p, h->d_mtx.p, h->d_pbox.p, store_grid ? h->grid.p : nullptr, h->inside.p);
+#define FB_SWEEP(CULL, SEM)                                                                                                                             \
+  hipLaunchKernelGGL((k_sweep<CULL, SEM>), dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, h->d_prog.p, (int)h->prog.size(), h->n_prims, h->depth, \
+                     h->d_prims.p, h->d_mtx.p, h->d_pbox.p, h->d_cbox.p, store_grid ? h->grid.p : nullptr, h->inside.p)
+  const bool cull = h->n_prims > 2;
+  switch (h->sem) {
+    case SEM_CPU_BOX: if (cull) FB_SWEEP(true, SEM_CPU_BOX); else FB_SWEEP(false, SEM_CPU_BOX); break;
+    case SEM_OPENCL: if (cull) FB_SWEEP(true, SEM_OPENCL); else FB_SWEEP(false, SEM_OPENCL); break;
+    default: if (cull) FB_SWEEP(true, SEM_CPU); else FB_SWEEP(false, SEM_CPU); break;
+  }
+#undef FB_SWEEP
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -1469,8 +1689,8 @@ int do_surface_emit(fb_poly_s* h) {
                      h->crossz.p, h->ebase.p, h->ibase.p, h->d_nvert.p, h->elist.p, h->tlist.p);
   FB_HIP(hipGetLastError());
   if (nv > 0) {
-    hipLaunchKernelGGL(k_surface_vertices, dim3((int)((nv + kPB - 1) / kPB)), dim3(kPB), stack_bytes(h), h->stream, G, nv, h->elist.p, h->d_prog.p,
-                       (int)h->prog.size(), h->n_prims, h->d_prims.p, h->d_mtx.p, h->grid.p, h->vinc.p, h->vbase.p, h->sv.p, h->sn.p, h->sends.p, h->sfrac.p);
+    FB_LAUNCH_SEM(h, k_surface_vertices, dim3((int)((nv + kPB - 1) / kPB)), dim3(kPB), stack_bytes(h), G, nv, h->elist.p, h->d_prog.p,
+                  (int)h->prog.size(), h->n_prims, h->d_prims.p, h->d_mtx.p, h->d_cbox.p, h->grid.p, h->vinc.p, h->vbase.p, h->sv.p, h->sn.p, h->sends.p, h->sfrac.p);
     FB_HIP(hipGetLastError());
   }
   if (ntri > 0) {
@@ -1546,6 +1766,37 @@ int fb_poly_compile_info(int n_ops, const float* ops16, int n_prims, const float
   return FB_OK;
 }
 
+int fb_poly_set_field_semantics(fb_poly_t h, int semantics, const float* prim_boxes6) {
+  CHECK_POLY(h);
+  if (semantics != SEM_CPU && semantics != SEM_CPU_BOX && semantics != SEM_OPENCL) return fail(FB_EINVAL, "unknown field semantics %d", semantics);
+  if (semantics == SEM_CPU_BOX && !prim_boxes6) return fail(FB_EINVAL, "FB_FIELD_CPU_BOX needs the primitive boxes (6 floats per primitive)");
+  FB_HIP(hipStreamSynchronize(h->stream));
+  const int old = h->sem;
+  const std::vector<Instr> old_prog = h->prog;
+  const int old_depth = h->depth;
+  h->sem = semantics;
+  int rc = compile_tree(h);
+  if (rc != FB_OK) {  // the handle keeps working with the semantics it had
+    h->sem = old; h->prog = old_prog; h->depth = old_depth;
+    return rc;
+  }
+  std::vector<Instr> prog = h->prog;
+  if (prog.empty()) prog.resize(1);
+  FB_TRY(h->d_prog.upload(prog, h->stream));
+  h->cbox.clear();
+  if (semantics == SEM_CPU_BOX) {
+    h->cbox.assign(prim_boxes6, prim_boxes6 + 6 * (size_t)h->n_prims);
+    FB_TRY(h->d_cbox.upload(h->cbox, h->stream));
+  }
+  support_boxes(h);
+  FB_TRY(h->d_pbox.upload(h->pbox, h->stream));
+  FB_HIP(hipStreamSynchronize(h->stream));
+  h->have_grid = h->classified = h->tetra = h->surfaced = false;  // results of the old semantics are void
+  return FB_OK;
+}
+
+int fb_poly_field_semantics(fb_poly_t h) { return h ? h->sem : FB_EINVAL; }
+
 int fb_poly_destroy(fb_poly_t h) {
   if (!h) return FB_OK;
   (void)hipSetDevice(h->device);
@@ -1564,8 +1815,8 @@ int fb_poly_field_array(fb_poly_t h, int n, float* xyzf) {
   if (n == 0) return FB_OK;
   DevBuf<float4> pts;
   FB_TRY(pts.upload((const float4*)xyzf, (size_t)n, h->stream));
-  hipLaunchKernelGGL(k_field_array, dim3(ceil_div(n, kPB)), dim3(kPB), stack_bytes(h), h->stream, n, h->d_prog.p, (int)h->prog.size(),
-                     h->n_prims, h->d_prims.p, h->d_mtx.p, pts.p);
+  FB_LAUNCH_SEM(h, k_field_array, dim3(ceil_div(n, kPB)), dim3(kPB), stack_bytes(h), n, h->d_prog.p, (int)h->prog.size(), h->n_prims, h->d_prims.p,
+                h->d_mtx.p, h->d_cbox.p, pts.p);
   FB_HIP(hipGetLastError());
   return pts.download((float4*)xyzf, (size_t)n, h->stream);
 }
@@ -1807,6 +2058,7 @@ int fb_poly_read_surface_colors(fb_poly_t h, float* rgba) {
   CHECK_POLY(h);
   if (!h->surfaced) return fail(FB_EINVAL, "run fb_poly_surface first");
   if (!rgba) return fail(FB_EINVAL, "null output");
+  if (h->sem != SEM_CPU) return fail(FB_EINVAL, "the colour pass is built for FB_FIELD_CPU semantics only");
   const long long nv = h->counts.n_surface_vertices;
   if (nv == 0) return FB_OK;
   const long long kChunk = 1 << 16;
@@ -1826,6 +2078,7 @@ int fb_poly_read_surface_colors(fb_poly_t h, float* rgba) {
 int fb_poly_field_color_array(fb_poly_t h, int n, float* xyzf, float* rgb) {
   CHECK_POLY(h);
   if (n < 0 || (n > 0 && (!xyzf || !rgb))) return fail(FB_EINVAL, "bad point array");
+  if (h->sem != SEM_CPU) return fail(FB_EINVAL, "the colour pass is built for FB_FIELD_CPU semantics only");
   if (n == 0) return FB_OK;
   DevBuf<float4> pts;
   DevBuf<float> scratch, col;
@@ -1847,8 +2100,8 @@ int fb_poly_off_surface(fb_poly_t h, float len, float* xyzf_pairs) {
   if (nv == 0) return FB_OK;
   DevBuf<float4> out;
   FB_TRY(out.alloc((size_t)(2 * nv)));
-  hipLaunchKernelGGL(k_off_surface, dim3((int)((nv + kPB - 1) / kPB)), dim3(kPB), stack_bytes(h), h->stream, nv, len, h->sv.p, h->sn.p, h->d_prog.p,
-                     (int)h->prog.size(), h->n_prims, h->d_prims.p, h->d_mtx.p, out.p);
+  FB_LAUNCH_SEM(h, k_off_surface, dim3((int)((nv + kPB - 1) / kPB)), dim3(kPB), stack_bytes(h), nv, len, h->sv.p, h->sn.p, h->d_prog.p,
+                (int)h->prog.size(), h->n_prims, h->d_prims.p, h->d_mtx.p, h->d_cbox.p, out.p);
   FB_HIP(hipGetLastError());
   return out.download((float4*)xyzf_pairs, (size_t)(2 * nv), h->stream);
 }

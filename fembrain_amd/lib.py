@@ -128,6 +128,8 @@ def lib():
         "fb_poly_create": (C.c_int, [C.POINTER(vp), C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp]),
         "fb_poly_destroy": (C.c_int, [vp]),
         "fb_poly_field_array": (C.c_int, [vp, C.c_int, _fp]),
+        "fb_poly_set_field_semantics": (C.c_int, [vp, C.c_int, _fp]),
+        "fb_poly_field_semantics": (C.c_int, [vp]),
         "fb_poly_sweep": (C.c_int, [vp, C.c_float, _ip]),
         "fb_poly_sweep_grid": (C.c_int, [vp, _fp, C.c_float, _ip]),
         "fb_poly_read_grid": (C.c_int, [vp, _fp]),

@@ -14,6 +14,8 @@ from .blobtree import BlobTree, read_blob, sphere_blob  # noqa: F401
 
 
 MESH_SURFACE, MESH_TET = 0, 1
+# which of the reference's two field evaluations a handle follows (fembrain_hip.h: fb_poly_set_field_semantics)
+FIELD_CPU, FIELD_CPU_BOX, FIELD_OPENCL = 0, 1, 2
 
 
 def cube_table():
@@ -47,6 +49,17 @@ class GpuPoly:
             self.close()
         except Exception:
             pass
+
+    def set_field_semantics(self, semantics):
+        """FIELD_CPU (default), FIELD_CPU_BOX (CPU path with its primitive box cull; boxes from the reader) or FIELD_OPENCL
+        (the OpenCL kernels' evaluation -- what the reference's shipped .veg outputs were made with)."""
+        box = None
+        if semantics == FIELD_CPU_BOX:
+            if self.blob.prim_boxes is None:
+                raise ValueError("FIELD_CPU_BOX needs the primitive boxes of the reader (BlobTree.prim_boxes)")
+            box = np.ascontiguousarray(self.blob.prim_boxes, dtype=np.float32).reshape(-1, 6)
+        _l.check(self._L.fb_poly_set_field_semantics(self.h, semantics, None if box is None else _l.fptr(box)))
+        self.counts = self.dims = None
 
     # GPUPoly::computeFieldArray / FieldComputer::field(n, 4, xyzf)
     def compute_field_array(self, xyzf):

@@ -399,6 +399,9 @@ inline bool readBlobFile(const char* path, LinearBlobTreeData& out, std::string*
     O[11] = O[15] = 1.0f;
   }
   out.mtx = R.inv;
+  out.primBoxes.assign(6 * pb.size(), 0.0f);
+  for (size_t i = 0; i < pb.size(); i++)
+    for (int a = 0; a < 3; a++) { out.primBoxes[6 * i + a] = pb[i].lo[a]; out.primBoxes[6 * i + 3 + a] = pb[i].hi[a]; }
   return true;
 }
 

@@ -25,6 +25,8 @@ struct LinearBlobTreeData {
   std::vector<float> ops;     // 16 per operator
   std::vector<float> prims;   // 20 per primitive
   std::vector<float> mtx;     // 12 per matrix node (index 0 = identity)
+  std::vector<float> primBoxes;  // optional, 6 per primitive (lo, hi): PrepareAllBoxes' primitive boxes (BlobReader.h fills them);
+                                 // only FB_FIELD_CPU_BOX reads them
   int countPrimitives() const { return (int)(prims.size() / 20); }
   int countOperators() const { return (int)(ops.size() / 16); }
   int countMtxNodes() const { return (int)(mtx.size() / 12); }
@@ -44,9 +46,17 @@ class GPUPoly {
   bool setBlob(const LinearBlobTreeData& blob) {
     fb_poly_destroy(h_);
     h_ = nullptr;
+    m_primBoxes = blob.primBoxes.size() == 6 * (size_t)blob.countPrimitives() ? blob.primBoxes : std::vector<float>();
     return fb_poly_create(&h_, m_device, blob.header.data(), blob.countOperators(), blob.ops.data(), blob.countPrimitives(), blob.prims.data(),
                           blob.countMtxNodes(), blob.mtx.data()) == FB_OK;
   }
+  // Which of the reference's two field evaluations to follow (fembrain_hip.h: fb_poly_set_field_semantics): FB_FIELD_CPU
+  // (default), FB_FIELD_CPU_BOX (needs blob.primBoxes at setBlob time) or FB_FIELD_OPENCL -- what the OpenCL GPUPoly this
+  // class replaces computes, operator-index defect included.
+  bool setFieldSemantics(int semantics) {
+    return fb_poly_set_field_semantics(h_, semantics, m_primBoxes.empty() ? nullptr : m_primBoxes.data()) == FB_OK;
+  }
+  int fieldSemantics() const { return fb_poly_field_semantics(h_); }
   void setCellSize(float c) { m_cellsize = c; }
   float cellsize() const { return m_cellsize; }
 
@@ -184,6 +194,7 @@ class GPUPoly {
  private:
   fb_poly_t h_;
   float m_cellsize;
+  std::vector<float> m_primBoxes;
   int m_device;
   fb_poly_counts m_counts;
 };

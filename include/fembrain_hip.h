@@ -220,6 +220,29 @@ int fb_poly_create(fb_poly_t* out, int device, const float* header12, int n_ops,
                    int n_prims, const float* prims20, int n_mtx, const float* mtx12);
 int fb_poly_destroy(fb_poly_t h);
 
+/* Which of the reference's field evaluations the handle follows (the reference has two that disagree):
+ *   FB_FIELD_CPU      (default) FieldComputer::fieldValue / computePrimitiveField (implicit/Polygonizer.cpp:1544-2108) without
+ *                     its primitive bounding-box cull: range operators sum, binary operators act by their type, instanced
+ *                     nodes are evaluated.
+ *   FB_FIELD_CPU_BOX  the same WITH computePrimitiveField's isOutsidePrim cull (Polygonizer.cpp:1485-1505,1548-1552), tested
+ *                     per point: a primitive contributes 0 outside its box.  prim_boxes6 = lo.xyz, hi.xyz per primitive as
+ *                     PrepareAllBoxes makes them (Polygonizer.cpp:210-540, offset ISO_VALUE; BlobReader.h / blobtree.py
+ *                     compute them), copied.
+ *   FB_FIELD_OPENCL   the OpenCL kernels GPUPoly actually runs (data/opencl/Polygonizer.cl:483-886): ComputeField over the
+ *                     traversal route of LinearBlobTree::setTraversalRoute (implicit/LinearBlobTree.cpp:333-429), binary
+ *                     operators through ComputeOpField(idxBranchOp, ...) -- the operator's INDEX where its type is meant
+ *                     (:825) --, range operators by their own type, instanced nodes 0.  This is the evaluation that wrote the
+ *                     reference's shipped outputs (data/models/blobtree/{tumor,peanut,dumbel,dumbelclose,eggshell}.veg): every
+ *                     surface vertex of the five files is reproduced in order (tests/golden/surface_*.npz).  FB_EINVAL for
+ *                     trees the reference's route builder cannot handle (an operator with two operator children).
+ * Takes effect for every later sweep / field / surface call; grids swept before are dropped.  On failure the handle keeps
+ * its previous semantics.  The colour pass (fb_poly_read_surface_colors, fb_poly_field_color_array) exists for FB_FIELD_CPU only. */
+#define FB_FIELD_CPU 0
+#define FB_FIELD_CPU_BOX 1
+#define FB_FIELD_OPENCL 2
+int fb_poly_set_field_semantics(fb_poly_t h, int semantics, const float* prim_boxes6);
+int fb_poly_field_semantics(fb_poly_t h);
+
 /* GPUPoly::computeFieldArray / FieldComputer::field(n,4,xyzf) (OclPolygonizer.cpp:943-986): xyzf is n*4 floats,
  * .w overwritten with the field value */
 int fb_poly_field_array(fb_poly_t h, int n, float* xyzf);

@@ -17,7 +17,7 @@ int main(int argc, char** argv) {
   if (!std::strcmp(argv[1], "blob")) {
     PS::SKETCH::LinearBlobTreeData d;
     if (!PS::SKETCH::readBlobFile(argv[2], d, &err)) { std::printf("ERROR %s\n", err.c_str()); return 1; }
-    dump("header", d.header); dump("ops", d.ops); dump("prims", d.prims); dump("mtx", d.mtx);
+    dump("header", d.header); dump("ops", d.ops); dump("prims", d.prims); dump("mtx", d.mtx); dump("pbox", d.primBoxes);
     return 0;
   }
   std::vector<double> v;

@@ -102,7 +102,7 @@ def test_cpp_blob_and_veg_readers_match_the_python_readers(tmp_path):
         out = subprocess.check_output([exe, "blob", f], text=True)
         arr = {ln.split()[0]: np.array(ln.split()[2:], dtype=np.float32) for ln in out.strip().splitlines()}
         b = read_blob(f)
-        for name, want in (("header", b.header), ("ops", b.ops), ("prims", b.prims), ("mtx", b.mtx)):
+        for name, want in (("header", b.header), ("ops", b.ops), ("prims", b.prims), ("mtx", b.mtx), ("pbox", np.array(b.prim_boxes))):
             want = np.asarray(want, np.float32).reshape(-1)
             assert arr[name].shape == want.shape, (f, name)
             assert np.allclose(arr[name], want, rtol=2e-6, atol=2e-6), (f, name, np.abs(arr[name] - want).max())

@@ -637,3 +637,176 @@ def test_slab_argument_checks(gpu):
     with pytest.raises(fl.FbError):
         g.slab_counts(5, 4, 4)                            # last owned layer 8 needs plane 10
     assert g.slab_counts(5, 3, 3)[1] % 6 == 0
+
+
+# ---- field semantics (fb_poly_set_field_semantics): the OpenCL kernels' evaluation and the CPU path's primitive box cull ----------
+SURFACE_FIXTURES = (("tumor", 1138), ("peanut", 436), ("dumbel", 698), ("dumbelclose", 626), ("eggshell", 816))
+
+
+@pytest.mark.parametrize("name,n_vertices", SURFACE_FIXTURES)
+def test_shipped_reference_surfaces_through_the_c_abi(gpu, name, n_vertices):
+    """The reference ships the outputs of its own GPU polygonizer for five models (data/models/blobtree/*.veg; the leading
+    vertices are the marching-cubes surface, tests/golden/make_surface_golden.py).  With FB_FIELD_OPENCL the HIP path gives
+    every one of those vertices, in the reference's order, to the 6 digits the files print -- and is bit-identical to the
+    oracle in the same mode."""
+    from fembrain_amd.poly import FIELD_OPENCL
+    from oracle.pyfield import FIELD_OPENCL as ORC_OPENCL, field_mode
+    gold = np.load(os.path.join(GOLD, "surface_%s.npz" % name))
+    blob = read_blob(os.path.join(GOLD, "blob", name + ".blob"))
+    cs = float(gold["cellsize"])
+    g = GpuPoly(blob)
+    g.set_field_semantics(FIELD_OPENCL)
+    g.sweep(cs)
+    g.classify()
+    g.surface()
+    pos, nrm, tri = g.read_surface()
+    want = gold["vertices"]
+    assert len(pos) == len(want) == n_vertices
+    assert (np.abs(pos - want) <= 6e-6 * np.maximum(1.0, np.abs(want))).all(), np.abs(pos - want).max()
+    r = (blob.bbox[0].astype(np.float64) - gold["lattice_phase"]) / cs   # the grid origin sits on the file's lattice
+    assert np.abs(r - np.rint(r)).max() * cs < 2e-5
+    with field_mode(ORC_OPENCL):
+        o = OrcPoly(blob)
+        o.sweep(cs)
+        o.classify()
+        opos, onrm, otri = o.surface()
+    assert np.array_equal(tri, otri) and np.array_equal(pos, opos) and np.abs(nrm - onrm).max() <= 1e-6
+    surface_mesh_checks(pos, nrm, tri, smooth=False)
+    g.close()
+
+
+def _chain_tree(rng, n_levels):
+    """random tree the OpenCL traversal route exists for: a chain of binary / unary operators, each with at most one operator
+    child (left or right), ending in a binary or range operator over primitives; flags as ModelReader sets them"""
+    from fembrain_amd.blobtree import NULL_BLOB, BlobTree
+    P, ops = [], []
+
+    def prim():
+        p = np.zeros(20)
+        p[0] = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 7, 8]))
+        p[4:7] = rng.uniform(-0.6, 0.6, 3)
+        d = rng.normal(size=3)
+        p[8:11] = d / np.linalg.norm(d)
+        if p[0] == 1:
+            p[8:11] = p[4:7] + p[8:11] * 0.6
+        p[12:15] = [rng.uniform(0.1, 0.5), rng.uniform(0.2, 0.9), 0.0]
+        if p[0] == 7:
+            r = rng.uniform(0.5, 1.0)
+            p[8:11] = [1.0, r, r * r]
+            p[12:15] = [1.0 / r ** 4, -2.0 / r ** 2, 1.0]
+        p[16:20] = [*rng.uniform(0, 1, 3), 1]
+        P.append(p)
+        return len(P) - 1
+
+    for lvl in range(n_levels):
+        o = {"type": int(rng.choice([0, 1, 2, 3, 4, 5])), "lc": 0, "rc": 0, "flags": 0, "res": [0.0, 0.0]}
+        if o["type"] == 5:
+            o["res"] = [2.0, 0.5]
+        ops.append(o)
+    for i, o in enumerate(ops):
+        last = i == n_levels - 1
+        if last:
+            if rng.random() < 0.5:
+                first = prim()
+                lastp = first
+                for _ in range(int(rng.integers(1, 4))):
+                    lastp = prim()
+                o.update(lc=first, rc=lastp, flags=4)
+            else:
+                o.update(lc=prim(), rc=prim())
+        elif rng.random() < 0.2:   # unary warp over the next operator
+            o.update(type=int(rng.choice([9, 10, 11, 12])), lc=i + 1, flags=8 | 2)
+        elif rng.random() < 0.5:
+            o.update(lc=i + 1, rc=prim(), flags=2)
+        else:
+            o.update(lc=prim(), rc=i + 1, flags=1)
+            ops[i + 1]["flags"] |= 16   # ofIsRightOp (ReadSceneModel.cpp:486)
+    O = np.zeros((len(ops), 16), np.float32)
+    for i, o in enumerate(ops):
+        O[i, 0:4] = [o["type"], o["lc"], o["rc"], NULL_BLOB]
+        O[i, 4:6], O[i, 7] = o["res"], o["flags"]
+        O[i, 8:11], O[i, 12:15] = -50.0, 50.0
+    header = np.zeros(12, np.float32)
+    header[0:3], header[3], header[4:7], header[7] = -1.5, 1, 1.5, 1
+    header[8:12] = [len(P), len(ops), 1, NULL_BLOB]
+    return BlobTree(header, O, np.array(P, np.float32), np.eye(4, dtype=np.float32)[:3].reshape(1, 12))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_opencl_semantics_match_oracle_on_random_chains(gpu, seed):
+    from fembrain_amd.poly import FIELD_CPU, FIELD_OPENCL
+    from oracle.pyfield import FIELD_OPENCL as ORC_OPENCL, cl_has_route, field_mode
+    rng = np.random.default_rng(7000 + seed)
+    blob = _chain_tree(rng, 1 + seed % 5)
+    assert cl_has_route(blob)
+    g = GpuPoly(blob)
+    pts = np.zeros((4000, 4), np.float32)
+    pts[:, :3] = rng.uniform(-1.6, 1.6, size=(4000, 3)).astype(np.float32)
+    cpu_before = g.compute_field_array(pts)[:, 3]
+    g.set_field_semantics(FIELD_OPENCL)
+    with field_mode(ORC_OPENCL):
+        o = OrcPoly(blob)
+        want = o.field_array(pts)[:, 3]
+        og = o.sweep_grid((-1.5, -1.5, -1.5), 0.1, (31, 30, 29))
+    got = g.compute_field_array(pts)[:, 3]
+    assert np.isfinite(want).all()
+    assert np.abs(got - want).max() <= 4e-6 * max(1.0, np.abs(want).max())
+    g.sweep_grid((-1.5, -1.5, -1.5), 0.1, (31, 30, 29))
+    grid = g.read_grid()
+    assert np.array_equal(g.compute_field_array(grid)[:, 3], grid[:, 3])  # culled sweep kernel == unculled point kernel
+    assert np.abs(grid[:, 3] - og[:, 3]).max() <= 4e-6 * max(1.0, np.abs(og[:, 3]).max())
+    # and back: the default semantics are what they were
+    g.set_field_semantics(FIELD_CPU)
+    assert np.array_equal(g.compute_field_array(pts)[:, 3], cpu_before)
+    assert np.abs(cpu_before - OrcPoly(blob).field_array(pts)[:, 3]).max() <= 4e-6 * max(1.0, np.abs(cpu_before).max())
+    g.close()
+
+
+def test_opencl_semantics_refuse_trees_the_reference_route_builder_cannot_walk(gpu):
+    from fembrain_amd import lib as fl
+    from fembrain_amd.poly import FIELD_OPENCL
+    blob = read_blob(os.path.join(GOLD, "blob", "complex.blob"))   # operators with two operator children
+    g = GpuPoly(blob)
+    pts = np.zeros((100, 4), np.float32)
+    pts[:, :3] = np.random.default_rng(5).uniform(-1, 1, (100, 3))
+    before = g.compute_field_array(pts)
+    with pytest.raises(fl.FbError, match="traversal"):
+        g.set_field_semantics(FIELD_OPENCL)
+    assert np.array_equal(g.compute_field_array(pts), before)   # the handle kept its semantics
+    # colours exist for the default semantics only
+    g2 = GpuPoly(read_blob(os.path.join(GOLD, "blob", "tumor.blob")))
+    g2.set_field_semantics(FIELD_OPENCL)
+    with pytest.raises(fl.FbError, match="colour"):
+        g2.field_color_array(pts)
+    g.close(); g2.close()
+
+
+@pytest.mark.parametrize("name", ["tumor", "ventricle", "complex", "peanutInstanced", "pizaL2P4", "peanut"])
+def test_cpu_box_cull_semantics_match_oracle(gpu, name):
+    """FB_FIELD_CPU_BOX = the CPU path with computePrimitiveField's isOutsidePrim cull, per point, boxes from the reader
+    (PrepareAllBoxes).  It changes values (a primitive's box is tighter than its support), which is why it is a mode."""
+    from fembrain_amd.poly import FIELD_CPU_BOX
+    from oracle.pyfield import FIELD_CPU_BOX as ORC_BOX, field_mode
+    blob = read_blob(os.path.join(GOLD, "blob", name + ".blob"))
+    lo, hi = blob.bbox
+    rng = np.random.default_rng(11)
+    pts = np.zeros((6000, 4), np.float32)
+    pts[:, :3] = rng.uniform(lo - 0.3, hi + 0.3, size=(6000, 3)).astype(np.float32)
+    g = GpuPoly(blob)
+    plain = g.compute_field_array(pts)[:, 3]
+    g.set_field_semantics(FIELD_CPU_BOX)
+    got = g.compute_field_array(pts)[:, 3]
+    cs = float((hi - lo).max()) / 40
+    dims = g.sweep(cs)
+    grid = g.read_grid()
+    with field_mode(ORC_BOX, blob):
+        o = OrcPoly(blob)
+        want = o.field_array(pts)[:, 3]
+        og = o.sweep(cs)
+    assert dims == tuple(int(x) for x in o.g)
+    tol = 4e-6 * max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() <= tol and np.abs(grid[:, 3] - og[:, 3]).max() <= tol
+    assert np.array_equal(g.compute_field_array(grid)[:, 3], grid[:, 3])
+    if name in ("tumor", "ventricle", "peanut"):
+        assert (got != plain).any()   # the cull is not a no-op on blended primitives
+    g.close()
