@@ -459,6 +459,43 @@ def test_full_size_1M_tet_properties(gpu):
     assert not dv[fixed].any()
 
 
+def test_full_size_8M_tet_properties(gpu):
+    """BASELINE config 5 mesh (111^3 nodes, 7,986,000 tets) on one GPU: the block count of SURVEY.md section 8, the
+    non-temporal SpMV with 16-bit column ids (what systems this large run) linear and symmetric, one step from rest
+    converged with the residual the reference's stopping rule asks for."""
+    n = 111
+    v, t, fixed = _cube(n)
+    assert len(t) == 7986000
+    g = FemIntegrator(v, t, fixed)
+    assert g.num_blocks() == 20220091                       # SURVEY.md section 8 table
+    assert fl.lib().fb_fem_plan_on_device(g.h) == 1
+    rng = np.random.default_rng(12)
+    assert abs(g.mass().sum() - 1000.0 * (0.1 * (n - 1)) ** 3) <= 1e-6 * 1000.0 * (0.1 * (n - 1)) ** 3
+    g.set_uniform_force(1, -10000.0)
+    K, rhs = g.system()
+    x, y = rng.normal(size=g.r), rng.normal(size=g.r)
+    Ax, Ay = g.spmv(x), g.spmv(y)
+    assert np.abs(g.spmv(2.0 * x - 3.0 * y) - (2.0 * Ax - 3.0 * Ay)).max() <= 1e-12 * np.abs(Ax).max()
+    assert abs(y @ Ax - x @ Ay) <= 1e-12 * abs(y @ Ax)
+    assert np.array_equal(Ax[fixed], x[fixed])
+    it, dv = g.pcg(rhs, eps=1e-6, max_iter=10000)
+    assert 1500 < it < 5000
+    res = rhs - g.spmv(dv)
+    bptr, bcol = g.pattern()
+    diag = np.empty(g.r)
+    isdiag = bcol == np.repeat(np.arange(len(v)), np.diff(bptr))
+    diag.reshape(-1, 3)[:] = np.stack([K[isdiag][:, k, k] for k in range(3)], 1)
+    assert (res * res / diag).sum() <= 1.5e-12 * (rhs * rhs / diag).sum()
+    assert not dv[fixed].any()
+    # and the step itself (rebuild + assembly + PCG + state update) agrees with that solve
+    g.rebuild_elements()
+    its = g.do_timestep()
+    assert abs(its - it) <= max(3, 0.02 * it)
+    q, qv, _ = g.get_q_state()
+    assert np.abs(qv - dv).max() <= 1e-6 * np.abs(dv).max()     # q_vel = 0 + dv from rest
+    g.close()
+
+
 def test_device_is_an_mi355x(gpu):
     import ctypes as C
     L = fl.lib()

@@ -133,6 +133,69 @@ def _run_sharded(world, variant, p2p, n, spmv=0):
     assert np.abs(vg - vs).max() <= 1e-5 * np.abs(vs).max()
 
 
+def _bench_worker(rank, world, shm_name, n, q):
+    """one rank of bench.py's sharded 8M-tet leg: i-plane slabs, rebuild + uniform load + one step from rest"""
+    try:
+        from fembrain_amd import lib as fl
+        from fembrain_amd.fem import FemIntegrator
+        L = fl.lib()
+        comm = C.c_void_p()
+        fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 16 << 20, 0))
+        v, t, fixed, splits = _mesh(n, world)
+        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm))
+        g.rebuild_elements()
+        g.set_uniform_force(1, -10000.0)
+        its = g.do_timestep()
+        qq = g.get_q_state()[0]
+        lo, hi = 3 * int(splits[rank]), 3 * int(splits[rank + 1])
+        q.put((rank, its, qq[lo:hi].copy(), None, lo, hi))
+        g.close()
+        L.fb_comm_destroy(comm)
+    except Exception as e:
+        q.put((rank, repr(e), None, None, 0, 0))
+        q.close()
+        q.join_thread()
+        os._exit(1)
+
+
+def test_config5_8M_tets_in_two_processes_match_the_unsharded_handle(gpu):
+    """BASELINE config 5 at size: the 111^3-node cube (7,986,000 tets) as two i-plane slabs in two processes (host-staged
+    communicator: the box has one GPU) against the unsharded handle -- the check bench.py's sharded runs do on themselves
+    before timing: first step from rest, iterations within max(3, 2 %), displacements within 2e-4 of max|q|."""
+    import multiprocessing as mp
+    from fembrain_amd.fem import FemIntegrator
+    world, n = 2, 111
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "/fembrain_test_%d_cfg5" % os.getpid()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, name, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=500))
+            assert res[-1][2] is not None, res[-1]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    v, t, fixed, _ = _mesh(n, world)
+    g = FemIntegrator(v, t, fixed)
+    g.rebuild_elements()
+    g.set_uniform_force(1, -10000.0)
+    it1 = g.do_timestep()
+    q1 = g.get_q_state()[0]
+    g.close()
+    qs = np.zeros_like(q1)
+    for rank, its, qq, _, lo, hi in res:
+        assert its == res[0][1]
+        assert abs(its - it1) <= max(3, 0.02 * it1), (its, it1)
+        qs[lo:hi] = qq
+    assert np.abs(qs - q1).max() <= 2e-4 * np.abs(q1).max()
+
+
 def test_p2p_wait_is_bounded_when_a_peer_leaves(gpu):
     """One rank exits after the collective set-up.  The survivor's exchange kernels give up at the wall-clock bound, poison
     the inbox, drain the queue, and the step returns FB_ECOMM -- no hang."""
