@@ -171,6 +171,43 @@ def field_bench_sharded(device, rank, world, allreduce):
             "field_partition": "z-slabs x%d, %d planes swept per rank for %d owned" % (world, z_count, own_planes)}
 
 
+class BenchAbort(Exception):
+    """a stage failed on some rank; every rank raises it together (agree()), rank 0 prints the line with an `error` field"""
+
+
+_state = {"out": None, "rank": 0, "printed": False, "stage": "start-up"}
+
+
+def _emit(error=None):
+    """rank 0's ONE JSON line: whatever has been measured so far, plus `error` when the run did not finish"""
+    if _state["rank"] != 0 or _state["printed"]:
+        return
+    _state["printed"] = True
+    out = dict(_state["out"] or {"metric": "FEM steps/sec (assemble+PCG) at 1M tets", "value": None, "unit": "steps/s"})
+    if error is not None:
+        out["error"] = error
+    print(json.dumps(out), flush=True)
+
+
+def _watchdog(seconds):
+    """A rank that is stuck (a collective whose partner has left) cannot agree on anything: after `seconds` without a stage
+    change it reports and leaves with a non-zero code, and the launcher tears the other ranks down.  Never restarts anything."""
+    import threading
+
+    def run():
+        last, since = None, time.time()
+        while True:
+            time.sleep(5.0)
+            if _state["printed"]:
+                return
+            if _state["stage"] != last:
+                last, since = _state["stage"], time.time()
+            elif time.time() - since > seconds:
+                _emit("stuck in stage '%s' for more than %d s on rank %d" % (last, seconds, _state["rank"]))
+                os._exit(3)
+    threading.Thread(target=run, daemon=True).start()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,18 +222,36 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    _state["rank"] = rank
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
         args.gpus = world
 
+    import signal
     import torch
     from fembrain_amd import lib as fl
     from fembrain_amd.fem import FemIntegrator
-    from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (the HIP path has no CPU fallback)")
+    # The launcher ends the other ranks with SIGTERM when one leaves: rank 0 still prints what it has, with the reason.  The
+    # main thread may sit inside a native call (a collective) where a Python-level handler never runs, so the signal is
+    # picked up from the wake-up pipe by a helper thread.
+    import threading
+    rfd, wfd = os.pipe()
+    os.set_blocking(wfd, False)
+    signal.signal(signal.SIGTERM, lambda *_: None)
+    signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+
+    def on_term():
+        while True:
+            b = os.read(rfd, 1)
+            if b and b[0] == signal.SIGTERM:
+                _emit("terminated by the launcher in stage '%s' (a peer rank failed)" % _state["stage"])
+                os._exit(4)
+    threading.Thread(target=on_term, daemon=True).start()
+    _watchdog(int(os.environ.get("FEMBRAIN_BENCH_STAGE_TIMEOUT_S", "420")))
     # FEMBRAIN_BENCH_LOCAL_COMM=1: rehearsal of the N > 1 flow on a ONE-GPU box -- every rank uses device 0, the process
     # group is gloo and the solver talks through the host-staged shared-memory communicator (RCCL refuses two ranks on
     # one device).  Numbers from this mode are meaningless; it exists to exercise the control flow.
@@ -209,17 +264,20 @@ def main():
     # FEMBRAIN_BENCH_FORCE_DIST=1 runs the one-process-per-GPU plumbing (process group, unique-id broadcast, RCCL
     # communicator, sharded handle) even at world size 1 -- the rehearsal available on a one-GPU box
     dist_mode = world > 1 or os.environ.get("FEMBRAIN_BENCH_FORCE_DIST") == "1"
+    dist = None
     if dist_mode:
         import ctypes as C
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         comm = C.c_void_p()
+        pg_timeout = datetime.timedelta(seconds=300)   # a collective whose partner has left fails instead of waiting 10 minutes
         if local_comm:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
             name = "/fembrain_bench_%s" % os.environ.get("MASTER_PORT", "0")
             fl.check(fl.lib().fb_comm_create_local(C.byref(comm), rank, world, name.encode(), 64 << 20, device))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device), timeout=pg_timeout)
             uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
                 buf = (C.c_ubyte * 128)()
@@ -228,258 +286,336 @@ def main():
             dist.broadcast(uid, 0)
             idb = (C.c_ubyte * 128)(*uid.cpu().tolist())
             fl.check(fl.lib().fb_comm_create(C.byref(comm), rank, world, idb, device))
+    tdev = "cpu" if local_comm else "cuda"
 
-    n, text = WORKLOADS[args.workload]
-    v, t, fixed = workload_mesh(args.workload, device)
-    if dist_mode:
-        # slabs of whole i-planes (node index = i*n*n + j*n + k): <= 2 neighbours per rank
-        if n:
-            planes = [n * r // world for r in range(world + 1)]
-            splits = np.array([p * n * n for p in planes], dtype=np.int32)
-        else:  # grid-ordered polygonizer mesh: equal node ranges (z slabs of the voxel grid)
-            splits = np.array([len(v) * r // world for r in range(world + 1)], dtype=np.int32)
-        shard = (world, rank, splits, comm)
-    prec = fl.FB_MATRIX_F64 if args.precision == "f64" else fl.FB_MATRIX_F32
-    g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device, shard=shard)
+    def reduce_scalar(x, op):
+        if not dist_mode:
+            return float(x)
+        tt = torch.tensor([x], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tt, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN, "sum": dist.ReduceOp.SUM}[op])
+        return float(tt.item())
+
+    def agree(ok):
+        """did this succeed on EVERY rank?  (a peer-to-peer wait that times out returns FB_ECOMM after its bounded wait)"""
+        return reduce_scalar(1.0 if ok else 0.0, "min") > 0.5
+
+    def stage(name, fn, optional=False):
+        """Runs fn on every rank, then lets the ranks agree on the outcome: either all carry on with their results, or all
+        skip (optional stage: (None, reason)) / all abort (BenchAbort) TOGETHER -- no rank is left waiting in a barrier
+        for a peer that took another path."""
+        _state["stage"] = name
+        err, res = None, None
+        try:
+            res = fn()
+        except Exception as e:  # noqa: BLE001 -- whatever it is, the other ranks must learn about it
+            err = "%s: %r" % (name, e)
+        if agree(err is None):
+            return res, None
+        why = err or "%s: failed on another rank" % name
+        if optional:
+            return None, why
+        raise BenchAbort(why)
 
     def barrier():
         if dist_mode:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step():
-        g.rebuild_elements()
-        g.set_uniform_force(1, -10000.0)
-        return g.do_timestep()
+    rc = 0
+    g = None
+    try:
+        n, text = WORKLOADS[args.workload]
+        prec = fl.FB_MATRIX_F64 if args.precision == "f64" else fl.FB_MATRIX_F32
 
-    # Sharded runs: the exchange modes give bitwise identical iterates, so the fastest one ON THIS MACHINE is picked by
-    # timing one step in each (max over ranks); untimed, before the warmup.
-    xch_trials = {}
-    xch_note = None
+        def create():
+            v, t, fixed = workload_mesh(args.workload, device)
+            sh = None
+            if dist_mode:
+                # slabs of whole i-planes (node index = i*n*n + j*n + k): <= 2 neighbours per rank
+                if n:
+                    planes = [n * r // world for r in range(world + 1)]
+                    splits = np.array([p * n * n for p in planes], dtype=np.int32)
+                else:  # grid-ordered polygonizer mesh: equal node ranges (z slabs of the voxel grid)
+                    splits = np.array([len(v) * r // world for r in range(world + 1)], dtype=np.int32)
+                sh = (world, rank, splits, comm)
+            return v, t, fixed, sh, FemIntegrator(v, t, fixed, matrix_precision=prec, device=device, shard=sh)
+        (v, t, fixed, shard, g), _ = stage("create the %s handle" % args.workload, create)
 
-    def all_ok(ok):
-        """did the step succeed on EVERY rank?  (a peer-to-peer wait that times out returns FB_ECOMM after its bounded wait)"""
-        tt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cpu" if local_comm else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
-        return bool(tt.item() > 0.5)
+        def one_step(h=None):
+            h = h or g
+            h.rebuild_elements()
+            h.set_uniform_force(1, -10000.0)
+            return h.do_timestep()
 
-    def guarded_step():
-        try:
-            one_step()
-            return all_ok(True), None
-        except fl.FbError as e:
-            all_ok(False)
-            return False, str(e)
+        # Sharded runs: the exchange modes give bitwise identical iterates, so the fastest one ON THIS MACHINE is picked by
+        # timing one step in each (max over ranks); untimed, before the warmup.  A form that fails on any rank ends the trials
+        # for every rank alike and the collective library carries the run.
+        xch_trials = {}
+        xch_note = None
+        if dist_mode and g.transport() >= fl.FB_XCH_P2P and os.environ.get("FEMBRAIN_XCH_MODE") is None:
+            names = {fl.FB_XCH_COLLECTIVE: "collective", fl.FB_XCH_P2P: "p2p", fl.FB_XCH_P2P_SUMS: "p2p_sums", fl.FB_XCH_P2P_FUSED: "p2p_fused"}
+            modes = (fl.FB_XCH_P2P, fl.FB_XCH_P2P_SUMS, fl.FB_XCH_P2P_FUSED)
+            if not local_comm and os.environ.get("FEMBRAIN_BENCH_TRY_RCCL") == "1":
+                modes = (fl.FB_XCH_COLLECTIVE,) + modes   # the collective library, for the record (opt-in)
+            _, why = stage("exchange trial: first step", one_step, optional=True)
+            for mode in modes if why is None else ():
+                def trial():
+                    g.set_exchange_mode(mode)
+                    barrier()
+                    ts = time.perf_counter()
+                    one_step()
+                    barrier()
+                    return time.perf_counter() - ts
+                dt_trial, why = stage("exchange trial: %s" % names[mode], trial, optional=True)
+                if why is not None:
+                    break
+                xch_trials[names[mode]] = reduce_scalar(dt_trial, "max") * 1e3
+            if why is None:
+                best = min(xch_trials, key=xch_trials.get)
+                g.set_exchange_mode({vv: k for k, vv in names.items()}[best])
+            else:
+                # a peer-to-peer form failed on some rank (its inbox is poisoned from then on): the collective library carries
+                # the rest of the run, on every rank alike, and the line says so
+                xch_note = "peer-to-peer exchange failed in the trial step (%s); fell back to the collective library" % why
+                g.set_exchange_mode(fl.FB_XCH_COLLECTIVE)
+            g.reset_to_rest()   # the timed steps start from the same state as the one-GPU run's
+        # Sharded runs check themselves before anything is timed: the first step from rest, gathered over the ranks, against
+        # the same step of an UNSHARDED handle on rank 0's GPU (iteration count within max(3, 2 %), displacements within 2e-4
+        # of max|q| -- the tolerance of the parity tests for two solves that both stop at a 1e-6 residual; the same check runs
+        # under pytest at 8M tets: tests/test_sharded_gpu.py).  If a peer-to-peer form fails the check, the collective library
+        # takes over and is checked the same way; if that fails too the run aborts: a wrong solver is not timed.
+        sharded_check = None
+        if dist_mode and os.environ.get("FEMBRAIN_BENCH_NO_CHECK") != "1":
+            def reference_step():
+                if rank != 0:
+                    return None
+                g1 = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device)
+                it_ref = one_step(g1)
+                q_ref = g1.get_q_state()[0]
+                g1.close()
+                return it_ref, q_ref
+            ref, _ = stage("self-check: unsharded reference step on rank 0", reference_step)
 
-    if dist_mode and g.transport() >= fl.FB_XCH_P2P and os.environ.get("FEMBRAIN_XCH_MODE") is None:
-        names = {fl.FB_XCH_COLLECTIVE: "collective", fl.FB_XCH_P2P: "p2p", fl.FB_XCH_P2P_SUMS: "p2p_sums", fl.FB_XCH_P2P_FUSED: "p2p_fused"}
-        modes = (fl.FB_XCH_P2P, fl.FB_XCH_P2P_SUMS, fl.FB_XCH_P2P_FUSED)
-        if not local_comm and os.environ.get("FEMBRAIN_BENCH_TRY_RCCL") == "1":
-            modes = (fl.FB_XCH_COLLECTIVE,) + modes   # the collective library, for the record (opt-in: RCCL with N > 1 could not
-            #                                           be rehearsed on the one-GPU development box)
-        ok, why = guarded_step()
-        for mode in modes if ok else ():
-            g.set_exchange_mode(mode)
-            barrier()
-            ts = time.perf_counter()
-            ok, why = guarded_step()
-            if not ok:
-                break
-            barrier()
-            tt = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cpu" if local_comm else "cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            xch_trials[names[mode]] = float(tt.item()) * 1e3
-        if ok:
-            best = min(xch_trials, key=xch_trials.get)
-            g.set_exchange_mode({v: k for k, v in names.items()}[best])
-        else:
-            # a peer-to-peer form failed on some rank (its inbox is poisoned from then on): the collective library carries
-            # the rest of the run, on every rank alike, and the line says so
-            xch_note = "peer-to-peer exchange failed in the trial step (%s); fell back to the collective library" % (why or "on another rank")
-            g.set_exchange_mode(fl.FB_XCH_COLLECTIVE)
-        g.reset_to_rest()   # the timed steps start from the same state as the one-GPU run's
-    # Sharded runs check themselves before anything is timed: the first step from rest, gathered over the ranks, against
-    # the same step of an UNSHARDED handle on rank 0's GPU (iteration count within max(3, 2 %), displacements within 2e-4
-    # of max|q| -- the tolerance of the parity tests for two solves that both stop at a 1e-6 residual).  If a peer-to-peer
-    # form fails the check, the collective library takes over and is checked the same way.
-    sharded_check = None
-    if dist_mode and os.environ.get("FEMBRAIN_BENCH_NO_CHECK") != "1":
-        ref = None
-        if rank == 0:
-            g1 = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device)
-            g1.rebuild_elements()
-            g1.set_uniform_force(1, -10000.0)
-            it_ref = g1.do_timestep()
-            ref = (it_ref, g1.get_q_state()[0])
-            g1.close()
-        dist.barrier()   # the other ranks wait HERE for rank 0's reference step, not inside a bounded peer-to-peer wait
+            def check_once():
+                g.reset_to_rest()
+                its, why = stage("self-check: sharded step", one_step, optional=True)
+                q = g.get_q_state()[0] if why is None else np.zeros(g.r)
+                tq = torch.from_numpy(q.copy()).to(tdev)
+                dist.all_reduce(tq, op=dist.ReduceOp.SUM)   # every rank fills its owned range only
+                res = {"ok": False, "error": why} if why is not None else None
+                good = 0.0
+                if rank == 0 and why is None:
+                    qa = tq.cpu().numpy()
+                    diff = float(np.abs(qa - ref[1]).max() / np.abs(ref[1]).max())
+                    res = {"iterations_sharded": int(its), "iterations_one_gpu": int(ref[0]), "max_rel_diff_q": diff,
+                           "ok": bool(abs(its - ref[0]) <= max(3, 0.02 * ref[0]) and diff <= 2e-4)}
+                    good = 1.0 if res["ok"] else 0.0
+                return reduce_scalar(good, "max") > 0.5, res
 
-        def check_once():
-            g.reset_to_rest()
-            ok, why = guarded_step()
-            its = g.last.cg_iterations if ok else -1
-            q = g.get_q_state()[0] if ok else np.zeros(g.r)
-            tq = torch.from_numpy(q.copy())
-            if not local_comm:
-                tq = tq.cuda()
-            dist.all_reduce(tq, op=dist.ReduceOp.SUM)   # every rank fills its owned range only
-            res = {"ok": False, "error": why} if not ok else None
-            good = torch.zeros(1, dtype=torch.float64, device=tq.device)
-            if rank == 0 and ok:
-                qa = tq.cpu().numpy()
-                diff = float(np.abs(qa - ref[1]).max() / np.abs(ref[1]).max())
-                res = {"iterations_sharded": int(its), "iterations_one_gpu": int(ref[0]), "max_rel_diff_q": diff,
-                       "ok": bool(abs(its - ref[0]) <= max(3, 0.02 * ref[0]) and diff <= 2e-4)}
-                good[0] = 1.0 if res["ok"] else 0.0
-            dist.broadcast(good, src=0)
-            return bool(good.item() > 0.5), res
-
-        passed, sharded_check = check_once()
-        if not passed and g.transport() >= fl.FB_XCH_P2P:
-            first = sharded_check
-            xch_note = ((xch_note + "; ") if xch_note else "") + "the peer-to-peer exchange failed the self-check, the collective library took over"
-            g.set_exchange_mode(fl.FB_XCH_COLLECTIVE)
             passed, sharded_check = check_once()
-            if rank == 0 and sharded_check is not None:
-                sharded_check["peer_to_peer_attempt"] = first
-        g.reset_to_rest()
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    t0 = time.perf_counter()
-    iters, asm_s, solve_s = [], 0.0, 0.0
-    for _ in range(args.steps):
-        iters.append(one_step())
-        asm_s += g.last.assembly_seconds
-        solve_s += g.last.solve_seconds
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist_mode:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if local_comm else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+            if not passed and g.transport() >= fl.FB_XCH_P2P:
+                first = sharded_check
+                xch_note = ((xch_note + "; ") if xch_note else "") + "the peer-to-peer exchange failed the self-check, the collective library took over"
+                g.set_exchange_mode(fl.FB_XCH_COLLECTIVE)
+                passed, sharded_check = check_once()
+                if rank == 0 and sharded_check is not None:
+                    sharded_check["peer_to_peer_attempt"] = first
+            if not passed:
+                _state["out"] = {"metric": "FEM steps/sec (assemble+PCG) at 1M tets", "value": None, "unit": "steps/s", "n_gpus": world,
+                                 "config": {"sharded_self_check": sharded_check, "exchange_note": xch_note}}
+                raise BenchAbort("the sharded solver failed its self-check against the unsharded handle")
+            g.reset_to_rest()
 
-    # dominant kernel: the PCG SpMV.  Average launch duration measured with HIP events on the handle's stream.
-    spmv_s = g.time_spmv(200)
-    spmv_bytes = g.spmv_bytes()
-    asm_k_s = g.time_assembly(10)
-    halo_s, sum_s = g.time_exchange(200) if dist_mode else (0.0, 0.0)
-    k0_s = g.time_element_stiffness(3)
-    resync_ms = None
-    if not dist_mode:  # Deformable::syncForceModel after a cut: host plan (pattern, SELL, contribution lists) + upload + rest state
-        ts = time.perf_counter()
-        g.resync(v, t, fixed)
-        torch.cuda.synchronize()
-        resync_ms = (time.perf_counter() - ts) * 1e3
-    out = None
-    if rank == 0:
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "spmv_pmc.json")
-        if os.path.exists(pmc) and args.workload == "cube56" and world == 1 and args.precision == "f32":
+        def timed():
+            for _ in range(args.warmup):
+                one_step()
+            barrier()
+            t0 = time.perf_counter()
+            iters, asm_s, solve_s = [], 0.0, 0.0
+            for _ in range(args.steps):
+                iters.append(one_step())
+                asm_s += g.last.assembly_seconds
+                solve_s += g.last.solve_seconds
+            barrier()
+            return time.perf_counter() - t0, iters, asm_s, solve_s
+        (dt, iters, asm_s, solve_s), _ = stage("warm-up and timed steps", timed)
+        dt = reduce_scalar(dt, "max")
+
+        # The trajectory above continues a loaded dynamic simulation, so its iteration counts depend on --warmup / --steps.
+        # Beside it: the same step from the SAME state every time (reset to rest before each timed step; only the step is timed).
+        def fixed_state():
+            tot, its = 0.0, []
+            for _ in range(args.steps):
+                g.reset_to_rest()
+                barrier()
+                ts = time.perf_counter()
+                its.append(one_step())
+                barrier()
+                tot += time.perf_counter() - ts
+            return tot, its
+        fs, fs_why = stage("steps from the rest state", fixed_state, optional=True)
+        fixed_dt, fixed_iters = (reduce_scalar(fs[0], "max"), fs[1]) if fs else (None, None)
+
+        def probes():
+            # dominant kernel: the PCG SpMV.  Average launch duration measured with HIP events on the handle's stream.
+            spmv_s = g.time_spmv(200)
+            asm_k_s = g.time_assembly(10)
+            halo_s, sum_s = g.time_exchange(200) if dist_mode else (0.0, 0.0)
+            k0_s = g.time_element_stiffness(3)
+            resync_ms = None
+            if not dist_mode:  # Deformable::syncForceModel after a cut: plan (pattern, SELL, contribution lists) + rest state
+                ts = time.perf_counter()
+                g.resync(v, t, fixed)
+                torch.cuda.synchronize()
+                resync_ms = (time.perf_counter() - ts) * 1e3
+            return spmv_s, g.spmv_bytes(), asm_k_s, halo_s, sum_s, k0_s, resync_ms
+        (spmv_s, spmv_bytes, asm_k_s, halo_s, sum_s, k0_s, resync_ms), _ = stage("kernel probes", probes)
+
+        if rank == 0:
+            # HBM traffic of the dominant kernel from the PMC counters: taken from the committed profile only while the kernel
+            # sources are still the ones that were profiled (tools/summarize_profiles.py records their hash), else null
+            traffic, traffic_note = None, "no PMC profile of the current kernel sources under profiles/"
+            pmc = os.path.join(ROOT, "profiles", "spmv_pmc.json")
+            if os.path.exists(pmc) and args.workload == "cube56" and world == 1 and args.precision == "f32":
+                try:
+                    rec = json.load(open(pmc))
+                    if rec.get("kernel_source_sha256") == fl.source_sha256():
+                        traffic, traffic_note = rec.get("hbm_bytes_per_launch"), "profiles/spmv_pmc.json (same kernel sources)"
+                    else:
+                        traffic_note = "profiles/spmv_pmc.json was recorded for other kernel sources: not reported"
+                except Exception:
+                    pass
+            storage = "f64 arithmetic / f32 stored matrix" if args.precision == "f32" else "f64"
+            _state["out"] = {
+                "metric": "FEM steps/sec (assemble+PCG) at 1M tets" if args.workload == "cube56" else "FEM steps/sec (assemble+PCG)", "value": args.steps / dt, "unit": "steps/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                # the arithmetic type of the path: every product, sum and vector is fp64; only the STORED matrix values are fp32 by
+                # default (the reference stores fp64: sparseMatrix.h:352-356; the north star allows fp32 within a stated tolerance)
+                "dtype": storage, "data": "synthetic",
+                "config": {"workload": text, "nodes": int(len(v)), "tets": int(len(t)), "partition": "i-plane slabs x%d" % world, "matrix_storage": args.precision,
+                           "exchange": ["none (one GPU)", "host-staged test communicator (rehearsal)" if local_comm else "RCCL all-reduce + send/recv",
+                                        "peer-to-peer inboxes over xGMI (HIP IPC), one kernel per exchange",
+                                        "peer-to-peer inboxes, sums inside the PCG kernels",
+                                        "peer-to-peer inboxes, sums and halo values inside the PCG kernels"][g.transport()],
+                           "exchange_trials_ms_per_step": xch_trials, "exchange_note": xch_note, "sharded_self_check": sharded_check,
+                           "cg_eps": 1e-6, "cg_max_iter": 10000},
+                "cg_iterations": [int(i) for i in iters], "cg_iterations_per_step": float(np.mean(iters)),
+                "value_note": "timed steps continue the loaded simulation after the warm-up steps (trajectory); value_at_fixed_state times the same "
+                              "step from the rest state every time",
+                "value_at_fixed_state": (args.steps / fixed_dt) if fixed_dt else None,
+                "cg_iterations_at_fixed_state": [int(i) for i in fixed_iters] if fixed_iters else fs_why,
+                "assembly_ms_per_step": asm_s / args.steps * 1e3,
+                "solve_ms_per_step": solve_s / args.steps * 1e3, "us_per_cg_iteration": solve_s / max(sum(iters), 1) * 1e6,
+                "resync_ms": resync_ms,
+                # informational (north star: MFMA only for the batched 12x12 element contractions): forming every K0 = V B^T E B on the
+                # fp64 matrix cores; 2*(6*6*12 + 12*6*12) flop and 1152 B written per element.  The per-step path never forms K0.
+                "element_k0_mfma": {"us_per_pass": k0_s * 1e6, "gflops": 2592.0 * len(t) / k0_s / 1e9 if shard is None else None,
+                                    "write_gbs": 1152.0 * len(t) / k0_s / 1e9 if shard is None else None},
+                "exchange_us": {"halo_refresh": halo_s * 1e6, "global_sum_3": sum_s * 1e6},
+                "assembly_kernels_us": asm_k_s * 1e6, "assembly_gbs": g.assembly_bytes() / asm_k_s / 1e9,
+                "roofline": {"kernel": "k_spmv (SELL-64 3x3-block SpMV of the PCG)", "bound": "hbm",
+                             "achieved": spmv_bytes / spmv_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": spmv_bytes / spmv_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                             "algorithmic_bytes_per_launch": spmv_bytes, "us_per_launch": spmv_s * 1e6,
+                             # for comparison, SURVEY 8d's plain BSR figure (4-byte column ids, x read once, y written once, here in fp64):
+                             # it leaves out what this fused launch also streams (own r and 1/diag for the merged sums, the low part of
+                             # the diagonal blocks) and what it saves (16-bit column differences)
+                             "survey_bsr_bytes_per_launch": (g.num_blocks() * 40.0 + (len(v) + 1) * 4.0 + 3.0 * len(v) * 16.0) if shard is None else None},
+                "cpu_baseline": None,
+            }
+        out = _state["out"]
+        mode_used = g.transport()
+        g.close()
+        g = None
+
+        # ---- optional legs: each is entered and left by all ranks together; a failure is recorded, the headline survives ----
+        if dist_mode and world > 1 and not args.no_field:
+            fs, why = stage("field grid dealt to the ranks", lambda: field_bench_sharded(device, rank, world, reduce_scalar), optional=True)
+            if out is not None:
+                out.update(fs if fs else {"field_error": why})
+        if world == 1 and not args.no_field:
+            extra, why = stage("field bench", lambda: field_bench(device, cpu=not args.no_cpu_baseline), optional=True)
+            if out is not None:
+                out.update(extra if extra else {"field_error": why})
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            _state["stage"] = "cpu baseline"
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "FEM steps/sec (assemble+PCG) at 1M tets" if args.workload == "cube56" else "FEM steps/sec (assemble+PCG)", "value": args.steps / dt, "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            # the arithmetic type of the path: every product, sum and vector is fp64; only the STORED matrix values are fp32 by default
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": text, "nodes": int(len(v)), "tets": int(len(t)), "partition": "i-plane slabs x%d" % world, "matrix_storage": args.precision,
-                       "exchange": ["none (one GPU)", "host-staged test communicator (rehearsal)" if local_comm else "RCCL all-reduce + send/recv",
-                                    "peer-to-peer inboxes over xGMI (HIP IPC), one kernel per exchange",
-                                    "peer-to-peer inboxes, sums inside the PCG kernels",
-                                    "peer-to-peer inboxes, sums and halo values inside the PCG kernels"][g.transport()],
-                       "exchange_trials_ms_per_step": xch_trials, "exchange_note": xch_note, "sharded_self_check": sharded_check,
-                       "cg_eps": 1e-6, "cg_max_iter": 10000},
-            "cg_iterations_per_step": float(np.mean(iters)), "assembly_ms_per_step": asm_s / args.steps * 1e3,
-            "solve_ms_per_step": solve_s / args.steps * 1e3, "us_per_cg_iteration": solve_s / max(sum(iters), 1) * 1e6,
-            "resync_ms": resync_ms,
-            # informational (north star: MFMA only for the batched 12x12 element contractions): forming every K0 = V B^T E B on the
-            # fp64 matrix cores; 2*(6*6*12 + 12*6*12) flop and 1152 B written per element.  The per-step path never forms K0.
-            "element_k0_mfma": {"us_per_pass": k0_s * 1e6, "gflops": 2592.0 * len(t) / k0_s / 1e9 if shard is None else None,
-                                "write_gbs": 1152.0 * len(t) / k0_s / 1e9 if shard is None else None},
-            "exchange_us": {"halo_refresh": halo_s * 1e6, "global_sum_3": sum_s * 1e6},
-            "assembly_kernels_us": asm_k_s * 1e6, "assembly_gbs": g.assembly_bytes() / asm_k_s / 1e9,
-            "roofline": {"kernel": "k_spmv (SELL-64 3x3-block SpMV of the PCG)", "bound": "hbm",
-                         "achieved": spmv_bytes / spmv_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": spmv_bytes / spmv_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": spmv_bytes, "us_per_launch": spmv_s * 1e6,
-                         # for comparison, SURVEY 8d's plain BSR figure (4-byte column ids, x read once, y written once, here in fp64):
-                         # it leaves out what this fused launch also streams (own r and 1/diag for the merged sums, the low part of
-                         # the diagonal blocks) and what it saves (16-bit column differences)
-                         "survey_bsr_bytes_per_launch": (g.num_blocks() * 40.0 + (len(v) + 1) * 4.0 + 3.0 * len(v) * 16.0) if shard is None else None},
-        }
-    if dist_mode and world > 1 and not args.no_field:
-        def allreduce(x, op):
-            tt = torch.tensor([x], dtype=torch.float64, device="cpu" if local_comm else "cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
-            return float(tt.item())
-        try:
-            fs = field_bench_sharded(device, rank, world, allreduce)
-        except Exception as e:  # the headline line must survive
-            fs = {"field_error": repr(e)}
-        if out is not None:
-            out.update(fs)
-    if world == 1 and not args.no_field:
-        extra = field_bench(device, cpu=not args.no_cpu_baseline)
-        if out is not None:
-            out.update(extra)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline((v, t, fixed), int(round(np.mean(iters))))
-        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-    elif rank == 0:
-        out["cpu_baseline"] = None
-    mode_used = g.transport()
-    g.close()
-    # BASELINE config 5 in the same run: the 8M-tet cube (111^3 nodes) on the same ranks, 1 warm-up + 2 timed steps, so that
-    # the N = 1, 2, 4, 8 runs of this script also give the 8M-tet strong-scaling series of the north star.  Reported
-    # under "cube111"; never part of `value`.
-    if args.workload == "cube56" and os.environ.get("FEMBRAIN_BENCH_SKIP_8M") != "1":
-        big = None
-        try:
-            n8 = WORKLOADS["cube111"][0]
-            v8, t8, fixed8 = workload_mesh("cube111", device)
-            shard8 = None
-            if dist_mode:
-                planes = [n8 * r // world for r in range(world + 1)]
-                shard8 = (world, rank, np.array([p * n8 * n8 for p in planes], dtype=np.int32), comm)
-            g8 = FemIntegrator(v8, t8, fixed8, matrix_precision=prec, device=device, shard=shard8)
-            if dist_mode and mode_used != g8.transport() and g8.transport() >= fl.FB_XCH_P2P:
-                g8.set_exchange_mode(mode_used)   # the form picked (or fallen back to) above
+                out["cpu_baseline"] = cpu_baseline((v, t, fixed), int(round(np.mean(iters))))
+                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline_error"] = repr(e)
+        # BASELINE config 5 in the same run: the 8M-tet cube (111^3 nodes) on the same ranks, 1 warm-up + 2 timed steps, so that
+        # the N = 1, 2, 4, 8 runs of this script also give the 8M-tet strong-scaling series of the north star.  Reported
+        # under "cube111"; never part of `value`.  Every stage of the leg is agreed on by all ranks.
+        if args.workload == "cube56" and os.environ.get("FEMBRAIN_BENCH_SKIP_8M") != "1":
+            big, g8 = None, None
 
-            def step8():
-                g8.rebuild_elements()
-                g8.set_uniform_force(1, -10000.0)
-                return g8.do_timestep()
-            step8()
-            barrier()
-            ts = time.perf_counter()
-            it8, solve8 = [], 0.0
-            for _ in range(2):
-                it8.append(step8())
-                solve8 += g8.last.solve_seconds
-            barrier()
-            dt8 = time.perf_counter() - ts
-            if dist_mode:
-                tt = torch.tensor([dt8], dtype=torch.float64, device="cpu" if local_comm else "cuda")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt8 = float(tt.item())
-            big = {"workload": WORKLOADS["cube111"][1], "tets": int(len(t8)), "steps": 2, "warmup": 1, "value": 2 / dt8, "unit": "steps/s",
-                   "ms_per_step": dt8 / 2 * 1e3, "cg_iterations_per_step": float(np.mean(it8)), "us_per_cg_iteration": solve8 / max(sum(it8), 1) * 1e6,
-                   "spmv_gbs": (g8.spmv_bytes() / g8.time_spmv(50) / 1e9) if not dist_mode else None}
-            g8.close()
-        except Exception as e:  # the headline line must survive whatever happens here
-            big = {"error": repr(e)}
-        if out is not None:
-            out["cube111"] = big
-    if dist_mode:
-        fl.lib().fb_comm_destroy(comm)
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
+            def create8():
+                n8 = WORKLOADS["cube111"][0]
+                v8, t8, fixed8 = workload_mesh("cube111", device)
+                shard8 = None
+                if dist_mode:
+                    planes = [n8 * r // world for r in range(world + 1)]
+                    shard8 = (world, rank, np.array([p * n8 * n8 for p in planes], dtype=np.int32), comm)
+                h8 = FemIntegrator(v8, t8, fixed8, matrix_precision=prec, device=device, shard=shard8)
+                return h8, len(t8)
+            made, why = stage("8M-tet leg: create", create8, optional=True)
+            if made:
+                g8, ntets8 = made
+                if dist_mode and mode_used != g8.transport() and g8.transport() >= fl.FB_XCH_P2P:
+                    g8.set_exchange_mode(mode_used)   # collective; the form picked (or fallen back to) above
+                _, why = stage("8M-tet leg: warm-up step", lambda: one_step(g8), optional=True)
+            if made and why is None:
+                def timed8():
+                    barrier()
+                    ts = time.perf_counter()
+                    it8, solve8 = [], 0.0
+                    for k8 in range(2):
+                        if os.environ.get("FEMBRAIN_BENCH_INJECT_FAILURE") == "8m" and rank == world - 1 and k8 == 1:
+                            raise RuntimeError("injected failure (rehearsal of the failure path)")
+                        it8.append(one_step(g8))
+                        solve8 += g8.last.solve_seconds
+                    barrier()
+                    return time.perf_counter() - ts, it8, solve8
+                res8, why = stage("8M-tet leg: timed steps", timed8, optional=True)
+                if res8:
+                    dt8 = reduce_scalar(res8[0], "max")
+                    it8, solve8 = res8[1], res8[2]
+                    spmv8 = None
+                    if not dist_mode:
+                        try:
+                            spmv8 = g8.spmv_bytes() / g8.time_spmv(50) / 1e9
+                        except Exception:  # noqa: BLE001
+                            pass
+                    big = {"workload": WORKLOADS["cube111"][1], "tets": int(ntets8), "steps": 2, "warmup": 1, "value": 2 / dt8, "unit": "steps/s",
+                           "ms_per_step": dt8 / 2 * 1e3, "cg_iterations": [int(i) for i in it8], "cg_iterations_per_step": float(np.mean(it8)),
+                           "us_per_cg_iteration": solve8 / max(sum(it8), 1) * 1e6, "spmv_gbs": spmv8}
+            if g8 is not None:
+                g8.close()
+            if out is not None:
+                out["cube111"] = big if big else {"error": why}
+    except BenchAbort as e:
+        rc = 1
+        _emit(str(e))
+    except Exception as e:  # noqa: BLE001 -- outside any agreed stage: report and leave non-zero, the launcher ends the peers
+        rc = 2
+        _emit("%s (stage '%s', rank %d)" % (repr(e), _state["stage"], rank))
+    if rc == 0:
+        _state["stage"] = "shutdown"
+        if g is not None:
+            g.close()
+        if dist_mode:
+            fl.lib().fb_comm_destroy(comm)
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001 -- nothing is measured after this point
+                pass
+        _emit()
+    sys.stdout.flush()
+    if rc != 0:
+        os._exit(rc)   # do not wait in destructors for peers that may be gone
 
 
 if __name__ == "__main__":

@@ -5,11 +5,15 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 
 #include "common.h"
+#include "../../include/fembrain_hip_testing.h"
 
 namespace {
 
@@ -83,7 +87,10 @@ int load_rccl() {
 // the stream, stages through a POSIX shared-memory segment and meets the peers at a process barrier.  Same call
 // sequence and data movement as the RCCL path (fixed rank-order sums, owner-grouped halo segments), none of its speed.
 constexpr int kLocalMaxRanks = 8;
+constexpr unsigned int kLocalMagic = 0xFB10CA1u;
 struct LocalShm {
+  std::atomic<unsigned int> magic;  // set last by rank 0: the segment is initialised
+  std::atomic<int> poison;          // a rank failed or gave up waiting, or rank 0 of a LATER run found this segment: leave
   std::atomic<int> count;
   std::atomic<int> sense;
   double scal[kLocalMaxRanks][8];
@@ -96,18 +103,43 @@ struct LocalComm {
   LocalShm* shm = nullptr;
   size_t map_bytes = 0;
   int local_sense = 0;
+  double timeout_s = 20.0;
   std::string name;
   char* outbox(int r) const { return (char*)(shm + 1) + (size_t)r * shm->outbox_bytes; }
 };
 
-void local_barrier(LocalComm* L, int n_ranks) {
+double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+// sense-reversing barrier with a wall-clock bound: a peer that left (or a segment a later run has taken over) ends the wait
+// with FB_ECOMM and poisons the segment, so every other rank leaves its own wait at once instead of spinning for ever
+int local_barrier(LocalComm* L, int n_ranks) {
+  if (L->shm->poison.load()) return fb::fail(FB_ECOMM, "local transport: a peer rank failed (segment %s is poisoned)", L->name.c_str());
   L->local_sense ^= 1;
   if (L->shm->count.fetch_add(1) == n_ranks - 1) {
     L->shm->count.store(0);
     L->shm->sense.store(L->local_sense);
-  } else {
-    while (L->shm->sense.load() != L->local_sense) usleep(20);
+    return FB_OK;
   }
+  const double deadline = now_s() + L->timeout_s;
+  while (L->shm->sense.load() != L->local_sense) {
+    if (L->shm->poison.load()) return fb::fail(FB_ECOMM, "local transport: a peer rank failed (segment %s is poisoned)", L->name.c_str());
+    if (now_s() > deadline) {
+      L->shm->poison.store(1);
+      return fb::fail(FB_ECOMM, "local transport: timed out after %.0f s waiting for the peer ranks", L->timeout_s);
+    }
+    usleep(20);
+  }
+  return FB_OK;
+}
+
+// an error between two barriers: tell the peers before leaving
+int local_fail(LocalComm* L, int code) {
+  L->shm->poison.store(1);
+  return code;
 }
 
 int local_allreduce(fb_comm_s* c, double* dev_buf, int count, hipStream_t s) {
@@ -117,13 +149,13 @@ int local_allreduce(fb_comm_s* c, double* dev_buf, int count, hipStream_t s) {
   FB_HIP(hipMemcpyAsync(v, dev_buf, sizeof(double) * count, hipMemcpyDeviceToHost, s));
   FB_HIP(hipStreamSynchronize(s));
   memcpy(L->shm->scal[c->rank], v, sizeof(double) * count);
-  local_barrier(L, c->n_ranks);
+  FB_TRY(local_barrier(L, c->n_ranks));
   for (int k = 0; k < count; k++) {
     double t = 0.0;
     for (int r = 0; r < c->n_ranks; r++) t += L->shm->scal[r][k];  // fixed rank order: identical on every rank
     v[k] = t;
   }
-  local_barrier(L, c->n_ranks);  // everyone has read before the slots are reused
+  FB_TRY(local_barrier(L, c->n_ranks));  // everyone has read before the slots are reused
   FB_HIP(hipMemcpyAsync(dev_buf, v, sizeof(double) * count, hipMemcpyHostToDevice, s));
   FB_HIP(hipStreamSynchronize(s));
   return FB_OK;
@@ -133,33 +165,33 @@ int local_exchange(fb_comm_s* c, const double* sendbuf, const int* send_off, dou
   LocalComm* L = (LocalComm*)c->local;
   const int n = c->n_ranks, me = c->rank;
   const size_t bytes = sizeof(double) * (size_t)width * send_off[n];
-  if (bytes > L->shm->outbox_bytes) return fb::fail(FB_EINVAL, "local transport: outbox too small (%zu > %zu)", bytes, L->shm->outbox_bytes);
-  if (bytes) FB_HIP(hipMemcpyAsync(L->outbox(me), sendbuf, bytes, hipMemcpyDeviceToHost, s));
-  FB_HIP(hipStreamSynchronize(s));
+  if (bytes > L->shm->outbox_bytes) return local_fail(L, fb::fail(FB_EINVAL, "local transport: outbox too small (%zu > %zu)", bytes, L->shm->outbox_bytes));
+  if (bytes && hipMemcpyAsync(L->outbox(me), sendbuf, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return local_fail(L, fb::fail(FB_EDEVICE, "local transport: copy to the outbox failed"));
+  if (hipStreamSynchronize(s) != hipSuccess) return local_fail(L, fb::fail(FB_EDEVICE, "local transport: stream error"));
   memcpy(L->shm->send_off[me], send_off, sizeof(int) * (n + 1));
-  local_barrier(L, n);
+  FB_TRY(local_barrier(L, n));
   for (int q = 0; q < n; q++) {
     if (q == me) continue;
     const int nr = recv_off[q + 1] - recv_off[q];
     if (nr <= 0) continue;
     const int* so = L->shm->send_off[q];
-    if (so[me + 1] - so[me] != nr) return fb::fail(FB_ECOMM, "local transport: rank %d sends %d nodes to rank %d, which expects %d", q, so[me + 1] - so[me], me, nr);
-    FB_HIP(hipMemcpyAsync(recv_base + (size_t)width * recv_off[q], L->outbox(q) + sizeof(double) * (size_t)width * so[me], sizeof(double) * (size_t)width * nr,
-                          hipMemcpyHostToDevice, s));
+    if (so[me + 1] - so[me] != nr)
+      return local_fail(L, fb::fail(FB_ECOMM, "local transport: rank %d sends %d nodes to rank %d, which expects %d", q, so[me + 1] - so[me], me, nr));
+    if (hipMemcpyAsync(recv_base + (size_t)width * recv_off[q], L->outbox(q) + sizeof(double) * (size_t)width * so[me], sizeof(double) * (size_t)width * nr,
+                       hipMemcpyHostToDevice, s) != hipSuccess)
+      return local_fail(L, fb::fail(FB_EDEVICE, "local transport: copy from the outbox failed"));
   }
-  FB_HIP(hipStreamSynchronize(s));
-  local_barrier(L, n);  // outboxes may be overwritten again
-  return FB_OK;
+  if (hipStreamSynchronize(s) != hipSuccess) return local_fail(L, fb::fail(FB_EDEVICE, "local transport: stream error"));
+  return local_barrier(L, n);  // outboxes may be overwritten again
 }
 
 int local_allgather(fb_comm_s* c, const void* mine, void* all, size_t bytes) {
   LocalComm* L = (LocalComm*)c->local;
   if (bytes > sizeof L->shm->meta[0]) return fb::fail(FB_EINVAL, "local transport: all-gather item too large");
   memcpy(L->shm->meta[c->rank], mine, bytes);
-  local_barrier(L, c->n_ranks);
+  FB_TRY(local_barrier(L, c->n_ranks));
   for (int r = 0; r < c->n_ranks; r++) memcpy((char*)all + (size_t)r * bytes, L->shm->meta[r], bytes);
-  local_barrier(L, c->n_ranks);
-  return FB_OK;
+  return local_barrier(L, c->n_ranks);
 }
 
 bool env_flag(const char* name, bool dflt) {
@@ -205,20 +237,76 @@ int fb_comm_create(fb_comm_t* out, int rank, int n_ranks, const unsigned char id
 int fb_comm_create_local(fb_comm_t* out, int rank, int n_ranks, const char* shm_name, size_t outbox_bytes, int device) {
   if (!out || !shm_name || n_ranks < 1 || n_ranks > kLocalMaxRanks || rank < 0 || rank >= n_ranks) return fb::fail(FB_EINVAL, "bad local communicator arguments");
   const size_t total = sizeof(LocalShm) + (size_t)n_ranks * outbox_bytes;
-  int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
-  if (fd < 0) return fb::fail(FB_ECOMM, "shm_open(%s) failed", shm_name);
-  if (ftruncate(fd, (off_t)total) != 0) { close(fd); return fb::fail(FB_ECOMM, "ftruncate(%s) failed", shm_name); }
-  void* p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (p == MAP_FAILED) return fb::fail(FB_ECOMM, "mmap(%s) failed", shm_name);
+  const char* te = getenv("FEMBRAIN_LOCAL_TIMEOUT_MS");
+  const double timeout_s = te ? std::max(0.1, atof(te) * 1e-3) : 20.0;
+  LocalShm* shm = nullptr;
+  if (rank == 0) {
+    // a segment of this name left by a killed run carries stale barrier state: poison it (a late rank of THIS run that has
+    // already attached to it then comes back for the new one), unlink it, and create the segment afresh
+    int old = shm_open(shm_name, O_RDWR, 0600);
+    if (old >= 0) {
+      struct stat st;
+      if (fstat(old, &st) == 0 && (size_t)st.st_size >= sizeof(LocalShm)) {
+        void* q = mmap(nullptr, sizeof(LocalShm), PROT_READ | PROT_WRITE, MAP_SHARED, old, 0);
+        if (q != MAP_FAILED) { ((LocalShm*)q)->poison.store(1); munmap(q, sizeof(LocalShm)); }
+      }
+      close(old);
+      shm_unlink(shm_name);
+    }
+    int fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) return fb::fail(FB_ECOMM, "shm_open(%s, O_EXCL) failed", shm_name);
+    if (ftruncate(fd, (off_t)total) != 0) { close(fd); shm_unlink(shm_name); return fb::fail(FB_ECOMM, "ftruncate(%s) failed", shm_name); }
+    void* p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { shm_unlink(shm_name); return fb::fail(FB_ECOMM, "mmap(%s) failed", shm_name); }
+    shm = (LocalShm*)p;  // zero-filled: count = sense = poison = 0
+    shm->outbox_bytes = outbox_bytes;
+    shm->magic.store(kLocalMagic);
+  }
   LocalComm* L = new LocalComm;
-  L->shm = (LocalShm*)p; L->map_bytes = total; L->name = shm_name;
-  L->shm->outbox_bytes = outbox_bytes;  // same value from every rank; a fresh segment is zero-filled (count = sense = 0)
+  L->map_bytes = total; L->name = shm_name; L->timeout_s = timeout_s;
+  const double deadline = now_s() + 3.0 * timeout_s;
+  for (;;) {  // the other ranks attach to the segment rank 0 made and meet it at a first barrier
+    if (rank != 0) {
+      shm = nullptr;
+      int fd = shm_open(shm_name, O_RDWR, 0600);
+      if (fd >= 0) {
+        struct stat st;
+        if (fstat(fd, &st) == 0 && (size_t)st.st_size >= total) {
+          void* p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+          if (p != MAP_FAILED) shm = (LocalShm*)p;
+        }
+        close(fd);
+      }
+      if (shm && (shm->magic.load() != kLocalMagic || shm->poison.load() || shm->outbox_bytes != outbox_bytes)) { munmap(shm, total); shm = nullptr; }
+      if (!shm) {
+        if (now_s() > deadline) { delete L; return fb::fail(FB_ECOMM, "local transport: rank 0 did not create %s in time", shm_name); }
+        usleep(2000);
+        continue;
+      }
+    }
+    L->shm = shm;
+    L->local_sense = 0;
+    if (local_barrier(L, n_ranks) == FB_OK) break;
+    // rank 0: the peers did not come.  Others: this was a stale segment that rank 0 has poisoned meanwhile -- look again.
+    if (rank == 0 || now_s() > deadline) {
+      munmap(shm, total);
+      if (rank == 0) shm_unlink(shm_name);
+      delete L;
+      return FB_ECOMM;
+    }
+    munmap(shm, total);
+  }
   fb_comm_s* c = new fb_comm_s;
   c->rank = rank; c->n_ranks = n_ranks; c->device = device; c->local = L;
   c->want_p2p = env_flag("FEMBRAIN_P2P", false);  // the test transport stays host-staged unless asked
   *out = c;
   return FB_OK;
+}
+
+int fb_comm_test_allgather(fb_comm_t c, const void* mine, void* all, size_t bytes) {
+  if (!c || !c->local || !mine || !all) return fb::fail(FB_EINVAL, "fb_comm_test_allgather needs a host-staged communicator");
+  return local_allgather(c, mine, all, bytes);
 }
 
 int fb_comm_destroy(fb_comm_t c) {
@@ -261,13 +349,17 @@ int comm_exchange_nodes(fb_comm_s* c, const double* sendbuf, const int* send_off
   if (c && c->local) return c->n_ranks == 1 ? FB_OK : local_exchange(c, sendbuf, send_off, recv_base, recv_off, width, s);
   if (!c || !c->nccl || c->n_ranks == 1) return FB_OK;
   FB_NCCL(g_rccl.GroupStart());
-  for (int q = 0; q < c->n_ranks; q++) {
+  ncclResult_t bad = ncclSuccess;  // an error inside the group must still close it
+  const char* what = "";
+  for (int q = 0; q < c->n_ranks && bad == ncclSuccess; q++) {
     if (q == c->rank) continue;
     const int ns = send_off[q + 1] - send_off[q], nr = recv_off[q + 1] - recv_off[q];
-    if (ns > 0) FB_NCCL(g_rccl.Send(sendbuf + (size_t)width * send_off[q], (size_t)width * ns, ncclFloat64, q, (ncclComm_t)c->nccl, s));
-    if (nr > 0) FB_NCCL(g_rccl.Recv(recv_base + (size_t)width * recv_off[q], (size_t)width * nr, ncclFloat64, q, (ncclComm_t)c->nccl, s));
+    if (ns > 0) { bad = g_rccl.Send(sendbuf + (size_t)width * send_off[q], (size_t)width * ns, ncclFloat64, q, (ncclComm_t)c->nccl, s); what = "ncclSend"; }
+    if (nr > 0 && bad == ncclSuccess) { bad = g_rccl.Recv(recv_base + (size_t)width * recv_off[q], (size_t)width * nr, ncclFloat64, q, (ncclComm_t)c->nccl, s); what = "ncclRecv"; }
   }
-  FB_NCCL(g_rccl.GroupEnd());
+  const ncclResult_t end = g_rccl.GroupEnd();
+  if (bad != ncclSuccess) return fail(FB_ECOMM, "%s failed: %s", what, g_rccl.GetErrorString(bad));
+  if (end != ncclSuccess) return fail(FB_ECOMM, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(end));
   return FB_OK;
 }
 

@@ -49,6 +49,19 @@ class PolyCounts(C.Structure):
                 ("n_surface_indices", C.c_int)]
 
 
+def source_sha256():
+    """Hash of the kernel sources (csrc/*.hip, *.h, *.cpp).  A profile under profiles/ records it; bench.py reports PMC traffic
+    from that profile only while the kernels are still the ones that were profiled."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
 def build(force=False):
     """Compile libfembrain_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     mk = os.path.join(_HERE, "csrc", "Makefile")
@@ -112,6 +125,7 @@ def lib():
         "fb_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _bp, C.c_int]),
         "fb_comm_destroy": (C.c_int, [vp]),
         "fb_comm_create_local": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_int]),
+        "fb_comm_test_allgather": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_size_t]),
         "fb_fem_create_from_poly": (C.c_int, [C.POINTER(vp), vp, C.c_int, _ip, C.POINTER(FemParams)]),
         "fb_fem_device_plan_get": (C.c_longlong, [vp, C.c_char_p, _ip, C.c_longlong]),
         "fb_fem_plan_on_device": (C.c_int, [vp]),

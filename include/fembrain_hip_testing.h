@@ -29,6 +29,11 @@ int fb_plan_get(fb_plan_t p, const char* name, int* out, size_t capacity);
  * run on a one-GPU box.  Every rank passes the same name, n_ranks and outbox_bytes; destroy with fb_comm_destroy. */
 struct fb_comm_s;
 int fb_comm_create_local(struct fb_comm_s** out, int rank, int n_ranks, const char* shm_name, size_t outbox_bytes, int device);
+/* Rank 0 replaces a segment of the same name left by a killed run; every wait is bounded by FEMBRAIN_LOCAL_TIMEOUT_MS
+ * (default 20000): a rank whose peers do not come gets FB_ECOMM and poisons the segment, which ends every other rank's
+ * wait at once.  fb_comm_test_allgather (host only, no device call): `bytes` (<= 512) from every rank into `all`, in rank
+ * order -- the barrier pair every collective of the transport is made of. */
+int fb_comm_test_allgather(struct fb_comm_s* c, const void* mine, void* all, size_t bytes);
 
 /* Host-only: compiles a BlobTree (operator walk order, slot allocation, expansion of instanced subtrees) exactly as
  * fb_poly_create does and reports the number of evaluation steps and of per-point value slots; needs no device.

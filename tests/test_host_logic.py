@@ -3,6 +3,7 @@ the per-rank plan (pattern, SELL-64 layout, contribution lists, halo/send lists)
 import ctypes as C
 import os
 import re
+import time
 
 import numpy as np
 import pytest
@@ -339,3 +340,69 @@ def test_c_abi_header_is_plain_c99(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
                            "-L", os.path.join(root, "fembrain_amd"), "-lfembrain_hip", "-Wl,-rpath," + os.path.join(root, "fembrain_amd")])
     assert subprocess.call([str(exe)]) == 0
+
+
+# ---- host-staged test communicator: stale segments and lost peers (no device call involved) ----------------------------------
+def _comm_worker(rank, world, name, q, behave):
+    import ctypes as C
+    os.environ["FEMBRAIN_LOCAL_TIMEOUT_MS"] = "1500"
+    from fembrain_amd import lib as fl
+    L = fl.lib()
+    comm = C.c_void_p()
+    rc = L.fb_comm_create_local(C.byref(comm), rank, world, name.encode(), 4096, 0)
+    if rc != 0:
+        q.put((rank, "create", rc))
+        return
+    mine = np.array([rank + 10], np.int64)
+    got = np.zeros(world, np.int64)
+    rcs = []
+    for k in range(3):
+        if behave == "leave" and rank == world - 1 and k == 1:
+            q.put((rank, "left", 0))
+            q.close()
+            q.join_thread()   # flush the feeder thread
+            os._exit(0)       # between two collectives, without telling anyone
+        rcs.append(L.fb_comm_test_allgather(comm, mine.ctypes.data, got.ctypes.data, 8))
+        if rcs[-1] != 0:
+            break
+    q.put((rank, rcs, got.tolist()))
+    L.fb_comm_destroy(comm)
+
+
+def _run_comm(world, name, behave):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_comm_worker, args=(r, world, name, q, behave)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = [q.get(timeout=60) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=20)
+        assert not p.is_alive()
+    return {o[0]: o[1:] for o in out}
+
+
+def test_local_communicator_replaces_a_stale_segment():
+    """a segment of the same name left by a killed run (non-zero barrier state) must not deadlock the next run"""
+    name = "/fembrain_hosttest_%d_stale" % os.getpid()
+    with open("/dev/shm" + name, "wb") as f:
+        f.write(b"\x07" * 65536)   # magic / count / sense all garbage
+    res = _run_comm(3, name, "ok")
+    for r in range(3):
+        assert res[r][0] == [0, 0, 0] and res[r][1] == [10, 11, 12], res
+    assert not os.path.exists("/dev/shm" + name)   # rank 0 unlinked it on destroy
+
+
+def test_local_communicator_bounds_its_waits_when_a_peer_leaves():
+    name = "/fembrain_hosttest_%d_leave" % os.getpid()
+    t0 = time.time()
+    res = _run_comm(3, name, "leave")
+    assert res[2][0] == "left"
+    for r in (0, 1):   # the survivors got FB_ECOMM (-5) at the second collective instead of waiting for ever
+        assert res[r][0][0] == 0 and res[r][0][-1] == -5, res
+    assert time.time() - t0 < 30
+    try:
+        os.unlink("/dev/shm" + name)
+    except FileNotFoundError:
+        pass
