@@ -50,6 +50,7 @@ struct fb_fem_s {
   CGState* st_host = nullptr;  // pinned, 2 slots
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr}, ev_batch[2] = {nullptr, nullptr};
   bool system_valid = false;
+  bool poisoned = false;  // a re-sync failed half way: the buffers no longer belong to one mesh; only a successful re-sync (or destroy) is accepted
   double last_assembly_s = 0, last_solve_s = 0;
   // one batch of 30 PCG iterations (29 merged + the exact-residual one) captured once and replayed: the launch sequence
   // and every kernel argument repeat from batch to batch, and on meshes of ~100k tets the host's launch rate, not the
@@ -735,8 +736,9 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
   return FB_OK;
 }
 
-#define CHECK_HANDLE(h)                                   \
-  if (!(h)) return fail(FB_EINVAL, "null FEM handle");   \
+#define CHECK_HANDLE(h)                                                                                                        \
+  if (!(h)) return fail(FB_EINVAL, "null FEM handle");                                                                        \
+  if ((h)->poisoned) return fail(FB_EINVAL, "handle unusable after a failed fb_fem_resync: re-sync it with a valid mesh or destroy it"); \
   FB_HIP(hipSetDevice((h)->prm.device))
 
 // global-length host vector -> local device vector (owned + halo)
@@ -872,11 +874,18 @@ int fb_fem_set_exchange_mode(fb_fem_t h, int mode) {
 }
 
 int fb_fem_resync(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed_dofs, const int* fixed_dofs) {
-  CHECK_HANDLE(h);
+  if (!h) return fail(FB_EINVAL, "null FEM handle");
+  FB_HIP(hipSetDevice(h->prm.device));
   if (!xyz || !tets) return fail(FB_EINVAL, "null mesh");
   if (h->plan.n_ranks > 1) return fail(FB_EINVAL, "resync of a sharded handle: destroy and create it again on every rank");
   FB_HIP(hipStreamSynchronize(h->stream));
-  return build(h, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs, 1, 0, nullptr);
+  // build() replaces the plan and the buffers in place; if it fails half way (a node id out of range after a bad
+  // subdivision, a flat element, no memory) the handle holds pieces of two meshes and must not step
+  h->poisoned = true;
+  h->system_valid = false;
+  FB_TRY(build(h, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs, 1, 0, nullptr));
+  h->poisoned = false;
+  return FB_OK;
 }
 
 int fb_fem_rebuild_elements(fb_fem_t h) {

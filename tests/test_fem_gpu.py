@@ -856,3 +856,32 @@ def test_resync_through_meshes_of_different_sizes(gpu):
         assert g.do_timestep() == fresh.do_timestep()
         assert np.array_equal(g.get_q_state()[0], fresh.get_q_state()[0])
         fresh.close()
+
+
+def test_failed_resync_poisons_the_handle_until_a_good_one(gpu):
+    """a re-sync that fails half way (node id out of range after a bad subdivision; a flat element) must not leave a handle
+    that steps over buffers of two meshes: every call returns an error until a valid re-sync recovers it"""
+    v, t, fixed = _cube(6)
+    g = FemIntegrator(v, t, fixed)
+    g.set_uniform_force(1, -3000.0)
+    g.do_timestep()
+    v2, t2, fixed2 = _cube(9)
+    bad = t2.copy()
+    bad[17, 2] = len(v2) + 5                      # out of range
+    with pytest.raises(fl.FbError, match="outside"):
+        g.resync(v2, bad, fixed2)
+    for call in (g.do_timestep, g.rebuild_elements, lambda: g.set_uniform_force(1, -1.0), g.get_q_state):
+        with pytest.raises(fl.FbError, match="unusable after a failed"):
+            call()
+    flat = v2.copy()
+    flat[t2[3]] = flat[t2[3, 0]]                  # a degenerate element
+    with pytest.raises(fl.FbError, match="rest volume"):
+        g.resync(flat, t2, fixed2)
+    with pytest.raises(fl.FbError, match="unusable after a failed"):
+        g.do_timestep()
+    g.resync(v2, t2, fixed2)                      # recovery
+    fresh = FemIntegrator(v2, t2, fixed2)
+    for h in (g, fresh):
+        h.set_uniform_force(1, -3000.0)
+    assert g.do_timestep() == fresh.do_timestep()
+    assert np.array_equal(g.get_q_state()[0], fresh.get_q_state()[0])
