@@ -9,6 +9,7 @@
 #include "common.h"
 #include "fem_device.hip.h"
 #include "fem_plan.h"
+#include "pcg_persist.hip.h"
 #include "plan_device.h"
 
 using namespace fb;
@@ -62,6 +63,14 @@ struct fb_fem_s {
   hipGraphExec_t batch_graph = nullptr;
   const double* graph_rhs = nullptr;
   bool use_graph = true;
+  // persistent PCG iterations (pcg_persist.hip.h): one workgroup per CU, `persist_waves` wavefronts = slices each
+  bool persist = false;
+  int persist_blocks = 0, persist_waves = 0;
+  unsigned int persist_seq = 0;
+  DevBuf<unsigned long long> persist_post;
+  DevBuf<unsigned int> persist_flags;  // [blocks padded to 4] flags, then the error word
+  DevBuf<long long> persist_timing;    // FEMBRAIN_PERSIST_TIMING=1 (development aid)
+  DevBuf<double> persist_dsoa;         // the search direction in three planes (k_persist_planes)
 };
 
 namespace {
@@ -145,6 +154,36 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   // small meshes: one 16-byte pair per thread in the merged vector pass (8.9 vs 9.3 us per iteration at 105k tets; on the 1M-tet
   // mesh the extra blocks cost more in the partial-sum prologue than they save: 29.9 vs 29.1)
   h->vgrid = h->split == 4 ? 8 * std::max(1, ceil_div(chunk * 96, kBlock)) : h->grid;
+  // Persistent iterations: unsharded handles whose slices fit one wavefront each on the CUs of the device.  Opt-in by
+  // fb_fem_params.pcg_variant = FB_PCG_PERSISTENT or FEMBRAIN_PCG_PERSIST=1 (=0 forces it off)
+  {
+    h->persist = false;
+    hipDeviceProp_t prop;
+    FB_HIP(hipGetDeviceProperties(&prop, h->prm.device));
+    const int nb = std::min(kPersistMaxBlocks, (prop.multiProcessorCount / 8) * 8);
+    const char* e = getenv("FEMBRAIN_PCG_PERSIST");
+    const bool want_p = e ? atoi(e) != 0 : h->prm.pcg_variant == FB_PCG_PERSISTENT;
+    if (want_p && nb >= 8 && P.n_ranks == 1) {
+      const int w = ceil_div(ceil_div(P.n_slices, 8), nb / 8);
+      if (w >= 1 && w <= kPersistMaxWaves) {
+        h->persist = true; h->persist_blocks = nb; h->persist_waves = w;
+        FB_TRY(h->persist_post.alloc((size_t)2 * nb * 8));
+        FB_TRY(h->persist_post.zero(s));
+        FB_TRY(h->persist_flags.alloc((size_t)nb + 8));
+        FB_TRY(h->persist_flags.zero(s));
+        h->persist_seq = 0;
+        FB_TRY(h->persist_dsoa.alloc((size_t)3 * P.n_slices * 64));
+        if (getenv("FEMBRAIN_PERSIST_TIMING")) {
+          FB_TRY(h->persist_timing.alloc((size_t)nb * kPersistMaxWaves * 5));
+          FB_TRY(h->persist_timing.zero(s));
+        }
+      } else if (h->prm.pcg_variant == FB_PCG_PERSISTENT) {
+        return fail(FB_EINVAL, "FB_PCG_PERSISTENT needs at most %d slices per CU, this mesh has %d on %d CUs", kPersistMaxWaves, w, nb);
+      }
+    } else if (h->prm.pcg_variant == FB_PCG_PERSISTENT && P.n_ranks > 1) {
+      return fail(FB_EINVAL, "FB_PCG_PERSISTENT is for unsharded handles");
+    }
+  }
   FB_TRY(h->part_a.alloc(3 * kMaxPartials));
   FB_TRY(h->part_b.alloc(kMaxPartials));
   FB_TRY(h->part_c.alloc(3 * kMaxPartials));
@@ -412,6 +451,68 @@ bool host_finished(const CGState& s) {
 // Jacobi-PCG on the assembled system, rhs b -> h->x.  iters_out: + converged / - not (CGSolver.cpp:189).
 int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state);
 
+// `n` merged iterations starting at (1-based) iteration `it`, none of them an exact-residual one, in one persistent launch
+int launch_persist(fb_fem_s* h, int it, int n) {
+  PersistArgs pa;
+  pa.post = h->persist_post.p; pa.flags = h->persist_flags.p; pa.error = h->persist_flags.p + h->persist_blocks + 4;
+  pa.seq_base = h->persist_seq; pa.first_iter = it; pa.n_iters = n;
+  static const long long ticks = (long long)((getenv("FEMBRAIN_PERSIST_TIMEOUT_MS") ? atof(getenv("FEMBRAIN_PERSIST_TIMEOUT_MS")) : 2000.0) * 1e5);  // 100 MHz
+  pa.timeout_ticks = ticks;
+  pa.timing = h->persist_timing.p;
+  pa.dsoa = h->persist_dsoa.p; pa.n_pad = (size_t)h->plan.n_slices * 64;
+  h->persist_seq += (unsigned int)n;
+  hipLaunchKernelGGL(k_persist_planes, dim3((unsigned)ceil_div((long long)pa.n_pad, (long long)kBlock)), dim3(kBlock), 0, h->stream, h->plan.n_owned, pa.n_pad,
+                     h->d.p, h->persist_dsoa.p);
+  // LDS: the sync buffers, then as many slots of every slice as fit (resident part of the matrix, fp32 storage only); the
+  // request is always more than half a CU's 160 KB, so exactly one workgroup lands on each CU
+  const size_t lds_max = 160 * 1024, sync_bytes = sizeof(double) * kPersistSyncDoubles, slot_bytes = (size_t)h->persist_waves * 10 * 64 * 4;
+  static const int want_slots = getenv("FEMBRAIN_PERSIST_LDS_SLOTS") ? atoi(getenv("FEMBRAIN_PERSIST_LDS_SLOTS")) : 64;
+  pa.lds_slots = h->f64 ? 0 : std::max(0, std::min(want_slots, (int)((lds_max - sync_bytes) / slot_bytes)));
+  const size_t lds = lds_max;
+  const dim3 grid(h->persist_blocks), block(64 * h->persist_waves);
+#define FB_PERSIST(MT, C16, KR, WMAX, KLT)                                                                                                        \
+  do {                                                                                                                                       \
+    static bool attr = false;                                                                                                                \
+    if (!attr) {                                                                                                                             \
+      FB_HIP(hipFuncSetAttribute((const void*)k_pcg_persist<MT, C16, KR, WMAX, KLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));  \
+      attr = true;                                                                                                                           \
+    }                                                                                                                                        \
+    hipLaunchKernelGGL((k_pcg_persist<MT, C16, KR, WMAX, KLT>), grid, block, lds, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, \
+                       h->invdiag.p, h->x.p, h->r.p, h->d.p, h->st.p, pa);                                                                   \
+  } while (0)
+  // register-resident slots by workgroup size: 512 registers per lane and SIMD are shared by ceil(waves / 4) wavefronts
+#define FB_PERSIST_W(MT, C16)                                                        \
+  do {                                                                               \
+    const int kl = pa.lds_slots;                                                     \
+    if (h->persist_waves <= 4) FB_PERSIST(MT, C16, 0, 4, 0);                         \
+    else if (h->persist_waves <= 8) FB_PERSIST(MT, C16, 0, 8, 0);                    \
+    else if (h->persist_waves <= 12) {                                               \
+      if (kl >= 5) { pa.lds_slots = 5; FB_PERSIST(MT, C16, 0, 12, 5); }              \
+      else if (kl >= 4) { pa.lds_slots = 4; FB_PERSIST(MT, C16, 0, 12, 4); }         \
+      else { pa.lds_slots = 0; FB_PERSIST(MT, C16, 0, 12, 0); }                      \
+    } else { pa.lds_slots = 0; FB_PERSIST(MT, C16, 0, 16, 0); }                      \
+  } while (0)
+  if (h->f64) { if (h->c16) FB_PERSIST_W(double, true); else FB_PERSIST_W(double, false); }
+  else { if (h->c16) FB_PERSIST_W(float, true); else FB_PERSIST_W(float, false); }
+#undef FB_PERSIST_W
+#undef FB_PERSIST
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+// iterations it .. it + n - 1 of the merged solver: persistent launches between the exact-residual iterations
+int pcg_run_persist(fb_fem_s* h, int it, int n, const double* b) {
+  const int end = it + n;
+  while (it < end) {
+    if (it % 30 == 0) { FB_TRY(pcg_iteration(h, it, b)); it++; continue; }
+    int stop = std::min(end, (it / 30 + 1) * 30);  // the next exact-residual iteration, or the end of the batch
+    if (const char* e = getenv("FEMBRAIN_PERSIST_MAX_RUN")) stop = std::min(stop, it + std::max(1, atoi(e)));  // test knob: cut the run into shorter launches
+    FB_TRY(launch_persist(h, it, stop - it));
+    it = stop;
+  }
+  return FB_OK;
+}
+
 int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state) {
   if (h->prm.pcg_variant == FB_PCG_FUSED) return pcg_solve_fused(h, b, eps, max_iter, iters_out, final_state);
   const FemPlan& P = h->plan;
@@ -431,7 +532,7 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
   bool finished = false;
   // replay pays on small meshes only (us per iteration, replay vs launches: 8.2 vs 9.6 at 22k tets, 9.4 vs 9.8 at 105k,
   // 13.1 vs 12.9 at 257k, 29.4 vs 29.1 at 1M); sharded kernels carry sequence numbers and are launched one by one
-  const bool graphable = h->use_graph && P.n_slices <= 512 && (!h->comm || h->comm->n_ranks == 1);
+  const bool graphable = h->use_graph && !h->persist && P.n_slices <= 512 && (!h->comm || h->comm->n_ranks == 1);
   while (!finished) {
     const int n = std::min(kBatch, max_iter - it + 1);
     bool replayed = false;
@@ -445,7 +546,10 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
         h->use_graph = false;
       }
     }
-    if (!replayed) {
+    if (!replayed && h->persist && h->prm.pcg_variant != FB_PCG_REFERENCE) {
+      FB_TRY(pcg_run_persist(h, it, n, b));
+      it += n;
+    } else if (!replayed) {
       for (int k = 0; k < n; k++, it++) FB_TRY(pcg_iteration(h, it, b));
     }
     FB_HIP(hipMemcpyAsync(&h->st_host[slot], h->st.p, sizeof(CGState), hipMemcpyDeviceToHost, s));
@@ -462,6 +566,33 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
   }
   FB_HIP(hipStreamSynchronize(s));
   if (h->p2p) FB_TRY(p2p_check(h->p2p, s));
+  if (h->persist && h->persist_timing.p) {  // development aid: where the iterations of this solve spent their time
+    std::vector<long long> tm((size_t)h->persist_blocks * kPersistMaxWaves * 5);
+    FB_TRY(h->persist_timing.download(tm.data(), tm.size(), s));
+    FB_TRY(h->persist_timing.zero(s));
+    const char* names[4] = {"A products", "post+sweep1", "B update+publish", "sweep2+acquire"};
+    for (int k = 0; k < 4; k++) {
+      double mn = 1e30, mx = 0, av = 0;
+      int cnt = 0;
+      for (int b = 0; b < h->persist_blocks; b++)
+        for (int w = 0; w < h->persist_waves; w++) {
+          const long long* t = &tm[((size_t)b * kPersistMaxWaves + w) * 5];
+          if (t[4] <= 0) continue;
+          const double us = (double)t[k] / (double)t[4] * 0.01;
+          mn = std::min(mn, us); mx = std::max(mx, us); av += us; cnt++;
+        }
+      fprintf(stderr, "[fembrain] persistent PCG %-18s per iteration: avg %.2f us  min %.2f  max %.2f (over %d waves)\n", names[k], av / std::max(cnt, 1), mn, mx, cnt);
+    }
+  }
+  if (h->persist) {
+    unsigned int err = 0;
+    FB_HIP(hipMemcpyAsync(&err, h->persist_flags.p + h->persist_blocks + 4, sizeof err, hipMemcpyDeviceToHost, s));
+    FB_HIP(hipStreamSynchronize(s));
+    if (err) {
+      FB_TRY(h->persist_flags.zero(s));
+      return fail(FB_EDEVICE, "persistent PCG: a grid-wide wait timed out (the workgroups were not all resident?)");
+    }
+  }
   // the newest snapshot is in the slot written last
   fin = h->st_host[slot ^ 1];
   if (!host_finished(fin)) return fail(FB_EDEVICE, "internal: PCG batches ended without a terminal state (iter %d)", fin.iter);

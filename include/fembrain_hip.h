@@ -36,6 +36,12 @@ extern "C" {
  * iteration.  Correct (same iteration counts), but measured 1.8x SLOWER than MERGED on MI355X at 1M tets (51 vs 28 us per
  * iteration): the 6 x 16-byte gathers per neighbour cost more than the vector pass they remove.  Kept for reference. */
 #define FB_PCG_FUSED 2
+/* PERSISTENT: the merged recurrence with all iterations between two exact-residual ones inside ONE launch: one workgroup per
+ * CU, one wavefront per SELL slice, every lane keeps its row's x, r, d, 1/diag in registers; per iteration only the new search
+ * direction is written (for the neighbours' gathers) and the three sums cross the chip through tagged 8-byte granules
+ * (fembrain_amd/csrc/pcg_persist.hip.h).  Unsharded handles of up to 16 slices per CU (~1.5M tets on 256 CUs).  Iterates
+ * agree with MERGED to rounding (the sums are grouped per workgroup), bitwise with themselves however the run is cut. */
+#define FB_PCG_PERSISTENT 3
 
 const char* fb_last_error(void);
 int fb_device_count(void);

@@ -885,3 +885,40 @@ def test_failed_resync_poisons_the_handle_until_a_good_one(gpu):
         h.set_uniform_force(1, -3000.0)
     assert g.do_timestep() == fresh.do_timestep()
     assert np.array_equal(g.get_q_state()[0], fresh.get_q_state()[0])
+
+
+@pytest.mark.parametrize("n", [14, 31, 40])
+def test_persistent_pcg_matches_merged_and_itself(gpu, n, monkeypatch):
+    """FB_PCG_PERSISTENT (all merged iterations between two exact-residual ones in one launch, vectors in registers, the sums
+    and the search direction handed between the workgroups inside the launch) against FB_PCG_MERGED: same iteration counts to
+    max(3, 2 %), same solution to the solver tolerance; and against ITSELF cut into one-iteration launches -- where every
+    hand-off is a kernel boundary instead of an in-launch flag -- bit for bit: a stale read inside the launch would show here.
+    Slices per workgroup: 1 (n = 14, 31: fewer slices than CUs / a few) and 4 (n = 40)."""
+    v, t, fixed = _cube(n)
+    gm = FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_MERGED)
+    gp = FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT)
+    for g in (gm, gp):
+        g.set_uniform_force(1, -10000.0)
+    _, rhs = gm.system()
+    gp.system()
+    itm, xm = gm.pcg(rhs, eps=1e-9, max_iter=20000)
+    itp, xp = gp.pcg(rhs, eps=1e-9, max_iter=20000)
+    assert itm > 60 and abs(itp - itm) <= max(3, 0.02 * itm), (itp, itm)
+    assert np.abs(xp - xm).max() <= 1e-7 * np.abs(xm).max()
+    assert not xp[fixed].any()
+    for run in ("1", "7"):
+        monkeypatch.setenv("FEMBRAIN_PERSIST_MAX_RUN", run)
+        itc, xc = gp.pcg(rhs, eps=1e-9, max_iter=20000)
+        assert itc == itp and np.array_equal(xc, xp), run
+    monkeypatch.delenv("FEMBRAIN_PERSIST_MAX_RUN")
+    itl, _ = gp.pcg(rhs, eps=1e-9, max_iter=37)            # iteration cap inside a run: -37 as the reference returns
+    assert itl == -37
+    itz, xz = gp.pcg(np.zeros_like(rhs), eps=1e-6, max_iter=100)
+    assert itz == 0 and not xz.any()
+    # full steps: three reference-load steps against MERGED
+    for k in range(3):
+        im, ip = gm.do_timestep(), gp.do_timestep()
+        assert abs(im - ip) <= max(3, 0.02 * im)
+        qm, qp = gm.get_q_state()[0], gp.get_q_state()[0]
+        assert np.abs(qm - qp).max() <= 2e-5 * np.abs(qm).max()
+    gm.close(); gp.close()
