@@ -162,9 +162,15 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
     FB_HIP(hipGetDeviceProperties(&prop, h->prm.device));
     const int nb = std::min(kPersistMaxBlocks, (prop.multiProcessorCount / 8) * 8);
     const char* e = getenv("FEMBRAIN_PCG_PERSIST");
-    const bool want_p = e ? atoi(e) != 0 : h->prm.pcg_variant == FB_PCG_PERSISTENT;
+    const int w = nb >= 8 ? ceil_div(ceil_div(P.n_slices, 8), nb / 8) : 0;
+    // asked for explicitly (parameter or FEMBRAIN_PCG_PERSIST=1), or by default where it was measured faster than the
+    // two-launch iteration: fp32 storage, 4..12 slices per CU (us per iteration, merged vs persistent, on MI355X: 15.9 / 15.4 at
+    // 1,000 slices, 20.5 / 17.6 at 1,728, 25.1 / 20.7 at 2,197, 27.4 / 22.8 at 2,744 = 1M tets; 12.1 / 14.9 at 729 and
+    // 34.2 / 41.4 at 3,375, where 16 wavefronts per CU leave 128 registers per lane and 3 LDS slots)
+    const bool by_default = h->prm.pcg_variant == FB_PCG_MERGED && !h->f64 && w >= 4 && w <= 12;
+    const bool want_p = e ? atoi(e) != 0 && h->prm.pcg_variant != FB_PCG_REFERENCE && h->prm.pcg_variant != FB_PCG_FUSED
+                          : (h->prm.pcg_variant == FB_PCG_PERSISTENT || by_default);
     if (want_p && nb >= 8 && P.n_ranks == 1) {
-      const int w = ceil_div(ceil_div(P.n_slices, 8), nb / 8);
       if (w >= 1 && w <= kPersistMaxWaves) {
         h->persist = true; h->persist_blocks = nb; h->persist_waves = w;
         FB_TRY(h->persist_post.alloc((size_t)2 * nb * 8));
@@ -481,19 +487,21 @@ int launch_persist(fb_fem_s* h, int it, int n) {
                        h->invdiag.p, h->x.p, h->r.p, h->d.p, h->st.p, pa);                                                                   \
   } while (0)
   // register-resident slots by workgroup size: 512 registers per lane and SIMD are shared by ceil(waves / 4) wavefronts
-#define FB_PERSIST_W(MT, C16)                                                        \
-  do {                                                                               \
-    const int kl = pa.lds_slots;                                                     \
-    if (h->persist_waves <= 4) FB_PERSIST(MT, C16, 0, 4, 0);                         \
-    else if (h->persist_waves <= 8) FB_PERSIST(MT, C16, 0, 8, 0);                    \
-    else if (h->persist_waves <= 12) {                                               \
-      if (kl >= 5) { pa.lds_slots = 5; FB_PERSIST(MT, C16, 0, 12, 5); }              \
-      else if (kl >= 4) { pa.lds_slots = 4; FB_PERSIST(MT, C16, 0, 12, 4); }         \
-      else { pa.lds_slots = 0; FB_PERSIST(MT, C16, 0, 12, 0); }                      \
-    } else { pa.lds_slots = 0; FB_PERSIST(MT, C16, 0, 16, 0); }                      \
+  // instantiation by workgroup size: WMAX bounds the wavefronts (registers per lane), KLT is the number of slots per slice that
+  // fit into the CU's 160 KB of LDS beside the sync buffers (fp32 storage only): (160 KB - 13 KB) / (waves * 2560 B)
+#define FB_PERSIST_W(MT, C16, LDSOK)                                                                  \
+  do {                                                                                                \
+    const int w = h->persist_waves, kl = LDSOK ? pa.lds_slots : 0;                                    \
+    if (w <= 8 && kl >= 7) { pa.lds_slots = 7; FB_PERSIST(MT, C16, 0, 8, (LDSOK ? 7 : 0)); }          \
+    else if (w <= 8) { pa.lds_slots = 0; FB_PERSIST(MT, C16, 0, 8, 0); }                              \
+    else if (w <= 12 && kl >= 5) { pa.lds_slots = 5; FB_PERSIST(MT, C16, 0, 12, (LDSOK ? 5 : 0)); }   \
+    else if (w <= 12 && kl >= 4) { pa.lds_slots = 4; FB_PERSIST(MT, C16, 0, 12, (LDSOK ? 4 : 0)); }   \
+    else if (w <= 12) { pa.lds_slots = 0; FB_PERSIST(MT, C16, 0, 12, 0); }                            \
+    else if (kl >= 3) { pa.lds_slots = 3; FB_PERSIST(MT, C16, 0, 16, (LDSOK ? 3 : 0)); }              \
+    else { pa.lds_slots = 0; FB_PERSIST(MT, C16, 0, 16, 0); }                                         \
   } while (0)
-  if (h->f64) { if (h->c16) FB_PERSIST_W(double, true); else FB_PERSIST_W(double, false); }
-  else { if (h->c16) FB_PERSIST_W(float, true); else FB_PERSIST_W(float, false); }
+  if (h->f64) { if (h->c16) FB_PERSIST_W(double, true, false); else FB_PERSIST_W(double, false, false); }
+  else { if (h->c16) FB_PERSIST_W(float, true, true); else FB_PERSIST_W(float, false, true); }
 #undef FB_PERSIST_W
 #undef FB_PERSIST
   FB_HIP(hipGetLastError());
@@ -589,8 +597,14 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
     FB_HIP(hipMemcpyAsync(&err, h->persist_flags.p + h->persist_blocks + 4, sizeof err, hipMemcpyDeviceToHost, s));
     FB_HIP(hipStreamSynchronize(s));
     if (err) {
+      // a wait inside the launch gave up: the workgroups were not all resident (the device is shared with another process's
+      // kernels?).  Nothing is lost but time: the solve starts from x = 0 anyway, so it is run again with a launch per phase,
+      // and this handle stays with that.
       FB_TRY(h->persist_flags.zero(s));
-      return fail(FB_EDEVICE, "persistent PCG: a grid-wide wait timed out (the workgroups were not all resident?)");
+      h->persist = false;
+      if (h->prm.pcg_variant == FB_PCG_PERSISTENT && getenv("FEMBRAIN_PERSIST_STRICT"))
+        return fail(FB_EDEVICE, "persistent PCG: a grid-wide wait timed out (the workgroups were not all resident?)");
+      return pcg_solve(h, b, eps, max_iter, iters_out, final_state);
     }
   }
   // the newest snapshot is in the slot written last

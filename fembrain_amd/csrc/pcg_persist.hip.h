@@ -145,15 +145,15 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_persist(SellView sv, const MT
     }
   }
   // LDS-resident part: the first KL slots of this wave's slice, [KL][10][64] words (9 values + the column id), loaded once
-  const int KL = min(KLT, width);  // KLT == pa.lds_slots (the host picks the instantiation)
+  const int KL = min(KR + KLT, width);  // slots [KR, KR + KLT) live in LDS; KLT == pa.lds_slots (the host picks the instantiation)
   unsigned int* lres = (unsigned int*)(lds + kPersistSyncDoubles) + (size_t)wv * KLT * 10 * 64 + lane;
-  for (int k = 0; k < KL; k++) {
+  for (int k = KR; k < KL; k++) {
     const MT* vk = v + (size_t)k * 9 * 64;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-      if (sizeof(MT) == 4) lres[(k * 10 + j) * 64] = __float_as_uint((float)vk[j * 64]);
+      if (sizeof(MT) == 4) lres[((k - KR) * 10 + j) * 64] = __float_as_uint((float)vk[j * 64]);
     }
-    lres[(k * 10 + 9) * 64] = (unsigned int)(C16 ? row + (int)cd[(size_t)k * 64] : ci[(size_t)k * 64]);
+    lres[((k - KR) * 10 + 9) * 64] = (unsigned int)(C16 ? row + (int)cd[(size_t)k * 64] : ci[(size_t)k * 64]);
   }
   double rho = st->rho[(pa.first_iter - 1) & 1];
   const double rho0 = st->rho0, eps2 = st->eps2;
@@ -190,12 +190,11 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_persist(SellView sv, const MT
             y2 += (double)t[6] * x0 + (double)t[7] * x1 + (double)t[8] * x2;
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
       if (sizeof(MT) == 4) {
 #pragma unroll
-        for (int k = KR; k < KLT; k++) if (k < KL) {  // LDS-resident slots
-          const unsigned int* lk = lres + (size_t)k * 10 * 64;
+        for (int k = KR; k < KR + KLT; k++) if (k < KL) {  // LDS-resident slots
+          const unsigned int* lk = lres + (size_t)(k - KR) * 10 * 64;
           const double* xp = pa.dsoa + (size_t)lk[9 * 64];
           const double x0 = xp[0], x1 = xp[pa.n_pad], x2 = xp[2 * pa.n_pad];
           y0 += (double)__uint_as_float(lk[0 * 64]) * x0 + (double)__uint_as_float(lk[1 * 64]) * x1 + (double)__uint_as_float(lk[2 * 64]) * x2;
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_persist(SellView sv, const MT
         }
       }
 #pragma unroll 2
-      for (int k = (sizeof(MT) == 4 ? (KR > KLT ? KR : KLT) : KR); k < width; k++) {
+      for (int k = (sizeof(MT) == 4 ? KR + KLT : KR); k < width; k++) {
         const int col = C16 ? row + (int)cd[(size_t)k * 64] : ci[(size_t)k * 64];
         const double* xp = pa.dsoa + (size_t)col;
         const double x0 = xp[0], x1 = xp[pa.n_pad], x2 = xp[2 * pa.n_pad];
