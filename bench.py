@@ -459,6 +459,8 @@ def main():
         def probes():
             # dominant kernel: the PCG SpMV.  Average launch duration measured with HIP events on the handle's stream.
             spmv_s = g.time_spmv(200)
+            persist = g.persist_info()
+            persist_s = g.time_persist(20, 29) if persist[0] else None
             asm_k_s = g.time_assembly(10)
             halo_s, sum_s = g.time_exchange(200) if dist_mode else (0.0, 0.0)
             k0_s = g.time_element_stiffness(3)
@@ -468,23 +470,46 @@ def main():
                 g.resync(v, t, fixed)
                 torch.cuda.synchronize()
                 resync_ms = (time.perf_counter() - ts) * 1e3
-            return spmv_s, g.spmv_bytes(), asm_k_s, halo_s, sum_s, k0_s, resync_ms
-        (spmv_s, spmv_bytes, asm_k_s, halo_s, sum_s, k0_s, resync_ms), _ = stage("kernel probes", probes)
+            return spmv_s, g.spmv_bytes(), asm_k_s, halo_s, sum_s, k0_s, resync_ms, persist, persist_s, g.iteration_bytes()
+        (spmv_s, spmv_bytes, asm_k_s, halo_s, sum_s, k0_s, resync_ms, persist, persist_s, iter_bytes), _ = stage("kernel probes", probes)
 
         if rank == 0:
             # HBM traffic of the dominant kernel from the PMC counters: taken from the committed profile only while the kernel
             # sources are still the ones that were profiled (tools/summarize_profiles.py records their hash), else null
             traffic, traffic_note = None, "no PMC profile of the current kernel sources under profiles/"
-            pmc = os.path.join(ROOT, "profiles", "spmv_pmc.json")
+            dominant = "k_pcg_persist" if persist[0] else "k_spmv"
+            pmc = os.path.join(ROOT, "profiles", "dominant_pmc.json")
             if os.path.exists(pmc) and args.workload == "cube56" and world == 1 and args.precision == "f32":
                 try:
                     rec = json.load(open(pmc))
-                    if rec.get("kernel_source_sha256") == fl.source_sha256():
-                        traffic, traffic_note = rec.get("hbm_bytes_per_launch"), "profiles/spmv_pmc.json (same kernel sources)"
+                    if rec.get("kernel_source_sha256") != fl.source_sha256():
+                        traffic_note = "profiles/dominant_pmc.json was recorded for other kernel sources: not reported"
+                    elif not rec.get("kernel", "").startswith(dominant):
+                        traffic_note = "profiles/dominant_pmc.json is for %s, this run's dominant kernel is %s" % (rec.get("kernel"), dominant)
                     else:
-                        traffic_note = "profiles/spmv_pmc.json was recorded for other kernel sources: not reported"
+                        traffic, traffic_note = rec.get("hbm_bytes_per_launch"), "profiles/dominant_pmc.json (same kernel sources)"
                 except Exception:
                     pass
+            spmv_roof = {"kernel": "k_spmv (SELL-64 3x3-block SpMV of the two-launch PCG iteration; the exact-residual iterations and systems "
+                                   "outside the persistent kernel's range run it)",
+                         "achieved": spmv_bytes / spmv_s / 1e9, "frac": spmv_bytes / spmv_s / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": spmv_bytes, "us_per_launch": spmv_s * 1e6,
+                         # for comparison, SURVEY 8d's plain BSR figure (4-byte column ids, x read once, y written once, here in fp64)
+                         "survey_bsr_bytes_per_launch": (g.num_blocks() * 40.0 + (len(v) + 1) * 4.0 + 3.0 * len(v) * 16.0) if shard is None else None}
+            if persist[0]:
+                # dominant kernel: k_pcg_persist, ONE launch = 29 merged PCG iterations (everything between two exact-residual
+                # iterations).  Unit = one PCG iteration; algorithmic bytes per unit = SURVEY 8(d): BSR SpMV + the fused lower
+                # bound of the vector traffic (fb_fem_iteration_bytes).  The kernel keeps the vectors and part of the matrix
+                # on-chip, so its HBM/L3 traffic (PMC) is BELOW that figure -- the opposite of wasted re-reads.
+                roofline = {"kernel": "k_pcg_persist (29 merged Jacobi-PCG iterations per launch: SpMV + sums + vector update, vectors in registers, "
+                                      "%d of ~15 slots of every slice resident in LDS)" % persist[3],
+                            "bound": "hbm", "achieved": 29 * iter_bytes / persist_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": 29 * iter_bytes / persist_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                            "units_per_launch": 29, "algorithmic_bytes_per_unit": iter_bytes, "algorithmic_bytes_per_launch": 29 * iter_bytes,
+                            "us_per_launch": persist_s * 1e6, "us_per_unit": persist_s * 1e6 / 29,
+                            "wavefronts_per_cu": persist[1], "workgroups": persist[2], "spmv_kernel": spmv_roof}
+            else:
+                roofline = dict(spmv_roof, bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", traffic=traffic, traffic_source=traffic_note)
             storage = "f64 arithmetic / f32 stored matrix" if args.precision == "f32" else "f64"
             _state["out"] = {
                 "metric": "FEM steps/sec (assemble+PCG) at 1M tets" if args.workload == "cube56" else "FEM steps/sec (assemble+PCG)", "value": args.steps / dt, "unit": "steps/s",
@@ -499,7 +524,9 @@ def main():
                                         "peer-to-peer inboxes, sums inside the PCG kernels",
                                         "peer-to-peer inboxes, sums and halo values inside the PCG kernels"][g.transport()],
                            "exchange_trials_ms_per_step": xch_trials, "exchange_note": xch_note, "sharded_self_check": sharded_check,
-                           "cg_eps": 1e-6, "cg_max_iter": 10000},
+                           "cg_eps": 1e-6, "cg_max_iter": 10000,
+                           "pcg": ("persistent launches of up to 29 merged iterations (FB_PCG_PERSISTENT, default at this size)" if persist[0]
+                                   else "two launches per merged iteration (FB_PCG_MERGED)")},
                 "cg_iterations": [int(i) for i in iters], "cg_iterations_per_step": float(np.mean(iters)),
                 "value_note": "timed steps continue the loaded simulation after the warm-up steps (trajectory); value_at_fixed_state times the same "
                               "step from the rest state every time",
@@ -514,14 +541,7 @@ def main():
                                     "write_gbs": 1152.0 * len(t) / k0_s / 1e9 if shard is None else None},
                 "exchange_us": {"halo_refresh": halo_s * 1e6, "global_sum_3": sum_s * 1e6},
                 "assembly_kernels_us": asm_k_s * 1e6, "assembly_gbs": g.assembly_bytes() / asm_k_s / 1e9,
-                "roofline": {"kernel": "k_spmv (SELL-64 3x3-block SpMV of the PCG)", "bound": "hbm",
-                             "achieved": spmv_bytes / spmv_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": spmv_bytes / spmv_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                             "algorithmic_bytes_per_launch": spmv_bytes, "us_per_launch": spmv_s * 1e6,
-                             # for comparison, SURVEY 8d's plain BSR figure (4-byte column ids, x read once, y written once, here in fp64):
-                             # it leaves out what this fused launch also streams (own r and 1/diag for the merged sums, the low part of
-                             # the diagonal blocks) and what it saves (16-bit column differences)
-                             "survey_bsr_bytes_per_launch": (g.num_blocks() * 40.0 + (len(v) + 1) * 4.0 + 3.0 * len(v) * 16.0) if shard is None else None},
+                "roofline": roofline,
                 "cpu_baseline": None,
             }
         out = _state["out"]

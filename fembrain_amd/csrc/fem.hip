@@ -1394,6 +1394,62 @@ int fb_fem_time_assembly(fb_fem_t h, int reps, double* seconds_per_assembly) {
   return FB_OK;
 }
 
+int fb_fem_persist_info(fb_fem_t h, int* waves_per_cu, int* workgroups, int* lds_slots) {
+  if (!h) return fail(FB_EINVAL, "null FEM handle");
+  if (waves_per_cu) *waves_per_cu = h->persist ? h->persist_waves : 0;
+  if (workgroups) *workgroups = h->persist ? h->persist_blocks : 0;
+  if (lds_slots) {
+    *lds_slots = 0;
+    if (h->persist && !h->f64) {
+      const int fit = (int)((160 * 1024 - sizeof(double) * kPersistSyncDoubles) / ((size_t)h->persist_waves * 10 * 64 * 4));
+      const int w = h->persist_waves;
+      *lds_slots = w <= 8 ? (fit >= 7 ? 7 : 0) : (w <= 12 ? (fit >= 5 ? 5 : (fit >= 4 ? 4 : 0)) : (fit >= 3 ? 3 : 0));
+    }
+  }
+  return h->persist ? 1 : 0;
+}
+
+int fb_fem_time_persist(fb_fem_t h, int reps, int n_iters, double* seconds_per_launch) {
+  CHECK_HANDLE(h);
+  if (reps < 1 || n_iters < 1 || n_iters > 29 || !seconds_per_launch) return fail(FB_EINVAL, "bad arguments");
+  if (!h->persist) return fail(FB_EINVAL, "this handle does not run the persistent PCG iterations");
+  if (!h->system_valid) FB_TRY(assemble_system(h));
+  const FemPlan& P = h->plan;
+  double total = 0.0;
+  for (int r = -1; r < reps; r++) {  // r = -1: warm-up
+    // every launch starts from the state a solve of the current right-hand side starts from, with a tolerance it cannot reach
+    hipLaunchKernelGGL(k_cg_init, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->rhs.p, h->invdiag.p, h->x.p, h->r.p, h->d.p,
+                       h->part_b.p);
+    hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, h->stream, h->st.p, h->part_b.p, h->grid, (const double*)nullptr, 1e-30, 1 << 30);
+    FB_HIP(hipGetLastError());
+    // the plane conversion is part of the launch sequence of a run and is timed with it
+    FB_HIP(hipEventRecord(h->ev[0], h->stream));
+    FB_TRY(launch_persist(h, 1, n_iters));
+    FB_HIP(hipEventRecord(h->ev[1], h->stream));
+    FB_HIP(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    FB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    if (r >= 0) total += ms * 1e-3;
+  }
+  unsigned int err = 0;
+  FB_HIP(hipMemcpy(&err, h->persist_flags.p + h->persist_blocks + 4, sizeof err, hipMemcpyDeviceToHost));
+  if (err) { FB_TRY(h->persist_flags.zero(h->stream)); return fail(FB_EDEVICE, "persistent PCG: a grid-wide wait timed out"); }
+  h->system_valid = false;
+  *seconds_per_launch = total / reps;
+  return FB_OK;
+}
+
+int fb_fem_iteration_bytes(fb_fem_t h, double* bytes) {
+  if (!h || !bytes) return fail(FB_EINVAL, "null argument");
+  const FemPlan& P = h->plan;
+  // SURVEY.md 8(d), one Jacobi-PCG iteration: the BSR SpMV (nnzb 3x3 blocks with a 2- or 4-byte column id, the row pointers,
+  // the low part of the diagonal blocks) + the fused lower bound of the vector traffic, 9 vector streams (x, r, d read and
+  // written, q, 1/diag and d read by the product), here in fp64
+  const double idx = h->c16 ? 2.0 : 4.0;
+  *bytes = (double)P.n_blocks * (9.0 * mt_size(h) + idx) + (P.n_owned + 1) * 4.0 + 6.0 * mt_size(h) * P.n_owned + 9.0 * 3.0 * P.n_owned * 8.0;
+  return FB_OK;
+}
+
 int fb_fem_spmv_bytes(fb_fem_t h, double* bytes) {
   if (!h || !bytes) return fail(FB_EINVAL, "null argument");
   const FemPlan& P = h->plan;

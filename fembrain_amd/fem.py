@@ -230,6 +230,22 @@ class FemIntegrator:
         _l.check(self._L.fb_fem_time_spmv(self.h, reps, C.byref(s)))
         return s.value
 
+    def persist_info(self):
+        """(runs persistent PCG launches?, wavefronts per CU, workgroups, LDS-resident slots per slice)"""
+        w, b, k = C.c_int(0), C.c_int(0), C.c_int(0)
+        on = self._L.fb_fem_persist_info(self.h, C.byref(w), C.byref(b), C.byref(k))
+        return bool(on == 1), w.value, b.value, k.value
+
+    def time_persist(self, reps=10, n_iters=29):
+        s = C.c_double(0)
+        _l.check(self._L.fb_fem_time_persist(self.h, reps, n_iters, C.byref(s)))
+        return s.value
+
+    def iteration_bytes(self):
+        b = C.c_double(0)
+        _l.check(self._L.fb_fem_iteration_bytes(self.h, C.byref(b)))
+        return b.value
+
     def time_assembly(self, reps=10):
         s = C.c_double(0)
         _l.check(self._L.fb_fem_time_assembly(self.h, reps, C.byref(s)))

@@ -121,6 +121,9 @@ def lib():
         "fb_fem_time_assembly": (C.c_int, [vp, C.c_int, _dp]),
         "fb_fem_spmv_bytes": (C.c_int, [vp, _dp]),
         "fb_fem_assembly_bytes": (C.c_int, [vp, _dp]),
+        "fb_fem_persist_info": (C.c_int, [vp, _ip, _ip, _ip]),
+        "fb_fem_time_persist": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
+        "fb_fem_iteration_bytes": (C.c_int, [vp, _dp]),
         "fb_comm_unique_id": (C.c_int, [_bp]),
         "fb_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _bp, C.c_int]),
         "fb_comm_destroy": (C.c_int, [vp]),

@@ -202,6 +202,16 @@ int fb_fem_time_exchange(fb_fem_t h, int reps, double* seconds_per_halo, double*
  * fb_fem_element_stiffness (results go to a device scratch, nothing is copied out): what materialising the reference's
  * KElementUndeformed array would cost per rebuild; the per-step path never forms K0. */
 int fb_fem_time_element_stiffness(fb_fem_t h, int reps, double* seconds_per_pass);
+/* FB_PCG_PERSISTENT (chosen by default where it is faster, see fb_fem_params.pcg_variant): returns 1 if this handle runs its
+ * merged iterations inside persistent launches, else 0; wavefronts (= slices) per CU, workgroups, and how many slots of every
+ * slice stay resident in LDS for a launch (any pointer may be NULL) */
+int fb_fem_persist_info(fb_fem_t h, int* waves_per_cu, int* workgroups, int* lds_slots);
+/* average device seconds of ONE persistent launch of n_iters (1..29) merged PCG iterations on the current system, HIP events on
+ * the handle's stream around the launch sequence of a run (plane conversion + persistent kernel) */
+int fb_fem_time_persist(fb_fem_t h, int reps, int n_iters, double* seconds_per_launch);
+/* algorithmic bytes of ONE Jacobi-PCG iteration on this system: BSR SpMV + the fused lower bound of the vector
+ * traffic (9 fp64 vector streams) */
+int fb_fem_iteration_bytes(fb_fem_t h, double* bytes);
 /* algorithmic bytes moved by one SpMV launch / one assembly on this handle */
 int fb_fem_spmv_bytes(fb_fem_t h, double* bytes);
 int fb_fem_assembly_bytes(fb_fem_t h, double* bytes);
