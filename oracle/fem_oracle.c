@@ -31,6 +31,8 @@ typedef struct {
   double *K0;   /* 144 nt, row-major 12x12 */
   double lambda, mu, rho;
   int linear;   /* warp = 0: K = K0, f = K0 u (corotationalLinearFEM.cpp:429-453) */
+  int exact;    /* warp = 2: the exact tangent terms are added to K (corotationalLinearFEM.cpp:296-428) */
+  double *qaccel; /* Newmark state (orc_newmark_step) */
   /* node-level block pattern */
   int *bptr, *bcol, nblk;
   /* scalar CSR */
@@ -162,7 +164,7 @@ void orc_fem_destroy(void *h) {
   free(s->x0); free(s->tets); free(s->Minv); free(s->K0); free(s->bptr); free(s->bcol); free(s->ia); free(s->ja);
   free(s->elblk); free(s->mblk); free(s->fixed); free(s->cia); free(s->cja); free(s->csrc); free(s->c2f);
   free(s->K); free(s->D); free(s->sys); free(s->q); free(s->qvel); free(s->fext); free(s->fint); free(s->qres);
-  free(s->qdelta); free(s->buf); free(s->bufc); free(s->cg_r); free(s->cg_d); free(s->cg_q); free(s->cg_inv);
+  free(s->qdelta); free(s->qaccel); free(s->buf); free(s->bufc); free(s->cg_r); free(s->cg_d); free(s->cg_q); free(s->cg_inv);
   free(s);
 }
 
@@ -225,7 +227,8 @@ void orc_fem_element(void *h, int e, const double *u, double *Rout, double *Ke, 
     if (Ke) memcpy(Ke, K0, sizeof KE);
     return;
   }
-  double det = orc_polar(F, R, NULL, 1e-6);
+  double S[9];
+  double det = orc_polar(F, R, S, 1e-6);
   if (det < 0) for (int i = 0; i < 9; i++) R[i] *= -1.0;
   memset(RK, 0, sizeof RK); memset(KE, 0, sizeof KE);
   for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
@@ -239,11 +242,57 @@ void orc_fem_element(void *h, int e, const double *u, double *Rout, double *Ke, 
     for (int j = 0; j < 4; j++) for (int l = 0; l < 3; l++) a += KE[12 * i + 3 * j + l] * P[4 * l + j] - RK[12 * i + 3 * j + l] * s->x0[3 * t[j] + l];
     fe[i] = a;
   }
+  if (s->exact && Ke) {
+    /* corotationalLinearFEM.cpp:296-428: K += d(R)/dx terms.  G = (tr(S) I - S) R^T; for every entry (i,j) of F the
+     * rotation's derivative is skew(omega_ij) R with G omega_ij = 2 skew_part(e_j r_i^T) (r_i = row i of R placed in column j);
+     * chained with dF/dx = rows of Minv to dR/dx_l for the 12 element DOFs l = 3 k + j */
+    double G[9], T[9], invG[9], rhs[27], omega[27], dRdF[81], dRdx[108];
+    double tr = S[0] + S[4] + S[8];
+    for (int i = 0; i < 9; i++) T[i] = -S[i];
+    T[0] += tr; T[4] += tr; T[8] += tr;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) G[3 * i + j] = T[3 * i] * R[3 * j] + T[3 * i + 1] * R[3 * j + 1] + T[3 * i + 2] * R[3 * j + 2];
+    inv3(G, invG);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+      double tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = 0; k < 3; k++) tmp[3 * k + j] = R[3 * i + k];
+      double *w = rhs + 3 * (3 * i + j);  /* 2 * SKEW_PART */
+      w[0] = tmp[7] - tmp[5]; w[1] = tmp[2] - tmp[6]; w[2] = tmp[3] - tmp[1];
+    }
+    for (int c = 0; c < 9; c++) for (int a = 0; a < 3; a++) omega[3 * c + a] = invG[3 * a] * rhs[3 * c] + invG[3 * a + 1] * rhs[3 * c + 1] + invG[3 * a + 2] * rhs[3 * c + 2];
+    for (int c = 0; c < 9; c++) {
+      const double *w = omega + 3 * c;
+      double sk[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) dRdF[9 * c + 3 * a + b] = sk[3 * a] * R[b] + sk[3 * a + 1] * R[3 + b] + sk[3 * a + 2] * R[6 + b];
+    }
+    /* B[i][j][3 k + l] = dRdF[9 (3 j + l) + (3 i + k)];  dRdx column (3 v + j), rows 3 i .. 3 i + 2 = B[i][j] minv_v */
+    for (int v = 0; v < 4; v++) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) {
+      double a = 0;
+      for (int l = 0; l < 3; l++) a += dRdF[9 * (3 * j + l) + (3 * i + k)] * Mi[4 * v + l];
+      dRdx[9 * (3 * v + j) + 3 * i + k] = a;
+    }
+    double tv[12], av[12];
+    for (int v = 0; v < 4; v++) for (int a = 0; a < 3; a++)
+      tv[3 * v + a] = R[a] * P[v] + R[3 + a] * P[4 + v] + R[6 + a] * P[8 + v] - s->x0[3 * t[v] + a];
+    for (int i = 0; i < 12; i++) { double a = 0; for (int j = 0; j < 12; j++) a += K0[12 * i + j] * tv[j]; av[i] = a; }
+    for (int c = 0; c < 12; c++) {  /* term 1 */
+      const double *D = dRdx + 9 * c;
+      for (int j = 0; j < 4; j++) for (int a = 0; a < 3; a++)
+        KE[12 * (3 * j + a) + c] += D[3 * a] * av[3 * j] + D[3 * a + 1] * av[3 * j + 1] + D[3 * a + 2] * av[3 * j + 2];
+    }
+    for (int v = 0; v < 4; v++) for (int a = 0; a < 3; a++) av[3 * v + a] = P[4 * a + v];
+    for (int c = 0; c < 12; c++) {  /* term 2 */
+      const double *D = dRdx + 9 * c;
+      double b[12];
+      for (int j = 0; j < 4; j++) for (int a = 0; a < 3; a++) b[3 * j + a] = D[a] * av[3 * j] + D[3 + a] * av[3 * j + 1] + D[6 + a] * av[3 * j + 2];
+      for (int row = 0; row < 12; row++) { double a = 0; for (int j = 0; j < 12; j++) a += RK[12 * row + j] * b[j]; KE[12 * row + c] += a; }
+    }
+  }
   if (Rout) memcpy(Rout, R, sizeof R);
   if (Ke) memcpy(Ke, KE, sizeof KE);
 }
 
-void orc_fem_set_linear(void *h, int linear) { ((OrcFem *)h)->linear = linear; }
+void orc_fem_set_warp(void *h, int warp) { OrcFem *s = (OrcFem *)h; s->linear = warp == 0; s->exact = warp == 2; }
+void orc_fem_set_linear(void *h, int linear) { ((OrcFem *)h)->linear = linear; ((OrcFem *)h)->exact = 0; }
 
 /* f (may be NULL) and K values on the CSR pattern (may be NULL): zeroed, then accumulated in element order */
 void orc_fem_assemble(void *h, const double *u, double *f, double *Kv) {
@@ -357,6 +406,65 @@ int orc_step(void *hh, double cg_eps, int cg_maxiter, double *keff, double *rhs,
   for (int i = 0; i < r; i++) { s->qvel[i] += s->qdelta[i]; s->q[i] += s->h * s->qvel[i]; }
   for (int i = 0; i < s->nfixed; i++) s->q[s->fixed[i]] = s->qvel[s->fixed[i]] = 0.0;
   return info;
+}
+
+/* ImplicitNewmarkSparse::DoTimestep (implicitNewmarkSparse.cpp:183-379) with the PCG solver; alphas of UpdateAlphas (:96-104).
+ * As there the solver's start vector `buf` is not cleared between solves.  Returns the Newton iterations performed or -1. */
+void orc_get_accel(void *hh, double *qa) { OrcFem *s = (OrcFem *)hh; if (!s->qaccel) s->qaccel = (double *)calloc(s->r, sizeof(double)); memcpy(qa, s->qaccel, sizeof(double) * s->r); }
+void orc_set_accel(void *hh, const double *qa) { OrcFem *s = (OrcFem *)hh; if (!s->qaccel) s->qaccel = (double *)calloc(s->r, sizeof(double)); memcpy(s->qaccel, qa, sizeof(double) * s->r); }
+
+int orc_newmark_step(void *hh, double beta, double gamma, int max_newton, double epsilon, double cg_eps, int cg_maxiter, int *cg_total) {
+  OrcFem *s = (OrcFem *)hh; int r = s->r; size_t nnz = (size_t)s->nnz; double h = s->h;
+  if (!s->qaccel) s->qaccel = (double *)calloc(r, sizeof(double));
+  double alpha1 = 1.0 / (beta * h * h), alpha2 = 1.0 / (beta * h), alpha3 = (1.0 - 2.0 * beta) / (2.0 * beta);
+  double alpha4 = gamma / (beta * h), alpha5 = 1 - gamma / beta, alpha6 = (1.0 - gamma / (2.0 * beta)) * h;
+  double *q1 = (double *)malloc(sizeof(double) * 3 * (size_t)r), *v1 = q1 + r, *a1 = v1 + r;
+  memcpy(q1, s->q, sizeof(double) * r); memcpy(v1, s->qvel, sizeof(double) * r); memcpy(a1, s->qaccel, sizeof(double) * r);
+  for (int i = 0; i < r; i++) {
+    s->qaccel[i] = alpha1 * (s->q[i] - q1[i]) - alpha2 * v1[i] - alpha3 * a1[i];
+    s->qvel[i] = alpha4 * (s->q[i] - q1[i]) + alpha5 * v1[i] + alpha6 * a1[i];
+  }
+  int numIter = 0, total = 0, rc = 0; double error0 = 0, quot;
+  do {
+    orc_fem_assemble(s, s->q, s->fint, s->K);
+    for (int i = 0; i < r; i++) s->fint[i] *= s->scale;
+    for (size_t k = 0; k < nnz; k++) s->K[k] *= s->scale;
+    memset(s->qres, 0, sizeof(double) * r);
+    for (size_t k = 0; k < nnz; k++) s->D[k] = s->K[k] * s->cK;
+    for (int v = 0; v < s->nv; v++) for (int k = 0; k < 3; k++) for (int p = s->bptr[v]; p < s->bptr[v + 1]; p++)
+      s->D[s->ia[3 * v + k] + 3 * (p - s->bptr[v]) + k] += s->cM * s->mblk[p];
+    for (size_t k = 0; k < nnz; k++) s->K[k] += alpha4 * s->D[k];
+    for (int v = 0; v < s->nv; v++) for (int k = 0; k < 3; k++) for (int p = s->bptr[v]; p < s->bptr[v + 1]; p++)
+      s->K[s->ia[3 * v + k] + 3 * (p - s->bptr[v]) + k] += alpha1 * s->mblk[p];
+    for (int v = 0; v < s->nv; v++) for (int k = 0; k < 3; k++) {  /* M qaccel */
+      double a = 0;
+      for (int p = s->bptr[v]; p < s->bptr[v + 1]; p++) a += s->qaccel[3 * s->bcol[p] + k] * s->mblk[p];
+      s->qres[3 * v + k] = a;
+    }
+    for (int i = 0; i < r; i++) { double a = 0; for (int k = s->ia[i]; k < s->ia[i + 1]; k++) a += s->qvel[s->ja[k]] * s->D[k]; s->qres[i] += a; }
+    for (int i = 0; i < r; i++) { s->qres[i] += s->fint[i] - s->fext[i]; s->qres[i] *= -1; s->qdelta[i] = s->qres[i]; }
+    double error = 0;
+    for (int i = 0; i < r; i++) error += s->qres[i] * s->qres[i];
+    if (numIter == 0) { error0 = error; quot = 1.0; } else quot = error / error0;
+    if (quot < epsilon * epsilon) break;
+    for (int i = 0; i < s->rc; i++) s->bufc[i] = s->qdelta[s->c2f[i]];
+    for (int k = 0; k < s->nnzc; k++) s->sys[k] = s->K[s->csrc[k]];
+    int info = orc_pcg(s->rc, s->cia, s->cja, s->sys, s->bufc, s->buf, cg_eps, cg_maxiter, s->cg_r);
+    if (info < 0) { total -= info; rc = -1; break; }
+    total += info;
+    memset(s->qdelta, 0, sizeof(double) * r);
+    for (int i = 0; i < s->rc; i++) s->qdelta[s->c2f[i]] = s->buf[i];
+    for (int i = 0; i < r; i++) {
+      s->q[i] += s->qdelta[i];
+      s->qaccel[i] = alpha1 * (s->q[i] - q1[i]) - alpha2 * v1[i] - alpha3 * a1[i];
+      s->qvel[i] = alpha4 * (s->q[i] - q1[i]) + alpha5 * v1[i] + alpha6 * a1[i];
+    }
+    for (int i = 0; i < s->nfixed; i++) s->q[s->fixed[i]] = s->qvel[s->fixed[i]] = s->qaccel[s->fixed[i]] = 0.0;
+    numIter++;
+  } while (numIter < max_newton);
+  free(q1);
+  if (cg_total) *cg_total = total;
+  return rc < 0 ? -1 : numIter;
 }
 
 /* bench helper: build the system once and time `iters` PCG iterations' worth of work (SpMV + vector ops)

@@ -55,6 +55,12 @@ def _load(kind):
         getattr(lib, p + name).argtypes = [C.c_void_p, C.c_int, _dp]
     getattr(lib, p + "fem_assemble").argtypes = [C.c_void_p, _dp, _dp, _dp]
     getattr(lib, p + "fem_set_linear").argtypes = [C.c_void_p, C.c_int]
+    getattr(lib, p + "fem_set_warp").argtypes = [C.c_void_p, C.c_int]
+    getattr(lib, p + "get_accel").argtypes = [C.c_void_p, _dp]
+    getattr(lib, p + "set_accel").argtypes = [C.c_void_p, _dp]
+    nm = getattr(lib, p + "newmark_step")
+    nm.restype = C.c_int
+    nm.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, _ip]
     g = getattr(lib, p + "integrator_create")
     g.argtypes = [C.c_void_p, C.c_int, _ip, C.c_double, C.c_double, C.c_double]
     getattr(lib, p + "set_state").argtypes = [C.c_void_p, _dp, _dp]
@@ -134,6 +140,22 @@ class _Fem:
     def set_linear(self, linear=True):
         """warp = 0 of ComputeForceAndStiffnessMatrix (corotationalLinearFEM.cpp:429-453) instead of FemBrain's warp = 1"""
         getattr(self.lib, self.p + "fem_set_linear")(self.h, 1 if linear else 0)
+
+    def set_warp(self, warp):
+        """the `warp` argument of ComputeForceAndStiffnessMatrix: 0 linear, 1 corotational (FemBrain's), 2 corotational with
+        the exact tangent stiffness (corotationalLinearFEM.cpp:296-428)"""
+        getattr(self.lib, self.p + "fem_set_warp")(self.h, int(warp))
+
+    def newmark_step(self, beta=0.25, gamma=0.5, max_newton=1, epsilon=1e-6, cg_eps=1e-6, cg_maxiter=10000):
+        """ImplicitNewmarkSparse::DoTimestep (implicitNewmarkSparse.cpp:183-379): (Newton iterations or -1, total PCG iterations)"""
+        tot = C.c_int(0)
+        n = getattr(self.lib, self.p + "newmark_step")(self.h, beta, gamma, max_newton, epsilon, cg_eps, cg_maxiter, C.byref(tot))
+        return n, tot.value
+
+    def get_accel(self):
+        a = np.empty(self.r)
+        getattr(self.lib, self.p + "get_accel")(self.h, _d(a))
+        return a
 
     def assemble(self, u, want_K=True):
         u = np.ascontiguousarray(u, dtype=np.float64)

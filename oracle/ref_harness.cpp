@@ -102,6 +102,9 @@ int ref_fem_mass(void* h, int* ia, int* ja, double* a) {
 }
 
 void ref_fem_set_linear(void* h, int linear) { ((RefFem*)h)->warp = linear ? 0 : 1; }
+// the `warp` argument of ComputeForceAndStiffnessMatrix: 0 linear, 1 corotational (FemBrain), 2 corotational with the exact
+// tangent stiffness (corotationalLinearFEM.cpp:296-428)
+void ref_fem_set_warp(void* h, int warp) { ((RefFem*)h)->warp = warp; }
 
 // f_int and K values (CSR order of ref_fem_topology) for displacement u (warp = 1 unless ref_fem_set_linear)
 void ref_fem_assemble(void* h, const double* u, double* f, double* Kvals) {
@@ -194,6 +197,67 @@ int ref_step(void* hh, double cg_eps, int cg_maxiter, double* keff, double* rhs,
   }
   for (int i = 0; i < nf; i++) s->q[s->fixed[i]] = s->qvel[s->fixed[i]] = s->qaccel[s->fixed[i]] = 0.0;
   return info;
+}
+
+// --- restated ImplicitNewmarkSparse::DoTimestep (implicitNewmarkSparse.cpp:183-379; UpdateAlphas :96-104), dynamic branch, PCG
+//     solver, on the reference's own SparseMatrix / CGSolver objects.  As there: `buf` (the solver's start vector) is NOT
+//     cleared between solves, so every solve starts from the previous solution.  Returns the number of Newton iterations
+//     performed, or -1 when a solve failed; cg_total receives the sum of the PCG iteration counts. ---
+void ref_get_accel(void* hh, double* qaccel) { RefFem* s = (RefFem*)hh; memcpy(qaccel, s->qaccel.data(), sizeof(double) * s->r); }
+void ref_set_accel(void* hh, const double* qaccel) { RefFem* s = (RefFem*)hh; memcpy(s->qaccel.data(), qaccel, sizeof(double) * s->r); }
+
+int ref_newmark_step(void* hh, double beta, double gamma, int max_newton, double epsilon, double cg_eps, int cg_maxiter, int* cg_total) {
+  RefFem* s = (RefFem*)hh;
+  const int r = s->r, nf = (int)s->fixed.size();
+  const double h = s->h;
+  const double alpha1 = 1.0 / (beta * h * h), alpha2 = 1.0 / (beta * h), alpha3 = (1.0 - 2.0 * beta) / (2.0 * beta);
+  const double alpha4 = gamma / (beta * h), alpha5 = 1 - gamma / beta, alpha6 = (1.0 - gamma / (2.0 * beta)) * h;
+  std::vector<double> q_1(s->q), qvel_1(s->qvel), qaccel_1(s->qaccel);
+  for (int i = 0; i < r; i++) {
+    s->qaccel[i] = alpha1 * (s->q[i] - q_1[i]) - alpha2 * qvel_1[i] - alpha3 * qaccel_1[i];
+    s->qvel[i] = alpha4 * (s->q[i] - q_1[i]) + alpha5 * qvel_1[i] + alpha6 * qaccel_1[i];
+  }
+  int numIter = 0, total = 0;
+  double error0 = 0, errorQuotient;
+  do {
+    s->fem->ComputeForceAndStiffnessMatrix(s->q.data(), s->fint.data(), s->K, s->warp);
+    for (int i = 0; i < r; i++) s->fint[i] *= s->scale;
+    *s->K *= s->scale;
+    memset(s->qres.data(), 0, sizeof(double) * r);
+    s->K->ScalarMultiply(s->cK, s->D);
+    s->D->AddSubMatrix(s->cM, *s->mass);
+    s->D->ScalarMultiplyAdd(alpha4, s->K);
+    s->K->AddSubMatrix(alpha4, *s->damp, 1);
+    s->K->AddSubMatrix(alpha1, *s->mass);
+    s->mass->MultiplyVector(s->qaccel.data(), s->qres.data());
+    s->D->MultiplyVectorAdd(s->qvel.data(), s->qres.data());
+    s->damp->MultiplyVectorAdd(s->qvel.data(), s->qres.data());
+    for (int i = 0; i < r; i++) {
+      s->qres[i] += s->fint[i] - s->fext[i];
+      s->qres[i] *= -1;
+      s->qdelta[i] = s->qres[i];
+    }
+    double error = 0;
+    for (int i = 0; i < r; i++) error += s->qres[i] * s->qres[i];
+    if (numIter == 0) { error0 = error; errorQuotient = 1.0; } else errorQuotient = error / error0;
+    if (errorQuotient < epsilon * epsilon) break;
+    RemoveRows(r, s->bufc.data(), s->qdelta.data(), nf, s->fixed.data());
+    s->sys->AssignSuperMatrix(s->K);
+    int info = s->cg->SolveLinearSystemWithJacobiPreconditioner(s->buf.data(), s->bufc.data(), cg_eps, cg_maxiter);
+    s->last_iters = info;
+    if (info < 0) { if (cg_total) *cg_total = total - info; return -1; }
+    total += info;
+    InsertRows(r, s->buf.data(), s->qdelta.data(), nf, s->fixed.data());
+    for (int i = 0; i < r; i++) {
+      s->q[i] += s->qdelta[i];
+      s->qaccel[i] = alpha1 * (s->q[i] - q_1[i]) - alpha2 * qvel_1[i] - alpha3 * qaccel_1[i];
+      s->qvel[i] = alpha4 * (s->q[i] - q_1[i]) + alpha5 * qvel_1[i] + alpha6 * qaccel_1[i];
+    }
+    for (int i = 0; i < nf; i++) s->q[s->fixed[i]] = s->qvel[s->fixed[i]] = s->qaccel[s->fixed[i]] = 0.0;
+    numIter++;
+  } while (numIter < max_newton);
+  if (cg_total) *cg_total = total;
+  return numIter;
 }
 
 // system matrix (constrained) CSR export after a step, for SpMV/CG goldens

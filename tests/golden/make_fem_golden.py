@@ -7,6 +7,8 @@ at test time.
                   assembled f and K at a seeded displacement, Keff / rhs / PCG solution of one step from a seeded
                   state, q and qvel after 3 steps under the reference load (-10000/y-DOF) and a gentle one (-10)
   fem_cube5_linear.npz   the same cube with warp = 0 (linear elasticity): assembled f and K at a seeded displacement, q after 2 steps
+  fem_cube5_warp2.npz    warp = 2 (exact tangent stiffness): assembled f and K at a seeded displacement
+  fem_cube5_newmark.npz  ImplicitNewmarkSparse::DoTimestep (restated on the reference's objects): q, qvel, qaccel after 3 steps, 1 and 3 Newton iterations
   fem_beam3.npz   data/models/beam3/beam3_tet.veg (208 nodes / 450 tets, Vega's own sample) with beam3.bou clamps:
                   mesh, the reference's consistent mass matrix file beam3_tet.mass (a known answer shipped by the
                   reference), and q after 3 steps with -10 per y-DOF
@@ -93,6 +95,46 @@ def cube5_linear():
     print("cube5 linear: |f|", np.linalg.norm(f), "iters", its)
 
 
+def cube5_warp2():
+    """warp = 2 (corotational with the exact tangent stiffness, corotationalLinearFEM.cpp:296-428): assembled f and K at a
+    seeded displacement (K stays symmetric to rounding: |K - K^T| / |K| = 7e-15 here)"""
+    n = 5
+    v, t = truth_cube(n, n, n, 0.1)
+    r = RefFem(v, t)
+    r.set_warp(2)
+    rng = np.random.default_rng(24680)
+    u = rng.normal(size=r.r) * 0.01
+    f, K = r.assemble(u)
+    ia, ja = r.csr()
+    np.savez_compressed(os.path.join(HERE, "fem_cube5_warp2.npz"), n=n, u=u, f=f, K=K, ia=ia, ja=ja)
+    import scipy.sparse as sp
+    A = sp.csr_matrix((K, ja, ia), shape=(r.r, r.r))
+    print("cube5 warp2: |f|", np.linalg.norm(f), "|K - K^T| / |K|", abs(A - A.T).max() / abs(A).max())
+
+
+def cube5_newmark():
+    """ImplicitNewmarkSparse::DoTimestep restated on the reference's objects (oracle/ref_harness.cpp: ref_newmark_step), beta 1/4,
+    gamma 1/2, reference load, plane i = 0 clamped: q, qvel, qaccel after each of 3 steps with 1 and with 3 Newton iterations"""
+    n = 5
+    v, t = truth_cube(n, n, n, 0.1)
+    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    out = {}
+    for mx in (1, 3):
+        r = RefFem(v, t)
+        r.integrator(fixed)
+        f = np.zeros(r.r)
+        f[1::3] = -10000.0
+        qs, vs, acs, its = [], [], [], []
+        for _ in range(3):
+            r.set_external_forces(f)
+            its.append(r.newmark_step(max_newton=mx))
+            q, qv = r.get_state()
+            qs.append(q); vs.append(qv); acs.append(r.get_accel())
+        out["q_%d" % mx], out["qvel_%d" % mx], out["qaccel_%d" % mx], out["iters_%d" % mx] = np.array(qs), np.array(vs), np.array(acs), np.array(its)
+        print("cube5 newmark, %d Newton iteration(s): (newton, pcg) per step" % mx, its)
+    np.savez_compressed(os.path.join(HERE, "fem_cube5_newmark.npz"), n=n, fixed=fixed, **out)
+
+
 def beam3():
     v, t = read_veg(os.path.join(REF, "beam3", "beam3_tet.veg"))
     bou = [int(x) for x in open(os.path.join(REF, "beam3", "beam3.bou")).read().replace("\n", "").split(",") if x.strip()]
@@ -112,6 +154,9 @@ def beam3():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "linear":
         cube5_linear()   # added later: leaves the other two files as they are
+    elif len(sys.argv) > 1 and sys.argv[1] == "round2":
+        cube5_warp2()    # round 2: the exact-tangent option and the Newmark step
+        cube5_newmark()
     else:
         cube5()
         cube5_linear()

@@ -152,3 +152,49 @@ def test_linear_elasticity_mode_against_reference_vectors():
         q, _ = o.get_state()
         assert abs(abs(it) - g["it"][k]) <= 2
         assert np.abs(q - g["q"][k]).max() <= 1e-5 * np.abs(g["q"][k]).max()
+
+
+def test_warp2_exact_tangent_against_reference_golden_and_finite_differences():
+    """warp = 2 (corotationalLinearFEM.cpp:296-428): the oracle's f and K against the reference build's golden vectors; and the
+    reference's own self-check idea (ForceModel::TestStiffnessMatrix, forceModel.cpp:47-109): K is the derivative of f"""
+    g = np.load(os.path.join(GOLD, "fem_cube5_warp2.npz"))
+    n = int(g["n"])
+    v, t = truth_cube(n, n, n, 0.1)
+    o = OrcFem(v, t)
+    o.set_warp(2)
+    f, K = o.assemble(g["u"])
+    assert np.abs(f - g["f"]).max() <= 1e-12 * np.abs(g["f"]).max()
+    assert np.abs(K - g["K"]).max() <= 1e-11 * np.abs(g["K"]).max()
+    import scipy.sparse as sp
+    ia, ja = o.csr()
+    A = sp.csr_matrix((K, ja, ia), shape=(o.r, o.r))
+    assert abs(A - A.T).max() <= 1e-12 * abs(A).max()          # the exact tangent of this model is symmetric (to rounding)
+    rng = np.random.default_rng(3)
+    dq = rng.normal(size=o.r)
+    eps = 1e-7
+    fp, _ = o.assemble(g["u"] + eps * dq, want_K=False)
+    fm, _ = o.assemble(g["u"] - eps * dq, want_K=False)
+    fd = (fp - fm) / (2 * eps)
+    assert np.abs(fd - A @ dq).max() <= 2e-5 * np.abs(A @ dq).max()
+    o.set_warp(1)                                              # warp = 1 leaves the rotation's derivative out: not the derivative of f
+    _, K1 = o.assemble(g["u"])
+    A1 = sp.csr_matrix((K1, ja, ia), shape=(o.r, o.r))
+    assert np.abs(fd - A1 @ dq).max() > 1e-3 * np.abs(A @ dq).max()
+
+
+def test_newmark_step_against_reference_golden():
+    g = np.load(os.path.join(GOLD, "fem_cube5_newmark.npz"))
+    n = int(g["n"])
+    v, t = truth_cube(n, n, n, 0.1)
+    for mx in (1, 3):
+        o = OrcFem(v, t)
+        o.integrator(g["fixed"])
+        f = np.zeros(o.r)
+        f[1::3] = -10000.0
+        for k in range(3):
+            o.set_external_forces(f)
+            newton, pcg = o.newmark_step(max_newton=mx)
+            assert newton == g["iters_%d" % mx][k][0] and abs(pcg - g["iters_%d" % mx][k][1]) <= 3
+            q, qv = o.get_state()
+            for got, want in ((q, g["q_%d" % mx][k]), (qv, g["qvel_%d" % mx][k]), (o.get_accel(), g["qaccel_%d" % mx][k])):
+                assert np.abs(got - want).max() <= 5e-6 * np.abs(want).max()   # two solves that both stop at 1e-6
