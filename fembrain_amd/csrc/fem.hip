@@ -30,6 +30,12 @@ struct fb_fem_s {
   DevBuf<int4> tets;
   DevBuf<double> x0, rest, fe;
   DevBuf<char> rec;  // MT[16] per tet
+  DevBuf<char> kcorr;  // exact tangent (warp = 2): MT[144] per tet, the rotation-derivative terms of the element stiffness
+  // Newmark (ImplicitNewmarkSparse): acceleration and the state at the start of the step
+  DevBuf<double> qacc, q1, qvel1, qacc1;
+  double nm_beta = 0.25, nm_gamma = 0.5, nm_eps = 1e-6;
+  int nm_max_newton = 1;
+  bool pcg_warm = false;  // the next solve starts from the x left by the previous one (Newmark), not from 0
   // matrix
   DevBuf<int> slice_off, colidx, slot_coff, slot_ccnt, send_local;
   DevBuf<uint32_t> contrib;
@@ -116,6 +122,8 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   FB_TRY(h->rest.alloc((size_t)16 * P.n_tets));
   FB_TRY(h->fe.alloc((size_t)12 * P.n_tets));
   FB_TRY(h->rec.alloc((size_t)16 * P.n_tets * mt_size(h)));
+  if (h->prm.exact_tangent && !h->prm.linear) FB_TRY(h->kcorr.alloc((size_t)144 * P.n_tets * mt_size(h)));
+  else h->kcorr.release();
   FB_TRY(h->dofmask.upload(P.dofmask, s));
   if (!P.send_local.empty()) FB_TRY(h->send_local.upload(P.send_local, s));
   FB_TRY(h->sendbuf.alloc(std::max<size_t>(1, (size_t)12 * P.send_local.size())));
@@ -131,6 +139,12 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
     FB_TRY(v->alloc(nv));
     FB_TRY(v->zero(s));
   }
+  DevBuf<double>* nvecs[] = {&h->qacc, &h->q1, &h->qvel1, &h->qacc1};
+  for (auto* v : nvecs) {
+    if (h->prm.integrator == FB_INTEGRATOR_NEWMARK) { FB_TRY(v->alloc(nv)); FB_TRY(v->zero(s)); }
+    else v->release();
+  }
+  h->pcg_warm = false;
   const int chunk = ceil_div(P.n_slices, 8);
   const int per = std::max(1, std::min(kMaxPartials / 8, ceil_div(chunk, kWavesPerBlock)));
   h->grid = 8 * per;
@@ -239,17 +253,17 @@ template <typename MT>
 int launch_warp(fb_fem_s* h, const double* u, double* rot) {
   const int nt = h->plan.n_tets;
   hipLaunchKernelGGL(k_tet_warp<MT>, dim3(ceil_div(nt, kBlock)), dim3(kBlock), 0, h->stream, nt, h->tets.p, h->x0.p, u, h->rest.p,
-                     (MT*)h->rec.p, h->fe.p, rot, h->lambda, h->mu, h->prm.linear != 0 ? 1 : 0);
+                     (MT*)h->rec.p, h->fe.p, rot, h->lambda, h->mu, h->prm.linear != 0 ? 1 : 0, (MT*)h->kcorr.p);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
 
 template <typename MT>
 int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const double* fext, double* mblk_out, double* fint_out,
-                double* rhs, double* invdiag) {
+                double* rhs, double* invdiag, const double* qacc = nullptr) {
   hipLaunchKernelGGL(k_assemble_rows<MT>, dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), h->slot_coff.p, h->slot_ccnt.p,
                      h->contrib.p, (const MT*)h->rec.p, h->fe.p, h->dofmask.p, qvel, fext, (MT*)h->vals.p, (MT*)h->dlo.p, mblk_out, fint_out, rhs,
-                     invdiag, ap);
+                     invdiag, ap, (const MT*)h->kcorr.p, qacc);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -261,15 +275,26 @@ int assemble_system(fb_fem_s* h) {
   FB_TRY(halo_exchange(h, h->qvel.p));
   AsmParams ap;
   ap.lambda = h->lambda; ap.mu = h->mu; ap.rho20 = h->prm.rho / 20.0;
-  ap.s_k = hh * (hh + cK); ap.s_m = 1.0 + hh * cM;   // Keff = M + h D + h^2 K, D = cK K + cM M
-  ap.g_k = hh + cK; ap.g_m = cM;                     // (h K + D) qvel
-  ap.h = hh; ap.apply_mask = 1;
+  const double* qacc = nullptr;
+  if (h->prm.integrator == FB_INTEGRATOR_NEWMARK) {
+    // implicitNewmarkSparse.cpp:218-236: K_eff = K + alpha4 (cK K + cM M) + alpha1 M;  residual = -(M qaccel + (cK K + cM M) qvel + f_int - f_ext)
+    const double a1 = 1.0 / (h->nm_beta * hh * hh), a4 = h->nm_gamma / (h->nm_beta * hh);
+    FB_TRY(halo_exchange(h, h->qacc.p));
+    ap.s_k = 1.0 + a4 * cK; ap.s_m = a4 * cM + a1;
+    ap.g_k = cK; ap.g_m = cM; ap.g_a = 1.0; ap.rhs_scale = -1.0;
+    qacc = h->qacc.p;
+  } else {
+    ap.s_k = hh * (hh + cK); ap.s_m = 1.0 + hh * cM;   // Keff = M + h D + h^2 K, D = cK K + cM M
+    ap.g_k = hh + cK; ap.g_m = cM;                     // (h K + D) qvel
+    ap.g_a = 0.0; ap.rhs_scale = -hh;
+  }
+  ap.apply_mask = 1;
   if (h->f64) {
     FB_TRY(launch_warp<double>(h, h->q.p, nullptr));
-    FB_TRY(launch_rows<double>(h, ap, h->qvel.p, h->fext.p, nullptr, h->fint.p, h->rhs.p, h->invdiag.p));
+    FB_TRY(launch_rows<double>(h, ap, h->qvel.p, h->fext.p, nullptr, h->fint.p, h->rhs.p, h->invdiag.p, qacc));
   } else {
     FB_TRY(launch_warp<float>(h, h->q.p, nullptr));
-    FB_TRY(launch_rows<float>(h, ap, h->qvel.p, h->fext.p, nullptr, h->fint.p, h->rhs.p, h->invdiag.p));
+    FB_TRY(launch_rows<float>(h, ap, h->qvel.p, h->fext.p, nullptr, h->fint.p, h->rhs.p, h->invdiag.p, qacc));
   }
   h->system_valid = true;
   return FB_OK;
@@ -525,12 +550,24 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
   if (h->prm.pcg_variant == FB_PCG_FUSED) return pcg_solve_fused(h, b, eps, max_iter, iters_out, final_state);
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
-  hipLaunchKernelGGL(k_cg_init, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, b, h->invdiag.p, h->x.p, h->r.p, h->d.p,
-                     h->part_b.p);
-  FB_HIP(hipGetLastError());
   double* sc = nullptr;
-  FB_TRY(global_scalar(h, h->part_b.p, &sc, false));
-  hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, s, h->st.p, h->part_b.p, h->grid, sc, eps, max_iter);
+  if (h->pcg_warm) {
+    // start from the x the previous solve left (CGSolver.cpp:131-141 with a non-zero x): r = b - A x, d = r / diag
+    h->pcg_warm = false;
+    FB_TRY(h->st.zero(s));  // done = 0: the SpMV below is not a no-op
+    FB_TRY(halo_exchange(h, h->x.p));
+    FB_TRY(spmv<2>(h, h->x.p, h->r.p, b, h->part_b.p, 0));
+    hipLaunchKernelGGL(k_cg_init_warm, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->r.p, h->invdiag.p, h->d.p);
+    FB_HIP(hipGetLastError());
+    FB_TRY(global_scalar(h, h->part_b.p, &sc, false, 1, 0, h->sgrid));
+    hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, s, h->st.p, h->part_b.p, h->sgrid, sc, eps, max_iter);
+  } else {
+    hipLaunchKernelGGL(k_cg_init, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, b, h->invdiag.p, h->x.p, h->r.p, h->d.p,
+                       h->part_b.p);
+    FB_HIP(hipGetLastError());
+    FB_TRY(global_scalar(h, h->part_b.p, &sc, false));
+    hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, s, h->st.p, h->part_b.p, h->grid, sc, eps, max_iter);
+  }
   FB_HIP(hipGetLastError());
   const int kBatch = 30;
   int it = 1, slot = 0;
@@ -846,6 +883,7 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
   if (!out || (!dm && (!xyz || !tets)) || !params) return fail(FB_EINVAL, "null argument");
   if (dm && dm->device != params->device) return fail(FB_EINVAL, "the polygonizer lives on device %d, the FEM handle is asked for device %d", dm->device, params->device);
   if (n_fixed < 0 || (n_fixed > 0 && !fixed)) return fail(FB_EINVAL, "bad constrained DOF list");
+  if (params->integrator != FB_INTEGRATOR_VOLUME_CONSERVING && params->integrator != FB_INTEGRATOR_NEWMARK) return fail(FB_EINVAL, "unknown integrator %d", params->integrator);
   if (!(params->timestep > 0) || !(params->E > 0) || !(params->rho > 0) || !(params->nu > -1.0 && params->nu < 0.5))
     return fail(FB_EINVAL, "bad material / timestep parameters");
   if (n_ranks > 1 && !comm) return fail(FB_EINVAL, "sharded handle needs a communicator");
@@ -1069,8 +1107,87 @@ int fb_fem_set_uniform_force(fb_fem_t h, int axis, double value) {
   return FB_OK;
 }
 
+namespace {
+// ImplicitNewmarkSparse::DoTimestep (implicitNewmarkSparse.cpp:183-379), PCG solver
+int newmark_step(fb_fem_s* h, fb_step_info* info) {
+  hipStream_t s = h->stream;
+  const int n = 3 * h->plan.n_owned;
+  const double hh = h->prm.timestep, beta = h->nm_beta, gamma = h->nm_gamma;
+  NewmarkAlphas al;
+  al.a1 = 1.0 / (beta * hh * hh); al.a2 = 1.0 / (beta * hh); al.a3 = (1.0 - 2.0 * beta) / (2.0 * beta);
+  al.a4 = gamma / (beta * hh); al.a5 = 1 - gamma / beta; al.a6 = (1.0 - gamma / (2.0 * beta)) * hh;
+  FB_HIP(hipEventRecord(h->ev[0], s));
+  const size_t bytes = sizeof(double) * (size_t)n;
+  FB_HIP(hipMemcpyAsync(h->q1.p, h->q.p, bytes, hipMemcpyDeviceToDevice, s));
+  FB_HIP(hipMemcpyAsync(h->qvel1.p, h->qvel.p, bytes, hipMemcpyDeviceToDevice, s));
+  FB_HIP(hipMemcpyAsync(h->qacc1.p, h->qacc.p, bytes, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_newmark_update, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, s, n, (const double*)nullptr, h->dofmask.p, al, h->q1.p, h->qvel1.p, h->qacc1.p,
+                     h->q.p, h->qvel.p, h->qacc.p);
+  FB_HIP(hipGetLastError());
+  int total = 0, newton = 0;
+  double error0 = 0.0, asm_s = 0.0, solve_s = 0.0;
+  CGState fin;
+  memset(&fin, 0, sizeof fin);
+  bool ok = true;
+  do {
+    FB_HIP(hipEventRecord(h->ev[0], s));
+    FB_TRY(assemble_system(h));
+    // Newton error test on the residual (over the free DOFs: the clamped ones carry no equation here)
+    if (h->nm_max_newton > 1) {
+      hipLaunchKernelGGL(k_sumsq, dim3(1), dim3(kBlock), 0, s, (size_t)n, h->rhs.p, h->scal.p + 4);
+      FB_HIP(hipGetLastError());
+      double err = 0.0;
+      FB_HIP(hipMemcpyAsync(&err, h->scal.p + 4, sizeof err, hipMemcpyDeviceToHost, s));
+      FB_HIP(hipStreamSynchronize(s));
+      if (h->comm && h->comm->n_ranks > 1) return fail(FB_EINVAL, "Newmark with more than one Newton iteration is not built for sharded handles");
+      if (newton == 0) error0 = err;
+      else if (err / error0 < h->nm_eps * h->nm_eps) break;
+    }
+    FB_HIP(hipEventRecord(h->ev[1], s));
+    int iters = 0;
+    h->pcg_warm = true;  // `buffer` is not cleared between solves (implicitNewmarkSparse.cpp:317-320)
+    FB_TRY(pcg_solve(h, h->rhs.p, h->prm.cg_eps, h->prm.cg_max_iter, &iters, &fin));
+    FB_HIP(hipEventRecord(h->ev[2], s));
+    total += std::abs(iters);
+    if (iters < 0) { ok = false; break; }
+    hipLaunchKernelGGL(k_newmark_update, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, s, n, h->x.p, h->dofmask.p, al, h->q1.p, h->qvel1.p, h->qacc1.p, h->q.p,
+                       h->qvel.p, h->qacc.p);
+    FB_HIP(hipGetLastError());
+    FB_HIP(hipStreamSynchronize(s));
+    float ms_a = 0, ms_s = 0;
+    FB_HIP(hipEventElapsedTime(&ms_a, h->ev[0], h->ev[1]));
+    FB_HIP(hipEventElapsedTime(&ms_s, h->ev[1], h->ev[2]));
+    asm_s += ms_a * 1e-3; solve_s += ms_s * 1e-3;
+    newton++;
+  } while (newton < h->nm_max_newton);
+  FB_HIP(hipStreamSynchronize(s));
+  h->system_valid = false;
+  h->last_assembly_s = asm_s; h->last_solve_s = solve_s;
+  if (info) {
+    info->cg_iterations = total;
+    info->converged = ok ? 1 : 0;
+    info->assembly_seconds = asm_s;
+    info->solve_seconds = solve_s;
+    info->rho0 = fin.rho0;
+    info->rho = fin.rho[fin.iter & 1];
+  }
+  if (!ok) return fail(FB_ESOLVER, "PCG sparse solver returned non-zero exit status %d", -total);
+  return FB_OK;
+}
+}  // namespace
+
+int fb_fem_set_newmark(fb_fem_t h, double beta, double gamma, int max_newton_iterations, double epsilon) {
+  CHECK_HANDLE(h);
+  if (!(beta > 0) || !(gamma > 0) || max_newton_iterations < 1 || !(epsilon >= 0)) return fail(FB_EINVAL, "bad Newmark parameters");
+  if (h->prm.integrator != FB_INTEGRATOR_NEWMARK) return fail(FB_EINVAL, "the handle was not created with fb_fem_params.integrator = FB_INTEGRATOR_NEWMARK");
+  h->nm_beta = beta; h->nm_gamma = gamma; h->nm_max_newton = max_newton_iterations; h->nm_eps = epsilon;
+  h->system_valid = false;
+  return FB_OK;
+}
+
 int fb_fem_step(fb_fem_t h, fb_step_info* info) {
   CHECK_HANDLE(h);
+  if (h->prm.integrator == FB_INTEGRATOR_NEWMARK) return newmark_step(h, info);
   hipStream_t s = h->stream;
   FB_HIP(hipEventRecord(h->ev[0], s));
   FB_TRY(assemble_system(h));
@@ -1107,16 +1224,17 @@ int fb_fem_get_state(fb_fem_t h, double* q, double* qvel, double* qaccel) {
   CHECK_HANDLE(h);
   if (q) FB_TRY(download_owned(h, h->q, q));
   if (qvel) FB_TRY(download_owned(h, h->qvel, qvel));
-  if (qaccel) memset(qaccel + 3 * (size_t)h->plan.node_lo, 0, sizeof(double) * 3 * (size_t)h->plan.n_owned);  // forced 0, PS_VolumeConservingIntegrator.cpp:55
+  if (qaccel && h->prm.integrator == FB_INTEGRATOR_NEWMARK) FB_TRY(download_owned(h, h->qacc, qaccel));
+  else if (qaccel) memset(qaccel + 3 * (size_t)h->plan.node_lo, 0, sizeof(double) * 3 * (size_t)h->plan.n_owned);  // forced 0, PS_VolumeConservingIntegrator.cpp:55
   return FB_OK;
 }
 
 int fb_fem_set_state(fb_fem_t h, const double* q, const double* qvel, const double* qaccel) {
   CHECK_HANDLE(h);
-  (void)qaccel;
   if (!q) return fail(FB_EINVAL, "q must not be null (IntegratorBase::SetqState)");
   FB_TRY(upload_global_vec(h, q, h->q));
   if (qvel) FB_TRY(upload_global_vec(h, qvel, h->qvel));
+  if (qaccel && h->prm.integrator == FB_INTEGRATOR_NEWMARK) FB_TRY(upload_global_vec(h, qaccel, h->qacc));
   h->system_valid = false;
   return FB_OK;
 }
@@ -1125,6 +1243,10 @@ int fb_fem_reset(fb_fem_t h) {
   CHECK_HANDLE(h);
   FB_TRY(h->q.zero(h->stream));
   FB_TRY(h->qvel.zero(h->stream));
+  if (h->prm.integrator == FB_INTEGRATOR_NEWMARK) {
+    FB_TRY(h->qacc.zero(h->stream));
+    FB_TRY(h->x.zero(h->stream));  // the solver's start vector (IntegratorBase::ResetToRest clears its buffers)
+  }
   h->system_valid = false;
   return FB_OK;
 }
@@ -1275,7 +1397,7 @@ int fb_fem_assemble(fb_fem_t h, const double* u, double* f, double* K_blocks) {
   FB_TRY(h->Ad.zero(h->stream));  // stands in for qvel and fext (both unused in raw mode)
   AsmParams ap;
   ap.lambda = h->lambda; ap.mu = h->mu; ap.rho20 = h->prm.rho / 20.0;
-  ap.s_k = 1.0; ap.s_m = 0.0; ap.g_k = 0.0; ap.g_m = 0.0; ap.h = 0.0; ap.apply_mask = 0;
+  ap.s_k = 1.0; ap.s_m = 0.0; ap.g_k = 0.0; ap.g_m = 0.0; ap.g_a = 0.0; ap.rhs_scale = 0.0; ap.apply_mask = 0;
   if (h->f64) {
     FB_TRY(launch_warp<double>(h, h->tmp.p, nullptr));
     FB_TRY(launch_rows<double>(h, ap, h->Ad.p, h->Ad.p, h->mblk.p, h->r.p, nullptr, nullptr));

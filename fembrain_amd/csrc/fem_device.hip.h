@@ -114,11 +114,42 @@ __device__ inline double polar_rotation(const double* F, double* R, double tol) 
 //   K0[ij] = V [lambda b_i b_j^T + mu b_j b_i^T + mu (b_i.b_j) I]).
 // rec[16*e + 4*k + d] = c_k[d] (MT), rec[16*e + 4*k + 3] = V; fe[12*e + 3*k + d] fp64.
 // ------------------------------------------------------------------------------------------------------
+// y_i = sum_j K0[ij] v_j with the undeformed element stiffness in closed form, K0[ij] = V [lambda b_i b_j^T + mu b_j b_i^T + mu (b_i.b_j) I]
+__device__ inline void k0_apply(const double b[4][3], double V, double lambda, double mu, const double* v, double* y) {
+  double sl = 0.0, sm[3] = {0, 0, 0}, sg[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const double bv = b[j][0] * v[3 * j] + b[j][1] * v[3 * j + 1] + b[j][2] * v[3 * j + 2];
+    sl += bv;                                   // sum_j b_j . v_j
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      sm[a] += b[j][a] * bv;                    // unused below (kept symmetric form): sum_j b_j (b_j . v_j)
+#pragma unroll
+      for (int c = 0; c < 3; c++) sg[a][c] += b[j][a] * v[3 * j + c];  // sum_j b_j v_j^T
+    }
+  }
+  (void)sm;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      // lambda b_i (sum_j b_j.v_j) + mu sum_j b_j (b_i.v_j) + mu sum_j (b_i.b_j) v_j
+      double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) { t1 += sg[a][c] * b[i][c]; t2 += b[i][c] * sg[c][a]; }
+      y[3 * i + a] = V * (lambda * b[i][a] * sl + mu * t1 + mu * t2);
+    }
+}
+
+// kcorr (may be null): warp = 2 of CorotationalLinearFEMForceModel (corotationalLinearFEM.cpp:296-428) -- the two terms the
+// derivative of the element rotation adds to the element stiffness, as a row-major 12 x 12 matrix per element (MT):
+//   term 1: column l = blockdiag(dR/dx_l) K0 (R^T x - x0),   term 2: column l = R K0 blockdiag(dR/dx_l)^T x
+// with dR/dF from G omega = 2 skew_part(.), G = (tr(S) I - S) R^T (S = the symmetric polar factor R^T F, R before the flip).
 template <typename MT>
 __global__ __launch_bounds__(kBlock) void k_tet_warp(int nt, const int4* __restrict__ tets, const double* __restrict__ x0,
                                                      const double* __restrict__ u, const double* __restrict__ rest,
                                                      MT* __restrict__ rec, double* __restrict__ fe, double* __restrict__ rot,
-                                                     double lambda, double mu, int linear) {
+                                                     double lambda, double mu, int linear, MT* __restrict__ kcorr) {
   const int e = blockIdx.x * kBlock + threadIdx.x;
   if (e >= nt) return;
   const int4 t = tets[e];
@@ -144,6 +175,83 @@ __global__ __launch_bounds__(kBlock) void k_tet_warp(int nt, const int4* __restr
     for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
   } else {
     const double det = polar_rotation(F, R, 1e-6);
+    if (kcorr) {
+      // S = sym(Q^T F) with Q the rotation BEFORE the flip (PolarDecomposition::Compute returns it that way and the
+      // reference flips R only, corotationalLinearFEM.cpp:262-268)
+      double S[9];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) S[3 * i + j] = R[i] * F[j] + R[3 + i] * F[3 + j] + R[6 + i] * F[6 + j];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i + 1; j < 3; j++) S[3 * i + j] = S[3 * j + i] = 0.5 * (S[3 * i + j] + S[3 * j + i]);
+      double Rf[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) Rf[i] = det < 0 ? -R[i] : R[i];
+      const double tr = S[0] + S[4] + S[8];
+      double T[9], G[9], Gi[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) T[i] = ((i % 4 == 0) ? tr : 0.0) - S[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) G[3 * i + j] = T[3 * i] * Rf[3 * j] + T[3 * i + 1] * Rf[3 * j + 1] + T[3 * i + 2] * Rf[3 * j + 2];
+      inv3x3(G, Gi);
+      // a = K0 (R^T x - x0), xs = current positions
+      double tv[12], av[12], xs[12];
+#pragma unroll
+      for (int v = 0; v < 4; v++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          tv[3 * v + a] = Rf[a] * P[v][0] + Rf[3 + a] * P[v][1] + Rf[6 + a] * P[v][2] - X0[v][a];
+          xs[3 * v + a] = P[v][a];
+        }
+      k0_apply(b, V, lambda, mu, tv, av);
+      MT* C = kcorr + 144 * (size_t)e;
+      for (int v = 0; v < 4; v++)
+        for (int j = 0; j < 3; j++) {
+          // D = dR/dx_l, l = 3 v + j: rows 3i..3i+2 (i = 0..2) = B[i][j] b_v, B[i][j][3k+l'] = dRdF[column 3j+l'][row 3i+k],
+          // dRdF column c = (i', j') : skew(omega_c) R, G omega_c = 2 skew_part(e_j' r_i'^T)
+          double D[9];
+#pragma unroll
+          for (int q = 0; q < 9; q++) D[q] = 0.0;
+          for (int lp = 0; lp < 3; lp++) {        // column c = 3 j + lp of dRdF, i.e. F entry (row j, col lp)
+            // tmp = matrix with row j of R in column lp: tmp[3k + lp] = R[3j + k];  w = 2 skew_part(tmp)
+            double w[3] = {0, 0, 0};
+            {
+              double tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+              for (int k = 0; k < 3; k++) tmp[3 * k + lp] = Rf[3 * j + k];
+              w[0] = tmp[7] - tmp[5]; w[1] = tmp[2] - tmp[6]; w[2] = tmp[3] - tmp[1];
+            }
+            const double om[3] = {Gi[0] * w[0] + Gi[1] * w[1] + Gi[2] * w[2], Gi[3] * w[0] + Gi[4] * w[1] + Gi[5] * w[2],
+                                  Gi[6] * w[0] + Gi[7] * w[1] + Gi[8] * w[2]};
+            const double sk[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+            const double bl = b[v][lp];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+              for (int k = 0; k < 3; k++)   // (skew R)[i][k] * b_v[lp]: entry (row 3i+k of the 9-vector) -> D[i][k]
+                D[3 * i + k] += (sk[3 * i] * Rf[k] + sk[3 * i + 1] * Rf[3 + k] + sk[3 * i + 2] * Rf[6 + k]) * bl;
+          }
+          const int col = 3 * v + j;
+          double bb[12], rk[12];
+#pragma unroll
+          for (int w4 = 0; w4 < 4; w4++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) bb[3 * w4 + a] = D[a] * xs[3 * w4] + D[3 + a] * xs[3 * w4 + 1] + D[6 + a] * xs[3 * w4 + 2];  // D^T x_w
+          k0_apply(b, V, lambda, mu, bb, rk);
+#pragma unroll
+          for (int w4 = 0; w4 < 4; w4++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+              const double t1 = D[3 * a] * av[3 * w4] + D[3 * a + 1] * av[3 * w4 + 1] + D[3 * a + 2] * av[3 * w4 + 2];
+              const double t2 = Rf[3 * a] * rk[3 * w4] + Rf[3 * a + 1] * rk[3 * w4 + 1] + Rf[3 * a + 2] * rk[3 * w4 + 2];  // R (K0 bb)
+              C[12 * (3 * w4 + a) + col] = (MT)(t1 + t2);
+            }
+        }
+    }
     if (det < 0) {
 #pragma unroll
       for (int i = 0; i < 9; i++) R[i] = -R[i];
@@ -205,8 +313,9 @@ __global__ __launch_bounds__(kBlock) void k_tet_warp(int nt, const int4* __restr
 struct AsmParams {
   double lambda, mu, rho20;  // rho/20
   double s_k, s_m;           // stored matrix = s_k K + s_m M
-  double g_k, g_m;           // rhs operator  = g_k K + g_m M
-  double h;
+  double g_k, g_m;           // rhs operator on qvel = g_k K + g_m M
+  double g_a;                // rhs operator on qacc = g_a M (Newmark: M qaccel), 0 otherwise
+  double rhs_scale;          // rhs = rhs_scale (t + fint - fext): -h (FemBrain's step), -1 (Newmark)
   int apply_mask;
 };
 
@@ -217,7 +326,8 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
                                                           const uint8_t* __restrict__ dofmask, const double* __restrict__ qvel,
                                                           const double* __restrict__ fext, MT* __restrict__ vals, MT* __restrict__ dlo,
                                                           double* __restrict__ mblk_out, double* __restrict__ fint_out,
-                                                          double* __restrict__ rhs, double* __restrict__ invdiag, AsmParams ap) {
+                                                          double* __restrict__ rhs, double* __restrict__ invdiag, AsmParams ap,
+                                                          const MT* __restrict__ kcorr, const double* __restrict__ qacc) {
   const int lane = threadIdx.x & 63;
   for (SliceWalk w(sv.n_slices); w.valid(); w.next()) {
     const int s = w.s;
@@ -279,6 +389,13 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
 #pragma unroll
             for (int b = 0; b < 3; b++) K[3 * a + b] += vl * (ci[a] * cj[b]) + vm * (cj[a] * ci[b]);  // parenthesised so that K_ba == K_ab^T bitwise
           K[0] += vm * dij; K[4] += vm * dij; K[8] += vm * dij;
+          if (kcorr) {  // warp = 2: the rotation-derivative terms of this element, symmetric part (the exact tangent is symmetric to rounding)
+            const MT* C = kcorr + 144 * (size_t)e;
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+              for (int b = 0; b < 3; b++) K[3 * a + b] += 0.5 * ((double)C[12 * (3 * i + a) + 3 * j + b] + (double)C[12 * (3 * j + b) + 3 * i + a]);
+          }
           m += ap.rho20 * V * (i == j ? 2.0 : 1.0);
           if (diag) {
             const double* f = fe + 12 * (size_t)e + 3 * i;
@@ -291,6 +408,10 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
 #pragma unroll
       for (int a = 0; a < 3; a++)
         ta[a] += ap.g_k * (K[3 * a] * qv[0] + K[3 * a + 1] * qv[1] + K[3 * a + 2] * qv[2]) + ap.g_m * m * qv[a];
+      if (qacc) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) ta[a] += ap.g_a * m * qacc[3 * (size_t)col + a];
+      }
       uint8_t mb[3] = {1, 1, 1};
       if (ap.apply_mask) {
         mb[0] = dofmask[3 * (size_t)col];
@@ -343,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
       for (int a = 0; a < 3; a++) {
         const size_t d = 3 * (size_t)row + a;
         if (fint_out) fint_out[d] = fi[a];
-        if (rhs) rhs[d] = ma[a] ? -ap.h * (ta[a] + fi[a] - fext[d]) : 0.0;
+        if (rhs) rhs[d] = ma[a] ? ap.rhs_scale * (ta[a] + fi[a] - fext[d]) : 0.0;
         if (invdiag) invdiag[d] = 1.0 / dg[a];
       }
     }
@@ -603,6 +724,47 @@ __global__ __launch_bounds__(kBlock) void k_cg_init(int n_slices, int n_owned, c
   }
   const double tot = block_sum(acc, lds);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// warm start (ImplicitNewmarkSparse leaves the previous solution in the solver's start vector): r = b - A x has been formed by
+// k_spmv<MT,2> (which also left sum r^2 invdiag in the partials); here d = invdiag r
+__global__ __launch_bounds__(kBlock) void k_cg_init_warm(int n_slices, int n_owned, const double* __restrict__ r,
+                                                         const double* __restrict__ invdiag, double* __restrict__ d) {
+  const int lane = threadIdx.x & 63;
+  for (SliceWalk w(n_slices); w.valid(); w.next()) {
+    const int row = w.s * 64 + lane;
+    if (row < n_owned) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const size_t i = 3 * (size_t)row + a;
+        d[i] = invdiag[i] * r[i];
+      }
+    }
+  }
+}
+
+// Newmark (implicitNewmarkSparse.cpp:190-201, :356-364): q += dq (dq may be null: the predictor), then
+// qaccel = a1 (q - q_1) - a2 qvel_1 - a3 qaccel_1,  qvel = a4 (q - q_1) + a5 qvel_1 + a6 qaccel_1;  constrained DOFs -> 0
+struct NewmarkAlphas { double a1, a2, a3, a4, a5, a6; };
+__global__ __launch_bounds__(kBlock) void k_newmark_update(int n, const double* __restrict__ dq, const uint8_t* __restrict__ mask, NewmarkAlphas al,
+                                                           const double* __restrict__ q1, const double* __restrict__ v1, const double* __restrict__ a1,
+                                                           double* __restrict__ q, double* __restrict__ qvel, double* __restrict__ qacc) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  if (dq && !mask[i]) { q[i] = 0.0; qvel[i] = 0.0; qacc[i] = 0.0; return; }
+  const double qn = dq ? q[i] + dq[i] : q[i];
+  q[i] = qn;
+  qacc[i] = al.a1 * (qn - q1[i]) - al.a2 * v1[i] - al.a3 * a1[i];
+  qvel[i] = al.a4 * (qn - q1[i]) + al.a5 * v1[i] + al.a6 * a1[i];
+}
+
+// sum of squares of n doubles in one block, fixed order (Newton error test of the Newmark step)
+__global__ __launch_bounds__(kBlock) void k_sumsq(size_t n, const double* __restrict__ v, double* __restrict__ out) {
+  __shared__ double lds[4];
+  double a = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += kBlock) a += v[i] * v[i];
+  const double t = block_sum(a, lds);
+  if (threadIdx.x == 0) out[0] = t;
 }
 
 // one block: rho0 from the partials (or the all-reduced scalar), initial state

@@ -18,7 +18,7 @@ class FemIntegrator:
     def __init__(self, verts, tets, fixed_dofs=(), E=1e7, nu=0.46, rho=1000.0, timestep=0.0333,
                  damping_mass=0.0, damping_stiffness=0.01, cg_eps=1e-6, cg_max_iter=10000,
                  matrix_precision=_l.FB_MATRIX_F32, device=0, shard=None, pcg_variant=_l.FB_PCG_MERGED, spmv_kernel=_l.FB_SPMV_AUTO,
-                 linear=False):
+                 linear=False, exact_tangent=False, integrator=_l.FB_INTEGRATOR_VOLUME_CONSERVING):
         """shard = (n_ranks, rank, node_splits or None, comm_handle) for a domain-decomposed handle."""
         L = _l.lib()
         self._L = L
@@ -35,6 +35,8 @@ class FemIntegrator:
         p.pcg_variant = pcg_variant
         p.spmv_kernel = spmv_kernel
         p.linear = 1 if linear else 0
+        p.exact_tangent = 1 if exact_tangent else 0
+        p.integrator = integrator
         self.params = p
         self.h = C.c_void_p()
         self.node_lo, self.node_hi = 0, self.n_nodes
@@ -151,6 +153,9 @@ class FemIntegrator:
         qv = None if qvel is None else _l.as_f64(qvel, self.r)
         qa = None if qaccel is None else _l.as_f64(qaccel, self.r)
         _l.check(self._L.fb_fem_set_state(self.h, _l.dptr(_l.as_f64(q, self.r)), _l.dptr(qv), _l.dptr(qa)))
+
+    def set_newmark(self, beta=0.25, gamma=0.5, max_newton_iterations=1, epsilon=1e-6):
+        _l.check(self._L.fb_fem_set_newmark(self.h, beta, gamma, max_newton_iterations, epsilon))
 
     def reset_to_rest(self):
         _l.check(self._L.fb_fem_reset(self.h))

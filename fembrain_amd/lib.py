@@ -16,6 +16,7 @@ FB_MATRIX_F32, FB_MATRIX_F64 = 0, 1
 FB_XCH_COLLECTIVE, FB_XCH_P2P, FB_XCH_P2P_SUMS, FB_XCH_P2P_FUSED = 1, 2, 3, 4
 FB_PCG_MERGED, FB_PCG_REFERENCE, FB_PCG_FUSED, FB_PCG_PERSISTENT = 0, 1, 2, 3
 FB_SPMV_AUTO, FB_SPMV_ROWS, FB_SPMV_SPLIT = 0, 1, 2
+FB_INTEGRATOR_VOLUME_CONSERVING, FB_INTEGRATOR_NEWMARK = 0, 1
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
@@ -34,7 +35,7 @@ class FemParams(C.Structure):
     _fields_ = [("E", C.c_double), ("nu", C.c_double), ("rho", C.c_double), ("timestep", C.c_double),
                 ("damping_mass", C.c_double), ("damping_stiffness", C.c_double), ("cg_eps", C.c_double),
                 ("cg_max_iter", C.c_int), ("matrix_precision", C.c_int), ("device", C.c_int),
-                ("pcg_variant", C.c_int), ("spmv_kernel", C.c_int), ("linear", C.c_int), ("reserved", C.c_int * 2)]
+                ("pcg_variant", C.c_int), ("spmv_kernel", C.c_int), ("linear", C.c_int), ("exact_tangent", C.c_int), ("integrator", C.c_int)]
 
 
 class StepInfo(C.Structure):
@@ -121,6 +122,7 @@ def lib():
         "fb_fem_time_assembly": (C.c_int, [vp, C.c_int, _dp]),
         "fb_fem_spmv_bytes": (C.c_int, [vp, _dp]),
         "fb_fem_assembly_bytes": (C.c_int, [vp, _dp]),
+        "fb_fem_set_newmark": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, C.c_double]),
         "fb_fem_persist_info": (C.c_int, [vp, _ip, _ip, _ip]),
         "fb_fem_time_persist": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
         "fb_fem_iteration_bytes": (C.c_int, [vp, _dp]),

@@ -70,8 +70,13 @@ typedef struct fb_fem_params {
   int spmv_kernel;              /* 0 = choose by size, FB_SPMV_ROWS, FB_SPMV_SPLIT (small meshes: one slice per block) */
   int linear;                   /* non-zero: warp = 0 of CorotationalLinearFEMForceModel (corotationalLinearFEM.cpp:429-453): no rotation
                                  * extraction, K = K0 and f = K0 u.  0 = the corotational model FemBrain uses (warp = 1, its default) */
-  int reserved[2];
+  int exact_tangent;            /* non-zero: warp = 2 (corotationalLinearFEM.cpp:296-428): the derivative of the element rotation is added
+                                 * to the tangent stiffness (f_int is that of warp = 1); costs 144 stored values per element.  0 = FemBrain's */
+  int integrator;               /* FB_INTEGRATOR_VOLUME_CONSERVING (0, FemBrain's VolumeConservingIntegrator::DoTimestep) or
+                                 * FB_INTEGRATOR_NEWMARK (ImplicitNewmarkSparse::DoTimestep, implicitNewmarkSparse.cpp:183-379) */
 } fb_fem_params;
+#define FB_INTEGRATOR_VOLUME_CONSERVING 0
+#define FB_INTEGRATOR_NEWMARK 1
 #define FB_SPMV_ROWS 1
 #define FB_SPMV_SPLIT 2
 
@@ -150,6 +155,10 @@ int fb_fem_set_damping(fb_fem_t h, double damping_mass, double damping_stiffness
  * are multiplied by `factor` from the next assembly on (both are linear in Young's modulus, which is what is scaled) */
 int fb_fem_set_internal_force_scaling(fb_fem_t h, double factor);
 int fb_fem_set_cg(fb_fem_t h, double eps, int max_iter);
+/* Newmark parameters (implicitNewmarkSparse.h: NewmarkBeta 0.25, NewmarkGamma 0.5; IntegratorBase: maxIterations 1, epsilon
+ * 1e-6): the Newton loop stops when |residual|^2 / |first residual|^2 < epsilon^2 or after max_newton_iterations.  Each Newton
+ * iteration is one assembly + one PCG solve that -- as in the reference -- starts from the previous solution. */
+int fb_fem_set_newmark(fb_fem_t h, double beta, double gamma, int max_newton_iterations, double epsilon);
 /* IntegratorBaseSparse::setConstrainedDOF (integratorBaseSparse.cpp:73-87) -- takes effect at the next step
  * (the mask is applied when Keff is formed, so unlike the reference no stale systemMatrix can survive) */
 int fb_fem_set_constrained_dofs(fb_fem_t h, int n_fixed_dofs, const int* fixed_dofs);
