@@ -48,6 +48,7 @@ struct fb_fem_s {
   DevBuf<char> vals;  // MT[n_slots][9][64]
   DevBuf<char> dlo;   // MT[n_slices][9][64]: low part of every row's diagonal block
   DevBuf<double> mblk;
+  DevBuf<double> invblk;  // FB_PCG_BLOCK_JACOBI: inverse 3x3 diagonal block per row
   // vectors (3*n_local each)
   DevBuf<double> q, qvel, fext, fint, rhs, x, r, d, Ad, invdiag, tmp, sendbuf;
   DevBuf<double> part_a, part_b, part_c, scal;
@@ -133,6 +134,10 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   FB_TRY(h->dlo.zero(s));
   FB_TRY(h->mblk.alloc((size_t)P.n_slots * 64));
   FB_TRY(h->mblk.zero(s));
+  if (h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI) {
+    if (P.n_ranks > 1) return fail(FB_EINVAL, "FB_PCG_BLOCK_JACOBI is for unsharded handles");
+    FB_TRY(h->invblk.alloc((size_t)9 * P.n_local));
+  }
   const size_t nv = (size_t)3 * P.n_local + 2;  // spare doubles: the vector kernels walk owned rows in 16-byte pairs
   DevBuf<double>* vecs[] = {&h->q, &h->qvel, &h->fext, &h->fint, &h->rhs, &h->x, &h->r, &h->d, &h->Ad, &h->invdiag, &h->tmp};
   for (auto* v : vecs) {
@@ -182,7 +187,7 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
     // 1,000 slices, 20.5 / 17.6 at 1,728, 25.1 / 20.7 at 2,197, 27.4 / 22.8 at 2,744 = 1M tets; 12.1 / 14.9 at 729 and
     // 34.2 / 41.4 at 3,375, where 16 wavefronts per CU leave 128 registers per lane and 3 LDS slots)
     const bool by_default = h->prm.pcg_variant == FB_PCG_MERGED && !h->f64 && w >= 4 && w <= 12;
-    const bool want_p = e ? atoi(e) != 0 && h->prm.pcg_variant != FB_PCG_REFERENCE && h->prm.pcg_variant != FB_PCG_FUSED
+    const bool want_p = e ? atoi(e) != 0 && h->prm.pcg_variant != FB_PCG_REFERENCE && h->prm.pcg_variant != FB_PCG_FUSED && h->prm.pcg_variant != FB_PCG_BLOCK_JACOBI
                           : (h->prm.pcg_variant == FB_PCG_PERSISTENT || by_default);
     if (want_p && nb >= 8 && P.n_ranks == 1) {
       if (w >= 1 && w <= kPersistMaxWaves) {
@@ -263,7 +268,7 @@ int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const doub
                 double* rhs, double* invdiag, const double* qacc = nullptr) {
   hipLaunchKernelGGL(k_assemble_rows<MT>, dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), h->slot_coff.p, h->slot_ccnt.p,
                      h->contrib.p, (const MT*)h->rec.p, h->fe.p, h->dofmask.p, qvel, fext, (MT*)h->vals.p, (MT*)h->dlo.p, mblk_out, fint_out, rhs,
-                     invdiag, ap, (const MT*)h->kcorr.p, qacc);
+                     invdiag, ap, (const MT*)h->kcorr.p, qacc, invdiag && h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI ? h->invblk.p : nullptr);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -397,6 +402,22 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b) {
   const int parity = (it - 1) & 1;
   const bool refresh = (it % 30 == 0);
   double* sc = nullptr;
+  if (h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI) {  // literal sequence, z = B^-1 r (unsharded: the partials are summed by the consumers)
+    FB_TRY(spmv<1>(h, h->d.p, h->Ad.p, nullptr, h->part_a.p, parity));
+    if (!refresh) {
+      hipLaunchKernelGGL(k_bj_update<false>, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->sgrid, h->d.p,
+                         h->Ad.p, h->invblk.p, h->x.p, h->r.p, h->part_b.p);
+    } else {
+      hipLaunchKernelGGL(k_bj_update<true>, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->sgrid, h->d.p,
+                         h->Ad.p, h->invblk.p, h->x.p, h->r.p, h->part_b.p);
+      FB_TRY(spmv<2>(h, h->x.p, h->r.p, b, h->part_c.p, parity));  // r = b - A x (its Jacobi-weighted sum is not used)
+      hipLaunchKernelGGL(k_bj_rho, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, h->r.p, h->invblk.p, h->part_b.p);
+    }
+    hipLaunchKernelGGL(k_bj_direction, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_b.p, h->grid, h->r.p,
+                       h->invblk.p, h->d.p);
+    FB_HIP(hipGetLastError());
+    return FB_OK;
+  }
   if (!refresh && h->prm.pcg_variant == FB_PCG_MERGED && h->xch_mode >= FB_XCH_P2P_SUMS) {
     // Peer-to-peer transport with the exchanges inside the iteration's own kernels: the vector pass posts (block 0) and
     // awaits the three sums in its prologue; in FB_XCH_P2P_FUSED the SpMV also refreshes the halo in its prologue (a block
@@ -561,6 +582,10 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
     FB_HIP(hipGetLastError());
     FB_TRY(global_scalar(h, h->part_b.p, &sc, false, 1, 0, h->sgrid));
     hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, s, h->st.p, h->part_b.p, h->sgrid, sc, eps, max_iter);
+  } else if (h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI) {
+    hipLaunchKernelGGL(k_bj_init, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, b, h->invblk.p, h->x.p, h->r.p, h->d.p, h->part_b.p);
+    FB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, s, h->st.p, h->part_b.p, h->grid, (const double*)nullptr, eps, max_iter);
   } else {
     hipLaunchKernelGGL(k_cg_init, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, b, h->invdiag.p, h->x.p, h->r.p, h->d.p,
                        h->part_b.p);
@@ -577,7 +602,7 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
   bool finished = false;
   // replay pays on small meshes only (us per iteration, replay vs launches: 8.2 vs 9.6 at 22k tets, 9.4 vs 9.8 at 105k,
   // 13.1 vs 12.9 at 257k, 29.4 vs 29.1 at 1M); sharded kernels carry sequence numbers and are launched one by one
-  const bool graphable = h->use_graph && !h->persist && P.n_slices <= 512 && (!h->comm || h->comm->n_ranks == 1);
+  const bool graphable = h->use_graph && !h->persist && h->prm.pcg_variant != FB_PCG_BLOCK_JACOBI && P.n_slices <= 512 && (!h->comm || h->comm->n_ranks == 1);
   while (!finished) {
     const int n = std::min(kBatch, max_iter - it + 1);
     bool replayed = false;
@@ -591,7 +616,7 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
         h->use_graph = false;
       }
     }
-    if (!replayed && h->persist && h->prm.pcg_variant != FB_PCG_REFERENCE) {
+    if (!replayed && h->persist && h->prm.pcg_variant != FB_PCG_REFERENCE && h->prm.pcg_variant != FB_PCG_BLOCK_JACOBI) {
       FB_TRY(pcg_run_persist(h, it, n, b));
       it += n;
     } else if (!replayed) {

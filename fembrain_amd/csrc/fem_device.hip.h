@@ -327,7 +327,8 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
                                                           const double* __restrict__ fext, MT* __restrict__ vals, MT* __restrict__ dlo,
                                                           double* __restrict__ mblk_out, double* __restrict__ fint_out,
                                                           double* __restrict__ rhs, double* __restrict__ invdiag, AsmParams ap,
-                                                          const MT* __restrict__ kcorr, const double* __restrict__ qacc) {
+                                                          const MT* __restrict__ kcorr, const double* __restrict__ qacc,
+                                                          double* __restrict__ invblk) {
   const int lane = threadIdx.x & 63;
   for (SliceWalk w(sv.n_slices); w.valid(); w.next()) {
     const int s = w.s;
@@ -438,6 +439,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
     // s_k K + s_m M sum to s_m (sum_b m_ab) I; the diagonal block is therefore formed as that row sum minus the
     // off-diagonal blocks AS STORED and kept as a hi + lo pair, so that rounding the stiffness to fp32 does not give a
     // free body a spurious translational stiffness of the order of its mass term (eps_f32 * |K| vs M ~ rho L^2/(20 h^2 E) |K|).
+    double dfull[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // the diagonal block as stored (hi + lo), for the block-Jacobi option
     if (rvalid && kd >= 0) {
       MT* out = vals + (size_t)kd * 9 * 64 + lane;
       MT* lo = dlo + (size_t)s * 9 * 64 + lane;
@@ -452,6 +454,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
           const MT l = (MT)(v - (double)hi);
           out[(3 * a + b) * 64] = hi;
           lo[(3 * a + b) * 64] = l;
+          dfull[3 * a + b] = (double)hi + (double)l;
           if (a == b) dg[a] = (double)hi + (double)l;
         }
     } else if (kd < 0) {
@@ -466,6 +469,12 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
         if (fint_out) fint_out[d] = fi[a];
         if (rhs) rhs[d] = ma[a] ? ap.rhs_scale * (ta[a] + fi[a] - fext[d]) : 0.0;
         if (invdiag) invdiag[d] = 1.0 / dg[a];
+      }
+      if (invblk) {  // FB_PCG_BLOCK_JACOBI: the inverse of the row's 3x3 diagonal block (symmetric; identity on clamped DOFs)
+        double inv[9];
+        inv3x3(dfull, inv);
+#pragma unroll
+        for (int k = 0; k < 9; k++) invblk[9 * (size_t)row + k] = inv[k];
       }
     }
   }
@@ -765,6 +774,111 @@ __global__ __launch_bounds__(kBlock) void k_sumsq(size_t n, const double* __rest
   for (size_t i = threadIdx.x; i < n; i += kBlock) a += v[i] * v[i];
   const double t = block_sum(a, lds);
   if (threadIdx.x == 0) out[0] = t;
+}
+
+// ---- FB_PCG_BLOCK_JACOBI (opt-in, not part of the reference): the literal PCG of CGSolver.cpp:129-190 with z = B^-1 r, B the
+// 3x3 diagonal blocks, in place of the Jacobi scaling r / diag ----
+__device__ __forceinline__ void blk_apply(const double* __restrict__ B, const double* r, double* z) {
+  z[0] = B[0] * r[0] + B[1] * r[1] + B[2] * r[2];
+  z[1] = B[3] * r[0] + B[4] * r[1] + B[5] * r[2];
+  z[2] = B[6] * r[0] + B[7] * r[1] + B[8] * r[2];
+}
+// x = 0, r = b, d = B^-1 r, partial = sum r . B^-1 r
+__global__ __launch_bounds__(kBlock) void k_bj_init(int n_slices, int n_owned, const double* __restrict__ b, const double* __restrict__ invblk,
+                                                    double* __restrict__ x, double* __restrict__ r, double* __restrict__ d, double* __restrict__ partial) {
+  __shared__ double lds[4];
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (SliceWalk w(n_slices); w.valid(); w.next()) {
+    const int row = w.s * 64 + lane;
+    if (row < n_owned) {
+      const size_t i = 3 * (size_t)row;
+      const double rr[3] = {b[i], b[i + 1], b[i + 2]};
+      double z[3];
+      blk_apply(invblk + 9 * (size_t)row, rr, z);
+#pragma unroll
+      for (int a = 0; a < 3; a++) { x[i + a] = 0.0; r[i + a] = rr[a]; d[i + a] = z[a]; acc += rr[a] * z[a]; }
+    }
+  }
+  const double tot = block_sum(acc, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+// alpha = rho / (d.q); x += alpha d; REFRESH ? nothing more : (r -= alpha q, partial = sum r . B^-1 r)
+template <bool REFRESH>
+__global__ __launch_bounds__(kBlock) void k_bj_update(int n_slices, int n_owned, const CGState* __restrict__ st, int parity, const double* __restrict__ part_dq,
+                                                      int n_partial, const double* __restrict__ d, const double* __restrict__ q,
+                                                      const double* __restrict__ invblk, double* __restrict__ x, double* __restrict__ r,
+                                                      double* __restrict__ part_rho) {
+  __shared__ double lds[4];
+  if (st->done) return;
+  const double dq = sum_partials(part_dq, n_partial, lds);
+  const double alpha = st->rho[parity] / dq;
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (SliceWalk w(n_slices); w.valid(); w.next()) {
+    const int row = w.s * 64 + lane;
+    if (row < n_owned) {
+      const size_t i = 3 * (size_t)row;
+      double rr[3], z[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        x[i + a] += alpha * d[i + a];
+        if (!REFRESH) { rr[a] = r[i + a] - alpha * q[i + a]; r[i + a] = rr[a]; }
+      }
+      if (!REFRESH) {
+        blk_apply(invblk + 9 * (size_t)row, rr, z);
+        acc += rr[0] * z[0] + rr[1] * z[1] + rr[2] * z[2];
+      }
+    }
+  }
+  if (!REFRESH) {
+    const double tot = block_sum(acc, lds);
+    if (threadIdx.x == 0) part_rho[blockIdx.x] = tot;
+  }
+}
+// partial = sum r . B^-1 r of the exact residual the SpMV left in r
+__global__ __launch_bounds__(kBlock) void k_bj_rho(int n_slices, int n_owned, const CGState* __restrict__ st, const double* __restrict__ r,
+                                                   const double* __restrict__ invblk, double* __restrict__ part_rho) {
+  __shared__ double lds[4];
+  if (st->done) return;
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (SliceWalk w(n_slices); w.valid(); w.next()) {
+    const int row = w.s * 64 + lane;
+    if (row < n_owned) {
+      const size_t i = 3 * (size_t)row;
+      const double rr[3] = {r[i], r[i + 1], r[i + 2]};
+      double z[3];
+      blk_apply(invblk + 9 * (size_t)row, rr, z);
+      acc += rr[0] * z[0] + rr[1] * z[1] + rr[2] * z[2];
+    }
+  }
+  const double tot = block_sum(acc, lds);
+  if (threadIdx.x == 0) part_rho[blockIdx.x] = tot;
+}
+// beta = rho_new / rho; d = B^-1 r + beta d; block 0 publishes rho_new and the iteration count
+__global__ __launch_bounds__(kBlock) void k_bj_direction(int n_slices, int n_owned, CGState* st, int parity, const double* __restrict__ part_rho, int n_partial,
+                                                         const double* __restrict__ r, const double* __restrict__ invblk, double* __restrict__ d) {
+  __shared__ double lds[4];
+  if (st->done) return;
+  const double rho_new = sum_partials(part_rho, n_partial, lds);
+  const double beta = rho_new / st->rho[parity];
+  const int lane = threadIdx.x & 63;
+  for (SliceWalk w(n_slices); w.valid(); w.next()) {
+    const int row = w.s * 64 + lane;
+    if (row < n_owned) {
+      const size_t i = 3 * (size_t)row;
+      const double rr[3] = {r[i], r[i + 1], r[i + 2]};
+      double z[3];
+      blk_apply(invblk + 9 * (size_t)row, rr, z);
+#pragma unroll
+      for (int a = 0; a < 3; a++) d[i + a] = z[a] + beta * d[i + a];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->rho[1 - parity] = rho_new;
+    st->iter = st->iter + 1;
+  }
 }
 
 // one block: rho0 from the partials (or the all-reduced scalar), initial state

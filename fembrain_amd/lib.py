@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libfembrain_hip.so")
 FB_OK, FB_EINVAL, FB_EDEVICE, FB_ENOMEM, FB_ESOLVER, FB_ECOMM = 0, -1, -2, -3, -4, -5
 FB_MATRIX_F32, FB_MATRIX_F64 = 0, 1
 FB_XCH_COLLECTIVE, FB_XCH_P2P, FB_XCH_P2P_SUMS, FB_XCH_P2P_FUSED = 1, 2, 3, 4
-FB_PCG_MERGED, FB_PCG_REFERENCE, FB_PCG_FUSED, FB_PCG_PERSISTENT = 0, 1, 2, 3
+FB_PCG_MERGED, FB_PCG_REFERENCE, FB_PCG_FUSED, FB_PCG_PERSISTENT, FB_PCG_BLOCK_JACOBI = 0, 1, 2, 3, 4
 FB_SPMV_AUTO, FB_SPMV_ROWS, FB_SPMV_SPLIT = 0, 1, 2
 FB_INTEGRATOR_VOLUME_CONSERVING, FB_INTEGRATOR_NEWMARK = 0, 1
 

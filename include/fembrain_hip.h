@@ -42,6 +42,10 @@ extern "C" {
  * (fembrain_amd/csrc/pcg_persist.hip.h).  Unsharded handles of up to 16 slices per CU (~1.5M tets on 256 CUs).  Iterates
  * agree with MERGED to rounding (the sums are grouped per workgroup), bitwise with themselves however the run is cut. */
 #define FB_PCG_PERSISTENT 3
+/* BLOCK_JACOBI (opt-in; NOT the reference's solver, excluded from parity): the literal PCG with the inverse of every row's 3x3
+ * diagonal block as preconditioner instead of the inverse diagonal.  Same convergence test (on r . B^-1 r).  Unsharded handles.
+ * Measured on the 1M-tet cube, first step from rest: see DESIGN.md (iterations saved vs Jacobi). */
+#define FB_PCG_BLOCK_JACOBI 4
 
 const char* fb_last_error(void);
 int fb_device_count(void);
