@@ -91,6 +91,17 @@ SellView sell_view(const fb_fem_s* h) {
   return sv;
 }
 
+// one wavefront per slice: does any of its columns lie in the halo?
+__global__ __launch_bounds__(kBlock) void k_slice_halo(int n_slices, int n_owned, const int* __restrict__ slice_off, const int* __restrict__ colidx,
+                                                       unsigned char* __restrict__ out) {
+  const int s = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (s >= n_slices) return;
+  bool any = false;
+  for (int k = slice_off[s]; k < slice_off[s + 1]; k++) any = any || colidx[(size_t)k * 64 + lane] >= n_owned;
+  const unsigned long long b = __ballot(any);
+  if (lane == 0) out[s] = b != 0ULL ? 1 : 0;
+}
+
 __global__ __launch_bounds__(kBlock) void k_widen_positions(long long n, const float* __restrict__ in, double* __restrict__ out) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) out[i] = (double)in[i];
@@ -351,7 +362,13 @@ int launch_spmv_xch(fb_fem_s* h, const double* x, double* y, const double* b, do
     FB_HIP(hipGetLastError());
     return FB_OK;
   }
-  if (h->spmv_nt)
+  if (h->c16 && h->spmv_nt)
+    hipLaunchKernelGGL((k_spmv<MT, 3, XCH, true, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
+                       b, h->invdiag.p, partial, h->st.p, parity, pa);
+  else if (h->c16)
+    hipLaunchKernelGGL((k_spmv<MT, 3, XCH, false, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
+                       b, h->invdiag.p, partial, h->st.p, parity, pa);
+  else if (h->spmv_nt)
     hipLaunchKernelGGL((k_spmv<MT, 3, XCH, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
                        b, h->invdiag.p, partial, h->st.p, parity, pa);
   else
@@ -809,6 +826,34 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   return FB_OK;
 }
 
+// One rank's share of a sharded system: partition, local numbering, halo and send lists on the host (build_fem_partition: one
+// pass over the element list), then pattern / SELL-64 / contribution lists of the owned rows on the device -- the part that
+// took 68-75 ms per rank at 1M tets on the host.
+int build_shard_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed, int n_ranks, int rank,
+                               const int* splits) {
+  FemPlan& P = h->plan;
+  FB_TRY(build_fem_partition(P, n_nodes, n_tets, tets, n_ranks, rank, splits));
+  FB_TRY(plan_set_constraints(P, n_fixed, fixed));
+  FB_TRY(h->tets.upload((const int4*)P.tets.data(), (size_t)P.n_tets, h->stream));
+  DevBuf<int> d_halo;
+  if (P.n_halo > 0) FB_TRY(d_halo.upload(P.local2global.data() + P.n_owned, (size_t)P.n_halo, h->stream));
+  PlanShard sh;
+  sh.n_rows = P.n_owned; sh.node_lo = P.node_lo; sh.n_global = P.n_global; sh.d_halo = d_halo.p; sh.n_halo = P.n_halo;
+  long long owned_corners = 0;
+  for (size_t k = 0; k < P.tets.size(); k++) owned_corners += P.tets[k] < P.n_owned ? 1 : 0;
+  sh.n_pairs = 4 * owned_corners + P.n_owned;
+  DevicePlan D;
+  D.slice_off = &h->slice_off; D.colidx = &h->colidx; D.slot_coff = &h->slot_coff; D.slot_ccnt = &h->slot_ccnt; D.contrib = &h->contrib;
+  D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot; D.coldelta = &h->coldelta;
+  const int rc = build_plan_device(h->stream, P.n_local, P.n_tets, h->tets.p, D, h->plan_ws, &sh);
+  if (h->plan_ws.bytes() > ((size_t)2 << 30)) h->plan_ws.release();
+  FB_TRY(rc);
+  P.n_blocks = D.n_blocks; P.n_slices = D.n_slices; P.n_slots = D.n_slots; P.n_crows = D.n_crows;
+  h->c16 = D.deltas_fit16 && !(getenv("FEMBRAIN_SPMV_C16") && atoi(getenv("FEMBRAIN_SPMV_C16")) == 0);
+  P.slice_off = D.slice_off_host;
+  return FB_OK;
+}
+
 // inspection entry points (pattern, block values, mass) index the CSR pattern on the host
 int ensure_host_pattern(fb_fem_s* h) {
   if (h->host_pattern) return FB_OK;
@@ -832,10 +877,11 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
     if (timing) fprintf(stderr, "[fembrain] build: %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   };
   const bool want_device = !(getenv("FEMBRAIN_PLAN_DEVICE") && atoi(getenv("FEMBRAIN_PLAN_DEVICE")) == 0);
-  h->device_plan = (want_device || dm) && n_ranks == 1;
+  h->device_plan = (want_device || dm) && (n_ranks == 1 || !dm);
   h->host_pattern = !h->device_plan;
   if (h->device_plan) {
-    const int rc = build_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, dm ? dm->tets : nullptr);
+    const int rc = n_ranks > 1 ? build_shard_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits)
+                               : build_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, dm ? dm->tets : nullptr);
     if (dm && rc != FB_OK) return rc;
     if (rc == FB_ENOMEM) {  // no room for the sort's temporaries: the host builder needs none on the device
       (void)hipGetLastError();
@@ -895,10 +941,18 @@ int attach_p2p(fb_fem_s* h) {
   }
   FB_TRY(h->send_off_dev.upload(P.send_off, h->stream));
   FB_TRY(h->halo_off_dev.upload(P.halo_off, h->stream));
-  std::vector<unsigned char> sh((size_t)std::max(1, P.n_slices), 0);  // slices with a halo column are done after the halo wait
-  for (int sl = 0; sl < P.n_slices; sl++)
-    for (size_t k = (size_t)P.slice_off[sl] * kSliceRows; k < (size_t)P.slice_off[sl + 1] * kSliceRows && !sh[sl]; k++) sh[sl] = P.colidx[k] >= P.n_owned;
-  FB_TRY(h->slice_halo.upload(sh, h->stream));
+  // slices with a halo column are done after the halo wait
+  if (h->device_plan) {
+    FB_TRY(h->slice_halo.alloc((size_t)std::max(1, P.n_slices)));
+    hipLaunchKernelGGL(k_slice_halo, dim3(ceil_div(std::max(1, P.n_slices), kWavesPerBlock)), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->slice_off.p,
+                       h->colidx.p, h->slice_halo.p);
+    FB_HIP(hipGetLastError());
+  } else {
+    std::vector<unsigned char> sh((size_t)std::max(1, P.n_slices), 0);
+    for (int sl = 0; sl < P.n_slices; sl++)
+      for (size_t k = (size_t)P.slice_off[sl] * kSliceRows; k < (size_t)P.slice_off[sl + 1] * kSliceRows && !sh[sl]; k++) sh[sl] = P.colidx[k] >= P.n_owned;
+    FB_TRY(h->slice_halo.upload(sh, h->stream));
+  }
   if (P.send_local.empty()) FB_TRY(h->send_local.alloc(1));
   return FB_OK;
 }
@@ -1081,12 +1135,44 @@ int fb_fem_set_exchange_mode(fb_fem_t h, int mode) {
   return FB_OK;
 }
 
+// collective re-sync of a sharded handle; node_splits NULL keeps the handle's ranges when the node count is unchanged, else equal ranges
+static int resync_sharded(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed_dofs, const int* fixed_dofs,
+                          const int* node_splits) {
+  // every rank re-syncs at the same point of its program; the peer-to-peer inboxes are sized by the halo and are attached again
+  h->poisoned = true;
+  h->system_valid = false;
+  const int n_ranks = h->plan.n_ranks, rank = h->plan.rank;
+  const std::vector<int> kept = h->plan.splits;
+  if (!node_splits && n_nodes == h->plan.n_global) node_splits = kept.data();
+  FB_TRY(build(h, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs, n_ranks, rank, node_splits));
+  const int mode = h->xch_mode;
+  if (h->p2p) { p2p_detach(h->p2p); h->p2p = nullptr; }
+  if (h->comm && h->comm->n_ranks > 1) FB_TRY(attach_p2p(h));
+  if (h->p2p && mode >= FB_XCH_P2P) h->xch_mode = mode;   // the form chosen before the re-sync stays
+  else if (mode == FB_XCH_COLLECTIVE) h->xch_mode = FB_XCH_COLLECTIVE;
+  h->poisoned = false;
+  return FB_OK;
+}
+
+int fb_fem_resync_sharded(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed_dofs, const int* fixed_dofs,
+                          const int* node_splits) {
+  if (!h) return fail(FB_EINVAL, "null FEM handle");
+  FB_HIP(hipSetDevice(h->prm.device));
+  if (!xyz || !tets) return fail(FB_EINVAL, "null mesh");
+  FB_HIP(hipStreamSynchronize(h->stream));
+  if (h->plan.n_ranks == 1) {
+    if (node_splits && (node_splits[0] != 0 || node_splits[1] != n_nodes)) return fail(FB_EINVAL, "node splits must cover [0,%d)", n_nodes);
+    return fb_fem_resync(h, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs);
+  }
+  return resync_sharded(h, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs, node_splits);
+}
+
 int fb_fem_resync(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed_dofs, const int* fixed_dofs) {
   if (!h) return fail(FB_EINVAL, "null FEM handle");
   FB_HIP(hipSetDevice(h->prm.device));
   if (!xyz || !tets) return fail(FB_EINVAL, "null mesh");
-  if (h->plan.n_ranks > 1) return fail(FB_EINVAL, "resync of a sharded handle: destroy and create it again on every rank");
   FB_HIP(hipStreamSynchronize(h->stream));
+  if (h->plan.n_ranks > 1) return resync_sharded(h, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs, nullptr);
   // build() replaces the plan and the buffers in place; if it fails half way (a node id out of range after a bad
   // subdivision, a flat element, no memory) the handle holds pieces of two meshes and must not step
   h->poisoned = true;
@@ -1361,6 +1447,11 @@ long long fb_fem_device_plan_get(fb_fem_t h, const char* name, int* out, long lo
 int fb_fem_num_nodes(fb_fem_t h) { return h ? h->plan.n_global : 0; }
 int fb_fem_num_tets(fb_fem_t h) { return h ? h->plan.n_tets : 0; }
 int fb_fem_num_blocks(fb_fem_t h) { return h ? h->plan.n_blocks : 0; }
+int fb_fem_owned_range(fb_fem_t h, int lo_hi[2]) {
+  if (!h || !lo_hi) return fail(FB_EINVAL, "null argument");
+  lo_hi[0] = h->plan.node_lo; lo_hi[1] = h->plan.node_hi;
+  return FB_OK;
+}
 
 int fb_fem_pattern(fb_fem_t h, int* bptr, int* bcol) {
   if (!h || !bptr || !bcol) return fail(FB_EINVAL, "null argument");

@@ -70,8 +70,7 @@ int plan_set_constraints(FemPlan& P, int n_fixed, const int* fixed_dofs) {
   return FB_OK;
 }
 
-int build_fem_plan(FemPlan& P, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed_dofs,
-                   int n_ranks, int rank, const int* splits) {
+int build_fem_partition(FemPlan& P, int n_nodes, int n_tets, const int* tets, int n_ranks, int rank, const int* splits) {
   if (n_nodes <= 0 || n_tets <= 0 || !tets) return fail(FB_EINVAL, "empty mesh (%d nodes, %d tets)", n_nodes, n_tets);
   if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(FB_EINVAL, "bad rank %d of %d", rank, n_ranks);
   if ((long long)n_tets >= (1LL << 28)) return fail(FB_EINVAL, "too many tets for the packed contribution word");
@@ -153,6 +152,22 @@ int build_fem_plan(FemPlan& P, int n_nodes, int n_tets, const int* tets, int n_f
     }
   }
 
+  return FB_OK;
+}
+
+int build_fem_plan(FemPlan& P, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed_dofs,
+                   int n_ranks, int rank, const int* splits) {
+  {
+    const int rc = build_fem_partition(P, n_nodes, n_tets, tets, n_ranks, rank, splits);
+    if (rc != FB_OK) return rc;
+  }
+  auto owned = [&](int g) { return g >= P.node_lo && g < P.node_hi; };
+  const int* halo_b = P.local2global.data() + P.n_owned;
+  const int* halo_e = halo_b + P.n_halo;
+  auto to_local = [&](int g) -> int {
+    if (owned(g)) return g - P.node_lo;
+    return P.n_owned + int(std::lower_bound(halo_b, halo_e, g) - halo_b);
+  };
   // ---- pattern, SELL layout and contribution lists, row-parallel ------------------------------------------------------
   // Everything below is independent per block row (= owned node), so the rows are dealt to host threads in contiguous
   // ranges; the result does not depend on the number of threads.  (A re-sync after a cut rebuilds the whole plan: at

@@ -69,6 +69,9 @@ struct FemPlan {
 // Returns 0 or a negative FB_E* code (text via fb::last_error()).
 int build_fem_plan(FemPlan& plan, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed_dofs,
                    int n_ranks, int rank, const int* splits);
+// The first half of build_fem_plan only: partition, local elements and numbering, halo and send lists -- what the device plan
+// builder (plan_device.hip) needs from the host before it lays out pattern, SELL-64 and contribution lists itself.
+int build_fem_partition(FemPlan& plan, int n_nodes, int n_tets, const int* tets, int n_ranks, int rank, const int* splits);
 int plan_set_constraints(FemPlan& plan, int n_fixed, const int* fixed_dofs);
 
 }  // namespace fb

@@ -38,7 +38,20 @@ struct DevicePlan {
   int first_bad_tet = -1;  // lowest tet with a node id outside [0, n_nodes), -1 if none (the build then fails with FB_EINVAL)
 };
 
-// d_tets: n_tets x int4 node ids; their range is checked here (first_bad_tet).  Synchronises the stream before it returns.
-int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& out, PlanWorkspace& ws);
+// One rank's share of a sharded system: rows are the owned nodes (local ids [0, n_rows)), columns local ids (owned, then the
+// halo nodes in ascending global id); inside a row the blocks are ordered by GLOBAL column id -- the reference's order and
+// what fem_plan.cpp builds -- so the builder sorts by (local row, global column) and maps the columns back.
+struct PlanShard {
+  int n_rows = 0;               // owned nodes
+  int node_lo = 0;              // global id of local row 0
+  int n_global = 0;             // nodes of the whole mesh (column key width)
+  const int* d_halo = nullptr;  // device: ascending global ids of the n_halo halo nodes (local id n_rows + k)
+  int n_halo = 0;
+  long long n_pairs = 0;        // vertex pairs whose row is owned (host count) + n_rows markers
+};
+
+// d_tets: n_tets x int4 node ids (local ids for a shard); their range is checked here (first_bad_tet).  shard = nullptr: the
+// unsharded system (every node a row).  Synchronises the stream before it returns.
+int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& out, PlanWorkspace& ws, const PlanShard* shard = nullptr);
 
 }  // namespace fb

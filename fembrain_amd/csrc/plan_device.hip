@@ -1,4 +1,6 @@
-// Device-side builder of the unsharded FEM plan (the arrays of fem_plan.h that the per-step kernels read): block pattern,
+// Device-side builder of the FEM plan (the arrays of fem_plan.h that the per-step kernels read) -- the whole system of an
+// unsharded handle, or one rank's rows of a sharded one (PlanShard: the host does the partition, numbering and halo lists,
+// fem_plan.cpp build_fem_partition, everything per row happens here): block pattern,
 // SELL-64 layout and the per-(row, slot) element contribution lists, straight from the tet list in device memory.
 //
 // Deformable::syncForceModel (src/deformable/Deformable.cpp:127-220) rebuilds all of this after every cut; on the host
@@ -31,7 +33,16 @@ namespace {
 
 constexpr int kB = 256;
 
-__global__ __launch_bounds__(kB) void k_plan_pairs(int n_tets, int n_nodes, int row_bits, const int4* __restrict__ tets,
+// rows [0, n_rows) of local ids are matrix rows; a pair whose row is a halo node gets the row value n_rows and so sorts behind
+// every real pair.  The column part of the key is the GLOBAL id (node_lo + c for an owned column, halo[c - n_rows] otherwise;
+// unsharded: the id itself).
+struct PairGeom {
+  int n_rows, node_lo, col_bits;
+  const int* halo;
+};
+__device__ __forceinline__ unsigned int global_col(const PairGeom& g, int c) { return (unsigned int)(c < g.n_rows ? g.node_lo + c : g.halo[c - g.n_rows]); }
+
+__global__ __launch_bounds__(kB) void k_plan_pairs(int n_tets, int n_nodes, PairGeom g, const int4* __restrict__ tets,
                                                    unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, int* __restrict__ first_bad) {
   const long long i = (long long)blockIdx.x * kB + threadIdx.x;
   const long long n_tp = 16LL * n_tets;
@@ -39,23 +50,42 @@ __global__ __launch_bounds__(kB) void k_plan_pairs(int n_tets, int n_nodes, int 
     const int e = (int)(i >> 4), ij = (int)(i & 15);
     const int4 t = tets[e];
     const int id[4] = {t.x, t.y, t.z, t.w};
-    if ((unsigned int)id[ij & 3] >= (unsigned int)n_nodes) atomicMin(first_bad, e);  // the host reports it; the keys of this run are never used
-    keys[i] = ((unsigned long long)(unsigned int)id[ij >> 2] << row_bits) | (unsigned int)id[ij & 3];
-    vals[i] = ((uint32_t)e << 4) | (uint32_t)ij;
-  } else if (i < n_tp + n_nodes) {
+    const bool bad = (unsigned int)id[ij & 3] >= (unsigned int)n_nodes || (unsigned int)id[ij >> 2] >= (unsigned int)n_nodes;
+    if (bad) atomicMin(first_bad, e);  // the host reports it; the keys of this run are never used
+    const int row = id[ij >> 2];
+    if (bad || row >= g.n_rows) {
+      keys[i] = (unsigned long long)(unsigned int)g.n_rows << g.col_bits;
+      vals[i] = kNoContrib;
+    } else {
+      keys[i] = ((unsigned long long)(unsigned int)row << g.col_bits) | global_col(g, id[ij & 3]);
+      vals[i] = ((uint32_t)e << 4) | (uint32_t)ij;
+    }
+  } else if (i < n_tp + g.n_rows) {
     const unsigned int a = (unsigned int)(i - n_tp);
-    keys[i] = ((unsigned long long)a << row_bits) | a;
+    keys[i] = ((unsigned long long)a << g.col_bits) | (unsigned int)(g.node_lo + (int)a);
     vals[i] = kNoContrib;
   }
 }
 
 // block p: row, column; bptr by binary search of the first block of every row
-__global__ __launch_bounds__(kB) void k_plan_rows(int n_nodes, int n_blocks, int row_bits, const unsigned long long* __restrict__ ukeys,
+__global__ __launch_bounds__(kB) void k_plan_rows(int n_nodes, int n_blocks, PairGeom g, int n_halo, const unsigned long long* __restrict__ ukeys,
                                                   int* __restrict__ bptr, int* __restrict__ bcol) {
   const int i = blockIdx.x * kB + threadIdx.x;
-  if (i < n_blocks) bcol[i] = (int)(unsigned int)(ukeys[i] & ((1ULL << row_bits) - 1ULL));
+  if (i < n_blocks) {
+    const int gc = (int)(unsigned int)(ukeys[i] & ((1ULL << g.col_bits) - 1ULL));
+    int c = gc - g.node_lo;
+    if (c < 0 || c >= g.n_rows) {  // a halo column: its local id is n_rows + its rank among the halo nodes
+      int lo = 0, hi = n_halo;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (g.halo[mid] < gc) lo = mid + 1; else hi = mid;
+      }
+      c = g.n_rows + lo;
+    }
+    bcol[i] = c;
+  }
   if (i <= n_nodes) {
-    const unsigned long long want = (unsigned long long)(unsigned int)i << row_bits;
+    const unsigned long long want = (unsigned long long)(unsigned int)i << g.col_bits;
     int lo = 0, hi = n_blocks;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
@@ -133,7 +163,9 @@ __global__ __launch_bounds__(kB) void k_plan_contrib(int n_nodes, int n_slices, 
 
 }  // namespace
 
-int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& D, PlanWorkspace& W) {
+int build_plan_device(hipStream_t s, int n_nodes_local, int n_tets, const int4* d_tets, DevicePlan& D, PlanWorkspace& W, const PlanShard* shard) {
+  // n_nodes: matrix rows (owned nodes); n_nodes_local: range of the node ids in d_tets
+  const int n_nodes = shard ? shard->n_rows : n_nodes_local;
   const long long n_pairs = 16LL * n_tets + n_nodes;
   if (n_pairs >= (1LL << 31)) return fail(FB_EINVAL, "mesh too large for the device plan builder (%lld pairs)", n_pairs);
   DevBuf<unsigned long long>&keys = W.keys, &keys_s = W.keys_s, &ukeys = W.ukeys;
@@ -146,31 +178,38 @@ int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets
   FB_TRY(keys_s.reserve((size_t)n_pairs));
   FB_TRY(vals.reserve((size_t)n_pairs));
   FB_TRY(vals_s.reserve((size_t)n_pairs));
+  PairGeom geom;
+  geom.n_rows = n_nodes; geom.node_lo = shard ? shard->node_lo : 0; geom.halo = shard ? shard->d_halo : nullptr;
+  geom.col_bits = 1;
+  while ((1LL << geom.col_bits) < (shard ? shard->n_global : n_nodes)) geom.col_bits++;
   int row_bits = 1;
-  while ((1LL << row_bits) < n_nodes) row_bits++;
+  while ((1LL << row_bits) < (long long)n_nodes + (shard ? 1 : 0)) row_bits++;  // a shard needs the row value n_rows for the dropped pairs
+  if (row_bits + geom.col_bits > 63) return fail(FB_EINVAL, "mesh too large for the device plan builder's sort key");
+  const long long n_valid = shard ? shard->n_pairs : n_pairs;  // pairs that belong to a row
   const int init[2] = {0x7fffffff, 0};  // [0] lowest tet with a bad node id, [1] "a column difference does not fit 16 bits"
   const int none = init[0];
   FB_HIP(hipMemcpyAsync(W.flags.p, init, sizeof init, hipMemcpyHostToDevice, s));
   struct { int* p; } bad = {W.flags.p};
-  hipLaunchKernelGGL(k_plan_pairs, dim3((unsigned)((n_pairs + kB - 1) / kB)), dim3(kB), 0, s, n_tets, n_nodes, row_bits, d_tets, keys.p, vals.p, bad.p);
+  hipLaunchKernelGGL(k_plan_pairs, dim3((unsigned)((n_pairs + kB - 1) / kB)), dim3(kB), 0, s, n_tets, n_nodes_local, geom, d_tets, keys.p, vals.p, bad.p);
   FB_HIP(hipGetLastError());
   int first_bad = none;
   FB_HIP(hipMemcpyAsync(&first_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
   FB_HIP(hipStreamSynchronize(s));
   D.first_bad_tet = first_bad == none ? -1 : first_bad;
-  if (D.first_bad_tet >= 0) return fail(FB_EINVAL, "tet %d references a node outside [0,%d)", D.first_bad_tet, n_nodes);
+  if (D.first_bad_tet >= 0) return fail(FB_EINVAL, "tet %d references a node outside [0,%d)", D.first_bad_tet, n_nodes_local);
   size_t bytes = 0;
-  FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, (unsigned)(2 * row_bits), s));
+  const unsigned key_bits = (unsigned)(row_bits + geom.col_bits);
+  FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
   FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
-  FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, (unsigned)(2 * row_bits), s));
+  FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
   // blocks = runs of equal keys
   FB_TRY(ukeys.reserve((size_t)n_pairs));
   FB_TRY(ucnt.reserve((size_t)n_pairs));
   FB_TRY(nruns.reserve(1));
   bytes = 0;
-  FB_HIP(rocprim::run_length_encode(nullptr, bytes, keys_s.p, (unsigned int)n_pairs, ukeys.p, ucnt.p, nruns.p, s));
+  FB_HIP(rocprim::run_length_encode(nullptr, bytes, keys_s.p, (unsigned int)n_valid, ukeys.p, ucnt.p, nruns.p, s));
   FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
-  FB_HIP(rocprim::run_length_encode(temp.p, bytes, keys_s.p, (unsigned int)n_pairs, ukeys.p, ucnt.p, nruns.p, s));
+  FB_HIP(rocprim::run_length_encode(temp.p, bytes, keys_s.p, (unsigned int)n_valid, ukeys.p, ucnt.p, nruns.p, s));
   unsigned int nb = 0;
   FB_TRY(nruns.download(&nb, 1, s));
   D.n_blocks = (int)nb;
@@ -182,7 +221,7 @@ int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets
   FB_TRY(D.bptr->alloc((size_t)n_nodes + 1));
   FB_TRY(D.bcol->alloc((size_t)nb));
   FB_TRY(D.blk_slot->alloc((size_t)nb));
-  hipLaunchKernelGGL(k_plan_rows, dim3((unsigned)((std::max<long long>(nb, n_nodes + 1) + kB - 1) / kB)), dim3(kB), 0, s, n_nodes, (int)nb, row_bits, ukeys.p,
+  hipLaunchKernelGGL(k_plan_rows, dim3((unsigned)((std::max<long long>(nb, n_nodes + 1) + kB - 1) / kB)), dim3(kB), 0, s, n_nodes, (int)nb, geom, shard ? shard->n_halo : 0, ukeys.p,
                      D.bptr->p, D.bcol->p);
   FB_HIP(hipGetLastError());
   // SELL-64

@@ -113,15 +113,19 @@ class FemIntegrator:
         except Exception:
             pass
 
-    def resync(self, verts, tets, fixed_dofs=()):
-        """Deformable::syncForceModel after a cut."""
+    def resync(self, verts, tets, fixed_dofs=(), node_splits=None):
+        """Deformable::syncForceModel after a cut.  On a sharded handle the call is collective; node_splits = the new node
+        ranges (None: kept when the node count is unchanged, else the equal split)."""
         self.verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
         self.tets = np.ascontiguousarray(tets, dtype=np.int32).reshape(-1, 4)
         self.n_nodes, self.r = len(self.verts), 3 * len(self.verts)
-        self.node_lo, self.node_hi = 0, self.n_nodes
         fd = _l.as_i32(fixed_dofs)
-        _l.check(self._L.fb_fem_resync(self.h, self.n_nodes, _l.dptr(self.verts), len(self.tets), _l.iptr(self.tets),
-                                       len(fd), _l.iptr(fd)))
+        sp = None if node_splits is None else _l.as_i32(node_splits)
+        _l.check(self._L.fb_fem_resync_sharded(self.h, self.n_nodes, _l.dptr(self.verts), len(self.tets), _l.iptr(self.tets),
+                                               len(fd), _l.iptr(fd), _l.iptr(sp)))
+        rng = (C.c_int * 2)()
+        _l.check(self._L.fb_fem_owned_range(self.h, rng))
+        self.node_lo, self.node_hi = int(rng[0]), int(rng[1])
 
     def rebuild_elements(self):
         _l.check(self._L.fb_fem_rebuild_elements(self.h))

@@ -93,6 +93,7 @@ def lib():
                                             C.c_int, C.c_int, _ip, vp]),
         "fb_fem_destroy": (C.c_int, [vp]),
         "fb_fem_resync": (C.c_int, [vp, C.c_int, _dp, C.c_int, _ip, C.c_int, _ip]),
+        "fb_fem_resync_sharded": (C.c_int, [vp, C.c_int, _dp, C.c_int, _ip, C.c_int, _ip, _ip]),
         "fb_fem_rebuild_elements": (C.c_int, [vp]),
         "fb_fem_set_external_forces": (C.c_int, [vp, _dp]),
         "fb_fem_add_external_forces": (C.c_int, [vp, _dp]),
@@ -111,6 +112,7 @@ def lib():
         "fb_fem_num_nodes": (C.c_int, [vp]),
         "fb_fem_num_tets": (C.c_int, [vp]),
         "fb_fem_num_blocks": (C.c_int, [vp]),
+        "fb_fem_owned_range": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "fb_fem_pattern": (C.c_int, [vp, _ip, _ip]),
         "fb_fem_element_stiffness": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp]),
         "fb_fem_assemble": (C.c_int, [vp, _dp, _dp, _dp]),

@@ -93,9 +93,13 @@ int fb_fem_create(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
                   int n_fixed_dofs, const int* fixed_dofs, const fb_fem_params* params);
 
 /* Domain-decomposed variant: rank `rank` of `n_ranks` owns the contiguous node range
- * [node_splits[rank], node_splits[rank+1]) of the SAME global mesh every rank passes in (node_splits has
- * n_ranks+1 ascending entries covering [0, n_nodes); NULL = equal split); it assembles every tet touching an
- * owned node and keeps only owned rows, so no force/stiffness reduction is needed.
+ * [node_splits[rank], node_splits[rank+1]) of one global mesh (node_splits has n_ranks+1 ascending entries covering
+ * [0, n_nodes); NULL = equal split); it assembles every tet touching an owned node and keeps only owned rows, so no
+ * force/stiffness reduction is needed.
+ * Per-rank ingest: `tets` may be the whole element list (the rank filters it) or ONLY THE RANK'S OWN ELEMENTS -- every tet
+ * with at least one owned node, global node ids, in ascending global element order (the order fixes the rounding of the
+ * assembled sums).  Only the xyz rows of nodes those elements reference are read, so a rank may back `xyz` with a sparse
+ * mapping.  The plan (pattern, SELL-64, contribution lists) of the owned rows is built on the device.
  * Per PCG iteration: one halo exchange of the search direction and two fp64 scalar all-reduces over `comm`
  * (RCCL); `comm` may be NULL when n_ranks == 1. */
 typedef struct fb_comm_s* fb_comm_t;
@@ -122,6 +126,12 @@ int fb_fem_set_exchange_mode(fb_fem_t h, int mode);
  * same semantics as destroy + create but keeps the device, parameters and constraints. State is reset. */
 int fb_fem_resync(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const int* tets,
                   int n_fixed_dofs, const int* fixed_dofs);
+/* The same on a sharded handle, COLLECTIVE (every rank calls it at the same point, with the arguments fb_fem_create_sharded
+ * takes: the whole mesh or the rank's own elements).  node_splits: the new node ranges; NULL keeps the handle's ranges when
+ * the node count is unchanged and falls to the equal split otherwise (fb_fem_resync on a sharded handle does exactly that).
+ * The exchange mode in use stays; peer-to-peer inboxes are re-attached for the new halo. */
+int fb_fem_resync_sharded(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const int* tets,
+                          int n_fixed_dofs, const int* fixed_dofs, const int* node_splits);
 
 /* Per-element rest-state rebuild on the device (M^-1 rows / volume, corotationalLinearFEM.cpp:66-90 and
  * tetMesh.cpp:184-188) -- the per-step "K0 rebuild" of BASELINE config 4. */
@@ -176,6 +186,7 @@ int fb_fem_floor_collision(fb_fem_t h, double floor_y, double restitution, int* 
 int fb_fem_num_nodes(fb_fem_t h);   /* global */
 int fb_fem_num_tets(fb_fem_t h);    /* local (all for an unsharded handle) */
 int fb_fem_num_blocks(fb_fem_t h);  /* 3x3 blocks of the stiffness pattern (owned rows) */
+int fb_fem_owned_range(fb_fem_t h, int lo_hi[2]);  /* the node range this handle owns ([0, n_nodes) when unsharded) */
 /* node-level pattern, ascending columns per row (corotationalLinearFEM.cpp:163-186, sparseMatrix.cpp:238-262):
  * bptr[n_owned+1], bcol[num_blocks] (global node ids) */
 int fb_fem_pattern(fb_fem_t h, int* bptr, int* bcol);

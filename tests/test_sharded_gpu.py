@@ -278,3 +278,88 @@ def test_field_slabs_in_processes_concatenate_to_the_whole_mesh(gpu):
     xyz, tets = g.read_tetmesh()
     assert np.array_equal(np.concatenate([res[r][1] for r in range(world)]), xyz)
     assert np.array_equal(np.concatenate([res[r][2] for r in range(world)]), tets) and len(tets) > 10000
+
+
+def _plan_worker(rank, world, shm_name, n, q):
+    """one rank: its share of the plan built on the device (sharded handles since round 2) against the host builder, array by
+    array; then a collective re-sync on the same handle against a fresh one"""
+    try:
+        import time
+        from fembrain_amd import lib as fl
+        from fembrain_amd.fem import FemIntegrator
+        L = fl.lib()
+        comm = C.c_void_p()
+        fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
+        v, t, fixed, splits = _mesh(n, world)
+        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm))
+        assert L.fb_fem_plan_on_device(g.h) == 1
+        hp = C.c_void_p()
+        tt, fd = np.ascontiguousarray(t, np.int32).reshape(-1), np.ascontiguousarray(fixed, np.int32)
+        fl.check(L.fb_plan_create(C.byref(hp), len(v), len(t), fl.iptr(tt), len(fd), fl.iptr(fd), world, rank, fl.iptr(splits)))
+        bad = []
+        for name in ("bptr", "bcol", "blk_slot", "slice_off", "colidx", "slot_coff", "slot_ccnt", "contrib"):
+            cnt = L.fb_plan_get(hp, name.encode(), None, 0)
+            want = np.zeros(cnt, np.int32)
+            assert L.fb_plan_get(hp, name.encode(), fl.iptr(want), cnt) == cnt
+            dcnt = L.fb_fem_device_plan_get(g.h, name.encode(), None, 0)
+            got = np.zeros(max(dcnt, 1), np.int32)
+            L.fb_fem_device_plan_get(g.h, name.encode(), fl.iptr(got), dcnt)
+            if dcnt != cnt or not np.array_equal(got[:dcnt], want):
+                bad.append(name)
+        L.fb_plan_destroy(hp)
+        # collective re-sync to a different mesh size and back, then a step that must equal a fresh sharded handle's
+        v2, t2, fixed2, splits2 = _mesh(n + 2 if n > 0 else n, world)
+        g.resync(v2, t2, fixed2, node_splits=splits2)
+        assert (g.node_lo, g.node_hi) == (int(splits2[rank]), int(splits2[rank + 1]))
+        t0 = time.perf_counter()
+        g.resync(v, t, fixed, node_splits=splits)
+        resync_ms = (time.perf_counter() - t0) * 1e3
+        fresh = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm))
+        # per-rank ingest: only the elements with an owned node (ascending global order), positions of other ranks' nodes poisoned
+        own = ((t >= splits[rank]) & (t < splits[rank + 1])).any(axis=1)
+        vown = np.full_like(v, np.nan)
+        used = np.unique(t[own])
+        vown[used] = v[used]
+        mine = FemIntegrator(vown, t[own], fixed, shard=(world, rank, splits, comm))
+        its = []
+        for h in (g, fresh, mine):
+            h.set_uniform_force(1, -3000.0)
+            its.append(h.do_timestep())
+        qf = fresh.get_q_state()[0]
+        same = its[0] == its[1] == its[2] and np.array_equal(g.get_q_state()[0], qf) and np.array_equal(mine.get_q_state()[0], qf)
+        q.put((rank, bad, same, resync_ms, its))
+        g.close(); fresh.close(); mine.close()
+        L.fb_comm_destroy(comm)
+    except Exception as e:
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc(), False, 0.0, []))
+        q.close()
+        q.join_thread()
+        os._exit(1)
+
+
+@pytest.mark.parametrize("world,n", [(2, 12), (3, 14), (3, -900)])
+def test_sharded_device_plan_equals_host_plan_and_resyncs(gpu, world, n):
+    """every rank's rows of the plan built by plan_device.hip (sort by local row and GLOBAL column) are bit for bit the host
+    builder's (fem_plan.cpp) -- cubes cut into slabs and a Delaunay mesh in random node order where every rank neighbours every
+    other; fb_fem_resync_sharded (collective) gives the handle a fresh one would be, and a handle created from the rank's own
+    elements only (per-rank ingest) steps bit for bit like one created from the whole mesh"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "/fembrain_test_%d_plan_%d_%d" % (os.getpid(), world, abs(n))
+    procs = [ctx.Process(target=_plan_worker, args=(r, world, name, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=240))
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for rank, bad, same, ms, its in res:
+        assert bad == [], (rank, bad)
+        assert same, (rank, its)
