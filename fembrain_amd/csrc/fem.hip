@@ -2,6 +2,7 @@
 // inspection entry points.  Kernels live in fem_device.hip.h, the host-side plan in fem_plan.cpp.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include <chrono>
 
@@ -42,6 +43,7 @@ struct fb_fem_s {
   DevBuf<short> coldelta;  // 16-bit column - row (device-built plans); c16 says whether the SpMV may use it
   bool c16 = false;
   PlanWorkspace plan_ws;  // the device plan builder's temporaries, kept for the next re-sync
+  std::vector<double> x0_stage;  // host staging of the rest positions in local numbering (kept: a re-sync does not fault fresh pages)
   DevBuf<int> d_bptr, d_bcol, d_blk_slot;  // device-built plan only: pattern and slot table, fetched when an inspection entry point asks
   bool device_plan = false, host_pattern = true;
   DevBuf<uint8_t> dofmask;
@@ -126,10 +128,16 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
     hipLaunchKernelGGL(k_widen_positions, dim3((unsigned)((n3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n3, xyz_device, h->x0.p);
     FB_HIP(hipGetLastError());
   } else {
-    std::vector<double> x0((size_t)3 * P.n_local);
-    for (int l = 0; l < P.n_local; l++)
-      for (int k = 0; k < 3; k++) x0[3 * (size_t)l + k] = xyz_global[3 * (size_t)P.local2global[l] + k];
-    FB_TRY(h->x0.upload(x0, s));
+    if (P.n_ranks == 1) {  // identity numbering
+      FB_TRY(h->x0.upload(xyz_global, (size_t)3 * P.n_local, s));
+    } else {
+      std::vector<double>& x0 = h->x0_stage;
+      x0.resize((size_t)3 * P.n_local);
+      memcpy(x0.data(), xyz_global + 3 * (size_t)P.node_lo, sizeof(double) * 3 * (size_t)P.n_owned);  // owned nodes are a contiguous global range
+      for (int l = P.n_owned; l < P.n_local; l++)
+        for (int k = 0; k < 3; k++) x0[3 * (size_t)l + k] = xyz_global[3 * (size_t)P.local2global[l] + k];
+      FB_TRY(h->x0.upload(x0, s));
+    }
   }
   FB_TRY(h->rest.alloc((size_t)16 * P.n_tets));
   FB_TRY(h->fe.alloc((size_t)12 * P.n_tets));
@@ -826,22 +834,80 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   return FB_OK;
 }
 
+// global node ids of a rank's elements -> local ids: owned nodes first, then the halo in ascending global order
+__global__ void __launch_bounds__(kBlock) k_tets_to_local(int n_tets, int4* __restrict__ tets, int node_lo, int n_owned, const int* __restrict__ halo, int n_halo) {
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n_tets) return;
+  int4 t = tets[e];
+  int* v = &t.x;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int g = v[i];
+    if (g >= node_lo && g < node_lo + n_owned) { v[i] = g - node_lo; continue; }
+    int lo = 0, hi = n_halo;  // lower bound; g is in the list by construction
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (halo[mid] < g) lo = mid + 1; else hi = mid;
+    }
+    v[i] = n_owned + lo;
+  }
+  tets[e] = t;
+}
+
 // One rank's share of a sharded system: partition, local numbering, halo and send lists on the host (build_fem_partition: one
 // pass over the element list), then pattern / SELL-64 / contribution lists of the owned rows on the device -- the part that
 // took 68-75 ms per rank at 1M tets on the host.
 int build_shard_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed, int n_ranks, int rank,
                                const int* splits) {
   FemPlan& P = h->plan;
-  FB_TRY(build_fem_partition(P, n_nodes, n_tets, tets, n_ranks, rank, splits));
-  FB_TRY(plan_set_constraints(P, n_fixed, fixed));
-  FB_TRY(h->tets.upload((const int4*)P.tets.data(), (size_t)P.n_tets, h->stream));
+  static const bool timing = getenv("FEMBRAIN_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (timing) fprintf(stderr, "[fembrain] shard plan: %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  };
+  // per-rank ingest (the caller's elements are exactly this rank's): the partition is computed on the device from the uploaded
+  // list -- halo, send lists, local numbering; otherwise (the whole mesh passed in, or more than 64 ranks) on the host
+  bool on_device = n_ranks <= 64 && !(getenv("FEMBRAIN_PARTITION_DEVICE") && atoi(getenv("FEMBRAIN_PARTITION_DEVICE")) == 0);
   DevBuf<int> d_halo;
+  if (on_device) {
+    FB_TRY(begin_fem_partition(P, n_nodes, n_tets, n_ranks, rank, splits));
+    FB_TRY(h->tets.upload((const int4*)tets, (size_t)n_tets, h->stream));
+    DevicePartition dp;
+    const int rc = device_partition(h->stream, n_tets, h->tets.p, n_nodes, n_ranks, rank, P.splits, dp, h->plan_ws);
+    if (rc != FB_OK && dp.first_bad_tet >= 0) {  // say which node, as the host builder does
+      for (int k = 0; k < 4; k++) {
+        const int id = tets[4 * (size_t)dp.first_bad_tet + k];
+        if (id < 0 || id >= n_nodes) return fail(FB_EINVAL, "tet %d references node %d outside [0,%d)", dp.first_bad_tet, id, n_nodes);
+      }
+    }
+    FB_TRY(rc);
+    on_device = dp.all_kept;
+    if (on_device) {
+      P.n_tets = n_tets;
+      P.n_owned_corners = dp.owned_corners;
+      set_partition_halo(P, dp.halo);
+      P.send_off = dp.send_off;
+      P.send_local = dp.send_local;
+    }
+  }
+  if (!on_device) FB_TRY(build_fem_partition(P, n_nodes, n_tets, tets, n_ranks, rank, splits, false));
+  lap(on_device ? "partition (device)" : "partition (host)");
+  FB_TRY(plan_set_constraints(P, n_fixed, fixed));
+  lap("constraints");
   if (P.n_halo > 0) FB_TRY(d_halo.upload(P.local2global.data() + P.n_owned, (size_t)P.n_halo, h->stream));
+  if (on_device) {
+    // numbered locally already
+  } else if (P.tets.empty()) {  // host partition of the caller's own list: local numbering on the device
+    FB_TRY(h->tets.upload((const int4*)tets, (size_t)P.n_tets, h->stream));
+    hipLaunchKernelGGL(k_tets_to_local, dim3(ceil_div(P.n_tets, kBlock)), dim3(kBlock), 0, h->stream, P.n_tets, h->tets.p, P.node_lo, P.n_owned, d_halo.p, P.n_halo);
+    FB_HIP(hipGetLastError());
+  } else {
+    FB_TRY(h->tets.upload((const int4*)P.tets.data(), (size_t)P.n_tets, h->stream));
+  }
+  lap("element upload");
   PlanShard sh;
   sh.n_rows = P.n_owned; sh.node_lo = P.node_lo; sh.n_global = P.n_global; sh.d_halo = d_halo.p; sh.n_halo = P.n_halo;
-  long long owned_corners = 0;
-  for (size_t k = 0; k < P.tets.size(); k++) owned_corners += P.tets[k] < P.n_owned ? 1 : 0;
-  sh.n_pairs = 4 * owned_corners + P.n_owned;
+  sh.n_pairs = 4 * P.n_owned_corners + P.n_owned;
   DevicePlan D;
   D.slice_off = &h->slice_off; D.colidx = &h->colidx; D.slot_coff = &h->slot_coff; D.slot_ccnt = &h->slot_ccnt; D.contrib = &h->contrib;
   D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot; D.coldelta = &h->coldelta;
@@ -920,7 +986,8 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
     FB_TRY(launch_rest(h, flat.p));
     int first = none;
     FB_TRY(flat.download(&first, 1, h->stream));
-    if (first != none) return fail(FB_EINVAL, "element %d has zero (or non-finite) rest volume", first);
+    if (first != none)
+      return fail(FB_EINVAL, "element %d has zero (or non-finite) rest volume", h->plan.tet_global.empty() ? first : h->plan.tet_global[first]);
   } else {
     FB_TRY(launch_rest(h));
     FB_HIP(hipStreamSynchronize(h->stream));

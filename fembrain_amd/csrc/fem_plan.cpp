@@ -2,6 +2,7 @@
 #include "fem_plan.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -70,11 +71,18 @@ int plan_set_constraints(FemPlan& P, int n_fixed, const int* fixed_dofs) {
   return FB_OK;
 }
 
-int build_fem_partition(FemPlan& P, int n_nodes, int n_tets, const int* tets, int n_ranks, int rank, const int* splits) {
-  if (n_nodes <= 0 || n_tets <= 0 || !tets) return fail(FB_EINVAL, "empty mesh (%d nodes, %d tets)", n_nodes, n_tets);
+int begin_fem_partition(FemPlan& P, int n_nodes, int n_tets, int n_ranks, int rank, const int* splits) {
+  if (n_nodes <= 0 || n_tets <= 0) return fail(FB_EINVAL, "empty mesh (%d nodes, %d tets)", n_nodes, n_tets);
   if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(FB_EINVAL, "bad rank %d of %d", rank, n_ranks);
   if ((long long)n_tets >= (1LL << 28)) return fail(FB_EINVAL, "too many tets for the packed contribution word");
-  P = FemPlan();
+  {
+    // a re-sync builds into the same object: the element arrays keep their storage (16 MB of fresh pages at 1M tets cost more
+    // than the passes that fill them)
+    std::vector<int> keep_tets = std::move(P.tets), keep_ids = std::move(P.tet_global), keep_l2g = std::move(P.local2global);
+    P = FemPlan();
+    P.tets = std::move(keep_tets); P.tet_global = std::move(keep_ids); P.local2global = std::move(keep_l2g);
+    P.tets.clear(); P.tet_global.clear(); P.local2global.clear();
+  }
   P.n_global = n_nodes; P.n_ranks = n_ranks; P.rank = rank;
   P.splits.assign(n_ranks + 1, 0);
   if (splits) {
@@ -87,78 +95,148 @@ int build_fem_partition(FemPlan& P, int n_nodes, int n_tets, const int* tets, in
     if (P.splits[i + 1] <= P.splits[i]) return fail(FB_EINVAL, "rank %d owns no nodes", i);
   P.node_lo = P.splits[rank]; P.node_hi = P.splits[rank + 1];
   P.n_owned = P.node_hi - P.node_lo;
-  for (long long k = 0; k < 4LL * n_tets; k++)
-    if (tets[k] < 0 || tets[k] >= n_nodes) return fail(FB_EINVAL, "tet %lld references node %d outside [0,%d)", k / 4, tets[k], n_nodes);
+  return FB_OK;
+}
 
-  // local tets: any owned node
-  auto owned = [&](int g) { return g >= P.node_lo && g < P.node_hi; };
-  if (n_ranks == 1) {
-    P.tet_global.resize(n_tets);
-    for (int e = 0; e < n_tets; e++) P.tet_global[e] = e;
-  } else {
-    for (int e = 0; e < n_tets; e++) {
-      const int* t = tets + 4 * (size_t)e;
-      if (owned(t[0]) || owned(t[1]) || owned(t[2]) || owned(t[3])) P.tet_global.push_back(e);
-    }
-  }
-  P.n_tets = (int)P.tet_global.size();
-  // halo = non-owned nodes of local tets
-  std::vector<int> halo;
-  for (int le = 0; le < (n_ranks == 1 ? 0 : P.n_tets); le++) {
-    const int* t = tets + 4 * (size_t)P.tet_global[le];
-    for (int i = 0; i < 4; i++)
-      if (!owned(t[i])) halo.push_back(t[i]);
-  }
-  std::sort(halo.begin(), halo.end());
-  halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
+void set_partition_halo(FemPlan& P, const std::vector<int>& halo) {
   P.n_halo = (int)halo.size();
   P.n_local = P.n_owned + P.n_halo;
   P.local2global.resize(P.n_local);
   for (int l = 0; l < P.n_owned; l++) P.local2global[l] = P.node_lo + l;
   for (int h = 0; h < P.n_halo; h++) P.local2global[P.n_owned + h] = halo[h];
-  P.halo_off.assign(n_ranks + 1, 0);
+  P.halo_off.assign(P.n_ranks + 1, 0);
   for (int h = 0; h < P.n_halo; h++) P.halo_off[owner_of(P.splits, halo[h]) + 1]++;
-  for (int q = 0; q < n_ranks; q++) P.halo_off[q + 1] += P.halo_off[q];
-  auto to_local = [&](int g) -> int {
-    if (owned(g)) return g - P.node_lo;
-    return P.n_owned + int(std::lower_bound(halo.begin(), halo.end(), g) - halo.begin());
+  for (int q = 0; q < P.n_ranks; q++) P.halo_off[q + 1] += P.halo_off[q];
+}
+
+int build_fem_partition(FemPlan& P, int n_nodes, int n_tets, const int* tets, int n_ranks, int rank, const int* splits, bool need_local_tets) {
+  static const bool timing = getenv("FEMBRAIN_TIMING") != nullptr;  // development aid, as in fem.hip's build()
+  const auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (timing) fprintf(stderr, "[fembrain] partition: %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   };
-  if (n_ranks == 1) {
-    P.tets.assign(tets, tets + (size_t)4 * n_tets);  // local ids are the global ones
-  } else {
-    P.tets.resize((size_t)4 * P.n_tets);
-    for (int le = 0; le < P.n_tets; le++)
-      for (int i = 0; i < 4; i++) P.tets[(size_t)4 * le + i] = to_local(tets[4 * (size_t)P.tet_global[le] + i]);
-  }
-
-  // send lists: my owned nodes that share a tet with a node owned by q (that is exactly q's halo inside my range)
+  if (!tets) return fail(FB_EINVAL, "empty mesh (%d nodes, %d tets)", n_nodes, n_tets);
   {
-    std::vector<std::vector<int>> snd(n_ranks);
-    for (int le = 0; le < (n_ranks == 1 ? 0 : P.n_tets); le++) {
-      const int* t = tets + 4 * (size_t)P.tet_global[le];
-      int own[4];
-      for (int i = 0; i < 4; i++) own[i] = owned(t[i]) ? rank : owner_of(P.splits, t[i]);
-      for (int i = 0; i < 4; i++)
-        if (own[i] == rank)
-          for (int j = 0; j < 4; j++)
-            if (own[j] != rank) snd[own[j]].push_back(t[i] - P.node_lo);
-    }
-    P.send_off.assign(n_ranks + 1, 0);
-    for (int q = 0; q < n_ranks; q++) {
-      std::sort(snd[q].begin(), snd[q].end());
-      snd[q].erase(std::unique(snd[q].begin(), snd[q].end()), snd[q].end());
-      P.send_off[q + 1] = P.send_off[q] + (int)snd[q].size();
-      P.send_local.insert(P.send_local.end(), snd[q].begin(), snd[q].end());
-    }
+    const int rc = begin_fem_partition(P, n_nodes, n_tets, n_ranks, rank, splits);
+    if (rc != FB_OK) return rc;
+  }
+  auto owned = [&](int g) { return g >= P.node_lo && g < P.node_hi; };
+  if (n_ranks == 1) {  // local ids are the global ones
+    for (long long k = 0; k < 4LL * n_tets; k++)
+      if (tets[k] < 0 || tets[k] >= n_nodes) return fail(FB_EINVAL, "tet %lld references node %d outside [0,%d)", k / 4, tets[k], n_nodes);
+    P.tet_global.resize(n_tets);
+    for (int e = 0; e < n_tets; e++) P.tet_global[e] = e;
+    P.n_tets = n_tets;
+    P.n_halo = 0;
+    P.n_local = P.n_owned;
+    P.local2global.resize(P.n_local);
+    for (int l = 0; l < P.n_owned; l++) P.local2global[l] = l;
+    P.halo_off.assign(2, 0);
+    P.send_off.assign(2, 0);
+    P.tets.assign(tets, tets + (size_t)4 * n_tets);
+    P.n_owned_corners = 4LL * n_tets;
+    return FB_OK;
   }
 
+  lap("reset");
+  // Pass 1, element-parallel (contiguous element ranges per host thread, results joined in thread order so nothing depends
+  // on the thread count): range check, the elements with an owned node, their foreign nodes (halo candidates) and, per
+  // neighbour rank, the owned nodes it will want (send candidates).  A re-sync after a cut runs this on every rank.
+  const int T = plan_threads(n_tets / 8);
+  auto tet_lo = [&](int t) { return (int)((long long)n_tets * t / T); };
+  struct Part {
+    std::vector<int> halo;
+    std::vector<std::pair<int, int>> send;  // (rank, owned local id)
+    long long bad = -1, corners = 0;
+    int n_mine = 0;
+  };
+  std::vector<Part> part(T);
+  parallel_for(T, [&](int t) {
+    Part& W = part[t];
+    for (int e = tet_lo(t); e < tet_lo(t + 1); e++) {
+      const int* v = tets + 4 * (size_t)e;
+      bool own[4];
+      int n_own = 0;
+      for (int i = 0; i < 4; i++) {
+        if (v[i] < 0 || v[i] >= n_nodes) { if (W.bad < 0) W.bad = 4LL * e + i; own[i] = false; continue; }
+        own[i] = owned(v[i]);
+        n_own += own[i];
+      }
+      if (!n_own || W.bad >= 0) continue;
+      W.n_mine++;
+      W.corners += n_own;
+      if (n_own == 4) continue;
+      for (int j = 0; j < 4; j++) {
+        if (own[j]) continue;
+        W.halo.push_back(v[j]);
+        const int qj = owner_of(P.splits, v[j]);
+        for (int i = 0; i < 4; i++)
+          if (own[i]) W.send.emplace_back(qj, v[i] - P.node_lo);
+      }
+    }
+    std::sort(W.halo.begin(), W.halo.end());
+    W.halo.erase(std::unique(W.halo.begin(), W.halo.end()), W.halo.end());
+    std::sort(W.send.begin(), W.send.end());
+    W.send.erase(std::unique(W.send.begin(), W.send.end()), W.send.end());
+  });
+  lap("pass 1");
+  for (int t = 0; t < T; t++)
+    if (part[t].bad >= 0) {
+      const long long k = part[t].bad;
+      return fail(FB_EINVAL, "tet %lld references node %d outside [0,%d)", k / 4, tets[k], n_nodes);
+    }
+  std::vector<int> halo;
+  std::vector<std::pair<int, int>> send;
+  P.n_owned_corners = 0;
+  std::vector<int> first(T + 1, 0);  // local id of the first element each thread keeps
+  for (int t = 0; t < T; t++) {
+    first[t + 1] = first[t] + part[t].n_mine;
+    halo.insert(halo.end(), part[t].halo.begin(), part[t].halo.end());
+    send.insert(send.end(), part[t].send.begin(), part[t].send.end());
+    P.n_owned_corners += part[t].corners;
+  }
+  P.n_tets = first[T];
+  // halo = non-owned nodes of local tets, ascending => grouped by owner
+  std::sort(halo.begin(), halo.end());
+  halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
+  set_partition_halo(P, halo);
+  // send lists: my owned nodes that share a tet with a node owned by q (that is exactly q's halo inside my range), ascending
+  std::sort(send.begin(), send.end());
+  send.erase(std::unique(send.begin(), send.end()), send.end());
+  P.send_off.assign(n_ranks + 1, 0);
+  P.send_local.reserve(send.size());
+  for (const auto& qs : send) {
+    P.send_off[qs.first + 1]++;
+    P.send_local.push_back(qs.second);
+  }
+  for (int q = 0; q < n_ranks; q++) P.send_off[q + 1] += P.send_off[q];
+
+  lap("halo and send lists");
+  // per-rank ingest (the caller passed exactly this rank's elements) feeding the device builder: the elements are numbered
+  // locally by a device kernel from the caller's array, nothing to compact
+  if (!need_local_tets && P.n_tets == n_tets) return FB_OK;
+  // Pass 2, the same element ranges: global ids and local numbering of the kept elements
+  P.tet_global.resize((size_t)P.n_tets);
+  P.tets.resize((size_t)4 * P.n_tets);
+  parallel_for(T, [&](int t) {
+    int le = first[t];
+    for (int e = tet_lo(t); e < tet_lo(t + 1); e++) {
+      const int* v = tets + 4 * (size_t)e;
+      if (!(owned(v[0]) || owned(v[1]) || owned(v[2]) || owned(v[3]))) continue;
+      P.tet_global[le] = e;
+      for (int i = 0; i < 4; i++)
+        P.tets[(size_t)4 * le + i] = owned(v[i]) ? v[i] - P.node_lo : P.n_owned + int(std::lower_bound(halo.begin(), halo.end(), v[i]) - halo.begin());
+      le++;
+    }
+  });
+  lap("pass 2");
   return FB_OK;
 }
 
 int build_fem_plan(FemPlan& P, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed_dofs,
                    int n_ranks, int rank, const int* splits) {
   {
-    const int rc = build_fem_partition(P, n_nodes, n_tets, tets, n_ranks, rank, splits);
+    const int rc = build_fem_partition(P, n_nodes, n_tets, tets, n_ranks, rank, splits, true);
     if (rc != FB_OK) return rc;
   }
   auto owned = [&](int g) { return g >= P.node_lo && g < P.node_hi; };

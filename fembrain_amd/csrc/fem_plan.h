@@ -43,8 +43,9 @@ struct FemPlan {
   std::vector<int> send_local;             // owned local ids to pack for rank q: [send_off[q], send_off[q+1]), ascending
   // --- local elements ---
   int n_tets = 0;                          // tets with at least one owned node
-  std::vector<int> tet_global;             // n_tets global element ids (ascending)
+  std::vector<int> tet_global;             // n_tets global element ids (ascending); empty = 0..n_tets-1 of the caller's list
   std::vector<int> tets;                   // 4*n_tets local node ids
+  long long n_owned_corners = 0;           // element corners on an owned node (the device builder's pair count)
   // --- block pattern of owned rows (CSR, ascending global column order) ---
   std::vector<int> bptr;                   // n_owned+1
   std::vector<int> bcol;                   // local column ids
@@ -71,7 +72,14 @@ int build_fem_plan(FemPlan& plan, int n_nodes, int n_tets, const int* tets, int 
                    int n_ranks, int rank, const int* splits);
 // The first half of build_fem_plan only: partition, local elements and numbering, halo and send lists -- what the device plan
 // builder (plan_device.hip) needs from the host before it lays out pattern, SELL-64 and contribution lists itself.
-int build_fem_partition(FemPlan& plan, int n_nodes, int n_tets, const int* tets, int n_ranks, int rank, const int* splits);
+// need_local_tets = false: when every element passed in is kept (per-rank ingest), plan.tets / plan.tet_global stay empty (the
+// kept elements are the caller's, in the caller's order) and the caller numbers them locally itself.
+int build_fem_partition(FemPlan& plan, int n_nodes, int n_tets, const int* tets, int n_ranks, int rank, const int* splits,
+                        bool need_local_tets = true);
+// the two ends of build_fem_partition, for a partition computed elsewhere (plan_device.hip device_partition): reset + node
+// ranges (validated), and local numbering / per-owner offsets from the ascending halo list
+int begin_fem_partition(FemPlan& plan, int n_nodes, int n_tets, int n_ranks, int rank, const int* splits);
+void set_partition_halo(FemPlan& plan, const std::vector<int>& halo);
 int plan_set_constraints(FemPlan& plan, int n_fixed, const int* fixed_dofs);
 
 }  // namespace fb

@@ -161,7 +161,156 @@ __global__ __launch_bounds__(kB) void k_plan_contrib(int n_nodes, int n_slices, 
   }
 }
 
+// ---- partition of one rank from its own elements ------------------------------------------------------------------------
+struct PartCounters { int first_bad, bad_node, not_kept, pad; unsigned long long corners; };
+
+__device__ __forceinline__ int owner_of_node(const int* __restrict__ splits, int n_ranks, int g) {
+  int lo = 0, hi = n_ranks;  // largest q with splits[q] <= g
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (splits[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(kB) void k_part_mark(int n_tets, const int4* __restrict__ tets, int n_global, int node_lo, int n_owned, const int* __restrict__ splits,
+                                                  int n_ranks, unsigned char* __restrict__ nodeflag, unsigned long long* __restrict__ sendmask, PartCounters* __restrict__ cnt) {
+  const int e = blockIdx.x * kB + threadIdx.x;
+  int n_own = 0;
+  if (e < n_tets) {
+    const int4 t = tets[e];
+    const int v[4] = {t.x, t.y, t.z, t.w};
+    bool bad = false, own[4];
+    for (int i = 0; i < 4; i++) {
+      if ((unsigned int)v[i] >= (unsigned int)n_global) {
+        if (!bad && atomicMin(&cnt->first_bad, e) > e) cnt->bad_node = v[i];  // (the node reported may belong to another bad tet under a race; the host re-reads its own list)
+        bad = true;
+        own[i] = false;
+        continue;
+      }
+      own[i] = v[i] >= node_lo && v[i] < node_lo + n_owned;
+      n_own += own[i];
+    }
+    if (!bad) {
+      if (!n_own) atomicAdd(&cnt->not_kept, 1);
+      else if (n_own < 4) {
+        unsigned long long want = 0;
+        for (int j = 0; j < 4; j++)
+          if (!own[j]) {
+            nodeflag[v[j]] = 1;
+            want |= 1ull << owner_of_node(splits, n_ranks, v[j]);
+          }
+        for (int i = 0; i < 4; i++)
+          if (own[i]) atomicOr(&sendmask[v[i] - node_lo], want);
+      }
+    } else {
+      n_own = 0;
+    }
+  }
+  // corners on owned nodes: one atomic per wavefront
+  for (int o = 32; o; o >>= 1) n_own += __shfl_down(n_own, o);
+  if ((threadIdx.x & 63) == 0 && n_own) atomicAdd(&cnt->corners, (unsigned long long)n_own);
+}
+
+struct WantedBy {
+  const unsigned long long* mask;
+  int q;
+  __device__ bool operator()(int i) const { return (mask[i] >> q) & 1ull; }
+};
+
+__global__ __launch_bounds__(kB) void k_part_local(int n_tets, int4* __restrict__ tets, int node_lo, int n_owned, const int* __restrict__ halo, int n_halo) {
+  const int e = blockIdx.x * kB + threadIdx.x;
+  if (e >= n_tets) return;
+  int4 t = tets[e];
+  int* v = &t.x;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int g = v[i];
+    if (g >= node_lo && g < node_lo + n_owned) { v[i] = g - node_lo; continue; }
+    int lo = 0, hi = n_halo;  // lower bound; g is in the list by construction
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (halo[mid] < g) lo = mid + 1; else hi = mid;
+    }
+    v[i] = n_owned + lo;
+  }
+  tets[e] = t;
+}
+
 }  // namespace
+
+int device_partition(hipStream_t s, int n_tets, int4* d_tets, int n_global, int n_ranks, int rank, const std::vector<int>& splits,
+                     DevicePartition& out, PlanWorkspace& W) {
+  if (n_ranks > 64 || n_ranks < 2) return fail(FB_EINVAL, "device partition handles 2..64 ranks");
+  const int node_lo = splits[rank], n_owned = splits[rank + 1] - splits[rank];
+  out = DevicePartition();
+  FB_TRY(W.nodeflag.reserve((size_t)n_global));
+  FB_TRY(W.sendmask.reserve((size_t)n_owned));
+  FB_TRY(W.picked.reserve((size_t)std::max(n_global, n_owned) + 4));
+  FB_TRY(W.splits.reserve((size_t)n_ranks + 1));
+  FB_TRY(W.keys.reserve(4));  // the counters (8-byte aligned)
+  PartCounters* d_cnt = reinterpret_cast<PartCounters*>(W.keys.p);
+  PartCounters cnt = {0x7fffffff, 0, 0, 0, 0ull};
+  FB_HIP(hipMemcpyAsync(d_cnt, &cnt, sizeof cnt, hipMemcpyHostToDevice, s));
+  FB_HIP(hipMemcpyAsync(W.splits.p, splits.data(), sizeof(int) * (n_ranks + 1), hipMemcpyHostToDevice, s));
+  FB_HIP(hipMemsetAsync(W.nodeflag.p, 0, (size_t)n_global, s));
+  FB_HIP(hipMemsetAsync(W.sendmask.p, 0, sizeof(unsigned long long) * (size_t)n_owned, s));
+  hipLaunchKernelGGL(k_part_mark, dim3((n_tets + kB - 1) / kB), dim3(kB), 0, s, n_tets, d_tets, n_global, node_lo, n_owned, W.splits.p, n_ranks, W.nodeflag.p,
+                     W.sendmask.p, d_cnt);
+  FB_HIP(hipGetLastError());
+  // halo = the marked nodes, ascending
+  int* d_count = W.picked.p + std::max(n_global, n_owned);
+  size_t bytes = 0;
+  FB_HIP(rocprim::select(nullptr, bytes, rocprim::counting_iterator<int>(0), W.nodeflag.p, W.picked.p, d_count, (size_t)n_global, s));
+  FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+  FB_HIP(rocprim::select(W.temp.p, bytes, rocprim::counting_iterator<int>(0), W.nodeflag.p, W.picked.p, d_count, (size_t)n_global, s));
+  int n_halo = 0;
+  FB_HIP(hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
+  FB_HIP(hipMemcpyAsync(&n_halo, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+  FB_HIP(hipStreamSynchronize(s));
+  if (cnt.first_bad != 0x7fffffff) {
+    out.first_bad_tet = cnt.first_bad;
+    out.bad_node = cnt.bad_node;
+    return fail(FB_EINVAL, "tet %d references a node outside [0,%d)", cnt.first_bad, n_global);
+  }
+  out.all_kept = cnt.not_kept == 0;
+  out.owned_corners = (long long)cnt.corners;
+  if (!out.all_kept) return FB_OK;
+  out.halo.resize((size_t)n_halo);
+  if (n_halo) FB_HIP(hipMemcpyAsync(out.halo.data(), W.picked.p, sizeof(int) * (size_t)n_halo, hipMemcpyDeviceToHost, s));
+  // local numbering of the elements while the halo list is still in W.picked
+  hipLaunchKernelGGL(k_part_local, dim3((n_tets + kB - 1) / kB), dim3(kB), 0, s, n_tets, d_tets, node_lo, n_owned, W.picked.p, n_halo);
+  FB_HIP(hipGetLastError());
+  FB_HIP(hipStreamSynchronize(s));
+  // send lists: the neighbours are the owners of the halo nodes (a rank that wants my nodes owns nodes of the same elements)
+  out.send_off.assign((size_t)n_ranks + 1, 0);
+  std::vector<char> neighbour((size_t)n_ranks, 0);
+  {
+    int q = 0;
+    for (int g : out.halo) {
+      while (g >= splits[q + 1]) q++;
+      neighbour[q] = 1;
+    }
+  }
+  for (int q = 0; q < n_ranks; q++) {
+    if (neighbour[q]) {
+      WantedBy pred = {W.sendmask.p, q};
+      size_t b2 = 0;
+      FB_HIP(rocprim::select(nullptr, b2, rocprim::counting_iterator<int>(0), W.picked.p, d_count, (size_t)n_owned, pred, s));
+      FB_TRY(W.temp.reserve(std::max<size_t>(b2, 16)));
+      FB_HIP(rocprim::select(W.temp.p, b2, rocprim::counting_iterator<int>(0), W.picked.p, d_count, (size_t)n_owned, pred, s));
+      int n_send = 0;
+      FB_HIP(hipMemcpyAsync(&n_send, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+      FB_HIP(hipStreamSynchronize(s));
+      const size_t at = out.send_local.size();
+      out.send_local.resize(at + (size_t)n_send);
+      if (n_send) FB_HIP(hipMemcpyAsync(out.send_local.data() + at, W.picked.p, sizeof(int) * (size_t)n_send, hipMemcpyDeviceToHost, s));
+      FB_HIP(hipStreamSynchronize(s));
+    }
+    out.send_off[q + 1] = (int)out.send_local.size();
+  }
+  return FB_OK;
+}
 
 int build_plan_device(hipStream_t s, int n_nodes_local, int n_tets, const int4* d_tets, DevicePlan& D, PlanWorkspace& W, const PlanShard* shard) {
   // n_nodes: matrix rows (owned nodes); n_nodes_local: range of the node ids in d_tets

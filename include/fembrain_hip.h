@@ -98,7 +98,7 @@ int fb_fem_create(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
  * force/stiffness reduction is needed.
  * Per-rank ingest: `tets` may be the whole element list (the rank filters it) or ONLY THE RANK'S OWN ELEMENTS -- every tet
  * with at least one owned node, global node ids, in ascending global element order (the order fixes the rounding of the
- * assembled sums).  Only the xyz rows of nodes those elements reference are read, so a rank may back `xyz` with a sparse
+ * assembled sums).  Only the xyz rows of owned nodes and of nodes those elements reference are read, so a rank may back `xyz` with a sparse
  * mapping.  The plan (pattern, SELL-64, contribution lists) of the owned rows is built on the device.
  * Per PCG iteration: one halo exchange of the search direction and two fp64 scalar all-reduces over `comm`
  * (RCCL); `comm` may be NULL when n_ranks == 1. */
