@@ -43,10 +43,15 @@ struct fb_fem_s {
   DevBuf<short> coldelta;  // 16-bit column - row (device-built plans); c16 says whether the SpMV may use it
   bool c16 = false;
   PlanWorkspace plan_ws;  // the device plan builder's temporaries, kept for the next re-sync
+  DevBuf<int> inc_off;               // element-major assembly (k_assemble_tets): incidence lists per slice, see fem_device.hip.h
+  DevBuf<uint32_t> inc, inc_slot;
+  bool asm_tets = false;             // the assembly kernel in use
+  int asm_lds = 0, asm_grid = 0, asm_max_width = 0;
   std::vector<double> x0_stage;  // host staging of the rest positions in local numbering (kept: a re-sync does not fault fresh pages)
   DevBuf<int> d_bptr, d_bcol, d_blk_slot;  // device-built plan only: pattern and slot table, fetched when an inspection entry point asks
   bool device_plan = false, host_pattern = true;
   DevBuf<uint8_t> dofmask;
+  DevBuf<uint8_t> nodemask;  // the three dofmask bytes of a node as bits 0..2 (one gather per column in the assembly)
   DevBuf<char> vals;  // MT[n_slots][9][64]
   DevBuf<char> dlo;   // MT[n_slices][9][64]: low part of every row's diagonal block
   DevBuf<double> mblk;
@@ -109,6 +114,14 @@ __global__ __launch_bounds__(kBlock) void k_widen_positions(long long n, const f
   if (i < n) out[i] = (double)in[i];
 }
 
+int upload_masks(fb_fem_s* h) {
+  const FemPlan& P = h->plan;
+  FB_TRY(h->dofmask.upload(P.dofmask, h->stream));
+  std::vector<uint8_t> nm((size_t)P.n_local);
+  for (int l = 0; l < P.n_local; l++) nm[l] = (uint8_t)((P.dofmask[3 * (size_t)l] ? 1 : 0) | (P.dofmask[3 * (size_t)l + 1] ? 2 : 0) | (P.dofmask[3 * (size_t)l + 2] ? 4 : 0));
+  return h->nodemask.upload(nm, h->stream);
+}
+
 int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device = nullptr) {
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
@@ -144,7 +157,7 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   FB_TRY(h->rec.alloc((size_t)16 * P.n_tets * mt_size(h)));
   if (h->prm.exact_tangent && !h->prm.linear) FB_TRY(h->kcorr.alloc((size_t)144 * P.n_tets * mt_size(h)));
   else h->kcorr.release();
-  FB_TRY(h->dofmask.upload(P.dofmask, s));
+  FB_TRY(upload_masks(h));
   if (!P.send_local.empty()) FB_TRY(h->send_local.upload(P.send_local, s));
   FB_TRY(h->sendbuf.alloc(std::max<size_t>(1, (size_t)12 * P.send_local.size())));
   FB_TRY(h->vals.alloc((size_t)P.n_slots * 9 * 64 * mt_size(h)));
@@ -153,6 +166,35 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   FB_TRY(h->dlo.zero(s));
   FB_TRY(h->mblk.alloc((size_t)P.n_slots * 64));
   FB_TRY(h->mblk.zero(s));
+  {
+    // Element-major assembly where the accumulators of the widest slice fit the LDS of a CU (5 KB per slot: up to 32 slots);
+    // FEMBRAIN_ASM_KERNEL=rows keeps the slot-major kernel (same result bit for bit, tests/test_fem_gpu.py)
+    int mw = 0;
+    for (int sl = 0; sl < P.n_slices; sl++) mw = std::max(mw, P.slice_off[sl + 1] - P.slice_off[sl]);
+    hipDeviceProp_t prop;
+    FB_HIP(hipGetDeviceProperties(&prop, h->prm.device));
+    const int lds_cu = (int)std::min<size_t>(std::max<size_t>(prop.maxSharedMemoryPerMultiProcessor, prop.sharedMemPerBlock), 160 * 1024);  // gfx950: 160 KB per CU
+    const char* e = getenv("FEMBRAIN_ASM_KERNEL");
+    h->asm_max_width = mw;
+    h->asm_lds = (mw * 10 + kAsmExtra) * 64 * (int)sizeof(double);
+    h->asm_tets = mw >= 2 && h->asm_lds <= lds_cu && h->asm_lds <= (int)prop.sharedMemPerBlock && !(e && !strcmp(e, "rows"));
+    if (h->asm_tets) {
+      FB_TRY(build_incidence_device(s, P.n_slices, P.n_owned, h->slice_off.p, h->colidx.p, h->slot_coff.p, h->slot_ccnt.p, h->contrib.p, h->tets.p, h->inc_off,
+                                    h->inc, h->inc_slot, h->plan_ws));
+      int per_cu = std::max(1, lds_cu / h->asm_lds);
+      if (const char* pc = getenv("FEMBRAIN_ASM_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(pc)));  // development aid
+      const int cus = std::max(8, (prop.multiProcessorCount / 8) * 8);
+      const int chunk = ceil_div(P.n_slices, 8);
+      h->asm_grid = 8 * std::max(1, std::min(chunk, (cus / 8) * per_cu));
+      if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] element-major assembly: %d workgroups, %d B of LDS each (%d per CU; device reports %zu / %zu)\n", h->asm_grid, h->asm_lds, per_cu, (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlock);
+      const bool tangent = h->prm.exact_tangent && !h->prm.linear;
+      const void* kern = h->f64 ? (tangent ? (const void*)k_assemble_tets<double, 2, true> : (const void*)k_assemble_tets<double, 2, false>)
+                                : (tangent ? (const void*)k_assemble_tets<float, 4, true> : (const void*)k_assemble_tets<float, 4, false>);
+      FB_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, h->asm_lds));
+    } else {
+      h->inc_off.release(); h->inc.release(); h->inc_slot.release();
+    }
+  }
   if (h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI) {
     if (P.n_ranks > 1) return fail(FB_EINVAL, "FB_PCG_BLOCK_JACOBI is for unsharded handles");
     FB_TRY(h->invblk.alloc((size_t)9 * P.n_local));
@@ -285,9 +327,36 @@ int launch_warp(fb_fem_s* h, const double* u, double* rot) {
 template <typename MT>
 int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const double* fext, double* mblk_out, double* fint_out,
                 double* rhs, double* invdiag, const double* qacc = nullptr) {
-  hipLaunchKernelGGL(k_assemble_rows<MT>, dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), h->slot_coff.p, h->slot_ccnt.p,
-                     h->contrib.p, (const MT*)h->rec.p, h->fe.p, h->dofmask.p, qvel, fext, (MT*)h->vals.p, (MT*)h->dlo.p, mblk_out, fint_out, rhs,
-                     invdiag, ap, (const MT*)h->kcorr.p, qacc, invdiag && h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI ? h->invblk.p : nullptr);
+  AsmOut<MT> o;
+  o.dofmask = h->dofmask.p; o.nodemask = h->nodemask.p; o.qvel = qvel; o.fext = fext; o.qacc = qacc; o.vals = (MT*)h->vals.p; o.dlo = (MT*)h->dlo.p; o.mblk_out = mblk_out;
+  o.fint_out = fint_out; o.rhs = rhs; o.invdiag = invdiag;
+  o.invblk = invdiag && h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI ? h->invblk.p : nullptr;
+  if (h->asm_tets) {
+    constexpr int G = sizeof(MT) == 4 ? 4 : 2;  // elements whose records are in flight per lane
+    unsigned long long* prof = nullptr;
+    if (getenv("FEMBRAIN_ASM_PROFILE")) {
+      FB_HIP(hipMalloc((void**)&prof, 16 * sizeof(unsigned long long)));
+      FB_HIP(hipMemset(prof, 0, 16 * sizeof(unsigned long long)));
+    }
+    if (h->kcorr.p)
+      hipLaunchKernelGGL((k_assemble_tets<MT, G, true>), dim3(h->asm_grid), dim3(kBlock), (size_t)h->asm_lds, h->stream, sell_view(h), h->inc_off.p, h->inc.p,
+                         h->inc_slot.p, (const MT*)h->rec.p, h->fe.p, o, ap, (const MT*)h->kcorr.p, h->asm_max_width, prof);
+    else
+      hipLaunchKernelGGL((k_assemble_tets<MT, G, false>), dim3(h->asm_grid), dim3(kBlock), (size_t)h->asm_lds, h->stream, sell_view(h), h->inc_off.p, h->inc.p,
+                         h->inc_slot.p, (const MT*)h->rec.p, h->fe.p, o, ap, (const MT*)nullptr, h->asm_max_width, prof);
+    if (prof) {  // FEMBRAIN_ASM_PROFILE=1: where the wavefronts of k_assemble_tets spend their time (100 MHz ticks summed over the workgroups)
+      FB_HIP(hipStreamSynchronize(h->stream));
+      unsigned long long t[16];
+      FB_HIP(hipMemcpy(t, prof, sizeof t, hipMemcpyDeviceToHost));
+      for (int w = 0; w < 4; w++)
+        fprintf(stderr, "[fembrain] k_assemble_tets wavefront %d: elements %.1f us, wait %.1f, algebra %.1f, wait %.1f (mean per workgroup)\n", w,
+                t[4 * w] * 0.01 / h->asm_grid, t[4 * w + 1] * 0.01 / h->asm_grid, t[4 * w + 2] * 0.01 / h->asm_grid, t[4 * w + 3] * 0.01 / h->asm_grid);
+      (void)hipFree(prof);
+    }
+  } else {
+    hipLaunchKernelGGL(k_assemble_rows<MT>, dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), h->slot_coff.p, h->slot_ccnt.p,
+                       h->contrib.p, (const MT*)h->rec.p, h->fe.p, o, ap, (const MT*)h->kcorr.p);
+  }
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -1467,7 +1536,7 @@ int fb_fem_set_constrained_dofs(fb_fem_t h, int n_fixed_dofs, const int* fixed_d
   CHECK_HANDLE(h);
   if (n_fixed_dofs < 0 || (n_fixed_dofs > 0 && !fixed_dofs)) return fail(FB_EINVAL, "bad constrained DOF list");
   FB_TRY(plan_set_constraints(h->plan, n_fixed_dofs, fixed_dofs));
-  FB_TRY(h->dofmask.upload(h->plan.dofmask, h->stream));
+  FB_TRY(upload_masks(h));
   h->system_valid = false;
   return FB_OK;
 }
@@ -1487,6 +1556,7 @@ int fb_fem_floor_collision(fb_fem_t h, double floor_y, double restitution, int* 
 }
 
 int fb_fem_plan_on_device(fb_fem_t h) { return h && h->device_plan ? 1 : 0; }
+int fb_fem_assembly_kernel(fb_fem_t h) { return h && h->asm_tets ? 1 : 0; }
 
 long long fb_fem_device_plan_get(fb_fem_t h, const char* name, int* out, long long capacity) {
   CHECK_HANDLE(h);

@@ -319,40 +319,182 @@ struct AsmParams {
   int apply_mask;
 };
 
+// what both assembly kernels (k_assemble_rows: slot-major, k_assemble_tets: element-major) write
+template <typename MT>
+struct AsmOut {
+  const uint8_t* dofmask;
+  const uint8_t* nodemask;  // dofmask of a node packed into bits 0..2
+  const double* qvel;
+  const double* fext;
+  const double* qacc;
+  MT* vals;
+  MT* dlo;
+  double* mblk_out;
+  double* fint_out;
+  double* rhs;
+  double* invdiag;
+  double* invblk;
+};
+
+// what RowAlgebra::block reads at a block's column
+struct RowGather {
+  double qv[3], qa[3];
+  uint8_t mb[3];
+  template <typename MT>
+  __device__ __forceinline__ void load(const AsmOut<MT>& o, const AsmParams& ap, int col) {
+    qv[0] = o.qvel[3 * (size_t)col]; qv[1] = o.qvel[3 * (size_t)col + 1]; qv[2] = o.qvel[3 * (size_t)col + 2];
+    qa[0] = qa[1] = qa[2] = 0.0;
+    if (o.qacc) { qa[0] = o.qacc[3 * (size_t)col]; qa[1] = o.qacc[3 * (size_t)col + 1]; qa[2] = o.qacc[3 * (size_t)col + 2]; }
+    mb[0] = mb[1] = mb[2] = 1;
+    if (ap.apply_mask) {
+      const uint8_t nm = o.nodemask[col];
+      mb[0] = nm & 1; mb[1] = (nm >> 1) & 1; mb[2] = (nm >> 2) & 1;
+    }
+  }
+};
+
+// The a7 algebra of one block row, fed one finished block (K_ab, m_ab) at a time in slot order; the arithmetic and its order
+// are the same whichever kernel summed the block.
+template <typename MT>
+struct RowAlgebra {
+  double ta[3], fi[3], dg[3], off[9], msum;
+  uint8_t ma[3];
+  bool seen_diag;
+  int kd, nd;
+
+  __device__ __forceinline__ void begin(const AsmOut<MT>& o, const AsmParams& ap, int row, bool rvalid) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { ta[a] = 0.0; fi[a] = 0.0; dg[a] = 1.0; ma[a] = 1; }
+#pragma unroll
+    for (int v = 0; v < 9; v++) off[v] = 0.0;  // sum of the off-diagonal blocks exactly as stored (rounded)
+    msum = 0.0;                                // sum_b m_ab: the row sum the stored row must reproduce
+    seen_diag = false;
+    kd = -1; nd = 0;                           // slot and contribution count of the diagonal block
+    if (rvalid && ap.apply_mask) {
+      ma[0] = o.dofmask[3 * (size_t)row];
+      ma[1] = o.dofmask[3 * (size_t)row + 1];
+      ma[2] = o.dofmask[3 * (size_t)row + 2];
+    }
+  }
+  // the true diagonal block is the first slot whose column is the row itself (padding slots repeat the row id)
+  __device__ __forceinline__ bool is_diag(int row, int col, bool rvalid) {
+    const bool diag = rvalid && (col == row) && !seen_diag;
+    seen_diag = seen_diag || diag;
+    return diag;
+  }
+  __device__ __forceinline__ void block(const AsmOut<MT>& o, const AsmParams& ap, int slot, int lane, const RowGather& g, bool rvalid, bool diag, const double* K,
+                                        double m, int nc) {
+    // rhs operator on qvel (unmasked, as the reference multiplies the full matrix with the full qvel)
+    const double* qv = g.qv;
+    const uint8_t* mb = g.mb;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+      ta[a] += ap.g_k * (K[3 * a] * qv[0] + K[3 * a + 1] * qv[1] + K[3 * a + 2] * qv[2]) + ap.g_m * m * qv[a];
+    if (o.qacc) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) ta[a] += ap.g_a * m * g.qa[a];
+    }
+    msum += m;
+    if (diag) {
+      kd = slot; nd = nc;  // written by finish()
+    } else {
+      MT* out = o.vals + (size_t)slot * 9 * 64 + lane;
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          const MT u = (MT)(ap.s_k * K[3 * a + b] + (a == b ? ap.s_m * m : 0.0));
+          off[3 * a + b] += (double)u;
+          out[(3 * a + b) * 64] = (ma[a] && mb[b]) ? u : (MT)0;
+        }
+    }
+    if (o.mblk_out && rvalid) o.mblk_out[(size_t)slot * 64 + lane] = m;
+  }
+  // Diagonal block.  Translation invariance of the element stiffness (sum_j K0[ij] = 0) makes every block row of
+  // s_k K + s_m M sum to s_m (sum_b m_ab) I; the diagonal block is therefore formed as that row sum minus the
+  // off-diagonal blocks AS STORED and kept as a hi + lo pair, so that rounding the stiffness to fp32 does not give a
+  // free body a spurious translational stiffness of the order of its mass term (eps_f32 * |K| vs M ~ rho L^2/(20 h^2 E) |K|).
+  __device__ __forceinline__ void finish(const AsmOut<MT>& o, const AsmParams& ap, int s, int lane, int row, bool rvalid) {
+    double dfull[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // the diagonal block as stored (hi + lo), for the block-Jacobi option
+    if (rvalid && kd >= 0) {
+      MT* out = o.vals + (size_t)kd * 9 * 64 + lane;
+      MT* lo = o.dlo + (size_t)s * 9 * 64 + lane;
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          double v = (a == b ? ap.s_m * msum : 0.0) - 0.5 * (off[3 * a + b] + off[3 * b + a]);  // symmetric part: CG needs A = A^T
+          if (!(ma[a] && ma[b])) v = (a == b) ? 1.0 : 0.0;
+          if (nd == 0) v = (a == b) ? 1.0 : 0.0;  // a node no element references: identity row, stays at rest
+          const MT hi = (MT)v;
+          const MT l = (MT)(v - (double)hi);
+          out[(3 * a + b) * 64] = hi;
+          lo[(3 * a + b) * 64] = l;
+          dfull[3 * a + b] = (double)hi + (double)l;
+          if (a == b) dg[a] = (double)hi + (double)l;
+        }
+    } else if (kd < 0) {
+      MT* lo = o.dlo + (size_t)s * 9 * 64 + lane;  // padding lanes of the last slice
+#pragma unroll
+      for (int v = 0; v < 9; v++) lo[v * 64] = (MT)0;
+    }
+    if (rvalid) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const size_t d = 3 * (size_t)row + a;
+        if (o.fint_out) o.fint_out[d] = fi[a];
+        if (o.rhs) o.rhs[d] = ma[a] ? ap.rhs_scale * (ta[a] + fi[a] - o.fext[d]) : 0.0;
+        if (o.invdiag) o.invdiag[d] = 1.0 / dg[a];
+      }
+      if (o.invblk) {  // FB_PCG_BLOCK_JACOBI: the inverse of the row's 3x3 diagonal block (symmetric; identity on clamped DOFs)
+        double inv[9];
+        inv3x3(dfull, inv);
+#pragma unroll
+        for (int k = 0; k < 9; k++) o.invblk[9 * (size_t)row + k] = inv[k];
+      }
+    }
+  }
+};
+
+// one element contribution (i, j) to the block sums: the same three stages in the same order in both kernels
+template <typename MT>
+__device__ __forceinline__ void add_contribution(double* K, double& m, const double* ci, const double* cj, double V, int i, int j, uint32_t e, const AsmParams& ap,
+                                                 const MT* __restrict__ kcorr) {
+  const double dij = ci[0] * cj[0] + ci[1] * cj[1] + ci[2] * cj[2];
+  const double vl = V * ap.lambda, vm = V * ap.mu;
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) K[3 * a + b] += vl * (ci[a] * cj[b]) + vm * (cj[a] * ci[b]);  // parenthesised so that K_ba == K_ab^T bitwise
+  K[0] += vm * dij; K[4] += vm * dij; K[8] += vm * dij;
+  if (kcorr) {  // warp = 2: the rotation-derivative terms of this element, symmetric part (the exact tangent is symmetric to rounding)
+    const MT* C = kcorr + 144 * (size_t)e;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) K[3 * a + b] += 0.5 * ((double)C[12 * (3 * i + a) + 3 * j + b] + (double)C[12 * (3 * j + b) + 3 * i + a]);
+  }
+  m += ap.rho20 * V * (i == j ? 2.0 : 1.0);
+}
+
 template <typename MT>
 __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int* __restrict__ slot_coff,
                                                           const int* __restrict__ slot_ccnt, const uint32_t* __restrict__ contrib,
-                                                          const MT* __restrict__ rec, const double* __restrict__ fe,
-                                                          const uint8_t* __restrict__ dofmask, const double* __restrict__ qvel,
-                                                          const double* __restrict__ fext, MT* __restrict__ vals, MT* __restrict__ dlo,
-                                                          double* __restrict__ mblk_out, double* __restrict__ fint_out,
-                                                          double* __restrict__ rhs, double* __restrict__ invdiag, AsmParams ap,
-                                                          const MT* __restrict__ kcorr, const double* __restrict__ qacc,
-                                                          double* __restrict__ invblk) {
+                                                          const MT* __restrict__ rec, const double* __restrict__ fe, AsmOut<MT> o, AsmParams ap,
+                                                          const MT* __restrict__ kcorr) {
   const int lane = threadIdx.x & 63;
   for (SliceWalk w(sv.n_slices); w.valid(); w.next()) {
     const int s = w.s;
     const int row = s * 64 + lane;
     const bool rvalid = row < sv.n_owned;
     const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
-    double ta[3] = {0, 0, 0}, fi[3] = {0, 0, 0}, dg[3] = {1, 1, 1};
-    uint8_t ma[3] = {1, 1, 1};
-    if (rvalid && ap.apply_mask) {
-      ma[0] = dofmask[3 * (size_t)row];
-      ma[1] = dofmask[3 * (size_t)row + 1];
-      ma[2] = dofmask[3 * (size_t)row + 2];
-    }
-    bool seen_diag = false;
-    int kd = -1, nd = 0;                              // slot and contribution count of the diagonal block
-    double msum = 0.0;                                // sum_b m_ab: the row sum the stored row must reproduce
-    double off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // sum of the off-diagonal blocks exactly as stored (rounded)
+    RowAlgebra<MT> ra;
+    ra.begin(o, ap, row, rvalid);
     for (int k = 0; k < width; k++) {
       const int slot = so + k;
       const int col = sv.colidx[(size_t)slot * 64 + lane];
       const int coff = slot_coff[slot], ccnt = slot_ccnt[slot];
-      // the true diagonal block is the first slot whose column is the row itself (padding slots repeat the row id)
-      const bool diag = rvalid && (col == row) && !seen_diag;
-      seen_diag = seen_diag || diag;
+      const bool diag = ra.is_diag(row, col, rvalid);
       double K[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       double m = 0.0;
       int nc = 0;
@@ -382,102 +524,360 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
           const mt4 ri = rI[u], rj = rJ[u];
           const double ci[3] = {(double)ri.x, (double)ri.y, (double)ri.z};
           const double cj[3] = {(double)rj.x, (double)rj.y, (double)rj.z};
-          const double V = (double)ri.w;
-          const double dij = ci[0] * cj[0] + ci[1] * cj[1] + ci[2] * cj[2];
-          const double vl = V * ap.lambda, vm = V * ap.mu;
-#pragma unroll
-          for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) K[3 * a + b] += vl * (ci[a] * cj[b]) + vm * (cj[a] * ci[b]);  // parenthesised so that K_ba == K_ab^T bitwise
-          K[0] += vm * dij; K[4] += vm * dij; K[8] += vm * dij;
-          if (kcorr) {  // warp = 2: the rotation-derivative terms of this element, symmetric part (the exact tangent is symmetric to rounding)
-            const MT* C = kcorr + 144 * (size_t)e;
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-              for (int b = 0; b < 3; b++) K[3 * a + b] += 0.5 * ((double)C[12 * (3 * i + a) + 3 * j + b] + (double)C[12 * (3 * j + b) + 3 * i + a]);
-          }
-          m += ap.rho20 * V * (i == j ? 2.0 : 1.0);
+          add_contribution<MT>(K, m, ci, cj, (double)ri.w, i, j, e, ap, kcorr);
           if (diag) {
             const double* f = fe + 12 * (size_t)e + 3 * i;
-            fi[0] += f[0]; fi[1] += f[1]; fi[2] += f[2];
+            ra.fi[0] += f[0]; ra.fi[1] += f[1]; ra.fi[2] += f[2];
           }
         }
       }
-      // rhs operator on qvel (unmasked, as the reference multiplies the full matrix with the full qvel)
-      const double qv[3] = {qvel[3 * (size_t)col], qvel[3 * (size_t)col + 1], qvel[3 * (size_t)col + 2]};
-#pragma unroll
-      for (int a = 0; a < 3; a++)
-        ta[a] += ap.g_k * (K[3 * a] * qv[0] + K[3 * a + 1] * qv[1] + K[3 * a + 2] * qv[2]) + ap.g_m * m * qv[a];
-      if (qacc) {
-#pragma unroll
-        for (int a = 0; a < 3; a++) ta[a] += ap.g_a * m * qacc[3 * (size_t)col + a];
-      }
-      uint8_t mb[3] = {1, 1, 1};
-      if (ap.apply_mask) {
-        mb[0] = dofmask[3 * (size_t)col];
-        mb[1] = dofmask[3 * (size_t)col + 1];
-        mb[2] = dofmask[3 * (size_t)col + 2];
-      }
-      msum += m;
-      if (diag) {
-        kd = slot; nd = nc;  // written after the loop, see below
-      } else {
-        MT* out = vals + (size_t)slot * 9 * 64 + lane;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-          for (int b = 0; b < 3; b++) {
-            const MT u = (MT)(ap.s_k * K[3 * a + b] + (a == b ? ap.s_m * m : 0.0));
-            off[3 * a + b] += (double)u;
-            out[(3 * a + b) * 64] = (ma[a] && mb[b]) ? u : (MT)0;
-          }
-      }
-      if (mblk_out && rvalid) mblk_out[(size_t)slot * 64 + lane] = m;
+      RowGather gq;
+      gq.load(o, ap, col);
+      ra.block(o, ap, slot, lane, gq, rvalid, diag, K, m, nc);
     }
-    // Diagonal block.  Translation invariance of the element stiffness (sum_j K0[ij] = 0) makes every block row of
-    // s_k K + s_m M sum to s_m (sum_b m_ab) I; the diagonal block is therefore formed as that row sum minus the
-    // off-diagonal blocks AS STORED and kept as a hi + lo pair, so that rounding the stiffness to fp32 does not give a
-    // free body a spurious translational stiffness of the order of its mass term (eps_f32 * |K| vs M ~ rho L^2/(20 h^2 E) |K|).
-    double dfull[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // the diagonal block as stored (hi + lo), for the block-Jacobi option
-    if (rvalid && kd >= 0) {
-      MT* out = vals + (size_t)kd * 9 * 64 + lane;
-      MT* lo = dlo + (size_t)s * 9 * 64 + lane;
+    ra.finish(o, ap, s, lane, row, rvalid);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Element-major assembly.  k_assemble_rows walks a row slot by slot, so the 16 contributions of an element reach for its 64-B
+// record at 16 different times and every one of them misses L2 (an XCD's records are 8 MB at 1M tets).  Here a row's ELEMENTS
+// are walked in ascending order instead -- the incidence list is the contribution list of the diagonal block -- the record is
+// read once per element and its four blocks K_i0..K_i3 are added to the accumulators of the slots their columns have in the
+// row.  The accumulators (9 stiffness values + the mass entry per slot, fp64) live in LDS as [slot][value][row of the slice]:
+// every access is 64 consecutive doubles, conflict-free whatever the slots are.
+//
+// One workgroup of four wavefronts per slice, lane = row, and the VALUES are dealt to the wavefronts: wavefront a = 0..2 owns
+// row a of every 3x3 block (values 3a..3a+2), wavefront 3 owns the mass entry and the element forces.  Every accumulator has
+// one owner, so there is no ordering between lanes to keep, and the a7 algebra splits the same way (t_a, the stored row a,
+// the row-a sums of the off-diagonal blocks), which puts the fp64 arithmetic on all SIMDs of the CU: with one lane per row and
+// block the LDS allows two wavefronts per CU and the same arithmetic took 360 us; with (row, corner) lanes the four lanes of
+// a row hit one LDS bank (slot stride = 0 mod 64 banks): 225 us.
+// A block receives its contributions in ascending element order through the same operations as in k_assemble_rows, and the
+// finished blocks go through the same algebra in slot order: the result is bit for bit k_assemble_rows'.
+// LDS = slice width x 5 KB + 2 KB (78.8 KB at 15 slots: two workgroups per CU); the dispatcher falls back to k_assemble_rows when
+// a slice is wider than 31 slots (or the widest has a single slot).
+//
+//   inc_off  [n_slices+1]      first list row of the slice (height = longest incidence list of its 64 rows)
+//   inc      [rows][64] u32    element << 2 | corner of the lane's row in it, kNoInc past the end of the list
+//   inc_slot [rows][64] u32    4 x u8: the slot (within the slice) of the block (row, node j of the element), j = 0..3
+// ------------------------------------------------------------------------------------------------------
+constexpr uint32_t kNoInc = 0xFFFFFFFFu;
+constexpr int kAsmExtra = 3 + 1;  // LDS rows of 64 doubles after the accumulators: element forces, list lengths.  The row sums of the
+// off-diagonal blocks and (block-Jacobi) the diagonal block pass between the wavefronts through the value rows of slots 0 and 1,
+// each wavefront using the rows it owns; it zeroes them again before the next slice.
+
+// elements of the rows, wavefront A (row A of the blocks).  Software pipeline over groups of G list rows: the words of group g+2
+// and the records of group g+1 are in flight while group g is added up.
+template <typename MT, int G, int A, bool TANGENT>
+__device__ __forceinline__ void tets_accumulate(double* acc, int lane, int io, int height, const uint32_t* __restrict__ inc, const uint32_t* __restrict__ inc_slot,
+                                                const MT* __restrict__ rec, const AsmParams& ap, const MT* __restrict__ kcorr) {
+  typedef MT mt4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-      for (int a = 0; a < 3; a++)
+  for (int b = 0; b < 3; b++) acc[(3 * A + b) * 64 + lane] = acc[640 + (3 * A + b) * 64 + lane] = 0.0;  // (what tets_algebra passed through them)
+  uint32_t w0[G], s0[G], w1[G], s1[G];
+  mt4 r0[G][4];
+  auto load_words = [&](int t0, uint32_t* w, uint32_t* sl) {
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      const bool in = t0 + u < height;
+      w[u] = in ? inc[((size_t)io + t0 + u) * 64 + lane] : kNoInc;
+      sl[u] = in ? inc_slot[((size_t)io + t0 + u) * 64 + lane] : 0u;
+    }
+  };
+  auto load_records = [&](const uint32_t* w, mt4 (*r)[4]) {
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      const uint32_t c = w[u] == kNoInc ? 0u : w[u];  // padding reads element 0's record and is discarded below
+      const mt4* rp = (const mt4*)(rec + 16 * (size_t)(c >> 2));
+#pragma unroll
+      for (int k = 0; k < 4; k++) r[u][k] = rp[k];
+    }
+  };
+  load_words(0, w0, s0);
+  load_records(w0, r0);
+  load_words(G, w1, s1);
+  for (int t0 = 0; t0 < height; t0 += G) {
+    mt4 r1[G][4];
+    uint32_t w2[G], s2[G];
+    load_records(w1, r1);
+    load_words(t0 + 2 * G, w2, s2);
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      if (w0[u] == kNoInc) continue;
+      const uint32_t e = w0[u] >> 2;
+      const int i = (int)(w0[u] & 3);
+      const mt4 ri = i == 0 ? r0[u][0] : (i == 1 ? r0[u][1] : (i == 2 ? r0[u][2] : r0[u][3]));
+      const double ci[3] = {(double)ri.x, (double)ri.y, (double)ri.z};
+      const double V = (double)ri.w;
+      const double vl = V * ap.lambda, vm = V * ap.mu;
+      // the four blocks of an element sit in four different slots (its nodes are distinct): all twelve accumulators are read
+      // before any is written back, one LDS round trip per element instead of four
+      double* p[4];
+      double K[4][3];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        p[j] = acc + ((s0[u] >> (8 * j)) & 255u) * 640 + (3 * A) * 64 + lane;
+#pragma unroll
+        for (int b = 0; b < 3; b++) K[j][b] = p[j][b * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const mt4 rj = r0[u][j];
+        const double cj[3] = {(double)rj.x, (double)rj.y, (double)rj.z};
+        const double dij = ci[0] * cj[0] + ci[1] * cj[1] + ci[2] * cj[2];
 #pragma unroll
         for (int b = 0; b < 3; b++) {
-          double v = (a == b ? ap.s_m * msum : 0.0) - 0.5 * (off[3 * a + b] + off[3 * b + a]);  // symmetric part: CG needs A = A^T
-          if (!(ma[a] && ma[b])) v = (a == b) ? 1.0 : 0.0;
-          if (nd == 0) v = (a == b) ? 1.0 : 0.0;  // a node no element references: identity row, stays at rest
-          const MT hi = (MT)v;
-          const MT l = (MT)(v - (double)hi);
-          out[(3 * a + b) * 64] = hi;
-          lo[(3 * a + b) * 64] = l;
-          dfull[3 * a + b] = (double)hi + (double)l;
-          if (a == b) dg[a] = (double)hi + (double)l;
+          K[j][b] += vl * (ci[A] * cj[b]) + vm * (cj[A] * ci[b]);  // the three stages of add_contribution on value (A, b)
+          if (b == A) K[j][b] += vm * dij;
+          if (TANGENT) {  // warp = 2 (a template parameter: a run-time test here splits the element's arithmetic into twelve basic blocks)
+            const MT* C = kcorr + 144 * (size_t)e;
+            K[j][b] += 0.5 * ((double)C[12 * (3 * i + A) + 3 * j + b] + (double)C[12 * (3 * j + b) + 3 * i + A]);
+          }
         }
-    } else if (kd < 0) {
-      MT* lo = dlo + (size_t)s * 9 * 64 + lane;  // padding lanes of the last slice
+      }
 #pragma unroll
-      for (int v = 0; v < 9; v++) lo[v * 64] = (MT)0;
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) p[j][b * 64] = K[j][b];
     }
-    if (rvalid) {
 #pragma unroll
-      for (int a = 0; a < 3; a++) {
-        const size_t d = 3 * (size_t)row + a;
-        if (fint_out) fint_out[d] = fi[a];
-        if (rhs) rhs[d] = ma[a] ? ap.rhs_scale * (ta[a] + fi[a] - fext[d]) : 0.0;
-        if (invdiag) invdiag[d] = 1.0 / dg[a];
-      }
-      if (invblk) {  // FB_PCG_BLOCK_JACOBI: the inverse of the row's 3x3 diagonal block (symmetric; identity on clamped DOFs)
-        double inv[9];
-        inv3x3(dfull, inv);
+    for (int u = 0; u < G; u++) {
+      w0[u] = w1[u]; s0[u] = s1[u]; w1[u] = w2[u]; s1[u] = s2[u];
 #pragma unroll
-        for (int k = 0; k < 9; k++) invblk[9 * (size_t)row + k] = inv[k];
-      }
+      for (int k = 0; k < 4; k++) r0[u][k] = r1[u][k];
     }
   }
+}
+
+// wavefront 3: the mass entries of the four blocks, the element forces and the length of the list
+template <typename MT, int G>
+__device__ __forceinline__ void tets_mass_and_forces(double* acc, double* facc, double* nacc, int lane, int io, int height, int zero_slots,
+                                                     const uint32_t* __restrict__ inc, const uint32_t* __restrict__ inc_slot, const MT* __restrict__ rec,
+                                                     const double* __restrict__ fe, const AsmParams& ap) {
+  for (int k = 0; k < zero_slots; k++) acc[k * 640 + 9 * 64 + lane] = 0.0;  // (the algebra wavefronts only read the mass entries)
+  double fi[3] = {0, 0, 0};
+  int nd = 0;
+  uint32_t w[G], sl[G], w1[G], s1[G];
+  double V[G], f[G][3];
+  auto load_words = [&](int t0, uint32_t* ww, uint32_t* ss) {
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      const bool in = t0 + u < height;
+      ww[u] = in ? inc[((size_t)io + t0 + u) * 64 + lane] : kNoInc;
+      ss[u] = in ? inc_slot[((size_t)io + t0 + u) * 64 + lane] : 0u;
+    }
+  };
+  auto load_values = [&](const uint32_t* ww, double* VV, double (*ff)[3]) {
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      const uint32_t c = ww[u] == kNoInc ? 0u : ww[u];
+      VV[u] = (double)rec[16 * (size_t)(c >> 2) + 4 * (c & 3) + 3];
+      const double* fp = fe + 12 * (size_t)(c >> 2) + 3 * (c & 3);
+      ff[u][0] = fp[0]; ff[u][1] = fp[1]; ff[u][2] = fp[2];
+    }
+  };
+  load_words(0, w, sl);
+  load_values(w, V, f);
+  load_words(G, w1, s1);
+  for (int t0 = 0; t0 < height; t0 += G) {
+    double V1[G], f1[G][3];
+    uint32_t w2[G], s2[G];
+    load_values(w1, V1, f1);
+    load_words(t0 + 2 * G, w2, s2);
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      if (w[u] == kNoInc) continue;
+      nd++;
+      const int i = (int)(w[u] & 3);
+      double* p[4];
+      double m[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        p[j] = acc + ((sl[u] >> (8 * j)) & 255u) * 640 + 9 * 64 + lane;
+        m[j] = p[j][0];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) p[j][0] = m[j] + ap.rho20 * V[u] * (i == j ? 2.0 : 1.0);
+      fi[0] += f[u][0]; fi[1] += f[u][1]; fi[2] += f[u][2];
+    }
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      w[u] = w1[u]; sl[u] = s1[u]; w1[u] = w2[u]; s1[u] = s2[u];
+      V[u] = V1[u]; f[u][0] = f1[u][0]; f[u][1] = f1[u][1]; f[u][2] = f1[u][2];
+    }
+  }
+  facc[lane] = fi[0]; facc[64 + lane] = fi[1]; facc[128 + lane] = fi[2];
+  nacc[lane] = (double)nd;
+}
+
+// the a7 algebra of row A of the finished blocks, in slot order (RowAlgebra split by block row); leaves its accumulators zero
+template <typename MT, int A>
+__device__ __forceinline__ void tets_algebra(double* acc, const double* facc, const double* nacc, const SellView& sv,
+                                             const AsmOut<MT>& o, const AsmParams& ap, int s, int lane, int so, int width) {
+  const int row = s * 64 + lane;
+  const bool rvalid = row < sv.n_owned;
+  uint8_t ma[3] = {1, 1, 1};
+  if (rvalid && ap.apply_mask) {
+    ma[0] = o.dofmask[3 * (size_t)row];
+    ma[1] = o.dofmask[3 * (size_t)row + 1];
+    ma[2] = o.dofmask[3 * (size_t)row + 2];
+  }
+  double ta = 0.0, msum = 0.0, off[3] = {0, 0, 0};
+  bool seen_diag = false;
+  int kd = -1;
+  // software pipeline over chunks of kC slots: the columns of chunk c+2 and the gathers (which depend on the columns) of chunk
+  // c+1 are in flight while chunk c goes through the algebra
+  constexpr int kC = 4;
+  int col[kC], col1[kC];
+  RowGather gq[kC];
+  auto load_cols = [&](int k0, int* cc) {
+#pragma unroll
+    for (int c = 0; c < kC; c++) cc[c] = k0 + c < width ? sv.colidx[((size_t)so + k0 + c) * 64 + lane] : 0;
+  };
+  load_cols(0, col);
+#pragma unroll
+  for (int c = 0; c < kC; c++) gq[c].load(o, ap, col[c]);
+  load_cols(kC, col1);
+  for (int k0 = 0; k0 < width; k0 += kC) {
+    RowGather gq1[kC];
+    int col2[kC];
+#pragma unroll
+    for (int c = 0; c < kC; c++) gq1[c].load(o, ap, col1[c]);
+    load_cols(k0 + 2 * kC, col2);
+    double Kc[kC][3], mc[kC];
+#pragma unroll
+    for (int c = 0; c < kC; c++) {
+      double* p = acc + (k0 + c) * 640 + lane;  // (slots past the width: rows of the LDS tail or of the next slots, read and not used)
+      const bool in = k0 + c < width;
+#pragma unroll
+      for (int b = 0; b < 3; b++) Kc[c][b] = in ? p[(3 * A + b) * 64] : 0.0;
+      mc[c] = in ? p[9 * 64] : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < kC; c++) {
+      if (k0 + c >= width) break;
+      const int k = k0 + c, slot = so + k;
+      const bool diag = rvalid && (col[c] == row) && !seen_diag;
+      seen_diag = seen_diag || diag;
+      double* p = acc + k * 640 + lane;
+      const double* K = Kc[c];
+#pragma unroll
+      for (int b = 0; b < 3; b++) p[(3 * A + b) * 64] = 0.0;
+      const double m = mc[c];
+      const double* qv = gq[c].qv;
+      ta += ap.g_k * (K[0] * qv[0] + K[1] * qv[1] + K[2] * qv[2]) + ap.g_m * m * qv[A];
+      if (o.qacc) ta += ap.g_a * m * gq[c].qa[A];
+      msum += m;
+      if (diag) {
+        kd = slot;
+      } else {
+        MT* out = o.vals + (size_t)slot * 9 * 64 + lane;
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          const MT u = (MT)(ap.s_k * K[b] + (A == b ? ap.s_m * m : 0.0));
+          off[b] += (double)u;
+          out[(3 * A + b) * 64] = (ma[A] && gq[c].mb[b]) ? u : (MT)0;
+        }
+      }
+      if (A == 0 && o.mblk_out && rvalid) o.mblk_out[(size_t)slot * 64 + lane] = m;
+    }
+#pragma unroll
+    for (int c = 0; c < kC; c++) { col[c] = col1[c]; col1[c] = col2[c]; gq[c] = gq1[c]; }
+  }
+  // the diagonal block needs the sums of the other rows: off[3a+b] and off[3b+a]
+  double* xoff = acc;        // value rows of slot 0
+  double* dblk = acc + 640;  // value rows of slot 1
+#pragma unroll
+  for (int b = 0; b < 3; b++) xoff[(3 * A + b) * 64 + lane] = off[b];
+  __syncthreads();
+  const int nd = (int)nacc[lane];
+  double dg = 1.0;
+  if (rvalid && kd >= 0) {
+    MT* out = o.vals + (size_t)kd * 9 * 64 + lane;
+    MT* lo = o.dlo + (size_t)s * 9 * 64 + lane;
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      double v = (A == b ? ap.s_m * msum : 0.0) - 0.5 * (xoff[(3 * A + b) * 64 + lane] + xoff[(3 * b + A) * 64 + lane]);  // symmetric part: CG needs A = A^T
+      if (!(ma[A] && ma[b])) v = (A == b) ? 1.0 : 0.0;
+      if (nd == 0) v = (A == b) ? 1.0 : 0.0;  // a node no element references: identity row, stays at rest
+      const MT hi = (MT)v;
+      const MT l = (MT)(v - (double)hi);
+      out[(3 * A + b) * 64] = hi;
+      lo[(3 * A + b) * 64] = l;
+      if (o.invblk) dblk[(3 * A + b) * 64 + lane] = (double)hi + (double)l;
+      if (A == b) dg = (double)hi + (double)l;
+    }
+  } else {
+    if (kd < 0) {
+      MT* lo = o.dlo + (size_t)s * 9 * 64 + lane;  // padding lanes of the last slice
+#pragma unroll
+      for (int b = 0; b < 3; b++) lo[(3 * A + b) * 64] = (MT)0;
+    }
+    if (o.invblk) {
+#pragma unroll
+      for (int b = 0; b < 3; b++) dblk[(3 * A + b) * 64 + lane] = A == b ? 1.0 : 0.0;
+    }
+  }
+  if (rvalid) {
+    const size_t d = 3 * (size_t)row + A;
+    const double fi = facc[A * 64 + lane];
+    if (o.fint_out) o.fint_out[d] = fi;
+    if (o.rhs) o.rhs[d] = ma[A] ? ap.rhs_scale * (ta + fi - o.fext[d]) : 0.0;
+    if (o.invdiag) o.invdiag[d] = 1.0 / dg;
+  }
+}
+
+template <typename MT, int G, bool TANGENT>
+__global__ __launch_bounds__(kBlock) void k_assemble_tets(SellView sv, const int* __restrict__ inc_off, const uint32_t* __restrict__ inc,
+                                                          const uint32_t* __restrict__ inc_slot, const MT* __restrict__ rec, const double* __restrict__ fe,
+                                                          AsmOut<MT> o, AsmParams ap, const MT* __restrict__ kcorr, int max_width, unsigned long long* __restrict__ prof) {
+  extern __shared__ double acc[];  // [slot][10][64], then kAsmExtra rows of 64
+  unsigned long long tp[4] = {0, 0, 0, 0}, tc = prof ? wall_clock64() : 0;  // development aid: 100 MHz ticks per phase
+  auto lap = [&](int k) { if (prof) { const unsigned long long n = wall_clock64(); tp[k] += n - tc; tc = n; } };
+  double* facc = acc + (size_t)max_width * 640;
+  double* nacc = facc + 3 * 64;
+  const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int v = threadIdx.x; v < (max_width * 10 + kAsmExtra) * 64; v += kBlock) acc[v] = 0.0;
+  __syncthreads();
+  // XCD-aware walk, one workgroup per slice: workgroup b serves slab b % 8
+  const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
+  const int chunk = (sv.n_slices + 7) >> 3;
+  const int hi = min((xcd + 1) * chunk, sv.n_slices);
+  int prev_width = 0;
+  for (int s = xcd * chunk + (blockIdx.x >> 3); s < hi; s += per) {
+    const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
+    const int io = inc_off[s], height = inc_off[s + 1] - io;
+    if (wq == 0) tets_accumulate<MT, G, 0, TANGENT>(acc, lane, io, height, inc, inc_slot, rec, ap, kcorr);
+    else if (wq == 1) tets_accumulate<MT, G, 1, TANGENT>(acc, lane, io, height, inc, inc_slot, rec, ap, kcorr);
+    else if (wq == 2) tets_accumulate<MT, G, 2, TANGENT>(acc, lane, io, height, inc, inc_slot, rec, ap, kcorr);
+    else tets_mass_and_forces<MT, G>(acc, facc, nacc, lane, io, height, prev_width, inc, inc_slot, rec, fe, ap);
+    prev_width = width;
+    lap(0);
+    __syncthreads();
+    lap(1);
+    if (wq == 0) tets_algebra<MT, 0>(acc, facc, nacc, sv, o, ap, s, lane, so, width);
+    else if (wq == 1) tets_algebra<MT, 1>(acc, facc, nacc, sv, o, ap, s, lane, so, width);
+    else if (wq == 2) tets_algebra<MT, 2>(acc, facc, nacc, sv, o, ap, s, lane, so, width);
+    else __syncthreads();  // (the one inside tets_algebra)
+    if (o.invblk) {  // FB_PCG_BLOCK_JACOBI: the inverse of the row's 3x3 diagonal block (symmetric; identity on clamped DOFs)
+      __syncthreads();
+      const int row = s * 64 + lane;
+      if (wq == 0 && row < sv.n_owned) {
+        double dfull[9], inv[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) dfull[k] = acc[640 + k * 64 + lane];
+        inv3x3(dfull, inv);
+#pragma unroll
+        for (int k = 0; k < 9; k++) o.invblk[9 * (size_t)row + k] = inv[k];
+      }
+    }
+    lap(2);
+    __syncthreads();
+    lap(3);
+  }
+  if (prof && lane == 0)
+    for (int k = 0; k < 4; k++) atomicAdd(&prof[4 * wq + k], tp[k]);
 }
 
 // ------------------------------------------------------------------------------------------------------

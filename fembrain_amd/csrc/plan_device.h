@@ -72,4 +72,11 @@ int device_partition(hipStream_t s, int n_tets, int4* d_tets, int n_global, int 
 // unsharded system (every node a row).  Synchronises the stream before it returns.
 int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& out, PlanWorkspace& ws, const PlanShard* shard = nullptr);
 
+// Incidence lists of the element-major assembly kernel (fem_device.hip.h k_assemble_tets), derived from a plan that is already
+// on the device (whichever builder made it): per slice the longest list of its 64 rows (inc_off = prefix sums), per (list row, lane)
+// the word element << 2 | corner (kNoContrib past the end) and the slots of the element's four blocks in the lane's row (4 x u8).
+// The incidence list of a row is the contribution list of its diagonal block, so the ascending element order carries over.
+int build_incidence_device(hipStream_t s, int n_slices, int n_owned, const int* slice_off, const int* colidx, const int* slot_coff, const int* slot_ccnt,
+                           const uint32_t* contrib, const int4* tets, DevBuf<int>& inc_off, DevBuf<uint32_t>& inc, DevBuf<uint32_t>& inc_slot, PlanWorkspace& ws);
+
 }  // namespace fb

@@ -161,6 +161,61 @@ __global__ __launch_bounds__(kB) void k_plan_contrib(int n_nodes, int n_slices, 
   }
 }
 
+// ---- incidence lists of the element-major assembly (fem_device.hip.h k_assemble_tets) ---------------------------------------
+// one wavefront per slice: length of every row's incidence list = contributions of its diagonal block
+__global__ __launch_bounds__(kB) void k_inc_heights(int n_slices, int n_owned, const int* __restrict__ slice_off, const int* __restrict__ colidx, const int* __restrict__ slot_coff, const int* __restrict__ slot_ccnt,
+                                                        const uint32_t* __restrict__ contrib, int* __restrict__ height) {
+  const int s = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (s >= n_slices) return;
+  const int row = s * 64 + lane;
+  const int so = slice_off[s], width = slice_off[s + 1] - so;
+  int cnt = 0;
+  if (row < n_owned)
+    for (int k = 0; k < width; k++)
+      if (colidx[((size_t)so + k) * 64 + lane] == row) {  // the first such slot is the diagonal block (padding repeats the row id later)
+        const int coff = slot_coff[so + k], ccnt = slot_ccnt[so + k];
+        while (cnt < ccnt && contrib[((size_t)coff + cnt) * 64 + lane] != 0xFFFFFFFFu) cnt++;
+        break;
+      }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt = max(cnt, __shfl_xor(cnt, o, 64));
+  if (lane == 0) height[s] = cnt;
+}
+
+__global__ __launch_bounds__(kB) void k_inc_fill(int n_slices, int n_owned, const int* __restrict__ slice_off, const int* __restrict__ colidx, const int* __restrict__ slot_coff, const int* __restrict__ slot_ccnt,
+                                                     const uint32_t* __restrict__ contrib, const int4* __restrict__ tets, const int* __restrict__ inc_off,
+                                                     uint32_t* __restrict__ inc, uint32_t* __restrict__ inc_slot) {
+  const int s = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (s >= n_slices) return;
+  const int row = s * 64 + lane;
+  const int so = slice_off[s], width = slice_off[s + 1] - so;
+  const int io = inc_off[s], height = inc_off[s + 1] - io;
+  int kd = -1;
+  if (row < n_owned)
+    for (int k = 0; k < width && kd < 0; k++)
+      if (colidx[((size_t)so + k) * 64 + lane] == row) kd = k;
+  const int coff = kd >= 0 ? slot_coff[so + kd] : 0, ccnt = kd >= 0 ? slot_ccnt[so + kd] : 0;
+  for (int t = 0; t < height; t++) {
+    uint32_t w = kNoContrib, sl = 0;
+    if (t < ccnt) {
+      const uint32_t c = contrib[((size_t)coff + t) * 64 + lane];
+      if (c != 0xFFFFFFFFu) {
+        const uint32_t e = c >> 4, i = (c >> 2) & 3;
+        w = (e << 2) | i;
+        const int4 tt = tets[e];
+        const int id[4] = {tt.x, tt.y, tt.z, tt.w};
+        for (int j = 0; j < 4; j++) {
+          int k = 0;
+          while (k < width && colidx[((size_t)so + k) * 64 + lane] != id[j]) k++;  // found by construction; the first match is the real block
+          sl |= (uint32_t)(k & 255) << (8 * j);
+        }
+      }
+    }
+    inc[((size_t)io + t) * 64 + lane] = w;
+    inc_slot[((size_t)io + t) * 64 + lane] = sl;
+  }
+}
+
 // ---- partition of one rank from its own elements ------------------------------------------------------------------------
 struct PartCounters { int first_bad, bad_node, not_kept, pad; unsigned long long corners; };
 
@@ -309,6 +364,27 @@ int device_partition(hipStream_t s, int n_tets, int4* d_tets, int n_global, int 
     }
     out.send_off[q + 1] = (int)out.send_local.size();
   }
+  return FB_OK;
+}
+
+int build_incidence_device(hipStream_t s, int n_slices, int n_owned, const int* slice_off, const int* colidx, const int* slot_coff, const int* slot_ccnt,
+                           const uint32_t* contrib, const int4* tets, DevBuf<int>& inc_off, DevBuf<uint32_t>& inc, DevBuf<uint32_t>& inc_slot, PlanWorkspace& W) {
+  FB_TRY(W.width.reserve((size_t)n_slices + 1));
+  FB_HIP(hipMemsetAsync(W.width.p, 0, sizeof(int) * ((size_t)n_slices + 1), s));
+  const dim3 sg((unsigned)((n_slices + kB / 64 - 1) / (kB / 64)));
+  hipLaunchKernelGGL(k_inc_heights, sg, dim3(kB), 0, s, n_slices, n_owned, slice_off, colidx, slot_coff, slot_ccnt, contrib, W.width.p);
+  FB_HIP(hipGetLastError());
+  FB_TRY(inc_off.alloc((size_t)n_slices + 1));
+  size_t bytes = 0;
+  FB_HIP(rocprim::exclusive_scan(nullptr, bytes, W.width.p, inc_off.p, 0, (size_t)n_slices + 1, rocprim::plus<int>(), s));
+  FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+  FB_HIP(rocprim::exclusive_scan(W.temp.p, bytes, W.width.p, inc_off.p, 0, (size_t)n_slices + 1, rocprim::plus<int>(), s));
+  int rows = 0;
+  FB_TRY(inc_off.download(&rows, 1, s, (size_t)n_slices));
+  FB_TRY(inc.alloc(std::max<size_t>(1, (size_t)rows * 64)));
+  FB_TRY(inc_slot.alloc(std::max<size_t>(1, (size_t)rows * 64)));
+  hipLaunchKernelGGL(k_inc_fill, sg, dim3(kB), 0, s, n_slices, n_owned, slice_off, colidx, slot_coff, slot_ccnt, contrib, tets, inc_off.p, inc.p, inc_slot.p);
+  FB_HIP(hipGetLastError());
   return FB_OK;
 }
 

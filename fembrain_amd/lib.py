@@ -136,6 +136,7 @@ def lib():
         "fb_fem_create_from_poly": (C.c_int, [C.POINTER(vp), vp, C.c_int, _ip, C.POINTER(FemParams)]),
         "fb_fem_device_plan_get": (C.c_longlong, [vp, C.c_char_p, _ip, C.c_longlong]),
         "fb_fem_plan_on_device": (C.c_int, [vp]),
+        "fb_fem_assembly_kernel": (C.c_int, [vp]),
         "fb_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int, C.c_int, _ip]),
         "fb_plan_destroy": (C.c_int, [vp]),
         "fb_plan_info": (C.c_int, [vp, _ip]),

@@ -208,7 +208,7 @@ int fb_fem_spmv(fb_fem_t h, const double* x, double* y);
 int fb_fem_pcg(fb_fem_t h, const double* rhs, double* x, double eps, int max_iter, int* iterations_out);
 
 /* timing helpers for bench.py: `reps` launches of the PCG loop's SpMV kernel (k_spmv<MT,3>: q = A d plus the three
- * merged sums) / `reps` assemblies (k_tet_warp + k_assemble_rows) on the current system; average device seconds per
+ * merged sums) / `reps` assemblies (k_tet_warp + k_assemble_tets / k_assemble_rows) on the current system; average device seconds per
  * launch measured with HIP events on the handle's stream. */
 /* Plan arrays as the device holds them (what the per-step kernels read), for checking the device-side plan builder against
  * the host one (fembrain_hip_testing.h, fb_plan_get -- same names: bptr, bcol, blk_slot, slice_off, colidx, slot_coff,
@@ -216,6 +216,9 @@ int fb_fem_pcg(fb_fem_t h, const double* rhs, double* x, double eps, int max_ite
 long long fb_fem_device_plan_get(fb_fem_t h, const char* name, int* out, long long capacity);
 /* 1 if the plan of this handle was built on the device (unsharded handles, unless FEMBRAIN_PLAN_DEVICE=0), else 0 */
 int fb_fem_plan_on_device(fb_fem_t h);
+/* the assembly kernel of this handle: 1 = element-major with LDS accumulators (k_assemble_tets; slices of at most 32 slots),
+ * 0 = slot-major (k_assemble_rows; also FEMBRAIN_ASM_KERNEL=rows).  Both write the same bits. */
+int fb_fem_assembly_kernel(fb_fem_t h);
 int fb_fem_time_spmv(fb_fem_t h, int reps, double* seconds_per_spmv);
 int fb_fem_time_assembly(fb_fem_t h, int reps, double* seconds_per_assembly);
 /* COLLECTIVE on a sharded handle (every rank calls it with the same reps): average device seconds of one halo refresh of

@@ -803,6 +803,62 @@ class _NoMesh:
         return np.zeros((4, 3), np.float32), np.zeros((1, 4), np.uint32)
 
 
+def _wide_mesh():
+    """a hub node shared by 40 tets: one row of more than 32 blocks"""
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(60, 3))
+    pts /= np.linalg.norm(pts, axis=1)[:, None]
+    from scipy.spatial import ConvexHull
+    hull = ConvexHull(pts)
+    v = np.concatenate([[[0.0, 0.0, 0.0]], pts])
+    t = np.array([[0, a + 1, b + 1, c + 1] for a, b, c in hull.simplices], np.int32)
+    return v, t, fixed_vertices_to_dofs(np.array([1, 2, 3]))
+
+
+@pytest.mark.parametrize("case", ["cube14", "cube14_f64", "cube14_tangent", "cube14_newmark", "cube14_block_jacobi", "beam3", "hub"])
+def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, monkeypatch, case):
+    """k_assemble_tets (lane walks its row's elements, blocks accumulated in LDS) against k_assemble_rows (FEMBRAIN_ASM_KERNEL=rows):
+    raw f and K at a seeded displacement, Keff and rhs of a step, the states after two steps -- all bit for bit, for both matrix
+    widths, the exact tangent, the Newmark step and the block-Jacobi inverse blocks; a mesh with a row wider than 32 slots keeps the
+    slot-major kernel by itself"""
+    kw = {}
+    if case == "beam3":
+        g0 = np.load(os.path.join(GOLD, "fem_beam3.npz"))
+        v, t, fixed = g0["verts"], g0["tets"], fixed_vertices_to_dofs(g0["fixed_vertices"])
+    elif case == "hub":
+        v, t, fixed = _wide_mesh()
+    else:
+        v, t, fixed = _cube(14)
+        if case.endswith("f64"):
+            kw["matrix_precision"] = fl.FB_MATRIX_F64
+        if case.endswith("tangent"):
+            kw["exact_tangent"] = True
+        if case.endswith("newmark"):
+            kw["integrator"] = fl.FB_INTEGRATOR_NEWMARK
+        if case.endswith("block_jacobi"):
+            kw["pcg_variant"] = fl.FB_PCG_BLOCK_JACOBI
+    u = np.random.default_rng(5).normal(size=3 * len(v)) * 0.003
+    out = []
+    for kern in ("tets", "rows"):
+        monkeypatch.setenv("FEMBRAIN_ASM_KERNEL", kern)
+        g = FemIntegrator(v, t, fixed, **kw)
+        assert fl.lib().fb_fem_assembly_kernel(g.h) == (1 if kern == "tets" and case != "hub" else 0)
+        f, K = g.assemble(u)
+        its = []
+        for _ in range(2):
+            g.set_uniform_force(1, -2000.0 if case != "hub" else -1.0)
+            its.append(g.do_timestep())
+        Keff, rhs = g.system()
+        out.append((f, K, its, Keff, rhs, g.get_q_state()[0], g.mass()))
+        g.close()
+    a, b = out
+    assert a[2] == b[2]
+    for x, y in zip(a, b):
+        if not isinstance(x, list):
+            assert np.array_equal(x, y)
+    assert np.abs(a[1]).max() > 0 and np.abs(a[5]).max() > 0
+
+
 def test_16bit_column_differences_give_identical_iterates(gpu, monkeypatch):
     """k_spmv<.., C16> reads column - row as 16-bit values (device-built plans whose differences all fit); the products are
     the same, so are the states -- bit for bit against the 32-bit index kernel (FEMBRAIN_SPMV_C16=0); a mesh whose node
