@@ -318,8 +318,12 @@ int halo_exchange(fb_fem_s* h, double* vec, int width = 3) {
 template <typename MT>
 int launch_warp(fb_fem_s* h, const double* u, double* rot) {
   const int nt = h->plan.n_tets;
-  hipLaunchKernelGGL(k_tet_warp<MT>, dim3(ceil_div(nt, kBlock)), dim3(kBlock), 0, h->stream, nt, h->tets.p, h->x0.p, u, h->rest.p,
-                     (MT*)h->rec.p, h->fe.p, rot, h->lambda, h->mu, h->prm.linear != 0 ? 1 : 0, (MT*)h->kcorr.p);
+  if (h->kcorr.p)
+    hipLaunchKernelGGL((k_tet_warp<MT, true>), dim3(ceil_div(nt, kBlock)), dim3(kBlock), 0, h->stream, nt, h->tets.p, h->x0.p, u, h->rest.p, (MT*)h->rec.p, h->fe.p,
+                       rot, h->lambda, h->mu, h->prm.linear != 0 ? 1 : 0, (MT*)h->kcorr.p);
+  else
+    hipLaunchKernelGGL((k_tet_warp<MT, false>), dim3(ceil_div(nt, kBlock)), dim3(kBlock), 0, h->stream, nt, h->tets.p, h->x0.p, u, h->rest.p, (MT*)h->rec.p, h->fe.p,
+                       rot, h->lambda, h->mu, h->prm.linear != 0 ? 1 : 0, (MT*)nullptr);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }

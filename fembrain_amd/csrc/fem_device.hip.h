@@ -145,7 +145,9 @@ __device__ inline void k0_apply(const double b[4][3], double V, double lambda, d
 // derivative of the element rotation adds to the element stiffness, as a row-major 12 x 12 matrix per element (MT):
 //   term 1: column l = blockdiag(dR/dx_l) K0 (R^T x - x0),   term 2: column l = R K0 blockdiag(dR/dx_l)^T x
 // with dR/dF from G omega = 2 skew_part(.), G = (tr(S) I - S) R^T (S = the symmetric polar factor R^T F, R before the flip).
-template <typename MT>
+// TANGENT (warp = 2) is a template parameter: as a run-time branch its registers (512 + scratch) cost the default kernel a third of
+// its speed
+template <typename MT, bool TANGENT>
 __global__ __launch_bounds__(kBlock) void k_tet_warp(int nt, const int4* __restrict__ tets, const double* __restrict__ x0,
                                                      const double* __restrict__ u, const double* __restrict__ rest,
                                                      MT* __restrict__ rec, double* __restrict__ fe, double* __restrict__ rot,
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_tet_warp(int nt, const int4* __restr
     for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
   } else {
     const double det = polar_rotation(F, R, 1e-6);
-    if (kcorr) {
+    if (TANGENT) {
       // S = sym(Q^T F) with Q the rotation BEFORE the flip (PolarDecomposition::Compute returns it that way and the
       // reference flips R only, corotationalLinearFEM.cpp:262-268)
       double S[9];
