@@ -188,9 +188,14 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
       h->asm_grid = 8 * std::max(1, std::min(chunk, (cus / 8) * per_cu));
       if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] element-major assembly: %d workgroups, %d B of LDS each (%d per CU; device reports %zu / %zu)\n", h->asm_grid, h->asm_lds, per_cu, (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlock);
       const bool tangent = h->prm.exact_tangent && !h->prm.linear;
-      const void* kern = h->f64 ? (tangent ? (const void*)k_assemble_tets<double, 2, true> : (const void*)k_assemble_tets<double, 2, false>)
-                                : (tangent ? (const void*)k_assemble_tets<float, 4, true> : (const void*)k_assemble_tets<float, 4, false>);
-      FB_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, h->asm_lds));
+      const void* kerns[2][2][2] = {{{(const void*)k_assemble_tets<float, 4, false, false>, (const void*)k_assemble_tets<float, 4, false, true>},
+                                     {(const void*)k_assemble_tets<float, 4, true, false>, (const void*)k_assemble_tets<float, 4, true, true>}},
+                                    {{(const void*)k_assemble_tets<double, 2, false, false>, (const void*)k_assemble_tets<double, 2, false, true>},
+                                     {(const void*)k_assemble_tets<double, 2, true, false>, (const void*)k_assemble_tets<double, 2, true, true>}}};
+      for (int nm = 0; nm < 2; nm++) {  // (a Newmark handle assembles without qacc too: fb_fem_assemble)
+        const void* kern = kerns[h->f64 ? 1 : 0][tangent ? 1 : 0][nm];
+        FB_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, h->asm_lds));
+      }
     } else {
       h->inc_off.release(); h->inc.release(); h->inc_slot.release();
     }
@@ -335,19 +340,19 @@ int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const doub
   o.dofmask = h->dofmask.p; o.nodemask = h->nodemask.p; o.qvel = qvel; o.fext = fext; o.qacc = qacc; o.vals = (MT*)h->vals.p; o.dlo = (MT*)h->dlo.p; o.mblk_out = mblk_out;
   o.fint_out = fint_out; o.rhs = rhs; o.invdiag = invdiag;
   o.invblk = invdiag && h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI ? h->invblk.p : nullptr;
-  if (h->asm_tets) {
+  if (h->asm_tets && !mblk_out) {  // (the per-block mass read-back, fb_fem_mass, goes through the slot-major kernel)
     constexpr int G = sizeof(MT) == 4 ? 4 : 2;  // elements whose records are in flight per lane
     unsigned long long* prof = nullptr;
     if (getenv("FEMBRAIN_ASM_PROFILE")) {
       FB_HIP(hipMalloc((void**)&prof, 16 * sizeof(unsigned long long)));
       FB_HIP(hipMemset(prof, 0, 16 * sizeof(unsigned long long)));
     }
-    if (h->kcorr.p)
-      hipLaunchKernelGGL((k_assemble_tets<MT, G, true>), dim3(h->asm_grid), dim3(kBlock), (size_t)h->asm_lds, h->stream, sell_view(h), h->inc_off.p, h->inc.p,
-                         h->inc_slot.p, (const MT*)h->rec.p, h->fe.p, o, ap, (const MT*)h->kcorr.p, h->asm_max_width, prof);
-    else
-      hipLaunchKernelGGL((k_assemble_tets<MT, G, false>), dim3(h->asm_grid), dim3(kBlock), (size_t)h->asm_lds, h->stream, sell_view(h), h->inc_off.p, h->inc.p,
-                         h->inc_slot.p, (const MT*)h->rec.p, h->fe.p, o, ap, (const MT*)nullptr, h->asm_max_width, prof);
+#define FB_ASM_TETS(TANGENT, NEWMARK)                                                                                                                        \
+  hipLaunchKernelGGL((k_assemble_tets<MT, G, TANGENT, NEWMARK>), dim3(h->asm_grid), dim3(kBlock), (size_t)h->asm_lds, h->stream, sell_view(h), h->inc_off.p, \
+                     h->inc.p, h->inc_slot.p, (const MT*)h->rec.p, h->fe.p, o, ap, (const MT*)h->kcorr.p, h->asm_max_width, prof)
+    if (h->kcorr.p) { if (qacc) FB_ASM_TETS(true, true); else FB_ASM_TETS(true, false); }
+    else { if (qacc) FB_ASM_TETS(false, true); else FB_ASM_TETS(false, false); }
+#undef FB_ASM_TETS
     if (prof) {  // FEMBRAIN_ASM_PROFILE=1: where the wavefronts of k_assemble_tets spend their time (100 MHz ticks summed over the workgroups)
       FB_HIP(hipStreamSynchronize(h->stream));
       unsigned long long t[16];

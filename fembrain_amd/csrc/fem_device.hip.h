@@ -342,6 +342,15 @@ struct AsmOut {
 struct RowGather {
   double qv[3], qa[3];
   uint8_t mb[3];
+  // the same without run-time branches (k_assemble_tets: a branch per slot ends the basic block and with it the loads in flight)
+  template <typename MT, bool NEWMARK>
+  __device__ __forceinline__ void load_straight(const AsmOut<MT>& o, const AsmParams& ap, int col) {
+    qv[0] = o.qvel[3 * (size_t)col]; qv[1] = o.qvel[3 * (size_t)col + 1]; qv[2] = o.qvel[3 * (size_t)col + 2];
+    qa[0] = qa[1] = qa[2] = 0.0;
+    if (NEWMARK) { qa[0] = o.qacc[3 * (size_t)col]; qa[1] = o.qacc[3 * (size_t)col + 1]; qa[2] = o.qacc[3 * (size_t)col + 2]; }
+    const uint8_t nm = o.nodemask[col] | (ap.apply_mask ? (uint8_t)0 : (uint8_t)7);
+    mb[0] = nm & 1; mb[1] = (nm >> 1) & 1; mb[2] = (nm >> 2) & 1;
+  }
   template <typename MT>
   __device__ __forceinline__ void load(const AsmOut<MT>& o, const AsmParams& ap, int col) {
     qv[0] = o.qvel[3 * (size_t)col]; qv[1] = o.qvel[3 * (size_t)col + 1]; qv[2] = o.qvel[3 * (size_t)col + 2];
@@ -579,12 +588,16 @@ __device__ __forceinline__ void tets_accumulate(double* acc, int lane, int io, i
   for (int b = 0; b < 3; b++) acc[(3 * A + b) * 64 + lane] = acc[640 + (3 * A + b) * 64 + lane] = 0.0;  // (what tets_algebra passed through them)
   uint32_t w0[G], s0[G], w1[G], s1[G];
   mt4 r0[G][4];
+  if (height <= 0) return;
+  // list rows past the end are read from the last row and turned into padding (no run-time branch around a load)
   auto load_words = [&](int t0, uint32_t* w, uint32_t* sl) {
 #pragma unroll
     for (int u = 0; u < G; u++) {
+      const size_t at = ((size_t)io + min(t0 + u, height - 1)) * 64 + lane;
+      const uint32_t ww = inc[at], ss = inc_slot[at];
       const bool in = t0 + u < height;
-      w[u] = in ? inc[((size_t)io + t0 + u) * 64 + lane] : kNoInc;
-      sl[u] = in ? inc_slot[((size_t)io + t0 + u) * 64 + lane] : 0u;
+      w[u] = in ? ww : kNoInc;
+      sl[u] = in ? ss : 0u;
     }
   };
   auto load_records = [&](const uint32_t* w, mt4 (*r)[4]) {
@@ -658,6 +671,11 @@ __device__ __forceinline__ void tets_mass_and_forces(double* acc, double* facc, 
                                                      const uint32_t* __restrict__ inc, const uint32_t* __restrict__ inc_slot, const MT* __restrict__ rec,
                                                      const double* __restrict__ fe, const AsmParams& ap) {
   for (int k = 0; k < zero_slots; k++) acc[k * 640 + 9 * 64 + lane] = 0.0;  // (the algebra wavefronts only read the mass entries)
+  if (height <= 0) {  // a slice of nodes no element references
+    facc[lane] = facc[64 + lane] = facc[128 + lane] = 0.0;
+    nacc[lane] = 0.0;
+    return;
+  }
   double fi[3] = {0, 0, 0};
   int nd = 0;
   uint32_t w[G], sl[G], w1[G], s1[G];
@@ -665,9 +683,11 @@ __device__ __forceinline__ void tets_mass_and_forces(double* acc, double* facc, 
   auto load_words = [&](int t0, uint32_t* ww, uint32_t* ss) {
 #pragma unroll
     for (int u = 0; u < G; u++) {
+      const size_t at = ((size_t)io + min(t0 + u, height - 1)) * 64 + lane;
+      const uint32_t a = inc[at], b = inc_slot[at];
       const bool in = t0 + u < height;
-      ww[u] = in ? inc[((size_t)io + t0 + u) * 64 + lane] : kNoInc;
-      ss[u] = in ? inc_slot[((size_t)io + t0 + u) * 64 + lane] : 0u;
+      ww[u] = in ? a : kNoInc;
+      ss[u] = in ? b : 0u;
     }
   };
   auto load_values = [&](const uint32_t* ww, double* VV, double (*ff)[3]) {
@@ -714,7 +734,7 @@ __device__ __forceinline__ void tets_mass_and_forces(double* acc, double* facc, 
 }
 
 // the a7 algebra of row A of the finished blocks, in slot order (RowAlgebra split by block row); leaves its accumulators zero
-template <typename MT, int A>
+template <typename MT, int A, bool NEWMARK>
 __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, const double* nacc, const SellView& sv,
                                              const AsmOut<MT>& o, const AsmParams& ap, int s, int lane, int so, int width) {
   const int row = s * 64 + lane;
@@ -739,13 +759,13 @@ __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, co
   };
   load_cols(0, col);
 #pragma unroll
-  for (int c = 0; c < kC; c++) gq[c].load(o, ap, col[c]);
+  for (int c = 0; c < kC; c++) gq[c].template load_straight<MT, NEWMARK>(o, ap, col[c]);
   load_cols(kC, col1);
   for (int k0 = 0; k0 < width; k0 += kC) {
     RowGather gq1[kC];
     int col2[kC];
 #pragma unroll
-    for (int c = 0; c < kC; c++) gq1[c].load(o, ap, col1[c]);
+    for (int c = 0; c < kC; c++) gq1[c].template load_straight<MT, NEWMARK>(o, ap, col1[c]);
     load_cols(k0 + 2 * kC, col2);
     double Kc[kC][3], mc[kC];
 #pragma unroll
@@ -769,7 +789,7 @@ __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, co
       const double m = mc[c];
       const double* qv = gq[c].qv;
       ta += ap.g_k * (K[0] * qv[0] + K[1] * qv[1] + K[2] * qv[2]) + ap.g_m * m * qv[A];
-      if (o.qacc) ta += ap.g_a * m * gq[c].qa[A];
+      if (NEWMARK) ta += ap.g_a * m * gq[c].qa[A];
       msum += m;
       if (diag) {
         kd = slot;
@@ -782,7 +802,6 @@ __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, co
           out[(3 * A + b) * 64] = (ma[A] && gq[c].mb[b]) ? u : (MT)0;
         }
       }
-      if (A == 0 && o.mblk_out && rvalid) o.mblk_out[(size_t)slot * 64 + lane] = m;
     }
 #pragma unroll
     for (int c = 0; c < kC; c++) { col[c] = col1[c]; col1[c] = col2[c]; gq[c] = gq1[c]; }
@@ -830,7 +849,7 @@ __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, co
   }
 }
 
-template <typename MT, int G, bool TANGENT>
+template <typename MT, int G, bool TANGENT, bool NEWMARK>
 __global__ __launch_bounds__(kBlock) void k_assemble_tets(SellView sv, const int* __restrict__ inc_off, const uint32_t* __restrict__ inc,
                                                           const uint32_t* __restrict__ inc_slot, const MT* __restrict__ rec, const double* __restrict__ fe,
                                                           AsmOut<MT> o, AsmParams ap, const MT* __restrict__ kcorr, int max_width, unsigned long long* __restrict__ prof) {
@@ -858,9 +877,9 @@ __global__ __launch_bounds__(kBlock) void k_assemble_tets(SellView sv, const int
     lap(0);
     __syncthreads();
     lap(1);
-    if (wq == 0) tets_algebra<MT, 0>(acc, facc, nacc, sv, o, ap, s, lane, so, width);
-    else if (wq == 1) tets_algebra<MT, 1>(acc, facc, nacc, sv, o, ap, s, lane, so, width);
-    else if (wq == 2) tets_algebra<MT, 2>(acc, facc, nacc, sv, o, ap, s, lane, so, width);
+    if (wq == 0) tets_algebra<MT, 0, NEWMARK>(acc, facc, nacc, sv, o, ap, s, lane, so, width);
+    else if (wq == 1) tets_algebra<MT, 1, NEWMARK>(acc, facc, nacc, sv, o, ap, s, lane, so, width);
+    else if (wq == 2) tets_algebra<MT, 2, NEWMARK>(acc, facc, nacc, sv, o, ap, s, lane, so, width);
     else __syncthreads();  // (the one inside tets_algebra)
     if (o.invblk) {  // FB_PCG_BLOCK_JACOBI: the inverse of the row's 3x3 diagonal block (symmetric; identity on clamped DOFs)
       __syncthreads();
