@@ -943,15 +943,15 @@ int build_shard_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* 
   auto lap = [&](const char* what) {
     if (timing) fprintf(stderr, "[fembrain] shard plan: %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   };
-  // per-rank ingest (the caller's elements are exactly this rank's): the partition is computed on the device from the uploaded
-  // list -- halo, send lists, local numbering; otherwise (the whole mesh passed in, or more than 64 ranks) on the host
-  bool on_device = n_ranks <= 64 && !(getenv("FEMBRAIN_PARTITION_DEVICE") && atoi(getenv("FEMBRAIN_PARTITION_DEVICE")) == 0);
+  // the partition (elements with an owned node, halo, send lists, local numbering) is computed on the device from the uploaded
+  // list, be it the rank's own elements or the whole mesh; on the host only for more than 64 ranks or FEMBRAIN_PARTITION_DEVICE=0
+  const bool on_device = n_ranks <= 64 && !(getenv("FEMBRAIN_PARTITION_DEVICE") && atoi(getenv("FEMBRAIN_PARTITION_DEVICE")) == 0);
   DevBuf<int> d_halo;
   if (on_device) {
     FB_TRY(begin_fem_partition(P, n_nodes, n_tets, n_ranks, rank, splits));
     FB_TRY(h->tets.upload((const int4*)tets, (size_t)n_tets, h->stream));
     DevicePartition dp;
-    const int rc = device_partition(h->stream, n_tets, h->tets.p, n_nodes, n_ranks, rank, P.splits, dp, h->plan_ws);
+    const int rc = device_partition(h->stream, n_tets, h->tets, n_nodes, n_ranks, rank, P.splits, dp, h->plan_ws);
     if (rc != FB_OK && dp.first_bad_tet >= 0) {  // say which node, as the host builder does
       for (int k = 0; k < 4; k++) {
         const int id = tets[4 * (size_t)dp.first_bad_tet + k];
@@ -959,16 +959,15 @@ int build_shard_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* 
       }
     }
     FB_TRY(rc);
-    on_device = dp.all_kept;
-    if (on_device) {
-      P.n_tets = n_tets;
-      P.n_owned_corners = dp.owned_corners;
-      set_partition_halo(P, dp.halo);
-      P.send_off = dp.send_off;
-      P.send_local = dp.send_local;
-    }
+    P.n_tets = dp.n_kept;
+    P.tet_global = dp.tet_global;
+    P.n_owned_corners = dp.owned_corners;
+    set_partition_halo(P, dp.halo);
+    P.send_off = dp.send_off;
+    P.send_local = dp.send_local;
+  } else {
+    FB_TRY(build_fem_partition(P, n_nodes, n_tets, tets, n_ranks, rank, splits, false));
   }
-  if (!on_device) FB_TRY(build_fem_partition(P, n_nodes, n_tets, tets, n_ranks, rank, splits, false));
   lap(on_device ? "partition (device)" : "partition (host)");
   FB_TRY(plan_set_constraints(P, n_fixed, fixed));
   lap("constraints");

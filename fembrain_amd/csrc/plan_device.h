@@ -19,13 +19,15 @@ struct PlanWorkspace {
   DevBuf<char> temp;
   DevBuf<unsigned char> nodeflag;          // device_partition: halo marks over the global nodes
   DevBuf<unsigned long long> sendmask;     // device_partition: per owned node, the ranks that want it
-  DevBuf<int> picked, splits;              // device_partition: selected ids (+ count at the end), node ranges
+  DevBuf<int> picked, splits, idsel;       // device_partition: selected ids (+ count at the end), node ranges, kept element ids
+  DevBuf<unsigned char> keep;              // device_partition: element has an owned node
+  DevBuf<int4> tetsel;                     // device_partition: the kept elements (swapped with the handle's buffer)
   size_t bytes() const {
-    return nodeflag.n + sendmask.n * 8 + picked.n * 4 + keys.n * 8 + keys_s.n * 8 + ukeys.n * 8 + vals.n * 4 + vals_s.n * 4 + ucnt.n * 4 + cstart.n * 4 + nruns.n * 4 + width.n * 4 + flags.n * 4 + temp.n;
+    return nodeflag.n + sendmask.n * 8 + picked.n * 4 + idsel.n * 4 + keep.n + tetsel.n * 16 + keys.n * 8 + keys_s.n * 8 + ukeys.n * 8 + vals.n * 4 + vals_s.n * 4 + ucnt.n * 4 + cstart.n * 4 + nruns.n * 4 + width.n * 4 + flags.n * 4 + temp.n;
   }
   void release() {
     keys.release(); keys_s.release(); ukeys.release(); vals.release(); vals_s.release(); ucnt.release(); cstart.release(); nruns.release();
-    width.release(); flags.release(); temp.release(); nodeflag.release(); sendmask.release(); picked.release(); splits.release();
+    width.release(); flags.release(); temp.release(); nodeflag.release(); sendmask.release(); picked.release(); splits.release(); idsel.release(); keep.release(); tetsel.release();
   }
 };
 
@@ -53,19 +55,19 @@ struct PlanShard {
   long long n_pairs = 0;        // vertex pairs whose row is owned (host count) + n_rows markers
 };
 
-// The partition of one rank from ITS OWN element list (per-rank ingest, fb_fem_create_sharded) on the device: what
-// fem_plan.cpp's build_fem_partition computes on the host.  d_tets: n_tets x int4 GLOBAL node ids, replaced by local ids
-// (owned first, then the halo ascending) when the call succeeds.  Outputs: halo (ascending global ids), per neighbour rank the
-// owned local ids it wants (send_off / send_local, ascending), the count of element corners on owned nodes.  all_kept is false
-// when some element has no owned node (the caller passed more than this rank's elements: the host partition compacts those) --
-// d_tets is then left as it was.  n_ranks <= 64.  Synchronises the stream.
+// The partition of one rank on the device: what fem_plan.cpp's build_fem_partition computes on the host.  tets: n_tets x int4
+// GLOBAL node ids -- the rank's own elements (per-rank ingest) or any superset up to the whole mesh; on success it holds the
+// n_kept elements with an owned node, in the caller's order, in local ids (owned first, then the halo ascending).  Outputs:
+// halo (ascending global ids), per neighbour rank the owned local ids it wants (send_off / send_local, ascending), the count of
+// element corners on owned nodes, the caller's indices of the kept elements.  n_ranks <= 64.  Synchronises the stream.
 struct DevicePartition {
   std::vector<int> halo, send_off, send_local;
+  std::vector<int> tet_global;  // ids of the kept elements in the caller's list; empty when all were kept
   long long owned_corners = 0;
-  int first_bad_tet = -1, bad_node = 0;
+  int first_bad_tet = -1, bad_node = 0, n_kept = 0;
   bool all_kept = false;
 };
-int device_partition(hipStream_t s, int n_tets, int4* d_tets, int n_global, int n_ranks, int rank, const std::vector<int>& splits,
+int device_partition(hipStream_t s, int n_tets, DevBuf<int4>& tets, int n_global, int n_ranks, int rank, const std::vector<int>& splits,
                      DevicePartition& out, PlanWorkspace& ws);
 
 // d_tets: n_tets x int4 node ids (local ids for a shard); their range is checked here (first_bad_tet).  shard = nullptr: the

@@ -229,7 +229,8 @@ __device__ __forceinline__ int owner_of_node(const int* __restrict__ splits, int
 }
 
 __global__ __launch_bounds__(kB) void k_part_mark(int n_tets, const int4* __restrict__ tets, int n_global, int node_lo, int n_owned, const int* __restrict__ splits,
-                                                  int n_ranks, unsigned char* __restrict__ nodeflag, unsigned long long* __restrict__ sendmask, PartCounters* __restrict__ cnt) {
+                                                  int n_ranks, unsigned char* __restrict__ nodeflag, unsigned long long* __restrict__ sendmask, unsigned char* __restrict__ keep,
+                                                  PartCounters* __restrict__ cnt) {
   const int e = blockIdx.x * kB + threadIdx.x;
   int n_own = 0;
   if (e < n_tets) {
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(kB) void k_part_mark(int n_tets, const int4* __rest
     } else {
       n_own = 0;
     }
+    keep[e] = n_own > 0 ? 1 : 0;
   }
   // corners on owned nodes: one atomic per wavefront
   for (int o = 32; o; o >>= 1) n_own += __shfl_down(n_own, o);
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(kB) void k_part_local(int n_tets, int4* __restrict_
 
 }  // namespace
 
-int device_partition(hipStream_t s, int n_tets, int4* d_tets, int n_global, int n_ranks, int rank, const std::vector<int>& splits,
+int device_partition(hipStream_t s, int n_tets, DevBuf<int4>& tets, int n_global, int n_ranks, int rank, const std::vector<int>& splits,
                      DevicePartition& out, PlanWorkspace& W) {
   if (n_ranks > 64 || n_ranks < 2) return fail(FB_EINVAL, "device partition handles 2..64 ranks");
   const int node_lo = splits[rank], n_owned = splits[rank + 1] - splits[rank];
@@ -303,6 +305,7 @@ int device_partition(hipStream_t s, int n_tets, int4* d_tets, int n_global, int 
   FB_TRY(W.sendmask.reserve((size_t)n_owned));
   FB_TRY(W.picked.reserve((size_t)std::max(n_global, n_owned) + 4));
   FB_TRY(W.splits.reserve((size_t)n_ranks + 1));
+  FB_TRY(W.keep.reserve((size_t)n_tets));
   FB_TRY(W.keys.reserve(4));  // the counters (8-byte aligned)
   PartCounters* d_cnt = reinterpret_cast<PartCounters*>(W.keys.p);
   PartCounters cnt = {0x7fffffff, 0, 0, 0, 0ull};
@@ -310,8 +313,8 @@ int device_partition(hipStream_t s, int n_tets, int4* d_tets, int n_global, int 
   FB_HIP(hipMemcpyAsync(W.splits.p, splits.data(), sizeof(int) * (n_ranks + 1), hipMemcpyHostToDevice, s));
   FB_HIP(hipMemsetAsync(W.nodeflag.p, 0, (size_t)n_global, s));
   FB_HIP(hipMemsetAsync(W.sendmask.p, 0, sizeof(unsigned long long) * (size_t)n_owned, s));
-  hipLaunchKernelGGL(k_part_mark, dim3((n_tets + kB - 1) / kB), dim3(kB), 0, s, n_tets, d_tets, n_global, node_lo, n_owned, W.splits.p, n_ranks, W.nodeflag.p,
-                     W.sendmask.p, d_cnt);
+  hipLaunchKernelGGL(k_part_mark, dim3((n_tets + kB - 1) / kB), dim3(kB), 0, s, n_tets, tets.p, n_global, node_lo, n_owned, W.splits.p, n_ranks, W.nodeflag.p,
+                     W.sendmask.p, W.keep.p, d_cnt);
   FB_HIP(hipGetLastError());
   // halo = the marked nodes, ascending
   int* d_count = W.picked.p + std::max(n_global, n_owned);
@@ -329,8 +332,31 @@ int device_partition(hipStream_t s, int n_tets, int4* d_tets, int n_global, int 
     return fail(FB_EINVAL, "tet %d references a node outside [0,%d)", cnt.first_bad, n_global);
   }
   out.all_kept = cnt.not_kept == 0;
+  out.n_kept = n_tets - cnt.not_kept;
   out.owned_corners = (long long)cnt.corners;
-  if (!out.all_kept) return FB_OK;
+  if (out.n_kept <= 0) return fail(FB_EINVAL, "rank %d: no element touches its nodes [%d,%d)", rank, node_lo, node_lo + n_owned);
+  if (!out.all_kept) {
+    // the caller passed more than this rank's elements (the whole mesh): keep those with an owned node, in their order, and
+    // remember which they were (error messages name global element ids)
+    FB_TRY(W.tetsel.reserve((size_t)out.n_kept));
+    FB_TRY(W.idsel.reserve((size_t)out.n_kept + 4));
+    int* d_n = W.idsel.p + out.n_kept;
+    bytes = 0;
+    FB_HIP(rocprim::select(nullptr, bytes, tets.p, W.keep.p, W.tetsel.p, d_n, (size_t)n_tets, s));
+    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::select(W.temp.p, bytes, tets.p, W.keep.p, W.tetsel.p, d_n, (size_t)n_tets, s));
+    bytes = 0;
+    FB_HIP(rocprim::select(nullptr, bytes, rocprim::counting_iterator<int>(0), W.keep.p, W.idsel.p, d_n, (size_t)n_tets, s));
+    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::select(W.temp.p, bytes, rocprim::counting_iterator<int>(0), W.keep.p, W.idsel.p, d_n, (size_t)n_tets, s));
+    out.tet_global.resize((size_t)out.n_kept);
+    FB_HIP(hipMemcpyAsync(out.tet_global.data(), W.idsel.p, sizeof(int) * (size_t)out.n_kept, hipMemcpyDeviceToHost, s));
+    FB_HIP(hipStreamSynchronize(s));
+    std::swap(tets.p, W.tetsel.p);  // the handle's element buffer is now the compacted list (the old one serves the next re-sync)
+    std::swap(tets.n, W.tetsel.n);
+  }
+  n_tets = out.n_kept;
+  int4* d_tets = tets.p;
   out.halo.resize((size_t)n_halo);
   if (n_halo) FB_HIP(hipMemcpyAsync(out.halo.data(), W.picked.p, sizeof(int) * (size_t)n_halo, hipMemcpyDeviceToHost, s));
   // local numbering of the elements while the halo list is still in W.picked

@@ -1,5 +1,6 @@
 """Two ranks on one GPU: time of a collective fb_fem_resync_sharded and the SpMV byte count of a sharded handle
-(2-byte column deltas where they fit).  usage: python tools/probe_sharded_resync.py [n=71] [world=2]"""
+(2-byte column deltas where they fit).  usage: python tools/probe_sharded_resync.py [n=71] [world=2] [own|whole]
+(own: every rank passes its own elements; whole: every rank passes the whole mesh and the device keeps its share)"""
 import ctypes as C
 import multiprocessing as mp
 import os
@@ -11,7 +12,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
-def worker(rank, world, name, n, q):
+def worker(rank, world, name, n, q, whole=False):
     from fembrain_amd import lib as fl
     from fembrain_amd.fem import FemIntegrator
     from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
@@ -22,7 +23,7 @@ def worker(rank, world, name, n, q):
     fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
     splits = np.array([(n * r // world) * n * n for r in range(world + 1)], np.int32)
     own = ((t >= splits[rank]) & (t < splits[rank + 1])).any(axis=1)
-    to = np.ascontiguousarray(t[own])
+    to = np.ascontiguousarray(t if whole else t[own])
     t0 = time.perf_counter()
     g = FemIntegrator(v, to, fixed, shard=(world, rank, splits, comm))
     create_ms = (time.perf_counter() - t0) * 1e3
@@ -33,7 +34,7 @@ def worker(rank, world, name, n, q):
         ms.append((time.perf_counter() - t0) * 1e3)
     g.set_uniform_force(1, -3000.0)
     its = g.do_timestep()
-    q.put((rank, len(to), create_ms, ms, g.num_blocks(), g.spmv_bytes(), its, g.last.solve_seconds))
+    q.put((rank, int(own.sum()), create_ms, ms, g.num_blocks(), g.spmv_bytes(), its, g.last.solve_seconds))
     g.close()
     L.fb_comm_destroy(comm)
 
@@ -41,10 +42,11 @@ def worker(rank, world, name, n, q):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 71
     world = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    whole = len(sys.argv) > 3 and sys.argv[3] == "whole"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     name = "/fembrain_probe_resync_%d" % os.getpid()
-    ps = [ctx.Process(target=worker, args=(r, world, name, n, q)) for r in range(world)]
+    ps = [ctx.Process(target=worker, args=(r, world, name, n, q, whole)) for r in range(world)]
     for p in ps:
         p.start()
     for _ in ps:
