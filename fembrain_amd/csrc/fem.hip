@@ -177,7 +177,7 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
     const char* e = getenv("FEMBRAIN_ASM_KERNEL");
     h->asm_max_width = mw;
     h->asm_lds = (mw * 10 + kAsmExtra) * 64 * (int)sizeof(double);
-    h->asm_tets = mw >= 2 && h->asm_lds <= lds_cu && h->asm_lds <= (int)prop.sharedMemPerBlock && !(e && !strcmp(e, "rows"));
+    h->asm_tets = mw >= 2 && mw <= kIncMaxWidth && h->asm_lds <= lds_cu && h->asm_lds <= (int)prop.sharedMemPerBlock && !(e && !strcmp(e, "rows"));
     if (h->asm_tets) {
       FB_TRY(build_incidence_device(s, P.n_slices, P.n_owned, h->slice_off.p, h->colidx.p, h->slot_coff.p, h->slot_ccnt.p, h->contrib.p, h->tets.p, h->inc_off,
                                     h->inc, h->inc_slot, h->plan_ws));
@@ -188,8 +188,8 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
       h->asm_grid = 8 * std::max(1, std::min(chunk, (cus / 8) * per_cu));
       if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] element-major assembly: %d workgroups, %d B of LDS each (%d per CU; device reports %zu / %zu)\n", h->asm_grid, h->asm_lds, per_cu, (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlock);
       const bool tangent = h->prm.exact_tangent && !h->prm.linear;
-      const void* kerns[2][2][2] = {{{(const void*)k_assemble_tets<float, 4, false, false>, (const void*)k_assemble_tets<float, 4, false, true>},
-                                     {(const void*)k_assemble_tets<float, 4, true, false>, (const void*)k_assemble_tets<float, 4, true, true>}},
+      const void* kerns[2][2][2] = {{{(const void*)k_assemble_tets<float, 2, false, false>, (const void*)k_assemble_tets<float, 2, false, true>},
+                                     {(const void*)k_assemble_tets<float, 2, true, false>, (const void*)k_assemble_tets<float, 2, true, true>}},
                                     {{(const void*)k_assemble_tets<double, 2, false, false>, (const void*)k_assemble_tets<double, 2, false, true>},
                                      {(const void*)k_assemble_tets<double, 2, true, false>, (const void*)k_assemble_tets<double, 2, true, true>}}};
       for (int nm = 0; nm < 2; nm++) {  // (a Newmark handle assembles without qacc too: fb_fem_assemble)
@@ -341,7 +341,7 @@ int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const doub
   o.fint_out = fint_out; o.rhs = rhs; o.invdiag = invdiag;
   o.invblk = invdiag && h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI ? h->invblk.p : nullptr;
   if (h->asm_tets && !mblk_out) {  // (the per-block mass read-back, fb_fem_mass, goes through the slot-major kernel)
-    constexpr int G = sizeof(MT) == 4 ? 4 : 2;  // elements whose records are in flight per lane
+    constexpr int G = 2;  // list rows whose records are in flight per lane (measured at 1M tets, fp32: 224 us with 4, 209 with 2, 211 with 1)
     unsigned long long* prof = nullptr;
     if (getenv("FEMBRAIN_ASM_PROFILE")) {
       FB_HIP(hipMalloc((void**)&prof, 16 * sizeof(unsigned long long)));

@@ -1,5 +1,6 @@
 // FEM device kernels (included by fem.hip only).
 #pragma once
+#include <type_traits>
 #include "fem_kernels.h"
 #include "p2p_device.hip.h"
 
@@ -753,32 +754,25 @@ __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, co
   constexpr int kC = 4;
   int col[kC], col1[kC];
   RowGather gq[kC];
+  // (columns past the width are read from the last slot: no run-time branch around a load; the chunks that lie wholly inside the
+  // width go through a copy of the body without any test)
   auto load_cols = [&](int k0, int* cc) {
 #pragma unroll
-    for (int c = 0; c < kC; c++) cc[c] = k0 + c < width ? sv.colidx[((size_t)so + k0 + c) * 64 + lane] : 0;
+    for (int c = 0; c < kC; c++) cc[c] = sv.colidx[((size_t)so + min(k0 + c, width - 1)) * 64 + lane];
   };
-  load_cols(0, col);
-#pragma unroll
-  for (int c = 0; c < kC; c++) gq[c].template load_straight<MT, NEWMARK>(o, ap, col[c]);
-  load_cols(kC, col1);
-  for (int k0 = 0; k0 < width; k0 += kC) {
-    RowGather gq1[kC];
-    int col2[kC];
-#pragma unroll
-    for (int c = 0; c < kC; c++) gq1[c].template load_straight<MT, NEWMARK>(o, ap, col1[c]);
-    load_cols(k0 + 2 * kC, col2);
+  auto chunk = [&](int k0, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
     double Kc[kC][3], mc[kC];
 #pragma unroll
     for (int c = 0; c < kC; c++) {
-      double* p = acc + (k0 + c) * 640 + lane;  // (slots past the width: rows of the LDS tail or of the next slots, read and not used)
-      const bool in = k0 + c < width;
+      double* p = acc + min(k0 + c, width - 1) * 640 + lane;
 #pragma unroll
-      for (int b = 0; b < 3; b++) Kc[c][b] = in ? p[(3 * A + b) * 64] : 0.0;
-      mc[c] = in ? p[9 * 64] : 0.0;
+      for (int b = 0; b < 3; b++) Kc[c][b] = p[(3 * A + b) * 64];
+      mc[c] = p[9 * 64];
     }
 #pragma unroll
     for (int c = 0; c < kC; c++) {
-      if (k0 + c >= width) break;
+      if (!FULL && k0 + c >= width) break;
       const int k = k0 + c, slot = so + k;
       const bool diag = rvalid && (col[c] == row) && !seen_diag;
       seen_diag = seen_diag || diag;
@@ -803,8 +797,23 @@ __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, co
         }
       }
     }
+  };
+  if (width > 0) {
+    load_cols(0, col);
 #pragma unroll
-    for (int c = 0; c < kC; c++) { col[c] = col1[c]; col1[c] = col2[c]; gq[c] = gq1[c]; }
+    for (int c = 0; c < kC; c++) gq[c].template load_straight<MT, NEWMARK>(o, ap, col[c]);
+    load_cols(kC, col1);
+    for (int k0 = 0; k0 < width; k0 += kC) {
+      RowGather gq1[kC];
+      int col2[kC];
+#pragma unroll
+      for (int c = 0; c < kC; c++) gq1[c].template load_straight<MT, NEWMARK>(o, ap, col1[c]);
+      load_cols(k0 + 2 * kC, col2);
+      if (k0 + kC <= width) chunk(k0, std::true_type());
+      else chunk(k0, std::false_type());
+#pragma unroll
+      for (int c = 0; c < kC; c++) { col[c] = col1[c]; col1[c] = col2[c]; gq[c] = gq1[c]; }
+    }
   }
   // the diagonal block needs the sums of the other rows: off[3a+b] and off[3b+a]
   double* xoff = acc;        // value rows of slot 0

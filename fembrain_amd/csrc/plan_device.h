@@ -78,6 +78,7 @@ int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets
 // on the device (whichever builder made it): per slice the longest list of its 64 rows (inc_off = prefix sums), per (list row, lane)
 // the word element << 2 | corner (kNoContrib past the end) and the slots of the element's four blocks in the lane's row (4 x u8).
 // The incidence list of a row is the contribution list of its diagonal block, so the ascending element order carries over.
+constexpr int kIncMaxWidth = 31;  // widest slice (in slots) the element-major assembly kernel takes
 int build_incidence_device(hipStream_t s, int n_slices, int n_owned, const int* slice_off, const int* colidx, const int* slot_coff, const int* slot_ccnt,
                            const uint32_t* contrib, const int4* tets, DevBuf<int>& inc_off, DevBuf<uint32_t>& inc, DevBuf<uint32_t>& inc_slot, PlanWorkspace& ws);
 

@@ -185,15 +185,21 @@ __global__ __launch_bounds__(kB) void k_inc_heights(int n_slices, int n_owned, c
 __global__ __launch_bounds__(kB) void k_inc_fill(int n_slices, int n_owned, const int* __restrict__ slice_off, const int* __restrict__ colidx, const int* __restrict__ slot_coff, const int* __restrict__ slot_ccnt,
                                                      const uint32_t* __restrict__ contrib, const int4* __restrict__ tets, const int* __restrict__ inc_off,
                                                      uint32_t* __restrict__ inc, uint32_t* __restrict__ inc_slot) {
-  const int s = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // the columns of the slice are searched 4 x (list length) times per row: staged in LDS once (the builder is called for
+  // slices of at most kIncMaxWidth slots, the limit of the kernel that reads the lists)
+  __shared__ int cols[kB / 64][kIncMaxWidth][64];
+  const int wv = threadIdx.x >> 6;
+  const int s = blockIdx.x * (kB / 64) + wv, lane = threadIdx.x & 63;
   if (s >= n_slices) return;
   const int row = s * 64 + lane;
-  const int so = slice_off[s], width = slice_off[s + 1] - so;
+  const int so = slice_off[s], width = min(slice_off[s + 1] - so, kIncMaxWidth);
   const int io = inc_off[s], height = inc_off[s + 1] - io;
   int kd = -1;
-  if (row < n_owned)
-    for (int k = 0; k < width && kd < 0; k++)
-      if (colidx[((size_t)so + k) * 64 + lane] == row) kd = k;
+  for (int k = 0; k < width; k++) {
+    const int c = colidx[((size_t)so + k) * 64 + lane];
+    cols[wv][k][lane] = c;
+    if (row < n_owned && kd < 0 && c == row) kd = k;
+  }
   const int coff = kd >= 0 ? slot_coff[so + kd] : 0, ccnt = kd >= 0 ? slot_ccnt[so + kd] : 0;
   for (int t = 0; t < height; t++) {
     uint32_t w = kNoContrib, sl = 0;
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(kB) void k_inc_fill(int n_slices, int n_owned, cons
         const int id[4] = {tt.x, tt.y, tt.z, tt.w};
         for (int j = 0; j < 4; j++) {
           int k = 0;
-          while (k < width && colidx[((size_t)so + k) * 64 + lane] != id[j]) k++;  // found by construction; the first match is the real block
+          while (k < width && cols[wv][k][lane] != id[j]) k++;  // found by construction; the first match is the real block
           sl |= (uint32_t)(k & 255) << (8 * j);
         }
       }
