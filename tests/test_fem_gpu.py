@@ -815,7 +815,21 @@ def _wide_mesh():
     return v, t, fixed_vertices_to_dofs(np.array([1, 2, 3]))
 
 
-@pytest.mark.parametrize("case", ["cube14", "cube14_f64", "cube14_tangent", "cube14_newmark", "cube14_block_jacobi", "beam3", "hub"])
+def _jittered_lattice():
+    """Delaunay tetrahedra of a 9^3 lattice with jittered points: irregular valences, longest block row 29 (slices of 16..29
+    slots: the element-major kernel with one workgroup per CU)"""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(1)
+    n = 9
+    g = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(float)
+    pts = (g + rng.uniform(-0.3, 0.3, size=g.shape)) * 0.1
+    t = Delaunay(pts).simplices.astype(np.int32)
+    vol = np.einsum("ij,ij->i", pts[t[:, 1]] - pts[t[:, 0]], np.cross(pts[t[:, 2]] - pts[t[:, 0]], pts[t[:, 3]] - pts[t[:, 0]])) / 6
+    t = np.ascontiguousarray(t[np.abs(vol) > 1e-10])
+    return pts, t, fixed_vertices_to_dofs(np.nonzero(g[:, 0] == 0)[0])
+
+
+@pytest.mark.parametrize("case", ["cube14", "cube14_f64", "cube14_tangent", "cube14_newmark", "cube14_block_jacobi", "beam3", "jitter", "jitter_f64", "hub"])
 def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, monkeypatch, case):
     """k_assemble_tets (lane walks its row's elements, blocks accumulated in LDS) against k_assemble_rows (FEMBRAIN_ASM_KERNEL=rows):
     raw f and K at a seeded displacement, Keff and rhs of a step, the states after two steps -- all bit for bit, for both matrix
@@ -827,6 +841,10 @@ def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, mo
         v, t, fixed = g0["verts"], g0["tets"], fixed_vertices_to_dofs(g0["fixed_vertices"])
     elif case == "hub":
         v, t, fixed = _wide_mesh()
+    elif case.startswith("jitter"):
+        v, t, fixed = _jittered_lattice()
+        if case.endswith("f64"):
+            kw["matrix_precision"] = fl.FB_MATRIX_F64
     else:
         v, t, fixed = _cube(14)
         if case.endswith("f64"):
@@ -846,7 +864,7 @@ def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, mo
         f, K = g.assemble(u)
         its = []
         for _ in range(2):
-            g.set_uniform_force(1, -2000.0 if case != "hub" else -1.0)
+            g.set_uniform_force(1, -2000.0 if case not in ("hub", "jitter", "jitter_f64") else -1.0)
             its.append(g.do_timestep())
         Keff, rhs = g.system()
         out.append((f, K, its, Keff, rhs, g.get_q_state()[0], g.mass()))
