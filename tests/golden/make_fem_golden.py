@@ -9,6 +9,9 @@ at test time.
   fem_cube5_linear.npz   the same cube with warp = 0 (linear elasticity): assembled f and K at a seeded displacement, q after 2 steps
   fem_cube5_warp2.npz    warp = 2 (exact tangent stiffness): assembled f and K at a seeded displacement
   fem_cube5_newmark.npz  ImplicitNewmarkSparse::DoTimestep (restated on the reference's objects): q, qvel, qaccel after 3 steps, 1 and 3 Newton iterations
+  fem_disc.npz, fem_pyramid.npz   the other two tet meshes the reference ships (data/models/disc/disc.1.veg: 68 nodes / 121 tets,
+                  data/models/pyramid/pyramid.1.veg: 34 / 32; written by FemBrain from TetGen output): mesh, f and K at a seeded
+                  displacement, q / qvel after 3 steps with -10 per y-DOF, the nodes of the lowest quarter in x clamped
   fem_beam3.npz   data/models/beam3/beam3_tet.veg (208 nodes / 450 tets, Vega's own sample) with beam3.bou clamps:
                   mesh, the reference's consistent mass matrix file beam3_tet.mass (a known answer shipped by the
                   reference), and q after 3 steps with -10 per y-DOF
@@ -151,13 +154,36 @@ def beam3():
     print("beam3:", v.shape, t.shape, "fixed", fixed_vertices, "iters", its, "mass entries", len(tri))
 
 
+def shipped_meshes():
+    """disc.1.veg and pyramid.1.veg: assembled f, K at a seeded displacement and 3 gentle steps of the reference build"""
+    for name, rel in (("disc", "disc/disc.1.veg"), ("pyramid", "pyramid/pyramid.1.veg")):
+        v, t = read_veg(os.path.join(REF, rel))
+        fixed_vertices = np.nonzero(v[:, 0] <= v[:, 0].min() + 0.25 * (v[:, 0].max() - v[:, 0].min()))[0].astype(np.int32)  # the quarter of lowest x
+        fixed = fixed_vertices_to_dofs(fixed_vertices)
+        r = RefFem(v, t)
+        ia, ja = r.csr()
+        rng = np.random.default_rng(97)
+        u = rng.normal(size=r.r) * 0.01 * (v.max() - v.min())
+        f, K = r.assemble(u)
+        # the disc is a thin plate of slivers (2,000+ PCG iterations on 204 DOFs): at the reference tolerance 1e-6 two correct solvers
+        # agree only to ~1e-3, so its steps are solved to 1e-9
+        eps = 1e-9 if name == "disc" else 1e-6
+        q, qv, its = steps(v, t, fixed, -10.0, n=3, eps=eps)
+        np.savez_compressed(os.path.join(HERE, "fem_%s.npz" % name), verts=v, tets=t, fixed_vertices=fixed_vertices, ia=ia, ja=ja, u=u, f=f, K=K,
+                            q=q, qvel=qv, iters=its, cg_eps=eps)
+        print(name, v.shape, t.shape, "fixed vertices", len(fixed_vertices), "iters", its, "|q|", np.abs(q[-1]).max())
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "linear":
         cube5_linear()   # added later: leaves the other two files as they are
     elif len(sys.argv) > 1 and sys.argv[1] == "round2":
         cube5_warp2()    # round 2: the exact-tangent option and the Newmark step
         cube5_newmark()
+    elif len(sys.argv) > 1 and sys.argv[1] == "shipped":
+        shipped_meshes()
     else:
         cube5()
         cube5_linear()
         beam3()
+        shipped_meshes()

@@ -275,6 +275,35 @@ def test_beam3_against_reference_golden(gpu):
         assert abs(M - Mref).max() <= (1e-12 if prec == fl.FB_MATRIX_F64 else 1e-7) * abs(Mref).max()
 
 
+@pytest.mark.parametrize("name", ["disc", "pyramid"])
+def test_shipped_disc_and_pyramid_meshes_against_reference_golden(gpu, name):
+    """data/models/disc/disc.1.veg (a thin plate of slivers) and pyramid/pyramid.1.veg, the other tet meshes the reference ships:
+    pattern, f and K at a seeded displacement and three gentle steps against the reference build's vectors"""
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "fem_%s.npz" % name))
+    fixed = fixed_vertices_to_dofs(gold["fixed_vertices"])
+    # fp32 matrix storage on the disc: every entry rounded to 6e-8 times a condition number of ~1e5 (2,800 PCG iterations on 204 DOFs)
+    for prec, tol_k, tol_q in ((fl.FB_MATRIX_F64, 1e-9, 2e-5), (fl.FB_MATRIX_F32, 5e-7, 1e-2 if name == "disc" else 3e-4)):
+        g = FemIntegrator(gold["verts"], gold["tets"], fixed, matrix_precision=prec, cg_eps=float(gold["cg_eps"]))  # (disc: 1e-9, see make_fem_golden.py)
+        f, K = g.assemble(gold["u"])
+        bptr, bcol = g.pattern()
+        # the golden K is the reference's scalar CSR: compare through a sparse matrix
+        import scipy.sparse as sp
+        n = len(gold["verts"])
+        A = sp.bsr_matrix((K, bcol, bptr), shape=(3 * n, 3 * n)).tocsr()
+        Aref = sp.csr_matrix((gold["K"], gold["ja"], gold["ia"]), shape=(3 * n, 3 * n))
+        assert abs(A - Aref).max() <= tol_k * abs(Aref).max()
+        assert np.abs(f - gold["f"]).max() <= (1e-9 if prec == fl.FB_MATRIX_F64 else 1e-9) * np.abs(gold["f"]).max()
+        fe = np.zeros(g.r)
+        fe[1::3] = -10.0
+        for k in range(3):
+            g.set_external_forces(fe)
+            it = g.do_timestep()
+            q, _, _ = g.get_q_state()
+            assert abs(it - int(gold["iters"][k])) <= max(5, 0.15 * int(gold["iters"][k])), (name, k, it, int(gold["iters"][k]))
+            assert np.abs(q - gold["q"][k]).max() <= tol_q * np.abs(gold["q"][k]).max(), (name, k, prec, np.abs(q - gold["q"][k]).max() / np.abs(gold["q"][k]).max())
+        g.close()
+
+
 def test_ragged_inputs(gpu):
     """Edge cases: a node no element references (kept at rest), a single tet, no constraints at all (singular K but
     Keff = M + ... is SPD), arbitrary (not node-aligned) constrained DOFs."""
