@@ -12,6 +12,9 @@ at test time.
   fem_disc.npz, fem_pyramid.npz   the other two tet meshes the reference ships (data/models/disc/disc.1.veg: 68 nodes / 121 tets,
                   data/models/pyramid/pyramid.1.veg: 34 / 32; written by FemBrain from TetGen output): mesh, f and K at a seeded
                   displacement, q / qvel after 3 steps with -10 per y-DOF, the nodes of the lowest quarter in x clamped
+  fem_peanut.npz  data/models/blobtree/peanut.veg (3,224 nodes / 12,947 tets: a mesh FemBrain itself simulates -- its polygonizer's
+                  surface vertices tetrahedralized by TetGen): mesh (float32 positions as the file prints them), q after 2 steps under
+                  the reference load (-10000 per y-DOF) and under -10, the tenth of the nodes with the lowest y clamped
   fem_beam3.npz   data/models/beam3/beam3_tet.veg (208 nodes / 450 tets, Vega's own sample) with beam3.bou clamps:
                   mesh, the reference's consistent mass matrix file beam3_tet.mass (a known answer shipped by the
                   reference), and q after 3 steps with -10 per y-DOF
@@ -174,6 +177,19 @@ def shipped_meshes():
         print(name, v.shape, t.shape, "fixed vertices", len(fixed_vertices), "iters", its, "|q|", np.abs(q[-1]).max())
 
 
+def peanut():
+    v, t = read_veg(os.path.join(REF, "blobtree", "peanut.veg"))
+    v = v.astype(np.float32).astype(np.float64)  # (the file prints 6 digits)
+    order = np.argsort(v[:, 1], kind="stable")
+    fixed_vertices = np.sort(order[:len(v) // 10]).astype(np.int32)
+    fixed = fixed_vertices_to_dofs(fixed_vertices)
+    qa, _, ia_ = steps(v, t, fixed, -10000.0, n=2)
+    qb, _, ib_ = steps(v, t, fixed, -10.0, n=2)
+    np.savez_compressed(os.path.join(HERE, "fem_peanut.npz"), verts=v.astype(np.float32), tets=t.astype(np.int32), fixed_vertices=fixed_vertices,
+                        q_ref_load=qa, it_ref_load=ia_, q_gentle=qb, it_gentle=ib_)
+    print("peanut:", v.shape, t.shape, "fixed", len(fixed_vertices), "iters", ia_, ib_, "|q|", np.abs(qa[-1]).max(), np.abs(qb[-1]).max())
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "linear":
         cube5_linear()   # added later: leaves the other two files as they are
@@ -182,8 +198,11 @@ if __name__ == "__main__":
         cube5_newmark()
     elif len(sys.argv) > 1 and sys.argv[1] == "shipped":
         shipped_meshes()
+    elif len(sys.argv) > 1 and sys.argv[1] == "peanut":
+        peanut()
     else:
         cube5()
         cube5_linear()
         beam3()
         shipped_meshes()
+        peanut()

@@ -304,6 +304,27 @@ def test_shipped_disc_and_pyramid_meshes_against_reference_golden(gpu, name):
         g.close()
 
 
+def test_peanut_veg_steps_against_reference_golden(gpu):
+    """data/models/blobtree/peanut.veg, a mesh FemBrain itself simulates (3,224 nodes / 12,947 TetGen tets), against the reference
+    build's q after two steps under the reference load and under a gentle one; both matrix widths"""
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "fem_peanut.npz"))
+    v = gold["verts"].astype(np.float64)
+    fixed = fixed_vertices_to_dofs(gold["fixed_vertices"])
+    for prec, tol in ((fl.FB_MATRIX_F64, 2e-5), (fl.FB_MATRIX_F32, 3e-4)):
+        for load, key in ((-10000.0, "ref_load"), (-10.0, "gentle")):
+            g = FemIntegrator(v, gold["tets"], fixed, matrix_precision=prec)
+            f = np.zeros(g.r)
+            f[1::3] = load
+            for k in range(2):
+                g.set_external_forces(f)
+                it = g.do_timestep()
+                q, _, _ = g.get_q_state()
+                ref = gold["q_" + key][k]
+                assert abs(it - int(gold["it_" + key][k])) <= max(5, 0.03 * int(gold["it_" + key][k])), (key, k, it)
+                assert np.abs(q - ref).max() <= tol * np.abs(ref).max(), (prec, key, k, np.abs(q - ref).max() / np.abs(ref).max())
+            g.close()
+
+
 def test_ragged_inputs(gpu):
     """Edge cases: a node no element references (kept at rest), a single tet, no constraints at all (singular K but
     Keff = M + ... is SPD), arbitrary (not node-aligned) constrained DOFs."""

@@ -222,3 +222,23 @@ def test_shipped_disc_and_pyramid_meshes(name):
         q, _ = o.get_state()
         assert abs(it - int(g["iters"][k])) <= max(5, 0.1 * int(g["iters"][k])), (k, it, int(g["iters"][k]))
         assert np.abs(q - g["q"][k]).max() <= 5e-6 * np.abs(g["q"][k]).max()
+
+
+def test_peanut_veg_steps_against_reference_build():
+    """data/models/blobtree/peanut.veg -- a mesh FemBrain itself simulates (its polygonizer's surface, tetrahedralized by TetGen;
+    3,224 nodes / 12,947 tets) -- through the oracle against the reference build (tests/golden/fem_peanut.npz): two steps under the
+    reference load and two under a gentle one"""
+    g = np.load(os.path.join(GOLD, "fem_peanut.npz"))
+    v = g["verts"].astype(np.float64)
+    fixed = fixed_vertices_to_dofs(g["fixed_vertices"])
+    for load, key in ((-10000.0, "ref_load"), (-10.0, "gentle")):
+        o = OrcFem(v, g["tets"])
+        o.integrator(fixed)
+        fe = np.zeros(o.r)
+        fe[1::3] = load
+        for k in range(2):
+            o.set_external_forces(fe)
+            it = abs(o.step())
+            q, _ = o.get_state()
+            assert abs(it - int(g["it_" + key][k])) <= max(3, 0.02 * int(g["it_" + key][k]))
+            assert np.abs(q - g["q_" + key][k]).max() <= 5e-6 * np.abs(g["q_" + key][k]).max()
