@@ -40,8 +40,9 @@ struct fb_fem_s {
   // matrix
   DevBuf<int> slice_off, colidx, slot_coff, slot_ccnt, send_local;
   DevBuf<uint32_t> contrib;
-  DevBuf<short> coldelta;  // 16-bit column - row (device-built plans); c16 says whether the SpMV may use it
-  bool c16 = false;
+  DevBuf<short> coldelta;  // 16-bit column words (device-built plans); c16 says whether the SpMV may use them and in which form:
+  int c16 = 0;             // 0 no, 1 column - row (unsharded), 2 the halo form of a shard (plan_device.hip k_plan_sell)
+  DevBuf<int> halo_base;   // c16 == 2: lowest halo column of every slice
   PlanWorkspace plan_ws;  // the device plan builder's temporaries, kept for the next re-sync
   DevBuf<int> inc_off;               // element-major assembly (k_assemble_tets): incidence lists per slice, see fem_device.hip.h
   DevBuf<uint32_t> inc, inc_slot;
@@ -95,6 +96,7 @@ SellView sell_view(const fb_fem_s* h) {
   SellView sv;
   sv.slice_off = h->slice_off.p; sv.colidx = h->colidx.p; sv.n_slices = h->plan.n_slices; sv.n_owned = h->plan.n_owned;
   sv.coldelta = h->c16 ? h->coldelta.p : nullptr;
+  sv.halo_base = h->c16 == 2 ? h->halo_base.p : nullptr;
   return sv;
 }
 
@@ -416,11 +418,17 @@ int launch_spmv(fb_fem_s* h, const double* x, double* y, const double* b, double
     FB_HIP(hipGetLastError());
     return FB_OK;
   }
-  if (h->c16 && h->spmv_nt)
-    hipLaunchKernelGGL((k_spmv<MT, MODE, 0, true, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x,
+  if (h->c16 == 2 && h->spmv_nt)
+    hipLaunchKernelGGL((k_spmv<MT, MODE, 0, true, 2>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x,
+                       y, b, h->invdiag.p, partial, h->st.p, parity, P2PArgs());
+  else if (h->c16 == 2)
+    hipLaunchKernelGGL((k_spmv<MT, MODE, 0, false, 2>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x,
+                       y, b, h->invdiag.p, partial, h->st.p, parity, P2PArgs());
+  else if (h->c16 && h->spmv_nt)
+    hipLaunchKernelGGL((k_spmv<MT, MODE, 0, true, 1>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x,
                        y, b, h->invdiag.p, partial, h->st.p, parity, P2PArgs());
   else if (h->c16)
-    hipLaunchKernelGGL((k_spmv<MT, MODE, 0, false, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x,
+    hipLaunchKernelGGL((k_spmv<MT, MODE, 0, false, 1>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x,
                        y, b, h->invdiag.p, partial, h->st.p, parity, P2PArgs());
   else if (h->spmv_nt)
     hipLaunchKernelGGL((k_spmv<MT, MODE, 0, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
@@ -448,11 +456,17 @@ int launch_spmv_xch(fb_fem_s* h, const double* x, double* y, const double* b, do
     FB_HIP(hipGetLastError());
     return FB_OK;
   }
-  if (h->c16 && h->spmv_nt)
-    hipLaunchKernelGGL((k_spmv<MT, 3, XCH, true, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
+  if (h->c16 == 2 && h->spmv_nt)
+    hipLaunchKernelGGL((k_spmv<MT, 3, XCH, true, 2>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
+                       b, h->invdiag.p, partial, h->st.p, parity, pa);
+  else if (h->c16 == 2)
+    hipLaunchKernelGGL((k_spmv<MT, 3, XCH, false, 2>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
+                       b, h->invdiag.p, partial, h->st.p, parity, pa);
+  else if (h->c16 && h->spmv_nt)
+    hipLaunchKernelGGL((k_spmv<MT, 3, XCH, true, 1>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
                        b, h->invdiag.p, partial, h->st.p, parity, pa);
   else if (h->c16)
-    hipLaunchKernelGGL((k_spmv<MT, 3, XCH, false, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
+    hipLaunchKernelGGL((k_spmv<MT, 3, XCH, false, 1>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
                        b, h->invdiag.p, partial, h->st.p, parity, pa);
   else if (h->spmv_nt)
     hipLaunchKernelGGL((k_spmv<MT, 3, XCH, true>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, x, y,
@@ -907,7 +921,7 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   }
   FB_TRY(rc);
   P.n_blocks = D.n_blocks; P.n_slices = D.n_slices; P.n_slots = D.n_slots; P.n_crows = D.n_crows;
-  h->c16 = D.deltas_fit16 && !(getenv("FEMBRAIN_SPMV_C16") && atoi(getenv("FEMBRAIN_SPMV_C16")) == 0);
+  h->c16 = (D.deltas_fit16 && !(getenv("FEMBRAIN_SPMV_C16") && atoi(getenv("FEMBRAIN_SPMV_C16")) == 0)) ? 1 : 0;
   P.slice_off = D.slice_off_host;
   return FB_OK;
 }
@@ -987,12 +1001,12 @@ int build_shard_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* 
   sh.n_pairs = 4 * P.n_owned_corners + P.n_owned;
   DevicePlan D;
   D.slice_off = &h->slice_off; D.colidx = &h->colidx; D.slot_coff = &h->slot_coff; D.slot_ccnt = &h->slot_ccnt; D.contrib = &h->contrib;
-  D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot; D.coldelta = &h->coldelta;
+  D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot; D.coldelta = &h->coldelta; D.halo_base = &h->halo_base;
   const int rc = build_plan_device(h->stream, P.n_local, P.n_tets, h->tets.p, D, h->plan_ws, &sh);
   if (h->plan_ws.bytes() > ((size_t)2 << 30)) h->plan_ws.release();
   FB_TRY(rc);
   P.n_blocks = D.n_blocks; P.n_slices = D.n_slices; P.n_slots = D.n_slots; P.n_crows = D.n_crows;
-  h->c16 = D.deltas_fit16 && !(getenv("FEMBRAIN_SPMV_C16") && atoi(getenv("FEMBRAIN_SPMV_C16")) == 0);
+  h->c16 = (D.deltas_fit16 && !(getenv("FEMBRAIN_SPMV_C16") && atoi(getenv("FEMBRAIN_SPMV_C16")) == 0)) ? 2 : 0;  // the halo form
   P.slice_off = D.slice_off_host;
   return FB_OK;
 }
@@ -1036,7 +1050,7 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
     lap("device plan");
   }
   if (!h->device_plan) {
-    h->c16 = false;
+    h->c16 = 0;
     FB_TRY(build_fem_plan(h->plan, n_nodes, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits));
     lap("host plan");
   }

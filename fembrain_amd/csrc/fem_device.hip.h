@@ -931,7 +931,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_tets(SellView sv, const int
 // (crossover measured between 341 MB and 469 MB per iteration; FEMBRAIN_SPMV_NT=0/1 overrides).
 // C16: column ids are read as 16-bit differences to the row (2 instead of 4 bytes per block; unsharded handles whose
 // plan was built on the device, when every difference fits) -- same columns, same products, 4 % fewer bytes.
-template <typename MT, int MODE, int XCH = 0, bool NT = false, bool C16 = false>
+template <typename MT, int MODE, int XCH = 0, bool NT = false, int C16 = 0>
 __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo, const double* __restrict__ x,
                                                  double* __restrict__ y, const double* __restrict__ bvec,
                                                  const double* __restrict__ invdiag, double* __restrict__ partial,
@@ -956,10 +956,17 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SellView sv, const MT* __restri
     const MT* v = vals + (size_t)so * 9 * 64 + lane;
     const int* ci = sv.colidx + (size_t)so * 64 + lane;
     const short* cd = C16 ? sv.coldelta + (size_t)so * 64 + lane : nullptr;
+    const int hcol = C16 == 2 ? sv.n_owned + sv.halo_base[s] : 0;
     double y0 = 0, y1 = 0, y2 = 0;
 #pragma unroll 2  // measured at 1M tets: 27.4 us per iteration with 2, 27.7 with 1, 28.1 with 3, 28.25 with 4, 41 with 8 (registers)
     for (int k = 0; k < width; k++) {
-      const int col = C16 ? row + (int)cd[(size_t)k * 64] : ci[(size_t)k * 64];
+      int col;
+      if (C16 == 2) {  // sharded handle: bit 0 of the word says whether it counts from the row or from the slice's first halo column
+        const int wd = (int)cd[(size_t)k * 64];
+        col = (wd & 1) ? hcol + (wd >> 1) : row + (wd >> 1);
+      } else {
+        col = C16 ? row + (int)cd[(size_t)k * 64] : ci[(size_t)k * 64];
+      }
       const double* xp = ((XCH == 2 && col >= sv.n_owned) ? halo_in : x) + 3 * (size_t)col;
       const double x0 = xp[0], x1 = xp[1], x2 = xp[2];
       const MT* vk = v + (size_t)k * 9 * 64;

@@ -33,7 +33,9 @@ struct CGState {
 struct SellView {
   const int* slice_off;  // n_slices+1
   const int* colidx;     // n_slots*64
-  const short* coldelta; // n_slots*64: column - row where every such difference fits 16 bits (k_spmv<..., C16>), else null
+  const short* coldelta; // n_slots*64: 16-bit column words where they all fit (k_spmv<..., C16>), else null: column - row (C16 = 1) or,
+                         // on a sharded handle, the halo form (C16 = 2, plan_device.hip k_plan_sell)
+  const int* halo_base;  // n_slices: the slice's lowest halo column (C16 = 2)
   int n_slices;
   int n_owned;
 };

@@ -35,7 +35,8 @@ struct DevicePlan {
   // outputs, allocated by the builder (the caller owns the buffers)
   DevBuf<int>*slice_off = nullptr, *colidx = nullptr, *slot_coff = nullptr, *slot_ccnt = nullptr;
   DevBuf<uint32_t>* contrib = nullptr;
-  DevBuf<short>* coldelta = nullptr;  // column - row per slot and lane; usable by the SpMV when deltas_fit16
+  DevBuf<short>* coldelta = nullptr;  // 16-bit column word per slot and lane (plan_device.hip k_plan_sell); usable by the SpMV when deltas_fit16
+  DevBuf<int>* halo_base = nullptr;   // shards: the slice's lowest halo column (the halo form of the 16-bit words), else unused
   bool deltas_fit16 = false;
   DevBuf<int>*bptr = nullptr, *bcol = nullptr, *blk_slot = nullptr;  // CSR pattern and slot of every block (inspection entry points)
   int n_blocks = 0, n_slices = 0, n_slots = 0, n_crows = 0;

@@ -111,16 +111,38 @@ __global__ __launch_bounds__(kB) void k_plan_widths(int n_nodes, int n_slices, c
   if (lane == 0) width[s] = w;
 }
 
-// one wavefront per slice: column ids, the slot of every block, and the height of every slot's contribution list
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// one wavefront per slice: column ids, the slot of every block, and the height of every slot's contribution list.
+// 16-bit column words (coldelta), two forms:
+//   halo_base == nullptr (unsharded): column - row;
+//   else (a shard: columns >= n_nodes are halo nodes, numbered after the owned ones, far from any row): bit 0 = 0: (column - row) << 1;
+//   bit 0 = 1: (column - n_nodes - halo_base[slice]) << 1 | 1, halo_base[slice] = the slice's lowest halo column -- the halo
+//   columns of 64 consecutive rows lie close together.  `wide` is set when a value does not fit.
 __global__ __launch_bounds__(kB) void k_plan_sell(int n_nodes, int n_slices, const int* __restrict__ bptr, const int* __restrict__ bcol,
                                                   const unsigned int* __restrict__ ucnt, const int* __restrict__ slice_off, int* __restrict__ colidx,
                                                   int* __restrict__ blk_slot, int* __restrict__ slot_ccnt, short* __restrict__ coldelta,
-                                                  int* __restrict__ wide) {
+                                                  int* __restrict__ wide, int* __restrict__ halo_base) {
   const int s = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (s >= n_slices) return;
   const int a = s * 64 + lane;
   const int so = slice_off[s], w = slice_off[s + 1] - so;
   const int first = a < n_nodes ? bptr[a] : 0, len = a < n_nodes ? bptr[a + 1] - first : 0;
+  int hb = 0;
+  if (halo_base) {
+    int lo = 0x7fffffff;
+    for (int k = 0; k < len; k++) {
+      const int col = bcol[first + k];
+      if (col >= n_nodes) lo = min(lo, col - n_nodes);
+    }
+    lo = wave_min(lo);
+    hb = lo == 0x7fffffff ? 0 : lo;
+    if (lane == 0) halo_base[s] = hb;
+  }
   for (int k = 0; k < w; k++) {
     int c = 0, col;
     if (k < len) {
@@ -133,9 +155,20 @@ __global__ __launch_bounds__(kB) void k_plan_sell(int n_nodes, int n_slices, con
       colidx[((size_t)so + k) * 64 + lane] = col;  // padding: any valid column, its values stay zero
       if (a >= n_nodes) col = n_nodes - 1;       // (in the 16-bit form a lane past the last row points at the last row instead)
     }
-    const int delta = col - a;
-    if (delta < -32768 || delta > 32767) atomicOr(wide, 1);
-    coldelta[((size_t)so + k) * 64 + lane] = (short)delta;
+    int word;
+    if (!halo_base) {
+      word = col - a;
+      if (word < -32768 || word > 32767) atomicOr(wide, 1);
+    } else if (col >= n_nodes) {
+      const int off = col - n_nodes - hb;
+      if (off > 16383) atomicOr(wide, 1);
+      word = (off << 1) | 1;
+    } else {
+      const int d = col - a;
+      if (d < -16384 || d > 16383) atomicOr(wide, 1);
+      word = d * 2;
+    }
+    coldelta[((size_t)so + k) * 64 + lane] = (short)word;
     const int m = wave_max(c);
     if (lane == 0) slot_ccnt[so + k] = m;
   }
@@ -502,9 +535,10 @@ int build_plan_device(hipStream_t s, int n_nodes_local, int n_tets, const int4* 
   FB_TRY(D.slot_ccnt->zero(s));
   FB_TRY(D.slot_coff->alloc((size_t)D.n_slots + 1));
   FB_TRY(D.coldelta->alloc(std::max<size_t>(1, (size_t)D.n_slots * kSliceRows)));
+  if (shard && D.halo_base) FB_TRY(D.halo_base->alloc((size_t)std::max(1, n_slices)));
   struct { int* p; } wide = {W.flags.p + 1};
   hipLaunchKernelGGL(k_plan_sell, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, D.slice_off->p, D.colidx->p, D.blk_slot->p,
-                     D.slot_ccnt->p, D.coldelta->p, wide.p);
+                     D.slot_ccnt->p, D.coldelta->p, wide.p, (shard && D.halo_base) ? D.halo_base->p : nullptr);
   FB_HIP(hipGetLastError());
   int w = 0;
   FB_HIP(hipMemcpyAsync(&w, wide.p, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -148,6 +148,10 @@ def _bench_worker(rank, world, shm_name, n, q):
         its = g.do_timestep()
         qq = g.get_q_state()[0]
         lo, hi = 3 * int(splits[rank]), 3 * int(splits[rank + 1])
+        # 2-byte column words on a shard of 4M tets (the halo form: halo columns count from the slice's first halo column)
+        n_own = int(splits[rank + 1] - splits[rank])
+        index_bytes = (g.spmv_bytes() - (n_own + 1) * 4 - 24 * n_own - 96 * n_own) / g.num_blocks() - 36
+        assert index_bytes == 2.0, index_bytes
         q.put((rank, its, qq[lo:hi].copy(), None, lo, hi))
         g.close()
         L.fb_comm_destroy(comm)
