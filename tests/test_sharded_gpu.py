@@ -331,6 +331,12 @@ def _plan_worker(rank, world, shm_name, n, q):
             its.append(h.do_timestep())
         qf = fresh.get_q_state()[0]
         same = its[0] == its[1] == its[2] and np.array_equal(g.get_q_state()[0], qf) and np.array_equal(mine.get_q_state()[0], qf)
+        # a re-sync without node ranges to a mesh of another size falls to the equal split (fb_fem_resync's rule), and steps
+        g.resync(v2, t2, fixed2)
+        eq = [len(v2) * i // world for i in range(world + 1)]
+        same = same and (g.node_lo, g.node_hi) == (eq[rank], eq[rank + 1])
+        g.set_uniform_force(1, -100.0)
+        same = same and g.do_timestep() > 0 and bool(np.isfinite(g.get_q_state()[0]).all())
         q.put((rank, bad, same, resync_ms, its))
         g.close(); fresh.close(); mine.close()
         L.fb_comm_destroy(comm)
