@@ -9,8 +9,13 @@ A surface vertex lies on a grid edge: two of its coordinates are on the lattice 
 the linear root.  Nothing of ours is used to pick them: the lattice is inferred from the file alone (coordinate values
 that repeat), and the surface vertices are the leading run with >= 2 lattice coordinates.
 
+TetGen also keeps the input TRIANGLES where it did not refine the boundary: a face that belongs to exactly one tet of the file
+and whose three corners are all among those leading surface vertices is a triangle of the marching-cubes surface the reference
+handed to TetGen (about a third of them survive the quality refinement).  They are stored as sorted vertex-id triples
+(``kept_triangles``): a reference-held pin of the triangle connectivity, as a subset.
+
 Stored (data only): the leading surface vertices as printed (%g, 6 significant digits), the inferred cellsize and
-lattice phase per axis, and the file's vertex / element totals.  Run here once; the .npz files are committed, the
+lattice phase per axis, the surviving surface triangles, and the file's vertex / element totals.  Run here once; the .npz files are committed, the
 reference tree is not needed at test time."""
 import os
 import sys
@@ -30,7 +35,15 @@ def read_veg_vertices(path):
     v = np.array([[float(x) for x in ln.split()[1:4]] for ln in lines[i + 2:i + 2 + n]])
     j = next(k for k, ln in enumerate(lines) if ln.startswith("*ELEMENTS"))
     m = int(lines[j + 2].split()[0])
-    return v, m
+    t = np.array([[int(x) - 1 for x in ln.split()[1:5]] for ln in lines[j + 3:j + 3 + m]], np.int64)  # 1-indexed in the file
+    return v, m, t
+
+
+def boundary_faces(t):
+    """faces that belong to exactly one tet, as sorted vertex-id triples"""
+    f = np.sort(np.concatenate([t[:, [0, 1, 2]], t[:, [0, 1, 3]], t[:, [0, 2, 3]], t[:, [1, 2, 3]]]), axis=1)
+    u, c = np.unique(f, axis=0, return_counts=True)
+    return u[c == 1]
 
 
 def busy_gap(values):
@@ -63,7 +76,7 @@ def on_lattice(v, step, phase, tol):
 
 
 for name in MODELS:
-    v, n_tets = read_veg_vertices(REF + name + ".veg")
+    v, n_tets, tets = read_veg_vertices(REF + name + ".veg")
     gaps = [busy_gap(v[:, a]) for a in range(3)]
     gap = min(gaps)  # an axis with few busy grid lines may show a multiple of the cell size
     assert all(abs(g / gap - round(g / gap)) < 1e-3 for g in gaps), (name, gaps)
@@ -74,6 +87,9 @@ for name in MODELS:
     lead = int(np.argmax(hits < 2)) if (hits < 2).any() else len(v)
     surf = v[:lead]
     # which axis carries the root: the off-lattice one (vertices with all three on the lattice: the root fell on a grid point)
+    bnd = boundary_faces(tets)
+    kept = bnd[bnd.max(axis=1) < lead].astype(np.int32)
     np.savez_compressed(os.path.join(HERE, "surface_%s.npz" % name), vertices=surf, cellsize=np.float64(round(cellsize, 4)),
-                        lattice_phase=np.array(phases), n_file_vertices=np.int64(len(v)), n_file_tets=np.int64(n_tets))
-    print("%-12s cellsize %.4f (fit %.6f)  surface vertices %d of %d  tets %d" % (name, round(cellsize, 4), cellsize, lead, len(v), n_tets))
+                        lattice_phase=np.array(phases), n_file_vertices=np.int64(len(v)), n_file_tets=np.int64(n_tets), kept_triangles=kept)
+    print("%-12s cellsize %.4f (fit %.6f)  surface vertices %d of %d  tets %d  boundary faces %d, on surface vertices only %d"
+          % (name, round(cellsize, 4), cellsize, lead, len(v), n_tets, len(bnd), len(kept)))

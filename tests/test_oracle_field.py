@@ -244,6 +244,26 @@ def test_which_reference_path_wrote_the_shipped_files():
         assert not match[n, FIELD_CPU] and not match[n, FIELD_CPU_BOX]
 
 
+def test_surviving_triangles_of_the_shipped_tet_meshes_are_in_the_triangle_list():
+    """TetGen keeps an input triangle where it does not refine the boundary: every face of the reference's .veg tet mesh that belongs
+    to one tet only and has surface vertices only (tests/golden/surface_*.npz: kept_triangles, 29-33 % of the surface) must be a
+    triangle of the marching-cubes list -- the part of the triangle connectivity the reference's own files pin."""
+    from oracle.pyfield import FIELD_OPENCL, field_mode
+    for name in SURFACE_FIXTURES:
+        g = np.load(os.path.join(GOLD, "surface_%s.npz" % name))
+        blob = read_blob(os.path.join(GOLD, "blob", name + ".blob"))
+        with field_mode(FIELD_OPENCL, blob):
+            o = OrcPoly(blob)
+            o.sweep(float(g["cellsize"]))
+            o.classify()
+            _, _, tri = o.surface()
+        tri = np.sort(tri.reshape(-1, 3).astype(np.int64), axis=1)
+        have = set(map(tuple, tri.tolist()))
+        kept = g["kept_triangles"]
+        assert len(kept) > 0.25 * len(tri)
+        assert all(tuple(k) in have for k in kept.tolist()), name
+
+
 def test_opencl_mode_semantics():
     from oracle.pyfield import FIELD_OPENCL, cl_has_route, field_mode
     pts = [(0, (0.0, 0, 0), (0, 0, 0), (0, 0, 0)), (0, (0.6, 0, 0), (0, 0, 0), (0, 0, 0)), (0, (0, 0.6, 0), (0, 0, 0), (0, 0, 0))]

@@ -672,6 +672,11 @@ def test_shipped_reference_surfaces_through_the_c_abi(gpu, name, n_vertices):
         opos, onrm, otri = o.surface()
     assert np.array_equal(tri, otri) and np.array_equal(pos, opos) and np.abs(nrm - onrm).max() <= 1e-6
     surface_mesh_checks(pos, nrm, tri, smooth=False)
+    # triangle connectivity: the faces of the reference's tet mesh that TetGen left as they were handed to it (boundary faces on
+    # surface vertices only, make_surface_golden.py) are all in the triangle list -- a third of it, pinned by the reference's file
+    have = set(map(tuple, np.sort(tri.reshape(-1, 3).astype(np.int64), axis=1).tolist()))
+    kept = gold["kept_triangles"]
+    assert len(kept) > 0.25 * len(tri.reshape(-1, 3)) and all(tuple(k) in have for k in kept.tolist())
     g.close()
 
 
