@@ -348,7 +348,7 @@ def _plan_worker(rank, world, shm_name, n, q):
         os._exit(1)
 
 
-@pytest.mark.parametrize("world,n", [(2, 12), (3, 14), (3, -900)])
+@pytest.mark.parametrize("world,n", [(2, 12), (3, 14), (3, -900), (5, 10), (4, -1300)])
 def test_sharded_device_plan_equals_host_plan_and_resyncs(gpu, world, n):
     """every rank's rows of the plan built by plan_device.hip (sort by local row and GLOBAL column) are bit for bit the host
     builder's (fem_plan.cpp) -- cubes cut into slabs and a Delaunay mesh in random node order where every rank neighbours every
