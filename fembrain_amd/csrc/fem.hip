@@ -11,6 +11,7 @@
 #include "fem_device.hip.h"
 #include "fem_plan.h"
 #include "pcg_persist.hip.h"
+#include "pcg_pipe.hip.h"
 #include "plan_device.h"
 
 using namespace fb;
@@ -60,7 +61,6 @@ struct fb_fem_s {
   // vectors (3*n_local each)
   DevBuf<double> q, qvel, fext, fint, rhs, x, r, d, Ad, invdiag, tmp, sendbuf;
   DevBuf<double> part_a, part_b, part_c, scal;
-  DevBuf<double> rec_s[2];  // FB_PCG_FUSED: 12 doubles per local node, double buffered
   DevBuf<CGState> st;
   DevBuf<int> counter;
   CGState* st_host = nullptr;  // pinned, 2 slots
@@ -86,6 +86,18 @@ struct fb_fem_s {
   DevBuf<unsigned int> persist_flags;  // [blocks padded to 4] flags, then the error word
   DevBuf<long long> persist_timing;    // FEMBRAIN_PERSIST_TIMING=1 (development aid)
   DevBuf<double> persist_dsoa;         // the search direction in three planes (k_persist_planes)
+  // pipelined persistent solve (pcg_pipe.hip.h): the whole solve in one launch
+  int persist_kind = 0;                // 1 = merged-reduction launches of 29 iterations (k_pcg_persist), 2 = pipelined whole solve (k_pcg_pipe)
+  DevBuf<unsigned long long> pipe_post;
+  DevBuf<unsigned int> pipe_flags;     // [blocks padded to 4] flags, [+4] the error word, [+8..9] the two sequence numbers
+  DevBuf<int> pipe_prod, pipe_prod_count;
+  DevBuf<double> pipe_planes, pipe_z, pipe_s, pipe_state;
+  int pipe_klt = 0, pipe_wmax = 0;
+  int pipe_max_producers = 0;          // longest producer list (-1: some workgroup polls all)
+  long long persist_timeout_ticks = 0; // wall_clock64 ticks (100 MHz) a wait inside a persistent launch may last
+  int persist_fallbacks = 0;           // solves that had to be repeated with the two-launch form
+  int persist_launches = 0;            // persistent launches made by this handle
+  int last_pcg_path = 0;               // FB_PCG_PATH_* of the last solve
 };
 
 namespace {
@@ -122,6 +134,110 @@ int upload_masks(fb_fem_s* h) {
   std::vector<uint8_t> nm((size_t)P.n_local);
   for (int l = 0; l < P.n_local; l++) nm[l] = (uint8_t)((P.dofmask[3 * (size_t)l] ? 1 : 0) | (P.dofmask[3 * (size_t)l + 1] ? 2 : 0) | (P.dofmask[3 * (size_t)l + 2] ? 4 : 0));
   return h->nodemask.upload(nm, h->stream);
+}
+
+// Decides whether this handle solves inside persistent launches and allocates what they need (called for every (re)built plan).
+int setup_persist(fb_fem_s* h) {
+  const FemPlan& P = h->plan;
+  hipStream_t s = h->stream;
+  h->persist = false;
+  h->persist_kind = 0;
+  hipDeviceProp_t prop;
+  FB_HIP(hipGetDeviceProperties(&prop, h->prm.device));
+  const int nb = std::min(kPipeMaxBlocks, (prop.multiProcessorCount / 8) * 8);
+  const char* e = getenv("FEMBRAIN_PCG_PERSIST");
+  const int w = nb >= 8 ? ceil_div(ceil_div(P.n_slices, 8), nb / 8) : 0;
+  {
+    const char* t = getenv("FEMBRAIN_PERSIST_TIMEOUT_MS");  // how long a wait inside a persistent launch may last before the launch gives up
+    const double ms = t ? atof(t) : 50.0;                   // default 50 ms: a whole 1M-tet solve is ~25 ms, one wait is microseconds
+    h->persist_timeout_ticks = (long long)(std::max(ms, 0.001) * 1e5);  // 100 MHz
+  }
+  const bool explicit_p = h->prm.pcg_variant == FB_PCG_PERSISTENT;
+  if (explicit_p && P.n_ranks > 1) return fail(FB_EINVAL, "FB_PCG_PERSISTENT is for unsharded handles");
+  if (explicit_p && h->f64) return fail(FB_EINVAL, "FB_PCG_PERSISTENT needs FB_MATRIX_F32 storage (part of the matrix is kept in LDS as fp32 words)");
+  if (explicit_p && (nb < 8 || w < 1 || w > kPipeMaxWaves))
+    return fail(FB_EINVAL, "FB_PCG_PERSISTENT needs at most %d slices per CU, this mesh has %d on %d CUs", kPipeMaxWaves, w, nb);
+  // asked for explicitly (parameter or FEMBRAIN_PCG_PERSIST=1), or by default where it was measured faster than the
+  // two-launch iteration: fp32 storage, up to 12 slices per CU
+  const bool eligible = !h->f64 && P.n_ranks == 1 && nb >= 8 && w >= 1 && w <= kPipeMaxWaves;
+  static const int min_w = getenv("FEMBRAIN_PERSIST_MIN_WAVES") ? atoi(getenv("FEMBRAIN_PERSIST_MIN_WAVES")) : 4;
+  const bool by_default = h->prm.pcg_variant == FB_PCG_MERGED && w >= min_w;
+  const bool want_p = e ? atoi(e) != 0 && (h->prm.pcg_variant == FB_PCG_MERGED || explicit_p) : (explicit_p || by_default);
+  if (!want_p || !eligible) return FB_OK;
+  const char* kind = getenv("FEMBRAIN_PERSIST_KIND");  // development aid: "merged" = the round-2 kernel
+  h->persist_kind = kind && !strcmp(kind, "merged") ? 1 : 2;
+  h->persist = true; h->persist_blocks = nb; h->persist_waves = w;
+  if (h->persist_kind == 1) {
+    FB_TRY(h->persist_post.alloc((size_t)2 * nb * 8));
+    FB_TRY(h->persist_post.zero(s));
+    FB_TRY(h->persist_flags.alloc((size_t)nb + 8));
+    FB_TRY(h->persist_flags.zero(s));
+    h->persist_seq = 0;
+    FB_TRY(h->persist_dsoa.alloc((size_t)3 * P.n_slices * 64));
+    if (getenv("FEMBRAIN_PERSIST_TIMING")) {
+      FB_TRY(h->persist_timing.alloc((size_t)nb * kPersistMaxWaves * 5));
+      FB_TRY(h->persist_timing.zero(s));
+    }
+    return FB_OK;
+  }
+  // pipelined whole-solve kernel
+  h->pipe_wmax = w <= 8 ? 8 : 12;
+  h->pipe_klt = w <= 8 ? 7 : 5;   // slots of every slice resident in LDS: (160 KB - sync) / (wavefronts * 2560 B)
+  FB_TRY(h->pipe_post.alloc((size_t)2 * nb * 4));
+  FB_TRY(h->pipe_post.zero(s));
+  FB_TRY(h->pipe_flags.alloc((size_t)nb + 16));
+  FB_TRY(h->pipe_flags.zero(s));
+  const size_t n_pad = (size_t)P.n_slices * 64, nv = (size_t)3 * P.n_local + 2;
+  FB_TRY(h->pipe_planes.alloc(2 * 3 * n_pad));
+  FB_TRY(h->pipe_planes.zero(s));
+  FB_TRY(h->pipe_z.alloc(nv));
+  FB_TRY(h->pipe_s.alloc(nv));
+  FB_TRY(h->pipe_state.alloc(2));
+  FB_TRY(h->pipe_state.zero(s));
+  if (getenv("FEMBRAIN_PERSIST_TIMING")) {
+    FB_TRY(h->persist_timing.alloc((size_t)nb * kPipeMaxWaves * 6));
+    FB_TRY(h->persist_timing.zero(s));
+  } else {
+    h->persist_timing.release();
+  }
+  // producer lists: the workgroups that own the rows this workgroup's columns lie in (a range per slice, so a superset)
+  DevBuf<int2> range;
+  FB_TRY(range.alloc((size_t)std::max(1, P.n_slices)));
+  hipLaunchKernelGGL(k_slice_colrange, dim3(ceil_div(std::max(1, P.n_slices), kWavesPerBlock)), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->slice_off.p, h->colidx.p,
+                     range.p);
+  FB_HIP(hipGetLastError());
+  std::vector<int2> rg((size_t)std::max(1, P.n_slices));
+  FB_TRY(range.download(rg.data(), rg.size(), s));
+  std::vector<int> owner((size_t)P.n_slices, 0), prod((size_t)nb * kPipeMaxProducers, -1), cnt((size_t)nb, 0);
+  for (int b = 0; b < nb; b++) {
+    int first, count;
+    pipe_slices(P.n_slices, nb, b, &first, &count);
+    for (int k = 0; k < count; k++) owner[first + k] = b;
+  }
+  const bool poll_all = getenv("FEMBRAIN_PERSIST_POLL_ALL") && atoi(getenv("FEMBRAIN_PERSIST_POLL_ALL")) != 0;  // development aid
+  std::vector<char> mark((size_t)nb);
+  h->pipe_max_producers = 0;
+  for (int b = 0; b < nb; b++) {
+    int first, count;
+    pipe_slices(P.n_slices, nb, b, &first, &count);
+    std::fill(mark.begin(), mark.end(), 0);
+    int n = 0;
+    for (int k = 0; k < count; k++) {
+      const int2 r = rg[first + k];
+      if (r.y < r.x) continue;
+      for (int sl = r.x >> 6; sl <= (r.y >> 6) && sl < P.n_slices; sl++) {
+        const int o = owner[sl];
+        if (o != b && !mark[o]) { mark[o] = 1; n++; }
+      }
+    }
+    if (n > kPipeMaxProducers || poll_all) { cnt[b] = -1; h->pipe_max_producers = -1; continue; }
+    cnt[b] = n;
+    if (h->pipe_max_producers >= 0) h->pipe_max_producers = std::max(h->pipe_max_producers, n);
+    for (int o = 0, k = 0; o < nb; o++) if (mark[o]) prod[(size_t)b * kPipeMaxProducers + k++] = o;
+  }
+  FB_TRY(h->pipe_prod.upload(prod, s));
+  FB_TRY(h->pipe_prod_count.upload(cnt, s));
+  return FB_OK;
 }
 
 int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device = nullptr) {
@@ -241,49 +357,12 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   // small meshes: one 16-byte pair per thread in the merged vector pass (8.9 vs 9.3 us per iteration at 105k tets; on the 1M-tet
   // mesh the extra blocks cost more in the partial-sum prologue than they save: 29.9 vs 29.1)
   h->vgrid = h->split == 4 ? 8 * std::max(1, ceil_div(chunk * 96, kBlock)) : h->grid;
-  // Persistent iterations: unsharded handles whose slices fit one wavefront each on the CUs of the device.  Opt-in by
+  // Persistent solver: unsharded handles whose slices fit one wavefront each on the CUs of the device.  Opt-in by
   // fb_fem_params.pcg_variant = FB_PCG_PERSISTENT or FEMBRAIN_PCG_PERSIST=1 (=0 forces it off)
-  {
-    h->persist = false;
-    hipDeviceProp_t prop;
-    FB_HIP(hipGetDeviceProperties(&prop, h->prm.device));
-    const int nb = std::min(kPersistMaxBlocks, (prop.multiProcessorCount / 8) * 8);
-    const char* e = getenv("FEMBRAIN_PCG_PERSIST");
-    const int w = nb >= 8 ? ceil_div(ceil_div(P.n_slices, 8), nb / 8) : 0;
-    // asked for explicitly (parameter or FEMBRAIN_PCG_PERSIST=1), or by default where it was measured faster than the
-    // two-launch iteration: fp32 storage, 4..12 slices per CU (us per iteration, merged vs persistent, on MI355X: 15.9 / 15.4 at
-    // 1,000 slices, 20.5 / 17.6 at 1,728, 25.1 / 20.7 at 2,197, 27.4 / 22.8 at 2,744 = 1M tets; 12.1 / 14.9 at 729 and
-    // 34.2 / 41.4 at 3,375, where 16 wavefronts per CU leave 128 registers per lane and 3 LDS slots)
-    const bool by_default = h->prm.pcg_variant == FB_PCG_MERGED && !h->f64 && w >= 4 && w <= 12;
-    const bool want_p = e ? atoi(e) != 0 && h->prm.pcg_variant != FB_PCG_REFERENCE && h->prm.pcg_variant != FB_PCG_FUSED && h->prm.pcg_variant != FB_PCG_BLOCK_JACOBI
-                          : (h->prm.pcg_variant == FB_PCG_PERSISTENT || by_default);
-    if (want_p && nb >= 8 && P.n_ranks == 1) {
-      if (w >= 1 && w <= kPersistMaxWaves) {
-        h->persist = true; h->persist_blocks = nb; h->persist_waves = w;
-        FB_TRY(h->persist_post.alloc((size_t)2 * nb * 8));
-        FB_TRY(h->persist_post.zero(s));
-        FB_TRY(h->persist_flags.alloc((size_t)nb + 8));
-        FB_TRY(h->persist_flags.zero(s));
-        h->persist_seq = 0;
-        FB_TRY(h->persist_dsoa.alloc((size_t)3 * P.n_slices * 64));
-        if (getenv("FEMBRAIN_PERSIST_TIMING")) {
-          FB_TRY(h->persist_timing.alloc((size_t)nb * kPersistMaxWaves * 5));
-          FB_TRY(h->persist_timing.zero(s));
-        }
-      } else if (h->prm.pcg_variant == FB_PCG_PERSISTENT) {
-        return fail(FB_EINVAL, "FB_PCG_PERSISTENT needs at most %d slices per CU, this mesh has %d on %d CUs", kPersistMaxWaves, w, nb);
-      }
-    } else if (h->prm.pcg_variant == FB_PCG_PERSISTENT && P.n_ranks > 1) {
-      return fail(FB_EINVAL, "FB_PCG_PERSISTENT is for unsharded handles");
-    }
-  }
+  FB_TRY(setup_persist(h));
   FB_TRY(h->part_a.alloc(3 * kMaxPartials));
   FB_TRY(h->part_b.alloc(kMaxPartials));
   FB_TRY(h->part_c.alloc(3 * kMaxPartials));
-  for (auto& r : h->rec_s) {
-    FB_TRY(r.alloc((size_t)12 * P.n_local + 2));
-    FB_TRY(r.zero(s));
-  }
   FB_TRY(h->scal.alloc(8));
   FB_TRY(h->st.alloc(1));
   FB_TRY(h->st.zero(s));
@@ -618,15 +697,13 @@ bool host_finished(const CGState& s) {
 }
 
 // Jacobi-PCG on the assembled system, rhs b -> h->x.  iters_out: + converged / - not (CGSolver.cpp:189).
-int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state);
 
 // `n` merged iterations starting at (1-based) iteration `it`, none of them an exact-residual one, in one persistent launch
 int launch_persist(fb_fem_s* h, int it, int n) {
   PersistArgs pa;
   pa.post = h->persist_post.p; pa.flags = h->persist_flags.p; pa.error = h->persist_flags.p + h->persist_blocks + 4;
   pa.seq_base = h->persist_seq; pa.first_iter = it; pa.n_iters = n;
-  static const long long ticks = (long long)((getenv("FEMBRAIN_PERSIST_TIMEOUT_MS") ? atof(getenv("FEMBRAIN_PERSIST_TIMEOUT_MS")) : 2000.0) * 1e5);  // 100 MHz
-  pa.timeout_ticks = ticks;
+  pa.timeout_ticks = h->persist_timeout_ticks;
   pa.timing = h->persist_timing.p;
   pa.dsoa = h->persist_dsoa.p; pa.n_pad = (size_t)h->plan.n_slices * 64;
   h->persist_seq += (unsigned int)n;
@@ -684,8 +761,120 @@ int pcg_run_persist(fb_fem_s* h, int it, int n, const double* b) {
   return FB_OK;
 }
 
+// One launch of the pipelined persistent solver (pcg_pipe.hip.h): `start` 1 = new solve from x = 0, 2 = new solve from the x in
+// memory, 0 = continue; at most n_iters iterations
+int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps, int max_iter) {
+  PipeArgs pa;
+  pa.post = h->pipe_post.p; pa.flags = h->pipe_flags.p; pa.error = h->pipe_flags.p + h->persist_blocks + 4; pa.seqs = h->pipe_flags.p + h->persist_blocks + 8;
+  pa.producers = h->pipe_prod.p; pa.prod_count = h->pipe_prod_count.p;
+  pa.start = start; pa.n_iters = n_iters; pa.eps2 = eps * eps; pa.max_iter = max_iter;
+  pa.timeout_ticks = h->persist_timeout_ticks;
+  pa.timing = h->persist_timing.p;
+  pa.planes = h->pipe_planes.p; pa.n_pad = (size_t)h->plan.n_slices * 64;
+  pa.pstate = h->pipe_state.p;
+  // LDS: the sync buffers, then KLT slots of every slice; the request is the whole 160 KB of a CU, so exactly one workgroup lands on each
+  const size_t lds = 160 * 1024;
+  const dim3 grid(h->persist_blocks), block(64 * h->persist_waves);
+#define FB_PIPE(C16, WMAX, KLT, TIMING)                                                                                                        \
+  do {                                                                                                                                         \
+    static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)WMAX * KLT * 10 * 64 * 4 <= 160 * 1024, "LDS budget of k_pcg_pipe");             \
+    static bool attr = false;                                                                                                                  \
+    if (!attr) {                                                                                                                               \
+      FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe<float, C16, WMAX, KLT, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      attr = true;                                                                                                                             \
+    }                                                                                                                                          \
+    hipLaunchKernelGGL((k_pcg_pipe<float, C16, WMAX, KLT, TIMING>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p,       \
+                       (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);       \
+  } while (0)
+  // the instantiations: (wavefronts, LDS slots) = (8, 7) up to 8 slices per CU, (12, 5) up to 12; 16- or 32-bit column words
+  if (getenv("FEMBRAIN_PIPE_NOASM")) {  // debugging aid
+    hipFuncSetAttribute((const void*)k_pcg_pipe<float, true, 8, 7, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_pcg_pipe<float, true, 8, 7, false, true>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p,
+                       (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);
+  } else
+  if (pa.timing) {  // development build with the phase clocks: the 1M-tet configuration only
+    if (h->pipe_wmax == 12 && h->c16) FB_PIPE(true, 12, 5, true);
+    else return fail(FB_EINVAL, "FEMBRAIN_PERSIST_TIMING is built for 9..12 slices per CU with 16-bit column words");
+  } else if (h->pipe_wmax == 8) { if (h->c16) FB_PIPE(true, 8, 7, false); else FB_PIPE(false, 8, 7, false); }
+  else { if (h->c16) FB_PIPE(true, 12, 5, false); else FB_PIPE(false, 12, 5, false); }
+#undef FB_PIPE
+  FB_HIP(hipGetLastError());
+  h->persist_launches++;
+  return FB_OK;
+}
+
+void print_pipe_timing(fb_fem_s* h) {
+  std::vector<long long> tm((size_t)h->persist_blocks * kPipeMaxWaves * 6);
+  if (h->persist_timing.download(tm.data(), tm.size(), h->stream) != FB_OK) return;
+  (void)h->persist_timing.zero(h->stream);
+  const char* names[5] = {"publish (drained)", "flag+wait+acquire", "product", "sums sweep", "recurrences(+refresh)"};
+  for (int k = 0; k < 5; k++) {
+    double mn = 1e30, mx = 0, av = 0;
+    int cnt = 0;
+    for (int b = 0; b < h->persist_blocks; b++)
+      for (int w = 0; w < h->persist_waves; w++) {
+        const long long* t = &tm[((size_t)b * kPipeMaxWaves + w) * 6];
+        if (t[5] <= 0) continue;
+        const double us = (double)t[k] / (double)t[5] * 0.01;
+        mn = std::min(mn, us); mx = std::max(mx, us); av += us; cnt++;
+      }
+    fprintf(stderr, "[fembrain] pipelined PCG %-22s per iteration: avg %.2f us  min %.2f  max %.2f (over %d waves)\n", names[k], av / std::max(cnt, 1), mn, mx, cnt);
+  }
+}
+
+int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state);
+
+// Jacobi-PCG inside persistent launches (normally ONE): CGSolver.cpp:129-190 in its pipelined form
+int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state) {
+  hipStream_t s = h->stream;
+  const bool warm = h->pcg_warm;
+  h->pcg_warm = false;
+  int cut = max_iter + 1;  // iterations per launch: all of them (the kernel stops at convergence or max_iter)
+  if (const char* e = getenv("FEMBRAIN_PERSIST_MAX_RUN")) cut = std::max(1, atoi(e));  // test knob: cut the solve into shorter launches
+  int start = warm ? 2 : 1;
+  CGState fin;
+  memset(&fin, 0, sizeof fin);
+  for (;;) {
+    FB_TRY(launch_pipe(h, b, start, cut, eps, max_iter));
+    unsigned int err = 0;
+    FB_HIP(hipMemcpyAsync(&h->st_host[0], h->st.p, sizeof(CGState), hipMemcpyDeviceToHost, s));
+    FB_HIP(hipMemcpyAsync(&err, h->pipe_flags.p + h->persist_blocks + 4, sizeof err, hipMemcpyDeviceToHost, s));
+    FB_HIP(hipStreamSynchronize(s));
+    if (err) {
+      // A wait inside the launch gave up: the workgroups were not all resident (the device is shared with another process's
+      // kernels?).  The launch wrote nothing back, so the solve is repeated from the same start with a launch per phase, and
+      // this handle stays with that; fb_step_info.pcg_path / persist_fallbacks tell the host.
+      FB_TRY(h->pipe_flags.zero(s));
+      FB_TRY(h->pipe_post.zero(s));
+      h->persist = false;
+      h->persist_fallbacks++;
+      if (getenv("FEMBRAIN_PERSIST_STRICT") && atoi(getenv("FEMBRAIN_PERSIST_STRICT")) != 0)
+        return fail(FB_EDEVICE, "persistent PCG: a wait inside the launch timed out after %.1f ms (the workgroups were not all resident?)", h->persist_timeout_ticks * 1e-5);
+      fprintf(stderr, "[fembrain] persistent PCG: a wait timed out after %.1f ms; this handle falls back to the two-launch iteration\n", h->persist_timeout_ticks * 1e-5);
+      h->pcg_warm = warm;
+      const int rc = pcg_solve(h, b, eps, max_iter, iters_out, final_state);
+      h->last_pcg_path = FB_PCG_PATH_FALLBACK;
+      return rc;
+    }
+    fin = h->st_host[0];
+    if (fin.done) break;
+    if (fin.iter > max_iter) return fail(FB_EDEVICE, "internal: persistent PCG ran past max_iter (iter %d)", fin.iter);
+    start = 0;
+  }
+  if (h->persist_timing.p) print_pipe_timing(h);
+  h->last_pcg_path = FB_PCG_PATH_PERSISTENT;
+  const double rho = fin.rho[fin.iter & 1];
+  const bool converged = !(rho > fin.eps2 * fin.rho0);
+  if (iters_out) *iters_out = converged ? fin.iter : -fin.iter;
+  if (final_state) *final_state = fin;
+  return FB_OK;
+}
+
 int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state) {
-  if (h->prm.pcg_variant == FB_PCG_FUSED) return pcg_solve_fused(h, b, eps, max_iter, iters_out, final_state);
+  if (h->persist && h->persist_kind == 2 && (h->prm.pcg_variant == FB_PCG_MERGED || h->prm.pcg_variant == FB_PCG_PERSISTENT))
+    return pcg_solve_pipe(h, b, eps, max_iter, iters_out, final_state);
+  h->last_pcg_path = h->persist ? FB_PCG_PATH_PERSISTENT : FB_PCG_PATH_TWO_LAUNCH;
+  const bool was_warm = h->pcg_warm;
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
   double* sc = nullptr;
@@ -781,9 +970,13 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
       // and this handle stays with that.
       FB_TRY(h->persist_flags.zero(s));
       h->persist = false;
-      if (h->prm.pcg_variant == FB_PCG_PERSISTENT && getenv("FEMBRAIN_PERSIST_STRICT"))
+      h->persist_fallbacks++;
+      if (getenv("FEMBRAIN_PERSIST_STRICT") && atoi(getenv("FEMBRAIN_PERSIST_STRICT")) != 0)
         return fail(FB_EDEVICE, "persistent PCG: a grid-wide wait timed out (the workgroups were not all resident?)");
-      return pcg_solve(h, b, eps, max_iter, iters_out, final_state);
+      h->pcg_warm = was_warm;
+      const int rc = pcg_solve(h, b, eps, max_iter, iters_out, final_state);
+      h->last_pcg_path = FB_PCG_PATH_FALLBACK;
+      return rc;
     }
   }
   // the newest snapshot is in the slot written last
@@ -793,92 +986,6 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
   const bool converged = !(rho > fin.eps2 * fin.rho0);
   if (iters_out) *iters_out = converged ? fin.iter : -fin.iter;
   if (final_state) *final_state = fin;
-  return FB_OK;
-}
-
-template <typename MT, bool FIRST>
-int launch_mega(fb_fem_s* h, int cur, const double* sc, int k) {
-  // partial sums ping-pong with the records: a block may publish its new sums while another still reads the old ones
-  double* pin = cur ? h->part_c.p : h->part_a.p;
-  double* pout = cur ? h->part_a.p : h->part_c.p;
-  hipLaunchKernelGGL((k_cg_mega<MT, FIRST>), dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, h->rec_s[cur].p,
-                     h->rec_s[cur ^ 1].p, h->x.p, pin, h->grid, sc, pout, h->st.p, k);
-  FB_HIP(hipGetLastError());
-  return FB_OK;
-}
-
-template <bool FIRST>
-int mega(fb_fem_s* h, int cur, const double* sc, int k) {
-  return h->f64 ? launch_mega<double, FIRST>(h, cur, sc, k) : launch_mega<float, FIRST>(h, cur, sc, k);
-}
-
-// FB_PCG_FUSED: one launch per iteration (see k_cg_mega).  Launch j computes q_j; the launch after it completes
-// iteration j, so n iterations take n+1 launches; every 30th iteration is completed by the exact-residual sequence.
-int pcg_solve_fused(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state) {
-  const FemPlan& P = h->plan;
-  hipStream_t s = h->stream;
-  int cur = 0;
-  hipLaunchKernelGGL(k_rec_init, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, b, h->invdiag.p, h->x.p, h->rec_s[0].p, h->part_b.p);
-  FB_HIP(hipGetLastError());
-  double* sc = nullptr;
-  FB_TRY(global_scalar(h, h->part_b.p, &sc, false));
-  hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, s, h->st.p, h->part_b.p, h->grid, sc, eps, max_iter);
-  FB_HIP(hipGetLastError());
-  // launch 0: q_1 = A d_1
-  FB_TRY(halo_exchange(h, h->rec_s[cur].p, 12));
-  FB_TRY(mega<true>(h, cur, nullptr, 0));
-  cur ^= 1;
-  auto pending_sums = [&]() { return cur ? h->part_c.p : h->part_a.p; };  // what the launch that produced rec_s[cur] wrote
-  FB_TRY(global_scalar(h, pending_sums(), &sc, true, 3));
-  const int kBatch = 30;
-  int k = 1, slot = 0;
-  bool pending[2] = {false, false}, finished = false;
-  while (!finished) {
-    for (int n = 0; n < kBatch && k <= max_iter; n++, k++) {  // k = iteration being completed
-      if (k % 30 == 0) {
-        hipLaunchKernelGGL(k_rec_apply_x, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->rec_s[cur].p, h->x.p, pending_sums(), h->grid,
-                           sc, h->st.p, k);
-        FB_HIP(hipGetLastError());
-        FB_TRY(halo_exchange(h, h->x.p));
-        FB_TRY(spmv<2>(h, h->x.p, h->r.p, b, h->part_b.p, 0));
-        double* sc2 = nullptr;
-        FB_TRY(global_scalar(h, h->part_b.p, &sc2, true, 1, 3, h->sgrid));
-        hipLaunchKernelGGL(k_rec_refresh, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->rec_s[cur].p, h->rec_s[cur ^ 1].p, h->r.p,
-                           h->part_b.p, h->sgrid, sc2, h->st.p, k);
-        FB_HIP(hipGetLastError());
-        cur ^= 1;
-        FB_TRY(halo_exchange(h, h->rec_s[cur].p, 12));
-        FB_TRY(mega<true>(h, cur, nullptr, k));
-      } else {
-        FB_TRY(halo_exchange(h, h->rec_s[cur].p, 12));
-        FB_TRY(mega<false>(h, cur, sc, k));
-      }
-      cur ^= 1;
-      FB_TRY(global_scalar(h, pending_sums(), &sc, true, 3));
-    }
-    FB_HIP(hipMemcpyAsync(&h->st_host[slot], h->st.p, sizeof(CGState), hipMemcpyDeviceToHost, s));
-    FB_HIP(hipEventRecord(h->ev_batch[slot], s));
-    pending[slot] = true;
-    const int prev = slot ^ 1;
-    if (pending[prev]) {
-      FB_HIP(hipEventSynchronize(h->ev_batch[prev]));
-      pending[prev] = false;
-      if (h->st_host[prev].done) finished = true;
-    }
-    if (k > max_iter) finished = true;
-    slot ^= 1;
-  }
-  FB_HIP(hipStreamSynchronize(s));
-  if (h->p2p) FB_TRY(p2p_check(h->p2p, s));
-  const CGState fin = h->st_host[slot ^ 1];
-  if (!fin.done) return fail(FB_EDEVICE, "internal: fused PCG ended without a terminal state (iter %d)", fin.iter);
-  const double rho = fin.rho[(fin.iter + 1) & 1];
-  const bool converged = !(rho > fin.eps2 * fin.rho0);
-  if (iters_out) *iters_out = converged ? fin.iter : -fin.iter;
-  if (final_state) {
-    *final_state = fin;
-    final_state->rho[fin.iter & 1] = rho;  // callers read rho[iter & 1] (the literal solver's convention)
-  }
   return FB_OK;
 }
 
@@ -1123,6 +1230,9 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
   if (params->integrator != FB_INTEGRATOR_VOLUME_CONSERVING && params->integrator != FB_INTEGRATOR_NEWMARK) return fail(FB_EINVAL, "unknown integrator %d", params->integrator);
   if (!(params->timestep > 0) || !(params->E > 0) || !(params->rho > 0) || !(params->nu > -1.0 && params->nu < 0.5))
     return fail(FB_EINVAL, "bad material / timestep parameters");
+  if (params->pcg_variant != FB_PCG_MERGED && params->pcg_variant != FB_PCG_REFERENCE && params->pcg_variant != FB_PCG_PERSISTENT &&
+      params->pcg_variant != FB_PCG_BLOCK_JACOBI)
+    return fail(FB_EINVAL, "unknown pcg_variant %d", params->pcg_variant);
   if (n_ranks > 1 && !comm) return fail(FB_EINVAL, "sharded handle needs a communicator");
   if (comm && (comm->n_ranks != n_ranks || comm->rank != rank)) return fail(FB_EINVAL, "communicator rank/size does not match the handle");
   int ndev = 0;
@@ -1439,6 +1549,8 @@ int newmark_step(fb_fem_s* h, fb_step_info* info) {
     info->solve_seconds = solve_s;
     info->rho0 = fin.rho0;
     info->rho = fin.rho[fin.iter & 1];
+    info->pcg_path = h->last_pcg_path;
+    info->persist_fallbacks = h->persist_fallbacks;
   }
   if (!ok) return fail(FB_ESOLVER, "PCG sparse solver returned non-zero exit status %d", -total);
   return FB_OK;
@@ -1484,6 +1596,8 @@ int fb_fem_step(fb_fem_t h, fb_step_info* info) {
     info->solve_seconds = h->last_solve_s;
     info->rho0 = fin.rho0;
     info->rho = fin.rho[fin.iter & 1];
+    info->pcg_path = h->last_pcg_path;
+    info->persist_fallbacks = h->persist_fallbacks;
   }
   if (!ok) return fail(FB_ESOLVER, "PCG sparse solver returned non-zero exit status %d", iters);
   return FB_OK;
@@ -1797,7 +1911,8 @@ int fb_fem_persist_info(fb_fem_t h, int* waves_per_cu, int* workgroups, int* lds
   if (workgroups) *workgroups = h->persist ? h->persist_blocks : 0;
   if (lds_slots) {
     *lds_slots = 0;
-    if (h->persist && !h->f64) {
+    if (h->persist && h->persist_kind == 2) *lds_slots = h->pipe_klt;
+    else if (h->persist && !h->f64) {
       const int fit = (int)((160 * 1024 - sizeof(double) * kPersistSyncDoubles) / ((size_t)h->persist_waves * 10 * 64 * 4));
       const int w = h->persist_waves;
       *lds_slots = w <= 8 ? (fit >= 7 ? 7 : 0) : (w <= 12 ? (fit >= 5 ? 5 : (fit >= 4 ? 4 : 0)) : (fit >= 3 ? 3 : 0));
@@ -1806,31 +1921,57 @@ int fb_fem_persist_info(fb_fem_t h, int* waves_per_cu, int* workgroups, int* lds
   return h->persist ? 1 : 0;
 }
 
+int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches, int* persist_fallbacks, int* max_producers) {
+  if (!h) return fail(FB_EINVAL, "null FEM handle");
+  if (name && name_len > 0) {
+    if (h->persist && h->persist_kind == 2) snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_klt);
+    else if (h->persist) snprintf(name, name_len, "k_pcg_persist");
+    else name[0] = 0;
+  }
+  if (persist_launches) *persist_launches = h->persist_launches;
+  if (persist_fallbacks) *persist_fallbacks = h->persist_fallbacks;
+  if (max_producers) *max_producers = h->persist && h->persist_kind == 2 ? h->pipe_max_producers : 0;
+  return h->last_pcg_path;
+}
+
 int fb_fem_time_persist(fb_fem_t h, int reps, int n_iters, double* seconds_per_launch) {
   CHECK_HANDLE(h);
-  if (reps < 1 || n_iters < 1 || n_iters > 29 || !seconds_per_launch) return fail(FB_EINVAL, "bad arguments");
+  if (reps < 1 || n_iters < 1 || n_iters > 100000 || !seconds_per_launch) return fail(FB_EINVAL, "bad arguments");
   if (!h->persist) return fail(FB_EINVAL, "this handle does not run the persistent PCG iterations");
   if (!h->system_valid) FB_TRY(assemble_system(h));
   const FemPlan& P = h->plan;
   double total = 0.0;
   for (int r = -1; r < reps; r++) {  // r = -1: warm-up
-    // every launch starts from the state a solve of the current right-hand side starts from, with a tolerance it cannot reach
-    hipLaunchKernelGGL(k_cg_init, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->rhs.p, h->invdiag.p, h->x.p, h->r.p, h->d.p,
-                       h->part_b.p);
-    hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, h->stream, h->st.p, h->part_b.p, h->grid, (const double*)nullptr, 1e-30, 1 << 30);
-    FB_HIP(hipGetLastError());
-    // the plane conversion is part of the launch sequence of a run and is timed with it
-    FB_HIP(hipEventRecord(h->ev[0], h->stream));
-    FB_TRY(launch_persist(h, 1, n_iters));
-    FB_HIP(hipEventRecord(h->ev[1], h->stream));
-    FB_HIP(hipStreamSynchronize(h->stream));
     float ms = 0;
+    if (h->persist_kind == 2) {
+      // a solve of the current right-hand side with a tolerance it cannot reach, cut after n_iters iterations
+      FB_HIP(hipEventRecord(h->ev[0], h->stream));
+      FB_TRY(launch_pipe(h, h->rhs.p, 1, n_iters, 1e-30, 1 << 30));
+      FB_HIP(hipEventRecord(h->ev[1], h->stream));
+    } else {
+      if (n_iters > 29) return fail(FB_EINVAL, "the merged persistent kernel runs at most 29 iterations per launch");
+      // every launch starts from the state a solve of the current right-hand side starts from, with a tolerance it cannot reach
+      hipLaunchKernelGGL(k_cg_init, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->rhs.p, h->invdiag.p, h->x.p, h->r.p, h->d.p,
+                         h->part_b.p);
+      hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, h->stream, h->st.p, h->part_b.p, h->grid, (const double*)nullptr, 1e-30, 1 << 30);
+      FB_HIP(hipGetLastError());
+      // the plane conversion is part of the launch sequence of a run and is timed with it
+      FB_HIP(hipEventRecord(h->ev[0], h->stream));
+      FB_TRY(launch_persist(h, 1, n_iters));
+      FB_HIP(hipEventRecord(h->ev[1], h->stream));
+    }
+    FB_HIP(hipStreamSynchronize(h->stream));
     FB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
     if (r >= 0) total += ms * 1e-3;
   }
   unsigned int err = 0;
-  FB_HIP(hipMemcpy(&err, h->persist_flags.p + h->persist_blocks + 4, sizeof err, hipMemcpyDeviceToHost));
-  if (err) { FB_TRY(h->persist_flags.zero(h->stream)); return fail(FB_EDEVICE, "persistent PCG: a grid-wide wait timed out"); }
+  DevBuf<unsigned int>& fl = h->persist_kind == 2 ? h->pipe_flags : h->persist_flags;
+  FB_HIP(hipMemcpy(&err, fl.p + h->persist_blocks + 4, sizeof err, hipMemcpyDeviceToHost));
+  if (err) {
+    FB_TRY(fl.zero(h->stream));
+    if (h->persist_kind == 2) FB_TRY(h->pipe_post.zero(h->stream));
+    return fail(FB_EDEVICE, "persistent PCG: a wait inside the launch timed out");
+  }
   h->system_valid = false;
   *seconds_per_launch = total / reps;
   return FB_OK;

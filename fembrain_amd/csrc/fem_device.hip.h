@@ -1476,222 +1476,6 @@ __global__ __launch_bounds__(kBlock) void k_cg_fused(int n_slices, int n_owned, 
   }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Single-kernel PCG iteration (FB_PCG_FUSED).  Per node one 96-byte record S = {d[3], r[3], q[3], invdiag[3]},
-// double buffered.  Launch K(k) first reads the three sums the previous launch left (S0 = d_k.q_k, S1, S2), forms
-//   alpha_k = rho_k / S0,  rho_{k+1} = rho_k - 2 alpha_k S1 + alpha_k^2 S2,  beta_k = rho_{k+1} / rho_k
-// and then, per row, completes iteration k (x += alpha_k d_k; r_{k+1}; d_{k+1}) while ALREADY multiplying with the
-// new direction: every gathered column j recomputes d_{k+1,j} = invdiag_j (r_j - alpha_k q_j) + beta_k d_j from the
-// old records (bitwise the value row j writes for itself), so q_{k+1} = A d_{k+1} needs no grid-wide dependency and
-// one launch = one full PCG iteration of CGSolver.cpp:149-182 (one reduction; rounding differs from the literal form).
-// FIRST = no pending update (first launch and the launch after an exact-residual refresh): d is taken as stored.
-// ------------------------------------------------------------------------------------------------------
-struct Rec {
-  double d[3], r[3], q[3], inv[3];
-};
-
-__device__ inline Rec load_rec(const double* __restrict__ S, int node) {
-  const double2* p = (const double2*)(S + 12 * (size_t)node);
-  const double2 a = p[0], b = p[1], c = p[2], e = p[3], f = p[4], g = p[5];
-  Rec R;
-  R.d[0] = a.x; R.d[1] = a.y; R.d[2] = b.x; R.r[0] = b.y; R.r[1] = c.x; R.r[2] = c.y;
-  R.q[0] = e.x; R.q[1] = e.y; R.q[2] = f.x; R.inv[0] = f.y; R.inv[1] = g.x; R.inv[2] = g.y;
-  return R;
-}
-
-__device__ inline void store_rec(double* __restrict__ S, int node, const double* d, const double* r, const double* q, const double* inv) {
-  double2* p = (double2*)(S + 12 * (size_t)node);
-  p[0] = make_double2(d[0], d[1]); p[1] = make_double2(d[2], r[0]); p[2] = make_double2(r[1], r[2]);
-  p[3] = make_double2(q[0], q[1]); p[4] = make_double2(q[2], inv[0]); p[5] = make_double2(inv[1], inv[2]);
-}
-
-// three fixed-order sums of the per-block partials [0,n) [n,2n) [2n,3n)  (lds: 12 doubles)
-__device__ inline void sum3_partials(const double* __restrict__ part, int n, double* lds, double& s0, double& s1, double& s2) {
-  double a0 = 0, a1 = 0, a2 = 0;
-  for (int k = threadIdx.x; k < n; k += kBlock) { a0 += part[k]; a1 += part[n + k]; a2 += part[2 * n + k]; }
-  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) { lds[wv] = a0; lds[4 + wv] = a1; lds[8 + wv] = a2; }
-  __syncthreads();
-  s0 = (lds[0] + lds[1]) + (lds[2] + lds[3]);
-  s1 = (lds[4] + lds[5]) + (lds[6] + lds[7]);
-  s2 = (lds[8] + lds[9]) + (lds[10] + lds[11]);
-}
-
-// records from the right-hand side: d = invdiag b, r = b, q = 0; x = 0; partial = sum b^2 invdiag
-__global__ __launch_bounds__(kBlock) void k_rec_init(int n_slices, int n_owned, const double* __restrict__ b,
-                                                     const double* __restrict__ invdiag, double* __restrict__ x, double* __restrict__ S,
-                                                     double* __restrict__ partial) {
-  __shared__ double lds[4];
-  const int lane = threadIdx.x & 63;
-  double acc = 0.0;
-  for (SliceWalk w(n_slices); w.valid(); w.next()) {
-    const int row = w.s * 64 + lane;
-    if (row < n_owned) {
-      double d[3], r[3], q[3] = {0, 0, 0}, inv[3];
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        const size_t i = 3 * (size_t)row + a;
-        r[a] = b[i]; inv[a] = invdiag[i]; d[a] = inv[a] * r[a];
-        x[i] = 0.0;
-        acc += r[a] * r[a] * inv[a];
-      }
-      store_rec(S, row, d, r, q, inv);
-    }
-  }
-  const double tot = block_sum(acc, lds);
-  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
-}
-
-template <typename MT, bool FIRST>
-__global__ __launch_bounds__(kBlock) void k_cg_mega(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo, const double* __restrict__ Sin,
-                                                    double* __restrict__ Sout, double* __restrict__ x, const double* __restrict__ part_in,
-                                                    int n_partial, const double* __restrict__ sc, double* __restrict__ part_out,
-                                                    CGState* __restrict__ st, int k) {
-  __shared__ double lds[12];
-  if (st->done) return;
-  double alpha = 0.0, beta = 0.0, rho_new = 0.0;
-  bool stop;
-  if (!FIRST) {
-    double s0, s1, s2;
-    if (sc) { s0 = sc[0]; s1 = sc[1]; s2 = sc[2]; }
-    else sum3_partials(part_in, n_partial, lds, s0, s1, s2);
-    const double rho = st->rho[k & 1];
-    alpha = rho / s0;
-    rho_new = fmax(rho - 2.0 * alpha * s1 + alpha * alpha * s2, 0.0);
-    beta = rho_new / rho;
-    stop = !(rho_new > st->eps2 * st->rho0) || k >= st->max_iter;  // while-condition of CGSolver.cpp:147 after iteration k
-  } else {
-    stop = (k == 0) && (!(st->rho0 > st->eps2 * st->rho0) || st->max_iter < 1);
-  }
-  const int lane = threadIdx.x & 63;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  for (SliceWalk w(sv.n_slices); w.valid(); w.next()) {
-    const int s = w.s;
-    const int row = s * 64 + lane;
-    const bool rvalid = row < sv.n_owned;
-    Rec o;
-    double dn[3] = {0, 0, 0}, rn[3] = {0, 0, 0};
-    if (rvalid) {
-      o = load_rec(Sin, row);
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        if (FIRST) { rn[a] = o.r[a]; dn[a] = o.d[a]; }
-        else {
-          x[3 * (size_t)row + a] += alpha * o.d[a];
-          rn[a] = o.r[a] - alpha * o.q[a];
-          dn[a] = o.inv[a] * rn[a] + beta * o.d[a];
-        }
-      }
-    }
-    if (stop) continue;
-    const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
-    const MT* v = vals + (size_t)so * 9 * 64 + lane;
-    const int* ci = sv.colidx + (size_t)so * 64 + lane;
-    double y0 = 0, y1 = 0, y2 = 0;
-#pragma unroll 2
-    for (int kk = 0; kk < width; kk++) {
-      const int col = ci[(size_t)kk * 64];
-      double x0, x1, x2;
-      if (FIRST) {
-        const double2* p = (const double2*)(Sin + 12 * (size_t)col);
-        const double2 pa = p[0], pb = p[1];
-        x0 = pa.x; x1 = pa.y; x2 = pb.x;
-      } else {
-        const Rec c = load_rec(Sin, col);
-        x0 = c.inv[0] * (c.r[0] - alpha * c.q[0]) + beta * c.d[0];
-        x1 = c.inv[1] * (c.r[1] - alpha * c.q[1]) + beta * c.d[1];
-        x2 = c.inv[2] * (c.r[2] - alpha * c.q[2]) + beta * c.d[2];
-      }
-      const MT* vk = v + (size_t)kk * 9 * 64;
-      y0 += (double)vk[0 * 64] * x0 + (double)vk[1 * 64] * x1 + (double)vk[2 * 64] * x2;
-      y1 += (double)vk[3 * 64] * x0 + (double)vk[4 * 64] * x1 + (double)vk[5 * 64] * x2;
-      y2 += (double)vk[6 * 64] * x0 + (double)vk[7 * 64] * x1 + (double)vk[8 * 64] * x2;
-    }
-    if (rvalid) {
-      const MT* l = dlo + (size_t)s * 9 * 64 + lane;
-      y0 += (double)l[0 * 64] * dn[0] + (double)l[1 * 64] * dn[1] + (double)l[2 * 64] * dn[2];
-      y1 += (double)l[3 * 64] * dn[0] + (double)l[4 * 64] * dn[1] + (double)l[5 * 64] * dn[2];
-      y2 += (double)l[6 * 64] * dn[0] + (double)l[7 * 64] * dn[1] + (double)l[8 * 64] * dn[2];
-      const double qn[3] = {y0, y1, y2};
-      store_rec(Sout, row, dn, rn, qn, o.inv);
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        a0 += dn[a] * qn[a];
-        a1 += o.inv[a] * rn[a] * qn[a];
-        a2 += o.inv[a] * qn[a] * qn[a];
-      }
-    }
-  }
-  if (!stop) {
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
-    const int wv = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) { lds[wv] = a0; lds[4 + wv] = a1; lds[8 + wv] = a2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      part_out[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
-      part_out[gridDim.x + blockIdx.x] = (lds[4] + lds[5]) + (lds[6] + lds[7]);
-      part_out[2 * gridDim.x + blockIdx.x] = (lds[8] + lds[9]) + (lds[10] + lds[11]);
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (!FIRST) { st->rho[(k + 1) & 1] = rho_new; st->iter = k; }
-    if (stop) st->done = 1;
-  }
-}
-
-// exact-residual refresh, part 1 (CGSolver.cpp:155-158): x += alpha_k d_k with alpha_k from the pending sums
-__global__ __launch_bounds__(kBlock) void k_rec_apply_x(int n_slices, int n_owned, const double* __restrict__ S, double* __restrict__ x,
-                                                        const double* __restrict__ part_in, int n_partial, const double* __restrict__ sc,
-                                                        const CGState* __restrict__ st, int k) {
-  __shared__ double lds[12];
-  if (st->done) return;
-  double s0, s1, s2;
-  if (sc) s0 = sc[0];
-  else sum3_partials(part_in, n_partial, lds, s0, s1, s2);
-  const double alpha = st->rho[k & 1] / s0;
-  const int lane = threadIdx.x & 63;
-  for (SliceWalk w(n_slices); w.valid(); w.next()) {
-    const int row = w.s * 64 + lane;
-    if (row < n_owned) {
-      const double2* p = (const double2*)(S + 12 * (size_t)row);
-      const double2 pa = p[0], pb = p[1];
-      x[3 * (size_t)row] += alpha * pa.x; x[3 * (size_t)row + 1] += alpha * pa.y; x[3 * (size_t)row + 2] += alpha * pb.x;
-    }
-  }
-}
-
-// part 3 (CGSolver.cpp:169-176): rho_{k+1} = exact sum, beta, d_{k+1} = invdiag r + beta d_k into the next record buffer
-__global__ __launch_bounds__(kBlock) void k_rec_refresh(int n_slices, int n_owned, const double* __restrict__ Sin, double* __restrict__ Sout,
-                                                        const double* __restrict__ r, const double* __restrict__ part_rho, int n_partial,
-                                                        const double* __restrict__ sc, CGState* __restrict__ st, int k) {
-  __shared__ double lds[4];
-  if (st->done) return;
-  const double rho_new = sc ? sc[3] : sum_partials(part_rho, n_partial, lds);
-  const double beta = rho_new / st->rho[k & 1];
-  const int lane = threadIdx.x & 63;
-  for (SliceWalk w(n_slices); w.valid(); w.next()) {
-    const int row = w.s * 64 + lane;
-    if (row < n_owned) {
-      const Rec o = load_rec(Sin, row);
-      double dn[3], rn[3], qn[3] = {0, 0, 0};
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        rn[a] = r[3 * (size_t)row + a];
-        dn[a] = o.inv[a] * rn[a] + beta * o.d[a];
-      }
-      store_rec(Sout, row, dn, rn, qn, o.inv);
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    st->rho[(k + 1) & 1] = rho_new;
-    st->iter = k;
-    if (!(rho_new > st->eps2 * st->rho0) || k >= st->max_iter) st->done = 1;
-  }
-}
-
 // state update of PS_VolumeConservingIntegrator.cpp:229-237: qvel += dv, q += h qvel, constrained -> 0
 __global__ __launch_bounds__(kBlock) void k_state_update(int n, const double* __restrict__ dv, const uint8_t* __restrict__ mask,
                                                          double h, double* __restrict__ q, double* __restrict__ qvel) {

@@ -28,6 +28,7 @@
 // stand-alone kernels; the run ends there and at convergence, writing x and r back.
 #pragma once
 #include "fem_kernels.h"
+#include "pcg_pipe.hip.h"
 
 namespace fb {
 
@@ -62,18 +63,6 @@ __global__ __launch_bounds__(kBlock) void k_persist_planes(int n_owned, size_t n
 }
 
 
-
-__device__ __forceinline__ void st_sc1_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long ld_sc1_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1_u32(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned int ld_sc1_u32(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// one 16-byte sc1 load, waited for (a poll of four flags / two granules in one request)
-__device__ __forceinline__ uint4 ld_sc1_u128(const void* p) {
-  uint4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
 
 // slices of workgroup b: XCD b & 7 keeps the contiguous eighth of the rows it has in every other FEM kernel (SliceWalk); its
 // gridDim/8 workgroups share that slab as evenly as whole slices allow

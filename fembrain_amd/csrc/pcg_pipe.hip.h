@@ -1,0 +1,441 @@
+// Persistent PIPELINED Jacobi-PCG (included by fem.hip only): a whole solve of CGSolver.cpp:129-190 inside ONE launch, for
+// systems whose vectors fit on the chip.  One workgroup per CU owns a fixed run of SELL slices, one wavefront per slice, one
+// lane per block row; the lane keeps its row of x, r, w, z, s, p and 1/diag in REGISTERS for the whole solve.
+//
+// Why pipelined.  The merged-reduction iteration of round 2 (k_pcg_persist) crossed the chip twice per iteration: the three
+// sums all-to-all (alpha, beta are needed before the new search direction exists), then the new direction to the neighbours
+// -- 9 of its 22 us at 1M tets were those two hand-offs, with the memory system idle.  The recurrences of Ghysels & Vanroose
+// (pipelined CG, Parallel Computing 40 (2014), Alg. 4; M = diag folded in: u = r/diag, m = w/diag) compute the SAME iterates in
+// exact arithmetic from
+//     gamma = r . u,  delta = w . u                (both sums of LOCAL quantities, known before the product starts)
+//     n = A m,  m = w / diag                       (the product of the iteration)
+//     beta = gamma / gamma_old,  alpha = gamma / (delta - beta gamma / alpha_old)
+//     z = n + beta z,  s = w + beta s,  p = u + beta p,  x += alpha p,  r -= alpha s,  w -= alpha z
+// so the sums are POSTED before the product and READ after it (their trip across the chip hides behind ~10 us of matrix
+// stream), and the only wait of an iteration is for the m of the few workgroups whose rows this workgroup's columns touch
+// (+-5 workgroups on the slab-ordered cube; per-workgroup producer lists built at plan time, "all" as the fall-back).
+// Every 30th iteration takes the exact residual r = b - A x as the reference does (CGSolver.cpp:159-166), and with it
+// w = A (r / diag), as two more in-launch products.  Measured against the literal solver on the oracle's systems
+// (tools/pipelined_pcg_numerics.py): identical iteration counts at 4k..1M tets, solutions equal to 1e-7 (both stop at 1e-6).
+//
+// Hand-off form (MI355X_MICROARCH.md, "valid forms"): payload sc1 stores -> s_waitcnt vmcnt(0) -> workgroup barrier -> ONE
+// sc1 flag store per workgroup; consumer: agent-scope acquire issued early (buffer_inv sc1: nothing of this CU loads the
+// planes between it and the barrier), sc1 poll of the producers' flags, s_waitcnt vmcnt(0), workgroup barrier, plain loads.
+// The sums travel as tagged 8-byte granules (value half + sequence number in one store: no flag, no ordering).
+// Hazards: the planes are double-buffered by publish parity -- a workgroup overwrites buffer P two publishes after it was
+// filled, and it can be there only after every consumer of its rows has published in between, i.e. finished its reads
+// (consumers of my rows = producers of my columns: A is symmetric, and the wait on them is part of every product); sums are
+// double-buffered by sequence parity the same way.  Every spin is bounded by the wall clock; on expiry an error word is
+// set, every other spin sees it, the launch drains WITHOUT writing any state back and the host re-solves with the
+// two-launch form (fb_step_info.pcg_path says so).
+#pragma once
+#include "fem_kernels.h"
+#include "pcg_pipe_stream.hip.h"
+
+namespace fb {
+
+constexpr int kPipeMaxWaves = 12;    // wavefronts (= slices) per workgroup
+constexpr int kPipeMaxBlocks = 256;  // workgroups = CUs
+constexpr int kPipeSyncDoubles = 2 * 16 + 2 * kPipeMaxBlocks + 8;  // LDS in front of the resident values: wave sums | gathered sums | broadcast
+constexpr int kPipeMaxProducers = 64;
+
+struct PipeArgs {
+  unsigned long long* post;   // [2][n_blocks][4] granules: (hi, lo) of gamma, delta, each | sequence << 32
+  unsigned int* flags;        // [n_blocks (padded to 4)]: publish number of the workgroup's last complete plane store
+  unsigned int* error;        // set on a timed-out wait
+  unsigned int* seqs;         // [2] publish / sum sequence numbers reached by the previous launch (block 0 writes them at the end)
+  const int* producers;       // [n_blocks][64] workgroups whose rows this workgroup's columns touch; prod_count < 0: poll all
+  const int* prod_count;      // [n_blocks]
+  int start;                  // 0 continue a solve (state from memory), 1 new solve from x = 0, 2 new solve from the x in memory
+  int n_iters;                // at most this many iterations in this launch
+  double eps2;                // squared tolerance (start != 0; a continued solve reads the CGState)
+  int max_iter;
+  long long timeout_ticks;    // wall_clock64 ticks (100 MHz)
+  long long* timing;          // development aid (FEMBRAIN_PERSIST_TIMING=1), else null: per wavefront 6 accumulated phase times
+  double* planes;             // [2][3][n_pad]: the published vector as the gathers read it, x | y | z planes
+  size_t n_pad;               // rows padded to whole slices
+  double* pstate;             // [2] gamma_old, alpha_old between the launches of one solve
+};
+
+__device__ __forceinline__ void st_sc1_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1_u32(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned int ld_sc1_u32(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one 16-byte sc1 load, waited for (a poll of four flags / two granules in one request)
+__device__ __forceinline__ uint4 ld_sc1_u128(const void* p) {
+  uint4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// a value every lane holds alike, moved to scalar registers (a uniform double in vector registers costs two per lane for nothing)
+__device__ __forceinline__ double uniform_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)(b & 0xffffffffLL)), hi = __builtin_amdgcn_readfirstlane((unsigned int)((unsigned long long)b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ bool uniform_flag(bool f) { return __builtin_amdgcn_readfirstlane(f ? 1 : 0) != 0; }
+
+// slices of workgroup b: XCD b & 7 keeps the contiguous eighth of the rows it has in every other FEM kernel (SliceWalk); its
+// n_blocks/8 workgroups share that slab as evenly as whole slices allow.  Host and device use the same function.
+__host__ __device__ inline void pipe_slices(int n_slices, int n_blocks, int b, int* first, int* count) {
+  const int xcd = b & 7, j = b >> 3, per = n_blocks >> 3;
+  const int chunk = (n_slices + 7) >> 3;
+  const int lo = xcd * chunk;
+  int len = n_slices - lo;
+  len = len < 0 ? 0 : (len > chunk ? chunk : len);
+  const int base = len / per, rem = len - base * per;
+  *first = lo + j * base + (j < rem ? j : rem);
+  *count = base + (j < rem ? 1 : 0);
+}
+
+// lowest and highest column of every slice (rows past the last one hold padding)
+__global__ __launch_bounds__(kBlock) void k_slice_colrange(int n_slices, int n_owned, const int* __restrict__ slice_off, const int* __restrict__ colidx,
+                                                           int2* __restrict__ out) {
+  const int s = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (s >= n_slices) return;
+  const int row = s * 64 + lane;
+  int lo = 0x7fffffff, hi = -1;
+  if (row < n_owned)
+    for (int k = slice_off[s]; k < slice_off[s + 1]; k++) {
+      const int c = colidx[(size_t)k * 64 + lane];
+      lo = min(lo, c); hi = max(hi, c);
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
+  if (lane == 0) out[s] = make_int2(lo, hi);
+}
+
+// WMAX: wavefronts per workgroup the instantiation is bounded for (512 registers per lane and SIMD are shared by
+// ceil(WMAX / 4) wavefronts).  KLT: the first KLT slots of every slice (9 values + the column id per lane) are loaded into LDS
+// ONCE per launch -- the matrix does not change during a solve; slots beyond are streamed every product as in k_spmv.
+// TIMING: the development build with per-phase clocks (FEMBRAIN_PERSIST_TIMING=1).
+template <typename MT, bool C16, int WMAX, int KLT, bool TIMING, bool NOASM = false>
+__global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo,
+                                                        const double* __restrict__ invdiag, const double* __restrict__ bvec, double* __restrict__ xg,
+                                                        double* __restrict__ rg, double* __restrict__ wg, double* __restrict__ zg,
+                                                        double* __restrict__ sg, double* __restrict__ pg, CGState* __restrict__ st, PipeArgs pa) {
+  static_assert(sizeof(MT) == 4, "k_pcg_pipe keeps part of the matrix in LDS as fp32 words and streams the rest as fp32");
+  extern __shared__ double lds[];  // the request is padded so that one workgroup fills a CU
+  double* wsum = lds;                          // [2][16] wave sums
+  double* gath = lds + 32;                     // [2][kPipeMaxBlocks] all workgroups' sums
+  double* bc = gath + 2 * kPipeMaxBlocks;      // [0..1] totals, [2] a wait failed (sweep), [3] a wait failed (product), [4] a sum poller gave up
+  const int n_waves = blockDim.x >> 6, nb = gridDim.x;
+  if (pa.start == 0 && st->done) return;  // grid-uniform: written by an earlier launch
+  if (threadIdx.x == 0) bc[4] = 0.0;      // set by a sum poller that gave up (read after the next barrier)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int first, count;
+  pipe_slices(sv.n_slices, nb, blockIdx.x, &first, &count);
+  const bool live = wv < count;  // wave-uniform
+  const int sl = first + wv;
+  const int row = sl * 64 + lane;
+  const bool rvalid = live && row < sv.n_owned;
+  const size_t dof = 3 * (size_t)(rvalid ? row : 0);
+  int so = 0, width = 0;
+  if (live) { so = sv.slice_off[sl]; width = sv.slice_off[sl + 1] - so; }
+  so = __builtin_amdgcn_readfirstlane(so); width = __builtin_amdgcn_readfirstlane(width);  // wave-uniform: scalar registers
+  const MT* v = vals + (size_t)so * 9 * 64 + lane;
+  const int* ci = sv.colidx + (size_t)so * 64 + lane;
+  const short* cd = C16 ? sv.coldelta + (size_t)so * 64 + lane : nullptr;
+  // low part of the diagonal block (symmetric: 6 planes) and 1/diag, fixed for the solve
+  MT m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;
+  double iv[3] = {0, 0, 0};
+  if (rvalid) {
+    const MT* l = dlo + (size_t)sl * 9 * 64 + lane;
+    m00 = l[0 * 64]; m01 = l[1 * 64]; m02 = l[2 * 64]; m11 = l[4 * 64]; m12 = l[5 * 64]; m22 = l[8 * 64];
+#pragma unroll
+    for (int a = 0; a < 3; a++) iv[a] = invdiag[dof + a];
+  }
+  // LDS-resident part of the matrix: the first KL slots of this wave's slice, [KLT][10][64] words (9 values + the column id)
+  const int KL = min(KLT, width);
+  unsigned int* lres = (unsigned int*)(lds + kPipeSyncDoubles) + (size_t)wv * KLT * 10 * 64 + lane;
+  if (sizeof(MT) == 4) {
+    for (int k = 0; k < KL; k++) {
+      const MT* vk = v + (size_t)k * 9 * 64;
+#pragma unroll
+      for (int j = 0; j < 9; j++) lres[(k * 10 + j) * 64] = __float_as_uint((float)vk[j * 64]);
+      lres[(k * 10 + 9) * 64] = (unsigned int)(C16 ? row + (int)cd[(size_t)k * 64] : ci[(size_t)k * 64]);
+    }
+  }
+  // the producers of this workgroup's columns: one per lane of wavefront 0
+  const int n_prod = pa.prod_count[blockIdx.x];
+  int my_prod = -1;
+  if (wv == 0 && n_prod >= 0 && lane < n_prod) my_prod = pa.producers[(size_t)blockIdx.x * kPipeMaxProducers + lane];
+
+  unsigned int pub = pa.seqs[0], sums = pa.seqs[1];  // grid-uniform: written by the previous launch
+  const long long t_limit = pa.timeout_ticks;
+  bool failed = false;
+  long long tm[TIMING ? 6 : 1] = {0}, tprev = TIMING ? wall_clock64() : 0;  // (TIMING: the phase clocks cost 14 registers per lane)
+  auto lap = [&](int k) { if (TIMING) { const long long t = wall_clock64(); tm[k] += t - tprev; tprev = t; } };
+
+  // y = A vin: publish vin, wait for the producers of this workgroup's columns, multiply.  post_sums: the two wave sums in
+  // wsum[.][wv] are this iteration's local parts of gamma and delta -- posted with the flag, read after the product.
+  auto product = [&](const double* vin, double* y, bool post_sums) {
+    pub++;
+    double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
+    if (rvalid) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * pa.n_pad + (size_t)row, vin[a]);  // 512 contiguous bytes per wave and plane
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    lap(0);  // publish, drained
+    if (post_sums) sums++;
+    if (wv == 0) {
+      if (lane == 0) st_sc1_u32(pa.flags + blockIdx.x, pub);
+      if (post_sums && lane < 2) {  // workgroup sums in wave order, posted as two tagged halves each
+        double t = 0.0;
+        for (int w = 0; w < n_waves; w++) t += wsum[lane * 16 + w];
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(t), tag = (unsigned long long)sums << 32;
+        unsigned long long* post = pa.post + ((size_t)(sums & 1u) * nb + blockIdx.x) * 4 + 2 * lane;
+        st_sc1_u64(post, (bits >> 32) | tag);
+        st_sc1_u64(post + 1, (bits & 0xffffffffULL) | tag);
+      }
+      // Every wave of this workgroup is past its last gather from the buffer published now (two products ago) and none loads
+      // from the planes before the barrier below: drop this CU's L1 lines NOW (asynchronous), the poll runs meanwhile.
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const long long t0 = wall_clock64();
+      if (n_prod >= 0) {
+        for (;;) {
+          bool ok = true;
+          if (my_prod >= 0) ok = (int)(ld_sc1_u32(pa.flags + my_prod) - pub) >= 0;
+          if (__ballot(!ok) == 0ULL) break;
+          if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      } else {
+        for (int b = 4 * lane; b - 4 * lane < nb && !failed; b += 256) {  // four flags per lane in one 16-byte request
+          for (;;) {
+            bool ok = true;
+            if (b < nb) {
+              const uint4 f = ld_sc1_u128(pa.flags + b);
+              ok = (int)(f.x - pub) >= 0 && (b + 1 >= nb || (int)(f.y - pub) >= 0) && (b + 2 >= nb || (int)(f.z - pub) >= 0) && (b + 3 >= nb || (int)(f.w - pub) >= 0);
+            }
+            if (__ballot(!ok) == 0ULL) break;
+            if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+      }
+      if (failed && lane == 0) st_sc1_u32(pa.error, 1u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) bc[3] = (failed || ld_sc1_u32(pa.error) != 0u) ? 1.0 : 0.0;  // one lane decides for the whole workgroup
+    }
+    __syncthreads();
+    lap(1);  // flag + wait for the producers + acquire
+    if (uniform_flag(bc[3] != 0.0)) { failed = true; return; }
+    // the low part of the diagonal block times the own entry first: vin is not needed beyond this point
+    double y0 = 0, y1 = 0, y2 = 0;
+    if (rvalid) {
+      MT u00 = m00, u01 = m01, u02 = m02, u11 = m11, u12 = m12, u22 = m22;  // kept in storage type: without the (empty) asm the
+      asm volatile("" : "+v"(u00), "+v"(u01), "+v"(u02), "+v"(u11), "+v"(u12), "+v"(u22));  // compiler hoists the conversions and keeps 12 registers
+      const double l00 = (double)u00, l01 = (double)u01, l02 = (double)u02, l11 = (double)u11, l12 = (double)u12, l22 = (double)u22;
+      y0 = l00 * vin[0] + l01 * vin[1] + l02 * vin[2];
+      y1 = l01 * vin[0] + l11 * vin[1] + l12 * vin[2];
+      y2 = l02 * vin[0] + l12 * vin[1] + l22 * vin[2];
+    }
+    if (live) {
+      if (sizeof(MT) == 4) {
+#pragma unroll
+        for (int k = 0; k < KLT; k++) if (k < KL) {  // LDS-resident slots
+          const unsigned int* lk = lres + (size_t)k * 10 * 64;
+          const double* xp = pl + (size_t)lk[9 * 64];
+          const double x0 = xp[0], x1 = xp[pa.n_pad], x2 = xp[2 * pa.n_pad];
+          y0 += (double)__uint_as_float(lk[0 * 64]) * x0 + (double)__uint_as_float(lk[1 * 64]) * x1 + (double)__uint_as_float(lk[2 * 64]) * x2;
+          y1 += (double)__uint_as_float(lk[3 * 64]) * x0 + (double)__uint_as_float(lk[4 * 64]) * x1 + (double)__uint_as_float(lk[5 * 64]) * x2;
+          y2 += (double)__uint_as_float(lk[6 * 64]) * x0 + (double)__uint_as_float(lk[7 * 64]) * x1 + (double)__uint_as_float(lk[8 * 64]) * x2;
+        }
+      }
+      // the streamed slots: hand-pipelined loads (pcg_pipe_stream.hip.h)
+      const int n_str = width - KLT;
+      if (NOASM) {  // debugging aid: the compiler's loop
+        for (int k = KLT; k < width; k++) {
+          const int col = C16 ? row + (int)cd[(size_t)k * 64] : ci[(size_t)k * 64];
+          const double* xp = pl + (size_t)col;
+          const double x0 = xp[0], x1 = xp[pa.n_pad], x2 = xp[2 * pa.n_pad];
+          const MT* vk = v + (size_t)k * 9 * 64;
+          y0 += (double)vk[0 * 64] * x0 + (double)vk[1 * 64] * x1 + (double)vk[2 * 64] * x2;
+          y1 += (double)vk[3 * 64] * x0 + (double)vk[4 * 64] * x1 + (double)vk[5 * 64] * x2;
+          y2 += (double)vk[6 * 64] * x0 + (double)vk[7 * 64] * x1 + (double)vk[8 * 64] * x2;
+        }
+      } else if (n_str > 0) {
+        int so_k = so + KLT;
+        asm volatile("" : "+s"(so_k));  // opaque: keeps the two offsets below from being hoisted out of the solver loop into live registers
+        pipe_stream_slots<C16>(n_str, ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
+                               ((unsigned int)so_k * 64u + (unsigned int)lane) * (unsigned int)(C16 ? sizeof(short) : sizeof(int)), vals,
+                               C16 ? (const void*)sv.coldelta : (const void*)sv.colidx, pl, pl + pa.n_pad, pl + 2 * pa.n_pad, row, y0, y1, y2);
+      }
+    }
+    y[0] = y0; y[1] = y1; y[2] = y2;
+    lap(2);  // product
+  };
+
+  // this row's vectors stay here for the whole solve
+  double xr[3] = {0, 0, 0}, rr[3] = {0, 0, 0}, wr[3] = {0, 0, 0}, zr[3] = {0, 0, 0}, sr[3] = {0, 0, 0}, pr[3] = {0, 0, 0};
+  double rho0 = 0.0, eps2 = pa.eps2, gamma_old = 1.0, alpha_old = 1.0;
+  int iter = 0, max_iter = pa.max_iter;
+  // One product per trip of the loop below (ONE copy of the product's code): what is multiplied and what becomes of the result
+  // depends on the phase.  WARM_X / REFRESH_X: y = A x, r = b - y (CGSolver.cpp:131-136 / :159-166); INIT_W / REFRESH_W:
+  // w = A (r / diag); ITER: an iteration.
+  enum { PH_WARM_X = 0, PH_INIT_W = 1, PH_ITER = 2, PH_REFRESH_X = 3, PH_REFRESH_W = 4 };
+  int phase = PH_ITER;
+  bool fresh = pa.start != 0;  // the next iteration is the first of a solve (beta = 0)
+  if (pa.start == 0) {
+    if (rvalid) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) { xr[a] = xg[dof + a]; rr[a] = rg[dof + a]; wr[a] = wg[dof + a]; zr[a] = zg[dof + a]; sr[a] = sg[dof + a]; pr[a] = pg[dof + a]; }
+    }
+    rho0 = uniform_f64(st->rho0); eps2 = uniform_f64(st->eps2); iter = st->iter; max_iter = st->max_iter;
+    gamma_old = uniform_f64(pa.pstate[0]); alpha_old = uniform_f64(pa.pstate[1]);
+  } else if (pa.start == 2) {
+    if (rvalid) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) xr[a] = xg[dof + a];
+    }
+    phase = PH_WARM_X;
+  } else {
+    if (rvalid) {  // x = 0: r = b
+#pragma unroll
+      for (int a = 0; a < 3; a++) rr[a] = bvec[dof + a];
+    }
+    phase = PH_INIT_W;
+  }
+
+  bool done = false;
+  double gamma = 0.0;
+  int it_done = 0;
+  while (!failed) {
+    if (phase == PH_ITER && it_done >= pa.n_iters) break;  // a launch is cut between iterations only
+    double vin[3];
+    if (phase == PH_WARM_X || phase == PH_REFRESH_X) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) vin[a] = xr[a];
+    } else if (phase == PH_ITER) {
+      // local parts of gamma = r . u and delta = w . u (u = r / diag); the product's input is m = w / diag
+      const double u[3] = {iv[0] * rr[0], iv[1] * rr[1], iv[2] * rr[2]};
+      double a0 = rr[0] * u[0] + rr[1] * u[1] + rr[2] * u[2];
+      double a1 = wr[0] * u[0] + wr[1] * u[1] + wr[2] * u[2];
+      a0 = wave_sum(a0); a1 = wave_sum(a1);
+      int wvo = wv;
+      asm volatile("" : "+v"(wvo));  // opaque: the LDS address is formed here instead of living in a register through the solve
+      if (lane == 0) { wsum[wvo] = a0; wsum[16 + wvo] = a1; }
+#pragma unroll
+      for (int a = 0; a < 3; a++) vin[a] = iv[a] * wr[a];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; a++) vin[a] = iv[a] * rr[a];
+    }
+    double y[3];
+    product(vin, y, phase == PH_ITER);
+    if (failed) break;
+    if (phase == PH_WARM_X || phase == PH_REFRESH_X) {
+      unsigned int d3 = 3u * (unsigned int)(rvalid ? row : 0);
+      asm volatile("" : "+v"(d3));  // opaque: the address of b is formed here, not kept in two registers through the whole solve
+#pragma unroll
+      for (int a = 0; a < 3; a++) rr[a] = rvalid ? bvec[d3 + a] - y[a] : 0.0;
+      phase = phase == PH_WARM_X ? PH_INIT_W : PH_REFRESH_W;
+      continue;
+    }
+    if (phase != PH_ITER) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) wr[a] = y[a];
+      phase = PH_ITER;
+      continue;
+    }
+    // ---- all workgroups' sums (posted before their products: they are there) ----
+    {
+      const int pollers = min(n_waves, 4);
+      if (wv < pollers) {
+        const long long t0 = wall_clock64();
+        const unsigned long long* post = pa.post + (size_t)(sums & 1u) * nb * 4;
+        for (int b = wv * 64 + lane; b - lane < nb && !failed; b += pollers * 64) {  // wave-uniform trip count
+          const bool mine = b < nb;
+          uint4 q4[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+          for (;;) {
+            bool ok = true;
+            if (mine) {  // the record's four granules in two 16-byte requests (each granule is one 8-byte store of its writer)
+              asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                           : "=&v"(q4[0]), "=&v"(q4[1]) : "v"(post + (size_t)b * 4) : "memory");
+              ok = q4[0].y == sums && q4[0].w == sums && q4[1].y == sums && q4[1].w == sums;
+            }
+            if (__ballot(!ok) == 0ULL) break;
+            if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (mine && !failed) {
+            gath[b] = __longlong_as_double((long long)(((unsigned long long)q4[0].x << 32) | (unsigned long long)q4[0].z));
+            gath[kPipeMaxBlocks + b] = __longlong_as_double((long long)(((unsigned long long)q4[1].x << 32) | (unsigned long long)q4[1].z));
+          }
+        }
+        if (failed && lane == 0) { st_sc1_u32(pa.error, 1u); bc[4] = 1.0; }
+      }
+      __syncthreads();
+      if (wv == 0) {  // fixed order: lane l adds workgroups l, l + 64, ...; then the wave tree -- the same bits in every workgroup
+        double t0s = 0, t1s = 0;
+        int l0 = lane;
+        asm volatile("" : "+v"(l0));  // (opaque, as above)
+        for (int b = l0; b < nb; b += 64) { t0s += gath[b]; t1s += gath[kPipeMaxBlocks + b]; }
+        t0s = wave_sum(t0s); t1s = wave_sum(t1s);
+        if (lane == 0) { bc[0] = t0s; bc[1] = t1s; bc[2] = (bc[4] != 0.0 || ld_sc1_u32(pa.error) != 0u) ? 1.0 : 0.0; }
+      }
+      __syncthreads();
+    }
+    lap(3);  // sweep of the sums
+    if (uniform_flag(bc[2] != 0.0)) { failed = true; break; }  // a wait timed out somewhere: every workgroup leaves within one phase
+    gamma = uniform_f64(bc[0]);
+    const double delta = uniform_f64(bc[1]);
+    if (fresh) rho0 = gamma;
+    // the while-condition of CGSolver.cpp:147 at the head of the iteration; gamma is bitwise the same in every workgroup
+    if (!(gamma > eps2 * rho0) || iter >= max_iter) { done = true; break; }
+    double alpha, beta;
+    if (fresh) { beta = 0.0; alpha = gamma / delta; }
+    else { beta = gamma / gamma_old; alpha = gamma / (delta - beta * gamma / alpha_old); }
+    fresh = false;
+    // ---- recurrences, in registers (y = n = A m) ----
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      zr[a] = y[a] + beta * zr[a];
+      sr[a] = wr[a] + beta * sr[a];
+      pr[a] = iv[a] * rr[a] + beta * pr[a];
+      xr[a] = xr[a] + alpha * pr[a];
+    }
+    iter++;
+    it_done++;
+    gamma_old = gamma; alpha_old = alpha;
+    if (iter % 30 == 0) {
+      phase = PH_REFRESH_X;  // exact residual (CGSolver.cpp:159-166), and the w that goes with it: two more products
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        rr[a] = rr[a] - alpha * sr[a];
+        wr[a] = wr[a] - alpha * zr[a];
+      }
+    }
+    lap(4);  // recurrences
+  }
+  if (TIMING && lane == 0) {
+    for (int k = 0; k < 5; k++) atomicAdd((unsigned long long*)pa.timing + ((size_t)blockIdx.x * kPipeMaxWaves + wv) * 6 + k, (unsigned long long)tm[k]);
+    atomicAdd((unsigned long long*)pa.timing + ((size_t)blockIdx.x * kPipeMaxWaves + wv) * 6 + 5, (unsigned long long)it_done);
+  }
+  if (failed) return;  // nothing written back: the host re-solves from the vectors it handed over
+  if (rvalid) {
+    unsigned int dof = 3u * (unsigned int)row;
+    asm volatile("" : "+v"(dof));  // (formed here: see the exact-residual phase)
+#pragma unroll
+    for (int a = 0; a < 3; a++) xg[dof + a] = xr[a];
+    if (!done) {  // the launch was cut (test knob): the next one continues from here
+#pragma unroll
+      for (int a = 0; a < 3; a++) { rg[dof + a] = rr[a]; wg[dof + a] = wr[a]; zg[dof + a] = zr[a]; sg[dof + a] = sr[a]; pg[dof + a] = pr[a]; }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->rho0 = rho0; st->eps2 = eps2; st->max_iter = max_iter;
+    st->iter = iter;
+    st->rho[iter & 1] = done ? gamma : gamma_old;  // what the host's convergence test reads (CGSolver.cpp:189)
+    st->done = done ? 1 : 0;
+    pa.pstate[0] = gamma_old; pa.pstate[1] = alpha_old;
+    pa.seqs[0] = pub; pa.seqs[1] = sums;
+  }
+}
+
+}  // namespace fb

@@ -245,6 +245,14 @@ class FemIntegrator:
         on = self._L.fb_fem_persist_info(self.h, C.byref(w), C.byref(b), C.byref(k))
         return bool(on == 1), w.value, b.value, k.value
 
+    def pcg_path(self):
+        """What ran: dict(path = FB_PCG_PATH_* of the last solve, kernel = the persistent instantiation this handle launches or '',
+        launches, fallbacks, max_producers)"""
+        name = C.create_string_buffer(96)
+        nl, nf, mp = C.c_int(0), C.c_int(0), C.c_int(0)
+        path = self._L.fb_fem_pcg_path(self.h, name, 96, C.byref(nl), C.byref(nf), C.byref(mp))
+        return dict(path=path, kernel=name.value.decode(), launches=nl.value, fallbacks=nf.value, max_producers=mp.value)
+
     def time_persist(self, reps=10, n_iters=29):
         s = C.c_double(0)
         _l.check(self._L.fb_fem_time_persist(self.h, reps, n_iters, C.byref(s)))

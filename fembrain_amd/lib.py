@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libfembrain_hip.so")
 FB_OK, FB_EINVAL, FB_EDEVICE, FB_ENOMEM, FB_ESOLVER, FB_ECOMM = 0, -1, -2, -3, -4, -5
 FB_MATRIX_F32, FB_MATRIX_F64 = 0, 1
 FB_XCH_COLLECTIVE, FB_XCH_P2P, FB_XCH_P2P_SUMS, FB_XCH_P2P_FUSED = 1, 2, 3, 4
-FB_PCG_MERGED, FB_PCG_REFERENCE, FB_PCG_FUSED, FB_PCG_PERSISTENT, FB_PCG_BLOCK_JACOBI = 0, 1, 2, 3, 4
+FB_PCG_MERGED, FB_PCG_REFERENCE, FB_PCG_PERSISTENT, FB_PCG_BLOCK_JACOBI = 0, 1, 3, 4  # (2 was an experiment, removed)
+FB_PCG_PATH_TWO_LAUNCH, FB_PCG_PATH_PERSISTENT, FB_PCG_PATH_FALLBACK = 0, 1, 2
 FB_SPMV_AUTO, FB_SPMV_ROWS, FB_SPMV_SPLIT = 0, 1, 2
 FB_INTEGRATOR_VOLUME_CONSERVING, FB_INTEGRATOR_NEWMARK = 0, 1
 
@@ -40,7 +41,8 @@ class FemParams(C.Structure):
 
 class StepInfo(C.Structure):
     _fields_ = [("cg_iterations", C.c_int), ("converged", C.c_int), ("assembly_seconds", C.c_double),
-                ("solve_seconds", C.c_double), ("rho0", C.c_double), ("rho", C.c_double)]
+                ("solve_seconds", C.c_double), ("rho0", C.c_double), ("rho", C.c_double), ("pcg_path", C.c_int),
+                ("persist_fallbacks", C.c_int)]
 
 
 class PolyCounts(C.Structure):
@@ -126,6 +128,7 @@ def lib():
         "fb_fem_assembly_bytes": (C.c_int, [vp, _dp]),
         "fb_fem_set_newmark": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, C.c_double]),
         "fb_fem_persist_info": (C.c_int, [vp, _ip, _ip, _ip]),
+        "fb_fem_pcg_path": (C.c_int, [vp, C.c_char_p, C.c_int, _ip, _ip, _ip]),
         "fb_fem_time_persist": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
         "fb_fem_iteration_bytes": (C.c_int, [vp, _dp]),
         "fb_comm_unique_id": (C.c_int, [_bp]),

@@ -31,16 +31,18 @@ extern "C" {
  * reduction (one RCCL all-reduce when sharded); iterates agree to rounding, checked by the parity tests. */
 #define FB_PCG_MERGED 0
 #define FB_PCG_REFERENCE 1
-/* FUSED (experimental): the merged recurrence with the vector update folded into the SpMV launch: each gathered column
- * recomputes its new search-direction entry from a 96-byte per-node record {d, r, q, 1/diag}, so one launch is one
- * iteration.  Correct (same iteration counts), but measured 1.8x SLOWER than MERGED on MI355X at 1M tets (51 vs 28 us per
- * iteration): the 6 x 16-byte gathers per neighbour cost more than the vector pass they remove.  Kept for reference. */
-#define FB_PCG_FUSED 2
-/* PERSISTENT: the merged recurrence with all iterations between two exact-residual ones inside ONE launch: one workgroup per
- * CU, one wavefront per SELL slice, every lane keeps its row's x, r, d, 1/diag in registers; per iteration only the new search
- * direction is written (for the neighbours' gathers) and the three sums cross the chip through tagged 8-byte granules
- * (fembrain_amd/csrc/pcg_persist.hip.h).  Unsharded handles of up to 16 slices per CU (~1.5M tets on 256 CUs).  Iterates
- * agree with MERGED to rounding (the sums are grouped per workgroup), bitwise with themselves however the run is cut. */
+/* (value 2, an experimental one-launch-per-iteration form that measured 1.8x slower, was removed in round 3: FB_EINVAL) */
+/* PERSISTENT: the whole solve inside ONE launch (fembrain_amd/csrc/pcg_pipe.hip.h): one workgroup per CU, one wavefront per SELL
+ * slice, every lane keeps its row's x, r, w, z, s, p, 1/diag in registers.  The iteration is the PIPELINED form of the same
+ * Jacobi-PCG (Ghysels & Vanroose 2014: the same iterates in exact arithmetic): its two sums are posted before the product and
+ * read after it, so the only wait of an iteration is for the neighbouring workgroups' part of the product's input vector.
+ * Every 30th iteration takes the exact residual as CGSolver.cpp:159-166 does.  Unsharded handles, FB_MATRIX_F32 storage, up to
+ * 12 slices per CU (~1.1M tets on 256 CUs); chosen BY DEFAULT there (FB_PCG_MERGED + FEMBRAIN_PCG_PERSIST unset).  Iteration
+ * counts equal those of the literal solver within max(3, 2 %) (tests), iterates agree to rounding and are bitwise
+ * reproducible however the solve is cut into launches.  If a wait inside the launch times out (FEMBRAIN_PERSIST_TIMEOUT_MS,
+ * default 50; the workgroups must all be resident) the solve is repeated with the two-launch iteration and the handle stays
+ * with it: fb_step_info.pcg_path = FB_PCG_PATH_FALLBACK, fb_step_info.persist_fallbacks counts (FEMBRAIN_PERSIST_STRICT=1:
+ * FB_EDEVICE instead). */
 #define FB_PCG_PERSISTENT 3
 /* BLOCK_JACOBI (opt-in; NOT the reference's solver, excluded from parity): the literal PCG with the inverse of every row's 3x3
  * diagonal block as preconditioner instead of the inverse diagonal.  Same convergence test (on r . B^-1 r).  Unsharded handles.
@@ -152,7 +154,12 @@ typedef struct fb_step_info {
   double assembly_seconds;/* IntegratorBaseSparse::GetForceAssemblyTime (integratorBaseSparse.h:66), hipEvent-timed */
   double solve_seconds;   /* IntegratorBaseSparse::GetSystemSolveTime (integratorBaseSparse.h:67) */
   double rho0, rho;       /* initial / final sum r^2 / diag */
+  int pcg_path;           /* FB_PCG_PATH_*: which solver form ran the (last) solve of this step */
+  int persist_fallbacks;  /* solves of this handle so far that a timed-out persistent launch handed to the two-launch form */
 } fb_step_info;
+#define FB_PCG_PATH_TWO_LAUNCH 0  /* k_spmv + k_cg_fused per iteration (or the literal / block-Jacobi sequences) */
+#define FB_PCG_PATH_PERSISTENT 1  /* the persistent launch (FB_PCG_PERSISTENT) */
+#define FB_PCG_PATH_FALLBACK 2    /* a persistent launch timed out; the solve was repeated with the two-launch form */
 
 /* VolumeConservingIntegrator::DoTimestep (PS_VolumeConservingIntegrator.cpp:46-260): assembly, Keff/rhs, PCG,
  * state update.  Returns FB_OK, or FB_ESOLVER when PCG hit cg_max_iter (state is then left unchanged). */
@@ -233,8 +240,13 @@ int fb_fem_time_element_stiffness(fb_fem_t h, int reps, double* seconds_per_pass
  * merged iterations inside persistent launches, else 0; wavefronts (= slices) per CU, workgroups, and how many slots of every
  * slice stay resident in LDS for a launch (any pointer may be NULL) */
 int fb_fem_persist_info(fb_fem_t h, int* waves_per_cu, int* workgroups, int* lds_slots);
-/* average device seconds of ONE persistent launch of n_iters (1..29) merged PCG iterations on the current system, HIP events on
- * the handle's stream around the launch sequence of a run (plane conversion + persistent kernel) */
+/* What ran: the FB_PCG_PATH_* of the last solve (return value); the persistent kernel instantiation this handle launches
+ * ("k_pcg_pipe<float,c16,12,5>", "" when it has none) into name; persistent launches and fallbacks so far; the longest
+ * producer list of a workgroup (-1: some workgroup polls all flags).  Any pointer may be NULL. */
+int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches, int* persist_fallbacks, int* max_producers);
+/* average device seconds of ONE persistent launch that starts a solve of the current system and is cut after n_iters
+ * iterations (tolerance out of reach), HIP events on the handle's stream around the launch; the difference of two lengths
+ * prices an iteration without the launch's fixed cost */
 int fb_fem_time_persist(fb_fem_t h, int reps, int n_iters, double* seconds_per_launch);
 /* algorithmic bytes of ONE Jacobi-PCG iteration on this system: BSR SpMV + the fused lower bound of the vector
  * traffic (9 fp64 vector streams) */
