@@ -176,6 +176,9 @@ class BenchAbort(Exception):
 
 
 _state = {"out": None, "rank": 0, "printed": False, "stage": "start-up"}
+# iteration count of every persistent launch (one per solve) in launch order; FEMBRAIN_BENCH_LAUNCH_LOG=<path> writes it out for
+# tools/summarize_profiles.py, which divides the per-launch PMC counters by it (bytes per PCG iteration)
+_pipe_launch_iterations = []
 
 
 def _emit(error=None):
@@ -187,6 +190,12 @@ def _emit(error=None):
     if error is not None:
         out["error"] = error
     print(json.dumps(out), flush=True)
+    log = os.environ.get("FEMBRAIN_BENCH_LAUNCH_LOG")
+    if log:
+        try:
+            json.dump({"k_pcg_pipe_launch_iterations": _pipe_launch_iterations}, open(log, "w"))
+        except OSError:
+            pass
 
 
 def _watchdog(seconds):
@@ -345,7 +354,10 @@ def main():
             h = h or g
             h.rebuild_elements()
             h.set_uniform_force(1, -10000.0)
-            return h.do_timestep()
+            it = h.do_timestep()
+            if h.last.pcg_path == fl.FB_PCG_PATH_PERSISTENT:
+                _pipe_launch_iterations.append(int(it))   # one persistent launch per solve: its iteration count, in launch order
+            return it
 
         # Sharded runs: the exchange modes give bitwise identical iterates, so the fastest one ON THIS MACHINE is picked by
         # timing one step in each (max over ranks); untimed, before the warmup.  A form that fails on any rank ends the trials
@@ -460,7 +472,7 @@ def main():
             # dominant kernel: the PCG SpMV.  Average launch duration measured with HIP events on the handle's stream.
             spmv_s = g.time_spmv(200)
             persist = g.persist_info()
-            persist_s = g.time_persist(20, 29) if persist[0] else None
+            persist_s = g.persist_stats() if persist[0] else None   # every persistent launch this handle's solves have made: (launches, device seconds, iterations)
             asm_k_s = g.time_assembly(10)
             halo_s, sum_s = g.time_exchange(200) if dist_mode else (0.0, 0.0)
             k0_s = g.time_element_stiffness(3)
@@ -477,7 +489,7 @@ def main():
             # HBM traffic of the dominant kernel from the PMC counters: taken from the committed profile only while the kernel
             # sources are still the ones that were profiled (tools/summarize_profiles.py records their hash), else null
             traffic, traffic_note = None, "no PMC profile of the current kernel sources under profiles/"
-            dominant = "k_pcg_persist" if persist[0] else "k_spmv"
+            dominant = "k_pcg_pipe" if persist[0] else "k_spmv"
             pmc = os.path.join(ROOT, "profiles", "dominant_pmc.json")
             if os.path.exists(pmc) and args.workload == "cube56" and world == 1 and args.precision == "f32":
                 try:
@@ -487,7 +499,7 @@ def main():
                     elif not rec.get("kernel", "").startswith(dominant):
                         traffic_note = "profiles/dominant_pmc.json is for %s, this run's dominant kernel is %s" % (rec.get("kernel"), dominant)
                     else:
-                        traffic, traffic_note = rec.get("hbm_bytes_per_launch"), "profiles/dominant_pmc.json (same kernel sources)"
+                        traffic, traffic_note = rec.get("hbm_bytes_per_unit" if persist[0] else "hbm_bytes_per_launch"), "profiles/dominant_pmc.json (same kernel sources)"
                 except Exception:
                     pass
             spmv_roof = {"kernel": "k_spmv (SELL-64 3x3-block SpMV of the two-launch PCG iteration; the exact-residual iterations and systems "
@@ -497,17 +509,26 @@ def main():
                          # for comparison, SURVEY 8d's plain BSR figure (4-byte column ids, x read once, y written once, here in fp64)
                          "survey_bsr_bytes_per_launch": (g.num_blocks() * 40.0 + (len(v) + 1) * 4.0 + 3.0 * len(v) * 16.0) if shard is None else None}
             if persist[0]:
-                # dominant kernel: k_pcg_persist, ONE launch = 29 merged PCG iterations (everything between two exact-residual
-                # iterations).  Unit = one PCG iteration; algorithmic bytes per unit = SURVEY 8(d): BSR SpMV + the fused lower
-                # bound of the vector traffic (fb_fem_iteration_bytes).  The kernel keeps the vectors and part of the matrix
-                # on-chip, so its HBM/L3 traffic (PMC) is BELOW that figure -- the opposite of wasted re-reads.
-                roofline = {"kernel": "k_pcg_persist (29 merged Jacobi-PCG iterations per launch: SpMV + sums + vector update, vectors in registers, "
-                                      "%d of ~15 slots of every slice resident in LDS)" % persist[3],
-                            "bound": "hbm", "achieved": 29 * iter_bytes / persist_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": 29 * iter_bytes / persist_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                            "units_per_launch": 29, "algorithmic_bytes_per_unit": iter_bytes, "algorithmic_bytes_per_launch": 29 * iter_bytes,
-                            "us_per_launch": persist_s * 1e6, "us_per_unit": persist_s * 1e6 / 29,
-                            "wavefronts_per_cu": persist[1], "workgroups": persist[2], "spmv_kernel": spmv_roof}
+                # dominant kernel: k_pcg_pipe, ONE launch = ONE whole solve (every iteration of a step).  Unit = one PCG iteration;
+                # algorithmic bytes per unit = SURVEY 8(d): BSR SpMV + the fused lower bound of the vector traffic
+                # (fb_fem_iteration_bytes); the exact-residual products every 30th iteration are NOT counted as work.  Launch
+                # durations: HIP events on the handle's stream around EVERY persistent launch this process made (warm-up, timed
+                # and fixed-state steps alike), so the average is the one a kernel trace of the same command shows.
+                # The kernel keeps the vectors and part of the matrix on-chip, so its HBM/L3 traffic (PMC) is BELOW the
+                # algorithmic figure -- the opposite of wasted re-reads; bus_frac = that traffic / time / peak.
+                n_launch, sec, n_it = persist_s
+                upl = n_it / max(n_launch, 1)
+                ach = n_it * iter_bytes / sec / 1e9
+                traffic_launch = traffic * upl if traffic is not None else None
+                roofline = {"kernel": "%s (pipelined Jacobi-PCG, one launch per solve: product + sums + recurrences of every iteration, vectors in "
+                                      "registers, %d of ~15 slots of every slice resident in LDS)" % (g.pcg_path()["kernel"], persist[3]),
+                            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                            "traffic": traffic_launch, "traffic_per_unit": traffic, "traffic_source": traffic_note,
+                            "bus_frac": (traffic_launch / (sec / n_launch) / 1e9 / HBM_PEAK_GBS) if traffic_launch is not None else None,
+                            "launches": n_launch, "units_per_launch": upl, "algorithmic_bytes_per_unit": iter_bytes,
+                            "algorithmic_bytes_per_launch": upl * iter_bytes, "us_per_launch": sec / n_launch * 1e6, "us_per_unit": sec / n_it * 1e6,
+                            "wavefronts_per_cu": persist[1], "workgroups": persist[2], "max_producers_per_workgroup": g.pcg_path()["max_producers"],
+                            "persist_fallbacks": g.pcg_path()["fallbacks"], "spmv_kernel": spmv_roof}
             else:
                 roofline = dict(spmv_roof, bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", traffic=traffic, traffic_source=traffic_note)
             storage = "f64 arithmetic / f32 stored matrix" if args.precision == "f32" else "f64"
@@ -525,8 +546,9 @@ def main():
                                         "peer-to-peer inboxes, sums and halo values inside the PCG kernels"][g.transport()],
                            "exchange_trials_ms_per_step": xch_trials, "exchange_note": xch_note, "sharded_self_check": sharded_check,
                            "cg_eps": 1e-6, "cg_max_iter": 10000,
-                           "pcg": ("persistent launches of up to 29 merged iterations (FB_PCG_PERSISTENT, default at this size)" if persist[0]
-                                   else "two launches per merged iteration (FB_PCG_MERGED)")},
+                           "pcg": ("one persistent launch per solve, pipelined iteration (FB_PCG_PERSISTENT, default at this size)" if persist[0]
+                                   else "two launches per merged iteration (FB_PCG_MERGED)"),
+                           "pcg_path_last_step": int(g.last.pcg_path), "persist_fallbacks": int(g.last.persist_fallbacks)},
                 "cg_iterations": [int(i) for i in iters], "cg_iterations_per_step": float(np.mean(iters)),
                 "value_note": "timed steps continue the loaded simulation after the warm-up steps (trajectory); value_at_fixed_state times the same "
                               "step from the rest state every time",

@@ -10,7 +10,6 @@
 #include "common.h"
 #include "fem_device.hip.h"
 #include "fem_plan.h"
-#include "pcg_persist.hip.h"
 #include "pcg_pipe.hip.h"
 #include "plan_device.h"
 
@@ -78,19 +77,14 @@ struct fb_fem_s {
   hipGraphExec_t batch_graph = nullptr;
   const double* graph_rhs = nullptr;
   bool use_graph = true;
-  // persistent PCG iterations (pcg_persist.hip.h): one workgroup per CU, `persist_waves` wavefronts = slices each
+  // persistent solver (pcg_pipe.hip.h): one workgroup per CU, `persist_waves` wavefronts = slices each, the whole solve in one launch
   bool persist = false;
   int persist_blocks = 0, persist_waves = 0;
-  unsigned int persist_seq = 0;
-  DevBuf<unsigned long long> persist_post;
-  DevBuf<unsigned int> persist_flags;  // [blocks padded to 4] flags, then the error word
   DevBuf<long long> persist_timing;    // FEMBRAIN_PERSIST_TIMING=1 (development aid)
-  DevBuf<double> persist_dsoa;         // the search direction in three planes (k_persist_planes)
-  // pipelined persistent solve (pcg_pipe.hip.h): the whole solve in one launch
-  int persist_kind = 0;                // 1 = merged-reduction launches of 29 iterations (k_pcg_persist), 2 = pipelined whole solve (k_pcg_pipe)
   DevBuf<unsigned long long> pipe_post;
   DevBuf<unsigned int> pipe_flags;     // [blocks padded to 4] flags, [+4] the error word, [+8..9] the two sequence numbers
-  DevBuf<int> pipe_prod, pipe_prod_count;
+  DevBuf<int> pipe_prod, pipe_prod_count, pipe_prod_xcd;
+  int pipe_plain_local = 0;            // interior workgroups publish with plain stores (FEMBRAIN_PIPE_PLAIN_STORES)
   DevBuf<double> pipe_planes, pipe_z, pipe_s, pipe_state;
   int pipe_klt = 0, pipe_wmax = 0;
   int pipe_max_producers = 0;          // longest producer list (-1: some workgroup polls all)
@@ -98,6 +92,9 @@ struct fb_fem_s {
   int persist_fallbacks = 0;           // solves that had to be repeated with the two-launch form
   int persist_launches = 0;            // persistent launches made by this handle
   int last_pcg_path = 0;               // FB_PCG_PATH_* of the last solve
+  hipEvent_t ev_p[2] = {nullptr, nullptr};  // around every persistent launch
+  double persist_seconds = 0;          // device seconds of all persistent launches of this handle (HIP events on its stream)
+  long long persist_iterations = 0;    // PCG iterations they ran
 };
 
 namespace {
@@ -141,7 +138,6 @@ int setup_persist(fb_fem_s* h) {
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
   h->persist = false;
-  h->persist_kind = 0;
   hipDeviceProp_t prop;
   FB_HIP(hipGetDeviceProperties(&prop, h->prm.device));
   const int nb = std::min(kPipeMaxBlocks, (prop.multiProcessorCount / 8) * 8);
@@ -150,7 +146,7 @@ int setup_persist(fb_fem_s* h) {
   {
     const char* t = getenv("FEMBRAIN_PERSIST_TIMEOUT_MS");  // how long a wait inside a persistent launch may last before the launch gives up
     const double ms = t ? atof(t) : 50.0;                   // default 50 ms: a whole 1M-tet solve is ~25 ms, one wait is microseconds
-    h->persist_timeout_ticks = (long long)(std::max(ms, 0.001) * 1e5);  // 100 MHz
+    h->persist_timeout_ticks = std::max(1LL, (long long)(ms * 1e5));  // 100 MHz
   }
   const bool explicit_p = h->prm.pcg_variant == FB_PCG_PERSISTENT;
   if (explicit_p && P.n_ranks > 1) return fail(FB_EINVAL, "FB_PCG_PERSISTENT is for unsharded handles");
@@ -164,22 +160,7 @@ int setup_persist(fb_fem_s* h) {
   const bool by_default = h->prm.pcg_variant == FB_PCG_MERGED && w >= min_w;
   const bool want_p = e ? atoi(e) != 0 && (h->prm.pcg_variant == FB_PCG_MERGED || explicit_p) : (explicit_p || by_default);
   if (!want_p || !eligible) return FB_OK;
-  const char* kind = getenv("FEMBRAIN_PERSIST_KIND");  // development aid: "merged" = the round-2 kernel
-  h->persist_kind = kind && !strcmp(kind, "merged") ? 1 : 2;
   h->persist = true; h->persist_blocks = nb; h->persist_waves = w;
-  if (h->persist_kind == 1) {
-    FB_TRY(h->persist_post.alloc((size_t)2 * nb * 8));
-    FB_TRY(h->persist_post.zero(s));
-    FB_TRY(h->persist_flags.alloc((size_t)nb + 8));
-    FB_TRY(h->persist_flags.zero(s));
-    h->persist_seq = 0;
-    FB_TRY(h->persist_dsoa.alloc((size_t)3 * P.n_slices * 64));
-    if (getenv("FEMBRAIN_PERSIST_TIMING")) {
-      FB_TRY(h->persist_timing.alloc((size_t)nb * kPersistMaxWaves * 5));
-      FB_TRY(h->persist_timing.zero(s));
-    }
-    return FB_OK;
-  }
   // pipelined whole-solve kernel
   h->pipe_wmax = w <= 8 ? 8 : 12;
   h->pipe_klt = w <= 8 ? 7 : 5;   // slots of every slice resident in LDS: (160 KB - sync) / (wavefronts * 2560 B)
@@ -208,7 +189,7 @@ int setup_persist(fb_fem_s* h) {
   FB_HIP(hipGetLastError());
   std::vector<int2> rg((size_t)std::max(1, P.n_slices));
   FB_TRY(range.download(rg.data(), rg.size(), s));
-  std::vector<int> owner((size_t)P.n_slices, 0), prod((size_t)nb * kPipeMaxProducers, -1), cnt((size_t)nb, 0);
+  std::vector<int> owner((size_t)P.n_slices, 0), prod((size_t)nb * kPipeMaxProducers, -1), cnt((size_t)nb, 0), far((size_t)nb, 0);
   for (int b = 0; b < nb; b++) {
     int first, count;
     pipe_slices(P.n_slices, nb, b, &first, &count);
@@ -227,16 +208,21 @@ int setup_persist(fb_fem_s* h) {
       if (r.y < r.x) continue;
       for (int sl = r.x >> 6; sl <= (r.y >> 6) && sl < P.n_slices; sl++) {
         const int o = owner[sl];
-        if (o != b && !mark[o]) { mark[o] = 1; n++; }
+        if (o != b && !mark[o]) { mark[o] = 1; n++; if ((o & 7) != (b & 7)) far[b] = 1; }
       }
     }
-    if (n > kPipeMaxProducers || poll_all) { cnt[b] = -1; h->pipe_max_producers = -1; continue; }
+    if (n > kPipeMaxProducers || poll_all) { cnt[b] = -1; far[b] = 1; h->pipe_max_producers = -1; continue; }
     cnt[b] = n;
     if (h->pipe_max_producers >= 0) h->pipe_max_producers = std::max(h->pipe_max_producers, n);
     for (int o = 0, k = 0; o < nb; o++) if (mark[o]) prod[(size_t)b * kPipeMaxProducers + k++] = o;
   }
   FB_TRY(h->pipe_prod.upload(prod, s));
   FB_TRY(h->pipe_prod_count.upload(cnt, s));
+  FB_TRY(h->pipe_prod_xcd.upload(far, s));
+  {
+    const char* e = getenv("FEMBRAIN_PIPE_PLAIN_STORES");
+    h->pipe_plain_local = e ? atoi(e) : 0;
+  }
   return FB_OK;
 }
 
@@ -698,75 +684,12 @@ bool host_finished(const CGState& s) {
 
 // Jacobi-PCG on the assembled system, rhs b -> h->x.  iters_out: + converged / - not (CGSolver.cpp:189).
 
-// `n` merged iterations starting at (1-based) iteration `it`, none of them an exact-residual one, in one persistent launch
-int launch_persist(fb_fem_s* h, int it, int n) {
-  PersistArgs pa;
-  pa.post = h->persist_post.p; pa.flags = h->persist_flags.p; pa.error = h->persist_flags.p + h->persist_blocks + 4;
-  pa.seq_base = h->persist_seq; pa.first_iter = it; pa.n_iters = n;
-  pa.timeout_ticks = h->persist_timeout_ticks;
-  pa.timing = h->persist_timing.p;
-  pa.dsoa = h->persist_dsoa.p; pa.n_pad = (size_t)h->plan.n_slices * 64;
-  h->persist_seq += (unsigned int)n;
-  hipLaunchKernelGGL(k_persist_planes, dim3((unsigned)ceil_div((long long)pa.n_pad, (long long)kBlock)), dim3(kBlock), 0, h->stream, h->plan.n_owned, pa.n_pad,
-                     h->d.p, h->persist_dsoa.p);
-  // LDS: the sync buffers, then as many slots of every slice as fit (resident part of the matrix, fp32 storage only); the
-  // request is always more than half a CU's 160 KB, so exactly one workgroup lands on each CU
-  const size_t lds_max = 160 * 1024, sync_bytes = sizeof(double) * kPersistSyncDoubles, slot_bytes = (size_t)h->persist_waves * 10 * 64 * 4;
-  static const int want_slots = getenv("FEMBRAIN_PERSIST_LDS_SLOTS") ? atoi(getenv("FEMBRAIN_PERSIST_LDS_SLOTS")) : 64;
-  pa.lds_slots = h->f64 ? 0 : std::max(0, std::min(want_slots, (int)((lds_max - sync_bytes) / slot_bytes)));
-  const size_t lds = lds_max;
-  const dim3 grid(h->persist_blocks), block(64 * h->persist_waves);
-#define FB_PERSIST(MT, C16, KR, WMAX, KLT)                                                                                                        \
-  do {                                                                                                                                       \
-    static bool attr = false;                                                                                                                \
-    if (!attr) {                                                                                                                             \
-      FB_HIP(hipFuncSetAttribute((const void*)k_pcg_persist<MT, C16, KR, WMAX, KLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));  \
-      attr = true;                                                                                                                           \
-    }                                                                                                                                        \
-    hipLaunchKernelGGL((k_pcg_persist<MT, C16, KR, WMAX, KLT>), grid, block, lds, h->stream, sell_view(h), (const MT*)h->vals.p, (const MT*)h->dlo.p, \
-                       h->invdiag.p, h->x.p, h->r.p, h->d.p, h->st.p, pa);                                                                   \
-  } while (0)
-  // register-resident slots by workgroup size: 512 registers per lane and SIMD are shared by ceil(waves / 4) wavefronts
-  // instantiation by workgroup size: WMAX bounds the wavefronts (registers per lane), KLT is the number of slots per slice that
-  // fit into the CU's 160 KB of LDS beside the sync buffers (fp32 storage only): (160 KB - 13 KB) / (waves * 2560 B)
-#define FB_PERSIST_W(MT, C16, LDSOK)                                                                  \
-  do {                                                                                                \
-    const int w = h->persist_waves, kl = LDSOK ? pa.lds_slots : 0;                                    \
-    if (w <= 8 && kl >= 7) { pa.lds_slots = 7; FB_PERSIST(MT, C16, 0, 8, (LDSOK ? 7 : 0)); }          \
-    else if (w <= 8) { pa.lds_slots = 0; FB_PERSIST(MT, C16, 0, 8, 0); }                              \
-    else if (w <= 12 && kl >= 5) { pa.lds_slots = 5; FB_PERSIST(MT, C16, 0, 12, (LDSOK ? 5 : 0)); }   \
-    else if (w <= 12 && kl >= 4) { pa.lds_slots = 4; FB_PERSIST(MT, C16, 0, 12, (LDSOK ? 4 : 0)); }   \
-    else if (w <= 12) { pa.lds_slots = 0; FB_PERSIST(MT, C16, 0, 12, 0); }                            \
-    else if (kl >= 3) { pa.lds_slots = 3; FB_PERSIST(MT, C16, 0, 16, (LDSOK ? 3 : 0)); }              \
-    else { pa.lds_slots = 0; FB_PERSIST(MT, C16, 0, 16, 0); }                                         \
-  } while (0)
-  if (h->f64) { if (h->c16) FB_PERSIST_W(double, true, false); else FB_PERSIST_W(double, false, false); }
-  else { if (h->c16) FB_PERSIST_W(float, true, true); else FB_PERSIST_W(float, false, true); }
-#undef FB_PERSIST_W
-#undef FB_PERSIST
-  FB_HIP(hipGetLastError());
-  return FB_OK;
-}
-
-// iterations it .. it + n - 1 of the merged solver: persistent launches between the exact-residual iterations
-int pcg_run_persist(fb_fem_s* h, int it, int n, const double* b) {
-  const int end = it + n;
-  while (it < end) {
-    if (it % 30 == 0) { FB_TRY(pcg_iteration(h, it, b)); it++; continue; }
-    int stop = std::min(end, (it / 30 + 1) * 30);  // the next exact-residual iteration, or the end of the batch
-    if (const char* e = getenv("FEMBRAIN_PERSIST_MAX_RUN")) stop = std::min(stop, it + std::max(1, atoi(e)));  // test knob: cut the run into shorter launches
-    FB_TRY(launch_persist(h, it, stop - it));
-    it = stop;
-  }
-  return FB_OK;
-}
-
 // One launch of the pipelined persistent solver (pcg_pipe.hip.h): `start` 1 = new solve from x = 0, 2 = new solve from the x in
 // memory, 0 = continue; at most n_iters iterations
 int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps, int max_iter) {
   PipeArgs pa;
   pa.post = h->pipe_post.p; pa.flags = h->pipe_flags.p; pa.error = h->pipe_flags.p + h->persist_blocks + 4; pa.seqs = h->pipe_flags.p + h->persist_blocks + 8;
-  pa.producers = h->pipe_prod.p; pa.prod_count = h->pipe_prod_count.p;
+  pa.producers = h->pipe_prod.p; pa.prod_count = h->pipe_prod_count.p; pa.prod_xcd = h->pipe_prod_xcd.p; pa.plain_local = h->pipe_plain_local;
   pa.start = start; pa.n_iters = n_iters; pa.eps2 = eps * eps; pa.max_iter = max_iter;
   pa.timeout_ticks = h->persist_timeout_ticks;
   pa.timing = h->persist_timing.p;
@@ -775,6 +698,7 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   // LDS: the sync buffers, then KLT slots of every slice; the request is the whole 160 KB of a CU, so exactly one workgroup lands on each
   const size_t lds = 160 * 1024;
   const dim3 grid(h->persist_blocks), block(64 * h->persist_waves);
+  FB_HIP(hipEventRecord(h->ev_p[0], h->stream));
 #define FB_PIPE(C16, WMAX, KLT, TIMING)                                                                                                        \
   do {                                                                                                                                         \
     static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)WMAX * KLT * 10 * 64 * 4 <= 160 * 1024, "LDS budget of k_pcg_pipe");             \
@@ -787,11 +711,6 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
                        (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);       \
   } while (0)
   // the instantiations: (wavefronts, LDS slots) = (8, 7) up to 8 slices per CU, (12, 5) up to 12; 16- or 32-bit column words
-  if (getenv("FEMBRAIN_PIPE_NOASM")) {  // debugging aid
-    hipFuncSetAttribute((const void*)k_pcg_pipe<float, true, 8, 7, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_pcg_pipe<float, true, 8, 7, false, true>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p,
-                       (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);
-  } else
   if (pa.timing) {  // development build with the phase clocks: the 1M-tet configuration only
     if (h->pipe_wmax == 12 && h->c16) FB_PIPE(true, 12, 5, true);
     else return fail(FB_EINVAL, "FEMBRAIN_PERSIST_TIMING is built for 9..12 slices per CU with 16-bit column words");
@@ -799,7 +718,7 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   else { if (h->c16) FB_PIPE(true, 12, 5, false); else FB_PIPE(false, 12, 5, false); }
 #undef FB_PIPE
   FB_HIP(hipGetLastError());
-  h->persist_launches++;
+  FB_HIP(hipEventRecord(h->ev_p[1], h->stream));
   return FB_OK;
 }
 
@@ -836,10 +755,15 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
   memset(&fin, 0, sizeof fin);
   for (;;) {
     FB_TRY(launch_pipe(h, b, start, cut, eps, max_iter));
+    h->persist_launches++;
     unsigned int err = 0;
     FB_HIP(hipMemcpyAsync(&h->st_host[0], h->st.p, sizeof(CGState), hipMemcpyDeviceToHost, s));
     FB_HIP(hipMemcpyAsync(&err, h->pipe_flags.p + h->persist_blocks + 4, sizeof err, hipMemcpyDeviceToHost, s));
     FB_HIP(hipStreamSynchronize(s));
+    {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, h->ev_p[0], h->ev_p[1]) == hipSuccess) h->persist_seconds += ms * 1e-3;
+    }
     if (err) {
       // A wait inside the launch gave up: the workgroups were not all resident (the device is shared with another process's
       // kernels?).  The launch wrote nothing back, so the solve is repeated from the same start with a launch per phase, and
@@ -856,6 +780,7 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
       h->last_pcg_path = FB_PCG_PATH_FALLBACK;
       return rc;
     }
+    h->persist_iterations += h->st_host[0].iter - (start == 0 ? fin.iter : 0);
     fin = h->st_host[0];
     if (fin.done) break;
     if (fin.iter > max_iter) return fail(FB_EDEVICE, "internal: persistent PCG ran past max_iter (iter %d)", fin.iter);
@@ -871,10 +796,9 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
 }
 
 int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state) {
-  if (h->persist && h->persist_kind == 2 && (h->prm.pcg_variant == FB_PCG_MERGED || h->prm.pcg_variant == FB_PCG_PERSISTENT))
+  if (h->persist && (h->prm.pcg_variant == FB_PCG_MERGED || h->prm.pcg_variant == FB_PCG_PERSISTENT))
     return pcg_solve_pipe(h, b, eps, max_iter, iters_out, final_state);
-  h->last_pcg_path = h->persist ? FB_PCG_PATH_PERSISTENT : FB_PCG_PATH_TWO_LAUNCH;
-  const bool was_warm = h->pcg_warm;
+  h->last_pcg_path = FB_PCG_PATH_TWO_LAUNCH;
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
   double* sc = nullptr;
@@ -908,7 +832,7 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
   bool finished = false;
   // replay pays on small meshes only (us per iteration, replay vs launches: 8.2 vs 9.6 at 22k tets, 9.4 vs 9.8 at 105k,
   // 13.1 vs 12.9 at 257k, 29.4 vs 29.1 at 1M); sharded kernels carry sequence numbers and are launched one by one
-  const bool graphable = h->use_graph && !h->persist && h->prm.pcg_variant != FB_PCG_BLOCK_JACOBI && P.n_slices <= 512 && (!h->comm || h->comm->n_ranks == 1);
+  const bool graphable = h->use_graph && h->prm.pcg_variant != FB_PCG_BLOCK_JACOBI && P.n_slices <= 512 && (!h->comm || h->comm->n_ranks == 1);
   while (!finished) {
     const int n = std::min(kBatch, max_iter - it + 1);
     bool replayed = false;
@@ -922,10 +846,7 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
         h->use_graph = false;
       }
     }
-    if (!replayed && h->persist && h->prm.pcg_variant != FB_PCG_REFERENCE && h->prm.pcg_variant != FB_PCG_BLOCK_JACOBI) {
-      FB_TRY(pcg_run_persist(h, it, n, b));
-      it += n;
-    } else if (!replayed) {
+    if (!replayed) {
       for (int k = 0; k < n; k++, it++) FB_TRY(pcg_iteration(h, it, b));
     }
     FB_HIP(hipMemcpyAsync(&h->st_host[slot], h->st.p, sizeof(CGState), hipMemcpyDeviceToHost, s));
@@ -942,43 +863,6 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
   }
   FB_HIP(hipStreamSynchronize(s));
   if (h->p2p) FB_TRY(p2p_check(h->p2p, s));
-  if (h->persist && h->persist_timing.p) {  // development aid: where the iterations of this solve spent their time
-    std::vector<long long> tm((size_t)h->persist_blocks * kPersistMaxWaves * 5);
-    FB_TRY(h->persist_timing.download(tm.data(), tm.size(), s));
-    FB_TRY(h->persist_timing.zero(s));
-    const char* names[4] = {"A products", "post+sweep1", "B update+publish", "sweep2+acquire"};
-    for (int k = 0; k < 4; k++) {
-      double mn = 1e30, mx = 0, av = 0;
-      int cnt = 0;
-      for (int b = 0; b < h->persist_blocks; b++)
-        for (int w = 0; w < h->persist_waves; w++) {
-          const long long* t = &tm[((size_t)b * kPersistMaxWaves + w) * 5];
-          if (t[4] <= 0) continue;
-          const double us = (double)t[k] / (double)t[4] * 0.01;
-          mn = std::min(mn, us); mx = std::max(mx, us); av += us; cnt++;
-        }
-      fprintf(stderr, "[fembrain] persistent PCG %-18s per iteration: avg %.2f us  min %.2f  max %.2f (over %d waves)\n", names[k], av / std::max(cnt, 1), mn, mx, cnt);
-    }
-  }
-  if (h->persist) {
-    unsigned int err = 0;
-    FB_HIP(hipMemcpyAsync(&err, h->persist_flags.p + h->persist_blocks + 4, sizeof err, hipMemcpyDeviceToHost, s));
-    FB_HIP(hipStreamSynchronize(s));
-    if (err) {
-      // a wait inside the launch gave up: the workgroups were not all resident (the device is shared with another process's
-      // kernels?).  Nothing is lost but time: the solve starts from x = 0 anyway, so it is run again with a launch per phase,
-      // and this handle stays with that.
-      FB_TRY(h->persist_flags.zero(s));
-      h->persist = false;
-      h->persist_fallbacks++;
-      if (getenv("FEMBRAIN_PERSIST_STRICT") && atoi(getenv("FEMBRAIN_PERSIST_STRICT")) != 0)
-        return fail(FB_EDEVICE, "persistent PCG: a grid-wide wait timed out (the workgroups were not all resident?)");
-      h->pcg_warm = was_warm;
-      const int rc = pcg_solve(h, b, eps, max_iter, iters_out, final_state);
-      h->last_pcg_path = FB_PCG_PATH_FALLBACK;
-      return rc;
-    }
-  }
   // the newest snapshot is in the slot written last
   fin = h->st_host[slot ^ 1];
   if (!host_finished(fin)) return fail(FB_EDEVICE, "internal: PCG batches ended without a terminal state (iter %d)", fin.iter);
@@ -1250,6 +1134,7 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(FB_EDEVICE, "hipStreamCreate failed"); break; }
     for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) rc = fail(FB_EDEVICE, "hipEventCreate failed");
     for (auto& e : h->ev_batch) if (hipEventCreate(&e) != hipSuccess) rc = fail(FB_EDEVICE, "hipEventCreate failed");
+    for (auto& e : h->ev_p) if (hipEventCreate(&e) != hipSuccess) rc = fail(FB_EDEVICE, "hipEventCreate failed");
     if (rc != FB_OK) break;
     if (hipHostMalloc((void**)&h->st_host, 2 * sizeof(CGState), hipHostMallocDefault) != hipSuccess) { rc = fail(FB_ENOMEM, "hipHostMalloc failed"); break; }
     if (const char* e = getenv("FEMBRAIN_GRAPH")) h->use_graph = atoi(e) != 0;
@@ -1375,6 +1260,7 @@ int fb_fem_destroy(fb_fem_t h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->ev_batch) if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->ev_p) if (e) (void)hipEventDestroy(e);
   if (h->st_host) (void)hipHostFree(h->st_host);
   if (h->p2p) p2p_detach(h->p2p);
   drop_graph(h);
@@ -1911,12 +1797,7 @@ int fb_fem_persist_info(fb_fem_t h, int* waves_per_cu, int* workgroups, int* lds
   if (workgroups) *workgroups = h->persist ? h->persist_blocks : 0;
   if (lds_slots) {
     *lds_slots = 0;
-    if (h->persist && h->persist_kind == 2) *lds_slots = h->pipe_klt;
-    else if (h->persist && !h->f64) {
-      const int fit = (int)((160 * 1024 - sizeof(double) * kPersistSyncDoubles) / ((size_t)h->persist_waves * 10 * 64 * 4));
-      const int w = h->persist_waves;
-      *lds_slots = w <= 8 ? (fit >= 7 ? 7 : 0) : (w <= 12 ? (fit >= 5 ? 5 : (fit >= 4 ? 4 : 0)) : (fit >= 3 ? 3 : 0));
-    }
+    if (h->persist) *lds_slots = h->pipe_klt;
   }
   return h->persist ? 1 : 0;
 }
@@ -1924,14 +1805,21 @@ int fb_fem_persist_info(fb_fem_t h, int* waves_per_cu, int* workgroups, int* lds
 int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches, int* persist_fallbacks, int* max_producers) {
   if (!h) return fail(FB_EINVAL, "null FEM handle");
   if (name && name_len > 0) {
-    if (h->persist && h->persist_kind == 2) snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_klt);
-    else if (h->persist) snprintf(name, name_len, "k_pcg_persist");
+    if (h->persist) snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_klt);
     else name[0] = 0;
   }
   if (persist_launches) *persist_launches = h->persist_launches;
   if (persist_fallbacks) *persist_fallbacks = h->persist_fallbacks;
-  if (max_producers) *max_producers = h->persist && h->persist_kind == 2 ? h->pipe_max_producers : 0;
+  if (max_producers) *max_producers = h->persist ? h->pipe_max_producers : 0;
   return h->last_pcg_path;
+}
+
+int fb_fem_persist_stats(fb_fem_t h, int* launches, double* seconds, long long* iterations) {
+  if (!h) return fail(FB_EINVAL, "null FEM handle");
+  if (launches) *launches = h->persist_launches;
+  if (seconds) *seconds = h->persist_seconds;
+  if (iterations) *iterations = h->persist_iterations;
+  return FB_OK;
 }
 
 int fb_fem_time_persist(fb_fem_t h, int reps, int n_iters, double* seconds_per_launch) {
@@ -1939,37 +1827,22 @@ int fb_fem_time_persist(fb_fem_t h, int reps, int n_iters, double* seconds_per_l
   if (reps < 1 || n_iters < 1 || n_iters > 100000 || !seconds_per_launch) return fail(FB_EINVAL, "bad arguments");
   if (!h->persist) return fail(FB_EINVAL, "this handle does not run the persistent PCG iterations");
   if (!h->system_valid) FB_TRY(assemble_system(h));
-  const FemPlan& P = h->plan;
   double total = 0.0;
   for (int r = -1; r < reps; r++) {  // r = -1: warm-up
     float ms = 0;
-    if (h->persist_kind == 2) {
-      // a solve of the current right-hand side with a tolerance it cannot reach, cut after n_iters iterations
-      FB_HIP(hipEventRecord(h->ev[0], h->stream));
-      FB_TRY(launch_pipe(h, h->rhs.p, 1, n_iters, 1e-30, 1 << 30));
-      FB_HIP(hipEventRecord(h->ev[1], h->stream));
-    } else {
-      if (n_iters > 29) return fail(FB_EINVAL, "the merged persistent kernel runs at most 29 iterations per launch");
-      // every launch starts from the state a solve of the current right-hand side starts from, with a tolerance it cannot reach
-      hipLaunchKernelGGL(k_cg_init, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->rhs.p, h->invdiag.p, h->x.p, h->r.p, h->d.p,
-                         h->part_b.p);
-      hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, h->stream, h->st.p, h->part_b.p, h->grid, (const double*)nullptr, 1e-30, 1 << 30);
-      FB_HIP(hipGetLastError());
-      // the plane conversion is part of the launch sequence of a run and is timed with it
-      FB_HIP(hipEventRecord(h->ev[0], h->stream));
-      FB_TRY(launch_persist(h, 1, n_iters));
-      FB_HIP(hipEventRecord(h->ev[1], h->stream));
-    }
+    // a solve of the current right-hand side with a tolerance it cannot reach, cut after n_iters iterations
+    FB_HIP(hipEventRecord(h->ev[0], h->stream));
+    FB_TRY(launch_pipe(h, h->rhs.p, 1, n_iters, 1e-30, 1 << 30));
+    FB_HIP(hipEventRecord(h->ev[1], h->stream));
     FB_HIP(hipStreamSynchronize(h->stream));
     FB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
     if (r >= 0) total += ms * 1e-3;
   }
   unsigned int err = 0;
-  DevBuf<unsigned int>& fl = h->persist_kind == 2 ? h->pipe_flags : h->persist_flags;
-  FB_HIP(hipMemcpy(&err, fl.p + h->persist_blocks + 4, sizeof err, hipMemcpyDeviceToHost));
+  FB_HIP(hipMemcpy(&err, h->pipe_flags.p + h->persist_blocks + 4, sizeof err, hipMemcpyDeviceToHost));
   if (err) {
-    FB_TRY(fl.zero(h->stream));
-    if (h->persist_kind == 2) FB_TRY(h->pipe_post.zero(h->stream));
+    FB_TRY(h->pipe_flags.zero(h->stream));
+    FB_TRY(h->pipe_post.zero(h->stream));
     return fail(FB_EDEVICE, "persistent PCG: a wait inside the launch timed out");
   }
   h->system_valid = false;

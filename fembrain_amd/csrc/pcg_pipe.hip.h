@@ -46,6 +46,8 @@ struct PipeArgs {
   unsigned int* seqs;         // [2] publish / sum sequence numbers reached by the previous launch (block 0 writes them at the end)
   const int* producers;       // [n_blocks][64] workgroups whose rows this workgroup's columns touch; prod_count < 0: poll all
   const int* prod_count;      // [n_blocks]
+  const int* prod_xcd;        // [n_blocks] non-zero: a producer (= consumer) of this workgroup sits on another XCD, or it polls all
+  int plain_local;            // non-zero: workgroups without such a neighbour publish with plain stores (see publish)
   int start;                  // 0 continue a solve (state from memory), 1 new solve from x = 0, 2 new solve from the x in memory
   int n_iters;                // at most this many iterations in this launch
   double eps2;                // squared tolerance (start != 0; a continued solve reads the CGState)
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_slice_colrange(int n_slices, int n_o
 // ceil(WMAX / 4) wavefronts).  KLT: the first KLT slots of every slice (9 values + the column id per lane) are loaded into LDS
 // ONCE per launch -- the matrix does not change during a solve; slots beyond are streamed every product as in k_spmv.
 // TIMING: the development build with per-phase clocks (FEMBRAIN_PERSIST_TIMING=1).
-template <typename MT, bool C16, int WMAX, int KLT, bool TIMING, bool NOASM = false>
+template <typename MT, bool C16, int WMAX, int KLT, bool TIMING>
 __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo,
                                                         const double* __restrict__ invdiag, const double* __restrict__ bvec, double* __restrict__ xg,
                                                         double* __restrict__ rg, double* __restrict__ wg, double* __restrict__ zg,
@@ -168,15 +170,29 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
   long long tm[TIMING ? 6 : 1] = {0}, tprev = TIMING ? wall_clock64() : 0;  // (TIMING: the phase clocks cost 14 registers per lane)
   auto lap = [&](int k) { if (TIMING) { const long long t = wall_clock64(); tm[k] += t - tprev; tprev = t; } };
 
-  // y = A vin: publish vin, wait for the producers of this workgroup's columns, multiply.  post_sums: the two wave sums in
-  // wsum[.][wv] are this iteration's local parts of gamma and delta -- posted with the flag, read after the product.
-  auto product = [&](const double* vin, double* y, bool post_sums) {
+  // Stores of the next product's input vector into the plane buffer of the next publish number (512 contiguous bytes per wave
+  // and plane).  Write-through (sc1) where a workgroup of ANOTHER XCD gathers these rows; a workgroup all of whose consumers
+  // share its XCD (= its L2) may store plainly (pa.plain_local): the line then stays in that L2, the store is acknowledged
+  // there, and the consumers -- their L1 invalidated -- read it from there.
+  const bool through = pa.plain_local == 0 || pa.prod_xcd[blockIdx.x] != 0;  // workgroup-uniform
+  auto publish = [&](const double* vin) {
     pub++;
     double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
     if (rvalid) {
+      if (through) {
 #pragma unroll
-      for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * pa.n_pad + (size_t)row, vin[a]);  // 512 contiguous bytes per wave and plane
+        for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * pa.n_pad + (size_t)row, vin[a]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < 3; a++) pl[a * pa.n_pad + (size_t)row] = vin[a];
+      }
     }
+  };
+  // y = A vin for the vector published last: drain the stores, flag, wait for the producers of this workgroup's columns,
+  // multiply.  post_sums: the two wave sums in wsum[.][wv] are this iteration's local parts of gamma and delta -- posted with
+  // the flag, read after the product.
+  auto product = [&](const double* vin, double* y, bool post_sums) {
+    double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     lap(0);  // publish, drained
@@ -248,17 +264,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
       }
       // the streamed slots: hand-pipelined loads (pcg_pipe_stream.hip.h)
       const int n_str = width - KLT;
-      if (NOASM) {  // debugging aid: the compiler's loop
-        for (int k = KLT; k < width; k++) {
-          const int col = C16 ? row + (int)cd[(size_t)k * 64] : ci[(size_t)k * 64];
-          const double* xp = pl + (size_t)col;
-          const double x0 = xp[0], x1 = xp[pa.n_pad], x2 = xp[2 * pa.n_pad];
-          const MT* vk = v + (size_t)k * 9 * 64;
-          y0 += (double)vk[0 * 64] * x0 + (double)vk[1 * 64] * x1 + (double)vk[2 * 64] * x2;
-          y1 += (double)vk[3 * 64] * x0 + (double)vk[4 * 64] * x1 + (double)vk[5 * 64] * x2;
-          y2 += (double)vk[6 * 64] * x0 + (double)vk[7 * 64] * x1 + (double)vk[8 * 64] * x2;
-        }
-      } else if (n_str > 0) {
+      if (n_str > 0) {
         int so_k = so + KLT;
         asm volatile("" : "+s"(so_k));  // opaque: keeps the two offsets below from being hoisted out of the solver loop into live registers
         pipe_stream_slots<C16>(n_str, ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     phase = PH_INIT_W;
   }
 
-  bool done = false;
+  bool done = false, published = false;  // published: the stores of the next product's input are on their way already
   double gamma = 0.0;
   int it_done = 0;
   while (!failed) {
@@ -311,7 +317,16 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
 #pragma unroll
       for (int a = 0; a < 3; a++) vin[a] = xr[a];
     } else if (phase == PH_ITER) {
-      // local parts of gamma = r . u and delta = w . u (u = r / diag); the product's input is m = w / diag
+#pragma unroll
+      for (int a = 0; a < 3; a++) vin[a] = iv[a] * wr[a];  // m = w / diag
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; a++) vin[a] = iv[a] * rr[a];
+    }
+    if (!published) publish(vin);
+    published = false;
+    if (phase == PH_ITER) {
+      // local parts of gamma = r . u and delta = w . u (u = r / diag), while the stores drain
       const double u[3] = {iv[0] * rr[0], iv[1] * rr[1], iv[2] * rr[2]};
       double a0 = rr[0] * u[0] + rr[1] * u[1] + rr[2] * u[2];
       double a1 = wr[0] * u[0] + wr[1] * u[1] + wr[2] * u[2];
@@ -319,11 +334,6 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
       int wvo = wv;
       asm volatile("" : "+v"(wvo));  // opaque: the LDS address is formed here instead of living in a register through the solve
       if (lane == 0) { wsum[wvo] = a0; wsum[16 + wvo] = a1; }
-#pragma unroll
-      for (int a = 0; a < 3; a++) vin[a] = iv[a] * wr[a];
-    } else {
-#pragma unroll
-      for (int a = 0; a < 3; a++) vin[a] = iv[a] * rr[a];
     }
     double y[3];
     product(vin, y, phase == PH_ITER);
@@ -392,24 +402,34 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     else { beta = gamma / gamma_old; alpha = gamma / (delta - beta * gamma / alpha_old); }
     fresh = false;
     // ---- recurrences, in registers (y = n = A m) ----
+    iter++;
+    it_done++;
+    gamma_old = gamma; alpha_old = alpha;
+    const bool refresh = iter % 30 == 0;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       zr[a] = y[a] + beta * zr[a];
       sr[a] = wr[a] + beta * sr[a];
+    }
+    if (!refresh) {
+      // w first: the next product's input m = w / diag leaves now, the rest of the recurrences runs while its stores drain.
+      // (Every workgroup has posted this iteration's sums, i.e. finished the product before this one: the buffer is free.)
+      double m[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) { wr[a] = wr[a] - alpha * zr[a]; m[a] = iv[a] * wr[a]; }
+      publish(m);
+      published = true;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
       pr[a] = iv[a] * rr[a] + beta * pr[a];
       xr[a] = xr[a] + alpha * pr[a];
     }
-    iter++;
-    it_done++;
-    gamma_old = gamma; alpha_old = alpha;
-    if (iter % 30 == 0) {
+    if (refresh) {
       phase = PH_REFRESH_X;  // exact residual (CGSolver.cpp:159-166), and the w that goes with it: two more products
     } else {
 #pragma unroll
-      for (int a = 0; a < 3; a++) {
-        rr[a] = rr[a] - alpha * sr[a];
-        wr[a] = wr[a] - alpha * zr[a];
-      }
+      for (int a = 0; a < 3; a++) rr[a] = rr[a] - alpha * sr[a];
     }
     lap(4);  // recurrences
   }

@@ -253,6 +253,12 @@ class FemIntegrator:
         path = self._L.fb_fem_pcg_path(self.h, name, 96, C.byref(nl), C.byref(nf), C.byref(mp))
         return dict(path=path, kernel=name.value.decode(), launches=nl.value, fallbacks=nf.value, max_producers=mp.value)
 
+    def persist_stats(self):
+        """(persistent launches of this handle's solves so far, their device seconds, the PCG iterations they ran)"""
+        n, sec, it = C.c_int(0), C.c_double(0), C.c_longlong(0)
+        _l.check(self._L.fb_fem_persist_stats(self.h, C.byref(n), C.byref(sec), C.byref(it)))
+        return n.value, sec.value, it.value
+
     def time_persist(self, reps=10, n_iters=29):
         s = C.c_double(0)
         _l.check(self._L.fb_fem_time_persist(self.h, reps, n_iters, C.byref(s)))

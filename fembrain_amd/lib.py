@@ -129,6 +129,7 @@ def lib():
         "fb_fem_set_newmark": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, C.c_double]),
         "fb_fem_persist_info": (C.c_int, [vp, _ip, _ip, _ip]),
         "fb_fem_pcg_path": (C.c_int, [vp, C.c_char_p, C.c_int, _ip, _ip, _ip]),
+        "fb_fem_persist_stats": (C.c_int, [vp, _ip, _dp, C.POINTER(C.c_longlong)]),
         "fb_fem_time_persist": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
         "fb_fem_iteration_bytes": (C.c_int, [vp, _dp]),
         "fb_comm_unique_id": (C.c_int, [_bp]),

@@ -248,6 +248,9 @@ int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches,
  * iterations (tolerance out of reach), HIP events on the handle's stream around the launch; the difference of two lengths
  * prices an iteration without the launch's fixed cost */
 int fb_fem_time_persist(fb_fem_t h, int reps, int n_iters, double* seconds_per_launch);
+/* the persistent launches of the SOLVES this handle has made so far (fb_fem_step, fb_fem_pcg; not the timing helper above): how
+ * many, their device seconds (HIP events on the handle's stream around each launch) and the PCG iterations they ran */
+int fb_fem_persist_stats(fb_fem_t h, int* launches, double* seconds, long long* iterations);
 /* algorithmic bytes of ONE Jacobi-PCG iteration on this system: BSR SpMV + the fused lower bound of the vector
  * traffic (9 fp64 vector streams) */
 int fb_fem_iteration_bytes(fb_fem_t h, double* bytes);

@@ -15,6 +15,8 @@ at test time.
   fem_peanut.npz  data/models/blobtree/peanut.veg (3,224 nodes / 12,947 tets: a mesh FemBrain itself simulates -- its polygonizer's
                   surface vertices tetrahedralized by TetGen): mesh (float32 positions as the file prints them), q after 2 steps under
                   the reference load (-10000 per y-DOF) and under -10, the tenth of the nodes with the lowest y clamped
+  fem_cube56_step1.npz, fem_cube58_step1.npz   (round 3, `python make_fem_golden.py cube 56`) the first reference-load step of the
+                  56^3 / 58^3 truth cubes (998,250 / 1,111,158 tets): iteration count, norms, q and qvel at 2,000 seeded DOFs
   fem_beam3.npz   data/models/beam3/beam3_tet.veg (208 nodes / 450 tets, Vega's own sample) with beam3.bou clamps:
                   mesh, the reference's consistent mass matrix file beam3_tet.mass (a known answer shipped by the
                   reference), and q after 3 steps with -10 per y-DOF
@@ -190,8 +192,33 @@ def peanut():
     print("peanut:", v.shape, t.shape, "fixed", len(fixed_vertices), "iters", ia_, ib_, "|q|", np.abs(qa[-1]).max(), np.abs(qb[-1]).max())
 
 
+def cube_big(n):
+    """Round 3: the FIRST step from rest of the n^3-node truth cube under the reference load (plane i = 0 clamped, -10000 per y-DOF,
+    CG eps 1e-6) by the reference build -- 56^3 = BASELINE config 4 (998,250 tets), 58^3 = the largest cube of 12 slices per CU:
+    PCG iteration count, |q|_2, |qvel|_2, max|q| and q, qvel at 2,000 seeded DOFs (one ~45 s reference run each)."""
+    import time
+    v, t = truth_cube(n, n, n, 0.1)
+    fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+    t0 = time.time()
+    r = RefFem(v, t)
+    r.integrator(fixed)
+    f = np.zeros(r.r)
+    f[1::3] = -10000.0
+    r.set_external_forces(f)
+    t1 = time.time()
+    it = r.step(cg_eps=1e-6)
+    q, qv = r.get_state()
+    idx = np.sort(np.random.default_rng(n).choice(r.r, size=2000, replace=False))
+    np.savez_compressed(os.path.join(HERE, "fem_cube%d_step1.npz" % n), n=n, iters=it, q_norm=np.linalg.norm(q), qvel_norm=np.linalg.norm(qv),
+                        q_maxabs=np.abs(q).max(), qvel_maxabs=np.abs(qv).max(), idx=idx, q=q[idx], qvel=qv[idx])
+    print("cube%d: %d tets, set-up %.1f s, step %.1f s, %d PCG iterations, |q| %.6f, max|q| %.6f" % (n, len(t), t1 - t0, time.time() - t1, it,
+          np.linalg.norm(q), np.abs(q).max()))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "linear":
+    if len(sys.argv) > 2 and sys.argv[1] == "cube":
+        cube_big(int(sys.argv[2]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "linear":
         cube5_linear()   # added later: leaves the other two files as they are
     elif len(sys.argv) > 1 and sys.argv[1] == "round2":
         cube5_warp2()    # round 2: the exact-tangent option and the Newmark step

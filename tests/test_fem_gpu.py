@@ -114,7 +114,9 @@ def test_system_spmv_pcg(gpu, prec, tol, spmv):
     it, xg = g.pcg(rhs_g, eps=1e-12, max_iter=20000)
     assert it > 0
     assert np.abs(xg - dv).max() <= max(50 * tol, 1e-8) * np.abs(dv).max()
-    for variant in (fl.FB_PCG_REFERENCE, fl.FB_PCG_FUSED):
+    for variant in (fl.FB_PCG_REFERENCE, fl.FB_PCG_PERSISTENT):
+        if variant == fl.FB_PCG_PERSISTENT and prec == fl.FB_MATRIX_F64:
+            continue    # the persistent solver keeps part of the matrix in LDS as fp32 words: FB_MATRIX_F32 only
         g2 = FemIntegrator(v, t, fixed, matrix_precision=prec, pcg_variant=variant)
         g2.set_q_state(q0, v0)
         g2.set_external_forces(fext)
@@ -129,7 +131,7 @@ def test_system_spmv_pcg(gpu, prec, tol, spmv):
 
 
 @pytest.mark.parametrize("spmv", [fl.FB_SPMV_ROWS, fl.FB_SPMV_SPLIT])
-@pytest.mark.parametrize("variant", [fl.FB_PCG_MERGED, fl.FB_PCG_REFERENCE, fl.FB_PCG_FUSED])
+@pytest.mark.parametrize("variant", [fl.FB_PCG_MERGED, fl.FB_PCG_REFERENCE, fl.FB_PCG_PERSISTENT])
 @pytest.mark.parametrize("prec", [fl.FB_MATRIX_F64, fl.FB_MATRIX_F32])
 def test_three_steps_reference_load(gpu, prec, variant, spmv):
     """q, qvel after 3 steps under the reference load (-10000 per y DOF, plane i=0 clamped, CG eps 1e-6).
@@ -140,6 +142,10 @@ def test_three_steps_reference_load(gpu, prec, variant, spmv):
     2e-5 (fp64 matrix)."""
     n = 9
     v, t, fixed = _cube(n)
+    if variant == fl.FB_PCG_PERSISTENT and prec == fl.FB_MATRIX_F64:
+        with pytest.raises(fl.FbError, match="FB_MATRIX_F32"):
+            FemIntegrator(v, t, fixed, matrix_precision=prec, pcg_variant=variant, spmv_kernel=spmv)
+        return
     o = OrcFem(v, t)
     o.integrator(fixed)
     g = FemIntegrator(v, t, fixed, matrix_precision=prec, pcg_variant=variant, spmv_kernel=spmv)
@@ -1011,41 +1017,219 @@ def test_failed_resync_poisons_the_handle_until_a_good_one(gpu):
     assert np.array_equal(g.get_q_state()[0], fresh.get_q_state()[0])
 
 
-@pytest.mark.parametrize("n", [14, 31, 40])
-def test_persistent_pcg_matches_merged_and_itself(gpu, n, monkeypatch):
-    """FB_PCG_PERSISTENT (all merged iterations between two exact-residual ones in one launch, vectors in registers, the sums
-    and the search direction handed between the workgroups inside the launch) against FB_PCG_MERGED: same iteration counts to
-    max(3, 2 %), same solution to the solver tolerance; and against ITSELF cut into one-iteration launches -- where every
-    hand-off is a kernel boundary instead of an in-launch flag -- bit for bit: a stale read inside the launch would show here.
-    Slices per workgroup: 1 (n = 14, 31: fewer slices than CUs / a few) and 4 (n = 40)."""
+# ---- the persistent pipelined solver (pcg_pipe.hip.h): every instantiation the dispatch can select ------------------------------
+# k_pcg_pipe<float, c16 | c32, (8, 7) | (12, 5)>: 16- or 32-bit column words; up to 8 slices per CU with 7 LDS-resident slots, 9..12
+# with 5.  Each is checked against the oracle or a reference-built golden (fem_cube56_step1.npz / fem_cube58_step1.npz: the
+# reference's own CorotationalLinearFEM + CGSolver, tests/golden/make_fem_golden.py) AND against the two-launch solver of the same
+# library; fb_fem_pcg_path says which kernel ran.
+def _two_launch(monkeypatch, *a, **kw):
+    monkeypatch.setenv("FEMBRAIN_PCG_PERSIST", "0")
+    g = FemIntegrator(*a, **kw)
+    monkeypatch.delenv("FEMBRAIN_PCG_PERSIST")
+    assert not g.persist_info()[0] and g.pcg_path()["kernel"] == ""
+    return g
+
+
+def _persistent(monkeypatch, kernel, *a, c16=True, **kw):
+    monkeypatch.setenv("FEMBRAIN_PERSIST_MIN_WAVES", "1")   # (read once per process: the default starts at 4 slices per CU)
+    if not c16:
+        monkeypatch.setenv("FEMBRAIN_SPMV_C16", "0")
+    g = FemIntegrator(*a, pcg_variant=fl.FB_PCG_PERSISTENT, **kw)
+    if not c16:
+        monkeypatch.delenv("FEMBRAIN_SPMV_C16")
+    assert g.persist_info()[0] and g.pcg_path()["kernel"] == kernel, g.pcg_path()
+    return g
+
+
+@pytest.mark.parametrize("n,c16,kernel", [(14, True, "k_pcg_pipe<float,c16,8,7>"), (14, False, "k_pcg_pipe<float,c32,8,7>"),
+                                          (26, True, "k_pcg_pipe<float,c16,8,7>"), (26, False, "k_pcg_pipe<float,c32,8,7>")])
+def test_persistent_solver_against_the_oracle(gpu, monkeypatch, n, c16, kernel):
+    """One and two slices per workgroup (2,744 / 17,576 nodes): the solution of a tight solve and three reference-load steps against
+    the CPU oracle (CGSolver.cpp:129-190 restated), iteration counts within max(3, 2 %)."""
     v, t, fixed = _cube(n)
-    gm = FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_MERGED)
-    gp = FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT)
-    for g in (gm, gp):
+    o = OrcFem(v, t)
+    o.integrator(fixed)
+    g = _persistent(monkeypatch, kernel, v, t, fixed, c16=c16)
+    fext = np.zeros(o.r)
+    fext[1::3] = -10000.0
+    o.set_external_forces(fext)
+    g.set_external_forces(fext)
+    info, keff, rhs, dv = o.step(cg_eps=1e-12, cg_maxiter=20000, want=True)
+    o.set_state(np.zeros(o.r), np.zeros(o.r))
+    _, rhs_g = g.system()
+    assert np.abs(rhs_g - rhs).max() <= 2e-7 * np.abs(rhs).max()
+    it, xg = g.pcg(rhs_g, eps=1e-12, max_iter=20000)
+    assert abs(it - abs(info)) <= max(3, 0.02 * abs(info)), (it, info)
+    assert np.abs(xg - dv).max() <= 5e-6 * np.abs(dv).max()       # fp32-stored matrix: K entries rounded to 6e-8, cond ~ 1e2
+    for k in range(3):
+        o.set_external_forces(fext)
+        io, ig = abs(o.step()), g.do_timestep()
+        assert abs(ig - io) <= max(3, 0.02 * io), (k, ig, io)
+        qo, qg = o.get_state()[0], g.get_q_state()[0]
+        assert np.abs(qg - qo).max() <= 2e-4 * np.abs(qo).max(), k
+        assert g.last.pcg_path == fl.FB_PCG_PATH_PERSISTENT and g.last.persist_fallbacks == 0
+    p = g.pcg_path()
+    assert p["path"] == fl.FB_PCG_PATH_PERSISTENT and p["launches"] >= 4 and p["fallbacks"] == 0 and 0 < p["max_producers"] <= 64
+    g.close()
+
+
+@pytest.mark.parametrize("n", [14, 31, 40])
+def test_persistent_solver_matches_two_launch_and_itself(gpu, n, monkeypatch):
+    """The persistent solver against the two-launch solver (k_spmv + k_cg_fused, an independent code path: the handle is created
+    with FEMBRAIN_PCG_PERSIST=0 and says so): same iteration counts to max(3, 2 %), same solution to the solver tolerance; and
+    against ITSELF cut into launches of 1 and 7 iterations -- every state vector goes through memory at a cut, every hand-off
+    around it is a kernel boundary -- bit for bit: a stale read inside the launch would show here.  Slices per workgroup: 1
+    (n = 14), 2 (n = 31), 4 (n = 40).  Also the poll-all form of the neighbour wait (what an unstructured numbering gets)."""
+    v, t, fixed = _cube(n)
+    gm = _two_launch(monkeypatch, v, t, fixed)
+    gp = _persistent(monkeypatch, "k_pcg_pipe<float,c16,8,7>", v, t, fixed)
+    monkeypatch.setenv("FEMBRAIN_PERSIST_POLL_ALL", "1")
+    ga = _persistent(monkeypatch, "k_pcg_pipe<float,c16,8,7>", v, t, fixed)
+    monkeypatch.delenv("FEMBRAIN_PERSIST_POLL_ALL")
+    assert ga.pcg_path()["max_producers"] == -1 and gp.pcg_path()["max_producers"] > 0
+    for g in (gm, gp, ga):
         g.set_uniform_force(1, -10000.0)
     _, rhs = gm.system()
-    gp.system()
+    gp.system(); ga.system()
     itm, xm = gm.pcg(rhs, eps=1e-9, max_iter=20000)
     itp, xp = gp.pcg(rhs, eps=1e-9, max_iter=20000)
+    ita, xa = ga.pcg(rhs, eps=1e-9, max_iter=20000)
+    assert gm.pcg_path()["path"] == fl.FB_PCG_PATH_TWO_LAUNCH and gp.pcg_path()["path"] == fl.FB_PCG_PATH_PERSISTENT
     assert itm > 60 and abs(itp - itm) <= max(3, 0.02 * itm), (itp, itm)
-    assert np.abs(xp - xm).max() <= 1e-7 * np.abs(xm).max()
+    assert np.abs(xp - xm).max() <= 1e-6 * np.abs(xm).max()
+    assert ita == itp and np.array_equal(xa, xp)            # which flags are polled changes no bit
     assert not xp[fixed].any()
-    for run in ("1", "7"):
+    for run in ("1", "7", "30", "31"):
         monkeypatch.setenv("FEMBRAIN_PERSIST_MAX_RUN", run)
         itc, xc = gp.pcg(rhs, eps=1e-9, max_iter=20000)
         assert itc == itp and np.array_equal(xc, xp), run
     monkeypatch.delenv("FEMBRAIN_PERSIST_MAX_RUN")
-    itl, _ = gp.pcg(rhs, eps=1e-9, max_iter=37)            # iteration cap inside a run: -37 as the reference returns
-    assert itl == -37
+    for cap in (1, 29, 30, 37):
+        itl, xl = gp.pcg(rhs, eps=1e-9, max_iter=cap)       # iteration cap (also on and next to an exact-residual iteration): -cap as the reference returns
+        itk, xk = gm.pcg(rhs, eps=1e-9, max_iter=cap)
+        assert itl == -cap and itk == -cap and np.abs(xl - xk).max() <= 1e-9 * np.abs(xk).max(), cap
     itz, xz = gp.pcg(np.zeros_like(rhs), eps=1e-6, max_iter=100)
     assert itz == 0 and not xz.any()
-    # full steps: three reference-load steps against MERGED
+    # full steps: three reference-load steps against the two-launch solver
     for k in range(3):
         im, ip = gm.do_timestep(), gp.do_timestep()
         assert abs(im - ip) <= max(3, 0.02 * im)
         qm, qp = gm.get_q_state()[0], gp.get_q_state()[0]
         assert np.abs(qm - qp).max() <= 2e-5 * np.abs(qm).max()
-    gm.close(); gp.close()
+    gm.close(); gp.close(); ga.close()
+
+
+def _check_against_big_golden(g, gold, tol_q=2e-4):
+    g.set_uniform_force(1, -10000.0)
+    it = g.do_timestep()
+    q, qv, _ = g.get_q_state()
+    want = int(abs(gold["iters"]))
+    assert abs(it - want) <= max(3, 0.02 * want), (it, want)
+    assert np.abs(q[gold["idx"]] - gold["q"]).max() <= tol_q * float(gold["q_maxabs"])
+    assert np.abs(qv[gold["idx"]] - gold["qvel"]).max() <= tol_q * float(gold["qvel_maxabs"])
+    assert abs(np.linalg.norm(q) - float(gold["q_norm"])) <= tol_q * float(gold["q_norm"])
+    assert abs(np.linalg.norm(qv) - float(gold["qvel_norm"])) <= tol_q * float(gold["qvel_norm"])
+    return it, q
+
+
+@pytest.mark.parametrize("n,c16,kernel,slices_per_cu", [(56, True, "k_pcg_pipe<float,c16,12,5>", 11), (56, False, "k_pcg_pipe<float,c32,12,5>", 11),
+                                                        (58, True, "k_pcg_pipe<float,c16,12,5>", 12)])
+def test_default_handle_at_1M_tets_against_the_reference_built_golden(gpu, monkeypatch, n, c16, kernel, slices_per_cu):
+    """BASELINE config 4 (56^3 nodes, 998,250 tets: 11 slices per CU) and the largest cube the persistent solver takes (58^3, 1.11M
+    tets: 12 per CU): the DEFAULT handle -- no variant asked for -- runs the persistent kernel and reproduces the first reference-load
+    step of the reference's own CorotationalLinearFEM + CGSolver (tests/golden/fem_cube5x_step1.npz): iteration count within
+    max(3, 2 %), q and qvel at 2,000 seeded DOFs and their norms within 2e-4 (fp32-stored matrix, both solvers stop at 1e-6); the same
+    step by the two-launch solver of this library agrees as well."""
+    gold = np.load(os.path.join(GOLD, "fem_cube%d_step1.npz" % n))
+    v, t, fixed = _cube(n)
+    if not c16:
+        monkeypatch.setenv("FEMBRAIN_SPMV_C16", "0")
+    g = FemIntegrator(v, t, fixed)
+    monkeypatch.delenv("FEMBRAIN_SPMV_C16", raising=False)
+    on, waves, wgs, slots = g.persist_info()
+    assert on and waves == slices_per_cu and wgs == 256 and slots == 5 and g.pcg_path()["kernel"] == kernel
+    it, q = _check_against_big_golden(g, gold)
+    p = g.pcg_path()
+    assert p["path"] == fl.FB_PCG_PATH_PERSISTENT and p["launches"] == 1 and p["fallbacks"] == 0 and 0 < p["max_producers"] <= 64
+    g.close()
+    if c16:
+        g2 = _two_launch(monkeypatch, v, t, fixed)
+        it2, q2 = _check_against_big_golden(g2, gold)
+        assert abs(it2 - it) <= max(3, 0.02 * it) and np.abs(q2 - q).max() <= 2e-5 * np.abs(q).max()
+        g2.close()
+
+
+def test_persistent_solver_limits_are_refused_not_degraded(gpu, monkeypatch):
+    """FB_PCG_PERSISTENT asked for explicitly where it cannot run is an error, not a silent other solver: fp64 storage, more than 12
+    slices per CU.  The default (FB_PCG_MERGED) falls to the two-launch solver there and says so."""
+    v, t, fixed = _cube(9)
+    with pytest.raises(fl.FbError, match="FB_MATRIX_F32"):
+        FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT, matrix_precision=fl.FB_MATRIX_F64)
+    with pytest.raises(fl.FbError, match="unknown pcg_variant"):
+        FemIntegrator(v, t, fixed, pcg_variant=2)           # the removed FB_PCG_FUSED
+    v, t, fixed = _cube(60)                                # 216,000 nodes = 3,375 slices: 14 per CU
+    with pytest.raises(fl.FbError, match="slices per CU"):
+        FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT)
+    g = FemIntegrator(v, t, fixed)
+    assert not g.persist_info()[0]
+    g.set_uniform_force(1, -10000.0)
+    g.do_timestep()
+    assert g.last.pcg_path == fl.FB_PCG_PATH_TWO_LAUNCH
+    g.close()
+
+
+def test_persistent_timeout_falls_back_visibly_or_fails_strictly(gpu):
+    """A wait inside the persistent launch that times out (here: FEMBRAIN_PERSIST_TIMEOUT_MS tiny, read when the handle is made;
+    in production: workgroups that are not all resident).  Non-strict: the step is repeated by the two-launch solver, the result is
+    the two-launch result, fb_step_info says FALLBACK and counts it, the handle stays with the two-launch solver -- and a Newmark
+    step keeps its warm start.  Strict (FEMBRAIN_PERSIST_STRICT=1): FB_EDEVICE.  In subprocesses: the knobs are process-wide."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from fembrain_amd import lib as fl
+from fembrain_amd.fem import FemIntegrator
+from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
+mode = sys.argv[1]
+n = 40
+v, t = truth_cube(n, n, n, 0.1)
+fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+kw = dict(integrator=fl.FB_INTEGRATOR_NEWMARK) if mode == "newmark" else {}
+os.environ["FEMBRAIN_PCG_PERSIST"] = "0"
+ref = FemIntegrator(v, t, fixed, **kw)
+del os.environ["FEMBRAIN_PCG_PERSIST"]
+os.environ["FEMBRAIN_PERSIST_TIMEOUT_MS"] = "0.0001"     # 10 ticks of the 100 MHz clock: a wait that is not over at its first poll gives up
+g = FemIntegrator(v, t, fixed, **kw)
+assert g.persist_info()[0] and not ref.persist_info()[0]
+for h in (ref, g):
+    h.set_uniform_force(1, -10000.0)
+if mode == "strict":
+    os.environ["FEMBRAIN_PERSIST_STRICT"] = "1"
+    try:
+        g.do_timestep()
+    except fl.FbError as e:
+        assert e.code == fl.FB_EDEVICE and "timed out" in str(e), e
+        print("STRICT-OK")
+    sys.exit(0)
+its = []
+for k in range(2):          # Newmark: the second step's solve starts from the first one's solution
+    ir, ig = ref.do_timestep(), g.do_timestep()
+    assert ir == ig, (k, ir, ig)
+    assert np.array_equal(ref.get_q_state()[0], g.get_q_state()[0]), k
+    its.append(ig)
+    assert g.last.pcg_path == (fl.FB_PCG_PATH_FALLBACK if k == 0 else fl.FB_PCG_PATH_TWO_LAUNCH), (k, g.last.pcg_path)
+    assert g.last.persist_fallbacks == 1
+p = g.pcg_path()
+assert p["fallbacks"] == 1 and p["kernel"] == "" and not g.persist_info()[0]
+print("FALLBACK-OK", its)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    for mode in ("fallback", "newmark", "strict"):
+        r = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and ("STRICT-OK" if mode == "strict" else "FALLBACK-OK") in r.stdout, (mode, r.stdout[-2000:], r.stderr[-2000:])
+        if mode != "strict":
+            assert "falls back to the two-launch iteration" in r.stderr
 
 
 # ---- SURVEY 8f-4: exact tangent stiffness (warp = 2) and the Newmark step ---------------------------------------------------------

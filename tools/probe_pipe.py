@@ -1,6 +1,5 @@
-"""development aid: the three forms of the PCG iteration on truth cubes (argv: nodes per side ...): two-launch (k_spmv + k_cg_fused),
-the round-2 merged persistent kernel (FEMBRAIN_PERSIST_KIND=merged) and the pipelined persistent kernel: iteration counts, us per
-iteration, difference of the solutions, bitwise reproducibility across launch cuts"""
+"""development aid: the two forms of the PCG iteration on truth cubes (argv: nodes per side ...): two-launch (k_spmv + k_cg_fused) and the
+pipelined persistent kernel: iteration counts, us per iteration, difference of the solutions, bitwise reproducibility across launch cuts"""
 import os
 import sys
 
@@ -13,13 +12,10 @@ from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, tr
 
 
 def make(v, t, fixed, kind):
-    for k in ("FEMBRAIN_PCG_PERSIST", "FEMBRAIN_PERSIST_KIND"):
-        os.environ.pop(k, None)
+    os.environ.pop("FEMBRAIN_PCG_PERSIST", None)
     if kind == "two-launch":
         os.environ["FEMBRAIN_PCG_PERSIST"] = "0"
         return FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_MERGED)
-    if kind == "merged-persistent":
-        os.environ["FEMBRAIN_PERSIST_KIND"] = "merged"
     return FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT)
 
 
@@ -27,7 +23,7 @@ for n in [int(a) for a in sys.argv[1:]] or [56]:
     v, t = truth_cube(n, n, n, 0.1)
     fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
     ref = None
-    for kind in ("two-launch", "merged-persistent", "pipelined"):
+    for kind in ("two-launch", "pipelined"):
         try:
             g = make(v, t, fixed, kind)
         except fl.FbError as e:

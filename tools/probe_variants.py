@@ -13,7 +13,7 @@ from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, tr
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 27
 v, t = truth_cube(n, n, n, 0.1)
 fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
-for variant, vname in ((fl.FB_PCG_MERGED, "merged"), (fl.FB_PCG_REFERENCE, "reference"), (fl.FB_PCG_FUSED, "fused")):
+for variant, vname in ((fl.FB_PCG_MERGED, "merged"), (fl.FB_PCG_REFERENCE, "reference"), (fl.FB_PCG_PERSISTENT, "persistent")):
     for spmv, sname in ((fl.FB_SPMV_ROWS, "rows"), (fl.FB_SPMV_SPLIT, "split")):
         try:
             g = FemIntegrator(v, t, fixed, pcg_variant=variant, spmv_kernel=spmv)

@@ -7,7 +7,11 @@ export FEMBRAIN_BENCH_SKIP_8M=${FEMBRAIN_BENCH_SKIP_8M:-1}   # the 8M-tet leg ha
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$R/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+# (every pass writes the iteration count of each persistent launch, in launch order: the summaries divide per-launch figures by it)
+export FEMBRAIN_BENCH_LAUNCH_LOG=$R/gpurun_out/prof_kt_launches.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt -o kt -- python3 $ARGS > $R/gpurun_out/prof_kt.log 2>&1
+export FEMBRAIN_BENCH_LAUNCH_LOG=$R/gpurun_out/prof_fetch_launches.json
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -o fetch -- python3 $ARGS --no-field > $R/gpurun_out/prof_fetch.log 2>&1
+export FEMBRAIN_BENCH_LAUNCH_LOG=$R/gpurun_out/prof_write_launches.json
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -o write -- python3 $ARGS --no-field > $R/gpurun_out/prof_write.log 2>&1
 ls -R $R/gpurun_out/prof_kt $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write | head -30
