@@ -77,6 +77,7 @@ struct fb_fem_s {
   hipGraphExec_t batch_graph = nullptr;
   const double* graph_rhs = nullptr;
   bool use_graph = true;
+  bool literal_now = false, graph_literal = false;  // this solve runs the literal two-reduction sequence (tolerance below kPersistMinEps); what the captured batch runs
   // persistent solver (pcg_pipe.hip.h): one workgroup per CU, `persist_waves` wavefronts = slices each, the whole solve in one launch
   bool persist = false;
   int persist_blocks = 0, persist_waves = 0;
@@ -581,10 +582,11 @@ int global_scalar(fb_fem_s* h, const double* partial, double** out, bool check_d
 
 int pcg_iteration(fb_fem_s* h, int it, const double* b) {
   const FemPlan& P = h->plan;
+  const int variant = h->literal_now ? FB_PCG_REFERENCE : h->prm.pcg_variant;  // (a tight tolerance runs the literal sequence, see pcg_solve)
   const int parity = (it - 1) & 1;
   const bool refresh = (it % 30 == 0);
   double* sc = nullptr;
-  if (h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI) {  // literal sequence, z = B^-1 r (unsharded: the partials are summed by the consumers)
+  if (variant == FB_PCG_BLOCK_JACOBI) {  // literal sequence, z = B^-1 r (unsharded: the partials are summed by the consumers)
     FB_TRY(spmv<1>(h, h->d.p, h->Ad.p, nullptr, h->part_a.p, parity));
     if (!refresh) {
       hipLaunchKernelGGL(k_bj_update<false>, dim3(h->grid), dim3(kBlock), 0, h->stream, P.n_slices, P.n_owned, h->st.p, parity, h->part_a.p, h->sgrid, h->d.p,
@@ -600,7 +602,7 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b) {
     FB_HIP(hipGetLastError());
     return FB_OK;
   }
-  if (!refresh && h->prm.pcg_variant == FB_PCG_MERGED && h->xch_mode >= FB_XCH_P2P_SUMS) {
+  if (!refresh && (variant == FB_PCG_MERGED || variant == FB_PCG_PERSISTENT) && h->xch_mode >= FB_XCH_P2P_SUMS) {
     // Peer-to-peer transport with the exchanges inside the iteration's own kernels: the vector pass posts (block 0) and
     // awaits the three sums in its prologue; in FB_XCH_P2P_FUSED the SpMV also refreshes the halo in its prologue (a block
     // per neighbour sends, every block waits and gathers halo columns from the inbox) -- two launches, as on one GPU.
@@ -620,7 +622,7 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b) {
     return FB_OK;
   }
   FB_TRY(halo_exchange(h, h->d.p));
-  if (!refresh && h->prm.pcg_variant == FB_PCG_MERGED) {
+  if (!refresh && (variant == FB_PCG_MERGED || variant == FB_PCG_PERSISTENT)) {
     // merged-reduction iteration: SpMV with the three sums, then one fused vector pass (one reduction / all-reduce)
     FB_TRY(spmv<3>(h, h->d.p, h->Ad.p, h->r.p, h->part_a.p, parity));
     FB_TRY(global_scalar(h, h->part_a.p, &sc, true, 3, 0, h->sgrid));
@@ -660,8 +662,9 @@ int pcg_iteration(fb_fem_s* h, int it, const double* b);
 
 // captures iterations 1..30 (parity and the position of the exact-residual iteration repeat with period 30)
 int ensure_batch_graph(fb_fem_s* h, const double* b, int batch) {
-  if (h->batch_graph && h->graph_rhs == b) return FB_OK;
+  if (h->batch_graph && h->graph_rhs == b && h->graph_literal == h->literal_now) return FB_OK;
   drop_graph(h);
+  h->graph_literal = h->literal_now;
   hipGraph_t g = nullptr;
   FB_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = FB_OK;
@@ -741,7 +744,7 @@ void print_pipe_timing(fb_fem_s* h) {
   }
 }
 
-int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state);
+int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state, bool allow_persist = true);
 
 // Jacobi-PCG inside persistent launches (normally ONE): CGSolver.cpp:129-190 in its pipelined form
 int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state) {
@@ -776,7 +779,7 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
         return fail(FB_EDEVICE, "persistent PCG: a wait inside the launch timed out after %.1f ms (the workgroups were not all resident?)", h->persist_timeout_ticks * 1e-5);
       fprintf(stderr, "[fembrain] persistent PCG: a wait timed out after %.1f ms; this handle falls back to the two-launch iteration\n", h->persist_timeout_ticks * 1e-5);
       h->pcg_warm = warm;
-      const int rc = pcg_solve(h, b, eps, max_iter, iters_out, final_state);
+      const int rc = pcg_solve(h, b, eps, max_iter, iters_out, final_state, false);
       h->last_pcg_path = FB_PCG_PATH_FALLBACK;
       return rc;
     }
@@ -790,15 +793,34 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
   h->last_pcg_path = FB_PCG_PATH_PERSISTENT;
   const double rho = fin.rho[fin.iter & 1];
   const bool converged = !(rho > fin.eps2 * fin.rho0);
+  if (!converged) {
+    // The iteration cap was reached.  Whether the system needs more iterations or the pipelined recurrences have stalled cannot
+    // be told from here, so the literal recurrences get the last word: the solve is repeated by the two-launch solver from
+    // the same start, and what it returns (normally the same -max_iter, as CGSolver.cpp:189 would) is the result.
+    h->pcg_warm = warm;
+    const int rc = pcg_solve(h, b, eps, max_iter, iters_out, final_state, false);
+    h->last_pcg_path = FB_PCG_PATH_RESOLVED;
+    return rc;
+  }
   if (iters_out) *iters_out = converged ? fin.iter : -fin.iter;
   if (final_state) *final_state = fin;
   return FB_OK;
 }
 
-int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state) {
-  if (h->persist && (h->prm.pcg_variant == FB_PCG_MERGED || h->prm.pcg_variant == FB_PCG_PERSISTENT))
+// The pipelined recurrences of the persistent solver stop making progress at a relative residual of ~1e-11 on these systems
+// (measured, tools/pipelined_pcg_numerics.py and DESIGN.md; the literal recurrences go on below 1e-12): a solve asked for a
+// tolerance within three orders of that goes to the two-launch solver, whatever the handle runs otherwise.
+constexpr double kPersistMinEps = 1e-8;
+
+int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state, bool allow_persist) {
+  if (allow_persist && h->persist && eps >= kPersistMinEps && (h->prm.pcg_variant == FB_PCG_MERGED || h->prm.pcg_variant == FB_PCG_PERSISTENT))
     return pcg_solve_pipe(h, b, eps, max_iter, iters_out, final_state);
   h->last_pcg_path = FB_PCG_PATH_TWO_LAUNCH;
+  // The merged recurrence for rho (rho' = rho - 2 alpha S1 + alpha^2 S2) loses digits the literal sum r.r/diag keeps: measured on
+  // the 17,576-node cube it stalls above 1e-12 where the literal sequence converges.  Tolerances below kPersistMinEps therefore run
+  // the literal sequence of FB_PCG_REFERENCE, whatever variant the handle was made with (block-Jacobi is literal already).
+  struct LiteralScope { fb_fem_s* h; ~LiteralScope() { h->literal_now = false; } } literal_scope{h};
+  h->literal_now = eps < kPersistMinEps && (h->prm.pcg_variant == FB_PCG_MERGED || h->prm.pcg_variant == FB_PCG_PERSISTENT);
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
   double* sc = nullptr;

@@ -438,7 +438,8 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     atomicAdd((unsigned long long*)pa.timing + ((size_t)blockIdx.x * kPipeMaxWaves + wv) * 6 + 5, (unsigned long long)it_done);
   }
   if (failed) return;  // nothing written back: the host re-solves from the vectors it handed over
-  if (rvalid) {
+  // (the same when the iteration cap ended the solve: the two-launch solver repeats it from the same start, see pcg_solve_pipe)
+  if (rvalid && !(done && gamma > eps2 * rho0)) {
     unsigned int dof = 3u * (unsigned int)row;
     asm volatile("" : "+v"(dof));  // (formed here: see the exact-residual phase)
 #pragma unroll

@@ -15,7 +15,7 @@ FB_OK, FB_EINVAL, FB_EDEVICE, FB_ENOMEM, FB_ESOLVER, FB_ECOMM = 0, -1, -2, -3, -
 FB_MATRIX_F32, FB_MATRIX_F64 = 0, 1
 FB_XCH_COLLECTIVE, FB_XCH_P2P, FB_XCH_P2P_SUMS, FB_XCH_P2P_FUSED = 1, 2, 3, 4
 FB_PCG_MERGED, FB_PCG_REFERENCE, FB_PCG_PERSISTENT, FB_PCG_BLOCK_JACOBI = 0, 1, 3, 4  # (2 was an experiment, removed)
-FB_PCG_PATH_TWO_LAUNCH, FB_PCG_PATH_PERSISTENT, FB_PCG_PATH_FALLBACK = 0, 1, 2
+FB_PCG_PATH_TWO_LAUNCH, FB_PCG_PATH_PERSISTENT, FB_PCG_PATH_FALLBACK, FB_PCG_PATH_RESOLVED = 0, 1, 2, 3
 FB_SPMV_AUTO, FB_SPMV_ROWS, FB_SPMV_SPLIT = 0, 1, 2
 FB_INTEGRATOR_VOLUME_CONSERVING, FB_INTEGRATOR_NEWMARK = 0, 1
 

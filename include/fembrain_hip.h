@@ -42,7 +42,9 @@ extern "C" {
  * reproducible however the solve is cut into launches.  If a wait inside the launch times out (FEMBRAIN_PERSIST_TIMEOUT_MS,
  * default 50; the workgroups must all be resident) the solve is repeated with the two-launch iteration and the handle stays
  * with it: fb_step_info.pcg_path = FB_PCG_PATH_FALLBACK, fb_step_info.persist_fallbacks counts (FEMBRAIN_PERSIST_STRICT=1:
- * FB_EDEVICE instead). */
+ * FB_EDEVICE instead).  ACCURACY LIMIT: the pipelined recurrences stall at a relative residual of ~1e-11 on these systems (the
+ * literal ones go on below 1e-12), so solves with a tolerance below 1e-8 (the reference uses 1e-6) run the two-launch solver, and
+ * a persistent solve that ends at the iteration cap is repeated by it (FB_PCG_PATH_RESOLVED). */
 #define FB_PCG_PERSISTENT 3
 /* BLOCK_JACOBI (opt-in; NOT the reference's solver, excluded from parity): the literal PCG with the inverse of every row's 3x3
  * diagonal block as preconditioner instead of the inverse diagonal.  Same convergence test (on r . B^-1 r).  Unsharded handles.
@@ -160,6 +162,7 @@ typedef struct fb_step_info {
 #define FB_PCG_PATH_TWO_LAUNCH 0  /* k_spmv + k_cg_fused per iteration (or the literal / block-Jacobi sequences) */
 #define FB_PCG_PATH_PERSISTENT 1  /* the persistent launch (FB_PCG_PERSISTENT) */
 #define FB_PCG_PATH_FALLBACK 2    /* a persistent launch timed out; the solve was repeated with the two-launch form */
+#define FB_PCG_PATH_RESOLVED 3    /* the persistent solve reached the iteration cap; repeated by the two-launch solver, whose result stands */
 
 /* VolumeConservingIntegrator::DoTimestep (PS_VolumeConservingIntegrator.cpp:46-260): assembly, Keff/rhs, PCG,
  * state update.  Returns FB_OK, or FB_ESOLVER when PCG hit cg_max_iter (state is then left unchanged). */

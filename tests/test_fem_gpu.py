@@ -1054,13 +1054,20 @@ def test_persistent_solver_against_the_oracle(gpu, monkeypatch, n, c16, kernel):
     fext[1::3] = -10000.0
     o.set_external_forces(fext)
     g.set_external_forces(fext)
-    info, keff, rhs, dv = o.step(cg_eps=1e-12, cg_maxiter=20000, want=True)
+    info, keff, rhs, dv = o.step(cg_eps=1e-8, cg_maxiter=20000, want=True)
     o.set_state(np.zeros(o.r), np.zeros(o.r))
     _, rhs_g = g.system()
-    assert np.abs(rhs_g - rhs).max() <= 2e-7 * np.abs(rhs).max()
-    it, xg = g.pcg(rhs_g, eps=1e-12, max_iter=20000)
+    free = np.ones(o.r, bool)
+    free[fixed] = False          # (the oracle removes the clamped DOFs, here they are identity rows with a zero right-hand side)
+    assert np.abs(rhs_g[free] - rhs[free]).max() <= 2e-7 * np.abs(rhs).max() and not rhs_g[~free].any()
+    it, xg = g.pcg(rhs_g, eps=1e-8, max_iter=20000)
+    assert g.pcg_path()["path"] == fl.FB_PCG_PATH_PERSISTENT
     assert abs(it - abs(info)) <= max(3, 0.02 * abs(info)), (it, info)
     assert np.abs(xg - dv).max() <= 5e-6 * np.abs(dv).max()       # fp32-stored matrix: K entries rounded to 6e-8, cond ~ 1e2
+    # a tolerance below 1e-8 is within three orders of where the pipelined recurrences stall (~1e-11): the two-launch solver takes it
+    # (1e-10: the true residual b - A x, taken every 30th iteration as the reference does, has its own floor near 1e-12 at this size)
+    it10, x10 = g.pcg(rhs_g, eps=1e-10, max_iter=20000)
+    assert g.pcg_path()["path"] == fl.FB_PCG_PATH_TWO_LAUNCH and it10 > it and np.abs(x10 - xg).max() <= 1e-6 * np.abs(xg).max()
     for k in range(3):
         o.set_external_forces(fext)
         io, ig = abs(o.step()), g.do_timestep()
@@ -1091,9 +1098,9 @@ def test_persistent_solver_matches_two_launch_and_itself(gpu, n, monkeypatch):
         g.set_uniform_force(1, -10000.0)
     _, rhs = gm.system()
     gp.system(); ga.system()
-    itm, xm = gm.pcg(rhs, eps=1e-9, max_iter=20000)
-    itp, xp = gp.pcg(rhs, eps=1e-9, max_iter=20000)
-    ita, xa = ga.pcg(rhs, eps=1e-9, max_iter=20000)
+    itm, xm = gm.pcg(rhs, eps=1e-8, max_iter=20000)
+    itp, xp = gp.pcg(rhs, eps=1e-8, max_iter=20000)
+    ita, xa = ga.pcg(rhs, eps=1e-8, max_iter=20000)
     assert gm.pcg_path()["path"] == fl.FB_PCG_PATH_TWO_LAUNCH and gp.pcg_path()["path"] == fl.FB_PCG_PATH_PERSISTENT
     assert itm > 60 and abs(itp - itm) <= max(3, 0.02 * itm), (itp, itm)
     assert np.abs(xp - xm).max() <= 1e-6 * np.abs(xm).max()
@@ -1101,13 +1108,13 @@ def test_persistent_solver_matches_two_launch_and_itself(gpu, n, monkeypatch):
     assert not xp[fixed].any()
     for run in ("1", "7", "30", "31"):
         monkeypatch.setenv("FEMBRAIN_PERSIST_MAX_RUN", run)
-        itc, xc = gp.pcg(rhs, eps=1e-9, max_iter=20000)
+        itc, xc = gp.pcg(rhs, eps=1e-8, max_iter=20000)
         assert itc == itp and np.array_equal(xc, xp), run
     monkeypatch.delenv("FEMBRAIN_PERSIST_MAX_RUN")
     for cap in (1, 29, 30, 37):
-        itl, xl = gp.pcg(rhs, eps=1e-9, max_iter=cap)       # iteration cap (also on and next to an exact-residual iteration): -cap as the reference returns
-        itk, xk = gm.pcg(rhs, eps=1e-9, max_iter=cap)
-        assert itl == -cap and itk == -cap and np.abs(xl - xk).max() <= 1e-9 * np.abs(xk).max(), cap
+        itl, xl = gp.pcg(rhs, eps=1e-8, max_iter=cap)       # iteration cap (also on and next to an exact-residual iteration): -cap as the reference
+        itk, xk = gm.pcg(rhs, eps=1e-8, max_iter=cap)       # returns, and the literal recurrences have the last word (FB_PCG_PATH_RESOLVED)
+        assert itl == -cap and itk == -cap and np.array_equal(xl, xk) and gp.pcg_path()["path"] == fl.FB_PCG_PATH_RESOLVED, cap
     itz, xz = gp.pcg(np.zeros_like(rhs), eps=1e-6, max_iter=100)
     assert itz == 0 and not xz.any()
     # full steps: three reference-load steps against the two-launch solver
