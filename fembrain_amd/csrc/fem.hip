@@ -1249,6 +1249,20 @@ int fb_device_info(int dev, char* name, int name_len, char* arch, int arch_len, 
   return FB_OK;
 }
 
+int fb_host_register(void* p, unsigned long long bytes) {
+  if (!p || bytes == 0) return fail(FB_EINVAL, "null argument");
+  const hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(FB_EDEVICE, "hipHostRegister(%llu bytes): %s", bytes, hipGetErrorString(e)); }
+  return FB_OK;
+}
+
+int fb_host_unregister(void* p) {
+  if (!p) return FB_OK;
+  const hipError_t e = hipHostUnregister(p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(FB_EDEVICE, "hipHostUnregister: %s", hipGetErrorString(e)); }
+  return FB_OK;
+}
+
 void fb_fem_default_params(fb_fem_params* p) {
   if (!p) return;
   memset(p, 0, sizeof *p);

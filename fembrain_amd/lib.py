@@ -89,6 +89,8 @@ def lib():
     sig = {
         "fb_device_count": (C.c_int, []),
         "fb_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, _ip]),
+        "fb_host_register": (C.c_int, [C.c_void_p, C.c_ulonglong]),
+        "fb_host_unregister": (C.c_int, [C.c_void_p]),
         "fb_fem_default_params": (None, [C.POINTER(FemParams)]),
         "fb_fem_create": (C.c_int, [C.POINTER(vp), C.c_int, _dp, C.c_int, _ip, C.c_int, _ip, C.POINTER(FemParams)]),
         "fb_fem_create_sharded": (C.c_int, [C.POINTER(vp), C.c_int, _dp, C.c_int, _ip, C.c_int, _ip, C.POINTER(FemParams),

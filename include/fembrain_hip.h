@@ -55,6 +55,11 @@ const char* fb_last_error(void);
 int fb_device_count(void);
 /* name/arch of device `dev` into caller buffers (may be NULL) */
 int fb_device_info(int dev, char* name, int name_len, char* arch, int arch_len, int* n_cu);
+/* Page-locks caller memory (hipHostRegister) so that the state copies of a step (fb_fem_set_state / fb_fem_get_state /
+ * fb_fem_set_external_forces: the q, qvel, qaccel, externalForces arrays IntegratorBase allocates, integratorBase.cpp:36-60) run
+ * at PCIe speed instead of through a staging copy.  Optional; unregister before the memory is freed. */
+int fb_host_register(void* p, unsigned long long bytes);
+int fb_host_unregister(void* p);
 
 /* ------------------------------------------------------------------------------------------------------
  * FEM handle.  One handle = what Deformable::syncForceModel builds (deformable/Deformable.cpp:127-220):

@@ -8,10 +8,17 @@
 //   2. the reference's CGSolver runs its own CG loop on the device matrix through its black-box product hook
 //      (CGSolver.h:65-66) -> fb_fem_spmv
 //   3. HipVolumeConservingIntegrator (an IntegratorBaseSparse) steps; |q| printed for the Python test to compare with the oracle
+//   4. the reference's own self-checks run on the device path: ForceModel::TestStiffnessMatrix (forceModel.cpp:47-109: finite
+//      differences of f against K, on the warp = 2 model whose K is the exact tangent) and
+//      SparseMatrix::CheckLinearSystemSolution (sparseMatrix.cpp:1560-1592) of the device's PCG solution in the reference's matrix
+//   `ref_seam --bench N [steps]`: steps/s of N^3-node truth cube steps from the rest state THROUGH AN IntegratorBaseSparse* (what
+//   FemBrain's Deformable holds), host arrays crossing the boundary every step -- to set beside bench.py's value_at_fixed_state.
 // Prints KEY=value lines.  Needs a GPU to RUN; compiling and linking it is the CPU-side proof.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <time.h>
 
 #include <vector>
 
@@ -37,8 +44,55 @@ static void truth_cube(int n, double cell, std::vector<double>& v, std::vector<i
       }
 }
 
-int main() {
+static double now_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+// steps/s through the reference's abstract integrator interface; every step starts from the rest state (SetqState) under the
+// reference load, as bench.py's value_at_fixed_state does
+static int bench(int n, int steps) {
+  std::vector<double> v;
+  std::vector<int> t;
+  truth_cube(n, 0.1, v, t);
+  const int nv = (int)v.size() / 3, ne = (int)t.size() / 4, r = 3 * nv;
+  TetMesh mesh(nv, &v[0], ne, &t[0], 1e7, 0.46, 1000.0);
+  SparseMatrix* M = NULL;
+  GenerateMassMatrix::computeMassMatrix(&mesh, &M, true);
+  std::vector<int> fixed;
+  for (int j = 0; j < n * n; j++)
+    for (int k = 0; k < 3; k++) fixed.push_back(3 * j + k);
+  PS::FEM::HipCorotationalForceModel hip(&mesh, 1e7, 0.46, 1000.0);
+  if (!hip.ok()) { printf("ERROR=no device\n"); return 1; }
+  PS::FEM::HipVolumeConservingIntegrator hipInt(r, 0.0333, M, &hip, 0, (int)fixed.size(), &fixed[0], 0.0, 0.01);
+  IntegratorBaseSparse* integ = &hipInt;
+  std::vector<double> fext(r, 0.0), zero(r, 0.0);
+  for (int i = 0; i < nv; i++) fext[3 * i + 1] = -10000.0;
+  double total = 0.0;
+  int iters = 0;
+  for (int s = -2; s < steps; s++) {  // two warm-up steps
+    integ->SetqState(&zero[0], &zero[0], &zero[0]);
+    const double t0 = now_s();
+    integ->SetExternalForcesToZero();
+    integ->SetExternalForces(&fext[0]);
+    if (integ->DoTimestep() != 0) { printf("ERROR=step failed\n"); return 1; }
+    const double dt = now_s() - t0;
+    if (s >= 0) { total += dt; iters += hipInt.lastIterations(); }
+  }
+  double qn = 0;
+  for (int i = 0; i < r; i++) qn += integ->Getq()[i] * integ->Getq()[i];
+  printf("BENCH_TETS=%d\nBENCH_STEPS=%d\nBENCH_STEPS_PER_S=%.4f\nBENCH_MS_PER_STEP=%.4f\nBENCH_ITERS_PER_STEP=%.1f\nBENCH_PCG_PATH=%d\nBENCH_QNORM=%.10e\n"
+         "BENCH_SOLVE_MS=%.4f\nBENCH_ASSEMBLY_MS=%.4f\nBENCH_MATRIX_HANDLE=%d\n",
+         ne, steps, steps / total, total / steps * 1e3, (double)iters / steps, hipInt.lastPcgPath(), sqrt(qn), integ->GetSystemSolveTime() * 1e3,
+         integ->GetForceAssemblyTime() * 1e3, hip.matrixHandle() != NULL);
+  delete M;
+  return 0;
+}
+
+int main(int argc, char** argv) {
   setvbuf(stdout, NULL, _IONBF, 0);
+  if (argc >= 3 && !strcmp(argv[1], "--bench")) return bench(atoi(argv[2]), argc >= 4 ? atoi(argv[3]) : 5);
   const int n = 5;
   std::vector<double> v;
   std::vector<int> t;
@@ -72,8 +126,23 @@ int main() {
         nk = fmax(nk, fabs(Kr->GetEntry(i, j)));
       }
     }
-    printf("WARP%d_PATTERN=%d\nWARP%d_F_RELDIFF=%.3e\nWARP%d_K_RELDIFF=%.3e\n", warp, same_pattern, warp, df / nf, warp, dk / nk);
+    // f alone comes from the stepping handle (fp32-stored matrix): it must be the same f
+    std::vector<double> f2(r);
+    fm->GetInternalForce(&u[0], &f2[0]);
+    double df2 = 0;
+    for (int i = 0; i < r; i++) df2 = fmax(df2, fabs(f2[i] - fr[i]));
+    printf("WARP%d_PATTERN=%d\nWARP%d_F_RELDIFF=%.3e\nWARP%d_K_RELDIFF=%.3e\nWARP%d_F_STEPPING_HANDLE_RELDIFF=%.3e\n", warp, same_pattern, warp, df / nf, warp,
+           dk / nk, warp, df2 / nf);
     delete K; delete Kr;
+    if (warp == 2) {
+      // 4a. the reference's finite-difference check of K against f (prints its own "eps=...: maxEntry=..." lines): with the exact
+      // tangent, f(q + eps dq) - f(q) - K eps dq is O(eps^2)
+      std::vector<double> dq(r);
+      for (int i = 0; i < r; i++) dq[i] = 0.01 * cos(0.61 * i);
+      printf("TESTSTIFFNESS_BEGIN=1\n");
+      fm->TestStiffnessMatrix(&u[0], &dq[0]);
+      printf("TESTSTIFFNESS_END=1\n");
+    }
   }
 
   // 2 + 3. integrator derived from the reference's IntegratorBaseSparse; the reference's CGSolver on the device matrix
@@ -104,6 +173,25 @@ int main() {
   double res = 0, nb = 0;
   for (int i = 0; i < r; i++) { res += (Ax[i] - rhs[i]) * (Ax[i] - rhs[i]); nb += rhs[i] * rhs[i]; }
   printf("REFCG_INFO=%d\nREFCG_RESIDUAL=%.3e\n", info, sqrt(res / nb));
+  // 4b. the device's own Jacobi-PCG solution of that system, checked by the reference's SparseMatrix::CheckLinearSystemSolution in
+  // a reference SparseMatrix filled with the device's Keff
+  {
+    SparseMatrix* Keff = NULL;
+    hip.GetTangentStiffnessMatrixTopology(&Keff);
+    std::vector<int> bptr(nv + 1), bcol(fb_fem_num_blocks(hip.handle()));
+    fb_fem_pattern(hip.handle(), &bptr[0], &bcol[0]);
+    for (int a = 0; a < nv; a++)
+      for (int p = bptr[a]; p < bptr[a + 1]; p++)
+        for (int k = 0; k < 3; k++)
+          for (int l = 0; l < 3; l++) Keff->SetEntry(3 * a + k, 3 * (p - bptr[a]) + l, Kb[9 * (size_t)p + 3 * k + l]);
+    std::vector<double> xd(r, 0.0);
+    int its = 0;
+    fb_fem_pcg(hip.handle(), &rhs[0], &xd[0], 1e-6, 10000, &its);
+    const double rel = Keff->CheckLinearSystemSolution(&xd[0], &rhs[0], 1);
+    printf("DEVICE_PCG_ITERS=%d\nREF_CHECKLINEARSYSTEM_RELINF=%.3e\n", its, rel);
+    delete Keff;
+  }
+  printf("MATRIX_HANDLE_CREATED=%d\n", hip.matrixHandle() != NULL);
   delete M;
   return 0;
 }

@@ -155,10 +155,27 @@ def test_reference_classes_drive_the_hip_path_through_the_seam(gpu):
     from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
     from oracle.pyoracle import OrcFem
     out = subprocess.check_output([SEAM], text=True)
-    kv = dict(line.split("=", 1) for line in out.strip().splitlines())
+    kv = dict(line.split("=", 1) for line in out.strip().splitlines() if "=" in line and not line.startswith("eps="))
     for w in ("1", "2"):
         assert kv["WARP%s_PATTERN" % w] == "1"
         assert float(kv["WARP%s_F_RELDIFF" % w]) < 1e-9 and float(kv["WARP%s_K_RELDIFF" % w]) < 1e-10, kv
+        # the force alone is served by the handle the integrator steps on (fp32-STORED matrix; f itself is formed in fp64)
+        assert float(kv["WARP%s_F_STEPPING_HANDLE_RELDIFF" % w]) < 1e-9, kv
+    assert kv["MATRIX_HANDLE_CREATED"] == "1"   # (K for host code came from the reference-width handle)
+    # the reference's own ForceModel::TestStiffnessMatrix (forceModel.cpp:47-109) on the warp = 2 device model: its lines
+    # "eps=E: maxEntry=M ..." -- f(q + eps dq) - f(q) - K eps dq must shrink like eps^2 until rounding takes over
+    fd = {}
+    for line in out.splitlines():
+        if line.startswith("eps="):
+            e, m = line.split(":")[0][4:], line.split("maxEntry=")[1].split()[0]
+            fd[float(e)] = float(m)
+    assert len(fd) >= 10, out[-3000:]
+    for e in (1e-1, 1e-2, 1e-3):
+        lo = min(k for k in fd if abs(k / (e / 10) - 1) < 1e-6)
+        hi = min(k for k in fd if abs(k / e - 1) < 1e-6)
+        assert 50 < fd[hi] / fd[lo] < 200, (e, fd)          # second order: a factor ~100 per decade
+    # the reference's SparseMatrix::CheckLinearSystemSolution (sparseMatrix.cpp:1560-1592) of the device's Jacobi-PCG solution (eps 1e-6)
+    assert int(kv["DEVICE_PCG_ITERS"]) > 0 and float(kv["REF_CHECKLINEARSYSTEM_RELINF"]) < 1e-4, kv
     n = 5
     v, t = truth_cube(n, n, n, 0.1)
     o = OrcFem(v, t)
@@ -174,3 +191,16 @@ def test_reference_classes_drive_the_hip_path_through_the_seam(gpu):
         assert abs(int(kv["STEP%d_ITERS" % k]) - it) <= max(3, 0.02 * it)
     assert abs(float(kv["TOTAL_MASS"]) - 3 * 1000.0 * 0.4 ** 3) < 1e-6 * 192
     assert int(kv["REFCG_INFO"]) > 0 and float(kv["REFCG_RESIDUAL"]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_link_unchanged_route_runs_the_measured_path(gpu):
+    """`ref_seam --bench 40`: steps from the rest state through an IntegratorBaseSparse* (the reference's abstract class, what
+    Deformable.cpp:205-214 holds) run the persistent solver of the fp32-stored handle -- the path bench.py measures -- without ever
+    creating the fp64 matrix handle; iteration count of the 40^3 cube as the two-launch solver finds it (1413)."""
+    if not os.path.exists(SEAM):
+        pytest.skip("oracle/_ref/ref_seam did not travel")
+    out = subprocess.check_output([SEAM, "--bench", "40", "3"], text=True)
+    kv = dict(line.split("=", 1) for line in out.strip().splitlines() if "=" in line)
+    assert kv["BENCH_PCG_PATH"] == "1" and kv["BENCH_MATRIX_HANDLE"] == "0", kv
+    assert abs(float(kv["BENCH_ITERS_PER_STEP"]) - 1413) <= 28 and float(kv["BENCH_STEPS_PER_S"]) > 5, kv

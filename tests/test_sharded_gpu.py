@@ -71,8 +71,8 @@ def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False
         os._exit(1)
 
 
-@pytest.mark.parametrize("world,variant,p2p", [(2, 0, 0), (3, 0, 0), (2, 1, 0), (4, 2, 0),
-                                               (2, 0, 2), (3, 0, 3), (2, 0, 4), (4, 0, 4), (3, 1, 4), (3, 2, 4)])
+@pytest.mark.parametrize("world,variant,p2p", [(2, 0, 0), (3, 0, 0), (2, 1, 0), (4, 1, 0),
+                                               (2, 0, 2), (3, 0, 3), (2, 0, 4), (4, 0, 4), (3, 1, 4), (4, 1, 2)])
 def test_sharded_ranks_on_one_gpu_match_the_unsharded_handle(gpu, world, variant, p2p):
     _run_sharded(world, variant, p2p, 12)
 
