@@ -157,7 +157,9 @@ int setup_persist(fb_fem_s* h) {
   // asked for explicitly (parameter or FEMBRAIN_PCG_PERSIST=1), or by default where it was measured faster than the
   // two-launch iteration: fp32 storage, up to 12 slices per CU
   const bool eligible = !h->f64 && P.n_ranks == 1 && nb >= 8 && w >= 1 && w <= kPipeMaxWaves;
-  static const int min_w = getenv("FEMBRAIN_PERSIST_MIN_WAVES") ? atoi(getenv("FEMBRAIN_PERSIST_MIN_WAVES")) : 4;
+  // (us per iteration, two-launch vs persistent, on MI355X: 7.7 / 10.2 at 43 slices, 9.05 / 9.55 at 466 = 2 per CU, 10.9 / 9.9 at 614 =
+  // 3 per CU, 14.0 / 10.3 at 792, 15.8 / 9.5 at 1,000, 27.4 / 17.1 at 2,744 = 1M tets)
+  static const int min_w = getenv("FEMBRAIN_PERSIST_MIN_WAVES") ? atoi(getenv("FEMBRAIN_PERSIST_MIN_WAVES")) : 3;
   const bool by_default = h->prm.pcg_variant == FB_PCG_MERGED && w >= min_w;
   const bool want_p = e ? atoi(e) != 0 && (h->prm.pcg_variant == FB_PCG_MERGED || explicit_p) : (explicit_p || by_default);
   if (!want_p || !eligible) return FB_OK;
@@ -221,8 +223,11 @@ int setup_persist(fb_fem_s* h) {
   FB_TRY(h->pipe_prod_count.upload(cnt, s));
   FB_TRY(h->pipe_prod_xcd.upload(far, s));
   {
+    // interior workgroups publish with plain stores where the iteration is latency-bound (measured, us per iteration with / without:
+    // 9.5 / 10.2 at 466 slices, 9.5 / 9.9 at 1,000; 17.4 / 17.1 at 2,744 = 1M tets, where the matrix stream evicts the lines from
+    // L2 anyway): up to 8 slices per CU.  FEMBRAIN_PIPE_PLAIN_STORES=0/1 overrides.
     const char* e = getenv("FEMBRAIN_PIPE_PLAIN_STORES");
-    h->pipe_plain_local = e ? atoi(e) : 0;
+    h->pipe_plain_local = e ? atoi(e) : (w <= 8 ? 1 : 0);
   }
   return FB_OK;
 }
@@ -700,7 +705,10 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   pa.pstate = h->pipe_state.p;
   // LDS: the sync buffers, then KLT slots of every slice; the request is the whole 160 KB of a CU, so exactly one workgroup lands on each
   const size_t lds = 160 * 1024;
-  const dim3 grid(h->persist_blocks), block(64 * h->persist_waves);
+  // one wavefront more than slices where the instantiation has room: it collects the sums while the others multiply
+  static const bool want_service = !(getenv("FEMBRAIN_PIPE_SERVICE_WAVE") && atoi(getenv("FEMBRAIN_PIPE_SERVICE_WAVE")) == 0);
+  pa.service = want_service && h->persist_waves < h->pipe_wmax ? 1 : 0;
+  const dim3 grid(h->persist_blocks), block(64 * (h->persist_waves + pa.service));
   FB_HIP(hipEventRecord(h->ev_p[0], h->stream));
 #define FB_PIPE(C16, WMAX, KLT, TIMING)                                                                                                        \
   do {                                                                                                                                         \

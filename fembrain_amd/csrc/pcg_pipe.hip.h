@@ -48,6 +48,7 @@ struct PipeArgs {
   const int* prod_count;      // [n_blocks]
   const int* prod_xcd;        // [n_blocks] non-zero: a producer (= consumer) of this workgroup sits on another XCD, or it polls all
   int plain_local;            // non-zero: workgroups without such a neighbour publish with plain stores (see publish)
+  int service;                // non-zero: the workgroups were launched with one wavefront more than slices; it collects the sums
   int start;                  // 0 continue a solve (state from memory), 1 new solve from x = 0, 2 new solve from the x in memory
   int n_iters;                // at most this many iterations in this launch
   double eps2;                // squared tolerance (start != 0; a continued solve reads the CGState)
@@ -353,7 +354,40 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
       continue;
     }
     // ---- all workgroups' sums (posted before their products: they are there) ----
-    {
+    if (pa.service) {
+      // A workgroup with a wavefront to spare (fewer slices than the instantiation's wavefronts) has its LAST wavefront -- no
+      // slice, it idles through the product -- collect the sums meanwhile: same order of additions as below, so the same bits;
+      // the others find the totals behind ONE barrier.
+      if (wv == n_waves - 1) {
+        const long long t0 = wall_clock64();
+        const unsigned long long* post = pa.post + (size_t)(sums & 1u) * nb * 4;
+        double t0s = 0, t1s = 0;
+        for (int b = lane; b - lane < nb && !failed; b += 64) {
+          const bool mine = b < nb;
+          uint4 q4[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+          for (;;) {
+            bool ok = true;
+            if (mine) {
+              asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                           : "=&v"(q4[0]), "=&v"(q4[1]) : "v"(post + (size_t)b * 4) : "memory");
+              ok = q4[0].y == sums && q4[0].w == sums && q4[1].y == sums && q4[1].w == sums;
+            }
+            if (__ballot(!ok) == 0ULL) break;
+            if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (mine && !failed) {
+            t0s += __longlong_as_double((long long)(((unsigned long long)q4[0].x << 32) | (unsigned long long)q4[0].z));
+            t1s += __longlong_as_double((long long)(((unsigned long long)q4[1].x << 32) | (unsigned long long)q4[1].z));
+          }
+        }
+        failed = uniform_flag(failed);
+        if (failed && lane == 0) st_sc1_u32(pa.error, 1u);
+        t0s = wave_sum(t0s); t1s = wave_sum(t1s);
+        if (lane == 0) { bc[0] = t0s; bc[1] = t1s; bc[2] = (failed || ld_sc1_u32(pa.error) != 0u) ? 1.0 : 0.0; }
+      }
+      __syncthreads();
+    } else {
       const int pollers = min(n_waves, 4);
       if (wv < pollers) {
         const long long t0 = wall_clock64();
