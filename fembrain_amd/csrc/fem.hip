@@ -708,6 +708,10 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   // one wavefront more than slices where the instantiation has room: it collects the sums while the others multiply
   static const bool want_service = !(getenv("FEMBRAIN_PIPE_SERVICE_WAVE") && atoi(getenv("FEMBRAIN_PIPE_SERVICE_WAVE")) == 0);
   pa.service = want_service && h->persist_waves < h->pipe_wmax ? 1 : 0;
+  // values of the first streamed slots pulled into L2 during the neighbour wait: pays where the product is bandwidth-bound (9 and more
+  // slices per CU: -6 % per iteration at 1M tets; neutral at 1,000 slices).  FEMBRAIN_PIPE_PREFETCH=0..4 overrides.
+  static const int prefetch = getenv("FEMBRAIN_PIPE_PREFETCH") ? std::max(0, std::min(4, atoi(getenv("FEMBRAIN_PIPE_PREFETCH")))) : -1;
+  pa.prefetch_slots = prefetch >= 0 ? prefetch : (h->persist_waves >= 9 ? 4 : 0);
   const dim3 grid(h->persist_blocks), block(64 * (h->persist_waves + pa.service));
   FB_HIP(hipEventRecord(h->ev_p[0], h->stream));
 #define FB_PIPE(C16, WMAX, KLT, TIMING)                                                                                                        \

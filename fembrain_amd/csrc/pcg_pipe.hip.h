@@ -48,6 +48,7 @@ struct PipeArgs {
   const int* prod_count;      // [n_blocks]
   const int* prod_xcd;        // [n_blocks] non-zero: a producer (= consumer) of this workgroup sits on another XCD, or it polls all
   int plain_local;            // non-zero: workgroups without such a neighbour publish with plain stores (see publish)
+  int prefetch_slots;         // streamed slots per slice whose values the idle wavefronts pull into L2 during the neighbour wait (0..4)
   int service;                // non-zero: the workgroups were launched with one wavefront more than slices; it collects the sums
   int start;                  // 0 continue a solve (state from memory), 1 new solve from x = 0, 2 new solve from the x in memory
   int n_iters;                // at most this many iterations in this launch
@@ -198,6 +199,14 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     __syncthreads();
     lap(0);  // publish, drained
     if (post_sums) sums++;
+    if (wv != 0 && live && pa.prefetch_slots > 0 && width > KLT) {
+      // idle until wavefront 0 has seen the neighbours' flags: the first streamed slots' values go to L2 meanwhile (measured at 1M
+      // tets, us per iteration with 0 / 2 / 3 / 4 slots: 17.15 / 16.25 / 16.1 / 16.05; the same during the drain of the publish
+      // stores instead delays the flag and loses: 16.85)
+      int so_k = so + KLT;
+      asm volatile("" : "+s"(so_k));  // (opaque, as for the streamed loop below)
+      pipe_prefetch_values(min(pa.prefetch_slots, width - KLT), ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float), vals);
+    }
     if (wv == 0) {
       if (lane == 0) st_sc1_u32(pa.flags + blockIdx.x, pub);
       if (post_sums && lane < 2) {  // workgroup sums in wave order, posted as two tagged halves each

@@ -131,6 +131,11 @@ namespace fb {
 // n >= 1 slots (wave-uniform); voff = byte offset of the lane's first value of the first slot from `vals` (advances 2304 per
 // slot), coff = byte offset of the lane's column word of the first slot from `cols`; pl0..2 = the three planes of the gathered
 // vector; row = the lane's row (16-bit words count from it).  All lanes of the wavefront must be active.
+// Pulls the values of the first n (<= 4) streamed slots of the lane's slice into the XCD's L2 and waits for them: 9 x n loads into
+// the temporaries, never read.  Called by the wavefronts that idle while wavefront 0 waits for the neighbours' flags -- the memory
+// system idles with them -- so that the product finds these lines in L2 and takes that much less from the Infinity Cache.
+__device__ __forceinline__ void pipe_prefetch_values(int n, unsigned int voff, const float* vals);
+
 // a pointer every lane holds alike, forced into a scalar register pair (an "s" operand of a value the compiler takes for
 // divergent would otherwise be handed over in vector registers)
 template <typename T>
@@ -138,6 +143,30 @@ __device__ __forceinline__ T* scalar_ptr(T* p) {
   const unsigned long long b = (unsigned long long)p;
   const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)b), hi = __builtin_amdgcn_readfirstlane((unsigned int)(b >> 32));
   return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void pipe_prefetch_values(int n, unsigned int voff, const float* vals) {
+  vals = scalar_ptr(vals);
+  n = __builtin_amdgcn_readfirstlane(n);
+  asm volatile("s_nop 4\n\t"
+               "s_cmp_lt_i32 %[n], 1\n\t"
+               "s_cbranch_scc1 .Lfbp_pf_end_%=\n\t"
+               FBP_LOADV("v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128")
+               "s_cmp_lt_i32 %[n], 2\n\t"
+               "s_cbranch_scc1 .Lfbp_pf_wait_%=\n\t"
+               FBP_LOADV("v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137")
+               "s_cmp_lt_i32 %[n], 3\n\t"
+               "s_cbranch_scc1 .Lfbp_pf_wait_%=\n\t"
+               FBP_LOADV("v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146")
+               "s_cmp_lt_i32 %[n], 4\n\t"
+               "s_cbranch_scc1 .Lfbp_pf_wait_%=\n\t"
+               FBP_LOADV("v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155")
+               ".Lfbp_pf_wait_%=:\n\t"
+               "s_waitcnt vmcnt(0)\n"
+               ".Lfbp_pf_end_%=:\n\t"
+               : [voff] "+v"(voff)
+               : [n] "s"(n), [svals] "s"(vals)
+               : FBP_CLOBBERS);
 }
 
 template <bool C16>
