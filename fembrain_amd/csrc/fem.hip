@@ -1173,6 +1173,16 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
     if (hipHostMalloc((void**)&h->st_host, 2 * sizeof(CGState), hipHostMallocDefault) != hipSuccess) { rc = fail(FB_ENOMEM, "hipHostMalloc failed"); break; }
     if (const char* e = getenv("FEMBRAIN_GRAPH")) h->use_graph = atoi(e) != 0;
     rc = build(h, n_nodes, xyz, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits, dm);
+    if (comm && comm->n_ranks > 1) {  // creation is collective: the ranks agree on build()'s outcome before the collective attach
+      const std::string why = rc == FB_OK ? std::string() : last_error();
+      std::vector<int> rcs((size_t)n_ranks, 0);
+      const int mine = rc;
+      const int rc_x = comm_allgather_bytes(comm, &mine, rcs.data(), sizeof(int), h->stream);
+      if (rc_x != FB_OK) { rc = rc_x; break; }
+      for (int q = 0; q < n_ranks && rc == FB_OK; q++)
+        if (rcs[q] != FB_OK) rc = fail(rcs[q], "handle creation failed on rank %d (code %d)", q, rcs[q]);
+      if (mine != FB_OK) { last_error() = why; rc = mine; }
+    }
     if (rc == FB_OK && comm && comm->n_ranks > 1) rc = attach_p2p(h);
   } while (0);
   if (rc != FB_OK) {
@@ -1346,7 +1356,20 @@ static int resync_sharded(fb_fem_t h, int n_nodes, const double* xyz, int n_tets
   const int n_ranks = h->plan.n_ranks, rank = h->plan.rank;
   const std::vector<int> kept = h->plan.splits;
   if (!node_splits && n_nodes == h->plan.n_global) node_splits = kept.data();
-  FB_TRY(build(h, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs, n_ranks, rank, node_splits));
+  // build() is rank-local (a bad node id or a flat element after a cut, no memory ...); what follows is collective.  The ranks
+  // agree on the outcome first: if any of them failed, none enters the collective attach -- all stay poisoned and return an
+  // error, instead of the healthy ones waiting in an all-gather for a rank that has left.
+  const int rc_mine = build(h, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs, n_ranks, rank, node_splits);
+  const std::string why_mine = rc_mine == FB_OK ? std::string() : last_error();
+  if (h->comm && h->comm->n_ranks > 1) {
+    std::vector<int> rcs((size_t)n_ranks, 0);
+    const int rc_x = comm_allgather_bytes(h->comm, &rc_mine, rcs.data(), sizeof(int), h->stream);
+    if (rc_x != FB_OK) return rc_x;
+    for (int q = 0; q < n_ranks; q++)
+      if (rcs[q] != FB_OK && rc_mine == FB_OK)
+        return fail(rcs[q], "re-sync failed on rank %d (code %d); this rank's handle is unusable until a re-sync succeeds on every rank", q, rcs[q]);
+  }
+  if (rc_mine != FB_OK) { last_error() = why_mine; return rc_mine; }
   const int mode = h->xch_mode;
   if (h->p2p) { p2p_detach(h->p2p); h->p2p = nullptr; }
   if (h->comm && h->comm->n_ranks > 1) FB_TRY(attach_p2p(h));
@@ -1445,7 +1468,10 @@ int newmark_step(fb_fem_s* h, fb_step_info* info) {
   do {
     FB_HIP(hipEventRecord(h->ev[0], s));
     FB_TRY(assemble_system(h));
-    // Newton error test on the residual (over the free DOFs: the clamped ones carry no equation here)
+    // Newton error test on the residual.  DEVIATION (parity unpinned): the sum runs over the FREE DOFs -- the rows of the
+    // clamped ones are identity rows here and their right-hand side is 0 -- where implicitNewmarkSparse.cpp:258-262 sums qresidual over
+    // all r DOFs before RemoveRows, reaction forces at the clamps included; with clamped nodes and max_newton > 1 the loop can
+    // therefore stop an iteration earlier than the reference's.  FemBrain runs one Newton iteration (Deformable.cpp:205-214).
     if (h->nm_max_newton > 1) {
       hipLaunchKernelGGL(k_sumsq, dim3(1), dim3(kBlock), 0, s, (size_t)n, h->rhs.p, h->scal.p + 4);
       FB_HIP(hipGetLastError());
@@ -1495,6 +1521,8 @@ int fb_fem_set_newmark(fb_fem_t h, double beta, double gamma, int max_newton_ite
   CHECK_HANDLE(h);
   if (!(beta > 0) || !(gamma > 0) || max_newton_iterations < 1 || !(epsilon >= 0)) return fail(FB_EINVAL, "bad Newmark parameters");
   if (h->prm.integrator != FB_INTEGRATOR_NEWMARK) return fail(FB_EINVAL, "the handle was not created with fb_fem_params.integrator = FB_INTEGRATOR_NEWMARK");
+  if (max_newton_iterations > 1 && h->comm && h->comm->n_ranks > 1)
+    return fail(FB_EINVAL, "Newmark with more than one Newton iteration is not built for sharded handles (the error quotient is a global sum)");
   h->nm_beta = beta; h->nm_gamma = gamma; h->nm_max_newton = max_newton_iterations; h->nm_eps = epsilon;
   h->system_valid = false;
   return FB_OK;

@@ -186,7 +186,9 @@ int fb_fem_set_internal_force_scaling(fb_fem_t h, double factor);
 int fb_fem_set_cg(fb_fem_t h, double eps, int max_iter);
 /* Newmark parameters (implicitNewmarkSparse.h: NewmarkBeta 0.25, NewmarkGamma 0.5; IntegratorBase: maxIterations 1, epsilon
  * 1e-6): the Newton loop stops when |residual|^2 / |first residual|^2 < epsilon^2 or after max_newton_iterations.  Each Newton
- * iteration is one assembly + one PCG solve that -- as in the reference -- starts from the previous solution. */
+ * iteration is one assembly + one PCG solve that -- as in the reference -- starts from the previous solution.  Deviation: the error
+ * quotient is taken over the free DOFs (the reference includes the reaction forces at the clamped ones, implicitNewmarkSparse.cpp:
+ * 258-262), so with max_newton_iterations > 1 the loop may stop earlier; unsharded handles only for more than one iteration. */
 int fb_fem_set_newmark(fb_fem_t h, double beta, double gamma, int max_newton_iterations, double epsilon);
 /* IntegratorBaseSparse::setConstrainedDOF (integratorBaseSparse.cpp:73-87) -- takes effect at the next step
  * (the mask is applied when Keff is formed, so unlike the reference no stale systemMatrix can survive) */

@@ -17,6 +17,8 @@ at test time.
                   the reference load (-10000 per y-DOF) and under -10, the tenth of the nodes with the lowest y clamped
   fem_cube56_step1.npz, fem_cube58_step1.npz   (round 3, `python make_fem_golden.py cube 56`) the first reference-load step of the
                   56^3 / 58^3 truth cubes (998,250 / 1,111,158 tets): iteration count, norms, q and qvel at 2,000 seeded DOFs
+  fem_{tumor,dumbel,dumbelclose,eggshell,implicit_sphere}.npz   (round 3, `python make_fem_golden.py round3`) the remaining tet meshes the
+                  reference ships as polygonizer output: mesh, q after 2 steps under the reference load and under -10, iteration counts
   fem_beam3.npz   data/models/beam3/beam3_tet.veg (208 nodes / 450 tets, Vega's own sample) with beam3.bou clamps:
                   mesh, the reference's consistent mass matrix file beam3_tet.mass (a known answer shipped by the
                   reference), and q after 3 steps with -10 per y-DOF
@@ -192,6 +194,35 @@ def peanut():
     print("peanut:", v.shape, t.shape, "fixed", len(fixed_vertices), "iters", ia_, ib_, "|q|", np.abs(qa[-1]).max(), np.abs(qb[-1]).max())
 
 
+def shipped_tet_mesh(name, rel):
+    """Round 3: the other tet meshes the reference ships as polygonizer output -- data/models/blobtree/{tumor,dumbel,dumbelclose,eggshell}.veg
+    (GPUPoly surfaces tetrahedralized by TetGen, like peanut.veg) and data/models/sphere/implicit_sphere.veg (the tet polygonizer's own
+    output: 624 cells of 6 tets, vertices not welded, so every cell is a body of its own) -- through the reference build: q after the
+    second step under the reference load and under -10 per y-DOF, the tenth of the nodes with the lowest y clamped, iteration counts
+    of both steps."""
+    v, t = read_veg(os.path.join(REF, rel))
+    v = v.astype(np.float32).astype(np.float64)  # (the files print 6 digits)
+    order = np.argsort(v[:, 1], kind="stable")
+    fixed_vertices = np.sort(order[:len(v) // 10]).astype(np.int32)
+    fixed = fixed_vertices_to_dofs(fixed_vertices)
+    r0 = RefFem(v, t)
+    f0, K0 = r0.assemble(np.zeros(r0.r))
+    if not (np.isfinite(K0).all() and np.isfinite(f0).all()):
+        # tumor.veg: 524 of its 32,303 tets have zero volume at the 6 digits the file prints; inverse4x4 divides by zero and the
+        # reference's K and f are NaN from the first assembly on (its PCG then "converges" in 0 iterations on NaN).  Recorded as such.
+        p = v[t]
+        vol = np.einsum("ij,ij->i", np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), p[:, 3] - p[:, 0]) / 6
+        np.savez_compressed(os.path.join(HERE, "fem_%s.npz" % name), verts=v.astype(np.float32), tets=t.astype(np.int32), fixed_vertices=fixed_vertices,
+                            reference_K_finite=False, n_flat_tets=int((vol == 0).sum()), first_flat_tet=int(np.nonzero(vol == 0)[0][0]))
+        print("%s: reference K is not finite (%d tets of exactly zero volume, first %d)" % (name, (vol == 0).sum(), np.nonzero(vol == 0)[0][0]))
+        return
+    qa, _, ia_ = steps(v, t, fixed, -10000.0, n=2)
+    qb, _, ib_ = steps(v, t, fixed, -10.0, n=2)
+    np.savez_compressed(os.path.join(HERE, "fem_%s.npz" % name), verts=v.astype(np.float32), tets=t.astype(np.int32), fixed_vertices=fixed_vertices,
+                        q_ref_load=qa[-1].astype(np.float64), it_ref_load=ia_, q_gentle=qb[-1], it_gentle=ib_)
+    print("%s:" % name, v.shape, t.shape, "fixed", len(fixed_vertices), "iters", ia_, ib_, "|q|", np.abs(qa[-1]).max(), np.abs(qb[-1]).max())
+
+
 def cube_big(n):
     """Round 3: the FIRST step from rest of the n^3-node truth cube under the reference load (plane i = 0 clamped, -10000 per y-DOF,
     CG eps 1e-6) by the reference build -- 56^3 = BASELINE config 4 (998,250 tets), 58^3 = the largest cube of 12 slices per CU:
@@ -218,6 +249,10 @@ def cube_big(n):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "cube":
         cube_big(int(sys.argv[2]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "round3":
+        for nm in ("tumor", "dumbel", "dumbelclose", "eggshell"):
+            shipped_tet_mesh(nm, "blobtree/%s.veg" % nm)
+        shipped_tet_mesh("implicit_sphere", "sphere/implicit_sphere.veg")
     elif len(sys.argv) > 1 and sys.argv[1] == "linear":
         cube5_linear()   # added later: leaves the other two files as they are
     elif len(sys.argv) > 1 and sys.argv[1] == "round2":

@@ -373,3 +373,80 @@ def test_sharded_device_plan_equals_host_plan_and_resyncs(gpu, world, n):
     for rank, bad, same, ms, its in res:
         assert bad == [], (rank, bad)
         assert same, (rank, its)
+
+
+def _bad_resync_worker(rank, world, shm_name, q):
+    try:
+        from fembrain_amd import lib as fl
+        from fembrain_amd.fem import FemIntegrator
+        L = fl.lib()
+        comm = C.c_void_p()
+        fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
+        v, t, fixed, splits = _mesh(10, world)
+        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm))
+        g.set_uniform_force(1, -3000.0)
+        it0 = g.do_timestep()
+        # the re-sync mesh of the LAST rank has a flat element among its own (every rank passes its own elements: per-rank ingest)
+        own = ((t >= splits[rank]) & (t < splits[rank + 1])).any(axis=1)
+        t_mine = t[own].copy()
+        v_mine = v.copy()
+        if rank == world - 1:
+            e = t_mine[len(t_mine) // 2]
+            v_mine[e[3]] = v_mine[e[0]]
+        msg = None
+        try:
+            g.resync(v_mine, t_mine, fixed, node_splits=splits)
+        except fl.FbError as e:
+            msg = str(e)
+        poisoned = None
+        try:
+            g.do_timestep()
+        except fl.FbError as e:
+            poisoned = str(e)
+        # a good collective re-sync heals every rank, and the step is the step of a fresh handle
+        g.resync(v, t, fixed, node_splits=splits)
+        g.set_uniform_force(1, -3000.0)
+        it1 = g.do_timestep()
+        q.put((rank, msg, poisoned, it0, it1))
+        g.close()
+        L.fb_comm_destroy(comm)
+    except Exception as e:
+        import traceback
+        q.put((rank, "EXC " + repr(e) + traceback.format_exc(), None, 0, 0))
+        q.close()
+        q.join_thread()
+        os._exit(1)
+
+
+def test_a_failed_collective_resync_fails_on_every_rank_instead_of_hanging(gpu):
+    """fb_fem_resync_sharded is collective, its plan build is not: one rank's mesh has a flat element after a 'cut'.  The ranks
+    agree on the outcome before the collective attach of the peer inboxes: the bad rank reports its element, the
+    healthy rank reports that rank -- within the call, not after a communicator time-out --, both handles are unusable until a
+    re-sync that succeeds everywhere, and that one restores the step of a fresh handle."""
+    import multiprocessing as mp
+    import time
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "/fembrain_test_%d_badresync" % os.getpid()
+    procs = [ctx.Process(target=_bad_resync_worker, args=(r, world, name, q)) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            r = q.get(timeout=120)
+            res[r[0]] = r
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert time.time() - t0 < 100
+    for rank in range(world):
+        _, msg, poisoned, it0, it1 = res[rank]
+        assert msg is not None and not msg.startswith("EXC"), res[rank]
+        assert ("rest volume" in msg) if rank == world - 1 else ("failed on rank %d" % (world - 1) in msg), (rank, msg)
+        assert poisoned is not None and "unusable after a failed" in poisoned, (rank, poisoned)
+        assert it0 > 0 and it1 == it0, (rank, it0, it1)
