@@ -11,6 +11,7 @@
 #include "fem_device.hip.h"
 #include "fem_plan.h"
 #include "pcg_pipe.hip.h"
+#include "pcg_pipe2.hip.h"
 #include "plan_device.h"
 
 using namespace fb;
@@ -88,6 +89,7 @@ struct fb_fem_s {
   int pipe_plain_local = 0;            // interior workgroups publish with plain stores (FEMBRAIN_PIPE_PLAIN_STORES)
   DevBuf<double> pipe_planes, pipe_z, pipe_s, pipe_state;
   int pipe_klt = 0, pipe_wmax = 0;
+  int pipe_rows = 1;                   // rows per lane: 1 = k_pcg_pipe (up to 12 slices per CU), 2 = k_pcg_pipe2 (13..24)
   int pipe_max_producers = 0;          // longest producer list (-1: some workgroup polls all)
   long long persist_timeout_ticks = 0; // wall_clock64 ticks (100 MHz) a wait inside a persistent launch may last
   int persist_fallbacks = 0;           // solves that had to be repeated with the two-launch form
@@ -152,11 +154,11 @@ int setup_persist(fb_fem_s* h) {
   const bool explicit_p = h->prm.pcg_variant == FB_PCG_PERSISTENT;
   if (explicit_p && P.n_ranks > 1) return fail(FB_EINVAL, "FB_PCG_PERSISTENT is for unsharded handles");
   if (explicit_p && h->f64) return fail(FB_EINVAL, "FB_PCG_PERSISTENT needs FB_MATRIX_F32 storage (part of the matrix is kept in LDS as fp32 words)");
-  if (explicit_p && (nb < 8 || w < 1 || w > kPipeMaxWaves))
-    return fail(FB_EINVAL, "FB_PCG_PERSISTENT needs at most %d slices per CU, this mesh has %d on %d CUs", kPipeMaxWaves, w, nb);
+  if (explicit_p && (nb < 8 || w < 1 || w > 2 * kPipeMaxWaves))
+    return fail(FB_EINVAL, "FB_PCG_PERSISTENT needs at most %d slices per CU, this mesh has %d on %d CUs", 2 * kPipeMaxWaves, w, nb);
   // asked for explicitly (parameter or FEMBRAIN_PCG_PERSIST=1), or by default where it was measured faster than the
   // two-launch iteration: fp32 storage, up to 12 slices per CU
-  const bool eligible = !h->f64 && P.n_ranks == 1 && nb >= 8 && w >= 1 && w <= kPipeMaxWaves;
+  const bool eligible = !h->f64 && P.n_ranks == 1 && nb >= 8 && w >= 1 && w <= 2 * kPipeMaxWaves;
   // (us per iteration, two-launch vs persistent, on MI355X: 7.7 / 10.2 at 43 slices, 9.05 / 9.55 at 466 = 2 per CU, 10.9 / 9.9 at 614 =
   // 3 per CU, 14.0 / 10.3 at 792, 15.8 / 9.5 at 1,000, 27.4 / 17.1 at 2,744 = 1M tets)
   static const int min_w = getenv("FEMBRAIN_PERSIST_MIN_WAVES") ? atoi(getenv("FEMBRAIN_PERSIST_MIN_WAVES")) : 3;
@@ -165,8 +167,11 @@ int setup_persist(fb_fem_s* h) {
   if (!want_p || !eligible) return FB_OK;
   h->persist = true; h->persist_blocks = nb; h->persist_waves = w;
   // pipelined whole-solve kernel
-  h->pipe_wmax = w <= 8 ? 8 : 12;
-  h->pipe_klt = w <= 8 ? 7 : 5;   // slots of every slice resident in LDS: (160 KB - sync) / (wavefronts * 2560 B)
+  // up to 12 slices per CU: one row per lane (k_pcg_pipe); 13..24: two (k_pcg_pipe2, no LDS-resident slots).  FEMBRAIN_PERSIST_ROWS=2
+  // forces the two-row kernel on a smaller system (tests).
+  h->pipe_rows = w > kPipeMaxWaves || (getenv("FEMBRAIN_PERSIST_ROWS") && atoi(getenv("FEMBRAIN_PERSIST_ROWS")) == 2) ? 2 : 1;
+  h->pipe_wmax = h->pipe_rows == 2 ? 12 : (w <= 8 ? 8 : 12);
+  h->pipe_klt = h->pipe_rows == 2 ? 0 : (w <= 8 ? 7 : 5);   // slots of every slice resident in LDS: (160 KB - sync) / (wavefronts * 2560 B)
   FB_TRY(h->pipe_post.alloc((size_t)2 * nb * 4));
   FB_TRY(h->pipe_post.zero(s));
   FB_TRY(h->pipe_flags.alloc((size_t)nb + 16));
@@ -707,12 +712,13 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   const size_t lds = 160 * 1024;
   // one wavefront more than slices where the instantiation has room: it collects the sums while the others multiply
   static const bool want_service = !(getenv("FEMBRAIN_PIPE_SERVICE_WAVE") && atoi(getenv("FEMBRAIN_PIPE_SERVICE_WAVE")) == 0);
-  pa.service = want_service && h->persist_waves < h->pipe_wmax ? 1 : 0;
+  const int cwaves = h->pipe_rows == 2 ? ceil_div(h->persist_waves, 2) : h->persist_waves;  // wavefronts that own slices
+  pa.service = want_service && cwaves < h->pipe_wmax ? 1 : 0;
   // values of the first streamed slots pulled into L2 during the neighbour wait: pays where the product is bandwidth-bound (9 and more
   // slices per CU: -6 % per iteration at 1M tets; neutral at 1,000 slices).  FEMBRAIN_PIPE_PREFETCH=0..4 overrides.
   static const int prefetch = getenv("FEMBRAIN_PIPE_PREFETCH") ? std::max(0, std::min(4, atoi(getenv("FEMBRAIN_PIPE_PREFETCH")))) : -1;
-  pa.prefetch_slots = prefetch >= 0 ? prefetch : (h->persist_waves >= 9 ? 4 : 0);
-  const dim3 grid(h->persist_blocks), block(64 * (h->persist_waves + pa.service));
+  pa.prefetch_slots = prefetch >= 0 ? prefetch : (h->persist_waves >= 9 ? (h->pipe_rows == 2 ? 3 : 4) : 0);
+  const dim3 grid(h->persist_blocks), block(64 * (cwaves + pa.service));
   FB_HIP(hipEventRecord(h->ev_p[0], h->stream));
 #define FB_PIPE(C16, WMAX, KLT, TIMING)                                                                                                        \
   do {                                                                                                                                         \
@@ -725,7 +731,23 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     hipLaunchKernelGGL((k_pcg_pipe<float, C16, WMAX, KLT, TIMING>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p,       \
                        (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);       \
   } while (0)
-  // the instantiations: (wavefronts, LDS slots) = (8, 7) up to 8 slices per CU, (12, 5) up to 12; 16- or 32-bit column words
+  // the instantiations: (wavefronts, LDS slots) = (8, 7) up to 8 slices per CU, (12, 5) up to 12; 16- or 32-bit column words;
+  // two rows per lane (k_pcg_pipe2) for 13..24 slices per CU
+  if (h->pipe_rows == 2) {
+    static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)kPipeMaxWaves * 2 * kPipe2LdsWordsPerRow * 64 * 4 <= 160 * 1024, "LDS budget of k_pcg_pipe2");
+    static bool attr2[2] = {false, false};
+    const void* kern = h->c16 ? (const void*)k_pcg_pipe2<true> : (const void*)k_pcg_pipe2<false>;
+    if (!attr2[h->c16 ? 1 : 0]) {
+      FB_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr2[h->c16 ? 1 : 0] = true;
+    }
+    if (h->c16)
+      hipLaunchKernelGGL((k_pcg_pipe2<true>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b,
+                         h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);
+    else
+      hipLaunchKernelGGL((k_pcg_pipe2<false>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b,
+                         h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);
+  } else
   if (pa.timing) {  // development build with the phase clocks: the 1M-tet configuration only
     if (h->pipe_wmax == 12 && h->c16) FB_PIPE(true, 12, 5, true);
     else return fail(FB_EINVAL, "FEMBRAIN_PERSIST_TIMING is built for 9..12 slices per CU with 16-bit column words");
@@ -801,7 +823,7 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
     if (fin.iter > max_iter) return fail(FB_EDEVICE, "internal: persistent PCG ran past max_iter (iter %d)", fin.iter);
     start = 0;
   }
-  if (h->persist_timing.p) print_pipe_timing(h);
+  if (h->persist_timing.p && h->pipe_rows == 1) print_pipe_timing(h);
   h->last_pcg_path = FB_PCG_PATH_PERSISTENT;
   const double rho = fin.rho[fin.iter & 1];
   const bool converged = !(rho > fin.eps2 * fin.rho0);
@@ -1881,7 +1903,8 @@ int fb_fem_persist_info(fb_fem_t h, int* waves_per_cu, int* workgroups, int* lds
 int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches, int* persist_fallbacks, int* max_producers) {
   if (!h) return fail(FB_EINVAL, "null FEM handle");
   if (name && name_len > 0) {
-    if (h->persist) snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_klt);
+    if (h->persist && h->pipe_rows == 2) snprintf(name, name_len, "k_pcg_pipe2<%s>", h->c16 ? "c16" : "c32");
+    else if (h->persist) snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_klt);
     else name[0] = 0;
   }
   if (persist_launches) *persist_launches = h->persist_launches;

@@ -1207,15 +1207,75 @@ def test_default_handle_at_1M_tets_against_the_reference_built_golden(gpu, monke
         g2.close()
 
 
+@pytest.mark.parametrize("n,c16,kernel", [(14, True, "k_pcg_pipe2<c16>"), (26, False, "k_pcg_pipe2<c32>"), (31, True, "k_pcg_pipe2<c16>")])
+def test_two_row_persistent_solver_against_the_oracle_and_itself(gpu, monkeypatch, n, c16, kernel):
+    """k_pcg_pipe2 (a wavefront owns two slices, x / p / z in LDS; the form of 13..24 slices per CU) forced onto small cubes
+    (FEMBRAIN_PERSIST_ROWS=2): three reference-load steps against the CPU oracle, a tight solve against the two-launch solver, and
+    itself cut into launches of 1 and 7 iterations bit for bit.  n = 14: one wavefront with one row set in use; 26 / 31: two row
+    sets, one or two wavefronts per workgroup."""
+    v, t, fixed = _cube(n)
+    o = OrcFem(v, t)
+    o.integrator(fixed)
+    monkeypatch.setenv("FEMBRAIN_PERSIST_ROWS", "2")
+    g = _persistent(monkeypatch, kernel, v, t, fixed, c16=c16)
+    monkeypatch.delenv("FEMBRAIN_PERSIST_ROWS")
+    gm = _two_launch(monkeypatch, v, t, fixed)
+    for h in (g, gm):
+        h.set_uniform_force(1, -10000.0)
+    _, rhs = gm.system()
+    g.system()
+    itm, xm = gm.pcg(rhs, eps=1e-8, max_iter=20000)
+    itp, xp = g.pcg(rhs, eps=1e-8, max_iter=20000)
+    assert g.pcg_path()["path"] == fl.FB_PCG_PATH_PERSISTENT and abs(itp - itm) <= max(3, 0.02 * itm)
+    assert np.abs(xp - xm).max() <= 1e-6 * np.abs(xm).max() and not xp[fixed].any()
+    for run in ("1", "7", "30"):
+        monkeypatch.setenv("FEMBRAIN_PERSIST_MAX_RUN", run)
+        itc, xc = g.pcg(rhs, eps=1e-8, max_iter=20000)
+        assert itc == itp and np.array_equal(xc, xp), run
+    monkeypatch.delenv("FEMBRAIN_PERSIST_MAX_RUN")
+    itl, xl = g.pcg(rhs, eps=1e-8, max_iter=37)
+    assert itl == -37 and g.pcg_path()["path"] == fl.FB_PCG_PATH_RESOLVED
+    fext = np.zeros(o.r)
+    fext[1::3] = -10000.0
+    for k in range(3):
+        o.set_external_forces(fext)
+        g.set_external_forces(fext)
+        io, ig = abs(o.step()), g.do_timestep()
+        assert abs(ig - io) <= max(3, 0.02 * io), (k, ig, io)
+        qo, qg = o.get_state()[0], g.get_q_state()[0]
+        assert np.abs(qg - qo).max() <= 2e-4 * np.abs(qo).max(), k
+        assert g.last.pcg_path == fl.FB_PCG_PATH_PERSISTENT
+    g.close(); gm.close()
+
+
+@pytest.mark.parametrize("n,c16,kernel,slices_per_cu", [(60, True, "k_pcg_pipe2<c16>", 14), (60, False, "k_pcg_pipe2<c32>", 14), (73, True, "k_pcg_pipe2<c16>", 24)])
+def test_default_handle_between_1M_and_2M_tets_against_the_reference_built_golden(gpu, monkeypatch, n, c16, kernel, slices_per_cu):
+    """13..24 slices per CU: 60^3 nodes (1,232,274 tets, 14 per CU) and 73^3 (2,239,488 tets, 24 per CU, the largest the persistent
+    solver takes).  The DEFAULT handle runs the two-row persistent kernel and reproduces the first reference-load step of the
+    reference's own CorotationalLinearFEM + CGSolver (tests/golden/fem_cube60_step1.npz / fem_cube73_step1.npz)."""
+    gold = np.load(os.path.join(GOLD, "fem_cube%d_step1.npz" % n))
+    v, t, fixed = _cube(n)
+    if not c16:
+        monkeypatch.setenv("FEMBRAIN_SPMV_C16", "0")
+    g = FemIntegrator(v, t, fixed)
+    monkeypatch.delenv("FEMBRAIN_SPMV_C16", raising=False)
+    on, waves, wgs, slots = g.persist_info()
+    assert on and waves == slices_per_cu and wgs == 256 and slots == 0 and g.pcg_path()["kernel"] == kernel
+    _check_against_big_golden(g, gold)
+    p = g.pcg_path()
+    assert p["path"] == fl.FB_PCG_PATH_PERSISTENT and p["launches"] == 1 and p["fallbacks"] == 0
+    g.close()
+
+
 def test_persistent_solver_limits_are_refused_not_degraded(gpu, monkeypatch):
-    """FB_PCG_PERSISTENT asked for explicitly where it cannot run is an error, not a silent other solver: fp64 storage, more than 12
+    """FB_PCG_PERSISTENT asked for explicitly where it cannot run is an error, not a silent other solver: fp64 storage, more than 24
     slices per CU.  The default (FB_PCG_MERGED) falls to the two-launch solver there and says so."""
     v, t, fixed = _cube(9)
     with pytest.raises(fl.FbError, match="FB_MATRIX_F32"):
         FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT, matrix_precision=fl.FB_MATRIX_F64)
     with pytest.raises(fl.FbError, match="unknown pcg_variant"):
         FemIntegrator(v, t, fixed, pcg_variant=2)           # the removed FB_PCG_FUSED
-    v, t, fixed = _cube(60)                                # 216,000 nodes = 3,375 slices: 14 per CU
+    v, t, fixed = _cube(75)                                # 421,875 nodes = 6,592 slices: 26 per CU
     with pytest.raises(fl.FbError, match="slices per CU"):
         FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT)
     g = FemIntegrator(v, t, fixed)
