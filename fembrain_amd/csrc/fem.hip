@@ -171,7 +171,8 @@ int setup_persist(fb_fem_s* h) {
   // forces the two-row kernel on a smaller system (tests).
   h->pipe_rows = w > kPipeMaxWaves || (getenv("FEMBRAIN_PERSIST_ROWS") && atoi(getenv("FEMBRAIN_PERSIST_ROWS")) == 2) ? 2 : 1;
   h->pipe_wmax = h->pipe_rows == 2 ? 12 : (w <= 8 ? 8 : 12);
-  h->pipe_klt = h->pipe_rows == 2 ? 0 : (w <= 8 ? 7 : 5);   // slots of every slice resident in LDS: (160 KB - sync) / (wavefronts * 2560 B)
+  // slots of every slice resident in LDS at least: the CU's kPipeLdsSlots dealt to the slices of a workgroup (k_pcg_pipe), at most 8 / 6
+  h->pipe_klt = h->pipe_rows == 2 ? 0 : std::min(w <= 8 ? 8 : 6, kPipeLdsSlots / std::max(w, 1));
   FB_TRY(h->pipe_post.alloc((size_t)2 * nb * 4));
   FB_TRY(h->pipe_post.zero(s));
   FB_TRY(h->pipe_flags.alloc((size_t)nb + 16));
@@ -722,7 +723,6 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   FB_HIP(hipEventRecord(h->ev_p[0], h->stream));
 #define FB_PIPE(C16, WMAX, KLT, TIMING)                                                                                                        \
   do {                                                                                                                                         \
-    static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)WMAX * KLT * 10 * 64 * 4 <= 160 * 1024, "LDS budget of k_pcg_pipe");             \
     static bool attr = false;                                                                                                                  \
     if (!attr) {                                                                                                                               \
       FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe<float, C16, WMAX, KLT, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -731,7 +731,7 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     hipLaunchKernelGGL((k_pcg_pipe<float, C16, WMAX, KLT, TIMING>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p,       \
                        (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);       \
   } while (0)
-  // the instantiations: (wavefronts, LDS slots) = (8, 7) up to 8 slices per CU, (12, 5) up to 12; 16- or 32-bit column words;
+  // the instantiations: (wavefronts, most LDS slots per wavefront) = (8, 8) up to 8 slices per CU, (12, 6) up to 12; 16- or 32-bit column words;
   // two rows per lane (k_pcg_pipe2) for 13..24 slices per CU
   if (h->pipe_rows == 2) {
     static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)kPipeMaxWaves * 2 * kPipe2LdsWordsPerRow * 64 * 4 <= 160 * 1024, "LDS budget of k_pcg_pipe2");
@@ -749,10 +749,10 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
                          h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);
   } else
   if (pa.timing) {  // development build with the phase clocks: the 1M-tet configuration only
-    if (h->pipe_wmax == 12 && h->c16) FB_PIPE(true, 12, 5, true);
+    if (h->pipe_wmax == 12 && h->c16) FB_PIPE(true, 12, 6, true);
     else return fail(FB_EINVAL, "FEMBRAIN_PERSIST_TIMING is built for 9..12 slices per CU with 16-bit column words");
-  } else if (h->pipe_wmax == 8) { if (h->c16) FB_PIPE(true, 8, 7, false); else FB_PIPE(false, 8, 7, false); }
-  else { if (h->c16) FB_PIPE(true, 12, 5, false); else FB_PIPE(false, 12, 5, false); }
+  } else if (h->pipe_wmax == 8) { if (h->c16) FB_PIPE(true, 8, 8, false); else FB_PIPE(false, 8, 8, false); }
+  else { if (h->c16) FB_PIPE(true, 12, 6, false); else FB_PIPE(false, 12, 6, false); }
 #undef FB_PIPE
   FB_HIP(hipGetLastError());
   FB_HIP(hipEventRecord(h->ev_p[1], h->stream));
@@ -1904,7 +1904,7 @@ int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches,
   if (!h) return fail(FB_EINVAL, "null FEM handle");
   if (name && name_len > 0) {
     if (h->persist && h->pipe_rows == 2) snprintf(name, name_len, "k_pcg_pipe2<%s>", h->c16 ? "c16" : "c32");
-    else if (h->persist) snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_klt);
+    else if (h->persist) snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_wmax == 8 ? 8 : 6);
     else name[0] = 0;
   }
   if (persist_launches) *persist_launches = h->persist_launches;

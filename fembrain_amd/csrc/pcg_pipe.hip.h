@@ -38,6 +38,8 @@ constexpr int kPipeMaxWaves = 12;    // wavefronts (= slices) per workgroup
 constexpr int kPipeMaxBlocks = 256;  // workgroups = CUs
 constexpr int kPipeSyncDoubles = 2 * 16 + 2 * kPipeMaxBlocks + 8;  // LDS in front of the resident values: wave sums | gathered sums | broadcast
 constexpr int kPipeMaxProducers = 64;
+constexpr int kPipeLdsSlots = 60;     // wavefront-slots of 10 x 64 words that fit the CU's 160 KB beside the sync buffers
+static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)kPipeLdsSlots * 10 * 64 * 4 <= 160 * 1024, "LDS budget of k_pcg_pipe");
 
 struct PipeArgs {
   unsigned long long* post;   // [2][n_blocks][4] granules: (hi, lo) of gamma, delta, each | sequence << 32
@@ -111,8 +113,11 @@ __global__ __launch_bounds__(kBlock) void k_slice_colrange(int n_slices, int n_o
 }
 
 // WMAX: wavefronts per workgroup the instantiation is bounded for (512 registers per lane and SIMD are shared by
-// ceil(WMAX / 4) wavefronts).  KLT: the first KLT slots of every slice (9 values + the column id per lane) are loaded into LDS
-// ONCE per launch -- the matrix does not change during a solve; slots beyond are streamed every product as in k_spmv.
+// ceil(WMAX / 4) wavefronts).  LDS-resident part of the matrix: the first slots of every slice (9 values + the column id per lane)
+// are loaded into LDS ONCE per launch -- the matrix does not change during a solve; slots beyond are streamed every product as in
+// k_spmv.  The CU's LDS holds kPipeLdsSlots = 60 wavefront-slots (2,560 B each) beside the sync buffers; a workgroup deals them
+// to its `count` live wavefronts, count-th part each and the remainder one more for the first ones (11 slices: 5 slots each and a
+// sixth for five of them; 10 slices: 6 each), at most KLT per wavefront (the unroll bound of the LDS loop).
 // TIMING: the development build with per-phase clocks (FEMBRAIN_PERSIST_TIMING=1).
 template <typename MT, bool C16, int WMAX, int KLT, bool TIMING>
 __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo,
@@ -150,9 +155,11 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
 #pragma unroll
     for (int a = 0; a < 3; a++) iv[a] = invdiag[dof + a];
   }
-  // LDS-resident part of the matrix: the first KL slots of this wave's slice, [KLT][10][64] words (9 values + the column id)
-  const int KL = min(KLT, width);
-  unsigned int* lres = (unsigned int*)(lds + kPipeSyncDoubles) + (size_t)wv * KLT * 10 * 64 + lane;
+  // LDS-resident part of the matrix: the first KL slots of this wave's slice, [klt_w][10][64] words (9 values + the column id)
+  const int lbase = min(KLT, kPipeLdsSlots / max(count, 1)), lrem = lbase < KLT ? min(count, kPipeLdsSlots - lbase * count) : 0;  // workgroup-uniform
+  const int klt_w = __builtin_amdgcn_readfirstlane(live ? lbase + (wv < lrem ? 1 : 0) : 0);
+  const int KL = min(klt_w, width);
+  unsigned int* lres = (unsigned int*)(lds + kPipeSyncDoubles) + (size_t)(wv * lbase + min(wv, lrem)) * 10 * 64 + lane;
   if (sizeof(MT) == 4) {
     for (int k = 0; k < KL; k++) {
       const MT* vk = v + (size_t)k * 9 * 64;
@@ -199,13 +206,13 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     __syncthreads();
     lap(0);  // publish, drained
     if (post_sums) sums++;
-    if (wv != 0 && live && pa.prefetch_slots > 0 && width > KLT) {
+    if (wv != 0 && live && pa.prefetch_slots > 0 && width > klt_w) {
       // idle until wavefront 0 has seen the neighbours' flags: the first streamed slots' values go to L2 meanwhile (measured at 1M
       // tets, us per iteration with 0 / 2 / 3 / 4 slots: 17.15 / 16.25 / 16.1 / 16.05; the same during the drain of the publish
       // stores instead delays the flag and loses: 16.85)
-      int so_k = so + KLT;
+      int so_k = so + klt_w;
       asm volatile("" : "+s"(so_k));  // (opaque, as for the streamed loop below)
-      pipe_prefetch_values(min(pa.prefetch_slots, width - KLT), ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float), vals);
+      pipe_prefetch_values(min(pa.prefetch_slots, width - klt_w), ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float), vals);
     }
     if (wv == 0) {
       if (lane == 0) st_sc1_u32(pa.flags + blockIdx.x, pub);
@@ -273,9 +280,9 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
         }
       }
       // the streamed slots: hand-pipelined loads (pcg_pipe_stream.hip.h)
-      const int n_str = width - KLT;
+      const int n_str = width - klt_w;
       if (n_str > 0) {
-        int so_k = so + KLT;
+        int so_k = so + klt_w;
         asm volatile("" : "+s"(so_k));  // opaque: keeps the two offsets below from being hoisted out of the solver loop into live registers
         pipe_stream_slots<C16>(n_str, ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
                                ((unsigned int)so_k * 64u + (unsigned int)lane) * (unsigned int)(C16 ? sizeof(short) : sizeof(int)), vals,

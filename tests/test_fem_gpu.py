@@ -1059,8 +1059,8 @@ def test_failed_resync_poisons_the_handle_until_a_good_one(gpu):
 
 
 # ---- the persistent pipelined solver (pcg_pipe.hip.h): every instantiation the dispatch can select ------------------------------
-# k_pcg_pipe<float, c16 | c32, (8, 7) | (12, 5)>: 16- or 32-bit column words; up to 8 slices per CU with 7 LDS-resident slots, 9..12
-# with 5.  Each is checked against the oracle or a reference-built golden (fem_cube56_step1.npz / fem_cube58_step1.npz: the
+# k_pcg_pipe<float, c16 | c32, (8, 8) | (12, 6)>: 16- or 32-bit column words; up to 8 slices per CU with up to 8 LDS-resident slots per
+# slice, 9..12 with up to 6 (the CU's 60 wavefront-slots dealt to the workgroup's slices); k_pcg_pipe2<c16 | c32> for 13..24.  Each is checked against the oracle or a reference-built golden (fem_cube56_step1.npz / fem_cube58_step1.npz: the
 # reference's own CorotationalLinearFEM + CGSolver, tests/golden/make_fem_golden.py) AND against the two-launch solver of the same
 # library; fb_fem_pcg_path says which kernel ran.
 def _two_launch(monkeypatch, *a, **kw):
@@ -1082,8 +1082,8 @@ def _persistent(monkeypatch, kernel, *a, c16=True, **kw):
     return g
 
 
-@pytest.mark.parametrize("n,c16,kernel", [(14, True, "k_pcg_pipe<float,c16,8,7>"), (14, False, "k_pcg_pipe<float,c32,8,7>"),
-                                          (26, True, "k_pcg_pipe<float,c16,8,7>"), (26, False, "k_pcg_pipe<float,c32,8,7>")])
+@pytest.mark.parametrize("n,c16,kernel", [(14, True, "k_pcg_pipe<float,c16,8,8>"), (14, False, "k_pcg_pipe<float,c32,8,8>"),
+                                          (26, True, "k_pcg_pipe<float,c16,8,8>"), (26, False, "k_pcg_pipe<float,c32,8,8>")])
 def test_persistent_solver_against_the_oracle(gpu, monkeypatch, n, c16, kernel):
     """One and two slices per workgroup (2,744 / 17,576 nodes): the solution of a tight solve and three reference-load steps against
     the CPU oracle (CGSolver.cpp:129-190 restated), iteration counts within max(3, 2 %)."""
@@ -1130,9 +1130,9 @@ def test_persistent_solver_matches_two_launch_and_itself(gpu, n, monkeypatch):
     (n = 14), 2 (n = 31), 4 (n = 40).  Also the poll-all form of the neighbour wait (what an unstructured numbering gets)."""
     v, t, fixed = _cube(n)
     gm = _two_launch(monkeypatch, v, t, fixed)
-    gp = _persistent(monkeypatch, "k_pcg_pipe<float,c16,8,7>", v, t, fixed)
+    gp = _persistent(monkeypatch, "k_pcg_pipe<float,c16,8,8>", v, t, fixed)
     monkeypatch.setenv("FEMBRAIN_PERSIST_POLL_ALL", "1")
-    ga = _persistent(monkeypatch, "k_pcg_pipe<float,c16,8,7>", v, t, fixed)
+    ga = _persistent(monkeypatch, "k_pcg_pipe<float,c16,8,8>", v, t, fixed)
     monkeypatch.delenv("FEMBRAIN_PERSIST_POLL_ALL")
     assert ga.pcg_path()["max_producers"] == -1 and gp.pcg_path()["max_producers"] > 0
     for g in (gm, gp, ga):
@@ -1180,8 +1180,8 @@ def _check_against_big_golden(g, gold, tol_q=2e-4):
     return it, q
 
 
-@pytest.mark.parametrize("n,c16,kernel,slices_per_cu", [(56, True, "k_pcg_pipe<float,c16,12,5>", 11), (56, False, "k_pcg_pipe<float,c32,12,5>", 11),
-                                                        (58, True, "k_pcg_pipe<float,c16,12,5>", 12)])
+@pytest.mark.parametrize("n,c16,kernel,slices_per_cu", [(56, True, "k_pcg_pipe<float,c16,12,6>", 11), (56, False, "k_pcg_pipe<float,c32,12,6>", 11),
+                                                        (58, True, "k_pcg_pipe<float,c16,12,6>", 12)])
 def test_default_handle_at_1M_tets_against_the_reference_built_golden(gpu, monkeypatch, n, c16, kernel, slices_per_cu):
     """BASELINE config 4 (56^3 nodes, 998,250 tets: 11 slices per CU) and the largest cube the persistent solver takes (58^3, 1.11M
     tets: 12 per CU): the DEFAULT handle -- no variant asked for -- runs the persistent kernel and reproduces the first reference-load
