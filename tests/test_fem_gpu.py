@@ -258,7 +258,8 @@ def test_config1_sphere_tetmesh_one_step(gpu):
 
 
 def test_beam3_against_reference_golden(gpu):
-    """Vega's own beam (208 nodes / 450 tets, TetGen-style unstructured) with the reference build's q after 3 steps."""
+    """Vega's own beam (208 nodes / 450 tets, TetGen-style unstructured) with the q after 3 steps of the step sequence restated on
+    reference objects (oracle/ref_harness.cpp over the reference's own force model, matrix and solver code)."""
     import os
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "fem_beam3.npz"))
     fixed = fixed_vertices_to_dofs(gold["fixed_vertices"])
@@ -1396,7 +1397,8 @@ def test_exact_tangent_steps_match_oracle(gpu):
 @pytest.mark.parametrize("max_newton", [1, 3])
 def test_newmark_step_matches_reference_golden_and_oracle(gpu, prec, tol, max_newton):
     """ImplicitNewmarkSparse::DoTimestep (implicitNewmarkSparse.cpp:183-379; beta 1/4, gamma 1/2): q, qvel, qaccel after each of
-    3 steps against the vectors of the reference build (the step restated on its own objects, tests/golden/fem_cube5_newmark.npz),
+    3 steps against tests/golden/fem_cube5_newmark.npz -- ImplicitNewmarkSparse::DoTimestep RESTATED ON REFERENCE OBJECTS (oracle/ref_harness.cpp drives the
+    reference's own CorotationalLinearFEM / SparseMatrix / CGSolver; its integrator translation units need PARDISO and do not build here),
     then 3 steps of a 9^3 cube against the oracle.  PCG iteration totals within max(3, 2 %) (each solve starts from the
     previous solution, as there)."""
     gold = np.load(os.path.join(GOLD, "fem_cube5_newmark.npz"))
