@@ -29,6 +29,9 @@ WORKLOADS = {
     "cube27": (27, "truth cube 27^3 nodes / 105,456 tets (BASELINE config 2 canonical mesh)"),
     "cube56": (56, "truth cube 56^3 nodes / 998,250 tets, plane i=0 clamped, -10000 per y DOF, per-step re-assembly (BASELINE config 4)"),
     "cube111": (111, "truth cube 111^3 nodes / 7,986,000 tets (BASELINE config 5 mesh)"),
+    # between the two: the sizes the two-row persistent solver (k_pcg_pipe2) takes, 13..24 slices per CU
+    "cube64": (64, "truth cube 64^3 nodes / 1,500,282 tets (16 slices per CU: two-row persistent solver)"),
+    "cube73": (73, "truth cube 73^3 nodes / 2,239,488 tets (24 slices per CU: the largest system the persistent solver takes)"),
     # BASELINE config 2 on a reference model: ventricle.blob polygonized on the device at cellsize 0.115
     "ventricle": (0, "ventricle.blob (17 primitives) -> tetrahedral polygonizer at cellsize 0.115 -> 107,820 tets, lowest 5 % of the nodes "
                      "in y clamped, -10000 per y DOF (BASELINE config 2)"),
