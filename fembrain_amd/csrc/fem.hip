@@ -159,9 +159,9 @@ int setup_persist(fb_fem_s* h) {
   // asked for explicitly (parameter or FEMBRAIN_PCG_PERSIST=1), or by default where it was measured faster than the
   // two-launch iteration: fp32 storage, up to 12 slices per CU
   const bool eligible = !h->f64 && P.n_ranks == 1 && nb >= 8 && w >= 1 && w <= 2 * kPipeMaxWaves;
-  // (us per iteration, two-launch vs persistent, on MI355X: 7.7 / 10.2 at 43 slices, 9.05 / 9.55 at 466 = 2 per CU, 10.9 / 9.9 at 614 =
-  // 3 per CU, 14.0 / 10.3 at 792, 15.8 / 9.5 at 1,000, 27.4 / 17.1 at 2,744 = 1M tets)
-  static const int min_w = getenv("FEMBRAIN_PERSIST_MIN_WAVES") ? atoi(getenv("FEMBRAIN_PERSIST_MIN_WAVES")) : 3;
+  // (us per iteration, two-launch vs persistent, on MI355X: 7.83 / 7.87 at 125 slices = 1 per CU, 8.74 / 8.74 at 308 and 8.98 / 8.64 at 466
+  // = 2 per CU, 10.9 / 8.8 at 614 = 3 per CU, 14.0 / 10.3 at 792, 15.8 / 8.9 at 1,000, 27.4 / 15.75 at 2,744 = 1M tets)
+  static const int min_w = getenv("FEMBRAIN_PERSIST_MIN_WAVES") ? atoi(getenv("FEMBRAIN_PERSIST_MIN_WAVES")) : 2;
   const bool by_default = h->prm.pcg_variant == FB_PCG_MERGED && w >= min_w;
   const bool want_p = e ? atoi(e) != 0 && (h->prm.pcg_variant == FB_PCG_MERGED || explicit_p) : (explicit_p || by_default);
   if (!want_p || !eligible) return FB_OK;

@@ -38,7 +38,7 @@ extern "C" {
  * read after it, so the only wait of an iteration is for the neighbouring workgroups' part of the product's input vector.
  * Every 30th iteration takes the exact residual as CGSolver.cpp:159-166 does.  Unsharded handles, FB_MATRIX_F32 storage, up to
  * 24 slices per CU (~2.2M tets on 256 CUs: one row per lane up to 12 slices per CU, two rows per lane with x, p, z in LDS from 13
- * on); chosen BY DEFAULT from 3 slices per CU on (FB_PCG_MERGED + FEMBRAIN_PCG_PERSIST unset).  Iteration
+ * on); chosen BY DEFAULT from 2 slices per CU on (FB_PCG_MERGED + FEMBRAIN_PCG_PERSIST unset).  Iteration
  * counts equal those of the literal solver within max(3, 2 %) (tests), iterates agree to rounding and are bitwise
  * reproducible however the solve is cut into launches.  If a wait inside the launch times out (FEMBRAIN_PERSIST_TIMEOUT_MS,
  * default 50; the workgroups must all be resident) the solve is repeated with the two-launch iteration and the handle stays
