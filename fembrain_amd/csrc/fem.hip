@@ -12,6 +12,7 @@
 #include "fem_plan.h"
 #include "pcg_pipe.hip.h"
 #include "pcg_pipe2.hip.h"
+#include "pcg_pipe_shard.hip.h"
 #include "plan_device.h"
 
 using namespace fb;
@@ -89,12 +90,22 @@ struct fb_fem_s {
   int pipe_plain_local = 0;            // interior workgroups publish with plain stores (FEMBRAIN_PIPE_PLAIN_STORES)
   DevBuf<double> pipe_planes, pipe_z, pipe_s, pipe_state;
   int pipe_klt = 0, pipe_wmax = 0;
+  // sharded persistent solver (pcg_pipe_shard.hip.h; opt-in FEMBRAIN_SHARDED_PERSIST=1, unmeasured on multi-GPU hardware)
+  bool shard_persist = false;
+  char* sbox = nullptr;                // my box (fine-grained, mapped by the peers)
+  void* sbox_opened[kP2PMaxRanks] = {nullptr};
+  long long sbox_halo_cap = 0;
+  DevBuf<char*> sbox_peers;
+  DevBuf<int> sh_peer_seg, sh_halo_off, sh_row_send_off, sh_row_send_rank, sh_row_send_pos, sh_n_senders, sh_proxy_wg;
+  DevBuf<unsigned int> sh_wg_send_mask;
+  int pipe_flag_extra = 0;             // flag slots after the workgroups' (the proxies' flags of a sharded handle)
   int pipe_rows = 1;                   // rows per lane: 1 = k_pcg_pipe (up to 12 slices per CU), 2 = k_pcg_pipe2 (13..24)
   int pipe_max_producers = 0;          // longest producer list (-1: some workgroup polls all)
   long long persist_timeout_ticks = 0; // wall_clock64 ticks (100 MHz) a wait inside a persistent launch may last
   int persist_fallbacks = 0;           // solves that had to be repeated with the two-launch form
   int persist_launches = 0;            // persistent launches made by this handle
   int last_pcg_path = 0;               // FB_PCG_PATH_* of the last solve
+  int cu_limit = 0;                    // > 0: the stream is confined to this many CUs (FEMBRAIN_CU_MASK)
   hipEvent_t ev_p[2] = {nullptr, nullptr};  // around every persistent launch
   double persist_seconds = 0;          // device seconds of all persistent launches of this handle (HIP events on its stream)
   long long persist_iterations = 0;    // PCG iterations they ran
@@ -136,6 +147,106 @@ int upload_masks(fb_fem_s* h) {
   return h->nodemask.upload(nm, h->stream);
 }
 
+void release_shard_persist(fb_fem_s* h) {
+  for (auto& o : h->sbox_opened) { if (o) (void)hipIpcCloseMemHandle(o); o = nullptr; }
+  if (h->sbox) (void)hipFree(h->sbox);
+  h->sbox = nullptr;
+  h->shard_persist = false;
+}
+
+// The rank-local half of the sharded persistent solver's set-up (pcg_pipe_shard.hip.h): planes over owned + halo columns, per-row send
+// lists, producer lists with the proxies' flags.  The collective half (boxes, sender counts) is attach_pipe_shard.
+int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
+  const FemPlan& P = h->plan;
+  hipStream_t s = h->stream;
+  const int R = P.n_ranks;
+  if (R > kP2PMaxRanks) return FB_OK;
+  h->pipe_rows = 1;
+  h->pipe_wmax = w < 8 ? 8 : 12;   // (w + 1 wavefronts: the spare one serves the proxies and the sums)
+  h->pipe_klt = std::min(h->pipe_wmax == 8 ? 8 : 6, kPipeLdsSlots / std::max(w, 1));
+  h->persist_blocks = nb; h->persist_waves = w;
+  h->pipe_flag_extra = kP2PMaxRanks;
+  FB_TRY(h->pipe_post.alloc((size_t)2 * nb * 4));
+  FB_TRY(h->pipe_post.zero(s));
+  FB_TRY(h->pipe_flags.alloc((size_t)nb + h->pipe_flag_extra + 16));
+  FB_TRY(h->pipe_flags.zero(s));
+  const size_t n_pad = (size_t)ceil_div(P.n_local, 64) * 64, nv = (size_t)3 * P.n_local + 2;
+  FB_TRY(h->pipe_planes.alloc(2 * 3 * n_pad));
+  FB_TRY(h->pipe_planes.zero(s));
+  FB_TRY(h->pipe_z.alloc(nv));
+  FB_TRY(h->pipe_s.alloc(nv));
+  FB_TRY(h->pipe_state.alloc(2));
+  FB_TRY(h->pipe_state.zero(s));
+  h->persist_timing.release();
+  // slice -> workgroup
+  std::vector<int> owner((size_t)P.n_slices, 0);
+  for (int b = 0; b < nb; b++) {
+    int first, count;
+    pipe_slices(P.n_slices, nb, b, &first, &count);
+    for (int k = 0; k < count; k++) owner[first + k] = b;
+  }
+  // per-row send lists and per-workgroup destination masks from the plan's send lists (ascending owned ids per destination: the
+  // position of a row in that list is its position in the destination's halo segment of this rank)
+  std::vector<int> row_off((size_t)P.n_owned + 1, 0);
+  for (int q = 0; q < R; q++)
+    for (int k = P.send_off[q]; k < P.send_off[q + 1]; k++) row_off[(size_t)P.send_local[k] + 1]++;
+  for (int a = 0; a < P.n_owned; a++) row_off[(size_t)a + 1] += row_off[a];
+  std::vector<int> row_rank((size_t)std::max(1, row_off[P.n_owned])), row_pos(row_rank.size()), fill(row_off.begin(), row_off.end() - 1);
+  std::vector<unsigned int> wg_mask((size_t)nb, 0u);
+  for (int q = 0; q < R; q++)
+    for (int k = P.send_off[q]; k < P.send_off[q + 1]; k++) {
+      const int a = P.send_local[k];
+      row_rank[fill[a]] = q; row_pos[fill[a]] = k - P.send_off[q]; fill[a]++;
+      wg_mask[owner[a >> 6]] |= 1u << q;
+    }
+  FB_TRY(h->sh_row_send_off.upload(row_off, s));
+  FB_TRY(h->sh_row_send_rank.upload(row_rank, s));
+  FB_TRY(h->sh_row_send_pos.upload(row_pos, s));
+  FB_TRY(h->sh_wg_send_mask.upload(wg_mask, s));
+  FB_TRY(h->sh_halo_off.upload(P.halo_off, s));
+  // proxies: one workgroup per rank I have halo nodes of, from the last workgroup downwards
+  std::vector<int> proxy((size_t)R, -1);
+  for (int q = 0, k = 0; q < R; q++)
+    if (P.halo_off[q + 1] > P.halo_off[q]) proxy[q] = nb - 1 - (k++ % nb);
+  FB_TRY(h->sh_proxy_wg.upload(proxy, s));
+  // producer lists: local workgroups from the owned column range of every slice, proxies from the ranks its halo columns belong to
+  DevBuf<int4> range;
+  FB_TRY(range.alloc((size_t)std::max(1, P.n_slices)));
+  hipLaunchKernelGGL(k_slice_colrange_shard, dim3(ceil_div(std::max(1, P.n_slices), kWavesPerBlock)), dim3(kBlock), 0, s, P.n_slices, P.n_owned, R, h->slice_off.p,
+                     h->colidx.p, h->sh_halo_off.p, range.p);
+  FB_HIP(hipGetLastError());
+  std::vector<int4> rg((size_t)std::max(1, P.n_slices));
+  FB_TRY(range.download(rg.data(), rg.size(), s));
+  std::vector<int> prod((size_t)nb * kPipeMaxProducers, -1), cnt((size_t)nb, 0), far((size_t)nb, 1);
+  std::vector<char> mark((size_t)nb + R);
+  h->pipe_max_producers = 0;
+  for (int b = 0; b < nb; b++) {
+    int first, count;
+    pipe_slices(P.n_slices, nb, b, &first, &count);
+    std::fill(mark.begin(), mark.end(), 0);
+    int n = 0;
+    for (int k = 0; k < count; k++) {
+      const int4 r = rg[first + k];
+      for (int sl = r.x >> 6; r.y >= r.x && sl <= (r.y >> 6) && sl < P.n_slices; sl++) {
+        const int o = owner[sl];
+        if (o != b && !mark[o]) { mark[o] = 1; n++; }
+      }
+      for (int q = 0; q < R; q++)
+        if (((unsigned int)r.z >> q & 1u) && !mark[nb + q]) { mark[nb + q] = 1; n++; }
+    }
+    if (n > kPipeMaxProducers) { cnt[b] = -1; h->pipe_max_producers = -1; continue; }
+    cnt[b] = n;
+    if (h->pipe_max_producers >= 0) h->pipe_max_producers = std::max(h->pipe_max_producers, n);
+    for (int o = 0, k = 0; o < nb + R; o++) if (mark[o]) prod[(size_t)b * kPipeMaxProducers + k++] = o;
+  }
+  FB_TRY(h->pipe_prod.upload(prod, s));
+  FB_TRY(h->pipe_prod_count.upload(cnt, s));
+  FB_TRY(h->pipe_prod_xcd.upload(far, s));
+  h->pipe_plain_local = 0;
+  h->shard_persist = true;  // (confirmed or withdrawn by attach_pipe_shard, collectively)
+  return FB_OK;
+}
+
 // Decides whether this handle solves inside persistent launches and allocates what they need (called for every (re)built plan).
 int setup_persist(fb_fem_s* h) {
   const FemPlan& P = h->plan;
@@ -143,7 +254,7 @@ int setup_persist(fb_fem_s* h) {
   h->persist = false;
   hipDeviceProp_t prop;
   FB_HIP(hipGetDeviceProperties(&prop, h->prm.device));
-  const int nb = std::min(kPipeMaxBlocks, (prop.multiProcessorCount / 8) * 8);
+  const int nb = std::min(kPipeMaxBlocks, ((h->cu_limit > 0 ? std::min(h->cu_limit, prop.multiProcessorCount) : prop.multiProcessorCount) / 8) * 8);
   const char* e = getenv("FEMBRAIN_PCG_PERSIST");
   const int w = nb >= 8 ? ceil_div(ceil_div(P.n_slices, 8), nb / 8) : 0;
   {
@@ -152,19 +263,22 @@ int setup_persist(fb_fem_s* h) {
     h->persist_timeout_ticks = std::max(1LL, (long long)(ms * 1e5));  // 100 MHz
   }
   const bool explicit_p = h->prm.pcg_variant == FB_PCG_PERSISTENT;
-  if (explicit_p && P.n_ranks > 1) return fail(FB_EINVAL, "FB_PCG_PERSISTENT is for unsharded handles");
+  const bool shard_opt = P.n_ranks > 1 && getenv("FEMBRAIN_SHARDED_PERSIST") && atoi(getenv("FEMBRAIN_SHARDED_PERSIST")) != 0;
+  if (explicit_p && P.n_ranks > 1 && !shard_opt) return fail(FB_EINVAL, "FB_PCG_PERSISTENT on a sharded handle needs FEMBRAIN_SHARDED_PERSIST=1 (unmeasured on multi-GPU hardware)");
   if (explicit_p && h->f64) return fail(FB_EINVAL, "FB_PCG_PERSISTENT needs FB_MATRIX_F32 storage (part of the matrix is kept in LDS as fp32 words)");
   if (explicit_p && (nb < 8 || w < 1 || w > 2 * kPipeMaxWaves))
     return fail(FB_EINVAL, "FB_PCG_PERSISTENT needs at most %d slices per CU, this mesh has %d on %d CUs", 2 * kPipeMaxWaves, w, nb);
   // asked for explicitly (parameter or FEMBRAIN_PCG_PERSIST=1), or by default where it was measured faster than the
   // two-launch iteration: fp32 storage, up to 12 slices per CU
-  const bool eligible = !h->f64 && P.n_ranks == 1 && nb >= 8 && w >= 1 && w <= 2 * kPipeMaxWaves;
+  // (a sharded handle: opt-in, one row per lane, and a spare wavefront per workgroup for the proxies and the sums)
+  const bool eligible = !h->f64 && nb >= 8 && w >= 1 && (P.n_ranks == 1 ? w <= 2 * kPipeMaxWaves : (shard_opt && w < kPipeMaxWaves));
   // (us per iteration, two-launch vs persistent, on MI355X: 7.83 / 7.87 at 125 slices = 1 per CU, 8.74 / 8.74 at 308 and 8.98 / 8.64 at 466
   // = 2 per CU, 10.9 / 8.8 at 614 = 3 per CU, 14.0 / 10.3 at 792, 15.8 / 8.9 at 1,000, 27.4 / 15.75 at 2,744 = 1M tets)
   static const int min_w = getenv("FEMBRAIN_PERSIST_MIN_WAVES") ? atoi(getenv("FEMBRAIN_PERSIST_MIN_WAVES")) : 2;
   const bool by_default = h->prm.pcg_variant == FB_PCG_MERGED && w >= min_w;
   const bool want_p = e ? atoi(e) != 0 && (h->prm.pcg_variant == FB_PCG_MERGED || explicit_p) : (explicit_p || by_default);
   if (!want_p || !eligible) return FB_OK;
+  if (P.n_ranks > 1) return setup_persist_shard_local(h, nb, w);
   h->persist = true; h->persist_blocks = nb; h->persist_waves = w;
   // pipelined whole-solve kernel
   // up to 12 slices per CU: one row per lane (k_pcg_pipe); 13..24: two (k_pcg_pipe2, no LDS-resident slots).  FEMBRAIN_PERSIST_ROWS=2
@@ -175,7 +289,8 @@ int setup_persist(fb_fem_s* h) {
   h->pipe_klt = h->pipe_rows == 2 ? 0 : std::min(w <= 8 ? 8 : 6, kPipeLdsSlots / std::max(w, 1));
   FB_TRY(h->pipe_post.alloc((size_t)2 * nb * 4));
   FB_TRY(h->pipe_post.zero(s));
-  FB_TRY(h->pipe_flags.alloc((size_t)nb + 16));
+  h->pipe_flag_extra = P.n_ranks > 1 ? kP2PMaxRanks : 0;
+  FB_TRY(h->pipe_flags.alloc((size_t)nb + h->pipe_flag_extra + 16));
   FB_TRY(h->pipe_flags.zero(s));
   const size_t n_pad = (size_t)P.n_slices * 64, nv = (size_t)3 * P.n_local + 2;
   FB_TRY(h->pipe_planes.alloc(2 * 3 * n_pad));
@@ -702,19 +817,19 @@ bool host_finished(const CGState& s) {
 // memory, 0 = continue; at most n_iters iterations
 int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps, int max_iter) {
   PipeArgs pa;
-  pa.post = h->pipe_post.p; pa.flags = h->pipe_flags.p; pa.error = h->pipe_flags.p + h->persist_blocks + 4; pa.seqs = h->pipe_flags.p + h->persist_blocks + 8;
+  pa.post = h->pipe_post.p; pa.flags = h->pipe_flags.p; pa.error = h->pipe_flags.p + h->persist_blocks + h->pipe_flag_extra + 4; pa.seqs = h->pipe_flags.p + h->persist_blocks + h->pipe_flag_extra + 8;
   pa.producers = h->pipe_prod.p; pa.prod_count = h->pipe_prod_count.p; pa.prod_xcd = h->pipe_prod_xcd.p; pa.plain_local = h->pipe_plain_local;
   pa.start = start; pa.n_iters = n_iters; pa.eps2 = eps * eps; pa.max_iter = max_iter;
   pa.timeout_ticks = h->persist_timeout_ticks;
   pa.timing = h->persist_timing.p;
-  pa.planes = h->pipe_planes.p; pa.n_pad = (size_t)h->plan.n_slices * 64;
+  pa.planes = h->pipe_planes.p; pa.n_pad = h->shard_persist ? (size_t)ceil_div(h->plan.n_local, 64) * 64 : (size_t)h->plan.n_slices * 64;
   pa.pstate = h->pipe_state.p;
   // LDS: the sync buffers, then KLT slots of every slice; the request is the whole 160 KB of a CU, so exactly one workgroup lands on each
   const size_t lds = 160 * 1024;
   // one wavefront more than slices where the instantiation has room: it collects the sums while the others multiply
   static const bool want_service = !(getenv("FEMBRAIN_PIPE_SERVICE_WAVE") && atoi(getenv("FEMBRAIN_PIPE_SERVICE_WAVE")) == 0);
   const int cwaves = h->pipe_rows == 2 ? ceil_div(h->persist_waves, 2) : h->persist_waves;  // wavefronts that own slices
-  pa.service = want_service && cwaves < h->pipe_wmax ? 1 : 0;
+  pa.service = (h->shard_persist || want_service) && cwaves < h->pipe_wmax ? 1 : 0;
   // values of the first streamed slots pulled into L2 during the neighbour wait: pays where the product is bandwidth-bound (9 and more
   // slices per CU: -6 % per iteration at 1M tets; neutral at 1,000 slices).  FEMBRAIN_PIPE_PREFETCH=0..4 overrides.
   static const int prefetch = getenv("FEMBRAIN_PIPE_PREFETCH") ? std::max(0, std::min(4, atoi(getenv("FEMBRAIN_PIPE_PREFETCH")))) : -1;
@@ -732,7 +847,27 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
                        (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);       \
   } while (0)
   // the instantiations: (wavefronts, most LDS slots per wavefront) = (8, 8) up to 8 slices per CU, (12, 6) up to 12; 16- or 32-bit column words;
-  // two rows per lane (k_pcg_pipe2) for 13..24 slices per CU
+  // two rows per lane (k_pcg_pipe2) for 13..24 slices per CU; k_pcg_pipe_shard<8, 8> / <12, 6> on a sharded handle
+  if (h->shard_persist) {
+    ShardArgs sa;
+    sa.rank = h->plan.rank; sa.n_ranks = h->plan.n_ranks; sa.n_owned = h->plan.n_owned; sa.n_halo = h->plan.n_local - h->plan.n_owned;
+    sa.box = h->sbox; sa.peer_box = h->sbox_peers.p; sa.peer_seg = h->sh_peer_seg.p; sa.halo_cap = h->sbox_halo_cap;
+    sa.halo_off = h->sh_halo_off.p; sa.row_send_off = h->sh_row_send_off.p; sa.row_send_rank = h->sh_row_send_rank.p; sa.row_send_pos = h->sh_row_send_pos.p;
+    sa.wg_send_mask = h->sh_wg_send_mask.p; sa.n_senders = h->sh_n_senders.p; sa.proxy_wg = h->sh_proxy_wg.p;
+    static bool attr_s[2] = {false, false};
+    const int wi = h->pipe_wmax == 8 ? 0 : 1;
+    const void* kern = wi == 0 ? (const void*)k_pcg_pipe_shard<8, 8> : (const void*)k_pcg_pipe_shard<12, 6>;
+    if (!attr_s[wi]) {
+      FB_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_s[wi] = true;
+    }
+    if (wi == 0)
+      hipLaunchKernelGGL((k_pcg_pipe_shard<8, 8>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b,
+                         h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);
+    else
+      hipLaunchKernelGGL((k_pcg_pipe_shard<12, 6>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b,
+                         h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);
+  } else
   if (h->pipe_rows == 2) {
     static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)kPipeMaxWaves * 2 * kPipe2LdsWordsPerRow * 64 * 4 <= 160 * 1024, "LDS budget of k_pcg_pipe2");
     static bool attr2[2] = {false, false};
@@ -795,11 +930,16 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
     h->persist_launches++;
     unsigned int err = 0;
     FB_HIP(hipMemcpyAsync(&h->st_host[0], h->st.p, sizeof(CGState), hipMemcpyDeviceToHost, s));
-    FB_HIP(hipMemcpyAsync(&err, h->pipe_flags.p + h->persist_blocks + 4, sizeof err, hipMemcpyDeviceToHost, s));
+    FB_HIP(hipMemcpyAsync(&err, h->pipe_flags.p + h->persist_blocks + h->pipe_flag_extra + 4, sizeof err, hipMemcpyDeviceToHost, s));
     FB_HIP(hipStreamSynchronize(s));
     {
       float ms = 0;
       if (hipEventElapsedTime(&ms, h->ev_p[0], h->ev_p[1]) == hipSuccess) h->persist_seconds += ms * 1e-3;
+    }
+    if (h->shard_persist) {  // a time-out on any rank sends every rank to the two-launch solver, together
+      std::vector<unsigned int> errs((size_t)h->plan.n_ranks);
+      FB_TRY(comm_allgather_bytes(h->comm, &err, errs.data(), sizeof err, s));
+      for (unsigned int e2 : errs) err |= e2;
     }
     if (err) {
       // A wait inside the launch gave up: the workgroups were not all resident (the device is shared with another process's
@@ -1134,6 +1274,74 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
   return FB_OK;
 }
 
+// The collective half: every rank allocates its box, the ranks exchange the IPC handles, the halo sizes and how many of their
+// workgroups send to whom, map each other's boxes, and agree that all of it worked -- otherwise every rank alike runs the
+// two-launch iteration.
+int attach_pipe_shard(fb_fem_s* h) {
+  const FemPlan& P = h->plan;
+  const int R = P.n_ranks, me = P.rank;
+  if (R < 2 || !h->comm) return FB_OK;
+  if (!(getenv("FEMBRAIN_SHARDED_PERSIST") && atoi(getenv("FEMBRAIN_SHARDED_PERSIST")) != 0)) return FB_OK;  // (the same on every rank)
+  {  // a re-sync: the previous box and mappings go first
+    const bool keep = h->shard_persist;
+    release_shard_persist(h);
+    h->shard_persist = keep;
+  }
+  struct Meta { hipIpcMemHandle_t handle; long long n_halo; int halo_off[kP2PMaxRanks + 1]; int senders_to[kP2PMaxRanks]; int ok; };
+  Meta mine;
+  memset(&mine, 0, sizeof mine);
+  bool ok = h->shard_persist && R <= kP2PMaxRanks;
+  // the box is sized by the largest halo of all ranks, so a first round agrees on that
+  long long nh = ok ? P.n_local - P.n_owned : -1;
+  std::vector<long long> nhs((size_t)R);
+  FB_TRY(comm_allgather_bytes(h->comm, &nh, nhs.data(), sizeof nh, h->stream));
+  long long cap = 1;
+  for (int q = 0; q < R; q++) { if (nhs[q] < 0) ok = false; cap = std::max(cap, nhs[q]); }
+  const ShardBoxLayout BL = shard_box_layout(cap);
+  if (ok) {
+    ok = hipExtMallocWithFlags((void**)&h->sbox, BL.bytes, hipDeviceMallocFinegrained) == hipSuccess;
+    ok = ok && hipMemsetAsync(h->sbox, 0, BL.bytes, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;
+    ok = ok && hipIpcGetMemHandle(&mine.handle, h->sbox) == hipSuccess;
+    (void)hipGetLastError();
+    mine.n_halo = P.n_local - P.n_owned;
+    for (int q = 0; q <= R; q++) mine.halo_off[q] = P.halo_off[q];
+    std::vector<unsigned int> wg_mask((size_t)h->persist_blocks);
+    ok = ok && h->sh_wg_send_mask.download(wg_mask.data(), wg_mask.size(), h->stream) == FB_OK;
+    for (unsigned int m : wg_mask)
+      for (int q = 0; q < R; q++) mine.senders_to[q] += (m >> q) & 1u;
+  }
+  mine.ok = ok ? 1 : 0;
+  std::vector<Meta> all((size_t)R);
+  FB_TRY(comm_allgather_bytes(h->comm, &mine, all.data(), sizeof(Meta), h->stream));
+  bool all_ok = true;
+  for (int q = 0; q < R; q++) all_ok = all_ok && all[q].ok;
+  int opened_ok = 1;
+  std::vector<char*> peers((size_t)R, nullptr);
+  std::vector<int> seg((size_t)R, 0), senders((size_t)R, 0);
+  if (all_ok) {
+    for (int q = 0; q < R; q++) {
+      seg[q] = all[q].halo_off[me];
+      senders[q] = all[q].senders_to[me];
+      if (q == me) { peers[q] = h->sbox; continue; }
+      void* ptr = nullptr;
+      if (hipIpcOpenMemHandle(&ptr, all[q].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); opened_ok = 0; break; }
+      h->sbox_opened[q] = ptr;
+      peers[q] = (char*)ptr;
+    }
+  }
+  std::vector<int> oks((size_t)R);
+  FB_TRY(comm_allgather_bytes(h->comm, &opened_ok, oks.data(), sizeof(int), h->stream));
+  for (int q = 0; q < R; q++) all_ok = all_ok && oks[q];
+  if (!all_ok) { release_shard_persist(h); h->persist = false; return FB_OK; }
+  h->sbox_halo_cap = cap;
+  FB_TRY(h->sbox_peers.upload(peers.data(), peers.size(), h->stream));
+  FB_TRY(h->sh_peer_seg.upload(seg, h->stream));
+  FB_TRY(h->sh_n_senders.upload(senders, h->stream));
+  h->persist = true;
+  if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] rank %d: sharded persistent solver attached (%d workgroups, %d slices per CU, halo %lld of cap %lld)\n", me, h->persist_blocks, h->persist_waves, (long long)(P.n_local - P.n_owned), cap);
+  return FB_OK;
+}
+
 // collective: every rank of the communicator creates its handle at the same point of its program
 int attach_p2p(fb_fem_s* h) {
   const FemPlan& P = h->plan;
@@ -1187,6 +1395,17 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
   h->mu = params->E / (2 * (1 + params->nu));
   int rc = FB_OK;
   do {
+    // FEMBRAIN_CU_MASK=first:count -- the handle's stream runs on `count` CUs from bit `first` of the CU mask only (development and test
+    // aid: two processes on one GPU, each with a persistent kernel on its own half of the CUs); the persistent grid follows
+    if (const char* cm = getenv("FEMBRAIN_CU_MASK")) {
+      int first = 0, count = 0;
+      if (sscanf(cm, "%d:%d", &first, &count) != 2 || first < 0 || count < 8 || first + count > 512) { rc = fail(FB_EINVAL, "FEMBRAIN_CU_MASK=first:count"); break; }
+      uint32_t mask[16];
+      memset(mask, 0, sizeof mask);
+      for (int b = first; b < first + count; b++) mask[b >> 5] |= 1u << (b & 31);
+      if (hipExtStreamCreateWithCUMask(&h->stream, 16, mask) != hipSuccess) { rc = fail(FB_EDEVICE, "hipExtStreamCreateWithCUMask failed"); break; }
+      h->cu_limit = count;
+    } else
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(FB_EDEVICE, "hipStreamCreate failed"); break; }
     for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) rc = fail(FB_EDEVICE, "hipEventCreate failed");
     for (auto& e : h->ev_batch) if (hipEventCreate(&e) != hipSuccess) rc = fail(FB_EDEVICE, "hipEventCreate failed");
@@ -1206,6 +1425,7 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
       if (mine != FB_OK) { last_error() = why; rc = mine; }
     }
     if (rc == FB_OK && comm && comm->n_ranks > 1) rc = attach_p2p(h);
+    if (rc == FB_OK && comm && comm->n_ranks > 1) rc = attach_pipe_shard(h);
   } while (0);
   if (rc != FB_OK) {
     std::string keep = last_error();
@@ -1343,6 +1563,7 @@ int fb_fem_destroy(fb_fem_t h) {
   for (auto& e : h->ev_p) if (e) (void)hipEventDestroy(e);
   if (h->st_host) (void)hipHostFree(h->st_host);
   if (h->p2p) p2p_detach(h->p2p);
+  release_shard_persist(h);
   drop_graph(h);
   DevBuf<double>* vecs[] = {&h->q, &h->qvel, &h->fext, &h->fint, &h->rhs, &h->x, &h->r, &h->d, &h->Ad, &h->invdiag, &h->tmp};
   for (auto* v : vecs) v->release();
@@ -1395,6 +1616,7 @@ static int resync_sharded(fb_fem_t h, int n_nodes, const double* xyz, int n_tets
   const int mode = h->xch_mode;
   if (h->p2p) { p2p_detach(h->p2p); h->p2p = nullptr; }
   if (h->comm && h->comm->n_ranks > 1) FB_TRY(attach_p2p(h));
+  if (h->comm && h->comm->n_ranks > 1) FB_TRY(attach_pipe_shard(h));
   if (h->p2p && mode >= FB_XCH_P2P) h->xch_mode = mode;   // the form chosen before the re-sync stays
   else if (mode == FB_XCH_COLLECTIVE) h->xch_mode = FB_XCH_COLLECTIVE;
   h->poisoned = false;
@@ -1903,7 +2125,8 @@ int fb_fem_persist_info(fb_fem_t h, int* waves_per_cu, int* workgroups, int* lds
 int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches, int* persist_fallbacks, int* max_producers) {
   if (!h) return fail(FB_EINVAL, "null FEM handle");
   if (name && name_len > 0) {
-    if (h->persist && h->pipe_rows == 2) snprintf(name, name_len, "k_pcg_pipe2<%s>", h->c16 ? "c16" : "c32");
+    if (h->persist && h->shard_persist) snprintf(name, name_len, "k_pcg_pipe_shard<%d,%d>", h->pipe_wmax, h->pipe_wmax == 8 ? 8 : 6);
+    else if (h->persist && h->pipe_rows == 2) snprintf(name, name_len, "k_pcg_pipe2<%s>", h->c16 ? "c16" : "c32");
     else if (h->persist) snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_wmax == 8 ? 8 : 6);
     else name[0] = 0;
   }
@@ -1938,7 +2161,7 @@ int fb_fem_time_persist(fb_fem_t h, int reps, int n_iters, double* seconds_per_l
     if (r >= 0) total += ms * 1e-3;
   }
   unsigned int err = 0;
-  FB_HIP(hipMemcpy(&err, h->pipe_flags.p + h->persist_blocks + 4, sizeof err, hipMemcpyDeviceToHost));
+  FB_HIP(hipMemcpy(&err, h->pipe_flags.p + h->persist_blocks + h->pipe_flag_extra + 4, sizeof err, hipMemcpyDeviceToHost));
   if (err) {
     FB_TRY(h->pipe_flags.zero(h->stream));
     FB_TRY(h->pipe_post.zero(h->stream));

@@ -1,0 +1,457 @@
+// k_pcg_pipe_shard: the persistent pipelined Jacobi-PCG of pcg_pipe.hip.h on a SHARDED handle -- one launch per solve on every rank,
+// the halo values and the global sums crossing the GPUs inside the launches (stores, atomics and polls on peer memory mapped through
+// HIP IPC over xGMI; no collective library on the path).  UNMEASURED ON HARDWARE: the build box has one GPU; the kernel is exercised
+// by two processes on one GPU, each confined to half the CUs (FEMBRAIN_CU_MASK), against the unsharded handle
+// (tests/test_sharded_gpu.py).  Opt-in: FEMBRAIN_SHARDED_PERSIST=1.
+//
+// What the pipelined recurrence buys across GPUs is the same it buys across CUs: gamma and delta are sums of local quantities, known
+// before the product starts, so the ALL-RANK reduction (rank sums posted into every peer's box, read after the product) hides behind
+// the product, and the only wait is for the neighbours' part of the product's input vector -- now including the halo rows a
+// neighbour RANK owns.  Per rank, in a fine-grained buffer the peers map ("box"):
+//   counters[s]        u32, rank s's workgroups that own rows of MY halo add 1 each per publish (remote atomic) after their stores
+//   rsum[p][s][4]      tagged 8-byte granules: rank s's gamma, delta of the sum sequence with parity p (posted by its workgroup 0)
+//   halo[p][3][n_halo] the halo rows of the published vector, written by the owners' lanes straight from their registers
+// and in ordinary device memory the planes [2][3][n_pad] of pcg_pipe.hip.h, n_pad covering owned AND halo columns: a PROXY -- the
+// spare wavefront of one workgroup per neighbour rank -- waits for counters[s] to reach (workgroups of s that send to me) x (publish
+// number), copies s's segment from the box into the halo part of the planes (so that the products' gathers stay cached, ordinary
+// loads), drains and raises a flag of its own (flags[n_blocks + s]); slices with halo columns of rank s have that flag in their
+// producer list.  Hazards as in pcg_pipe.hip.h: the box's halo area is double-buffered by publish parity, and a sender can be two
+// publishes ahead of a receiver only after it has received that receiver's publish in between (the neighbour relation is symmetric).
+// Everything else -- state in registers, LDS-resident slots, the assembly loop over the streamed slots (32-bit local column ids),
+// exact-residual iterations, launch cuts, bounded waits -- is k_pcg_pipe's.  A workgroup needs its spare wavefront (at most 11 / 7
+// slices per CU).
+#pragma once
+#include "comm.h"
+#include "pcg_pipe.hip.h"
+
+namespace fb {
+
+struct ShardBoxLayout {  // byte offsets inside a rank's box (the same on every rank: n_halo_cap = the largest halo of all ranks)
+  size_t counters, rsum, halo, bytes;
+  long long halo_cap;
+};
+__host__ __device__ inline ShardBoxLayout shard_box_layout(long long halo_cap) {
+  ShardBoxLayout L;
+  L.halo_cap = halo_cap;
+  L.counters = 0;
+  L.rsum = 256;                                                     // kP2PMaxRanks * 4 B, padded
+  L.halo = L.rsum + (size_t)2 * kP2PMaxRanks * 4 * 8;
+  L.halo = (L.halo + 255) & ~(size_t)255;
+  L.bytes = L.halo + (size_t)2 * 3 * (size_t)(halo_cap > 0 ? halo_cap : 1) * sizeof(double);
+  return L;
+}
+
+struct ShardArgs {
+  int rank, n_ranks;
+  int n_owned, n_halo;
+  char* box;                          // mine
+  char* const* peer_box;              // [n_ranks] device array; peer_box[rank] == box
+  const int* peer_seg;                // [n_ranks] device array: first position of MY rows inside peer q's halo
+  long long halo_cap;
+  const int* halo_off;                // [n_ranks + 1] my halo segments by owner rank (device copy)
+  const int* row_send_off;            // [n_owned + 1] per owned row: its entries in the two lists below
+  const int* row_send_rank;           // destination rank
+  const int* row_send_pos;            // position inside my segment of that rank's halo
+  const unsigned int* wg_send_mask;   // [n_blocks] ranks this workgroup has rows to send to
+  const int* n_senders;               // [n_ranks] workgroups of rank s that send to me
+  const int* proxy_wg;                // [n_ranks] the workgroup whose spare wavefront copies rank s's segment (-1: no halo from s)
+};
+
+__device__ __forceinline__ void st_sys_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned int ld_sys_u32(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned long long ld_sys_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double ld_sys_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// per slice: lowest and highest OWNED column, and the set of ranks whose halo columns it touches (bit s)
+__global__ __launch_bounds__(kBlock) void k_slice_colrange_shard(int n_slices, int n_owned, int n_ranks, const int* __restrict__ slice_off,
+                                                                 const int* __restrict__ colidx, const int* __restrict__ halo_off, int4* __restrict__ out) {
+  const int s = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (s >= n_slices) return;
+  const int row = s * 64 + lane;
+  int lo = 0x7fffffff, hi = -1;
+  unsigned int ranks = 0;
+  if (row < n_owned)
+    for (int k = slice_off[s]; k < slice_off[s + 1]; k++) {
+      const int c = colidx[(size_t)k * 64 + lane];
+      if (c < n_owned) { lo = min(lo, c); hi = max(hi, c); }
+      else {
+        const int hidx = c - n_owned;
+        int q = 0;
+        while (q + 1 < n_ranks && hidx >= halo_off[q + 1]) q++;
+        ranks |= 1u << q;
+      }
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); ranks |= __shfl_down(ranks, off, 64);
+  }
+  if (lane == 0) out[s] = make_int4(lo, hi, (int)ranks, 0);
+}
+
+template <int WMAX, int KLT>
+__global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe_shard(SellView sv, const float* __restrict__ vals, const float* __restrict__ dlo,
+                                                              const double* __restrict__ invdiag, const double* __restrict__ bvec, double* __restrict__ xg,
+                                                              double* __restrict__ rg, double* __restrict__ wg, double* __restrict__ zg,
+                                                              double* __restrict__ sg, double* __restrict__ pg, CGState* __restrict__ st, PipeArgs pa,
+                                                              ShardArgs sa) {
+  extern __shared__ double lds[];
+  double* wsum = lds;
+  double* gath = lds + 32;
+  double* bc = gath + 2 * kPipeMaxBlocks;
+  (void)gath;
+  const int n_waves = blockDim.x >> 6, nb = gridDim.x;
+  if (pa.start == 0 && st->done) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool service = wv == n_waves - 1;  // the spare wavefront: sums, proxy copies (it owns no slice)
+  int first, count;
+  pipe_slices(sv.n_slices, nb, blockIdx.x, &first, &count);
+  const bool live = wv < count && !service;
+  const int sl = first + wv;
+  const int row = sl * 64 + lane;
+  const bool rvalid = live && row < sv.n_owned;
+  const size_t dof = 3 * (size_t)(rvalid ? row : 0);
+  int so = 0, width = 0;
+  if (live) { so = sv.slice_off[sl]; width = sv.slice_off[sl + 1] - so; }
+  so = __builtin_amdgcn_readfirstlane(so); width = __builtin_amdgcn_readfirstlane(width);
+  const float* v = vals + (size_t)so * 9 * 64 + lane;
+  const int* ci = sv.colidx + (size_t)so * 64 + lane;
+  float m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;
+  double iv[3] = {0, 0, 0};
+  int send_beg = 0, send_end = 0;  // this row's entries of the send lists
+  if (rvalid) {
+    const float* l = dlo + (size_t)sl * 9 * 64 + lane;
+    m00 = l[0 * 64]; m01 = l[1 * 64]; m02 = l[2 * 64]; m11 = l[4 * 64]; m12 = l[5 * 64]; m22 = l[8 * 64];
+#pragma unroll
+    for (int a = 0; a < 3; a++) iv[a] = invdiag[dof + a];
+    send_beg = sa.row_send_off[row]; send_end = sa.row_send_off[row + 1];
+  }
+  const int lbase = min(KLT, kPipeLdsSlots / max(count, 1)), lrem = lbase < KLT ? min(count, kPipeLdsSlots - lbase * count) : 0;
+  const int klt_w = __builtin_amdgcn_readfirstlane(live ? lbase + (wv < lrem ? 1 : 0) : 0);
+  const int KL = min(klt_w, width);
+  unsigned int* lres = (unsigned int*)(lds + kPipeSyncDoubles) + (size_t)(wv * lbase + min(wv, lrem)) * 10 * 64 + lane;
+  for (int k = 0; k < KL; k++) {
+    const float* vk = v + (size_t)k * 9 * 64;
+#pragma unroll
+    for (int j = 0; j < 9; j++) lres[(k * 10 + j) * 64] = __float_as_uint(vk[j * 64]);
+    lres[(k * 10 + 9) * 64] = (unsigned int)ci[(size_t)k * 64];
+  }
+  const int n_prod = pa.prod_count[blockIdx.x];
+  int my_prod = -1;
+  if (wv == 0 && n_prod >= 0 && lane < n_prod) my_prod = pa.producers[(size_t)blockIdx.x * kPipeMaxProducers + lane];
+  const unsigned int send_mask = sa.wg_send_mask[blockIdx.x];  // workgroup-uniform
+  const ShardBoxLayout BL = shard_box_layout(sa.halo_cap);
+
+  unsigned int pub = pa.seqs[0], sums = pa.seqs[1];
+  const long long t_limit = pa.timeout_ticks;
+  bool failed = false;
+
+  auto publish = [&](const double* vin) {
+    pub++;
+    double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
+    if (rvalid) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * pa.n_pad + (size_t)row, vin[a]);
+      for (int e = send_beg; e < send_end; e++) {  // rows a neighbour rank gathers: straight into its box
+        const int q = sa.row_send_rank[e];
+        double* hq = (double*)(sa.peer_box[q] + BL.halo) + (size_t)(pub & 1u) * 3 * (size_t)sa.halo_cap + (size_t)(sa.peer_seg[q] + sa.row_send_pos[e]);
+#pragma unroll
+        for (int a = 0; a < 3; a++) st_sys_f64(hq + (size_t)a * (size_t)sa.halo_cap, vin[a]);
+      }
+    }
+  };
+  auto product = [&](const double* vin, double* y, bool post_sums) {
+    double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (post_sums) sums++;
+    if (wv != 0 && live && pa.prefetch_slots > 0 && width > klt_w) {
+      int so_k = so + klt_w;
+      asm volatile("" : "+s"(so_k));
+      pipe_prefetch_values(min(pa.prefetch_slots, width - klt_w), ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float), vals);
+    }
+    if (service) {
+      // every store of this workgroup's rows has drained: tell the ranks that gather them
+      if (lane < sa.n_ranks && (send_mask >> lane & 1u))
+        __hip_atomic_fetch_add((unsigned int*)(sa.peer_box[lane] + BL.counters) + sa.rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // proxy: the halo segments this workgroup copies from the box into the planes
+      const long long t0 = wall_clock64();
+      for (int s = 0; s < sa.n_ranks && !failed; s++) {
+        if (sa.proxy_wg[s] != (int)blockIdx.x) continue;  // workgroup-uniform
+        const unsigned int want = (unsigned int)sa.n_senders[s] * pub;
+        const unsigned int* cnt = (const unsigned int*)(sa.box + BL.counters) + s;
+        while ((int)(ld_sys_u32(cnt) - want) < 0) {
+          if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (failed) break;
+        const int h0 = sa.halo_off[s], h1 = sa.halo_off[s + 1];
+        const double* in = (const double*)(sa.box + BL.halo) + (size_t)(pub & 1u) * 3 * (size_t)sa.halo_cap;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+          for (int i = h0 + lane; i < h1; i += 64) st_sc1_f64(pl + a * pa.n_pad + (size_t)sa.n_owned + i, ld_sys_f64(in + (size_t)a * (size_t)sa.halo_cap + i));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) st_sc1_u32(pa.flags + nb + s, pub);
+      }
+      failed = uniform_flag(failed);
+      if (failed && lane == 0) { st_sc1_u32(pa.error, 1u); bc[4] = 1.0; }
+    }
+    if (wv == 0) {
+      if (lane == 0) st_sc1_u32(pa.flags + blockIdx.x, pub);
+      if (post_sums && lane < 2) {
+        double t = 0.0;
+        for (int w = 0; w < n_waves; w++) t += wsum[lane * 16 + w];
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(t), tag = (unsigned long long)sums << 32;
+        unsigned long long* post = pa.post + ((size_t)(sums & 1u) * nb + blockIdx.x) * 4 + 2 * lane;
+        st_sc1_u64(post, (bits >> 32) | tag);
+        st_sc1_u64(post + 1, (bits & 0xffffffffULL) | tag);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const long long t0 = wall_clock64();
+      if (n_prod >= 0) {
+        for (;;) {
+          bool ok = true;
+          if (my_prod >= 0) ok = (int)(ld_sc1_u32(pa.flags + my_prod) - pub) >= 0;
+          if (__ballot(!ok) == 0ULL) break;
+          if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      } else {
+        for (int b = lane; b - lane < nb + sa.n_ranks && !failed; b += 64) {  // all workgroups and all proxies
+          for (;;) {
+            bool ok = true;
+            if (b < nb || (b < nb + sa.n_ranks && sa.proxy_wg[b - nb] >= 0)) ok = (int)(ld_sc1_u32(pa.flags + b) - pub) >= 0;
+            if (__ballot(!ok) == 0ULL) break;
+            if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+      }
+      if (failed && lane == 0) st_sc1_u32(pa.error, 1u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) bc[3] = (failed || ld_sc1_u32(pa.error) != 0u) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (uniform_flag(bc[3] != 0.0 || bc[4] != 0.0)) { failed = true; return; }
+    double y0 = 0, y1 = 0, y2 = 0;
+    if (rvalid) {
+      float u00 = m00, u01 = m01, u02 = m02, u11 = m11, u12 = m12, u22 = m22;
+      asm volatile("" : "+v"(u00), "+v"(u01), "+v"(u02), "+v"(u11), "+v"(u12), "+v"(u22));
+      const double l00 = (double)u00, l01 = (double)u01, l02 = (double)u02, l11 = (double)u11, l12 = (double)u12, l22 = (double)u22;
+      y0 = l00 * vin[0] + l01 * vin[1] + l02 * vin[2];
+      y1 = l01 * vin[0] + l11 * vin[1] + l12 * vin[2];
+      y2 = l02 * vin[0] + l12 * vin[1] + l22 * vin[2];
+    }
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < KLT; k++) if (k < KL) {
+        const unsigned int* lk = lres + (size_t)k * 10 * 64;
+        const double* xp = pl + (size_t)lk[9 * 64];
+        const double x0 = xp[0], x1 = xp[pa.n_pad], x2 = xp[2 * pa.n_pad];
+        y0 += (double)__uint_as_float(lk[0 * 64]) * x0 + (double)__uint_as_float(lk[1 * 64]) * x1 + (double)__uint_as_float(lk[2 * 64]) * x2;
+        y1 += (double)__uint_as_float(lk[3 * 64]) * x0 + (double)__uint_as_float(lk[4 * 64]) * x1 + (double)__uint_as_float(lk[5 * 64]) * x2;
+        y2 += (double)__uint_as_float(lk[6 * 64]) * x0 + (double)__uint_as_float(lk[7 * 64]) * x1 + (double)__uint_as_float(lk[8 * 64]) * x2;
+      }
+      const int n_str = width - klt_w;
+      if (n_str > 0) {
+        int so_k = so + klt_w;
+        asm volatile("" : "+s"(so_k));
+        pipe_stream_slots<false>(n_str, ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
+                                 ((unsigned int)so_k * 64u + (unsigned int)lane) * (unsigned int)sizeof(int), vals, (const void*)sv.colidx, pl, pl + pa.n_pad,
+                                 pl + 2 * pa.n_pad, row, y0, y1, y2);
+      }
+    }
+    y[0] = y0; y[1] = y1; y[2] = y2;
+  };
+
+  double xr[3] = {0, 0, 0}, rr[3] = {0, 0, 0}, wr[3] = {0, 0, 0}, zr[3] = {0, 0, 0}, sr[3] = {0, 0, 0}, pr[3] = {0, 0, 0};
+  double rho0 = 0.0, eps2 = pa.eps2, gamma_old = 1.0, alpha_old = 1.0;
+  int iter = 0, max_iter = pa.max_iter;
+  enum { PH_WARM_X = 0, PH_INIT_W = 1, PH_ITER = 2, PH_REFRESH_X = 3, PH_REFRESH_W = 4 };
+  int phase = PH_ITER;
+  bool fresh = pa.start != 0;
+  if (threadIdx.x == 0) bc[4] = 0.0;
+  if (pa.start == 0) {
+    if (rvalid) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) { xr[a] = xg[dof + a]; rr[a] = rg[dof + a]; wr[a] = wg[dof + a]; zr[a] = zg[dof + a]; sr[a] = sg[dof + a]; pr[a] = pg[dof + a]; }
+    }
+    rho0 = uniform_f64(st->rho0); eps2 = uniform_f64(st->eps2); iter = st->iter; max_iter = st->max_iter;
+    gamma_old = uniform_f64(pa.pstate[0]); alpha_old = uniform_f64(pa.pstate[1]);
+  } else if (pa.start == 2) {
+    if (rvalid) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) xr[a] = xg[dof + a];
+    }
+    phase = PH_WARM_X;
+  } else {
+    if (rvalid) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) rr[a] = bvec[dof + a];
+    }
+    phase = PH_INIT_W;
+  }
+
+  bool done = false, published = false;
+  double gamma = 0.0;
+  int it_done = 0;
+  while (!failed) {
+    if (phase == PH_ITER && it_done >= pa.n_iters) break;
+    double vin[3];
+    if (phase == PH_WARM_X || phase == PH_REFRESH_X) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) vin[a] = xr[a];
+    } else if (phase == PH_ITER) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) vin[a] = iv[a] * wr[a];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; a++) vin[a] = iv[a] * rr[a];
+    }
+    if (!published) publish(vin);
+    published = false;
+    if (phase == PH_ITER) {
+      const double u[3] = {iv[0] * rr[0], iv[1] * rr[1], iv[2] * rr[2]};
+      double a0 = rr[0] * u[0] + rr[1] * u[1] + rr[2] * u[2];
+      double a1 = wr[0] * u[0] + wr[1] * u[1] + wr[2] * u[2];
+      a0 = wave_sum(a0); a1 = wave_sum(a1);
+      int wvo = wv;
+      asm volatile("" : "+v"(wvo));
+      if (lane == 0) { wsum[wvo] = a0; wsum[16 + wvo] = a1; }
+    }
+    double y[3];
+    product(vin, y, phase == PH_ITER);
+    if (failed) break;
+    if (phase == PH_WARM_X || phase == PH_REFRESH_X) {
+      unsigned int d3 = 3u * (unsigned int)(rvalid ? row : 0);
+      asm volatile("" : "+v"(d3));
+#pragma unroll
+      for (int a = 0; a < 3; a++) rr[a] = rvalid ? bvec[d3 + a] - y[a] : 0.0;
+      phase = phase == PH_WARM_X ? PH_INIT_W : PH_REFRESH_W;
+      continue;
+    }
+    if (phase != PH_ITER) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) wr[a] = y[a];
+      phase = PH_ITER;
+      continue;
+    }
+    // ---- the sums: this rank's (workgroup 0 collects them and posts them to every rank), then all ranks' ----
+    if (service) {
+      const long long t0 = wall_clock64();
+      if (blockIdx.x == 0) {
+        const unsigned long long* post = pa.post + (size_t)(sums & 1u) * nb * 4;
+        double t0s = 0, t1s = 0;
+        for (int b = lane; b - lane < nb && !failed; b += 64) {
+          const bool mine = b < nb;
+          uint4 q4[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+          for (;;) {
+            bool ok = true;
+            if (mine) {
+              asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                           : "=&v"(q4[0]), "=&v"(q4[1]) : "v"(post + (size_t)b * 4) : "memory");
+              ok = q4[0].y == sums && q4[0].w == sums && q4[1].y == sums && q4[1].w == sums;
+            }
+            if (__ballot(!ok) == 0ULL) break;
+            if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (mine && !failed) {
+            t0s += __longlong_as_double((long long)(((unsigned long long)q4[0].x << 32) | (unsigned long long)q4[0].z));
+            t1s += __longlong_as_double((long long)(((unsigned long long)q4[1].x << 32) | (unsigned long long)q4[1].z));
+          }
+        }
+        t0s = wave_sum(t0s); t1s = wave_sum(t1s);
+        t0s = __shfl(t0s, 0, 64); t1s = __shfl(t1s, 0, 64);
+        if (lane < sa.n_ranks && !failed) {  // lane q posts this rank's two sums into rank q's box
+          unsigned long long* dst = (unsigned long long*)(sa.peer_box[lane] + BL.rsum) + ((size_t)(sums & 1u) * kP2PMaxRanks + sa.rank) * 4;
+          const unsigned long long b0 = (unsigned long long)__double_as_longlong(t0s), b1 = (unsigned long long)__double_as_longlong(t1s), tag = (unsigned long long)sums << 32;
+          st_sys_u64(dst, (b0 >> 32) | tag); st_sys_u64(dst + 1, (b0 & 0xffffffffULL) | tag);
+          st_sys_u64(dst + 2, (b1 >> 32) | tag); st_sys_u64(dst + 3, (b1 & 0xffffffffULL) | tag);
+        }
+      }
+      // all ranks' sums from my box, added in rank order: the same bits on every rank and workgroup
+      double g0 = 0, g1 = 0;
+      {
+        const unsigned long long* rs = (const unsigned long long*)(sa.box + BL.rsum) + ((size_t)(sums & 1u) * kP2PMaxRanks + (lane < sa.n_ranks ? lane : 0)) * 4;
+        unsigned long long g[4] = {0, 0, 0, 0};
+        while (!failed) {
+          bool ok = true;
+          if (lane < sa.n_ranks) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { g[k] = ld_sys_u64(rs + k); ok = ok && (unsigned int)(g[k] >> 32) == sums; }
+          }
+          if (__ballot(!ok) == 0ULL) break;
+          if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        const double v0 = __longlong_as_double((long long)(((g[0] & 0xffffffffULL) << 32) | (g[1] & 0xffffffffULL)));
+        const double v1 = __longlong_as_double((long long)(((g[2] & 0xffffffffULL) << 32) | (g[3] & 0xffffffffULL)));
+        for (int q = 0; q < sa.n_ranks; q++) { g0 += __shfl(v0, q, 64); g1 += __shfl(v1, q, 64); }
+      }
+      failed = uniform_flag(failed);
+      if (failed && lane == 0) st_sc1_u32(pa.error, 1u);
+      if (lane == 0) { bc[0] = g0; bc[1] = g1; bc[2] = (failed || ld_sc1_u32(pa.error) != 0u) ? 1.0 : 0.0; }
+    }
+    __syncthreads();
+    if (uniform_flag(bc[2] != 0.0)) { failed = true; break; }
+    gamma = uniform_f64(bc[0]);
+    const double delta = uniform_f64(bc[1]);
+    if (fresh) rho0 = gamma;
+    if (!(gamma > eps2 * rho0) || iter >= max_iter) { done = true; break; }
+    double alpha, beta;
+    if (fresh) { beta = 0.0; alpha = gamma / delta; }
+    else { beta = gamma / gamma_old; alpha = gamma / (delta - beta * gamma / alpha_old); }
+    fresh = false;
+    iter++;
+    it_done++;
+    gamma_old = gamma; alpha_old = alpha;
+    const bool refresh = iter % 30 == 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      zr[a] = y[a] + beta * zr[a];
+      sr[a] = wr[a] + beta * sr[a];
+    }
+    if (!refresh) {
+      double m[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) { wr[a] = wr[a] - alpha * zr[a]; m[a] = iv[a] * wr[a]; }
+      publish(m);
+      published = true;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      pr[a] = iv[a] * rr[a] + beta * pr[a];
+      xr[a] = xr[a] + alpha * pr[a];
+    }
+    if (refresh) {
+      phase = PH_REFRESH_X;
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; a++) rr[a] = rr[a] - alpha * sr[a];
+    }
+  }
+  if (failed) return;
+  if (rvalid && !(done && gamma > eps2 * rho0)) {
+    unsigned int dofo = 3u * (unsigned int)row;
+    asm volatile("" : "+v"(dofo));
+#pragma unroll
+    for (int a = 0; a < 3; a++) xg[dofo + a] = xr[a];
+    if (!done) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) { rg[dofo + a] = rr[a]; wg[dofo + a] = wr[a]; zg[dofo + a] = zr[a]; sg[dofo + a] = sr[a]; pg[dofo + a] = pr[a]; }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->rho0 = rho0; st->eps2 = eps2; st->max_iter = max_iter;
+    st->iter = iter;
+    st->rho[iter & 1] = done ? gamma : gamma_old;
+    st->done = done ? 1 : 0;
+    pa.pstate[0] = gamma_old; pa.pstate[1] = alpha_old;
+    // a launch cut after a pre-publish takes the publish back: its rows are in the planes and the boxes, but no counter was raised for
+    // it, and the next launch publishes the same values under the same number
+    pa.seqs[0] = published ? pub - 1u : pub; pa.seqs[1] = sums;
+  }
+}
+
+}  // namespace fb

@@ -450,3 +450,140 @@ def test_a_failed_collective_resync_fails_on_every_rank_instead_of_hanging(gpu):
         assert ("rest volume" in msg) if rank == world - 1 else ("failed on rank %d" % (world - 1) in msg), (rank, msg)
         assert poisoned is not None and "unusable after a failed" in poisoned, (rank, poisoned)
         assert it0 > 0 and it1 == it0, (rank, it0, it1)
+
+
+def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_ms="2000"):
+    try:
+        os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world), 256 // world)   # each rank on its own share of the CUs
+        os.environ["FEMBRAIN_SHARDED_PERSIST"] = "1"
+        os.environ["FEMBRAIN_PERSIST_TIMEOUT_MS"] = timeout_ms
+        if cut:
+            os.environ["FEMBRAIN_PERSIST_MAX_RUN"] = str(cut)
+        from fembrain_amd import lib as fl
+        from fembrain_amd.fem import FemIntegrator
+        L = fl.lib()
+        comm = C.c_void_p()
+        fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
+        v, t, fixed, splits = _mesh(n, world)
+        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), cg_eps=1e-6 if n > 0 else 1e-8)
+        f = np.zeros(g.r)
+        f[1::3] = -10000.0 if n > 0 else -200.0
+        f[0::3] = (300.0 if n > 0 else 20.0) * np.sin(np.arange(len(v)))
+        its, paths = [], []
+        for _ in range(steps):
+            g.set_external_forces(f)
+            its.append(g.do_timestep())
+            paths.append(int(g.last.pcg_path))
+        qq = g.get_q_state()[0]
+        lo, hi = 3 * int(splits[rank]), 3 * int(splits[rank + 1])
+        q.put((rank, its, qq[lo:hi].copy(), g.pcg_path(), paths, g.persist_info(), lo, hi))
+        g.close()
+        L.fb_comm_destroy(comm)
+    except Exception as e:
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc(), None, None, None, None, 0, 0))
+        q.close()
+        q.join_thread()
+        os._exit(1)
+
+
+@pytest.mark.parametrize("world,n,kernel", [(2, 40, "k_pcg_pipe_shard<8,8>"), (2, -30000, "k_pcg_pipe_shard<8,8>"), (4, 40, "k_pcg_pipe_shard<8,8>"),
+                                            (2, 56, "k_pcg_pipe_shard<12,6>")])
+def test_sharded_persistent_solver_on_disjoint_cus_matches_the_unsharded_handle(gpu, world, n, kernel):
+    """The sharded persistent pipelined solver (pcg_pipe_shard.hip.h; opt-in FEMBRAIN_SHARDED_PERSIST=1; UNMEASURED on multi-GPU
+    hardware): one persistent launch per solve ON EVERY RANK, the halo rows written by their owners straight into the neighbour rank's
+    box (HIP IPC), copied into the planes by a proxy wavefront, the rank sums posted into every rank's box -- no collective on the
+    path.  Here the ranks are processes on the one GPU of the box, each confined to its own share of the CUs (FEMBRAIN_CU_MASK), so
+    their persistent grids are resident together.  Three steps against the unsharded handle: the same iteration counts to max(2, 1 %),
+    the gathered displacements to 1e-6; every rank reports the sharded kernel, the persistent path and no fallback; a solve cut into
+    launches of 7 iterations gives the same bits.  Cube slabs (two neighbours at most), a Delaunay mesh in random node order (every
+    rank neighbours every other, every workgroup polls all flags), four ranks, and the 12-wavefront instantiation."""
+    import multiprocessing as mp
+    from fembrain_amd.fem import FemIntegrator
+    from fembrain_amd import lib as fl
+    steps = 3
+    ctx = mp.get_context("spawn")
+    runs = []
+    for cut in (None, 7):
+        q = ctx.Queue()
+        name = "/fembrain_test_%d_sp_%d_%d_%s" % (os.getpid(), world, abs(n), cut)
+        procs = [ctx.Process(target=_shard_persist_worker, args=(r, world, name, n, steps, q, cut)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = []
+        try:
+            for _ in range(world):
+                res.append(q.get(timeout=300))
+                assert res[-1][2] is not None, res[-1]
+        finally:
+            for p in procs:
+                p.join(timeout=30)
+                if p.is_alive():
+                    p.kill()
+        runs.append(sorted(res, key=lambda r: r[0]))
+        if n < 0 or world > 2:
+            break      # (the cut run for the slab cubes only)
+    v, t, fixed, _ = _mesh(n, world)
+    g = FemIntegrator(v, t, fixed, cg_eps=1e-6 if n > 0 else 1e-8)   # (the ill-conditioned Delaunay systems: two solvers agree to the tolerance they stop at)
+    f = np.zeros(g.r)
+    f[1::3] = -10000.0 if n > 0 else -200.0
+    f[0::3] = (300.0 if n > 0 else 20.0) * np.sin(np.arange(len(v)))
+    its = []
+    for _ in range(steps):
+        g.set_external_forces(f)
+        its.append(g.do_timestep())
+    qs = g.get_q_state()[0]
+    qg = np.zeros_like(qs)
+    for rank, rits, qq, path, paths, info, lo, hi in runs[0]:
+        assert rits == runs[0][0][1]
+        assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its)), (rits, its)
+        assert path["kernel"] == kernel and path["fallbacks"] == 0 and all(p == fl.FB_PCG_PATH_PERSISTENT for p in paths), (rank, path, paths)
+        assert info[0] and info[2] == 256 // world, info
+        qg[lo:hi] = qq
+    # the Delaunay mesh has sliver tets: fp32 matrix entries summed in another order move its solution by 3e-5 (the two-launch sharded
+    # path sits 3.0e-5 from the unsharded handle at eps 1e-8, this one 3.2e-5, the two sharded paths 1e-5 from each other)
+    assert np.abs(qg - qs).max() <= (1e-6 if n > 0 else 1e-4) * np.abs(qs).max()
+    if len(runs) > 1:
+        for a, b in zip(runs[0], runs[1]):
+            assert a[1] == b[1] and np.array_equal(a[2], b[2]), "a cut solve differs from the uncut one"
+
+
+def test_sharded_persistent_solver_that_times_out_falls_back_on_every_rank(gpu):
+    """A wait bound no launch can meet (0.1 us): every rank's first launch gives up, the ranks agree on it (the error words are
+    gathered), and all of them repeat the solve with the two-launch sharded iteration and stay with it -- same result as the unsharded
+    handle, the path reported as fallback, one fallback counted per rank."""
+    import multiprocessing as mp
+    from fembrain_amd.fem import FemIntegrator
+    from fembrain_amd import lib as fl
+    world, n, steps = 2, 40, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_persist_worker, args=(r, world, "/fembrain_test_%d_spto" % os.getpid(), n, steps, q, None, "0.0001")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=300))
+            assert res[-1][2] is not None, res[-1]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    v, t, fixed, _ = _mesh(n, world)
+    g = FemIntegrator(v, t, fixed)
+    f = np.zeros(g.r)
+    f[1::3] = -10000.0
+    f[0::3] = 300.0 * np.sin(np.arange(len(v)))
+    its = []
+    for _ in range(steps):
+        g.set_external_forces(f)
+        its.append(g.do_timestep())
+    qs = g.get_q_state()[0]
+    qg = np.zeros_like(qs)
+    for rank, rits, qq, path, paths, info, lo, hi in res:
+        assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its)), (rits, its)
+        assert path["fallbacks"] == 1 and paths == [fl.FB_PCG_PATH_FALLBACK, fl.FB_PCG_PATH_TWO_LAUNCH], (rank, path, paths)
+        qg[lo:hi] = qq
+    assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
