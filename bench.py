@@ -339,6 +339,15 @@ def main():
         n, text = WORKLOADS[args.workload]
         prec = fl.FB_MATRIX_F64 if args.precision == "f64" else fl.FB_MATRIX_F32
 
+        # Sharded runs try the sharded persistent solver (one launch per solve on every rank, halo rows and rank sums crossing the
+        # GPUs inside the launches; opt-in in the library because it is unmeasured on multi-GPU hardware): it is attached here, timed
+        # as one more candidate beside the exchange modes, and checked like them before anything is timed.  Not in the one-GPU
+        # rehearsal unless the ranks are confined to CU shares of their own (the persistent grids of two ranks must be resident together).
+        if local_comm and os.environ.get("FEMBRAIN_BENCH_CU_SPLIT") == "1":   # rehearsal: every rank on its own share of the one GPU's CUs
+            os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world), 256 // world)
+        if dist_mode and os.environ.get("FEMBRAIN_BENCH_NO_SHARDED_PERSIST") != "1" and (not local_comm or os.environ.get("FEMBRAIN_CU_MASK")):
+            os.environ.setdefault("FEMBRAIN_SHARDED_PERSIST", "1")
+
         def create():
             v, t, fixed = workload_mesh(args.workload, device)
             sh = None
@@ -367,6 +376,25 @@ def main():
         # for every rank alike and the collective library carries the run.
         xch_trials = {}
         xch_note = None
+        sp_attached = dist_mode and g.sharded_persist()   # (agreed by the ranks when the handle was created)
+        sp_use = False
+        if sp_attached:
+            def sp_trial():
+                one_step()                                # first step (allocations, first-touch)
+                barrier()
+                ts = time.perf_counter()
+                one_step()
+                barrier()
+                return time.perf_counter() - ts, int(g.last.pcg_path)
+            sp_res, why = stage("exchange trial: sharded persistent launches", sp_trial, optional=True)
+            ran = why is None and reduce_scalar(1.0 if sp_res[1] == fl.FB_PCG_PATH_PERSISTENT else 0.0, "min") > 0.5
+            if ran:
+                xch_trials["sharded_persistent"] = reduce_scalar(sp_res[0], "max") * 1e3
+                sp_use = True
+                g.set_sharded_persist(False)              # the exchange modes' turn
+            else:
+                xch_note = "the sharded persistent solver did not run its trial step (%s)" % (why or "a wait timed out, every rank fell back")
+            g.reset_to_rest()
         if dist_mode and g.transport() >= fl.FB_XCH_P2P and os.environ.get("FEMBRAIN_XCH_MODE") is None:
             names = {fl.FB_XCH_COLLECTIVE: "collective", fl.FB_XCH_P2P: "p2p", fl.FB_XCH_P2P_SUMS: "p2p_sums", fl.FB_XCH_P2P_FUSED: "p2p_fused"}
             modes = (fl.FB_XCH_P2P, fl.FB_XCH_P2P_SUMS, fl.FB_XCH_P2P_FUSED)
@@ -386,14 +414,17 @@ def main():
                     break
                 xch_trials[names[mode]] = reduce_scalar(dt_trial, "max") * 1e3
             if why is None:
-                best = min(xch_trials, key=xch_trials.get)
+                best = min((k for k in xch_trials if k != "sharded_persistent"), key=xch_trials.get)
                 g.set_exchange_mode({vv: k for k, vv in names.items()}[best])
+                sp_use = sp_use and xch_trials["sharded_persistent"] <= xch_trials[best]
             else:
                 # a peer-to-peer form failed on some rank (its inbox is poisoned from then on): the collective library carries
                 # the rest of the run, on every rank alike, and the line says so
                 xch_note = "peer-to-peer exchange failed in the trial step (%s); fell back to the collective library" % why
                 g.set_exchange_mode(fl.FB_XCH_COLLECTIVE)
             g.reset_to_rest()   # the timed steps start from the same state as the one-GPU run's
+        if sp_attached and g.persist_info()[0] != sp_use and not (sp_use and g.pcg_path()["fallbacks"]):
+            g.set_sharded_persist(sp_use)
         # Sharded runs check themselves before anything is timed: the first step from rest, gathered over the ranks, against
         # the same step of an UNSHARDED handle on rank 0's GPU (iteration count within max(3, 2 %), displacements within 2e-4
         # of max|q| -- the tolerance of the parity tests for two solves that both stop at a 1e-6 residual; the same check runs
@@ -428,6 +459,13 @@ def main():
                 return reduce_scalar(good, "max") > 0.5, res
 
             passed, sharded_check = check_once()
+            if not passed and sp_attached and g.sharded_persist():
+                first = sharded_check
+                xch_note = ((xch_note + "; ") if xch_note else "") + "the sharded persistent solver failed the self-check, the two-launch iteration took over"
+                g.set_sharded_persist(False)
+                passed, sharded_check = check_once()
+                if rank == 0 and sharded_check is not None:
+                    sharded_check["sharded_persistent_attempt"] = first
             if not passed and g.transport() >= fl.FB_XCH_P2P:
                 first = sharded_check
                 xch_note = ((xch_note + "; ") if xch_note else "") + "the peer-to-peer exchange failed the self-check, the collective library took over"
@@ -546,10 +584,14 @@ def main():
                            "exchange": ["none (one GPU)", "host-staged test communicator (rehearsal)" if local_comm else "RCCL all-reduce + send/recv",
                                         "peer-to-peer inboxes over xGMI (HIP IPC), one kernel per exchange",
                                         "peer-to-peer inboxes, sums inside the PCG kernels",
-                                        "peer-to-peer inboxes, sums and halo values inside the PCG kernels"][g.transport()],
+                                        "peer-to-peer inboxes, sums and halo values inside the PCG kernels"][g.transport()]
+                                       if not (dist_mode and g.sharded_persist()) else
+                                       "sharded persistent launches: halo rows stored into the neighbour rank's box and rank sums posted to every rank "
+                                       "inside the one launch per solve (HIP IPC over xGMI, no exchange kernel, no collective)",
                            "exchange_trials_ms_per_step": xch_trials, "exchange_note": xch_note, "sharded_self_check": sharded_check,
                            "cg_eps": 1e-6, "cg_max_iter": 10000,
-                           "pcg": ("one persistent launch per solve, pipelined iteration (FB_PCG_PERSISTENT, default at this size)" if persist[0]
+                           "pcg": ("one persistent launch per solve, pipelined iteration (%s)" % ("FB_PCG_PERSISTENT, default at this size" if shard is None
+                                                                                                    else "k_pcg_pipe_shard, on every rank") if persist[0]
                                    else "two launches per merged iteration (FB_PCG_MERGED)"),
                            "pcg_path_last_step": int(g.last.pcg_path), "persist_fallbacks": int(g.last.persist_fallbacks)},
                 "cg_iterations": [int(i) for i in iters], "cg_iterations_per_step": float(np.mean(iters)),
@@ -571,6 +613,7 @@ def main():
             }
         out = _state["out"]
         mode_used = g.transport()
+        sp_final = bool(dist_mode and g.sharded_persist())
         g.close()
         g = None
 
@@ -610,6 +653,8 @@ def main():
                 g8, ntets8 = made
                 if dist_mode and mode_used != g8.transport() and g8.transport() >= fl.FB_XCH_P2P:
                     g8.set_exchange_mode(mode_used)   # collective; the form picked (or fallen back to) above
+                if dist_mode and g8.sharded_persist() and not sp_final:
+                    g8.set_sharded_persist(False)     # the sharded persistent solver only where it passed the trial and the self-check above
                 _, why = stage("8M-tet leg: warm-up step", lambda: one_step(g8), optional=True)
             if made and why is None:
                 def timed8():
@@ -635,7 +680,8 @@ def main():
                             pass
                     big = {"workload": WORKLOADS["cube111"][1], "tets": int(ntets8), "steps": 2, "warmup": 1, "value": 2 / dt8, "unit": "steps/s",
                            "ms_per_step": dt8 / 2 * 1e3, "cg_iterations": [int(i) for i in it8], "cg_iterations_per_step": float(np.mean(it8)),
-                           "us_per_cg_iteration": solve8 / max(sum(it8), 1) * 1e6, "spmv_gbs": spmv8}
+                           "us_per_cg_iteration": solve8 / max(sum(it8), 1) * 1e6, "spmv_gbs": spmv8,
+                           "pcg_kernel": g8.pcg_path()["kernel"] or "two-launch iteration", "pcg_path_last_step": int(g8.last.pcg_path)}
             if g8 is not None:
                 g8.close()
             if out is not None:

@@ -92,11 +92,13 @@ struct fb_fem_s {
   int pipe_klt = 0, pipe_wmax = 0;
   // sharded persistent solver (pcg_pipe_shard.hip.h; opt-in FEMBRAIN_SHARDED_PERSIST=1, unmeasured on multi-GPU hardware)
   bool shard_persist = false;
+  bool persist_broken = false;  // a launch timed out: the handle stays with the two-launch iteration
   char* sbox = nullptr;                // my box (fine-grained, mapped by the peers)
   void* sbox_opened[kP2PMaxRanks] = {nullptr};
   long long sbox_halo_cap = 0;
   DevBuf<char*> sbox_peers;
-  DevBuf<int> sh_peer_seg, sh_halo_off, sh_row_send_off, sh_row_send_rank, sh_row_send_pos, sh_n_senders, sh_proxy_wg;
+  DevBuf<int> sh_peer_seg, sh_halo_off, sh_row_send_off, sh_row_send_rank, sh_row_send_pos, sh_n_senders, sh_proxy_wg, sh_wg_duty;
+  int sh_n_proxy = 1;
   DevBuf<unsigned int> sh_wg_send_mask;
   int pipe_flag_extra = 0;             // flag slots after the workgroups' (the proxies' flags of a sharded handle)
   int pipe_rows = 1;                   // rows per lane: 1 = k_pcg_pipe (up to 12 slices per CU), 2 = k_pcg_pipe2 (13..24)
@@ -165,7 +167,7 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   h->pipe_wmax = w < 8 ? 8 : 12;   // (w + 1 wavefronts: the spare one serves the proxies and the sums)
   h->pipe_klt = std::min(h->pipe_wmax == 8 ? 8 : 6, kPipeLdsSlots / std::max(w, 1));
   h->persist_blocks = nb; h->persist_waves = w;
-  h->pipe_flag_extra = kP2PMaxRanks;
+  h->pipe_flag_extra = kP2PMaxRanks * kShardProxies;
   FB_TRY(h->pipe_post.alloc((size_t)2 * nb * 4));
   FB_TRY(h->pipe_post.zero(s));
   FB_TRY(h->pipe_flags.alloc((size_t)nb + h->pipe_flag_extra + 16));
@@ -205,10 +207,22 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   FB_TRY(h->sh_wg_send_mask.upload(wg_mask, s));
   FB_TRY(h->sh_halo_off.upload(P.halo_off, s));
   // proxies: one workgroup per rank I have halo nodes of, from the last workgroup downwards
-  std::vector<int> proxy((size_t)R, -1);
-  for (int q = 0, k = 0; q < R; q++)
-    if (P.halo_off[q + 1] > P.halo_off[q]) proxy[q] = nb - 1 - (k++ % nb);
+  int n_src = 0;
+  for (int q = 0; q < R; q++) n_src += P.halo_off[q + 1] > P.halo_off[q];
+  const int K = std::max(1, std::min(kShardProxies, nb * kShardDuties / std::max(1, n_src)));
+  h->sh_n_proxy = K;
+  std::vector<int> proxy((size_t)R * K, -1), duty((size_t)nb * kShardDuties, -1), n_duty((size_t)nb, 0);
+  for (int q = 0, idx = 0; q < R; q++)
+    for (int k = 0; k < K; k++) {
+      int lo, hi;
+      shard_proxy_rows(P.halo_off[q], P.halo_off[q + 1], K, k, &lo, &hi);
+      if (hi <= lo) continue;
+      const int b = nb - 1 - (idx++ % nb);   // (idx < nb * kShardDuties by the choice of K)
+      proxy[(size_t)q * K + k] = b;
+      duty[(size_t)b * kShardDuties + n_duty[b]++] = q * K + k;
+    }
   FB_TRY(h->sh_proxy_wg.upload(proxy, s));
+  FB_TRY(h->sh_wg_duty.upload(duty, s));
   // producer lists: local workgroups from the owned column range of every slice, proxies from the ranks its halo columns belong to
   DevBuf<int4> range;
   FB_TRY(range.alloc((size_t)std::max(1, P.n_slices)));
@@ -218,7 +232,7 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   std::vector<int4> rg((size_t)std::max(1, P.n_slices));
   FB_TRY(range.download(rg.data(), rg.size(), s));
   std::vector<int> prod((size_t)nb * kPipeMaxProducers, -1), cnt((size_t)nb, 0), far((size_t)nb, 1);
-  std::vector<char> mark((size_t)nb + R);
+  std::vector<char> mark((size_t)nb + (size_t)R * K);
   h->pipe_max_producers = 0;
   for (int b = 0; b < nb; b++) {
     int first, count;
@@ -232,12 +246,14 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
         if (o != b && !mark[o]) { mark[o] = 1; n++; }
       }
       for (int q = 0; q < R; q++)
-        if (((unsigned int)r.z >> q & 1u) && !mark[nb + q]) { mark[nb + q] = 1; n++; }
+        if ((unsigned int)r.z >> q & 1u)
+          for (int kk = 0; kk < K; kk++)   // (all proxies of a rank this slice gathers halo rows of)
+            if (proxy[(size_t)q * K + kk] >= 0 && !mark[nb + q * K + kk]) { mark[nb + q * K + kk] = 1; n++; }
     }
     if (n > kPipeMaxProducers) { cnt[b] = -1; h->pipe_max_producers = -1; continue; }
     cnt[b] = n;
     if (h->pipe_max_producers >= 0) h->pipe_max_producers = std::max(h->pipe_max_producers, n);
-    for (int o = 0, k = 0; o < nb + R; o++) if (mark[o]) prod[(size_t)b * kPipeMaxProducers + k++] = o;
+    for (int o = 0, k = 0; o < nb + R * K; o++) if (mark[o]) prod[(size_t)b * kPipeMaxProducers + k++] = o;
   }
   FB_TRY(h->pipe_prod.upload(prod, s));
   FB_TRY(h->pipe_prod_count.upload(cnt, s));
@@ -853,7 +869,7 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     sa.rank = h->plan.rank; sa.n_ranks = h->plan.n_ranks; sa.n_owned = h->plan.n_owned; sa.n_halo = h->plan.n_local - h->plan.n_owned;
     sa.box = h->sbox; sa.peer_box = h->sbox_peers.p; sa.peer_seg = h->sh_peer_seg.p; sa.halo_cap = h->sbox_halo_cap;
     sa.halo_off = h->sh_halo_off.p; sa.row_send_off = h->sh_row_send_off.p; sa.row_send_rank = h->sh_row_send_rank.p; sa.row_send_pos = h->sh_row_send_pos.p;
-    sa.wg_send_mask = h->sh_wg_send_mask.p; sa.n_senders = h->sh_n_senders.p; sa.proxy_wg = h->sh_proxy_wg.p;
+    sa.wg_send_mask = h->sh_wg_send_mask.p; sa.n_senders = h->sh_n_senders.p; sa.proxy_wg = h->sh_proxy_wg.p; sa.n_proxy = h->sh_n_proxy; sa.wg_duty = h->sh_wg_duty.p;
     static bool attr_s[2] = {false, false};
     const int wi = h->pipe_wmax == 8 ? 0 : 1;
     const void* kern = wi == 0 ? (const void*)k_pcg_pipe_shard<8, 8> : (const void*)k_pcg_pipe_shard<12, 6>;
@@ -948,6 +964,7 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
       FB_TRY(h->pipe_flags.zero(s));
       FB_TRY(h->pipe_post.zero(s));
       h->persist = false;
+      h->persist_broken = true;
       h->persist_fallbacks++;
       if (getenv("FEMBRAIN_PERSIST_STRICT") && atoi(getenv("FEMBRAIN_PERSIST_STRICT")) != 0)
         return fail(FB_EDEVICE, "persistent PCG: a wait inside the launch timed out after %.1f ms (the workgroups were not all resident?)", h->persist_timeout_ticks * 1e-5);
@@ -1587,6 +1604,20 @@ int fb_fem_set_exchange_mode(fb_fem_t h, int mode) {
   if (mode == FB_XCH_COLLECTIVE && !h->comm->nccl && !h->comm->local) return fail(FB_ECOMM, "the communicator has no collective library");
   FB_HIP(hipStreamSynchronize(h->stream));
   h->xch_mode = mode;
+  return FB_OK;
+}
+
+int fb_fem_sharded_persist(fb_fem_t h) {
+  if (!h) return 0;
+  return h->shard_persist && h->persist ? 1 : 0;
+}
+
+int fb_fem_set_sharded_persist(fb_fem_t h, int on) {
+  CHECK_HANDLE(h);
+  if (!h->shard_persist || !h->sbox) return fail(FB_EINVAL, "the sharded persistent solver is not attached to this handle (FEMBRAIN_SHARDED_PERSIST=1 at creation, <= %d slices per CU)", kPipeMaxWaves - 1);
+  if (on && h->persist_broken) return fail(FB_EDEVICE, "the sharded persistent solver of this handle timed out before; it stays with the two-launch iteration");
+  FB_HIP(hipStreamSynchronize(h->stream));
+  h->persist = on != 0;
   return FB_OK;
 }
 

@@ -14,8 +14,9 @@
 // and in ordinary device memory the planes [2][3][n_pad] of pcg_pipe.hip.h, n_pad covering owned AND halo columns: a PROXY -- the
 // spare wavefront of one workgroup per neighbour rank -- waits for counters[s] to reach (workgroups of s that send to me) x (publish
 // number), copies s's segment from the box into the halo part of the planes (so that the products' gathers stay cached, ordinary
-// loads), drains and raises a flag of its own (flags[n_blocks + s]); slices with halo columns of rank s have that flag in their
-// producer list.  Hazards as in pcg_pipe.hip.h: the box's halo area is double-buffered by publish parity, and a sender can be two
+// loads), drains and raises a flag of its own; slices with halo columns of rank s have that flag in their producer list.  A segment
+// is dealt to up to 16 proxies (s, k) in 64-row groups -- a copy is a chain of uncached loads, so it is spread over as many
+// wavefronts as the workgroups can spare (at most 4 duties per workgroup) -- with flags[n_blocks + s * n_proxy + k].  Hazards as in pcg_pipe.hip.h: the box's halo area is double-buffered by publish parity, and a sender can be two
 // publishes ahead of a receiver only after it has received that receiver's publish in between (the neighbour relation is symmetric).
 // Everything else -- state in registers, LDS-resident slots, the assembly loop over the streamed slots (32-bit local column ids),
 // exact-residual iterations, launch cuts, bounded waits -- is k_pcg_pipe's.  A workgroup needs its spare wavefront (at most 11 / 7
@@ -54,8 +55,18 @@ struct ShardArgs {
   const int* row_send_pos;            // position inside my segment of that rank's halo
   const unsigned int* wg_send_mask;   // [n_blocks] ranks this workgroup has rows to send to
   const int* n_senders;               // [n_ranks] workgroups of rank s that send to me
-  const int* proxy_wg;                // [n_ranks] the workgroup whose spare wavefront copies rank s's segment (-1: no halo from s)
+  int n_proxy;                        // proxies per source rank: proxy (s, k) copies the k-th chunk of rank s's segment
+  const int* proxy_wg;                // [n_ranks * n_proxy] the workgroup whose spare wavefront is proxy (s, k) (-1: nothing to copy)
+  const int* wg_duty;                 // [n_blocks * kShardDuties] the proxies (s * n_proxy + k) of every workgroup, -1 padded
 };
+constexpr int kShardProxies = 16;     // at most, per source rank
+constexpr int kShardDuties = 4;       // at most, per workgroup
+// rows [lo, hi) of a halo segment [h0, h1) that proxy k of n copies (whole 64-row groups)
+__host__ __device__ inline void shard_proxy_rows(int h0, int h1, int n, int k, int* lo, int* hi) {
+  const int chunk = (((h1 - h0) + n - 1) / n + 63) & ~63;
+  *lo = h0 + k * chunk < h1 ? h0 + k * chunk : h1;
+  *hi = *lo + chunk < h1 ? *lo + chunk : h1;
+}
 
 __device__ __forceinline__ void st_sys_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_sys_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -176,8 +187,10 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe_shard(SellView sv, const
         __hip_atomic_fetch_add((unsigned int*)(sa.peer_box[lane] + BL.counters) + sa.rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       // proxy: the halo segments this workgroup copies from the box into the planes
       const long long t0 = wall_clock64();
-      for (int s = 0; s < sa.n_ranks && !failed; s++) {
-        if (sa.proxy_wg[s] != (int)blockIdx.x) continue;  // workgroup-uniform
+      for (int d = 0; d < kShardDuties && !failed; d++) {
+        const int duty = sa.wg_duty[blockIdx.x * kShardDuties + d];  // workgroup-uniform
+        if (duty < 0) break;
+        const int s = duty / sa.n_proxy, k = duty - s * sa.n_proxy;
         const unsigned int want = (unsigned int)sa.n_senders[s] * pub;
         const unsigned int* cnt = (const unsigned int*)(sa.box + BL.counters) + s;
         while ((int)(ld_sys_u32(cnt) - want) < 0) {
@@ -185,13 +198,23 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe_shard(SellView sv, const
           __builtin_amdgcn_s_sleep(1);
         }
         if (failed) break;
-        const int h0 = sa.halo_off[s], h1 = sa.halo_off[s + 1];
+        int lo, hi;
+        shard_proxy_rows(sa.halo_off[s], sa.halo_off[s + 1], sa.n_proxy, k, &lo, &hi);
         const double* in = (const double*)(sa.box + BL.halo) + (size_t)(pub & 1u) * 3 * (size_t)sa.halo_cap;
+        double* out = pl + (size_t)sa.n_owned;
+        for (int i0 = lo + lane; i0 < hi; i0 += 4 * 64) {  // twelve loads in flight per lane
+          double t[3][4];
 #pragma unroll
-        for (int a = 0; a < 3; a++)
-          for (int i = h0 + lane; i < h1; i += 64) st_sc1_f64(pl + a * pa.n_pad + (size_t)sa.n_owned + i, ld_sys_f64(in + (size_t)a * (size_t)sa.halo_cap + i));
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) t[a][j] = i0 + 64 * j < hi ? ld_sys_f64(in + (size_t)a * (size_t)sa.halo_cap + i0 + 64 * j) : 0.0;
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) if (i0 + 64 * j < hi) st_sc1_f64(out + a * pa.n_pad + i0 + 64 * j, t[a][j]);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) st_sc1_u32(pa.flags + nb + s, pub);
+        if (lane == 0) st_sc1_u32(pa.flags + nb + duty, pub);
       }
       failed = uniform_flag(failed);
       if (failed && lane == 0) { st_sc1_u32(pa.error, 1u); bc[4] = 1.0; }
@@ -217,10 +240,11 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe_shard(SellView sv, const
           __builtin_amdgcn_s_sleep(1);
         }
       } else {
-        for (int b = lane; b - lane < nb + sa.n_ranks && !failed; b += 64) {  // all workgroups and all proxies
+        const int n_flags = nb + sa.n_ranks * sa.n_proxy;
+        for (int b = lane; b - lane < n_flags && !failed; b += 64) {  // all workgroups and all proxies
           for (;;) {
             bool ok = true;
-            if (b < nb || (b < nb + sa.n_ranks && sa.proxy_wg[b - nb] >= 0)) ok = (int)(ld_sc1_u32(pa.flags + b) - pub) >= 0;
+            if (b < nb || (b < n_flags && sa.proxy_wg[b - nb] >= 0)) ok = (int)(ld_sc1_u32(pa.flags + b) - pub) >= 0;
             if (__ballot(!ok) == 0ULL) break;
             if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
             __builtin_amdgcn_s_sleep(1);

@@ -102,6 +102,14 @@ class FemIntegrator:
         """Collective: every rank of a sharded handle switches between two solves."""
         _l.check(self._L.fb_fem_set_exchange_mode(self.h, mode))
 
+    def sharded_persist(self):
+        """True when this sharded handle's solves run inside the sharded persistent launches (FEMBRAIN_SHARDED_PERSIST=1)."""
+        return bool(self._L.fb_fem_sharded_persist(self.h))
+
+    def set_sharded_persist(self, on):
+        """Collective: every rank switches between two solves."""
+        _l.check(self._L.fb_fem_set_sharded_persist(self.h, 1 if on else 0))
+
     def close(self):
         if getattr(self, "h", None):
             self._L.fb_fem_destroy(self.h)

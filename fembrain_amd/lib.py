@@ -151,6 +151,8 @@ def lib():
     poly_sig = {
         "fb_fem_transport": (C.c_int, [vp]),
         "fb_fem_set_exchange_mode": (C.c_int, [vp, C.c_int]),
+        "fb_fem_sharded_persist": (C.c_int, [vp]),
+        "fb_fem_set_sharded_persist": (C.c_int, [vp, C.c_int]),
         "fb_fem_time_exchange": (C.c_int, [vp, C.c_int, _dp, _dp]),
         "fb_fem_time_element_stiffness": (C.c_int, [vp, C.c_int, _dp]),
         "fb_poly_create": (C.c_int, [C.POINTER(vp), C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp]),
