@@ -98,7 +98,8 @@ struct fb_fem_s {
   long long sbox_halo_cap = 0;
   DevBuf<char*> sbox_peers;
   DevBuf<int> sh_peer_seg, sh_halo_off, sh_row_send_off, sh_row_send_rank, sh_row_send_pos, sh_n_senders, sh_proxy_wg, sh_wg_duty;
-  int sh_n_proxy = 1;
+  DevBuf<int2> sh_wg_range;
+  int sh_n_proxy = 1, sh_relief = 0;
   DevBuf<unsigned int> sh_wg_send_mask;
   int pipe_flag_extra = 0;             // flag slots after the workgroups' (the proxies' flags of a sharded handle)
   int pipe_rows = 1;                   // rows per lane: 1 = k_pcg_pipe (up to 12 slices per CU), 2 = k_pcg_pipe2 (13..24)
@@ -164,10 +165,61 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   const int R = P.n_ranks;
   if (R > kP2PMaxRanks) return FB_OK;
   h->pipe_rows = 1;
+  FB_TRY(h->sh_halo_off.upload(P.halo_off, s));
+  // per slice: its owned column range and the ranks whose halo rows it gathers
+  DevBuf<int4> range;
+  FB_TRY(range.alloc((size_t)std::max(1, P.n_slices)));
+  hipLaunchKernelGGL(k_slice_colrange_shard, dim3(ceil_div(std::max(1, P.n_slices), kWavesPerBlock)), dim3(kBlock), 0, s, P.n_slices, P.n_owned, R, h->slice_off.p,
+                     h->colidx.p, h->sh_halo_off.p, range.p);
+  FB_HIP(hipGetLastError());
+  std::vector<int4> rg((size_t)std::max(1, P.n_slices));
+  FB_TRY(range.download(rg.data(), rg.size(), s));
+  // slice -> workgroup.  A workgroup whose slices gather halo rows gets its input later than the others by the length of the
+  // cross-rank chain (drain -> counter -> proxy copy -> flag; ~4.5 us between two processes on one MI355X) EVERY iteration, and the
+  // whole grid ends up at its pace.  So it is dealt fewer slices ("relief", FEMBRAIN_SHARD_RELIEF=n, default 35 % of the
+  // slices per CU): its shorter product absorbs the wait.
+  static const int relief_env = getenv("FEMBRAIN_SHARD_RELIEF") ? atoi(getenv("FEMBRAIN_SHARD_RELIEF")) : -1;
+  std::vector<int2> wg_range((size_t)nb, make_int2(0, 0));   // first slice and slice count of every workgroup
+  int Q = w, relief = std::min(w - 1, relief_env >= 0 ? relief_env : std::max(0, (w * 35 + 50) / 100));
+  for (;; relief--) {
+    Q = 0;
+    if (relief <= 0 || (nb & 7)) {  // the even deal of the unsharded kernel
+      relief = 0;
+      for (int b = 0; b < nb; b++) {
+        int first, count;
+        pipe_slices(P.n_slices, nb, b, &first, &count);
+        wg_range[b] = make_int2(first, count);
+        Q = std::max(Q, count);
+      }
+      break;
+    }
+    // a slice that gathers halo rows weighs w / (w - relief) slices; equal weight per workgroup, contiguous, and in pipe_slices'
+    // order: the workgroups of XCD b & 7 (round-robin dispatch) hold a contiguous eighth
+    const double rho = (double)w / (double)(w - relief);
+    double W = 0;
+    for (int sl = 0; sl < P.n_slices; sl++) W += rg[sl].z != 0 ? rho : 1.0;
+    std::vector<int> start((size_t)nb + 1, P.n_slices);
+    double acc = 0;
+    int pos = 0;
+    for (int sl = 0; sl < P.n_slices; sl++) {
+      while (pos < nb && acc >= W * pos / nb - 1e-9) start[pos++] = sl;   // position pos starts at the first slice at or past its share
+      acc += rg[sl].z != 0 ? rho : 1.0;
+    }
+    const int per = nb >> 3;
+    for (int p2 = 0; p2 < nb; p2++) {
+      const int b = (p2 % per) * 8 + p2 / per;
+      wg_range[b] = make_int2(start[p2], start[p2 + 1] - start[p2]);
+      Q = std::max(Q, start[p2 + 1] - start[p2]);
+    }
+    if (Q < kPipeMaxWaves) break;
+  }
+  w = Q;
   h->pipe_wmax = w < 8 ? 8 : 12;   // (w + 1 wavefronts: the spare one serves the proxies and the sums)
   h->pipe_klt = std::min(h->pipe_wmax == 8 ? 8 : 6, kPipeLdsSlots / std::max(w, 1));
   h->persist_blocks = nb; h->persist_waves = w;
+  h->sh_relief = relief;
   h->pipe_flag_extra = kP2PMaxRanks * kShardProxies;
+  FB_TRY(h->sh_wg_range.upload(wg_range, s));
   FB_TRY(h->pipe_post.alloc((size_t)2 * nb * 4));
   FB_TRY(h->pipe_post.zero(s));
   FB_TRY(h->pipe_flags.alloc((size_t)nb + h->pipe_flag_extra + 16));
@@ -180,13 +232,9 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   FB_TRY(h->pipe_state.alloc(2));
   FB_TRY(h->pipe_state.zero(s));
   h->persist_timing.release();
-  // slice -> workgroup
   std::vector<int> owner((size_t)P.n_slices, 0);
-  for (int b = 0; b < nb; b++) {
-    int first, count;
-    pipe_slices(P.n_slices, nb, b, &first, &count);
-    for (int k = 0; k < count; k++) owner[first + k] = b;
-  }
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < wg_range[b].y; k++) owner[wg_range[b].x + k] = b;
   // per-row send lists and per-workgroup destination masks from the plan's send lists (ascending owned ids per destination: the
   // position of a row in that list is its position in the destination's halo segment of this rank)
   std::vector<int> row_off((size_t)P.n_owned + 1, 0);
@@ -205,8 +253,7 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   FB_TRY(h->sh_row_send_rank.upload(row_rank, s));
   FB_TRY(h->sh_row_send_pos.upload(row_pos, s));
   FB_TRY(h->sh_wg_send_mask.upload(wg_mask, s));
-  FB_TRY(h->sh_halo_off.upload(P.halo_off, s));
-  // proxies: one workgroup per rank I have halo nodes of, from the last workgroup downwards
+  // proxies: up to kShardProxies per rank I have halo nodes of, dealt to the workgroups from the last one downwards
   int n_src = 0;
   for (int q = 0; q < R; q++) n_src += P.halo_off[q + 1] > P.halo_off[q];
   const int K = std::max(1, std::min(kShardProxies, nb * kShardDuties / std::max(1, n_src)));
@@ -224,23 +271,14 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   FB_TRY(h->sh_proxy_wg.upload(proxy, s));
   FB_TRY(h->sh_wg_duty.upload(duty, s));
   // producer lists: local workgroups from the owned column range of every slice, proxies from the ranks its halo columns belong to
-  DevBuf<int4> range;
-  FB_TRY(range.alloc((size_t)std::max(1, P.n_slices)));
-  hipLaunchKernelGGL(k_slice_colrange_shard, dim3(ceil_div(std::max(1, P.n_slices), kWavesPerBlock)), dim3(kBlock), 0, s, P.n_slices, P.n_owned, R, h->slice_off.p,
-                     h->colidx.p, h->sh_halo_off.p, range.p);
-  FB_HIP(hipGetLastError());
-  std::vector<int4> rg((size_t)std::max(1, P.n_slices));
-  FB_TRY(range.download(rg.data(), rg.size(), s));
   std::vector<int> prod((size_t)nb * kPipeMaxProducers, -1), cnt((size_t)nb, 0), far((size_t)nb, 1);
   std::vector<char> mark((size_t)nb + (size_t)R * K);
   h->pipe_max_producers = 0;
   for (int b = 0; b < nb; b++) {
-    int first, count;
-    pipe_slices(P.n_slices, nb, b, &first, &count);
     std::fill(mark.begin(), mark.end(), 0);
     int n = 0;
-    for (int k = 0; k < count; k++) {
-      const int4 r = rg[first + k];
+    for (int sl0 = wg_range[b].x; sl0 < wg_range[b].x + wg_range[b].y; sl0++) {
+      const int4 r = rg[sl0];
       for (int sl = r.x >> 6; r.y >= r.x && sl <= (r.y >> 6) && sl < P.n_slices; sl++) {
         const int o = owner[sl];
         if (o != b && !mark[o]) { mark[o] = 1; n++; }
@@ -869,7 +907,7 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     sa.rank = h->plan.rank; sa.n_ranks = h->plan.n_ranks; sa.n_owned = h->plan.n_owned; sa.n_halo = h->plan.n_local - h->plan.n_owned;
     sa.box = h->sbox; sa.peer_box = h->sbox_peers.p; sa.peer_seg = h->sh_peer_seg.p; sa.halo_cap = h->sbox_halo_cap;
     sa.halo_off = h->sh_halo_off.p; sa.row_send_off = h->sh_row_send_off.p; sa.row_send_rank = h->sh_row_send_rank.p; sa.row_send_pos = h->sh_row_send_pos.p;
-    sa.wg_send_mask = h->sh_wg_send_mask.p; sa.n_senders = h->sh_n_senders.p; sa.proxy_wg = h->sh_proxy_wg.p; sa.n_proxy = h->sh_n_proxy; sa.wg_duty = h->sh_wg_duty.p;
+    sa.wg_send_mask = h->sh_wg_send_mask.p; sa.n_senders = h->sh_n_senders.p; sa.proxy_wg = h->sh_proxy_wg.p; sa.n_proxy = h->sh_n_proxy; sa.wg_duty = h->sh_wg_duty.p; sa.wg_range = h->sh_wg_range.p;
     static bool attr_s[2] = {false, false};
     const int wi = h->pipe_wmax == 8 ? 0 : 1;
     const void* kern = wi == 0 ? (const void*)k_pcg_pipe_shard<8, 8> : (const void*)k_pcg_pipe_shard<12, 6>;
@@ -1355,7 +1393,7 @@ int attach_pipe_shard(fb_fem_s* h) {
   FB_TRY(h->sh_peer_seg.upload(seg, h->stream));
   FB_TRY(h->sh_n_senders.upload(senders, h->stream));
   h->persist = true;
-  if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] rank %d: sharded persistent solver attached (%d workgroups, %d slices per CU, halo %lld of cap %lld)\n", me, h->persist_blocks, h->persist_waves, (long long)(P.n_local - P.n_owned), cap);
+  if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] rank %d: sharded persistent solver attached (%d workgroups, up to %d slices per CU, %d fewer where halo rows are gathered, %d proxies per source rank, halo %lld of cap %lld)\n", me, h->persist_blocks, h->persist_waves, h->sh_relief, h->sh_n_proxy, (long long)(P.n_local - P.n_owned), cap);
   return FB_OK;
 }
 

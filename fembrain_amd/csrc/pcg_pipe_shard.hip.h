@@ -58,6 +58,7 @@ struct ShardArgs {
   int n_proxy;                        // proxies per source rank: proxy (s, k) copies the k-th chunk of rank s's segment
   const int* proxy_wg;                // [n_ranks * n_proxy] the workgroup whose spare wavefront is proxy (s, k) (-1: nothing to copy)
   const int* wg_duty;                 // [n_blocks * kShardDuties] the proxies (s * n_proxy + k) of every workgroup, -1 padded
+  const int2* wg_range;               // [n_blocks] first slice and slice count of every workgroup (those that gather halo rows get fewer: fem.hip)
 };
 constexpr int kShardProxies = 16;     // at most, per source rank
 constexpr int kShardDuties = 4;       // at most, per workgroup
@@ -115,8 +116,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe_shard(SellView sv, const
   if (pa.start == 0 && st->done) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool service = wv == n_waves - 1;  // the spare wavefront: sums, proxy copies (it owns no slice)
-  int first, count;
-  pipe_slices(sv.n_slices, nb, blockIdx.x, &first, &count);
+  const int first = sa.wg_range[blockIdx.x].x, count = sa.wg_range[blockIdx.x].y;
   const bool live = wv < count && !service;
   const int sl = first + wv;
   const int row = sl * 64 + lane;

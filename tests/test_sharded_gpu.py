@@ -452,6 +452,18 @@ def test_a_failed_collective_resync_fails_on_every_rank_instead_of_hanging(gpu):
         assert it0 > 0 and it1 == it0, (rank, it0, it1)
 
 
+def _sp_force(n, v):
+    """Load of the sharded persistent tests.  The 56^3 cube gets a quarter of the smaller cubes' load: under the full one its third step
+    sits on a discontinuity of the corotational model (an element's rotation flips), where runs that agree to 1e-7 after two steps
+    and whose solves all meet the tolerance on the same system (measured: true residuals 1.30e-6 .. 1.31e-6, x within 3e-7) end
+    2.7e-4 or 5.4e-4 apart depending on the rounding of their sums -- not a property of any solver."""
+    f = np.zeros(3 * len(v))
+    scale = 0.25 if n >= 50 else 1.0
+    f[1::3] = (-10000.0 if n > 0 else -200.0) * scale
+    f[0::3] = (300.0 if n > 0 else 20.0) * scale * np.sin(np.arange(len(v)))
+    return f
+
+
 def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_ms="2000"):
     try:
         os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world), 256 // world)   # each rank on its own share of the CUs
@@ -466,9 +478,7 @@ def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_
         fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
         v, t, fixed, splits = _mesh(n, world)
         g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), cg_eps=1e-6 if n > 0 else 1e-8)
-        f = np.zeros(g.r)
-        f[1::3] = -10000.0 if n > 0 else -200.0
-        f[0::3] = (300.0 if n > 0 else 20.0) * np.sin(np.arange(len(v)))
+        f = _sp_force(n, v)
         its, paths = [], []
         for _ in range(steps):
             g.set_external_forces(f)
@@ -525,9 +535,7 @@ def test_sharded_persistent_solver_on_disjoint_cus_matches_the_unsharded_handle(
             break      # (the cut run for the slab cubes only)
     v, t, fixed, _ = _mesh(n, world)
     g = FemIntegrator(v, t, fixed, cg_eps=1e-6 if n > 0 else 1e-8)   # (the ill-conditioned Delaunay systems: two solvers agree to the tolerance they stop at)
-    f = np.zeros(g.r)
-    f[1::3] = -10000.0 if n > 0 else -200.0
-    f[0::3] = (300.0 if n > 0 else 20.0) * np.sin(np.arange(len(v)))
+    f = _sp_force(n, v)
     its = []
     for _ in range(steps):
         g.set_external_forces(f)
@@ -573,9 +581,7 @@ def test_sharded_persistent_solver_that_times_out_falls_back_on_every_rank(gpu):
                 p.kill()
     v, t, fixed, _ = _mesh(n, world)
     g = FemIntegrator(v, t, fixed)
-    f = np.zeros(g.r)
-    f[1::3] = -10000.0
-    f[0::3] = 300.0 * np.sin(np.arange(len(v)))
+    f = _sp_force(n, v)
     its = []
     for _ in range(steps):
         g.set_external_forces(f)

@@ -54,7 +54,7 @@ for st in range(steps):
     info, keff, rhs, dv = o.step(want=True)
     b = rhs[free]
     iv = 1.0 / A.diagonal()
-    t0 = time.time(); i1, x1 = cg(A, b, iv); t1 = time.time(); i2, x2 = pipecg(A, b, iv); t2 = time.time(); i3, x3 = pipecg(A, b, iv, full=False); i4, x4 = pipecg(A, b, iv, refresh=10**9); print('partial-refresh', i3, 'no-refresh', i4)
+    t0 = time.time(); i1, x1 = cg(A, b, iv); t1 = time.time(); i2, x2 = pipecg(A, b, iv); t2 = time.time(); i3, x3 = pipecg(A, b, iv, full=False); i4, x4 = pipecg(A, b, iv, refresh=10**9); print('partial-refresh', i3, 'true res %.3e' % (np.linalg.norm(b - A @ x3) / np.linalg.norm(b)), '| no-refresh', i4, 'true res %.3e' % (np.linalg.norm(b - A @ x4) / np.linalg.norm(b)))
     print("n=%d step %d oracle iters %d | cg %d (%.1fs) | pipecg %d (%.1fs) | rel diff x %.3e | true res cg %.3e pipe %.3e" % (
         n, st, abs(info), i1, t1 - t0, i2, t2 - t1, np.abs(x1 - x2).max() / np.abs(x1).max(),
         np.linalg.norm(b - A @ x1) / np.linalg.norm(b), np.linalg.norm(b - A @ x2) / np.linalg.norm(b)))
