@@ -965,6 +965,40 @@ void print_pipe_timing(fb_fem_s* h) {
       }
     fprintf(stderr, "[fembrain] pipelined PCG %-22s per iteration: avg %.2f us  min %.2f  max %.2f (over %d waves)\n", names[k], av / std::max(cnt, 1), mn, mx, cnt);
   }
+  if (getenv("FEMBRAIN_PERSIST_TIMING") && atoi(getenv("FEMBRAIN_PERSIST_TIMING")) >= 2) {
+    // where the slow products are: by wavefront index, by XCD (workgroup & 7), and the slowest workgroups
+    for (int k = 1; k <= 2; k++) {
+      fprintf(stderr, "[fembrain] %s by wavefront:", names[k]);
+      for (int w = 0; w < h->persist_waves; w++) {
+        double av = 0; int cnt = 0;
+        for (int b = 0; b < h->persist_blocks; b++) { const long long* t = &tm[((size_t)b * kPipeMaxWaves + w) * 6]; if (t[5] > 0) { av += (double)t[k] / (double)t[5] * 0.01; cnt++; } }
+        fprintf(stderr, " %.2f", av / std::max(cnt, 1));
+      }
+      fprintf(stderr, "\n[fembrain] %s by XCD (avg / max over its workgroups' slowest wavefront):", names[k]);
+      for (int x = 0; x < 8; x++) {
+        double av = 0, mx = 0; int cnt = 0;
+        for (int b = x; b < h->persist_blocks; b += 8) {
+          double wmx = 0;
+          for (int w = 0; w < h->persist_waves; w++) { const long long* t = &tm[((size_t)b * kPipeMaxWaves + w) * 6]; if (t[5] > 0) wmx = std::max(wmx, (double)t[k] / (double)t[5] * 0.01); }
+          av += wmx; mx = std::max(mx, wmx); cnt++;
+        }
+        fprintf(stderr, " %.2f/%.2f", av / std::max(cnt, 1), mx);
+      }
+      fprintf(stderr, "\n");
+    }
+    std::vector<std::pair<double, int>> slow;
+    for (int b = 0; b < h->persist_blocks; b++) {
+      double wmx = 0;
+      for (int w = 0; w < h->persist_waves; w++) { const long long* t = &tm[((size_t)b * kPipeMaxWaves + w) * 6]; if (t[5] > 0) wmx = std::max(wmx, (double)t[2] / (double)t[5] * 0.01); }
+      slow.push_back({wmx, b});
+    }
+    std::sort(slow.begin(), slow.end());
+    fprintf(stderr, "[fembrain] slowest product of a workgroup: median %.2f us, fastest", slow[slow.size() / 2].first);
+    for (int k = 0; k < 6 && k < (int)slow.size(); k++) fprintf(stderr, " wg%d %.2f", slow[k].second, slow[k].first);
+    fprintf(stderr, "; slowest");
+    for (int k = 0; k < 12 && k < (int)slow.size(); k++) fprintf(stderr, " wg%d %.2f", slow[slow.size() - 1 - k].second, slow[slow.size() - 1 - k].first);
+    fprintf(stderr, "\n");
+  }
 }
 
 int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state, bool allow_persist = true);

@@ -464,7 +464,7 @@ def _sp_force(n, v):
     return f
 
 
-def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_ms="2000"):
+def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_ms="2000", newmark=False):
     try:
         os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world), 256 // world)   # each rank on its own share of the CUs
         os.environ["FEMBRAIN_SHARDED_PERSIST"] = "1"
@@ -477,7 +477,8 @@ def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_
         comm = C.c_void_p()
         fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
         v, t, fixed, splits = _mesh(n, world)
-        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), cg_eps=1e-6 if n > 0 else 1e-8)
+        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), cg_eps=1e-6 if n > 0 else 1e-8,
+                          integrator=fl.FB_INTEGRATOR_NEWMARK if newmark else fl.FB_INTEGRATOR_VOLUME_CONSERVING)
         f = _sp_force(n, v)
         its, paths = [], []
         for _ in range(steps):
@@ -591,5 +592,44 @@ def test_sharded_persistent_solver_that_times_out_falls_back_on_every_rank(gpu):
     for rank, rits, qq, path, paths, info, lo, hi in res:
         assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its)), (rits, its)
         assert path["fallbacks"] == 1 and paths == [fl.FB_PCG_PATH_FALLBACK, fl.FB_PCG_PATH_TWO_LAUNCH], (rank, path, paths)
+        qg[lo:hi] = qq
+    assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
+
+
+def test_sharded_persistent_solver_under_the_newmark_integrator_keeps_the_warm_start(gpu):
+    """ImplicitNewmarkSparse does not clear its solution buffer between solves (implicitNewmarkSparse.cpp:317-320): every solve after
+    the first starts from the previous x, which in the persistent kernels is a launch that begins with r = b - A x (the halo rows of x
+    cross the ranks like any other published vector).  Three Newmark steps on two ranks against the unsharded handle."""
+    import multiprocessing as mp
+    from fembrain_amd.fem import FemIntegrator
+    from fembrain_amd import lib as fl
+    world, n, steps = 2, 40, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_persist_worker, args=(r, world, "/fembrain_test_%d_spnm" % os.getpid(), n, steps, q, None, "2000", True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=300))
+            assert res[-1][2] is not None, res[-1]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    v, t, fixed, _ = _mesh(n, world)
+    g = FemIntegrator(v, t, fixed, integrator=fl.FB_INTEGRATOR_NEWMARK)
+    f = _sp_force(n, v)
+    its = []
+    for _ in range(steps):
+        g.set_external_forces(f)
+        its.append(g.do_timestep())
+    qs = g.get_q_state()[0]
+    qg = np.zeros_like(qs)
+    for rank, rits, qq, path, paths, info, lo, hi in res:
+        assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its)), (rits, its)
+        assert path["kernel"] == "k_pcg_pipe_shard<8,8>" and path["fallbacks"] == 0 and all(p == fl.FB_PCG_PATH_PERSISTENT for p in paths), (rank, path, paths)
         qg[lo:hi] = qq
     assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
