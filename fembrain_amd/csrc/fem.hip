@@ -313,7 +313,9 @@ int setup_persist(fb_fem_s* h) {
   const int w = nb >= 8 ? ceil_div(ceil_div(P.n_slices, 8), nb / 8) : 0;
   {
     const char* t = getenv("FEMBRAIN_PERSIST_TIMEOUT_MS");  // how long a wait inside a persistent launch may last before the launch gives up
-    const double ms = t ? atof(t) : 50.0;                   // default 50 ms: a whole 1M-tet solve is ~25 ms, one wait is microseconds
+    // default 50 ms: a whole 1M-tet solve is ~25 ms, one wait is microseconds.  A sharded handle also waits for the OTHER RANKS' launches
+    // to begin, and those are separated by host jitter (first launch: code object load): 2 s there
+    const double ms = t ? atof(t) : (P.n_ranks > 1 ? 2000.0 : 50.0);
     h->persist_timeout_ticks = std::max(1LL, (long long)(ms * 1e5));  // 100 MHz
   }
   const bool explicit_p = h->prm.pcg_variant == FB_PCG_PERSISTENT;
