@@ -50,6 +50,9 @@ struct fb_fem_s {
   DevBuf<uint32_t> inc, inc_slot;
   bool asm_tets = false;             // the assembly kernel in use
   int asm_lds = 0, asm_grid = 0, asm_max_width = 0;
+  bool asm_staged = false;           // k_assemble_tets_st (records staged in LDS, mass entries precomputed) instead of k_assemble_tets
+  int asm_lds_st = 0, asm_grid_st = 0;
+  bool mass_valid = false;           // h->mblk holds the mass entries of the current rest data (k_mass_blocks)
   std::vector<double> x0_stage;  // host staging of the rest positions in local numbering (kept: a re-sync does not fault fresh pages)
   DevBuf<int> d_bptr, d_bcol, d_blk_slot;  // device-built plan only: pattern and slot table, fetched when an inspection entry point asks
   bool device_plan = false, host_pattern = true;
@@ -58,6 +61,7 @@ struct fb_fem_s {
   DevBuf<char> vals;  // MT[n_slots][9][64]
   DevBuf<char> dlo;   // MT[n_slices][9][64]: low part of every row's diagonal block
   DevBuf<double> mblk;
+  DevBuf<float> volf;                // rest volumes as the fp32 records hold them (k_tet_rest -> k_mass_blocks)
   DevBuf<double> invblk;  // FB_PCG_BLOCK_JACOBI: inverse 3x3 diagonal block per row
   // vectors (3*n_local each)
   DevBuf<double> q, qvel, fext, fint, rhs, x, r, d, Ad, invdiag, tmp, sendbuf;
@@ -440,6 +444,7 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
     }
   }
   FB_TRY(h->rest.alloc((size_t)16 * P.n_tets));
+  FB_TRY(h->volf.alloc((size_t)std::max(1, P.n_tets)));
   FB_TRY(h->fe.alloc((size_t)12 * P.n_tets));
   FB_TRY(h->rec.alloc((size_t)16 * P.n_tets * mt_size(h)));
   if (h->prm.exact_tangent && !h->prm.linear) FB_TRY(h->kcorr.alloc((size_t)144 * P.n_tets * mt_size(h)));
@@ -483,9 +488,24 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
         const void* kern = kerns[h->f64 ? 1 : 0][tangent ? 1 : 0][nm];
         FB_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, h->asm_lds));
       }
+      // fp32 records and the plain tangent: the staged form (one record fetch per row and element, mass entries precomputed);
+      // FEMBRAIN_ASM_KERNEL=tets1 keeps the unstaged element-major kernel (same bits)
+      h->asm_lds_st = (mw * 9 + kAsmExtra) * 64 * (int)sizeof(double) + kAsmStageDoubles * (int)sizeof(double);
+      h->asm_staged = !h->f64 && !tangent && h->asm_lds_st <= lds_cu && h->asm_lds_st <= (int)prop.sharedMemPerBlock && !(e && !strcmp(e, "tets1"));
+      if (h->asm_staged) {
+        int per_cu_st = std::max(1, lds_cu / h->asm_lds_st);
+        if (const char* pc = getenv("FEMBRAIN_ASM_PER_CU")) per_cu_st = std::max(1, std::min(per_cu_st, atoi(pc)));
+        h->asm_grid_st = 8 * std::max(1, std::min(chunk, (cus / 8) * per_cu_st));
+        FB_HIP(hipFuncSetAttribute((const void*)k_assemble_tets_st<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->asm_lds_st));
+        FB_HIP(hipFuncSetAttribute((const void*)k_assemble_tets_st<true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->asm_lds_st));
+        FB_HIP(hipFuncSetAttribute((const void*)k_mass_blocks<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (kBlock / 64) * mw * 64 * (int)sizeof(double)));
+        if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] staged element-major assembly: %d workgroups, %d B of LDS each (%d per CU)\n", h->asm_grid_st, h->asm_lds_st, per_cu_st);
+      }
     } else {
+      h->asm_staged = false;
       h->inc_off.release(); h->inc.release(); h->inc_slot.release();
     }
+    h->mass_valid = false;
   }
   if (h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI) {
     if (P.n_ranks > 1) return fail(FB_EINVAL, "FB_PCG_BLOCK_JACOBI is for unsharded handles");
@@ -542,8 +562,9 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
 }
 
 int launch_rest(fb_fem_s* h, int* first_flat = nullptr) {
+  h->mass_valid = false;  // (the rest volumes may change)
   const int nt = h->plan.n_tets;
-  hipLaunchKernelGGL(k_tet_rest, dim3(ceil_div(nt, kBlock)), dim3(kBlock), 0, h->stream, nt, h->tets.p, h->x0.p, h->rest.p, first_flat);
+  hipLaunchKernelGGL(k_tet_rest, dim3(ceil_div(nt, kBlock)), dim3(kBlock), 0, h->stream, nt, h->tets.p, h->x0.p, h->rest.p, first_flat, h->volf.p);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -590,7 +611,35 @@ int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const doub
   o.dofmask = h->dofmask.p; o.nodemask = h->nodemask.p; o.qvel = qvel; o.fext = fext; o.qacc = qacc; o.vals = (MT*)h->vals.p; o.dlo = (MT*)h->dlo.p; o.mblk_out = mblk_out;
   o.fint_out = fint_out; o.rhs = rhs; o.invdiag = invdiag;
   o.invblk = invdiag && h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI ? h->invblk.p : nullptr;
-  if (h->asm_tets && !mblk_out) {  // (the per-block mass read-back, fb_fem_mass, goes through the slot-major kernel)
+  o.mblk_in = nullptr;
+  if (h->asm_tets && h->asm_staged && std::is_same<MT, float>::value && !h->kcorr.p && !mblk_out) {
+    if (!h->mass_valid) {  // once per rebuild of the rest data
+      hipLaunchKernelGGL(k_mass_blocks<float>, dim3(ceil_div(h->plan.n_slices, kBlock / 64)), dim3(kBlock), (size_t)(kBlock / 64) * h->asm_max_width * 64 * sizeof(double),
+                         h->stream, sell_view(h), h->inc_off.p, h->inc.p, h->inc_slot.p, h->volf.p, ap.rho20, h->asm_max_width, h->mblk.p);
+      FB_HIP(hipGetLastError());
+      h->mass_valid = true;
+    }
+    o.mblk_in = h->mblk.p;
+    unsigned long long* prof = nullptr;
+    if (getenv("FEMBRAIN_ASM_PROFILE")) {
+      FB_HIP(hipMalloc((void**)&prof, 16 * sizeof(unsigned long long)));
+      FB_HIP(hipMemset(prof, 0, 16 * sizeof(unsigned long long)));
+    }
+    const AsmOut<float>& of = reinterpret_cast<const AsmOut<float>&>(o);
+    if (qacc) hipLaunchKernelGGL(k_assemble_tets_st<true>, dim3(h->asm_grid_st), dim3(kBlock), (size_t)h->asm_lds_st, h->stream, sell_view(h), h->inc_off.p, h->inc.p, h->inc_slot.p,
+                                 (const float*)h->rec.p, h->fe.p, of, ap, h->asm_max_width, prof);
+    else hipLaunchKernelGGL(k_assemble_tets_st<false>, dim3(h->asm_grid_st), dim3(kBlock), (size_t)h->asm_lds_st, h->stream, sell_view(h), h->inc_off.p, h->inc.p, h->inc_slot.p,
+                            (const float*)h->rec.p, h->fe.p, of, ap, h->asm_max_width, prof);
+    if (prof) {
+      FB_HIP(hipStreamSynchronize(h->stream));
+      unsigned long long t[16];
+      FB_HIP(hipMemcpy(t, prof, sizeof t, hipMemcpyDeviceToHost));
+      for (int w = 0; w < 4; w++)
+        fprintf(stderr, "[fembrain] k_assemble_tets_st wavefront %d: elements %.1f us, wait %.1f, algebra %.1f, wait %.1f (mean per workgroup)\n", w,
+                t[4 * w] * 0.01 / h->asm_grid_st, t[4 * w + 1] * 0.01 / h->asm_grid_st, t[4 * w + 2] * 0.01 / h->asm_grid_st, t[4 * w + 3] * 0.01 / h->asm_grid_st);
+      (void)hipFree(prof);
+    }
+  } else if (h->asm_tets && !mblk_out) {  // (the per-block mass read-back, fb_fem_mass, goes through the slot-major kernel)
     constexpr int G = 2;  // list rows whose records are in flight per lane (measured at 1M tets, fp32: 224 us with 4, 209 with 2, 211 with 1)
     unsigned long long* prof = nullptr;
     if (getenv("FEMBRAIN_ASM_PROFILE")) {
@@ -2003,7 +2052,7 @@ int fb_fem_floor_collision(fb_fem_t h, double floor_y, double restitution, int* 
 }
 
 int fb_fem_plan_on_device(fb_fem_t h) { return h && h->device_plan ? 1 : 0; }
-int fb_fem_assembly_kernel(fb_fem_t h) { return h && h->asm_tets ? 1 : 0; }
+int fb_fem_assembly_kernel(fb_fem_t h) { return h && h->asm_tets ? (h->asm_staged ? 2 : 1) : 0; }
 
 long long fb_fem_device_plan_get(fb_fem_t h, const char* name, int* out, long long capacity) {
   CHECK_HANDLE(h);

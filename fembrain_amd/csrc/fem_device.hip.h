@@ -21,8 +21,10 @@ __device__ inline void inv3x3(const double* A, double* I) {
 
 // first_flat (may be null): receives the lowest index of an element whose rest volume is zero or not finite -- the check
 // build() otherwise makes on the host, same expression
+// volf (may be null): the rest volume as the fp32 records hold it, one float per element (k_mass_blocks gathers it: 4 MB at 1M tets
+// instead of one line of every 128-byte rest record)
 __global__ __launch_bounds__(kBlock) void k_tet_rest(int nt, const int4* __restrict__ tets, const double* __restrict__ x0,
-                                                     double* __restrict__ rest, int* __restrict__ first_flat) {
+                                                     double* __restrict__ rest, int* __restrict__ first_flat, float* __restrict__ volf) {
   const int e = blockIdx.x * kBlock + threadIdx.x;
   if (e >= nt) return;
   const int4 t = tets[e];
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(kBlock) void k_tet_rest(int nt, const int4* __restr
   const double w[3] = {p[2][0] - p[3][0], p[2][1] - p[3][1], p[2][2] - p[3][2]};
   const double cx = v[1] * w[2] - v[2] * w[1], cy = v[2] * w[0] - v[0] * w[2], cz = v[0] * w[1] - v[1] * w[0];
   r[12] = (1.0 / 6) * fabs(u[0] * cx + u[1] * cy + u[2] * cz);
+  if (volf) volf[e] = (float)r[12];
   r[13] = r[14] = r[15] = 0.0;
 }
 
@@ -333,6 +336,7 @@ struct AsmOut {
   MT* vals;
   MT* dlo;
   double* mblk_out;
+  const double* mblk_in;  // k_assemble_tets_st: the per-block mass entries (k_mass_blocks), [slot][64]
   double* fint_out;
   double* rhs;
   double* invdiag;
@@ -735,7 +739,8 @@ __device__ __forceinline__ void tets_mass_and_forces(double* acc, double* facc, 
 }
 
 // the a7 algebra of row A of the finished blocks, in slot order (RowAlgebra split by block row); leaves its accumulators zero
-template <typename MT, int A, bool NEWMARK>
+// (STRIDE: doubles per slot of the accumulators; MASS_G: the mass entries come from o.mblk_in instead of the tenth value row)
+template <typename MT, int A, bool NEWMARK, int STRIDE = 640, bool MASS_G = false>
 __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, const double* nacc, const SellView& sv,
                                              const AsmOut<MT>& o, const AsmParams& ap, int s, int lane, int so, int width) {
   const int row = s * 64 + lane;
@@ -754,6 +759,7 @@ __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, co
   constexpr int kC = 4;
   int col[kC], col1[kC];
   RowGather gq[kC];
+  double mq[kC];  // (MASS_G) the mass entries of the chunk, loaded with its gathers
   // (columns past the width are read from the last slot: no run-time branch around a load; the chunks that lie wholly inside the
   // width go through a copy of the body without any test)
   auto load_cols = [&](int k0, int* cc) {
@@ -765,10 +771,10 @@ __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, co
     double Kc[kC][3], mc[kC];
 #pragma unroll
     for (int c = 0; c < kC; c++) {
-      double* p = acc + min(k0 + c, width - 1) * 640 + lane;
+      double* p = acc + min(k0 + c, width - 1) * STRIDE + lane;
 #pragma unroll
       for (int b = 0; b < 3; b++) Kc[c][b] = p[(3 * A + b) * 64];
-      mc[c] = p[9 * 64];
+      mc[c] = MASS_G ? mq[c] : p[(MASS_G ? 0 : 9) * 64];
     }
 #pragma unroll
     for (int c = 0; c < kC; c++) {
@@ -776,7 +782,7 @@ __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, co
       const int k = k0 + c, slot = so + k;
       const bool diag = rvalid && (col[c] == row) && !seen_diag;
       seen_diag = seen_diag || diag;
-      double* p = acc + k * 640 + lane;
+      double* p = acc + k * STRIDE + lane;
       const double* K = Kc[c];
 #pragma unroll
       for (int b = 0; b < 3; b++) p[(3 * A + b) * 64] = 0.0;
@@ -801,23 +807,30 @@ __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, co
   if (width > 0) {
     load_cols(0, col);
 #pragma unroll
-    for (int c = 0; c < kC; c++) gq[c].template load_straight<MT, NEWMARK>(o, ap, col[c]);
+    for (int c = 0; c < kC; c++) {
+      gq[c].template load_straight<MT, NEWMARK>(o, ap, col[c]);
+      mq[c] = MASS_G ? o.mblk_in[((size_t)so + min(c, width - 1)) * 64 + lane] : 0.0;
+    }
     load_cols(kC, col1);
     for (int k0 = 0; k0 < width; k0 += kC) {
       RowGather gq1[kC];
+      double mq1[kC];
       int col2[kC];
 #pragma unroll
-      for (int c = 0; c < kC; c++) gq1[c].template load_straight<MT, NEWMARK>(o, ap, col1[c]);
+      for (int c = 0; c < kC; c++) {
+        gq1[c].template load_straight<MT, NEWMARK>(o, ap, col1[c]);
+        mq1[c] = MASS_G ? o.mblk_in[((size_t)so + min(k0 + kC + c, width - 1)) * 64 + lane] : 0.0;
+      }
       load_cols(k0 + 2 * kC, col2);
       if (k0 + kC <= width) chunk(k0, std::true_type());
       else chunk(k0, std::false_type());
 #pragma unroll
-      for (int c = 0; c < kC; c++) { col[c] = col1[c]; col1[c] = col2[c]; gq[c] = gq1[c]; }
+      for (int c = 0; c < kC; c++) { col[c] = col1[c]; col1[c] = col2[c]; gq[c] = gq1[c]; mq[c] = mq1[c]; }
     }
   }
   // the diagonal block needs the sums of the other rows: off[3a+b] and off[3b+a]
   double* xoff = acc;        // value rows of slot 0
-  double* dblk = acc + 640;  // value rows of slot 1
+  double* dblk = acc + STRIDE;  // value rows of slot 1
 #pragma unroll
   for (int b = 0; b < 3; b++) xoff[(3 * A + b) * 64 + lane] = off[b];
   __syncthreads();
@@ -905,6 +918,276 @@ __global__ __launch_bounds__(kBlock) void k_assemble_tets(SellView sv, const int
     lap(2);
     __syncthreads();
     lap(3);
+  }
+  if (prof && lane == 0)
+    for (int k = 0; k < 4; k++) atomicAdd(&prof[4 * wq + k], tp[k]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Element-major assembly with ONE fetch of every record per (row, element): k_assemble_tets_st (fp32 records, warp = 1).
+// In k_assemble_tets the three value wavefronts each gather the lane's 64-byte record (four 16-byte requests to 64 different cache
+// lines per wavefront and list row) and the fourth gathers V and the element forces: the texture-address unit of the CU works
+// through ~1,000 line requests per list row and workgroup and is what the element phase waits for, not the arithmetic.  Here the
+// FOURTH wavefront alone fetches the records (two list rows ahead, in registers) and stages them in LDS -- one list row per buffer,
+// two buffers, 4 KB each, [quarter][lane] so that a 16-byte read per lane is conflict-free -- and the value wavefronts read them
+// from there; one barrier per list row hands a buffer over.  The LDS for the staging comes from the MASS entries: they do not
+// depend on the state, so k_mass_blocks forms them once per rebuild of the rest data (same sums, same order), the accumulators
+// shrink from 10 to 9 value rows per slot (69 KB at 15 slots: still two workgroups per CU, with the 8 KB of staging), and the
+// algebra reads them from memory with its gathers.  Same contributions, same operations, same order: bit for bit k_assemble_tets.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kAsmStride = 576;                  // doubles per slot: 9 value rows of 64
+constexpr int kAsmStageDoubles = 2 * 4 * 64 * 2;  // two buffers of 4 quarters x 64 lanes x 16 bytes
+
+template <typename MT>
+__global__ __launch_bounds__(kBlock) void k_mass_blocks(SellView sv, const int* __restrict__ inc_off, const uint32_t* __restrict__ inc,
+                                                        const uint32_t* __restrict__ inc_slot, const float* __restrict__ volf, double rho20, int max_width,
+                                                        double* __restrict__ mblk) {
+  extern __shared__ double macc[];  // [wavefront][slot][64]
+  const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = blockIdx.x * (kBlock / 64) + wq;
+  if (s >= sv.n_slices) return;  // (no barrier in this kernel: a wavefront works on its own slice)
+  double* acc = macc + (size_t)wq * max_width * 64;
+  const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
+  const int io = inc_off[s], height = inc_off[s + 1] - io;
+  for (int k = 0; k < width; k++) acc[k * 64 + lane] = 0.0;
+  // groups of four list rows: their words, then their volumes, are in flight together (one row at a time is two dependent memory
+  // round trips per row: 75 us for the kernel at 1M tets); the sums themselves run in list order
+  constexpr int G = 4;
+  uint32_t wn[G], sn[G];
+#pragma unroll
+  for (int u = 0; u < G; u++) {
+    const size_t at = ((size_t)io + min(u, max(height - 1, 0))) * 64 + lane;
+    wn[u] = height > 0 ? inc[at] : kNoInc; sn[u] = height > 0 ? inc_slot[at] : 0u;
+  }
+  for (int t0 = 0; t0 < height; t0 += G) {
+    uint32_t w[G], sl[G];
+    double V[G];
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      w[u] = t0 + u < height ? wn[u] : kNoInc; sl[u] = sn[u];
+      V[u] = (double)volf[(w[u] == kNoInc ? 0u : w[u]) >> 2];  // what k_tet_warp stores in the record
+    }
+#pragma unroll
+    for (int u = 0; u < G; u++) {  // the next group's words
+      const size_t at = ((size_t)io + min(t0 + G + u, height - 1)) * 64 + lane;
+      wn[u] = inc[at]; sn[u] = inc_slot[at];
+    }
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      if (w[u] == kNoInc) continue;
+      const int i = (int)(w[u] & 3);
+      double* p[4];
+      double m[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        p[j] = acc + ((sl[u] >> (8 * j)) & 255u) * 64 + lane;
+        m[j] = p[j][0];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) p[j][0] = m[j] + rho20 * V[u] * (i == j ? 2.0 : 1.0);
+    }
+  }
+  for (int k = 0; k < width; k++) mblk[((size_t)so + k) * 64 + lane] = acc[k * 64 + lane];
+}
+
+// The hand-over of a staging buffer: LDS operations done, then the workgroup barrier -- WITHOUT the wait for the vector memory loads
+// in flight that __syncthreads() implies (its fence covers global memory: every list row would pay a full memory round trip for
+// the records and words just requested; measured 390 vs 127 us for the element phase).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// value wavefront A of k_assemble_tets_st: tets_accumulate with the records read from the staging buffers
+template <int A>
+__device__ __forceinline__ void tets_accumulate_st(double* acc, const float4* stage, int lane, int io, int height, const uint32_t* __restrict__ inc,
+                                                   const uint32_t* __restrict__ inc_slot, const AsmParams& ap) {
+#pragma unroll
+  for (int b = 0; b < 3; b++) acc[(3 * A + b) * 64 + lane] = acc[kAsmStride + (3 * A + b) * 64 + lane] = 0.0;  // (what tets_algebra passed through them)
+  if (height <= 0) return;
+  auto load_words = [&](int t, uint32_t& w, uint32_t& sl) {  // (rows past the end: read from the last row, turned into padding)
+    const size_t at = ((size_t)io + min(t, height - 1)) * 64 + lane;
+    const uint32_t ww = inc[at], ss = inc_slot[at];
+    w = t < height ? ww : kNoInc;
+    sl = t < height ? ss : 0u;
+  };
+  // words of rows t, t+1, t+2 and (wn, sn) of row t+3, requested one trip earlier: a copy never touches a load of the same trip
+  uint32_t w0, s0, w1, s1, w2, s2, wn, sn;
+  load_words(0, w0, s0);
+  load_words(1, w1, s1);
+  load_words(2, wn, sn);
+  for (int t = 0; t < height; t++) {
+    w2 = wn; s2 = sn;
+    load_words(t + 3, wn, sn);
+    lds_barrier();  // buffer t & 1 holds the records of list row t
+    if (w0 != kNoInc) {
+      const float4* st = stage + (t & 1) * 256 + lane;
+      const float4 q0 = st[0], q1 = st[64], q2 = st[128], q3 = st[192];  // (named: an array indexed by the corner went to scratch memory)
+      const int i = (int)(w0 & 3);
+      const float4 ri = i == 0 ? q0 : (i == 1 ? q1 : (i == 2 ? q2 : q3));
+      const double ci[3] = {(double)ri.x, (double)ri.y, (double)ri.z};
+      const double V = (double)ri.w;
+      const double vl = V * ap.lambda, vm = V * ap.mu;
+      double* p[4];
+      double K[4][3];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        p[j] = acc + ((s0 >> (8 * j)) & 255u) * kAsmStride + (3 * A) * 64 + lane;
+#pragma unroll
+        for (int b = 0; b < 3; b++) K[j][b] = p[j][b * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float4 rj = j == 0 ? q0 : (j == 1 ? q1 : (j == 2 ? q2 : q3));  // (j is a constant after unrolling)
+        const double cj[3] = {(double)rj.x, (double)rj.y, (double)rj.z};
+        const double dij = ci[0] * cj[0] + ci[1] * cj[1] + ci[2] * cj[2];
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          K[j][b] += vl * (ci[A] * cj[b]) + vm * (cj[A] * ci[b]);  // the three stages of add_contribution on value (A, b)
+          if (b == A) K[j][b] += vm * dij;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) p[j][b * 64] = K[j][b];
+    }
+    w0 = w1; s0 = s1; w1 = w2; s1 = s2;
+  }
+}
+
+// wavefront 3 of k_assemble_tets_st: fetches the records (two list rows ahead) and stages them, sums the element forces, counts the
+// list.  Its pipeline registers (every one has a NAME: sets kept in arrays and handed to helpers ended up in scratch memory):
+// three sets for the records (rows t+1, t+2, t+3) and the forces (rows t, t+1, t+2), rotated by unrolling the loop three times -- a
+// register COPY of a value still in flight would wait for it, and the pipeline would be one list row deep whatever is requested
+// ahead -- and the words of rows t .. t+4 in a chain whose newest link was requested one trip earlier.
+// (plain local variables of the kernel and macros over them: a struct handed to helper functions ended up in scratch memory as well)
+#define FB_ST_DECLARE                                                                  \
+  float4 S0a, S0b, S0c, S0d, S1a, S1b, S1c, S1d, S2a, S2b, S2c, S2d;                   \
+  double F0x, F0y, F0z, F1x, F1y, F1z, F2x = 0.0, F2y = 0.0, F2z = 0.0;                \
+  uint32_t wa = kNoInc, wb = kNoInc, wc = kNoInc, wd = kNoInc, we = kNoInc;            \
+  int st_io = 0, st_height = 0;
+#define FB_ST_WORD(T) ((T) < st_height ? inc[((size_t)st_io + min((T), st_height - 1)) * 64 + lane] : (inc[((size_t)st_io + st_height - 1) * 64 + lane], kNoInc))
+#define FB_ST_RECORD(W, S)                                                                               \
+  {                                                                                                      \
+    const float4* rp = (const float4*)(rec + 16 * (size_t)(((W) == kNoInc ? 0u : (W)) >> 2));            \
+    S##a = rp[0]; S##b = rp[1]; S##c = rp[2]; S##d = rp[3]; /* (padding reads element 0's record) */     \
+  }
+#define FB_ST_FORCE(W, F)                                              \
+  {                                                                    \
+    const uint32_t c_ = (W) == kNoInc ? 0u : (W);                      \
+    const double* fp = fe + 12 * (size_t)(c_ >> 2) + 3 * (c_ & 3);     \
+    F##x = fp[0]; F##y = fp[1]; F##z = fp[2];                          \
+  }
+#define FB_ST_PUT(BUF, S)                                                \
+  {                                                                      \
+    float4* st = stage + (BUF) * 256 + lane;                             \
+    st[0] = S##a; st[64] = S##b; st[128] = S##c; st[192] = S##d;         \
+  }
+// the first requests of slice SL: its words, the records of its list rows 0..2, the forces of rows 0..1; row 0 goes to buffer 0.
+// Issued while the value wavefronts are in the algebra of the PREVIOUS slice (they do not touch the staging buffers there), so that
+// the two dependent round trips (words, then records) are not paid at the start of every slice.
+#define FB_ST_BEGIN(SL)                                                                                         \
+  {                                                                                                             \
+    st_io = inc_off[SL]; st_height = inc_off[(SL) + 1] - st_io;                                                 \
+    if (st_height > 0) {                                                                                        \
+      wa = FB_ST_WORD(0); wb = FB_ST_WORD(1); wc = FB_ST_WORD(2); wd = FB_ST_WORD(3); we = FB_ST_WORD(4);       \
+      FB_ST_RECORD(wa, S0) FB_ST_RECORD(wb, S1) FB_ST_RECORD(wc, S2) FB_ST_FORCE(wa, F0) FB_ST_FORCE(wb, F1)    \
+      FB_ST_PUT(0, S0)                                                                                          \
+    }                                                                                                           \
+  }
+// trip t: Sw holds row t+1 (staged now), Sl is free and gets row t+3; Fc holds row t (summed now), Fl gets row t+2
+#define FB_ST_TRIP(T, Sw, Sl, Fc, Fl)                                                                                      \
+  {                                                                                                                         \
+    const uint32_t wf = FB_ST_WORD((T) + 5);                                                                                \
+    FB_ST_RECORD(wd, Sl)                                                                                                    \
+    FB_ST_FORCE(wc, Fl)                                                                                                     \
+    lds_barrier(); /* the value wavefronts have read buffer (T + 1) & 1 (list row T - 1); buffer T & 1 is theirs now */     \
+    FB_ST_PUT(((T) + 1) & 1, Sw)                                                                                            \
+    if (wa != kNoInc) {                                                                                                     \
+      nd++;                                                                                                                 \
+      fi[0] += Fc##x; fi[1] += Fc##y; fi[2] += Fc##z;                                                                       \
+    }                                                                                                                       \
+    wa = wb; wb = wc; wc = wd; wd = we; we = wf;                                                                            \
+  }
+// the element phase of the staging wavefront for the slice FB_ST_BEGIN prepared
+#define FB_ST_RUN                                                                              \
+  if (st_height <= 0) { /* a slice of nodes no element references */                           \
+    facc[lane] = facc[64 + lane] = facc[128 + lane] = 0.0;                                     \
+    nacc[lane] = 0.0;                                                                          \
+  } else {                                                                                     \
+    double fi[3] = {0, 0, 0};                                                                  \
+    int nd = 0, t = 0;                                                                         \
+    for (; t + 2 < st_height; t += 3) {                                                        \
+      FB_ST_TRIP(t, S1, S0, F0, F2)                                                            \
+      FB_ST_TRIP(t + 1, S2, S1, F1, F0)                                                        \
+      FB_ST_TRIP(t + 2, S0, S2, F2, F1)                                                        \
+    }                                                                                          \
+    if (t < st_height) FB_ST_TRIP(t, S1, S0, F0, F2)                                           \
+    if (t + 1 < st_height) FB_ST_TRIP(t + 1, S2, S1, F1, F0)                                   \
+    facc[lane] = fi[0]; facc[64 + lane] = fi[1]; facc[128 + lane] = fi[2];                     \
+    nacc[lane] = (double)nd;                                                                   \
+  }
+
+template <bool NEWMARK>
+__global__ __launch_bounds__(kBlock) void k_assemble_tets_st(SellView sv, const int* __restrict__ inc_off, const uint32_t* __restrict__ inc,
+                                                             const uint32_t* __restrict__ inc_slot, const float* __restrict__ rec, const double* __restrict__ fe,
+                                                             AsmOut<float> o, AsmParams ap, int max_width, unsigned long long* __restrict__ prof) {
+  extern __shared__ double acc[];  // [slot][9][64], then kAsmExtra rows of 64, then the staging buffers
+  unsigned long long tp[4] = {0, 0, 0, 0}, tc = prof ? wall_clock64() : 0;  // development aid: 100 MHz ticks per phase
+  auto lap = [&](int k) { if (prof) { const unsigned long long n = wall_clock64(); tp[k] += n - tc; tc = n; } };
+  double* facc = acc + (size_t)max_width * kAsmStride;
+  double* nacc = facc + 3 * 64;
+  float4* stage = (float4*)(nacc + 64);
+  const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int v = threadIdx.x; v < (max_width * 9 + kAsmExtra) * 64; v += kBlock) acc[v] = 0.0;
+  __syncthreads();
+  // XCD-aware walk, one workgroup per slice: workgroup b serves slab b % 8
+  const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
+  const int chunk = (sv.n_slices + 7) >> 3;
+  const int hi = min((xcd + 1) * chunk, sv.n_slices);
+  const int s_first = xcd * chunk + (blockIdx.x >> 3);
+  if (wq == 3) {  // the staging wavefront: same barriers as the others, its own work in between
+    FB_ST_DECLARE
+    if (s_first < hi) FB_ST_BEGIN(s_first)
+    for (int s = s_first; s < hi; s += per) {
+      FB_ST_RUN
+      lap(0);
+      __syncthreads();
+      lap(1);
+      if (s + per < hi) FB_ST_BEGIN(s + per)  // (the others are in the algebra)
+      __syncthreads();  // (the one inside tets_algebra)
+      if (o.invblk) __syncthreads();
+      lap(2);
+      __syncthreads();
+      lap(3);
+    }
+  } else {
+    for (int s = s_first; s < hi; s += per) {
+      const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
+      const int io = inc_off[s], height = inc_off[s + 1] - io;
+      if (wq == 0) tets_accumulate_st<0>(acc, stage, lane, io, height, inc, inc_slot, ap);
+      else if (wq == 1) tets_accumulate_st<1>(acc, stage, lane, io, height, inc, inc_slot, ap);
+      else tets_accumulate_st<2>(acc, stage, lane, io, height, inc, inc_slot, ap);
+      lap(0);
+      __syncthreads();
+      lap(1);
+      if (wq == 0) tets_algebra<float, 0, NEWMARK, kAsmStride, true>(acc, facc, nacc, sv, o, ap, s, lane, so, width);
+      else if (wq == 1) tets_algebra<float, 1, NEWMARK, kAsmStride, true>(acc, facc, nacc, sv, o, ap, s, lane, so, width);
+      else tets_algebra<float, 2, NEWMARK, kAsmStride, true>(acc, facc, nacc, sv, o, ap, s, lane, so, width);
+      if (o.invblk) {  // FB_PCG_BLOCK_JACOBI: the inverse of the row's 3x3 diagonal block (symmetric; identity on clamped DOFs)
+        __syncthreads();
+        const int row = s * 64 + lane;
+        if (wq == 0 && row < sv.n_owned) {
+          double dfull[9], inv[9];
+#pragma unroll
+          for (int k = 0; k < 9; k++) dfull[k] = acc[kAsmStride + k * 64 + lane];
+          inv3x3(dfull, inv);
+#pragma unroll
+          for (int k = 0; k < 9; k++) o.invblk[9 * (size_t)row + k] = inv[k];
+        }
+      }
+      lap(2);
+      __syncthreads();
+      lap(3);
+    }
   }
   if (prof && lane == 0)
     for (int k = 0; k < 4; k++) atomicAdd(&prof[4 * wq + k], tp[k]);

@@ -241,8 +241,10 @@ int fb_fem_pcg(fb_fem_t h, const double* rhs, double* x, double eps, int max_ite
 long long fb_fem_device_plan_get(fb_fem_t h, const char* name, int* out, long long capacity);
 /* 1 if the plan of this handle was built on the device (unsharded handles, unless FEMBRAIN_PLAN_DEVICE=0), else 0 */
 int fb_fem_plan_on_device(fb_fem_t h);
-/* the assembly kernel of this handle: 1 = element-major with LDS accumulators (k_assemble_tets; slices of at most 32 slots),
- * 0 = slot-major (k_assemble_rows; also FEMBRAIN_ASM_KERNEL=rows).  Both write the same bits. */
+/* the assembly kernel of this handle: 2 = element-major, records staged in LDS by one wavefront and mass entries precomputed
+ * (k_assemble_tets_st: FB_MATRIX_F32, warp = 1), 1 = element-major with every value wavefront fetching its records
+ * (k_assemble_tets; slices of at most 31 slots; also FEMBRAIN_ASM_KERNEL=tets1), 0 = slot-major (k_assemble_rows; also
+ * FEMBRAIN_ASM_KERNEL=rows).  All three write the same bits. */
 int fb_fem_assembly_kernel(fb_fem_t h);
 int fb_fem_time_spmv(fb_fem_t h, int reps, double* seconds_per_spmv);
 int fb_fem_time_assembly(fb_fem_t h, int reps, double* seconds_per_assembly);

@@ -929,7 +929,7 @@ def _jittered_lattice():
 
 @pytest.mark.parametrize("case", ["cube14", "cube14_f64", "cube14_tangent", "cube14_newmark", "cube14_block_jacobi", "beam3", "jitter", "jitter_f64", "hub"])
 def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, monkeypatch, case):
-    """k_assemble_tets (lane walks its row's elements, blocks accumulated in LDS) against k_assemble_rows (FEMBRAIN_ASM_KERNEL=rows):
+    """k_assemble_tets_st / k_assemble_tets (lane walks its row's elements, blocks accumulated in LDS) against k_assemble_rows (FEMBRAIN_ASM_KERNEL=rows):
     raw f and K at a seeded displacement, Keff and rhs of a step, the states after two steps -- all bit for bit, for both matrix
     widths, the exact tangent, the Newmark step and the block-Jacobi inverse blocks; a mesh with a row wider than 32 slots keeps the
     slot-major kernel by itself"""
@@ -955,24 +955,30 @@ def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, mo
             kw["pcg_variant"] = fl.FB_PCG_BLOCK_JACOBI
     u = np.random.default_rng(5).normal(size=3 * len(v)) * 0.003
     out = []
-    for kern in ("tets", "rows"):
+    # "tets": the default -- k_assemble_tets_st (2: records staged in LDS by one wavefront, mass entries from k_mass_blocks) for fp32
+    # records and the plain tangent, else k_assemble_tets (1); "tets1": k_assemble_tets; "rows": k_assemble_rows (0)
+    staged = not case.endswith("f64") and not case.endswith("tangent")
+    for kern in ("tets", "tets1", "rows"):
         monkeypatch.setenv("FEMBRAIN_ASM_KERNEL", kern)
         g = FemIntegrator(v, t, fixed, **kw)
-        assert fl.lib().fb_fem_assembly_kernel(g.h) == (1 if kern == "tets" and case != "hub" else 0)
+        assert fl.lib().fb_fem_assembly_kernel(g.h) == (0 if kern == "rows" or case == "hub" else (2 if kern == "tets" and staged else 1))
         f, K = g.assemble(u)
         its = []
-        for _ in range(2):
+        for k in range(2):
+            if k:
+                g.rebuild_elements()     # (the rest data again: the mass entries are formed again with it)
             g.set_uniform_force(1, -2000.0 if case not in ("hub", "jitter", "jitter_f64") else -1.0)
             its.append(g.do_timestep())
         Keff, rhs = g.system()
         out.append((f, K, its, Keff, rhs, g.get_q_state()[0], g.mass()))
         g.close()
-    a, b = out
-    assert a[2] == b[2]
-    for x, y in zip(a, b):
-        if not isinstance(x, list):
-            assert np.array_equal(x, y)
-    assert np.abs(a[1]).max() > 0 and np.abs(a[5]).max() > 0
+    b = out[2]
+    for a in out[:2]:
+        assert a[2] == b[2]
+        for x, y in zip(a, b):
+            if not isinstance(x, list):
+                assert np.array_equal(x, y)
+    assert np.abs(b[1]).max() > 0 and np.abs(b[5]).max() > 0
 
 
 def test_16bit_column_differences_give_identical_iterates(gpu, monkeypatch):

@@ -12,7 +12,7 @@ from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, tr
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 56
 v, t = truth_cube(n, n, n, 0.1)
 fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
-for kern in ("tets", "rows"):
+for kern in ("tets", "tets1", "rows"):
     os.environ["FEMBRAIN_ASM_KERNEL"] = kern
     g = FemIntegrator(v, t, fixed)
     g.set_uniform_force(1, -10000.0)
