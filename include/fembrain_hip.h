@@ -36,12 +36,13 @@ extern "C" {
  * slice, every lane keeps its row's x, r, w, z, s, p, 1/diag in registers.  The iteration is the PIPELINED form of the same
  * Jacobi-PCG (Ghysels & Vanroose 2014: the same iterates in exact arithmetic): its two sums are posted before the product and
  * read after it, so the only wait of an iteration is for the neighbouring workgroups' part of the product's input vector.
- * Every 30th iteration takes the exact residual as CGSolver.cpp:159-166 does.  Unsharded handles, FB_MATRIX_F32 storage, up to
+ * Every 30th iteration takes the exact residual as CGSolver.cpp:159-166 does.  Unsharded handles (sharded ones: opt-in, see
+ * fb_fem_set_sharded_persist), FB_MATRIX_F32 storage, up to
  * 24 slices per CU (~2.2M tets on 256 CUs: one row per lane up to 12 slices per CU, two rows per lane with x, p, z in LDS from 13
  * on); chosen BY DEFAULT from 2 slices per CU on (FB_PCG_MERGED + FEMBRAIN_PCG_PERSIST unset).  Iteration
  * counts equal those of the literal solver within max(3, 2 %) (tests), iterates agree to rounding and are bitwise
  * reproducible however the solve is cut into launches.  If a wait inside the launch times out (FEMBRAIN_PERSIST_TIMEOUT_MS,
- * default 50; the workgroups must all be resident) the solve is repeated with the two-launch iteration and the handle stays
+ * default 50, 2000 on a sharded handle; the workgroups must all be resident) the solve is repeated with the two-launch iteration and the handle stays
  * with it: fb_step_info.pcg_path = FB_PCG_PATH_FALLBACK, fb_step_info.persist_fallbacks counts (FEMBRAIN_PERSIST_STRICT=1:
  * FB_EDEVICE instead).  ACCURACY LIMIT: the pipelined recurrences stall at a relative residual of ~1e-11 on these systems (the
  * literal ones go on below 1e-12), so solves with a tolerance below 1e-8 (the reference uses 1e-6) run the two-launch solver, and
