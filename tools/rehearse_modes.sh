@@ -11,3 +11,9 @@ FEMBRAIN_BENCH_CU_SPLIT=1 FEMBRAIN_PERSIST_TIMEOUT_MS=2000 timeout -k 10 400 pyt
 grep -E '^\{' gpurun_out/bench_n2_sp.log | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']; print('trials', c['exchange_trials_ms_per_step'], '|', c['exchange'][:40], '|', c['pcg'], '| ms/step %.1f us/iter %.1f' % (d['ms_per_step'], d['us_per_cg_iteration']), c['sharded_self_check'], c['exchange_note'], 'cube111', d.get('cube111'))"
+# the big leg's own decision about the sharded persistent solver, rehearsed with a mesh whose halves it takes (the 1M-tet cube again)
+FEMBRAIN_BENCH_CU_SPLIT=1 FEMBRAIN_BENCH_BIG_WORKLOAD=cube56 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 \
+  bench.py --gpus 2 --steps 2 --warmup 1 --no-field > gpurun_out/bench_n2_sp_big.log 2>&1; echo "N=2 CU split, big leg = cube56 rc=$?"
+grep -E '^\{' gpurun_out/bench_n2_sp_big.log | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); b=d['cube111']; print('big leg:', b.get('pcg_kernel'), 'us/iter %.1f' % b.get('us_per_cg_iteration', 0), b.get('sharded_persistent_trial'), b.get('error'))"
