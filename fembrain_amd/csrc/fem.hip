@@ -13,6 +13,7 @@
 #include "pcg_pipe.hip.h"
 #include "pcg_pipe2.hip.h"
 #include "pcg_pipe_shard.hip.h"
+#include "pcg_pipe2_shard.hip.h"
 #include "plan_device.h"
 
 using namespace fb;
@@ -168,7 +169,6 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   hipStream_t s = h->stream;
   const int R = P.n_ranks;
   if (R > kP2PMaxRanks) return FB_OK;
-  h->pipe_rows = 1;
   FB_TRY(h->sh_halo_off.upload(P.halo_off, s));
   // per slice: its owned column range and the ranks whose halo rows it gathers
   DevBuf<int4> range;
@@ -215,11 +215,12 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
       wg_range[b] = make_int2(start[p2], start[p2 + 1] - start[p2]);
       Q = std::max(Q, start[p2 + 1] - start[p2]);
     }
-    if (Q < kPipeMaxWaves) break;
+    if (Q <= 2 * (kPipeMaxWaves - 1)) break;
   }
   w = Q;
-  h->pipe_wmax = w < 8 ? 8 : 12;   // (w + 1 wavefronts: the spare one serves the proxies and the sums)
-  h->pipe_klt = std::min(h->pipe_wmax == 8 ? 8 : 6, kPipeLdsSlots / std::max(w, 1));
+  h->pipe_rows = w < kPipeMaxWaves ? 1 : 2;   // 12..22 slices per CU: two rows per lane (k_pcg_pipe2_shard)
+  h->pipe_wmax = h->pipe_rows == 2 ? 12 : (w < 8 ? 8 : 12);   // (one wavefront more than slices / slice pairs: the spare one serves the proxies and the sums)
+  h->pipe_klt = h->pipe_rows == 2 ? 0 : std::min(h->pipe_wmax == 8 ? 8 : 6, kPipeLdsSlots / std::max(w, 1));
   h->persist_blocks = nb; h->persist_waves = w;
   h->sh_relief = relief;
   h->pipe_flag_extra = kP2PMaxRanks * kShardProxies;
@@ -331,7 +332,7 @@ int setup_persist(fb_fem_s* h) {
   // asked for explicitly (parameter or FEMBRAIN_PCG_PERSIST=1), or by default where it was measured faster than the
   // two-launch iteration: fp32 storage, up to 12 slices per CU
   // (a sharded handle: opt-in, one row per lane, and a spare wavefront per workgroup for the proxies and the sums)
-  const bool eligible = !h->f64 && nb >= 8 && w >= 1 && (P.n_ranks == 1 ? w <= 2 * kPipeMaxWaves : (shard_opt && w < kPipeMaxWaves));
+  const bool eligible = !h->f64 && nb >= 8 && w >= 1 && (P.n_ranks == 1 ? w <= 2 * kPipeMaxWaves : (shard_opt && w <= 2 * (kPipeMaxWaves - 1)));  // (sharded: the spare wavefront leaves 11 for slices, two rows per lane from 12 slices on)
   // (us per iteration, two-launch vs persistent, on MI355X: 7.83 / 7.87 at 125 slices = 1 per CU, 8.74 / 8.74 at 308 and 8.98 / 8.64 at 466
   // = 2 per CU, 10.9 / 8.8 at 614 = 3 per CU, 14.0 / 10.3 at 792, 15.8 / 8.9 at 1,000, 27.4 / 15.75 at 2,744 = 1M tets)
   static const int min_w = getenv("FEMBRAIN_PERSIST_MIN_WAVES") ? atoi(getenv("FEMBRAIN_PERSIST_MIN_WAVES")) : 2;
@@ -959,14 +960,17 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     sa.box = h->sbox; sa.peer_box = h->sbox_peers.p; sa.peer_seg = h->sh_peer_seg.p; sa.halo_cap = h->sbox_halo_cap;
     sa.halo_off = h->sh_halo_off.p; sa.row_send_off = h->sh_row_send_off.p; sa.row_send_rank = h->sh_row_send_rank.p; sa.row_send_pos = h->sh_row_send_pos.p;
     sa.wg_send_mask = h->sh_wg_send_mask.p; sa.n_senders = h->sh_n_senders.p; sa.proxy_wg = h->sh_proxy_wg.p; sa.n_proxy = h->sh_n_proxy; sa.wg_duty = h->sh_wg_duty.p; sa.wg_range = h->sh_wg_range.p;
-    static bool attr_s[2] = {false, false};
-    const int wi = h->pipe_wmax == 8 ? 0 : 1;
-    const void* kern = wi == 0 ? (const void*)k_pcg_pipe_shard<8, 8> : (const void*)k_pcg_pipe_shard<12, 6>;
+    static bool attr_s[3] = {false, false, false};
+    const int wi = h->pipe_rows == 2 ? 2 : (h->pipe_wmax == 8 ? 0 : 1);
+    const void* kern = wi == 0 ? (const void*)k_pcg_pipe_shard<8, 8> : (wi == 1 ? (const void*)k_pcg_pipe_shard<12, 6> : (const void*)k_pcg_pipe2_shard);
     if (!attr_s[wi]) {
       FB_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_s[wi] = true;
     }
-    if (wi == 0)
+    if (wi == 2)
+      hipLaunchKernelGGL(k_pcg_pipe2_shard, grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b,
+                         h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);
+    else if (wi == 0)
       hipLaunchKernelGGL((k_pcg_pipe_shard<8, 8>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b,
                          h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);
     else
@@ -1737,7 +1741,7 @@ int fb_fem_sharded_persist(fb_fem_t h) {
 
 int fb_fem_set_sharded_persist(fb_fem_t h, int on) {
   CHECK_HANDLE(h);
-  if (!h->shard_persist || !h->sbox) return fail(FB_EINVAL, "the sharded persistent solver is not attached to this handle (FEMBRAIN_SHARDED_PERSIST=1 at creation, <= %d slices per CU)", kPipeMaxWaves - 1);
+  if (!h->shard_persist || !h->sbox) return fail(FB_EINVAL, "the sharded persistent solver is not attached to this handle (FEMBRAIN_SHARDED_PERSIST=1 at creation, <= %d slices per CU)", 2 * (kPipeMaxWaves - 1));
   if (on && h->persist_broken) return fail(FB_EDEVICE, "the sharded persistent solver of this handle timed out before; it stays with the two-launch iteration");
   FB_HIP(hipStreamSynchronize(h->stream));
   h->persist = on != 0;
@@ -2279,7 +2283,8 @@ int fb_fem_persist_info(fb_fem_t h, int* waves_per_cu, int* workgroups, int* lds
 int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches, int* persist_fallbacks, int* max_producers) {
   if (!h) return fail(FB_EINVAL, "null FEM handle");
   if (name && name_len > 0) {
-    if (h->persist && h->shard_persist) snprintf(name, name_len, "k_pcg_pipe_shard<%d,%d>", h->pipe_wmax, h->pipe_wmax == 8 ? 8 : 6);
+    if (h->persist && h->shard_persist && h->pipe_rows == 2) snprintf(name, name_len, "k_pcg_pipe2_shard");
+    else if (h->persist && h->shard_persist) snprintf(name, name_len, "k_pcg_pipe_shard<%d,%d>", h->pipe_wmax, h->pipe_wmax == 8 ? 8 : 6);
     else if (h->persist && h->pipe_rows == 2) snprintf(name, name_len, "k_pcg_pipe2<%s>", h->c16 ? "c16" : "c32");
     else if (h->persist) snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_wmax == 8 ? 8 : 6);
     else name[0] = 0;

@@ -1,0 +1,415 @@
+// k_pcg_pipe2_shard: the two-rows-per-lane persistent solver of pcg_pipe2.hip.h (13..22 slices per CU) on a SHARDED handle -- what
+// k_pcg_pipe_shard (pcg_pipe_shard.hip.h) is to k_pcg_pipe: halo rows stored into the neighbour rank's box by their owners, copied
+// into the planes by proxy wavefronts, rank sums posted to every rank, all inside the one launch per solve.  Same box, counters,
+// proxies, relief and hazards; 32-bit local column ids; the spare wavefront leaves 11 for slices (22 per CU: 2M tets per rank -- the
+// 8M-tet mesh of the north star on four GPUs).  Opt-in with FEMBRAIN_SHARDED_PERSIST=1, UNMEASURED ON MULTI-GPU HARDWARE.
+#pragma once
+#include "pcg_pipe2.hip.h"
+#include "pcg_pipe_shard.hip.h"
+
+namespace fb {
+
+__global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2_shard(SellView sv, const float* __restrict__ vals, const float* __restrict__ dlo,
+                                                                  const double* __restrict__ invdiag, const double* __restrict__ bvec,
+                                                                  double* __restrict__ xg, double* __restrict__ rg, double* __restrict__ wg,
+                                                                  double* __restrict__ zg, double* __restrict__ sg, double* __restrict__ pg,
+                                                                  CGState* __restrict__ st, PipeArgs pa, ShardArgs sa) {
+  extern __shared__ double lds[];
+  double* wsum = lds;                          // [2][16] wave sums
+  double* gath = lds + 32;                     // [2][kPipeMaxBlocks] all workgroups' sums
+  double* bc = gath + 2 * kPipeMaxBlocks;      // [0..1] totals, [2] a wait failed (sweep), [3] a wait failed (product), [4] a sum poller gave up
+  const int n_waves = blockDim.x >> 6, nb = gridDim.x;
+  if (pa.start == 0 && st->done) return;  // grid-uniform: written by an earlier launch
+  if (threadIdx.x == 0) bc[4] = 0.0;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool service = wv == n_waves - 1;  // the spare wavefront: sums, proxy copies (it owns no slice)
+  const int first = sa.wg_range[blockIdx.x].x, count = sa.wg_range[blockIdx.x].y;
+  bool live[2], rvalid[2];
+  int row[2], so[2], width[2], send_beg[2], send_end[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    live[h] = 2 * wv + h < count && !service;  // wave-uniform
+    const int sl = first + 2 * wv + h;
+    row[h] = sl * 64 + lane;
+    rvalid[h] = live[h] && row[h] < sv.n_owned;
+    int o = 0, wd = 0;
+    if (live[h]) { o = sv.slice_off[sl]; wd = sv.slice_off[sl + 1] - o; }
+    so[h] = __builtin_amdgcn_readfirstlane(o); width[h] = __builtin_amdgcn_readfirstlane(wd);
+    send_beg[h] = send_end[h] = 0;  // this row's entries of the send lists
+    if (rvalid[h]) { send_beg[h] = sa.row_send_off[row[h]]; send_end[h] = sa.row_send_off[row[h] + 1]; }
+  }
+  // LDS of this wavefront and row set h: nine doubles (x, p, z: k = 0..8) then six floats (low diagonal part) per lane, each as a
+  // plane of 64 lanes -- 24 words per row, conflict-free
+  char* lbase = (char*)(lds + kPipeSyncDoubles) + (size_t)wv * 2 * kPipe2LdsWordsPerRow * 64 * 4;
+  auto lds_d = [&](int h, int k) -> double* { return (double*)(lbase + (size_t)h * kPipe2LdsWordsPerRow * 256 + (size_t)k * 512) + lane; };
+  auto lds_f = [&](int h, int k) -> float* { return (float*)(lbase + (size_t)h * kPipe2LdsWordsPerRow * 256 + 9 * 512 + (size_t)k * 256) + lane; };
+  double iv[2][3] = {{0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    float m6[6] = {0, 0, 0, 0, 0, 0};
+    if (rvalid[h]) {
+      const float* l = dlo + (size_t)(first + 2 * wv + h) * 9 * 64 + lane;
+      m6[0] = l[0 * 64]; m6[1] = l[1 * 64]; m6[2] = l[2 * 64]; m6[3] = l[4 * 64]; m6[4] = l[5 * 64]; m6[5] = l[8 * 64];
+#pragma unroll
+      for (int a = 0; a < 3; a++) iv[h][a] = invdiag[3 * (size_t)row[h] + a];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) *lds_f(h, k) = m6[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) *lds_d(h, k) = 0.0;
+  }
+  const int n_prod = pa.prod_count[blockIdx.x];
+  int my_prod = -1;
+  if (wv == 0 && n_prod >= 0 && lane < n_prod) my_prod = pa.producers[(size_t)blockIdx.x * kPipeMaxProducers + lane];
+
+  const unsigned int send_mask = sa.wg_send_mask[blockIdx.x];  // workgroup-uniform
+  const ShardBoxLayout BL = shard_box_layout(sa.halo_cap);
+  unsigned int pub = pa.seqs[0], sums = pa.seqs[1];
+  const long long t_limit = pa.timeout_ticks;
+  bool failed = false;
+
+  // (publish / product: as in k_pcg_pipe, for the two rows of the lane; write-through stores always -- the plain-store form is
+  // for the latency-bound small systems)
+  auto publish = [&](const double vin[2][3]) {
+    pub++;
+    double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if (rvalid[h]) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * pa.n_pad + (size_t)row[h], vin[h][a]);
+        for (int e = send_beg[h]; e < send_end[h]; e++) {  // rows a neighbour rank gathers: straight into its box
+          const int q = sa.row_send_rank[e];
+          double* hq = (double*)(sa.peer_box[q] + BL.halo) + (size_t)(pub & 1u) * 3 * (size_t)sa.halo_cap + (size_t)(sa.peer_seg[q] + sa.row_send_pos[e]);
+#pragma unroll
+          for (int a = 0; a < 3; a++) st_sys_f64(hq + (size_t)a * (size_t)sa.halo_cap, vin[h][a]);
+        }
+      }
+  };
+  auto product = [&](const double vin[2][3], double y[2][3], bool post_sums) {
+    double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (post_sums) sums++;
+    if (wv != 0 && live[0] && pa.prefetch_slots > 0 && width[0] > 0) {
+      int so_k = so[0];
+      asm volatile("" : "+s"(so_k));
+      pipe_prefetch_values(min(pa.prefetch_slots, width[0]), ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float), vals);
+    }
+    if (service) {
+      // every store of this workgroup's rows has drained: tell the ranks that gather them
+      if (lane < sa.n_ranks && (send_mask >> lane & 1u))
+        __hip_atomic_fetch_add((unsigned int*)(sa.peer_box[lane] + BL.counters) + sa.rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // proxy: the halo segments this workgroup copies from the box into the planes
+      const long long t0 = wall_clock64();
+      for (int d = 0; d < kShardDuties && !failed; d++) {
+        const int duty = sa.wg_duty[blockIdx.x * kShardDuties + d];  // workgroup-uniform
+        if (duty < 0) break;
+        const int s = duty / sa.n_proxy, k = duty - s * sa.n_proxy;
+        const unsigned int want = (unsigned int)sa.n_senders[s] * pub;
+        const unsigned int* cnt = (const unsigned int*)(sa.box + BL.counters) + s;
+        while ((int)(ld_sys_u32(cnt) - want) < 0) {
+          if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (failed) break;
+        int lo, hi;
+        shard_proxy_rows(sa.halo_off[s], sa.halo_off[s + 1], sa.n_proxy, k, &lo, &hi);
+        const double* in = (const double*)(sa.box + BL.halo) + (size_t)(pub & 1u) * 3 * (size_t)sa.halo_cap;
+        double* out = pl + (size_t)sa.n_owned;
+        for (int i0 = lo + lane; i0 < hi; i0 += 4 * 64) {  // twelve loads in flight per lane
+          double t[3][4];
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) t[a][j] = i0 + 64 * j < hi ? ld_sys_f64(in + (size_t)a * (size_t)sa.halo_cap + i0 + 64 * j) : 0.0;
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) if (i0 + 64 * j < hi) st_sc1_f64(out + a * pa.n_pad + i0 + 64 * j, t[a][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) st_sc1_u32(pa.flags + nb + duty, pub);
+      }
+      failed = uniform_flag(failed);
+      if (failed && lane == 0) { st_sc1_u32(pa.error, 1u); bc[4] = 1.0; }
+    }
+    if (wv == 0) {
+      if (lane == 0) st_sc1_u32(pa.flags + blockIdx.x, pub);
+      if (post_sums && lane < 2) {
+        double t = 0.0;
+        for (int w = 0; w < n_waves; w++) t += wsum[lane * 16 + w];
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(t), tag = (unsigned long long)sums << 32;
+        unsigned long long* post = pa.post + ((size_t)(sums & 1u) * nb + blockIdx.x) * 4 + 2 * lane;
+        st_sc1_u64(post, (bits >> 32) | tag);
+        st_sc1_u64(post + 1, (bits & 0xffffffffULL) | tag);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const long long t0 = wall_clock64();
+      if (n_prod >= 0) {
+        for (;;) {
+          bool ok = true;
+          if (my_prod >= 0) ok = (int)(ld_sc1_u32(pa.flags + my_prod) - pub) >= 0;
+          if (__ballot(!ok) == 0ULL) break;
+          if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      } else {
+        const int n_flags = nb + sa.n_ranks * sa.n_proxy;
+        for (int b = lane; b - lane < n_flags && !failed; b += 64) {  // all workgroups and all proxies
+          for (;;) {
+            bool ok = true;
+            if (b < nb || (b < n_flags && sa.proxy_wg[b - nb] >= 0)) ok = (int)(ld_sc1_u32(pa.flags + b) - pub) >= 0;
+            if (__ballot(!ok) == 0ULL) break;
+            if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+      }
+      if (failed && lane == 0) st_sc1_u32(pa.error, 1u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) bc[3] = (failed || ld_sc1_u32(pa.error) != 0u) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (uniform_flag(bc[3] != 0.0 || bc[4] != 0.0)) { failed = true; return; }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      double y0 = 0, y1 = 0, y2 = 0;
+      if (rvalid[h]) {  // the low part of the diagonal block times the own entry
+        const double l00 = (double)*lds_f(h, 0), l01 = (double)*lds_f(h, 1), l02 = (double)*lds_f(h, 2), l11 = (double)*lds_f(h, 3), l12 = (double)*lds_f(h, 4),
+                     l22 = (double)*lds_f(h, 5);
+        y0 = l00 * vin[h][0] + l01 * vin[h][1] + l02 * vin[h][2];
+        y1 = l01 * vin[h][0] + l11 * vin[h][1] + l12 * vin[h][2];
+        y2 = l02 * vin[h][0] + l12 * vin[h][1] + l22 * vin[h][2];
+      }
+      if (live[h] && width[h] > 0) {
+        int so_k = so[h];
+        asm volatile("" : "+s"(so_k));
+        pipe_stream_slots<false>(width[h], ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
+                               ((unsigned int)so_k * 64u + (unsigned int)lane) * (unsigned int)sizeof(int), vals,
+                               (const void*)sv.colidx, pl, pl + pa.n_pad, pl + 2 * pa.n_pad, row[h], y0, y1, y2);
+      }
+      y[h][0] = y0; y[h][1] = y1; y[h][2] = y2;
+    }
+  };
+
+  double rr[2][3] = {{0, 0, 0}, {0, 0, 0}}, wr[2][3] = {{0, 0, 0}, {0, 0, 0}}, sr[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  double rho0 = 0.0, eps2 = pa.eps2, gamma_old = 1.0, alpha_old = 1.0;
+  int iter = 0, max_iter = pa.max_iter;
+  enum { PH_WARM_X = 0, PH_INIT_W = 1, PH_ITER = 2, PH_REFRESH_X = 3, PH_REFRESH_W = 4 };
+  int phase = PH_ITER;
+  bool fresh = pa.start != 0;
+  if (pa.start == 0) {
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if (rvalid[h]) {
+        const size_t dof = 3 * (size_t)row[h];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          rr[h][a] = rg[dof + a]; wr[h][a] = wg[dof + a]; sr[h][a] = sg[dof + a];
+          *lds_d(h, a) = xg[dof + a]; *lds_d(h, 3 + a) = pg[dof + a]; *lds_d(h, 6 + a) = zg[dof + a];
+        }
+      }
+    rho0 = uniform_f64(st->rho0); eps2 = uniform_f64(st->eps2); iter = st->iter; max_iter = st->max_iter;
+    gamma_old = uniform_f64(pa.pstate[0]); alpha_old = uniform_f64(pa.pstate[1]);
+  } else if (pa.start == 2) {
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if (rvalid[h]) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) *lds_d(h, a) = xg[3 * (size_t)row[h] + a];
+      }
+    phase = PH_WARM_X;
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if (rvalid[h]) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) rr[h][a] = bvec[3 * (size_t)row[h] + a];
+      }
+    phase = PH_INIT_W;
+  }
+
+  bool done = false, published = false;
+  double gamma = 0.0;
+  int it_done = 0;
+  while (!failed) {
+    if (phase == PH_ITER && it_done >= pa.n_iters) break;
+    double vin[2][3];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+        vin[h][a] = (phase == PH_WARM_X || phase == PH_REFRESH_X) ? *lds_d(h, a) : (phase == PH_ITER ? iv[h][a] * wr[h][a] : iv[h][a] * rr[h][a]);
+    if (!published) publish(vin);
+    published = false;
+    if (phase == PH_ITER) {
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const double u[3] = {iv[h][0] * rr[h][0], iv[h][1] * rr[h][1], iv[h][2] * rr[h][2]};
+        // (row set 1 is added to row set 0's sum: a fixed order)
+        a0 += rr[h][0] * u[0] + rr[h][1] * u[1] + rr[h][2] * u[2];
+        a1 += wr[h][0] * u[0] + wr[h][1] * u[1] + wr[h][2] * u[2];
+      }
+      a0 = wave_sum(a0); a1 = wave_sum(a1);
+      int wvo = wv;
+      asm volatile("" : "+v"(wvo));
+      if (lane == 0) { wsum[wvo] = a0; wsum[16 + wvo] = a1; }
+    }
+    double y[2][3];
+    product(vin, y, phase == PH_ITER);
+    if (failed) break;
+    if (phase == PH_WARM_X || phase == PH_REFRESH_X) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        unsigned int d3 = 3u * (unsigned int)(rvalid[h] ? row[h] : 0);
+        asm volatile("" : "+v"(d3));
+#pragma unroll
+        for (int a = 0; a < 3; a++) rr[h][a] = rvalid[h] ? bvec[d3 + a] - y[h][a] : 0.0;
+      }
+      phase = phase == PH_WARM_X ? PH_INIT_W : PH_REFRESH_W;
+      continue;
+    }
+    if (phase != PH_ITER) {
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) wr[h][a] = y[h][a];
+      phase = PH_ITER;
+      continue;
+    }
+    // ---- the sums: this rank's (workgroup 0 collects them and posts them to every rank), then all ranks' ----
+    if (service) {
+      const long long t0 = wall_clock64();
+      if (blockIdx.x == 0) {
+        const unsigned long long* post = pa.post + (size_t)(sums & 1u) * nb * 4;
+        double t0s = 0, t1s = 0;
+        for (int b = lane; b - lane < nb && !failed; b += 64) {
+          const bool mine = b < nb;
+          uint4 q4[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+          for (;;) {
+            bool ok = true;
+            if (mine) {
+              asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                           : "=&v"(q4[0]), "=&v"(q4[1]) : "v"(post + (size_t)b * 4) : "memory");
+              ok = q4[0].y == sums && q4[0].w == sums && q4[1].y == sums && q4[1].w == sums;
+            }
+            if (__ballot(!ok) == 0ULL) break;
+            if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (mine && !failed) {
+            t0s += __longlong_as_double((long long)(((unsigned long long)q4[0].x << 32) | (unsigned long long)q4[0].z));
+            t1s += __longlong_as_double((long long)(((unsigned long long)q4[1].x << 32) | (unsigned long long)q4[1].z));
+          }
+        }
+        t0s = wave_sum(t0s); t1s = wave_sum(t1s);
+        t0s = __shfl(t0s, 0, 64); t1s = __shfl(t1s, 0, 64);
+        if (lane < sa.n_ranks && !failed) {  // lane q posts this rank's two sums into rank q's box
+          unsigned long long* dst = (unsigned long long*)(sa.peer_box[lane] + BL.rsum) + ((size_t)(sums & 1u) * kP2PMaxRanks + sa.rank) * 4;
+          const unsigned long long b0 = (unsigned long long)__double_as_longlong(t0s), b1 = (unsigned long long)__double_as_longlong(t1s), tag = (unsigned long long)sums << 32;
+          st_sys_u64(dst, (b0 >> 32) | tag); st_sys_u64(dst + 1, (b0 & 0xffffffffULL) | tag);
+          st_sys_u64(dst + 2, (b1 >> 32) | tag); st_sys_u64(dst + 3, (b1 & 0xffffffffULL) | tag);
+        }
+      }
+      // all ranks' sums from my box, added in rank order: the same bits on every rank and workgroup
+      double g0 = 0, g1 = 0;
+      {
+        const unsigned long long* rs = (const unsigned long long*)(sa.box + BL.rsum) + ((size_t)(sums & 1u) * kP2PMaxRanks + (lane < sa.n_ranks ? lane : 0)) * 4;
+        unsigned long long g[4] = {0, 0, 0, 0};
+        while (!failed) {
+          bool ok = true;
+          if (lane < sa.n_ranks) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { g[k] = ld_sys_u64(rs + k); ok = ok && (unsigned int)(g[k] >> 32) == sums; }
+          }
+          if (__ballot(!ok) == 0ULL) break;
+          if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        const double v0 = __longlong_as_double((long long)(((g[0] & 0xffffffffULL) << 32) | (g[1] & 0xffffffffULL)));
+        const double v1 = __longlong_as_double((long long)(((g[2] & 0xffffffffULL) << 32) | (g[3] & 0xffffffffULL)));
+        for (int q = 0; q < sa.n_ranks; q++) { g0 += __shfl(v0, q, 64); g1 += __shfl(v1, q, 64); }
+      }
+      failed = uniform_flag(failed);
+      if (failed && lane == 0) st_sc1_u32(pa.error, 1u);
+      if (lane == 0) { bc[0] = g0; bc[1] = g1; bc[2] = (failed || ld_sc1_u32(pa.error) != 0u) ? 1.0 : 0.0; }
+    }
+    __syncthreads();
+    if (uniform_flag(bc[2] != 0.0)) { failed = true; break; }
+    gamma = uniform_f64(bc[0]);
+    const double delta = uniform_f64(bc[1]);
+    if (fresh) rho0 = gamma;
+    if (!(gamma > eps2 * rho0) || iter >= max_iter) { done = true; break; }
+    double alpha, beta;
+    if (fresh) { beta = 0.0; alpha = gamma / delta; }
+    else { beta = gamma / gamma_old; alpha = gamma / (delta - beta * gamma / alpha_old); }
+    fresh = false;
+    iter++;
+    it_done++;
+    gamma_old = gamma; alpha_old = alpha;
+    const bool refresh = iter % 30 == 0;
+    // ---- recurrences: z, p, x in LDS, the rest in registers ----
+    double zn[2][3];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        zn[h][a] = y[h][a] + beta * *lds_d(h, 6 + a);
+        *lds_d(h, 6 + a) = zn[h][a];
+        sr[h][a] = wr[h][a] + beta * sr[h][a];
+      }
+    if (!refresh) {
+      double m[2][3];
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) { wr[h][a] = wr[h][a] - alpha * zn[h][a]; m[h][a] = iv[h][a] * wr[h][a]; }
+      publish(m);
+      published = true;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const double pn = iv[h][a] * rr[h][a] + beta * *lds_d(h, 3 + a);
+        *lds_d(h, 3 + a) = pn;
+        *lds_d(h, a) = *lds_d(h, a) + alpha * pn;
+      }
+    if (refresh) {
+      phase = PH_REFRESH_X;
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) rr[h][a] = rr[h][a] - alpha * sr[h][a];
+    }
+  }
+  if (failed) return;  // nothing written back: the host re-solves from the vectors it handed over
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+    if (rvalid[h] && !(done && gamma > eps2 * rho0)) {
+      unsigned int dof = 3u * (unsigned int)row[h];
+      asm volatile("" : "+v"(dof));
+#pragma unroll
+      for (int a = 0; a < 3; a++) xg[dof + a] = *lds_d(h, a);
+      if (!done) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          rg[dof + a] = rr[h][a]; wg[dof + a] = wr[h][a]; sg[dof + a] = sr[h][a];
+          pg[dof + a] = *lds_d(h, 3 + a); zg[dof + a] = *lds_d(h, 6 + a);
+        }
+      }
+    }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->rho0 = rho0; st->eps2 = eps2; st->max_iter = max_iter;
+    st->iter = iter;
+    st->rho[iter & 1] = done ? gamma : gamma_old;
+    st->done = done ? 1 : 0;
+    pa.pstate[0] = gamma_old; pa.pstate[1] = alpha_old;
+    pa.seqs[0] = published ? pub - 1u : pub; pa.seqs[1] = sums;  // (a launch cut after a pre-publish takes the publish back: pcg_pipe_shard.hip.h)
+  }
+}
+
+}  // namespace fb

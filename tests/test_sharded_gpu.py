@@ -499,7 +499,7 @@ def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_
 
 
 @pytest.mark.parametrize("world,n,kernel", [(2, 40, "k_pcg_pipe_shard<8,8>"), (2, -30000, "k_pcg_pipe_shard<8,8>"), (4, 40, "k_pcg_pipe_shard<8,8>"),
-                                            (2, 56, "k_pcg_pipe_shard<12,6>")])
+                                            (2, 56, "k_pcg_pipe_shard<12,6>"), (2, 70, "k_pcg_pipe2_shard")])
 def test_sharded_persistent_solver_on_disjoint_cus_matches_the_unsharded_handle(gpu, world, n, kernel):
     """The sharded persistent pipelined solver (pcg_pipe_shard.hip.h; opt-in FEMBRAIN_SHARDED_PERSIST=1; UNMEASURED on multi-GPU
     hardware): one persistent launch per solve ON EVERY RANK, the halo rows written by their owners straight into the neighbour rank's
@@ -508,7 +508,8 @@ def test_sharded_persistent_solver_on_disjoint_cus_matches_the_unsharded_handle(
     their persistent grids are resident together.  Three steps against the unsharded handle: the same iteration counts to max(2, 1 %),
     the gathered displacements to 1e-6; every rank reports the sharded kernel, the persistent path and no fallback; a solve cut into
     launches of 7 iterations gives the same bits.  Cube slabs (two neighbours at most), a Delaunay mesh in random node order (every
-    rank neighbours every other, every workgroup polls all flags), four ranks, and the 12-wavefront instantiation."""
+    rank neighbours every other, every workgroup polls all flags), four ranks, the 12-wavefront instantiation, and the two-rows-per-lane
+    kernel (2M tets, 21 slices per CU on half a GPU)."""
     import multiprocessing as mp
     from fembrain_amd.fem import FemIntegrator
     from fembrain_amd import lib as fl

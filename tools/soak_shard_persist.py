@@ -72,7 +72,7 @@ if __name__ == "__main__":
         first = next((k for k in range(steps) if ra[2][k] != rb[2][k]), None)
         print("rank %d: %s, %d launches, %d fallbacks; passes %s%s" % (ra[0], ra[3]["kernel"], ra[3]["launches"], ra[3]["fallbacks"], "identical" if same else "DIFFER",
                                                                      "" if same else " from step %s" % first), flush=True)
-        ok = ok and same and ra[3]["fallbacks"] == 0 and ra[3]["kernel"].startswith("k_pcg_pipe_shard")
+        ok = ok and same and ra[3]["fallbacks"] == 0 and "shard" in ra[3]["kernel"]
     worst = max(abs(x - y) / max(y, 1) for x, y in zip(a[0][1][:10], ref[0][1][:10]))
     print("iterations: persistent %d..%d, two-launch %d..%d, largest relative difference over the first ten steps %.4f" % (min(a[0][1]), max(a[0][1]), min(ref[0][1]), max(ref[0][1]), worst))
     bad = [(k, x, y) for k, (x, y) in enumerate(zip(a[0][1][:10], ref[0][1][:10])) if abs(x - y) > max(2, 0.01 * y)]
