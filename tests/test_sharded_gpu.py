@@ -464,7 +464,7 @@ def _sp_force(n, v):
     return f
 
 
-def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_ms="2000", newmark=False):
+def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_ms="2000", newmark=False, resync=False):
     try:
         os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world), 256 // world)   # each rank on its own share of the CUs
         os.environ["FEMBRAIN_SHARDED_PERSIST"] = "1"
@@ -481,7 +481,12 @@ def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_
                           integrator=fl.FB_INTEGRATOR_NEWMARK if newmark else fl.FB_INTEGRATOR_VOLUME_CONSERVING)
         f = _sp_force(n, v)
         its, paths = [], []
-        for _ in range(steps):
+        for k in range(steps):
+            if resync and k == steps - 1:
+                # Deformable::syncForceModel after a cut, collective: the last tets of the mesh go (the slab boundaries move with them),
+                # the box, the send lists, the proxies and the relief deal are all made again
+                t = np.ascontiguousarray(t[:len(t) - len(t) // 50])
+                g.resync(v, t, fixed, node_splits=splits)
             g.set_external_forces(f)
             its.append(g.do_timestep())
             paths.append(int(g.last.pcg_path))
@@ -625,6 +630,48 @@ def test_sharded_persistent_solver_under_the_newmark_integrator_keeps_the_warm_s
     f = _sp_force(n, v)
     its = []
     for _ in range(steps):
+        g.set_external_forces(f)
+        its.append(g.do_timestep())
+    qs = g.get_q_state()[0]
+    qg = np.zeros_like(qs)
+    for rank, rits, qq, path, paths, info, lo, hi in res:
+        assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its)), (rits, its)
+        assert path["kernel"] == "k_pcg_pipe_shard<8,8>" and path["fallbacks"] == 0 and all(p == fl.FB_PCG_PATH_PERSISTENT for p in paths), (rank, path, paths)
+        qg[lo:hi] = qq
+    assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
+
+
+def test_sharded_persistent_solver_survives_a_collective_resync(gpu):
+    """fb_fem_resync_sharded on handles that run the sharded persistent solver: every rank drops 2 % of the elements between the second
+    and the third step (state reset, as Deformable::syncForceModel does) -- boxes, mappings, send lists, proxies are rebuilt -- and the
+    third step still runs in persistent launches and matches the unsharded handle put through the same re-sync."""
+    import multiprocessing as mp
+    from fembrain_amd.fem import FemIntegrator
+    from fembrain_amd import lib as fl
+    world, n, steps = 2, 40, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_persist_worker, args=(r, world, "/fembrain_test_%d_sprs" % os.getpid(), n, steps, q, None, "2000", False, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=300))
+            assert res[-1][2] is not None, res[-1]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    v, t, fixed, _ = _mesh(n, world)
+    g = FemIntegrator(v, t, fixed)
+    f = _sp_force(n, v)
+    its = []
+    for k in range(steps):
+        if k == steps - 1:
+            t = np.ascontiguousarray(t[:len(t) - len(t) // 50])
+            g.resync(v, t, fixed)
         g.set_external_forces(f)
         its.append(g.do_timestep())
     qs = g.get_q_state()[0]
