@@ -344,7 +344,7 @@ def main():
         # as one more candidate beside the exchange modes, and checked like them before anything is timed.  Not in the one-GPU
         # rehearsal unless the ranks are confined to CU shares of their own (the persistent grids of two ranks must be resident together).
         if local_comm and os.environ.get("FEMBRAIN_BENCH_CU_SPLIT") == "1":   # rehearsal: every rank on its own share of the one GPU's CUs
-            os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world), 256 // world)
+            os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world // 32 * 32), 256 // world // 32 * 32)
         if dist_mode and os.environ.get("FEMBRAIN_BENCH_NO_SHARDED_PERSIST") != "1" and (not local_comm or os.environ.get("FEMBRAIN_CU_MASK")):
             os.environ.setdefault("FEMBRAIN_SHARDED_PERSIST", "1")
 

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 
 def worker(rank, world, name, n, steps, q, persist, mode):
-    os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world), 256 // world)
+    os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world // 32 * 32), 256 // world // 32 * 32)
     os.environ["FEMBRAIN_PERSIST_TIMEOUT_MS"] = "2000"
     os.environ["FEMBRAIN_P2P"] = "1"
     if persist:
@@ -60,7 +60,7 @@ if __name__ == "__main__":
             p.join()
         r0 = res[0]
         line = "cube %d^3, %d ranks on %d CUs each: %s  iterations %s  solve %.1f us/iteration" % (
-            n, world, 256 // world, "sharded persistent" if persist else "two-launch, exchange mode %d" % mode, r0[1], max(r[2] for r in res) / sum(r0[1]) * 1e6)
+            n, world, 256 // world // 32 * 32, "sharded persistent" if persist else "two-launch, exchange mode %d" % mode, r0[1], max(r[2] for r in res) / sum(r0[1]) * 1e6)
         if persist:
             line += "  | launches: " + ", ".join("rank %d %.2f us/iteration (%d launches, kernel %s, %d fallbacks)" % (r[0], r[3][1] / max(r[3][2], 1) * 1e6, r[3][0], r[4], r[5]) for r in res)
         print(line, flush=True)

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 
 
 def worker(rank, world, name, n, steps, q, persist):
-    os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world), 256 // world)
+    os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world // 32 * 32), 256 // world // 32 * 32)
     os.environ["FEMBRAIN_P2P"] = "1"
     if persist:
         os.environ["FEMBRAIN_SHARDED_PERSIST"] = "1"
