@@ -1,3 +1,6 @@
+"""Development aid: the persistent pipelined PCG on a truth cube (argv: nodes per side) solving its first right-hand side with iteration
+caps 1, 2, 5, 29, 30, 31, 100 and without one, then one step; FEMBRAIN_PERSIST_TIMING=1 (or 2: also by wavefront, by XCD, slowest
+workgroups) prints the phase clocks of the development build of k_pcg_pipe after every solve."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 os.environ["FEMBRAIN_PERSIST_MIN_WAVES"] = "1"

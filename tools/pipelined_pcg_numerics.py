@@ -1,5 +1,9 @@
+"""Development aid (CPU, numpy): the pipelined Jacobi-PCG recurrences of k_pcg_pipe (Ghysels & Vanroose) against the literal ones on the
+oracle's systems of a truth cube -- iteration counts, true residuals, with the exact-residual refresh of every 30th iteration in its full
+and partial form and without it.   python tools/pipelined_pcg_numerics.py <nodes per side> [steps] [f32: round the matrix to fp32]"""
 import sys, time, numpy as np, scipy.sparse as sp
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from fembrain_amd.meshgen import truth_cube, cube_fixed_plane_i0, fixed_vertices_to_dofs
 from oracle.pyoracle import OrcFem
 n = int(sys.argv[1]); steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development aid (GPU box, through gpurun): the two-launch PCG iteration at 8M tets (BASELINE config 5 on one GPU) -- kernel trace and
-# the two HBM counters in their own passes; summaries by tools/summarize_8m.py
+# the two HBM counters in their own passes; summarised by hand into profiles/r03_cube111_iteration_breakdown.json (tools/summarize_profiles.py for the kernel stats)
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
