@@ -464,7 +464,7 @@ def _sp_force(n, v):
     return f
 
 
-def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_ms="2000", newmark=False, resync=False):
+def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_ms="2000", newmark=False, resync=False, planes=None):
     try:
         os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world // 32 * 32), 256 // world // 32 * 32)   # each rank on its own share of the CUs: whole XCDs (mask bits 32 k .. 32 k + 31 are one XCD; a share that cuts an XCD leaves workgroups without a CU)
         os.environ["FEMBRAIN_SHARDED_PERSIST"] = "1"
@@ -477,6 +477,8 @@ def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_
         comm = C.c_void_p()
         fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
         v, t, fixed, splits = _mesh(n, world)
+        if planes is not None:   # (uneven slabs)
+            splits = np.array([p * n * n for p in planes], np.int32)
         g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), cg_eps=1e-6 if n > 0 else 1e-8,
                           integrator=fl.FB_INTEGRATOR_NEWMARK if newmark else fl.FB_INTEGRATOR_VOLUME_CONSERVING)
         f = _sp_force(n, v)
@@ -680,4 +682,46 @@ def test_sharded_persistent_solver_survives_a_collective_resync(gpu):
         assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its)), (rits, its)
         assert path["kernel"] == "k_pcg_pipe_shard<8,8>" and path["fallbacks"] == 0 and all(p == fl.FB_PCG_PATH_PERSISTENT for p in paths), (rank, path, paths)
         qg[lo:hi] = qq
+    assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
+
+
+def test_sharded_persistent_ranks_with_different_kernels_interoperate(gpu):
+    """Uneven slabs of the 58^3 cube on two half-GPUs: 26 planes (11 slices per CU: the one-row kernel) and 32 planes (14 per CU: the
+    two-row kernel).  Box, counters, proxies and sums are the same protocol in both, so the ranks need not run the same kernel; three
+    steps against the unsharded handle."""
+    import multiprocessing as mp
+    from fembrain_amd.fem import FemIntegrator
+    from fembrain_amd import lib as fl
+    world, n, steps, planes = 2, 58, 3, (0, 26, 58)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_persist_worker, args=(r, world, "/fembrain_test_%d_spmx" % os.getpid(), n, steps, q, None, "2000", False, False, planes)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=300))
+            assert res[-1][2] is not None, res[-1]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    v, t, fixed, _ = _mesh(n, world)
+    g = FemIntegrator(v, t, fixed)
+    f = _sp_force(n, v)
+    its = []
+    for _ in range(steps):
+        g.set_external_forces(f)
+        its.append(g.do_timestep())
+    qs = g.get_q_state()[0]
+    qg = np.zeros_like(qs)
+    kernels = {}
+    for rank, rits, qq, path, paths, info, lo, hi in res:
+        assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its)), (rits, its)
+        assert path["fallbacks"] == 0 and all(p == fl.FB_PCG_PATH_PERSISTENT for p in paths), (rank, path, paths)
+        kernels[rank] = path["kernel"]
+        qg[lo:hi] = qq
+    assert kernels == {0: "k_pcg_pipe_shard<12,6>", 1: "k_pcg_pipe2_shard"}, kernels
     assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
