@@ -98,6 +98,137 @@ def cpu_baseline(mesh, cg_iterations, sample_iters=40):
                       "iterations per step of the GPU run; set-up excluded" % (what, t_asm, sample_iters, t_it * 1e3, cg_iterations)}
 
 
+def cpu_full_step(mesh):
+    """ONE full step of the reference's CPU path (oracle/_ref/libfem_ref.so, else the C restatement) on `mesh`, 1 core, from rest under
+    the reference load, PCG to its tolerance -- no extrapolation (2.3-2.6 s at 105k tets)."""
+    from oracle import pyoracle
+    v, t, fixed = mesh
+    kind, cls = "port", pyoracle.OrcFem
+    if os.environ.get("FEMBRAIN_BENCH_CPU_KIND") != "port":
+        try:
+            pyoracle._load("ref")
+            kind, cls = "reference", pyoracle.RefFem
+        except Exception:
+            pass
+    o = cls(v, t)
+    o.integrator(fixed)
+    f = np.zeros(o.r)
+    f[1::3] = -10000.0
+    o.set_external_forces(f)
+    t0 = time.perf_counter()
+    it = abs(o.step())
+    dt = time.perf_counter() - t0
+    o.close()
+    rec = {"value": 1.0 / dt, "unit": "steps/s", "cores": 1, "kind": kind, "cg_iterations": int(it),
+           "sample": "one whole step from rest (assembly + system algebra + %d PCG iterations), %.2f s; set-up excluded" % (it, dt)}
+    if kind == "port":
+        rec["why_port"] = "oracle/_ref/libfem_ref.so (the reference's own translation units) did not travel with this snapshot; oracle/fem_oracle.c is its restatement"
+    return rec
+
+
+def small_leg(name, device, prec, cpu, steps=5):
+    """BASELINE configs 1-2 as driver-timed legs (never part of `value`): the 27^3 truth cube (105,456 tets) and a BlobTree model
+    polygonized on the device to ~100k tets and handed to the FEM handle without a host hop (fb_fem_create_from_poly).  Steps from
+    the rest state under the reference load (every step the same system: `value`), and the steps of the loaded trajectory."""
+    from fembrain_amd import lib as fl
+    from fembrain_amd.fem import FemIntegrator
+    from fembrain_amd.meshgen import fixed_vertices_to_dofs
+    import torch
+    poly = None
+    if WORKLOADS[name][0]:
+        v, t, fixed = workload_mesh(name, device)
+        g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device)
+    else:
+        from fembrain_amd.blobtree import read_blob
+        from fembrain_amd.poly import GpuPoly
+        poly = GpuPoly(read_blob(os.path.join(ROOT, "tests", "golden", "blob", "ventricle.blob")), device=device)
+        xyz, tets = poly.run_tetrahedralizer(0.115)
+        v, t = xyz.astype(np.float64), tets.astype(np.int32)
+        ycut = np.sort(v[:, 1])[len(v) // 20]
+        fixed = fixed_vertices_to_dofs(np.nonzero(v[:, 1] <= ycut)[0])
+        g = FemIntegrator.from_poly(poly, fixed, matrix_precision=prec, device=device)
+
+    def step():
+        g.rebuild_elements()
+        g.set_uniform_force(1, -10000.0)
+        return g.do_timestep()
+    step()
+    tot, its, solve, asm = 0.0, [], 0.0, 0.0
+    for _ in range(steps):
+        g.reset_to_rest()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        its.append(step())
+        torch.cuda.synchronize()
+        tot += time.perf_counter() - ts
+        solve += g.last.solve_seconds
+        asm += g.last.assembly_seconds
+    g.reset_to_rest()
+    torch.cuda.synchronize()
+    ts = time.perf_counter()
+    traj = [step() for _ in range(steps)]
+    torch.cuda.synchronize()
+    traj_dt = time.perf_counter() - ts
+    path = g.pcg_path()
+    out = {"workload": WORKLOADS[name][1], "nodes": int(len(v)), "tets": int(len(t)), "steps": steps, "value": steps / tot, "unit": "steps/s",
+           "value_is": "steps from the rest state under the reference load (the same system every step)", "ms_per_step": tot / steps * 1e3,
+           "cg_iterations": [int(i) for i in its], "us_per_cg_iteration": solve / max(sum(its), 1) * 1e6, "assembly_ms_per_step": asm / steps * 1e3,
+           "trajectory_steps_per_s": steps / traj_dt, "trajectory_cg_iterations": [int(i) for i in traj],
+           "pcg_kernel": path["kernel"] or ("k_spmv_split + k_cg_fused (hipGraph of 30 iterations)" if len(v) < 512 * 64 else "k_spmv + k_cg_fused"),
+           "pcg_path_last_step": int(g.last.pcg_path), "max_producers_per_workgroup": path["max_producers"],
+           "created_from": "fb_fem_create_from_poly (tet mesh left on the device by the polygonizer)" if poly is not None else "fb_fem_create",
+           "renumbered": bool(g.renumbering()[0])}
+    g.close()
+    if poly is not None:
+        poly.close()
+    if cpu:
+        try:
+            out["cpu_baseline"] = cpu_full_step((v, t, fixed))
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline_error"] = repr(e)
+    return out
+
+
+def numbering_leg(device, prec):
+    """VERDICT r3 item 1: the headline mesh in a RANDOM node order (what a caller's numbering may be after cuts: CuttableMesh::cut
+    appends its new nodes at the end of the list).  The handle renumbers internally (fembrain_amd/csrc/renumber.h); reported: the
+    kernel it ends up with, us per PCG iteration, the re-sync time including the renumbering."""
+    from fembrain_amd.fem import FemIntegrator
+    from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
+    import torch
+    n = WORKLOADS["cube56"][0]
+    v0, t0 = truth_cube(n, n, n, 0.1)
+    m = np.random.default_rng(12345).permutation(len(v0))
+    v = np.empty_like(v0)
+    v[m] = v0
+    t = np.ascontiguousarray(m[t0].astype(np.int32))
+    fixed = fixed_vertices_to_dofs(np.sort(m[cube_fixed_plane_i0(n, n)]))
+    g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device)
+    its, solve = [], 0.0
+    for k in range(3):
+        g.reset_to_rest()
+        g.set_uniform_force(1, -10000.0)
+        it = g.do_timestep()
+        if k:
+            its.append(it)
+            solve += g.last.solve_seconds
+    rs = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        g.resync(v, t, fixed)
+        torch.cuda.synchronize()
+        rs.append((time.perf_counter() - ts) * 1e3)
+    on, sc, si = g.renumbering()
+    path = g.pcg_path()
+    g.close()
+    return {"workload": "the 56^3 truth cube with its node ids randomly permuted", "renumbered": bool(on), "widest_element_caller_order": sc,
+            "widest_element_internal_order": si, "pcg_kernel": path["kernel"], "max_producers_per_workgroup": path["max_producers"],
+            "cg_iterations": [int(i) for i in its], "us_per_cg_iteration": solve / max(sum(its), 1) * 1e6, "resync_ms": min(rs),
+            "resync_ms_all": [round(x, 3) for x in rs]}
+
+
 def field_bench(device, cpu=True):
     """256^3 sweep + classify + tetrahedralize of sphere.blob (BASELINE config 3); returns extra JSON keys."""
     from fembrain_amd.poly import GpuPoly, sphere_blob
@@ -108,10 +239,26 @@ def field_bench(device, cpu=True):
     c = p.classify()
     p.tetrahedralize()
     sweep_s, pipe_s = p.time_pipeline(10)
+    st = p.time_stages(10)
     p.surface()
     surf_s = p.time_surface(10)
     npts = dims[0] * dims[1] * dims[2]
-    out = {"field_mvoxels_per_s": npts / pipe_s / 1e6, "field_sweep_mvoxels_per_s": npts / sweep_s / 1e6, "field_grid": list(dims),
+    # roofline of the field half: the dominant kernel is k_tet_elements, a pure store stream -- 6 tets x 16 B per
+    # included cell -- plus the two bit masks and scan bases it reads (2 x 1 bit + 2 x 4 B per 64 points); the whole pipeline moves
+    # 16 B per point (sweep) + 12 B per tet-mesh vertex + 96 B per included cell + ~3 B per point of masks and scans
+    n_inc, n_tv = int(c.n_included_cells), int(p.counts.n_tet_vertices)
+    elem_bytes = 96.0 * n_inc + npts / 64.0 * 24.0
+    pipe_bytes = 16.0 * npts + 12.0 * n_tv + 96.0 * n_inc + 3.0 * npts
+    field_roofline = {"kernel": "k_tet_elements (6 tets of 16 B per included cell, one wavefront per run of 4 mask words, records transposed through LDS)",
+                      "bound": "hbm", "achieved": elem_bytes / st[3] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": elem_bytes / st[3] / 1e9 / HBM_PEAK_GBS,
+                      "algorithmic_bytes_per_launch": elem_bytes, "us_per_launch": st[3] * 1e6,
+                      "traffic": None, "traffic_source": "store stream: WRITE_SIZE of the same kernel is in profiles/r04_poly256_pmc.json when recorded",
+                      "ceiling_measured": {"gbs": 6700.0, "what": "plain 16-byte store stream of this part, tools/ubench/writebw.hip (DESIGN.md section 4)"},
+                      "stages_us": {"k_sweep": st[0] * 1e6, "classification_and_scans": st[1] * 1e6, "k_tet_vertices": st[2] * 1e6, "k_tet_elements": st[3] * 1e6,
+                                    "all_with_events_between": st[4] * 1e6},
+                      "pipeline": {"algorithmic_bytes": pipe_bytes, "us": pipe_s * 1e6, "achieved": pipe_bytes / pipe_s / 1e9, "frac": pipe_bytes / pipe_s / 1e9 / HBM_PEAK_GBS},
+                      "sweep": {"algorithmic_bytes": 16.0 * npts, "us": sweep_s * 1e6, "achieved": 16.0 * npts / sweep_s / 1e9, "frac": 16.0 * npts / sweep_s / 1e9 / HBM_PEAK_GBS}}
+    out = {"field_roofline": field_roofline, "field_mvoxels_per_s": npts / pipe_s / 1e6, "field_sweep_mvoxels_per_s": npts / sweep_s / 1e6, "field_grid": list(dims),
            "field_sweep_gbs": npts * 16 / sweep_s / 1e9, "field_pipeline_us": pipe_s * 1e6, "field_tets": int(p.counts.n_tets),
            "field_surface_us": surf_s * 1e6, "field_surface_vertices": int(p.counts.n_surface_vertices),
            "field_surface_triangles": int(p.counts.n_surface_indices) // 3,
@@ -127,7 +274,9 @@ def field_bench(device, cpu=True):
         o.classify()
         o.tetrahedralize()
         dt = time.perf_counter() - t0
-        out["field_cpu_baseline"] = {"value": dims[0] * dims[1] * zs / dt / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+        why_port = ("the reference's CPU polygonizer (src/implicit/Polygonizer.cpp) needs TBB headers this image lacks and its GPU path is OpenCL + GL: "
+                    "neither builds here without stand-in headers, which the rules forbid; oracle/field_oracle.c is the scalar restatement pinned by the reference's shipped outputs")
+        out["field_cpu_baseline"] = {"value": dims[0] * dims[1] * zs / dt / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port", "why_port": why_port,
                                      "sample": "oracle/field_oracle.c, 256x256x%d slab of the same grid through the sphere, sweep+classify+tets" % zs}
         # the reference's CPU polygonizer is TBB-parallel over cores (Polygonizer.cpp:627-629): the same slab on every core of the
         # box's share at once (threads; the C oracle runs outside the GIL), as a courtesy number
@@ -143,7 +292,7 @@ def field_bench(device, cpu=True):
         with ThreadPoolExecutor(cores) as ex:
             list(ex.map(one, range(cores)))
         dta = time.perf_counter() - t0
-        out["field_cpu_baseline_all_cores"] = {"value": cores * dims[0] * dims[1] * zs / dta / 1e6, "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+        out["field_cpu_baseline_all_cores"] = {"value": cores * dims[0] * dims[1] * zs / dta / 1e6, "unit": "Mvoxels/s", "cores": cores, "kind": "port", "why_port": why_port,
                                                "sample": "%d threads, one 256x256x%d slab each" % (cores, zs)}
     p.close()
     return out
@@ -525,6 +674,7 @@ def main():
                 resync_ms = (time.perf_counter() - ts) * 1e3
             return spmv_s, g.spmv_bytes(), asm_k_s, halo_s, sum_s, k0_s, resync_ms, persist, persist_s, g.iteration_bytes()
         (spmv_s, spmv_bytes, asm_k_s, halo_s, sum_s, k0_s, resync_ms, persist, persist_s, iter_bytes), _ = stage("kernel probes", probes)
+        slots_total = int(fl.lib().fb_fem_device_plan_get(g.h, b"slot_coff", None, 0))   # SELL slots (64 block rows each) of this rank's matrix
 
         if rank == 0:
             # HBM traffic of the dominant kernel from the PMC counters: taken from the committed profile only while the kernel
@@ -559,17 +709,35 @@ def main():
                 # algorithmic figure -- the opposite of wasted re-reads; bus_frac = that traffic / time / peak.
                 n_launch, sec, n_it = persist_s
                 upl = n_it / max(n_launch, 1)
-                ach = n_it * iter_bytes / sec / 1e9
-                traffic_launch = traffic * upl if traffic is not None else None
+                work = n_it * iter_bytes / sec / 1e9          # work-equivalent rate: algorithmic bytes / time (exceeds the peak: see below)
+                # Bytes that really cross the L2 <-> fabric boundary per iteration.  Measured: PMC 2 x FETCH_SIZE + WRITE_SIZE from the
+                # committed profile of these kernel sources.  Without a matching profile: a MODEL of the same quantity -- the streamed
+                # slots of the matrix (values + column words), the published vector written through once and fetched once per XCD that
+                # gathers it (~1.5x), flags and sums -- labelled as such.
+                streamed = max(0.0, 1.0 - persist[3] * persist[1] * persist[2] / max(1.0, float(slots_total))) if slots_total else 1.0
+                model = slots_total * 64.0 * (36.0 + (2.0 if "c16" in g.pcg_path()["kernel"] else 4.0)) * streamed + 2.5 * 24.0 * len(v)
+                bus_unit, bus_src = (traffic, traffic_note) if traffic is not None else (model, "MODEL (no PMC profile of the current kernel sources under profiles/): "
+                                                                                         "streamed matrix slots + published vector stores and fetches")
+                bus = bus_unit * n_it / sec / 1e9
                 roofline = {"kernel": "%s (pipelined Jacobi-PCG, one launch per solve: product + sums + recurrences of every iteration, vectors in "
                                       "registers, %d of ~15 slots of every slice resident in LDS)" % (g.pcg_path()["kernel"], persist[3]),
-                            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                            "traffic": traffic_launch, "traffic_per_unit": traffic, "traffic_source": traffic_note,
-                            "bus_frac": (traffic_launch / (sec / n_launch) / 1e9 / HBM_PEAK_GBS) if traffic_launch is not None else None,
+                            "bound": "hbm", "achieved": bus, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bus / HBM_PEAK_GBS,
+                            "frac_is": "bytes that cross the L2 <-> fabric boundary (PMC 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction) / time / 8 TB/s: what the "
+                                       "memory system really sustains.  The algorithmic bytes of the same iterations (SURVEY 8d: BSR SpMV + 9 vector "
+                                       "streams) are under work_equivalent_*; their rate exceeds the peak because two fifths of them never leave the "
+                                       "registers / LDS",
+                            "traffic": bus_unit * upl, "traffic_per_unit": bus_unit, "traffic_source": bus_src,
+                            "traffic_measured": traffic is not None,
+                            "work_equivalent_gbs": work, "work_equivalent_frac": work / HBM_PEAK_GBS,
+                            "served_from": "the 256 MiB Infinity Cache: the system of an iteration (100 MB of matrix, 12 MB of vectors) stays resident between "
+                                           "iterations, so HBM itself is nearly idle; FETCH_SIZE / WRITE_SIZE count L2-to-fabric requests, cache hits included",
+                            "ceiling_measured": {"gbs": 6600.0, "what": "streaming read of a 102 MB Infinity-Cache-resident buffer on this part "
+                                                                        "(tools/ubench/readbw.hip; 6.2 TB/s for 1 GB from HBM)",
+                                                 "frac_of_ceiling": bus / 6600.0},
                             "launches": n_launch, "units_per_launch": upl, "algorithmic_bytes_per_unit": iter_bytes,
                             "algorithmic_bytes_per_launch": upl * iter_bytes, "us_per_launch": sec / n_launch * 1e6, "us_per_unit": sec / n_it * 1e6,
                             "wavefronts_per_cu": persist[1], "workgroups": persist[2], "max_producers_per_workgroup": g.pcg_path()["max_producers"],
-                            "persist_fallbacks": g.pcg_path()["fallbacks"], "spmv_kernel": spmv_roof}
+                            "persist_fallbacks": g.pcg_path()["fallbacks"], "persist_rearms": int(fl.lib().fb_fem_persist_rearms(g.h)), "spmv_kernel": spmv_roof}
             else:
                 roofline = dict(spmv_roof, bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", traffic=traffic, traffic_source=traffic_note)
             storage = "f64 arithmetic / f32 stored matrix" if args.precision == "f32" else "f64"

@@ -15,6 +15,7 @@
 #include "pcg_pipe_shard.hip.h"
 #include "pcg_pipe2_shard.hip.h"
 #include "plan_device.h"
+#include "renumber.h"
 
 using namespace fb;
 
@@ -54,6 +55,13 @@ struct fb_fem_s {
   bool asm_staged = false;           // k_assemble_tets_st (records staged in LDS, mass entries precomputed) instead of k_assemble_tets
   int asm_lds_st = 0, asm_grid_st = 0;
   bool mass_valid = false;           // h->mblk holds the mass entries of the current rest data (k_mass_blocks)
+  // locality renumbering behind the ABI (renumber.h): the handle works in its own node order, ids are mapped on the way in and out
+  Renumbering ren;
+  DevBuf<double> xyz_in;               // the caller-order rest positions the order was derived from
+  DevBuf<double> io;                   // staging of a caller-order vector on its way to / from the internal order
+  bool x0_ready = false;               // build_plan_on_device has put the (permuted) rest positions in place already
+  std::vector<int> c_bptr, c_bcol, c_src;  // the pattern in the caller's numbering and the internal block behind each of its blocks (inspection entry points)
+  bool caller_pattern = false;
   std::vector<double> x0_stage;  // host staging of the rest positions in local numbering (kept: a re-sync does not fault fresh pages)
   DevBuf<int> d_bptr, d_bcol, d_blk_slot;  // device-built plan only: pattern and slot table, fetched when an inspection entry point asks
   bool device_plan = false, host_pattern = true;
@@ -92,12 +100,18 @@ struct fb_fem_s {
   DevBuf<unsigned long long> pipe_post;
   DevBuf<unsigned int> pipe_flags;     // [blocks padded to 4] flags, [+4] the error word, [+8..9] the two sequence numbers
   DevBuf<int> pipe_prod, pipe_prod_count, pipe_prod_xcd;
+  DevBuf<unsigned int> pipe_xcc;        // per workgroup: the XCC id it announced in the current launch (k_pcg_pipe: plain-store publish)
   int pipe_plain_local = 0;            // interior workgroups publish with plain stores (FEMBRAIN_PIPE_PLAIN_STORES)
   DevBuf<double> pipe_planes, pipe_z, pipe_s, pipe_state;
   int pipe_klt = 0, pipe_wmax = 0;
   // sharded persistent solver (pcg_pipe_shard.hip.h; opt-in FEMBRAIN_SHARDED_PERSIST=1, unmeasured on multi-GPU hardware)
   bool shard_persist = false;
-  bool persist_broken = false;  // a launch timed out: the handle stays with the two-launch iteration
+  bool persist_broken = false;  // a launch timed out: the handle runs the two-launch iteration until it is re-armed (below) or re-synced
+  // Re-arming: one co-tenant burst must not cost a 1M-tet host 40 % of its speed for the life of the handle.  After
+  // `rearm_after` clean two-launch solves an unsharded handle tries the persistent launch again; every further time-out doubles the
+  // wait (32, 64, 128, ... solves; FEMBRAIN_PERSIST_REARM=n sets the first, 0 = never).  A sharded handle re-arms at a re-sync only
+  // (the ranks must switch together).
+  int rearm_after = 32, clean_solves = 0, persist_rearms = 0;
   char* sbox = nullptr;                // my box (fine-grained, mapped by the peers)
   void* sbox_opened[kP2PMaxRanks] = {nullptr};
   long long sbox_halo_cap = 0;
@@ -145,6 +159,12 @@ __global__ __launch_bounds__(kBlock) void k_slice_halo(int n_slices, int n_owned
 __global__ __launch_bounds__(kBlock) void k_widen_positions(long long n, const float* __restrict__ in, double* __restrict__ out) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) out[i] = (double)in[i];
+}
+
+// FB_RENUMBER_* of this handle: fb_fem_params.renumber unless FEMBRAIN_RENUMBER=0/1 says otherwise; a sharded handle renumbers on request only
+int renumber_mode(const fb_fem_s* h) {
+  if (const char* e = getenv("FEMBRAIN_RENUMBER")) return atoi(e) != 0 ? FB_RENUMBER_ON : FB_RENUMBER_OFF;
+  return h->prm.renumber > 0 ? FB_RENUMBER_ON : (h->prm.renumber < 0 ? FB_RENUMBER_OFF : FB_RENUMBER_AUTO);
 }
 
 int upload_masks(fb_fem_s* h) {
@@ -306,23 +326,35 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   return FB_OK;
 }
 
+// how long a wait inside a persistent launch may last before the launch gives up (read when a plan is built and when the solver is re-armed)
+void read_persist_timeout(fb_fem_s* h) {
+  const char* t = getenv("FEMBRAIN_PERSIST_TIMEOUT_MS");
+  // default 50 ms: a whole 1M-tet solve is ~25 ms, one wait is microseconds.  A sharded handle also waits for the OTHER RANKS' launches
+  // to begin, and those are separated by host jitter (first launch: code object load): 2 s there
+  const double ms = t ? atof(t) : (h->plan.n_ranks > 1 ? 2000.0 : 50.0);
+  h->persist_timeout_ticks = std::max(1LL, (long long)(ms * 1e5));  // 100 MHz
+}
+
 // Decides whether this handle solves inside persistent launches and allocates what they need (called for every (re)built plan).
 int setup_persist(fb_fem_s* h) {
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
   h->persist = false;
+  // Nothing of the previous plan's sharded persistent solver survives a rebuild: a re-sync to a mesh that is no longer
+  // eligible must not leave attach_pipe_shard a stale "keep", stale send lists or a stale workgroup deal.  setup_persist_shard_local
+  // is the only place that sets shard_persist again; a fresh plan also gets a fresh chance after a time-out.
+  h->shard_persist = false;
+  h->persist_broken = false;
+  h->clean_solves = 0;
+  h->rearm_after = getenv("FEMBRAIN_PERSIST_REARM") ? std::max(0, atoi(getenv("FEMBRAIN_PERSIST_REARM"))) : 32;
+  h->sh_halo_off.release(); h->sh_row_send_off.release(); h->sh_row_send_rank.release(); h->sh_row_send_pos.release(); h->sh_proxy_wg.release();
+  h->sh_wg_duty.release(); h->sh_wg_range.release(); h->sh_wg_send_mask.release();
   hipDeviceProp_t prop;
   FB_HIP(hipGetDeviceProperties(&prop, h->prm.device));
   const int nb = std::min(kPipeMaxBlocks, ((h->cu_limit > 0 ? std::min(h->cu_limit, prop.multiProcessorCount) : prop.multiProcessorCount) / 8) * 8);
   const char* e = getenv("FEMBRAIN_PCG_PERSIST");
   const int w = nb >= 8 ? ceil_div(ceil_div(P.n_slices, 8), nb / 8) : 0;
-  {
-    const char* t = getenv("FEMBRAIN_PERSIST_TIMEOUT_MS");  // how long a wait inside a persistent launch may last before the launch gives up
-    // default 50 ms: a whole 1M-tet solve is ~25 ms, one wait is microseconds.  A sharded handle also waits for the OTHER RANKS' launches
-    // to begin, and those are separated by host jitter (first launch: code object load): 2 s there
-    const double ms = t ? atof(t) : (P.n_ranks > 1 ? 2000.0 : 50.0);
-    h->persist_timeout_ticks = std::max(1LL, (long long)(ms * 1e5));  // 100 MHz
-  }
+  read_persist_timeout(h);
   const bool explicit_p = h->prm.pcg_variant == FB_PCG_PERSISTENT;
   const bool shard_opt = P.n_ranks > 1 && getenv("FEMBRAIN_SHARDED_PERSIST") && atoi(getenv("FEMBRAIN_SHARDED_PERSIST")) != 0;
   if (explicit_p && P.n_ranks > 1 && !shard_opt) return fail(FB_EINVAL, "FB_PCG_PERSISTENT on a sharded handle needs FEMBRAIN_SHARDED_PERSIST=1 (unmeasured on multi-GPU hardware)");
@@ -366,44 +398,48 @@ int setup_persist(fb_fem_s* h) {
   } else {
     h->persist_timing.release();
   }
-  // producer lists: the workgroups that own the rows this workgroup's columns lie in (a range per slice, so a superset)
-  DevBuf<int2> range;
-  FB_TRY(range.alloc((size_t)std::max(1, P.n_slices)));
-  hipLaunchKernelGGL(k_slice_colrange, dim3(ceil_div(std::max(1, P.n_slices), kWavesPerBlock)), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->slice_off.p, h->colidx.p,
-                     range.p);
-  FB_HIP(hipGetLastError());
-  std::vector<int2> rg((size_t)std::max(1, P.n_slices));
-  FB_TRY(range.download(rg.data(), rg.size(), s));
-  std::vector<int> owner((size_t)P.n_slices, 0), prod((size_t)nb * kPipeMaxProducers, -1), cnt((size_t)nb, 0), far((size_t)nb, 0);
+  // producer lists: the workgroups that own the rows this workgroup's columns lie in, exactly (k_slice_producers)
+  static_assert(kPipeMaxBlocks <= 256, "k_slice_producers holds 256 workgroups in its 8 mask words");
+  std::vector<int> owner((size_t)std::max(1, P.n_slices), 0), prod((size_t)nb * kPipeMaxProducers, -1), cnt((size_t)nb, 0), far((size_t)nb, 0);
   for (int b = 0; b < nb; b++) {
     int first, count;
     pipe_slices(P.n_slices, nb, b, &first, &count);
     for (int k = 0; k < count; k++) owner[first + k] = b;
   }
+  DevBuf<int> d_owner;
+  DevBuf<unsigned int> d_mask;
+  FB_TRY(d_owner.upload(owner, s));
+  FB_TRY(d_mask.alloc((size_t)std::max(1, P.n_slices) * 8));
+  hipLaunchKernelGGL(k_slice_producers, dim3(ceil_div(std::max(1, P.n_slices), kWavesPerBlock)), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->slice_off.p, h->colidx.p,
+                     d_owner.p, d_mask.p);
+  FB_HIP(hipGetLastError());
+  std::vector<unsigned int> mask((size_t)std::max(1, P.n_slices) * 8);
+  FB_TRY(d_mask.download(mask.data(), mask.size(), s));
   const bool poll_all = getenv("FEMBRAIN_PERSIST_POLL_ALL") && atoi(getenv("FEMBRAIN_PERSIST_POLL_ALL")) != 0;  // development aid
-  std::vector<char> mark((size_t)nb);
   h->pipe_max_producers = 0;
   for (int b = 0; b < nb; b++) {
     int first, count;
     pipe_slices(P.n_slices, nb, b, &first, &count);
-    std::fill(mark.begin(), mark.end(), 0);
+    unsigned int m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    for (int k = 0; k < count; k++)
+      for (int i = 0; i < 8; i++) m[i] |= mask[(size_t)(first + k) * 8 + i];
+    m[b >> 5] &= ~(1u << (b & 31));
     int n = 0;
-    for (int k = 0; k < count; k++) {
-      const int2 r = rg[first + k];
-      if (r.y < r.x) continue;
-      for (int sl = r.x >> 6; sl <= (r.y >> 6) && sl < P.n_slices; sl++) {
-        const int o = owner[sl];
-        if (o != b && !mark[o]) { mark[o] = 1; n++; if ((o & 7) != (b & 7)) far[b] = 1; }
-      }
-    }
+    for (int i = 0; i < 8; i++) n += __builtin_popcount(m[i]);
     if (n > kPipeMaxProducers || poll_all) { cnt[b] = -1; far[b] = 1; h->pipe_max_producers = -1; continue; }
     cnt[b] = n;
     if (h->pipe_max_producers >= 0) h->pipe_max_producers = std::max(h->pipe_max_producers, n);
-    for (int o = 0, k = 0; o < nb; o++) if (mark[o]) prod[(size_t)b * kPipeMaxProducers + k++] = o;
+    for (int o = 0, k = 0; o < nb; o++)
+      if (m[o >> 5] >> (o & 31) & 1u) {
+        prod[(size_t)b * kPipeMaxProducers + k++] = o;
+        if ((o & 7) != (b & 7)) far[b] = 1;
+      }
   }
   FB_TRY(h->pipe_prod.upload(prod, s));
   FB_TRY(h->pipe_prod_count.upload(cnt, s));
   FB_TRY(h->pipe_prod_xcd.upload(far, s));
+  FB_TRY(h->pipe_xcc.alloc((size_t)nb));
+  FB_TRY(h->pipe_xcc.zero(s));
   {
     // interior workgroups publish with plain stores where the iteration is latency-bound (measured, us per iteration with / without:
     // 9.5 / 10.2 at 466 slices, 9.5 / 9.9 at 1,000; 17.4 / 17.1 at 2,744 = 1M tets, where the matrix stream evicts the lines from
@@ -427,7 +463,9 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
     FB_TRY(h->slot_ccnt.upload(P.slot_ccnt, s));
     FB_TRY(h->contrib.upload(P.contrib.data(), P.contrib.size(), s));
   }
-  if (xyz_device) {  // mesh handed over on the device (fb_fem_create_from_poly): float positions widened in place
+  if (h->x0_ready) {
+    // (renumbered: gathered into the internal order by build_plan_on_device)
+  } else if (xyz_device) {  // mesh handed over on the device (fb_fem_create_from_poly): float positions widened in place
     const long long n3 = 3LL * P.n_local;
     FB_TRY(h->x0.alloc((size_t)n3));
     hipLaunchKernelGGL(k_widen_positions, dim3((unsigned)((n3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, n3, xyz_device, h->x0.p);
@@ -924,7 +962,7 @@ bool host_finished(const CGState& s) {
 int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps, int max_iter) {
   PipeArgs pa;
   pa.post = h->pipe_post.p; pa.flags = h->pipe_flags.p; pa.error = h->pipe_flags.p + h->persist_blocks + h->pipe_flag_extra + 4; pa.seqs = h->pipe_flags.p + h->persist_blocks + h->pipe_flag_extra + 8;
-  pa.producers = h->pipe_prod.p; pa.prod_count = h->pipe_prod_count.p; pa.prod_xcd = h->pipe_prod_xcd.p; pa.plain_local = h->pipe_plain_local;
+  pa.producers = h->pipe_prod.p; pa.prod_count = h->pipe_prod_count.p; pa.prod_xcd = h->pipe_prod_xcd.p; pa.plain_local = h->pipe_plain_local; pa.xcc = h->pipe_xcc.p;
   pa.start = start; pa.n_iters = n_iters; pa.eps2 = eps * eps; pa.max_iter = max_iter;
   pa.timeout_ticks = h->persist_timeout_ticks;
   pa.timing = h->persist_timing.p;
@@ -1093,6 +1131,8 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
       h->persist = false;
       h->persist_broken = true;
       h->persist_fallbacks++;
+      h->clean_solves = 0;
+      if (h->persist_fallbacks > 1) h->rearm_after = std::min(h->rearm_after * 2, 1 << 20);
       if (getenv("FEMBRAIN_PERSIST_STRICT") && atoi(getenv("FEMBRAIN_PERSIST_STRICT")) != 0)
         return fail(FB_EDEVICE, "persistent PCG: a wait inside the launch timed out after %.1f ms (the workgroups were not all resident?)", h->persist_timeout_ticks * 1e-5);
       fprintf(stderr, "[fembrain] persistent PCG: a wait timed out after %.1f ms; this handle falls back to the two-launch iteration\n", h->persist_timeout_ticks * 1e-5);
@@ -1131,8 +1171,16 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
 constexpr double kPersistMinEps = 1e-8;
 
 int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters_out, CGState* final_state, bool allow_persist) {
+  if (allow_persist && !h->persist && h->persist_broken && !h->shard_persist && h->plan.n_ranks == 1 && h->rearm_after > 0 && h->clean_solves >= h->rearm_after) {
+    h->persist = true;  // the set-up of the persistent solver is still in place (flags and sums were cleared when it fell back)
+    h->persist_broken = false;
+    h->persist_rearms++;
+    read_persist_timeout(h);
+    fprintf(stderr, "[fembrain] persistent PCG: re-armed after %d two-launch solves\n", h->clean_solves);
+  }
   if (allow_persist && h->persist && eps >= kPersistMinEps && (h->prm.pcg_variant == FB_PCG_MERGED || h->prm.pcg_variant == FB_PCG_PERSISTENT))
     return pcg_solve_pipe(h, b, eps, max_iter, iters_out, final_state);
+  if (allow_persist && h->persist_broken) h->clean_solves++;
   h->last_pcg_path = FB_PCG_PATH_TWO_LAUNCH;
   // The merged recurrence for rho (rho' = rho - 2 alpha S1 + alpha^2 S2) loses digits the literal sum r.r/diag keeps: measured on
   // the 17,576-node cube it stalls above 1e-12 where the literal sequence converges.  Tolerances below kPersistMinEps therefore run
@@ -1217,7 +1265,8 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
 // the identity numbering and the constraint mask; the pattern arrays stay on the device until an inspection entry point
 // asks for them (ensure_host_pattern).
 // tets: host node ids, or -- d_tets non-null -- ids already on this device (the polygonizer's own output: in range by construction)
-int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed, const uint4* d_tets = nullptr) {
+int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed, const double* xyz, const uint4* d_tets = nullptr,
+                         const float* d_xyz = nullptr) {
   if (n_nodes <= 0 || n_tets <= 0 || (!tets && !d_tets)) return fail(FB_EINVAL, "empty mesh (%d nodes, %d tets)", n_nodes, n_tets);
   if ((long long)n_tets >= (1LL << 28)) return fail(FB_EINVAL, "too many tets for the packed contribution word");
 
@@ -1232,13 +1281,37 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   P.halo_off.assign(2, 0);
   P.send_off.assign(2, 0);
   P.n_tets = n_tets;
-  FB_TRY(plan_set_constraints(P, n_fixed, fixed));
   if (d_tets) {
     FB_TRY(h->tets.alloc((size_t)n_tets));
     FB_HIP(hipMemcpyAsync(h->tets.p, d_tets, sizeof(int4) * (size_t)n_tets, hipMemcpyDeviceToDevice, h->stream));
   } else {
     FB_TRY(h->tets.upload((const int4*)tets, (size_t)n_tets, h->stream));
   }
+  {
+    // the internal node order (renumber.h): decided from the widest element, built from the rest positions
+    bool want = false;
+    FB_TRY(renumber_decide(h->stream, renumber_mode(h), n_nodes, n_tets, h->tets.p, h->plan_ws, h->ren, &want));
+    if (want) {
+      FB_TRY(h->xyz_in.reserve((size_t)3 * n_nodes));
+      if (d_xyz) {
+        const long long n3 = 3LL * n_nodes;
+        hipLaunchKernelGGL(k_widen_positions, dim3((unsigned)((n3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, n3, d_xyz, h->xyz_in.p);
+        FB_HIP(hipGetLastError());
+      } else {
+        FB_HIP(hipMemcpyAsync(h->xyz_in.p, xyz, sizeof(double) * 3 * (size_t)n_nodes, hipMemcpyHostToDevice, h->stream));
+      }
+      FB_TRY(renumber_build(h->stream, renumber_mode(h), n_nodes, n_tets, h->tets.p, h->xyz_in.p, h->plan_ws, h->ren));
+      if (h->ren.active) {
+        FB_TRY(relabel_tets(h->stream, n_tets, h->tets.p, n_nodes, h->ren.d_new_of_old.p));
+        FB_TRY(h->x0.alloc((size_t)3 * n_nodes));
+        FB_TRY(gather_nodes(h->stream, n_nodes, 3, h->xyz_in.p, h->ren.d_old_of_new.p, h->x0.p));
+        h->x0_ready = true;
+        P.local2global = h->ren.old_of_new;  // internal id -> the caller's
+      }
+    }
+    if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] node order: widest element %d -> %d (%s)\n", h->ren.span_before, h->ren.span_after, h->ren.active ? "renumbered" : "caller's order kept");
+  }
+  FB_TRY(plan_set_constraints(P, n_fixed, fixed));
   DevicePlan D;
   D.slice_off = &h->slice_off; D.colidx = &h->colidx; D.slot_coff = &h->slot_coff; D.slot_ccnt = &h->slot_ccnt; D.contrib = &h->contrib;
   D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot; D.coldelta = &h->coldelta;
@@ -1359,6 +1432,9 @@ int ensure_host_pattern(fb_fem_s* h) {
 int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed, const int* fixed, int n_ranks,
           int rank, const int* splits, const DeviceTetMesh* dm = nullptr) {
   drop_graph(h);  // the buffers it refers to are about to be replaced
+  h->ren.clear();
+  h->x0_ready = false;
+  h->caller_pattern = false;
   static const bool timing = getenv("FEMBRAIN_TIMING") != nullptr;  // development aid: where a (re)build spends its time
   const auto t0 = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -1369,12 +1445,14 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
   h->host_pattern = !h->device_plan;
   if (h->device_plan) {
     const int rc = n_ranks > 1 ? build_shard_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits)
-                               : build_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, dm ? dm->tets : nullptr);
+                               : build_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, xyz, dm ? dm->tets : nullptr, dm ? dm->xyz : nullptr);
     if (dm && rc != FB_OK) return rc;
     if (rc == FB_ENOMEM) {  // no room for the sort's temporaries: the host builder needs none on the device
       (void)hipGetLastError();
       h->device_plan = false;
       h->host_pattern = true;
+      h->ren.clear();  // (the host builder works in the caller's order)
+      h->x0_ready = false;
     } else if (rc != FB_OK) {
       return rc;
     }
@@ -1589,6 +1667,13 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
 // global-length host vector -> local device vector (owned + halo)
 int upload_global_vec(fb_fem_s* h, const double* g, DevBuf<double>& dst) {
   const FemPlan& P = h->plan;
+  if (P.n_ranks == 1 && h->ren.active) {  // caller order -> internal order on the device
+    FB_TRY(h->io.reserve((size_t)3 * P.n_local));
+    FB_HIP(hipMemcpyAsync(h->io.p, g, sizeof(double) * 3 * (size_t)P.n_local, hipMemcpyHostToDevice, h->stream));
+    FB_TRY(gather_nodes(h->stream, P.n_local, 3, h->io.p, h->ren.d_old_of_new.p, dst.p));
+    FB_HIP(hipStreamSynchronize(h->stream));
+    return FB_OK;
+  }
   if (P.n_ranks == 1) {
     FB_HIP(hipMemcpyAsync(dst.p, g, sizeof(double) * 3 * (size_t)P.n_local, hipMemcpyHostToDevice, h->stream));
     FB_HIP(hipStreamSynchronize(h->stream));
@@ -1605,8 +1690,38 @@ int upload_global_vec(fb_fem_s* h, const double* g, DevBuf<double>& dst) {
 // owned part of a device vector -> its range of a global-length host vector
 int download_owned(fb_fem_s* h, const DevBuf<double>& src, double* g) {
   const FemPlan& P = h->plan;
+  if (P.n_ranks == 1 && h->ren.active) {  // internal order -> caller order on the device, one contiguous copy out
+    FB_TRY(h->io.reserve((size_t)3 * P.n_local));
+    FB_TRY(gather_nodes(h->stream, P.n_local, 3, src.p, h->ren.d_new_of_old.p, h->io.p));
+    return h->io.download(g, (size_t)3 * P.n_local, h->stream);
+  }
   return src.download(g + 3 * (size_t)P.node_lo, (size_t)3 * P.n_owned, h->stream);
 }
+
+// The pattern in the caller's numbering (renumbered handles): row g of the caller = internal row new_of_old[g], its columns mapped
+// back and sorted ascending -- fb_fem_pattern's contract -- with the internal block each of them is.
+int ensure_caller_pattern(fb_fem_s* h) {
+  FB_TRY(ensure_host_pattern(h));
+  if (h->caller_pattern) return FB_OK;
+  FB_TRY(h->ren.host_new_of_old(h->stream));
+  const FemPlan& P = h->plan;
+  h->c_bptr.assign((size_t)P.n_owned + 1, 0);
+  h->c_bcol.resize((size_t)P.n_blocks);
+  h->c_src.resize((size_t)P.n_blocks);
+  std::vector<std::pair<int, int>> row;
+  int at = 0;
+  for (int g = 0; g < P.n_owned; g++) {
+    const int a = h->ren.new_of_old[g];
+    row.clear();
+    for (int p = P.bptr[a]; p < P.bptr[a + 1]; p++) row.emplace_back(P.local2global[P.bcol[p]], p);
+    std::sort(row.begin(), row.end());
+    for (const auto& e : row) { h->c_bcol[at] = e.first; h->c_src[at] = e.second; at++; }
+    h->c_bptr[(size_t)g + 1] = at;
+  }
+  h->caller_pattern = true;
+  return FB_OK;
+}
+
 
 // SELL device values -> 9 doubles per block in CSR (fb_fem_pattern) order (diagonal blocks: hi + lo)
 int download_blocks(fb_fem_s* h, double* out) {
@@ -1626,13 +1741,22 @@ int download_blocks(fb_fem_s* h, double* out) {
     for (size_t i = 0; i < n; i++) host[i] = hf[i];
     for (size_t i = 0; i < nl; i++) lo[i] = lf[i];
   }
+  const bool mapped = P.n_ranks == 1 && h->ren.active;
+  std::vector<double> internal;
+  if (mapped) {
+    FB_TRY(ensure_caller_pattern(h));
+    internal.resize((size_t)9 * P.n_blocks);
+  }
+  double* dst = mapped ? internal.data() : out;
   for (int a = 0; a < P.n_owned; a++)
     for (int p = P.bptr[a]; p < P.bptr[a + 1]; p++)
       for (int v = 0; v < 9; v++) {
         double x = host[((size_t)P.blk_slot[p] * 9 + v) * 64 + (a & 63)];
         if (P.bcol[p] == a) x += lo[((size_t)(a >> 6) * 9 + v) * 64 + (a & 63)];
-        out[9 * (size_t)p + v] = x;
+        dst[9 * (size_t)p + v] = x;
       }
+  if (mapped)
+    for (int pc = 0; pc < P.n_blocks; pc++) memcpy(out + 9 * (size_t)pc, internal.data() + 9 * (size_t)h->c_src[pc], 9 * sizeof(double));
   return FB_OK;
 }
 
@@ -2095,8 +2219,28 @@ int fb_fem_pattern(fb_fem_t h, int* bptr, int* bcol) {
   FB_HIP(hipSetDevice(h->prm.device));
   FB_TRY(ensure_host_pattern(h));
   const FemPlan& P = h->plan;
+  if (P.n_ranks == 1 && h->ren.active) {
+    FB_TRY(ensure_caller_pattern(h));
+    memcpy(bptr, h->c_bptr.data(), sizeof(int) * (P.n_owned + 1));
+    memcpy(bcol, h->c_bcol.data(), sizeof(int) * (size_t)P.n_blocks);
+    return FB_OK;
+  }
   memcpy(bptr, P.bptr.data(), sizeof(int) * (P.n_owned + 1));
   for (int p = 0; p < P.n_blocks; p++) bcol[p] = P.local2global[P.bcol[p]];
+  return FB_OK;
+}
+
+int fb_fem_renumbering(fb_fem_t h, int* span_caller, int* span_internal) {
+  if (!h) return 0;
+  if (span_caller) *span_caller = h->ren.span_before;
+  if (span_internal) *span_internal = h->ren.span_after;
+  return h->ren.active ? 1 : 0;
+}
+
+int fb_fem_owned_nodes(fb_fem_t h, int* ids) {
+  if (!h || !ids) return fail(FB_EINVAL, "null argument");
+  const FemPlan& P = h->plan;
+  for (int l = 0; l < P.n_owned; l++) ids[l] = P.local2global[l];
   return FB_OK;
 }
 
@@ -2181,8 +2325,17 @@ int fb_fem_mass(fb_fem_t h, double* m_blocks) {
   const FemPlan& P = h->plan;
   std::vector<double> host((size_t)P.n_slots * 64);
   FB_TRY(h->mblk.download(host.data(), host.size(), h->stream));
+  const bool mapped = P.n_ranks == 1 && h->ren.active;
+  std::vector<double> internal;
+  if (mapped) {
+    FB_TRY(ensure_caller_pattern(h));
+    internal.resize((size_t)P.n_blocks);
+  }
+  double* dst = mapped ? internal.data() : m_blocks;
   for (int a = 0; a < P.n_owned; a++)
-    for (int p = P.bptr[a]; p < P.bptr[a + 1]; p++) m_blocks[p] = host[(size_t)P.blk_slot[p] * 64 + (a & 63)];
+    for (int p = P.bptr[a]; p < P.bptr[a + 1]; p++) dst[p] = host[(size_t)P.blk_slot[p] * 64 + (a & 63)];
+  if (mapped)
+    for (int pc = 0; pc < P.n_blocks; pc++) m_blocks[pc] = internal[(size_t)h->c_src[pc]];
   return FB_OK;
 }
 
@@ -2295,6 +2448,8 @@ int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches,
   return h->last_pcg_path;
 }
 
+int fb_fem_persist_rearms(fb_fem_t h) { return h ? h->persist_rearms : 0; }
+
 int fb_fem_persist_stats(fb_fem_t h, int* launches, double* seconds, long long* iterations) {
   if (!h) return fail(FB_EINVAL, "null FEM handle");
   if (launches) *launches = h->persist_launches;
@@ -2324,6 +2479,12 @@ int fb_fem_time_persist(fb_fem_t h, int reps, int n_iters, double* seconds_per_l
   if (err) {
     FB_TRY(h->pipe_flags.zero(h->stream));
     FB_TRY(h->pipe_post.zero(h->stream));
+    if (h->shard_persist) {
+      // the peers' cumulative box counters are ahead of the flags just cleared: this handle must not launch the sharded kernel again
+      // (ADVICE r3); its solves run the two-launch iteration until a re-sync attaches fresh boxes
+      h->persist = false;
+      h->persist_broken = true;
+    }
     return fail(FB_EDEVICE, "persistent PCG: a wait inside the launch timed out");
   }
   h->system_valid = false;

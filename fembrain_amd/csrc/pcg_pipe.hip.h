@@ -50,6 +50,7 @@ struct PipeArgs {
   const int* prod_count;      // [n_blocks]
   const int* prod_xcd;        // [n_blocks] non-zero: a producer (= consumer) of this workgroup sits on another XCD, or it polls all
   int plain_local;            // non-zero: workgroups without such a neighbour publish with plain stores (see publish)
+  unsigned int* xcc;          // [n_blocks] (first publish number of the launch) << 4 | HW_REG_XCC_ID of the workgroup: where it REALLY runs
   int prefetch_slots;         // streamed slots per slice whose values the idle wavefronts pull into L2 during the neighbour wait (0..4)
   int service;                // non-zero: the workgroups were launched with one wavefront more than slices; it collects the sums
   int start;                  // 0 continue a solve (state from memory), 1 new solve from x = 0, 2 new solve from the x in memory
@@ -95,21 +96,29 @@ __host__ __device__ inline void pipe_slices(int n_slices, int n_blocks, int b, i
   *count = base + (j < rem ? 1 : 0);
 }
 
-// lowest and highest column of every slice (rows past the last one hold padding)
-__global__ __launch_bounds__(kBlock) void k_slice_colrange(int n_slices, int n_owned, const int* __restrict__ slice_off, const int* __restrict__ colidx,
-                                                           int2* __restrict__ out) {
+// The workgroups whose rows the columns of a slice lie in: a bit mask over the (at most kPipeMaxBlocks = 256) workgroups, 8 words per
+// slice.  EXACT, where a column range per slice (rounds 2-3) gave a superset: one element that joins two distant nodes (a sliver on the hull of a Delaunay
+// mesh, a cut that was closed again) widens the range of its slice to "everyone" but adds ONE producer to the exact list.
+__global__ __launch_bounds__(kBlock) void k_slice_producers(int n_slices, int n_owned, const int* __restrict__ slice_off, const int* __restrict__ colidx,
+                                                            const int* __restrict__ slice_owner, unsigned int* __restrict__ out) {
   const int s = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (s >= n_slices) return;
   const int row = s * 64 + lane;
-  int lo = 0x7fffffff, hi = -1;
+  unsigned int m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   if (row < n_owned)
     for (int k = slice_off[s]; k < slice_off[s + 1]; k++) {
       const int c = colidx[(size_t)k * 64 + lane];
-      lo = min(lo, c); hi = max(hi, c);
+      if (c >= n_owned) continue;  // (a shard's halo column: the proxies' business)
+      const int o = slice_owner[c >> 6];
+#pragma unroll
+      for (int i = 0; i < 8; i++) m[i] |= (o >> 5) == i ? 1u << (o & 31) : 0u;
     }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
-  if (lane == 0) out[s] = make_int2(lo, hi);
+  for (int i = 0; i < 8; i++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m[i] |= __shfl_xor(m[i], off, 64);
+    if (lane == 0) out[(size_t)s * 8 + i] = m[i];
+  }
 }
 
 // WMAX: wavefronts per workgroup the instantiation is bounded for (512 registers per lane and SIMD are shared by
@@ -182,8 +191,15 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
   // Stores of the next product's input vector into the plane buffer of the next publish number (512 contiguous bytes per wave
   // and plane).  Write-through (sc1) where a workgroup of ANOTHER XCD gathers these rows; a workgroup all of whose consumers
   // share its XCD (= its L2) may store plainly (pa.plain_local): the line then stays in that L2, the store is acknowledged
-  // there, and the consumers -- their L1 invalidated -- read it from there.
-  const bool through = pa.plain_local == 0 || pa.prod_xcd[blockIdx.x] != 0;  // workgroup-uniform
+  // there, and the consumers -- their L1 invalidated -- read it from there.  Which workgroups share an XCD is NOT the launch's to
+  // promise (blockIdx & 7 is the observed round-robin deal, good for speed only; a CU-masked stream deals otherwise): every
+  // workgroup announces the XCC id the hardware reports, its first publish of a launch goes through, and it stores plainly from
+  // the second on only if all its producers (= its consumers: A is symmetric) announced the same id (checked in product()).
+  const bool plain_cand = pa.plain_local != 0 && pa.prod_xcd[blockIdx.x] == 0;  // workgroup-uniform
+  bool through = true, xcc_known = false;
+  unsigned int my_xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(my_xcc));
+  if (threadIdx.x == 0) st_sc1_u32(pa.xcc + blockIdx.x, ((pub + 1u) << 4) | my_xcc);  // (visible before this workgroup's first flag: product() drains before it flags)
   auto publish = [&](const double* vin) {
     pub++;
     double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
@@ -251,12 +267,18 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
         }
       }
       if (failed && lane == 0) st_sc1_u32(pa.error, 1u);
+      if (plain_cand && !xcc_known && !failed) {  // first product of the launch: the producers' flags are in, so are their XCC ids
+        const bool same = my_prod < 0 || ld_sc1_u32(pa.xcc + my_prod) == ((pub << 4) | my_xcc);
+        const bool all_same = __ballot(!same) == 0ULL;
+        if (lane == 0) bc[5] = all_same ? 1.0 : 0.0;
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) bc[3] = (failed || ld_sc1_u32(pa.error) != 0u) ? 1.0 : 0.0;  // one lane decides for the whole workgroup
     }
     __syncthreads();
     lap(1);  // flag + wait for the producers + acquire
     if (uniform_flag(bc[3] != 0.0)) { failed = true; return; }
+    if (plain_cand && !xcc_known) { through = !uniform_flag(bc[5] != 0.0); xcc_known = true; }
     // the low part of the diagonal block times the own entry first: vin is not needed beyond this point
     double y0 = 0, y1 = 0, y2 = 0;
     if (rvalid) {

@@ -6,6 +6,7 @@
 #include "../../include/fembrain_hip.h"
 #include "../../include/fembrain_hip_testing.h"
 #include "fem_plan.h"
+#include "renumber.h"
 
 namespace fb {
 int fail(int code, const char* fmt, ...);
@@ -71,6 +72,15 @@ int fb_plan_get(fb_plan_t p, const char* name, int* out, size_t capacity) {
     memcpy(out, v->data(), v->size() * sizeof(int));
   }
   return (int)v->size();
+}
+
+int fb_plan_slab_order(int n_nodes, const double* xyz, int n_tets, const int* tets, int* old_of_new, int* span_caller, int* span_internal) {
+  if (!xyz || !tets || !old_of_new || n_nodes < 1 || n_tets < 0) return fb::fail(FB_EINVAL, "bad argument");
+  std::vector<int> o;
+  const int rc = fb::host_slab_order(n_nodes, xyz, n_tets, tets, o, span_caller, span_internal);
+  if (rc != FB_OK) return rc;
+  memcpy(old_of_new, o.data(), sizeof(int) * (size_t)n_nodes);
+  return FB_OK;
 }
 
 }  // extern "C"

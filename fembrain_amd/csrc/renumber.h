@@ -1,0 +1,83 @@
+// Locality renumbering of the mesh nodes behind the ABI ("the same contiguous-range rule after an RCM /
+// space-filling-curve renumbering done once").  The reference appends every node a cut creates at the END of the node list
+// (src/deformable/VolMesh.cpp:1086-1091,1639-1642, called from CuttableMesh.cpp:283,407) and the tet meshes it ships
+// (data/models/blobtree/*.veg) are TetGen outputs -- surface vertices first, Steiner points after.  On such numbering a row's
+// columns lie anywhere in the vector: no 16-bit column words, gathers without an XCD-local slab, a producer list of "everyone"
+// in the persistent solver, and every rank a neighbour of every other (measured at 1M tets: 46-47 us per PCG iteration against
+// 15.8 in grid order, profiles/r04_numbering_probe_before.json).
+//
+// The internal order is a SLAB order: nodes sorted by the lexicographic key (q_major, q_mid, q_minor) of their rest position
+// quantised to cells of edge h = 0.8 (bounding-box volume / nodes)^(1/3), major = the longest axis of the bounding box (an axis
+// displaces an earlier one only when it is 5 % longer, so a cube keeps x, y, z), ties in caller order (stable sort).  A
+// structured grid in any caller order gets its own plane-by-plane order back; an unstructured mesh gets slabs one cell thick, so
+// a row's columns lie within ~2 slabs = O(n^(2/3)) ids, and a contiguous range of ids is a slab of the body with two
+// neighbours.  Elements keep the caller's order (the order in which a block accumulates its contributions is the reference's,
+// corotationalLinearFEM.cpp:230-469); only node ids are mapped, on the way in and on the way out.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "common.h"
+#include "plan_device.h"
+
+namespace fb {
+
+struct SlabKeyGeom {
+  double lo[3];
+  double inv_h;
+  int axis[3];  // major, mid, minor
+  int bits[3];  // key bits of each, in that order
+};
+
+__host__ __device__ inline unsigned long long slab_key(const SlabKeyGeom& g, double x, double y, double z) {
+  const double p[3] = {x, y, z};
+  unsigned long long k = 0;
+  for (int a = 0; a < 3; a++) {
+    const int ax = g.axis[a];
+    const double t = (p[ax] - g.lo[ax]) * g.inv_h + 0.5;
+    const long long top = (1LL << g.bits[a]) - 1;
+    long long q = t > 0.0 ? (long long)t : 0;  // (NaN compares false: cell 0)
+    if (q > top) q = top;
+    k = (k << g.bits[a]) | (unsigned long long)q;
+  }
+  return k;
+}
+
+// key geometry from the bounding box; false when the nodes do not span a volume to cut into cells (all on one point)
+bool slab_key_geometry(int n_nodes, const double lo[3], const double hi[3], SlabKeyGeom* out);
+
+// AUTO renumbers a mesh of at least kRenumberMinNodes nodes whose widest element (largest difference of two node ids of one tet
+// = the half bandwidth of the matrix) exceeds what the solver's fast paths take -- 32,767 (16-bit column words) or nodes / 8 (at
+// most 64 of 256 workgroups produce a workgroup's columns) -- and keeps the result if it makes the elements at least a quarter narrower on average
+constexpr int kRenumberMinNodes = 8192;
+inline int renumber_span_limit(int n_nodes) { return n_nodes / 8 < 32767 ? n_nodes / 8 : 32767; }
+
+struct Renumbering {
+  bool active = false;
+  int span_before = 0, span_after = 0;      // widest element before / after (span_after = span_before when inactive)
+  double mean_before = 0, mean_after = 0;   // mean width of an element before / after
+  DevBuf<int> d_old_of_new, d_new_of_old;   // internal id -> caller id and back
+  std::vector<int> old_of_new, new_of_old;  // host copies: old_of_new with the build, new_of_old on demand
+  int host_new_of_old(hipStream_t s);
+  void clear() { active = false; span_before = span_after = 0; mean_before = mean_after = 0; old_of_new.clear(); new_of_old.clear(); }
+};
+
+// widest element of the list under the node map `new_of_old` (nullptr: identity); tets with an id outside [0, n_nodes) are left
+// to the plan builder's range check.  Synchronises the stream.
+int tet_span_device(hipStream_t s, int n_tets, const int4* d_tets, int n_nodes, const int* d_new_of_old, PlanWorkspace& W, int* span, double* mean);
+// Phase 1 (mode: FB_RENUMBER_*): measures the widest element and says whether a renumbering is to be tried (*want); phase 2
+// builds it from the caller-order rest positions on the device (3 doubles per node) and decides whether it stands (R.active).
+// Both synchronise the stream.
+int renumber_decide(hipStream_t s, int mode, int n_nodes, int n_tets, const int4* d_tets, PlanWorkspace& W, Renumbering& R, bool* want);
+int renumber_build(hipStream_t s, int mode, int n_nodes, int n_tets, const int4* d_tets, const double* d_xyz, PlanWorkspace& W, Renumbering& R);
+int relabel_tets(hipStream_t s, int n_tets, int4* d_tets, int n_nodes, const int* d_new_of_old);
+// node-wise permutations of arrays of `width` doubles per node: dst[l] = src[map[l]] / dst[map[l]] = src[l]
+int gather_nodes(hipStream_t s, int n, int width, const double* src, const int* map, double* dst);
+int scatter_nodes(hipStream_t s, int n, int width, const double* src, const int* map, double* dst);
+
+// the same on the host (fb_plan_* test entry points, CPU tests): old_of_new of the slab order, spans under both orders
+int host_slab_order(int n_nodes, const double* xyz, int n_tets, const int* tets, std::vector<int>& old_of_new, int* span_before, int* span_after, double* mean_before = nullptr,
+                    double* mean_after = nullptr);
+
+}  // namespace fb

@@ -18,7 +18,7 @@ class FemIntegrator:
     def __init__(self, verts, tets, fixed_dofs=(), E=1e7, nu=0.46, rho=1000.0, timestep=0.0333,
                  damping_mass=0.0, damping_stiffness=0.01, cg_eps=1e-6, cg_max_iter=10000,
                  matrix_precision=_l.FB_MATRIX_F32, device=0, shard=None, pcg_variant=_l.FB_PCG_MERGED, spmv_kernel=_l.FB_SPMV_AUTO,
-                 linear=False, exact_tangent=False, integrator=_l.FB_INTEGRATOR_VOLUME_CONSERVING):
+                 linear=False, exact_tangent=False, integrator=_l.FB_INTEGRATOR_VOLUME_CONSERVING, renumber=_l.FB_RENUMBER_AUTO):
         """shard = (n_ranks, rank, node_splits or None, comm_handle) for a domain-decomposed handle."""
         L = _l.lib()
         self._L = L
@@ -37,6 +37,7 @@ class FemIntegrator:
         p.linear = 1 if linear else 0
         p.exact_tangent = 1 if exact_tangent else 0
         p.integrator = integrator
+        p.renumber = renumber
         self.params = p
         self.h = C.c_void_p()
         self.node_lo, self.node_hi = 0, self.n_nodes
@@ -101,6 +102,18 @@ class FemIntegrator:
     def set_exchange_mode(self, mode):
         """Collective: every rank of a sharded handle switches between two solves."""
         _l.check(self._L.fb_fem_set_exchange_mode(self.h, mode))
+
+    def renumbering(self):
+        """(works in an internal node order?, widest element in the caller's order, in the internal order)"""
+        a, b = C.c_int(0), C.c_int(0)
+        on = self._L.fb_fem_renumbering(self.h, C.byref(a), C.byref(b))
+        return bool(on), a.value, b.value
+
+    def owned_nodes(self):
+        """caller ids of the owned nodes in internal order"""
+        ids = np.empty(self.node_hi - self.node_lo, np.int32)
+        _l.check(self._L.fb_fem_owned_nodes(self.h, _l.iptr(ids)))
+        return ids
 
     def sharded_persist(self):
         """True when this sharded handle's solves run inside the sharded persistent launches (FEMBRAIN_SHARDED_PERSIST=1)."""

@@ -18,6 +18,7 @@ FB_PCG_MERGED, FB_PCG_REFERENCE, FB_PCG_PERSISTENT, FB_PCG_BLOCK_JACOBI = 0, 1, 
 FB_PCG_PATH_TWO_LAUNCH, FB_PCG_PATH_PERSISTENT, FB_PCG_PATH_FALLBACK, FB_PCG_PATH_RESOLVED = 0, 1, 2, 3
 FB_SPMV_AUTO, FB_SPMV_ROWS, FB_SPMV_SPLIT = 0, 1, 2
 FB_INTEGRATOR_VOLUME_CONSERVING, FB_INTEGRATOR_NEWMARK = 0, 1
+FB_RENUMBER_AUTO, FB_RENUMBER_ON, FB_RENUMBER_OFF = 0, 1, -1
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
@@ -36,7 +37,7 @@ class FemParams(C.Structure):
     _fields_ = [("E", C.c_double), ("nu", C.c_double), ("rho", C.c_double), ("timestep", C.c_double),
                 ("damping_mass", C.c_double), ("damping_stiffness", C.c_double), ("cg_eps", C.c_double),
                 ("cg_max_iter", C.c_int), ("matrix_precision", C.c_int), ("device", C.c_int),
-                ("pcg_variant", C.c_int), ("spmv_kernel", C.c_int), ("linear", C.c_int), ("exact_tangent", C.c_int), ("integrator", C.c_int)]
+                ("pcg_variant", C.c_int), ("spmv_kernel", C.c_int), ("linear", C.c_int), ("exact_tangent", C.c_int), ("integrator", C.c_int), ("renumber", C.c_int)]
 
 
 class StepInfo(C.Structure):
@@ -145,12 +146,16 @@ def lib():
         "fb_fem_assembly_kernel": (C.c_int, [vp]),
         "fb_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int, C.c_int, _ip]),
         "fb_plan_destroy": (C.c_int, [vp]),
+        "fb_plan_slab_order": (C.c_int, [C.c_int, _dp, C.c_int, _ip, _ip, _ip, _ip]),
         "fb_plan_info": (C.c_int, [vp, _ip]),
         "fb_plan_get": (C.c_int, [vp, C.c_char_p, _ip, C.c_size_t]),
     }
     poly_sig = {
         "fb_fem_transport": (C.c_int, [vp]),
         "fb_fem_set_exchange_mode": (C.c_int, [vp, C.c_int]),
+        "fb_fem_persist_rearms": (C.c_int, [vp]),
+        "fb_fem_renumbering": (C.c_int, [vp, _ip, _ip]),
+        "fb_fem_owned_nodes": (C.c_int, [vp, _ip]),
         "fb_fem_sharded_persist": (C.c_int, [vp]),
         "fb_fem_set_sharded_persist": (C.c_int, [vp, C.c_int]),
         "fb_fem_time_exchange": (C.c_int, [vp, C.c_int, _dp, _dp]),
@@ -168,6 +173,7 @@ def lib():
         "fb_poly_tetrahedralize": (C.c_int, [vp, C.POINTER(PolyCounts)]),
         "fb_poly_read_tetmesh": (C.c_int, [vp, _fp, _up]),
         "fb_poly_time_pipeline": (C.c_int, [vp, C.c_int, _dp, _dp]),
+        "fb_poly_time_stages": (C.c_int, [vp, C.c_int, _dp]),
         "fb_poly_surface": (C.c_int, [vp, C.POINTER(PolyCounts)]),
         "fb_poly_read_surface": (C.c_int, [vp, _fp, _fp, _up]),
         "fb_poly_cube_table": (C.c_int, [_bp, _bp]),

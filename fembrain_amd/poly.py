@@ -221,6 +221,12 @@ class GpuPoly:
         _l.check(self._L.fb_poly_time_pipeline(self.h, reps, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def time_stages(self, reps=5):
+        """device seconds of (sweep, classification + scans, tet-mesh vertices, tet elements, all four) with HIP events between them"""
+        out = np.zeros(5)
+        _l.check(self._L.fb_poly_time_stages(self.h, reps, _l.dptr(out)))
+        return tuple(float(x) for x in out)
+
 
 def slab_plan(planes, world, rank):
     """z-slab of rank `rank`: owned point planes [p0, p1), the slab to sweep [z_first, z_first + z_count) (one plane below,

@@ -89,7 +89,23 @@ typedef struct fb_fem_params {
                                  * to the tangent stiffness (f_int is that of warp = 1); costs 144 stored values per element.  0 = FemBrain's */
   int integrator;               /* FB_INTEGRATOR_VOLUME_CONSERVING (0, FemBrain's VolumeConservingIntegrator::DoTimestep) or
                                  * FB_INTEGRATOR_NEWMARK (ImplicitNewmarkSparse::DoTimestep, implicitNewmarkSparse.cpp:183-379) */
+  int renumber;                 /* FB_RENUMBER_AUTO (0) / FB_RENUMBER_ON / FB_RENUMBER_OFF: locality renumbering of the nodes inside the handle,
+                                 * see below.  FEMBRAIN_RENUMBER=0/1 in the environment overrides */
 } fb_fem_params;
+/* Node numbering.  FemBrain appends every node a cut creates at the end of the node list (deformable/VolMesh.cpp:1086-1091,
+ * 1639-1642) and its shipped tet meshes are TetGen outputs (surface vertices first): numberings in which a node's neighbours lie
+ * anywhere in the list.  The handle then works in an INTERNAL slab order of its own (nodes sorted by their rest position quantised
+ * to cells, longest axis of the bounding box first; fembrain_amd/csrc/renumber.h) and maps node ids on the way in and out: xyz,
+ * tets, constrained DOFs, forces, state and fb_fem_pattern / the block arrays in its order all stay in the CALLER's numbering
+ * (columns ascending in the caller's ids); elements keep their order.  Only the rounding of a row's sum in the SpMV changes with
+ * the order of its columns.  AUTO renumbers meshes of >= 8,192 nodes whose widest element (largest id difference inside a tet)
+ * exceeds min(32,767, nodes / 8) and keeps the caller's order when the slab order is not at least a quarter narrower.  On a sharded
+ * handle (fb_fem_create_sharded) the renumbering is opt-in (ON), needs the whole mesh on every rank, and the rank then owns a
+ * contiguous range of the INTERNAL order: fb_fem_owned_range reports that range, fb_fem_owned_nodes the caller ids in it, and the
+ * state / force arrays are read and written at those nodes' positions. */
+#define FB_RENUMBER_AUTO 0
+#define FB_RENUMBER_ON 1
+#define FB_RENUMBER_OFF (-1)
 #define FB_INTEGRATOR_VOLUME_CONSERVING 0
 #define FB_INTEGRATOR_NEWMARK 1
 #define FB_SPMV_ROWS 1
@@ -212,7 +228,12 @@ int fb_fem_floor_collision(fb_fem_t h, double floor_y, double restitution, int* 
 int fb_fem_num_nodes(fb_fem_t h);   /* global */
 int fb_fem_num_tets(fb_fem_t h);    /* local (all for an unsharded handle) */
 int fb_fem_num_blocks(fb_fem_t h);  /* 3x3 blocks of the stiffness pattern (owned rows) */
-int fb_fem_owned_range(fb_fem_t h, int lo_hi[2]);  /* the node range this handle owns ([0, n_nodes) when unsharded) */
+int fb_fem_owned_range(fb_fem_t h, int lo_hi[2]);  /* the node range this handle owns ([0, n_nodes) when unsharded); of the INTERNAL order when renumbered */
+/* 1 when the handle works in an internal node order; widest element (largest id difference inside a tet) in the caller's and in the
+ * internal order (equal when not renumbered; 0 when never measured: FB_RENUMBER_OFF).  Pointers may be NULL. */
+int fb_fem_renumbering(fb_fem_t h, int* span_caller, int* span_internal);
+/* caller ids of the nodes this handle owns, in internal order (hi - lo entries of fb_fem_owned_range; the identity range when not renumbered) */
+int fb_fem_owned_nodes(fb_fem_t h, int* ids);
 /* node-level pattern, ascending columns per row (corotationalLinearFEM.cpp:163-186, sparseMatrix.cpp:238-262):
  * bptr[n_owned+1], bcol[num_blocks] (global node ids) */
 int fb_fem_pattern(fb_fem_t h, int* bptr, int* bcol);
@@ -265,6 +286,11 @@ int fb_fem_persist_info(fb_fem_t h, int* waves_per_cu, int* workgroups, int* lds
  * ("k_pcg_pipe<float,c16,12,5>", "" when it has none) into name; persistent launches and fallbacks so far; the longest
  * producer list of a workgroup (-1: some workgroup polls all flags).  Any pointer may be NULL. */
 int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches, int* persist_fallbacks, int* max_producers);
+/* A handle whose persistent launch timed out runs the two-launch iteration, but not for ever: after 32 such solves (doubling with
+ * every further time-out; FEMBRAIN_PERSIST_REARM=n sets the first wait, 0 = never) an unsharded handle launches the persistent solver
+ * again, and every re-sync re-arms it (sharded handles: at a re-sync only, the ranks switch together).  Returns how often this handle
+ * was re-armed by the count. */
+int fb_fem_persist_rearms(fb_fem_t h);
 /* average device seconds of ONE persistent launch that starts a solve of the current system and is cut after n_iters
  * iterations (tolerance out of reach), HIP events on the handle's stream around the launch; the difference of two lengths
  * prices an iteration without the launch's fixed cost */
@@ -404,6 +430,10 @@ int fb_poly_off_surface(fb_poly_t h, float len, float* xyzf_pairs);
 int fb_poly_time_surface(fb_poly_t h, int reps, double* seconds);
 /* average device seconds of one sweep / one classify+tetrahedralize pipeline on the current grid */
 int fb_poly_time_pipeline(fb_poly_t h, int reps, double* sweep_seconds, double* pipeline_seconds);
+/* the same pipeline with HIP events between its stages (the events cost a little: fb_poly_time_pipeline is the rate to quote):
+ * average device seconds of [0] the sweep, [1] classification + scans, [2] tet-mesh vertices, [3] tet elements (the dominant kernel:
+ * 96 B written per included cell), [4] all of it */
+int fb_poly_time_stages(fb_poly_t h, int reps, double seconds[5]);
 
 /* Field grid -> tets -> FEM with no host hop: the tet mesh fb_poly_tetrahedralize left on the device becomes
  * the mesh of a new FEM handle -- node ids copied device to device, float positions widened to double, pattern / SELL-64

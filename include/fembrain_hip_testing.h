@@ -23,6 +23,10 @@ int fb_plan_info(fb_plan_t p, int info[12]);
  *        slot_coff, slot_ccnt, contrib (uint32 bits), dofmask (one int per DOF) */
 int fb_plan_get(fb_plan_t p, const char* name, int* out, size_t capacity);
 
+/* Host restatement of the handle's internal node order (fembrain_amd/csrc/renumber.h: slab order of the rest positions): the caller id of
+ * every internal id, and the widest element (largest id difference inside a tet) in the caller's and in that order */
+int fb_plan_slab_order(int n_nodes, const double* xyz, int n_tets, const int* tets, int* old_of_new, int* span_caller, int* span_internal);
+
 /* Host-staged communicator for tests: processes sharing ONE GPU (or none of them owning more than one) exchange through
  * the POSIX shared-memory segment `shm_name` with a process barrier per collective.  It drives exactly the sharded
  * solver path of fb_fem_create_sharded (halo lists, packing, rank-ordered sums) without RCCL, so the N > 1 path can be

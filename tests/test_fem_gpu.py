@@ -1005,13 +1005,17 @@ def test_16bit_column_differences_give_identical_iterates(gpu, monkeypatch):
     v2 = np.concatenate([v[:half], pad, v[half:]])
     t2 = np.where(t >= half, t + 40000, t).astype(np.int32)
     fixed2 = fixed_vertices_to_dofs(np.nonzero(v2[:, 0] < v[:, 0].min() + 1e-9)[0])
-    g2 = FemIntegrator(v2, t2, fixed2, spmv_kernel=fl.FB_SPMV_ROWS)
+    g2 = FemIntegrator(v2, t2, fixed2, spmv_kernel=fl.FB_SPMV_ROWS, renumber=fl.FB_RENUMBER_OFF)
 
     def index_bytes(g):
         n, nb = g.n_nodes, g.num_blocks()
         return (g.spmv_bytes() - (n + 1) * 4 - 24 * n - 96 * n) / nb - 36
 
     assert index_bytes(g2) == 4.0
+    # (round 4) left to itself the handle renumbers such a mesh (fembrain_amd/csrc/renumber.h) and the differences fit again
+    g4 = FemIntegrator(v2, t2, fixed2, spmv_kernel=fl.FB_SPMV_ROWS)
+    assert g4.renumbering()[0] and index_bytes(g4) == 2.0
+    g4.close()
     g3 = FemIntegrator(v, t, fixed, spmv_kernel=fl.FB_SPMV_ROWS)
     assert index_bytes(g3) == 2.0
     g2.set_uniform_force(1, -1000.0)
@@ -1293,11 +1297,44 @@ def test_persistent_solver_limits_are_refused_not_degraded(gpu, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("mask", ["0:128", "24:96", "5:64"])
+def test_plain_store_publish_does_not_trust_the_dispatch_order(gpu, monkeypatch, mask):
+    """workgroups whose consumers all share their XCD publish with plain stores (the line stays in the shared L2) -- but
+    which workgroups share an XCD is only OBSERVED to follow blockIdx & 7, and a CU-masked stream deals them otherwise.  The kernel
+    therefore asks the hardware (HW_REG_XCC_ID) and stores plainly only where every producer / consumer announced the same id.  With
+    plain stores forced on and the stream confined to odd sets of CUs the solve must be, bit for bit, the solve with write-through
+    stores only (the arithmetic is the same; a stale gather would change it)."""
+    n = 30
+    v, t, fixed = _cube(n)
+    monkeypatch.setenv("FEMBRAIN_CU_MASK", mask)
+    monkeypatch.setenv("FEMBRAIN_PERSIST_MIN_WAVES", "1")
+    out = []
+    for plain in ("1", "0"):
+        monkeypatch.setenv("FEMBRAIN_PIPE_PLAIN_STORES", plain)
+        g = FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT)
+        its = []
+        for _ in range(3):
+            g.set_uniform_force(1, -10000.0)
+            its.append(g.do_timestep())
+        assert g.pcg_path()["path"] == fl.FB_PCG_PATH_PERSISTENT and g.pcg_path()["fallbacks"] == 0
+        out.append((its, g.get_q_state()[0]))
+        g.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    monkeypatch.delenv("FEMBRAIN_CU_MASK")
+    ref = _two_launch(monkeypatch, v, t, fixed)
+    for _ in range(3):
+        ref.set_uniform_force(1, -10000.0)
+        ref.do_timestep()
+    assert np.abs(out[0][1] - ref.get_q_state()[0]).max() <= 2e-5 * np.abs(ref.get_q_state()[0]).max()
+    ref.close()
+
+
 def test_persistent_timeout_falls_back_visibly_or_fails_strictly(gpu):
     """A wait inside the persistent launch that times out (here: FEMBRAIN_PERSIST_TIMEOUT_MS tiny, read when the handle is made;
     in production: workgroups that are not all resident).  Non-strict: the step is repeated by the two-launch solver, the result is
     the two-launch result, fb_step_info says FALLBACK and counts it, the handle stays with the two-launch solver -- and a Newmark
-    step keeps its warm start.  Strict (FEMBRAIN_PERSIST_STRICT=1): FB_EDEVICE.  In subprocesses: the knobs are process-wide."""
+    step keeps its warm start.  Strict (FEMBRAIN_PERSIST_STRICT=1): FB_EDEVICE.  Re-arm (round 4): after FEMBRAIN_PERSIST_REARM clean
+    two-launch solves, or at a re-sync, the persistent solver is tried again.  In subprocesses: the knobs are process-wide."""
     import subprocess
     import sys
     code = r"""
@@ -1308,6 +1345,9 @@ from fembrain_amd import lib as fl
 from fembrain_amd.fem import FemIntegrator
 from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
 mode = sys.argv[1]
+L = fl.lib()
+if mode == "rearm":
+    os.environ["FEMBRAIN_PERSIST_REARM"] = "2"
 n = 40
 v, t = truth_cube(n, n, n, 0.1)
 fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
@@ -1320,6 +1360,32 @@ g = FemIntegrator(v, t, fixed, **kw)
 assert g.persist_info()[0] and not ref.persist_info()[0]
 for h in (ref, g):
     h.set_uniform_force(1, -10000.0)
+if mode == "rearm":
+    # round 4: the fallback is not for life.  After FEMBRAIN_PERSIST_REARM clean two-launch solves the handle launches the persistent
+    # solver again (with the time-out the environment holds THEN), and a re-sync re-arms it at once.
+    assert g.do_timestep() > 0 and g.last.pcg_path == fl.FB_PCG_PATH_FALLBACK and L.fb_fem_persist_rearms(g.h) == 0
+    os.environ["FEMBRAIN_PERSIST_TIMEOUT_MS"] = "50"
+    for k in range(2):
+        g.do_timestep()
+        assert g.last.pcg_path == fl.FB_PCG_PATH_TWO_LAUNCH and not g.persist_info()[0]
+    ref.do_timestep(); ref.do_timestep(); ref.do_timestep()
+    ir, ig = ref.do_timestep(), g.do_timestep()
+    assert g.last.pcg_path == fl.FB_PCG_PATH_PERSISTENT and g.persist_info()[0] and L.fb_fem_persist_rearms(g.h) == 1, (g.last.pcg_path, g.pcg_path())
+    assert abs(ir - ig) <= max(3, 0.02 * ir) and np.abs(ref.get_q_state()[0] - g.get_q_state()[0]).max() <= 2e-5 * np.abs(ref.get_q_state()[0]).max()
+    assert g.last.persist_fallbacks == 1
+    # a re-sync re-arms at once: time out again (tiny bound, read at the re-sync), fall back, re-sync with a sane bound
+    os.environ["FEMBRAIN_PERSIST_TIMEOUT_MS"] = "0.0001"
+    g.resync(v, t, fixed)
+    g.set_uniform_force(1, -10000.0)
+    g.do_timestep()
+    assert g.last.pcg_path == fl.FB_PCG_PATH_FALLBACK and g.last.persist_fallbacks == 2
+    os.environ["FEMBRAIN_PERSIST_TIMEOUT_MS"] = "50"
+    g.resync(v, t, fixed)
+    g.set_uniform_force(1, -10000.0)
+    g.do_timestep()
+    assert g.last.pcg_path == fl.FB_PCG_PATH_PERSISTENT and L.fb_fem_persist_rearms(g.h) == 1
+    print("REARM-OK")
+    sys.exit(0)
 if mode == "strict":
     os.environ["FEMBRAIN_PERSIST_STRICT"] = "1"
     try:
@@ -1340,11 +1406,13 @@ p = g.pcg_path()
 assert p["fallbacks"] == 1 and p["kernel"] == "" and not g.persist_info()[0]
 print("FALLBACK-OK", its)
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
-    for mode in ("fallback", "newmark", "strict"):
+    for mode in ("fallback", "newmark", "strict", "rearm"):
         r = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and ("STRICT-OK" if mode == "strict" else "FALLBACK-OK") in r.stdout, (mode, r.stdout[-2000:], r.stderr[-2000:])
+        assert r.returncode == 0 and {"strict": "STRICT-OK", "rearm": "REARM-OK"}.get(mode, "FALLBACK-OK") in r.stdout, (mode, r.stdout[-2000:], r.stderr[-2000:])
         if mode != "strict":
             assert "falls back to the two-launch iteration" in r.stderr
+        if mode == "rearm":
+            assert "re-armed after 2 two-launch solves" in r.stderr
 
 
 # ---- SURVEY 8f-4: exact tangent stiffness (warp = 2) and the Newmark step ---------------------------------------------------------

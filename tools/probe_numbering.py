@@ -56,6 +56,19 @@ def cases(n):
     new_of_old = np.empty(N, np.int64)
     new_of_old[order] = np.arange(N)
     yield "c_surface_first", *relabel(v, t, fx, new_of_old)
+    if os.environ.get("PROBE_DELAUNAY", "1") != "0":
+        # (d) an UNSTRUCTURED mesh: Delaunay tetrahedra of a jittered grid (no grid order to find again), nodes in random order
+        from scipy.spatial import Delaunay
+        m = max(8, int(round(n * 0.8)))
+        g = np.stack(np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float64)
+        pts = (g + rng.uniform(-0.35, 0.35, size=g.shape)) * 0.1
+        pts = pts[rng.permutation(len(pts))]
+        tt = Delaunay(pts).simplices.astype(np.int32)
+        vol = np.einsum("ij,ij->i", pts[tt[:, 1]] - pts[tt[:, 0]], np.cross(pts[tt[:, 2]] - pts[tt[:, 0]], pts[tt[:, 3]] - pts[tt[:, 0]])) / 6
+        tt = tt[np.abs(vol) > 1e-6 * 1e-3]
+        neg = vol[np.abs(vol) > 1e-6 * 1e-3] < 0
+        tt[neg] = tt[neg][:, [0, 2, 1, 3]]
+        yield "d_delaunay_jittered_random_order", pts, np.ascontiguousarray(tt), np.nonzero(pts[:, 0] < 0.1)[0].astype(np.int32)
 
 
 def main():
@@ -70,10 +83,15 @@ def main():
         its, us = [], []
         for _ in range(3):
             g.reset_to_rest()
-            g.set_uniform_force(1, -10000.0)
-            it = g.do_timestep()
+            g.set_uniform_force(1, -10.0 if name.startswith("d_") else -10000.0)
+            try:
+                it = g.do_timestep()
+            except fl.FbError as e:       # (a sliver mesh may not converge in 10,000 iterations: the time per iteration is what is asked)
+                row["note"] = str(e)[:80]
+                it = g.last.cg_iterations
             its.append(it)
             us.append(g.last.solve_seconds / max(it, 1) * 1e6)
+        row["renumbering"] = g.renumbering()
         row.update(iterations=its, us_per_iteration=[round(u, 2) for u in us], path=g.pcg_path(), persist=g.persist_info(),
                    spmv_mb=round(g.spmv_bytes() / 1e6, 1), spmv_us=round(g.time_spmv(50) * 1e6, 2),
                    assembly_us=round(g.time_assembly(10) * 1e6, 1), assembly_kernel=int(g._L.fb_fem_assembly_kernel(g.h)))
