@@ -794,6 +794,15 @@ def main():
             extra, why = stage("field bench", lambda: field_bench(device, cpu=not args.no_cpu_baseline), optional=True)
             if out is not None:
                 out.update(extra if extra else {"field_error": why})
+        # BASELINE configs 1-2 and the numbering leg, one GPU only (driver-timed, never part of `value`)
+        if world == 1 and args.workload == "cube56" and os.environ.get("FEMBRAIN_BENCH_SKIP_LEGS") != "1":
+            for key, wl in (("cube27", "cube27"), ("blob100k", "ventricle")):
+                leg, why = stage("leg: %s" % key, lambda wl=wl: small_leg(wl, device, prec, cpu=not args.no_cpu_baseline), optional=True)
+                if out is not None:
+                    out[key] = leg if leg else {"error": why}
+            leg, why = stage("leg: scrambled node order", lambda: numbering_leg(device, prec), optional=True)
+            if out is not None:
+                out["cube56_scrambled"] = leg if leg else {"error": why}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             _state["stage"] = "cpu baseline"
             try:
@@ -807,6 +816,7 @@ def main():
         if args.workload == "cube56" and os.environ.get("FEMBRAIN_BENCH_SKIP_8M") != "1":
             big, g8 = None, None
 
+            steps8 = max(2, int(os.environ.get("FEMBRAIN_BENCH_8M_STEPS", "5")))
             big_name = os.environ.get("FEMBRAIN_BENCH_BIG_WORKLOAD", "cube111")   # (rehearsals on one GPU: a mesh whose shards the sharded persistent solver takes)
 
             def create8():
@@ -864,7 +874,7 @@ def main():
                     barrier()
                     ts = time.perf_counter()
                     it8, solve8 = [], 0.0
-                    for k8 in range(2):
+                    for k8 in range(steps8):
                         if os.environ.get("FEMBRAIN_BENCH_INJECT_FAILURE") == "8m" and rank == world - 1 and k8 == 1:
                             raise RuntimeError("injected failure (rehearsal of the failure path)")
                         it8.append(one_step(g8))
@@ -881,8 +891,16 @@ def main():
                             spmv8 = g8.spmv_bytes() / g8.time_spmv(50) / 1e9
                         except Exception:  # noqa: BLE001
                             pass
-                    big = {"workload": WORKLOADS[big_name][1], "tets": int(ntets8), "steps": 2, "warmup": 1, "value": 2 / dt8, "unit": "steps/s",
-                           "ms_per_step": dt8 / 2 * 1e3, "cg_iterations": [int(i) for i in it8], "cg_iterations_per_step": float(np.mean(it8)),
+                    us_it_rank = solve8 / max(sum(it8), 1) * 1e6
+                    if dist_mode:   # every rank's own figure (solve seconds are device time on the rank's stream)
+                        tl = torch.zeros(world, dtype=torch.float64, device=tdev)
+                        tl[rank] = us_it_rank
+                        dist.all_reduce(tl, op=dist.ReduceOp.SUM)
+                        us_it_ranks = [float(x) for x in tl.cpu().tolist()]
+                    else:
+                        us_it_ranks = [us_it_rank]
+                    big = {"workload": WORKLOADS[big_name][1], "tets": int(ntets8), "steps": steps8, "warmup": 1, "value": steps8 / dt8, "unit": "steps/s",
+                           "ms_per_step": dt8 / steps8 * 1e3, "us_per_cg_iteration_per_rank": us_it_ranks, "cg_iterations": [int(i) for i in it8], "cg_iterations_per_step": float(np.mean(it8)),
                            "us_per_cg_iteration": solve8 / max(sum(it8), 1) * 1e6, "spmv_gbs": spmv8,
                            "pcg_kernel": (g8.pcg_path()["kernel"] if g8.last.pcg_path == fl.FB_PCG_PATH_PERSISTENT else "") or "two-launch iteration",
                            "pcg_path_last_step": int(g8.last.pcg_path), "sharded_persistent_trial": sp8}

@@ -60,6 +60,10 @@ struct fb_fem_s {
   DevBuf<double> xyz_in;               // the caller-order rest positions the order was derived from
   DevBuf<double> io;                   // staging of a caller-order vector on its way to / from the internal order
   bool x0_ready = false;               // build_plan_on_device has put the (permuted) rest positions in place already
+  bool masks_ready = false;            // ... and the constraint masks (device_constraint_masks)
+  std::vector<int> l2c;                // a renumbered SHARDED handle: caller id of every local node (owned, then halo); empty otherwise
+  unsigned long long order_sum = 0;    // ... and a checksum of the order, compared across the ranks
+  DevBuf<int> fixed_stage;
   std::vector<int> c_bptr, c_bcol, c_src;  // the pattern in the caller's numbering and the internal block behind each of its blocks (inspection entry points)
   bool caller_pattern = false;
   std::vector<double> x0_stage;  // host staging of the rest positions in local numbering (kept: a re-sync does not fault fresh pages)
@@ -476,9 +480,10 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
     } else {
       std::vector<double>& x0 = h->x0_stage;
       x0.resize((size_t)3 * P.n_local);
-      memcpy(x0.data(), xyz_global + 3 * (size_t)P.node_lo, sizeof(double) * 3 * (size_t)P.n_owned);  // owned nodes are a contiguous global range
-      for (int l = P.n_owned; l < P.n_local; l++)
-        for (int k = 0; k < 3; k++) x0[3 * (size_t)l + k] = xyz_global[3 * (size_t)P.local2global[l] + k];
+      const bool mapped = !h->l2c.empty();  // (renumbered: the owned nodes are a range of the INTERNAL order, anywhere in the caller's)
+      if (!mapped) memcpy(x0.data(), xyz_global + 3 * (size_t)P.node_lo, sizeof(double) * 3 * (size_t)P.n_owned);  // owned nodes are a contiguous global range
+      for (int l = mapped ? 0 : P.n_owned; l < P.n_local; l++)
+        for (int k = 0; k < 3; k++) x0[3 * (size_t)l + k] = xyz_global[3 * (size_t)(mapped ? h->l2c[l] : P.local2global[l]) + k];
       FB_TRY(h->x0.upload(x0, s));
     }
   }
@@ -488,7 +493,7 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   FB_TRY(h->rec.alloc((size_t)16 * P.n_tets * mt_size(h)));
   if (h->prm.exact_tangent && !h->prm.linear) FB_TRY(h->kcorr.alloc((size_t)144 * P.n_tets * mt_size(h)));
   else h->kcorr.release();
-  FB_TRY(upload_masks(h));
+  if (!h->masks_ready) FB_TRY(upload_masks(h));
   if (!P.send_local.empty()) FB_TRY(h->send_local.upload(P.send_local, s));
   FB_TRY(h->sendbuf.alloc(std::max<size_t>(1, (size_t)12 * P.send_local.size())));
   FB_TRY(h->vals.alloc((size_t)P.n_slots * 9 * 64 * mt_size(h)));
@@ -1270,6 +1275,11 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   if (n_nodes <= 0 || n_tets <= 0 || (!tets && !d_tets)) return fail(FB_EINVAL, "empty mesh (%d nodes, %d tets)", n_nodes, n_tets);
   if ((long long)n_tets >= (1LL << 28)) return fail(FB_EINVAL, "too many tets for the packed contribution word");
 
+  static const bool timing = getenv("FEMBRAIN_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (timing) fprintf(stderr, "[fembrain] device plan: %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  };
   FemPlan& P = h->plan;
   P = FemPlan();
   P.n_global = n_nodes; P.n_ranks = 1; P.rank = 0;
@@ -1287,6 +1297,7 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   } else {
     FB_TRY(h->tets.upload((const int4*)tets, (size_t)n_tets, h->stream));
   }
+  lap("elements uploaded");
   {
     // the internal node order (renumber.h): decided from the widest element, built from the rest positions
     bool want = false;
@@ -1305,13 +1316,17 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
         FB_TRY(relabel_tets(h->stream, n_tets, h->tets.p, n_nodes, h->ren.d_new_of_old.p));
         FB_TRY(h->x0.alloc((size_t)3 * n_nodes));
         FB_TRY(gather_nodes(h->stream, n_nodes, 3, h->xyz_in.p, h->ren.d_old_of_new.p, h->x0.p));
-        h->x0_ready = true;
-        P.local2global = h->ren.old_of_new;  // internal id -> the caller's
+        h->x0_ready = true;  // (P.local2global -- internal id -> the caller's -- is fetched when an inspection entry point asks: ensure_host_order)
       }
     }
     if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] node order: widest element %d -> %d (%s)\n", h->ren.span_before, h->ren.span_after, h->ren.active ? "renumbered" : "caller's order kept");
   }
-  FB_TRY(plan_set_constraints(P, n_fixed, fixed));
+  lap("node order");
+  // constraint masks on the device, in the internal order (host: 0.23 ms of loops and two uploads at 1M tets)
+  FB_TRY(device_constraint_masks(h->stream, n_nodes, n_fixed, fixed, h->ren.active ? h->ren.d_new_of_old.p : nullptr, h->fixed_stage, h->dofmask, h->nodemask));
+  P.n_fixed_owned = n_fixed;
+  h->masks_ready = true;
+  lap("constraints");
   DevicePlan D;
   D.slice_off = &h->slice_off; D.colidx = &h->colidx; D.slot_coff = &h->slot_coff; D.slot_ccnt = &h->slot_ccnt; D.contrib = &h->contrib;
   D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot; D.coldelta = &h->coldelta;
@@ -1354,7 +1369,7 @@ __global__ void __launch_bounds__(kBlock) k_tets_to_local(int n_tets, int4* __re
 // pass over the element list), then pattern / SELL-64 / contribution lists of the owned rows on the device -- the part that
 // took 68-75 ms per rank at 1M tets on the host.
 int build_shard_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed, int n_ranks, int rank,
-                               const int* splits) {
+                               const int* splits, const double* xyz) {
   FemPlan& P = h->plan;
   static const bool timing = getenv("FEMBRAIN_TIMING") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
@@ -1368,6 +1383,25 @@ int build_shard_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* 
   if (on_device) {
     FB_TRY(begin_fem_partition(P, n_nodes, n_tets, n_ranks, rank, splits));
     FB_TRY(h->tets.upload((const int4*)tets, (size_t)n_tets, h->stream));
+    if (renumber_mode(h) == FB_RENUMBER_ON) {
+      // Opt-in on a sharded handle (include/fembrain_hip.h, "Node numbering"): every rank derives the SAME internal order from the whole
+      // mesh, relabels its copy of the element list, and the ranks then own contiguous ranges of THAT order -- slabs of the body with
+      // two neighbours each, whatever the caller's numbering.  Everything below works on internal ids; l2c maps back at the ABI.
+      bool want = false;
+      FB_TRY(renumber_decide(h->stream, FB_RENUMBER_ON, n_nodes, n_tets, h->tets.p, h->plan_ws, h->ren, &want));
+      if (want) {
+        FB_TRY(h->xyz_in.reserve((size_t)3 * n_nodes));
+        FB_HIP(hipMemcpyAsync(h->xyz_in.p, xyz, sizeof(double) * 3 * (size_t)n_nodes, hipMemcpyHostToDevice, h->stream));
+        FB_TRY(renumber_build(h->stream, FB_RENUMBER_ON, n_nodes, n_tets, h->tets.p, h->xyz_in.p, h->plan_ws, h->ren));
+      }
+      if (h->ren.active) {
+        FB_TRY(relabel_tets(h->stream, n_tets, h->tets.p, n_nodes, h->ren.d_new_of_old.p));
+        FB_TRY(h->ren.host_maps(h->stream));
+        h->order_sum = 0;
+        for (int l = 0; l < n_nodes; l++) h->order_sum += (unsigned long long)(l + 1) * (unsigned long long)(h->ren.old_of_new[l] + 7);
+      }
+      lap("node order");
+    }
     DevicePartition dp;
     const int rc = device_partition(h->stream, n_tets, h->tets, n_nodes, n_ranks, rank, P.splits, dp, h->plan_ws);
     if (rc != FB_OK && dp.first_bad_tet >= 0) {  // say which node, as the host builder does
@@ -1387,7 +1421,21 @@ int build_shard_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* 
     FB_TRY(build_fem_partition(P, n_nodes, n_tets, tets, n_ranks, rank, splits, false));
   }
   lap(on_device ? "partition (device)" : "partition (host)");
-  FB_TRY(plan_set_constraints(P, n_fixed, fixed));
+  if (h->ren.active) {
+    // caller ids of the local nodes, and the constrained DOFs in internal ids (ascending again)
+    h->l2c.resize((size_t)P.n_local);
+    for (int l = 0; l < P.n_local; l++) h->l2c[l] = h->ren.old_of_new[P.local2global[l]];
+    for (int i = 0; i < n_fixed; i++) {
+      if (fixed[i] < 0 || fixed[i] >= 3 * n_nodes) return fail(FB_EINVAL, "constrained DOF %d out of range [0,%d)", fixed[i], 3 * n_nodes);
+      if (i && fixed[i] <= fixed[i - 1]) return fail(FB_EINVAL, "constrained DOFs must be strictly ascending (index %d)", i);
+    }
+    std::vector<int> mapped((size_t)n_fixed);
+    for (int i = 0; i < n_fixed; i++) mapped[i] = 3 * h->ren.new_of_old[fixed[i] / 3] + fixed[i] % 3;
+    std::sort(mapped.begin(), mapped.end());
+    FB_TRY(plan_set_constraints(P, n_fixed, mapped.data()));
+  } else {
+    FB_TRY(plan_set_constraints(P, n_fixed, fixed));
+  }
   lap("constraints");
   if (P.n_halo > 0) FB_TRY(d_halo.upload(P.local2global.data() + P.n_owned, (size_t)P.n_halo, h->stream));
   if (on_device) {
@@ -1433,7 +1481,10 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
           int rank, const int* splits, const DeviceTetMesh* dm = nullptr) {
   drop_graph(h);  // the buffers it refers to are about to be replaced
   h->ren.clear();
+  h->l2c.clear();
+  h->order_sum = 0;
   h->x0_ready = false;
+  h->masks_ready = false;
   h->caller_pattern = false;
   static const bool timing = getenv("FEMBRAIN_TIMING") != nullptr;  // development aid: where a (re)build spends its time
   const auto t0 = std::chrono::steady_clock::now();
@@ -1444,7 +1495,7 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
   h->device_plan = (want_device || dm) && (n_ranks == 1 || !dm);
   h->host_pattern = !h->device_plan;
   if (h->device_plan) {
-    const int rc = n_ranks > 1 ? build_shard_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits)
+    const int rc = n_ranks > 1 ? build_shard_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits, xyz)
                                : build_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, xyz, dm ? dm->tets : nullptr, dm ? dm->xyz : nullptr);
     if (dm && rc != FB_OK) return rc;
     if (rc == FB_ENOMEM) {  // no room for the sort's temporaries: the host builder needs none on the device
@@ -1452,7 +1503,10 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
       h->device_plan = false;
       h->host_pattern = true;
       h->ren.clear();  // (the host builder works in the caller's order)
+      h->l2c.clear();
+      h->order_sum = 0;
       h->x0_ready = false;
+      h->masks_ready = false;
     } else if (rc != FB_OK) {
       return rc;
     }
@@ -1564,6 +1618,18 @@ int attach_pipe_shard(fb_fem_s* h) {
   return FB_OK;
 }
 
+// collective: a renumbered sharded handle works only if every rank derived the same internal order (from the same whole mesh)
+int agree_on_node_order(fb_fem_s* h) {
+  if (!h->comm || h->comm->n_ranks < 2) return FB_OK;
+  const int R = h->comm->n_ranks;
+  std::vector<unsigned long long> sums((size_t)R);
+  FB_TRY(comm_allgather_bytes(h->comm, &h->order_sum, sums.data(), sizeof(unsigned long long), h->stream));
+  for (int q = 0; q < R; q++)
+    if (sums[q] != sums[0])
+      return fail(FB_EINVAL, "the ranks derived different node orders (FB_RENUMBER_ON on a sharded handle needs the WHOLE mesh -- all nodes, all elements -- on every rank, and the same setting)");
+  return FB_OK;
+}
+
 // collective: every rank of the communicator creates its handle at the same point of its program
 int attach_p2p(fb_fem_s* h) {
   const FemPlan& P = h->plan;
@@ -1645,6 +1711,7 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
       for (int q = 0; q < n_ranks && rc == FB_OK; q++)
         if (rcs[q] != FB_OK) rc = fail(rcs[q], "handle creation failed on rank %d (code %d)", q, rcs[q]);
       if (mine != FB_OK) { last_error() = why; rc = mine; }
+      if (rc == FB_OK) rc = agree_on_node_order(h);
     }
     if (rc == FB_OK && comm && comm->n_ranks > 1) rc = attach_p2p(h);
     if (rc == FB_OK && comm && comm->n_ranks > 1) rc = attach_pipe_shard(h);
@@ -1680,8 +1747,9 @@ int upload_global_vec(fb_fem_s* h, const double* g, DevBuf<double>& dst) {
     return FB_OK;
   }
   std::vector<double> loc((size_t)3 * P.n_local);
+  const int* ids = h->l2c.empty() ? P.local2global.data() : h->l2c.data();
   for (int l = 0; l < P.n_local; l++)
-    for (int k = 0; k < 3; k++) loc[3 * (size_t)l + k] = g[3 * (size_t)P.local2global[l] + k];
+    for (int k = 0; k < 3; k++) loc[3 * (size_t)l + k] = g[3 * (size_t)ids[l] + k];
   FB_HIP(hipMemcpyAsync(dst.p, loc.data(), sizeof(double) * loc.size(), hipMemcpyHostToDevice, h->stream));
   FB_HIP(hipStreamSynchronize(h->stream));
   return FB_OK;
@@ -1695,7 +1763,22 @@ int download_owned(fb_fem_s* h, const DevBuf<double>& src, double* g) {
     FB_TRY(gather_nodes(h->stream, P.n_local, 3, src.p, h->ren.d_new_of_old.p, h->io.p));
     return h->io.download(g, (size_t)3 * P.n_local, h->stream);
   }
+  if (!h->l2c.empty()) {  // a renumbered shard: its owned nodes lie anywhere in the caller's order
+    std::vector<double> loc((size_t)3 * P.n_owned);
+    FB_TRY(src.download(loc.data(), loc.size(), h->stream));
+    for (int l = 0; l < P.n_owned; l++)
+      for (int k = 0; k < 3; k++) g[3 * (size_t)h->l2c[l] + k] = loc[3 * (size_t)l + k];
+    return FB_OK;
+  }
   return src.download(g + 3 * (size_t)P.node_lo, (size_t)3 * P.n_owned, h->stream);
+}
+
+// host copies of the node maps of a renumbered handle (inspection entry points only)
+int ensure_host_order(fb_fem_s* h) {
+  if (!h->ren.active) return FB_OK;
+  FB_TRY(h->ren.host_maps(h->stream));
+  if (h->plan.n_ranks == 1) h->plan.local2global = h->ren.old_of_new;  // (a shard keeps its local -> internal map there, and l2c beside it)
+  return FB_OK;
 }
 
 // The pattern in the caller's numbering (renumbered handles): row g of the caller = internal row new_of_old[g], its columns mapped
@@ -1703,17 +1786,18 @@ int download_owned(fb_fem_s* h, const DevBuf<double>& src, double* g) {
 int ensure_caller_pattern(fb_fem_s* h) {
   FB_TRY(ensure_host_pattern(h));
   if (h->caller_pattern) return FB_OK;
-  FB_TRY(h->ren.host_new_of_old(h->stream));
+  FB_TRY(ensure_host_order(h));
   const FemPlan& P = h->plan;
   h->c_bptr.assign((size_t)P.n_owned + 1, 0);
   h->c_bcol.resize((size_t)P.n_blocks);
   h->c_src.resize((size_t)P.n_blocks);
   std::vector<std::pair<int, int>> row;
   int at = 0;
+  const bool shard = !h->l2c.empty();  // (a renumbered shard: rows in the order of fb_fem_owned_nodes, columns in the caller's ids)
   for (int g = 0; g < P.n_owned; g++) {
-    const int a = h->ren.new_of_old[g];
+    const int a = shard ? g : h->ren.new_of_old[g];
     row.clear();
-    for (int p = P.bptr[a]; p < P.bptr[a + 1]; p++) row.emplace_back(P.local2global[P.bcol[p]], p);
+    for (int p = P.bptr[a]; p < P.bptr[a + 1]; p++) row.emplace_back(shard ? h->l2c[P.bcol[p]] : P.local2global[P.bcol[p]], p);
     std::sort(row.begin(), row.end());
     for (const auto& e : row) { h->c_bcol[at] = e.first; h->c_src[at] = e.second; at++; }
     h->c_bptr[(size_t)g + 1] = at;
@@ -1741,7 +1825,7 @@ int download_blocks(fb_fem_s* h, double* out) {
     for (size_t i = 0; i < n; i++) host[i] = hf[i];
     for (size_t i = 0; i < nl; i++) lo[i] = lf[i];
   }
-  const bool mapped = P.n_ranks == 1 && h->ren.active;
+  const bool mapped = h->ren.active;
   std::vector<double> internal;
   if (mapped) {
     FB_TRY(ensure_caller_pattern(h));
@@ -1895,6 +1979,7 @@ static int resync_sharded(fb_fem_t h, int n_nodes, const double* xyz, int n_tets
         return fail(rcs[q], "re-sync failed on rank %d (code %d); this rank's handle is unusable until a re-sync succeeds on every rank", q, rcs[q]);
   }
   if (rc_mine != FB_OK) { last_error() = why_mine; return rc_mine; }
+  FB_TRY(agree_on_node_order(h));
   const int mode = h->xch_mode;
   if (h->p2p) { p2p_detach(h->p2p); h->p2p = nullptr; }
   if (h->comm && h->comm->n_ranks > 1) FB_TRY(attach_p2p(h));
@@ -2096,6 +2181,9 @@ int fb_fem_get_state(fb_fem_t h, double* q, double* qvel, double* qaccel) {
   if (q) FB_TRY(download_owned(h, h->q, q));
   if (qvel) FB_TRY(download_owned(h, h->qvel, qvel));
   if (qaccel && h->prm.integrator == FB_INTEGRATOR_NEWMARK) FB_TRY(download_owned(h, h->qacc, qaccel));
+  else if (qaccel && !h->l2c.empty()) {
+    for (int l = 0; l < h->plan.n_owned; l++) memset(qaccel + 3 * (size_t)h->l2c[l], 0, 3 * sizeof(double));
+  } else if (qaccel && h->ren.active) memset(qaccel, 0, sizeof(double) * 3 * (size_t)h->plan.n_global);
   else if (qaccel) memset(qaccel + 3 * (size_t)h->plan.node_lo, 0, sizeof(double) * 3 * (size_t)h->plan.n_owned);  // forced 0, PS_VolumeConservingIntegrator.cpp:55
   return FB_OK;
 }
@@ -2159,8 +2247,24 @@ int fb_fem_set_cg(fb_fem_t h, double eps, int max_iter) {
 int fb_fem_set_constrained_dofs(fb_fem_t h, int n_fixed_dofs, const int* fixed_dofs) {
   CHECK_HANDLE(h);
   if (n_fixed_dofs < 0 || (n_fixed_dofs > 0 && !fixed_dofs)) return fail(FB_EINVAL, "bad constrained DOF list");
-  FB_TRY(plan_set_constraints(h->plan, n_fixed_dofs, fixed_dofs));
-  FB_TRY(upload_masks(h));
+  if (h->device_plan && h->plan.n_ranks == 1) {
+    FB_TRY(device_constraint_masks(h->stream, h->plan.n_global, n_fixed_dofs, fixed_dofs, h->ren.active ? h->ren.d_new_of_old.p : nullptr, h->fixed_stage, h->dofmask, h->nodemask));
+    h->plan.n_fixed_owned = n_fixed_dofs;
+  } else if (!h->l2c.empty()) {  // a renumbered shard: the list in internal ids, ascending again
+    const int r = 3 * h->plan.n_global;
+    for (int i = 0; i < n_fixed_dofs; i++) {
+      if (fixed_dofs[i] < 0 || fixed_dofs[i] >= r) return fail(FB_EINVAL, "constrained DOF %d out of range [0,%d)", fixed_dofs[i], r);
+      if (i && fixed_dofs[i] <= fixed_dofs[i - 1]) return fail(FB_EINVAL, "constrained DOFs must be strictly ascending (index %d)", i);
+    }
+    std::vector<int> mapped((size_t)n_fixed_dofs);
+    for (int i = 0; i < n_fixed_dofs; i++) mapped[i] = 3 * h->ren.new_of_old[fixed_dofs[i] / 3] + fixed_dofs[i] % 3;
+    std::sort(mapped.begin(), mapped.end());
+    FB_TRY(plan_set_constraints(h->plan, n_fixed_dofs, mapped.data()));
+    FB_TRY(upload_masks(h));
+  } else {
+    FB_TRY(plan_set_constraints(h->plan, n_fixed_dofs, fixed_dofs));
+    FB_TRY(upload_masks(h));
+  }
   h->system_valid = false;
   return FB_OK;
 }
@@ -2219,7 +2323,7 @@ int fb_fem_pattern(fb_fem_t h, int* bptr, int* bcol) {
   FB_HIP(hipSetDevice(h->prm.device));
   FB_TRY(ensure_host_pattern(h));
   const FemPlan& P = h->plan;
-  if (P.n_ranks == 1 && h->ren.active) {
+  if (h->ren.active) {
     FB_TRY(ensure_caller_pattern(h));
     memcpy(bptr, h->c_bptr.data(), sizeof(int) * (P.n_owned + 1));
     memcpy(bcol, h->c_bcol.data(), sizeof(int) * (size_t)P.n_blocks);
@@ -2227,6 +2331,16 @@ int fb_fem_pattern(fb_fem_t h, int* bptr, int* bcol) {
   }
   memcpy(bptr, P.bptr.data(), sizeof(int) * (P.n_owned + 1));
   for (int p = 0; p < P.n_blocks; p++) bcol[p] = P.local2global[P.bcol[p]];
+  return FB_OK;
+}
+
+int fb_fem_halo_info(fb_fem_t h, int* n_halo_nodes, int* n_neighbour_ranks) {
+  if (!h) return fail(FB_EINVAL, "null FEM handle");
+  const FemPlan& P = h->plan;
+  if (n_halo_nodes) *n_halo_nodes = P.n_local - P.n_owned;
+  int nb = 0;
+  for (int q = 0; q + 1 < (int)P.halo_off.size(); q++) nb += P.halo_off[q + 1] > P.halo_off[q] ? 1 : 0;
+  if (n_neighbour_ranks) *n_neighbour_ranks = nb;
   return FB_OK;
 }
 
@@ -2239,8 +2353,10 @@ int fb_fem_renumbering(fb_fem_t h, int* span_caller, int* span_internal) {
 
 int fb_fem_owned_nodes(fb_fem_t h, int* ids) {
   if (!h || !ids) return fail(FB_EINVAL, "null argument");
+  FB_HIP(hipSetDevice(h->prm.device));
+  FB_TRY(ensure_host_order(h));
   const FemPlan& P = h->plan;
-  for (int l = 0; l < P.n_owned; l++) ids[l] = P.local2global[l];
+  for (int l = 0; l < P.n_owned; l++) ids[l] = h->l2c.empty() ? P.local2global[l] : h->l2c[l];
   return FB_OK;
 }
 
@@ -2325,7 +2441,7 @@ int fb_fem_mass(fb_fem_t h, double* m_blocks) {
   const FemPlan& P = h->plan;
   std::vector<double> host((size_t)P.n_slots * 64);
   FB_TRY(h->mblk.download(host.data(), host.size(), h->stream));
-  const bool mapped = P.n_ranks == 1 && h->ren.active;
+  const bool mapped = h->ren.active;
   std::vector<double> internal;
   if (mapped) {
     FB_TRY(ensure_caller_pattern(h));

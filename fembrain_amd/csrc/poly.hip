@@ -2181,23 +2181,23 @@ int fb_poly_time_stages(fb_poly_t h, int reps, double seconds[5]) {
   const long long words = (G.n_points + 63) / 64;
   const int pb = (int)std::min<long long>((G.n_points + kPB - 1) / kPB, std::max<long long>(1, (words + 15) / 16));  // (do_emit's grid)
   for (int r = 0; r < reps && rc == FB_OK; r++) {
-    hipEventRecord(ev[0], h->stream);
+    (void)hipEventRecord(ev[0], h->stream);
     rc = do_sweep(h, true);
-    hipEventRecord(ev[1], h->stream);
+    (void)hipEventRecord(ev[1], h->stream);
     if (rc == FB_OK) rc = do_classify(h);
-    hipEventRecord(ev[2], h->stream);
+    (void)hipEventRecord(ev[2], h->stream);
     hipLaunchKernelGGL(k_tet_vertices, dim3(pb), dim3(kPB), 0, h->stream, G, h->vinc.p, h->vbase.p, h->tv.p);
-    hipEventRecord(ev[3], h->stream);
+    (void)hipEventRecord(ev[3], h->stream);
     hipLaunchKernelGGL(k_tet_elements, dim3(pb), dim3(kPB), 0, h->stream, G, h->cinc.p, h->cbase.p, h->vinc.p, h->vbase.p, h->tt.p);
-    hipEventRecord(ev[4], h->stream);
+    (void)hipEventRecord(ev[4], h->stream);
     if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail(FB_EDEVICE, "stage timing failed"); break; }
     for (int k = 0; k < 4; k++) {
       float ms = 0;
-      hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+      (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
       acc[k] += ms * 1e-3;
     }
     float ms = 0;
-    hipEventElapsedTime(&ms, ev[0], ev[4]);
+    (void)hipEventElapsedTime(&ms, ev[0], ev[4]);
     acc[4] += ms * 1e-3;
   }
   for (auto& e : ev) (void)hipEventDestroy(e);

@@ -58,8 +58,9 @@ struct Renumbering {
   int span_before = 0, span_after = 0;      // widest element before / after (span_after = span_before when inactive)
   double mean_before = 0, mean_after = 0;   // mean width of an element before / after
   DevBuf<int> d_old_of_new, d_new_of_old;   // internal id -> caller id and back
-  std::vector<int> old_of_new, new_of_old;  // host copies: old_of_new with the build, new_of_old on demand
-  int host_new_of_old(hipStream_t s);
+  std::vector<int> old_of_new, new_of_old;  // host copies, fetched on demand (inspection entry points)
+  int n = 0;
+  int host_maps(hipStream_t s);
   void clear() { active = false; span_before = span_after = 0; mean_before = mean_after = 0; old_of_new.clear(); new_of_old.clear(); }
 };
 
@@ -75,6 +76,12 @@ int relabel_tets(hipStream_t s, int n_tets, int4* d_tets, int n_nodes, const int
 // node-wise permutations of arrays of `width` doubles per node: dst[l] = src[map[l]] / dst[map[l]] = src[l]
 int gather_nodes(hipStream_t s, int n, int width, const double* src, const int* map, double* dst);
 int scatter_nodes(hipStream_t s, int n, int width, const double* src, const int* map, double* dst);
+
+// Constraint masks of an unsharded handle built on the device: dofmask (1 free / 0 constrained per DOF) and nodemask (the three bytes of a
+// node as bits 0..2) in the INTERNAL order from the caller's ascending list of constrained DOFs (IntegratorBaseSparse::setConstrainedDOF's
+// argument; validated here as fem_plan.cpp's plan_set_constraints validates it).  d_new_of_old: nullptr = identity.
+int device_constraint_masks(hipStream_t s, int n_nodes, int n_fixed, const int* fixed_dofs, const int* d_new_of_old, DevBuf<int>& stage, DevBuf<unsigned char>& dofmask,
+                            DevBuf<unsigned char>& nodemask);
 
 // the same on the host (fb_plan_* test entry points, CPU tests): old_of_new of the slab order, spans under both orders
 int host_slab_order(int n_nodes, const double* xyz, int n_tets, const int* tets, std::vector<int>& old_of_new, int* span_before, int* span_after, double* mean_before = nullptr,

@@ -220,17 +220,55 @@ int renumber_build(hipStream_t s, int mode, int n_nodes, int n_tets, const int4*
   // AUTO keeps the new order only if the elements get a quarter narrower ON AVERAGE (the widest one may be an outlier -- a sliver on the
   // hull of a Delaunay mesh joins nodes a body apart in any order); ON keeps it
   if (mode != FB_RENUMBER_ON && R.mean_after * 4.0 > R.mean_before * 3.0) { R.span_after = R.span_before; R.mean_after = R.mean_before; return FB_OK; }
-  R.old_of_new.resize((size_t)n_nodes);
-  FB_TRY(R.d_old_of_new.download(R.old_of_new.data(), (size_t)n_nodes, s));
-  R.new_of_old.clear();  // (fetched when an inspection entry point asks: Renumbering::host_new_of_old)
+  R.old_of_new.clear();  // (the host copies are fetched when an inspection entry point asks: Renumbering::host_maps)
+  R.new_of_old.clear();
+  R.n = n_nodes;
   R.active = true;
   return FB_OK;
 }
 
-int Renumbering::host_new_of_old(hipStream_t s) {
-  if (!active || new_of_old.size() == old_of_new.size()) return FB_OK;
-  new_of_old.resize(old_of_new.size());
-  return d_new_of_old.download(new_of_old.data(), new_of_old.size(), s);
+int Renumbering::host_maps(hipStream_t s) {
+  if (!active || (int)new_of_old.size() == n) return FB_OK;
+  old_of_new.resize((size_t)n);
+  new_of_old.resize((size_t)n);
+  FB_TRY(d_old_of_new.download(old_of_new.data(), (size_t)n, s));
+  return d_new_of_old.download(new_of_old.data(), (size_t)n, s);
+}
+
+namespace {
+__global__ __launch_bounds__(kB) void k_fix_dofs(int n_fixed, const int* __restrict__ fixed, const int* __restrict__ new_of_old, unsigned char* __restrict__ dofmask) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n_fixed) return;
+  const int d = fixed[i], node = d / 3;
+  dofmask[3 * (size_t)(new_of_old ? new_of_old[node] : node) + (d - 3 * node)] = 0;
+}
+__global__ __launch_bounds__(kB) void k_node_masks(int n, const unsigned char* __restrict__ dofmask, unsigned char* __restrict__ nodemask) {
+  const int l = blockIdx.x * kB + threadIdx.x;
+  if (l >= n) return;
+  nodemask[l] = (unsigned char)((dofmask[3 * (size_t)l] ? 1 : 0) | (dofmask[3 * (size_t)l + 1] ? 2 : 0) | (dofmask[3 * (size_t)l + 2] ? 4 : 0));
+}
+}  // namespace
+
+int device_constraint_masks(hipStream_t s, int n_nodes, int n_fixed, const int* fixed_dofs, const int* d_new_of_old, DevBuf<int>& stage, DevBuf<unsigned char>& dofmask,
+                            DevBuf<unsigned char>& nodemask) {
+  const int r = 3 * n_nodes;
+  for (int i = 0; i < n_fixed; i++) {
+    if (fixed_dofs[i] < 0 || fixed_dofs[i] >= r) return fail(FB_EINVAL, "constrained DOF %d out of range [0,%d)", fixed_dofs[i], r);
+    if (i && fixed_dofs[i] <= fixed_dofs[i - 1]) return fail(FB_EINVAL, "constrained DOFs must be strictly ascending (index %d)", i);
+  }
+  FB_TRY(dofmask.alloc((size_t)r));
+  FB_TRY(nodemask.alloc((size_t)n_nodes));
+  FB_HIP(hipMemsetAsync(dofmask.p, 1, (size_t)r, s));
+  if (n_fixed > 0) {
+    FB_TRY(stage.reserve((size_t)n_fixed));
+    FB_HIP(hipMemcpyAsync(stage.p, fixed_dofs, sizeof(int) * (size_t)n_fixed, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_fix_dofs, dim3((unsigned)((n_fixed + kB - 1) / kB)), dim3(kB), 0, s, n_fixed, stage.p, d_new_of_old, dofmask.p);
+    FB_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_node_masks, dim3((unsigned)((n_nodes + kB - 1) / kB)), dim3(kB), 0, s, n_nodes, dofmask.p, nodemask.p);
+  FB_HIP(hipGetLastError());
+  FB_HIP(hipStreamSynchronize(s));  // (the caller's list may go away)
+  return FB_OK;
 }
 
 int relabel_tets(hipStream_t s, int n_tets, int4* d_tets, int n_nodes, const int* d_new_of_old) {

@@ -115,6 +115,12 @@ class FemIntegrator:
         _l.check(self._L.fb_fem_owned_nodes(self.h, _l.iptr(ids)))
         return ids
 
+    def halo_info(self):
+        """(halo nodes, neighbour ranks) of a sharded handle"""
+        a, b = C.c_int(0), C.c_int(0)
+        _l.check(self._L.fb_fem_halo_info(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def sharded_persist(self):
         """True when this sharded handle's solves run inside the sharded persistent launches (FEMBRAIN_SHARDED_PERSIST=1)."""
         return bool(self._L.fb_fem_sharded_persist(self.h))

@@ -156,6 +156,7 @@ def lib():
         "fb_fem_persist_rearms": (C.c_int, [vp]),
         "fb_fem_renumbering": (C.c_int, [vp, _ip, _ip]),
         "fb_fem_owned_nodes": (C.c_int, [vp, _ip]),
+        "fb_fem_halo_info": (C.c_int, [vp, _ip, _ip]),
         "fb_fem_sharded_persist": (C.c_int, [vp]),
         "fb_fem_set_sharded_persist": (C.c_int, [vp, C.c_int]),
         "fb_fem_time_exchange": (C.c_int, [vp, C.c_int, _dp, _dp]),

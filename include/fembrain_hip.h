@@ -232,6 +232,8 @@ int fb_fem_owned_range(fb_fem_t h, int lo_hi[2]);  /* the node range this handle
 /* 1 when the handle works in an internal node order; widest element (largest id difference inside a tet) in the caller's and in the
  * internal order (equal when not renumbered; 0 when never measured: FB_RENUMBER_OFF).  Pointers may be NULL. */
 int fb_fem_renumbering(fb_fem_t h, int* span_caller, int* span_internal);
+/* a sharded handle's halo: nodes of other ranks its elements touch, and how many ranks own them (0, 0 when unsharded) */
+int fb_fem_halo_info(fb_fem_t h, int* n_halo_nodes, int* n_neighbour_ranks);
 /* caller ids of the nodes this handle owns, in internal order (hi - lo entries of fb_fem_owned_range; the identity range when not renumbered) */
 int fb_fem_owned_nodes(fb_fem_t h, int* ids);
 /* node-level pattern, ascending columns per row (corotationalLinearFEM.cpp:163-186, sparseMatrix.cpp:238-262):

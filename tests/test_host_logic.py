@@ -406,3 +406,43 @@ def test_local_communicator_bounds_its_waits_when_a_peer_leaves():
         os.unlink("/dev/shm" + name)
     except FileNotFoundError:
         pass
+
+
+def test_slab_order_finds_a_grid_again_and_gives_every_rank_two_neighbours():
+    """The handle's internal node order (fembrain_amd/csrc/renumber.h, host restatement fb_plan_slab_order): a grid in ANY
+    caller order gets its plane-by-plane order back (longest axis first), the widest element shrinks from ~the whole list to one plane,
+    and contiguous ranges of the new order are slabs -- at most two neighbour ranks each, where equal ranges of the caller's ids make
+    every rank a neighbour of every other (the reference appends cut nodes at the end of the list, VolMesh.cpp:1086-1091)."""
+    L = fl.lib()
+    v0, t0 = truth_cube(9, 14, 11, 0.1)
+    rng = np.random.default_rng(3)
+    m = rng.permutation(len(v0))
+    v = np.empty_like(v0)
+    v[m] = v0
+    t = np.ascontiguousarray(m[t0].astype(np.int32))
+    o = np.empty(len(v), np.int32)
+    a, b = C.c_int(0), C.c_int(0)
+    fl.check(L.fb_plan_slab_order(len(v), fl.dptr(v), len(t), fl.iptr(t), fl.iptr(o), C.byref(a), C.byref(b)))
+    assert sorted(o.tolist()) == list(range(len(v)))
+    # y (14 planes) is the longest axis, then z, then x
+    assert np.array_equal(v[o], v0[np.lexsort((v0[:, 0], v0[:, 2], v0[:, 1]))])
+    assert a.value > len(v) // 2 and b.value <= 9 * 11 + 11 + 1
+    new_of_old = np.empty(len(v), np.int64)
+    new_of_old[o] = np.arange(len(v))
+    t_int = np.ascontiguousarray(new_of_old[t].astype(np.int32))
+    for world in (2, 4, 7):
+        for tets, want_few in ((t, False), (t_int, True)):
+            worst = 0
+            for rank in range(world):
+                info, get, (_, h) = _plan(v, tets, [], world, rank)
+                worst = max(worst, int((np.diff(get("halo_off")) > 0).sum()))
+                L.fb_plan_destroy(h)
+            assert (worst <= 2) if want_few else (worst == world - 1), (world, want_few, worst)
+    # an already banded order is found again exactly: nothing to gain
+    fl.check(L.fb_plan_slab_order(len(v0), fl.dptr(v0), len(t0), fl.iptr(np.ascontiguousarray(t0)), fl.iptr(o), C.byref(a), C.byref(b)))
+    assert b.value <= a.value
+    # degenerate input: all nodes on one point -> the caller's order stands
+    z = np.zeros((5, 3))
+    tz = np.array([[0, 1, 2, 3]], np.int32)
+    fl.check(L.fb_plan_slab_order(5, fl.dptr(z), 1, fl.iptr(tz), fl.iptr(o[:5].copy()), C.byref(a), C.byref(b)))
+    assert a.value == b.value == 3

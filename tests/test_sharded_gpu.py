@@ -77,6 +77,135 @@ def test_sharded_ranks_on_one_gpu_match_the_unsharded_handle(gpu, world, variant
     _run_sharded(world, variant, p2p, 12)
 
 
+def _scrambled_cube(n):
+    from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
+    v0, t0 = truth_cube(n, n, n, 0.1)
+    m = np.random.default_rng(4).permutation(len(v0))
+    v = np.empty_like(v0)
+    v[m] = v0
+    t = np.ascontiguousarray(m[t0].astype(np.int32))
+    return v, t, fixed_vertices_to_dofs(np.sort(m[cube_fixed_plane_i0(n, n)]))
+
+
+def _renumbered_worker(rank, world, shm_name, n, p2p, q, subset):
+    try:
+        if p2p:
+            os.environ["FEMBRAIN_P2P"] = "1"
+            os.environ["FEMBRAIN_XCH_MODE"] = str(p2p)
+        from fembrain_amd import lib as fl
+        from fembrain_amd.fem import FemIntegrator
+        L = fl.lib()
+        comm = C.c_void_p()
+        fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
+        v, t, fixed = _scrambled_cube(n)
+        if subset and rank == world - 1:
+            t = np.ascontiguousarray(t[: len(t) // 2])      # NOT the whole mesh on this rank: the ranks must notice
+            v = v * np.array([1.0, 1.0, 0.5])
+        try:
+            g = FemIntegrator(v, t, fixed, shard=(world, rank, None, comm), renumber=fl.FB_RENUMBER_ON)
+        except fl.FbError as e:
+            q.put((rank, "refused: %s" % e, None, None, None, None))
+            return
+        on, sc, si = g.renumbering()
+        halo, nbr = g.halo_info()
+        own = g.owned_nodes()
+        f = np.zeros(g.r)
+        f[1::3] = -10000.0
+        f[0::3] = 300.0 * np.sin(v[:, 2] * 7.0)   # (a function of the position, not of the caller's id)
+        its = []
+        for _ in range(2):
+            g.set_external_forces(f)
+            its.append(g.do_timestep())
+        qq = g.get_q_state()[0]
+        bptr, bcol = g.pattern()
+        q.put((rank, its, (on, sc, si, halo, nbr), own, qq, (bptr, bcol)))
+        g.close()
+        L.fb_comm_destroy(comm)
+    except Exception as e:
+        q.put((rank, repr(e), None, None, None, None))
+        q.close()
+        q.join_thread()
+        os._exit(1)
+
+
+@pytest.mark.parametrize("world,p2p", [(2, 0), (3, 4), (4, 2)])
+def test_renumbered_shards_of_a_scrambled_cube_are_slabs_with_two_neighbours(gpu, world, p2p):
+    """SURVEY 8e / VERDICT r3 item 1: a cube whose node ids are a random permutation, cut into equal index ranges, makes every rank a
+    neighbour of every other with half the mesh as halo.  With FB_RENUMBER_ON every rank derives the same slab order from the whole
+    mesh and owns a contiguous range of THAT: at most two neighbour ranks, a halo of one or two grid planes, the ranks' owned nodes
+    partition the caller's ids, patterns come back in the caller's ids (ascending), and two steps gathered over the ranks equal the
+    unsharded handle's on the same caller mesh."""
+    import multiprocessing as mp
+    from fembrain_amd.fem import FemIntegrator
+    n = 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "/fembrain_test_%d_renum_%d_%d" % (os.getpid(), world, p2p)
+    procs = [ctx.Process(target=_renumbered_worker, args=(r, world, name, n, p2p, q, False)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=240))
+            assert res[-1][2] is not None, res[-1]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    v, t, fixed = _scrambled_cube(n)
+    g = FemIntegrator(v, t, fixed, renumber=0)
+    f = np.zeros(g.r)
+    f[1::3] = -10000.0
+    f[0::3] = 300.0 * np.sin(v[:, 2] * 7.0)
+    its = []
+    for _ in range(2):
+        g.set_external_forces(f)
+        its.append(g.do_timestep())
+    qs = g.get_q_state()[0]
+    gb, gc = g.pattern()
+    qg = np.zeros_like(qs)
+    seen = np.zeros(len(v), int)
+    for rank, rits, info, own, qq, (bptr, bcol) in res:
+        on, sc, si, halo, nbr = info
+        assert on and si <= n * n + n + 1 < sc
+        assert nbr <= 2 and halo <= 2 * (n * n + n + 1), (rank, halo, nbr)      # a slab: one neighbour below, one above
+        assert rits == res[0][1] and all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its))
+        seen[own] += 1
+        dofs = (3 * own[:, None] + np.arange(3)[None, :]).reshape(-1)
+        qg[dofs] = qq[dofs]
+        outside = np.setdiff1d(np.arange(3 * len(v)), dofs)
+        assert not qq[outside].any()                                         # a rank fills the entries of its own nodes only
+        for k, node in enumerate(own):                                       # its rows of the pattern, in the caller's ids, ascending
+            assert np.array_equal(bcol[bptr[k]:bptr[k + 1]], gc[gb[node]:gb[node + 1]])
+    assert (seen == 1).all()
+    assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
+    g.close()
+
+
+def test_renumbered_shards_refuse_ranks_that_hold_different_meshes(gpu):
+    """the internal order is derived per rank; ranks that were not given the same whole mesh derive different orders, and creation
+    fails on every rank alike instead of solving a scrambled system"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "/fembrain_test_%d_renum_bad" % os.getpid()
+    procs = [ctx.Process(target=_renumbered_worker, args=(r, 2, name, 10, 0, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(2):
+            res.append(q.get(timeout=240))
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert all(isinstance(r[1], str) and "refused" in r[1] and "different node orders" in r[1] for r in res), res
+
+
 @pytest.mark.parametrize("world,variant,p2p", [(2, 0, 0), (3, 0, 2), (2, 0, 3), (3, 0, 4), (2, 1, 4)])
 def test_sharded_ranks_with_the_row_kernel(gpu, world, variant, p2p):
     """small shards take the split SpMV by themselves (the tests above); the row kernel of large shards is forced here"""
