@@ -447,57 +447,25 @@ __device__ inline unsigned long long bwd_word(const unsigned long long* __restri
 
 // one-time per grid: bits of the points with ix == gx-1 / iy == gy-1 / iz == gz-1 and of the points inside the grid
 __global__ __launch_bounds__(kPB) void k_grid_masks(Grid G, unsigned long long* __restrict__ lastx, unsigned long long* __restrict__ lasty,
-                                                    unsigned long long* __restrict__ lastz, unsigned long long* __restrict__ valid) {
+                                                    unsigned long long* __restrict__ lastz, unsigned long long* __restrict__ valid,
+                                                    unsigned long long* __restrict__ firstx, unsigned long long* __restrict__ firsty,
+                                                    unsigned long long* __restrict__ firstz) {
   const long long gid = (long long)blockIdx.x * kPB + threadIdx.x;
-  bool lx = false, ly = false, lz = false, in = false;
+  bool lx = false, ly = false, lz = false, in = false, fx = false, fy = false, fz = false;
   if (gid < G.n_points) {
     const int gxy = G.g[0] * G.g[1];
     const int z = (int)(gid / gxy);
     const int rem = (int)(gid - (long long)z * gxy);
     const int y = rem / G.g[0], x = rem - y * G.g[0];
     lx = x == G.g[0] - 1; ly = y == G.g[1] - 1; lz = z == G.g[2] - 1; in = true;
+    fx = x == 0; fy = y == 0; fz = z == 0;
   }
   const unsigned long long bx = __ballot(lx), by = __ballot(ly), bz = __ballot(lz), bv = __ballot(in);
+  const unsigned long long ax = __ballot(fx), ay = __ballot(fy), az = __ballot(fz);
   if ((threadIdx.x & 63) == 0 && gid < ((G.n_points + 63) & ~63LL)) {
     lastx[gid >> 6] = bx; lasty[gid >> 6] = by; lastz[gid >> 6] = bz; valid[gid >> 6] = bv;
+    firstx[gid >> 6] = ax; firsty[gid >> 6] = ay; firstz[gid >> 6] = az;
   }
-}
-
-__global__ __launch_bounds__(kPB) void k_classify_bits(Grid G, long long nwords, const unsigned long long* __restrict__ inside,
-                                                       const unsigned long long* __restrict__ lastx, const unsigned long long* __restrict__ lasty,
-                                                       const unsigned long long* __restrict__ lastz, const unsigned long long* __restrict__ valid,
-                                                       unsigned long long* __restrict__ cinc, unsigned long long* __restrict__ crossx,
-                                                       unsigned long long* __restrict__ crossy, unsigned long long* __restrict__ crossz,
-                                                       unsigned int* __restrict__ cinc_pop, unsigned int* __restrict__ aux_pop) {
-  const long long w = (long long)blockIdx.x * kPB + threadIdx.x;
-  if (w >= nwords) return;
-  const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
-  const unsigned long long c0 = inside[w];
-  const unsigned long long cx = fwd_word(inside, nwords, w, 1), cy = fwd_word(inside, nwords, w, gx), cz = fwd_word(inside, nwords, w, gxy);
-  const unsigned long long cxy = fwd_word(inside, nwords, w, gx + 1), cxz = fwd_word(inside, nwords, w, gxy + 1),
-                           cyz = fwd_word(inside, nwords, w, gxy + gx), cxyz = fwd_word(inside, nwords, w, gxy + gx + 1);
-  const unsigned long long lx = lastx[w], ly = lasty[w], lz = lastz[w], vd = valid[w];
-  const unsigned long long cellok = vd & ~(lx | ly | lz);
-  const unsigned long long any = (c0 | cx | cy | cz | cxy | cxz | cyz | cxyz) & cellok;
-  const unsigned long long all = (c0 & cx & cy & cz & cxy & cxz & cyz & cxyz) & cellok;
-  const unsigned long long ex = (c0 ^ cx) & vd & ~lx, ey = (c0 ^ cy) & vd & ~ly, ez = (c0 ^ cz) & vd & ~lz;
-  cinc[w] = any; crossx[w] = ex; crossy[w] = ey; crossz[w] = ez;
-  cinc_pop[w] = (unsigned int)__popcll(any);
-  // two counters packed for the sum pass: crossed edges (low 16 bits: <= 192) and surface cells (high bits: <= 64)
-  aux_pop[w] = (unsigned int)(__popcll(ex) + __popcll(ey) + __popcll(ez)) | ((unsigned int)__popcll(any & ~all) << 16);
-}
-
-__global__ __launch_bounds__(kPB) void k_vertex_bits(Grid G, long long nwords, const unsigned long long* __restrict__ cinc,
-                                                     unsigned long long* __restrict__ vinc, unsigned int* __restrict__ vinc_pop) {
-  const long long w = (long long)blockIdx.x * kPB + threadIdx.x;
-  if (w >= nwords) return;
-  const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
-  // cinc is 0 at every invalid lower corner (last x / y / z), so the backward shifts cannot leak across rows or planes
-  const unsigned long long v = cinc[w] | bwd_word(cinc, nwords, w, 1) | bwd_word(cinc, nwords, w, gx) | bwd_word(cinc, nwords, w, gxy) |
-                               bwd_word(cinc, nwords, w, gx + 1) | bwd_word(cinc, nwords, w, gxy + 1) | bwd_word(cinc, nwords, w, gxy + gx) |
-                               bwd_word(cinc, nwords, w, gxy + gx + 1);
-  vinc[w] = v;
-  vinc_pop[w] = (unsigned int)__popcll(v);
 }
 
 // on-demand materialisation of the reference's per-item outputs for read-back: edge flags (X=4,Y=2,Z=1) per point and
@@ -542,6 +510,112 @@ __device__ inline unsigned int block_excl_scan256(unsigned int v, unsigned int* 
   for (int k = 0; k < w; k++) woff += sh[k];
   *total = sh[0] + sh[1] + sh[2] + sh[3];
   return woff + incl - v;
+}
+
+// ---- classification of a swept grid in TWO launches (round 4; rounds 1-3: k_classify_bits, k_vertex_bits and three scan launches.  A
+// single launch with the scans inside -- every workgroup posting tagged sums and adding up its predecessors' -- measured 33 us at
+// 256^3 against 8 + 4 here: a thousand workgroups spinning with uncached loads on the same 16 KB) ----
+// 66 bits of the bit array `a` from bit position B on (B may be negative or past the end: zeros there): lo = bits [B, B + 64), hi = the two after
+__device__ inline void window66(const unsigned long long* __restrict__ a, long long nwords, long long B, unsigned long long& lo, unsigned int& hi) {
+  const long long q = B >> 6;  // (floor: arithmetic shift)
+  const int r = (int)(B & 63);
+  const unsigned long long w0 = (q >= 0 && q < nwords) ? a[q] : 0ULL, w1 = (q + 1 >= 0 && q + 1 < nwords) ? a[q + 1] : 0ULL;
+  if (r == 0) { lo = w0; hi = (unsigned int)(w1 & 3ULL); return; }
+  lo = (w0 >> r) | (w1 << (64 - r));
+  unsigned long long h = w1 >> r;
+  if (r == 63) h |= ((q + 2 >= 0 && q + 2 < nwords) ? a[q + 2] : 0ULL) << 1;
+  hi = (unsigned int)(h & 3ULL);
+}
+
+// Per 64-point word w (bit i = grid point 64 w + i; a cell is addressed by its lower corner):
+//   cinc   config != 0: OR of `inside` over the cell's 8 corners, at valid lower corners      (Tetrahedralizer.cl:3-35)
+//   crossX/Y/Z  inside ^ inside(+1 / +gx / +gx gy), not on the last x / y / z                 (Polygonizer.cl:1353-1415)
+//   vinc   the point is a corner of an included cell = OR of `inside` over the points p + {-1,0,1}^3 that share a valid cell with p:
+//          per axis the offset +1 counts unless p is on the last plane of that axis, -1 unless on the first -- the dilation is separable,
+//          so no pass over cinc is needed (rounds 1-3 made vinc from cinc in a second kernel)   (TetMeshCells' marks, Tetrahedralizer.cl:39-64)
+// from nine 66-bit windows of `inside` (rows y-1, y, y+1 of planes z-1, z, z+1); per workgroup the four sums the ranks and totals are made of.
+__global__ __launch_bounds__(kPB) void k_classify(Grid G, long long nwords, const unsigned long long* __restrict__ inside,
+                                                  const unsigned long long* __restrict__ lastx, const unsigned long long* __restrict__ lasty,
+                                                  const unsigned long long* __restrict__ lastz, const unsigned long long* __restrict__ firstx,
+                                                  const unsigned long long* __restrict__ firsty, const unsigned long long* __restrict__ firstz,
+                                                  const unsigned long long* __restrict__ valid, unsigned long long* __restrict__ cinc,
+                                                  unsigned long long* __restrict__ crossx, unsigned long long* __restrict__ crossy,
+                                                  unsigned long long* __restrict__ crossz, unsigned long long* __restrict__ vinc,
+                                                  unsigned int* __restrict__ aux_pop, uint4* __restrict__ block_sums) {
+  __shared__ unsigned int sh[4];
+  const long long gx = G.g[0], gxy = (long long)G.g[0] * G.g[1];
+  const long long w = (long long)blockIdx.x * kPB + threadIdx.x;
+  unsigned int pc = 0, pv = 0, ne = 0, ns = 0;
+  if (w < nwords) {
+    const unsigned long long lx = lastx[w], ly = lasty[w], lz = lastz[w], fx = firstx[w], fy = firsty[w], fz = firstz[w], vd = valid[w];
+    unsigned long long any = 0ULL, all = ~0ULL, dil = 0ULL, c0 = 0ULL, cx = 0ULL, cy = 0ULL, cz = 0ULL;
+#pragma unroll
+    for (int oz = -1; oz <= 1; oz++)
+#pragma unroll
+      for (int oy = -1; oy <= 1; oy++) {
+        unsigned long long lo;
+        unsigned int hi;
+        window66(inside, nwords, 64 * w + oz * gxy + oy * gx - 1, lo, hi);
+        const unsigned long long left = lo, mid = (lo >> 1) | ((unsigned long long)(hi & 1u) << 63), right = (lo >> 2) | ((unsigned long long)hi << 62);
+        unsigned long long row = mid | (right & ~lx) | (left & ~fx);
+        if (oy > 0) row &= ~ly;
+        if (oy < 0) row &= ~fy;
+        if (oz > 0) row &= ~lz;
+        if (oz < 0) row &= ~fz;
+        dil |= row;
+        if (oy >= 0 && oz >= 0) { any |= mid | right; all &= mid & right; }
+        if (oy == 0 && oz == 0) { c0 = mid; cx = right; }
+        if (oy == 1 && oz == 0) cy = mid;
+        if (oy == 0 && oz == 1) cz = mid;
+      }
+    const unsigned long long cellok = vd & ~(lx | ly | lz);
+    any &= cellok; all &= cellok;
+    const unsigned long long ex = (c0 ^ cx) & vd & ~lx, ey = (c0 ^ cy) & vd & ~ly, ez = (c0 ^ cz) & vd & ~lz;
+    const unsigned long long v = dil & vd;
+    cinc[w] = any; crossx[w] = ex; crossy[w] = ey; crossz[w] = ez; vinc[w] = v;
+    ne = (unsigned int)(__popcll(ex) + __popcll(ey) + __popcll(ez)); ns = (unsigned int)__popcll(any & ~all);
+    aux_pop[w] = ne | (ns << 16);  // (the marching-cubes pass reads the crossed-edge count of the word from here)
+    pc = (unsigned int)__popcll(any); pv = (unsigned int)__popcll(v);
+  }
+  unsigned int tc, tv, te, ts;
+  block_excl_scan256(pc, &tc, sh);
+  block_excl_scan256(pv, &tv, sh);
+  block_excl_scan256(ne, &te, sh);
+  block_excl_scan256(ns, &ts, sh);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = make_uint4(tc, tv, te, ts);
+}
+
+// ranks: cbase[w] / vbase[w] = included cells / vertices in the words before w -- the sums of the workgroups before this one (plain
+// cached loads of at most 16 bytes x workgroups: the kernel boundary makes them final) plus the scan inside the workgroup; the
+// last workgroup leaves the totals ([0] crossed edges, [1] surface cells, [2] included cells, [3] tet vertices)
+__global__ __launch_bounds__(kPB) void k_ranks(long long nwords, const unsigned long long* __restrict__ cinc, const unsigned long long* __restrict__ vinc,
+                                               const uint4* __restrict__ block_sums, unsigned int* __restrict__ cbase, unsigned int* __restrict__ vbase,
+                                               unsigned int* __restrict__ totals) {
+  __shared__ unsigned int sh[4];
+  __shared__ unsigned int s_pre[4];
+  if (threadIdx.x < 4) s_pre[threadIdx.x] = 0u;
+  __syncthreads();
+  unsigned int acc[4] = {0u, 0u, 0u, 0u};
+  for (unsigned int j = threadIdx.x; j < blockIdx.x; j += kPB) {
+    const uint4 t = block_sums[j];
+    acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_xor(acc[q], off, 64);
+    if ((threadIdx.x & 63) == 0 && acc[q]) atomicAdd(&s_pre[q], acc[q]);
+  }
+  __syncthreads();
+  const long long w = (long long)blockIdx.x * kPB + threadIdx.x;
+  const unsigned int pc = w < nwords ? (unsigned int)__popcll(cinc[w]) : 0u, pv = w < nwords ? (unsigned int)__popcll(vinc[w]) : 0u;
+  unsigned int tc, tv;
+  const unsigned int ec = block_excl_scan256(pc, &tc, sh), ev = block_excl_scan256(pv, &tv, sh);
+  if (w < nwords) { cbase[w] = s_pre[0] + ec; vbase[w] = s_pre[1] + ev; }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    const uint4 mine = block_sums[blockIdx.x];
+    totals[0] = s_pre[2] + mine.z; totals[1] = s_pre[3] + mine.w; totals[2] = s_pre[0] + tc; totals[3] = s_pre[1] + tv;
+  }
 }
 
 // two independent scans share every launch: blockIdx.y picks the job
@@ -647,46 +721,90 @@ __device__ __forceinline__ unsigned int pick32(unsigned int v, int j) { return (
 
 constexpr int kRun = 62;  // mask words a wave prefetches at once: lane j holds word j of the run (and j + 1 for the row windows)
 
-// TetMeshVertices (Tetrahedralizer.cl:39-64): included grid points compacted in grid order, xyz = the sweep's positions.
-// One wavefront = one 64-point word of the included-vertex mask at a time: its output is the contiguous float range
-// [3*vbase[word], 3*(vbase[word]+popc)), staged in LDS and written with lane-contiguous stores.  The masks and bases of the
-// wave's whole run of words are fetched up front, one per lane, and picked with readlane inside the loop: with a load per
-// word in the loop the kernel was bound by that load's latency (40 us at 256^3 for 80 MB of output).
-__global__ __launch_bounds__(kPB) void k_tet_vertices(Grid G, const unsigned long long* __restrict__ vinc,
+// TetMeshVertices (Tetrahedralizer.cl:39-64): included grid points compacted in grid order, xyz = the sweep's positions: the
+// vertex of point p goes to rank vbase[p / 64] + popc(mask & lower bits).
+// Division of a grid index (< 2^31) by a grid extent without the ~25-instruction division sequence: n / d = mulhi(n, m) >> s with
+// m = floor(2^(31 + c) / d) + 1, s = c - 1, c = ceil(log2 d) (exact for n < 2^31: the error term n e / 2^(31 + c) is below 1 / d).
+// k_tet_vertices spent two thirds of its time in the two divisions per grid point (35 -> measured below at 256^3).
+struct FastDiv {
+  unsigned int mul, shift, one;  // one: d == 1
+};
+inline FastDiv fast_div(unsigned int d) {
+  FastDiv f = {0u, 0u, d <= 1u ? 1u : 0u};
+  if (d <= 1u) return f;
+  unsigned int c = 0;
+  while ((1ull << c) < d) c++;
+  f.mul = (unsigned int)(((1ull << (31 + c)) / d) + 1ull);
+  f.shift = c - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned int div_by(unsigned int n, const FastDiv f) { return f.one ? n : (__umulhi(n, f.mul) >> f.shift); }
+
+constexpr int kVW = 16;  // mask words (1,024 grid points) per workgroup of k_tet_vertices
+__global__ __launch_bounds__(kPB) void k_tet_vertices(Grid G, FastDiv dxy, FastDiv dx, const unsigned long long* __restrict__ vinc,
                                                       const unsigned int* __restrict__ vbase, float* __restrict__ xyz) {
-  __shared__ float stage[kPB / 64][64 * 3];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // Round 4: a WORKGROUP compacts kVW consecutive words of the mask: its vertices are one contiguous range of the output, staged in
+  // LDS at their rank inside the workgroup (one pass, one barrier) and streamed out by all 256 threads, 1 KB per store instruction --
+  // whole lines but for the two ends of the range.  Rounds 1-3 had every wavefront loop over its own words with an LDS round trip
+  // and two wave barriers per word (32-35 us at 256^3 for 80 MB); a thread per point storing its three floats directly (12-byte
+  // stride: three partial writes to every line) measured 38 us.
+  __shared__ float stage[kVW * 64 * 3];
+  __shared__ unsigned long long smask[kVW];
+  __shared__ unsigned int sbase[kVW + 1];
   const long long nwords = (G.n_points + 63) >> 6;
-  const long long nwaves = (long long)gridDim.x * (kPB / 64);
-  // each wave owns a CONTIGUOUS run of mask words, so neighbouring output ranges (which share cache lines at their
-  // 96-/12-byte-granular ends) are written by the same CU instead of by waves on different XCDs
-  const long long per = (nwords + nwaves - 1) / nwaves, wid = (long long)blockIdx.x * (kPB / 64) + wv;
-  const long long end = min((wid + 1) * per, nwords);
-  for (long long first = wid * per; first < end; first += kRun) {  // wave-uniform loops
-    const int cnt = (int)min((long long)kRun, end - first);
-    const unsigned long long my_mask = lane < cnt ? vinc[first + lane] : 0ULL;
-    const unsigned int my_base = lane < cnt ? vbase[first + lane] : 0u;
-    for (int j = 0; j < cnt; j++) {
-      const unsigned long long mask = pick64(my_mask, j);
-      if (mask == 0ULL) continue;
-      if ((mask >> lane) & 1ULL) {
-        const unsigned int g32 = (unsigned int)((first + j) * 64 + lane), gx = (unsigned int)G.g[0], gxy = gx * (unsigned int)G.g[1];
-        const unsigned int iz = g32 / gxy, rem = g32 - iz * gxy;
-        const unsigned int iy = rem / gx, ix = rem - iy * gx;
-        float* o = &stage[wv][3 * __popcll(mask & ((1ULL << lane) - 1ULL))];
-        o[0] = G.lo[0] + G.cellsize * (float)ix;
-        o[1] = G.lo[1] + G.cellsize * (float)iy;
-        o[2] = G.lo[2] + G.cellsize * (float)(iz + (unsigned int)G.z0);
+  const long long w0 = (long long)blockIdx.x * kVW;
+  if (threadIdx.x < kVW) {
+    const long long w = w0 + threadIdx.x;
+    smask[threadIdx.x] = w < nwords ? vinc[w] : 0ULL;
+    sbase[threadIdx.x] = w < nwords ? vbase[w] : 0u;
+  }
+  __syncthreads();
+  const unsigned int first = sbase[0];
+  const unsigned int gx = (unsigned int)G.g[0], gxy = gx * (unsigned int)G.g[1];
+  unsigned int total = 0;
+#pragma unroll
+  for (int k = 0; k < kVW * 64 / kPB; k++) {
+    const int local = k * kPB + threadIdx.x, wl = local >> 6, lane = local & 63;  // (a wavefront = one word)
+    const unsigned long long mask = smask[wl];
+    if (mask == 0ULL) continue;  // (wave-uniform)
+    // grid coordinates of the word's first point in scalar registers, the lane's from them (rows of at least 64 points: one carry per axis)
+    const unsigned int g0 = __builtin_amdgcn_readfirstlane((unsigned int)(w0 * 64) + (unsigned int)(local & ~63));
+    const unsigned int iz0 = div_by(g0, dxy), rem0 = g0 - iz0 * gxy;
+    const unsigned int iy0 = div_by(rem0, dx), ix0 = rem0 - iy0 * gx;
+    if ((mask >> lane) & 1ULL) {
+      unsigned int ix, iy, iz;
+      if (gx >= 64u) {
+        ix = ix0 + (unsigned int)lane;
+        const bool cx = ix >= gx;
+        ix -= cx ? gx : 0u;
+        iy = iy0 + (cx ? 1u : 0u);
+        const bool cy = iy >= (unsigned int)G.g[1];
+        iy -= cy ? (unsigned int)G.g[1] : 0u;
+        iz = iz0 + (cy ? 1u : 0u);
+      } else {
+        const unsigned int g32 = g0 + (unsigned int)lane;
+        iz = div_by(g32, dxy);
+        const unsigned int rem = g32 - iz * gxy;
+        iy = div_by(rem, dx);
+        ix = rem - iy * gx;
       }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      const int total = 3 * __popcll(mask);
-      float* out = xyz + 3 * (size_t)pick32(my_base, j);
-      for (int i = lane; i < total; i += 64) out[i] = stage[wv][i];
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      float* o = &stage[3 * (sbase[wl] - first + (unsigned int)__popcll(mask & ((1ULL << lane) - 1ULL)))];
+      o[0] = G.lo[0] + G.cellsize * (float)ix;
+      o[1] = G.lo[1] + G.cellsize * (float)iy;
+      o[2] = G.lo[2] + G.cellsize * (float)(iz + (unsigned int)G.z0);
     }
   }
+  // vertices of this workgroup: up to and including its last non-empty word
+  if (threadIdx.x == 0) {
+    unsigned int n = 0;
+    for (int k = kVW - 1; k >= 0; k--)
+      if (smask[k]) { n = sbase[k] - first + (unsigned int)__popcll(smask[k]); break; }
+    sbase[kVW] = n;
+  }
+  __syncthreads();
+  total = 3u * sbase[kVW];
+  float* out = xyz + 3 * (size_t)first;
+  for (unsigned int i = threadIdx.x; i < total; i += kPB) out[i] = stage[i];
 }
 
 // TetMeshElements (Tetrahedralizer.cl:67-132): 6 tets per included cell, corners LBN,LBF,LTN,LTF,RBN,RBF,RTN,RTF = 0..7.
@@ -1139,9 +1257,11 @@ struct fb_poly_s {
   int gz_total = 0;  // point planes of the whole grid this one is a slab of (= G.g[2] for a grid of its own)
   bool have_grid = false, classified = false, tetra = false, materialized = false;
   DevBuf<float4> grid;
-  DevBuf<unsigned long long> inside, cinc, vinc, lastx, lasty, lastz, valid, crossx, crossy, crossz;
+  DevBuf<unsigned long long> inside, cinc, vinc, lastx, lasty, lastz, valid, crossx, crossy, crossz, firstx, firsty, firstz;
+  DevBuf<uint4> block_sums;                // k_classify -> k_ranks: included cells, tet vertices, crossed edges, surface cells per workgroup
+  long long n_words = 0;
   DevBuf<unsigned char> config, flags;
-  DevBuf<unsigned int> cinc_pop, vinc_pop, aux_pop, cbase, vbase, csum, vsum, csum_aux;
+  DevBuf<unsigned int> aux_pop, cbase, vbase, vsum;
   DevBuf<unsigned int> totals;  // [0] crossed edges [1] surface cells [2] included cells [3] tet vertices
   DevBuf<float> tv;
   DevBuf<uint4> tt;
@@ -1591,18 +1711,16 @@ int set_grid(fb_poly_s* h, const float lo[3], float cellsize, const int dims[3],
   const size_t pw = (size_t)((G.n_points + 63) / 64);
   FB_TRY(h->grid.alloc((size_t)G.n_points));
   DevBuf<unsigned long long>* masks[] = {&h->inside, &h->cinc, &h->vinc, &h->lastx, &h->lasty, &h->lastz, &h->valid, &h->crossx, &h->crossy, &h->crossz,
-                                         &h->surf};
+                                         &h->surf, &h->firstx, &h->firsty, &h->firstz};
   for (auto* m : masks) FB_TRY(m->alloc(pw + 1));
-  FB_TRY(h->vinc_pop.alloc(pw));
+  h->n_words = (long long)pw;
   FB_TRY(h->vbase.alloc(pw));
-  FB_TRY(h->cinc_pop.alloc(pw));
   FB_TRY(h->cbase.alloc(pw));
   FB_TRY(h->aux_pop.alloc(pw));
   const size_t pch = (pw + kChunk - 1) / kChunk;
   if (pch > 16 * kPB) return fail(FB_EINVAL, "grid too large for the chunked scan");
-  FB_TRY(h->vsum.alloc(pch));
-  FB_TRY(h->csum.alloc(pch));
-  FB_TRY(h->csum_aux.alloc(2 * pch));
+  FB_TRY(h->vsum.alloc(pch));  // (sized per chunk: the surface pass's scans and the emission grids read its length)
+  FB_TRY(h->block_sums.alloc((pw + kPB - 1) / kPB));
   DevBuf<unsigned int>* words[] = {&h->edge_pop, &h->idx_pop, &h->ebase, &h->ibase};
   for (auto* m : words) FB_TRY(m->alloc(pw));
   FB_TRY(h->esum.alloc(pch));
@@ -1610,7 +1728,8 @@ int set_grid(fb_poly_s* h, const float lo[3], float cellsize, const int dims[3],
   FB_TRY(h->config.alloc((size_t)G.n_cells));
   FB_TRY(h->flags.alloc((size_t)G.n_points));
   FB_TRY(h->totals.alloc(6));
-  hipLaunchKernelGGL(k_grid_masks, dim3((int)((G.n_points + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, G, h->lastx.p, h->lasty.p, h->lastz.p, h->valid.p);
+  hipLaunchKernelGGL(k_grid_masks, dim3((int)((G.n_points + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, G, h->lastx.p, h->lasty.p, h->lastz.p, h->valid.p,
+                     h->firstx.p, h->firsty.p, h->firstz.p);
   FB_HIP(hipGetLastError());
   h->materialized = false;
   h->have_grid = h->classified = h->tetra = h->surfaced = false;
@@ -1619,18 +1738,11 @@ int set_grid(fb_poly_s* h, const float lo[3], float cellsize, const int dims[3],
 
 int do_classify(fb_poly_s* h) {
   const Grid& G = h->G;
-  const long long pw = (long long)h->vinc_pop.n;
-  const int wb = (int)((pw + kPB - 1) / kPB), pch = (int)h->vsum.n;
-  hipLaunchKernelGGL(k_classify_bits, dim3(wb), dim3(kPB), 0, h->stream, G, pw, h->inside.p, h->lastx.p, h->lasty.p, h->lastz.p, h->valid.p, h->cinc.p,
-                     h->crossx.p, h->crossy.p, h->crossz.p, h->cinc_pop.p, h->aux_pop.p);
-  hipLaunchKernelGGL(k_vertex_bits, dim3(wb), dim3(kPB), 0, h->stream, G, pw, h->cinc.p, h->vinc.p, h->vinc_pop.p);
-  // totals: [0] crossed edges, [1] surface cells (the two packed counters), [2] included cells, [3] tet vertices
-  ScanJobs jobs;
-  jobs.j[0] = ScanJob{h->cinc_pop.p, h->aux_pop.p, h->csum.p, h->csum_aux.p, h->cbase.p, h->totals.p + 2, h->totals.p + 0};
-  jobs.j[1] = ScanJob{h->vinc_pop.p, nullptr, h->vsum.p, nullptr, h->vbase.p, h->totals.p + 3, nullptr};
-  hipLaunchKernelGGL(k_chunk_sums, dim3(pch, 2), dim3(kPB), 0, h->stream, jobs, (int)pw);
-  hipLaunchKernelGGL(k_scan_chunks, dim3(2), dim3(kPB), 0, h->stream, jobs, pch);
-  hipLaunchKernelGGL(k_chunk_scan, dim3(pch, 2), dim3(kPB), 0, h->stream, jobs, (int)pw);
+  const long long pw = h->n_words;
+  const int nblk = (int)((pw + kPB - 1) / kPB);
+  hipLaunchKernelGGL(k_classify, dim3(nblk), dim3(kPB), 0, h->stream, G, pw, h->inside.p, h->lastx.p, h->lasty.p, h->lastz.p, h->firstx.p, h->firsty.p,
+                     h->firstz.p, h->valid.p, h->cinc.p, h->crossx.p, h->crossy.p, h->crossz.p, h->vinc.p, h->aux_pop.p, h->block_sums.p);
+  hipLaunchKernelGGL(k_ranks, dim3(nblk), dim3(kPB), 0, h->stream, pw, h->cinc.p, h->vinc.p, h->block_sums.p, h->cbase.p, h->vbase.p, h->totals.p);
   FB_HIP(hipGetLastError());
   h->materialized = false;
   return FB_OK;
@@ -1656,7 +1768,7 @@ int do_emit(fb_poly_s* h) {
   static const int emit_blocks = getenv("FB_EMIT_BLOCKS") ? atoi(getenv("FB_EMIT_BLOCKS")) : 0;  // tuning knob (development)
   const long long words = (G.n_points + 63) / 64;
   const int pb = (int)std::min<long long>((G.n_points + kPB - 1) / kPB, emit_blocks > 0 ? emit_blocks : std::max<long long>(1, (words + 15) / 16));
-  hipLaunchKernelGGL(k_tet_vertices, dim3(pb), dim3(kPB), 0, h->stream, G, h->vinc.p, h->vbase.p, h->tv.p);
+  hipLaunchKernelGGL(k_tet_vertices, dim3((unsigned)((((G.n_points + 63) >> 6) + kVW - 1) / kVW)), dim3(kPB), 0, h->stream, G, fast_div((unsigned int)G.g[0] * (unsigned int)G.g[1]), fast_div((unsigned int)G.g[0]), h->vinc.p, h->vbase.p, h->tv.p);
   FB_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_tet_elements, dim3(pb), dim3(kPB), 0, h->stream, G, h->cinc.p, h->cbase.p, h->vinc.p, h->vbase.p, h->tt.p);
   FB_HIP(hipGetLastError());
@@ -1666,7 +1778,7 @@ int do_emit(fb_poly_s* h) {
 // scans + emission of the marching-cubes surface; totals[4] = surface vertices, totals[5] = triangle indices
 int do_surface_counts(fb_poly_s* h) {
   const Grid& G = h->G;
-  const long long pw = (long long)h->vinc_pop.n;
+  const long long pw = h->n_words;
   const int wb = (int)((pw + kPB - 1) / kPB), pch = (int)h->vsum.n;
   hipLaunchKernelGGL(k_surface_pops, dim3(wb), dim3(kPB), 0, h->stream, G, pw, h->inside.p, h->lastx.p, h->lasty.p, h->lastz.p, h->valid.p, h->aux_pop.p,
                      h->d_nvert.p, h->surf.p, h->edge_pop.p, h->idx_pop.p);
@@ -1682,7 +1794,7 @@ int do_surface_counts(fb_poly_s* h) {
 
 int do_surface_emit(fb_poly_s* h) {
   const Grid& G = h->G;
-  const long long pw = (long long)h->vinc_pop.n;
+  const long long pw = h->n_words;
   const long long nv = h->counts.n_surface_vertices, ntri = h->counts.n_surface_indices / 3;
   if (nv == 0 && ntri == 0) return FB_OK;
   hipLaunchKernelGGL(k_surface_lists, dim3((int)((pw + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, G, pw, h->inside.p, h->surf.p, h->crossx.p, h->crossy.p,
@@ -2186,7 +2298,7 @@ int fb_poly_time_stages(fb_poly_t h, int reps, double seconds[5]) {
     (void)hipEventRecord(ev[1], h->stream);
     if (rc == FB_OK) rc = do_classify(h);
     (void)hipEventRecord(ev[2], h->stream);
-    hipLaunchKernelGGL(k_tet_vertices, dim3(pb), dim3(kPB), 0, h->stream, G, h->vinc.p, h->vbase.p, h->tv.p);
+    hipLaunchKernelGGL(k_tet_vertices, dim3((unsigned)((((G.n_points + 63) >> 6) + kVW - 1) / kVW)), dim3(kPB), 0, h->stream, G, fast_div((unsigned int)G.g[0] * (unsigned int)G.g[1]), fast_div((unsigned int)G.g[0]), h->vinc.p, h->vbase.p, h->tv.p);
     (void)hipEventRecord(ev[3], h->stream);
     hipLaunchKernelGGL(k_tet_elements, dim3(pb), dim3(kPB), 0, h->stream, G, h->cinc.p, h->cbase.p, h->vinc.p, h->vbase.p, h->tt.p);
     (void)hipEventRecord(ev[4], h->stream);
