@@ -12,8 +12,6 @@
 #include "fem_plan.h"
 #include "pcg_pipe.hip.h"
 #include "pcg_pipe2.hip.h"
-#include "pcg_pipe_shard.hip.h"
-#include "pcg_pipe2_shard.hip.h"
 #include "plan_device.h"
 #include "renumber.h"
 
@@ -108,7 +106,7 @@ struct fb_fem_s {
   int pipe_plain_local = 0;            // interior workgroups publish with plain stores (FEMBRAIN_PIPE_PLAIN_STORES)
   DevBuf<double> pipe_planes, pipe_z, pipe_s, pipe_state;
   int pipe_klt = 0, pipe_wmax = 0;
-  // sharded persistent solver (pcg_pipe_shard.hip.h; opt-in FEMBRAIN_SHARDED_PERSIST=1, unmeasured on multi-GPU hardware)
+  // sharded persistent solver (pcg_shard_box.hip.h; opt-in FEMBRAIN_SHARDED_PERSIST=1, unmeasured on multi-GPU hardware)
   bool shard_persist = false;
   bool persist_broken = false;  // a launch timed out: the handle runs the two-launch iteration until it is re-armed (below) or re-synced
   // Re-arming: one co-tenant burst must not cost a 1M-tet host 40 % of its speed for the life of the handle.  After
@@ -186,7 +184,7 @@ void release_shard_persist(fb_fem_s* h) {
   h->shard_persist = false;
 }
 
-// The rank-local half of the sharded persistent solver's set-up (pcg_pipe_shard.hip.h): planes over owned + halo columns, per-row send
+// The rank-local half of the sharded persistent solver's set-up (pcg_shard_box.hip.h): planes over owned + halo columns, per-row send
 // lists, producer lists with the proxies' flags.  The collective half (boxes, sender counts) is attach_pipe_shard.
 int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   const FemPlan& P = h->plan;
@@ -985,61 +983,42 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   pa.prefetch_slots = prefetch >= 0 ? prefetch : (h->persist_waves >= 9 ? (h->pipe_rows == 2 ? 3 : 4) : 0);
   const dim3 grid(h->persist_blocks), block(64 * (cwaves + pa.service));
   FB_HIP(hipEventRecord(h->ev_p[0], h->stream));
-#define FB_PIPE(C16, WMAX, KLT, TIMING)                                                                                                        \
-  do {                                                                                                                                         \
-    static bool attr = false;                                                                                                                  \
-    if (!attr) {                                                                                                                               \
-      FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe<float, C16, WMAX, KLT, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      attr = true;                                                                                                                             \
-    }                                                                                                                                          \
-    hipLaunchKernelGGL((k_pcg_pipe<float, C16, WMAX, KLT, TIMING>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p,       \
-                       (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);       \
-  } while (0)
-  // the instantiations: (wavefronts, most LDS slots per wavefront) = (8, 8) up to 8 slices per CU, (12, 6) up to 12; 16- or 32-bit column words;
-  // two rows per lane (k_pcg_pipe2) for 13..24 slices per CU; k_pcg_pipe_shard<8, 8> / <12, 6> on a sharded handle
+  ShardArgs sa;
+  memset(&sa, 0, sizeof sa);
   if (h->shard_persist) {
-    ShardArgs sa;
     sa.rank = h->plan.rank; sa.n_ranks = h->plan.n_ranks; sa.n_owned = h->plan.n_owned; sa.n_halo = h->plan.n_local - h->plan.n_owned;
     sa.box = h->sbox; sa.peer_box = h->sbox_peers.p; sa.peer_seg = h->sh_peer_seg.p; sa.halo_cap = h->sbox_halo_cap;
     sa.halo_off = h->sh_halo_off.p; sa.row_send_off = h->sh_row_send_off.p; sa.row_send_rank = h->sh_row_send_rank.p; sa.row_send_pos = h->sh_row_send_pos.p;
     sa.wg_send_mask = h->sh_wg_send_mask.p; sa.n_senders = h->sh_n_senders.p; sa.proxy_wg = h->sh_proxy_wg.p; sa.n_proxy = h->sh_n_proxy; sa.wg_duty = h->sh_wg_duty.p; sa.wg_range = h->sh_wg_range.p;
-    static bool attr_s[3] = {false, false, false};
-    const int wi = h->pipe_rows == 2 ? 2 : (h->pipe_wmax == 8 ? 0 : 1);
-    const void* kern = wi == 0 ? (const void*)k_pcg_pipe_shard<8, 8> : (wi == 1 ? (const void*)k_pcg_pipe_shard<12, 6> : (const void*)k_pcg_pipe2_shard);
-    if (!attr_s[wi]) {
-      FB_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_s[wi] = true;
-    }
-    if (wi == 2)
-      hipLaunchKernelGGL(k_pcg_pipe2_shard, grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b,
-                         h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);
-    else if (wi == 0)
-      hipLaunchKernelGGL((k_pcg_pipe_shard<8, 8>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b,
-                         h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);
-    else
-      hipLaunchKernelGGL((k_pcg_pipe_shard<12, 6>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b,
-                         h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);
-  } else
-  if (h->pipe_rows == 2) {
-    static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)kPipeMaxWaves * 2 * kPipe2LdsWordsPerRow * 64 * 4 <= 160 * 1024, "LDS budget of k_pcg_pipe2");
-    static bool attr2[2] = {false, false};
-    const void* kern = h->c16 ? (const void*)k_pcg_pipe2<true> : (const void*)k_pcg_pipe2<false>;
-    if (!attr2[h->c16 ? 1 : 0]) {
-      FB_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr2[h->c16 ? 1 : 0] = true;
-    }
-    if (h->c16)
-      hipLaunchKernelGGL((k_pcg_pipe2<true>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b,
-                         h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);
-    else
-      hipLaunchKernelGGL((k_pcg_pipe2<false>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b,
-                         h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa);
-  } else
-  if (pa.timing) {  // development build with the phase clocks: the 1M-tet configuration only
-    if (h->pipe_wmax == 12 && h->c16) FB_PIPE(true, 12, 6, true);
+  }
+  // (the attribute is per device and cheap to set: set at every launch)
+#define FB_PIPE(C16, WMAX, KLT, TIMING, SHARD)                                                                                                        \
+  do {                                                                                                                                                \
+    FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe<float, C16, WMAX, KLT, TIMING, SHARD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_pcg_pipe<float, C16, WMAX, KLT, TIMING, SHARD>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p,       \
+                       (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);          \
+  } while (0)
+#define FB_PIPE2(C16, SHARD)                                                                                                                          \
+  do {                                                                                                                                                \
+    FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe2<C16, SHARD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+    hipLaunchKernelGGL((k_pcg_pipe2<C16, SHARD>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p,        \
+                       h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);                                  \
+  } while (0)
+  static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)kPipeMaxWaves * 2 * kPipe2LdsWordsPerRow * 64 * 4 <= 160 * 1024, "LDS budget of k_pcg_pipe2");
+  // the instantiations: (wavefronts, most LDS slots per wavefront) = (8, 8) up to 8 slices per CU, (12, 6) up to 12; 16- or 32-bit column words;
+  // two rows per lane (k_pcg_pipe2) for 13..24 slices per CU; SHARD = true on a sharded handle (32-bit local column ids)
+  if (h->shard_persist) {
+    if (h->pipe_rows == 2) FB_PIPE2(false, true);
+    else if (h->pipe_wmax == 8) FB_PIPE(false, 8, 8, false, true);
+    else FB_PIPE(false, 12, 6, false, true);
+  } else if (h->pipe_rows == 2) {
+    if (h->c16) FB_PIPE2(true, false); else FB_PIPE2(false, false);
+  } else if (pa.timing) {  // development build with the phase clocks: the 1M-tet configuration only
+    if (h->pipe_wmax == 12 && h->c16) FB_PIPE(true, 12, 6, true, false);
     else return fail(FB_EINVAL, "FEMBRAIN_PERSIST_TIMING is built for 9..12 slices per CU with 16-bit column words");
-  } else if (h->pipe_wmax == 8) { if (h->c16) FB_PIPE(true, 8, 8, false); else FB_PIPE(false, 8, 8, false); }
-  else { if (h->c16) FB_PIPE(true, 12, 6, false); else FB_PIPE(false, 12, 6, false); }
+  } else if (h->pipe_wmax == 8) { if (h->c16) FB_PIPE(true, 8, 8, false, false); else FB_PIPE(false, 8, 8, false, false); }
+  else { if (h->c16) FB_PIPE(true, 12, 6, false, false); else FB_PIPE(false, 12, 6, false, false); }
+#undef FB_PIPE2
 #undef FB_PIPE
   FB_HIP(hipGetLastError());
   FB_HIP(hipEventRecord(h->ev_p[1], h->stream));

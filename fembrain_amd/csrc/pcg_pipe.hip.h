@@ -121,6 +121,36 @@ __global__ __launch_bounds__(kBlock) void k_slice_producers(int n_slices, int n_
   }
 }
 
+// One wavefront's share of the collection of all workgroups' posted sums of sequence number `sums`: lane `l0` of `stride` takes workgroups
+// l0, l0 + stride, ...; adds their two values to t0s / t1s in that order (the callers fix the order of the rest).  Bounded by the wall clock.
+__device__ __forceinline__ void pipe_collect_posts(const PipeArgs& pa, unsigned int sums, int nb, int lane, int stride, int l0, long long t0, long long t_limit, bool& failed,
+                                                   double& t0s, double& t1s) {
+  const unsigned long long* post = pa.post + (size_t)(sums & 1u) * nb * 4;
+  for (int b = l0; b - lane < nb && !failed; b += stride) {  // wave-uniform trip count
+    const bool mine = b < nb;
+    uint4 q4[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    for (;;) {
+      bool ok = true;
+      if (mine) {  // the record's four granules in two 16-byte requests (each granule is one 8-byte store of its writer)
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(q4[0]), "=&v"(q4[1]) : "v"(post + (size_t)b * 4) : "memory");
+        ok = q4[0].y == sums && q4[0].w == sums && q4[1].y == sums && q4[1].w == sums;
+      }
+      if (__ballot(!ok) == 0ULL) break;
+      if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (mine && !failed) {
+      t0s += __longlong_as_double((long long)(((unsigned long long)q4[0].x << 32) | (unsigned long long)q4[0].z));
+      t1s += __longlong_as_double((long long)(((unsigned long long)q4[1].x << 32) | (unsigned long long)q4[1].z));
+    }
+  }
+}
+
+}  // namespace fb
+#include "pcg_shard_box.hip.h"
+namespace fb {
+
 // WMAX: wavefronts per workgroup the instantiation is bounded for (512 registers per lane and SIMD are shared by
 // ceil(WMAX / 4) wavefronts).  LDS-resident part of the matrix: the first slots of every slice (9 values + the column id per lane)
 // are loaded into LDS ONCE per launch -- the matrix does not change during a solve; slots beyond are streamed every product as in
@@ -128,11 +158,16 @@ __global__ __launch_bounds__(kBlock) void k_slice_producers(int n_slices, int n_
 // to its `count` live wavefronts, count-th part each and the remainder one more for the first ones (11 slices: 5 slots each and a
 // sixth for five of them; 10 slices: 6 each), at most KLT per wavefront (the unroll bound of the LDS loop).
 // TIMING: the development build with per-phase clocks (FEMBRAIN_PERSIST_TIMING=1).
-template <typename MT, bool C16, int WMAX, int KLT, bool TIMING>
+// SHARD: the kernel of a sharded handle (pcg_shard_box.hip.h; "k_pcg_pipe_shard<WMAX,KLT>" in fb_fem_pcg_path): the slices come from the
+// plan's deal (sa.wg_range), the last wavefront is the spare one (sums, counters, proxy copies), rows a neighbour rank gathers are also
+// stored into its box, the sums go through the rank level; 32-bit column words, write-through stores.  sa is not read otherwise.
+template <typename MT, bool C16, int WMAX, int KLT, bool TIMING, bool SHARD>
 __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo,
                                                         const double* __restrict__ invdiag, const double* __restrict__ bvec, double* __restrict__ xg,
                                                         double* __restrict__ rg, double* __restrict__ wg, double* __restrict__ zg,
-                                                        double* __restrict__ sg, double* __restrict__ pg, CGState* __restrict__ st, PipeArgs pa) {
+                                                        double* __restrict__ sg, double* __restrict__ pg, CGState* __restrict__ st, PipeArgs pa,
+                                                        ShardArgs sa) {
+  static_assert(!SHARD || (!C16 && !TIMING), "a shard's columns are 32-bit local ids; the phase clocks are built for the unsharded kernel");
   static_assert(sizeof(MT) == 4, "k_pcg_pipe keeps part of the matrix in LDS as fp32 words and streams the rest as fp32");
   extern __shared__ double lds[];  // the request is padded so that one workgroup fills a CU
   double* wsum = lds;                          // [2][16] wave sums
@@ -143,8 +178,10 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
   if (threadIdx.x == 0) bc[4] = 0.0;      // set by a sum poller that gave up (read after the next barrier)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int first, count;
-  pipe_slices(sv.n_slices, nb, blockIdx.x, &first, &count);
-  const bool live = wv < count;  // wave-uniform
+  if constexpr (SHARD) { first = sa.wg_range[blockIdx.x].x; count = sa.wg_range[blockIdx.x].y; }
+  else pipe_slices(sv.n_slices, nb, blockIdx.x, &first, &count);
+  const bool spare = SHARD && wv == n_waves - 1;  // a shard's spare wavefront: sums, counters, proxy copies (it owns no slice)
+  const bool live = wv < count && !spare;         // wave-uniform
   const int sl = first + wv;
   const int row = sl * 64 + lane;
   const bool rvalid = live && row < sv.n_owned;
@@ -158,11 +195,13 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
   // low part of the diagonal block (symmetric: 6 planes) and 1/diag, fixed for the solve
   MT m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;
   double iv[3] = {0, 0, 0};
+  int send_beg = 0, send_end = 0;  // (SHARD) this row's entries of the send lists
   if (rvalid) {
     const MT* l = dlo + (size_t)sl * 9 * 64 + lane;
     m00 = l[0 * 64]; m01 = l[1 * 64]; m02 = l[2 * 64]; m11 = l[4 * 64]; m12 = l[5 * 64]; m22 = l[8 * 64];
 #pragma unroll
     for (int a = 0; a < 3; a++) iv[a] = invdiag[dof + a];
+    if constexpr (SHARD) { send_beg = sa.row_send_off[row]; send_end = sa.row_send_off[row + 1]; }
   }
   // LDS-resident part of the matrix: the first KL slots of this wave's slice, [klt_w][10][64] words (9 values + the column id)
   const int lbase = min(KLT, kPipeLdsSlots / max(count, 1)), lrem = lbase < KLT ? min(count, kPipeLdsSlots - lbase * count) : 0;  // workgroup-uniform
@@ -182,6 +221,9 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
   int my_prod = -1;
   if (wv == 0 && n_prod >= 0 && lane < n_prod) my_prod = pa.producers[(size_t)blockIdx.x * kPipeMaxProducers + lane];
 
+  unsigned int send_mask = 0u;  // (SHARD) workgroup-uniform: the ranks this workgroup has rows to send to
+  ShardBoxLayout BL = {};
+  if constexpr (SHARD) { send_mask = sa.wg_send_mask[blockIdx.x]; BL = shard_box_layout(sa.halo_cap); }
   unsigned int pub = pa.seqs[0], sums = pa.seqs[1];  // grid-uniform: written by the previous launch
   const long long t_limit = pa.timeout_ticks;
   bool failed = false;
@@ -195,11 +237,13 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
   // promise (blockIdx & 7 is the observed round-robin deal, good for speed only; a CU-masked stream deals otherwise): every
   // workgroup announces the XCC id the hardware reports, its first publish of a launch goes through, and it stores plainly from
   // the second on only if all its producers (= its consumers: A is symmetric) announced the same id (checked in product()).
-  const bool plain_cand = pa.plain_local != 0 && pa.prod_xcd[blockIdx.x] == 0;  // workgroup-uniform
+  const bool plain_cand = !SHARD && pa.plain_local != 0 && pa.prod_xcd[blockIdx.x] == 0;  // workgroup-uniform
   bool through = true, xcc_known = false;
-  unsigned int my_xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(my_xcc));
-  if (threadIdx.x == 0) st_sc1_u32(pa.xcc + blockIdx.x, ((pub + 1u) << 4) | my_xcc);  // (visible before this workgroup's first flag: product() drains before it flags)
+  unsigned int my_xcc = 0u;
+  if constexpr (!SHARD) {
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(my_xcc));
+    if (threadIdx.x == 0) st_sc1_u32(pa.xcc + blockIdx.x, ((pub + 1u) << 4) | my_xcc);  // (visible before this workgroup's first flag: product() drains before it flags)
+  }
   auto publish = [&](const double* vin) {
     pub++;
     double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
@@ -211,6 +255,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
 #pragma unroll
         for (int a = 0; a < 3; a++) pl[a * pa.n_pad + (size_t)row] = vin[a];
       }
+      if constexpr (SHARD) shard_send_row(sa, BL, pub, send_beg, send_end, vin);
     }
   };
   // y = A vin for the vector published last: drain the stores, flag, wait for the producers of this workgroup's columns,
@@ -229,6 +274,9 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
       int so_k = so + klt_w;
       asm volatile("" : "+s"(so_k));  // (opaque, as for the streamed loop below)
       pipe_prefetch_values(min(pa.prefetch_slots, width - klt_w), ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float), vals);
+    }
+    if constexpr (SHARD) {
+      if (spare) shard_service_product(sa, BL, pa, pub, pl, nb, lane, send_mask, t_limit, bc, failed);
     }
     if (wv == 0) {
       if (lane == 0) st_sc1_u32(pa.flags + blockIdx.x, pub);
@@ -252,6 +300,8 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
           if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
+      } else if constexpr (SHARD) {
+        shard_poll_all(sa, pa, pub, nb, lane, t0, t_limit, failed);
       } else {
         for (int b = 4 * lane; b - 4 * lane < nb && !failed; b += 256) {  // four flags per lane in one 16-byte request
           for (;;) {
@@ -277,7 +327,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     }
     __syncthreads();
     lap(1);  // flag + wait for the producers + acquire
-    if (uniform_flag(bc[3] != 0.0)) { failed = true; return; }
+    if (uniform_flag(bc[3] != 0.0 || (SHARD && bc[4] != 0.0))) { failed = true; return; }
     if (plain_cand && !xcc_known) { through = !uniform_flag(bc[5] != 0.0); xcc_known = true; }
     // the low part of the diagonal block times the own entry first: vin is not needed beyond this point
     double y0 = 0, y1 = 0, y2 = 0;
@@ -392,33 +442,17 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
       continue;
     }
     // ---- all workgroups' sums (posted before their products: they are there) ----
-    if (pa.service) {
+    if constexpr (SHARD) {
+      if (spare) shard_rank_sums(sa, BL, pa, sums, nb, lane, t_limit, bc, failed);
+      __syncthreads();
+    } else if (pa.service) {
       // A workgroup with a wavefront to spare (fewer slices than the instantiation's wavefronts) has its LAST wavefront -- no
       // slice, it idles through the product -- collect the sums meanwhile: same order of additions as below, so the same bits;
       // the others find the totals behind ONE barrier.
       if (wv == n_waves - 1) {
         const long long t0 = wall_clock64();
-        const unsigned long long* post = pa.post + (size_t)(sums & 1u) * nb * 4;
         double t0s = 0, t1s = 0;
-        for (int b = lane; b - lane < nb && !failed; b += 64) {
-          const bool mine = b < nb;
-          uint4 q4[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-          for (;;) {
-            bool ok = true;
-            if (mine) {
-              asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                           : "=&v"(q4[0]), "=&v"(q4[1]) : "v"(post + (size_t)b * 4) : "memory");
-              ok = q4[0].y == sums && q4[0].w == sums && q4[1].y == sums && q4[1].w == sums;
-            }
-            if (__ballot(!ok) == 0ULL) break;
-            if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          if (mine && !failed) {
-            t0s += __longlong_as_double((long long)(((unsigned long long)q4[0].x << 32) | (unsigned long long)q4[0].z));
-            t1s += __longlong_as_double((long long)(((unsigned long long)q4[1].x << 32) | (unsigned long long)q4[1].z));
-          }
-        }
+        pipe_collect_posts(pa, sums, nb, lane, 64, lane, t0, t_limit, failed, t0s, t1s);
         failed = uniform_flag(failed);
         if (failed && lane == 0) st_sc1_u32(pa.error, 1u);
         t0s = wave_sum(t0s); t1s = wave_sum(t1s);
@@ -527,7 +561,9 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     st->rho[iter & 1] = done ? gamma : gamma_old;  // what the host's convergence test reads (CGSolver.cpp:189)
     st->done = done ? 1 : 0;
     pa.pstate[0] = gamma_old; pa.pstate[1] = alpha_old;
-    pa.seqs[0] = pub; pa.seqs[1] = sums;
+    // (a shard's launch cut after a pre-publish takes the publish back: its rows are in the planes and the boxes, but no counter was raised
+    // for it, and the next launch publishes the same values under the same number)
+    pa.seqs[0] = (SHARD && published) ? pub - 1u : pub; pa.seqs[1] = sums;
   }
 }
 

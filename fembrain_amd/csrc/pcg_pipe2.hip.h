@@ -14,12 +14,14 @@ namespace fb {
 
 constexpr int kPipe2LdsWordsPerRow = 24;  // x[3], p[3], z[3] as doubles (18 words) + 6 floats of the diagonal block's low part
 
-template <bool C16>
+// SHARD: the kernel of a sharded handle ("k_pcg_pipe2_shard" in fb_fem_pcg_path; pcg_shard_box.hip.h) -- as for k_pcg_pipe
+template <bool C16, bool SHARD>
 __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, const float* __restrict__ vals, const float* __restrict__ dlo,
                                                                   const double* __restrict__ invdiag, const double* __restrict__ bvec,
                                                                   double* __restrict__ xg, double* __restrict__ rg, double* __restrict__ wg,
                                                                   double* __restrict__ zg, double* __restrict__ sg, double* __restrict__ pg,
-                                                                  CGState* __restrict__ st, PipeArgs pa) {
+                                                                  CGState* __restrict__ st, PipeArgs pa, ShardArgs sa) {
+  static_assert(!SHARD || !C16, "a shard's columns are 32-bit local ids");
   extern __shared__ double lds[];
   double* wsum = lds;                          // [2][16] wave sums
   double* gath = lds + 32;                     // [2][kPipeMaxBlocks] all workgroups' sums
@@ -29,18 +31,22 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
   if (threadIdx.x == 0) bc[4] = 0.0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int first, count;
-  pipe_slices(sv.n_slices, nb, blockIdx.x, &first, &count);
+  if constexpr (SHARD) { first = sa.wg_range[blockIdx.x].x; count = sa.wg_range[blockIdx.x].y; }
+  else pipe_slices(sv.n_slices, nb, blockIdx.x, &first, &count);
+  const bool spare = SHARD && wv == n_waves - 1;  // a shard's spare wavefront: sums, counters, proxy copies (it owns no slice)
   bool live[2], rvalid[2];
-  int row[2], so[2], width[2];
+  int row[2], so[2], width[2], send_beg[2], send_end[2];
 #pragma unroll
   for (int h = 0; h < 2; h++) {
-    live[h] = 2 * wv + h < count;  // wave-uniform
+    live[h] = 2 * wv + h < count && !spare;  // wave-uniform
     const int sl = first + 2 * wv + h;
     row[h] = sl * 64 + lane;
     rvalid[h] = live[h] && row[h] < sv.n_owned;
     int o = 0, wd = 0;
     if (live[h]) { o = sv.slice_off[sl]; wd = sv.slice_off[sl + 1] - o; }
     so[h] = __builtin_amdgcn_readfirstlane(o); width[h] = __builtin_amdgcn_readfirstlane(wd);
+    send_beg[h] = send_end[h] = 0;  // (SHARD) this row's entries of the send lists
+    if constexpr (SHARD) if (rvalid[h]) { send_beg[h] = sa.row_send_off[row[h]]; send_end[h] = sa.row_send_off[row[h] + 1]; }
   }
   // LDS of this wavefront and row set h: nine doubles (x, p, z: k = 0..8) then six floats (low diagonal part) per lane, each as a
   // plane of 64 lanes -- 24 words per row, conflict-free
@@ -66,6 +72,9 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
   int my_prod = -1;
   if (wv == 0 && n_prod >= 0 && lane < n_prod) my_prod = pa.producers[(size_t)blockIdx.x * kPipeMaxProducers + lane];
 
+  unsigned int send_mask = 0u;  // (SHARD) workgroup-uniform
+  ShardBoxLayout BL = {};
+  if constexpr (SHARD) { send_mask = sa.wg_send_mask[blockIdx.x]; BL = shard_box_layout(sa.halo_cap); }
   unsigned int pub = pa.seqs[0], sums = pa.seqs[1];
   const long long t_limit = pa.timeout_ticks;
   bool failed = false;
@@ -80,6 +89,7 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
       if (rvalid[h]) {
 #pragma unroll
         for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * pa.n_pad + (size_t)row[h], vin[h][a]);
+        if constexpr (SHARD) shard_send_row(sa, BL, pub, send_beg[h], send_end[h], vin[h]);
       }
   };
   auto product = [&](const double vin[2][3], double y[2][3], bool post_sums) {
@@ -91,6 +101,9 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
       int so_k = so[0];
       asm volatile("" : "+s"(so_k));
       pipe_prefetch_values(min(pa.prefetch_slots, width[0]), ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float), vals);
+    }
+    if constexpr (SHARD) {
+      if (spare) shard_service_product(sa, BL, pa, pub, pl, nb, lane, send_mask, t_limit, bc, failed);
     }
     if (wv == 0) {
       if (lane == 0) st_sc1_u32(pa.flags + blockIdx.x, pub);
@@ -112,6 +125,8 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
           if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
+      } else if constexpr (SHARD) {
+        shard_poll_all(sa, pa, pub, nb, lane, t0, t_limit, failed);
       } else {
         for (int b = 4 * lane; b - 4 * lane < nb && !failed; b += 256) {
           for (;;) {
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
       if (lane == 0) bc[3] = (failed || ld_sc1_u32(pa.error) != 0u) ? 1.0 : 0.0;
     }
     __syncthreads();
-    if (uniform_flag(bc[3] != 0.0)) { failed = true; return; }
+    if (uniform_flag(bc[3] != 0.0 || (SHARD && bc[4] != 0.0))) { failed = true; return; }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       double y0 = 0, y1 = 0, y2 = 0;
@@ -240,30 +255,14 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
       continue;
     }
     // ---- all workgroups' sums ----
-    if (pa.service) {
+    if constexpr (SHARD) {
+      if (spare) shard_rank_sums(sa, BL, pa, sums, nb, lane, t_limit, bc, failed);
+      __syncthreads();
+    } else if (pa.service) {
       if (wv == n_waves - 1) {
         const long long t0 = wall_clock64();
-        const unsigned long long* post = pa.post + (size_t)(sums & 1u) * nb * 4;
         double t0s = 0, t1s = 0;
-        for (int b = lane; b - lane < nb && !failed; b += 64) {
-          const bool mine = b < nb;
-          uint4 q4[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-          for (;;) {
-            bool ok = true;
-            if (mine) {
-              asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                           : "=&v"(q4[0]), "=&v"(q4[1]) : "v"(post + (size_t)b * 4) : "memory");
-              ok = q4[0].y == sums && q4[0].w == sums && q4[1].y == sums && q4[1].w == sums;
-            }
-            if (__ballot(!ok) == 0ULL) break;
-            if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          if (mine && !failed) {
-            t0s += __longlong_as_double((long long)(((unsigned long long)q4[0].x << 32) | (unsigned long long)q4[0].z));
-            t1s += __longlong_as_double((long long)(((unsigned long long)q4[1].x << 32) | (unsigned long long)q4[1].z));
-          }
-        }
+        pipe_collect_posts(pa, sums, nb, lane, 64, lane, t0, t_limit, failed, t0s, t1s);
         failed = uniform_flag(failed);
         if (failed && lane == 0) st_sc1_u32(pa.error, 1u);
         t0s = wave_sum(t0s); t1s = wave_sum(t1s);
@@ -378,7 +377,7 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
     st->rho[iter & 1] = done ? gamma : gamma_old;
     st->done = done ? 1 : 0;
     pa.pstate[0] = gamma_old; pa.pstate[1] = alpha_old;
-    pa.seqs[0] = pub; pa.seqs[1] = sums;
+    pa.seqs[0] = (SHARD && published) ? pub - 1u : pub; pa.seqs[1] = sums;  // (a shard's launch cut after a pre-publish takes the publish back: pcg_pipe.hip.h)
   }
 }
 

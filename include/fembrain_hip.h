@@ -148,7 +148,7 @@ int fb_fem_destroy(fb_fem_t h);
 #define FB_XCH_P2P_FUSED 4
 int fb_fem_transport(fb_fem_t h);
 int fb_fem_set_exchange_mode(fb_fem_t h, int mode);
-/* The sharded persistent pipelined solver (pcg_pipe_shard.hip.h): one launch per solve on every rank, halo rows and rank sums crossing
+/* The sharded persistent pipelined solver (pcg_shard_box.hip.h): one launch per solve on every rank, halo rows and rank sums crossing
  * the GPUs inside the launches, no exchange kernels or collectives on the path.  OPT-IN (FEMBRAIN_SHARDED_PERSIST=1 when the handle
  * is created; <= 22 slices per CU -- two rows per lane from 12 on -- and <= 16 ranks) and UNMEASURED on multi-GPU hardware.  fb_fem_sharded_persist: 1 when the handle's
  * solves run in it.  fb_fem_set_sharded_persist is COLLECTIVE like fb_fem_set_exchange_mode (0: the two-launch iteration with the

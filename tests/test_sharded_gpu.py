@@ -637,7 +637,7 @@ def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_
 @pytest.mark.parametrize("world,n,kernel", [(2, 40, "k_pcg_pipe_shard<8,8>"), (2, -30000, "k_pcg_pipe_shard<8,8>"), (3, 40, "k_pcg_pipe_shard<8,8>"), (4, 40, "k_pcg_pipe_shard<8,8>"),
                                             (2, 56, "k_pcg_pipe_shard<12,6>"), (2, 70, "k_pcg_pipe2_shard")])
 def test_sharded_persistent_solver_on_disjoint_cus_matches_the_unsharded_handle(gpu, world, n, kernel):
-    """The sharded persistent pipelined solver (pcg_pipe_shard.hip.h; opt-in FEMBRAIN_SHARDED_PERSIST=1; UNMEASURED on multi-GPU
+    """The sharded persistent pipelined solver (pcg_shard_box.hip.h; opt-in FEMBRAIN_SHARDED_PERSIST=1; UNMEASURED on multi-GPU
     hardware): one persistent launch per solve ON EVERY RANK, the halo rows written by their owners straight into the neighbour rank's
     box (HIP IPC), copied into the planes by a proxy wavefront, the rank sums posted into every rank's box -- no collective on the
     path.  Here the ranks are processes on the one GPU of the box, each confined to its own share of the CUs (FEMBRAIN_CU_MASK), so
