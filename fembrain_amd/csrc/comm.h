@@ -30,6 +30,12 @@ int comm_allgather_bytes(fb_comm_s* c, const void* mine, void* all, size_t bytes
 // fallback when peer mapping is unavailable.  Every wait has a wall-clock bound: on expiry the inbox error word is set,
 // all later waits fall through, and the host reports FB_ECOMM at the next synchronisation point.
 constexpr int kP2PMaxRanks = 16;
+// FEMBRAIN_REMOTE_DELAY_US (development): wall_clock64 ticks by which remote signals are delayed in the one-GPU rehearsals of N > 1
+inline long long remote_delay_ticks() {
+  const char* e = getenv("FEMBRAIN_REMOTE_DELAY_US");
+  return e ? (long long)(atof(e) * 100.0) : 0LL;
+}
+
 struct P2PDev {  // passed to kernels by value
   int rank, n_ranks;
   char* inbox;
@@ -38,6 +44,7 @@ struct P2PDev {  // passed to kernels by value
   long long peer_cap[kP2PMaxRanks];  // halo nodes per buffer of peer q's inbox
   long long cap;
   long long timeout_ticks;           // wall_clock64 ticks (100 MHz)
+  long long delay_ticks;             // development (FEMBRAIN_REMOTE_DELAY_US): every remote signal is raised this much later and seen this much later
 };
 struct P2P;
 struct P2PArgs {  // what a PCG kernel that carries an exchange in its prologue needs

@@ -206,7 +206,15 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   // slices per CU): its shorter product absorbs the wait.
   static const int relief_env = getenv("FEMBRAIN_SHARD_RELIEF") ? atoi(getenv("FEMBRAIN_SHARD_RELIEF")) : -1;
   std::vector<int2> wg_range((size_t)nb, make_int2(0, 0));   // first slice and slice count of every workgroup
-  int Q = w, relief = std::min(w - 1, relief_env >= 0 ? relief_env : std::max(0, (w * 35 + 50) / 100));
+  // Default (profiles/r04_remote_delay.json: two and four ranks on CU shares of one GPU, remote signals delayed by 0 / 1 / 2 / 5 us): relief
+  // pays where FEW workgroups gather halo rows -- 1M tets on two ranks, 2 of 28 planes per rank: 18.5 against 20.6 us per iteration, and
+  // still 21.4 against 22.8 with 2 us added per hop -- and costs where many do: on four ranks (14 planes per rank, the geometry of the
+  // 8M-tet mesh on eight GPUs) the even deal runs 20.4 against 23.5.  So: 35 % of the slices per CU while at most a twelfth of the slices
+  // gather halo rows, none beyond.
+  int halo_slices = 0;
+  for (int sl = 0; sl < P.n_slices; sl++) halo_slices += rg[sl].z != 0 ? 1 : 0;
+  const int relief_default = 12 * halo_slices <= P.n_slices ? std::max(0, (w * 35 + 50) / 100) : 0;
+  int Q = w, relief = std::min(w - 1, relief_env >= 0 ? relief_env : relief_default);
   for (;; relief--) {
     Q = 0;
     if (relief <= 0 || (nb & 7)) {  // the even deal of the unsharded kernel
@@ -990,6 +998,7 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     sa.box = h->sbox; sa.peer_box = h->sbox_peers.p; sa.peer_seg = h->sh_peer_seg.p; sa.halo_cap = h->sbox_halo_cap;
     sa.halo_off = h->sh_halo_off.p; sa.row_send_off = h->sh_row_send_off.p; sa.row_send_rank = h->sh_row_send_rank.p; sa.row_send_pos = h->sh_row_send_pos.p;
     sa.wg_send_mask = h->sh_wg_send_mask.p; sa.n_senders = h->sh_n_senders.p; sa.proxy_wg = h->sh_proxy_wg.p; sa.n_proxy = h->sh_n_proxy; sa.wg_duty = h->sh_wg_duty.p; sa.wg_range = h->sh_wg_range.p;
+    sa.delay_ticks = remote_delay_ticks();
   }
   // (the attribute is per device and cheap to set: set at every launch)
 #define FB_PIPE(C16, WMAX, KLT, TIMING, SHARD)                                                                                                        \
@@ -1662,6 +1671,9 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
   h->mu = params->E / (2 * (1 + params->nu));
   int rc = FB_OK;
   do {
+   // rank-local set-up; a failure here (stream, events, pinned memory, the build) must still reach the agreement below -- the other ranks
+   // are on their way into that all-gather
+   do {
     // FEMBRAIN_CU_MASK=first:count -- the handle's stream runs on `count` CUs from bit `first` of the CU mask only (development and test
     // aid: two processes on one GPU, each with a persistent kernel on its own half of the CUs); the persistent grid follows
     if (const char* cm = getenv("FEMBRAIN_CU_MASK")) {
@@ -1681,11 +1693,12 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
     if (hipHostMalloc((void**)&h->st_host, 2 * sizeof(CGState), hipHostMallocDefault) != hipSuccess) { rc = fail(FB_ENOMEM, "hipHostMalloc failed"); break; }
     if (const char* e = getenv("FEMBRAIN_GRAPH")) h->use_graph = atoi(e) != 0;
     rc = build(h, n_nodes, xyz, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits, dm);
-    if (comm && comm->n_ranks > 1) {  // creation is collective: the ranks agree on build()'s outcome before the collective attach
+   } while (0);
+    if (comm && comm->n_ranks > 1) {  // creation is collective: the ranks agree on the outcome so far before the collective attach
       const std::string why = rc == FB_OK ? std::string() : last_error();
       std::vector<int> rcs((size_t)n_ranks, 0);
       const int mine = rc;
-      const int rc_x = comm_allgather_bytes(comm, &mine, rcs.data(), sizeof(int), h->stream);
+      const int rc_x = comm_allgather_bytes(comm, &mine, rcs.data(), sizeof(int), h->stream);  // (host-staged or on the null stream if ours could not be made)
       if (rc_x != FB_OK) { rc = rc_x; break; }
       for (int q = 0; q < n_ranks && rc == FB_OK; q++)
         if (rcs[q] != FB_OK) rc = fail(rcs[q], "handle creation failed on rank %d (code %d)", q, rcs[q]);

@@ -113,6 +113,7 @@ int p2p_attach(fb_comm_s* c, int n_halo_nodes, const int* halo_off, hipStream_t 
   p->dev.cap = std::max(1, n_halo_nodes);
   const char* te = getenv("FEMBRAIN_P2P_TIMEOUT_MS");
   p->dev.timeout_ticks = (long long)(te ? atof(te) : 20000.0) * 100000LL;
+  p->dev.delay_ticks = remote_delay_ticks();
   p->inbox_bytes = kOffHalo + 2 * (size_t)p->dev.cap * kMaxWidth * sizeof(double);
   Meta mine;
   memset(&mine, 0, sizeof mine);

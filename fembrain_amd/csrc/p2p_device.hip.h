@@ -24,6 +24,16 @@ __device__ __forceinline__ void st_release_sys(unsigned long long* p, unsigned l
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Development knob for the one-GPU rehearsals of N > 1 (FEMBRAIN_REMOTE_DELAY_US = 1 / 2 / 5 ...): between processes that
+// share one GPU a "remote" store lands in the same HBM within a microsecond, across xGMI it does not.  With the knob set, every signal a
+// rank raises for a peer (chunk flag, sum flag, box counter, rank sums) is raised `ticks` later than its data was stored, and every such
+// signal is acted on `ticks` after it was seen -- the protocol then runs as if each hop took that much longer.  0: nothing is executed.
+__device__ __forceinline__ void remote_delay(long long ticks) {
+  if (ticks <= 0) return;
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(1);
+}
+
 // spin until *flag >= seq; bounded by the wall clock.  A timeout anywhere poisons the inbox so that the queue drains.
 __device__ inline bool p2p_wait_flag(const P2PDev& c, const unsigned long long* flag, unsigned long long seq) {
   unsigned long long* err = (unsigned long long*)(c.inbox + kOffErr);
@@ -36,6 +46,7 @@ __device__ inline bool p2p_wait_flag(const P2PDev& c, const unsigned long long* 
     }
     __builtin_amdgcn_s_sleep(4);
   }
+  remote_delay(c.delay_ticks);
   return true;
 }
 
@@ -52,6 +63,7 @@ __device__ inline void p2p_post_sums(const P2PDev& c, unsigned long long seq, co
     double* slot = (double*)(c.peer[t] + kOffRed) + ((size_t)par * kP2PMaxRanks + c.rank) * 8;
     for (int k = 0; k < count; k++) slot[k] = mine[k];
     __threadfence_system();
+    remote_delay(c.delay_ticks);
     st_release_sys((unsigned long long*)(c.peer[t] + kOffRedFlag) + c.rank, seq);
   }
 }
@@ -117,7 +129,7 @@ __device__ inline void p2p_send_halo_jobs(const P2PDev& c, unsigned long long se
       }
       __threadfence_system();
       __syncthreads();
-      if (threadIdx.x == 0) st_release_sys((unsigned long long*)(c.peer[q] + kOffHaloFlag) + c.rank * kP2PChunks + k, seq);
+      if (threadIdx.x == 0) { remote_delay(c.delay_ticks); st_release_sys((unsigned long long*)(c.peer[q] + kOffHaloFlag) + c.rank * kP2PChunks + k, seq); }
     }
   }
 }

@@ -25,6 +25,7 @@
 // slices per CU).
 #pragma once
 // (included by pcg_pipe.hip.h after PipeArgs and the sc1 helpers)
+#include "p2p_device.hip.h"
 namespace fb {
 
 struct ShardBoxLayout {  // byte offsets inside a rank's box (the same on every rank: n_halo_cap = the largest halo of all ranks)
@@ -59,6 +60,7 @@ struct ShardArgs {
   const int* proxy_wg;                // [n_ranks * n_proxy] the workgroup whose spare wavefront is proxy (s, k) (-1: nothing to copy)
   const int* wg_duty;                 // [n_blocks * kShardDuties] the proxies (s * n_proxy + k) of every workgroup, -1 padded
   const int2* wg_range;               // [n_blocks] first slice and slice count of every workgroup (those that gather halo rows get fewer: fem.hip)
+  long long delay_ticks;              // development (FEMBRAIN_REMOTE_DELAY_US, p2p_device.hip.h remote_delay)
 };
 constexpr int kShardProxies = 16;     // at most, per source rank
 constexpr int kShardDuties = 4;       // at most, per workgroup
@@ -116,6 +118,7 @@ __device__ __forceinline__ void shard_send_row(const ShardArgs& sa, const ShardB
 // then this workgroup's proxy duties (halo segments copied from the box into the planes, a flag of their own each)
 __device__ __forceinline__ void shard_service_product(const ShardArgs& sa, const ShardBoxLayout& BL, const PipeArgs& pa, unsigned int pub, double* pl, int nb, int lane,
                                                       unsigned int send_mask, long long t_limit, double* bc, bool& failed) {
+  remote_delay(sa.delay_ticks);
   if (lane < sa.n_ranks && (send_mask >> lane & 1u))
     __hip_atomic_fetch_add((unsigned int*)(sa.peer_box[lane] + BL.counters) + sa.rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const long long t0 = wall_clock64();
@@ -130,6 +133,7 @@ __device__ __forceinline__ void shard_service_product(const ShardArgs& sa, const
       __builtin_amdgcn_s_sleep(1);
     }
     if (failed) break;
+    remote_delay(sa.delay_ticks);
     int lo, hi;
     shard_proxy_rows(sa.halo_off[s], sa.halo_off[s + 1], sa.n_proxy, k, &lo, &hi);
     const double* in = (const double*)(sa.box + BL.halo) + (size_t)(pub & 1u) * 3 * (size_t)sa.halo_cap;
@@ -176,6 +180,7 @@ __device__ __forceinline__ void shard_rank_sums(const ShardArgs& sa, const Shard
     pipe_collect_posts(pa, sums, nb, lane, 64, lane, t0, t_limit, failed, t0s, t1s);
     t0s = wave_sum(t0s); t1s = wave_sum(t1s);
     t0s = __shfl(t0s, 0, 64); t1s = __shfl(t1s, 0, 64);
+    remote_delay(sa.delay_ticks);
     if (lane < sa.n_ranks && !failed) {  // lane q posts this rank's two sums into rank q's box
       unsigned long long* dst = (unsigned long long*)(sa.peer_box[lane] + BL.rsum) + ((size_t)(sums & 1u) * kP2PMaxRanks + sa.rank) * 4;
       const unsigned long long b0 = (unsigned long long)__double_as_longlong(t0s), b1 = (unsigned long long)__double_as_longlong(t1s), tag = (unsigned long long)sums << 32;
@@ -197,6 +202,7 @@ __device__ __forceinline__ void shard_rank_sums(const ShardArgs& sa, const Shard
       if (ld_sc1_u32(pa.error) != 0u || wall_clock64() - t0 > t_limit) { failed = true; break; }
       __builtin_amdgcn_s_sleep(1);
     }
+    remote_delay(sa.delay_ticks);
     const double v0 = __longlong_as_double((long long)(((g[0] & 0xffffffffULL) << 32) | (g[1] & 0xffffffffULL)));
     const double v1 = __longlong_as_double((long long)(((g[2] & 0xffffffffULL) << 32) | (g[3] & 0xffffffffULL)));
     for (int q = 0; q < sa.n_ranks; q++) { g0 += __shfl(v0, q, 64); g1 += __shfl(v1, q, 64); }

@@ -814,6 +814,86 @@ def test_sharded_persistent_solver_survives_a_collective_resync(gpu):
     assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
 
 
+def _sp_eligibility_worker(rank, world, shm_name, sizes, q):
+    try:
+        os.environ["FEMBRAIN_CU_MASK"] = "%d:%d" % (rank * (256 // world // 32 * 32), 256 // world // 32 * 32)
+        os.environ["FEMBRAIN_SHARDED_PERSIST"] = "1"
+        os.environ["FEMBRAIN_PERSIST_TIMEOUT_MS"] = "2000"
+        from fembrain_amd import lib as fl
+        from fembrain_amd.fem import FemIntegrator
+        L = fl.lib()
+        comm = C.c_void_p()
+        fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
+        g = None
+        out = []
+        for n in sizes:
+            v, t, fixed, splits = _mesh(n, world)
+            if g is None:
+                g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm))
+            else:
+                g.resync(v, t, fixed, node_splits=splits)
+            g.set_external_forces(_sp_force(n, v))
+            it = g.do_timestep()
+            qq = g.get_q_state()[0]
+            lo, hi = 3 * int(splits[rank]), 3 * int(splits[rank + 1])
+            out.append((n, it, bool(g.sharded_persist()), int(g.last.pcg_path), g.pcg_path()["kernel"], g.pcg_path()["fallbacks"], qq[lo:hi].copy(), lo, hi))
+        q.put((rank, out))
+        g.close()
+        L.fb_comm_destroy(comm)
+    except Exception as e:
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+        q.close()
+        q.join_thread()
+        os._exit(1)
+
+
+def test_sharded_persistent_solver_across_resyncs_that_cross_its_limits(gpu):
+    """a collective re-sync may take a handle out of the sharded persistent solver's range and back -- 40^3 (4 slices per
+    CU on two half-GPUs: the persistent kernel), 12^3 (less than one per CU: the two-launch iteration), 40^3 again, 72^3 (23 per CU:
+    one more than the two-row kernel takes), 40^3 again.  Nothing of an old plan's send lists, workgroup deal or box may survive into
+    the next: fb_fem_sharded_persist() says what runs, and every step matches an unsharded handle led through the same meshes."""
+    import multiprocessing as mp
+    from fembrain_amd.fem import FemIntegrator
+    from fembrain_amd import lib as fl
+    world, sizes = 2, [40, 12, 40, 72, 40]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sp_eligibility_worker, args=(r, world, "/fembrain_test_%d_spel" % os.getpid(), sizes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            r = q.get(timeout=600)
+            assert not isinstance(r[1], str), r
+            res[r[0]] = r[1]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    g = None
+    for k, n in enumerate(sizes):
+        v, t, fixed, _ = _mesh(n, world)
+        if g is None:
+            g = FemIntegrator(v, t, fixed)
+        else:
+            g.resync(v, t, fixed)
+        g.set_external_forces(_sp_force(n, v))
+        it = g.do_timestep()
+        qs = g.get_q_state()[0]
+        qg = np.zeros_like(qs)
+        for rank in range(world):
+            rn, rit, on, path, kernel, fallbacks, qq, lo, hi = res[rank][k]
+            assert rn == n and abs(rit - it) <= max(2, 0.01 * it) and fallbacks == 0, (rank, k, rit, it, fallbacks)
+            assert on == (n == 40) and (path == fl.FB_PCG_PATH_PERSISTENT) == (n == 40), (rank, n, on, path)
+            assert kernel == ("k_pcg_pipe_shard<8,8>" if n == 40 else ""), (rank, n, kernel)
+            qg[lo:hi] = qq
+        assert np.abs(qg - qs).max() <= 2e-6 * np.abs(qs).max(), (n, np.abs(qg - qs).max() / np.abs(qs).max())
+    g.close()
+
+
 def test_sharded_persistent_ranks_with_different_kernels_interoperate(gpu):
     """Uneven slabs of the 58^3 cube on two half-GPUs: 26 planes (11 slices per CU: the one-row kernel) and 32 planes (14 per CU: the
     two-row kernel).  Box, counters, proxies and sums are the same protocol in both, so the ranks need not run the same kernel; three
