@@ -1318,7 +1318,9 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   DevicePlan D;
   D.slice_off = &h->slice_off; D.colidx = &h->colidx; D.slot_coff = &h->slot_coff; D.slot_ccnt = &h->slot_ccnt; D.contrib = &h->contrib;
   D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot; D.coldelta = &h->coldelta;
-  const int rc = build_plan_device(h->stream, n_nodes, n_tets, h->tets.p, D, h->plan_ws);
+  // (the widest element was measured for the node order: FB_RENUMBER_OFF skips that pass and leaves the sort its 64-bit keys)
+  const int span = renumber_mode(h) == FB_RENUMBER_OFF ? -1 : (h->ren.active ? h->ren.span_after : h->ren.span_before);
+  const int rc = build_plan_device(h->stream, n_nodes, n_tets, h->tets.p, D, h->plan_ws, nullptr, span);
   if (h->plan_ws.bytes() > ((size_t)2 << 30)) h->plan_ws.release();  // kept for the next re-sync only while it is small change (0.8 GB at 1M tets)
   if (rc != FB_OK && D.first_bad_tet >= 0 && tets) {  // say which node, as the host builder does
     for (int k = 0; k < 4; k++) {

@@ -73,7 +73,8 @@ int device_partition(hipStream_t s, int n_tets, DevBuf<int4>& tets, int n_global
 
 // d_tets: n_tets x int4 node ids (local ids for a shard); their range is checked here (first_bad_tet).  shard = nullptr: the
 // unsharded system (every node a row).  Synchronises the stream before it returns.
-int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& out, PlanWorkspace& ws, const PlanShard* shard = nullptr);
+// span >= 0: the widest element of the list (largest id difference inside a tet, renumber.h) when the caller has measured it -- lets the sort use 32-bit keys
+int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& out, PlanWorkspace& ws, const PlanShard* shard = nullptr, int span = -1);
 
 // Incidence lists of the element-major assembly kernel (fem_device.hip.h k_assemble_tets), derived from a plan that is already
 // on the device (whichever builder made it): per slice the longest list of its 64 rows (inc_off = prefix sums), per (list row, lane)

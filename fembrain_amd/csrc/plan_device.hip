@@ -67,6 +67,47 @@ __global__ __launch_bounds__(kB) void k_plan_pairs(int n_tets, int n_nodes, Pair
   }
 }
 
+// The same with 32-bit keys (round 4) for an unsharded mesh whose widest element `span` (largest id difference inside a tet, measured by
+// renumber.hip) leaves room: key = row << cb | (col - row + span), cb = bits of 2 span + 1 -- the same order as (row, col), a third fewer
+// bytes through every pass of the sort and one pass fewer (1M-tet cube: 18 + 13 = 31 bits against 36; the sort was a quarter of a re-sync).
+__global__ __launch_bounds__(kB) void k_plan_pairs32(int n_tets, int n_nodes, int cb, int span, const int4* __restrict__ tets, unsigned int* __restrict__ keys,
+                                                     uint32_t* __restrict__ vals, int* __restrict__ first_bad) {
+  const long long i = (long long)blockIdx.x * kB + threadIdx.x;
+  const long long n_tp = 16LL * n_tets;
+  if (i < n_tp) {
+    const int e = (int)(i >> 4), ij = (int)(i & 15);
+    const int4 t = tets[e];
+    const int id[4] = {t.x, t.y, t.z, t.w};
+    const bool bad = (unsigned int)id[ij & 3] >= (unsigned int)n_nodes || (unsigned int)id[ij >> 2] >= (unsigned int)n_nodes;
+    if (bad) { atomicMin(first_bad, e); keys[i] = 0xFFFFFFFFu; vals[i] = kNoContrib; return; }  // (the host reports it; the keys of this run are never used)
+    const int row = id[ij >> 2], col = id[ij & 3];
+    keys[i] = ((unsigned int)row << cb) | (unsigned int)(col - row + span);
+    vals[i] = ((uint32_t)e << 4) | (uint32_t)ij;
+  } else if (i < n_tp + n_nodes) {
+    const unsigned int a = (unsigned int)(i - n_tp);
+    keys[i] = (a << cb) | (unsigned int)span;
+    vals[i] = kNoContrib;
+  }
+}
+
+__global__ __launch_bounds__(kB) void k_plan_rows32(int n_nodes, int n_blocks, int cb, int span, const unsigned int* __restrict__ ukeys, int* __restrict__ bptr,
+                                                    int* __restrict__ bcol) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i < n_blocks) {
+    const unsigned int k = ukeys[i];
+    bcol[i] = (int)(k >> cb) + (int)(k & ((1u << cb) - 1u)) - span;
+  }
+  if (i <= n_nodes) {
+    const unsigned long long want = (unsigned long long)(unsigned int)i << cb;  // (64-bit: row n_nodes may not fit the key)
+    int lo = 0, hi = n_blocks;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((unsigned long long)ukeys[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    bptr[i] = lo;
+  }
+}
+
 // block p: row, column; bptr by binary search of the first block of every row
 __global__ __launch_bounds__(kB) void k_plan_rows(int n_nodes, int n_blocks, PairGeom g, int n_halo, const unsigned long long* __restrict__ ukeys,
                                                   int* __restrict__ bptr, int* __restrict__ bcol) {
@@ -453,7 +494,7 @@ int build_incidence_device(hipStream_t s, int n_slices, int n_owned, const int* 
   return FB_OK;
 }
 
-int build_plan_device(hipStream_t s, int n_nodes_local, int n_tets, const int4* d_tets, DevicePlan& D, PlanWorkspace& W, const PlanShard* shard) {
+int build_plan_device(hipStream_t s, int n_nodes_local, int n_tets, const int4* d_tets, DevicePlan& D, PlanWorkspace& W, const PlanShard* shard, int span) {
   // n_nodes: matrix rows (owned nodes); n_nodes_local: range of the node ids in d_tets
   const int n_nodes = shard ? shard->n_rows : n_nodes_local;
   const long long n_pairs = 16LL * n_tets + n_nodes;
@@ -476,11 +517,20 @@ int build_plan_device(hipStream_t s, int n_nodes_local, int n_tets, const int4* 
   while ((1LL << row_bits) < (long long)n_nodes + (shard ? 1 : 0)) row_bits++;  // a shard needs the row value n_rows for the dropped pairs
   if (row_bits + geom.col_bits > 63) return fail(FB_EINVAL, "mesh too large for the device plan builder's sort key");
   const long long n_valid = shard ? shard->n_pairs : n_pairs;  // pairs that belong to a row
+  // 32-bit keys where the mesh is banded enough (see k_plan_pairs32)
+  int cb32 = 1;
+  while (span >= 0 && cb32 < 31 && (1LL << cb32) < 2LL * span + 1) cb32++;
+  int rb32 = 1;
+  while ((1LL << rb32) < (long long)n_nodes) rb32++;
+  const bool narrow = !shard && span >= 0 && span < n_nodes && rb32 + cb32 <= 32 && !(getenv("FEMBRAIN_PLAN_KEYS64") && atoi(getenv("FEMBRAIN_PLAN_KEYS64")) != 0);
   const int init[2] = {0x7fffffff, 0};  // [0] lowest tet with a bad node id, [1] "a column difference does not fit 16 bits"
   const int none = init[0];
   FB_HIP(hipMemcpyAsync(W.flags.p, init, sizeof init, hipMemcpyHostToDevice, s));
   struct { int* p; } bad = {W.flags.p};
-  hipLaunchKernelGGL(k_plan_pairs, dim3((unsigned)((n_pairs + kB - 1) / kB)), dim3(kB), 0, s, n_tets, n_nodes_local, geom, d_tets, keys.p, vals.p, bad.p);
+  unsigned int* keys32 = reinterpret_cast<unsigned int*>(keys.p);
+  unsigned int* keys32_s = reinterpret_cast<unsigned int*>(keys_s.p);
+  if (narrow) hipLaunchKernelGGL(k_plan_pairs32, dim3((unsigned)((n_pairs + kB - 1) / kB)), dim3(kB), 0, s, n_tets, n_nodes_local, cb32, span, d_tets, keys32, vals.p, bad.p);
+  else hipLaunchKernelGGL(k_plan_pairs, dim3((unsigned)((n_pairs + kB - 1) / kB)), dim3(kB), 0, s, n_tets, n_nodes_local, geom, d_tets, keys.p, vals.p, bad.p);
   FB_HIP(hipGetLastError());
   int first_bad = none;
   FB_HIP(hipMemcpyAsync(&first_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -488,18 +538,28 @@ int build_plan_device(hipStream_t s, int n_nodes_local, int n_tets, const int4* 
   D.first_bad_tet = first_bad == none ? -1 : first_bad;
   if (D.first_bad_tet >= 0) return fail(FB_EINVAL, "tet %d references a node outside [0,%d)", D.first_bad_tet, n_nodes_local);
   size_t bytes = 0;
-  const unsigned key_bits = (unsigned)(row_bits + geom.col_bits);
-  FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
-  FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
-  FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
-  // blocks = runs of equal keys
+  const unsigned key_bits = narrow ? (unsigned)(rb32 + cb32) : (unsigned)(row_bits + geom.col_bits);
   FB_TRY(ukeys.reserve((size_t)n_pairs));
   FB_TRY(ucnt.reserve((size_t)n_pairs));
   FB_TRY(nruns.reserve(1));
-  bytes = 0;
-  FB_HIP(rocprim::run_length_encode(nullptr, bytes, keys_s.p, (unsigned int)n_valid, ukeys.p, ucnt.p, nruns.p, s));
-  FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
-  FB_HIP(rocprim::run_length_encode(temp.p, bytes, keys_s.p, (unsigned int)n_valid, ukeys.p, ucnt.p, nruns.p, s));
+  unsigned int* ukeys32 = reinterpret_cast<unsigned int*>(ukeys.p);
+  if (narrow) {
+    FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys32, keys32_s, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
+    FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys32, keys32_s, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
+    bytes = 0;  // blocks = runs of equal keys
+    FB_HIP(rocprim::run_length_encode(nullptr, bytes, keys32_s, (unsigned int)n_valid, ukeys32, ucnt.p, nruns.p, s));
+    FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::run_length_encode(temp.p, bytes, keys32_s, (unsigned int)n_valid, ukeys32, ucnt.p, nruns.p, s));
+  } else {
+    FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
+    FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
+    bytes = 0;  // blocks = runs of equal keys
+    FB_HIP(rocprim::run_length_encode(nullptr, bytes, keys_s.p, (unsigned int)n_valid, ukeys.p, ucnt.p, nruns.p, s));
+    FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::run_length_encode(temp.p, bytes, keys_s.p, (unsigned int)n_valid, ukeys.p, ucnt.p, nruns.p, s));
+  }
   unsigned int nb = 0;
   FB_TRY(nruns.download(&nb, 1, s));
   D.n_blocks = (int)nb;
@@ -511,8 +571,12 @@ int build_plan_device(hipStream_t s, int n_nodes_local, int n_tets, const int4* 
   FB_TRY(D.bptr->alloc((size_t)n_nodes + 1));
   FB_TRY(D.bcol->alloc((size_t)nb));
   FB_TRY(D.blk_slot->alloc((size_t)nb));
-  hipLaunchKernelGGL(k_plan_rows, dim3((unsigned)((std::max<long long>(nb, n_nodes + 1) + kB - 1) / kB)), dim3(kB), 0, s, n_nodes, (int)nb, geom, shard ? shard->n_halo : 0, ukeys.p,
-                     D.bptr->p, D.bcol->p);
+  if (narrow)
+    hipLaunchKernelGGL(k_plan_rows32, dim3((unsigned)((std::max<long long>(nb, n_nodes + 1) + kB - 1) / kB)), dim3(kB), 0, s, n_nodes, (int)nb, cb32, span, ukeys32, D.bptr->p,
+                       D.bcol->p);
+  else
+    hipLaunchKernelGGL(k_plan_rows, dim3((unsigned)((std::max<long long>(nb, n_nodes + 1) + kB - 1) / kB)), dim3(kB), 0, s, n_nodes, (int)nb, geom, shard ? shard->n_halo : 0, ukeys.p,
+                       D.bptr->p, D.bcol->p);
   FB_HIP(hipGetLastError());
   // SELL-64
   const int n_slices = (n_nodes + kSliceRows - 1) / kSliceRows;

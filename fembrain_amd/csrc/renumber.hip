@@ -65,11 +65,16 @@ __global__ __launch_bounds__(kB) void k_invert(int n, const uint32_t* __restrict
   new_of_old[o] = l;
 }
 
-// out[0] = widest element, out[2..3] (one 64-bit word) = sum of the widths
+// out[0] = widest element, out[2..3] (one 64-bit word) = sum of the widths.  A fixed, small grid walks the list and ends with ONE pair of
+// atomics per workgroup: same-address atomics serialise at 12-17 ns each on this part, and a pair per wavefront of a thread-per-element
+// grid (15,600 wavefronts at 1M tets) made this trivial pass the second most expensive kernel of a re-sync (368 us).
+constexpr int kSpanBlocks = 256;
 __global__ __launch_bounds__(kB) void k_tet_span(int n_tets, const int4* __restrict__ tets, int n_nodes, const int* __restrict__ map, int* __restrict__ out) {
-  const int e = blockIdx.x * kB + threadIdx.x;
+  __shared__ int s_max[kB / 64];
+  __shared__ unsigned long long s_sum[kB / 64];
   int span = 0;
-  if (e < n_tets) {
+  unsigned long long sum = 0;
+  for (int e = blockIdx.x * kB + threadIdx.x; e < n_tets; e += gridDim.x * kB) {
     const int4 t = tets[e];
     const int v[4] = {t.x, t.y, t.z, t.w};
     bool ok = true;
@@ -80,15 +85,20 @@ __global__ __launch_bounds__(kB) void k_tet_span(int n_tets, const int4* __restr
         const int m = map ? map[v[i]] : v[i];
         lo = min(lo, m); hi = max(hi, m);
       }
-      span = hi - lo;
+      span = max(span, hi - lo);
+      sum += (unsigned long long)(hi - lo);
     }
   }
-  unsigned long long sum = (unsigned long long)span;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { span = max(span, __shfl_xor(span, o, 64)); sum += __shfl_xor(sum, o, 64); }
-  if ((threadIdx.x & 63) == 0 && span > 0) {
-    atomicMax(out, span);
-    atomicAdd(reinterpret_cast<unsigned long long*>(out + 2), sum);
+  if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = span; s_sum[threadIdx.x >> 6] = sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kB / 64; w++) { span = max(span, s_max[w]); sum += s_sum[w]; }
+    if (span > 0) {
+      atomicMax(out, span);
+      atomicAdd(reinterpret_cast<unsigned long long*>(out + 2), sum);
+    }
   }
 }
 
@@ -162,7 +172,7 @@ bool slab_key_geometry(int n_nodes, const double lo[3], const double hi[3], Slab
 int tet_span_device(hipStream_t s, int n_tets, const int4* d_tets, int n_nodes, const int* d_new_of_old, PlanWorkspace& W, int* span, double* mean) {
   FB_TRY(W.flags.reserve(4));
   FB_HIP(hipMemsetAsync(W.flags.p, 0, 4 * sizeof(int), s));
-  hipLaunchKernelGGL(k_tet_span, dim3((unsigned)((n_tets + kB - 1) / kB)), dim3(kB), 0, s, n_tets, d_tets, n_nodes, d_new_of_old, W.flags.p);
+  hipLaunchKernelGGL(k_tet_span, dim3((unsigned)std::max(1, std::min(kSpanBlocks, (n_tets + kB - 1) / kB))), dim3(kB), 0, s, n_tets, d_tets, n_nodes, d_new_of_old, W.flags.p);
   FB_HIP(hipGetLastError());
   int out[4];
   FB_HIP(hipMemcpyAsync(out, W.flags.p, sizeof out, hipMemcpyDeviceToHost, s));
