@@ -247,12 +247,24 @@ def field_bench(device, cpu=True):
     # included cell -- plus the two bit masks and scan bases it reads (2 x 1 bit + 2 x 4 B per 64 points); the whole pipeline moves
     # 16 B per point (sweep) + 12 B per tet-mesh vertex + 96 B per included cell + ~3 B per point of masks and scans
     n_inc, n_tv = int(c.n_included_cells), int(p.counts.n_tet_vertices)
+    # PMC traffic of the dominant kernel from the committed profile, only while the kernel sources are the profiled ones
+    ftraffic, fnote = None, "no PMC profile of the current kernel sources under profiles/"
+    try:
+        from fembrain_amd import lib as _fl
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r04_poly256_pmc.json")))
+        if rec.get("kernel_source_sha256") == _fl.source_sha256():
+            ftraffic = rec["kernels"]["k_tet_elements"]["bytes"]
+            fnote = "profiles/r04_poly256_pmc.json (2 x FETCH_SIZE + WRITE_SIZE of k_tet_elements, separate --pmc passes; same kernel sources)"
+        else:
+            fnote = "profiles/r04_poly256_pmc.json was recorded for other kernel sources: not reported"
+    except Exception:  # noqa: BLE001
+        pass
     elem_bytes = 96.0 * n_inc + npts / 64.0 * 24.0
     pipe_bytes = 16.0 * npts + 12.0 * n_tv + 96.0 * n_inc + 3.0 * npts
     field_roofline = {"kernel": "k_tet_elements (6 tets of 16 B per included cell, one wavefront per run of 4 mask words, records transposed through LDS)",
                       "bound": "hbm", "achieved": elem_bytes / st[3] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": elem_bytes / st[3] / 1e9 / HBM_PEAK_GBS,
                       "algorithmic_bytes_per_launch": elem_bytes, "us_per_launch": st[3] * 1e6,
-                      "traffic": None, "traffic_source": "store stream: WRITE_SIZE of the same kernel is in profiles/r04_poly256_pmc.json when recorded",
+                      "traffic": ftraffic, "traffic_source": fnote,
                       "ceiling_measured": {"gbs": 6700.0, "what": "plain 16-byte store stream of this part, tools/ubench/writebw.hip (DESIGN.md section 4)"},
                       "stages_us": {"k_sweep": st[0] * 1e6, "classification_and_scans": st[1] * 1e6, "k_tet_vertices": st[2] * 1e6, "k_tet_elements": st[3] * 1e6,
                                     "all_with_events_between": st[4] * 1e6},

@@ -282,3 +282,33 @@ def test_polygonizer_mesh_handed_over_on_the_device_can_be_renumbered(gpu):
     assert np.abs(qa - qb).max() <= 2e-5 * np.abs(qb).max() and not qa[fixed].any()
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("kw", [dict(integrator=fl.FB_INTEGRATOR_NEWMARK), dict(exact_tangent=True, matrix_precision=fl.FB_MATRIX_F64), dict(linear=True),
+                                dict(pcg_variant=fl.FB_PCG_REFERENCE), dict(pcg_variant=fl.FB_PCG_BLOCK_JACOBI), dict(spmv_kernel=fl.FB_SPMV_ROWS)])
+def test_every_force_model_and_solver_option_works_on_a_renumbered_handle(gpu, kw):
+    """SURVEY 8f-4's options (warp = 0 / 2, the Newmark step) and the solver variants on a scrambled cube with the renumbering forced: three
+    steps equal to those of a handle that keeps the caller's order (both stop at the same tolerance; tolerances of the un-renumbered tests)"""
+    n = 10
+    v0, t0 = truth_cube(n, n, n, 0.1)
+    m = np.random.default_rng(8).permutation(len(v0))
+    v, t, fx = scramble(v0, t0, cube_fixed_plane_i0(n, n), m)
+    fixed = fixed_vertices_to_dofs(fx)
+    a = FemIntegrator(v, t, fixed, renumber=fl.FB_RENUMBER_ON, **kw)
+    b = FemIntegrator(v, t, fixed, renumber=fl.FB_RENUMBER_OFF, **kw)
+    assert a.renumbering()[0] and not b.renumbering()[0]
+    f = np.zeros(a.r)
+    f[1::3] = -3000.0
+    f[0::3] = 200.0 * np.sin(7.0 * v[:, 2])
+    for _ in range(3):
+        for g in (a, b):
+            g.set_external_forces(f)
+        ia, ib = a.do_timestep(), b.do_timestep()
+        assert abs(ia - ib) <= max(3, 0.02 * ib), (kw, ia, ib)
+    (qa, wa, aa), (qb, wb, ab) = a.get_q_state(), b.get_q_state()
+    tol = 2e-5 if kw.get("matrix_precision") == fl.FB_MATRIX_F64 else 2e-4
+    assert np.abs(qa - qb).max() <= tol * np.abs(qb).max() and np.abs(wa - wb).max() <= 5 * tol * np.abs(wb).max() and not qa[fixed].any()
+    if "integrator" in kw:
+        assert np.abs(aa - ab).max() <= 20 * tol * np.abs(ab).max()
+    a.close()
+    b.close()
