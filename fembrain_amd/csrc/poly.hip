@@ -355,9 +355,26 @@ __device__ __forceinline__ float eval_field(const Instr* __restrict__ prog, int 
   return eval_field_t<false, SEM>(prog, n_instr, n_prims, prims, mtx, x, y, z, stk, none);
 }
 
+// Division of a grid index (< 2^31) by a grid extent without the ~25-instruction division sequence: n / d = mulhi(n, m) >> s with
+// m = floor(2^(31 + c) / d) + 1, s = c - 1, c = ceil(log2 d) (exact for n < 2^31: the error term n e / 2^(31 + c) is below 1 / d).
+// k_tet_vertices spent two thirds of its time in the two divisions per grid point (35 -> measured below at 256^3).
+struct FastDiv {
+  unsigned int mul, shift, one;  // one: d == 1
+};
+inline FastDiv fast_div(unsigned int d) {
+  FastDiv f = {0u, 0u, d <= 1u ? 1u : 0u};
+  if (d <= 1u) return f;
+  unsigned int c = 0;
+  while ((1ull << c) < d) c++;
+  f.mul = (unsigned int)(((1ull << (31 + c)) / d) + 1ull);
+  f.shift = c - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned int div_by(unsigned int n, const FastDiv f) { return f.one ? n : (__umulhi(n, f.mul) >> f.shift); }
+
 // ---- ComputeAllFields (Polygonizer.cl:1215-1236): v = lo + cellsize*(ix,iy,iz), index iz*gx*gy + iy*gx + ix ----
 template <bool CULL, int SEM>
-__global__ __launch_bounds__(kPB) void k_sweep(Grid G, const Instr* __restrict__ prog, int n_instr, int n_prims, int depth,
+__global__ __launch_bounds__(kPB) void k_sweep(Grid G, FastDiv dxy, FastDiv dx, const Instr* __restrict__ prog, int n_instr, int n_prims, int depth,
                                                const float* __restrict__ prims, const float* __restrict__ mtx, const float* __restrict__ pbox,
                                                const float* __restrict__ cbox, float4* __restrict__ grid, unsigned long long* __restrict__ inside) {
   extern __shared__ float stack[];
@@ -370,8 +387,8 @@ __global__ __launch_bounds__(kPB) void k_sweep(Grid G, const Instr* __restrict__
     bool in = false;
     // every lane's grid index (lanes past the end of the grid compute one too: harmless, they evaluate nothing)
     const unsigned int g32 = (unsigned int)gid;
-    const unsigned int iz = g32 / gxy, rem = g32 - iz * gxy;
-    const unsigned int iy = rem / gx, ix = rem - iy * gx;
+    const unsigned int iz = div_by(g32, dxy), rem = g32 - iz * gxy;
+    const unsigned int iy = div_by(rem, dx), ix = rem - iy * gx;
     // bounding box of this wavefront's 64-point run from the indices of its first and last valid lane (scalar reads of
     // values the lanes hold anyway)
     SegBox sb;
@@ -723,23 +740,6 @@ constexpr int kRun = 62;  // mask words a wave prefetches at once: lane j holds 
 
 // TetMeshVertices (Tetrahedralizer.cl:39-64): included grid points compacted in grid order, xyz = the sweep's positions: the
 // vertex of point p goes to rank vbase[p / 64] + popc(mask & lower bits).
-// Division of a grid index (< 2^31) by a grid extent without the ~25-instruction division sequence: n / d = mulhi(n, m) >> s with
-// m = floor(2^(31 + c) / d) + 1, s = c - 1, c = ceil(log2 d) (exact for n < 2^31: the error term n e / 2^(31 + c) is below 1 / d).
-// k_tet_vertices spent two thirds of its time in the two divisions per grid point (35 -> measured below at 256^3).
-struct FastDiv {
-  unsigned int mul, shift, one;  // one: d == 1
-};
-inline FastDiv fast_div(unsigned int d) {
-  FastDiv f = {0u, 0u, d <= 1u ? 1u : 0u};
-  if (d <= 1u) return f;
-  unsigned int c = 0;
-  while ((1ull << c) < d) c++;
-  f.mul = (unsigned int)(((1ull << (31 + c)) / d) + 1ull);
-  f.shift = c - 1;
-  return f;
-}
-__device__ __forceinline__ unsigned int div_by(unsigned int n, const FastDiv f) { return f.one ? n : (__umulhi(n, f.mul) >> f.shift); }
-
 constexpr int kVW = 16;  // mask words (1,024 grid points) per workgroup of k_tet_vertices
 __global__ __launch_bounds__(kPB) void k_tet_vertices(Grid G, FastDiv dxy, FastDiv dx, const unsigned long long* __restrict__ vinc,
                                                       const unsigned int* __restrict__ vbase, float* __restrict__ xyz) {
@@ -1681,7 +1681,8 @@ int do_sweep(fb_poly_s* h, bool store_grid) {
   const int blocks = (int)((G.n_points + (long long)kPB * kSweepPts - 1) / ((long long)kPB * kSweepPts));
   // with one or two primitives the box test costs more than it can save (sphere at 256^3: 66 vs 50 us)
 #define FB_SWEEP(CULL, SEM)                                                                                                                             \
-  hipLaunchKernelGGL((k_sweep<CULL, SEM>), dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, h->d_prog.p, (int)h->prog.size(), h->n_prims, h->depth, \
+  hipLaunchKernelGGL((k_sweep<CULL, SEM>), dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, fast_div((unsigned int)G.g[0] * (unsigned int)G.g[1]),                  \
+                     fast_div((unsigned int)G.g[0]), h->d_prog.p, (int)h->prog.size(), h->n_prims, h->depth, \
                      h->d_prims.p, h->d_mtx.p, h->d_pbox.p, h->d_cbox.p, store_grid ? h->grid.p : nullptr, h->inside.p)
   const bool cull = h->n_prims > 2;
   switch (h->sem) {
