@@ -252,7 +252,7 @@ def field_bench(device, cpu=True):
     try:
         from fembrain_amd import lib as _fl
         rec = json.load(open(os.path.join(ROOT, "profiles", "r04_poly256_pmc.json")))
-        if rec.get("kernel_source_sha256") == _fl.source_sha256():
+        if rec.get("kernel_source_sha256") == _fl.source_sha256("poly"):
             ftraffic = rec["kernels"]["k_tet_elements"]["bytes"]
             fnote = "profiles/r04_poly256_pmc.json (2 x FETCH_SIZE + WRITE_SIZE of k_tet_elements, separate --pmc passes; same kernel sources)"
         else:
@@ -697,7 +697,7 @@ def main():
             if os.path.exists(pmc) and args.workload == "cube56" and world == 1 and args.precision == "f32":
                 try:
                     rec = json.load(open(pmc))
-                    if rec.get("kernel_source_sha256") != fl.source_sha256():
+                    if rec.get("kernel_source_sha256") != fl.source_sha256("fem"):
                         traffic_note = "profiles/dominant_pmc.json was recorded for other kernel sources: not reported"
                     elif not rec.get("kernel", "").startswith(dominant):
                         traffic_note = "profiles/dominant_pmc.json is for %s, this run's dominant kernel is %s" % (rec.get("kernel"), dominant)

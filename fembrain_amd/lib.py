@@ -53,16 +53,23 @@ class PolyCounts(C.Structure):
                 ("n_surface_indices", C.c_int)]
 
 
-def source_sha256():
+def source_sha256(part=None):
     """Hash of the kernel sources (csrc/*.hip, *.h, *.cpp).  A profile under profiles/ records it; bench.py reports PMC traffic
-    from that profile only while the kernels are still the ones that were profiled."""
+    from that profile only while the kernels are still the ones that were profiled.  part = "fem": everything but the field / cutting
+    translation units (poly.hip, cut.hip); "poly": poly.hip and the shared headers it includes -- so that an edit of one half does not
+    retire the other half's profile."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(_HERE, "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+        if not name.endswith((".hip", ".h", ".cpp")):
+            continue
+        if part == "fem" and name in ("poly.hip", "cut.hip"):
+            continue
+        if part == "poly" and name not in ("poly.hip", "common.h"):
+            continue
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()
 
 

@@ -46,5 +46,5 @@ for k in sorted(set(f) | set(wv)):
               "duration_us_median_under_pmc": statistics.median(x[1] for x in fk) / 1e3}
 json.dump({"workload": "sphere.blob, 256^3 grid: sweep + classification + ranks + tet vertices + tet elements (tools/probe_poly.py, 31 pipeline runs)",
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact for 16-byte-per-lane stores",
-           "kernels": out, "kernel_source_sha256": source_sha256()}, open("profiles/%s_poly256_pmc.json" % tag, "w"), indent=1)
+           "kernels": out, "kernel_source_sha256": source_sha256("poly")}, open("profiles/%s_poly256_pmc.json" % tag, "w"), indent=1)
 print(open("profiles/%s_poly256_pmc.json" % tag).read())
