@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
   // y = A vin for the vector published last: drain the stores, flag, wait for the producers of this workgroup's columns,
   // multiply.  post_sums: the two wave sums in wsum[.][wv] are this iteration's local parts of gamma and delta -- posted with
   // the flag, read after the product.
-  auto product = [&](const double* vin, double* y, bool post_sums) {
+  auto product = [&](const double* vin, double* y, bool post_sums, bool late_acquire) {
     double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -289,8 +289,12 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
         st_sc1_u64(post + 1, (bits & 0xffffffffULL) | tag);
       }
       // Every wave of this workgroup is past its last gather from the buffer published now (two products ago) and none loads
-      // from the planes before the barrier below: drop this CU's L1 lines NOW (asynchronous), the poll runs meanwhile.
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // from the planes before the barrier below: drop this CU's L1 lines NOW (asynchronous), the poll runs meanwhile.  That early
+      // form rests on the sums: every workgroup has posted this iteration's sums, i.e. finished the product before the previous one, so
+      // no CU of this XCD pulls a line of this buffer's previous contents into the shared L2 any more.  Products that do not follow a
+      // sums sweep (the first of a launch, the exact-residual pair, the iteration after them) have no such guarantee about a sibling
+      // CU two products behind -- they take the guide's order, acquire AFTER the poll.
+      if (!late_acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       const long long t0 = wall_clock64();
       if (n_prod >= 0) {
         for (;;) {
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
         }
       }
       if (failed && lane == 0) st_sc1_u32(pa.error, 1u);
+      if (late_acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       if (plain_cand && !xcc_known && !failed) {  // first product of the launch: the producers' flags are in, so are their XCC ids
         const bool same = my_prod < 0 || ld_sc1_u32(pa.xcc + my_prod) == ((pub << 4) | my_xcc);
         const bool all_same = __ballot(!same) == 0ULL;
@@ -397,6 +402,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
   }
 
   bool done = false, published = false;  // published: the stores of the next product's input are on their way already
+  bool unsettled = true;                 // the next product does not follow a sums sweep of this launch: acquire after the poll
   double gamma = 0.0;
   int it_done = 0;
   while (!failed) {
@@ -425,7 +431,8 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
       if (lane == 0) { wsum[wvo] = a0; wsum[16 + wvo] = a1; }
     }
     double y[3];
-    product(vin, y, phase == PH_ITER);
+    product(vin, y, phase == PH_ITER, phase != PH_ITER || unsettled);
+    unsettled = phase != PH_ITER;  // (an iteration's sums sweep settles the next product's early acquire)
     if (failed) break;
     if (phase == PH_WARM_X || phase == PH_REFRESH_X) {
       unsigned int d3 = 3u * (unsigned int)(rvalid ? row : 0);

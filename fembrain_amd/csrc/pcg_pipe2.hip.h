@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
         if constexpr (SHARD) shard_send_row(sa, BL, pub, send_beg[h], send_end[h], vin[h]);
       }
   };
-  auto product = [&](const double vin[2][3], double y[2][3], bool post_sums) {
+  auto product = [&](const double vin[2][3], double y[2][3], bool post_sums, bool late_acquire) {
     double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
         st_sc1_u64(post, (bits >> 32) | tag);
         st_sc1_u64(post + 1, (bits & 0xffffffffULL) | tag);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (!late_acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (early where the product follows a sums sweep, else after the poll: pcg_pipe.hip.h)
       const long long t0 = wall_clock64();
       if (n_prod >= 0) {
         for (;;) {
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
         }
       }
       if (failed && lane == 0) st_sc1_u32(pa.error, 1u);
+      if (late_acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) bc[3] = (failed || ld_sc1_u32(pa.error) != 0u) ? 1.0 : 0.0;
     }
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
     phase = PH_INIT_W;
   }
 
+  bool unsettled = true;  // the next product does not follow a sums sweep of this launch: acquire after the poll
   bool done = false, published = false;
   double gamma = 0.0;
   int it_done = 0;
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
       if (lane == 0) { wsum[wvo] = a0; wsum[16 + wvo] = a1; }
     }
     double y[2][3];
-    product(vin, y, phase == PH_ITER);
+    product(vin, y, phase == PH_ITER, phase != PH_ITER || unsettled);
+    unsettled = phase != PH_ITER;
     if (failed) break;
     if (phase == PH_WARM_X || phase == PH_REFRESH_X) {
 #pragma unroll
