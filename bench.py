@@ -229,6 +229,38 @@ def numbering_leg(device, prec):
             "resync_ms_all": [round(x, 3) for x in rs]}
 
 
+def block_jacobi_leg(device, prec, steps=5):
+    """the headline mesh with the OPT-IN 3x3 block-Jacobi preconditioner (FB_PCG_BLOCK_JACOBI, not the reference's
+    preconditioner, outside every parity claim and never part of `value`) inside the same persistent kernel (k_pcg_pipe<.., BJ>):
+    steps from the rest state under the reference load, as `value` is."""
+    from fembrain_amd import lib as fl
+    from fembrain_amd.fem import FemIntegrator
+    import torch
+    v, t, fixed = workload_mesh("cube56", device)
+    g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device, pcg_variant=fl.FB_PCG_BLOCK_JACOBI)
+
+    def step():
+        g.rebuild_elements()
+        g.set_uniform_force(1, -10000.0)
+        return g.do_timestep()
+    step()
+    tot, its, solve = 0.0, [], 0.0
+    for _ in range(steps):
+        g.reset_to_rest()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        its.append(step())
+        torch.cuda.synchronize()
+        tot += time.perf_counter() - ts
+        solve += g.last.solve_seconds
+    path, last_path = g.pcg_path(), int(g.last.pcg_path)
+    g.close()
+    return {"workload": WORKLOADS["cube56"][1], "preconditioner": "inverse 3x3 diagonal blocks (opt-in; the reference and `value` use 1/diag)",
+            "parity": "outside the parity claim: same system, same tolerance, another preconditioner (tests compare the solutions at 1e-4)",
+            "steps": steps, "value": steps / tot, "unit": "steps/s", "ms_per_step": tot / steps * 1e3, "cg_iterations": [int(i) for i in its],
+            "us_per_cg_iteration": solve / max(sum(its), 1) * 1e6, "pcg_kernel": path["kernel"], "pcg_path_last_step": last_path}
+
+
 def field_bench(device, cpu=True):
     """256^3 sweep + classify + tetrahedralize of sphere.blob (BASELINE config 3); returns extra JSON keys."""
     from fembrain_amd.poly import GpuPoly, sphere_blob
@@ -815,6 +847,9 @@ def main():
             leg, why = stage("leg: scrambled node order", lambda: numbering_leg(device, prec), optional=True)
             if out is not None:
                 out["cube56_scrambled"] = leg if leg else {"error": why}
+            leg, why = stage("leg: opt-in block-Jacobi", lambda: block_jacobi_leg(device, prec), optional=True)
+            if out is not None:
+                out["cube56_block_jacobi_opt_in"] = leg if leg else {"error": why}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             _state["stage"] = "cpu baseline"
             try:

@@ -378,15 +378,19 @@ int setup_persist(fb_fem_s* h) {
   // (us per iteration, two-launch vs persistent, on MI355X: 7.83 / 7.87 at 125 slices = 1 per CU, 8.74 / 8.74 at 308 and 8.98 / 8.64 at 466
   // = 2 per CU, 10.9 / 8.8 at 614 = 3 per CU, 14.0 / 10.3 at 792, 15.8 / 8.9 at 1,000, 27.4 / 15.75 at 2,744 = 1M tets)
   static const int min_w = getenv("FEMBRAIN_PERSIST_MIN_WAVES") ? atoi(getenv("FEMBRAIN_PERSIST_MIN_WAVES")) : 2;
-  const bool by_default = h->prm.pcg_variant == FB_PCG_MERGED && w >= min_w;
-  const bool want_p = e ? atoi(e) != 0 && (h->prm.pcg_variant == FB_PCG_MERGED || explicit_p) : (explicit_p || by_default);
+  // FB_PCG_BLOCK_JACOBI (opt-in, outside parity): the one-row persistent kernel with the block preconditioner, same rule
+  const bool bj = h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI;
+  const bool rows2_forced = getenv("FEMBRAIN_PERSIST_ROWS") && atoi(getenv("FEMBRAIN_PERSIST_ROWS")) == 2;
+  const bool by_default = (h->prm.pcg_variant == FB_PCG_MERGED || bj) && w >= min_w;
+  const bool want_p = e ? atoi(e) != 0 && (h->prm.pcg_variant == FB_PCG_MERGED || explicit_p || bj) : (explicit_p || by_default);
   if (!want_p || !eligible) return FB_OK;
+  if (bj && (w > kPipeMaxWaves || rows2_forced || P.n_ranks > 1)) return FB_OK;  // (no two-row form with the block preconditioner)
   if (P.n_ranks > 1) return setup_persist_shard_local(h, nb, w);
   h->persist = true; h->persist_blocks = nb; h->persist_waves = w;
   // pipelined whole-solve kernel
   // up to 12 slices per CU: one row per lane (k_pcg_pipe); 13..24: two (k_pcg_pipe2, no LDS-resident slots).  FEMBRAIN_PERSIST_ROWS=2
   // forces the two-row kernel on a smaller system (tests).
-  h->pipe_rows = w > kPipeMaxWaves || (getenv("FEMBRAIN_PERSIST_ROWS") && atoi(getenv("FEMBRAIN_PERSIST_ROWS")) == 2) ? 2 : 1;
+  h->pipe_rows = w > kPipeMaxWaves || rows2_forced ? 2 : 1;
   h->pipe_wmax = h->pipe_rows == 2 ? 12 : (w <= 8 ? 8 : 12);
   // slots of every slice resident in LDS at least: the CU's kPipeLdsSlots dealt to the slices of a workgroup (k_pcg_pipe), at most 8 / 6
   h->pipe_klt = h->pipe_rows == 2 ? 0 : std::min(w <= 8 ? 8 : 6, kPipeLdsSlots / std::max(w, 1));
@@ -1007,6 +1011,13 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     hipLaunchKernelGGL((k_pcg_pipe<float, C16, WMAX, KLT, TIMING, SHARD>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p,       \
                        (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);          \
   } while (0)
+#define FB_PIPE_BJ(C16, WMAX, KLT)                                                                                                                     \
+  do {                                                                                                                                                \
+    FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe<float, C16, WMAX, KLT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                               (int)lds));                                                                                                           \
+    hipLaunchKernelGGL((k_pcg_pipe<float, C16, WMAX, KLT, false, false, true>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p,  \
+                       (const float*)h->dlo.p, h->invblk.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);           \
+  } while (0)
 #define FB_PIPE2(C16, SHARD)                                                                                                                          \
   do {                                                                                                                                                \
     FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe2<C16, SHARD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
@@ -1016,7 +1027,11 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)kPipeMaxWaves * 2 * kPipe2LdsWordsPerRow * 64 * 4 <= 160 * 1024, "LDS budget of k_pcg_pipe2");
   // the instantiations: (wavefronts, most LDS slots per wavefront) = (8, 8) up to 8 slices per CU, (12, 6) up to 12; 16- or 32-bit column words;
   // two rows per lane (k_pcg_pipe2) for 13..24 slices per CU; SHARD = true on a sharded handle (32-bit local column ids)
-  if (h->shard_persist) {
+  if (h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI) {  // (setup_persist: unsharded, one row per lane)
+    if (pa.timing) return fail(FB_EINVAL, "FEMBRAIN_PERSIST_TIMING is built for the Jacobi kernel");
+    if (h->pipe_wmax == 8) { if (h->c16) FB_PIPE_BJ(true, 8, 8); else FB_PIPE_BJ(false, 8, 8); }
+    else { if (h->c16) FB_PIPE_BJ(true, 12, 6); else FB_PIPE_BJ(false, 12, 6); }
+  } else if (h->shard_persist) {
     if (h->pipe_rows == 2) FB_PIPE2(false, true);
     else if (h->pipe_wmax == 8) FB_PIPE(false, 8, 8, false, true);
     else FB_PIPE(false, 12, 6, false, true);
@@ -1028,6 +1043,7 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   } else if (h->pipe_wmax == 8) { if (h->c16) FB_PIPE(true, 8, 8, false, false); else FB_PIPE(false, 8, 8, false, false); }
   else { if (h->c16) FB_PIPE(true, 12, 6, false, false); else FB_PIPE(false, 12, 6, false, false); }
 #undef FB_PIPE2
+#undef FB_PIPE_BJ
 #undef FB_PIPE
   FB_HIP(hipGetLastError());
   FB_HIP(hipEventRecord(h->ev_p[1], h->stream));
@@ -1171,7 +1187,8 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
     read_persist_timeout(h);
     fprintf(stderr, "[fembrain] persistent PCG: re-armed after %d two-launch solves\n", h->clean_solves);
   }
-  if (allow_persist && h->persist && eps >= kPersistMinEps && (h->prm.pcg_variant == FB_PCG_MERGED || h->prm.pcg_variant == FB_PCG_PERSISTENT))
+  if (allow_persist && h->persist && eps >= kPersistMinEps &&
+      (h->prm.pcg_variant == FB_PCG_MERGED || h->prm.pcg_variant == FB_PCG_PERSISTENT || h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI))
     return pcg_solve_pipe(h, b, eps, max_iter, iters_out, final_state);
   if (allow_persist && h->persist_broken) h->clean_solves++;
   h->last_pcg_path = FB_PCG_PATH_TWO_LAUNCH;
@@ -1189,10 +1206,16 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
     FB_TRY(h->st.zero(s));  // done = 0: the SpMV below is not a no-op
     FB_TRY(halo_exchange(h, h->x.p));
     FB_TRY(spmv<2>(h, h->x.p, h->r.p, b, h->part_b.p, 0));
-    hipLaunchKernelGGL(k_cg_init_warm, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->r.p, h->invdiag.p, h->d.p);
-    FB_HIP(hipGetLastError());
-    FB_TRY(global_scalar(h, h->part_b.p, &sc, false, 1, 0, h->sgrid));
-    hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, s, h->st.p, h->part_b.p, h->sgrid, sc, eps, max_iter);
+    if (h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI) {  // d = B^-1 r and rho = r . B^-1 r (the SpMV's Jacobi-weighted sum is not used)
+      hipLaunchKernelGGL(k_bj_init_warm, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->r.p, h->invblk.p, h->d.p, h->part_b.p);
+      FB_HIP(hipGetLastError());
+      hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, s, h->st.p, h->part_b.p, h->grid, (const double*)nullptr, eps, max_iter);
+    } else {
+      hipLaunchKernelGGL(k_cg_init_warm, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->r.p, h->invdiag.p, h->d.p);
+      FB_HIP(hipGetLastError());
+      FB_TRY(global_scalar(h, h->part_b.p, &sc, false, 1, 0, h->sgrid));
+      hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, s, h->st.p, h->part_b.p, h->sgrid, sc, eps, max_iter);
+    }
   } else if (h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI) {
     hipLaunchKernelGGL(k_bj_init, dim3(h->grid), dim3(kBlock), 0, s, P.n_slices, P.n_owned, b, h->invblk.p, h->x.p, h->r.p, h->d.p, h->part_b.p);
     FB_HIP(hipGetLastError());
@@ -2549,7 +2572,9 @@ int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches,
     if (h->persist && h->shard_persist && h->pipe_rows == 2) snprintf(name, name_len, "k_pcg_pipe2_shard");
     else if (h->persist && h->shard_persist) snprintf(name, name_len, "k_pcg_pipe_shard<%d,%d>", h->pipe_wmax, h->pipe_wmax == 8 ? 8 : 6);
     else if (h->persist && h->pipe_rows == 2) snprintf(name, name_len, "k_pcg_pipe2<%s>", h->c16 ? "c16" : "c32");
-    else if (h->persist) snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_wmax == 8 ? 8 : 6);
+    else if (h->persist)
+      snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d%s>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_wmax == 8 ? 8 : 6,
+               h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI ? ",bj" : "");
     else name[0] = 0;
   }
   if (persist_launches) *persist_launches = h->persist_launches;

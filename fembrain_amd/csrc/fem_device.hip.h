@@ -1523,6 +1523,26 @@ __global__ __launch_bounds__(kBlock) void k_bj_init(int n_slices, int n_owned, c
   const double tot = block_sum(acc, lds);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
+// warm start (x kept, r = b - A x left by the SpMV): d = B^-1 r, partial = sum r . B^-1 r
+__global__ __launch_bounds__(kBlock) void k_bj_init_warm(int n_slices, int n_owned, const double* __restrict__ r, const double* __restrict__ invblk,
+                                                         double* __restrict__ d, double* __restrict__ partial) {
+  __shared__ double lds[4];
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (SliceWalk w(n_slices); w.valid(); w.next()) {
+    const int row = w.s * 64 + lane;
+    if (row < n_owned) {
+      const size_t i = 3 * (size_t)row;
+      const double rr[3] = {r[i], r[i + 1], r[i + 2]};
+      double z[3];
+      blk_apply(invblk + 9 * (size_t)row, rr, z);
+#pragma unroll
+      for (int a = 0; a < 3; a++) { d[i + a] = z[a]; acc += rr[a] * z[a]; }
+    }
+  }
+  const double tot = block_sum(acc, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
 // alpha = rho / (d.q); x += alpha d; REFRESH ? nothing more : (r -= alpha q, partial = sum r . B^-1 r)
 template <bool REFRESH>
 __global__ __launch_bounds__(kBlock) void k_bj_update(int n_slices, int n_owned, const CGState* __restrict__ st, int parity, const double* __restrict__ part_dq,

@@ -161,13 +161,16 @@ namespace fb {
 // SHARD: the kernel of a sharded handle (pcg_shard_box.hip.h; "k_pcg_pipe_shard<WMAX,KLT>" in fb_fem_pcg_path): the slices come from the
 // plan's deal (sa.wg_range), the last wavefront is the spare one (sums, counters, proxy copies), rows a neighbour rank gathers are also
 // stored into its box, the sums go through the rank level; 32-bit column words, write-through stores.  sa is not read otherwise.
-template <typename MT, bool C16, int WMAX, int KLT, bool TIMING, bool SHARD>
+// BJ (FB_PCG_BLOCK_JACOBI, opt-in and not part of the reference): the preconditioner is the inverse of the row's 3x3 diagonal block
+// instead of 1/diag -- `invdiag` then points at 9 doubles per row (symmetric: 6 are loaded).  The Jacobi instantiations do not change.
+template <typename MT, bool C16, int WMAX, int KLT, bool TIMING, bool SHARD, bool BJ = false>
 __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo,
                                                         const double* __restrict__ invdiag, const double* __restrict__ bvec, double* __restrict__ xg,
                                                         double* __restrict__ rg, double* __restrict__ wg, double* __restrict__ zg,
                                                         double* __restrict__ sg, double* __restrict__ pg, CGState* __restrict__ st, PipeArgs pa,
                                                         ShardArgs sa) {
   static_assert(!SHARD || (!C16 && !TIMING), "a shard's columns are 32-bit local ids; the phase clocks are built for the unsharded kernel");
+  static_assert(!BJ || (!SHARD && !TIMING), "block-Jacobi is for unsharded handles");
   static_assert(sizeof(MT) == 4, "k_pcg_pipe keeps part of the matrix in LDS as fp32 words and streams the rest as fp32");
   extern __shared__ double lds[];  // the request is padded so that one workgroup fills a CU
   double* wsum = lds;                          // [2][16] wave sums
@@ -194,13 +197,18 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
   const short* cd = C16 ? sv.coldelta + (size_t)so * 64 + lane : nullptr;
   // low part of the diagonal block (symmetric: 6 planes) and 1/diag, fixed for the solve
   MT m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;
-  double iv[3] = {0, 0, 0};
+  double iv[BJ ? 6 : 3] = {0};  // 1/diag, or (BJ) the inverse diagonal block: 00 01 02 11 12 22
   int send_beg = 0, send_end = 0;  // (SHARD) this row's entries of the send lists
   if (rvalid) {
     const MT* l = dlo + (size_t)sl * 9 * 64 + lane;
     m00 = l[0 * 64]; m01 = l[1 * 64]; m02 = l[2 * 64]; m11 = l[4 * 64]; m12 = l[5 * 64]; m22 = l[8 * 64];
+    if constexpr (BJ) {
+      const double* B = invdiag + 3 * dof;
+      iv[0] = B[0]; iv[1] = B[1]; iv[2] = B[2]; iv[3] = B[4]; iv[4] = B[5]; iv[5] = B[8];
+    } else {
 #pragma unroll
-    for (int a = 0; a < 3; a++) iv[a] = invdiag[dof + a];
+      for (int a = 0; a < 3; a++) iv[a] = invdiag[dof + a];
+    }
     if constexpr (SHARD) { send_beg = sa.row_send_off[row]; send_end = sa.row_send_off[row + 1]; }
   }
   // LDS-resident part of the matrix: the first KL slots of this wave's slice, [klt_w][10][64] words (9 values + the column id)
@@ -401,6 +409,17 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     phase = PH_INIT_W;
   }
 
+  // out = M^-1 v: v / diag, or (BJ) the inverse diagonal block times v
+  auto precond = [&](const double* vv, double* out) {
+    if constexpr (BJ) {
+      out[0] = iv[0] * vv[0] + iv[1] * vv[1] + iv[2] * vv[2];
+      out[1] = iv[1] * vv[0] + iv[3] * vv[1] + iv[4] * vv[2];
+      out[2] = iv[2] * vv[0] + iv[4] * vv[1] + iv[5] * vv[2];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; a++) out[a] = iv[a] * vv[a];
+    }
+  };
   bool done = false, published = false;  // published: the stores of the next product's input are on their way already
   bool unsettled = true;                 // the next product does not follow a sums sweep of this launch: acquire after the poll
   double gamma = 0.0;
@@ -412,17 +431,16 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
 #pragma unroll
       for (int a = 0; a < 3; a++) vin[a] = xr[a];
     } else if (phase == PH_ITER) {
-#pragma unroll
-      for (int a = 0; a < 3; a++) vin[a] = iv[a] * wr[a];  // m = w / diag
+      precond(wr, vin);  // m = w / diag
     } else {
-#pragma unroll
-      for (int a = 0; a < 3; a++) vin[a] = iv[a] * rr[a];
+      precond(rr, vin);
     }
     if (!published) publish(vin);
     published = false;
     if (phase == PH_ITER) {
       // local parts of gamma = r . u and delta = w . u (u = r / diag), while the stores drain
-      const double u[3] = {iv[0] * rr[0], iv[1] * rr[1], iv[2] * rr[2]};
+      double u[3];
+      precond(rr, u);
       double a0 = rr[0] * u[0] + rr[1] * u[1] + rr[2] * u[2];
       double a1 = wr[0] * u[0] + wr[1] * u[1] + wr[2] * u[2];
       a0 = wave_sum(a0); a1 = wave_sum(a1);
@@ -529,15 +547,22 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
       // (Every workgroup has posted this iteration's sums, i.e. finished the product before this one: the buffer is free.)
       double m[3];
 #pragma unroll
-      for (int a = 0; a < 3; a++) { wr[a] = wr[a] - alpha * zr[a]; m[a] = iv[a] * wr[a]; }
+      for (int a = 0; a < 3; a++) wr[a] = wr[a] - alpha * zr[a];
+      precond(wr, m);
       publish(m);
       published = true;
     }
+    if constexpr (BJ) {
+      double ur[3];
+      precond(rr, ur);
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      pr[a] = iv[a] * rr[a] + beta * pr[a];
-      xr[a] = xr[a] + alpha * pr[a];
+      for (int a = 0; a < 3; a++) pr[a] = ur[a] + beta * pr[a];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; a++) pr[a] = iv[a] * rr[a] + beta * pr[a];
     }
+#pragma unroll
+    for (int a = 0; a < 3; a++) xr[a] = xr[a] + alpha * pr[a];
     if (refresh) {
       phase = PH_REFRESH_X;  // exact residual (CGSolver.cpp:159-166), and the w that goes with it: two more products
     } else {

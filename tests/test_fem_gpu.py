@@ -1518,6 +1518,41 @@ def test_newmark_needs_its_integrator_and_resets(gpu):
     assert gn.do_timestep() == a and all(np.array_equal(x, y) for x, y in zip(gn.get_q_state(), q1))
 
 
+@pytest.mark.parametrize("n,renumber,kernel", [(27, fl.FB_RENUMBER_OFF, "k_pcg_pipe<float,c16,8,8,bj>"), (56, fl.FB_RENUMBER_OFF, "k_pcg_pipe<float,c16,12,6,bj>"),
+                                              (30, fl.FB_RENUMBER_ON, "k_pcg_pipe<float,c16,8,8,bj>")])
+def test_block_jacobi_inside_the_persistent_kernel(gpu, monkeypatch, n, renumber, kernel):
+    """FB_PCG_BLOCK_JACOBI (opt-in, outside the parity claim) runs inside k_pcg_pipe<.., BJ> where the handle is eligible for the
+    one-row persistent kernel: the steps agree with the two-launch block-Jacobi solver (FEMBRAIN_PCG_PERSIST=0) to the solver
+    tolerance, in about the same number of iterations, fewer than Jacobi; a tight tolerance leaves the persistent kernel"""
+    v, t, fixed = _cube(n)
+    gp = FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_BLOCK_JACOBI, renumber=renumber)
+    assert gp.persist_info()[0] and gp.pcg_path()["kernel"] == kernel, gp.pcg_path()
+    monkeypatch.setenv("FEMBRAIN_PCG_PERSIST", "0")
+    g2 = FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_BLOCK_JACOBI, renumber=renumber)
+    monkeypatch.delenv("FEMBRAIN_PCG_PERSIST")
+    assert not g2.persist_info()[0] and g2.pcg_path()["kernel"] == ""
+    gj = FemIntegrator(v, t, fixed, renumber=renumber)
+    for k in range(3):
+        its = []
+        for g in (gp, g2, gj):
+            g.set_uniform_force(1, -1000.0)
+            its.append(g.do_timestep())
+        assert gp.last.pcg_path == fl.FB_PCG_PATH_PERSISTENT and g2.last.pcg_path == fl.FB_PCG_PATH_TWO_LAUNCH
+        assert 0 < its[0] < its[2] and abs(its[0] - its[1]) <= max(3, its[1] // 20), its
+        qp, q2, qj = (g.get_q_state()[0] for g in (gp, g2, gj))
+        assert np.abs(qp - q2).max() <= 2e-5 * np.abs(q2).max()
+        if k == 0:   # (another preconditioner stops on another norm: the trajectories part at the solver tolerance per step)
+            assert np.abs(qp - qj).max() <= 1e-4 * np.abs(qj).max()
+        assert not qp[fixed].any()
+    _, rhs = gp.system()
+    it, x = gp.pcg(rhs, eps=1e-10, max_iter=20000)   # below the persistent solver's tolerance floor: the literal two-launch sequence
+    assert it > 0 and gp.pcg_path()["path"] == fl.FB_PCG_PATH_TWO_LAUNCH
+    res = rhs - gp.spmv(x)
+    assert np.abs(res).max() <= 1e-6 * np.abs(rhs).max()
+    for g in (gp, g2, gj):
+        g.close()
+
+
 def test_block_jacobi_option_solves_the_same_system_in_fewer_iterations(gpu):
     """FB_PCG_BLOCK_JACOBI (opt-in, not the reference's preconditioner): same solution of the same Keff to the solver tolerance,
     the constrained rows stay put, and it needs fewer iterations than Jacobi on the reference-load cantilever"""
