@@ -33,7 +33,8 @@ int fail(int code, const char* fmt, ...);
 template <class T>
 struct DevBuf {
   T* p = nullptr;
-  size_t n = 0;
+  size_t n = 0;    // elements in use
+  size_t cap = 0;  // elements allocated (>= n)
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
@@ -42,19 +43,31 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    cap = 0;
   }
+  // An allocation is kept while the new size fits it and fills at least half of it, and a new one gets an eighth of slack: a re-sync
+  // after a cut changes every size a little (nodes and elements are added), and hipFree + hipMalloc of ~40 buffers of up to 100 MB
+  // cost 7 of the 10 ms such a re-sync took at 1M tets (tools/probe_resync_cut.py) when every size was exact.
   int alloc(size_t count) {
-    if (count == n && p) return FB_OK;
+    if (p && count <= cap && (count >= cap / 2 || cap * sizeof(T) <= (1u << 20)) && count > 0) { n = count; return FB_OK; }
     release();
     if (count == 0) return FB_OK;
-    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    const size_t want = count + (count * sizeof(T) >= (1u << 16) ? count / 8 : 0);
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e != hipSuccess && want != count) {  // no room for the slack: the exact size
+      (void)hipGetLastError();
+      e = hipMalloc((void**)&p, count * sizeof(T));
+      if (e == hipSuccess) { n = cap = count; return FB_OK; }
+    }
     if (e != hipSuccess) return fail(FB_ENOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
     n = count;
+    cap = want;
     return FB_OK;
   }
   // grow-only: keeps a larger allocation (workspaces that are reused with varying sizes)
   int reserve(size_t count) {
     if (p && n >= count) return FB_OK;
+    if (p && cap >= count) { n = count; return FB_OK; }
     return alloc(count);
   }
   int zero(hipStream_t s) {

@@ -83,3 +83,45 @@ def read_veg(path):
     e = np.array(tets, dtype=np.int64)
     base = int(v[:, 0].min()) if len(v) else 1
     return np.ascontiguousarray(v[:, 1:4]), np.ascontiguousarray((e[:, 1:5] - base).astype(np.int32))
+
+
+def apply_delta(v, t, delta):
+    """The mesh a topology delta describes (the contract of ``fb_fem_resync_delta``): ``changed`` elements get their new nodes in
+    place, ``removed`` elements are erased keeping the order of the rest (``VolMesh::remove_cell_core``: ``m_vCells.erase``, reference
+    src/deformable/VolMesh.cpp:630), ``added`` elements and ``new_xyz`` nodes are appended (``insert_node``: ``push_back``, :1083-1088)."""
+    t2 = np.array(t, dtype=np.int32, copy=True)
+    if len(delta["changed_ids"]):
+        t2[np.asarray(delta["changed_ids"], dtype=np.int64)] = np.asarray(delta["changed_nodes"], dtype=np.int32).reshape(-1, 4)
+    keep = np.ones(len(t2), dtype=bool)
+    keep[np.asarray(delta["removed"], dtype=np.int64)] = False
+    added = np.asarray(delta["added"], dtype=np.int32).reshape(-1, 4)
+    t2 = np.ascontiguousarray(np.concatenate([t2[keep], added], axis=0).astype(np.int32))
+    new_xyz = np.asarray(delta["new_xyz"], dtype=np.float64).reshape(-1, 3)
+    v2 = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64), new_xyz], axis=0))
+    return v2, t2
+
+
+def synthetic_cut(v, t, axis=1, where=0.5, every_changed=3):
+    """A cut-shaped topology change for tests and probes (not the reference's subdivision tables): every element (a, b, c, d) whose
+    nodes lie on both sides of the plane ``x[axis] = lo + where * (hi - lo)`` is split in four on a new node m at its centroid:
+    (a, b, c, m), (m, b, c, d), (a, m, c, d), (a, b, m, d).  Every ``every_changed``-th of them is changed in place to the first and the
+    other three are appended; the others are removed and all four appended.  Returns (v2, t2, delta) with delta = dict(removed,
+    changed_ids, changed_nodes, added, new_xyz) -- ids in the old numbering, removed ascending."""
+    v = np.asarray(v, dtype=np.float64)
+    t = np.asarray(t, dtype=np.int32)
+    x = v[:, axis][t]
+    c = v[:, axis].min() + where * (v[:, axis].max() - v[:, axis].min())
+    hit = np.nonzero((x.min(axis=1) < c) & (x.max(axis=1) > c))[0]
+    m = (len(v) + np.arange(len(hit))).astype(np.int32)
+    new_xyz = v[t[hit]].mean(axis=1)
+    a, b, cc, d = (t[hit, k] for k in range(4))
+    chg = (np.arange(len(hit)) % every_changed) == 0 if every_changed else np.zeros(len(hit), dtype=bool)
+    four = np.stack([np.stack([a, b, cc, m], axis=1), np.stack([m, b, cc, d], axis=1), np.stack([a, m, cc, d], axis=1),
+                     np.stack([a, b, m, d], axis=1)], axis=1)          # [hit, 4, 4]
+    take = np.ones((len(hit), 4), dtype=bool)
+    take[chg, 0] = False                                                # (the first piece of a changed element stays in its place)
+    delta = dict(removed=np.ascontiguousarray(hit[~chg].astype(np.int32)), changed_ids=np.ascontiguousarray(hit[chg].astype(np.int32)),
+                 changed_nodes=np.ascontiguousarray(four[chg, 0].astype(np.int32)),
+                 added=np.ascontiguousarray(four[take].reshape(-1, 4).astype(np.int32)), new_xyz=np.ascontiguousarray(new_xyz))
+    v2, t2 = apply_delta(v, t, delta)
+    return v2, t2, delta
