@@ -70,6 +70,11 @@ struct DevBuf {
     if (p && cap >= count) { n = count; return FB_OK; }
     return alloc(count);
   }
+  void swap(DevBuf& o) {
+    T* tp = p; p = o.p; o.p = tp;
+    size_t t = n; n = o.n; o.n = t;
+    t = cap; cap = o.cap; o.cap = t;
+  }
   int zero(hipStream_t s) {
     if (n) FB_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
     return FB_OK;
@@ -96,7 +101,8 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // the tet mesh a polygonizer handle holds on its device after fb_poly_tetrahedralize (poly.hip -> fem.hip hand-off):
 // positions 3 floats per vertex, elements 4 vertex ids per tet; the handle's stream has been synchronised
-struct DeviceTetMesh { int device, n_vertices, n_tets; const float* xyz; const uint4* tets; };
+// (xyz64: the positions as doubles instead -- the handle's own device copy, fb_fem_resync_delta)
+struct DeviceTetMesh { int device, n_vertices, n_tets; const float* xyz; const uint4* tets; const double* xyz64 = nullptr; };
 int poly_device_tetmesh(fb_poly_t h, DeviceTetMesh* out);
 
 }  // namespace fb

@@ -1,0 +1,363 @@
+// fb_fem_resync_delta: the device side (see delta.h)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+#include "delta.h"
+#include "fem_plan.h"
+
+namespace fb {
+namespace {
+
+constexpr int kB = 256;
+constexpr uint32_t kDropped = 0xFFFFFFFEu;  // (no contribution word: element ids stay below 2^28)
+
+inline int pad4(int x) { return (x + 3) & ~3; }
+inline dim3 grid_for(long long n) { return dim3((unsigned)std::max<long long>(1, (n + kB - 1) / kB)); }
+
+__global__ __launch_bounds__(kB) void k_delta_mark(int n_removed, const int* __restrict__ removed, int n_changed, const int* __restrict__ changed, unsigned char* __restrict__ estate) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i < n_removed) estate[removed[i]] = 1;
+  else if (i < n_removed + n_changed) estate[changed[i - n_removed]] = 2;
+}
+
+struct Stays {
+  __device__ int operator()(unsigned char st) const { return st != 1 ? 1 : 0; }
+};
+
+__global__ __launch_bounds__(kB) void k_delta_relabel(int n, int4* __restrict__ t, int n_nodes, const int* __restrict__ map) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  int4 v = t[i];
+  v.x = map[v.x]; v.y = map[v.y]; v.z = map[v.z]; v.w = map[v.w];
+  t[i] = v;
+}
+
+__global__ __launch_bounds__(kB) void k_delta_tets(int n_old, const int4* __restrict__ tets_old, const unsigned char* __restrict__ estate, const int* __restrict__ pos,
+                                                   const int* __restrict__ imap, int n_changed, const int* __restrict__ changed_ids, const int4* __restrict__ changed_nodes,
+                                                   int4* __restrict__ tets_new) {
+  const int e = blockIdx.x * kB + threadIdx.x;
+  if (e >= n_old) return;
+  const unsigned char st = estate[e];
+  if (st == 1) return;
+  int4 t;
+  if (st == 2) {
+    int lo = 0, hi = n_changed;  // (e is in the list)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (changed_ids[mid] < e) lo = mid + 1; else hi = mid;
+    }
+    t = changed_nodes[lo];
+  } else {
+    t = tets_old[e];
+    if (imap) { t.x = imap[t.x]; t.y = imap[t.y]; t.z = imap[t.z]; t.w = imap[t.w]; }
+  }
+  tets_new[pos[e]] = t;
+}
+
+__global__ __launch_bounds__(kB) void k_delta_keys(int n, const double* __restrict__ xyz, SlabKeyGeom g, unsigned long long* __restrict__ keys, uint32_t* __restrict__ ids) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = slab_key(g, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]);
+  ids[i] = (uint32_t)i;
+}
+
+// old internal node i moves up by the number of new nodes whose key is smaller (a new node with an equal key goes behind: its caller id is larger)
+__global__ __launch_bounds__(kB) void k_delta_imap(int n_old, const unsigned long long* __restrict__ keys_old, int n_new, const unsigned long long* __restrict__ nks,
+                                                   const int* __restrict__ old_of_new_old, int* __restrict__ imap, unsigned long long* __restrict__ keys_out,
+                                                   int* __restrict__ old_of_new, int* __restrict__ new_of_old) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n_old) return;
+  const unsigned long long k = keys_old[i];
+  int lo = 0, hi = n_new;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (nks[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  const int ni = i + lo, c = old_of_new_old[i];
+  imap[i] = ni;
+  keys_out[ni] = k;
+  old_of_new[ni] = c;
+  new_of_old[c] = ni;
+}
+__global__ __launch_bounds__(kB) void k_delta_newint(int n_new, const unsigned long long* __restrict__ nks, const uint32_t* __restrict__ nvs, int n_old,
+                                                     const unsigned long long* __restrict__ keys_old, int* __restrict__ newint, unsigned long long* __restrict__ keys_out,
+                                                     int* __restrict__ old_of_new, int* __restrict__ new_of_old) {
+  const int j = blockIdx.x * kB + threadIdx.x;
+  if (j >= n_new) return;
+  const unsigned long long k = nks[j];
+  int lo = 0, hi = n_old;  // old nodes with a key <= k
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys_old[mid] <= k) lo = mid + 1; else hi = mid;
+  }
+  const int ni = j + lo, which = (int)nvs[j], c = n_old + which;
+  newint[which] = ni;
+  keys_out[ni] = k;
+  old_of_new[ni] = c;
+  new_of_old[c] = ni;
+}
+
+__global__ __launch_bounds__(kB) void k_delta_positions(int n_old, int n_new, const double* __restrict__ x0_old, const double* __restrict__ new_xyz, const int* __restrict__ imap,
+                                                        const int* __restrict__ newint, double* __restrict__ x0_new) {
+  const long long i = (long long)blockIdx.x * kB + threadIdx.x;
+  const long long n3 = 3LL * (n_old + n_new);
+  if (i >= n3) return;
+  const int node = (int)(i / 3), k = (int)(i - 3LL * node);
+  if (node < n_old) x0_new[3 * (size_t)(imap ? imap[node] : node) + k] = x0_old[i];
+  else x0_new[3 * (size_t)(newint ? newint[node - n_old] : node) + k] = new_xyz[3 * (size_t)(node - n_old) + k];
+}
+
+// ---- the pair list ----
+struct PackDesc { int narrow, cb, span, col_bits; };
+__device__ __forceinline__ void unpack_key(const PackDesc& p, unsigned long long k, int& row, int& col) {
+  if (p.narrow) {
+    row = (int)(k >> p.cb);
+    col = row + (int)(k & ((1ULL << p.cb) - 1ULL)) - p.span;
+  } else {
+    row = (int)(k >> p.col_bits);
+    col = (int)(k & ((1ULL << p.col_bits) - 1ULL));
+  }
+}
+__device__ __forceinline__ unsigned long long pack_key(const PackDesc& p, int row, int col) {
+  return p.narrow ? (((unsigned long long)(unsigned int)row << p.cb) | (unsigned long long)(unsigned int)(col - row + p.span))
+                  : (((unsigned long long)(unsigned int)row << p.col_bits) | (unsigned long long)(unsigned int)col);
+}
+
+// an entry of the old list in the terms of the new one: nodes through imap, the element by its new id, the key in the new packing;
+// entries of removed and changed elements are marked for the selection to drop
+template <typename KIn, typename KOut>
+struct PairXform {
+  PackDesc in, out;
+  const int* imap;
+  const unsigned char* estate;
+  const int* pos;
+  __device__ rocprim::tuple<KOut, uint32_t> operator()(const rocprim::tuple<KIn, uint32_t>& t) const {
+    const uint32_t v = rocprim::get<1>(t);
+    int row, col;
+    unpack_key(in, (unsigned long long)rocprim::get<0>(t), row, col);
+    if (imap) { row = imap[row]; col = imap[col]; }
+    uint32_t vo = v;
+    if (v != kNoContrib) {
+      const uint32_t e = v >> 4;
+      vo = estate[e] ? kDropped : (((uint32_t)pos[e] << 4) | (v & 15u));
+    }
+    return rocprim::make_tuple((KOut)pack_key(out, row, col), vo);
+  }
+};
+struct NotDropped {
+  template <typename T>
+  __device__ bool operator()(const T& t) const { return rocprim::get<1>(t) != kDropped; }
+};
+// (row, column), then the contribution word: ascending (element, i, j) inside a block, the marker of a diagonal block last
+struct PairLess {
+  template <typename T>
+  __device__ bool operator()(const T& a, const T& b) const {
+    return rocprim::get<0>(a) < rocprim::get<0>(b) || (rocprim::get<0>(a) == rocprim::get<0>(b) && rocprim::get<1>(a) < rocprim::get<1>(b));
+  }
+};
+
+// the 16 pairs of every changed and added element, ascending in the new element id (changed ones keep an id below every added one), then
+// the markers of the new nodes
+template <typename KOut>
+__global__ __launch_bounds__(kB) void k_delta_new_pairs(int n_changed, int n_added, int n_new_nodes, int n_kept, int n_nodes_old, PackDesc out, const int* __restrict__ changed_ids,
+                                                        const int* __restrict__ pos, const int4* __restrict__ tets_new, const int* __restrict__ newint, KOut* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals) {
+  const long long i = (long long)blockIdx.x * kB + threadIdx.x;
+  const long long n_tp = 16LL * (n_changed + n_added);
+  if (i < n_tp) {
+    const int m = (int)(i >> 4), ij = (int)(i & 15);
+    const int e = m < n_changed ? pos[changed_ids[m]] : n_kept + (m - n_changed);
+    const int4 t = tets_new[e];
+    const int id[4] = {t.x, t.y, t.z, t.w};
+    keys[i] = (KOut)pack_key(out, id[ij >> 2], id[ij & 3]);
+    vals[i] = ((uint32_t)e << 4) | (uint32_t)ij;
+  } else if (i < n_tp + n_new_nodes) {
+    const int k = (int)(i - n_tp);
+    const int r = newint ? newint[k] : n_nodes_old + k;
+    keys[i] = (KOut)pack_key(out, r, r);
+    vals[i] = kNoContrib;
+  }
+}
+
+int bits_of(long long n) {
+  int b = 1;
+  while ((1LL << b) < n) b++;
+  return b;
+}
+
+template <typename KIn, typename KOut>
+int update_pairs(hipStream_t s, MeshDelta& D, const int4* tets_new, int n_nodes_old, const PackDesc& pin, const PackDesc& pout, unsigned key_bits, long long n_old_pairs,
+                 long long n_new_pairs, PlanWorkspace& W) {
+  const long long n_stay = n_old_pairs - 16LL * (D.n_removed + D.n_changed);
+  const long long n_fresh = 16LL * (D.n_changed + D.n_added) + D.n_new_nodes;
+  if (n_stay + n_fresh != n_new_pairs) return fail(FB_EINVAL, "internal: pair count of the change does not add up");
+  // 1. the old list, transformed, without the dropped entries: keys_s / vals_s -> keys / vals (scratch of the last build or change:
+  // sized for THAT list)
+  FB_TRY(W.nruns.reserve(1));
+  FB_TRY(W.keys.reserve((size_t)std::max<long long>(1, n_stay)));
+  FB_TRY(W.vals.reserve((size_t)std::max<long long>(1, n_stay)));
+  {
+    const auto in = rocprim::make_transform_iterator(
+        rocprim::make_zip_iterator(rocprim::make_tuple(reinterpret_cast<const KIn*>(W.keys_s.p), static_cast<const uint32_t*>(W.vals_s.p))),
+        PairXform<KIn, KOut>{pin, pout, D.mapped ? D.imap.p : nullptr, D.estate.p, D.pos.p});
+    auto out = rocprim::make_zip_iterator(rocprim::make_tuple(reinterpret_cast<KOut*>(W.keys.p), W.vals.p));
+    size_t bytes = 0;
+    FB_HIP(rocprim::select(nullptr, bytes, in, out, W.nruns.p, (size_t)n_old_pairs, NotDropped(), s));
+    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::select(W.temp.p, bytes, in, out, W.nruns.p, (size_t)n_old_pairs, NotDropped(), s));
+  }
+  // 2. the new entries, sorted among themselves (stable: ascending contribution words inside a block, its marker last)
+  FB_TRY(D.nk.reserve((size_t)std::max<long long>(1, n_fresh)));
+  FB_TRY(D.nks.reserve((size_t)std::max<long long>(1, n_fresh)));
+  FB_TRY(D.nv.reserve((size_t)std::max<long long>(1, n_fresh)));
+  FB_TRY(D.nvs.reserve((size_t)std::max<long long>(1, n_fresh)));
+  KOut* nk = reinterpret_cast<KOut*>(D.nk.p);
+  KOut* nks = reinterpret_cast<KOut*>(D.nks.p);
+  if (n_fresh > 0) {
+    hipLaunchKernelGGL(k_delta_new_pairs<KOut>, grid_for(n_fresh), dim3(kB), 0, s, D.n_changed, D.n_added, D.n_new_nodes, D.n_kept, n_nodes_old, pout, D.changed_ids, D.pos.p,
+                       tets_new, D.mapped ? D.newint.p : nullptr, nk, D.nv.p);
+    FB_HIP(hipGetLastError());
+    size_t bytes = 0;
+    FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, nk, nks, D.nv.p, D.nvs.p, (size_t)n_fresh, 0u, key_bits, s));
+    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::radix_sort_pairs(W.temp.p, bytes, nk, nks, D.nv.p, D.nvs.p, (size_t)n_fresh, 0u, key_bits, s));
+  }
+  // 3. merged into keys_s / vals_s (the old list is no longer needed: the buffers may grow)
+  FB_TRY(W.keys_s.reserve((size_t)n_new_pairs));
+  FB_TRY(W.vals_s.reserve((size_t)n_new_pairs));
+  {
+    const auto a = rocprim::make_zip_iterator(rocprim::make_tuple(reinterpret_cast<const KOut*>(W.keys.p), static_cast<const uint32_t*>(W.vals.p)));
+    const auto b = rocprim::make_zip_iterator(rocprim::make_tuple(static_cast<const KOut*>(nks), static_cast<const uint32_t*>(D.nvs.p)));
+    auto out = rocprim::make_zip_iterator(rocprim::make_tuple(reinterpret_cast<KOut*>(W.keys_s.p), W.vals_s.p));
+    size_t bytes = 0;
+    FB_HIP(rocprim::merge(nullptr, bytes, a, b, out, (size_t)n_stay, (size_t)n_fresh, PairLess(), s));
+    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::merge(W.temp.p, bytes, a, b, out, (size_t)n_stay, (size_t)n_fresh, PairLess(), s));
+  }
+  // (the unsorted buffers must hold the new list too when the next full build sorts into them: they are reserved there)
+  return FB_OK;
+}
+
+}  // namespace
+
+int delta_upload(hipStream_t s, int n_tets_old, int n_removed, const int* removed, int n_changed, const int* changed_ids, const int* changed_nodes, int n_added,
+                 const int* added, int n_new_nodes, const double* new_xyz, MeshDelta& D, PlanWorkspace& W) {
+  D.n_tets_old = n_tets_old; D.n_removed = n_removed; D.n_changed = n_changed; D.n_added = n_added; D.n_new_nodes = n_new_nodes;
+  D.n_kept = n_tets_old - n_removed;
+  D.mapped = false;
+  const int o_chg = pad4(n_removed), o_cn = o_chg + pad4(n_changed), o_add = o_cn + 4 * n_changed, total = o_add + 4 * n_added + 4;
+  std::vector<int> stage((size_t)total, 0);
+  if (n_removed) memcpy(stage.data(), removed, sizeof(int) * (size_t)n_removed);
+  if (n_changed) memcpy(stage.data() + o_chg, changed_ids, sizeof(int) * (size_t)n_changed);
+  if (n_changed) memcpy(stage.data() + o_cn, changed_nodes, sizeof(int) * 4 * (size_t)n_changed);
+  if (n_added) memcpy(stage.data() + o_add, added, sizeof(int) * 4 * (size_t)n_added);
+  FB_TRY(D.ints.reserve((size_t)total));
+  FB_HIP(hipMemcpyAsync(D.ints.p, stage.data(), sizeof(int) * (size_t)total, hipMemcpyHostToDevice, s));  // (pageable source: complete on return)
+  D.removed = D.ints.p; D.changed_ids = D.ints.p + o_chg;
+  D.changed_nodes = reinterpret_cast<int4*>(D.ints.p + o_cn); D.added = reinterpret_cast<int4*>(D.ints.p + o_add);
+  FB_TRY(D.new_xyz.reserve((size_t)std::max(1, 3 * n_new_nodes)));
+  if (n_new_nodes) FB_HIP(hipMemcpyAsync(D.new_xyz.p, new_xyz, sizeof(double) * 3 * (size_t)n_new_nodes, hipMemcpyHostToDevice, s));
+  FB_TRY(D.estate.reserve((size_t)n_tets_old + 1));
+  FB_HIP(hipMemsetAsync(D.estate.p, 0, (size_t)n_tets_old + 1, s));
+  if (n_removed + n_changed) {
+    hipLaunchKernelGGL(k_delta_mark, grid_for(n_removed + n_changed), dim3(kB), 0, s, n_removed, D.removed, n_changed, D.changed_ids, D.estate.p);
+    FB_HIP(hipGetLastError());
+  }
+  FB_TRY(D.pos.reserve((size_t)n_tets_old + 1));
+  const auto stays = rocprim::make_transform_iterator(static_cast<const unsigned char*>(D.estate.p), Stays());
+  size_t bytes = 0;
+  FB_HIP(rocprim::exclusive_scan(nullptr, bytes, stays, D.pos.p, 0, (size_t)n_tets_old, rocprim::plus<int>(), s));
+  FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+  FB_HIP(rocprim::exclusive_scan(W.temp.p, bytes, stays, D.pos.p, 0, (size_t)n_tets_old, rocprim::plus<int>(), s));
+  return FB_OK;
+}
+
+int delta_relabel_nodes(hipStream_t s, MeshDelta& D, int n_nodes, const int* map) {
+  // (changed_nodes and added lie back to back in the staging buffer)
+  const int n = D.n_changed + D.n_added;
+  if (n == 0) return FB_OK;
+  hipLaunchKernelGGL(k_delta_relabel, grid_for(n), dim3(kB), 0, s, n, D.changed_nodes, n_nodes, map);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int delta_tets(hipStream_t s, const MeshDelta& D, const int4* tets_old, const int* imap, int4* tets_new) {
+  hipLaunchKernelGGL(k_delta_tets, grid_for(D.n_tets_old), dim3(kB), 0, s, D.n_tets_old, tets_old, D.estate.p, D.pos.p, imap, D.n_changed, D.changed_ids, D.changed_nodes, tets_new);
+  FB_HIP(hipGetLastError());
+  if (D.n_added) FB_HIP(hipMemcpyAsync(tets_new + D.n_kept, D.added, sizeof(int4) * (size_t)D.n_added, hipMemcpyDeviceToDevice, s));
+  return FB_OK;
+}
+
+int delta_node_order(hipStream_t s, MeshDelta& D, int n_old, const SlabKeyGeom& g, const unsigned long long* keys_old, const int* old_of_new_old, DevBuf<int>& old_of_new,
+                     DevBuf<int>& new_of_old, PlanWorkspace& W) {
+  const int n_new = D.n_new_nodes, n = n_old + n_new;
+  FB_TRY(D.imap.reserve((size_t)std::max(1, n_old)));
+  FB_TRY(D.newint.reserve((size_t)std::max(1, n_new)));
+  FB_TRY(D.node_keys.reserve((size_t)n));
+  FB_TRY(old_of_new.alloc((size_t)n));
+  FB_TRY(new_of_old.alloc((size_t)n));
+  FB_TRY(D.nk.reserve((size_t)std::max(1, n_new)));
+  FB_TRY(D.nks.reserve((size_t)std::max(1, n_new)));
+  FB_TRY(D.nv.reserve((size_t)std::max(1, n_new)));
+  FB_TRY(D.nvs.reserve((size_t)std::max(1, n_new)));
+  if (n_new) {
+    hipLaunchKernelGGL(k_delta_keys, grid_for(n_new), dim3(kB), 0, s, n_new, D.new_xyz.p, g, D.nk.p, D.nv.p);
+    FB_HIP(hipGetLastError());
+    const unsigned key_bits = (unsigned)(g.bits[0] + g.bits[1] + g.bits[2]);
+    size_t bytes = 0;
+    FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, D.nk.p, D.nks.p, D.nv.p, D.nvs.p, (size_t)n_new, 0u, key_bits, s));
+    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::radix_sort_pairs(W.temp.p, bytes, D.nk.p, D.nks.p, D.nv.p, D.nvs.p, (size_t)n_new, 0u, key_bits, s));
+  }
+  hipLaunchKernelGGL(k_delta_imap, grid_for(n_old), dim3(kB), 0, s, n_old, keys_old, n_new, D.nks.p, old_of_new_old, D.imap.p, D.node_keys.p, old_of_new.p, new_of_old.p);
+  FB_HIP(hipGetLastError());
+  if (n_new) {
+    hipLaunchKernelGGL(k_delta_newint, grid_for(n_new), dim3(kB), 0, s, n_new, D.nks.p, D.nvs.p, n_old, keys_old, D.newint.p, D.node_keys.p, old_of_new.p, new_of_old.p);
+    FB_HIP(hipGetLastError());
+  }
+  D.mapped = true;
+  return FB_OK;
+}
+
+int delta_positions(hipStream_t s, const MeshDelta& D, int n_old, const double* x0_old, double* x0_new) {
+  hipLaunchKernelGGL(k_delta_positions, grid_for(3LL * (n_old + D.n_new_nodes)), dim3(kB), 0, s, n_old, D.n_new_nodes, x0_old, D.new_xyz.p, D.mapped ? D.imap.p : nullptr,
+                     D.mapped ? D.newint.p : nullptr, x0_new);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int delta_sorted_pairs(hipStream_t s, MeshDelta& D, const int4* tets_new, int n_nodes_new, int span, PlanWorkspace& W) {
+  SortedPairs& S = W.sorted;
+  if (!S.valid) return fail(FB_EINVAL, "internal: no sorted pair list to update");
+  const int n_nodes_old = S.n_nodes;
+  const long long n_new_pairs = 16LL * D.n_tets_new() + n_nodes_new;
+  if (n_new_pairs >= (1LL << 31)) return fail(FB_EINVAL, "mesh too large for the device plan builder (%lld pairs)", n_new_pairs);
+  if ((long long)D.n_tets_new() >= (1LL << 28)) return fail(FB_EINVAL, "too many tets for the packed contribution word");
+  const PackDesc pin = {S.narrow ? 1 : 0, S.cb, S.span, S.col_bits};
+  // the key width of the new list: the rule of build_plan_device
+  int cb32 = 1;
+  while (span >= 0 && cb32 < 31 && (1LL << cb32) < 2LL * span + 1) cb32++;
+  const int rb32 = bits_of(n_nodes_new), col_bits = bits_of(n_nodes_new), row_bits = bits_of(n_nodes_new);
+  const bool narrow = span >= 0 && span < n_nodes_new && rb32 + cb32 <= 32 && !(getenv("FEMBRAIN_PLAN_KEYS64") && atoi(getenv("FEMBRAIN_PLAN_KEYS64")) != 0);
+  const PackDesc pout = {narrow ? 1 : 0, cb32, span, col_bits};
+  const unsigned key_bits = narrow ? (unsigned)(rb32 + cb32) : (unsigned)(row_bits + col_bits);
+  S.valid = false;  // (until the new list is complete)
+  int rc;
+  if (S.narrow && narrow) rc = update_pairs<unsigned int, unsigned int>(s, D, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
+  else if (S.narrow) rc = update_pairs<unsigned int, unsigned long long>(s, D, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
+  else if (narrow) rc = update_pairs<unsigned long long, unsigned int>(s, D, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
+  else rc = update_pairs<unsigned long long, unsigned long long>(s, D, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
+  FB_TRY(rc);
+  S.narrow = narrow; S.cb = cb32; S.span = span; S.col_bits = col_bits;
+  S.n_pairs = n_new_pairs; S.n_nodes = n_nodes_new; S.n_tets = D.n_tets_new();
+  S.valid = true;
+  return FB_OK;
+}
+
+}  // namespace fb

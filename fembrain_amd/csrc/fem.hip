@@ -14,6 +14,7 @@
 #include "pcg_pipe2.hip.h"
 #include "plan_device.h"
 #include "renumber.h"
+#include "delta.h"
 
 using namespace fb;
 
@@ -46,6 +47,12 @@ struct fb_fem_s {
   int c16 = 0;             // 0 no, 1 column - row (unsharded), 2 the halo form of a shard (plan_device.hip k_plan_sell)
   DevBuf<int> halo_base;   // c16 == 2: lowest halo column of every slice
   PlanWorkspace plan_ws;  // the device plan builder's temporaries, kept for the next re-sync
+  MeshDelta delta;        // fb_fem_resync_delta: the change on the device and its scratch
+  DevBuf<int4> tets_next, tets_caller;   // (the element list being built; swapped with `tets`)
+  DevBuf<double> x0_next;
+  DevBuf<int> map_next_a, map_next_b;
+  int last_resync_path = FB_RESYNC_FULL;
+  DevBuf<int> flat_flag;
   DevBuf<int> inc_off;               // element-major assembly (k_assemble_tets): incidence lists per slice, see fem_device.hip.h
   DevBuf<uint32_t> inc, inc_slot;
   bool asm_tets = false;             // the assembly kernel in use
@@ -464,7 +471,7 @@ int setup_persist(fb_fem_s* h) {
   return FB_OK;
 }
 
-int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device = nullptr) {
+int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device = nullptr, const double* xyz_device64 = nullptr) {
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
   if (!h->device_plan) {  // (the device builder has put the tets and the plan arrays in place already)
@@ -479,6 +486,9 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   }
   if (h->x0_ready) {
     // (renumbered: gathered into the internal order by build_plan_on_device)
+  } else if (xyz_device64) {  // (fb_fem_resync_delta: the caller-order positions, already on this device)
+    FB_TRY(h->x0.alloc((size_t)3 * P.n_local));
+    FB_HIP(hipMemcpyAsync(h->x0.p, xyz_device64, sizeof(double) * 3 * (size_t)P.n_local, hipMemcpyDeviceToDevice, s));
   } else if (xyz_device) {  // mesh handed over on the device (fb_fem_create_from_poly): float positions widened in place
     const long long n3 = 3LL * P.n_local;
     FB_TRY(h->x0.alloc((size_t)n3));
@@ -1282,7 +1292,7 @@ int pcg_solve(fb_fem_s* h, const double* b, double eps, int max_iter, int* iters
 // asks for them (ensure_host_pattern).
 // tets: host node ids, or -- d_tets non-null -- ids already on this device (the polygonizer's own output: in range by construction)
 int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, int n_fixed, const int* fixed, const double* xyz, const uint4* d_tets = nullptr,
-                         const float* d_xyz = nullptr) {
+                         const float* d_xyz = nullptr, const double* d_xyz64 = nullptr) {
   if (n_nodes <= 0 || n_tets <= 0 || (!tets && !d_tets)) return fail(FB_EINVAL, "empty mesh (%d nodes, %d tets)", n_nodes, n_tets);
   if ((long long)n_tets >= (1LL << 28)) return fail(FB_EINVAL, "too many tets for the packed contribution word");
 
@@ -1315,7 +1325,9 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
     FB_TRY(renumber_decide(h->stream, renumber_mode(h), n_nodes, n_tets, h->tets.p, h->plan_ws, h->ren, &want));
     if (want) {
       FB_TRY(h->xyz_in.reserve((size_t)3 * n_nodes));
-      if (d_xyz) {
+      if (d_xyz64) {
+        FB_HIP(hipMemcpyAsync(h->xyz_in.p, d_xyz64, sizeof(double) * 3 * (size_t)n_nodes, hipMemcpyDeviceToDevice, h->stream));
+      } else if (d_xyz) {
         const long long n3 = 3LL * n_nodes;
         hipLaunchKernelGGL(k_widen_positions, dim3((unsigned)((n3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, n3, d_xyz, h->xyz_in.p);
         FB_HIP(hipGetLastError());
@@ -1490,9 +1502,23 @@ int ensure_host_pattern(fb_fem_s* h) {
   return FB_OK;
 }
 
+// rest state of a device-built plan; the kernel reports the first flat element (see build)
+int rest_state_checked(fb_fem_s* h) {
+  const int none = 0x7fffffff;
+  FB_TRY(h->flat_flag.alloc(1));
+  FB_HIP(hipMemcpyAsync(h->flat_flag.p, &none, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  FB_TRY(launch_rest(h, h->flat_flag.p));
+  int first = none;
+  FB_TRY(h->flat_flag.download(&first, 1, h->stream));
+  if (first != none)
+    return fail(FB_EINVAL, "element %d has zero (or non-finite) rest volume", h->plan.tet_global.empty() ? first : h->plan.tet_global[first]);
+  return FB_OK;
+}
+
 int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed, const int* fixed, int n_ranks,
           int rank, const int* splits, const DeviceTetMesh* dm = nullptr) {
   drop_graph(h);  // the buffers it refers to are about to be replaced
+  h->last_resync_path = FB_RESYNC_FULL;
   h->ren.clear();
   h->l2c.clear();
   h->order_sum = 0;
@@ -1509,7 +1535,7 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
   h->host_pattern = !h->device_plan;
   if (h->device_plan) {
     const int rc = n_ranks > 1 ? build_shard_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits, xyz)
-                               : build_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, xyz, dm ? dm->tets : nullptr, dm ? dm->xyz : nullptr);
+                               : build_plan_on_device(h, n_nodes, n_tets, tets, n_fixed, fixed, xyz, dm ? dm->tets : nullptr, dm ? dm->xyz : nullptr, dm ? dm->xyz64 : nullptr);
     if (dm && rc != FB_OK) return rc;
     if (rc == FB_ENOMEM) {  // no room for the sort's temporaries: the host builder needs none on the device
       (void)hipGetLastError();
@@ -1544,17 +1570,10 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
       return fail(FB_EINVAL, "element %d has zero (or non-finite) rest volume", h->plan.tet_global.empty() ? e : h->plan.tet_global[e]);
   }
   lap("volume check");
-  FB_TRY(upload_plan(h, xyz, dm ? dm->xyz : nullptr));
+  FB_TRY(upload_plan(h, xyz, dm ? dm->xyz : nullptr, dm ? dm->xyz64 : nullptr));
   lap("upload");
   if (h->device_plan) {
-    DevBuf<int> flat;
-    const int none = 0x7fffffff;
-    FB_TRY(flat.upload(&none, 1, h->stream));
-    FB_TRY(launch_rest(h, flat.p));
-    int first = none;
-    FB_TRY(flat.download(&first, 1, h->stream));
-    if (first != none)
-      return fail(FB_EINVAL, "element %d has zero (or non-finite) rest volume", h->plan.tet_global.empty() ? first : h->plan.tet_global[first]);
+    FB_TRY(rest_state_checked(h));
   } else {
     FB_TRY(launch_rest(h));
     FB_HIP(hipStreamSynchronize(h->stream));
@@ -2034,6 +2053,167 @@ int fb_fem_resync(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const 
   h->poisoned = false;
   return FB_OK;
 }
+
+// ---- fb_fem_resync_delta (delta.h) ----
+namespace {
+// The full builder from the device copy of the new mesh in the caller's numbering (no sorted list to update, or the new mesh is to
+// get a new node order): what fb_fem_resync does, without the host hop.
+int resync_delta_rebuild(fb_fem_s* h, int n_old, int n_new, int n_fixed, const int* fixed) {
+  hipStream_t s = h->stream;
+  MeshDelta& D = h->delta;
+  const int nt_old = D.n_tets_old, nt_new = D.n_tets_new();
+  // the old element list and the rest positions in the caller's numbering
+  FB_TRY(h->tets_caller.alloc((size_t)nt_old));
+  FB_HIP(hipMemcpyAsync(h->tets_caller.p, h->tets.p, sizeof(int4) * (size_t)nt_old, hipMemcpyDeviceToDevice, s));
+  if (h->ren.active) FB_TRY(relabel_tets(s, nt_old, h->tets_caller.p, n_old, h->ren.d_old_of_new.p));
+  FB_TRY(h->tets_next.alloc((size_t)nt_new));
+  FB_TRY(delta_tets(s, D, h->tets_caller.p, nullptr, h->tets_next.p));
+  FB_TRY(h->x0_next.alloc((size_t)3 * n_new));
+  if (h->ren.active) FB_TRY(scatter_nodes(s, n_old, 3, h->x0.p, h->ren.d_old_of_new.p, h->x0_next.p));
+  else FB_HIP(hipMemcpyAsync(h->x0_next.p, h->x0.p, sizeof(double) * 3 * (size_t)n_old, hipMemcpyDeviceToDevice, s));
+  if (D.n_new_nodes) FB_HIP(hipMemcpyAsync(h->x0_next.p + 3 * (size_t)n_old, D.new_xyz.p, sizeof(double) * 3 * (size_t)D.n_new_nodes, hipMemcpyDeviceToDevice, s));
+  DeviceTetMesh dm;
+  dm.device = h->prm.device; dm.n_vertices = n_new; dm.n_tets = nt_new; dm.xyz = nullptr;
+  dm.tets = reinterpret_cast<const uint4*>(h->tets_next.p); dm.xyz64 = h->x0_next.p;
+  FB_TRY(build(h, n_new, nullptr, nt_new, nullptr, n_fixed, fixed, 1, 0, nullptr, &dm));
+  h->last_resync_path = FB_RESYNC_DELTA_REBUILT;
+  return FB_OK;
+}
+
+int resync_delta(fb_fem_s* h, int n_removed, const int* removed, int n_changed, const int* changed_ids, const int* changed_nodes, int n_added, const int* added,
+                 int n_new_nodes, const double* new_xyz, int n_fixed, const int* fixed) {
+  static const bool timing = getenv("FEMBRAIN_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (timing) fprintf(stderr, "[fembrain] delta re-sync: %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  };
+  hipStream_t s = h->stream;
+  MeshDelta& D = h->delta;
+  PlanWorkspace& W = h->plan_ws;
+  const int n_old = h->plan.n_global, nt_old = h->plan.n_tets, n_new = n_old + n_new_nodes;
+  drop_graph(h);
+  FB_TRY(delta_upload(s, nt_old, n_removed, removed, n_changed, changed_ids, changed_nodes, n_added, added, n_new_nodes, new_xyz, D, W));
+  const int nt_new = D.n_tets_new();
+  lap("change uploaded");
+  const char* env = getenv("FEMBRAIN_RESYNC_DELTA");
+  bool merge = W.sorted.valid && W.sorted.n_nodes == n_old && W.sorted.n_tets == nt_old && !(env && !strcmp(env, "rebuild"));
+  const int mode = renumber_mode(h);
+  int span = -1;
+  double mean = 0.0;
+  if (merge && !h->ren.active && mode != FB_RENUMBER_OFF) {
+    // A handle in the caller's order: would the full builder try a new node order for the new mesh (renumber_decide)?  Then it is to
+    // decide.  The widest element of the new list: the kept elements are no wider than before, so the new ones settle it unless
+    // the old widest element was removed -- measured over the whole new list, as the builder would.
+    FB_TRY(h->tets_next.alloc((size_t)nt_new));
+    FB_TRY(delta_tets(s, D, h->tets.p, nullptr, h->tets_next.p));
+    FB_TRY(tet_span_device(s, nt_new, h->tets_next.p, n_new, nullptr, W, &span, &mean));
+    if (mode == FB_RENUMBER_ON || (n_new >= kRenumberMinNodes && span > renumber_span_limit(n_new))) merge = false;
+  }
+  if (!merge) return resync_delta_rebuild(h, n_old, n_new, n_fixed, fixed);
+
+  // ---- the node order ----
+  if (h->ren.active) {
+    if (n_new_nodes) {
+      FB_TRY(delta_node_order(s, D, n_old, h->ren.geom, h->ren.d_keys.p, h->ren.d_old_of_new.p, h->map_next_a, h->map_next_b, W));
+      h->ren.d_old_of_new.swap(h->map_next_a);
+      h->ren.d_new_of_old.swap(h->map_next_b);
+      h->ren.d_keys.swap(D.node_keys);
+      h->ren.n = n_new;
+      h->ren.old_of_new.clear();
+      h->ren.new_of_old.clear();
+    }
+    FB_TRY(delta_relabel_nodes(s, D, n_new, h->ren.d_new_of_old.p));
+    FB_TRY(h->tets_next.alloc((size_t)nt_new));
+    FB_TRY(delta_tets(s, D, h->tets.p, D.mapped ? D.imap.p : nullptr, h->tets_next.p));
+    FB_TRY(tet_span_device(s, nt_new, h->tets_next.p, n_new, nullptr, W, &span, &mean));
+    h->ren.span_after = span; h->ren.mean_after = mean;
+  } else {
+    h->ren.clear();
+    if (mode != FB_RENUMBER_OFF) { h->ren.span_before = h->ren.span_after = span; h->ren.mean_before = h->ren.mean_after = mean; }
+    else {
+      FB_TRY(h->tets_next.alloc((size_t)nt_new));
+      FB_TRY(delta_tets(s, D, h->tets.p, nullptr, h->tets_next.p));
+    }
+  }
+  h->tets.swap(h->tets_next);
+  FB_TRY(h->x0_next.alloc((size_t)3 * n_new));
+  FB_TRY(delta_positions(s, D, n_old, h->x0.p, h->x0_next.p));
+  h->x0.swap(h->x0_next);
+  h->l2c.clear();
+  h->order_sum = 0;
+  h->x0_ready = true;
+  h->caller_pattern = false;
+  h->last_resync_path = FB_RESYNC_DELTA_MERGED;
+  lap("node order and elements");
+  FB_TRY(device_constraint_masks(s, n_new, n_fixed, fixed, h->ren.active ? h->ren.d_new_of_old.p : nullptr, h->fixed_stage, h->dofmask, h->nodemask));
+  h->masks_ready = true;
+  // ---- the plan: the pair list updated, the rest of the builder as ever ----
+  FB_TRY(delta_sorted_pairs(s, D, h->tets.p, n_new, span, W));
+  lap("pair list updated");
+  FemPlan& P = h->plan;
+  P = FemPlan();
+  P.n_global = n_new; P.n_ranks = 1; P.rank = 0;
+  P.splits = {0, n_new};
+  P.node_lo = 0; P.node_hi = n_new;
+  P.n_owned = P.n_local = n_new; P.n_halo = 0;
+  P.local2global.resize(n_new);
+  for (int l = 0; l < n_new; l++) P.local2global[l] = l;
+  P.halo_off.assign(2, 0);
+  P.send_off.assign(2, 0);
+  P.n_tets = nt_new;
+  P.n_fixed_owned = n_fixed;
+  DevicePlan Dp;
+  Dp.slice_off = &h->slice_off; Dp.colidx = &h->colidx; Dp.slot_coff = &h->slot_coff; Dp.slot_ccnt = &h->slot_ccnt; Dp.contrib = &h->contrib;
+  Dp.bptr = &h->d_bptr; Dp.bcol = &h->d_bcol; Dp.blk_slot = &h->d_blk_slot; Dp.coldelta = &h->coldelta;
+  FB_TRY(plan_from_sorted_pairs(s, Dp, W));
+  P.n_blocks = Dp.n_blocks; P.n_slices = Dp.n_slices; P.n_slots = Dp.n_slots; P.n_crows = Dp.n_crows;
+  h->c16 = (Dp.deltas_fit16 && !(getenv("FEMBRAIN_SPMV_C16") && atoi(getenv("FEMBRAIN_SPMV_C16")) == 0)) ? 1 : 0;
+  P.slice_off = Dp.slice_off_host;
+  h->device_plan = true;
+  h->host_pattern = false;
+  lap("plan");
+  FB_TRY(upload_plan(h, nullptr));
+  lap("per-step arrays");
+  FB_TRY(rest_state_checked(h));
+  lap("rest state");
+  return FB_OK;
+}
+}  // namespace
+
+int fb_fem_resync_delta(fb_fem_t h, int n_removed, const int* removed, int n_changed, const int* changed_ids, const int* changed_nodes, int n_added,
+                        const int* added_tets, int n_new_nodes, const double* new_xyz, int n_fixed_dofs, const int* fixed_dofs) {
+  if (!h) return fail(FB_EINVAL, "null FEM handle");
+  FB_HIP(hipSetDevice(h->prm.device));
+  if (h->poisoned) return fail(FB_EINVAL, "the handle is unusable after a failed re-sync: a full fb_fem_resync first");
+  if (h->plan.n_ranks > 1 || !h->device_plan) return fail(FB_EINVAL, "fb_fem_resync_delta is for unsharded handles whose plan was built on the device");
+  if (n_removed < 0 || n_changed < 0 || n_added < 0 || n_new_nodes < 0 || n_fixed_dofs < 0) return fail(FB_EINVAL, "negative count");
+  if ((n_removed && !removed) || (n_changed && (!changed_ids || !changed_nodes)) || (n_added && !added_tets) || (n_new_nodes && !new_xyz) || (n_fixed_dofs && !fixed_dofs))
+    return fail(FB_EINVAL, "null array with a non-zero count");
+  const int nt_old = h->plan.n_tets;
+  const long long n_new = (long long)h->plan.n_global + n_new_nodes, nt_new = (long long)nt_old - n_removed + n_added;
+  if (n_new >= (1LL << 31) - 2 || nt_new >= (1LL << 28)) return fail(FB_EINVAL, "mesh too large");
+  if (nt_new < 1) return fail(FB_EINVAL, "the change leaves no element");
+  for (int k = 0; k < n_removed; k++)
+    if (removed[k] < 0 || removed[k] >= nt_old || (k && removed[k] <= removed[k - 1])) return fail(FB_EINVAL, "removed[%d] = %d: ids must ascend inside [0,%d)", k, removed[k], nt_old);
+  for (int k = 0, r = 0; k < n_changed; k++) {
+    if (changed_ids[k] < 0 || changed_ids[k] >= nt_old || (k && changed_ids[k] <= changed_ids[k - 1]))
+      return fail(FB_EINVAL, "changed_ids[%d] = %d: ids must ascend inside [0,%d)", k, changed_ids[k], nt_old);
+    while (r < n_removed && removed[r] < changed_ids[k]) r++;
+    if (r < n_removed && removed[r] == changed_ids[k]) return fail(FB_EINVAL, "element %d is both removed and changed", changed_ids[k]);
+  }
+  for (long long k = 0; k < 4LL * n_changed; k++)
+    if (changed_nodes[k] < 0 || changed_nodes[k] >= n_new) return fail(FB_EINVAL, "changed element %d references node %d outside [0,%lld)", changed_ids[k / 4], changed_nodes[k], n_new);
+  for (long long k = 0; k < 4LL * n_added; k++)
+    if (added_tets[k] < 0 || added_tets[k] >= n_new) return fail(FB_EINVAL, "added element %lld references node %d outside [0,%lld)", k / 4, added_tets[k], n_new);
+  FB_HIP(hipStreamSynchronize(h->stream));
+  h->poisoned = true;
+  h->system_valid = false;
+  FB_TRY(resync_delta(h, n_removed, removed, n_changed, changed_ids, changed_nodes, n_added, added_tets, n_new_nodes, new_xyz, n_fixed_dofs, fixed_dofs));
+  h->poisoned = false;
+  return FB_OK;
+}
+
+int fb_fem_resync_path(fb_fem_t h) { return h ? h->last_resync_path : FB_RESYNC_FULL; }
 
 int fb_fem_rebuild_elements(fb_fem_t h) {
   CHECK_HANDLE(h);

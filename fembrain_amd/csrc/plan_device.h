@@ -9,6 +9,16 @@
 
 namespace fb {
 
+// The sorted (row, column) -> contribution list the last unsharded plan was built from, left in the workspace (keys_s / vals_s):
+// fb_fem_resync_delta (delta.hip) updates it -- drops the pairs of removed elements, merges in those of new ones -- instead of sorting
+// 16 pairs per element again.  narrow: 32-bit keys row << cb | (col - row + span); else 64-bit keys row << col_bits | col.
+struct SortedPairs {
+  bool valid = false, narrow = false;
+  int cb = 0, span = 0, col_bits = 0;
+  long long n_pairs = 0;
+  int n_nodes = 0, n_tets = 0;
+};
+
 // temporaries of the builder, kept by the caller between builds (a re-sync after every cut would otherwise spend more time
 // in hipMalloc / hipFree of ~700 MB than in the kernels)
 struct PlanWorkspace {
@@ -22,11 +32,13 @@ struct PlanWorkspace {
   DevBuf<int> picked, splits, idsel;       // device_partition: selected ids (+ count at the end), node ranges, kept element ids
   DevBuf<unsigned char> keep;              // device_partition: element has an owned node
   DevBuf<int4> tetsel;                     // device_partition: the kept elements (swapped with the handle's buffer)
+  SortedPairs sorted;
   size_t bytes() const {
     return nodeflag.n + sendmask.n * 8 + picked.n * 4 + idsel.n * 4 + keep.n + tetsel.n * 16 + keys.n * 8 + keys_s.n * 8 + ukeys.n * 8 + vals.n * 4 + vals_s.n * 4 + ucnt.n * 4 + cstart.n * 4 + nruns.n * 4 + width.n * 4 + flags.n * 4 + temp.n;
   }
   void release() {
     keys.release(); keys_s.release(); ukeys.release(); vals.release(); vals_s.release(); ucnt.release(); cstart.release(); nruns.release();
+    sorted = SortedPairs();
     width.release(); flags.release(); temp.release(); nodeflag.release(); sendmask.release(); picked.release(); splits.release(); idsel.release(); keep.release(); tetsel.release();
   }
 };
@@ -75,6 +87,9 @@ int device_partition(hipStream_t s, int n_tets, DevBuf<int4>& tets, int n_global
 // unsharded system (every node a row).  Synchronises the stream before it returns.
 // span >= 0: the widest element of the list (largest id difference inside a tet, renumber.h) when the caller has measured it -- lets the sort use 32-bit keys
 int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& out, PlanWorkspace& ws, const PlanShard* shard = nullptr, int span = -1);
+
+// the rest of the builder from the sorted pair list W.sorted describes (unsharded; delta.hip)
+int plan_from_sorted_pairs(hipStream_t s, DevicePlan& out, PlanWorkspace& ws);
 
 // Incidence lists of the element-major assembly kernel (fem_device.hip.h k_assemble_tets), derived from a plan that is already
 // on the device (whichever builder made it): per slice the longest list of its 64 rows (inc_off = prefix sums), per (list row, lane)

@@ -494,15 +494,16 @@ int build_incidence_device(hipStream_t s, int n_slices, int n_owned, const int* 
   return FB_OK;
 }
 
+static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long long n_valid, bool narrow, int cb32, int span, const PairGeom& geom, const PlanShard* shard,
+                            DevicePlan& D, PlanWorkspace& W);
+
 int build_plan_device(hipStream_t s, int n_nodes_local, int n_tets, const int4* d_tets, DevicePlan& D, PlanWorkspace& W, const PlanShard* shard, int span) {
   // n_nodes: matrix rows (owned nodes); n_nodes_local: range of the node ids in d_tets
   const int n_nodes = shard ? shard->n_rows : n_nodes_local;
   const long long n_pairs = 16LL * n_tets + n_nodes;
   if (n_pairs >= (1LL << 31)) return fail(FB_EINVAL, "mesh too large for the device plan builder (%lld pairs)", n_pairs);
-  DevBuf<unsigned long long>&keys = W.keys, &keys_s = W.keys_s, &ukeys = W.ukeys;
+  DevBuf<unsigned long long>&keys = W.keys, &keys_s = W.keys_s;
   DevBuf<uint32_t>&vals = W.vals, &vals_s = W.vals_s;
-  DevBuf<unsigned int>&ucnt = W.ucnt, &cstart = W.cstart, &nruns = W.nruns;
-  DevBuf<int>& width = W.width;
   DevBuf<char>& temp = W.temp;
   FB_TRY(W.flags.reserve(2));
   FB_TRY(keys.reserve((size_t)n_pairs));
@@ -539,22 +540,51 @@ int build_plan_device(hipStream_t s, int n_nodes_local, int n_tets, const int4* 
   if (D.first_bad_tet >= 0) return fail(FB_EINVAL, "tet %d references a node outside [0,%d)", D.first_bad_tet, n_nodes_local);
   size_t bytes = 0;
   const unsigned key_bits = narrow ? (unsigned)(rb32 + cb32) : (unsigned)(row_bits + geom.col_bits);
+  if (narrow) {
+    FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys32, keys32_s, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
+    FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys32, keys32_s, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
+  } else {
+    FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
+    FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
+  }
+  // (kept in the workspace for a later fb_fem_resync_delta: delta.hip updates the sorted list instead of sorting again)
+  W.sorted = SortedPairs();
+  W.sorted.valid = !shard; W.sorted.narrow = narrow; W.sorted.cb = cb32; W.sorted.span = span; W.sorted.col_bits = geom.col_bits;
+  W.sorted.n_pairs = n_pairs; W.sorted.n_nodes = n_nodes; W.sorted.n_tets = n_tets;
+  return plan_from_sorted(s, n_nodes, n_pairs, n_valid, narrow, cb32, span, geom, shard, D, W);
+}
+
+int plan_from_sorted_pairs(hipStream_t s, DevicePlan& D, PlanWorkspace& W) {
+  const SortedPairs& S = W.sorted;
+  if (!S.valid) return fail(FB_EINVAL, "internal: no sorted pair list in the workspace");
+  PairGeom geom;
+  geom.n_rows = S.n_nodes; geom.node_lo = 0; geom.halo = nullptr; geom.col_bits = S.col_bits;
+  return plan_from_sorted(s, S.n_nodes, S.n_pairs, S.n_pairs, S.narrow, S.cb, S.span, geom, nullptr, D, W);
+}
+
+// The plan from the sorted pair list in W.keys_s / W.vals_s (stage 3 of the header comment)
+static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long long n_valid, bool narrow, int cb32, int span, const PairGeom& geom, const PlanShard* shard,
+                            DevicePlan& D, PlanWorkspace& W) {
+  DevBuf<unsigned long long>&keys_s = W.keys_s, &ukeys = W.ukeys;
+  DevBuf<uint32_t>& vals_s = W.vals_s;
+  DevBuf<unsigned int>&ucnt = W.ucnt, &cstart = W.cstart, &nruns = W.nruns;
+  DevBuf<int>& width = W.width;
+  DevBuf<char>& temp = W.temp;
+  unsigned int* keys32_s = reinterpret_cast<unsigned int*>(keys_s.p);
+  size_t bytes = 0;
+  FB_TRY(W.flags.reserve(2));
   FB_TRY(ukeys.reserve((size_t)n_pairs));
   FB_TRY(ucnt.reserve((size_t)n_pairs));
   FB_TRY(nruns.reserve(1));
   unsigned int* ukeys32 = reinterpret_cast<unsigned int*>(ukeys.p);
   if (narrow) {
-    FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys32, keys32_s, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
-    FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
-    FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys32, keys32_s, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
     bytes = 0;  // blocks = runs of equal keys
     FB_HIP(rocprim::run_length_encode(nullptr, bytes, keys32_s, (unsigned int)n_valid, ukeys32, ucnt.p, nruns.p, s));
     FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
     FB_HIP(rocprim::run_length_encode(temp.p, bytes, keys32_s, (unsigned int)n_valid, ukeys32, ucnt.p, nruns.p, s));
   } else {
-    FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
-    FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
-    FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
     bytes = 0;  // blocks = runs of equal keys
     FB_HIP(rocprim::run_length_encode(nullptr, bytes, keys_s.p, (unsigned int)n_valid, ukeys.p, ucnt.p, nruns.p, s));
     FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
@@ -601,6 +631,7 @@ int build_plan_device(hipStream_t s, int n_nodes_local, int n_tets, const int4* 
   FB_TRY(D.coldelta->alloc(std::max<size_t>(1, (size_t)D.n_slots * kSliceRows)));
   if (shard && D.halo_base) FB_TRY(D.halo_base->alloc((size_t)std::max(1, n_slices)));
   struct { int* p; } wide = {W.flags.p + 1};
+  FB_HIP(hipMemsetAsync(wide.p, 0, sizeof(int), s));
   hipLaunchKernelGGL(k_plan_sell, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, D.slice_off->p, D.colidx->p, D.blk_slot->p,
                      D.slot_ccnt->p, D.coldelta->p, wide.p, (shard && D.halo_base) ? D.halo_base->p : nullptr);
   FB_HIP(hipGetLastError());

@@ -58,6 +58,8 @@ struct Renumbering {
   int span_before = 0, span_after = 0;      // widest element before / after (span_after = span_before when inactive)
   double mean_before = 0, mean_after = 0;   // mean width of an element before / after
   DevBuf<int> d_old_of_new, d_new_of_old;   // internal id -> caller id and back
+  SlabKeyGeom geom = {};                    // the key geometry the order was built with, and the nodes' keys in the internal order
+  DevBuf<unsigned long long> d_keys;        // (fb_fem_resync_delta puts new nodes into the order under the same geometry)
   std::vector<int> old_of_new, new_of_old;  // host copies, fetched on demand (inspection entry points)
   int n = 0;
   int host_maps(hipStream_t s);

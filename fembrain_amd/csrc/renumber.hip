@@ -230,6 +230,9 @@ int renumber_build(hipStream_t s, int mode, int n_nodes, int n_tets, const int4*
   // AUTO keeps the new order only if the elements get a quarter narrower ON AVERAGE (the widest one may be an outlier -- a sliver on the
   // hull of a Delaunay mesh joins nodes a body apart in any order); ON keeps it
   if (mode != FB_RENUMBER_ON && R.mean_after * 4.0 > R.mean_before * 3.0) { R.span_after = R.span_before; R.mean_after = R.mean_before; return FB_OK; }
+  R.geom = g;
+  FB_TRY(R.d_keys.alloc((size_t)n_nodes));
+  FB_HIP(hipMemcpyAsync(R.d_keys.p, W.keys_s.p, sizeof(unsigned long long) * (size_t)n_nodes, hipMemcpyDeviceToDevice, s));
   R.old_of_new.clear();  // (the host copies are fetched when an inspection entry point asks: Renumbering::host_maps)
   R.new_of_old.clear();
   R.n = n_nodes;

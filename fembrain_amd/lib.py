@@ -19,6 +19,7 @@ FB_PCG_PATH_TWO_LAUNCH, FB_PCG_PATH_PERSISTENT, FB_PCG_PATH_FALLBACK, FB_PCG_PAT
 FB_SPMV_AUTO, FB_SPMV_ROWS, FB_SPMV_SPLIT = 0, 1, 2
 FB_INTEGRATOR_VOLUME_CONSERVING, FB_INTEGRATOR_NEWMARK = 0, 1
 FB_RENUMBER_AUTO, FB_RENUMBER_ON, FB_RENUMBER_OFF = 0, 1, -1
+FB_RESYNC_FULL, FB_RESYNC_DELTA_MERGED, FB_RESYNC_DELTA_REBUILT = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
@@ -106,6 +107,8 @@ def lib():
         "fb_fem_destroy": (C.c_int, [vp]),
         "fb_fem_resync": (C.c_int, [vp, C.c_int, _dp, C.c_int, _ip, C.c_int, _ip]),
         "fb_fem_resync_sharded": (C.c_int, [vp, C.c_int, _dp, C.c_int, _ip, C.c_int, _ip, _ip]),
+        "fb_fem_resync_delta": (C.c_int, [vp, C.c_int, _ip, C.c_int, _ip, _ip, C.c_int, _ip, C.c_int, _dp, C.c_int, _ip]),
+        "fb_fem_resync_path": (C.c_int, [vp]),
         "fb_fem_rebuild_elements": (C.c_int, [vp]),
         "fb_fem_set_external_forces": (C.c_int, [vp, _dp]),
         "fb_fem_add_external_forces": (C.c_int, [vp, _dp]),

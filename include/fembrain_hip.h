@@ -167,6 +167,31 @@ int fb_fem_resync(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const 
 int fb_fem_resync_sharded(fb_fem_t h, int n_nodes, const double* xyz, int n_tets, const int* tets,
                           int n_fixed_dofs, const int* fixed_dofs, const int* node_splits);
 
+/* The same re-sync from a DESCRIPTION of the change (fembrain_amd/csrc/delta.h).  CuttableMesh::cut (CuttableMesh.cpp:283-470) erases
+ * the cells its blade crosses keeping the order of the rest (VolMesh.cpp:630, m_vCells.erase), appends their pieces and the new nodes
+ * (push_back, VolMesh.cpp:1083-1088) and re-points cells on a split edge in place (:1630-1650); the host passes just that:
+ *   removed[n_removed]        ids (in the handle's CURRENT element list) of the elements to erase, ascending
+ *   changed_ids[n_changed]    ids of elements that stay in place with new nodes, ascending, none of them removed;
+ *   changed_nodes[4 n_changed]  their four node ids
+ *   added_tets[4 n_added]     elements appended behind the last one
+ *   new_xyz[3 n_new_nodes]    rest positions of nodes appended behind the last one (ids n_nodes, n_nodes + 1, ...)
+ *   fixed_dofs                the whole constrained-DOF list of the new mesh, as fb_fem_resync takes it
+ * The element list and the rest positions stay on the device; the result is the state fb_fem_resync would leave with the whole new
+ * mesh (state reset).  Where the handle still holds the sorted pair list its plan was built from, that list is updated instead of
+ * built and sorted again: for a handle in the caller's node order the plan is bit for bit the full rebuild's; a renumbered handle
+ * (fb_fem_renumbering) puts the new nodes into its slab order under the cell size the order was made with, where a full rebuild
+ * would derive a new cell size -- same pattern and values in the caller's ids, roundings of sums aside.  Otherwise (and with
+ * FEMBRAIN_RESYNC_DELTA=rebuild) the full builder runs from the device copy of the new mesh.  fb_fem_resync_path: what the last
+ * re-sync of the handle did.  Unsharded handles with a device-built plan only (FB_EINVAL otherwise); a bad id is refused before
+ * anything changes; after a failure further in the handle is unusable until a full fb_fem_resync succeeds. */
+#define FB_RESYNC_FULL 0           /* fb_fem_create / fb_fem_resync: whole mesh from the host */
+#define FB_RESYNC_DELTA_MERGED 1   /* fb_fem_resync_delta: pair list updated */
+#define FB_RESYNC_DELTA_REBUILT 2  /* fb_fem_resync_delta: full builder from the device copy of the mesh */
+int fb_fem_resync_delta(fb_fem_t h, int n_removed, const int* removed, int n_changed, const int* changed_ids, const int* changed_nodes,
+                        int n_added, const int* added_tets, int n_new_nodes, const double* new_xyz, int n_fixed_dofs, const int* fixed_dofs);
+int fb_fem_resync_path(fb_fem_t h);
+
+
 /* Per-element rest-state rebuild on the device (M^-1 rows / volume, corotationalLinearFEM.cpp:66-90 and
  * tetMesh.cpp:184-188) -- the per-step "K0 rebuild" of BASELINE config 4. */
 int fb_fem_rebuild_elements(fb_fem_t h);

@@ -1,0 +1,214 @@
+"""fb_fem_resync_delta (fembrain_amd/csrc/delta.h): the re-sync after a cut from a DESCRIPTION of the change.
+
+CuttableMesh::cut erases the cut cells keeping the order of the rest (src/deformable/VolMesh.cpp:630), appends their pieces and the new
+nodes (:1083-1088) and re-points cells in place (:1630-1650); Deformable::syncForceModel (src/deformable/Deformable.cpp:127-220) then
+rebuilds everything.  The handle keeps its mesh on the device and updates the sorted pair list its plan was built from.  Checked here
+against a handle made from the whole new mesh: every plan array, the assembled matrix and force, and a step, bit for bit where the
+handle works in the caller's node order; pattern, values and the step to rounding where the handle has an internal order of its own.
+The change is meshgen.synthetic_cut (every element crossing a plane split in four on a new centroid node: removed, changed in place,
+appended) -- not the reference's subdivision tables, which live in the host's CuttableMesh.
+"""
+import numpy as np
+import pytest
+
+from fembrain_amd import lib as fl
+from fembrain_amd.fem import FemIntegrator, bsr_to_scipy
+from fembrain_amd.meshgen import apply_delta, cube_fixed_plane_i0, fixed_vertices_to_dofs, synthetic_cut, truth_cube
+
+pytestmark = pytest.mark.gpu
+PLAN = ("bptr", "bcol", "blk_slot", "slice_off", "colidx", "slot_coff", "slot_ccnt", "contrib")
+
+
+def _cube(n):
+    v, t = truth_cube(n, n, n, 0.1)
+    return v, t, fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+
+
+def _device_plan(g, name):
+    L = fl.lib()
+    n = L.fb_fem_device_plan_get(g.h, name.encode(), None, 0)
+    assert n >= 0, (name, L.fb_last_error())
+    a = np.zeros(n, np.int32)
+    assert L.fb_fem_device_plan_get(g.h, name.encode(), fl.iptr(a), n) == n
+    return a
+
+
+def _same_bits(ga, gb, seed=5, load=-2000.0):
+    """plan arrays, assembled force and matrix, and two steps of two handles: bit for bit"""
+    for name in PLAN:
+        assert np.array_equal(_device_plan(ga, name), _device_plan(gb, name)), name
+    assert ga.r == gb.r
+    u = np.random.default_rng(seed).normal(size=ga.r) * 0.003
+    fa, Ka = ga.assemble(u)
+    fb_, Kb = gb.assemble(u)
+    assert np.array_equal(fa, fb_) and np.array_equal(Ka, Kb)
+    assert np.array_equal(ga.mass(), gb.mass())
+    for g in (ga, gb):
+        g.reset_to_rest()
+    for k in range(2):
+        its = []
+        for g in (ga, gb):
+            g.set_uniform_force(1, load)
+            its.append(g.do_timestep())
+        assert its[0] == its[1] > 0
+        assert np.array_equal(ga.get_q_state()[0], gb.get_q_state()[0])
+
+
+@pytest.mark.parametrize("n,axis,every_changed", [(10, 0, 3), (14, 1, 3), (14, 2, 0), (12, 1, 1)])
+def test_delta_resync_gives_the_plan_and_the_step_of_a_full_resync_bit_for_bit(gpu, n, axis, every_changed):
+    v, t, fixed = _cube(n)
+    g = FemIntegrator(v, t, fixed)
+    g.set_uniform_force(1, -500.0)
+    g.do_timestep()                     # (a state to be reset)
+    v2, t2, d = synthetic_cut(v, t, axis=axis, where=0.4, every_changed=every_changed)
+    assert len(d["removed"]) + len(d["changed_ids"]) > 0 and len(d["added"]) > 0 and len(d["new_xyz"]) > 0
+    g.resync_delta(d, fixed)
+    assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED
+    assert fl.lib().fb_fem_num_nodes(g.h) == len(v2) and fl.lib().fb_fem_num_tets(g.h) == len(t2)
+    assert not np.any(g.get_q_state()[0])
+    ref = FemIntegrator(v2, t2, fixed)
+    assert ref.resync_path() == fl.FB_RESYNC_FULL
+    _same_bits(g, ref)
+    # a second change on top of the first (the list now has 64-bit keys: the appended nodes make the elements wide), then a third
+    for where in (0.7, 0.2):
+        v3, t3, d2 = synthetic_cut(g.verts, g.tets, axis=(axis + 1) % 3, where=where, every_changed=2)
+        g.resync_delta(d2, fixed)
+        assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED
+        assert np.array_equal(g.tets, t3) and np.array_equal(g.verts, v3)
+    ref.resync(v3, t3, fixed)
+    _same_bits(g, ref, seed=6)
+    g.close()
+    ref.close()
+
+
+def test_delta_resync_partial_changes_and_new_constraints(gpu):
+    """removals only, additions only (no new node), changes only, nothing at all; the constrained DOFs follow the call's list"""
+    v, t, fixed = _cube(9)
+    g = FemIntegrator(v, t, fixed)
+    ref = FemIntegrator(v, t, fixed)
+    rng = np.random.default_rng(11)
+    empty = dict(removed=[], changed_ids=[], changed_nodes=[], added=[], new_xyz=[])
+    cur_v, cur_t = v, t
+    fixed2 = fixed_vertices_to_dofs(np.concatenate([cube_fixed_plane_i0(9, 9), [400, 401]]))
+    for step, fx in (("removed", fixed), ("added", fixed2), ("changed", fixed2), ("none", fixed)):
+        d = dict(empty)
+        if step == "removed":
+            d["removed"] = np.sort(rng.choice(len(cur_t), 40, replace=False)).astype(np.int32)
+        elif step == "added":
+            d["added"] = cur_t[rng.choice(len(cur_t), 25, replace=False)][:, [1, 0, 2, 3]]   # (duplicates of live elements, mirrored)
+        elif step == "changed":
+            ids = np.sort(rng.choice(len(cur_t), 30, replace=False)).astype(np.int32)
+            d["changed_ids"] = ids
+            d["changed_nodes"] = cur_t[ids][:, [0, 2, 1, 3]]
+        g.resync_delta(d, fx)
+        assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED
+        cur_v, cur_t = apply_delta(cur_v, cur_t, {k: np.asarray(x) for k, x in d.items()})
+        ref.resync(cur_v, cur_t, fx)
+        _same_bits(g, ref, load=-300.0)
+        q = g.get_q_state()[0]
+        assert not q[fx].any() and np.abs(q).max() > 0
+    g.close()
+    ref.close()
+
+
+def test_delta_resync_with_the_node_order_switched_off_and_forced_rebuild(gpu, monkeypatch):
+    """FB_RENUMBER_OFF above the size where AUTO looks at the numbering: the list is updated (64-bit keys), bit for bit; with
+    FEMBRAIN_RESYNC_DELTA=rebuild the full builder runs from the device copy of the mesh, bit for bit as well"""
+    v, t, fixed = _cube(22)
+    assert len(v) >= 8192
+    v2, t2, d = synthetic_cut(v, t, axis=1, where=0.45)
+    g = FemIntegrator(v, t, fixed, renumber=fl.FB_RENUMBER_OFF)
+    g.resync_delta(d, fixed)
+    assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED and not g.renumbering()[0]
+    ref = FemIntegrator(v2, t2, fixed, renumber=fl.FB_RENUMBER_OFF)
+    _same_bits(g, ref, load=-200.0)
+    monkeypatch.setenv("FEMBRAIN_RESYNC_DELTA", "rebuild")
+    g2 = FemIntegrator(v, t, fixed, renumber=fl.FB_RENUMBER_OFF)
+    g2.resync_delta(d, fixed)
+    assert g2.resync_path() == fl.FB_RESYNC_DELTA_REBUILT
+    _same_bits(g2, ref, seed=8, load=-200.0)
+    for h in (g, g2, ref):
+        h.close()
+
+
+def test_delta_resync_on_a_handle_with_its_own_node_order(gpu):
+    """AUTO at 10,648 nodes: the first cut appends nodes, the elements on them are as wide as the mesh, so the full builder is asked
+    (from the device copy of the mesh) and renumbers -- bit for bit what fb_fem_resync gives.  The second cut then finds a renumbered
+    handle: the new nodes go into its slab order under the cell size it was made with (a full rebuild would derive a new one), the pair
+    list is updated.  Same pattern and values in the caller's ids, the step to the solver's tolerance; the elements stay narrow."""
+    v, t, fixed = _cube(22)
+    g = FemIntegrator(v, t, fixed)
+    assert not g.renumbering()[0]
+    v2, t2, d = synthetic_cut(v, t, axis=1, where=0.45)
+    g.resync_delta(d, fixed)
+    assert g.resync_path() == fl.FB_RESYNC_DELTA_REBUILT
+    ref = FemIntegrator(v2, t2, fixed)
+    on, sc, si = g.renumbering()
+    assert on and ref.renumbering() == (on, sc, si) and si < 2000 < sc
+    _same_bits(g, ref, load=-200.0)
+    v3, t3, d2 = synthetic_cut(v2, t2, axis=0, where=0.6, every_changed=2)
+    g.resync_delta(d2, fixed)
+    assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED
+    ref.resync(v3, t3, fixed)
+    on, sc, si = g.renumbering()
+    ron, rsc, rsi = ref.renumbering()
+    assert on and ron and si <= 1.25 * rsi, ((on, sc, si), (ron, rsc, rsi))   # (as narrow as a fresh slab order makes them)
+    bp, bc = g.pattern()
+    rp, rc = ref.pattern()
+    assert np.array_equal(bp, rp) and np.array_equal(bc, rc)
+    u = np.random.default_rng(3).normal(size=g.r) * 0.003
+    fa, Ka = g.assemble(u)
+    fr, Kr = ref.assemble(u)
+    assert np.abs(fa - fr).max() <= 1e-12 * np.abs(fr).max()
+    assert np.abs(Ka - Kr).max() <= 2e-7 * np.abs(Kr).max()       # (fp32 stored matrix; the diagonal compensation sums in slot order)
+    assert np.abs(g.mass() - ref.mass()).max() <= 1e-12 * np.abs(ref.mass()).max()
+    for k in range(2):
+        its = []
+        for h in (g, ref):
+            h.set_uniform_force(1, -200.0)
+            its.append(h.do_timestep())
+        assert abs(its[0] - its[1]) <= 2
+        qa, qr = g.get_q_state()[0], ref.get_q_state()[0]
+        assert np.abs(qa - qr).max() <= 2e-5 * np.abs(qr).max() and not qa[fixed].any()
+    # the next full re-sync starts over
+    g.resync(v3, t3, fixed)
+    assert g.resync_path() == fl.FB_RESYNC_FULL
+    _same_bits(g, ref, seed=9, load=-200.0)
+    g.close()
+    ref.close()
+
+
+def test_delta_resync_refuses_bad_input_before_anything_changes(gpu):
+    v, t, fixed = _cube(8)
+    g = FemIntegrator(v, t, fixed)
+    ok = dict(removed=[], changed_ids=[], changed_nodes=[], added=[], new_xyz=[])
+    bad = [dict(ok, removed=[5, 5]), dict(ok, removed=[7, 3]), dict(ok, removed=[len(t)]), dict(ok, removed=[-1]),
+           dict(ok, removed=[4], changed_ids=[4], changed_nodes=[0, 1, 2, 3]), dict(ok, changed_ids=[3], changed_nodes=[0, 1, 2, len(v)]),
+           dict(ok, added=[0, 1, 2, len(v) + 1], new_xyz=[0.0, 0.0, 0.0]), dict(ok, added=[0, 1, -2, 3]),
+           dict(ok, removed=np.arange(len(t)))]
+    for d in bad:
+        with pytest.raises(fl.FbError):
+            g.resync_delta(d, fixed)
+    g.set_uniform_force(1, -100.0)
+    assert g.do_timestep() > 0          # still the old mesh, still usable
+    # a flat element gets through the id checks and is refused by the rest-state kernel: the handle is unusable until a full re-sync
+    with pytest.raises(fl.FbError):
+        g.resync_delta(dict(ok, added=[0, 1, 1, 2]), fixed)
+    with pytest.raises(fl.FbError):
+        g.do_timestep()
+    with pytest.raises(fl.FbError):
+        g.resync_delta(ok, fixed)
+    g.resync(v, t, fixed)
+    g.set_uniform_force(1, -100.0)
+    assert g.do_timestep() > 0
+    g.close()
+    # sharded handles and host-built plans say no
+    import os
+    os.environ["FEMBRAIN_PLAN_DEVICE"] = "0"
+    try:
+        gh = FemIntegrator(v, t, fixed)
+    finally:
+        del os.environ["FEMBRAIN_PLAN_DEVICE"]
+    with pytest.raises(fl.FbError):
+        gh.resync_delta(ok, fixed)
+    gh.close()
