@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -50,9 +51,12 @@ struct DevBuf {
   // cost 7 of the 10 ms such a re-sync took at 1M tets (tools/probe_resync_cut.py) when every size was exact.
   int alloc(size_t count) {
     if (p && count <= cap && (count >= cap / 2 || cap * sizeof(T) <= (1u << 20)) && count > 0) { n = count; return FB_OK; }
+    const size_t had = p ? cap : 0;
     release();
     if (count == 0) return FB_OK;
-    const size_t want = count + (count * sizeof(T) >= (1u << 16) ? count / 8 : 0);
+    // (a buffer that is GROWING gets half again what it had, so a mesh that grows cut by cut re-allocates every few cuts only)
+    const size_t grown = had && count > had ? had + had / 2 : 0;
+    const size_t want = std::max(count + (count * sizeof(T) >= (1u << 16) ? count / 8 : 0), count * sizeof(T) >= (1u << 16) ? grown : 0);
     hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
     if (e != hipSuccess && want != count) {  // no room for the slack: the exact size
       (void)hipGetLastError();

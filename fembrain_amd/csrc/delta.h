@@ -32,6 +32,9 @@ struct MeshDelta {
   DevBuf<int> pos;                  // per old element: its new id (elements before it that stay)
   DevBuf<unsigned long long> nk, nks;  // keys of the new pairs, unsorted / sorted
   DevBuf<uint32_t> nv, nvs;
+  DevBuf<int> tile_i;               // delta_sorted_pairs: per tile of the old list -- entries that stay, their prefix sums, bounds in the new entries
+  DevBuf<unsigned long long> tile_k;  // ... its first and last staying entry
+  DevBuf<uint32_t> tile_v;
   bool mapped = false;              // delta_node_order ran for this change: imap / newint / node_keys are its
   DevBuf<int> imap, newint;         // renumbered handles: old internal id -> new internal id; new node k -> its internal id
   DevBuf<unsigned long long> node_keys;  // merged slab keys (internal order)

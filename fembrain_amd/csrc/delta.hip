@@ -185,6 +185,152 @@ __global__ __launch_bounds__(kB) void k_delta_new_pairs(int n_changed, int n_add
   }
 }
 
+// ---- the update of the list in two passes of our own (the library's select over a transforming zip iterator took 490 us at 1M tets,
+// its merge another 110): tiles of kTile old entries; pass 1 counts the entries of every tile that stay and notes its first and last
+// one; pass 2 ranks them (tile base + rank inside the tile) and puts the new entries that fall between two of them in their places.
+// New entries below the first or above the last old entry are copied by k_upd_ends.
+constexpr int kTile = 2048, kTileItems = kTile / kB;
+template <typename K>
+__device__ __forceinline__ bool pair_less(K ka, uint32_t va, K kb, uint32_t vb) { return ka < kb || (ka == kb && va < vb); }
+
+template <typename KIn, typename KOut>
+__device__ __forceinline__ bool xform_entry(const PackDesc& in, const PackDesc& out, const int* __restrict__ imap, const unsigned char* __restrict__ estate,
+                                            const int* __restrict__ pos, KIn k, uint32_t v, KOut* ko, uint32_t* vo) {
+  int row, col;
+  unpack_key(in, (unsigned long long)k, row, col);
+  if (imap) { row = imap[row]; col = imap[col]; }
+  *ko = (KOut)pack_key(out, row, col);
+  *vo = v;
+  if (v == kNoContrib) return true;
+  const uint32_t e = v >> 4;
+  if (estate[e]) return false;
+  *vo = ((uint32_t)pos[e] << 4) | (v & 15u);
+  return true;
+}
+
+template <typename KIn, typename KOut>
+__global__ __launch_bounds__(kB) void k_upd_count(long long n_a, const KIn* __restrict__ ka, const uint32_t* __restrict__ va, PackDesc in, PackDesc out,
+                                                  const int* __restrict__ imap, const unsigned char* __restrict__ estate, const int* __restrict__ pos,
+                                                  int* __restrict__ tile_kept, KOut* __restrict__ first_k, uint32_t* __restrict__ first_v, KOut* __restrict__ last_k,
+                                                  uint32_t* __restrict__ last_v) {
+  __shared__ int s_cnt, s_min, s_max;
+  if (threadIdx.x == 0) { s_cnt = 0; s_min = kTile; s_max = -1; }
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * kTile;
+  int cnt = 0, mn = kTile, mx = -1;
+#pragma unroll
+  for (int i = 0; i < kTileItems; i++) {
+    const int q = i * kB + threadIdx.x;
+    const long long idx = base + q;
+    if (idx < n_a) {
+      const uint32_t v = va[idx];
+      const bool keep = v == kNoContrib || estate[v >> 4] == 0;
+      if (keep) { cnt++; mn = min(mn, q); mx = max(mx, q); }
+    }
+  }
+  if (cnt) { atomicAdd(&s_cnt, cnt); atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tile_kept[blockIdx.x] = s_cnt;
+    if (s_cnt) {
+      KOut k; uint32_t v;
+      xform_entry<KIn, KOut>(in, out, imap, estate, pos, ka[base + s_min], va[base + s_min], &k, &v);
+      first_k[blockIdx.x] = k; first_v[blockIdx.x] = v;
+      xform_entry<KIn, KOut>(in, out, imap, estate, pos, ka[base + s_max], va[base + s_max], &k, &v);
+      last_k[blockIdx.x] = k; last_v[blockIdx.x] = v;
+    }
+  }
+}
+
+template <typename K>
+__device__ __forceinline__ int lower_bound_pairs(const K* __restrict__ k, const uint32_t* __restrict__ v, int lo, int hi, K key, uint32_t val) {
+  while (lo < hi) {  // first index whose entry is not less than (key, val)
+    const int mid = (lo + hi) >> 1;
+    if (pair_less<K>(k[mid], v[mid], key, val)) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// per tile: the number of new entries below its first staying entry (-1: the tile keeps nothing); bounds[0] = that of the first such tile,
+// bounds[1] = the number of new entries below the LAST staying entry of the whole list
+template <typename KOut>
+__global__ __launch_bounds__(kB) void k_upd_bounds(int n_tiles, long long n_stay, const int* __restrict__ tile_kept, const int* __restrict__ tile_base,
+                                                   const KOut* __restrict__ first_k, const uint32_t* __restrict__ first_v, const KOut* __restrict__ last_k,
+                                                   const uint32_t* __restrict__ last_v, int n_b, const KOut* __restrict__ kb, const uint32_t* __restrict__ vb, int* __restrict__ lo,
+                                                   int* __restrict__ bounds) {
+  const int b = blockIdx.x * kB + threadIdx.x;
+  if (b >= n_tiles) return;
+  if (tile_kept[b] == 0) { lo[b] = -1; return; }
+  const int l = lower_bound_pairs<KOut>(kb, vb, 0, n_b, first_k[b], first_v[b]);
+  lo[b] = l;
+  if (tile_base[b] == 0) bounds[0] = l;
+  if ((long long)tile_base[b] + tile_kept[b] == n_stay) bounds[1] = lower_bound_pairs<KOut>(kb, vb, 0, n_b, last_k[b], last_v[b]);
+}
+
+template <typename KIn, typename KOut>
+__global__ __launch_bounds__(kB) void k_upd_merge(long long n_a, const KIn* __restrict__ ka, const uint32_t* __restrict__ va, PackDesc in, PackDesc out,
+                                                  const int* __restrict__ imap, const unsigned char* __restrict__ estate, const int* __restrict__ pos, int n_tiles,
+                                                  const int* __restrict__ tile_kept, const int* __restrict__ tile_base, const int* __restrict__ lo_of, const int* __restrict__ bounds,
+                                                  int n_b, const KOut* __restrict__ kb, const uint32_t* __restrict__ vb, KOut* __restrict__ kc, uint32_t* __restrict__ vc) {
+  __shared__ KOut ck[kTile];
+  __shared__ uint32_t cv[kTile];
+  __shared__ int s_wave[kB / 64], s_run, s_lo, s_hi;
+  const int kept = tile_kept[blockIdx.x];
+  if (kept == 0) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    s_run = 0;
+    s_lo = lo_of[blockIdx.x];
+    int hi = bounds[1];
+    for (int t = blockIdx.x + 1; t < n_tiles; t++)
+      if (lo_of[t] >= 0) { hi = lo_of[t]; break; }
+    s_hi = hi;
+  }
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * kTile;
+#pragma unroll 1
+  for (int i = 0; i < kTileItems; i++) {
+    const long long idx = base + i * kB + threadIdx.x;
+    KOut k = 0; uint32_t v = 0;
+    bool keep = false;
+    if (idx < n_a) keep = xform_entry<KIn, KOut>(in, out, imap, estate, pos, ka[idx], va[idx], &k, &v);
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ULL << lane) - 1ULL));
+    if (lane == 0) s_wave[wv] = __popcll(m);
+    __syncthreads();
+    int off = s_run;
+    for (int w = 0; w < wv; w++) off += s_wave[w];
+    if (keep) { ck[off + before] = k; cv[off + before] = v; }
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kB / 64; w++) t += s_wave[w]; s_run += t; }
+    __syncthreads();
+  }
+  const int lo = s_lo, hi = s_hi;
+  const long long gbase = tile_base[blockIdx.x];
+  // the staying entries: behind the new ones that are smaller
+  for (int q = threadIdx.x; q < kept; q += kB) {
+    const KOut k = ck[q]; const uint32_t v = cv[q];
+    const int nb = lower_bound_pairs<KOut>(kb, vb, lo, hi, k, v);
+    kc[gbase + q + nb] = k; vc[gbase + q + nb] = v;
+  }
+  // the new entries between this tile's first staying entry and the next tile's: behind the staying ones that are smaller
+  for (int j = lo + threadIdx.x; j < hi; j += kB) {
+    const KOut k = kb[j]; const uint32_t v = vb[j];
+    const int na = lower_bound_pairs<KOut>(ck, cv, 0, kept, k, v);
+    kc[gbase + na + j] = k; vc[gbase + na + j] = v;
+  }
+}
+
+// new entries below the first and above the last staying entry
+template <typename KOut>
+__global__ __launch_bounds__(kB) void k_upd_ends(long long n_stay, const int* __restrict__ bounds, int n_b, const KOut* __restrict__ kb, const uint32_t* __restrict__ vb,
+                                                 KOut* __restrict__ kc, uint32_t* __restrict__ vc) {
+  const int j = blockIdx.x * kB + threadIdx.x;
+  if (j >= n_b) return;
+  if (j < bounds[0]) { kc[j] = kb[j]; vc[j] = vb[j]; }
+  else if (j >= bounds[1]) { kc[n_stay + j] = kb[j]; vc[n_stay + j] = vb[j]; }
+}
+
 int bits_of(long long n) {
   int b = 1;
   while ((1LL << b) < n) b++;
@@ -197,22 +343,7 @@ int update_pairs(hipStream_t s, MeshDelta& D, const int4* tets_new, int n_nodes_
   const long long n_stay = n_old_pairs - 16LL * (D.n_removed + D.n_changed);
   const long long n_fresh = 16LL * (D.n_changed + D.n_added) + D.n_new_nodes;
   if (n_stay + n_fresh != n_new_pairs) return fail(FB_EINVAL, "internal: pair count of the change does not add up");
-  // 1. the old list, transformed, without the dropped entries: keys_s / vals_s -> keys / vals (scratch of the last build or change:
-  // sized for THAT list)
-  FB_TRY(W.nruns.reserve(1));
-  FB_TRY(W.keys.reserve((size_t)std::max<long long>(1, n_stay)));
-  FB_TRY(W.vals.reserve((size_t)std::max<long long>(1, n_stay)));
-  {
-    const auto in = rocprim::make_transform_iterator(
-        rocprim::make_zip_iterator(rocprim::make_tuple(reinterpret_cast<const KIn*>(W.keys_s.p), static_cast<const uint32_t*>(W.vals_s.p))),
-        PairXform<KIn, KOut>{pin, pout, D.mapped ? D.imap.p : nullptr, D.estate.p, D.pos.p});
-    auto out = rocprim::make_zip_iterator(rocprim::make_tuple(reinterpret_cast<KOut*>(W.keys.p), W.vals.p));
-    size_t bytes = 0;
-    FB_HIP(rocprim::select(nullptr, bytes, in, out, W.nruns.p, (size_t)n_old_pairs, NotDropped(), s));
-    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
-    FB_HIP(rocprim::select(W.temp.p, bytes, in, out, W.nruns.p, (size_t)n_old_pairs, NotDropped(), s));
-  }
-  // 2. the new entries, sorted among themselves (stable: ascending contribution words inside a block, its marker last)
+  // 1. the new entries, sorted among themselves (stable: ascending contribution words inside a block, its marker last)
   FB_TRY(D.nk.reserve((size_t)std::max<long long>(1, n_fresh)));
   FB_TRY(D.nks.reserve((size_t)std::max<long long>(1, n_fresh)));
   FB_TRY(D.nv.reserve((size_t)std::max<long long>(1, n_fresh)));
@@ -228,7 +359,65 @@ int update_pairs(hipStream_t s, MeshDelta& D, const int4* tets_new, int n_nodes_
     FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
     FB_HIP(rocprim::radix_sort_pairs(W.temp.p, bytes, nk, nks, D.nv.p, D.nvs.p, (size_t)n_fresh, 0u, key_bits, s));
   }
-  // 3. merged into keys_s / vals_s (the old list is no longer needed: the buffers may grow)
+  const int* imap = D.mapped ? D.imap.p : nullptr;
+  static const bool library = getenv("FEMBRAIN_DELTA_LIBRARY") && atoi(getenv("FEMBRAIN_DELTA_LIBRARY")) != 0;  // development aid: rocprim select + merge
+  if (!library) {
+    // 2. old list (keys_s / vals_s) + new entries -> keys / vals, then the buffers change places
+    const int n_tiles = (int)((n_old_pairs + kTile - 1) / kTile);
+    FB_TRY(W.keys.reserve((size_t)n_new_pairs));
+    FB_TRY(W.vals.reserve((size_t)n_new_pairs));
+    FB_TRY(D.tile_i.reserve((size_t)3 * (n_tiles + 1) + 2));
+    FB_TRY(D.tile_k.reserve((size_t)2 * n_tiles));
+    FB_TRY(D.tile_v.reserve((size_t)2 * n_tiles));
+    int* tile_kept = D.tile_i.p;
+    int* tile_base = tile_kept + (n_tiles + 1);
+    int* tile_lo = tile_base + (n_tiles + 1);
+    int* bounds = tile_lo + (n_tiles + 1);
+    KOut* first_k = reinterpret_cast<KOut*>(D.tile_k.p);
+    KOut* last_k = first_k + n_tiles;
+    uint32_t* first_v = D.tile_v.p;
+    uint32_t* last_v = first_v + n_tiles;
+    const KIn* ka = reinterpret_cast<const KIn*>(W.keys_s.p);
+    KOut* kc = reinterpret_cast<KOut*>(W.keys.p);
+    FB_HIP(hipMemsetAsync(tile_kept + n_tiles, 0, sizeof(int), s));
+    hipLaunchKernelGGL((k_upd_count<KIn, KOut>), dim3(n_tiles), dim3(kB), 0, s, n_old_pairs, ka, W.vals_s.p, pin, pout, imap, D.estate.p, D.pos.p, tile_kept, first_k, first_v,
+                       last_k, last_v);
+    FB_HIP(hipGetLastError());
+    size_t bytes = 0;
+    FB_HIP(rocprim::exclusive_scan(nullptr, bytes, tile_kept, tile_base, 0, (size_t)n_tiles + 1, rocprim::plus<int>(), s));
+    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::exclusive_scan(W.temp.p, bytes, tile_kept, tile_base, 0, (size_t)n_tiles + 1, rocprim::plus<int>(), s));
+    const int init_bounds[2] = {0, 0};
+    FB_HIP(hipMemcpyAsync(bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_upd_bounds<KOut>, grid_for(n_tiles), dim3(kB), 0, s, n_tiles, n_stay, tile_kept, tile_base, first_k, first_v, last_k, last_v, (int)n_fresh, nks, D.nvs.p,
+                       tile_lo, bounds);
+    FB_HIP(hipGetLastError());
+    hipLaunchKernelGGL((k_upd_merge<KIn, KOut>), dim3(n_tiles), dim3(kB), 0, s, n_old_pairs, ka, W.vals_s.p, pin, pout, imap, D.estate.p, D.pos.p, n_tiles, tile_kept, tile_base,
+                       tile_lo, bounds, (int)n_fresh, nks, D.nvs.p, kc, W.vals.p);
+    FB_HIP(hipGetLastError());
+    if (n_fresh > 0) {
+      hipLaunchKernelGGL(k_upd_ends<KOut>, grid_for(n_fresh), dim3(kB), 0, s, n_stay, bounds, (int)n_fresh, nks, D.nvs.p, kc, W.vals.p);
+      FB_HIP(hipGetLastError());
+    }
+    W.keys.swap(W.keys_s);
+    W.vals.swap(W.vals_s);
+    return FB_OK;
+  }
+  // (library path) the old list, transformed, without the dropped entries: keys_s / vals_s -> keys / vals
+  FB_TRY(W.nruns.reserve(1));
+  FB_TRY(W.keys.reserve((size_t)std::max<long long>(1, n_stay)));
+  FB_TRY(W.vals.reserve((size_t)std::max<long long>(1, n_stay)));
+  {
+    const auto in = rocprim::make_transform_iterator(
+        rocprim::make_zip_iterator(rocprim::make_tuple(reinterpret_cast<const KIn*>(W.keys_s.p), static_cast<const uint32_t*>(W.vals_s.p))),
+        PairXform<KIn, KOut>{pin, pout, imap, D.estate.p, D.pos.p});
+    auto out = rocprim::make_zip_iterator(rocprim::make_tuple(reinterpret_cast<KOut*>(W.keys.p), W.vals.p));
+    size_t bytes = 0;
+    FB_HIP(rocprim::select(nullptr, bytes, in, out, W.nruns.p, (size_t)n_old_pairs, NotDropped(), s));
+    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::select(W.temp.p, bytes, in, out, W.nruns.p, (size_t)n_old_pairs, NotDropped(), s));
+  }
+  // merged into keys_s / vals_s (the old list is no longer needed: the buffers may grow)
   FB_TRY(W.keys_s.reserve((size_t)n_new_pairs));
   FB_TRY(W.vals_s.reserve((size_t)n_new_pairs));
   {

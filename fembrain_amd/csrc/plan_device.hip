@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -235,6 +236,41 @@ __global__ __launch_bounds__(kB) void k_plan_contrib(int n_nodes, int n_slices, 
   }
 }
 
+// The same through LDS (round 4): the contribution words of a slice's 64 rows are ONE contiguous run of the sorted list (rows ascending,
+// a row's blocks ascending), so the wavefront fetches it with coalesced loads, and the lanes -- each walking its own row's part -- read
+// LDS instead of 64 different cache lines per load (314 -> see DESIGN.md; 1.1M tets).  A slice whose run exceeds `cap` words (hub nodes)
+// reads global memory as k_plan_contrib does.
+__global__ __launch_bounds__(64) void k_plan_contrib_lds(int n_nodes, int n_slices, const int* __restrict__ bptr, const int* __restrict__ bcol,
+                                                         const unsigned int* __restrict__ ucnt, const unsigned int* __restrict__ cstart, const uint32_t* __restrict__ vals,
+                                                         const int* __restrict__ slice_off, const int* __restrict__ slot_coff, const int* __restrict__ slot_ccnt,
+                                                         uint32_t* __restrict__ contrib, int cap) {
+  extern __shared__ uint32_t seg[];
+  const int s = blockIdx.x, lane = threadIdx.x;
+  if (s >= n_slices) return;
+  const int a = s * 64 + lane;
+  const int so = slice_off[s], w = slice_off[s + 1] - so;
+  const int first = a < n_nodes ? bptr[a] : 0, len = a < n_nodes ? bptr[a + 1] - first : 0;
+  const int b0 = bptr[s * 64], b1 = bptr[min(s * 64 + 64, n_nodes)];
+  const unsigned int seg_lo = b1 > b0 ? cstart[b0] : 0u, seg_hi = b1 > b0 ? cstart[b1 - 1] + ucnt[b1 - 1] : 0u;
+  const bool staged = seg_hi - seg_lo <= (unsigned int)cap;  // wave-uniform
+  if (staged) {
+    for (unsigned int i = lane; i < seg_hi - seg_lo; i += 64) seg[i] = vals[seg_lo + i];
+    __syncthreads();
+  }
+  for (int k = 0; k < w; k++) {
+    const int height = slot_ccnt[so + k];  // wave-uniform
+    const int cnt = k < len ? (int)ucnt[first + k] - (bcol[first + k] == a ? 1 : 0) : 0;
+    const unsigned int from = k < len ? cstart[first + k] : seg_lo;
+    uint32_t* out = contrib + (size_t)slot_coff[so + k] * 64 + lane;
+    if (staged) {
+      const uint32_t* in = seg + (from - seg_lo);
+      for (int t = 0; t < height; t++) out[(size_t)t * 64] = t < cnt ? in[t] : kNoContrib;
+    } else {
+      for (int t = 0; t < height; t++) out[(size_t)t * 64] = t < cnt ? vals[from + t] : kNoContrib;
+    }
+  }
+}
+
 // ---- incidence lists of the element-major assembly (fem_device.hip.h k_assemble_tets) ---------------------------------------
 // one wavefront per slice: length of every row's incidence list = contributions of its diagonal block
 __global__ __launch_bounds__(kB) void k_inc_heights(int n_slices, int n_owned, const int* __restrict__ slice_off, const int* __restrict__ colidx, const int* __restrict__ slot_coff, const int* __restrict__ slot_ccnt,
@@ -432,8 +468,7 @@ int device_partition(hipStream_t s, int n_tets, DevBuf<int4>& tets, int n_global
     out.tet_global.resize((size_t)out.n_kept);
     FB_HIP(hipMemcpyAsync(out.tet_global.data(), W.idsel.p, sizeof(int) * (size_t)out.n_kept, hipMemcpyDeviceToHost, s));
     FB_HIP(hipStreamSynchronize(s));
-    std::swap(tets.p, W.tetsel.p);  // the handle's element buffer is now the compacted list (the old one serves the next re-sync)
-    std::swap(tets.n, W.tetsel.n);
+    tets.swap(W.tetsel);  // the handle's element buffer is now the compacted list (the old one serves the next re-sync)
   }
   n_tets = out.n_kept;
   int4* d_tets = tets.p;
@@ -574,6 +609,13 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
   DevBuf<char>& temp = W.temp;
   unsigned int* keys32_s = reinterpret_cast<unsigned int*>(keys_s.p);
   size_t bytes = 0;
+  static const bool timing = getenv("FEMBRAIN_TIMING") && atoi(getenv("FEMBRAIN_TIMING")) >= 2;  // development aid: the stages, each synchronised
+  const auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(s);
+    fprintf(stderr, "[fembrain] plan from the sorted list: %s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  };
   FB_TRY(W.flags.reserve(2));
   FB_TRY(ukeys.reserve((size_t)n_pairs));
   FB_TRY(ucnt.reserve((size_t)n_pairs));
@@ -592,6 +634,7 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
   }
   unsigned int nb = 0;
   FB_TRY(nruns.download(&nb, 1, s));
+  lap("run-length encoding");
   D.n_blocks = (int)nb;
   FB_TRY(cstart.reserve((size_t)nb));
   bytes = 0;
@@ -608,6 +651,7 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
     hipLaunchKernelGGL(k_plan_rows, dim3((unsigned)((std::max<long long>(nb, n_nodes + 1) + kB - 1) / kB)), dim3(kB), 0, s, n_nodes, (int)nb, geom, shard ? shard->n_halo : 0, ukeys.p,
                        D.bptr->p, D.bcol->p);
   FB_HIP(hipGetLastError());
+  lap("block rows");
   // SELL-64
   const int n_slices = (n_nodes + kSliceRows - 1) / kSliceRows;
   D.n_slices = n_slices;
@@ -624,6 +668,7 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
   D.slice_off_host.resize((size_t)n_slices + 1);
   FB_TRY(D.slice_off->download(D.slice_off_host.data(), (size_t)n_slices + 1, s));
   D.n_slots = D.slice_off_host[n_slices];
+  lap("slice widths");
   FB_TRY(D.colidx->alloc((size_t)D.n_slots * kSliceRows));
   FB_TRY(D.slot_ccnt->alloc((size_t)D.n_slots + 1));
   FB_TRY(D.slot_ccnt->zero(s));
@@ -639,6 +684,7 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
   FB_HIP(hipMemcpyAsync(&w, wide.p, sizeof(int), hipMemcpyDeviceToHost, s));
   FB_HIP(hipStreamSynchronize(s));
   D.deltas_fit16 = w == 0;
+  lap("SELL layout");
   bytes = 0;
   FB_HIP(rocprim::exclusive_scan(nullptr, bytes, D.slot_ccnt->p, D.slot_coff->p, 0, (size_t)D.n_slots + 1, rocprim::plus<int>(), s));
   FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
@@ -647,11 +693,21 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
   FB_TRY(D.slot_coff->download(&crows, 1, s, (size_t)D.n_slots));
   if ((long long)crows * kSliceRows >= (1LL << 31)) return fail(FB_EINVAL, "contribution table too large (%d rows)", crows);
   D.n_crows = crows;
+  lap("slot offsets");
   FB_TRY(D.contrib->alloc(std::max<size_t>(1, (size_t)crows * kSliceRows)));
-  hipLaunchKernelGGL(k_plan_contrib, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, cstart.p, vals_s.p, D.slice_off->p, D.slot_coff->p,
-                     D.slot_ccnt->p, D.contrib->p);
+  static const bool direct = getenv("FEMBRAIN_PLAN_CONTRIB") && !strcmp(getenv("FEMBRAIN_PLAN_CONTRIB"), "direct");  // development aid: the round-1 kernel
+  if (direct) {
+    hipLaunchKernelGGL(k_plan_contrib, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, cstart.p, vals_s.p, D.slice_off->p, D.slot_coff->p,
+                       D.slot_ccnt->p, D.contrib->p);
+  } else {
+    constexpr int kSegCap = 10240;  // words: 40 KB of LDS per wavefront, four wavefronts per CU
+    FB_HIP(hipFuncSetAttribute((const void*)k_plan_contrib_lds, hipFuncAttributeMaxDynamicSharedMemorySize, kSegCap * (int)sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_plan_contrib_lds, dim3((unsigned)std::max(1, n_slices)), dim3(64), kSegCap * sizeof(uint32_t), s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, cstart.p,
+                       vals_s.p, D.slice_off->p, D.slot_coff->p, D.slot_ccnt->p, D.contrib->p, kSegCap);
+  }
   FB_HIP(hipGetLastError());
   FB_HIP(hipStreamSynchronize(s));  // the temporaries go out of scope
+  lap("contribution table");
   return FB_OK;
 }
 

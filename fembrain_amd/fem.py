@@ -154,10 +154,11 @@ class FemIntegrator:
         _l.check(self._L.fb_fem_owned_range(self.h, rng))
         self.node_lo, self.node_hi = int(rng[0]), int(rng[1])
 
-    def resync_delta(self, delta, fixed_dofs=()):
+    def resync_delta(self, delta, fixed_dofs=(), track=True):
         """The same from a description of the change (fb_fem_resync_delta): delta = dict(removed, changed_ids, changed_nodes, added,
         new_xyz) in the terms of ``meshgen.apply_delta`` -- ids of the handle's current element list, new nodes appended.  The
-        mesh stays on the device; ``self.verts`` / ``self.tets`` follow on the host for the caller's convenience."""
+        mesh stays on the device; ``self.verts`` / ``self.tets`` follow on the host for the caller's convenience (track=False: they
+        are dropped instead -- timing runs)."""
         from .meshgen import apply_delta
         rem = _l.as_i32(delta.get("removed", ()))
         cid = _l.as_i32(delta.get("changed_ids", ()))
@@ -167,8 +168,13 @@ class FemIntegrator:
         fd = _l.as_i32(fixed_dofs)
         _l.check(self._L.fb_fem_resync_delta(self.h, len(rem), _l.iptr(rem), len(cid), _l.iptr(cid), _l.iptr(cno), len(add) // 4, _l.iptr(add),
                                              len(nxy) // 3, _l.dptr(nxy), len(fd), _l.iptr(fd)))
-        self.verts, self.tets = apply_delta(self.verts, self.tets, dict(removed=rem, changed_ids=cid, changed_nodes=cno, added=add, new_xyz=nxy))
-        self.n_nodes, self.r = len(self.verts), 3 * len(self.verts)
+        if track and self.verts is not None:
+            self.verts, self.tets = apply_delta(self.verts, self.tets, dict(removed=rem, changed_ids=cid, changed_nodes=cno, added=add, new_xyz=nxy))
+            self.n_nodes = len(self.verts)
+        else:
+            self.verts = self.tets = None
+            self.n_nodes = int(self._L.fb_fem_num_nodes(self.h))
+        self.r = 3 * self.n_nodes
         self.node_lo, self.node_hi = 0, self.n_nodes
 
     def resync_path(self):
