@@ -132,6 +132,9 @@ struct fb_fem_s {
   int pipe_flag_extra = 0;             // flag slots after the workgroups' (the proxies' flags of a sharded handle)
   int pipe_rows = 1;                   // rows per lane: 1 = k_pcg_pipe (up to 12 slices per CU), 2 = k_pcg_pipe2 (13..24)
   int pipe_max_producers = 0;          // longest producer list (-1: some workgroup polls all)
+  bool pipe_stats_pending = false;     // ... still on the device (pipe_stats: [0] longest list, [1] someone polls all)
+  DevBuf<int> pipe_owner, pipe_stats;
+  DevBuf<unsigned int> pipe_mask;
   long long persist_timeout_ticks = 0; // wall_clock64 ticks (100 MHz) a wait inside a persistent launch may last
   int persist_fallbacks = 0;           // solves that had to be repeated with the two-launch form
   int persist_launches = 0;            // persistent launches made by this handle
@@ -171,6 +174,50 @@ __global__ __launch_bounds__(kBlock) void k_widen_positions(long long n, const f
 }
 
 // FB_RENUMBER_* of this handle: fb_fem_params.renumber unless FEMBRAIN_RENUMBER=0/1 says otherwise; a sharded handle renumbers on request only
+// Zero fills of a (re-)build, batched: about twenty buffers are cleared, and a fill per buffer costs 4-5 us of launch each however
+// small it is.  add() notes them (4-byte granularity), flush() clears up to kZeroMax per launch.
+constexpr int kZeroMax = 24;
+struct ZeroList { unsigned int* p[kZeroMax]; unsigned long long end[kZeroMax]; int n; };  // end: running total of 16-byte chunks
+__global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z, unsigned long long total_chunks) {
+  for (unsigned long long c = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; c < total_chunks; c += (unsigned long long)gridDim.x * kBlock) {
+    int b = 0;
+    while (c >= z.end[b]) b++;
+    const unsigned long long local = c - (b ? z.end[b - 1] : 0ULL);
+    reinterpret_cast<uint4*>(z.p[b])[local] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+struct ZeroBatch {
+  ZeroList z;
+  hipStream_t s;
+  int rc = FB_OK;
+  explicit ZeroBatch(hipStream_t stream) : s(stream) { z.n = 0; }
+  // p: the start of an allocation of its own (a DevBuf): the fill is rounded up to 16 bytes, inside the allocator's granule
+  void add(void* p, size_t bytes) {
+    if (!p || !bytes || rc != FB_OK) return;
+    if (bytes < 4096) {  // (small ones: the runtime's fill)
+      if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess) rc = fail(FB_EDEVICE, "hipMemsetAsync failed");
+      return;
+    }
+    if (z.n == kZeroMax) flush();
+    const unsigned long long chunks = (bytes + 15) / 16, before = z.n ? z.end[z.n - 1] : 0ULL;
+    z.p[z.n] = static_cast<unsigned int*>(p);
+    z.end[z.n] = before + chunks;
+    z.n++;
+  }
+  template <typename T>
+  void add(DevBuf<T>& b) { add(b.p, b.n * sizeof(T)); }
+  int flush() {
+    if (rc != FB_OK) return rc;
+    if (z.n == 0) return FB_OK;
+    const unsigned long long total = z.end[z.n - 1];
+    const unsigned int blocks = (unsigned int)std::min<unsigned long long>((total + kBlock - 1) / kBlock, 256ULL * 16);
+    hipLaunchKernelGGL(k_zero_many, dim3(blocks), dim3(kBlock), 0, s, z, total);
+    if (hipGetLastError() != hipSuccess) rc = fail(FB_EDEVICE, "k_zero_many failed to launch");
+    z.n = 0;
+    return rc;
+  }
+};
+
 int renumber_mode(const fb_fem_s* h) {
   if (const char* e = getenv("FEMBRAIN_RENUMBER")) return atoi(e) != 0 ? FB_RENUMBER_ON : FB_RENUMBER_OFF;
   return h->prm.renumber > 0 ? FB_RENUMBER_ON : (h->prm.renumber < 0 ? FB_RENUMBER_OFF : FB_RENUMBER_AUTO);
@@ -316,6 +363,7 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   std::vector<int> prod((size_t)nb * kPipeMaxProducers, -1), cnt((size_t)nb, 0), far((size_t)nb, 1);
   std::vector<char> mark((size_t)nb + (size_t)R * K);
   h->pipe_max_producers = 0;
+  h->pipe_stats_pending = false;
   for (int b = 0; b < nb; b++) {
     std::fill(mark.begin(), mark.end(), 0);
     int n = 0;
@@ -362,6 +410,7 @@ int setup_persist(fb_fem_s* h) {
   // is the only place that sets shard_persist again; a fresh plan also gets a fresh chance after a time-out.
   h->shard_persist = false;
   h->persist_broken = false;
+  h->pipe_stats_pending = false;
   h->clean_solves = 0;
   h->rearm_after = getenv("FEMBRAIN_PERSIST_REARM") ? std::max(0, atoi(getenv("FEMBRAIN_PERSIST_REARM"))) : 32;
   h->sh_halo_off.release(); h->sh_row_send_off.release(); h->sh_row_send_rank.release(); h->sh_row_send_pos.release(); h->sh_proxy_wg.release();
@@ -421,44 +470,22 @@ int setup_persist(fb_fem_s* h) {
   }
   // producer lists: the workgroups that own the rows this workgroup's columns lie in, exactly (k_slice_producers)
   static_assert(kPipeMaxBlocks <= 256, "k_slice_producers holds 256 workgroups in its 8 mask words");
-  std::vector<int> owner((size_t)std::max(1, P.n_slices), 0), prod((size_t)nb * kPipeMaxProducers, -1), cnt((size_t)nb, 0), far((size_t)nb, 0);
-  for (int b = 0; b < nb; b++) {
-    int first, count;
-    pipe_slices(P.n_slices, nb, b, &first, &count);
-    for (int k = 0; k < count; k++) owner[first + k] = b;
-  }
-  DevBuf<int> d_owner;
-  DevBuf<unsigned int> d_mask;
-  FB_TRY(d_owner.upload(owner, s));
-  FB_TRY(d_mask.alloc((size_t)std::max(1, P.n_slices) * 8));
-  hipLaunchKernelGGL(k_slice_producers, dim3(ceil_div(std::max(1, P.n_slices), kWavesPerBlock)), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->slice_off.p, h->colidx.p,
-                     d_owner.p, d_mask.p);
-  FB_HIP(hipGetLastError());
-  std::vector<unsigned int> mask((size_t)std::max(1, P.n_slices) * 8);
-  FB_TRY(d_mask.download(mask.data(), mask.size(), s));
   const bool poll_all = getenv("FEMBRAIN_PERSIST_POLL_ALL") && atoi(getenv("FEMBRAIN_PERSIST_POLL_ALL")) != 0;  // development aid
+  FB_TRY(h->pipe_owner.alloc((size_t)std::max(1, P.n_slices)));
+  FB_TRY(h->pipe_mask.alloc((size_t)std::max(1, P.n_slices) * 8));
+  FB_TRY(h->pipe_prod.alloc((size_t)nb * kPipeMaxProducers));
+  FB_TRY(h->pipe_prod_count.alloc((size_t)nb));
+  FB_TRY(h->pipe_prod_xcd.alloc((size_t)nb));
+  FB_TRY(h->pipe_stats.alloc(2));
+  FB_TRY(h->pipe_stats.zero(s));
+  hipLaunchKernelGGL(k_slice_owner, dim3(ceil_div(nb, kBlock)), dim3(kBlock), 0, s, P.n_slices, nb, h->pipe_owner.p);
+  hipLaunchKernelGGL(k_slice_producers, dim3(ceil_div(std::max(1, P.n_slices), kWavesPerBlock)), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->slice_off.p, h->colidx.p,
+                     h->pipe_owner.p, h->pipe_mask.p);
+  hipLaunchKernelGGL(k_wg_producers, dim3(ceil_div(nb, kBlock)), dim3(kBlock), 0, s, P.n_slices, nb, h->pipe_mask.p, poll_all ? 1 : 0, h->pipe_prod.p, h->pipe_prod_count.p,
+                     h->pipe_prod_xcd.p, h->pipe_stats.p);
+  FB_HIP(hipGetLastError());
+  h->pipe_stats_pending = true;  // (the longest list is fetched when fb_fem_pcg_path asks)
   h->pipe_max_producers = 0;
-  for (int b = 0; b < nb; b++) {
-    int first, count;
-    pipe_slices(P.n_slices, nb, b, &first, &count);
-    unsigned int m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    for (int k = 0; k < count; k++)
-      for (int i = 0; i < 8; i++) m[i] |= mask[(size_t)(first + k) * 8 + i];
-    m[b >> 5] &= ~(1u << (b & 31));
-    int n = 0;
-    for (int i = 0; i < 8; i++) n += __builtin_popcount(m[i]);
-    if (n > kPipeMaxProducers || poll_all) { cnt[b] = -1; far[b] = 1; h->pipe_max_producers = -1; continue; }
-    cnt[b] = n;
-    if (h->pipe_max_producers >= 0) h->pipe_max_producers = std::max(h->pipe_max_producers, n);
-    for (int o = 0, k = 0; o < nb; o++)
-      if (m[o >> 5] >> (o & 31) & 1u) {
-        prod[(size_t)b * kPipeMaxProducers + k++] = o;
-        if ((o & 7) != (b & 7)) far[b] = 1;
-      }
-  }
-  FB_TRY(h->pipe_prod.upload(prod, s));
-  FB_TRY(h->pipe_prod_count.upload(cnt, s));
-  FB_TRY(h->pipe_prod_xcd.upload(far, s));
   FB_TRY(h->pipe_xcc.alloc((size_t)nb));
   FB_TRY(h->pipe_xcc.zero(s));
   {
@@ -516,12 +543,13 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   if (!h->masks_ready) FB_TRY(upload_masks(h));
   if (!P.send_local.empty()) FB_TRY(h->send_local.upload(P.send_local, s));
   FB_TRY(h->sendbuf.alloc(std::max<size_t>(1, (size_t)12 * P.send_local.size())));
+  ZeroBatch zb(s);
   FB_TRY(h->vals.alloc((size_t)P.n_slots * 9 * 64 * mt_size(h)));
-  FB_TRY(h->vals.zero(s));
+  zb.add(h->vals);
   FB_TRY(h->dlo.alloc((size_t)P.n_slices * 9 * 64 * mt_size(h)));
-  FB_TRY(h->dlo.zero(s));
+  zb.add(h->dlo);
   FB_TRY(h->mblk.alloc((size_t)P.n_slots * 64));
-  FB_TRY(h->mblk.zero(s));
+  zb.add(h->mblk);
   {
     // Element-major assembly where the accumulators of the widest slice fit the LDS of a CU (5 KB per slot: up to 32 slots);
     // FEMBRAIN_ASM_KERNEL=rows keeps the slot-major kernel (same result bit for bit, tests/test_fem_gpu.py)
@@ -579,13 +607,14 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   DevBuf<double>* vecs[] = {&h->q, &h->qvel, &h->fext, &h->fint, &h->rhs, &h->x, &h->r, &h->d, &h->Ad, &h->invdiag, &h->tmp};
   for (auto* v : vecs) {
     FB_TRY(v->alloc(nv));
-    FB_TRY(v->zero(s));
+    zb.add(*v);
   }
   DevBuf<double>* nvecs[] = {&h->qacc, &h->q1, &h->qvel1, &h->qacc1};
   for (auto* v : nvecs) {
-    if (h->prm.integrator == FB_INTEGRATOR_NEWMARK) { FB_TRY(v->alloc(nv)); FB_TRY(v->zero(s)); }
+    if (h->prm.integrator == FB_INTEGRATOR_NEWMARK) { FB_TRY(v->alloc(nv)); zb.add(*v); }
     else v->release();
   }
+  FB_TRY(zb.flush());
   h->pcg_warm = false;
   const int chunk = ceil_div(P.n_slices, 8);
   const int per = std::max(1, std::min(kMaxPartials / 8, ceil_div(chunk, kWavesPerBlock)));
@@ -2759,6 +2788,12 @@ int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches,
   }
   if (persist_launches) *persist_launches = h->persist_launches;
   if (persist_fallbacks) *persist_fallbacks = h->persist_fallbacks;
+  if (max_producers && h->persist && h->pipe_stats_pending) {
+    int st[2] = {0, 0};
+    FB_TRY(h->pipe_stats.download(st, 2, h->stream));
+    h->pipe_max_producers = st[1] ? -1 : st[0];
+    h->pipe_stats_pending = false;
+  }
   if (max_producers) *max_producers = h->persist ? h->pipe_max_producers : 0;
   return h->last_pcg_path;
 }

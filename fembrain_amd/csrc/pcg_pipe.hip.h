@@ -121,6 +121,57 @@ __global__ __launch_bounds__(kBlock) void k_slice_producers(int n_slices, int n_
   }
 }
 
+// owner[slice] = the workgroup pipe_slices gives it to (a thread per workgroup)
+__global__ __launch_bounds__(kBlock) void k_slice_owner(int n_slices, int nb, int* __restrict__ owner) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= nb) return;
+  int first, count;
+  pipe_slices(n_slices, nb, b, &first, &count);
+  for (int k = 0; k < count; k++) owner[first + k] = b;
+}
+
+// The producer list of every workgroup from the masks of its slices (a thread per workgroup; round 4: on the device, the host loop
+// with its download and three uploads was 0.2 ms of every re-sync): prod[b][0..cnt[b]) ascending, cnt[b] = -1 (poll everyone) beyond
+// kPipeMaxProducers, far[b] = a producer sits on another XCD, stats[0] = longest list, stats[1] = some workgroup polls everyone.
+__global__ __launch_bounds__(kBlock) void k_wg_producers(int n_slices, int nb, const unsigned int* __restrict__ mask, int poll_all, int* __restrict__ prod,
+                                                         int* __restrict__ cnt, int* __restrict__ far, int* __restrict__ stats) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= nb) return;
+  int first, count;
+  pipe_slices(n_slices, nb, b, &first, &count);
+  unsigned int m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  for (int k = 0; k < count; k++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) m[i] |= mask[(size_t)(first + k) * 8 + i];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    if ((b >> 5) == i) m[i] &= ~(1u << (b & 31));
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) n += __popc(m[i]);
+  int* mine = prod + (size_t)b * kPipeMaxProducers;
+  if (n > kPipeMaxProducers || poll_all) {
+    for (int k = 0; k < kPipeMaxProducers; k++) mine[k] = -1;
+    cnt[b] = -1; far[b] = 1;
+    atomicOr(&stats[1], 1);
+    return;
+  }
+  int k = 0, f = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    unsigned int w = m[i];
+    while (w) {
+      const int o = 32 * i + __ffs((int)w) - 1;
+      w &= w - 1u;
+      mine[k++] = o;
+      if ((o & 7) != (b & 7)) f = 1;
+    }
+  }
+  for (; k < kPipeMaxProducers; k++) mine[k] = -1;
+  cnt[b] = n; far[b] = f;
+  atomicMax(&stats[0], n);
+}
+
 // One wavefront's share of the collection of all workgroups' posted sums of sequence number `sums`: lane `l0` of `stride` takes workgroups
 // l0, l0 + stride, ...; adds their two values to t0s / t1s in that order (the callers fix the order of the rest).  Bounded by the wall clock.
 __device__ __forceinline__ void pipe_collect_posts(const PipeArgs& pa, unsigned int sums, int nb, int lane, int stride, int l0, long long t0, long long t_limit, bool& failed,

@@ -240,24 +240,25 @@ __global__ __launch_bounds__(kB) void k_plan_contrib(int n_nodes, int n_slices, 
 // a row's blocks ascending), so the wavefront fetches it with coalesced loads, and the lanes -- each walking its own row's part -- read
 // LDS instead of 64 different cache lines per load (314 -> see DESIGN.md; 1.1M tets).  A slice whose run exceeds `cap` words (hub nodes)
 // reads global memory as k_plan_contrib does.
-__global__ __launch_bounds__(64) void k_plan_contrib_lds(int n_nodes, int n_slices, const int* __restrict__ bptr, const int* __restrict__ bcol,
-                                                         const unsigned int* __restrict__ ucnt, const unsigned int* __restrict__ cstart, const uint32_t* __restrict__ vals,
-                                                         const int* __restrict__ slice_off, const int* __restrict__ slot_coff, const int* __restrict__ slot_ccnt,
-                                                         uint32_t* __restrict__ contrib, int cap) {
+__global__ __launch_bounds__(kB) void k_plan_contrib_lds(int n_nodes, int n_slices, const int* __restrict__ bptr, const int* __restrict__ bcol,
+                                                          const unsigned int* __restrict__ ucnt, const unsigned int* __restrict__ cstart, const uint32_t* __restrict__ vals,
+                                                          const int* __restrict__ slice_off, const int* __restrict__ slot_coff, const int* __restrict__ slot_ccnt,
+                                                          uint32_t* __restrict__ contrib, int cap) {
+  // one workgroup of four wavefronts per slice: all fetch the run, then wavefront w fills the slots w, w + 4, ...
   extern __shared__ uint32_t seg[];
-  const int s = blockIdx.x, lane = threadIdx.x;
+  const int s = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (s >= n_slices) return;
   const int a = s * 64 + lane;
   const int so = slice_off[s], w = slice_off[s + 1] - so;
   const int first = a < n_nodes ? bptr[a] : 0, len = a < n_nodes ? bptr[a + 1] - first : 0;
   const int b0 = bptr[s * 64], b1 = bptr[min(s * 64 + 64, n_nodes)];
   const unsigned int seg_lo = b1 > b0 ? cstart[b0] : 0u, seg_hi = b1 > b0 ? cstart[b1 - 1] + ucnt[b1 - 1] : 0u;
-  const bool staged = seg_hi - seg_lo <= (unsigned int)cap;  // wave-uniform
+  const bool staged = seg_hi - seg_lo <= (unsigned int)cap;  // workgroup-uniform
   if (staged) {
-    for (unsigned int i = lane; i < seg_hi - seg_lo; i += 64) seg[i] = vals[seg_lo + i];
+    for (unsigned int i = threadIdx.x; i < seg_hi - seg_lo; i += kB) seg[i] = vals[seg_lo + i];
     __syncthreads();
   }
-  for (int k = 0; k < w; k++) {
+  for (int k = wv; k < w; k += kB / 64) {
     const int height = slot_ccnt[so + k];  // wave-uniform
     const int cnt = k < len ? (int)ucnt[first + k] - (bcol[first + k] == a ? 1 : 0) : 0;
     const unsigned int from = k < len ? cstart[first + k] : seg_lo;
@@ -700,9 +701,9 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
     hipLaunchKernelGGL(k_plan_contrib, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, cstart.p, vals_s.p, D.slice_off->p, D.slot_coff->p,
                        D.slot_ccnt->p, D.contrib->p);
   } else {
-    constexpr int kSegCap = 10240;  // words: 40 KB of LDS per wavefront, four wavefronts per CU
+    constexpr int kSegCap = 10240;  // words: 40 KB of LDS per workgroup, four workgroups per CU
     FB_HIP(hipFuncSetAttribute((const void*)k_plan_contrib_lds, hipFuncAttributeMaxDynamicSharedMemorySize, kSegCap * (int)sizeof(uint32_t)));
-    hipLaunchKernelGGL(k_plan_contrib_lds, dim3((unsigned)std::max(1, n_slices)), dim3(64), kSegCap * sizeof(uint32_t), s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, cstart.p,
+    hipLaunchKernelGGL(k_plan_contrib_lds, dim3((unsigned)std::max(1, n_slices)), dim3(kB), kSegCap * sizeof(uint32_t), s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, cstart.p,
                        vals_s.p, D.slice_off->p, D.slot_coff->p, D.slot_ccnt->p, D.contrib->p, kSegCap);
   }
   FB_HIP(hipGetLastError());
