@@ -261,6 +261,65 @@ def block_jacobi_leg(device, prec, steps=5):
             "us_per_cg_iteration": solve / max(sum(its), 1) * 1e6, "pcg_kernel": path["kernel"], "pcg_path_last_step": last_path}
 
 
+def cut_resync_leg(device, prec):
+    """VERDICT r3 item 7 / SURVEY 8f-3: the re-sync after a cut on the headline mesh, from a DESCRIPTION of the change (fb_fem_resync_delta:
+    the mesh stays on the device, the plan's sorted pair list is updated) against fb_fem_resync with the whole new mesh.  First a real
+    cut (meshgen.synthetic_cut: every element crossing a plane split in four on a new node; the mesh grows, so buffers grow with it), then
+    changes of constant size -- 1 % of the elements removed and appended again, mirrored -- that time the re-sync itself."""
+    from fembrain_amd import lib as fl
+    from fembrain_amd.fem import FemIntegrator
+    from fembrain_amd.meshgen import apply_delta, synthetic_cut
+    import torch
+    v, t, fixed = workload_mesh("cube56", device)
+    names = {fl.FB_RESYNC_FULL: "full", fl.FB_RESYNC_DELTA_MERGED: "pair list updated", fl.FB_RESYNC_DELTA_REBUILT: "full builder from the device copy of the mesh"}
+    g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device)
+    ref = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device)
+
+    def both(d, v2, t2):
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        g.resync_delta(d, fixed, track=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - ts) * 1e3
+        ts = time.perf_counter()
+        ref.resync(v2, t2, fixed)
+        torch.cuda.synchronize()
+        return dt, (time.perf_counter() - ts) * 1e3, names[g.resync_path()]
+    cv, ct = v, t
+    cuts = []
+    for k in range(2):
+        v2, t2, d = synthetic_cut(cv, ct, axis=1 + k, where=0.23 + 0.2 * k)
+        dt, dr, path = both(d, v2, t2)
+        cuts.append({"removed": int(len(d["removed"])), "changed": int(len(d["changed_ids"])), "added": int(len(d["added"])), "new_nodes": int(len(d["new_xyz"])),
+                     "tets_after": int(len(t2)), "delta_ms": dt, "delta_path": path, "full_resync_ms": dr})
+        cv, ct = v2, t2
+    small = []
+    for k in range(4):
+        x = cv[:, 1][ct]
+        c = cv[:, 1].min() + (0.31 + 0.07 * k) * (cv[:, 1].max() - cv[:, 1].min())
+        hit = np.nonzero((x.min(axis=1) < c) & (x.max(axis=1) > c))[0].astype(np.int32)
+        hit = hit[:: max(1, len(hit) // (len(ct) // 100))][: len(ct) // 100]
+        d = dict(removed=hit, changed_ids=np.zeros(0, np.int32), changed_nodes=np.zeros(0, np.int32), added=ct[hit][:, [1, 0, 2, 3]], new_xyz=np.zeros(0))
+        v2, t2 = apply_delta(cv, ct, d)
+        dt, dr, path = both(d, v2, t2)
+        small.append((dt, dr, path, int(len(hit))))
+        cv, ct = v2, t2
+    its = []
+    for h in (g, ref):
+        h.set_uniform_force(1, -10000.0)
+        its.append(int(h.do_timestep()))
+    out = {"workload": WORKLOADS["cube56"][1] + ", cut twice", "cuts": cuts,
+           "one_percent_change": {"elements_removed_and_appended": small[-1][3], "tets": int(len(ct)), "delta_ms": min(x[0] for x in small[1:]),
+                                  "delta_ms_all": [round(x[0], 3) for x in small], "delta_path": small[-1][2],
+                                  "full_resync_ms": min(x[1] for x in small[1:]), "full_resync_ms_all": [round(x[1], 3) for x in small]},
+           "first_step_cg_iterations_delta_vs_full": its,
+           "note": "host wall clock around the C call incl. the Python wrapper; the first cut of a handle in the caller's node order appends nodes, which "
+                   "makes the full builder choose a new node order (from the device copy of the mesh); later changes update the pair list"}
+    g.close()
+    ref.close()
+    return out
+
+
 def field_bench(device, cpu=True):
     """256^3 sweep + classify + tetrahedralize of sphere.blob (BASELINE config 3); returns extra JSON keys."""
     from fembrain_amd.poly import GpuPoly, sphere_blob
@@ -847,6 +906,9 @@ def main():
             leg, why = stage("leg: scrambled node order", lambda: numbering_leg(device, prec), optional=True)
             if out is not None:
                 out["cube56_scrambled"] = leg if leg else {"error": why}
+            leg, why = stage("leg: re-sync after a cut", lambda: cut_resync_leg(device, prec), optional=True)
+            if out is not None:
+                out["cut_resync"] = leg if leg else {"error": why}
             leg, why = stage("leg: opt-in block-Jacobi", lambda: block_jacobi_leg(device, prec), optional=True)
             if out is not None:
                 out["cube56_block_jacobi_opt_in"] = leg if leg else {"error": why}

@@ -32,9 +32,8 @@ struct MeshDelta {
   DevBuf<int> pos;                  // per old element: its new id (elements before it that stay)
   DevBuf<unsigned long long> nk, nks;  // keys of the new pairs, unsorted / sorted
   DevBuf<uint32_t> nv, nvs;
-  DevBuf<int> tile_i;               // delta_sorted_pairs: per tile of the old list -- entries that stay, their prefix sums, bounds in the new entries
-  DevBuf<unsigned long long> tile_k;  // ... its first and last staying entry
-  DevBuf<uint32_t> tile_v;
+  DevBuf<int> tile_i;               // delta_sorted_pairs: per tile of the old list -- entries that go, prefix sums of those that stay, bounds in the new entries
+  DevBuf<unsigned int> drop_bits;   // ... a bit per entry of the old list: it goes
   bool mapped = false;              // delta_node_order ran for this change: imap / newint / node_keys are its
   DevBuf<int> imap, newint;         // renumbered handles: old internal id -> new internal id; new node k -> its internal id
   DevBuf<unsigned long long> node_keys;  // merged slab keys (internal order)
@@ -54,8 +53,9 @@ int delta_node_order(hipStream_t s, MeshDelta& D, int n_old, const SlabKeyGeom& 
                      DevBuf<int>& old_of_new, DevBuf<int>& new_of_old, PlanWorkspace& W);
 // rest positions in the new internal order
 int delta_positions(hipStream_t s, const MeshDelta& D, int n_old, const double* x0_old, double* x0_new);
-// The sorted pair list of the workspace, updated (see the header comment).  tets_new: the new element list in the new internal ids;
+// The sorted pair list of the workspace, updated (see the header comment).  tets_old: the old element list in the old internal ids (the
+// entries of removed and changed elements are found by their keys); tets_new: the new element list in the new internal ids;
 // span: its widest element (decides the key width).  On return W.sorted describes the new list in W.keys_s / W.vals_s.
-int delta_sorted_pairs(hipStream_t s, MeshDelta& D, const int4* tets_new, int n_nodes_new, int span, PlanWorkspace& W);
+int delta_sorted_pairs(hipStream_t s, MeshDelta& D, const int4* tets_old, const int4* tets_new, int n_nodes_new, int span, PlanWorkspace& W);
 
 }  // namespace fb

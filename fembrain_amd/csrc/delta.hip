@@ -26,6 +26,9 @@ __global__ __launch_bounds__(kB) void k_delta_mark(int n_removed, const int* __r
   else if (i < n_removed + n_changed) estate[changed[i - n_removed]] = 2;
 }
 
+struct TileKept {
+  __device__ int operator()(int gone) const { return 2048 - gone; }  // (kTile)
+};
 struct Stays {
   __device__ int operator()(unsigned char st) const { return st != 1 ? 1 : 0; }
 };
@@ -186,60 +189,21 @@ __global__ __launch_bounds__(kB) void k_delta_new_pairs(int n_changed, int n_add
 }
 
 // ---- the update of the list in two passes of our own (the library's select over a transforming zip iterator took 490 us at 1M tets,
-// its merge another 110): tiles of kTile old entries; pass 1 counts the entries of every tile that stay and notes its first and last
-// one; pass 2 ranks them (tile base + rank inside the tile) and puts the new entries that fall between two of them in their places.
-// New entries below the first or above the last old entry are copied by k_upd_ends.
+// its merge another 110): tiles of kTile old entries; pass 1 marks the entries that go and counts them per tile; pass 2 ranks the others
+// (tile base + rank inside the tile) and puts the new entries that fall between two of them in their places.  New entries below the
+// first or above the last old entry are copied by k_upd_ends.
 constexpr int kTile = 2048, kTileItems = kTile / kB;
 template <typename K>
 __device__ __forceinline__ bool pair_less(K ka, uint32_t va, K kb, uint32_t vb) { return ka < kb || (ka == kb && va < vb); }
 
 template <typename KIn, typename KOut>
-__device__ __forceinline__ bool xform_entry(const PackDesc& in, const PackDesc& out, const int* __restrict__ imap, const unsigned char* __restrict__ estate,
-                                            const int* __restrict__ pos, KIn k, uint32_t v, KOut* ko, uint32_t* vo) {
+__device__ __forceinline__ void xform_entry(const PackDesc& in, const PackDesc& out, const int* __restrict__ imap, const int* __restrict__ pos, KIn k, uint32_t v, KOut* ko,
+                                            uint32_t* vo) {
   int row, col;
   unpack_key(in, (unsigned long long)k, row, col);
   if (imap) { row = imap[row]; col = imap[col]; }
   *ko = (KOut)pack_key(out, row, col);
-  *vo = v;
-  if (v == kNoContrib) return true;
-  const uint32_t e = v >> 4;
-  if (estate[e]) return false;
-  *vo = ((uint32_t)pos[e] << 4) | (v & 15u);
-  return true;
-}
-
-template <typename KIn, typename KOut>
-__global__ __launch_bounds__(kB) void k_upd_count(long long n_a, const KIn* __restrict__ ka, const uint32_t* __restrict__ va, PackDesc in, PackDesc out,
-                                                  const int* __restrict__ imap, const unsigned char* __restrict__ estate, const int* __restrict__ pos,
-                                                  int* __restrict__ tile_kept, KOut* __restrict__ first_k, uint32_t* __restrict__ first_v, KOut* __restrict__ last_k,
-                                                  uint32_t* __restrict__ last_v) {
-  __shared__ int s_cnt, s_min, s_max;
-  if (threadIdx.x == 0) { s_cnt = 0; s_min = kTile; s_max = -1; }
-  __syncthreads();
-  const long long base = (long long)blockIdx.x * kTile;
-  int cnt = 0, mn = kTile, mx = -1;
-#pragma unroll
-  for (int i = 0; i < kTileItems; i++) {
-    const int q = i * kB + threadIdx.x;
-    const long long idx = base + q;
-    if (idx < n_a) {
-      const uint32_t v = va[idx];
-      const bool keep = v == kNoContrib || estate[v >> 4] == 0;
-      if (keep) { cnt++; mn = min(mn, q); mx = max(mx, q); }
-    }
-  }
-  if (cnt) { atomicAdd(&s_cnt, cnt); atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    tile_kept[blockIdx.x] = s_cnt;
-    if (s_cnt) {
-      KOut k; uint32_t v;
-      xform_entry<KIn, KOut>(in, out, imap, estate, pos, ka[base + s_min], va[base + s_min], &k, &v);
-      first_k[blockIdx.x] = k; first_v[blockIdx.x] = v;
-      xform_entry<KIn, KOut>(in, out, imap, estate, pos, ka[base + s_max], va[base + s_max], &k, &v);
-      last_k[blockIdx.x] = k; last_v[blockIdx.x] = v;
-    }
-  }
+  *vo = v == kNoContrib ? v : (((uint32_t)pos[v >> 4] << 4) | (v & 15u));
 }
 
 template <typename K>
@@ -251,31 +215,69 @@ __device__ __forceinline__ int lower_bound_pairs(const K* __restrict__ k, const 
   return lo;
 }
 
+// Pass 1: the entries that go are FOUND rather than looked for -- the 16 entries of every removed or changed element sit at (row, column,
+// element << 4 | ij) of the old list: a binary search each, a bit in `drop`, a count per tile (a pass over the whole list that asked every
+// entry whether its element stays took 87 us at 1.1M tets; this one 290,000 searches).  tets_old: the old element list in the old ids.
+template <typename KIn>
+__global__ __launch_bounds__(kB) void k_upd_dropped(int n_removed, const int* __restrict__ removed, int n_changed, const int* __restrict__ changed, const int4* __restrict__ tets_old,
+                                                    PackDesc in, int n_a, const KIn* __restrict__ ka, const uint32_t* __restrict__ va, unsigned int* __restrict__ drop) {
+  const long long i = (long long)blockIdx.x * kB + threadIdx.x;
+  if (i >= 16LL * (n_removed + n_changed)) return;
+  const int m = (int)(i >> 4), ij = (int)(i & 15);
+  const int e = m < n_removed ? removed[m] : changed[m - n_removed];
+  const int4 t = tets_old[e];
+  const int id[4] = {t.x, t.y, t.z, t.w};
+  const KIn key = (KIn)pack_key(in, id[ij >> 2], id[ij & 3]);
+  const uint32_t val = ((uint32_t)e << 4) | (uint32_t)ij;
+  const int at = lower_bound_pairs<KIn>(ka, va, 0, n_a, key, val);  // (it is there)
+  atomicOr(&drop[at >> 5], 1u << (at & 31));
+}
+// ... and the count per tile from the bits (a counter per tile bumped by every entry: 121 us of same-address atomics)
+__global__ __launch_bounds__(kB) void k_upd_tile_counts(int n_tiles, const unsigned int* __restrict__ drop, int* __restrict__ tile_drop) {
+  const int b = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= n_tiles) return;
+  int c = __popc(drop[(size_t)b * (kTile / 32) + lane]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if (lane == 0 && c) atomicAdd(&tile_drop[b], c);  // (on top of the last tile's share beyond the list)
+}
+
 // per tile: the number of new entries below its first staying entry (-1: the tile keeps nothing); bounds[0] = that of the first such tile,
 // bounds[1] = the number of new entries below the LAST staying entry of the whole list
-template <typename KOut>
-__global__ __launch_bounds__(kB) void k_upd_bounds(int n_tiles, long long n_stay, const int* __restrict__ tile_kept, const int* __restrict__ tile_base,
-                                                   const KOut* __restrict__ first_k, const uint32_t* __restrict__ first_v, const KOut* __restrict__ last_k,
-                                                   const uint32_t* __restrict__ last_v, int n_b, const KOut* __restrict__ kb, const uint32_t* __restrict__ vb, int* __restrict__ lo,
+template <typename KIn, typename KOut>
+__global__ __launch_bounds__(kB) void k_upd_bounds(int n_tiles, long long n_stay, int n_a, const KIn* __restrict__ ka, const uint32_t* __restrict__ va, PackDesc in, PackDesc out,
+                                                   const int* __restrict__ imap, const int* __restrict__ pos, const unsigned int* __restrict__ drop, const int* __restrict__ tile_drop,
+                                                   const int* __restrict__ tile_base, int n_b, const KOut* __restrict__ kb, const uint32_t* __restrict__ vb, int* __restrict__ lo,
                                                    int* __restrict__ bounds) {
   const int b = blockIdx.x * kB + threadIdx.x;
   if (b >= n_tiles) return;
-  if (tile_kept[b] == 0) { lo[b] = -1; return; }
-  const int l = lower_bound_pairs<KOut>(kb, vb, 0, n_b, first_k[b], first_v[b]);
+  const int kept = kTile - tile_drop[b];
+  if (kept == 0) { lo[b] = -1; return; }
+  int f = b * kTile;
+  while (drop[f >> 5] >> (f & 31) & 1u) f++;  // (a staying entry exists)
+  KOut k; uint32_t v;
+  xform_entry<KIn, KOut>(in, out, imap, pos, ka[f], va[f], &k, &v);
+  const int l = lower_bound_pairs<KOut>(kb, vb, 0, n_b, k, v);
   lo[b] = l;
   if (tile_base[b] == 0) bounds[0] = l;
-  if ((long long)tile_base[b] + tile_kept[b] == n_stay) bounds[1] = lower_bound_pairs<KOut>(kb, vb, 0, n_b, last_k[b], last_v[b]);
+  if ((long long)tile_base[b] + kept == n_stay) {
+    int g = min(n_a, (b + 1) * kTile) - 1;
+    while (drop[g >> 5] >> (g & 31) & 1u) g--;
+    xform_entry<KIn, KOut>(in, out, imap, pos, ka[g], va[g], &k, &v);
+    bounds[1] = lower_bound_pairs<KOut>(kb, vb, 0, n_b, k, v);
+  }
 }
 
+// Pass 2: ranks the staying entries (tile base + rank inside the tile) and puts the new entries that fall between two of them in their places
 template <typename KIn, typename KOut>
 __global__ __launch_bounds__(kB) void k_upd_merge(long long n_a, const KIn* __restrict__ ka, const uint32_t* __restrict__ va, PackDesc in, PackDesc out,
-                                                  const int* __restrict__ imap, const unsigned char* __restrict__ estate, const int* __restrict__ pos, int n_tiles,
-                                                  const int* __restrict__ tile_kept, const int* __restrict__ tile_base, const int* __restrict__ lo_of, const int* __restrict__ bounds,
+                                                  const int* __restrict__ imap, const int* __restrict__ pos, const unsigned int* __restrict__ drop, int n_tiles,
+                                                  const int* __restrict__ tile_drop, const int* __restrict__ tile_base, const int* __restrict__ lo_of, const int* __restrict__ bounds,
                                                   int n_b, const KOut* __restrict__ kb, const uint32_t* __restrict__ vb, KOut* __restrict__ kc, uint32_t* __restrict__ vc) {
   __shared__ KOut ck[kTile];
   __shared__ uint32_t cv[kTile];
   __shared__ int s_wave[kB / 64], s_run, s_lo, s_hi;
-  const int kept = tile_kept[blockIdx.x];
+  const int kept = kTile - tile_drop[blockIdx.x];
   if (kept == 0) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (threadIdx.x == 0) {
@@ -292,8 +294,8 @@ __global__ __launch_bounds__(kB) void k_upd_merge(long long n_a, const KIn* __re
   for (int i = 0; i < kTileItems; i++) {
     const long long idx = base + i * kB + threadIdx.x;
     KOut k = 0; uint32_t v = 0;
-    bool keep = false;
-    if (idx < n_a) keep = xform_entry<KIn, KOut>(in, out, imap, estate, pos, ka[idx], va[idx], &k, &v);
+    const bool keep = idx < n_a && !(drop[idx >> 5] >> (idx & 31) & 1u);
+    if (keep) xform_entry<KIn, KOut>(in, out, imap, pos, ka[idx], va[idx], &k, &v);
     const unsigned long long m = __ballot(keep);
     const int before = __popcll(m & ((1ULL << lane) - 1ULL));
     if (lane == 0) s_wave[wv] = __popcll(m);
@@ -338,7 +340,7 @@ int bits_of(long long n) {
 }
 
 template <typename KIn, typename KOut>
-int update_pairs(hipStream_t s, MeshDelta& D, const int4* tets_new, int n_nodes_old, const PackDesc& pin, const PackDesc& pout, unsigned key_bits, long long n_old_pairs,
+int update_pairs(hipStream_t s, MeshDelta& D, const int4* tets_old, const int4* tets_new, int n_nodes_old, const PackDesc& pin, const PackDesc& pout, unsigned key_bits, long long n_old_pairs,
                  long long n_new_pairs, PlanWorkspace& W) {
   const long long n_stay = n_old_pairs - 16LL * (D.n_removed + D.n_changed);
   const long long n_fresh = 16LL * (D.n_changed + D.n_added) + D.n_new_nodes;
@@ -367,33 +369,37 @@ int update_pairs(hipStream_t s, MeshDelta& D, const int4* tets_new, int n_nodes_
     FB_TRY(W.keys.reserve((size_t)n_new_pairs));
     FB_TRY(W.vals.reserve((size_t)n_new_pairs));
     FB_TRY(D.tile_i.reserve((size_t)3 * (n_tiles + 1) + 2));
-    FB_TRY(D.tile_k.reserve((size_t)2 * n_tiles));
-    FB_TRY(D.tile_v.reserve((size_t)2 * n_tiles));
-    int* tile_kept = D.tile_i.p;
-    int* tile_base = tile_kept + (n_tiles + 1);
+    FB_TRY(D.drop_bits.reserve((size_t)n_tiles * (kTile / 32)));
+    int* tile_drop = D.tile_i.p;
+    int* tile_base = tile_drop + (n_tiles + 1);
     int* tile_lo = tile_base + (n_tiles + 1);
     int* bounds = tile_lo + (n_tiles + 1);
-    KOut* first_k = reinterpret_cast<KOut*>(D.tile_k.p);
-    KOut* last_k = first_k + n_tiles;
-    uint32_t* first_v = D.tile_v.p;
-    uint32_t* last_v = first_v + n_tiles;
     const KIn* ka = reinterpret_cast<const KIn*>(W.keys_s.p);
     KOut* kc = reinterpret_cast<KOut*>(W.keys.p);
-    FB_HIP(hipMemsetAsync(tile_kept + n_tiles, 0, sizeof(int), s));
-    hipLaunchKernelGGL((k_upd_count<KIn, KOut>), dim3(n_tiles), dim3(kB), 0, s, n_old_pairs, ka, W.vals_s.p, pin, pout, imap, D.estate.p, D.pos.p, tile_kept, first_k, first_v,
-                       last_k, last_v);
-    FB_HIP(hipGetLastError());
+    FB_HIP(hipMemsetAsync(D.drop_bits.p, 0, sizeof(unsigned int) * (size_t)n_tiles * (kTile / 32), s));
+    FB_HIP(hipMemsetAsync(tile_drop, 0, sizeof(int) * (size_t)(n_tiles + 1), s));
+    // (the part of the last tile beyond the list, and the scan's closing element, count as gone)
+    const int tail[2] = {(int)((long long)n_tiles * kTile - n_old_pairs), kTile};
+    FB_HIP(hipMemcpyAsync(tile_drop + (n_tiles - 1), tail, sizeof tail, hipMemcpyHostToDevice, s));
+    const int4* tets_old_p = tets_old;
+    if (D.n_removed + D.n_changed > 0) {
+      hipLaunchKernelGGL(k_upd_dropped<KIn>, grid_for(16LL * (D.n_removed + D.n_changed)), dim3(kB), 0, s, D.n_removed, D.removed, D.n_changed, D.changed_ids, tets_old_p, pin,
+                         (int)n_old_pairs, ka, W.vals_s.p, D.drop_bits.p);
+      hipLaunchKernelGGL(k_upd_tile_counts, dim3((unsigned)((n_tiles + kB / 64 - 1) / (kB / 64))), dim3(kB), 0, s, n_tiles, D.drop_bits.p, tile_drop);
+      FB_HIP(hipGetLastError());
+    }
+    const auto tile_kept = rocprim::make_transform_iterator(static_cast<const int*>(tile_drop), TileKept());
     size_t bytes = 0;
     FB_HIP(rocprim::exclusive_scan(nullptr, bytes, tile_kept, tile_base, 0, (size_t)n_tiles + 1, rocprim::plus<int>(), s));
     FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
     FB_HIP(rocprim::exclusive_scan(W.temp.p, bytes, tile_kept, tile_base, 0, (size_t)n_tiles + 1, rocprim::plus<int>(), s));
     const int init_bounds[2] = {0, 0};
     FB_HIP(hipMemcpyAsync(bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_upd_bounds<KOut>, grid_for(n_tiles), dim3(kB), 0, s, n_tiles, n_stay, tile_kept, tile_base, first_k, first_v, last_k, last_v, (int)n_fresh, nks, D.nvs.p,
-                       tile_lo, bounds);
+    hipLaunchKernelGGL((k_upd_bounds<KIn, KOut>), grid_for(n_tiles), dim3(kB), 0, s, n_tiles, n_stay, (int)n_old_pairs, ka, W.vals_s.p, pin, pout, imap, D.pos.p, D.drop_bits.p,
+                       tile_drop, tile_base, (int)n_fresh, nks, D.nvs.p, tile_lo, bounds);
     FB_HIP(hipGetLastError());
-    hipLaunchKernelGGL((k_upd_merge<KIn, KOut>), dim3(n_tiles), dim3(kB), 0, s, n_old_pairs, ka, W.vals_s.p, pin, pout, imap, D.estate.p, D.pos.p, n_tiles, tile_kept, tile_base,
-                       tile_lo, bounds, (int)n_fresh, nks, D.nvs.p, kc, W.vals.p);
+    hipLaunchKernelGGL((k_upd_merge<KIn, KOut>), dim3(n_tiles), dim3(kB), 0, s, n_old_pairs, ka, W.vals_s.p, pin, pout, imap, D.pos.p, D.drop_bits.p, n_tiles, tile_drop,
+                       tile_base, tile_lo, bounds, (int)n_fresh, nks, D.nvs.p, kc, W.vals.p);
     FB_HIP(hipGetLastError());
     if (n_fresh > 0) {
       hipLaunchKernelGGL(k_upd_ends<KOut>, grid_for(n_fresh), dim3(kB), 0, s, n_stay, bounds, (int)n_fresh, nks, D.nvs.p, kc, W.vals.p);
@@ -521,7 +527,7 @@ int delta_positions(hipStream_t s, const MeshDelta& D, int n_old, const double* 
   return FB_OK;
 }
 
-int delta_sorted_pairs(hipStream_t s, MeshDelta& D, const int4* tets_new, int n_nodes_new, int span, PlanWorkspace& W) {
+int delta_sorted_pairs(hipStream_t s, MeshDelta& D, const int4* tets_old, const int4* tets_new, int n_nodes_new, int span, PlanWorkspace& W) {
   SortedPairs& S = W.sorted;
   if (!S.valid) return fail(FB_EINVAL, "internal: no sorted pair list to update");
   const int n_nodes_old = S.n_nodes;
@@ -538,10 +544,10 @@ int delta_sorted_pairs(hipStream_t s, MeshDelta& D, const int4* tets_new, int n_
   const unsigned key_bits = narrow ? (unsigned)(rb32 + cb32) : (unsigned)(row_bits + col_bits);
   S.valid = false;  // (until the new list is complete)
   int rc;
-  if (S.narrow && narrow) rc = update_pairs<unsigned int, unsigned int>(s, D, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
-  else if (S.narrow) rc = update_pairs<unsigned int, unsigned long long>(s, D, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
-  else if (narrow) rc = update_pairs<unsigned long long, unsigned int>(s, D, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
-  else rc = update_pairs<unsigned long long, unsigned long long>(s, D, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
+  if (S.narrow && narrow) rc = update_pairs<unsigned int, unsigned int>(s, D, tets_old, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
+  else if (S.narrow) rc = update_pairs<unsigned int, unsigned long long>(s, D, tets_old, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
+  else if (narrow) rc = update_pairs<unsigned long long, unsigned int>(s, D, tets_old, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
+  else rc = update_pairs<unsigned long long, unsigned long long>(s, D, tets_old, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
   FB_TRY(rc);
   S.narrow = narrow; S.cb = cb32; S.span = span; S.col_bits = col_bits;
   S.n_pairs = n_new_pairs; S.n_nodes = n_nodes_new; S.n_tets = D.n_tets_new();

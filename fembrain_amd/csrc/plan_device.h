@@ -84,7 +84,7 @@ int device_partition(hipStream_t s, int n_tets, DevBuf<int4>& tets, int n_global
                      DevicePartition& out, PlanWorkspace& ws);
 
 // d_tets: n_tets x int4 node ids (local ids for a shard); their range is checked here (first_bad_tet).  shard = nullptr: the
-// unsharded system (every node a row).  Synchronises the stream before it returns.
+// unsharded system (every node a row).  The last kernel may still be running when it returns (stream order).
 // span >= 0: the widest element of the list (largest id difference inside a tet, renumber.h) when the caller has measured it -- lets the sort use 32-bit keys
 int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& out, PlanWorkspace& ws, const PlanShard* shard = nullptr, int span = -1);
 

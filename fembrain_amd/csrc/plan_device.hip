@@ -681,17 +681,16 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
   hipLaunchKernelGGL(k_plan_sell, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, D.slice_off->p, D.colidx->p, D.blk_slot->p,
                      D.slot_ccnt->p, D.coldelta->p, wide.p, (shard && D.halo_base) ? D.halo_base->p : nullptr);
   FB_HIP(hipGetLastError());
-  int w = 0;
-  FB_HIP(hipMemcpyAsync(&w, wide.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  FB_HIP(hipStreamSynchronize(s));
-  D.deltas_fit16 = w == 0;
   lap("SELL layout");
   bytes = 0;
   FB_HIP(rocprim::exclusive_scan(nullptr, bytes, D.slot_ccnt->p, D.slot_coff->p, 0, (size_t)D.n_slots + 1, rocprim::plus<int>(), s));
   FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
   FB_HIP(rocprim::exclusive_scan(temp.p, bytes, D.slot_ccnt->p, D.slot_coff->p, 0, (size_t)D.n_slots + 1, rocprim::plus<int>(), s));
-  int crows = 0;
-  FB_TRY(D.slot_coff->download(&crows, 1, s, (size_t)D.n_slots));
+  int crows = 0, w = 0;  // (one wait for both)
+  FB_HIP(hipMemcpyAsync(&w, wide.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  FB_HIP(hipMemcpyAsync(&crows, D.slot_coff->p + D.n_slots, sizeof(int), hipMemcpyDeviceToHost, s));
+  FB_HIP(hipStreamSynchronize(s));
+  D.deltas_fit16 = w == 0;
   if ((long long)crows * kSliceRows >= (1LL << 31)) return fail(FB_EINVAL, "contribution table too large (%d rows)", crows);
   D.n_crows = crows;
   lap("slot offsets");
@@ -707,7 +706,7 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
                        vals_s.p, D.slice_off->p, D.slot_coff->p, D.slot_ccnt->p, D.contrib->p, kSegCap);
   }
   FB_HIP(hipGetLastError());
-  FB_HIP(hipStreamSynchronize(s));  // the temporaries go out of scope
+  // (no wait here: the workspace and the plan's buffers outlive the kernel; the caller's next stages queue behind it)
   lap("contribution table");
   return FB_OK;
 }

@@ -101,17 +101,18 @@ def apply_delta(v, t, delta):
     return v2, t2
 
 
-def synthetic_cut(v, t, axis=1, where=0.5, every_changed=3):
+def synthetic_cut(v, t, axis=1, where=0.5, every_changed=3, stride=1):
     """A cut-shaped topology change for tests and probes (not the reference's subdivision tables): every element (a, b, c, d) whose
     nodes lie on both sides of the plane ``x[axis] = lo + where * (hi - lo)`` is split in four on a new node m at its centroid:
     (a, b, c, m), (m, b, c, d), (a, m, c, d), (a, b, m, d).  Every ``every_changed``-th of them is changed in place to the first and the
-    other three are appended; the others are removed and all four appended.  Returns (v2, t2, delta) with delta = dict(removed,
+    other three are appended; the others are removed and all four appended (stride: only every stride-th crossing element is cut).
+    Returns (v2, t2, delta) with delta = dict(removed,
     changed_ids, changed_nodes, added, new_xyz) -- ids in the old numbering, removed ascending."""
     v = np.asarray(v, dtype=np.float64)
     t = np.asarray(t, dtype=np.int32)
     x = v[:, axis][t]
     c = v[:, axis].min() + where * (v[:, axis].max() - v[:, axis].min())
-    hit = np.nonzero((x.min(axis=1) < c) & (x.max(axis=1) > c))[0]
+    hit = np.nonzero((x.min(axis=1) < c) & (x.max(axis=1) > c))[0][::max(1, stride)]
     m = (len(v) + np.arange(len(hit))).astype(np.int32)
     new_xyz = v[t[hit]].mean(axis=1)
     a, b, cc, d = (t[hit, k] for k in range(4))

@@ -128,6 +128,13 @@ class HipIntegrator {
     check(fb_fem_resync(h_, numVertices, rest, numElements, elements, nFixed, fixed));
     r_ = 3 * numVertices;
   }
+  // the same from a description of the change (fb_fem_resync_delta): the mesh stays on the device
+  void ResyncDelta(int nRemoved, const int* removed, int nChanged, const int* changedIds, const int* changedNodes, int nAdded, const int* added, int nNewVertices,
+                   const double* newRest, int nFixed, const int* fixed) {
+    mass_.clear(); bptr_.clear(); bcol_.clear();
+    check(fb_fem_resync_delta(h_, nRemoved, removed, nChanged, changedIds, changedNodes, nAdded, added, nNewVertices, newRest, nFixed, fixed));
+    r_ = 3 * fb_fem_num_nodes(h_);
+  }
   fb_fem_t handle() const { return h_; }
   static void check(int rc) {
     if (rc != FB_OK) throw std::runtime_error(std::string("fembrain_hip: ") + fb_last_error());
@@ -248,6 +255,35 @@ class Deformable {
     if (m_lpIntegrator) m_lpIntegrator->Resync(n, m_rest.data(), m, m_elements.data(), (int)m_vFixedDofs.size(), m_vFixedDofs.data());
     else m_lpIntegrator = new HipIntegrator(n, m_rest.data(), m, m_elements.data(), (int)m_vFixedDofs.size(), m_vFixedDofs.data(),
                                             m_timeStep, m_dampingMassCoeff, m_dampingStiffnessCoeff, 1e7, 0.46, 1000.0, m_device);
+    m_q.assign(m_dof, 0.0); m_qVel.assign(m_dof, 0.0); m_arrExtForces.assign(m_dof, 0.0);
+    m_bptr.clear(); m_bcol.clear();
+    m_restVolume = -1.0;
+    return true;
+  }
+  // The same after a cut that the host can describe (CuttableMesh::cut erases the cut cells -- VolMesh.cpp:630 -- appends their pieces
+  // and the new nodes -- :1083-1088 -- and re-points cells in place -- :1630-1650): `removed` ascending ids of the current element list,
+  // `changedIds` ascending with their new nodes, `added` and `newRest` appended.  The host copy of the mesh follows.
+  bool syncForceModelDelta(const std::vector<int>& removed, const std::vector<int>& changedIds, const std::vector<int>& changedNodes, const std::vector<int>& added,
+                           const std::vector<double>& newRest) {
+    if (!m_lpIntegrator) return syncForceModel();
+    for (size_t k = 0; k < changedIds.size(); k++)
+      for (int c = 0; c < 4; c++) m_elements[4 * (size_t)changedIds[k] + c] = changedNodes[4 * k + c];
+    if (!removed.empty()) {
+      std::vector<int> kept;
+      kept.reserve(m_elements.size());
+      size_t r = 0;
+      for (size_t e = 0; e < m_elements.size() / 4; e++) {
+        if (r < removed.size() && (size_t)removed[r] == e) { r++; continue; }
+        kept.insert(kept.end(), m_elements.begin() + 4 * e, m_elements.begin() + 4 * e + 4);
+      }
+      m_elements.swap(kept);
+    }
+    m_elements.insert(m_elements.end(), added.begin(), added.end());
+    m_rest.insert(m_rest.end(), newRest.begin(), newRest.end());
+    m_dof = (U32)m_rest.size();
+    FixedVerticesToFixedDOF(m_vFixedVertices, m_vFixedDofs);
+    m_lpIntegrator->ResyncDelta((int)removed.size(), removed.data(), (int)changedIds.size(), changedIds.data(), changedNodes.data(), (int)(added.size() / 4), added.data(),
+                                (int)(newRest.size() / 3), newRest.data(), (int)m_vFixedDofs.size(), m_vFixedDofs.data());
     m_q.assign(m_dof, 0.0); m_qVel.assign(m_dof, 0.0); m_arrExtForces.assign(m_dof, 0.0);
     m_bptr.clear(); m_bcol.clear();
     m_restVolume = -1.0;

@@ -149,6 +149,29 @@ int main() {
       }
     std::printf("SLAB_VERTS=%zu\nSLAB_TETS=%zu\nSLAB_SAME=%d\n", verts, tets, same ? 1 : 0);
   }
+  {  // Deformable::syncForceModelDelta: the cube with its first two elements cut out, split on a new centre node, one changed in place --
+     // against a Deformable made from the resulting mesh: same first step
+    std::vector<double> mid(3, 0.0);
+    for (int c = 0; c < 4; c++) for (int k = 0; k < 3; k++) mid[k] += 0.25 * v[3 * (size_t)t[c] + k];
+    const int m = n * n * n;
+    std::vector<int> removed = {0}, changedIds = {1}, changedNodes = {t[4], t[6], t[5], t[7]};
+    std::vector<int> added = {t[0], t[1], t[2], m, m, t[1], t[2], t[3], t[0], m, t[2], t[3], t[0], t[1], m, t[3]};
+    PS::FEM::Deformable dd(n * n * n, v.data(), (int)t.size() / 4, t.data(), fixed);
+    dd.timestep();
+    dd.syncForceModelDelta(removed, changedIds, changedNodes, added, mid);
+    std::vector<double> v2 = v;
+    v2.insert(v2.end(), mid.begin(), mid.end());
+    std::vector<int> t2(t.begin() + 4, t.end());
+    for (int c = 0; c < 4; c++) t2[c] = changedNodes[c];
+    t2.insert(t2.end(), added.begin(), added.end());
+    PS::FEM::Deformable fresh(m + 1, v2.data(), (int)t2.size() / 4, t2.data(), fixed);
+    dd.timestep();
+    fresh.timestep();
+    const std::vector<double> a = dd.currentPositions(), b = fresh.currentPositions();
+    bool same = a.size() == b.size() && dd.countCells() == fresh.countCells();
+    for (size_t i = 0; same && i < a.size(); i++) same = a[i] == b[i];
+    std::printf("DELTA_PATH=%d\nDELTA_NODES=%u\nDELTA_CELLS=%u\nDELTA_SAME=%d\n", fb_fem_resync_path(dd.integrator()->handle()), dd.countNodes(), dd.countCells(), same ? 1 : 0);
+  }
   // the cutting tool on the ball's current (deformed) mesh: a vertical needle through it, then a blade swept along x
   PS::FEM::Cutting cut(&ball);
   float known[4];

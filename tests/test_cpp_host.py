@@ -78,6 +78,8 @@ def test_cpp_host_program_matches_oracle(gpu):
     assert kv["STAT"] == "%d,%d,TET,JACOBI PRECONDITIONED CG" % (len(t), len(v)) and abs(float(kv["STAT_VOL"]) - 0.4 ** 3) < 1e-12
     assert kv["COLLIDE_NOFLOOR"] == "0"
     assert int(kv["DIRECT_R"]) == 3 * len(ox) and kv["DIRECT_SAME"] == "1"
+    # Deformable::syncForceModelDelta (fb_fem_resync_delta): list updated, and the step of a Deformable made from the resulting mesh
+    assert kv["DELTA_PATH"] == "1" and int(kv["DELTA_NODES"]) == 126 and int(kv["DELTA_CELLS"]) == 384 + 3 and kv["DELTA_SAME"] == "1"
     assert int(kv["SLAB_VERTS"]) == len(ox) and int(kv["SLAB_TETS"]) == len(ot) and kv["SLAB_SAME"] == "1"
     # PS::FEM::Cutting on the ball: the reference's known answer, hit list = count, the swept quad closes at the third call
     assert kv["CUT_KNOWN"] == "0,0,0,1"

@@ -146,7 +146,8 @@ def test_delta_resync_on_a_handle_with_its_own_node_order(gpu):
     on, sc, si = g.renumbering()
     assert on and ref.renumbering() == (on, sc, si) and si < 2000 < sc
     _same_bits(g, ref, load=-200.0)
-    v3, t3, d2 = synthetic_cut(v2, t2, axis=0, where=0.6, every_changed=2)
+    v3, t3, d2 = synthetic_cut(v2, t2, axis=0, where=0.6, every_changed=2, stride=5)
+    assert 0 < len(d2["new_xyz"]) < len(v2) // 10
     g.resync_delta(d2, fixed)
     assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED
     ref.resync(v3, t3, fixed)
@@ -170,8 +171,15 @@ def test_delta_resync_on_a_handle_with_its_own_node_order(gpu):
         assert abs(its[0] - its[1]) <= 2
         qa, qr = g.get_q_state()[0], ref.get_q_state()[0]
         assert np.abs(qa - qr).max() <= 2e-5 * np.abs(qr).max() and not qa[fixed].any()
+    # once a tenth more nodes have come than the order was built for, a change gets a fresh order: the full builder, bit for bit
+    v4, t4, d3 = synthetic_cut(v3, t3, axis=2, where=0.3)
+    assert len(v4) * 10 > len(v2) * 11
+    g.resync_delta(d3, fixed)
+    assert g.resync_path() == fl.FB_RESYNC_DELTA_REBUILT
+    ref.resync(v4, t4, fixed)
+    _same_bits(g, ref, seed=4, load=-200.0)
     # the next full re-sync starts over
-    g.resync(v3, t3, fixed)
+    g.resync(v4, t4, fixed)
     assert g.resync_path() == fl.FB_RESYNC_FULL
     _same_bits(g, ref, seed=9, load=-200.0)
     g.close()
