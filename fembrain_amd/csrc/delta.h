@@ -35,6 +35,7 @@ struct MeshDelta {
   DevBuf<int> tile_i;               // delta_sorted_pairs: per tile of the old list -- entries that go, prefix sums of those that stay, bounds in the new entries
   DevBuf<unsigned int> drop_bits;   // ... a bit per entry of the old list: it goes
   bool mapped = false;              // delta_node_order ran for this change: imap / newint / node_keys are its
+  DevBuf<int> new_count;            // elements of the change on every new node
   DevBuf<int> imap, newint;         // renumbered handles: old internal id -> new internal id; new node k -> its internal id
   DevBuf<unsigned long long> node_keys;  // merged slab keys (internal order)
   int n_tets_new() const { return n_kept + n_added; }
@@ -49,8 +50,9 @@ int delta_relabel_nodes(hipStream_t s, MeshDelta& D, int n_nodes, const int* map
 int delta_tets(hipStream_t s, const MeshDelta& D, const int4* tets_old, const int* imap, int4* tets_new);
 // A renumbered handle: the new nodes take their place in the slab order under the key geometry the order was built with (frozen until the
 // next full rebuild), ties behind the old nodes.  Outputs D.imap, D.newint, D.node_keys and the two maps of the new order.
+// n_windows > 0: the order has the second stage (renumber.h, sigma_window): keys_old are its keys, win_keys the slab key of every window's first node.
 int delta_node_order(hipStream_t s, MeshDelta& D, int n_old, const SlabKeyGeom& g, const unsigned long long* keys_old, const int* old_of_new_old,
-                     DevBuf<int>& old_of_new, DevBuf<int>& new_of_old, PlanWorkspace& W);
+                     DevBuf<int>& old_of_new, DevBuf<int>& new_of_old, PlanWorkspace& W, int n_windows, const unsigned long long* win_keys);
 // rest positions in the new internal order
 int delta_positions(hipStream_t s, const MeshDelta& D, int n_old, const double* x0_old, double* x0_new);
 // The sorted pair list of the workspace, updated (see the header comment).  tets_old: the old element list in the old internal ids (the

@@ -70,6 +70,31 @@ __global__ __launch_bounds__(kB) void k_delta_keys(int n, const double* __restri
   ids[i] = (uint32_t)i;
 }
 
+// elements of the change on every NEW node (caller ids n_old + k), and the new nodes' keys in a handle whose order has the second stage
+// (renumber.h: window of the slab key << 10 | clipped count, descending)
+__global__ __launch_bounds__(kB) void k_delta_new_counts(int n, const int4* __restrict__ t, int n_old, int* __restrict__ count) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  const int4 v = t[i];
+  const int id[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (id[k] >= n_old) atomicAdd(&count[id[k] - n_old], 1);
+}
+__global__ __launch_bounds__(kB) void k_delta_sigma_keys(int n, const int* __restrict__ count, int n_windows, const unsigned long long* __restrict__ win_keys,
+                                                         unsigned long long* __restrict__ keys) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = keys[i];
+  int lo = 0, hi = n_windows;  // windows whose first slab key is <= k
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (win_keys[mid] <= k) lo = mid + 1; else hi = mid;
+  }
+  const int w = max(lo - 1, 0), c = min(count[i], kSigmaMaxCount);
+  keys[i] = ((unsigned long long)w << 10) | (unsigned long long)(kSigmaMaxCount - c);
+}
+
 // old internal node i moves up by the number of new nodes whose key is smaller (a new node with an equal key goes behind: its caller id is larger)
 __global__ __launch_bounds__(kB) void k_delta_imap(int n_old, const unsigned long long* __restrict__ keys_old, int n_new, const unsigned long long* __restrict__ nks,
                                                    const int* __restrict__ old_of_new_old, int* __restrict__ imap, unsigned long long* __restrict__ keys_out,
@@ -490,7 +515,7 @@ int delta_tets(hipStream_t s, const MeshDelta& D, const int4* tets_old, const in
 }
 
 int delta_node_order(hipStream_t s, MeshDelta& D, int n_old, const SlabKeyGeom& g, const unsigned long long* keys_old, const int* old_of_new_old, DevBuf<int>& old_of_new,
-                     DevBuf<int>& new_of_old, PlanWorkspace& W) {
+                     DevBuf<int>& new_of_old, PlanWorkspace& W, int n_windows, const unsigned long long* win_keys) {
   const int n_new = D.n_new_nodes, n = n_old + n_new;
   FB_TRY(D.imap.reserve((size_t)std::max(1, n_old)));
   FB_TRY(D.newint.reserve((size_t)std::max(1, n_new)));
@@ -504,7 +529,17 @@ int delta_node_order(hipStream_t s, MeshDelta& D, int n_old, const SlabKeyGeom& 
   if (n_new) {
     hipLaunchKernelGGL(k_delta_keys, grid_for(n_new), dim3(kB), 0, s, n_new, D.new_xyz.p, g, D.nk.p, D.nv.p);
     FB_HIP(hipGetLastError());
-    const unsigned key_bits = (unsigned)(g.bits[0] + g.bits[1] + g.bits[2]);
+    unsigned key_bits = (unsigned)(g.bits[0] + g.bits[1] + g.bits[2]);
+    if (n_windows > 0) {  // the order has the second stage: keys_old are its keys, and the new nodes get theirs
+      FB_TRY(D.new_count.reserve((size_t)n_new));
+      FB_HIP(hipMemsetAsync(D.new_count.p, 0, sizeof(int) * (size_t)n_new, s));
+      const int n_el = D.n_changed + D.n_added;   // (changed_nodes and added lie back to back, still in the caller's ids)
+      if (n_el) hipLaunchKernelGGL(k_delta_new_counts, grid_for(n_el), dim3(kB), 0, s, n_el, D.changed_nodes, n_old, D.new_count.p);
+      hipLaunchKernelGGL(k_delta_sigma_keys, grid_for(n_new), dim3(kB), 0, s, n_new, D.new_count.p, n_windows, win_keys, D.nk.p);
+      FB_HIP(hipGetLastError());
+      key_bits = 10;
+      while ((1LL << (key_bits - 10)) < n_windows) key_bits++;
+    }
     size_t bytes = 0;
     FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, D.nk.p, D.nks.p, D.nv.p, D.nvs.p, (size_t)n_new, 0u, key_bits, s));
     FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));

@@ -2148,7 +2148,8 @@ int resync_delta(fb_fem_s* h, int n_removed, const int* removed, int n_changed, 
   // ---- the node order ----
   if (h->ren.active) {
     if (n_new_nodes) {
-      FB_TRY(delta_node_order(s, D, n_old, h->ren.geom, h->ren.d_keys.p, h->ren.d_old_of_new.p, h->map_next_a, h->map_next_b, W));
+      FB_TRY(delta_node_order(s, D, n_old, h->ren.geom, h->ren.d_keys.p, h->ren.d_old_of_new.p, h->map_next_a, h->map_next_b, W, h->ren.sigma ? h->ren.n_windows : 0,
+                              h->ren.sigma ? h->ren.d_win_keys.p : nullptr));
       h->ren.d_old_of_new.swap(h->map_next_a);
       h->ren.d_new_of_old.swap(h->map_next_b);
       h->ren.d_keys.swap(D.node_keys);

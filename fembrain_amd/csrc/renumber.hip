@@ -57,6 +57,42 @@ __global__ __launch_bounds__(kB) void k_slab_keys(int n, const double* __restric
   ids[i] = (uint32_t)i;
 }
 
+// elements on every node (ids outside the range are the plan builder's to report)
+__global__ __launch_bounds__(kB) void k_incident_count(int n_tets, const int4* __restrict__ tets, int n_nodes, int* __restrict__ count) {
+  const int e = blockIdx.x * kB + threadIdx.x;
+  if (e >= n_tets) return;
+  const int4 t = tets[e];
+  const int id[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if ((unsigned int)id[i] >= (unsigned int)n_nodes) return;
+#pragma unroll
+  for (int i = 0; i < 4; i++) atomicAdd(&count[id[i]], 1);
+}
+// per slice of 64 consecutive nodes of the order `ids`: the largest count and the sum (one wavefront per slice)
+__global__ __launch_bounds__(kB) void k_slice_counts(int n, const uint32_t* __restrict__ ids, const int* __restrict__ count, int2* __restrict__ out) {
+  const int s = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (s * 64 >= n) return;
+  const int l = s * 64 + lane;
+  int c = l < n ? count[ids[l]] : 0, m = c;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { m = max(m, __shfl_xor(m, o, 64)); c += __shfl_xor(c, o, 64); }
+  if (lane == 0) out[s] = make_int2(m, c);
+}
+__global__ __launch_bounds__(kB) void k_sigma_keys(int n, int window, const uint32_t* __restrict__ ids, const int* __restrict__ count, unsigned long long* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals) {
+  const int l = blockIdx.x * kB + threadIdx.x;
+  if (l >= n) return;
+  const uint32_t id = ids[l];
+  const int c = min(count[id], kSigmaMaxCount);
+  keys[l] = ((unsigned long long)(l / window) << 10) | (unsigned long long)(kSigmaMaxCount - c);
+  vals[l] = id;
+}
+__global__ __launch_bounds__(kB) void k_window_keys(int n_windows, int window, const unsigned long long* __restrict__ slab_keys, unsigned long long* __restrict__ out) {
+  const int w = blockIdx.x * kB + threadIdx.x;
+  if (w < n_windows) out[w] = slab_keys[(size_t)w * window];
+}
+
 __global__ __launch_bounds__(kB) void k_invert(int n, const uint32_t* __restrict__ old_of_new, int* __restrict__ o2n_out, int* __restrict__ new_of_old) {
   const int l = blockIdx.x * kB + threadIdx.x;
   if (l >= n) return;
@@ -127,6 +163,13 @@ __global__ __launch_bounds__(kB) void k_scatter_nodes(long long n, int width, co
   const long long node = i / width;
   const int c = (int)(i - node * width);
   dst[(size_t)map[node] * width + c] = src[i];
+}
+
+// the slab order alone pads by more than a tenth: 64 x the largest count of every slice against the sum of the counts
+bool sigma_wanted(int n_nodes, long long padded, long long used) {
+  static const char* e = getenv("FEMBRAIN_SIGMA");  // 0 / 1: never / always (development)
+  if (e) return atoi(e) != 0;
+  return n_nodes >= kRenumberMinNodes && padded > 0 && 10 * (padded - used) > padded;  // (small meshes are all surface, and no one waits for them)
 }
 
 int bits_for(long long cells) {  // bits that hold the cell indices 0 .. cells - 1
@@ -222,6 +265,39 @@ int renumber_build(hipStream_t s, int mode, int n_nodes, int n_tets, const int4*
   FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, W.keys.p, W.keys_s.p, W.vals.p, W.vals_s.p, (size_t)n_nodes, 0u, key_bits, s));
   FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
   FB_HIP(rocprim::radix_sort_pairs(W.temp.p, bytes, W.keys.p, W.keys_s.p, W.vals.p, W.vals_s.p, (size_t)n_nodes, 0u, key_bits, s));
+  // second stage (renumber.h: sigma_window): would the slab order pad the matrix by more than a tenth?
+  R.sigma = false;
+  R.n_windows = 0;
+  {
+    const int n_slices = (n_nodes + 63) / 64;
+    FB_TRY(R.d_count.alloc((size_t)n_nodes));
+    FB_TRY(R.d_count.zero(s));
+    hipLaunchKernelGGL(k_incident_count, dim3((unsigned)((n_tets + kB - 1) / kB)), dim3(kB), 0, s, n_tets, d_tets, n_nodes, R.d_count.p);
+    FB_TRY(W.temp.reserve(sizeof(int2) * (size_t)n_slices));
+    int2* d_sc = reinterpret_cast<int2*>(W.temp.p);
+    hipLaunchKernelGGL(k_slice_counts, dim3((unsigned)((n_slices + kB / 64 - 1) / (kB / 64))), dim3(kB), 0, s, n_nodes, W.vals_s.p, R.d_count.p, d_sc);
+    FB_HIP(hipGetLastError());
+    std::vector<int2> sc((size_t)n_slices);
+    FB_HIP(hipMemcpyAsync(sc.data(), d_sc, sizeof(int2) * (size_t)n_slices, hipMemcpyDeviceToHost, s));
+    FB_HIP(hipStreamSynchronize(s));
+    long long padded = 0, used = 0;
+    for (const int2& q : sc) { padded += 64LL * q.x; used += q.y; }
+    if (sigma_wanted(n_nodes, padded, used)) {
+      R.window = sigma_window(n_nodes);
+      R.n_windows = (n_nodes + R.window - 1) / R.window;
+      FB_TRY(R.d_win_keys.alloc((size_t)R.n_windows));
+      hipLaunchKernelGGL(k_window_keys, dim3((unsigned)((R.n_windows + kB - 1) / kB)), dim3(kB), 0, s, R.n_windows, R.window, W.keys_s.p, R.d_win_keys.p);
+      hipLaunchKernelGGL(k_sigma_keys, ng, dim3(kB), 0, s, n_nodes, R.window, W.vals_s.p, R.d_count.p, W.keys.p, W.vals.p);
+      FB_HIP(hipGetLastError());
+      unsigned bits2 = 10;
+      while ((1LL << (bits2 - 10)) < R.n_windows) bits2++;
+      bytes = 0;
+      FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, W.keys.p, W.keys_s.p, W.vals.p, W.vals_s.p, (size_t)n_nodes, 0u, bits2, s));
+      FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+      FB_HIP(rocprim::radix_sort_pairs(W.temp.p, bytes, W.keys.p, W.keys_s.p, W.vals.p, W.vals_s.p, (size_t)n_nodes, 0u, bits2, s));
+      R.sigma = true;
+    }
+  }
   FB_TRY(R.d_old_of_new.alloc((size_t)n_nodes));
   FB_TRY(R.d_new_of_old.alloc((size_t)n_nodes));
   hipLaunchKernelGGL(k_invert, ng, dim3(kB), 0, s, n_nodes, W.vals_s.p, R.d_old_of_new.p, R.d_new_of_old.p);
@@ -342,6 +418,26 @@ int host_slab_order(int n_nodes, const double* xyz, int n_tets, const int* tets,
   std::vector<unsigned long long> key((size_t)n_nodes);
   for (int i = 0; i < n_nodes; i++) key[i] = slab_key(g, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]);
   std::stable_sort(old_of_new.begin(), old_of_new.end(), [&](int a, int b) { return key[a] < key[b]; });
+  {  // second stage, as renumber_build decides and does it
+    std::vector<int> count((size_t)n_nodes, 0);
+    for (int e = 0; e < n_tets; e++) {
+      bool ok = true;
+      for (int i = 0; i < 4; i++) ok = ok && tets[4 * (size_t)e + i] >= 0 && tets[4 * (size_t)e + i] < n_nodes;
+      if (ok) for (int i = 0; i < 4; i++) count[tets[4 * (size_t)e + i]]++;
+    }
+    long long padded = 0, used = 0;
+    for (int s0 = 0; s0 < n_nodes; s0 += 64) {
+      int m = 0;
+      for (int l = s0; l < std::min(n_nodes, s0 + 64); l++) { m = std::max(m, count[old_of_new[l]]); used += count[old_of_new[l]]; }
+      padded += 64LL * m;
+    }
+    if (sigma_wanted(n_nodes, padded, used)) {
+      std::vector<unsigned long long> key2((size_t)n_nodes);
+      const int window = sigma_window(n_nodes);
+      for (int l = 0; l < n_nodes; l++) key2[old_of_new[l]] = sigma_key(l, window, count[old_of_new[l]]);
+      std::stable_sort(old_of_new.begin(), old_of_new.end(), [&](int a, int b) { return key2[a] < key2[b]; });
+    }
+  }
   if (span_after || mean_after) {
     std::vector<int> new_of_old((size_t)n_nodes);
     for (int l = 0; l < n_nodes; l++) new_of_old[old_of_new[l]] = l;
