@@ -1201,9 +1201,31 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
   const double rho = fin.rho[fin.iter & 1];
   const bool converged = !(rho > fin.eps2 * fin.rho0);
   if (!converged) {
-    // The iteration cap was reached.  Whether the system needs more iterations or the pipelined recurrences have stalled cannot
-    // be told from here, so the literal recurrences get the last word: the solve is repeated by the two-launch solver from
-    // the same start, and what it returns (normally the same -max_iter, as CGSolver.cpp:189 would) is the result.
+    // The iteration cap was reached (CGSolver.cpp:189 returns -max_iter with the iterate it has).  The launch left its iterate in d and
+    // the start vector in x.  One exact residual tells whether the pipelined recurrences were honest to the end: if the true
+    // r . r / diag of the iterate is within a factor of four of what they carried, the system simply needs more iterations and the
+    // iterate stands (a system that does not converge cost 2 x max_iter iterations).  Otherwise -- the recurrences
+    // stalled or drifted -- the literal recurrences get the last word: the two-launch solver repeats the solve from the same start.
+    const bool cap_check = !(getenv("FEMBRAIN_PERSIST_CAP_CHECK") && atoi(getenv("FEMBRAIN_PERSIST_CAP_CHECK")) == 0);  // (=0: always repeat; tests)
+    if (cap_check && h->prm.pcg_variant != FB_PCG_BLOCK_JACOBI) {  // (block-Jacobi carries r . B^-1 r: not what the product kernel sums)
+      FB_TRY(h->st.zero(s));  // done = 0: the product below is not a no-op
+      FB_TRY(halo_exchange(h, h->d.p));
+      FB_TRY(spmv<2>(h, h->d.p, h->r.p, b, h->part_b.p, 0));
+      double* sc = nullptr;
+      FB_TRY(global_scalar(h, h->part_b.p, &sc, false, 1, 0, h->sgrid));
+      hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(kBlock), 0, s, h->st.p, h->part_b.p, h->sgrid, sc, eps, max_iter);
+      FB_HIP(hipGetLastError());
+      CGState chk;
+      FB_HIP(hipMemcpyAsync(&chk, h->st.p, sizeof(CGState), hipMemcpyDeviceToHost, s));
+      FB_HIP(hipStreamSynchronize(s));
+      if (std::isfinite(chk.rho0) && chk.rho0 <= 4.0 * rho) {
+        FB_HIP(hipMemcpyAsync(h->x.p, h->d.p, sizeof(double) * 3 * (size_t)h->plan.n_local, hipMemcpyDeviceToDevice, s));
+        fin.rho[fin.iter & 1] = chk.rho0;  // (the exact one)
+        if (iters_out) *iters_out = -fin.iter;
+        if (final_state) *final_state = fin;
+        return FB_OK;
+      }
+    }
     h->pcg_warm = warm;
     const int rc = pcg_solve(h, b, eps, max_iter, iters_out, final_state, false);
     h->last_pcg_path = FB_PCG_PATH_RESOLVED;

@@ -627,15 +627,22 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     atomicAdd((unsigned long long*)pa.timing + ((size_t)blockIdx.x * kPipeMaxWaves + wv) * 6 + 5, (unsigned long long)it_done);
   }
   if (failed) return;  // nothing written back: the host re-solves from the vectors it handed over
-  // (the same when the iteration cap ended the solve: the two-launch solver repeats it from the same start, see pcg_solve_pipe)
-  if (rvalid && !(done && gamma > eps2 * rho0)) {
+  // The iteration cap ended the solve: x is left in pg and the start vector stays -- the host checks the iterate's true residual and
+  // either takes it or has the two-launch solver repeat the solve from the same start (pcg_solve_pipe)
+  const bool capped = done && gamma > eps2 * rho0;
+  if (rvalid) {
     unsigned int dof = 3u * (unsigned int)row;
     asm volatile("" : "+v"(dof));  // (formed here: see the exact-residual phase)
+    if (capped) {
 #pragma unroll
-    for (int a = 0; a < 3; a++) xg[dof + a] = xr[a];
-    if (!done) {  // the launch was cut (test knob): the next one continues from here
+      for (int a = 0; a < 3; a++) pg[dof + a] = xr[a];
+    } else {
 #pragma unroll
-      for (int a = 0; a < 3; a++) { rg[dof + a] = rr[a]; wg[dof + a] = wr[a]; zg[dof + a] = zr[a]; sg[dof + a] = sr[a]; pg[dof + a] = pr[a]; }
+      for (int a = 0; a < 3; a++) xg[dof + a] = xr[a];
+      if (!done) {  // the launch was cut (test knob): the next one continues from here
+#pragma unroll
+        for (int a = 0; a < 3; a++) { rg[dof + a] = rr[a]; wg[dof + a] = wr[a]; zg[dof + a] = zr[a]; sg[dof + a] = sr[a]; pg[dof + a] = pr[a]; }
+      }
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {

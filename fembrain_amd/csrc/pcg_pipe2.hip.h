@@ -359,11 +359,17 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
     }
   }
   if (failed) return;  // nothing written back: the host re-solves from the vectors it handed over
+  const bool capped = done && gamma > eps2 * rho0;  // (the iteration cap: x goes to pg for the host to check, pcg_pipe.hip.h)
 #pragma unroll
   for (int h = 0; h < 2; h++)
-    if (rvalid[h] && !(done && gamma > eps2 * rho0)) {
+    if (rvalid[h]) {
       unsigned int dof = 3u * (unsigned int)row[h];
       asm volatile("" : "+v"(dof));
+      if (capped) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) pg[dof + a] = *lds_d(h, a);
+        continue;
+      }
 #pragma unroll
       for (int a = 0; a < 3; a++) xg[dof + a] = *lds_d(h, a);
       if (!done) {

@@ -1164,9 +1164,17 @@ def test_persistent_solver_matches_two_launch_and_itself(gpu, n, monkeypatch):
         assert itc == itp and np.array_equal(xc, xp), run
     monkeypatch.delenv("FEMBRAIN_PERSIST_MAX_RUN")
     for cap in (1, 29, 30, 37):
-        itl, xl = gp.pcg(rhs, eps=1e-8, max_iter=cap)       # iteration cap (also on and next to an exact-residual iteration): -cap as the reference
-        itk, xk = gm.pcg(rhs, eps=1e-8, max_iter=cap)       # returns, and the literal recurrences have the last word (FB_PCG_PATH_RESOLVED)
-        assert itl == -cap and itk == -cap and np.array_equal(xl, xk) and gp.pcg_path()["path"] == fl.FB_PCG_PATH_RESOLVED, cap
+        # iteration cap (also on and next to an exact-residual iteration): -cap as the reference returns, with the iterate the launch has --
+        # after ONE exact residual has confirmed what its recurrences carried (it was repeated in full by the two-launch solver)
+        itl, xl = gp.pcg(rhs, eps=1e-8, max_iter=cap)
+        itk, xk = gm.pcg(rhs, eps=1e-8, max_iter=cap)
+        assert itl == -cap and itk == -cap and gp.pcg_path()["path"] == fl.FB_PCG_PATH_PERSISTENT, cap
+        assert np.abs(xl - xk).max() <= 1e-9 * np.abs(xk).max() and not xl[fixed].any(), cap
+        # ... and with the check switched off the literal recurrences have the last word (FB_PCG_PATH_RESOLVED), bit for bit
+        monkeypatch.setenv("FEMBRAIN_PERSIST_CAP_CHECK", "0")
+        itr, xr = gp.pcg(rhs, eps=1e-8, max_iter=cap)
+        monkeypatch.delenv("FEMBRAIN_PERSIST_CAP_CHECK")
+        assert itr == -cap and np.array_equal(xr, xk) and gp.pcg_path()["path"] == fl.FB_PCG_PATH_RESOLVED, cap
     itz, xz = gp.pcg(np.zeros_like(rhs), eps=1e-6, max_iter=100)
     assert itz == 0 and not xz.any()
     # full steps: three reference-load steps against the two-launch solver
@@ -1245,7 +1253,13 @@ def test_two_row_persistent_solver_against_the_oracle_and_itself(gpu, monkeypatc
         assert itc == itp and np.array_equal(xc, xp), run
     monkeypatch.delenv("FEMBRAIN_PERSIST_MAX_RUN")
     itl, xl = g.pcg(rhs, eps=1e-8, max_iter=37)
-    assert itl == -37 and g.pcg_path()["path"] == fl.FB_PCG_PATH_RESOLVED
+    assert itl == -37 and g.pcg_path()["path"] == fl.FB_PCG_PATH_PERSISTENT   # (the capped iterate stands after one exact residual)
+    itk, xk = gm.pcg(rhs, eps=1e-8, max_iter=37)
+    assert itk == -37 and np.abs(xl - xk).max() <= 1e-9 * np.abs(xk).max()
+    monkeypatch.setenv("FEMBRAIN_PERSIST_CAP_CHECK", "0")
+    itl, xl = g.pcg(rhs, eps=1e-8, max_iter=37)
+    monkeypatch.delenv("FEMBRAIN_PERSIST_CAP_CHECK")
+    assert itl == -37 and g.pcg_path()["path"] == fl.FB_PCG_PATH_RESOLVED and np.array_equal(xl, xk)
     fext = np.zeros(o.r)
     fext[1::3] = -10000.0
     for k in range(3):
