@@ -220,3 +220,71 @@ def test_delta_resync_refuses_bad_input_before_anything_changes(gpu):
     with pytest.raises(fl.FbError):
         gh.resync_delta(ok, fixed)
     gh.close()
+
+
+def test_delta_resync_random_changes_and_a_hub_node(gpu):
+    """a sequence of random changes (removals, in-place changes, additions on old and new nodes) on a small cube, bit for bit against the
+    full re-sync after every one; and a fan of 5,000 elements on one node -- the run of its diagonal block alone spans three 2,048-entry
+    tiles of the pair list -- losing all but a few of them (a tile of the list that keeps nothing)"""
+    v, t, fixed = _cube(8)
+    g = FemIntegrator(v, t, fixed)
+    ref = FemIntegrator(v, t, fixed)
+    rng = np.random.default_rng(2024)
+    cv, ct = v, t
+    for step in range(8):
+        n_t, n_v = len(ct), len(cv)
+        ids = rng.permutation(n_t)
+        n_rem, n_chg, n_add, n_new = (int(x) for x in rng.integers(0, 40, size=4))
+        rem = np.sort(ids[:n_rem]).astype(np.int32)
+        chg = np.sort(ids[n_rem:n_rem + n_chg]).astype(np.int32)
+        new_xyz = cv[rng.integers(0, n_v, size=n_new)] + rng.normal(size=(n_new, 3)) * 0.03
+        pool = n_v + n_new
+
+        def random_tets(k):
+            out = np.empty((k, 4), np.int32)
+            for i in range(k):
+                while True:
+                    q = rng.choice(pool, 4, replace=False)
+                    p = np.concatenate([cv, new_xyz])[q]
+                    if abs(np.dot(np.cross(p[1] - p[0], p[2] - p[0]), p[3] - p[0])) > 1e-7:
+                        break
+                out[i] = q
+            return out
+        d = dict(removed=rem, changed_ids=chg, changed_nodes=random_tets(n_chg), added=random_tets(n_add), new_xyz=new_xyz)
+        g.resync_delta(d, fixed)
+        assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED
+        cv, ct = apply_delta(cv, ct, d)
+        ref.resync(cv, ct, fixed)
+        for name in PLAN:
+            assert np.array_equal(_device_plan(g, name), _device_plan(ref, name)), (step, name)
+        u = rng.normal(size=g.r) * 0.002
+        fa, Ka = g.assemble(u)
+        fr, Kr = ref.assemble(u)
+        assert np.array_equal(fa, fr) and np.array_equal(Ka, Kr), step
+    g.close()
+    ref.close()
+    # the fan
+    k = 5000
+    pts = rng.normal(size=(3 * k, 3))
+    pts /= np.linalg.norm(pts, axis=1)[:, None]
+    fv = np.concatenate([np.zeros((1, 3)), pts * (1.0 + rng.uniform(0, 0.2, size=(3 * k, 1)))])
+    ft = np.stack([np.zeros(k, np.int32), 1 + 3 * np.arange(k), 2 + 3 * np.arange(k), 3 + 3 * np.arange(k)], axis=1).astype(np.int32)
+    vol = np.einsum("ij,ij->i", np.cross(fv[ft[:, 1]] - fv[ft[:, 0]], fv[ft[:, 2]] - fv[ft[:, 0]]), fv[ft[:, 3]] - fv[ft[:, 0]])
+    ft = np.ascontiguousarray(ft[np.abs(vol) > 1e-3])
+    ffix = fixed_vertices_to_dofs(np.array([1, 2, 3]))
+    g = FemIntegrator(fv, ft, ffix, renumber=fl.FB_RENUMBER_OFF)   # (15,001 nodes: AUTO would look at the numbering)
+    d = dict(removed=np.arange(5, len(ft) - 5, dtype=np.int32), changed_ids=[], changed_nodes=[], added=[], new_xyz=[])
+    g.resync_delta(d, ffix)
+    assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED
+    v2, t2 = apply_delta(fv, ft, d)
+    ref = FemIntegrator(v2, t2, ffix, renumber=fl.FB_RENUMBER_OFF)
+    for name in PLAN:
+        assert np.array_equal(_device_plan(g, name), _device_plan(ref, name)), name
+    d2 = dict(removed=[], changed_ids=[], changed_nodes=[], added=ft[5:3000], new_xyz=[])   # ... and getting them back, appended
+    g.resync_delta(d2, ffix)
+    v3, t3 = apply_delta(v2, t2, d2)
+    ref.resync(v3, t3, ffix)
+    for name in PLAN:
+        assert np.array_equal(_device_plan(g, name), _device_plan(ref, name)), name
+    g.close()
+    ref.close()
