@@ -446,3 +446,30 @@ def test_slab_order_finds_a_grid_again_and_gives_every_rank_two_neighbours():
     tz = np.array([[0, 1, 2, 3]], np.int32)
     fl.check(L.fb_plan_slab_order(5, fl.dptr(z), 1, fl.iptr(tz), fl.iptr(o[:5].copy()), C.byref(a), C.byref(b)))
     assert a.value == b.value == 3
+
+
+def test_synthetic_cut_and_apply_delta_describe_the_same_mesh():
+    """meshgen.synthetic_cut (the change the delta re-sync tests and probes use): splitting every element that crosses a plane in four on a
+    new centroid node keeps the volume and the orientation of every piece, and the delta it reports, applied to the old mesh by
+    meshgen.apply_delta (the contract of fb_fem_resync_delta: in-place changes, ordered erasure, appended elements and nodes), is the mesh
+    it returns"""
+    from fembrain_amd.meshgen import apply_delta, synthetic_cut, truth_cube
+    v, t = truth_cube(7, 8, 9, 0.1)
+
+    def vol(vv, tt):
+        p = vv[tt]
+        return np.einsum("ij,ij->i", np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), p[:, 3] - p[:, 0]) / 6.0
+    for axis, every, stride in ((0, 3, 1), (1, 0, 1), (2, 1, 2)):
+        v2, t2, d = synthetic_cut(v, t, axis=axis, where=0.37, every_changed=every, stride=stride)
+        hit = len(d["removed"]) + len(d["changed_ids"])
+        assert hit > 0 and len(d["new_xyz"]) == hit and len(d["added"]) == 4 * len(d["removed"]) + 3 * len(d["changed_ids"])
+        assert len(v2) == len(v) + hit and len(t2) == len(t) + 3 * hit
+        assert np.all(np.diff(d["removed"]) > 0) and np.all(np.diff(d["changed_ids"]) > 0) and not set(d["removed"]) & set(d["changed_ids"])
+        va, ta = apply_delta(v, t, d)
+        assert np.array_equal(va, v2) and np.array_equal(ta, t2)
+        w0, w2 = vol(v, t), vol(v2, t2)
+        assert abs(w2.sum() - w0.sum()) < 1e-12 and (np.sign(w2) == np.sign(w0[0])).all() and np.abs(w2).min() > 1e-9
+        kept = np.ones(len(t), bool)
+        kept[d["removed"]] = False
+        kept[d["changed_ids"]] = False
+        assert np.array_equal(t2[: kept.sum() + len(d["changed_ids"])][~np.isin(np.nonzero(np.ones(len(t), bool) & ~np.isin(np.arange(len(t)), d["removed"]))[0], d["changed_ids"])], t[kept])
