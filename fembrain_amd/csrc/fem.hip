@@ -2264,6 +2264,10 @@ int fb_fem_resync_delta(fb_fem_t h, int n_removed, const int* removed, int n_cha
     if (changed_nodes[k] < 0 || changed_nodes[k] >= n_new) return fail(FB_EINVAL, "changed element %d references node %d outside [0,%lld)", changed_ids[k / 4], changed_nodes[k], n_new);
   for (long long k = 0; k < 4LL * n_added; k++)
     if (added_tets[k] < 0 || added_tets[k] >= n_new) return fail(FB_EINVAL, "added element %lld references node %d outside [0,%lld)", k / 4, added_tets[k], n_new);
+  for (int k = 0; k < n_fixed_dofs; k++) {
+    if (fixed_dofs[k] < 0 || fixed_dofs[k] >= 3 * n_new) return fail(FB_EINVAL, "constrained DOF %d out of range [0,%lld)", fixed_dofs[k], 3 * n_new);
+    if (k && fixed_dofs[k] <= fixed_dofs[k - 1]) return fail(FB_EINVAL, "constrained DOFs must be strictly ascending (index %d)", k);
+  }
   FB_HIP(hipStreamSynchronize(h->stream));
   h->poisoned = true;
   h->system_valid = false;

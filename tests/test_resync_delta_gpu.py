@@ -197,6 +197,9 @@ def test_delta_resync_refuses_bad_input_before_anything_changes(gpu):
     for d in bad:
         with pytest.raises(fl.FbError):
             g.resync_delta(d, fixed)
+    for fx in ([3, 3], [5, 4], [-1], [3 * len(v)]):
+        with pytest.raises(fl.FbError):
+            g.resync_delta(ok, fx)
     g.set_uniform_force(1, -100.0)
     assert g.do_timestep() > 0          # still the old mesh, still usable
     # a flat element gets through the id checks and is refused by the rest-state kernel: the handle is unusable until a full re-sync
