@@ -291,3 +291,38 @@ def test_delta_resync_random_changes_and_a_hub_node(gpu):
         assert np.array_equal(_device_plan(g, name), _device_plan(ref, name)), name
     g.close()
     ref.close()
+
+
+@pytest.mark.parametrize("renumber", [fl.FB_RENUMBER_OFF, fl.FB_RENUMBER_ON])
+def test_delta_resynced_handle_against_the_cpu_oracle(gpu, renumber):
+    """the handle after two changes (the second one updates the pair list; with its own node order too) against the CPU oracle (oracle/fem_oracle.c,
+    pinned by the reference build) made from the resulting mesh: block pattern exact, warped assembly and a reference-load step to the
+    tolerances of tests/test_fem_gpu.py"""
+    from oracle.pyoracle import OrcFem
+    v, t, fixed = _cube(9)
+    g = FemIntegrator(v, t, fixed, renumber=renumber)
+    v2, t2, d = synthetic_cut(v, t, axis=1, where=0.4)
+    g.resync_delta(d, fixed)
+    v3, t3, d2 = synthetic_cut(v2, t2, axis=2, where=0.55, every_changed=2, stride=6)   # (few new nodes: the order is kept)
+    assert 0 < len(d2["new_xyz"]) * 10 < len(v2)
+    g.resync_delta(d2, fixed)
+    assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED and g.renumbering()[0] == (renumber == fl.FB_RENUMBER_ON)
+    o = OrcFem(v3, t3)
+    o.integrator(fixed)
+    obptr, obcol = o.blocks()
+    bptr, bcol = g.pattern()
+    assert np.array_equal(bptr, obptr) and np.array_equal(bcol, obcol)
+    u = np.random.default_rng(5).normal(size=o.r) * 0.01
+    fo, _ = o.assemble(u)
+    fg, _ = g.assemble(u)
+    assert np.abs(fg - fo).max() <= 1e-9 * np.abs(fo).max()
+    f = np.zeros(o.r)
+    f[1::3] = -10000.0
+    for k in range(2):
+        o.set_external_forces(f)
+        g.set_external_forces(f)
+        io, ig = abs(o.step()), g.do_timestep()
+        qo, _ = o.get_state()
+        qg = g.get_q_state()[0]
+        assert abs(io - ig) <= max(3, 0.02 * io), (k, io, ig)
+        assert np.abs(qg - qo).max() <= 2e-4 * np.abs(qo).max() and not qg[fixed].any()
