@@ -650,7 +650,7 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   FB_TRY(h->st.alloc(1));
   FB_TRY(h->st.zero(s));
   FB_TRY(h->counter.alloc(1));
-  FB_HIP(hipStreamSynchronize(s));
+  if (!h->device_plan) FB_HIP(hipStreamSynchronize(s));  // (a device-built plan: the rest-state check that follows waits for all of it)
   h->system_valid = false;
   return FB_OK;
 }

@@ -185,34 +185,47 @@ __global__ __launch_bounds__(kB) void k_plan_sell(int n_nodes, int n_slices, con
     hb = lo == 0x7fffffff ? 0 : lo;
     if (lane == 0) halo_base[s] = hb;
   }
-  for (int k = 0; k < w; k++) {
-    int c = 0, col;
-    if (k < len) {
-      col = bcol[first + k];
-      colidx[((size_t)so + k) * 64 + lane] = col;
-      blk_slot[first + k] = so + k;
-      c = (int)ucnt[first + k] - (col == a ? 1 : 0);  // the diagonal block's run ends with the marker pair
-    } else {
-      col = a < n_nodes ? a : 0;
-      colidx[((size_t)so + k) * 64 + lane] = col;  // padding: any valid column, its values stay zero
-      if (a >= n_nodes) col = n_nodes - 1;       // (in the 16-bit form a lane past the last row points at the last row instead)
+  // four slots at a time, their loads first: the loop was a chain of dependent global loads, one latency per slot (round 4)
+  for (int k0 = 0; k0 < w; k0 += 4) {
+    int colv[4], cntv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int k = k0 + j;
+      colv[j] = k < len ? bcol[first + k] : 0;
+      cntv[j] = k < len ? (int)ucnt[first + k] : 0;
     }
-    int word;
-    if (!halo_base) {
-      word = col - a;
-      if (word < -32768 || word > 32767) atomicOr(wide, 1);
-    } else if (col >= n_nodes) {
-      const int off = col - n_nodes - hb;
-      if (off > 16383) atomicOr(wide, 1);
-      word = (off << 1) | 1;
-    } else {
-      const int d = col - a;
-      if (d < -16384 || d > 16383) atomicOr(wide, 1);
-      word = d * 2;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int k = k0 + j;
+      if (k >= w) break;  // wave-uniform
+      int c = 0, col;
+      if (k < len) {
+        col = colv[j];
+        colidx[((size_t)so + k) * 64 + lane] = col;
+        blk_slot[first + k] = so + k;
+        c = cntv[j] - (col == a ? 1 : 0);  // the diagonal block's run ends with the marker pair
+      } else {
+        col = a < n_nodes ? a : 0;
+        colidx[((size_t)so + k) * 64 + lane] = col;  // padding: any valid column, its values stay zero
+        if (a >= n_nodes) col = n_nodes - 1;       // (in the 16-bit form a lane past the last row points at the last row instead)
+      }
+      int word;
+      if (!halo_base) {
+        word = col - a;
+        if (word < -32768 || word > 32767) atomicOr(wide, 1);
+      } else if (col >= n_nodes) {
+        const int off = col - n_nodes - hb;
+        if (off > 16383) atomicOr(wide, 1);
+        word = (off << 1) | 1;
+      } else {
+        const int d = col - a;
+        if (d < -16384 || d > 16383) atomicOr(wide, 1);
+        word = d * 2;
+      }
+      coldelta[((size_t)so + k) * 64 + lane] = (short)word;
+      const int m = wave_max(c);
+      if (lane == 0) slot_ccnt[so + k] = m;
     }
-    coldelta[((size_t)so + k) * 64 + lane] = (short)word;
-    const int m = wave_max(c);
-    if (lane == 0) slot_ccnt[so + k] = m;
   }
 }
 
@@ -258,16 +271,29 @@ __global__ __launch_bounds__(kB) void k_plan_contrib_lds(int n_nodes, int n_slic
     for (unsigned int i = threadIdx.x; i < seg_hi - seg_lo; i += kB) seg[i] = vals[seg_lo + i];
     __syncthreads();
   }
-  for (int k = wv; k < w; k += kB / 64) {
-    const int height = slot_ccnt[so + k];  // wave-uniform
-    const int cnt = k < len ? (int)ucnt[first + k] - (bcol[first + k] == a ? 1 : 0) : 0;
-    const unsigned int from = k < len ? cstart[first + k] : seg_lo;
-    uint32_t* out = contrib + (size_t)slot_coff[so + k] * 64 + lane;
-    if (staged) {
-      const uint32_t* in = seg + (from - seg_lo);
-      for (int t = 0; t < height; t++) out[(size_t)t * 64] = t < cnt ? in[t] : kNoContrib;
-    } else {
-      for (int t = 0; t < height; t++) out[(size_t)t * 64] = t < cnt ? vals[from + t] : kNoContrib;
+  // (two of the wavefront's slots at a time, their table entries loaded first: one latency per pair instead of per slot)
+  for (int k0 = wv; k0 < w; k0 += 2 * (kB / 64)) {
+    int height[2], cnt[2], coff[2];
+    unsigned int from[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int k = k0 + j * (kB / 64);
+      const bool on = k < w;
+      height[j] = on ? slot_ccnt[so + k] : 0;  // wave-uniform
+      coff[j] = on ? slot_coff[so + k] : 0;
+      const bool mine = on && k < len;
+      cnt[j] = mine ? (int)ucnt[first + k] - (bcol[first + k] == a ? 1 : 0) : 0;
+      from[j] = mine ? cstart[first + k] : seg_lo;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      uint32_t* out = contrib + (size_t)coff[j] * 64 + lane;
+      if (staged) {
+        const uint32_t* in = seg + (from[j] - seg_lo);
+        for (int t = 0; t < height[j]; t++) out[(size_t)t * 64] = t < cnt[j] ? in[t] : kNoContrib;
+      } else {
+        for (int t = 0; t < height[j]; t++) out[(size_t)t * 64] = t < cnt[j] ? vals[from[j] + t] : kNoContrib;
+      }
     }
   }
 }
