@@ -178,13 +178,17 @@ __global__ __launch_bounds__(kBlock) void k_widen_positions(long long n, const f
 // Zero fills of a (re-)build, batched: about twenty buffers are cleared, and a fill per buffer costs 4-5 us of launch each however
 // small it is.  add() notes them (4-byte granularity), flush() clears up to kZeroMax per launch.
 constexpr int kZeroMax = 24;
-struct ZeroList { unsigned int* p[kZeroMax]; unsigned long long end[kZeroMax]; int n; };  // end: running total of 16-byte chunks
+struct ZeroList { unsigned int* p[kZeroMax]; unsigned long long end[kZeroMax]; unsigned int tail_words[kZeroMax]; int n; };  // end: running total of 16-byte chunks
 __global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z, unsigned long long total_chunks) {
   for (unsigned long long c = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; c < total_chunks; c += (unsigned long long)gridDim.x * kBlock) {
     int b = 0;
     while (c >= z.end[b]) b++;
     const unsigned long long local = c - (b ? z.end[b - 1] : 0ULL);
-    reinterpret_cast<uint4*>(z.p[b])[local] = make_uint4(0u, 0u, 0u, 0u);
+    if (c + 1 == z.end[b] && z.tail_words[b]) {  // the buffer's last chunk holds fewer than four words: the fill never leaves the buffer
+      for (unsigned int k = 0; k < z.tail_words[b]; k++) z.p[b][4 * local + k] = 0u;
+    } else {
+      reinterpret_cast<uint4*>(z.p[b])[local] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
 }
 struct ZeroBatch {
@@ -192,10 +196,10 @@ struct ZeroBatch {
   hipStream_t s;
   int rc = FB_OK;
   explicit ZeroBatch(hipStream_t stream) : s(stream) { z.n = 0; }
-  // p: the start of an allocation of its own (a DevBuf): the fill is rounded up to 16 bytes, inside the allocator's granule
+  // p: 16-byte aligned (the start of an allocation); bytes: a multiple of 4 (else the runtime's fill takes it)
   void add(void* p, size_t bytes) {
     if (!p || !bytes || rc != FB_OK) return;
-    if (bytes < 4096) {  // (small ones: the runtime's fill)
+    if (bytes < 4096 || (bytes & 3)) {  // (small ones: the runtime's fill)
       if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess) rc = fail(FB_EDEVICE, "hipMemsetAsync failed");
       return;
     }
@@ -203,6 +207,7 @@ struct ZeroBatch {
     const unsigned long long chunks = (bytes + 15) / 16, before = z.n ? z.end[z.n - 1] : 0ULL;
     z.p[z.n] = static_cast<unsigned int*>(p);
     z.end[z.n] = before + chunks;
+    z.tail_words[z.n] = (unsigned int)((bytes & 15) / 4);
     z.n++;
   }
   template <typename T>
