@@ -551,7 +551,10 @@ __device__ inline void window66(const unsigned long long* __restrict__ a, long l
 //          per axis the offset +1 counts unless p is on the last plane of that axis, -1 unless on the first -- the dilation is separable,
 //          so no pass over cinc is needed (rounds 1-3 made vinc from cinc in a second kernel)   (TetMeshCells' marks, Tetrahedralizer.cl:39-64)
 // from nine 66-bit windows of `inside` (rows y-1, y, y+1 of planes z-1, z, z+1); per workgroup the four sums the ranks and totals are made of.
-__global__ __launch_bounds__(kPB) void k_classify(Grid G, long long nwords, const unsigned long long* __restrict__ inside,
+// ROWS64 (round 4): the grid's x extent is a multiple of 64, so a word lies inside one grid row and the seven position masks follow
+// from its row and plane -- computed instead of loaded (14.7 MB of the kernel's 28 at 256^3); dxy / dx: divisions by the plane and row sizes in words.
+template <bool ROWS64>
+__global__ __launch_bounds__(kPB) void k_classify(Grid G, FastDiv dxy, FastDiv dx, long long nwords, const unsigned long long* __restrict__ inside,
                                                   const unsigned long long* __restrict__ lastx, const unsigned long long* __restrict__ lasty,
                                                   const unsigned long long* __restrict__ lastz, const unsigned long long* __restrict__ firstx,
                                                   const unsigned long long* __restrict__ firsty, const unsigned long long* __restrict__ firstz,
@@ -564,7 +567,20 @@ __global__ __launch_bounds__(kPB) void k_classify(Grid G, long long nwords, cons
   const long long w = (long long)blockIdx.x * kPB + threadIdx.x;
   unsigned int pc = 0, pv = 0, ne = 0, ns = 0;
   if (w < nwords) {
-    const unsigned long long lx = lastx[w], ly = lasty[w], lz = lastz[w], fx = firstx[w], fy = firsty[w], fz = firstz[w], vd = valid[w];
+    unsigned long long lx, ly, lz, fx, fy, fz, vd;
+    if (ROWS64) {
+      const unsigned int wpr = (unsigned int)(G.g[0] >> 6), wpp = wpr * (unsigned int)G.g[1];  // words per row / per plane
+      const unsigned int w32 = (unsigned int)w, z = div_by(w32, dxy), rem = w32 - z * wpp, y = div_by(rem, dx), xw = rem - y * wpr;
+      lx = xw == wpr - 1u ? 1ULL << 63 : 0ULL;
+      fx = xw == 0u ? 1ULL : 0ULL;
+      ly = y == (unsigned int)G.g[1] - 1u ? ~0ULL : 0ULL;
+      fy = y == 0u ? ~0ULL : 0ULL;
+      lz = z == (unsigned int)G.g[2] - 1u ? ~0ULL : 0ULL;
+      fz = z == 0u ? ~0ULL : 0ULL;
+      vd = ~0ULL;  // (every word is full: n_points is a multiple of 64)
+    } else {
+      lx = lastx[w]; ly = lasty[w]; lz = lastz[w]; fx = firstx[w]; fy = firsty[w]; fz = firstz[w]; vd = valid[w];
+    }
     unsigned long long any = 0ULL, all = ~0ULL, dil = 0ULL, c0 = 0ULL, cx = 0ULL, cy = 0ULL, cz = 0ULL;
 #pragma unroll
     for (int oz = -1; oz <= 1; oz++)
@@ -1741,8 +1757,15 @@ int do_classify(fb_poly_s* h) {
   const Grid& G = h->G;
   const long long pw = h->n_words;
   const int nblk = (int)((pw + kPB - 1) / kPB);
-  hipLaunchKernelGGL(k_classify, dim3(nblk), dim3(kPB), 0, h->stream, G, pw, h->inside.p, h->lastx.p, h->lasty.p, h->lastz.p, h->firstx.p, h->firsty.p,
-                     h->firstz.p, h->valid.p, h->cinc.p, h->crossx.p, h->crossy.p, h->crossz.p, h->vinc.p, h->aux_pop.p, h->block_sums.p);
+  const bool no_rows64 = getenv("FEMBRAIN_CLASSIFY_MASKS") && atoi(getenv("FEMBRAIN_CLASSIFY_MASKS")) != 0;  // development aid: always load the masks
+  if (G.g[0] % 64 == 0 && pw < (1LL << 31) && !no_rows64) {
+    const unsigned int wpr = (unsigned int)(G.g[0] / 64);
+    hipLaunchKernelGGL(k_classify<true>, dim3(nblk), dim3(kPB), 0, h->stream, G, fast_div(wpr * (unsigned int)G.g[1]), fast_div(wpr), pw, h->inside.p, h->lastx.p, h->lasty.p,
+                       h->lastz.p, h->firstx.p, h->firsty.p, h->firstz.p, h->valid.p, h->cinc.p, h->crossx.p, h->crossy.p, h->crossz.p, h->vinc.p, h->aux_pop.p, h->block_sums.p);
+  } else {
+    hipLaunchKernelGGL(k_classify<false>, dim3(nblk), dim3(kPB), 0, h->stream, G, fast_div(1u), fast_div(1u), pw, h->inside.p, h->lastx.p, h->lasty.p, h->lastz.p, h->firstx.p,
+                       h->firsty.p, h->firstz.p, h->valid.p, h->cinc.p, h->crossx.p, h->crossy.p, h->crossz.p, h->vinc.p, h->aux_pop.p, h->block_sums.p);
+  }
   hipLaunchKernelGGL(k_ranks, dim3(nblk), dim3(kPB), 0, h->stream, pw, h->cinc.p, h->vinc.p, h->block_sums.p, h->cbase.p, h->vbase.p, h->totals.p);
   FB_HIP(hipGetLastError());
   h->materialized = false;

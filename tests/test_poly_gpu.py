@@ -207,6 +207,37 @@ def test_non_multiple_of_64_row_length_grid(gpu):
         assert np.array_equal(tets, otets) and np.array_equal(xyz, oxyz)
 
 
+@pytest.mark.parametrize("dims,cell", [((64, 19, 23), 0.035), ((128, 11, 9), 0.018), ((192, 7, 5), 0.012)])
+def test_row_aligned_grids_classify_without_the_position_masks(gpu, monkeypatch, dims, cell):
+    """gx a multiple of 64: k_classify<ROWS64> derives the seven position masks of a word from its row and plane instead of loading them.
+    Against the CPU oracle, and bit for bit against the kernel that loads the masks (FEMBRAIN_CLASSIFY_MASKS=1)."""
+    blob = _trees()["nested"]
+    lo = np.array([-1.12, -0.35, -0.4], np.float32)
+    o = OrcPoly(blob)
+    og = o.sweep_grid(lo, cell, dims)
+    oc = o.classify()
+    out = []
+    for masks in ("0", "1"):
+        monkeypatch.setenv("FEMBRAIN_CLASSIFY_MASKS", masks)
+        g = GpuPoly(blob)
+        g.sweep_grid(lo, cell, dims)
+        c = g.classify()
+        flags, cnt, cfg = g.read_classification()
+        g.tetrahedralize()
+        xyz, tets = g.read_tetmesh()
+        out.append((flags, cnt, cfg, xyz, tets, (c.n_crossed_edges, c.n_surface_cells, c.n_included_cells, c.n_tet_vertices)))
+    monkeypatch.delenv("FEMBRAIN_CLASSIFY_MASKS")
+    for a, b in zip(out[0][:5], out[1][:5]):
+        assert np.array_equal(a, b)
+    assert out[0][5] == out[1][5] and out[0][5][2] > 0
+    if (np.abs(og[:, 3] - 0.5) > 1e-5).all():
+        flags, cnt, cfg, xyz, tets, counts = out[0]
+        assert np.array_equal(flags, o.edge_flags) and np.array_equal(cfg, o.config)
+        assert counts == (oc["n_crossed_edges"], oc["n_surface_cells"], oc["n_included_cells"], oc["n_tet_vertices"])
+        oxyz, otets = o.tetrahedralize()
+        assert np.array_equal(tets, otets) and np.array_equal(xyz, oxyz)
+
+
 # ---- marching-cubes surface (GPUPoly::run) ---------------------------------------------------------------------------
 @pytest.mark.parametrize("name,cellsize", [("sphere", 0.1), ("blend6_noops", 0.07), ("range_blend", 0.11), ("two_ranges", 0.09), ("nested", 0.08),
                                            ("peanut.blob", 0.15), ("tumor.blob", 0.2)])
