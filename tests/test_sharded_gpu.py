@@ -128,19 +128,23 @@ def _renumbered_worker(rank, world, shm_name, n, p2p, q, subset):
         os._exit(1)
 
 
-@pytest.mark.parametrize("world,p2p", [(2, 0), (3, 4), (4, 2)])
-def test_renumbered_shards_of_a_scrambled_cube_are_slabs_with_two_neighbours(gpu, world, p2p):
+@pytest.mark.parametrize("world,p2p,sigma", [(2, 0, 0), (3, 4, 0), (4, 2, 0), (3, 4, 1)])
+def test_renumbered_shards_of_a_scrambled_cube_are_slabs_with_two_neighbours(gpu, monkeypatch, world, p2p, sigma):
     """SURVEY 8e / VERDICT r3 item 1: a cube whose node ids are a random permutation, cut into equal index ranges, makes every rank a
     neighbour of every other with half the mesh as halo.  With FB_RENUMBER_ON every rank derives the same slab order from the whole
     mesh and owns a contiguous range of THAT: at most two neighbour ranks, a halo of one or two grid planes, the ranks' owned nodes
     partition the caller's ids, patterns come back in the caller's ids (ascending), and two steps gathered over the ranks equal the
-    unsharded handle's on the same caller mesh."""
+    unsharded handle's on the same caller mesh.  sigma = 1: with the second stage of the node order forced on (FEMBRAIN_SIGMA=1: rows sorted
+    by element count inside windows of 256), the same, the slabs a window thicker at most."""
     import multiprocessing as mp
     from fembrain_amd.fem import FemIntegrator
     n = 12
+    if sigma:
+        monkeypatch.setenv("FEMBRAIN_SIGMA", "1")   # (the workers inherit it)
+    slack = 512 if sigma else 0   # (two nodes of an element may move a window each, apart)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    name = "/fembrain_test_%d_renum_%d_%d" % (os.getpid(), world, p2p)
+    name = "/fembrain_test_%d_renum_%d_%d_%d" % (os.getpid(), world, p2p, sigma)
     procs = [ctx.Process(target=_renumbered_worker, args=(r, world, name, n, p2p, q, False)) for r in range(world)]
     for p in procs:
         p.start()
@@ -169,8 +173,8 @@ def test_renumbered_shards_of_a_scrambled_cube_are_slabs_with_two_neighbours(gpu
     seen = np.zeros(len(v), int)
     for rank, rits, info, own, qq, (bptr, bcol) in res:
         on, sc, si, halo, nbr = info
-        assert on and si <= n * n + n + 1 < sc
-        assert nbr <= 2 and halo <= 2 * (n * n + n + 1), (rank, halo, nbr)      # a slab: one neighbour below, one above
+        assert on and si <= n * n + n + 1 + slack < sc
+        assert nbr <= 2 and halo <= 2 * (n * n + n + 1 + slack), (rank, halo, nbr)      # a slab: one neighbour below, one above
         assert rits == res[0][1] and all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its))
         seen[own] += 1
         dofs = (3 * own[:, None] + np.arange(3)[None, :]).reshape(-1)
