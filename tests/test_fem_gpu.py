@@ -1559,6 +1559,15 @@ def test_block_jacobi_inside_the_persistent_kernel(gpu, monkeypatch, n, renumber
             assert np.abs(qp - qj).max() <= 1e-4 * np.abs(qj).max()
         assert not qp[fixed].any()
     _, rhs = gp.system()
+    itp, xp = gp.pcg(rhs, eps=1e-8, max_iter=20000)
+    assert itp > 0 and gp.pcg_path()["path"] == fl.FB_PCG_PATH_PERSISTENT
+    for run in ("1", "7", "30"):                     # the solve cut into shorter launches: the same bits
+        monkeypatch.setenv("FEMBRAIN_PERSIST_MAX_RUN", run)
+        itc, xc = gp.pcg(rhs, eps=1e-8, max_iter=20000)
+        assert itc == itp and np.array_equal(xc, xp), run
+    monkeypatch.delenv("FEMBRAIN_PERSIST_MAX_RUN")
+    itl, xl = gp.pcg(rhs, eps=1e-8, max_iter=17)     # the iteration cap: repeated by the two-launch block-Jacobi solver
+    assert itl == -17 and gp.pcg_path()["path"] == fl.FB_PCG_PATH_RESOLVED
     it, x = gp.pcg(rhs, eps=1e-10, max_iter=20000)   # below the persistent solver's tolerance floor: the literal two-launch sequence
     assert it > 0 and gp.pcg_path()["path"] == fl.FB_PCG_PATH_TWO_LAUNCH
     res = rhs - gp.spmv(x)
