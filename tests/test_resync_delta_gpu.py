@@ -326,3 +326,21 @@ def test_delta_resynced_handle_against_the_cpu_oracle(gpu, renumber):
         qg = g.get_q_state()[0]
         assert abs(io - ig) <= max(3, 0.02 * io), (k, io, ig)
         assert np.abs(qg - qo).max() <= 2e-4 * np.abs(qo).max() and not qg[fixed].any()
+
+
+@pytest.mark.parametrize("kw", [dict(matrix_precision=fl.FB_MATRIX_F64), dict(integrator=fl.FB_INTEGRATOR_NEWMARK), dict(exact_tangent=1),
+                                dict(pcg_variant=fl.FB_PCG_BLOCK_JACOBI), dict(pcg_variant=fl.FB_PCG_REFERENCE, spmv_kernel=fl.FB_SPMV_ROWS)])
+def test_delta_resync_on_handles_of_every_kind(gpu, kw):
+    """fp64 matrix, Newmark, exact tangent, block-Jacobi, the literal two-launch solver: what a handle keeps beside the plan (Newmark's
+    vectors, the tangent's correction records, the inverse blocks) follows a delta re-sync as it follows a full one -- bit for bit"""
+    v, t, fixed = _cube(9)
+    g = FemIntegrator(v, t, fixed, **kw)
+    g.set_uniform_force(1, -300.0)
+    g.do_timestep()
+    v2, t2, d = synthetic_cut(v, t, axis=2, where=0.45, every_changed=2)
+    g.resync_delta(d, fixed)
+    assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED
+    ref = FemIntegrator(v2, t2, fixed, **kw)
+    _same_bits(g, ref, load=-300.0)
+    g.close()
+    ref.close()
