@@ -472,6 +472,44 @@ def _watchdog(seconds):
     threading.Thread(target=run, daemon=True).start()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) outside a launcher.  The parent never imports torch and never makes a HIP call (a process that has
+    initialised the GPU must not be replaced or forked on this pool): it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free port> bench.py <same arguments>` as a child process, passes the child's stdout through line by
+    line (rank 0's ONE JSON line among them), and returns the child's exit code.  If the ranks leave without a JSON line, the parent prints
+    one with an `error` field, so that the caller always has a line to parse."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL and the peer-to-peer inboxes need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    seen = False
+    try:
+        for line in child.stdout:
+            if line.lstrip().startswith("{") and '"metric"' in line:
+                seen = True
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        rc = child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        rc = child.wait()
+    if os.environ.get("FEMBRAIN_BENCH_PARENT_TRACE") == "1":   # (tests: the parent stayed clear of torch / HIP)
+        print("parent modules: torch=%s" % ("torch" in sys.modules), file=sys.stderr, flush=True)
+    if not seen:
+        print(json.dumps({"metric": "FEM steps/sec (assemble+PCG) at 1M tets", "value": None, "unit": "steps/s", "n_gpus": n,
+                          "error": "the %d ranks started by bench.py left with code %d before rank 0 printed its line" % (n, rc),
+                          "launched": " ".join(cmd)}), flush=True)
+        rc = rc or 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -488,8 +526,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     _state["rank"] = rank
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # `python bench.py --gpus N` without a launcher: this process starts the N ranks itself (self_launch) -- as CHILD processes,
+            # before torch or HIP has been touched here -- relays rank 0's line and leaves with the launcher's exit code
+            sys.exit(self_launch(args.gpus))
         args.gpus = world
 
     import signal
@@ -551,6 +591,12 @@ def main():
             idb = (C.c_ubyte * 128)(*uid.cpu().tolist())
             fl.check(fl.lib().fb_comm_create(C.byref(comm), rank, world, idb, device))
     tdev = "cpu" if local_comm else "cuda"
+    comm_info = None
+    if dist_mode:
+        cr, cn, ck = C.c_int(0), C.c_int(0), C.c_int(0)
+        fl.check(fl.lib().fb_comm_info(comm, C.byref(cr), C.byref(cn), C.byref(ck)))
+        comm_info = {"ranks": cr.value, "rccl_ranks": cn.value, "transport": ["none", "RCCL (ncclCommInitRank over the launcher's unique id)",
+                                                                              "host-staged shared-memory test transport (one-GPU rehearsal)"][ck.value]}
 
     def reduce_scalar(x, op):
         if not dist_mode:
@@ -650,8 +696,6 @@ def main():
         if dist_mode and g.transport() >= fl.FB_XCH_P2P and os.environ.get("FEMBRAIN_XCH_MODE") is None:
             names = {fl.FB_XCH_COLLECTIVE: "collective", fl.FB_XCH_P2P: "p2p", fl.FB_XCH_P2P_SUMS: "p2p_sums", fl.FB_XCH_P2P_FUSED: "p2p_fused"}
             modes = (fl.FB_XCH_P2P, fl.FB_XCH_P2P_SUMS, fl.FB_XCH_P2P_FUSED)
-            if not local_comm and os.environ.get("FEMBRAIN_BENCH_TRY_RCCL") == "1":
-                modes = (fl.FB_XCH_COLLECTIVE,) + modes   # the collective library, for the record (opt-in)
             _, why = stage("exchange trial: first step", one_step, optional=True)
             for mode in modes if why is None else ():
                 def trial():
@@ -875,7 +919,10 @@ def main():
                 "resync_ms": resync_ms,
                 # informational (north star: MFMA only for the batched 12x12 element contractions): forming every K0 = V B^T E B on the
                 # fp64 matrix cores; 2*(6*6*12 + 12*6*12) flop and 1152 B written per element.  The per-step path never forms K0.
-                "element_k0_mfma": {"us_per_pass": k0_s * 1e6, "gflops": 2592.0 * len(t) / k0_s / 1e9 if shard is None else None,
+                "element_k0_mfma": {"on_step_path": False,
+                                    "note": "not part of a step: the step path never forms K0 (block (i,j) of R K0 R^T is closed-form from a 64-byte "
+                                            "record per tet, DESIGN.md section 3); this kernel serves fb_fem_element_stiffness (inspection) only",
+                                    "us_per_pass": k0_s * 1e6, "gflops": 2592.0 * len(t) / k0_s / 1e9 if shard is None else None,
                                     "write_gbs": 1152.0 * len(t) / k0_s / 1e9 if shard is None else None},
                 "exchange_us": {"halo_refresh": halo_s * 1e6, "global_sum_3": sum_s * 1e6},
                 "assembly_kernels_us": asm_k_s * 1e6, "assembly_gbs": g.assembly_bytes() / asm_k_s / 1e9,
@@ -885,6 +932,39 @@ def main():
         out = _state["out"]
         mode_used = g.transport()
         sp_final = bool(dist_mode and g.sharded_persist())
+        # The north star's transport for the record: ONE step from rest with every exchange of every PCG iteration going
+        # through the collective library (RCCL all-reduce of the three sums + ncclSend/ncclRecv of the halo rows; FB_XCH_COLLECTIVE), and the
+        # same step in the form the timed steps used.  After the headline is in _state["out"], so that a collective that never returns
+        # costs this leg (the watchdog prints the line), not the run.  FEMBRAIN_BENCH_TRY_RCCL=0 skips it.
+        if dist_mode and os.environ.get("FEMBRAIN_BENCH_TRY_RCCL", "1") != "0":
+            def rest_step(mode, sp):
+                if sp_attached and g.persist_info()[0] != sp and not (sp and g.pcg_path()["fallbacks"]):
+                    g.set_sharded_persist(sp)
+                if g.transport() != mode:
+                    g.set_exchange_mode(mode)
+                g.reset_to_rest()
+                barrier()
+                ts = time.perf_counter()
+                it = one_step()
+                barrier()
+                return time.perf_counter() - ts, int(it), g.last.solve_seconds
+            leg = {}
+            for key, mode, sp in (("collective", fl.FB_XCH_COLLECTIVE, False), ("as_timed", mode_used, sp_final)):
+                res, why = stage("collective-library leg: %s" % key, lambda mode=mode, sp=sp: rest_step(mode, sp), optional=True)
+                if res is None:
+                    leg[key] = {"error": why}
+                    break
+                ms = reduce_scalar(res[0], "max") * 1e3
+                leg[key] = {"ms_per_step": ms, "cg_iterations": res[1], "us_per_cg_iteration": reduce_scalar(res[2], "max") / max(res[1], 1) * 1e6}
+            if out is not None:
+                if "ms_per_step" in leg.get("collective", {}):
+                    out["config"]["exchange_trials_ms_per_step"] = dict(out["config"]["exchange_trials_ms_per_step"], collective=leg["collective"]["ms_per_step"])
+                out["config"]["collective_library_leg"] = dict(leg, what="one step from the rest state on the same handle: every exchange through "
+                                                               "the collective library (FB_XCH_COLLECTIVE) against the form the timed steps used",
+                                                               communicator=comm_info)
+        if out is not None:
+            out["config"]["communicator"] = comm_info
+            out["config"]["rccl_ranks"] = comm_info["rccl_ranks"] if comm_info else 0
         g.close()
         g = None
 
@@ -1017,6 +1097,22 @@ def main():
                 g8.close()
             if out is not None:
                 out["cube111"] = big if big else {"error": why}
+                # the north star's multi-GPU question in one place: the 8M-tet mesh on these N ranks against the
+                # committed one-GPU figure of the same leg (profiles/n1_8m_reference.json, written from a --gpus 1 run of this script)
+                if big:
+                    ref8 = None
+                    try:
+                        ref8 = json.load(open(os.path.join(ROOT, "profiles", "n1_8m_reference.json")))
+                    except Exception:  # noqa: BLE001
+                        pass
+                    same = bool(ref8) and ref8.get("tets") == big["tets"]
+                    out["scaling_8m"] = {"workload": big["workload"], "n_gpus": world, "steps_per_s": big["value"], "ms_per_step": big["ms_per_step"],
+                                         "us_per_cg_iteration_per_rank": big["us_per_cg_iteration_per_rank"], "cg_iterations_per_step": big["cg_iterations_per_step"],
+                                         "pcg_kernel": big["pcg_kernel"], "scaling": "strong (the same 8M-tet mesh on every N)",
+                                         "n1_steps_per_s_committed": ref8.get("steps_per_s") if same else None,
+                                         "n1_source": ref8.get("source") if same else "profiles/n1_8m_reference.json holds no figure for this mesh",
+                                         "speedup_over_n1": (big["value"] / ref8["steps_per_s"]) if same and ref8.get("steps_per_s") else None,
+                                         "target": "north star: >= 6x at N = 8"}
     except BenchAbort as e:
         rc = 1
         _emit(str(e))

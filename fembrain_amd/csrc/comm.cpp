@@ -31,6 +31,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -64,6 +65,7 @@ int load_rccl() {
   SYM(GetUniqueId, "ncclGetUniqueId");
   SYM(CommInitRank, "ncclCommInitRank");
   SYM(CommDestroy, "ncclCommDestroy");
+  SYM(CommCount, "ncclCommCount");
   SYM(AllReduce, "ncclAllReduce");
   SYM(AllGather, "ncclAllGather");
   SYM(Send, "ncclSend");
@@ -307,6 +309,16 @@ int fb_comm_create_local(fb_comm_t* out, int rank, int n_ranks, const char* shm_
 int fb_comm_test_allgather(fb_comm_t c, const void* mine, void* all, size_t bytes) {
   if (!c || !c->local || !mine || !all) return fb::fail(FB_EINVAL, "fb_comm_test_allgather needs a host-staged communicator");
   return local_allgather(c, mine, all, bytes);
+}
+
+int fb_comm_info(fb_comm_t c, int* ranks, int* rccl_ranks, int* transport) {
+  if (!c) return fb::fail(FB_EINVAL, "null communicator");
+  int count = 0;
+  if (c->nccl) FB_NCCL(g_rccl.CommCount((ncclComm_t)c->nccl, &count));
+  if (ranks) *ranks = c->n_ranks;
+  if (rccl_ranks) *rccl_ranks = count;
+  if (transport) *transport = c->nccl ? 1 : (c->local ? 2 : 0);
+  return FB_OK;
 }
 
 int fb_comm_destroy(fb_comm_t c) {

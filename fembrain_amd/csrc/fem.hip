@@ -69,6 +69,8 @@ struct fb_fem_s {
   bool masks_ready = false;            // ... and the constraint masks (device_constraint_masks)
   std::vector<int> l2c;                // a renumbered SHARDED handle: caller id of every local node (owned, then halo); empty otherwise
   unsigned long long order_sum = 0;    // ... and a checksum of the order, compared across the ranks
+  bool shard_auto_on = false;          // FB_RENUMBER_AUTO on a sharded handle: the ranks voted for the internal order (vote_shard_order)
+  int shard_vote_neighbours = 0;       // most neighbour ranks any rank would have had under the caller's numbering (what the vote saw)
   DevBuf<int> fixed_stage;
   std::vector<int> c_bptr, c_bcol, c_src;  // the pattern in the caller's numbering and the internal block behind each of its blocks (inspection entry points)
   bool caller_pattern = false;
@@ -226,6 +228,7 @@ struct ZeroBatch {
 
 int renumber_mode(const fb_fem_s* h) {
   if (const char* e = getenv("FEMBRAIN_RENUMBER")) return atoi(e) != 0 ? FB_RENUMBER_ON : FB_RENUMBER_OFF;
+  if (h->prm.renumber == 0 && h->shard_auto_on) return FB_RENUMBER_ON;  // (a sharded handle under AUTO whose ranks voted for it)
   return h->prm.renumber > 0 ? FB_RENUMBER_ON : (h->prm.renumber < 0 ? FB_RENUMBER_OFF : FB_RENUMBER_AUTO);
 }
 
@@ -1710,6 +1713,50 @@ int attach_pipe_shard(fb_fem_s* h) {
   return FB_OK;
 }
 
+// Collective, BEFORE the rank-local build: FB_RENUMBER_AUTO on a sharded handle ("the same contiguous-range rule after an
+// RCM / space-filling-curve renumbering").  Equal ranges of the caller's ids are slabs of the body only while the caller numbers plane
+// by plane; after cuts (nodes appended at the end: VolMesh.cpp:1086-1091) or on a TetGen mesh every rank is a neighbour of every other
+// and half the mesh is halo (profiles/r04_numbering_probe_after.json: 7 neighbours and 128k halo nodes per rank at 8 ranks, against 2 and
+// 6k).  Every rank counts the ranks its own elements couple it to under the caller's numbering and sums a checksum of the element list
+// it was handed; the ranks all-gather (neighbours, sizes, checksum, mode) and switch the internal order on -- all of them or none --
+// when some rank would have more than two neighbours (or, from 8,192 nodes, most of its elements reaching into another rank) AND every
+// rank holds the same whole mesh (the internal order is derived from all
+// nodes and all elements; a rank that was handed its own elements only keeps the caller's numbering, as before).  One pass over the
+// element list on the host (2 ms per million tets) and one all-gather of 40 bytes.
+struct ShardOrderVote { int neighbours, n_nodes, n_tets, mode; unsigned long long sum; int splits_sum, own_elements, boundary_elements, pad; };
+int vote_shard_order(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, int n_ranks, int rank, const int* splits) {
+  h->shard_auto_on = false;
+  h->shard_vote_neighbours = 0;
+  if (!h->comm || n_ranks < 2) return FB_OK;
+  ShardOrderVote mine;
+  memset(&mine, 0, sizeof mine);
+  int mode = h->prm.renumber > 0 ? FB_RENUMBER_ON : (h->prm.renumber < 0 ? FB_RENUMBER_OFF : FB_RENUMBER_AUTO);
+  if (const char* e = getenv("FEMBRAIN_RENUMBER")) mode = atoi(e) != 0 ? FB_RENUMBER_ON : FB_RENUMBER_OFF;
+  mine.mode = mode; mine.n_nodes = n_nodes; mine.n_tets = n_tets; mine.neighbours = -1;
+  if (mode == FB_RENUMBER_AUTO && tets && n_tets > 0 && n_nodes > 0 && n_ranks <= 64) {
+    // (bad ranges, bad ids: the build refuses them with its own message; this rank then votes "unknown")
+    shard_neighbour_count(n_nodes, n_tets, tets, n_ranks, rank, splits, &mine.neighbours, &mine.sum, &mine.splits_sum, &mine.own_elements, &mine.boundary_elements);
+  }
+  std::vector<ShardOrderVote> all((size_t)n_ranks);
+  FB_TRY(comm_allgather_bytes(h->comm, &mine, all.data(), sizeof mine, h->stream));
+  bool same = true, any_wide = false;
+  int most = 0;
+  for (int q = 0; q < n_ranks; q++) {
+    same = same && all[q].mode == FB_RENUMBER_AUTO && all[q].neighbours >= 0 && all[q].n_nodes == all[0].n_nodes && all[q].n_tets == all[0].n_tets &&
+           all[q].sum == all[0].sum && all[q].splits_sum == all[0].splits_sum;
+    // more than two neighbour ranks; or (meshes of a size AUTO renumbers at all) most of a rank's elements reach into another rank -- the
+    // two-rank form of the same disorder, where "every rank a neighbour" still means one
+    any_wide = any_wide || all[q].neighbours > 2 || (n_nodes >= kRenumberMinNodes && 2LL * all[q].boundary_elements > all[q].own_elements);
+    most = std::max(most, all[q].neighbours);
+  }
+  h->shard_vote_neighbours = most;
+  h->shard_auto_on = same && any_wide;
+  if (getenv("FEMBRAIN_TIMING"))
+    fprintf(stderr, "[fembrain] rank %d: node-order vote: %d neighbour ranks here, %d at most, same mesh on every rank: %s -> %s\n", rank, mine.neighbours, most, same ? "yes" : "no",
+            h->shard_auto_on ? "internal slab order" : "caller's numbering");
+  return FB_OK;
+}
+
 // collective: a renumbered sharded handle works only if every rank derived the same internal order (from the same whole mesh)
 int agree_on_node_order(fb_fem_s* h) {
   if (!h->comm || h->comm->n_ranks < 2) return FB_OK;
@@ -1775,6 +1822,8 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
   h->mu = params->E / (2 * (1 + params->nu));
   int rc = FB_OK;
   do {
+   // collective, before anything rank-local can fail: the node order of a sharded handle under FB_RENUMBER_AUTO
+   if (comm && comm->n_ranks > 1 && (rc = vote_shard_order(h, n_nodes, n_tets, tets, n_ranks, rank, splits)) != FB_OK) break;
    // rank-local set-up; a failure here (stream, events, pinned memory, the build) must still reach the agreement below -- the other ranks
    // are on their way into that all-gather
    do {
@@ -2064,6 +2113,7 @@ static int resync_sharded(fb_fem_t h, int n_nodes, const double* xyz, int n_tets
   // build() is rank-local (a bad node id or a flat element after a cut, no memory ...); what follows is collective.  The ranks
   // agree on the outcome first: if any of them failed, none enters the collective attach -- all stay poisoned and return an
   // error, instead of the healthy ones waiting in an all-gather for a rank that has left.
+  FB_TRY(vote_shard_order(h, n_nodes, n_tets, tets, n_ranks, rank, node_splits));  // (collective; before the rank-local build)
   const int rc_mine = build(h, n_nodes, xyz, n_tets, tets, n_fixed_dofs, fixed_dofs, n_ranks, rank, node_splits);
   const std::string why_mine = rc_mine == FB_OK ? std::string() : last_error();
   if (h->comm && h->comm->n_ranks > 1) {

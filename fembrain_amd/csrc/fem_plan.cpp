@@ -52,6 +52,49 @@ static int owner_of(const std::vector<int>& splits, int g) {
   return q;
 }
 
+void shard_neighbour_count(int n_nodes, int n_tets, const int* tets, int n_ranks, int rank, const int* splits, int* neighbours, unsigned long long* list_sum,
+                           int* splits_sum, int* own_elements, int* boundary_elements) {
+  *neighbours = -1; *list_sum = 0; *splits_sum = 0; *own_elements = 0; *boundary_elements = 0;
+  if (!tets || n_tets <= 0 || n_nodes <= 0 || n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks) return;
+  std::vector<int> sp((size_t)n_ranks + 1);
+  for (int i = 0; i <= n_ranks; i++) sp[i] = splits ? splits[i] : int((long long)n_nodes * i / n_ranks);
+  if (sp[0] != 0 || sp[n_ranks] != n_nodes) return;
+  for (int i = 0; i < n_ranks; i++)
+    if (sp[i + 1] <= sp[i]) return;
+  const int lo = sp[rank], hi = sp[rank + 1];
+  const int T = plan_threads(n_tets / 8);
+  std::vector<unsigned long long> masks((size_t)T, 0ULL), sums((size_t)T, 0ULL);
+  std::vector<int> bad((size_t)T, 0), n_own((size_t)T, 0), n_bnd((size_t)T, 0);
+  parallel_for(T, [&](int t) {
+    unsigned long long m = 0, sum = 0;
+    int own_e = 0, bnd_e = 0;
+    const int e0 = (int)((long long)n_tets * t / T), e1 = (int)((long long)n_tets * (t + 1) / T);
+    for (int e = e0; e < e1; e++) {
+      const int* v = tets + 4 * (size_t)e;
+      sum += (unsigned long long)(unsigned)v[0] * 0x9E3779B1ULL + (unsigned long long)(unsigned)v[1] * 0x85EBCA77ULL + (unsigned long long)(unsigned)v[2] * 0xC2B2AE3DULL +
+             (unsigned long long)(unsigned)v[3] * 0x27D4EB2FULL + (unsigned long long)e;
+      const bool own = (v[0] >= lo && v[0] < hi) || (v[1] >= lo && v[1] < hi) || (v[2] >= lo && v[2] < hi) || (v[3] >= lo && v[3] < hi);
+      if (!own) continue;
+      own_e++;
+      bool foreign = false;
+      for (int k = 0; k < 4; k++) {
+        if (v[k] < 0 || v[k] >= n_nodes) { bad[t] = 1; continue; }
+        if (v[k] >= lo && v[k] < hi) continue;
+        foreign = true;
+        m |= 1ULL << owner_of(sp, v[k]);
+      }
+      bnd_e += foreign ? 1 : 0;
+    }
+    masks[t] = m; sums[t] = sum; n_own[t] = own_e; n_bnd[t] = bnd_e;
+  });
+  unsigned long long m = 0;
+  bool any_bad = false;
+  for (int t = 0; t < T; t++) { m |= masks[t]; *list_sum += sums[t]; any_bad = any_bad || bad[t]; *own_elements += n_own[t]; *boundary_elements += n_bnd[t]; }
+  m &= ~(1ULL << rank);
+  if (!any_bad) *neighbours = __builtin_popcountll(m);
+  for (int i = 0; i <= n_ranks; i++) *splits_sum += sp[i] * (i + 1);
+}
+
 int plan_set_constraints(FemPlan& P, int n_fixed, const int* fixed_dofs) {
   const int r = 3 * P.n_global;
   for (int i = 0; i < n_fixed; i++) {

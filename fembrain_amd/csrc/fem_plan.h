@@ -81,5 +81,11 @@ int build_fem_partition(FemPlan& plan, int n_nodes, int n_tets, const int* tets,
 int begin_fem_partition(FemPlan& plan, int n_nodes, int n_tets, int n_ranks, int rank, const int* splits);
 void set_partition_halo(FemPlan& plan, const std::vector<int>& halo);
 int plan_set_constraints(FemPlan& plan, int n_fixed, const int* fixed_dofs);
+// What a rank's vote on the node order of a sharded handle is made of (fem.hip vote_shard_order): the number of OTHER ranks that the
+// elements with a node in this rank's range couple it to under the caller's numbering (-1: bad ranges or a node id outside the
+// mesh -- the builder reports those), a checksum of the whole element list as handed over, and one of the ranges; how many elements
+// have a node of this rank, and how many of those also have a node of another rank.  splits may be null (equal ranges).  At most 64 ranks.
+void shard_neighbour_count(int n_nodes, int n_tets, const int* tets, int n_ranks, int rank, const int* splits, int* neighbours, unsigned long long* list_sum,
+                           int* splits_sum, int* own_elements, int* boundary_elements);
 
 }  // namespace fb

@@ -83,4 +83,12 @@ int fb_plan_slab_order(int n_nodes, const double* xyz, int n_tets, const int* te
   return FB_OK;
 }
 
+int fb_plan_shard_vote(int n_nodes, int n_tets, const int* tets, int n_ranks, int rank, const int* node_splits, int out[3]) {
+  if (!tets || !out) return fb::fail(FB_EINVAL, "null argument");
+  unsigned long long sum = 0;
+  int splits_sum = 0;
+  fb::shard_neighbour_count(n_nodes, n_tets, tets, n_ranks, rank, node_splits, &out[0], &sum, &splits_sum, &out[1], &out[2]);
+  return FB_OK;
+}
+
 }  // extern "C"

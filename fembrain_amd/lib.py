@@ -148,6 +148,7 @@ def lib():
         "fb_comm_unique_id": (C.c_int, [_bp]),
         "fb_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _bp, C.c_int]),
         "fb_comm_destroy": (C.c_int, [vp]),
+        "fb_comm_info": (C.c_int, [vp, _ip, _ip, _ip]),
         "fb_comm_create_local": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_int]),
         "fb_comm_test_allgather": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_size_t]),
         "fb_fem_create_from_poly": (C.c_int, [C.POINTER(vp), vp, C.c_int, _ip, C.POINTER(FemParams)]),
@@ -157,6 +158,7 @@ def lib():
         "fb_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int, C.c_int, _ip]),
         "fb_plan_destroy": (C.c_int, [vp]),
         "fb_plan_slab_order": (C.c_int, [C.c_int, _dp, C.c_int, _ip, _ip, _ip, _ip]),
+        "fb_plan_shard_vote": (C.c_int, [C.c_int, C.c_int, _ip, C.c_int, C.c_int, _ip, _ip]),
         "fb_plan_info": (C.c_int, [vp, _ip]),
         "fb_plan_get": (C.c_int, [vp, C.c_char_p, _ip, C.c_size_t]),
     }

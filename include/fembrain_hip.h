@@ -102,9 +102,13 @@ typedef struct fb_fem_params {
  * (columns ascending in the caller's ids); elements keep their order.  Only the rounding of a row's sum in the SpMV changes with
  * the order of its columns.  AUTO renumbers meshes of >= 8,192 nodes whose widest element (largest id difference inside a tet)
  * exceeds min(32,767, nodes / 8) and keeps the caller's order when the slab order is not at least a quarter narrower.  On a sharded
- * handle (fb_fem_create_sharded) the renumbering is opt-in (ON), needs the whole mesh on every rank, and the rank then owns a
- * contiguous range of the INTERNAL order: fb_fem_owned_range reports that range, fb_fem_owned_nodes the caller ids in it, and the
- * state / force arrays are read and written at those nodes' positions. */
+ * handle (fb_fem_create_sharded) the renumbering needs the whole mesh on every rank, and the rank then owns a contiguous range of the
+ * INTERNAL order: fb_fem_owned_range reports that range, fb_fem_owned_nodes the caller ids in it, and the state / force arrays are
+ * read and written at those nodes' positions.  AUTO on a sharded handle is a collective decision taken before the build (creation
+ * and every re-sync): every rank counts the ranks its elements couple it to under the caller's ranges, and the ranks switch to the
+ * internal order together when some rank would have more than two neighbour ranks (or, from 8,192 nodes, most of its elements
+ * reaching into another rank's range) and every rank was handed the same whole mesh (sizes and a checksum of the element list are
+ * compared); ranks that were handed their own elements only keep the caller's numbering.  ON / OFF must be the same on every rank. */
 #define FB_RENUMBER_AUTO 0
 #define FB_RENUMBER_ON 1
 #define FB_RENUMBER_OFF (-1)
@@ -341,6 +345,10 @@ int fb_fem_assembly_bytes(fb_fem_t h, double* bytes);
 int fb_comm_unique_id(unsigned char id[128]);
 int fb_comm_create(fb_comm_t* out, int rank, int n_ranks, const unsigned char id[128], int device);
 int fb_comm_destroy(fb_comm_t c);
+/* what the communicator is made of: *ranks = its size, *rccl_ranks = the rank count the RCCL communicator itself reports
+ * (ncclCommCount; 0 when the communicator has no RCCL handle: the host-staged test transport), *transport = 0 none (one rank, no library),
+ * 1 RCCL, 2 host-staged test transport.  Any pointer may be NULL. */
+int fb_comm_info(fb_comm_t c, int* ranks, int* rccl_ranks, int* transport);
 
 /* ------------------------------------------------------------------------------------------------------
  * BlobTree field / polygonizer handle = the GPU side of PS::SKETCH::GPUPoly (implicit/OclPolygonizer.h:45-231)

@@ -27,6 +27,12 @@ int fb_plan_get(fb_plan_t p, const char* name, int* out, size_t capacity);
  * every internal id, and the widest element (largest id difference inside a tet) in the caller's and in that order */
 int fb_plan_slab_order(int n_nodes, const double* xyz, int n_tets, const int* tets, int* old_of_new, int* span_caller, int* span_internal);
 
+/* Host restatement of one rank's vote on the node order of a sharded handle under FB_RENUMBER_AUTO (fem.hip vote_shard_order): out[0] =
+ * the number of other ranks the elements with a node in this rank's range couple it to under the caller's numbering (-1: bad ranges
+ * or node ids), out[1] = elements with a node of this rank, out[2] = those that also have a node of another rank.  node_splits may be
+ * NULL (equal ranges). */
+int fb_plan_shard_vote(int n_nodes, int n_tets, const int* tets, int n_ranks, int rank, const int* node_splits, int out[3]);
+
 /* Host-staged communicator for tests: processes sharing ONE GPU (or none of them owning more than one) exchange through
  * the POSIX shared-memory segment `shm_name` with a process barrier per collective.  It drives exactly the sharded
  * solver path of fb_fem_create_sharded (halo lists, packing, rank-ordered sums) without RCCL, so the N > 1 path can be

@@ -438,6 +438,24 @@ def test_slab_order_finds_a_grid_again_and_gives_every_rank_two_neighbours():
                 worst = max(worst, int((np.diff(get("halo_off")) > 0).sum()))
                 L.fb_plan_destroy(h)
             assert (worst <= 2) if want_few else (worst == world - 1), (world, want_few, worst)
+            # what a rank votes with under FB_RENUMBER_AUTO (fem.hip vote_shard_order) is the neighbour count of its plan
+            for rank in range(world):
+                info, get, (_, h) = _plan(v, tets, [], world, rank)
+                vote = np.zeros(3, np.int32)
+                fl.check(L.fb_plan_shard_vote(len(v), len(tets), fl.iptr(tets), world, rank, None, fl.iptr(vote)))
+                assert vote[0] == int((np.diff(get("halo_off")) > 0).sum()) and vote[1] == info["n_tets"] and 0 < vote[2] <= vote[1]
+                assert (2 * vote[2] > vote[1]) != want_few or world == 7    # most elements reach into another rank <=> scrambled (7 ranks: thin slabs)
+                L.fb_plan_destroy(h)
+    bad = t.copy()
+    bad[5, 2] = len(v)          # (in an element of rank 0 or not: the range check is the builder's, the vote says "unknown")
+    vote = np.zeros(3, np.int32)
+    ranks_unknown = 0
+    for rank in range(4):
+        fl.check(L.fb_plan_shard_vote(len(v), len(bad), fl.iptr(bad), 4, rank, None, fl.iptr(vote)))
+        ranks_unknown += vote[0] == -1
+    assert ranks_unknown >= 1
+    fl.check(L.fb_plan_shard_vote(len(v), len(t), fl.iptr(t), 4, 1, fl.iptr(np.array([0, 10, 10, 20, len(v)], np.int32)), fl.iptr(vote)))
+    assert vote[0] == -1        # a rank without nodes
     # an already banded order is found again exactly: nothing to gain
     fl.check(L.fb_plan_slab_order(len(v0), fl.dptr(v0), len(t0), fl.iptr(np.ascontiguousarray(t0)), fl.iptr(o), C.byref(a), C.byref(b)))
     assert b.value <= a.value

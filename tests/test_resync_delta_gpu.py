@@ -344,3 +344,62 @@ def test_delta_resync_on_handles_of_every_kind(gpu, kw):
     _same_bits(g, ref, load=-300.0)
     g.close()
     ref.close()
+
+
+_SIGMA_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from fembrain_amd import lib as fl
+from fembrain_amd.fem import FemIntegrator
+from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, synthetic_cut, truth_cube
+n = 22
+v, t = truth_cube(n, n, n, 0.1)
+fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
+g = FemIntegrator(v, t, fixed, renumber=fl.FB_RENUMBER_ON)
+assert g.renumbering()[0]
+cv, ct = v, t
+for k, (axis, where, stride) in enumerate(((0, 0.6, 6), (2, 0.35, 6))):
+    cv, ct, d = synthetic_cut(cv, ct, axis=axis, where=where, every_changed=2, stride=stride)
+    assert 0 < len(d["new_xyz"]) and len(cv) * 10 < len(v) * 11, (len(d["new_xyz"]), len(cv), len(v))
+    g.resync_delta(d, fixed)
+    assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED, g.resync_path()
+    assert np.array_equal(g.tets, ct) and np.array_equal(g.verts, cv)
+    own = g.owned_nodes()
+    assert len(own) == len(cv) and np.array_equal(np.sort(own), np.arange(len(cv)))          # old_of_new is a permutation
+ref = FemIntegrator(v, t, fixed, renumber=fl.FB_RENUMBER_ON)
+ref.resync(cv, ct, fixed)
+assert ref.resync_path() == fl.FB_RESYNC_FULL and ref.renumbering()[0]
+bp, bc = g.pattern()
+rp, rc = ref.pattern()
+assert np.array_equal(bp, rp) and np.array_equal(bc, rc)
+u = np.random.default_rng(3).normal(size=g.r) * 0.003
+fa, Ka = g.assemble(u)
+fr, Kr = ref.assemble(u)
+assert np.abs(fa - fr).max() <= 1e-12 * np.abs(fr).max()
+assert np.abs(Ka - Kr).max() <= 2e-7 * np.abs(Kr).max()
+assert np.abs(g.mass() - ref.mass()).max() <= 1e-12 * np.abs(ref.mass()).max()
+for h in (g, ref):
+    h.set_uniform_force(1, -200.0)
+its = [g.do_timestep(), ref.do_timestep()]
+qa, qr = g.get_q_state()[0], ref.get_q_state()[0]
+assert abs(its[0] - its[1]) <= 2 and np.abs(qa - qr).max() <= 2e-5 * np.abs(qr).max() and not qa[fixed].any(), its
+print("sigma delta ok", its, g.renumbering(), ref.renumbering())
+"""
+
+
+def test_delta_resync_on_a_node_order_with_the_second_stage(gpu):
+    """the merged delta path on a handle whose internal order has the SECOND stage (rows sorted by element count
+    inside windows: k_delta_new_counts, k_delta_sigma_keys, the window-key lookup, key_bits = 10 + window bits).  FEMBRAIN_SIGMA is read
+    once per process, so the case runs in a process of its own with FEMBRAIN_SIGMA=1 from the start: renumber = ON, two merged deltas that
+    add nodes, then pattern (caller ids) exactly, K / f / mass and a step against a handle re-synced with the whole mesh, and the node
+    map is a permutation."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FEMBRAIN_SIGMA="1", FEMBRAIN_TIMING="1")
+    out = subprocess.run([sys.executable, "-c", _SIGMA_SCRIPT, root], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    assert "sigma delta ok" in out.stdout
+    assert "rows sorted by element count inside windows" in out.stderr      # the second stage really ran

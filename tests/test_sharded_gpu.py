@@ -31,8 +31,9 @@ def _mesh(n, world):
     return v, t, fixed, np.array([(-n) * r // world for r in range(world + 1)], np.int32)
 
 
-def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False, spmv=0):
-    """p2p: 0 = host-staged test communicator, else the peer-to-peer exchange mode (lib.FB_XCH_P2P / _SUMS / _FUSED)."""
+def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False, spmv=0, renumber=0):
+    """p2p: 0 = host-staged test communicator, else the peer-to-peer exchange mode (lib.FB_XCH_P2P / _SUMS / _FUSED).
+    renumber: FB_RENUMBER_* of the handle (0 = AUTO: the ranks vote on the node order before they build)."""
     try:
         if p2p:
             os.environ["FEMBRAIN_P2P"] = "1"
@@ -45,7 +46,7 @@ def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False
         comm = C.c_void_p()
         fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
         v, t, fixed, splits = _mesh(n, world)
-        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), pcg_variant=variant, spmv_kernel=spmv)
+        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), pcg_variant=variant, spmv_kernel=spmv, renumber=renumber)
         assert L.fb_fem_transport(g.h) == (p2p if p2p else 1), L.fb_fem_transport(g.h)
         if quit_early and rank == world - 1:   # a rank that stops taking part: the others must time out, not hang
             q.put((rank, "left", None, None, 0, 0))
@@ -60,8 +61,12 @@ def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False
             g.set_external_forces(f)
             its.append(g.do_timestep())
         qq, vv, _ = g.get_q_state()
-        lo, hi = 3 * int(splits[rank]), 3 * int(splits[rank + 1])
-        q.put((rank, its, qq[lo:hi].copy(), vv[lo:hi].copy(), lo, hi))
+        # the nodes this rank owns: its range of the caller's ids, or -- when the ranks voted for the internal order -- whatever
+        # fb_fem_owned_nodes lists
+        own = g.owned_nodes()
+        dofs = (3 * own[:, None].astype(np.int64) + np.arange(3)[None, :]).reshape(-1)
+        info = (bool(g.renumbering()[0]),) + tuple(g.halo_info())
+        q.put((rank, its, qq[dofs].copy(), vv[dofs].copy(), dofs, info))
         g.close()
         L.fb_comm_destroy(comm)
     except Exception as e:  # surface the failure instead of hanging the peers' barrier forever
@@ -219,11 +224,30 @@ def test_sharded_ranks_with_the_row_kernel(gpu, world, variant, p2p):
 
 @pytest.mark.parametrize("world,p2p", [(2, 0), (3, 2), (3, 4), (4, 4)])
 def test_sharded_unstructured_mesh_all_to_all_halos(gpu, world, p2p):
-    """Delaunay mesh in random node order cut into equal index ranges: every rank is every other rank's neighbour."""
-    _run_sharded(world, 0, p2p, -900)
+    """Delaunay mesh in random node order cut into equal index ranges, the caller's numbering KEPT (FB_RENUMBER_OFF): every rank is
+    every other rank's neighbour."""
+    from fembrain_amd import lib as fl
+    info = _run_sharded(world, 0, p2p, -900, renumber=fl.FB_RENUMBER_OFF)
+    assert all(not on and nbr == world - 1 for on, halo, nbr in info), info
 
 
-def _run_sharded(world, variant, p2p, n, spmv=0):
+@pytest.mark.parametrize("world,p2p", [(4, 0), (4, 4), (5, 2)])
+def test_auto_node_order_on_shards_gives_slabs_without_being_asked(gpu, world, p2p):
+    """VERDICT r4 item 1 / SURVEY 8e: FB_RENUMBER_AUTO (the default) on a sharded handle.  The same Delaunay mesh in random node order:
+    equal ranges of the caller's ids would give every rank world - 1 neighbours, so the ranks vote for the internal slab order before
+    they build (no FB_RENUMBER_ON, no environment variable) and each ends up with at most two neighbour ranks; the steps gathered
+    through fb_fem_owned_nodes equal the unsharded handle's."""
+    info = _run_sharded(world, 0, p2p, -900)
+    assert all(on and nbr <= 2 for on, halo, nbr in info), info
+
+
+def test_auto_node_order_leaves_plane_slabs_alone(gpu):
+    """a cube numbered plane by plane and cut at planes: two neighbours at most under the caller's numbering, nothing to vote for"""
+    info = _run_sharded(4, 0, 4, 12)
+    assert all(not on and nbr <= 2 for on, halo, nbr in info), info
+
+
+def _run_sharded(world, variant, p2p, n, spmv=0, renumber=0):
     """p2p != 0: the direct inbox transport (HIP IPC mapped inboxes, kernels that store into the peer's inbox and spin --
     bounded -- on their own flags) between processes that share the GPU, in its three forms: an own kernel per exchange
     (2), sums inside the PCG kernels (3), sums and halo values inside the PCG kernels (4)."""
@@ -233,7 +257,7 @@ def _run_sharded(world, variant, p2p, n, spmv=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     name = "/fembrain_test_%d_%d_%d_%d" % (os.getpid(), world, variant, int(p2p))
-    procs = [ctx.Process(target=_worker, args=(r, world, name, n, variant, steps, q, p2p, False, spmv)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, name, n, variant, steps, q, p2p, False, spmv, renumber)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
@@ -257,13 +281,17 @@ def _run_sharded(world, variant, p2p, n, spmv=0):
         its.append(g.do_timestep())
     qs, vs, _ = g.get_q_state()
     qg, vg = np.zeros_like(qs), np.zeros_like(vs)
-    for rank, rits, qq, vv, lo, hi in res:
+    seen = np.zeros(len(qs), int)
+    for rank, rits, qq, vv, dofs, info in res:
         assert rits == res[0][1]                                  # every rank stopped at the same iteration
         assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its))
-        qg[lo:hi], vg[lo:hi] = qq, vv
+        qg[dofs], vg[dofs] = qq, vv
+        seen[dofs] += 1
+    assert (seen == 1).all()                                      # the ranks' owned nodes partition the mesh
     # rank-ordered partial sums instead of one block-ordered sum: same iterates up to rounding
     assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
     assert np.abs(vg - vs).max() <= 1e-5 * np.abs(vs).max()
+    return [r[5] for r in sorted(res, key=lambda r: r[0])]
 
 
 def _bench_worker(rank, world, shm_name, n, q):
