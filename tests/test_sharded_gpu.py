@@ -16,6 +16,9 @@ def _mesh(n, world):
     """n > 0: truth cube split into i-plane slabs; n < 0: Delaunay tetrahedra of |n| random points in RANDOM node order split
     into equal index ranges -- every rank neighbours every other and the halos are large and irregular."""
     from fembrain_amd.meshgen import cube_fixed_plane_i0, fixed_vertices_to_dofs, truth_cube
+    if n > 1000:   # the (n - 1000)^3 cube with its node ids randomly permuted, equal index ranges: every rank neighbours every other
+        v, t, fixed = _scrambled_cube(n - 1000)
+        return v, t, fixed, np.array([len(v) * r // world for r in range(world + 1)], np.int32)
     if n > 0:
         v, t = truth_cube(n, n, n, 0.1)
         fixed = fixed_vertices_to_dofs(cube_fixed_plane_i0(n, n))
@@ -55,7 +58,7 @@ def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False
             os._exit(0)
         f = np.zeros(g.r)
         f[1::3] = -10000.0 if n > 0 else -200.0
-        f[0::3] = (300.0 if n > 0 else 20.0) * np.sin(np.arange(len(v)))   # not symmetric across the slabs
+        f[0::3] = (300.0 if n > 0 else 20.0) * np.sin(np.arange(len(v)))   # not symmetric across the slabs (a function of the caller's ids)
         its = []
         for _ in range(steps):
             g.set_external_forces(f)
@@ -80,6 +83,19 @@ def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False
                                                (2, 0, 2), (3, 0, 3), (2, 0, 4), (4, 0, 4), (3, 1, 4), (4, 1, 2)])
 def test_sharded_ranks_on_one_gpu_match_the_unsharded_handle(gpu, world, variant, p2p):
     _run_sharded(world, variant, p2p, 12)
+
+
+def _own_dofs(g):
+    own = g.owned_nodes()
+    return (3 * own[:, None].astype(np.int64) + np.arange(3)[None, :]).reshape(-1)
+
+
+def _put(qg, qq, lo, hi):
+    """a rank's values into the gathered vector: a range, or (hi None) the DOFs fb_fem_owned_nodes listed"""
+    if hi is None:
+        qg[lo] = qq
+    else:
+        qg[lo:hi] = qq
 
 
 def _scrambled_cube(n):
@@ -233,12 +249,22 @@ def test_sharded_unstructured_mesh_all_to_all_halos(gpu, world, p2p):
 
 @pytest.mark.parametrize("world,p2p", [(4, 0), (4, 4), (5, 2)])
 def test_auto_node_order_on_shards_gives_slabs_without_being_asked(gpu, world, p2p):
-    """VERDICT r4 item 1 / SURVEY 8e: FB_RENUMBER_AUTO (the default) on a sharded handle.  The same Delaunay mesh in random node order:
-    equal ranges of the caller's ids would give every rank world - 1 neighbours, so the ranks vote for the internal slab order before
-    they build (no FB_RENUMBER_ON, no environment variable) and each ends up with at most two neighbour ranks; the steps gathered
-    through fb_fem_owned_nodes equal the unsharded handle's."""
-    info = _run_sharded(world, 0, p2p, -900)
-    assert all(on and nbr <= 2 for on, halo, nbr in info), info
+    """VERDICT r4 item 1 / SURVEY 8e: FB_RENUMBER_AUTO (the default) on a sharded handle.  A 12^3 cube whose node ids are a random
+    permutation: equal ranges of the caller's ids would give every rank world - 1 neighbours and half the mesh as halo, so the ranks vote
+    for the internal slab order before they build (no FB_RENUMBER_ON, no environment variable) and each ends up with at most two neighbour
+    ranks and a halo of a plane or two; the steps gathered through fb_fem_owned_nodes equal the unsharded handle's."""
+    info = _run_sharded(world, 0, p2p, 1012)
+    assert all(on and nbr <= 2 and halo <= 2 * (144 + 13) for on, halo, nbr in info), info
+
+
+def test_auto_node_order_on_an_unstructured_mesh(gpu):
+    """the Delaunay mesh of 900 random points in random order on 4 ranks: the vote switches the internal order on and the halos shrink
+    (hull slivers still join far slabs, so a rank may keep a third neighbour -- with a handful of nodes)"""
+    from fembrain_amd import lib as fl
+    off = _run_sharded(4, 0, 0, -900, renumber=fl.FB_RENUMBER_OFF)
+    auto = _run_sharded(4, 0, 0, -900)
+    assert all(on for on, halo, nbr in auto) and not any(on for on, halo, nbr in off)
+    assert sum(h for _, h, _ in auto) < 0.6 * sum(h for _, h, _ in off), (auto, off)
 
 
 def test_auto_node_order_leaves_plane_slabs_alone(gpu):
@@ -456,7 +482,8 @@ def _plan_worker(rank, world, shm_name, n, q):
         comm = C.c_void_p()
         fl.check(L.fb_comm_create_local(C.byref(comm), rank, world, shm_name.encode(), 8 << 20, 0))
         v, t, fixed, splits = _mesh(n, world)
-        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm))
+        # (the plan in the CALLER's numbering is what is compared: the vote of FB_RENUMBER_AUTO would give the unstructured meshes an internal order)
+        g = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), renumber=fl.FB_RENUMBER_OFF)
         assert L.fb_fem_plan_on_device(g.h) == 1
         hp = C.c_void_p()
         tt, fd = np.ascontiguousarray(t, np.int32).reshape(-1), np.ascontiguousarray(fixed, np.int32)
@@ -479,7 +506,7 @@ def _plan_worker(rank, world, shm_name, n, q):
         t0 = time.perf_counter()
         g.resync(v, t, fixed, node_splits=splits)
         resync_ms = (time.perf_counter() - t0) * 1e3
-        fresh = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm))
+        fresh = FemIntegrator(v, t, fixed, shard=(world, rank, splits, comm), renumber=fl.FB_RENUMBER_OFF)
         # per-rank ingest: only the elements with an owned node (ascending global order), positions of other ranks' nodes poisoned
         own = ((t >= splits[rank]) & (t < splits[rank + 1])).any(axis=1)
         vown = np.full_like(v, np.nan)
@@ -654,8 +681,8 @@ def _shard_persist_worker(rank, world, shm_name, n, steps, q, cut=None, timeout_
             its.append(g.do_timestep())
             paths.append(int(g.last.pcg_path))
         qq = g.get_q_state()[0]
-        lo, hi = 3 * int(splits[rank]), 3 * int(splits[rank + 1])
-        q.put((rank, its, qq[lo:hi].copy(), g.pcg_path(), paths, g.persist_info(), lo, hi))
+        lo, hi = _own_dofs(g), None     # (the rank's own nodes: a range of the caller's ids unless the ranks voted for the internal order)
+        q.put((rank, its, qq[lo].copy(), g.pcg_path(), paths, g.persist_info(), lo, hi))
         g.close()
         L.fb_comm_destroy(comm)
     except Exception as e:
@@ -717,7 +744,7 @@ def test_sharded_persistent_solver_on_disjoint_cus_matches_the_unsharded_handle(
         assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its)), (rits, its)
         assert path["kernel"] == kernel and path["fallbacks"] == 0 and all(p == fl.FB_PCG_PATH_PERSISTENT for p in paths), (rank, path, paths)
         assert info[0] and info[2] == 256 // world // 32 * 32, info
-        qg[lo:hi] = qq
+        _put(qg, qq, lo, hi)
     # the Delaunay mesh has sliver tets: fp32 matrix entries summed in another order move its solution by 3e-5 (the two-launch sharded
     # path sits 3.0e-5 from the unsharded handle at eps 1e-8, this one 3.2e-5, the two sharded paths 1e-5 from each other)
     assert np.abs(qg - qs).max() <= (1e-6 if n > 0 else 1e-4) * np.abs(qs).max()
@@ -761,7 +788,7 @@ def test_sharded_persistent_solver_that_times_out_falls_back_on_every_rank(gpu):
     for rank, rits, qq, path, paths, info, lo, hi in res:
         assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its)), (rits, its)
         assert path["fallbacks"] == 1 and paths == [fl.FB_PCG_PATH_FALLBACK, fl.FB_PCG_PATH_TWO_LAUNCH], (rank, path, paths)
-        qg[lo:hi] = qq
+        _put(qg, qq, lo, hi)
     assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
 
 
@@ -800,7 +827,7 @@ def test_sharded_persistent_solver_under_the_newmark_integrator_keeps_the_warm_s
     for rank, rits, qq, path, paths, info, lo, hi in res:
         assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its)), (rits, its)
         assert path["kernel"] == "k_pcg_pipe_shard<8,8>" and path["fallbacks"] == 0 and all(p == fl.FB_PCG_PATH_PERSISTENT for p in paths), (rank, path, paths)
-        qg[lo:hi] = qq
+        _put(qg, qq, lo, hi)
     assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
 
 
@@ -842,7 +869,7 @@ def test_sharded_persistent_solver_survives_a_collective_resync(gpu):
     for rank, rits, qq, path, paths, info, lo, hi in res:
         assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its)), (rits, its)
         assert path["kernel"] == "k_pcg_pipe_shard<8,8>" and path["fallbacks"] == 0 and all(p == fl.FB_PCG_PATH_PERSISTENT for p in paths), (rank, path, paths)
-        qg[lo:hi] = qq
+        _put(qg, qq, lo, hi)
     assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
 
 
@@ -921,7 +948,7 @@ def test_sharded_persistent_solver_across_resyncs_that_cross_its_limits(gpu):
             assert rn == n and abs(rit - it) <= max(2, 0.01 * it) and fallbacks == 0, (rank, k, rit, it, fallbacks)
             assert on == (n == 40) and (path == fl.FB_PCG_PATH_PERSISTENT) == (n == 40), (rank, n, on, path)
             assert kernel == ("k_pcg_pipe_shard<8,8>" if n == 40 else ""), (rank, n, kernel)
-            qg[lo:hi] = qq
+            _put(qg, qq, lo, hi)
         assert np.abs(qg - qs).max() <= 2e-6 * np.abs(qs).max(), (n, np.abs(qg - qs).max() / np.abs(qs).max())
     g.close()
 
@@ -963,6 +990,6 @@ def test_sharded_persistent_ranks_with_different_kernels_interoperate(gpu):
         assert all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(rits, its)), (rits, its)
         assert path["fallbacks"] == 0 and all(p == fl.FB_PCG_PATH_PERSISTENT for p in paths), (rank, path, paths)
         kernels[rank] = path["kernel"]
-        qg[lo:hi] = qq
+        _put(qg, qq, lo, hi)
     assert kernels == {0: "k_pcg_pipe_shard<12,6>", 1: "k_pcg_pipe2_shard"}, kernels
     assert np.abs(qg - qs).max() <= 1e-6 * np.abs(qs).max()
