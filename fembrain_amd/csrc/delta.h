@@ -4,11 +4,12 @@
 // the cell list keeping the order of the rest (VolMesh::remove_cell_core, src/deformable/VolMesh.cpp:630: m_vCells.erase), the pieces
 // and the new nodes are appended (insert_cell / insert_node: push_back, :1083-1088), and an edge split re-points the cells on that edge
 // in place (:1630-1650).  Deformable::syncForceModel (src/deformable/Deformable.cpp:127-220) then rebuilds everything from the whole
-// mesh.  Here the element list and the rest positions stay on the device between re-syncs, the change is applied to them there, and
-// the sorted (row, column) -> contribution list the plan was built from (plan_device.hip) is UPDATED -- pairs of removed and changed
-// elements dropped, element ids renumbered (a monotone map: the order stands), the pairs of changed and added elements sorted among
-// themselves and merged in -- instead of sorted again.  The rest of the plan builder runs on the same list a full rebuild would have
-// sorted, so the plan comes out bit for bit the same.
+// mesh.  Here the element list, the rest positions and the PLAN stay on the device between re-syncs and the change is applied to them
+// there: the block pattern (CSR: bptr, bcol and the pairs of every block) keeps the rows no element of the change touches -- columns
+// through the monotone node map -- and merges the few others with the sorted pairs of the changed and added elements; the SELL layout is
+// laid out again from the pattern (plan_layout_from_csr, the second half of the builder); the contribution table is written from the old
+// table with the element ids renumbered.  The plan is the same function of the same mesh as a full rebuild's and comes out bit for bit
+// the same (round 4 updated the sorted pair list the builder starts from and ran five passes over it again; see delta.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,10 +31,17 @@ struct MeshDelta {
   DevBuf<double> new_xyz;           // rest positions of the appended nodes
   DevBuf<unsigned char> estate;     // per old element: 0 kept, 1 removed, 2 changed
   DevBuf<int> pos;                  // per old element: its new id (elements before it that stay)
-  DevBuf<unsigned long long> nk, nks;  // keys of the new pairs, unsorted / sorted
+  DevBuf<unsigned long long> nk, nks;  // keys of the new pairs (new row << 32 | new column), unsorted / sorted
   DevBuf<uint32_t> nv, nvs;
-  DevBuf<int> tile_i;               // delta_sorted_pairs: per tile of the old list -- entries that go, prefix sums of those that stay, bounds in the new entries
-  DevBuf<unsigned int> drop_bits;   // ... a bit per entry of the old list: it goes
+  DevBuf<int> newid;                // per old element: its new id, -1 if its contributions go (removed, or changed: those come back as new pairs)
+  DevBuf<int> oldrow;               // per new row: the old row, -1 for a new node (renumbered handles with new nodes)
+  DevBuf<unsigned int> touched;     // a bit per new row: it loses or gains contributions
+  DevBuf<int> len;                  // new row lengths
+  DevBuf<int> src;                  // per new block: the old block its kept words come from, -1 none
+  // the plan being built next to the handle's (swapped in when it is complete)
+  DevBuf<int> bptr2, bcol2, blk_slot2, slice_off2, slot_coff2;
+  DevBuf<unsigned int> ucnt2;
+  DevBuf<uint32_t> contrib2;
   bool mapped = false;              // delta_node_order ran for this change: imap / newint / node_keys are its
   DevBuf<int> new_count;            // elements of the change on every new node
   DevBuf<int> imap, newint;         // renumbered handles: old internal id -> new internal id; new node k -> its internal id
@@ -55,9 +63,14 @@ int delta_node_order(hipStream_t s, MeshDelta& D, int n_old, const SlabKeyGeom& 
                      DevBuf<int>& old_of_new, DevBuf<int>& new_of_old, PlanWorkspace& W, int n_windows, const unsigned long long* win_keys);
 // rest positions in the new internal order
 int delta_positions(hipStream_t s, const MeshDelta& D, int n_old, const double* x0_old, double* x0_new);
-// The sorted pair list of the workspace, updated (see the header comment).  tets_old: the old element list in the old internal ids (the
-// entries of removed and changed elements are found by their keys); tets_new: the new element list in the new internal ids;
-// span: its widest element (decides the key width).  On return W.sorted describes the new list in W.keys_s / W.vals_s.
-int delta_sorted_pairs(hipStream_t s, MeshDelta& D, const int4* tets_old, const int4* tets_new, int n_nodes_new, int span, PlanWorkspace& W);
+// The plan the handle holds (OldPlanArrays: device pointers of the CURRENT plan, n_nodes / n_blocks its sizes), updated to the new mesh.
+// tets_old: the old element list in the old internal ids; tets_new: the new list in the new internal ids.  Builds into D's second set of
+// buffers and into out.colidx / slot_ccnt / coldelta (which nothing reads any more); the caller swaps bptr2 ... contrib2 with its own.
+// out.bptr etc. must point at D.bptr2 ...; fills out.n_blocks, n_slices, n_slots, n_crows, deltas_fit16, slice_off_host.
+struct OldPlanArrays {
+  const int* bptr; const int* bcol; const unsigned int* ucnt; const int* slice_off; const int* slot_coff; const uint32_t* contrib;
+  int n_nodes, n_blocks;
+};
+int delta_plan(hipStream_t s, MeshDelta& D, const OldPlanArrays& old_plan, const int4* tets_old, const int4* tets_new, int n_nodes_new, DevicePlan& out, PlanWorkspace& W);
 
 }  // namespace fb

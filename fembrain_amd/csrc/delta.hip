@@ -15,7 +15,6 @@ namespace fb {
 namespace {
 
 constexpr int kB = 256;
-constexpr uint32_t kDropped = 0xFFFFFFFEu;  // (no contribution word: element ids stay below 2^28)
 
 inline int pad4(int x) { return (x + 3) & ~3; }
 inline dim3 grid_for(long long n) { return dim3((unsigned)std::max<long long>(1, (n + kB - 1) / kB)); }
@@ -26,9 +25,6 @@ __global__ __launch_bounds__(kB) void k_delta_mark(int n_removed, const int* __r
   else if (i < n_removed + n_changed) estate[changed[i - n_removed]] = 2;
 }
 
-struct TileKept {
-  __device__ int operator()(int gone) const { return 2048 - gone; }  // (kTile)
-};
 struct Stays {
   __device__ int operator()(unsigned char st) const { return st != 1 ? 1 : 0; }
 };
@@ -141,221 +137,208 @@ __global__ __launch_bounds__(kB) void k_delta_positions(int n_old, int n_new, co
   else x0_new[3 * (size_t)(newint ? newint[node - n_old] : node) + k] = new_xyz[3 * (size_t)(node - n_old) + k];
 }
 
-// ---- the pair list ----
-struct PackDesc { int narrow, cb, span, col_bits; };
-__device__ __forceinline__ void unpack_key(const PackDesc& p, unsigned long long k, int& row, int& col) {
-  if (p.narrow) {
-    row = (int)(k >> p.cb);
-    col = row + (int)(k & ((1ULL << p.cb) - 1ULL)) - p.span;
-  } else {
-    row = (int)(k >> p.col_bits);
-    col = (int)(k & ((1ULL << p.col_bits) - 1ULL));
-  }
-}
-__device__ __forceinline__ unsigned long long pack_key(const PackDesc& p, int row, int col) {
-  return p.narrow ? (((unsigned long long)(unsigned int)row << p.cb) | (unsigned long long)(unsigned int)(col - row + p.span))
-                  : (((unsigned long long)(unsigned int)row << p.col_bits) | (unsigned long long)(unsigned int)col);
-}
-
-// an entry of the old list in the terms of the new one: nodes through imap, the element by its new id, the key in the new packing;
-// entries of removed and changed elements are marked for the selection to drop
-template <typename KIn, typename KOut>
-struct PairXform {
-  PackDesc in, out;
-  const int* imap;
-  const unsigned char* estate;
-  const int* pos;
-  __device__ rocprim::tuple<KOut, uint32_t> operator()(const rocprim::tuple<KIn, uint32_t>& t) const {
-    const uint32_t v = rocprim::get<1>(t);
-    int row, col;
-    unpack_key(in, (unsigned long long)rocprim::get<0>(t), row, col);
-    if (imap) { row = imap[row]; col = imap[col]; }
-    uint32_t vo = v;
-    if (v != kNoContrib) {
-      const uint32_t e = v >> 4;
-      vo = estate[e] ? kDropped : (((uint32_t)pos[e] << 4) | (v & 15u));
-    }
-    return rocprim::make_tuple((KOut)pack_key(out, row, col), vo);
-  }
+// ---- the plan from the plan (round 5) --------------------------------------------------------------------------------------------
+// Round 4 updated the SORTED PAIR LIST the plan was built from and ran the rest of the builder (run lengths, rows, SELL layout, contribution
+// table) over all of it again: five passes over 142 MB at 1.1M tets, 0.4 of the 0.8 ms of kernels.  Now the plan itself is the state that
+// is updated: the block pattern in CSR form with the length of every block's contribution list (bptr, bcol, ucnt: 20 MB), and the
+// contribution table.  Rows no element of the change touches keep their blocks (columns through the monotone node map); the few rows that
+// lose or gain contributions are merged one by one with the sorted pairs of the changed and added elements (thousands against millions); the
+// table is written once from the old one with the element ids renumbered on the way.  The result is the full rebuild's plan bit for bit
+// (tests/test_resync_delta_gpu.py), because it is the same function of the same mesh: blocks = vertex pairs of the elements + one
+// marker per node, a block's list = its (element, i, j) words ascending.
+struct OldPlan {
+  const int* bptr; const int* bcol; const unsigned int* ucnt; const int* slice_off; const int* slot_coff; const uint32_t* contrib;
+  int n_nodes;
 };
-struct NotDropped {
-  template <typename T>
-  __device__ bool operator()(const T& t) const { return rocprim::get<1>(t) != kDropped; }
+struct FreshPairs { const unsigned long long* k; const uint32_t* v; int n; };  // key = new row << 32 | new column, sorted by (key, word)
+struct RowMaps {
+  const int* oldrow;             // new row -> old row, -1 for a new node; nullptr: identity below n_old, new nodes behind
+  const int* imap;               // old node -> new node (monotone); nullptr: identity
+  const int* newid;              // old element -> new id, -1 if its contributions go (removed or changed)
+  const unsigned int* touched;   // a bit per NEW row: it loses or gains contributions
+  int n_old;
 };
-// (row, column), then the contribution word: ascending (element, i, j) inside a block, the marker of a diagonal block last
-struct PairLess {
-  template <typename T>
-  __device__ bool operator()(const T& a, const T& b) const {
-    return rocprim::get<0>(a) < rocprim::get<0>(b) || (rocprim::get<0>(a) == rocprim::get<0>(b) && rocprim::get<1>(a) < rocprim::get<1>(b));
-  }
-};
-
-// the 16 pairs of every changed and added element, ascending in the new element id (changed ones keep an id below every added one), then
-// the markers of the new nodes
-template <typename KOut>
-__global__ __launch_bounds__(kB) void k_delta_new_pairs(int n_changed, int n_added, int n_new_nodes, int n_kept, int n_nodes_old, PackDesc out, const int* __restrict__ changed_ids,
-                                                        const int* __restrict__ pos, const int4* __restrict__ tets_new, const int* __restrict__ newint, KOut* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals) {
-  const long long i = (long long)blockIdx.x * kB + threadIdx.x;
-  const long long n_tp = 16LL * (n_changed + n_added);
-  if (i < n_tp) {
-    const int m = (int)(i >> 4), ij = (int)(i & 15);
-    const int e = m < n_changed ? pos[changed_ids[m]] : n_kept + (m - n_changed);
-    const int4 t = tets_new[e];
-    const int id[4] = {t.x, t.y, t.z, t.w};
-    keys[i] = (KOut)pack_key(out, id[ij >> 2], id[ij & 3]);
-    vals[i] = ((uint32_t)e << 4) | (uint32_t)ij;
-  } else if (i < n_tp + n_new_nodes) {
-    const int k = (int)(i - n_tp);
-    const int r = newint ? newint[k] : n_nodes_old + k;
-    keys[i] = (KOut)pack_key(out, r, r);
-    vals[i] = kNoContrib;
-  }
-}
-
-// ---- the update of the list in two passes of our own (the library's select over a transforming zip iterator took 490 us at 1M tets,
-// its merge another 110): tiles of kTile old entries; pass 1 marks the entries that go and counts them per tile; pass 2 ranks the others
-// (tile base + rank inside the tile) and puts the new entries that fall between two of them in their places.  New entries below the
-// first or above the last old entry are copied by k_upd_ends.
-constexpr int kTile = 2048, kTileItems = kTile / kB;
-template <typename K>
-__device__ __forceinline__ bool pair_less(K ka, uint32_t va, K kb, uint32_t vb) { return ka < kb || (ka == kb && va < vb); }
-
-template <typename KIn, typename KOut>
-__device__ __forceinline__ void xform_entry(const PackDesc& in, const PackDesc& out, const int* __restrict__ imap, const int* __restrict__ pos, KIn k, uint32_t v, KOut* ko,
-                                            uint32_t* vo) {
-  int row, col;
-  unpack_key(in, (unsigned long long)k, row, col);
-  if (imap) { row = imap[row]; col = imap[col]; }
-  *ko = (KOut)pack_key(out, row, col);
-  *vo = v == kNoContrib ? v : (((uint32_t)pos[v >> 4] << 4) | (v & 15u));
-}
-
-template <typename K>
-__device__ __forceinline__ int lower_bound_pairs(const K* __restrict__ k, const uint32_t* __restrict__ v, int lo, int hi, K key, uint32_t val) {
-  while (lo < hi) {  // first index whose entry is not less than (key, val)
+__device__ __forceinline__ int old_row_of(const RowMaps& M, int rn) { return M.oldrow ? M.oldrow[rn] : (rn < M.n_old ? rn : -1); }
+__device__ __forceinline__ bool row_touched(const RowMaps& M, int rn) { return (M.touched[rn >> 5] >> (rn & 31)) & 1u; }
+__device__ __forceinline__ int fresh_lower(const FreshPairs& F, unsigned long long key) {
+  int lo = 0, hi = F.n;
+  while (lo < hi) {
     const int mid = (lo + hi) >> 1;
-    if (pair_less<K>(k[mid], v[mid], key, val)) lo = mid + 1; else hi = mid;
+    if (F.k[mid] < key) lo = mid + 1; else hi = mid;
   }
   return lo;
 }
+// contribution words of old block p (row r) whose element goes
+__device__ __forceinline__ int dropped_words(const OldPlan& C, const RowMaps& M, int p, int r) {
+  const int k = p - C.bptr[r], slot = C.slice_off[r >> 6] + k;
+  const int n = (int)C.ucnt[p] - (C.bcol[p] == r ? 1 : 0);
+  const uint32_t* w = C.contrib + (size_t)C.slot_coff[slot] * 64 + (r & 63);
+  int gone = 0;
+  for (int t = 0; t < n; t++) gone += M.newid[w[(size_t)t * 64] >> 4] < 0 ? 1 : 0;
+  return gone;
+}
+// The blocks of NEW row rn in ascending column order: visit(column, pairs incl. the marker, old block or -1, fresh entries [f0, f1)).
+template <class V>
+__device__ __forceinline__ void walk_row(const OldPlan& C, const FreshPairs& F, const RowMaps& M, int rn, V& visit) {
+  const int r = old_row_of(M, rn);
+  int p = r >= 0 ? C.bptr[r] : 0;
+  const int pe = r >= 0 ? C.bptr[r + 1] : 0;
+  int f = fresh_lower(F, (unsigned long long)(unsigned int)rn << 32);
+  const int fe = fresh_lower(F, (unsigned long long)((unsigned int)rn + 1u) << 32);
+  while (p < pe || f < fe) {
+    const int co = p < pe ? (M.imap ? M.imap[C.bcol[p]] : C.bcol[p]) : 0x7fffffff;
+    const int cf = f < fe ? (int)(unsigned int)(F.k[f] & 0xFFFFFFFFULL) : 0x7fffffff;
+    const int c = min(co, cf);
+    int src = -1, cnt = 0;
+    if (co == c) { src = p; cnt = (int)C.ucnt[p] - dropped_words(C, M, p, r); p++; }
+    const int f0 = f;
+    if (cf == c) while (f < fe && (int)(unsigned int)(F.k[f] & 0xFFFFFFFFULL) == c) f++;
+    cnt += f - f0;
+    if (cnt > 0) visit(c, cnt, src, f0, f);
+  }
+}
 
-// Pass 1: the entries that go are FOUND rather than looked for -- the 16 entries of every removed or changed element sit at (row, column,
-// element << 4 | ij) of the old list: a binary search each, a bit in `drop`, a count per tile (a pass over the whole list that asked every
-// entry whether its element stays took 87 us at 1.1M tets; this one 290,000 searches).  tets_old: the old element list in the old ids.
-template <typename KIn>
-__global__ __launch_bounds__(kB) void k_upd_dropped(int n_removed, const int* __restrict__ removed, int n_changed, const int* __restrict__ changed, const int4* __restrict__ tets_old,
-                                                    PackDesc in, int n_a, const KIn* __restrict__ ka, const uint32_t* __restrict__ va, unsigned int* __restrict__ drop) {
+__global__ __launch_bounds__(kB) void k_newid(int n_old, const unsigned char* __restrict__ estate, const int* __restrict__ pos, int* __restrict__ newid) {
+  const int e = blockIdx.x * kB + threadIdx.x;
+  if (e < n_old) newid[e] = estate[e] ? -1 : pos[e];
+}
+__global__ __launch_bounds__(kB) void k_oldrow(int n_old, int n_new_nodes, const int* __restrict__ imap, const int* __restrict__ newint, int* __restrict__ oldrow) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i < n_old) oldrow[imap[i]] = i;
+  else if (i < n_old + n_new_nodes) oldrow[newint[i - n_old]] = -1;
+}
+// rows of the fresh pairs, and the rows of the elements that go (their old nodes through the node map)
+__global__ __launch_bounds__(kB) void k_touch(int n_fresh, const unsigned long long* __restrict__ fk, int n_gone, const int* __restrict__ removed, int n_removed,
+                                              const int* __restrict__ changed, const int4* __restrict__ tets_old, const int* __restrict__ imap, unsigned int* __restrict__ touched) {
   const long long i = (long long)blockIdx.x * kB + threadIdx.x;
-  if (i >= 16LL * (n_removed + n_changed)) return;
-  const int m = (int)(i >> 4), ij = (int)(i & 15);
-  const int e = m < n_removed ? removed[m] : changed[m - n_removed];
-  const int4 t = tets_old[e];
-  const int id[4] = {t.x, t.y, t.z, t.w};
-  const KIn key = (KIn)pack_key(in, id[ij >> 2], id[ij & 3]);
-  const uint32_t val = ((uint32_t)e << 4) | (uint32_t)ij;
-  const int at = lower_bound_pairs<KIn>(ka, va, 0, n_a, key, val);  // (it is there)
-  atomicOr(&drop[at >> 5], 1u << (at & 31));
+  if (i < n_fresh) {
+    const unsigned int r = (unsigned int)(fk[i] >> 32);
+    atomicOr(&touched[r >> 5], 1u << (r & 31));
+  } else if (i < (long long)n_fresh + 4LL * n_gone) {
+    const long long j = i - n_fresh;
+    const int m = (int)(j >> 2), e = m < n_removed ? removed[m] : changed[m - n_removed];
+    const int4 t = tets_old[e];
+    const int id[4] = {t.x, t.y, t.z, t.w};
+    const int r = imap ? imap[id[j & 3]] : id[j & 3];
+    atomicOr(&touched[r >> 5], 1u << (r & 31));
+  }
 }
-// ... and the count per tile from the bits (a counter per tile bumped by every entry: 121 us of same-address atomics)
-__global__ __launch_bounds__(kB) void k_upd_tile_counts(int n_tiles, const unsigned int* __restrict__ drop, int* __restrict__ tile_drop) {
-  const int b = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (b >= n_tiles) return;
-  int c = __popc(drop[(size_t)b * (kTile / 32) + lane]);
+
+struct CountBlocks {
+  int n = 0;
+  __device__ void operator()(int, int, int, int, int) { n++; }
+};
+// length of every new row (len[n_new] = 0 closes the scan)
+__global__ __launch_bounds__(kB) void k_row_len(int n_new, OldPlan C, FreshPairs F, RowMaps M, int* __restrict__ len) {
+  const int rn = blockIdx.x * kB + threadIdx.x;
+  if (rn > n_new) return;
+  if (rn == n_new) { len[rn] = 0; return; }
+  if (!row_touched(M, rn)) {
+    const int r = old_row_of(M, rn);
+    len[rn] = C.bptr[r + 1] - C.bptr[r];
+    return;
+  }
+  CountBlocks v;
+  walk_row(C, F, M, rn, v);
+  len[rn] = v.n;
+}
+struct WriteBlocks {
+  int* bcol; unsigned int* ucnt; int* src; int at;
+  __device__ void operator()(int col, int cnt, int from, int, int) { bcol[at] = col; ucnt[at] = (unsigned int)cnt; src[at] = from; at++; }
+};
+// the blocks of every new row: column, pairs, and the old block its kept words come from (-1: none)
+__global__ __launch_bounds__(kB) void k_row_blocks(int n_new, OldPlan C, FreshPairs F, RowMaps M, const int* __restrict__ bptr_new, int* __restrict__ bcol, unsigned int* __restrict__ ucnt,
+                                                   int* __restrict__ src) {
+  const int rn = blockIdx.x * kB + threadIdx.x;
+  if (rn >= n_new) return;
+  const int q = bptr_new[rn];
+  if (!row_touched(M, rn)) {
+    const int r = old_row_of(M, rn), p = C.bptr[r], n = C.bptr[r + 1] - p;
+    for (int k = 0; k < n; k++) {
+      const int c = C.bcol[p + k];
+      bcol[q + k] = M.imap ? M.imap[c] : c;
+      ucnt[q + k] = C.ucnt[p + k];
+      src[q + k] = p + k;
+    }
+    return;
+  }
+  WriteBlocks v = {bcol, ucnt, src, q};
+  walk_row(C, F, M, rn, v);
+}
+
+// The contribution table of the new plan from the old one: a workgroup of four wavefronts per new slice, wavefront w the slots w, w + 4, ...;
+// lane = row.  An untouched row copies its lists word by word (element ids renumbered); a touched one merges the kept words of the old
+// block with the fresh words of the block, both ascending.
+__global__ __launch_bounds__(kB) void k_table_from_table(int n_new, int n_slices, OldPlan C, FreshPairs F, RowMaps M, const int* __restrict__ bptr, const int* __restrict__ bcol,
+                                                         const unsigned int* __restrict__ ucnt, const int* __restrict__ src, const int* __restrict__ slice_off,
+                                                         const int* __restrict__ slot_coff, const int* __restrict__ slot_ccnt, uint32_t* __restrict__ contrib) {
+  const int s = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (s >= n_slices) return;
+  const int rn = s * 64 + lane;
+  const int so = slice_off[s], w = slice_off[s + 1] - so;
+  const int first = rn < n_new ? bptr[rn] : 0, len = rn < n_new ? bptr[rn + 1] - first : 0;
+  const int r = rn < n_new ? old_row_of(M, rn) : -1;
+  const bool slow = rn < n_new && row_touched(M, rn);
+  const int so_old = r >= 0 ? C.slice_off[r >> 6] : 0, first_old = r >= 0 ? C.bptr[r] : 0;
+  for (int k = wv; k < w; k += kB / 64) {
+    const int height = slot_ccnt[so + k];  // wave-uniform
+    uint32_t* out = contrib + (size_t)slot_coff[so + k] * 64 + lane;
+    int cnt = 0, from = -1, col = -1;
+    if (k < len) { col = bcol[first + k]; cnt = (int)ucnt[first + k] - (col == rn ? 1 : 0); from = src[first + k]; }
+    if (!slow) {
+      // (an untouched row: block k of the new row is block k of the old one, in slot k of the old slice)
+      const uint32_t* in = from >= 0 ? C.contrib + (size_t)C.slot_coff[so_old + (from - first_old)] * 64 + (r & 63) : nullptr;
+      for (int t = 0; t < height; t++) {
+        uint32_t word = kNoContrib;
+        if (t < cnt) {
+          const uint32_t o = in[(size_t)t * 64];
+          word = ((uint32_t)M.newid[o >> 4] << 4) | (o & 15u);
+        }
+        out[(size_t)t * 64] = word;
+      }
+    } else {
+      int t = 0;
+      if (k < len) {
+        const uint32_t* in = nullptr;
+        int n_o = 0;
+        if (from >= 0) {
+          in = C.contrib + (size_t)C.slot_coff[so_old + (from - first_old)] * 64 + (r & 63);
+          n_o = (int)C.ucnt[from] - (C.bcol[from] == r ? 1 : 0);
+        }
+        const unsigned long long key = ((unsigned long long)(unsigned int)rn << 32) | (unsigned int)col;
+        int f = fresh_lower(F, key);
+        int fe = fresh_lower(F, key + 1ULL);
+        if (fe > f && F.v[fe - 1] == kNoContrib) fe--;  // (the marker of a new node's diagonal block: last of its run, not a contribution)
+        int i = 0;
+        uint32_t wo = 0;
+        bool have = false;
+        for (;;) {
+          while (!have && i < n_o) {  // next kept word of the old block
+            const uint32_t o = in[(size_t)i * 64];
+            i++;
+            const int id = M.newid[o >> 4];
+            if (id >= 0) { wo = ((uint32_t)id << 4) | (o & 15u); have = true; }
+          }
+          if (!have && f >= fe) break;
+          uint32_t word;
+          if (have && (f >= fe || wo < F.v[f])) { word = wo; have = false; }
+          else word = F.v[f++];
+          out[(size_t)t * 64] = word;
+          t++;
+        }
+      }
+      for (; t < height; t++) out[(size_t)t * 64] = kNoContrib;
+    }
+  }
+}
+
+// widest slice (the element-major assembly's limit is decided from it)
+__global__ __launch_bounds__(kB) void k_max_width(int n_slices, const int* __restrict__ width, int* __restrict__ out) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  int w = i < n_slices ? width[i] : 0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-  if (lane == 0 && c) atomicAdd(&tile_drop[b], c);  // (on top of the last tile's share beyond the list)
-}
-
-// per tile: the number of new entries below its first staying entry (-1: the tile keeps nothing); bounds[0] = that of the first such tile,
-// bounds[1] = the number of new entries below the LAST staying entry of the whole list
-template <typename KIn, typename KOut>
-__global__ __launch_bounds__(kB) void k_upd_bounds(int n_tiles, long long n_stay, int n_a, const KIn* __restrict__ ka, const uint32_t* __restrict__ va, PackDesc in, PackDesc out,
-                                                   const int* __restrict__ imap, const int* __restrict__ pos, const unsigned int* __restrict__ drop, const int* __restrict__ tile_drop,
-                                                   const int* __restrict__ tile_base, int n_b, const KOut* __restrict__ kb, const uint32_t* __restrict__ vb, int* __restrict__ lo,
-                                                   int* __restrict__ bounds) {
-  const int b = blockIdx.x * kB + threadIdx.x;
-  if (b >= n_tiles) return;
-  const int kept = kTile - tile_drop[b];
-  if (kept == 0) { lo[b] = -1; return; }
-  int f = b * kTile;
-  while (drop[f >> 5] >> (f & 31) & 1u) f++;  // (a staying entry exists)
-  KOut k; uint32_t v;
-  xform_entry<KIn, KOut>(in, out, imap, pos, ka[f], va[f], &k, &v);
-  const int l = lower_bound_pairs<KOut>(kb, vb, 0, n_b, k, v);
-  lo[b] = l;
-  if (tile_base[b] == 0) bounds[0] = l;
-  if ((long long)tile_base[b] + kept == n_stay) {
-    int g = min(n_a, (b + 1) * kTile) - 1;
-    while (drop[g >> 5] >> (g & 31) & 1u) g--;
-    xform_entry<KIn, KOut>(in, out, imap, pos, ka[g], va[g], &k, &v);
-    bounds[1] = lower_bound_pairs<KOut>(kb, vb, 0, n_b, k, v);
-  }
-}
-
-// Pass 2: ranks the staying entries (tile base + rank inside the tile) and puts the new entries that fall between two of them in their places
-template <typename KIn, typename KOut>
-__global__ __launch_bounds__(kB) void k_upd_merge(long long n_a, const KIn* __restrict__ ka, const uint32_t* __restrict__ va, PackDesc in, PackDesc out,
-                                                  const int* __restrict__ imap, const int* __restrict__ pos, const unsigned int* __restrict__ drop, int n_tiles,
-                                                  const int* __restrict__ tile_drop, const int* __restrict__ tile_base, const int* __restrict__ lo_of, const int* __restrict__ bounds,
-                                                  int n_b, const KOut* __restrict__ kb, const uint32_t* __restrict__ vb, KOut* __restrict__ kc, uint32_t* __restrict__ vc) {
-  __shared__ KOut ck[kTile];
-  __shared__ uint32_t cv[kTile];
-  __shared__ int s_wave[kB / 64], s_run, s_lo, s_hi;
-  const int kept = kTile - tile_drop[blockIdx.x];
-  if (kept == 0) return;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (threadIdx.x == 0) {
-    s_run = 0;
-    s_lo = lo_of[blockIdx.x];
-    int hi = bounds[1];
-    for (int t = blockIdx.x + 1; t < n_tiles; t++)
-      if (lo_of[t] >= 0) { hi = lo_of[t]; break; }
-    s_hi = hi;
-  }
-  __syncthreads();
-  const long long base = (long long)blockIdx.x * kTile;
-#pragma unroll 1
-  for (int i = 0; i < kTileItems; i++) {
-    const long long idx = base + i * kB + threadIdx.x;
-    KOut k = 0; uint32_t v = 0;
-    const bool keep = idx < n_a && !(drop[idx >> 5] >> (idx & 31) & 1u);
-    if (keep) xform_entry<KIn, KOut>(in, out, imap, pos, ka[idx], va[idx], &k, &v);
-    const unsigned long long m = __ballot(keep);
-    const int before = __popcll(m & ((1ULL << lane) - 1ULL));
-    if (lane == 0) s_wave[wv] = __popcll(m);
-    __syncthreads();
-    int off = s_run;
-    for (int w = 0; w < wv; w++) off += s_wave[w];
-    if (keep) { ck[off + before] = k; cv[off + before] = v; }
-    __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kB / 64; w++) t += s_wave[w]; s_run += t; }
-    __syncthreads();
-  }
-  const int lo = s_lo, hi = s_hi;
-  const long long gbase = tile_base[blockIdx.x];
-  // the staying entries: behind the new ones that are smaller
-  for (int q = threadIdx.x; q < kept; q += kB) {
-    const KOut k = ck[q]; const uint32_t v = cv[q];
-    const int nb = lower_bound_pairs<KOut>(kb, vb, lo, hi, k, v);
-    kc[gbase + q + nb] = k; vc[gbase + q + nb] = v;
-  }
-  // the new entries between this tile's first staying entry and the next tile's: behind the staying ones that are smaller
-  for (int j = lo + threadIdx.x; j < hi; j += kB) {
-    const KOut k = kb[j]; const uint32_t v = vb[j];
-    const int na = lower_bound_pairs<KOut>(ck, cv, 0, kept, k, v);
-    kc[gbase + na + j] = k; vc[gbase + na + j] = v;
-  }
-}
-
-// new entries below the first and above the last staying entry
-template <typename KOut>
-__global__ __launch_bounds__(kB) void k_upd_ends(long long n_stay, const int* __restrict__ bounds, int n_b, const KOut* __restrict__ kb, const uint32_t* __restrict__ vb,
-                                                 KOut* __restrict__ kc, uint32_t* __restrict__ vc) {
-  const int j = blockIdx.x * kB + threadIdx.x;
-  if (j >= n_b) return;
-  if (j < bounds[0]) { kc[j] = kb[j]; vc[j] = vb[j]; }
-  else if (j >= bounds[1]) { kc[n_stay + j] = kb[j]; vc[n_stay + j] = vb[j]; }
+  for (int o = 32; o > 0; o >>= 1) w = max(w, __shfl_xor(w, o, 64));
+  if ((threadIdx.x & 63) == 0 && w > 0) atomicMax(out, w);
 }
 
 int bits_of(long long n) {
@@ -364,104 +347,26 @@ int bits_of(long long n) {
   return b;
 }
 
-template <typename KIn, typename KOut>
-int update_pairs(hipStream_t s, MeshDelta& D, const int4* tets_old, const int4* tets_new, int n_nodes_old, const PackDesc& pin, const PackDesc& pout, unsigned key_bits, long long n_old_pairs,
-                 long long n_new_pairs, PlanWorkspace& W) {
-  const long long n_stay = n_old_pairs - 16LL * (D.n_removed + D.n_changed);
-  const long long n_fresh = 16LL * (D.n_changed + D.n_added) + D.n_new_nodes;
-  if (n_stay + n_fresh != n_new_pairs) return fail(FB_EINVAL, "internal: pair count of the change does not add up");
-  // 1. the new entries, sorted among themselves (stable: ascending contribution words inside a block, its marker last)
-  FB_TRY(D.nk.reserve((size_t)std::max<long long>(1, n_fresh)));
-  FB_TRY(D.nks.reserve((size_t)std::max<long long>(1, n_fresh)));
-  FB_TRY(D.nv.reserve((size_t)std::max<long long>(1, n_fresh)));
-  FB_TRY(D.nvs.reserve((size_t)std::max<long long>(1, n_fresh)));
-  KOut* nk = reinterpret_cast<KOut*>(D.nk.p);
-  KOut* nks = reinterpret_cast<KOut*>(D.nks.p);
-  if (n_fresh > 0) {
-    hipLaunchKernelGGL(k_delta_new_pairs<KOut>, grid_for(n_fresh), dim3(kB), 0, s, D.n_changed, D.n_added, D.n_new_nodes, D.n_kept, n_nodes_old, pout, D.changed_ids, D.pos.p,
-                       tets_new, D.mapped ? D.newint.p : nullptr, nk, D.nv.p);
-    FB_HIP(hipGetLastError());
-    size_t bytes = 0;
-    FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, nk, nks, D.nv.p, D.nvs.p, (size_t)n_fresh, 0u, key_bits, s));
-    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
-    FB_HIP(rocprim::radix_sort_pairs(W.temp.p, bytes, nk, nks, D.nv.p, D.nvs.p, (size_t)n_fresh, 0u, key_bits, s));
+// the 16 pairs of every changed and added element, ascending in the new element id (changed ones keep an id below every added one), then
+// the markers of the new nodes; key = new row << 32 | new column
+__global__ __launch_bounds__(kB) void k_delta_new_pairs(int n_changed, int n_added, int n_new_nodes, int n_kept, int n_nodes_old, const int* __restrict__ changed_ids,
+                                                        const int* __restrict__ pos, const int4* __restrict__ tets_new, const int* __restrict__ newint,
+                                                        unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const long long i = (long long)blockIdx.x * kB + threadIdx.x;
+  const long long n_tp = 16LL * (n_changed + n_added);
+  if (i < n_tp) {
+    const int m = (int)(i >> 4), ij = (int)(i & 15);
+    const int e = m < n_changed ? pos[changed_ids[m]] : n_kept + (m - n_changed);
+    const int4 t = tets_new[e];
+    const int id[4] = {t.x, t.y, t.z, t.w};
+    keys[i] = ((unsigned long long)(unsigned int)id[ij >> 2] << 32) | (unsigned int)id[ij & 3];
+    vals[i] = ((uint32_t)e << 4) | (uint32_t)ij;
+  } else if (i < n_tp + n_new_nodes) {
+    const int k = (int)(i - n_tp);
+    const unsigned int r = (unsigned int)(newint ? newint[k] : n_nodes_old + k);
+    keys[i] = ((unsigned long long)r << 32) | r;
+    vals[i] = kNoContrib;
   }
-  const int* imap = D.mapped ? D.imap.p : nullptr;
-  static const bool library = getenv("FEMBRAIN_DELTA_LIBRARY") && atoi(getenv("FEMBRAIN_DELTA_LIBRARY")) != 0;  // development aid: rocprim select + merge
-  if (!library) {
-    // 2. old list (keys_s / vals_s) + new entries -> keys / vals, then the buffers change places
-    const int n_tiles = (int)((n_old_pairs + kTile - 1) / kTile);
-    FB_TRY(W.keys.reserve((size_t)n_new_pairs));
-    FB_TRY(W.vals.reserve((size_t)n_new_pairs));
-    FB_TRY(D.tile_i.reserve((size_t)3 * (n_tiles + 1) + 2));
-    FB_TRY(D.drop_bits.reserve((size_t)n_tiles * (kTile / 32)));
-    int* tile_drop = D.tile_i.p;
-    int* tile_base = tile_drop + (n_tiles + 1);
-    int* tile_lo = tile_base + (n_tiles + 1);
-    int* bounds = tile_lo + (n_tiles + 1);
-    const KIn* ka = reinterpret_cast<const KIn*>(W.keys_s.p);
-    KOut* kc = reinterpret_cast<KOut*>(W.keys.p);
-    FB_HIP(hipMemsetAsync(D.drop_bits.p, 0, sizeof(unsigned int) * (size_t)n_tiles * (kTile / 32), s));
-    FB_HIP(hipMemsetAsync(tile_drop, 0, sizeof(int) * (size_t)(n_tiles + 1), s));
-    // (the part of the last tile beyond the list, and the scan's closing element, count as gone)
-    const int tail[2] = {(int)((long long)n_tiles * kTile - n_old_pairs), kTile};
-    FB_HIP(hipMemcpyAsync(tile_drop + (n_tiles - 1), tail, sizeof tail, hipMemcpyHostToDevice, s));
-    const int4* tets_old_p = tets_old;
-    if (D.n_removed + D.n_changed > 0) {
-      hipLaunchKernelGGL(k_upd_dropped<KIn>, grid_for(16LL * (D.n_removed + D.n_changed)), dim3(kB), 0, s, D.n_removed, D.removed, D.n_changed, D.changed_ids, tets_old_p, pin,
-                         (int)n_old_pairs, ka, W.vals_s.p, D.drop_bits.p);
-      hipLaunchKernelGGL(k_upd_tile_counts, dim3((unsigned)((n_tiles + kB / 64 - 1) / (kB / 64))), dim3(kB), 0, s, n_tiles, D.drop_bits.p, tile_drop);
-      FB_HIP(hipGetLastError());
-    }
-    const auto tile_kept = rocprim::make_transform_iterator(static_cast<const int*>(tile_drop), TileKept());
-    size_t bytes = 0;
-    FB_HIP(rocprim::exclusive_scan(nullptr, bytes, tile_kept, tile_base, 0, (size_t)n_tiles + 1, rocprim::plus<int>(), s));
-    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
-    FB_HIP(rocprim::exclusive_scan(W.temp.p, bytes, tile_kept, tile_base, 0, (size_t)n_tiles + 1, rocprim::plus<int>(), s));
-    const int init_bounds[2] = {0, 0};
-    FB_HIP(hipMemcpyAsync(bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL((k_upd_bounds<KIn, KOut>), grid_for(n_tiles), dim3(kB), 0, s, n_tiles, n_stay, (int)n_old_pairs, ka, W.vals_s.p, pin, pout, imap, D.pos.p, D.drop_bits.p,
-                       tile_drop, tile_base, (int)n_fresh, nks, D.nvs.p, tile_lo, bounds);
-    FB_HIP(hipGetLastError());
-    hipLaunchKernelGGL((k_upd_merge<KIn, KOut>), dim3(n_tiles), dim3(kB), 0, s, n_old_pairs, ka, W.vals_s.p, pin, pout, imap, D.pos.p, D.drop_bits.p, n_tiles, tile_drop,
-                       tile_base, tile_lo, bounds, (int)n_fresh, nks, D.nvs.p, kc, W.vals.p);
-    FB_HIP(hipGetLastError());
-    if (n_fresh > 0) {
-      hipLaunchKernelGGL(k_upd_ends<KOut>, grid_for(n_fresh), dim3(kB), 0, s, n_stay, bounds, (int)n_fresh, nks, D.nvs.p, kc, W.vals.p);
-      FB_HIP(hipGetLastError());
-    }
-    W.keys.swap(W.keys_s);
-    W.vals.swap(W.vals_s);
-    return FB_OK;
-  }
-  // (library path) the old list, transformed, without the dropped entries: keys_s / vals_s -> keys / vals
-  FB_TRY(W.nruns.reserve(1));
-  FB_TRY(W.keys.reserve((size_t)std::max<long long>(1, n_stay)));
-  FB_TRY(W.vals.reserve((size_t)std::max<long long>(1, n_stay)));
-  {
-    const auto in = rocprim::make_transform_iterator(
-        rocprim::make_zip_iterator(rocprim::make_tuple(reinterpret_cast<const KIn*>(W.keys_s.p), static_cast<const uint32_t*>(W.vals_s.p))),
-        PairXform<KIn, KOut>{pin, pout, imap, D.estate.p, D.pos.p});
-    auto out = rocprim::make_zip_iterator(rocprim::make_tuple(reinterpret_cast<KOut*>(W.keys.p), W.vals.p));
-    size_t bytes = 0;
-    FB_HIP(rocprim::select(nullptr, bytes, in, out, W.nruns.p, (size_t)n_old_pairs, NotDropped(), s));
-    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
-    FB_HIP(rocprim::select(W.temp.p, bytes, in, out, W.nruns.p, (size_t)n_old_pairs, NotDropped(), s));
-  }
-  // merged into keys_s / vals_s (the old list is no longer needed: the buffers may grow)
-  FB_TRY(W.keys_s.reserve((size_t)n_new_pairs));
-  FB_TRY(W.vals_s.reserve((size_t)n_new_pairs));
-  {
-    const auto a = rocprim::make_zip_iterator(rocprim::make_tuple(reinterpret_cast<const KOut*>(W.keys.p), static_cast<const uint32_t*>(W.vals.p)));
-    const auto b = rocprim::make_zip_iterator(rocprim::make_tuple(static_cast<const KOut*>(nks), static_cast<const uint32_t*>(D.nvs.p)));
-    auto out = rocprim::make_zip_iterator(rocprim::make_tuple(reinterpret_cast<KOut*>(W.keys_s.p), W.vals_s.p));
-    size_t bytes = 0;
-    FB_HIP(rocprim::merge(nullptr, bytes, a, b, out, (size_t)n_stay, (size_t)n_fresh, PairLess(), s));
-    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
-    FB_HIP(rocprim::merge(W.temp.p, bytes, a, b, out, (size_t)n_stay, (size_t)n_fresh, PairLess(), s));
-  }
-  // (the unsorted buffers must hold the new list too when the next full build sorts into them: they are reserved there)
-  return FB_OK;
 }
 
 }  // namespace
@@ -562,31 +467,71 @@ int delta_positions(hipStream_t s, const MeshDelta& D, int n_old, const double* 
   return FB_OK;
 }
 
-int delta_sorted_pairs(hipStream_t s, MeshDelta& D, const int4* tets_old, const int4* tets_new, int n_nodes_new, int span, PlanWorkspace& W) {
-  SortedPairs& S = W.sorted;
-  if (!S.valid) return fail(FB_EINVAL, "internal: no sorted pair list to update");
-  const int n_nodes_old = S.n_nodes;
-  const long long n_new_pairs = 16LL * D.n_tets_new() + n_nodes_new;
-  if (n_new_pairs >= (1LL << 31)) return fail(FB_EINVAL, "mesh too large for the device plan builder (%lld pairs)", n_new_pairs);
+int delta_plan(hipStream_t s, MeshDelta& D, const OldPlanArrays& O, const int4* tets_old, const int4* tets_new, int n_new, DevicePlan& out, PlanWorkspace& W) {
+  const int n_old = O.n_nodes;
+  const long long n_fresh = 16LL * (D.n_changed + D.n_added) + D.n_new_nodes;
+  if (n_fresh >= (1LL << 31) || 16LL * D.n_tets_new() + n_new >= (1LL << 31)) return fail(FB_EINVAL, "mesh too large for the device plan builder");
   if ((long long)D.n_tets_new() >= (1LL << 28)) return fail(FB_EINVAL, "too many tets for the packed contribution word");
-  const PackDesc pin = {S.narrow ? 1 : 0, S.cb, S.span, S.col_bits};
-  // the key width of the new list: the rule of build_plan_device
-  int cb32 = 1;
-  while (span >= 0 && cb32 < 31 && (1LL << cb32) < 2LL * span + 1) cb32++;
-  const int rb32 = bits_of(n_nodes_new), col_bits = bits_of(n_nodes_new), row_bits = bits_of(n_nodes_new);
-  const bool narrow = span >= 0 && span < n_nodes_new && rb32 + cb32 <= 32 && !(getenv("FEMBRAIN_PLAN_KEYS64") && atoi(getenv("FEMBRAIN_PLAN_KEYS64")) != 0);
-  const PackDesc pout = {narrow ? 1 : 0, cb32, span, col_bits};
-  const unsigned key_bits = narrow ? (unsigned)(rb32 + cb32) : (unsigned)(row_bits + col_bits);
-  S.valid = false;  // (until the new list is complete)
-  int rc;
-  if (S.narrow && narrow) rc = update_pairs<unsigned int, unsigned int>(s, D, tets_old, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
-  else if (S.narrow) rc = update_pairs<unsigned int, unsigned long long>(s, D, tets_old, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
-  else if (narrow) rc = update_pairs<unsigned long long, unsigned int>(s, D, tets_old, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
-  else rc = update_pairs<unsigned long long, unsigned long long>(s, D, tets_old, tets_new, n_nodes_old, pin, pout, key_bits, S.n_pairs, n_new_pairs, W);
-  FB_TRY(rc);
-  S.narrow = narrow; S.cb = cb32; S.span = span; S.col_bits = col_bits;
-  S.n_pairs = n_new_pairs; S.n_nodes = n_nodes_new; S.n_tets = D.n_tets_new();
-  S.valid = true;
+  // 1. the pairs of the changed and added elements and the markers of the new nodes, sorted (stable: ascending words inside a block, a marker last)
+  FB_TRY(D.nk.reserve((size_t)std::max<long long>(1, n_fresh)));
+  FB_TRY(D.nks.reserve((size_t)std::max<long long>(1, n_fresh)));
+  FB_TRY(D.nv.reserve((size_t)std::max<long long>(1, n_fresh)));
+  FB_TRY(D.nvs.reserve((size_t)std::max<long long>(1, n_fresh)));
+  if (n_fresh > 0) {
+    hipLaunchKernelGGL(k_delta_new_pairs, grid_for(n_fresh), dim3(kB), 0, s, D.n_changed, D.n_added, D.n_new_nodes, D.n_kept, n_old, D.changed_ids, D.pos.p, tets_new,
+                       D.mapped ? D.newint.p : nullptr, D.nk.p, D.nv.p);
+    FB_HIP(hipGetLastError());
+    const unsigned key_bits = 32u + (unsigned)bits_of(n_new);
+    size_t bytes = 0;
+    FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, D.nk.p, D.nks.p, D.nv.p, D.nvs.p, (size_t)n_fresh, 0u, key_bits, s));
+    FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+    FB_HIP(rocprim::radix_sort_pairs(W.temp.p, bytes, D.nk.p, D.nks.p, D.nv.p, D.nvs.p, (size_t)n_fresh, 0u, key_bits, s));
+  }
+  // 2. element ids, row map, touched rows
+  FB_TRY(D.newid.reserve((size_t)D.n_tets_old + 1));
+  hipLaunchKernelGGL(k_newid, grid_for(D.n_tets_old), dim3(kB), 0, s, D.n_tets_old, D.estate.p, D.pos.p, D.newid.p);
+  const bool mapped = D.mapped && D.n_new_nodes > 0;
+  if (mapped) {
+    FB_TRY(D.oldrow.reserve((size_t)n_new));
+    hipLaunchKernelGGL(k_oldrow, grid_for(n_new), dim3(kB), 0, s, n_old, D.n_new_nodes, D.imap.p, D.newint.p, D.oldrow.p);
+  }
+  const size_t tw = ((size_t)n_new + 31) / 32 + 1;
+  FB_TRY(D.touched.reserve(tw));
+  FB_HIP(hipMemsetAsync(D.touched.p, 0, sizeof(unsigned int) * tw, s));
+  const int n_gone = D.n_removed + D.n_changed;
+  if (n_fresh + n_gone > 0) {
+    hipLaunchKernelGGL(k_touch, grid_for(n_fresh + 4LL * n_gone), dim3(kB), 0, s, (int)n_fresh, D.nks.p, n_gone, D.removed, D.n_removed, D.changed_ids, tets_old,
+                       mapped ? D.imap.p : nullptr, D.touched.p);
+  }
+  FB_HIP(hipGetLastError());
+  OldPlan C = {O.bptr, O.bcol, O.ucnt, O.slice_off, O.slot_coff, O.contrib, n_old};
+  FreshPairs F = {D.nks.p, D.nvs.p, (int)n_fresh};
+  RowMaps M = {mapped ? D.oldrow.p : nullptr, mapped ? D.imap.p : nullptr, D.newid.p, D.touched.p, n_old};
+  // 3. the pattern: row lengths, their scan, the blocks
+  FB_TRY(D.len.reserve((size_t)n_new + 1));
+  hipLaunchKernelGGL(k_row_len, grid_for(n_new + 1), dim3(kB), 0, s, n_new, C, F, M, D.len.p);
+  FB_HIP(hipGetLastError());
+  FB_TRY(out.bptr->alloc((size_t)n_new + 1));
+  size_t bytes = 0;
+  FB_HIP(rocprim::exclusive_scan(nullptr, bytes, D.len.p, out.bptr->p, 0, (size_t)n_new + 1, rocprim::plus<int>(), s));
+  FB_TRY(W.temp.reserve(std::max<size_t>(bytes, 16)));
+  FB_HIP(rocprim::exclusive_scan(W.temp.p, bytes, D.len.p, out.bptr->p, 0, (size_t)n_new + 1, rocprim::plus<int>(), s));
+  int nb = 0;
+  FB_TRY(out.bptr->download(&nb, 1, s, (size_t)n_new));
+  out.n_blocks = nb;
+  FB_TRY(out.bcol->alloc((size_t)std::max(1, nb)));
+  FB_TRY(out.blk_slot->alloc((size_t)std::max(1, nb)));
+  FB_TRY(out.ucnt_keep->alloc((size_t)std::max(1, nb)));
+  FB_TRY(D.src.reserve((size_t)std::max(1, nb)));
+  hipLaunchKernelGGL(k_row_blocks, grid_for(n_new), dim3(kB), 0, s, n_new, C, F, M, out.bptr->p, out.bcol->p, out.ucnt_keep->p, D.src.p);
+  FB_HIP(hipGetLastError());
+  // 4. SELL layout, slot table, list heights and offsets: the second half of the builder, on the new pattern
+  FB_TRY(plan_layout_from_csr(s, n_new, out.ucnt_keep->p, false, out, W));
+  // 5. the contribution table from the old one
+  FB_TRY(out.contrib->alloc(std::max<size_t>(1, (size_t)out.n_crows * kSliceRows)));
+  hipLaunchKernelGGL(k_table_from_table, dim3((unsigned)std::max(1, out.n_slices)), dim3(kB), 0, s, n_new, out.n_slices, C, F, M, out.bptr->p, out.bcol->p, out.ucnt_keep->p,
+                     D.src.p, out.slice_off->p, out.slot_coff->p, out.slot_ccnt->p, out.contrib->p);
+  FB_HIP(hipGetLastError());
   return FB_OK;
 }
 

@@ -69,6 +69,7 @@ struct fb_fem_s {
   bool masks_ready = false;            // ... and the constraint masks (device_constraint_masks)
   std::vector<int> l2c;                // a renumbered SHARDED handle: caller id of every local node (owned, then halo); empty otherwise
   unsigned long long order_sum = 0;    // ... and a checksum of the order, compared across the ranks
+  int n_cu_device = 256;               // CUs of the device (FB_MATRIX_AUTO's size rule; setup_persist asks the device itself)
   bool shard_auto_on = false;          // FB_RENUMBER_AUTO on a sharded handle: the ranks voted for the internal order (vote_shard_order)
   int shard_vote_neighbours = 0;       // most neighbour ranks any rank would have had under the caller's numbering (what the vote saw)
   DevBuf<int> fixed_stage;
@@ -76,6 +77,8 @@ struct fb_fem_s {
   bool caller_pattern = false;
   std::vector<double> x0_stage;  // host staging of the rest positions in local numbering (kept: a re-sync does not fault fresh pages)
   DevBuf<int> d_bptr, d_bcol, d_blk_slot;  // device-built plan only: pattern and slot table, fetched when an inspection entry point asks
+  DevBuf<unsigned int> d_ucnt;             // ... and the pairs of every block (unsharded): with the three above and the contribution table, what fb_fem_resync_delta updates
+  bool csr_ready = false;                  // the four describe the current plan
   bool device_plan = false, host_pattern = true;
   DevBuf<uint8_t> dofmask;
   DevBuf<uint8_t> nodemask;  // the three dofmask bytes of a node as bits 0..2 (one gather per column in the assembly)
@@ -1415,7 +1418,7 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   lap("constraints");
   DevicePlan D;
   D.slice_off = &h->slice_off; D.colidx = &h->colidx; D.slot_coff = &h->slot_coff; D.slot_ccnt = &h->slot_ccnt; D.contrib = &h->contrib;
-  D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot; D.coldelta = &h->coldelta;
+  D.bptr = &h->d_bptr; D.bcol = &h->d_bcol; D.blk_slot = &h->d_blk_slot; D.coldelta = &h->coldelta; D.ucnt_keep = &h->d_ucnt;
   // (the widest element was measured for the node order: FB_RENUMBER_OFF skips that pass and leaves the sort its 64-bit keys)
   const int span = renumber_mode(h) == FB_RENUMBER_OFF ? -1 : (h->ren.active ? h->ren.span_after : h->ren.span_before);
   const int rc = build_plan_device(h->stream, n_nodes, n_tets, h->tets.p, D, h->plan_ws, nullptr, span);
@@ -1430,6 +1433,7 @@ int build_plan_on_device(fb_fem_s* h, int n_nodes, int n_tets, const int* tets, 
   P.n_blocks = D.n_blocks; P.n_slices = D.n_slices; P.n_slots = D.n_slots; P.n_crows = D.n_crows;
   h->c16 = (D.deltas_fit16 && !(getenv("FEMBRAIN_SPMV_C16") && atoi(getenv("FEMBRAIN_SPMV_C16")) == 0)) ? 1 : 0;
   P.slice_off = D.slice_off_host;
+  h->csr_ready = true;
   return FB_OK;
 }
 
@@ -1581,7 +1585,16 @@ int rest_state_checked(fb_fem_s* h) {
 int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed, const int* fixed, int n_ranks,
           int rank, const int* splits, const DeviceTetMesh* dm = nullptr) {
   drop_graph(h);  // the buffers it refers to are about to be replaced
+  if (h->prm.matrix_precision == FB_MATRIX_AUTO) {
+    // fp32 values from 2 slices per CU on (setup_persist's `w`, the persistent solver's range), on shards, and where the persistent
+    // solver is asked for by name; fp64 below (include/fembrain_hip.h, FB_MATRIX_AUTO)
+    const int cus = h->cu_limit > 0 ? std::min(h->cu_limit, h->n_cu_device) : h->n_cu_device;
+    const int nb = std::min(kPipeMaxBlocks, (cus / 8) * 8);
+    const int w = nb >= 8 ? ceil_div(ceil_div(ceil_div(n_nodes, 64), 8), nb / 8) : 0;
+    h->f64 = n_ranks == 1 && h->prm.pcg_variant != FB_PCG_PERSISTENT && w < 2;
+  }
   h->last_resync_path = FB_RESYNC_FULL;
+  h->csr_ready = false;
   h->ren.clear();
   h->l2c.clear();
   h->order_sum = 0;
@@ -1817,7 +1830,15 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
   fb_fem_s* h = new fb_fem_s;
   h->prm = *params;
   h->comm = comm;  // a one-rank communicator with a live RCCL handle still runs the collectives (plumbing test)
-  h->f64 = params->matrix_precision == FB_MATRIX_F64;
+  if (params->matrix_precision != FB_MATRIX_F32 && params->matrix_precision != FB_MATRIX_F64 && params->matrix_precision != FB_MATRIX_AUTO) {
+    delete h;
+    return fail(FB_EINVAL, "unknown matrix_precision %d", params->matrix_precision);
+  }
+  h->f64 = params->matrix_precision == FB_MATRIX_F64;  // (FB_MATRIX_AUTO: build() decides by size, at every re-sync again)
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, params->device) == hipSuccess) h->n_cu_device = prop.multiProcessorCount;
+  }
   h->lambda = (params->nu * params->E) / ((1 + params->nu) * (1 - 2 * params->nu));
   h->mu = params->E / (2 * (1 + params->nu));
   int rc = FB_OK;
@@ -2030,7 +2051,7 @@ void fb_fem_default_params(fb_fem_params* p) {
   p->E = 1e7; p->nu = 0.46; p->rho = 1000.0;
   p->timestep = 0.0333; p->damping_mass = 0.0; p->damping_stiffness = 0.01;
   p->cg_eps = 1e-6; p->cg_max_iter = 10000;
-  p->matrix_precision = FB_MATRIX_F32; p->device = 0;
+  p->matrix_precision = FB_MATRIX_AUTO; p->device = 0;
 }
 
 int fb_fem_create(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed_dofs,
@@ -2206,7 +2227,7 @@ int resync_delta(fb_fem_s* h, int n_removed, const int* removed, int n_changed, 
   const int nt_new = D.n_tets_new();
   lap("change uploaded");
   const char* env = getenv("FEMBRAIN_RESYNC_DELTA");
-  bool merge = W.sorted.valid && W.sorted.n_nodes == n_old && W.sorted.n_tets == nt_old && !(env && !strcmp(env, "rebuild"));
+  bool merge = h->csr_ready && !(env && !strcmp(env, "rebuild"));
   // A renumbered handle keeps the cell size its order was made with while nodes are added; once a tenth more nodes have come, a
   // fresh order pays for its rebuild (measured after six cuts of 5 % each at 1M tets: 151 against 130 us per PCG iteration)
   if (merge && h->ren.active && (long long)n_new * 10 > (long long)h->ren_nodes_at_build * 11) merge = false;
@@ -2261,9 +2282,8 @@ int resync_delta(fb_fem_s* h, int n_removed, const int* removed, int n_changed, 
   lap("node order and elements");
   FB_TRY(device_constraint_masks(s, n_new, n_fixed, fixed, h->ren.active ? h->ren.d_new_of_old.p : nullptr, h->fixed_stage, h->dofmask, h->nodemask));
   h->masks_ready = true;
-  // ---- the plan: the pair list updated, the rest of the builder as ever ----
-  FB_TRY(delta_sorted_pairs(s, D, h->tets_next.p, h->tets.p, n_new, span, W));  // (tets_next: the old list, swapped out above)
-  lap("pair list updated");
+  // ---- the plan, from the plan (delta.hip) ----
+  OldPlanArrays old_plan = {h->d_bptr.p, h->d_bcol.p, h->d_ucnt.p, h->slice_off.p, h->slot_coff.p, h->contrib.p, n_old, h->plan.n_blocks};
   FemPlan& P = h->plan;
   P = FemPlan();
   P.n_global = n_new; P.n_ranks = 1; P.rank = 0;
@@ -2277,9 +2297,15 @@ int resync_delta(fb_fem_s* h, int n_removed, const int* removed, int n_changed, 
   P.n_tets = nt_new;
   P.n_fixed_owned = n_fixed;
   DevicePlan Dp;
-  Dp.slice_off = &h->slice_off; Dp.colidx = &h->colidx; Dp.slot_coff = &h->slot_coff; Dp.slot_ccnt = &h->slot_ccnt; Dp.contrib = &h->contrib;
-  Dp.bptr = &h->d_bptr; Dp.bcol = &h->d_bcol; Dp.blk_slot = &h->d_blk_slot; Dp.coldelta = &h->coldelta;
-  FB_TRY(plan_from_sorted_pairs(s, Dp, W));
+  // (built next to the arrays it is built from; colidx, the list heights and the 16-bit column words are read by no stage of it)
+  Dp.slice_off = &D.slice_off2; Dp.colidx = &h->colidx; Dp.slot_coff = &D.slot_coff2; Dp.slot_ccnt = &h->slot_ccnt; Dp.contrib = &D.contrib2;
+  Dp.bptr = &D.bptr2; Dp.bcol = &D.bcol2; Dp.blk_slot = &D.blk_slot2; Dp.coldelta = &h->coldelta; Dp.ucnt_keep = &D.ucnt2;
+  h->csr_ready = false;
+  W.sorted.valid = false;
+  FB_TRY(delta_plan(s, D, old_plan, h->tets_next.p, h->tets.p, n_new, Dp, W));  // (tets_next: the old list, swapped out above)
+  h->slice_off.swap(D.slice_off2); h->slot_coff.swap(D.slot_coff2); h->contrib.swap(D.contrib2);
+  h->d_bptr.swap(D.bptr2); h->d_bcol.swap(D.bcol2); h->d_blk_slot.swap(D.blk_slot2); h->d_ucnt.swap(D.ucnt2);
+  h->csr_ready = true;
   P.n_blocks = Dp.n_blocks; P.n_slices = Dp.n_slices; P.n_slots = Dp.n_slots; P.n_crows = Dp.n_crows;
   h->c16 = (Dp.deltas_fit16 && !(getenv("FEMBRAIN_SPMV_C16") && atoi(getenv("FEMBRAIN_SPMV_C16")) == 0)) ? 1 : 0;
   P.slice_off = Dp.slice_off_host;
@@ -2627,6 +2653,7 @@ long long fb_fem_device_plan_get(fb_fem_t h, const char* name, int* out, long lo
 int fb_fem_num_nodes(fb_fem_t h) { return h ? h->plan.n_global : 0; }
 int fb_fem_num_tets(fb_fem_t h) { return h ? h->plan.n_tets : 0; }
 int fb_fem_num_blocks(fb_fem_t h) { return h ? h->plan.n_blocks : 0; }
+int fb_fem_matrix_precision(fb_fem_t h) { return h && h->f64 ? FB_MATRIX_F64 : FB_MATRIX_F32; }
 int fb_fem_owned_range(fb_fem_t h, int lo_hi[2]) {
   if (!h || !lo_hi) return fail(FB_EINVAL, "null argument");
   lo_hi[0] = h->plan.node_lo; lo_hi[1] = h->plan.node_hi;

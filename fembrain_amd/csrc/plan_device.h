@@ -51,6 +51,7 @@ struct DevicePlan {
   DevBuf<int>* halo_base = nullptr;   // shards: the slice's lowest halo column (the halo form of the 16-bit words), else unused
   bool deltas_fit16 = false;
   DevBuf<int>*bptr = nullptr, *bcol = nullptr, *blk_slot = nullptr;  // CSR pattern and slot of every block (inspection entry points)
+  DevBuf<unsigned int>* ucnt_keep = nullptr;  // optional: the pairs of every block (contributions, + 1 for a diagonal block's marker), kept for fb_fem_resync_delta
   int n_blocks = 0, n_slices = 0, n_slots = 0, n_crows = 0;
   std::vector<int> slice_off_host;
   int first_bad_tet = -1;  // lowest tet with a node id outside [0, n_nodes), -1 if none (the build then fails with FB_EINVAL)
@@ -88,8 +89,12 @@ int device_partition(hipStream_t s, int n_tets, DevBuf<int4>& tets, int n_global
 // span >= 0: the widest element of the list (largest id difference inside a tet, renumber.h) when the caller has measured it -- lets the sort use 32-bit keys
 int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& out, PlanWorkspace& ws, const PlanShard* shard = nullptr, int span = -1);
 
-// the rest of the builder from the sorted pair list W.sorted describes (unsharded; delta.hip)
+// the rest of the builder from the sorted pair list W.sorted describes (unsharded)
 int plan_from_sorted_pairs(hipStream_t s, DevicePlan& out, PlanWorkspace& ws);
+// SELL-64 layout, slot table and list heights of the pattern in out.bptr / out.bcol with `ucnt` pairs per block (the diagonal block's count
+// includes its marker): fills slice_off, colidx, blk_slot, coldelta, slot_ccnt, slot_coff and n_slices, n_slots, n_crows, deltas_fit16,
+// slice_off_host.  The second half of the builder; delta.hip calls it on the pattern it has updated.  Synchronises the stream.
+int plan_layout_from_csr(hipStream_t s, int n_nodes, const unsigned int* ucnt, bool shard, DevicePlan& out, PlanWorkspace& ws);
 
 // Incidence lists of the element-major assembly kernel (fem_device.hip.h k_assemble_tets), derived from a plan that is already
 // on the device (whichever builder made it): per slice the longest list of its 64 rows (inc_off = prefix sums), per (list row, lane)

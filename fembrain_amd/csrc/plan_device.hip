@@ -632,7 +632,6 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
   DevBuf<unsigned long long>&keys_s = W.keys_s, &ukeys = W.ukeys;
   DevBuf<uint32_t>& vals_s = W.vals_s;
   DevBuf<unsigned int>&ucnt = W.ucnt, &cstart = W.cstart, &nruns = W.nruns;
-  DevBuf<int>& width = W.width;
   DevBuf<char>& temp = W.temp;
   unsigned int* keys32_s = reinterpret_cast<unsigned int*>(keys_s.p);
   size_t bytes = 0;
@@ -679,6 +678,38 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
                        D.bptr->p, D.bcol->p);
   FB_HIP(hipGetLastError());
   lap("block rows");
+  if (D.ucnt_keep) {  // (the pairs of every block, kept with the pattern: fb_fem_resync_delta updates the plan from the plan, delta.hip)
+    FB_TRY(D.ucnt_keep->alloc((size_t)nb));
+    FB_HIP(hipMemcpyAsync(D.ucnt_keep->p, ucnt.p, sizeof(unsigned int) * (size_t)nb, hipMemcpyDeviceToDevice, s));
+  }
+  FB_TRY(plan_layout_from_csr(s, n_nodes, ucnt.p, shard != nullptr, D, W));
+  lap("SELL layout and slot offsets");
+  FB_TRY(D.contrib->alloc(std::max<size_t>(1, (size_t)D.n_crows * kSliceRows)));
+  const int n_slices = D.n_slices;
+  const dim3 sg((unsigned)((n_slices + kB / 64 - 1) / (kB / 64)));
+  static const bool direct = getenv("FEMBRAIN_PLAN_CONTRIB") && !strcmp(getenv("FEMBRAIN_PLAN_CONTRIB"), "direct");  // development aid: the round-1 kernel
+  if (direct) {
+    hipLaunchKernelGGL(k_plan_contrib, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, cstart.p, vals_s.p, D.slice_off->p, D.slot_coff->p,
+                       D.slot_ccnt->p, D.contrib->p);
+  } else {
+    constexpr int kSegCap = 10240;  // words: 40 KB of LDS per workgroup, four workgroups per CU
+    FB_HIP(hipFuncSetAttribute((const void*)k_plan_contrib_lds, hipFuncAttributeMaxDynamicSharedMemorySize, kSegCap * (int)sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_plan_contrib_lds, dim3((unsigned)std::max(1, n_slices)), dim3(kB), kSegCap * sizeof(uint32_t), s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, cstart.p,
+                       vals_s.p, D.slice_off->p, D.slot_coff->p, D.slot_ccnt->p, D.contrib->p, kSegCap);
+  }
+  FB_HIP(hipGetLastError());
+  // (no wait here: the workspace and the plan's buffers outlive the kernel; the caller's next stages queue behind it)
+  lap("contribution table");
+  return FB_OK;
+}
+
+// SELL-64 layout, slot table and list heights of the pattern in D.bptr / D.bcol with `ucnt` pairs per block (the diagonal block's count
+// includes its marker): slice_off, colidx, blk_slot, coldelta, slot_ccnt, slot_coff; n_slices, n_slots, n_crows, max_width, deltas_fit16.
+int plan_layout_from_csr(hipStream_t s, int n_nodes, const unsigned int* ucnt, bool shard, DevicePlan& D, PlanWorkspace& W) {
+  DevBuf<int>& width = W.width;
+  DevBuf<char>& temp = W.temp;
+  size_t bytes = 0;
+  FB_TRY(W.flags.reserve(2));
   // SELL-64
   const int n_slices = (n_nodes + kSliceRows - 1) / kSliceRows;
   D.n_slices = n_slices;
@@ -695,7 +726,6 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
   D.slice_off_host.resize((size_t)n_slices + 1);
   FB_TRY(D.slice_off->download(D.slice_off_host.data(), (size_t)n_slices + 1, s));
   D.n_slots = D.slice_off_host[n_slices];
-  lap("slice widths");
   FB_TRY(D.colidx->alloc((size_t)D.n_slots * kSliceRows));
   FB_TRY(D.slot_ccnt->alloc((size_t)D.n_slots + 1));
   FB_TRY(D.slot_ccnt->zero(s));
@@ -704,10 +734,9 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
   if (shard && D.halo_base) FB_TRY(D.halo_base->alloc((size_t)std::max(1, n_slices)));
   struct { int* p; } wide = {W.flags.p + 1};
   FB_HIP(hipMemsetAsync(wide.p, 0, sizeof(int), s));
-  hipLaunchKernelGGL(k_plan_sell, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, D.slice_off->p, D.colidx->p, D.blk_slot->p,
+  hipLaunchKernelGGL(k_plan_sell, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt, D.slice_off->p, D.colidx->p, D.blk_slot->p,
                      D.slot_ccnt->p, D.coldelta->p, wide.p, (shard && D.halo_base) ? D.halo_base->p : nullptr);
   FB_HIP(hipGetLastError());
-  lap("SELL layout");
   bytes = 0;
   FB_HIP(rocprim::exclusive_scan(nullptr, bytes, D.slot_ccnt->p, D.slot_coff->p, 0, (size_t)D.n_slots + 1, rocprim::plus<int>(), s));
   FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
@@ -719,21 +748,6 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
   D.deltas_fit16 = w == 0;
   if ((long long)crows * kSliceRows >= (1LL << 31)) return fail(FB_EINVAL, "contribution table too large (%d rows)", crows);
   D.n_crows = crows;
-  lap("slot offsets");
-  FB_TRY(D.contrib->alloc(std::max<size_t>(1, (size_t)crows * kSliceRows)));
-  static const bool direct = getenv("FEMBRAIN_PLAN_CONTRIB") && !strcmp(getenv("FEMBRAIN_PLAN_CONTRIB"), "direct");  // development aid: the round-1 kernel
-  if (direct) {
-    hipLaunchKernelGGL(k_plan_contrib, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, cstart.p, vals_s.p, D.slice_off->p, D.slot_coff->p,
-                       D.slot_ccnt->p, D.contrib->p);
-  } else {
-    constexpr int kSegCap = 10240;  // words: 40 KB of LDS per workgroup, four workgroups per CU
-    FB_HIP(hipFuncSetAttribute((const void*)k_plan_contrib_lds, hipFuncAttributeMaxDynamicSharedMemorySize, kSegCap * (int)sizeof(uint32_t)));
-    hipLaunchKernelGGL(k_plan_contrib_lds, dim3((unsigned)std::max(1, n_slices)), dim3(kB), kSegCap * sizeof(uint32_t), s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, cstart.p,
-                       vals_s.p, D.slice_off->p, D.slot_coff->p, D.slot_ccnt->p, D.contrib->p, kSegCap);
-  }
-  FB_HIP(hipGetLastError());
-  // (no wait here: the workspace and the plan's buffers outlive the kernel; the caller's next stages queue behind it)
-  lap("contribution table");
   return FB_OK;
 }
 

@@ -17,7 +17,7 @@ from .meshgen import fixed_vertices_to_dofs
 class FemIntegrator:
     def __init__(self, verts, tets, fixed_dofs=(), E=1e7, nu=0.46, rho=1000.0, timestep=0.0333,
                  damping_mass=0.0, damping_stiffness=0.01, cg_eps=1e-6, cg_max_iter=10000,
-                 matrix_precision=_l.FB_MATRIX_F32, device=0, shard=None, pcg_variant=_l.FB_PCG_MERGED, spmv_kernel=_l.FB_SPMV_AUTO,
+                 matrix_precision=_l.FB_MATRIX_AUTO, device=0, shard=None, pcg_variant=_l.FB_PCG_MERGED, spmv_kernel=_l.FB_SPMV_AUTO,
                  linear=False, exact_tangent=False, integrator=_l.FB_INTEGRATOR_VOLUME_CONSERVING, renumber=_l.FB_RENUMBER_AUTO):
         """shard = (n_ranks, rank, node_splits or None, comm_handle) for a domain-decomposed handle."""
         L = _l.lib()
@@ -57,7 +57,7 @@ class FemIntegrator:
 
     @classmethod
     def from_poly(cls, poly, fixed_dofs=(), E=1e7, nu=0.46, rho=1000.0, timestep=0.0333, damping_mass=0.0, damping_stiffness=0.01,
-                  cg_eps=1e-6, cg_max_iter=10000, matrix_precision=_l.FB_MATRIX_F32, device=0, linear=False):
+                  cg_eps=1e-6, cg_max_iter=10000, matrix_precision=_l.FB_MATRIX_AUTO, device=0, linear=False):
         """The tet mesh a GpuPoly holds on the device (after tetrahedralize) as the FEM mesh, without a host copy
         (fb_fem_create_from_poly).  verts / tets are read back only for the Python-side conveniences."""
         self = cls.__new__(cls)
@@ -251,6 +251,10 @@ class FemIntegrator:
 
     def num_blocks(self):
         return self._L.fb_fem_num_blocks(self.h)
+
+    def matrix_precision(self):
+        """lib.FB_MATRIX_F32 / FB_MATRIX_F64: the width the matrix values are stored in (FB_MATRIX_AUTO decides by size)"""
+        return int(self._L.fb_fem_matrix_precision(self.h))
 
     def pattern(self):
         n_owned = self.node_hi - self.node_lo

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfembrain_hip.so")
 
 FB_OK, FB_EINVAL, FB_EDEVICE, FB_ENOMEM, FB_ESOLVER, FB_ECOMM = 0, -1, -2, -3, -4, -5
-FB_MATRIX_F32, FB_MATRIX_F64 = 0, 1
+FB_MATRIX_F32, FB_MATRIX_F64, FB_MATRIX_AUTO = 0, 1, 2
 FB_XCH_COLLECTIVE, FB_XCH_P2P, FB_XCH_P2P_SUMS, FB_XCH_P2P_FUSED = 1, 2, 3, 4
 FB_PCG_MERGED, FB_PCG_REFERENCE, FB_PCG_PERSISTENT, FB_PCG_BLOCK_JACOBI = 0, 1, 3, 4  # (2 was an experiment, removed)
 FB_PCG_PATH_TWO_LAUNCH, FB_PCG_PATH_PERSISTENT, FB_PCG_PATH_FALLBACK, FB_PCG_PATH_RESOLVED = 0, 1, 2, 3
@@ -127,6 +127,7 @@ def lib():
         "fb_fem_num_nodes": (C.c_int, [vp]),
         "fb_fem_num_tets": (C.c_int, [vp]),
         "fb_fem_num_blocks": (C.c_int, [vp]),
+        "fb_fem_matrix_precision": (C.c_int, [vp]),
         "fb_fem_owned_range": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "fb_fem_pattern": (C.c_int, [vp, _ip, _ip]),
         "fb_fem_element_stiffness": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp]),

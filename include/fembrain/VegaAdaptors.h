@@ -103,7 +103,7 @@ class HipCorotationalForceModel : public ForceModel {
     nv_ = nv; ne_ = ne;
     fb_fem_default_params(&prm_);
     prm_.E = E; prm_.nu = nu; prm_.rho = rho; prm_.device = device;
-    prm_.matrix_precision = FB_MATRIX_F32;  // the handle that steps; host code gets its matrices from create64()
+    prm_.matrix_precision = FB_MATRIX_AUTO;  // the handle that steps (fp32 values from 2 slices per CU on); host code gets its matrices from create64()
     prm_.linear = warp == 0 ? 1 : 0;
     prm_.exact_tangent = warp == 2 ? 1 : 0;
     if (fb_fem_create(&h_, nv, &xyz_[0], ne, &tets_[0], 0, NULL, &prm_) != FB_OK) {

@@ -22,8 +22,14 @@ extern "C" {
 #define FB_ECOMM (-5)    /* RCCL not available / communicator error */
 
 /* matrix storage precision (vectors, dot products and all per-element geometry are always fp64) */
-#define FB_MATRIX_F32 0 /* default: north-star fp32 stiffness storage */
+#define FB_MATRIX_F32 0 /* north-star fp32 stiffness storage (every product, sum and vector stays fp64) */
 #define FB_MATRIX_F64 1 /* reference-width storage, used by the tight parity tests */
+/* default (fb_fem_default_params): by size.  fp32 where it buys speed -- from 2 SELL slices per CU on (> 16,384 nodes on 256 CUs: the
+ * persistent solver's range, where a third of the matrix stays in LDS) and on every sharded handle -- and fp64 below: a system that
+ * small is solved from L2 by the two-launch iteration either way, and fp32 storage only costs it accuracy (the 204-DOF disc.1.veg, condition
+ * ~1e5: 1e-2 of max|q| after three steps with fp32 values, 2e-5 with fp64).  Decided again at every re-sync.
+ * FB_PCG_PERSISTENT asked for explicitly means fp32. */
+#define FB_MATRIX_AUTO 2
 
 /* PCG formulation.  Both run the Jacobi-PCG of CGSolver.cpp:129-190 with the exact-residual refresh every 30th
  * iteration.  REFERENCE performs its two reductions per iteration literally (d.q, then sum r^2/diag).  MERGED obtains
@@ -81,7 +87,7 @@ typedef struct fb_fem_params {
   double damping_stiffness;     /* Rayleigh c_K, Deformable.cpp:110: 0.01 */
   double cg_eps;                /* PS_VolumeConservingIntegrator.cpp:196: 1e-6 */
   int cg_max_iter;              /* PS_VolumeConservingIntegrator.cpp:197: 10000 */
-  int matrix_precision;         /* FB_MATRIX_F32 / FB_MATRIX_F64 */
+  int matrix_precision;         /* FB_MATRIX_AUTO (default) / FB_MATRIX_F32 / FB_MATRIX_F64 */
   int device;                   /* HIP device ordinal */
   int pcg_variant;              /* FB_PCG_MERGED (default) / FB_PCG_REFERENCE */
   int spmv_kernel;              /* 0 = choose by size, FB_SPMV_ROWS, FB_SPMV_SPLIT (small meshes: one slice per block) */
@@ -259,6 +265,7 @@ int fb_fem_floor_collision(fb_fem_t h, double floor_y, double restitution, int* 
 int fb_fem_num_nodes(fb_fem_t h);   /* global */
 int fb_fem_num_tets(fb_fem_t h);    /* local (all for an unsharded handle) */
 int fb_fem_num_blocks(fb_fem_t h);  /* 3x3 blocks of the stiffness pattern (owned rows) */
+int fb_fem_matrix_precision(fb_fem_t h);  /* FB_MATRIX_F32 or FB_MATRIX_F64: the width the matrix values are stored in (what FB_MATRIX_AUTO chose) */
 int fb_fem_owned_range(fb_fem_t h, int lo_hi[2]);  /* the node range this handle owns ([0, n_nodes) when unsharded); of the INTERNAL order when renumbered */
 /* 1 when the handle works in an internal node order; widest element (largest id difference inside a tet) in the caller's and in the
  * internal order (equal when not renumbered; 0 when never measured: FB_RENUMBER_OFF).  Pointers may be NULL. */

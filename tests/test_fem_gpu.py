@@ -289,8 +289,11 @@ def test_shipped_disc_and_pyramid_meshes_against_reference_golden(gpu, name):
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "fem_%s.npz" % name))
     fixed = fixed_vertices_to_dofs(gold["fixed_vertices"])
     # fp32 matrix storage on the disc: every entry rounded to 6e-8 times a condition number of ~1e5 (2,800 PCG iterations on 204 DOFs)
-    for prec, tol_k, tol_q in ((fl.FB_MATRIX_F64, 1e-9, 2e-5), (fl.FB_MATRIX_F32, 5e-7, 1e-2 if name == "disc" else 3e-4)):
+    # The DEFAULT handle (FB_MATRIX_AUTO) stores a mesh this small as fp64 -- below the persistent solver's range fp32 values buy no
+    # speed -- and is held to the fp64 tolerance; fp32 storage asked for by name keeps its measured 1e-2 on the disc.
+    for prec, tol_k, tol_q in ((fl.FB_MATRIX_AUTO, 1e-9, 2e-5), (fl.FB_MATRIX_F64, 1e-9, 2e-5), (fl.FB_MATRIX_F32, 5e-7, 1e-2 if name == "disc" else 3e-4)):
         g = FemIntegrator(gold["verts"], gold["tets"], fixed, matrix_precision=prec, cg_eps=float(gold["cg_eps"]))  # (disc: 1e-9, see make_fem_golden.py)
+        assert g.matrix_precision() == (fl.FB_MATRIX_F32 if prec == fl.FB_MATRIX_F32 else fl.FB_MATRIX_F64)
         f, K = g.assemble(gold["u"])
         bptr, bcol = g.pattern()
         # the golden K is the reference's scalar CSR: compare through a sparse matrix

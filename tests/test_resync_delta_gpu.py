@@ -300,7 +300,10 @@ def test_delta_resynced_handle_against_the_cpu_oracle(gpu, renumber):
     tolerances of tests/test_fem_gpu.py"""
     from oracle.pyoracle import OrcFem
     v, t, fixed = _cube(9)
-    g = FemIntegrator(v, t, fixed, renumber=renumber)
+    # (fp32 values asked for by name, as at the headline size: FB_MATRIX_AUTO would store a mesh this small as fp64.  The second step's
+    # iteration count on this sliver mesh moves by a tenth with tolerance-level differences in the first step's solution, see
+    # tools/scratch/dbg_pcg.py: the literal solver and the merged one, both within 1e-6, give 400 and 354)
+    g = FemIntegrator(v, t, fixed, renumber=renumber, matrix_precision=fl.FB_MATRIX_F32)
     v2, t2, d = synthetic_cut(v, t, axis=1, where=0.4)
     g.resync_delta(d, fixed)
     v3, t3, d2 = synthetic_cut(v2, t2, axis=2, where=0.55, every_changed=2, stride=6)   # (few new nodes: the order is kept)
