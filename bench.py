@@ -272,7 +272,7 @@ def cut_resync_leg(device, prec):
     import torch
     v, t, fixed = workload_mesh("cube56", device)
     names = {fl.FB_RESYNC_FULL: "full", fl.FB_RESYNC_DELTA_MERGED: "pair list updated", fl.FB_RESYNC_DELTA_REBUILT: "full builder from the device copy of the mesh"}
-    g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device)
+    g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device, expect_cuts=True)   # (the caller of fb_fem_resync_delta says it will cut)
     ref = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device)
 
     def both(d, v2, t2):

@@ -30,6 +30,18 @@ int fail(int code, const char* fmt, ...);
     if (_r != FB_OK) return _r; \
   } while (0)
 
+// Slack of a fresh allocation in sixteenths of the size asked for (2 = an eighth, the default; 4 = a quarter for a handle whose caller
+// has said it will cut: fb_fem_params.expect_cuts).  Set for the duration of a build by the entry point that runs it (SlackScope).
+inline int& alloc_slack_sixteenths() {
+  static thread_local int v = 2;
+  return v;
+}
+struct SlackScope {
+  int before;
+  explicit SlackScope(int sixteenths) : before(alloc_slack_sixteenths()) { alloc_slack_sixteenths() = sixteenths; }
+  ~SlackScope() { alloc_slack_sixteenths() = before; }
+};
+
 // device array owned by a handle
 template <class T>
 struct DevBuf {
@@ -56,7 +68,7 @@ struct DevBuf {
     if (count == 0) return FB_OK;
     // (a buffer that is GROWING gets half again what it had, so a mesh that grows cut by cut re-allocates every few cuts only)
     const size_t grown = had && count > had ? had + had / 2 : 0;
-    const size_t want = std::max(count + (count * sizeof(T) >= (1u << 16) ? count / 8 : 0), count * sizeof(T) >= (1u << 16) ? grown : 0);
+    const size_t want = std::max(count + (count * sizeof(T) >= (1u << 16) ? count / 16 * (size_t)alloc_slack_sixteenths() : 0), count * sizeof(T) >= (1u << 16) ? grown : 0);
     hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
     if (e != hipSuccess && want != count) {  // no room for the slack: the exact size
       (void)hipGetLastError();

@@ -35,8 +35,9 @@ struct MeshDelta {
   DevBuf<uint32_t> nv, nvs;
   DevBuf<int> newid;                // per old element: its new id, -1 if its contributions go (removed, or changed: those come back as new pairs)
   DevBuf<int> oldrow;               // per new row: the old row, -1 for a new node (renumbered handles with new nodes)
-  DevBuf<unsigned int> touched;     // a bit per new row: it loses or gains contributions
+  DevBuf<unsigned int> touched;     // count of touched rows | a word per new row: it loses or gains contributions | its fresh entries | the list of touched rows
   DevBuf<int> len;                  // new row lengths
+  DevBuf<int> slot_slice;           // per new slot: its slice
   DevBuf<int> src;                  // per new block: the old block its kept words come from, -1 none
   // the plan being built next to the handle's (swapped in when it is complete)
   DevBuf<int> bptr2, bcol2, blk_slot2, slice_off2, slot_coff2;
@@ -71,6 +72,8 @@ struct OldPlanArrays {
   const int* bptr; const int* bcol; const unsigned int* ucnt; const int* slice_off; const int* slot_coff; const uint32_t* contrib;
   int n_nodes, n_blocks;
 };
+// room for a change of n_fresh pairs (16 per changed or added element), so that the first change does not allocate it
+int delta_reserve(hipStream_t s, MeshDelta& D, PlanWorkspace& W, long long n_fresh);
 int delta_plan(hipStream_t s, MeshDelta& D, const OldPlanArrays& old_plan, const int4* tets_old, const int4* tets_new, int n_nodes_new, DevicePlan& out, PlanWorkspace& W);
 
 }  // namespace fb

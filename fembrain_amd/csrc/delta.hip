@@ -150,31 +150,45 @@ struct OldPlan {
   const int* bptr; const int* bcol; const unsigned int* ucnt; const int* slice_off; const int* slot_coff; const uint32_t* contrib;
   int n_nodes;
 };
-struct FreshPairs { const unsigned long long* k; const uint32_t* v; int n; };  // key = new row << 32 | new column, sorted by (key, word)
+struct FreshPairs {  // key = new row << 32 | new column, sorted by (key, word)
+  const unsigned long long* k; const uint32_t* v; int n;
+  const int2* row;  // per NEW row: its entries [x, y) (0, 0: none); written by k_touch, which sees every first entry of a row anyway
+};
 struct RowMaps {
   const int* oldrow;             // new row -> old row, -1 for a new node; nullptr: identity below n_old, new nodes behind
   const int* imap;               // old node -> new node (monotone); nullptr: identity
   const int* newid;              // old element -> new id, -1 if its contributions go (removed or changed)
-  const unsigned int* touched;   // a bit per NEW row: it loses or gains contributions
+  const int* touched;            // per NEW row: non-zero if it loses or gains contributions (a word each: rows of one cut plane are neighbours, and a bit map made their atomics collide)
   int n_old;
+  const int* tlist;              // the touched rows, each once, in no particular order
+  const int* n_touched;          // ... and their number
 };
 __device__ __forceinline__ int old_row_of(const RowMaps& M, int rn) { return M.oldrow ? M.oldrow[rn] : (rn < M.n_old ? rn : -1); }
-__device__ __forceinline__ bool row_touched(const RowMaps& M, int rn) { return (M.touched[rn >> 5] >> (rn & 31)) & 1u; }
-__device__ __forceinline__ int fresh_lower(const FreshPairs& F, unsigned long long key) {
-  int lo = 0, hi = F.n;
+__device__ __forceinline__ bool row_touched(const RowMaps& M, int rn) { return M.touched[rn] != 0; }
+__device__ __forceinline__ int fresh_lower(const FreshPairs& F, unsigned long long key, int lo, int hi) {
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     if (F.k[mid] < key) lo = mid + 1; else hi = mid;
   }
   return lo;
 }
-// contribution words of old block p (row r) whose element goes
+// contribution words of old block p (row r) whose element goes; eight words in flight at a time (the loop is a chain of dependent
+// loads otherwise: word, then its element's entry of the id table)
 __device__ __forceinline__ int dropped_words(const OldPlan& C, const RowMaps& M, int p, int r) {
   const int k = p - C.bptr[r], slot = C.slice_off[r >> 6] + k;
   const int n = (int)C.ucnt[p] - (C.bcol[p] == r ? 1 : 0);
   const uint32_t* w = C.contrib + (size_t)C.slot_coff[slot] * 64 + (r & 63);
   int gone = 0;
-  for (int t = 0; t < n; t++) gone += M.newid[w[(size_t)t * 64] >> 4] < 0 ? 1 : 0;
+  for (int t0 = 0; t0 < n; t0 += 8) {
+    uint32_t o[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = t0 + j < n ? w[(size_t)(t0 + j) * 64] : 0u;
+    int id[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) id[j] = t0 + j < n ? M.newid[o[j] >> 4] : 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) gone += id[j] < 0 ? 1 : 0;
+  }
   return gone;
 }
 // The blocks of NEW row rn in ascending column order: visit(column, pairs incl. the marker, old block or -1, fresh entries [f0, f1)).
@@ -183,8 +197,9 @@ __device__ __forceinline__ void walk_row(const OldPlan& C, const FreshPairs& F, 
   const int r = old_row_of(M, rn);
   int p = r >= 0 ? C.bptr[r] : 0;
   const int pe = r >= 0 ? C.bptr[r + 1] : 0;
-  int f = fresh_lower(F, (unsigned long long)(unsigned int)rn << 32);
-  const int fe = fresh_lower(F, (unsigned long long)((unsigned int)rn + 1u) << 32);
+  const int2 fr = F.row[rn];
+  int f = fr.x;
+  const int fe = fr.y;
   while (p < pe || f < fe) {
     const int co = p < pe ? (M.imap ? M.imap[C.bcol[p]] : C.bcol[p]) : 0x7fffffff;
     const int cf = f < fe ? (int)(unsigned int)(F.k[f] & 0xFFFFFFFFULL) : 0x7fffffff;
@@ -207,128 +222,278 @@ __global__ __launch_bounds__(kB) void k_oldrow(int n_old, int n_new_nodes, const
   if (i < n_old) oldrow[imap[i]] = i;
   else if (i < n_old + n_new_nodes) oldrow[newint[i - n_old]] = -1;
 }
-// rows of the fresh pairs, and the rows of the elements that go (their old nodes through the node map)
+// rows of the fresh pairs, and the rows of the elements that go (their old nodes through the node map).  The fresh list is sorted by
+// row: one atomic per run of a row, not per entry (every entry of a row hits the same word: 99 us of same-address atomics at 1.1M tets)
+// appends the rows of the lanes with `mine` to the list: one atomic per wavefront (35 us of same-address atomics at 1.1M tets otherwise)
+__device__ __forceinline__ void append_rows(bool mine, int r, int* __restrict__ tlist, int* __restrict__ count) {
+  const unsigned long long m = __ballot(mine);
+  if (!m) return;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(count, __popcll(m));
+  base = __shfl(base, leader, 64);
+  if (mine) tlist[base + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
+}
 __global__ __launch_bounds__(kB) void k_touch(int n_fresh, const unsigned long long* __restrict__ fk, int n_gone, const int* __restrict__ removed, int n_removed,
-                                              const int* __restrict__ changed, const int4* __restrict__ tets_old, const int* __restrict__ imap, unsigned int* __restrict__ touched) {
+                                              const int* __restrict__ changed, const int4* __restrict__ tets_old, const int* __restrict__ imap, int* __restrict__ touched,
+                                              int2* __restrict__ frow, int* __restrict__ tlist, int* __restrict__ count) {
   const long long i = (long long)blockIdx.x * kB + threadIdx.x;
+  bool first = false;
+  int r = 0;
   if (i < n_fresh) {
-    const unsigned int r = (unsigned int)(fk[i] >> 32);
-    atomicOr(&touched[r >> 5], 1u << (r & 31));
+    r = (int)(unsigned int)(fk[i] >> 32);
+    const unsigned int before = i > 0 ? (unsigned int)(fk[i - 1] >> 32) : 0xFFFFFFFFu;
+    if (before != (unsigned int)r) {
+      first = atomicExch(&touched[r], 1) == 0;
+      frow[r].x = (int)i;
+      if (i > 0) frow[before].y = (int)i;
+    }
+    if (i == n_fresh - 1) frow[r].y = n_fresh;
   } else if (i < (long long)n_fresh + 4LL * n_gone) {
     const long long j = i - n_fresh;
     const int m = (int)(j >> 2), e = m < n_removed ? removed[m] : changed[m - n_removed];
     const int4 t = tets_old[e];
     const int id[4] = {t.x, t.y, t.z, t.w};
-    const int r = imap ? imap[id[j & 3]] : id[j & 3];
-    atomicOr(&touched[r >> 5], 1u << (r & 31));
+    r = imap ? imap[id[j & 3]] : id[j & 3];
+    first = touched[r] == 0 && atomicExch(&touched[r], 1) == 0;
   }
+  append_rows(first, r, tlist, count);
+}
+
+// ---- a touched row, one wavefront: lanes hold its old blocks and its fresh entries (up to 64 each; longer rows -- hub nodes -- are walked
+// by one lane, walk_row).  lower bound over a sorted array held one element per lane, the same steps on every lane (shuffles).
+__device__ __forceinline__ int wave_lower_bound(int mine, int n, int key) {
+  int pos = 0;
+#pragma unroll
+  for (int step = 32; step > 0; step >>= 1) {
+    const int idx = pos + step - 1;
+    const int v = __shfl(mine, idx & 63, 64);
+    if (idx < n && v < key) pos += step;
+  }
+  // (pos counts the elements below key among the first 63; the 64th is looked at on its own)
+  const int last = __shfl(mine, 63, 64);
+  if (pos == 63 && n == 64 && last < key) pos = 64;
+  return pos;
+}
+struct RowMerge {
+  // per lane: an old block (lane < n_old) and a fresh entry (lane < n_fresh)
+  int n_old, n_fresh, f0, p0;
+  int col_old, total_old, src_old;   // old block of this lane: new column, pairs after the change, its index
+  int col_fresh, run_fresh;          // fresh entry of this lane: column, length of the run it heads
+  unsigned long long mask_old, mask_new;  // old blocks that stay; fresh runs that make a new block
+  int pos_old, pos_new;              // place of this lane's old block / new block in the merged row
+  int len;
+};
+// returns false when the row does not fit the wavefront (the caller falls back to walk_row on one lane)
+__device__ __forceinline__ bool merge_row_wave(const OldPlan& C, const FreshPairs& F, const RowMaps& M, int rn, int lane, RowMerge& R) {
+  const int r = old_row_of(M, rn);
+  R.p0 = r >= 0 ? C.bptr[r] : 0;
+  R.n_old = r >= 0 ? C.bptr[r + 1] - R.p0 : 0;
+  const int2 fr = F.row[rn];
+  R.f0 = fr.x;
+  R.n_fresh = fr.y - fr.x;
+  if (R.n_old > 64 || R.n_fresh > 64) return false;  // (wave-uniform)
+  // fresh entries: columns, heads of runs, run lengths
+  R.col_fresh = lane < R.n_fresh ? (int)(unsigned int)(F.k[R.f0 + lane] & 0xFFFFFFFFULL) : 0x7fffffff;
+  const int prev = __shfl_up(R.col_fresh, 1, 64);
+  const bool head = lane < R.n_fresh && (lane == 0 || prev != R.col_fresh);
+  const int after = wave_lower_bound(R.col_fresh, R.n_fresh, R.col_fresh == 0x7fffffff ? 0x7fffffff : R.col_fresh + 1);
+  R.run_fresh = after - lane;
+  // old blocks: column through the node map, pairs that stay
+  R.src_old = R.p0 + lane;
+  R.col_old = 0x7fffffff;
+  int kept = 0;
+  if (lane < R.n_old) {
+    const int c = C.bcol[R.src_old];
+    R.col_old = M.imap ? M.imap[c] : c;
+    kept = (int)C.ucnt[R.src_old] - dropped_words(C, M, R.src_old, r);
+  }
+  const int below = wave_lower_bound(R.col_fresh, R.n_fresh, R.col_old);                                       // fresh entries of a smaller column
+  const int upto = wave_lower_bound(R.col_fresh, R.n_fresh, R.col_old == 0x7fffffff ? 0x7fffffff : R.col_old + 1);
+  R.total_old = kept + (lane < R.n_old ? upto - below : 0);
+  R.mask_old = __ballot(lane < R.n_old && R.total_old > 0);
+  // a fresh run makes a new block where no old block has its column
+  const int at = wave_lower_bound(R.col_old, R.n_old, R.col_fresh);
+  const int hit = __shfl(R.col_old, at & 63, 64);
+  const bool matched = at < R.n_old && hit == R.col_fresh;
+  R.mask_new = __ballot(head && !matched);
+  const unsigned long long lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+  const unsigned long long lt_below = below == 0 ? 0ULL : (below >= 64 ? ~0ULL : (~0ULL >> (64 - below)));
+  const unsigned long long lt_at = at == 0 ? 0ULL : (at >= 64 ? ~0ULL : (~0ULL >> (64 - at)));
+  R.pos_old = __popcll(R.mask_old & lt) + __popcll(R.mask_new & lt_below);
+  R.pos_new = __popcll(R.mask_new & lt) + __popcll(R.mask_old & lt_at);
+  R.len = __popcll(R.mask_old) + __popcll(R.mask_new);
+  return true;
 }
 
 struct CountBlocks {
   int n = 0;
   __device__ void operator()(int, int, int, int, int) { n++; }
 };
-// length of every new row (len[n_new] = 0 closes the scan)
-__global__ __launch_bounds__(kB) void k_row_len(int n_new, OldPlan C, FreshPairs F, RowMaps M, int* __restrict__ len) {
+// length of every new row (len[n_new] = 0 closes the scan).  An untouched row: a thread; the touched rows: the wavefronts of k_row_len_touched
+// take them from the list (a wavefront per row of the whole matrix was 26 rounds of resident wavefronts, each a chain of four loads)
+__global__ __launch_bounds__(kB) void k_row_len(int n_new, OldPlan C, RowMaps M, int* __restrict__ len) {
   const int rn = blockIdx.x * kB + threadIdx.x;
   if (rn > n_new) return;
   if (rn == n_new) { len[rn] = 0; return; }
-  if (!row_touched(M, rn)) {
-    const int r = old_row_of(M, rn);
-    len[rn] = C.bptr[r + 1] - C.bptr[r];
-    return;
+  if (row_touched(M, rn)) return;
+  const int r = old_row_of(M, rn);
+  len[rn] = C.bptr[r + 1] - C.bptr[r];
+}
+__global__ __launch_bounds__(kB) void k_row_len_touched(OldPlan C, FreshPairs F, RowMaps M, int* __restrict__ len) {
+  const int lane = threadIdx.x & 63, n_waves = gridDim.x * (kB / 64), n_t = M.n_touched[0];
+  for (int i = blockIdx.x * (kB / 64) + (threadIdx.x >> 6); i < n_t; i += n_waves) {
+    const int rn = M.tlist[i];
+    RowMerge R;
+    if (merge_row_wave(C, F, M, rn, lane, R)) {
+      if (lane == 0) len[rn] = R.len;
+    } else if (lane == 0) {
+      CountBlocks v;
+      walk_row(C, F, M, rn, v);
+      len[rn] = v.n;
+    }
   }
-  CountBlocks v;
-  walk_row(C, F, M, rn, v);
-  len[rn] = v.n;
 }
 struct WriteBlocks {
   int* bcol; unsigned int* ucnt; int* src; int at;
   __device__ void operator()(int col, int cnt, int from, int, int) { bcol[at] = col; ucnt[at] = (unsigned int)cnt; src[at] = from; at++; }
 };
-// the blocks of every new row: column, pairs, and the old block its kept words come from (-1: none)
-__global__ __launch_bounds__(kB) void k_row_blocks(int n_new, OldPlan C, FreshPairs F, RowMaps M, const int* __restrict__ bptr_new, int* __restrict__ bcol, unsigned int* __restrict__ ucnt,
+// the blocks of every new row: column, pairs, and the old block its kept words come from (-1: none).  Untouched rows: a wavefront per 64 rows,
+// the lanes walking the concatenated blocks of those rows (coalesced); touched rows: a wavefront each, lane = block
+__global__ __launch_bounds__(kB) void k_row_blocks(int n_new, OldPlan C, RowMaps M, const int* __restrict__ bptr_new, int* __restrict__ bcol, unsigned int* __restrict__ ucnt,
                                                    int* __restrict__ src) {
-  const int rn = blockIdx.x * kB + threadIdx.x;
-  if (rn >= n_new) return;
-  const int q = bptr_new[rn];
-  if (!row_touched(M, rn)) {
-    const int r = old_row_of(M, rn), p = C.bptr[r], n = C.bptr[r + 1] - p;
-    for (int k = 0; k < n; k++) {
-      const int c = C.bcol[p + k];
-      bcol[q + k] = M.imap ? M.imap[c] : c;
-      ucnt[q + k] = C.ucnt[p + k];
-      src[q + k] = p + k;
-    }
-    return;
+  const int r0 = (blockIdx.x * (kB / 64) + (threadIdx.x >> 6)) * 64, lane = threadIdx.x & 63;
+  if (r0 >= n_new) return;
+  const int rn = min(r0 + lane, n_new);
+  const int q_mine = bptr_new[rn];                         // (ascending over the lanes; lanes past the last row hold the end)
+  const int q_end = bptr_new[min(r0 + 64, n_new)];
+  const bool plain = r0 + lane < n_new && !row_touched(M, r0 + lane);
+  const int p_mine = plain ? C.bptr[old_row_of(M, r0 + lane)] : 0;
+  const int q0 = __shfl(q_mine, 0, 64);
+  for (int qb = q0; qb < q_end; qb += 64) {  // (the same trips on every lane: the shuffles below read every lane's registers)
+    const int q = qb + lane;
+    // the row of block q: the last lane whose first block is <= q
+    int j = wave_lower_bound(q_mine, 64, q + 1) - 1;
+    if (j < 0) j = 0;
+    const int qj = __shfl(q_mine, j, 64), pj = __shfl(p_mine, j, 64);
+    const bool pl = __shfl((int)plain, j, 64) != 0;
+    if (!pl || q >= q_end) continue;
+    const int p = pj + (q - qj);
+    const int c = C.bcol[p];
+    bcol[q] = M.imap ? M.imap[c] : c;
+    ucnt[q] = C.ucnt[p];
+    src[q] = p;
   }
-  WriteBlocks v = {bcol, ucnt, src, q};
-  walk_row(C, F, M, rn, v);
+}
+__global__ __launch_bounds__(kB) void k_row_blocks_touched(OldPlan C, FreshPairs F, RowMaps M, const int* __restrict__ bptr_new, int* __restrict__ bcol, unsigned int* __restrict__ ucnt,
+                                                           int* __restrict__ src) {
+  const int lane = threadIdx.x & 63, n_waves = gridDim.x * (kB / 64), n_t = M.n_touched[0];
+  for (int i = blockIdx.x * (kB / 64) + (threadIdx.x >> 6); i < n_t; i += n_waves) {
+    const int rn = M.tlist[i], q = bptr_new[rn];
+    RowMerge R;
+    if (merge_row_wave(C, F, M, rn, lane, R)) {
+      if ((R.mask_old >> lane) & 1ULL) { bcol[q + R.pos_old] = R.col_old; ucnt[q + R.pos_old] = (unsigned int)R.total_old; src[q + R.pos_old] = R.src_old; }
+      if ((R.mask_new >> lane) & 1ULL) { bcol[q + R.pos_new] = R.col_fresh; ucnt[q + R.pos_new] = (unsigned int)R.run_fresh; src[q + R.pos_new] = -1; }
+    } else if (lane == 0) {
+      WriteBlocks v = {bcol, ucnt, src, q};
+      walk_row(C, F, M, rn, v);
+    }
+  }
 }
 
-// The contribution table of the new plan from the old one: a workgroup of four wavefronts per new slice, wavefront w the slots w, w + 4, ...;
-// lane = row.  An untouched row copies its lists word by word (element ids renumbered); a touched one merges the kept words of the old
-// block with the fresh words of the block, both ascending.
-__global__ __launch_bounds__(kB) void k_table_from_table(int n_new, int n_slices, OldPlan C, FreshPairs F, RowMaps M, const int* __restrict__ bptr, const int* __restrict__ bcol,
-                                                         const unsigned int* __restrict__ ucnt, const int* __restrict__ src, const int* __restrict__ slice_off,
-                                                         const int* __restrict__ slot_coff, const int* __restrict__ slot_ccnt, uint32_t* __restrict__ contrib) {
-  const int s = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// The contribution table of the new plan from the old one.  Rows the change does not touch: one wavefront per (new slice, slot), lane =
+// row; block k of such a row is block k of its old row, in slot k of the old slice: its list is copied word by word with the element ids
+// renumbered (no block table is looked at; the old list ends at its first empty word).  The kernel is a chain word -> id table -> store
+// per list entry, so every lane keeps sixteen entries in flight.
+__global__ __launch_bounds__(kB) void k_slot_slices(int n_slices, const int* __restrict__ slice_off, int* __restrict__ slot_slice) {
+  const int s = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (s >= n_slices) return;
+  for (int g = slice_off[s] + lane; g < slice_off[s + 1]; g += 64) slot_slice[g] = s;
+}
+__global__ __launch_bounds__(kB) void k_table_plain(int n_new, int n_slots, OldPlan C, RowMaps M, const int* __restrict__ slice_off, const int* __restrict__ slot_slice,
+                                                    const int* __restrict__ slot_coff, uint32_t* __restrict__ contrib) {
+  const int g = blockIdx.x * (kB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // slot of the new plan
+  if (g >= n_slots) return;
+  const int s = slot_slice[g], k = g - slice_off[s];
   const int rn = s * 64 + lane;
-  const int so = slice_off[s], w = slice_off[s + 1] - so;
-  const int first = rn < n_new ? bptr[rn] : 0, len = rn < n_new ? bptr[rn + 1] - first : 0;
-  const int r = rn < n_new ? old_row_of(M, rn) : -1;
-  const bool slow = rn < n_new && row_touched(M, rn);
+  const bool row = rn < n_new;
+  const bool skip = row && row_touched(M, rn);  // (k_table_touched writes those columns)
+  const int r = row && !skip ? old_row_of(M, rn) : -1;
+  const int so_old = r >= 0 ? C.slice_off[r >> 6] : 0, w_old = r >= 0 ? C.slice_off[(r >> 6) + 1] - so_old : 0;
+  const int coff = slot_coff[g], height = slot_coff[g + 1] - coff;  // wave-uniform
+  uint32_t* out = contrib + (size_t)coff * 64 + lane;
+  int base = 0, h_old = 0;
+  if (k < w_old) { base = C.slot_coff[so_old + k]; h_old = C.slot_coff[so_old + k + 1] - base; }
+  const uint32_t* in = C.contrib + (size_t)base * 64 + (r >= 0 ? (r & 63) : 0);
+  for (int t0 = 0; t0 < height; t0 += 16) {
+    uint32_t o[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) o[j] = t0 + j < h_old ? in[(size_t)(t0 + j) * 64] : kNoContrib;
+    int id[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) id[j] = o[j] != kNoContrib ? M.newid[o[j] >> 4] : 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      if (t0 + j < height && !skip) out[(size_t)(t0 + j) * 64] = o[j] != kNoContrib ? (((uint32_t)id[j] << 4) | (o[j] & 15u)) : kNoContrib;
+  }
+}
+// ... and the touched rows: one wavefront per row, lane = slot of the row; the kept words of the old block and the fresh words of the block,
+// both ascending, merged; the rest of the slot's column empty
+__global__ __launch_bounds__(kB) void k_table_touched(int n_new, OldPlan C, FreshPairs F, RowMaps M, const int* __restrict__ bptr, const int* __restrict__ bcol,
+                                                      const unsigned int* __restrict__ ucnt, const int* __restrict__ src, const int* __restrict__ slice_off,
+                                                      const int* __restrict__ slot_coff, uint32_t* __restrict__ contrib) {
+  const int lane = threadIdx.x & 63, n_waves = gridDim.x * (kB / 64), n_t = M.n_touched[0];
+  for (int it = blockIdx.x * (kB / 64) + (threadIdx.x >> 6); it < n_t; it += n_waves) {
+  const int rn = M.tlist[it];
+  const int s = rn >> 6, so = slice_off[s], w = slice_off[s + 1] - so;
+  const int first = bptr[rn], len = bptr[rn + 1] - first;
+  const int r = old_row_of(M, rn);
   const int so_old = r >= 0 ? C.slice_off[r >> 6] : 0, first_old = r >= 0 ? C.bptr[r] : 0;
-  for (int k = wv; k < w; k += kB / 64) {
-    const int height = slot_ccnt[so + k];  // wave-uniform
-    uint32_t* out = contrib + (size_t)slot_coff[so + k] * 64 + lane;
-    int cnt = 0, from = -1, col = -1;
-    if (k < len) { col = bcol[first + k]; cnt = (int)ucnt[first + k] - (col == rn ? 1 : 0); from = src[first + k]; }
-    if (!slow) {
-      // (an untouched row: block k of the new row is block k of the old one, in slot k of the old slice)
-      const uint32_t* in = from >= 0 ? C.contrib + (size_t)C.slot_coff[so_old + (from - first_old)] * 64 + (r & 63) : nullptr;
-      for (int t = 0; t < height; t++) {
-        uint32_t word = kNoContrib;
-        if (t < cnt) {
-          const uint32_t o = in[(size_t)t * 64];
-          word = ((uint32_t)M.newid[o >> 4] << 4) | (o & 15u);
-        }
-        out[(size_t)t * 64] = word;
+  const int2 fr = F.row[rn];
+  for (int k = lane; k < w; k += 64) {
+    const int coff = slot_coff[so + k], height = slot_coff[so + k + 1] - coff;
+    uint32_t* out = contrib + (size_t)coff * 64 + (rn & 63);
+    int t = 0;
+    if (k < len) {
+      const int col = bcol[first + k], from = src[first + k];
+      const uint32_t* in = nullptr;
+      int n_o = 0;
+      if (from >= 0) {
+        in = C.contrib + (size_t)C.slot_coff[so_old + (from - first_old)] * 64 + (r & 63);
+        n_o = (int)C.ucnt[from] - (C.bcol[from] == r ? 1 : 0);
       }
-    } else {
-      int t = 0;
-      if (k < len) {
-        const uint32_t* in = nullptr;
-        int n_o = 0;
-        if (from >= 0) {
-          in = C.contrib + (size_t)C.slot_coff[so_old + (from - first_old)] * 64 + (r & 63);
-          n_o = (int)C.ucnt[from] - (C.bcol[from] == r ? 1 : 0);
-        }
-        const unsigned long long key = ((unsigned long long)(unsigned int)rn << 32) | (unsigned int)col;
-        int f = fresh_lower(F, key);
-        int fe = fresh_lower(F, key + 1ULL);
-        if (fe > f && F.v[fe - 1] == kNoContrib) fe--;  // (the marker of a new node's diagonal block: last of its run, not a contribution)
-        int i = 0;
-        uint32_t wo = 0;
-        bool have = false;
-        for (;;) {
-          while (!have && i < n_o) {  // next kept word of the old block
-            const uint32_t o = in[(size_t)i * 64];
-            i++;
-            const int id = M.newid[o >> 4];
-            if (id >= 0) { wo = ((uint32_t)id << 4) | (o & 15u); have = true; }
+      const unsigned long long key = ((unsigned long long)(unsigned int)rn << 32) | (unsigned int)col;
+      int f = fresh_lower(F, key, fr.x, fr.y);
+      int fe = fresh_lower(F, key + 1ULL, f, fr.y);
+      if (fe > f && F.v[fe - 1] == kNoContrib) fe--;  // (the marker of a new node's diagonal block: last of its run, not a contribution)
+      uint32_t fw = f < fe ? F.v[f] : 0xFFFFFFFFu;    // next fresh word
+      // the old block eight words at a time (their loads, then their id-table entries, in flight together); a kept word goes out behind
+      // the fresh words that are smaller
+      for (int i0 = 0; i0 < n_o; i0 += 8) {
+        uint32_t o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = i0 + j < n_o ? in[(size_t)(i0 + j) * 64] : 0u;
+        int id[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) id[j] = i0 + j < n_o ? M.newid[o[j] >> 4] : -1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (id[j] < 0) continue;
+          const uint32_t wo = ((uint32_t)id[j] << 4) | (o[j] & 15u);
+          while (fw < wo) {
+            out[(size_t)t * 64] = fw;
+            t++;
+            f++;
+            fw = f < fe ? F.v[f] : 0xFFFFFFFFu;
           }
-          if (!have && f >= fe) break;
-          uint32_t word;
-          if (have && (f >= fe || wo < F.v[f])) { word = wo; have = false; }
-          else word = F.v[f++];
-          out[(size_t)t * 64] = word;
+          out[(size_t)t * 64] = wo;
           t++;
         }
       }
-      for (; t < height; t++) out[(size_t)t * 64] = kNoContrib;
+      while (f < fe) { out[(size_t)t * 64] = F.v[f]; t++; f++; }
     }
+    for (; t < height; t++) out[(size_t)t * 64] = kNoContrib;
+  }
   }
 }
 
@@ -467,6 +632,14 @@ int delta_positions(hipStream_t s, const MeshDelta& D, int n_old, const double* 
   return FB_OK;
 }
 
+int delta_reserve(hipStream_t s, MeshDelta& D, PlanWorkspace& W, long long n_fresh) {
+  const size_t n = (size_t)std::max<long long>(1, n_fresh);
+  FB_TRY(D.nk.reserve(n)); FB_TRY(D.nks.reserve(n)); FB_TRY(D.nv.reserve(n)); FB_TRY(D.nvs.reserve(n));
+  size_t bytes = 0;
+  FB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, D.nk.p, D.nks.p, D.nv.p, D.nvs.p, n, 0u, 64u, s));
+  return W.temp.reserve(std::max<size_t>(bytes, 16));
+}
+
 int delta_plan(hipStream_t s, MeshDelta& D, const OldPlanArrays& O, const int4* tets_old, const int4* tets_new, int n_new, DevicePlan& out, PlanWorkspace& W) {
   const int n_old = O.n_nodes;
   const long long n_fresh = 16LL * (D.n_changed + D.n_added) + D.n_new_nodes;
@@ -495,21 +668,27 @@ int delta_plan(hipStream_t s, MeshDelta& D, const OldPlanArrays& O, const int4* 
     FB_TRY(D.oldrow.reserve((size_t)n_new));
     hipLaunchKernelGGL(k_oldrow, grid_for(n_new), dim3(kB), 0, s, n_old, D.n_new_nodes, D.imap.p, D.newint.p, D.oldrow.p);
   }
-  const size_t tw = ((size_t)n_new + 31) / 32 + 1;
-  FB_TRY(D.touched.reserve(tw));
-  FB_HIP(hipMemsetAsync(D.touched.p, 0, sizeof(unsigned int) * tw, s));
+  // one buffer, one fill: the number of touched rows | a word per row | an int2 per row (its fresh entries) | the list of touched rows
+  const size_t tw = ((size_t)n_new + 4) & ~(size_t)1;
+  FB_TRY(D.touched.reserve(2 + tw + 2 * (size_t)n_new + 2 + (size_t)n_new));
+  FB_HIP(hipMemsetAsync(D.touched.p, 0, sizeof(unsigned int) * (2 + tw + 2 * (size_t)n_new + 2), s));
+  int* touched = reinterpret_cast<int*>(D.touched.p) + 2;
+  int2* frow = reinterpret_cast<int2*>(D.touched.p + 2 + tw);
+  int* tlist = reinterpret_cast<int*>(D.touched.p) + 2 + tw + 2 * (size_t)n_new + 2;
   const int n_gone = D.n_removed + D.n_changed;
   if (n_fresh + n_gone > 0) {
     hipLaunchKernelGGL(k_touch, grid_for(n_fresh + 4LL * n_gone), dim3(kB), 0, s, (int)n_fresh, D.nks.p, n_gone, D.removed, D.n_removed, D.changed_ids, tets_old,
-                       mapped ? D.imap.p : nullptr, D.touched.p);
+                       mapped ? D.imap.p : nullptr, touched, frow, tlist, reinterpret_cast<int*>(D.touched.p));
   }
   FB_HIP(hipGetLastError());
   OldPlan C = {O.bptr, O.bcol, O.ucnt, O.slice_off, O.slot_coff, O.contrib, n_old};
-  FreshPairs F = {D.nks.p, D.nvs.p, (int)n_fresh};
-  RowMaps M = {mapped ? D.oldrow.p : nullptr, mapped ? D.imap.p : nullptr, D.newid.p, D.touched.p, n_old};
+  FreshPairs F = {D.nks.p, D.nvs.p, (int)n_fresh, frow};
+  RowMaps M = {mapped ? D.oldrow.p : nullptr, mapped ? D.imap.p : nullptr, D.newid.p, touched, n_old, tlist, reinterpret_cast<const int*>(D.touched.p)};
+  const dim3 touched_grid(1024);  // (4,096 wavefronts take the touched rows from the list in turn)
   // 3. the pattern: row lengths, their scan, the blocks
   FB_TRY(D.len.reserve((size_t)n_new + 1));
-  hipLaunchKernelGGL(k_row_len, grid_for(n_new + 1), dim3(kB), 0, s, n_new, C, F, M, D.len.p);
+  hipLaunchKernelGGL(k_row_len, grid_for(n_new + 1), dim3(kB), 0, s, n_new, C, M, D.len.p);
+  hipLaunchKernelGGL(k_row_len_touched, touched_grid, dim3(kB), 0, s, C, F, M, D.len.p);
   FB_HIP(hipGetLastError());
   FB_TRY(out.bptr->alloc((size_t)n_new + 1));
   size_t bytes = 0;
@@ -523,14 +702,19 @@ int delta_plan(hipStream_t s, MeshDelta& D, const OldPlanArrays& O, const int4* 
   FB_TRY(out.blk_slot->alloc((size_t)std::max(1, nb)));
   FB_TRY(out.ucnt_keep->alloc((size_t)std::max(1, nb)));
   FB_TRY(D.src.reserve((size_t)std::max(1, nb)));
-  hipLaunchKernelGGL(k_row_blocks, grid_for(n_new), dim3(kB), 0, s, n_new, C, F, M, out.bptr->p, out.bcol->p, out.ucnt_keep->p, D.src.p);
+  hipLaunchKernelGGL(k_row_blocks, dim3((unsigned)(((n_new + 63) / 64 + kB / 64 - 1) / (kB / 64))), dim3(kB), 0, s, n_new, C, M, out.bptr->p, out.bcol->p, out.ucnt_keep->p, D.src.p);
+  hipLaunchKernelGGL(k_row_blocks_touched, touched_grid, dim3(kB), 0, s, C, F, M, out.bptr->p, out.bcol->p, out.ucnt_keep->p, D.src.p);
   FB_HIP(hipGetLastError());
   // 4. SELL layout, slot table, list heights and offsets: the second half of the builder, on the new pattern
   FB_TRY(plan_layout_from_csr(s, n_new, out.ucnt_keep->p, false, out, W));
   // 5. the contribution table from the old one
   FB_TRY(out.contrib->alloc(std::max<size_t>(1, (size_t)out.n_crows * kSliceRows)));
-  hipLaunchKernelGGL(k_table_from_table, dim3((unsigned)std::max(1, out.n_slices)), dim3(kB), 0, s, n_new, out.n_slices, C, F, M, out.bptr->p, out.bcol->p, out.ucnt_keep->p,
-                     D.src.p, out.slice_off->p, out.slot_coff->p, out.slot_ccnt->p, out.contrib->p);
+  FB_TRY(D.slot_slice.reserve((size_t)std::max(1, out.n_slots)));
+  hipLaunchKernelGGL(k_slot_slices, dim3((unsigned)std::max(1, (out.n_slices + kB / 64 - 1) / (kB / 64))), dim3(kB), 0, s, out.n_slices, out.slice_off->p, D.slot_slice.p);
+  hipLaunchKernelGGL(k_table_plain, dim3((unsigned)std::max(1, (out.n_slots + kB / 64 - 1) / (kB / 64))), dim3(kB), 0, s, n_new, out.n_slots, C, M, out.slice_off->p, D.slot_slice.p,
+                     out.slot_coff->p, out.contrib->p);
+  hipLaunchKernelGGL(k_table_touched, touched_grid, dim3(kB), 0, s, n_new, C, F, M, out.bptr->p, out.bcol->p, out.ucnt_keep->p, D.src.p, out.slice_off->p, out.slot_coff->p,
+                     out.contrib->p);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }

@@ -78,6 +78,7 @@ struct fb_fem_s {
   std::vector<double> x0_stage;  // host staging of the rest positions in local numbering (kept: a re-sync does not fault fresh pages)
   DevBuf<int> d_bptr, d_bcol, d_blk_slot;  // device-built plan only: pattern and slot table, fetched when an inspection entry point asks
   DevBuf<unsigned int> d_ucnt;             // ... and the pairs of every block (unsharded): with the three above and the contribution table, what fb_fem_resync_delta updates
+  bool span_stale = false;                 // ren.span_after / mean_after are to be measured again (fb_fem_renumbering)
   bool csr_ready = false;                  // the four describe the current plan
   bool device_plan = false, host_pattern = true;
   DevBuf<uint8_t> dofmask;
@@ -204,7 +205,7 @@ struct ZeroBatch {
   // p: 16-byte aligned (the start of an allocation); bytes: a multiple of 4 (else the runtime's fill takes it)
   void add(void* p, size_t bytes) {
     if (!p || !bytes || rc != FB_OK) return;
-    if (bytes < 4096 || (bytes & 3)) {  // (small ones: the runtime's fill)
+    if (bytes & 3) {  // (not a whole number of words: the runtime's fill)
       if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess) rc = fail(FB_EDEVICE, "hipMemsetAsync failed");
       return;
     }
@@ -229,9 +230,27 @@ struct ZeroBatch {
   }
 };
 
+// slack of this handle's allocations (common.h): a quarter for a mesh that will be cut, or what reserve_nodes / reserve_elements ask for
+int handle_slack(const fb_fem_s* h, int n_nodes, int n_tets) {
+  if (!h->prm.expect_cuts) return 2;
+  double f = 0.25;
+  if (h->prm.reserve_nodes > n_nodes && n_nodes > 0) f = std::max(f, (double)h->prm.reserve_nodes / n_nodes - 1.0);
+  if (h->prm.reserve_elements > n_tets && n_tets > 0) f = std::max(f, (double)h->prm.reserve_elements / n_tets - 1.0);
+  return std::max(2, std::min(32, (int)std::ceil(f * 16.0)));
+}
+
+constexpr int kFreshOrderPercent = 2;
+int fresh_order_percent() {
+  const char* e = getenv("FEMBRAIN_FRESH_ORDER_PERCENT");
+  return e ? std::max(0, atoi(e)) : kFreshOrderPercent;
+}
+
 int renumber_mode(const fb_fem_s* h) {
   if (const char* e = getenv("FEMBRAIN_RENUMBER")) return atoi(e) != 0 ? FB_RENUMBER_ON : FB_RENUMBER_OFF;
   if (h->prm.renumber == 0 && h->shard_auto_on) return FB_RENUMBER_ON;  // (a sharded handle under AUTO whose ranks voted for it)
+  // a mesh that will be cut: the nodes a cut appends make any caller order wide, so the internal order is chosen at creation and the
+  // first fb_fem_resync_delta merges its nodes into it instead of sending the mesh through the full builder
+  if (h->prm.renumber == 0 && h->prm.expect_cuts && h->plan.n_ranks <= 1 && !h->comm) return FB_RENUMBER_ON;
   return h->prm.renumber > 0 ? FB_RENUMBER_ON : (h->prm.renumber < 0 ? FB_RENUMBER_OFF : FB_RENUMBER_AUTO);
 }
 
@@ -416,6 +435,7 @@ void read_persist_timeout(fb_fem_s* h) {
 int setup_persist(fb_fem_s* h) {
   const FemPlan& P = h->plan;
   hipStream_t s = h->stream;
+  ZeroBatch zb(s);  // (the clears of this set-up in one launch)
   h->persist = false;
   // Nothing of the previous plan's sharded persistent solver survives a rebuild: a re-sync to a mesh that is no longer
   // eligible must not leave attach_pipe_shard a stale "keep", stale send lists or a stale workgroup deal.  setup_persist_shard_local
@@ -463,17 +483,17 @@ int setup_persist(fb_fem_s* h) {
   // slots of every slice resident in LDS at least: the CU's kPipeLdsSlots dealt to the slices of a workgroup (k_pcg_pipe), at most 8 / 6
   h->pipe_klt = h->pipe_rows == 2 ? 0 : std::min(w <= 8 ? 8 : 6, kPipeLdsSlots / std::max(w, 1));
   FB_TRY(h->pipe_post.alloc((size_t)2 * nb * 4));
-  FB_TRY(h->pipe_post.zero(s));
+  zb.add(h->pipe_post);
   h->pipe_flag_extra = P.n_ranks > 1 ? kP2PMaxRanks : 0;
   FB_TRY(h->pipe_flags.alloc((size_t)nb + h->pipe_flag_extra + 16));
-  FB_TRY(h->pipe_flags.zero(s));
+  zb.add(h->pipe_flags);
   const size_t n_pad = (size_t)P.n_slices * 64, nv = (size_t)3 * P.n_local + 2;
   FB_TRY(h->pipe_planes.alloc(2 * 3 * n_pad));
-  FB_TRY(h->pipe_planes.zero(s));
+  zb.add(h->pipe_planes);
   FB_TRY(h->pipe_z.alloc(nv));
   FB_TRY(h->pipe_s.alloc(nv));
   FB_TRY(h->pipe_state.alloc(2));
-  FB_TRY(h->pipe_state.zero(s));
+  zb.add(h->pipe_state);
   if (getenv("FEMBRAIN_PERSIST_TIMING")) {
     FB_TRY(h->persist_timing.alloc((size_t)nb * kPipeMaxWaves * 6));
     FB_TRY(h->persist_timing.zero(s));
@@ -489,7 +509,8 @@ int setup_persist(fb_fem_s* h) {
   FB_TRY(h->pipe_prod_count.alloc((size_t)nb));
   FB_TRY(h->pipe_prod_xcd.alloc((size_t)nb));
   FB_TRY(h->pipe_stats.alloc(2));
-  FB_TRY(h->pipe_stats.zero(s));
+  zb.add(h->pipe_stats);
+  FB_TRY(zb.flush());
   hipLaunchKernelGGL(k_slice_owner, dim3(ceil_div(nb, kBlock)), dim3(kBlock), 0, s, P.n_slices, nb, h->pipe_owner.p);
   hipLaunchKernelGGL(k_slice_producers, dim3(ceil_div(std::max(1, P.n_slices), kWavesPerBlock)), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->slice_off.p, h->colidx.p,
                      h->pipe_owner.p, h->pipe_mask.p);
@@ -499,7 +520,8 @@ int setup_persist(fb_fem_s* h) {
   h->pipe_stats_pending = true;  // (the longest list is fetched when fb_fem_pcg_path asks)
   h->pipe_max_producers = 0;
   FB_TRY(h->pipe_xcc.alloc((size_t)nb));
-  FB_TRY(h->pipe_xcc.zero(s));
+  zb.add(h->pipe_xcc);
+  FB_TRY(zb.flush());
   {
     // interior workgroups publish with plain stores where the iteration is latency-bound (measured, us per iteration with / without:
     // 9.5 / 10.2 at 466 slices, 9.5 / 9.9 at 1,000; 17.4 / 17.1 at 2,744 = 1M tets, where the matrix stream evicts the lines from
@@ -1585,6 +1607,7 @@ int rest_state_checked(fb_fem_s* h) {
 int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed, const int* fixed, int n_ranks,
           int rank, const int* splits, const DeviceTetMesh* dm = nullptr) {
   drop_graph(h);  // the buffers it refers to are about to be replaced
+  SlackScope slack(handle_slack(h, n_nodes, n_tets));
   if (h->prm.matrix_precision == FB_MATRIX_AUTO) {
     // fp32 values from 2 slices per CU on (setup_persist's `w`, the persistent solver's range), on shards, and where the persistent
     // solver is asked for by name; fp64 below (include/fembrain_hip.h, FB_MATRIX_AUTO)
@@ -1595,6 +1618,7 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
   }
   h->last_resync_path = FB_RESYNC_FULL;
   h->csr_ready = false;
+  h->span_stale = false;
   h->ren.clear();
   h->l2c.clear();
   h->order_sum = 0;
@@ -1810,6 +1834,8 @@ int attach_p2p(fb_fem_s* h) {
   return FB_OK;
 }
 
+int prewarm_delta(fb_fem_s* h, int n_fixed, const int* fixed);
+
 int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, const int* tets, int n_fixed, const int* fixed,
                   const fb_fem_params* params, int n_ranks, int rank, const int* splits, fb_comm_t comm, const DeviceTetMesh* dm = nullptr) {
   if (!out || (!dm && (!xyz || !tets)) || !params) return fail(FB_EINVAL, "null argument");
@@ -1867,6 +1893,8 @@ int create_common(fb_fem_t* out, int n_nodes, const double* xyz, int n_tets, con
     if (hipHostMalloc((void**)&h->st_host, 2 * sizeof(CGState), hipHostMallocDefault) != hipSuccess) { rc = fail(FB_ENOMEM, "hipHostMalloc failed"); break; }
     if (const char* e = getenv("FEMBRAIN_GRAPH")) h->use_graph = atoi(e) != 0;
     rc = build(h, n_nodes, xyz, n_tets, tets, n_fixed, fixed, n_ranks, rank, splits, dm);
+    // a mesh that will be cut: the workspace of fb_fem_resync_delta now, not inside the first cut
+    if (rc == FB_OK && h->prm.expect_cuts && n_ranks == 1 && h->device_plan) rc = prewarm_delta(h, n_fixed, fixed);
    } while (0);
     if (comm && comm->n_ranks > 1) {  // creation is collective: the ranks agree on the outcome so far before the collective attach
       const std::string why = rc == FB_OK ? std::string() : last_error();
@@ -2222,15 +2250,20 @@ int resync_delta(fb_fem_s* h, int n_removed, const int* removed, int n_changed, 
   MeshDelta& D = h->delta;
   PlanWorkspace& W = h->plan_ws;
   const int n_old = h->plan.n_global, nt_old = h->plan.n_tets, n_new = n_old + n_new_nodes;
+  SlackScope slack(handle_slack(h, n_new, nt_old - n_removed + n_added));
   drop_graph(h);
   FB_TRY(delta_upload(s, nt_old, n_removed, removed, n_changed, changed_ids, changed_nodes, n_added, added, n_new_nodes, new_xyz, D, W));
   const int nt_new = D.n_tets_new();
   lap("change uploaded");
   const char* env = getenv("FEMBRAIN_RESYNC_DELTA");
   bool merge = h->csr_ready && !(env && !strcmp(env, "rebuild"));
-  // A renumbered handle keeps the cell size its order was made with while nodes are added; once a tenth more nodes have come, a
-  // fresh order pays for its rebuild (measured after six cuts of 5 % each at 1M tets: 151 against 130 us per PCG iteration)
-  if (merge && h->ren.active && (long long)n_new * 10 > (long long)h->ren_nodes_at_build * 11) merge = false;
+  // A renumbered handle keeps the order it has while nodes are added -- new nodes are merged in, old ones stay where they are although
+  // the cut has changed how many elements sit on them, so rows of unlike length come to share a slice and the matrix pads.  Measured at
+  // 1.1M tets (tools/probe_resync_delta.py): 9 % more nodes merged in, 42.5 us per PCG iteration against 30.6 in a fresh order -- 26 ms per
+  // step -- where the full builder from the device copy of the mesh costs 2.9 ms once.  So once kFreshOrderPercent more nodes have come
+  // than the order was built for, the change gets a fresh order (FEMBRAIN_FRESH_ORDER_PERCENT overrides: the tests keep the merged
+  // path busy with larger changes)
+  if (merge && h->ren.active && (long long)n_new * 100 > (long long)h->ren_nodes_at_build * (100 + fresh_order_percent())) merge = false;
   const int mode = renumber_mode(h);
   int span = -1;
   double mean = 0.0;
@@ -2260,8 +2293,7 @@ int resync_delta(fb_fem_s* h, int n_removed, const int* removed, int n_changed, 
     FB_TRY(delta_relabel_nodes(s, D, n_new, h->ren.d_new_of_old.p));
     FB_TRY(h->tets_next.alloc((size_t)nt_new));
     FB_TRY(delta_tets(s, D, h->tets.p, D.mapped ? D.imap.p : nullptr, h->tets_next.p));
-    FB_TRY(tet_span_device(s, nt_new, h->tets_next.p, n_new, nullptr, W, &span, &mean));
-    h->ren.span_after = span; h->ren.mean_after = mean;
+    h->span_stale = true;  // (the widest element under the merged order is measured when fb_fem_renumbering asks: a pass and a wait saved here)
   } else {
     h->ren.clear();
     if (mode != FB_RENUMBER_OFF) { h->ren.span_before = h->ren.span_after = span; h->ren.mean_before = h->ren.mean_after = mean; }
@@ -2318,6 +2350,23 @@ int resync_delta(fb_fem_s* h, int n_removed, const int* removed, int n_changed, 
   lap("rest state");
   return FB_OK;
 }
+
+// fb_fem_params.expect_cuts: everything a fb_fem_resync_delta allocates -- the second set of plan arrays it builds into, the element and
+// node maps, the sort's temporaries for a change of a twentieth of the elements -- is allocated at creation by running the empty change
+int prewarm_delta(fb_fem_s* h, int n_fixed, const int* fixed) {
+  MeshDelta& D = h->delta;
+  FB_TRY(delta_reserve(h->stream, D, h->plan_ws, (long long)16 * (h->plan.n_tets / 20 + 64)));
+  if (h->ren.active) {
+    // ... and the node order's second stage on this mesh, into a scratch order: a cut mesh needs it (renumber.h) where the uncut one did
+    // not, and the first launch of its kernels in a process costs milliseconds (7 of the 9.7 ms of a first cut, tools/probe_resync_delta.py)
+    Renumbering scratch;
+    FB_TRY(renumber_build(h->stream, FB_RENUMBER_ON, h->plan.n_global, h->plan.n_tets, h->tets.p, h->x0.p, h->plan_ws, scratch, true));
+  }
+  FB_TRY(resync_delta(h, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, n_fixed, fixed));
+  h->last_resync_path = FB_RESYNC_FULL;
+  return FB_OK;
+}
+
 }  // namespace
 
 int fb_fem_resync_delta(fb_fem_t h, int n_removed, const int* removed, int n_changed, const int* changed_ids, const int* changed_nodes, int n_added,
@@ -2688,6 +2737,14 @@ int fb_fem_halo_info(fb_fem_t h, int* n_halo_nodes, int* n_neighbour_ranks) {
 
 int fb_fem_renumbering(fb_fem_t h, int* span_caller, int* span_internal) {
   if (!h) return 0;
+  if (h->span_stale && !h->poisoned && hipSetDevice(h->prm.device) == hipSuccess) {  // (a merged fb_fem_resync_delta left the measurement for now)
+    int span = 0;
+    double mean = 0.0;
+    if (tet_span_device(h->stream, h->plan.n_tets, h->tets.p, h->plan.n_global, nullptr, h->plan_ws, &span, &mean) == FB_OK) {
+      h->ren.span_after = span; h->ren.mean_after = mean;
+      h->span_stale = false;
+    }
+  }
   if (span_caller) *span_caller = h->ren.span_before;
   if (span_internal) *span_internal = h->ren.span_after;
   return h->ren.active ? 1 : 0;

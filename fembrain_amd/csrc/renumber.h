@@ -38,8 +38,9 @@ __host__ __device__ inline unsigned long long slab_key(const SlabKeyGeom& g, dou
     const int ax = g.axis[a];
     const double t = (p[ax] - g.lo[ax]) * g.inv_h + 0.5;
     const long long top = (1LL << g.bits[a]) - 1;
-    long long q = t > 0.0 ? (long long)t : 0;  // (NaN compares false: cell 0)
-    if (q > top) q = top;
+    // clamped in floating point BEFORE the conversion (a huge or infinite coordinate converts to anything on the host and saturates on
+    // the device: the two orders would disagree); NaN compares false: cell 0
+    const long long q = !(t > 0.0) ? 0 : (t >= (double)top ? top : (long long)t);
     k = (k << g.bits[a]) | (unsigned long long)q;
   }
   return k;
@@ -98,7 +99,8 @@ int tet_span_device(hipStream_t s, int n_tets, const int4* d_tets, int n_nodes, 
 // builds it from the caller-order rest positions on the device (3 doubles per node) and decides whether it stands (R.active).
 // Both synchronise the stream.
 int renumber_decide(hipStream_t s, int mode, int n_nodes, int n_tets, const int4* d_tets, PlanWorkspace& W, Renumbering& R, bool* want);
-int renumber_build(hipStream_t s, int mode, int n_nodes, int n_tets, const int4* d_tets, const double* d_xyz, PlanWorkspace& W, Renumbering& R);
+// force_sigma: the second stage whatever the padding (fb_fem_params.expect_cuts warms its kernels and temporaries at creation)
+int renumber_build(hipStream_t s, int mode, int n_nodes, int n_tets, const int4* d_tets, const double* d_xyz, PlanWorkspace& W, Renumbering& R, bool force_sigma = false);
 int relabel_tets(hipStream_t s, int n_tets, int4* d_tets, int n_nodes, const int* d_new_of_old);
 // node-wise permutations of arrays of `width` doubles per node: dst[l] = src[map[l]] / dst[map[l]] = src[l]
 int gather_nodes(hipStream_t s, int n, int width, const double* src, const int* map, double* dst);

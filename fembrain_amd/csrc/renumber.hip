@@ -237,7 +237,7 @@ int renumber_decide(hipStream_t s, int mode, int n_nodes, int n_tets, const int4
   return FB_OK;
 }
 
-int renumber_build(hipStream_t s, int mode, int n_nodes, int n_tets, const int4* d_tets, const double* d_xyz, PlanWorkspace& W, Renumbering& R) {
+int renumber_build(hipStream_t s, int mode, int n_nodes, int n_tets, const int4* d_tets, const double* d_xyz, PlanWorkspace& W, Renumbering& R, bool force_sigma) {
   R.active = false;
   // bounding box
   FB_TRY(W.temp.reserve(sizeof(double) * 6 * kBoxBlocks));
@@ -282,7 +282,7 @@ int renumber_build(hipStream_t s, int mode, int n_nodes, int n_tets, const int4*
     FB_HIP(hipStreamSynchronize(s));
     long long padded = 0, used = 0;
     for (const int2& q : sc) { padded += 64LL * q.x; used += q.y; }
-    if (sigma_wanted(n_nodes, padded, used)) {
+    if (force_sigma || sigma_wanted(n_nodes, padded, used)) {
       R.window = sigma_window(n_nodes);
       R.n_windows = (n_nodes + R.window - 1) / R.window;
       FB_TRY(R.d_win_keys.alloc((size_t)R.n_windows));

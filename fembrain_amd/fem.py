@@ -18,7 +18,8 @@ class FemIntegrator:
     def __init__(self, verts, tets, fixed_dofs=(), E=1e7, nu=0.46, rho=1000.0, timestep=0.0333,
                  damping_mass=0.0, damping_stiffness=0.01, cg_eps=1e-6, cg_max_iter=10000,
                  matrix_precision=_l.FB_MATRIX_AUTO, device=0, shard=None, pcg_variant=_l.FB_PCG_MERGED, spmv_kernel=_l.FB_SPMV_AUTO,
-                 linear=False, exact_tangent=False, integrator=_l.FB_INTEGRATOR_VOLUME_CONSERVING, renumber=_l.FB_RENUMBER_AUTO):
+                 linear=False, exact_tangent=False, integrator=_l.FB_INTEGRATOR_VOLUME_CONSERVING, renumber=_l.FB_RENUMBER_AUTO, expect_cuts=False,
+                 reserve_nodes=0, reserve_elements=0):
         """shard = (n_ranks, rank, node_splits or None, comm_handle) for a domain-decomposed handle."""
         L = _l.lib()
         self._L = L
@@ -38,6 +39,7 @@ class FemIntegrator:
         p.exact_tangent = 1 if exact_tangent else 0
         p.integrator = integrator
         p.renumber = renumber
+        p.expect_cuts, p.reserve_nodes, p.reserve_elements = int(bool(expect_cuts)), int(reserve_nodes), int(reserve_elements)
         self.params = p
         self.h = C.c_void_p()
         self.node_lo, self.node_hi = 0, self.n_nodes

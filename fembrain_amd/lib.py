@@ -38,7 +38,8 @@ class FemParams(C.Structure):
     _fields_ = [("E", C.c_double), ("nu", C.c_double), ("rho", C.c_double), ("timestep", C.c_double),
                 ("damping_mass", C.c_double), ("damping_stiffness", C.c_double), ("cg_eps", C.c_double),
                 ("cg_max_iter", C.c_int), ("matrix_precision", C.c_int), ("device", C.c_int),
-                ("pcg_variant", C.c_int), ("spmv_kernel", C.c_int), ("linear", C.c_int), ("exact_tangent", C.c_int), ("integrator", C.c_int), ("renumber", C.c_int)]
+                ("pcg_variant", C.c_int), ("spmv_kernel", C.c_int), ("linear", C.c_int), ("exact_tangent", C.c_int), ("integrator", C.c_int), ("renumber", C.c_int),
+                ("expect_cuts", C.c_int), ("reserve_nodes", C.c_int), ("reserve_elements", C.c_int)]
 
 
 class StepInfo(C.Structure):

@@ -99,6 +99,15 @@ typedef struct fb_fem_params {
                                  * FB_INTEGRATOR_NEWMARK (ImplicitNewmarkSparse::DoTimestep, implicitNewmarkSparse.cpp:183-379) */
   int renumber;                 /* FB_RENUMBER_AUTO (0) / FB_RENUMBER_ON / FB_RENUMBER_OFF: locality renumbering of the nodes inside the handle,
                                  * see below.  FEMBRAIN_RENUMBER=0/1 in the environment overrides */
+  int expect_cuts;              /* non-zero: the caller will cut this mesh (CuttableMesh::cut, deformable/CuttableMesh.cpp:283-470: cells erased,
+                                 * pieces and nodes appended) and re-sync with fb_fem_resync_delta.  The handle then (1) keeps a quarter of slack
+                                 * in every buffer that grows with the mesh (an eighth otherwise) -- or room for reserve_nodes / reserve_elements --
+                                 * so that a growing mesh re-allocates every few cuts, not every second one; (2) chooses its internal node order
+                                 * at creation under FB_RENUMBER_AUTO (appended nodes make any caller order wide at the first cut: the full
+                                 * builder would run then); (3) allocates the re-sync's workspace at creation.  The first fb_fem_resync_delta is
+                                 * then as cheap as the fifth.  Unsharded handles. */
+  int reserve_nodes;            /* expect_cuts: node / element counts the mesh is expected to reach (0: a quarter more than it has) */
+  int reserve_elements;
 } fb_fem_params;
 /* Node numbering.  FemBrain appends every node a cut creates at the end of the node list (deformable/VolMesh.cpp:1086-1091,
  * 1639-1642) and its shipped tet meshes are TetGen outputs (surface vertices first): numberings in which a node's neighbours lie

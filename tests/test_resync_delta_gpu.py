@@ -16,6 +16,16 @@ from fembrain_amd.fem import FemIntegrator, bsr_to_scipy
 from fembrain_amd.meshgen import apply_delta, cube_fixed_plane_i0, fixed_vertices_to_dofs, synthetic_cut, truth_cube
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _keep_the_merged_path_busy(monkeypatch):
+    """By default a renumbered handle asks for a fresh node order once 2 % more nodes have come than its order was built for (a fresh order
+    pays for its rebuild within one step, fem.hip kFreshOrderPercent).  The tests below exercise the MERGED path with larger changes on
+    small meshes, so they run with the limit at a tenth (read at every call); test_fresh_order_rule checks the default."""
+    monkeypatch.setenv("FEMBRAIN_FRESH_ORDER_PERCENT", "10")
+
+
 PLAN = ("bptr", "bcol", "blk_slot", "slice_off", "colidx", "slot_coff", "slot_ccnt", "contrib")
 
 
@@ -184,6 +194,59 @@ def test_delta_resync_on_a_handle_with_its_own_node_order(gpu):
     _same_bits(g, ref, seed=9, load=-200.0)
     g.close()
     ref.close()
+
+
+def test_a_handle_that_expects_cuts_merges_its_first_cut(gpu):
+    """fb_fem_params.expect_cuts: the internal node order is chosen at creation -- a grid keeps its plane-by-plane
+    order -- so the FIRST cut already merges its nodes into it and updates the plan (FB_RESYNC_DELTA_MERGED) where a default handle sends
+    the mesh through the full builder; buffers carry a quarter of slack.  Same pattern, values and steps as a handle made from the cut mesh."""
+    v, t, fixed = _cube(22)
+    g = FemIntegrator(v, t, fixed, expect_cuts=True)
+    assert g.renumbering()[0] and g.resync_path() == fl.FB_RESYNC_FULL
+    g.set_uniform_force(1, -200.0)
+    assert g.do_timestep() > 0
+    cv, ct = v, t
+    for k, (axis, where) in enumerate(((1, 0.45), (0, 0.62))):
+        cv, ct, d = synthetic_cut(cv, ct, axis=axis, where=where, stride=5 + k)   # (fewer than a tenth more nodes in all: the order is kept)
+        g.resync_delta(d, fixed)
+        assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED, (k, g.resync_path())
+        assert not np.any(g.get_q_state()[0])
+    ref = FemIntegrator(cv, ct, fixed)
+    bp, bc = g.pattern()
+    rp, rc = ref.pattern()
+    assert np.array_equal(bp, rp) and np.array_equal(bc, rc)
+    u = np.random.default_rng(3).normal(size=g.r) * 0.003
+    fa, Ka = g.assemble(u)
+    fr, Kr = ref.assemble(u)
+    assert np.abs(fa - fr).max() <= 1e-12 * np.abs(fr).max() and np.abs(Ka - Kr).max() <= 2e-7 * np.abs(Kr).max()
+    for h in (g, ref):
+        h.set_uniform_force(1, -200.0)
+    its = [g.do_timestep(), ref.do_timestep()]
+    qa, qr = g.get_q_state()[0], ref.get_q_state()[0]
+    assert abs(its[0] - its[1]) <= 2 and np.abs(qa - qr).max() <= 2e-5 * np.abs(qr).max() and not qa[fixed].any()
+    # reserve_nodes / reserve_elements: room asked for by count
+    g2 = FemIntegrator(v, t, fixed, expect_cuts=True, reserve_nodes=2 * len(v), reserve_elements=2 * len(t))
+    g2.resync_delta(synthetic_cut(v, t, axis=1, where=0.45, stride=3)[2], fixed)
+    assert g2.resync_path() == fl.FB_RESYNC_DELTA_MERGED
+    g.close(); ref.close(); g2.close()
+
+
+def test_fresh_order_rule(gpu, monkeypatch):
+    """the default: a renumbered handle merges a change that brings fewer than 2 % more nodes than its order was built for, and sends a larger
+    one through the full builder (from the device copy of the mesh) for a fresh order -- bit for bit fb_fem_resync"""
+    monkeypatch.delenv("FEMBRAIN_FRESH_ORDER_PERCENT")
+    v, t, fixed = _cube(22)
+    g = FemIntegrator(v, t, fixed, expect_cuts=True)
+    v2, t2, d = synthetic_cut(v, t, axis=1, where=0.45, stride=16)       # 166 new nodes: 1.6 %
+    assert 0 < len(d["new_xyz"]) * 100 < 2 * len(v)
+    g.resync_delta(d, fixed)
+    assert g.resync_path() == fl.FB_RESYNC_DELTA_MERGED
+    v3, t3, d2 = synthetic_cut(v2, t2, axis=0, where=0.62, stride=16)    # ... and as many again: 3.1 % in all
+    g.resync_delta(d2, fixed)
+    assert g.resync_path() == fl.FB_RESYNC_DELTA_REBUILT
+    ref = FemIntegrator(v3, t3, fixed, renumber=fl.FB_RENUMBER_ON)
+    _same_bits(g, ref, load=-200.0)
+    g.close(); ref.close()
 
 
 def test_delta_resync_refuses_bad_input_before_anything_changes(gpu):
@@ -401,7 +464,7 @@ def test_delta_resync_on_a_node_order_with_the_second_stage(gpu):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FEMBRAIN_SIGMA="1", FEMBRAIN_TIMING="1")
+    env = dict(os.environ, FEMBRAIN_SIGMA="1", FEMBRAIN_TIMING="1", FEMBRAIN_FRESH_ORDER_PERCENT="10")
     out = subprocess.run([sys.executable, "-c", _SIGMA_SCRIPT, root], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
     assert "sigma delta ok" in out.stdout
