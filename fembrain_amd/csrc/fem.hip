@@ -1614,7 +1614,10 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
     const int cus = h->cu_limit > 0 ? std::min(h->cu_limit, h->n_cu_device) : h->n_cu_device;
     const int nb = std::min(kPipeMaxBlocks, (cus / 8) * 8);
     const int w = nb >= 8 ? ceil_div(ceil_div(ceil_div(n_nodes, 64), 8), nb / 8) : 0;
-    h->f64 = n_ranks == 1 && h->prm.pcg_variant != FB_PCG_PERSISTENT && w < 2;
+    // (a shard decides by the WHOLE mesh, so that the sharded and the unsharded handle of one mesh store the same values; the sharded
+    // persistent solver, asked for through the environment, needs fp32 as the unsharded one does)
+    const bool shard_persist_asked = n_ranks > 1 && getenv("FEMBRAIN_SHARDED_PERSIST") && atoi(getenv("FEMBRAIN_SHARDED_PERSIST")) != 0;
+    h->f64 = h->prm.pcg_variant != FB_PCG_PERSISTENT && !shard_persist_asked && w < 2;
   }
   h->last_resync_path = FB_RESYNC_FULL;
   h->csr_ready = false;

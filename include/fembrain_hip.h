@@ -25,7 +25,7 @@ extern "C" {
 #define FB_MATRIX_F32 0 /* north-star fp32 stiffness storage (every product, sum and vector stays fp64) */
 #define FB_MATRIX_F64 1 /* reference-width storage, used by the tight parity tests */
 /* default (fb_fem_default_params): by size.  fp32 where it buys speed -- from 2 SELL slices per CU on (> 16,384 nodes on 256 CUs: the
- * persistent solver's range, where a third of the matrix stays in LDS) and on every sharded handle -- and fp64 below: a system that
+ * persistent solver's range, where a third of the matrix stays in LDS; a shard decides by the whole mesh) -- and fp64 below: a system that
  * small is solved from L2 by the two-launch iteration either way, and fp32 storage only costs it accuracy (the 204-DOF disc.1.veg, condition
  * ~1e5: 1e-2 of max|q| after three steps with fp32 values, 2e-5 with fp64).  Decided again at every re-sync.
  * FB_PCG_PERSISTENT asked for explicitly means fp32. */

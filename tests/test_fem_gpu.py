@@ -961,6 +961,7 @@ def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, mo
     # "tets": the default -- k_assemble_tets_st (2: records staged in LDS by one wavefront, mass entries from k_mass_blocks) for fp32
     # records and the plain tangent, else k_assemble_tets (1); "tets1": k_assemble_tets; "rows": k_assemble_rows (0)
     staged = not case.endswith("f64") and not case.endswith("tangent")
+    kw.setdefault("matrix_precision", fl.FB_MATRIX_F32)       # (the fp32 kernels are the subject; FB_MATRIX_AUTO would store these small meshes as fp64)
     for kern in ("tets", "tets1", "rows"):
         monkeypatch.setenv("FEMBRAIN_ASM_KERNEL", kern)
         g = FemIntegrator(v, t, fixed, **kw)
@@ -992,7 +993,7 @@ def test_16bit_column_differences_give_identical_iterates(gpu, monkeypatch):
     out = []
     for c16 in ("1", "0"):
         monkeypatch.setenv("FEMBRAIN_SPMV_C16", c16)
-        g = FemIntegrator(v, t, fixed, spmv_kernel=fl.FB_SPMV_ROWS)
+        g = FemIntegrator(v, t, fixed, spmv_kernel=fl.FB_SPMV_ROWS, matrix_precision=fl.FB_MATRIX_F32)
         its = []
         for _ in range(2):
             g.set_uniform_force(1, -10000.0)
@@ -1008,7 +1009,7 @@ def test_16bit_column_differences_give_identical_iterates(gpu, monkeypatch):
     v2 = np.concatenate([v[:half], pad, v[half:]])
     t2 = np.where(t >= half, t + 40000, t).astype(np.int32)
     fixed2 = fixed_vertices_to_dofs(np.nonzero(v2[:, 0] < v[:, 0].min() + 1e-9)[0])
-    g2 = FemIntegrator(v2, t2, fixed2, spmv_kernel=fl.FB_SPMV_ROWS, renumber=fl.FB_RENUMBER_OFF)
+    g2 = FemIntegrator(v2, t2, fixed2, spmv_kernel=fl.FB_SPMV_ROWS, matrix_precision=fl.FB_MATRIX_F32, renumber=fl.FB_RENUMBER_OFF)
 
     def index_bytes(g):
         n, nb = g.n_nodes, g.num_blocks()
@@ -1016,10 +1017,10 @@ def test_16bit_column_differences_give_identical_iterates(gpu, monkeypatch):
 
     assert index_bytes(g2) == 4.0
     # (round 4) left to itself the handle renumbers such a mesh (fembrain_amd/csrc/renumber.h) and the differences fit again
-    g4 = FemIntegrator(v2, t2, fixed2, spmv_kernel=fl.FB_SPMV_ROWS)
+    g4 = FemIntegrator(v2, t2, fixed2, spmv_kernel=fl.FB_SPMV_ROWS, matrix_precision=fl.FB_MATRIX_F32)
     assert g4.renumbering()[0] and index_bytes(g4) == 2.0
     g4.close()
-    g3 = FemIntegrator(v, t, fixed, spmv_kernel=fl.FB_SPMV_ROWS)
+    g3 = FemIntegrator(v, t, fixed, spmv_kernel=fl.FB_SPMV_ROWS, matrix_precision=fl.FB_MATRIX_F32)
     assert index_bytes(g3) == 2.0
     g2.set_uniform_force(1, -1000.0)
     assert g2.do_timestep() > 0
@@ -1078,6 +1079,7 @@ def test_failed_resync_poisons_the_handle_until_a_good_one(gpu):
 # reference's own CorotationalLinearFEM + CGSolver, tests/golden/make_fem_golden.py) AND against the two-launch solver of the same
 # library; fb_fem_pcg_path says which kernel ran.
 def _two_launch(monkeypatch, *a, **kw):
+    kw.setdefault("matrix_precision", fl.FB_MATRIX_F32)   # (the partner of a persistent handle, whose values are fp32; FB_MATRIX_AUTO would store a small mesh as fp64)
     monkeypatch.setenv("FEMBRAIN_PCG_PERSIST", "0")
     g = FemIntegrator(*a, **kw)
     monkeypatch.delenv("FEMBRAIN_PCG_PERSIST")
