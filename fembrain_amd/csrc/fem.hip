@@ -479,9 +479,16 @@ int setup_persist(fb_fem_s* h) {
   // up to 12 slices per CU: one row per lane (k_pcg_pipe); 13..24: two (k_pcg_pipe2, no LDS-resident slots).  FEMBRAIN_PERSIST_ROWS=2
   // forces the two-row kernel on a smaller system (tests).
   h->pipe_rows = w > kPipeMaxWaves || rows2_forced ? 2 : 1;
-  h->pipe_wmax = h->pipe_rows == 2 ? 12 : (w <= 8 ? 8 : 12);
-  // slots of every slice resident in LDS at least: the CU's kPipeLdsSlots dealt to the slices of a workgroup (k_pcg_pipe), at most 8 / 6
-  h->pipe_klt = h->pipe_rows == 2 ? 0 : std::min(w <= 8 ? 8 : 6, kPipeLdsSlots / std::max(w, 1));
+  // Up to 4 slices per CU (BASELINE config 2: 105k tets = 2 per CU) k_pcg_pipe<..,5,16> keeps the WHOLE slice in LDS -- 16 slots each where
+  // (8, 8) keeps 8 of ~15 and streams the rest from L2 in every product.  Built, tested, measured -- and NOT the
+  // default: 9.24 / 9.50 / 9.63 us per iteration at 27^3 / 33^3 / 37^3 against 8.82 / 9.06 / 9.58 with (8, 8).  The phase table says why
+  // (profiles/r05_small_mesh_phase_table.txt): the product is 2.2 of the 8.9 us, the other 6.6 are the hand-offs between the CUs (drain of
+  // the publish stores 1.0, flag + neighbour wait + acquire 3.2, sweep of the sums 2.0, recurrences 0.5), which no residency shortens.
+  // FEMBRAIN_PIPE_SMALL=1 selects it.
+  const bool small = h->pipe_rows == 1 && w <= 4 && !bj && P.n_ranks == 1 && getenv("FEMBRAIN_PIPE_SMALL") && atoi(getenv("FEMBRAIN_PIPE_SMALL")) != 0;
+  h->pipe_wmax = h->pipe_rows == 2 ? 12 : (small ? 5 : (w <= 8 ? 8 : 12));
+  // slots of every slice resident in LDS at least: the CU's kPipeLdsSlots dealt to the slices of a workgroup (k_pcg_pipe), at most 16 / 8 / 6
+  h->pipe_klt = h->pipe_rows == 2 ? 0 : std::min(small ? 16 : (w <= 8 ? 8 : 6), kPipeLdsSlots / std::max(w, 1));
   FB_TRY(h->pipe_post.alloc((size_t)2 * nb * 4));
   zb.add(h->pipe_post);
   h->pipe_flag_extra = P.n_ranks > 1 ? kP2PMaxRanks : 0;
@@ -1110,10 +1117,13 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     else FB_PIPE(false, 12, 6, false, true);
   } else if (h->pipe_rows == 2) {
     if (h->c16) FB_PIPE2(true, false); else FB_PIPE2(false, false);
-  } else if (pa.timing) {  // development build with the phase clocks: the 1M-tet configuration only
+  } else if (pa.timing) {  // development build with the phase clocks: the 1M-tet configuration and the small one
     if (h->pipe_wmax == 12 && h->c16) FB_PIPE(true, 12, 6, true, false);
-    else return fail(FB_EINVAL, "FEMBRAIN_PERSIST_TIMING is built for 9..12 slices per CU with 16-bit column words");
-  } else if (h->pipe_wmax == 8) { if (h->c16) FB_PIPE(true, 8, 8, false, false); else FB_PIPE(false, 8, 8, false, false); }
+    else if (h->pipe_wmax == 5 && h->c16) FB_PIPE(true, 5, 16, true, false);
+    else if (h->pipe_wmax == 8 && h->c16) FB_PIPE(true, 8, 8, true, false);
+    else return fail(FB_EINVAL, "FEMBRAIN_PERSIST_TIMING is built for 16-bit column words, one row per lane");
+  } else if (h->pipe_wmax == 5) { if (h->c16) FB_PIPE(true, 5, 16, false, false); else FB_PIPE(false, 5, 16, false, false); }
+  else if (h->pipe_wmax == 8) { if (h->c16) FB_PIPE(true, 8, 8, false, false); else FB_PIPE(false, 8, 8, false, false); }
   else { if (h->c16) FB_PIPE(true, 12, 6, false, false); else FB_PIPE(false, 12, 6, false, false); }
 #undef FB_PIPE2
 #undef FB_PIPE_BJ
@@ -2958,7 +2968,7 @@ int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches,
     else if (h->persist && h->shard_persist) snprintf(name, name_len, "k_pcg_pipe_shard<%d,%d>", h->pipe_wmax, h->pipe_wmax == 8 ? 8 : 6);
     else if (h->persist && h->pipe_rows == 2) snprintf(name, name_len, "k_pcg_pipe2<%s>", h->c16 ? "c16" : "c32");
     else if (h->persist)
-      snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d%s>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_wmax == 8 ? 8 : 6,
+      snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d%s>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_wmax == 5 ? 16 : (h->pipe_wmax == 8 ? 8 : 6),
                h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI ? ",bj" : "");
     else name[0] = 0;
   }

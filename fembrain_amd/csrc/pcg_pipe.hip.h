@@ -404,7 +404,26 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
       y2 = l02 * vin[0] + l12 * vin[1] + l22 * vin[2];
     }
     if (live) {
-      if (sizeof(MT) == 4) {
+      if (sizeof(MT) == 4 && KLT >= 16) {
+        // whole slices in LDS, five wavefronts per CU: registers to spare, so ALL gathers of the product are in flight before the first
+        // multiplication (the loop below waits for each slot's three gathers in turn: 5.5 us for the slowest wavefronts at 105k tets, whose
+        // columns come from another XCD's rows, against 2.2 on average -- profiles/r05_small_mesh_phase_table.txt)
+        double gx[KLT][3];
+#pragma unroll
+        for (int k = 0; k < KLT; k++) {
+          const unsigned int col = k < KL ? lres[((size_t)k * 10 + 9) * 64] : 0u;
+          const double* xp = pl + (size_t)col;
+          gx[k][0] = k < KL ? xp[0] : 0.0; gx[k][1] = k < KL ? xp[pa.n_pad] : 0.0; gx[k][2] = k < KL ? xp[2 * pa.n_pad] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < KLT; k++) if (k < KL) {
+          const unsigned int* lk = lres + (size_t)k * 10 * 64;
+          const double x0 = gx[k][0], x1 = gx[k][1], x2 = gx[k][2];
+          y0 += (double)__uint_as_float(lk[0 * 64]) * x0 + (double)__uint_as_float(lk[1 * 64]) * x1 + (double)__uint_as_float(lk[2 * 64]) * x2;
+          y1 += (double)__uint_as_float(lk[3 * 64]) * x0 + (double)__uint_as_float(lk[4 * 64]) * x1 + (double)__uint_as_float(lk[5 * 64]) * x2;
+          y2 += (double)__uint_as_float(lk[6 * 64]) * x0 + (double)__uint_as_float(lk[7 * 64]) * x1 + (double)__uint_as_float(lk[8 * 64]) * x2;
+        }
+      } else if (sizeof(MT) == 4) {
 #pragma unroll
         for (int k = 0; k < KLT; k++) if (k < KL) {  // LDS-resident slots
           const unsigned int* lk = lres + (size_t)k * 10 * 64;

@@ -1091,7 +1091,11 @@ def _persistent(monkeypatch, kernel, *a, c16=True, **kw):
     monkeypatch.setenv("FEMBRAIN_PERSIST_MIN_WAVES", "1")   # (read once per process: the default starts at 4 slices per CU)
     if not c16:
         monkeypatch.setenv("FEMBRAIN_SPMV_C16", "0")
+    if ",5,16" in kernel:
+        monkeypatch.setenv("FEMBRAIN_PIPE_SMALL", "1")      # (opt-in: whole slices in LDS up to 4 slices per CU; measured no faster than (8, 8))
     g = FemIntegrator(*a, pcg_variant=fl.FB_PCG_PERSISTENT, **kw)
+    if ",5,16" in kernel:
+        monkeypatch.delenv("FEMBRAIN_PIPE_SMALL")
     if not c16:
         monkeypatch.delenv("FEMBRAIN_SPMV_C16")
     assert g.persist_info()[0] and g.pcg_path()["kernel"] == kernel, g.pcg_path()
@@ -1099,7 +1103,9 @@ def _persistent(monkeypatch, kernel, *a, c16=True, **kw):
 
 
 @pytest.mark.parametrize("n,c16,kernel", [(14, True, "k_pcg_pipe<float,c16,8,8>"), (14, False, "k_pcg_pipe<float,c32,8,8>"),
-                                          (26, True, "k_pcg_pipe<float,c16,8,8>"), (26, False, "k_pcg_pipe<float,c32,8,8>")])
+                                          (26, True, "k_pcg_pipe<float,c16,8,8>"), (26, False, "k_pcg_pipe<float,c32,8,8>"),
+                                          (14, True, "k_pcg_pipe<float,c16,5,16>"), (26, True, "k_pcg_pipe<float,c16,5,16>"), (26, False, "k_pcg_pipe<float,c32,5,16>"),
+                                          (33, True, "k_pcg_pipe<float,c16,5,16>")])
 def test_persistent_solver_against_the_oracle(gpu, monkeypatch, n, c16, kernel):
     """One and two slices per workgroup (2,744 / 17,576 nodes): the solution of a tight solve and three reference-load steps against
     the CPU oracle (CGSolver.cpp:129-190 restated), iteration counts within max(3, 2 %)."""
@@ -1137,18 +1143,20 @@ def test_persistent_solver_against_the_oracle(gpu, monkeypatch, n, c16, kernel):
     g.close()
 
 
-@pytest.mark.parametrize("n", [14, 31, 40])
-def test_persistent_solver_matches_two_launch_and_itself(gpu, n, monkeypatch):
+@pytest.mark.parametrize("n,kname", [(14, "k_pcg_pipe<float,c16,8,8>"), (31, "k_pcg_pipe<float,c16,8,8>"), (40, "k_pcg_pipe<float,c16,8,8>"),
+                                     (14, "k_pcg_pipe<float,c16,5,16>"), (31, "k_pcg_pipe<float,c16,5,16>"), (40, "k_pcg_pipe<float,c16,5,16>")])
+def test_persistent_solver_matches_two_launch_and_itself(gpu, n, kname, monkeypatch):
     """The persistent solver against the two-launch solver (k_spmv + k_cg_fused, an independent code path: the handle is created
     with FEMBRAIN_PCG_PERSIST=0 and says so): same iteration counts to max(3, 2 %), same solution to the solver tolerance; and
     against ITSELF cut into launches of 1 and 7 iterations -- every state vector goes through memory at a cut, every hand-off
     around it is a kernel boundary -- bit for bit: a stale read inside the launch would show here.  Slices per workgroup: 1
-    (n = 14), 2 (n = 31), 4 (n = 40).  Also the poll-all form of the neighbour wait (what an unstructured numbering gets)."""
+    (n = 14), 2 (n = 31), 4 (n = 40), with (8, 8) and with the opt-in whole-slice-in-LDS instantiation (5, 16).
+    Also the poll-all form of the neighbour wait (what an unstructured numbering gets)."""
     v, t, fixed = _cube(n)
     gm = _two_launch(monkeypatch, v, t, fixed)
-    gp = _persistent(monkeypatch, "k_pcg_pipe<float,c16,8,8>", v, t, fixed)
+    gp = _persistent(monkeypatch, kname, v, t, fixed)
     monkeypatch.setenv("FEMBRAIN_PERSIST_POLL_ALL", "1")
-    ga = _persistent(monkeypatch, "k_pcg_pipe<float,c16,8,8>", v, t, fixed)
+    ga = _persistent(monkeypatch, kname, v, t, fixed)
     monkeypatch.delenv("FEMBRAIN_PERSIST_POLL_ALL")
     assert ga.pcg_path()["max_producers"] == -1 and gp.pcg_path()["max_producers"] > 0
     for g in (gm, gp, ga):
