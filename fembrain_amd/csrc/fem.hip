@@ -21,6 +21,8 @@ using namespace fb;
 struct fb_fem_s {
   fb_fem_params prm;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;          // the slot-major assembly of the few slices too wide for the element-major kernel runs beside it (launch_rows)
+  hipEvent_t ev_side[2] = {nullptr, nullptr};
   fb_comm_s* comm = nullptr;  // not owned
   P2P* p2p = nullptr;         // direct peer mailboxes for halo refresh and dots (comm.h); null = collective library
   int xch_mode = FB_XCH_COLLECTIVE;     // how the exchanges of a sharded handle run (fb_fem_set_exchange_mode)
@@ -58,6 +60,7 @@ struct fb_fem_s {
   DevBuf<uint32_t> inc, inc_slot;
   bool asm_tets = false;             // the assembly kernel in use
   int asm_lds = 0, asm_grid = 0, asm_max_width = 0;
+  int asm_wide = 0;                  // slices wider than the element-major kernel takes (kIncMaxWidth slots): the slot-major kernel assembles those
   bool asm_staged = false;           // k_assemble_tets_st (records staged in LDS, mass entries precomputed) instead of k_assemble_tets
   int asm_lds_st = 0, asm_grid_st = 0;
   bool mass_valid = false;           // h->mblk holds the mass entries of the current rest data (k_mass_blocks)
@@ -594,8 +597,14 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
   {
     // Element-major assembly where the accumulators of the widest slice fit the LDS of a CU (5 KB per slot: up to 32 slots);
     // FEMBRAIN_ASM_KERNEL=rows keeps the slot-major kernel (same result bit for bit, tests/test_fem_gpu.py)
-    int mw = 0;
-    for (int sl = 0; sl < P.n_slices; sl++) mw = std::max(mw, P.slice_off[sl + 1] - P.slice_off[sl]);
+    // (the widest slice the element-major kernels take, and how many are wider: those few go to the slot-major kernel -- one hub node
+    // used to send the whole mesh there)
+    int mw = 0, n_wide = 0;
+    for (int sl = 0; sl < P.n_slices; sl++) {
+      const int wsl = P.slice_off[sl + 1] - P.slice_off[sl];
+      if (wsl > kIncMaxWidth) n_wide++; else mw = std::max(mw, wsl);
+    }
+    h->asm_wide = n_wide;
     hipDeviceProp_t prop;
     FB_HIP(hipGetDeviceProperties(&prop, h->prm.device));
     const int lds_cu = (int)std::min<size_t>(std::max<size_t>(prop.maxSharedMemoryPerMultiProcessor, prop.sharedMemPerBlock), 160 * 1024);  // gfx950: 160 KB per CU
@@ -746,6 +755,27 @@ int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const doub
   o.fint_out = fint_out; o.rhs = rhs; o.invdiag = invdiag;
   o.invblk = invdiag && h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI ? h->invblk.p : nullptr;
   o.mblk_in = nullptr;
+  // The few slices too wide for the element-major kernel (hub nodes, hull nodes of a Delaunay mesh): the slot-major kernel on those only,
+  // on a stream of its own BESIDE the element-major launch -- one wavefront takes ~0.8 ms for a 59-slot slice (one latency-bound slot after
+  // the other) while the element-major kernel does the other 1,300 slices of the 606k-tet probe in 0.19 ms; the two write disjoint slices.
+  // (A CU-masked handle has no second stream with the same mask: the pass then follows in order.)
+  const bool wide_pass = h->asm_tets && !mblk_out && h->asm_wide > 0;
+  bool wide_beside = false;
+  if (wide_pass) {
+    if (!h->side && h->cu_limit == 0) {
+      if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->side = nullptr; }
+      for (auto& e : h->ev_side) if (h->side && !e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); }
+    }
+    wide_beside = h->side && h->ev_side[0] && h->ev_side[1];
+    if (wide_beside) {
+      FB_HIP(hipEventRecord(h->ev_side[0], h->stream));  // (the records and element forces of this assembly are complete)
+      FB_HIP(hipStreamWaitEvent(h->side, h->ev_side[0], 0));
+      hipLaunchKernelGGL(k_assemble_rows<MT>, dim3(h->grid), dim3(kBlock), 0, h->side, sell_view(h), h->slot_coff.p, h->slot_ccnt.p,
+                         h->contrib.p, (const MT*)h->rec.p, h->fe.p, o, ap, (const MT*)h->kcorr.p, h->asm_max_width);
+      FB_HIP(hipGetLastError());
+      FB_HIP(hipEventRecord(h->ev_side[1], h->side));
+    }
+  }
   if (h->asm_tets && h->asm_staged && std::is_same<MT, float>::value && !h->kcorr.p && !mblk_out) {
     if (!h->mass_valid) {  // once per rebuild of the rest data
       hipLaunchKernelGGL(k_mass_blocks<float>, dim3(ceil_div(h->plan.n_slices, kBlock / 64)), dim3(kBlock), (size_t)(kBlock / 64) * h->asm_max_width * 64 * sizeof(double),
@@ -797,7 +827,15 @@ int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const doub
     }
   } else {
     hipLaunchKernelGGL(k_assemble_rows<MT>, dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), h->slot_coff.p, h->slot_ccnt.p,
-                       h->contrib.p, (const MT*)h->rec.p, h->fe.p, o, ap, (const MT*)h->kcorr.p);
+                       h->contrib.p, (const MT*)h->rec.p, h->fe.p, o, ap, (const MT*)h->kcorr.p, 0);
+  }
+  if (wide_pass && wide_beside) {
+    FB_HIP(hipStreamWaitEvent(h->stream, h->ev_side[1], 0));
+  } else if (wide_pass) {
+    AsmOut<MT> ow = o;
+    ow.mblk_in = nullptr;
+    hipLaunchKernelGGL(k_assemble_rows<MT>, dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), h->slot_coff.p, h->slot_ccnt.p,
+                       h->contrib.p, (const MT*)h->rec.p, h->fe.p, ow, ap, (const MT*)h->kcorr.p, h->asm_max_width);
   }
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -1121,7 +1159,8 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     if (h->pipe_wmax == 12 && h->c16) FB_PIPE(true, 12, 6, true, false);
     else if (h->pipe_wmax == 5 && h->c16) FB_PIPE(true, 5, 16, true, false);
     else if (h->pipe_wmax == 8 && h->c16) FB_PIPE(true, 8, 8, true, false);
-    else return fail(FB_EINVAL, "FEMBRAIN_PERSIST_TIMING is built for 16-bit column words, one row per lane");
+    else if (h->pipe_wmax == 8) FB_PIPE(false, 8, 8, true, false);
+    else return fail(FB_EINVAL, "FEMBRAIN_PERSIST_TIMING is built for one row per lane: (12, 6) and (5, 16) with 16-bit column words, (8, 8)");
   } else if (h->pipe_wmax == 5) { if (h->c16) FB_PIPE(true, 5, 16, false, false); else FB_PIPE(false, 5, 16, false, false); }
   else if (h->pipe_wmax == 8) { if (h->c16) FB_PIPE(true, 8, 8, false, false); else FB_PIPE(false, 8, 8, false, false); }
   else { if (h->c16) FB_PIPE(true, 12, 6, false, false); else FB_PIPE(false, 12, 6, false, false); }
@@ -2127,6 +2166,8 @@ int fb_fem_destroy(fb_fem_t h) {
   DevBuf<double>* vecs[] = {&h->q, &h->qvel, &h->fext, &h->fint, &h->rhs, &h->x, &h->r, &h->d, &h->Ad, &h->invdiag, &h->tmp};
   for (auto* v : vecs) v->release();
   hipStream_t s = h->stream;
+  if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+  for (auto& e : h->ev_side) if (e) (void)hipEventDestroy(e);
   delete h;  // frees the remaining device buffers
   if (s) (void)hipStreamDestroy(s);
   return FB_OK;
@@ -2688,6 +2729,7 @@ int fb_fem_floor_collision(fb_fem_t h, double floor_y, double restitution, int* 
 
 int fb_fem_plan_on_device(fb_fem_t h) { return h && h->device_plan ? 1 : 0; }
 int fb_fem_assembly_kernel(fb_fem_t h) { return h && h->asm_tets ? (h->asm_staged ? 2 : 1) : 0; }
+int fb_fem_assembly_wide_slices(fb_fem_t h) { return h && h->asm_tets ? h->asm_wide : 0; }
 
 long long fb_fem_device_plan_get(fb_fem_t h, const char* name, int* out, long long capacity) {
   CHECK_HANDLE(h);

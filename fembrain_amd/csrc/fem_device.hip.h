@@ -497,13 +497,15 @@ template <typename MT>
 __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int* __restrict__ slot_coff,
                                                           const int* __restrict__ slot_ccnt, const uint32_t* __restrict__ contrib,
                                                           const MT* __restrict__ rec, const double* __restrict__ fe, AsmOut<MT> o, AsmParams ap,
-                                                          const MT* __restrict__ kcorr) {
+                                                          const MT* __restrict__ kcorr, int min_width) {
+  // min_width > 0: only the slices wider than that (the element-major kernel has done the others)
   const int lane = threadIdx.x & 63;
   for (SliceWalk w(sv.n_slices); w.valid(); w.next()) {
     const int s = w.s;
     const int row = s * 64 + lane;
     const bool rvalid = row < sv.n_owned;
     const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
+    if (width <= min_width) continue;
     RowAlgebra<MT> ra;
     ra.begin(o, ap, row, rvalid);
     for (int k = 0; k < width; k++) {
@@ -871,6 +873,15 @@ __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, co
   }
 }
 
+// The element-major kernels take slices of up to max_width (<= kIncMaxWidth) slots: the accumulators of a slice live in LDS.  A mesh may
+// have a few wider ones (hull nodes of a Delaunay mesh with 40-60 neighbours: 111 of 1,424 slices on the 606k-tet probe) -- those are
+// left to the slot-major kernel (k_assemble_rows with min_width = max_width, same bits), which used to take the WHOLE mesh as soon as
+// one slice was too wide.  next_narrow: the first slice of the walk s, s + per, ... that is not too wide.
+__device__ __forceinline__ int next_narrow(const SellView& sv, int s, int per, int hi, int max_width) {
+  while (s < hi && sv.slice_off[s + 1] - sv.slice_off[s] > max_width) s += per;
+  return s;
+}
+
 template <typename MT, int G, bool TANGENT, bool NEWMARK>
 __global__ __launch_bounds__(kBlock) void k_assemble_tets(SellView sv, const int* __restrict__ inc_off, const uint32_t* __restrict__ inc,
                                                           const uint32_t* __restrict__ inc_slot, const MT* __restrict__ rec, const double* __restrict__ fe,
@@ -888,7 +899,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_tets(SellView sv, const int
   const int chunk = (sv.n_slices + 7) >> 3;
   const int hi = min((xcd + 1) * chunk, sv.n_slices);
   int prev_width = 0;
-  for (int s = xcd * chunk + (blockIdx.x >> 3); s < hi; s += per) {
+  for (int s = next_narrow(sv, xcd * chunk + (blockIdx.x >> 3), per, hi, max_width); s < hi; s = next_narrow(sv, s + per, per, hi, max_width)) {
     const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
     const int io = inc_off[s], height = inc_off[s + 1] - io;
     if (wq == 0) tets_accumulate<MT, G, 0, TANGENT>(acc, lane, io, height, inc, inc_slot, rec, ap, kcorr);
@@ -948,6 +959,7 @@ __global__ __launch_bounds__(kBlock) void k_mass_blocks(SellView sv, const int* 
   if (s >= sv.n_slices) return;  // (no barrier in this kernel: a wavefront works on its own slice)
   double* acc = macc + (size_t)wq * max_width * 64;
   const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
+  if (width > max_width) return;  // (a slice too wide for the element-major kernels: the slot-major kernel forms its mass entries itself)
   const int io = inc_off[s], height = inc_off[s + 1] - io;
   for (int k = 0; k < width; k++) acc[k * 64 + lane] = 0.0;
   // groups of four list rows: their words, then their volumes, are in flight together (one row at a time is two dependent memory
@@ -1143,16 +1155,17 @@ __global__ __launch_bounds__(kBlock) void k_assemble_tets_st(SellView sv, const 
   const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
   const int chunk = (sv.n_slices + 7) >> 3;
   const int hi = min((xcd + 1) * chunk, sv.n_slices);
-  const int s_first = xcd * chunk + (blockIdx.x >> 3);
+  const int s_first = next_narrow(sv, xcd * chunk + (blockIdx.x >> 3), per, hi, max_width);
   if (wq == 3) {  // the staging wavefront: same barriers as the others, its own work in between
     FB_ST_DECLARE
     if (s_first < hi) FB_ST_BEGIN(s_first)
-    for (int s = s_first; s < hi; s += per) {
+    for (int s = s_first, nxt; s < hi; s = nxt) {
+      nxt = next_narrow(sv, s + per, per, hi, max_width);
       FB_ST_RUN
       lap(0);
       __syncthreads();
       lap(1);
-      if (s + per < hi) FB_ST_BEGIN(s + per)  // (the others are in the algebra)
+      if (nxt < hi) FB_ST_BEGIN(nxt)  // (the others are in the algebra)
       __syncthreads();  // (the one inside tets_algebra)
       if (o.invblk) __syncthreads();
       lap(2);
@@ -1160,7 +1173,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_tets_st(SellView sv, const 
       lap(3);
     }
   } else {
-    for (int s = s_first; s < hi; s += per) {
+    for (int s = s_first; s < hi; s = next_narrow(sv, s + per, per, hi, max_width)) {
       const int so = sv.slice_off[s], width = sv.slice_off[s + 1] - so;
       const int io = inc_off[s], height = inc_off[s + 1] - io;
       if (wq == 0) tets_accumulate_st<0>(acc, stage, lane, io, height, inc, inc_slot, ap);

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kB) void k_inc_heights(int n_slices, int n_owned, c
   const int row = s * 64 + lane;
   const int so = slice_off[s], width = slice_off[s + 1] - so;
   int cnt = 0;
-  if (row < n_owned)
+  if (row < n_owned && width <= kIncMaxWidth)  // (a wider slice gets no lists: the slot-major assembly kernel takes it)
     for (int k = 0; k < width; k++)
       if (colidx[((size_t)so + k) * 64 + lane] == row) {  // the first such slot is the diagonal block (padding repeats the row id later)
         const int coff = slot_coff[so + k], ccnt = slot_ccnt[so + k];

@@ -157,6 +157,7 @@ def lib():
         "fb_fem_device_plan_get": (C.c_longlong, [vp, C.c_char_p, _ip, C.c_longlong]),
         "fb_fem_plan_on_device": (C.c_int, [vp]),
         "fb_fem_assembly_kernel": (C.c_int, [vp]),
+        "fb_fem_assembly_wide_slices": (C.c_int, [vp]),
         "fb_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int, C.c_int, _ip]),
         "fb_plan_destroy": (C.c_int, [vp]),
         "fb_plan_slab_order": (C.c_int, [C.c_int, _dp, C.c_int, _ip, _ip, _ip, _ip]),

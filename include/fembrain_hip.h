@@ -317,6 +317,9 @@ int fb_fem_plan_on_device(fb_fem_t h);
  * (k_assemble_tets; slices of at most 31 slots; also FEMBRAIN_ASM_KERNEL=tets1), 0 = slot-major (k_assemble_rows; also
  * FEMBRAIN_ASM_KERNEL=rows).  All three write the same bits. */
 int fb_fem_assembly_kernel(fb_fem_t h);
+/* slices of more than 31 slots (hub nodes, hull nodes of a Delaunay mesh): the element-major kernel leaves those to a second launch of the
+ * slot-major kernel (same bits); 0 when the slot-major kernel assembles everything anyway */
+int fb_fem_assembly_wide_slices(fb_fem_t h);
 int fb_fem_time_spmv(fb_fem_t h, int reps, double* seconds_per_spmv);
 int fb_fem_time_assembly(fb_fem_t h, int reps, double* seconds_per_assembly);
 /* COLLECTIVE on a sharded handle (every rank calls it with the same reps): average device seconds of one halo refresh of

@@ -913,7 +913,12 @@ def _wide_mesh():
     hull = ConvexHull(pts)
     v = np.concatenate([[[0.0, 0.0, 0.0]], pts])
     t = np.array([[0, a + 1, b + 1, c + 1] for a, b, c in hull.simplices], np.int32)
-    return v, t, fixed_vertices_to_dofs(np.array([1, 2, 3]))
+    # ... next to an ordinary body (a 7^3 cube, separate): slices of ordinary width beside the one that is too wide for the element-major
+    # kernel, which then takes all but that one (round 5; alone, the star is one slice and the slot-major kernel's)
+    vc, tc, fc = _cube(7)
+    vv = np.concatenate([v + np.array([5.0, 0.0, 0.0]), vc])
+    tt = np.concatenate([t, tc + len(v)]).astype(np.int32)
+    return vv, np.ascontiguousarray(tt), np.sort(np.concatenate([fixed_vertices_to_dofs(np.array([1, 2, 3])), fc + 3 * len(v)])).astype(np.int32)
 
 
 def _jittered_lattice():
@@ -965,7 +970,9 @@ def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, mo
     for kern in ("tets", "tets1", "rows"):
         monkeypatch.setenv("FEMBRAIN_ASM_KERNEL", kern)
         g = FemIntegrator(v, t, fixed, **kw)
-        assert fl.lib().fb_fem_assembly_kernel(g.h) == (0 if kern == "rows" or case == "hub" else (2 if kern == "tets" and staged else 1))
+        # (a hub node makes ONE slice too wide for the element-major kernel: that slice alone goes through the slot-major kernel, round 5)
+        assert fl.lib().fb_fem_assembly_kernel(g.h) == (0 if kern == "rows" else (2 if kern == "tets" and staged else 1))
+        assert (fl.lib().fb_fem_assembly_wide_slices(g.h) > 0) == (case == "hub" and kern != "rows")
         f, K = g.assemble(u)
         its = []
         for k in range(2):

@@ -74,7 +74,10 @@ def cases(n):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 56
     out = []
+    only = os.environ.get("PROBE_ONLY")   # e.g. "d": the cases whose name starts with it
     for name, v, t, fx in cases(n):
+        if only and not name.startswith(only):
+            continue
         fixed = fixed_vertices_to_dofs(fx)
         t0 = time.time()
         g = FemIntegrator(v, t, fixed)
@@ -95,6 +98,12 @@ def main():
         row.update(iterations=its, us_per_iteration=[round(u, 2) for u in us], path=g.pcg_path(), persist=g.persist_info(),
                    spmv_mb=round(g.spmv_bytes() / 1e6, 1), spmv_us=round(g.time_spmv(50) * 1e6, 2),
                    assembly_us=round(g.time_assembly(10) * 1e6, 1), assembly_kernel=int(g._L.fb_fem_assembly_kernel(g.h)))
+        # widths of the SELL slices (the element-major assembly takes up to 31 slots; wider slices went to the slot-major kernel)
+        cnt = g._L.fb_fem_device_plan_get(g.h, b"slice_off", None, 0)
+        so = np.zeros(cnt, np.int32)
+        g._L.fb_fem_device_plan_get(g.h, b"slice_off", fl.iptr(so), cnt)
+        w = np.diff(so)
+        row["slice_widths"] = dict(slices=int(len(w)), max=int(w.max()), mean=float(w.mean()), wider_than_31=int((w > 31).sum()), p50=int(np.percentile(w, 50)), p99=int(np.percentile(w, 99)))
         t0 = time.time()
         for _ in range(5):
             g.resync(v, t, fixed)
