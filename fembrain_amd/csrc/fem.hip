@@ -1287,7 +1287,9 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
     // the start vector in x.  One exact residual tells whether the pipelined recurrences were honest to the end: if the true
     // r . r / diag of the iterate is within a factor of four of what they carried, the system simply needs more iterations and the
     // iterate stands (a system that does not converge cost 2 x max_iter iterations).  Otherwise -- the recurrences
-    // stalled or drifted -- the literal recurrences get the last word: the two-launch solver repeats the solve from the same start.
+    // stalled or drifted -- the literal recurrences get the last word: the two-launch solver repeats the solve.  ("From the same start"
+    // holds for a solve in ONE launch, the product's case; with the test knob FEMBRAIN_PERSIST_MAX_RUN the earlier launches have written
+    // their iterate to x already, and the repeat continues from there as a warm start -- same answer to the tolerance, not the same bits.)
     const bool cap_check = !(getenv("FEMBRAIN_PERSIST_CAP_CHECK") && atoi(getenv("FEMBRAIN_PERSIST_CAP_CHECK")) == 0);  // (=0: always repeat; tests)
     if (cap_check && h->prm.pcg_variant != FB_PCG_BLOCK_JACOBI) {  // (block-Jacobi carries r . B^-1 r: not what the product kernel sums)
       FB_TRY(h->st.zero(s));  // done = 0: the product below is not a no-op
@@ -1303,6 +1305,11 @@ int pcg_solve_pipe(fb_fem_s* h, const double* b, double eps, int max_iter, int* 
       if (std::isfinite(chk.rho0) && chk.rho0 <= 4.0 * rho) {
         FB_HIP(hipMemcpyAsync(h->x.p, h->d.p, sizeof(double) * 3 * (size_t)h->plan.n_local, hipMemcpyDeviceToDevice, s));
         fin.rho[fin.iter & 1] = chk.rho0;  // (the exact one)
+        // the device copy of the solver state says what the solve ended with, not what the check's k_cg_begin left there
+        h->st_host[1] = fin;
+        h->st_host[1].done = 1;
+        FB_HIP(hipMemcpyAsync(h->st.p, &h->st_host[1], sizeof(CGState), hipMemcpyHostToDevice, s));
+        FB_HIP(hipStreamSynchronize(s));
         if (iters_out) *iters_out = -fin.iter;
         if (final_state) *final_state = fin;
         return FB_OK;

@@ -33,8 +33,9 @@ struct PlanWorkspace {
   DevBuf<unsigned char> keep;              // device_partition: element has an owned node
   DevBuf<int4> tetsel;                     // device_partition: the kept elements (swapped with the handle's buffer)
   SortedPairs sorted;
-  size_t bytes() const {
-    return nodeflag.n + sendmask.n * 8 + picked.n * 4 + idsel.n * 4 + keep.n + tetsel.n * 16 + keys.n * 8 + keys_s.n * 8 + ukeys.n * 8 + vals.n * 4 + vals_s.n * 4 + ucnt.n * 4 + cstart.n * 4 + nruns.n * 4 + width.n * 4 + flags.n * 4 + temp.n;
+  size_t bytes() const {  // what is really held: capacities, not the sizes in use
+    return nodeflag.cap + sendmask.cap * 8 + picked.cap * 4 + idsel.cap * 4 + keep.cap + tetsel.cap * 16 + keys.cap * 8 + keys_s.cap * 8 + ukeys.cap * 8 + vals.cap * 4 + vals_s.cap * 4 +
+           ucnt.cap * 4 + cstart.cap * 4 + nruns.cap * 4 + width.cap * 4 + flags.cap * 4 + temp.cap;
   }
   void release() {
     keys.release(); keys_s.release(); ukeys.release(); vals.release(); vals_s.release(); ucnt.release(); cstart.release(); nruns.release();

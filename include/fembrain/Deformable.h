@@ -33,7 +33,7 @@ class HipIntegrator {
   // constrainedDOFs: 0-indexed, ascending, copied (implicitNewmarkSparse.h:78-80)
   HipIntegrator(int numVertices, const double* restPositions, int numElements, const int* elements, int numConstrainedDOFs,
                 const int* constrainedDOFs, double timestep = 0.0333, double dampingMassCoef = 0.0, double dampingStiffnessCoef = 0.01,
-                double E = 1e7, double nu = 0.46, double density = 1000.0, int device = 0, int warp = 1)
+                double E = 1e7, double nu = 0.46, double density = 1000.0, int device = 0, int warp = 1, bool expectCuts = false)
       : r_(3 * numVertices), h_(nullptr) {
     // warp: the argument of CorotationalLinearFEMForceModel (corotationalLinearFEMForceModel.h:42): 1 = corotational (default,
     // what FemBrain runs), 0 = linear elasticity; 2 (exact tangent) is not offered -- its Keff is not symmetric
@@ -43,6 +43,7 @@ class HipIntegrator {
     prm_.E = E; prm_.nu = nu; prm_.rho = density;
     prm_.timestep = timestep; prm_.damping_mass = dampingMassCoef; prm_.damping_stiffness = dampingStiffnessCoef;
     prm_.device = device;
+    prm_.expect_cuts = expectCuts ? 1 : 0;  // (a cuttable body: slack, node order and re-sync workspace at creation, fembrain_hip.h)
     check(fb_fem_create(&h_, numVertices, restPositions, numElements, elements, numConstrainedDOFs, constrainedDOFs, &prm_));
     std::memset(&info_, 0, sizeof info_);
   }
@@ -254,7 +255,8 @@ class Deformable {
     FixedVerticesToFixedDOF(m_vFixedVertices, m_vFixedDofs);
     if (m_lpIntegrator) m_lpIntegrator->Resync(n, m_rest.data(), m, m_elements.data(), (int)m_vFixedDofs.size(), m_vFixedDofs.data());
     else m_lpIntegrator = new HipIntegrator(n, m_rest.data(), m, m_elements.data(), (int)m_vFixedDofs.size(), m_vFixedDofs.data(),
-                                            m_timeStep, m_dampingMassCoeff, m_dampingStiffnessCoeff, 1e7, 0.46, 1000.0, m_device);
+                                            m_timeStep, m_dampingMassCoeff, m_dampingStiffnessCoeff, 1e7, 0.46, 1000.0, m_device, 1,
+                                            /* a Deformable is what FemBrain's scalpel cuts (CuttableMesh): */ true);
     m_q.assign(m_dof, 0.0); m_qVel.assign(m_dof, 0.0); m_arrExtForces.assign(m_dof, 0.0);
     m_bptr.clear(); m_bcol.clear();
     m_restVolume = -1.0;
@@ -266,13 +268,25 @@ class Deformable {
   bool syncForceModelDelta(const std::vector<int>& removed, const std::vector<int>& changedIds, const std::vector<int>& changedNodes, const std::vector<int>& added,
                            const std::vector<double>& newRest) {
     if (!m_lpIntegrator) return syncForceModel();
+    // The DEVICE first: ResyncDelta refuses bad input before anything changes and throws; the host copy of the mesh is edited
+    // only after it has returned, so host and device never disagree.  Ids are range-checked here too: they index the host arrays below.
+    const size_t n_el = m_elements.size() / 4;
+    for (size_t k = 0; k < changedIds.size(); k++)
+      if (changedIds[k] < 0 || (size_t)changedIds[k] >= n_el) throw std::runtime_error("syncForceModelDelta: changed element id out of range");
+    for (size_t k = 0; k < removed.size(); k++)
+      if (removed[k] < 0 || (size_t)removed[k] >= n_el || (k && removed[k] <= removed[k - 1])) throw std::runtime_error("syncForceModelDelta: removed ids must ascend inside the element list");
+    if (changedNodes.size() != 4 * changedIds.size() || added.size() % 4 != 0 || newRest.size() % 3 != 0) throw std::runtime_error("syncForceModelDelta: array sizes do not match");
+    std::vector<int> fixedDofs;
+    FixedVerticesToFixedDOF(m_vFixedVertices, fixedDofs);
+    m_lpIntegrator->ResyncDelta((int)removed.size(), removed.data(), (int)changedIds.size(), changedIds.data(), changedNodes.data(), (int)(added.size() / 4), added.data(),
+                                (int)(newRest.size() / 3), newRest.data(), (int)fixedDofs.size(), fixedDofs.data());
     for (size_t k = 0; k < changedIds.size(); k++)
       for (int c = 0; c < 4; c++) m_elements[4 * (size_t)changedIds[k] + c] = changedNodes[4 * k + c];
     if (!removed.empty()) {
       std::vector<int> kept;
       kept.reserve(m_elements.size());
       size_t r = 0;
-      for (size_t e = 0; e < m_elements.size() / 4; e++) {
+      for (size_t e = 0; e < n_el; e++) {
         if (r < removed.size() && (size_t)removed[r] == e) { r++; continue; }
         kept.insert(kept.end(), m_elements.begin() + 4 * e, m_elements.begin() + 4 * e + 4);
       }
@@ -281,9 +295,7 @@ class Deformable {
     m_elements.insert(m_elements.end(), added.begin(), added.end());
     m_rest.insert(m_rest.end(), newRest.begin(), newRest.end());
     m_dof = (U32)m_rest.size();
-    FixedVerticesToFixedDOF(m_vFixedVertices, m_vFixedDofs);
-    m_lpIntegrator->ResyncDelta((int)removed.size(), removed.data(), (int)changedIds.size(), changedIds.data(), changedNodes.data(), (int)(added.size() / 4), added.data(),
-                                (int)(newRest.size() / 3), newRest.data(), (int)m_vFixedDofs.size(), m_vFixedDofs.data());
+    m_vFixedDofs.swap(fixedDofs);
     m_q.assign(m_dof, 0.0); m_qVel.assign(m_dof, 0.0); m_arrExtForces.assign(m_dof, 0.0);
     m_bptr.clear(); m_bcol.clear();
     m_restVolume = -1.0;

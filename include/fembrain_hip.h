@@ -52,7 +52,9 @@ extern "C" {
  * with it: fb_step_info.pcg_path = FB_PCG_PATH_FALLBACK, fb_step_info.persist_fallbacks counts (FEMBRAIN_PERSIST_STRICT=1:
  * FB_EDEVICE instead).  ACCURACY LIMIT: the pipelined recurrences stall at a relative residual of ~1e-11 on these systems (the
  * literal ones go on below 1e-12), so solves with a tolerance below 1e-8 (the reference uses 1e-6) run the two-launch solver, and
- * a persistent solve that ends at the iteration cap is repeated by it (FB_PCG_PATH_RESOLVED). */
+ * a persistent solve that ends at the iteration cap is checked with ONE exact residual: if the true r . r / diag of its iterate is within a
+ * factor of four of what the recurrences carried, the iterate stands (-max_iter iterations, as CGSolver.cpp:189 returns); otherwise the
+ * two-launch solver repeats the solve (FB_PCG_PATH_RESOLVED; FEMBRAIN_PERSIST_CAP_CHECK=0: always). */
 #define FB_PCG_PERSISTENT 3
 /* BLOCK_JACOBI (opt-in; NOT the reference's solver, excluded from parity): PCG with the inverse of every row's 3x3 diagonal block
  * as preconditioner instead of the inverse diagonal.  Same convergence test (on r . B^-1 r).  Unsharded handles.  Where the
