@@ -331,6 +331,7 @@ def field_bench(device, cpu=True):
     p.tetrahedralize()
     sweep_s, pipe_s = p.time_pipeline(10)
     st = p.time_stages(10)
+    grid_s = p.time_grid(10)   # sweep + the float4 (x, y, z, f) grid the API returns on request (16 B per point)
     p.surface()
     surf_s = p.time_surface(10)
     npts = dims[0] * dims[1] * dims[2]
@@ -351,7 +352,8 @@ def field_bench(device, cpu=True):
     except Exception:  # noqa: BLE001
         pass
     elem_bytes = 96.0 * n_inc + npts / 64.0 * 24.0
-    pipe_bytes = 16.0 * npts + 12.0 * n_tv + 96.0 * n_inc + 3.0 * npts
+    # (round 5: the sweep stores f alone, 4 B per point; the float4 grid is materialised only for fb_poly_read_grid)
+    pipe_bytes = 4.0 * npts + 12.0 * n_tv + 96.0 * n_inc + 3.0 * npts
     field_roofline = {"kernel": "k_tet_elements (6 tets of 16 B per included cell, one wavefront per run of 4 mask words, records transposed through LDS)",
                       "bound": "hbm", "achieved": elem_bytes / st[3] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": elem_bytes / st[3] / 1e9 / HBM_PEAK_GBS,
                       "algorithmic_bytes_per_launch": elem_bytes, "us_per_launch": st[3] * 1e6,
@@ -360,12 +362,18 @@ def field_bench(device, cpu=True):
                       "stages_us": {"k_sweep": st[0] * 1e6, "classification_and_scans": st[1] * 1e6, "k_tet_vertices": st[2] * 1e6, "k_tet_elements": st[3] * 1e6,
                                     "all_with_events_between": st[4] * 1e6},
                       "pipeline": {"algorithmic_bytes": pipe_bytes, "us": pipe_s * 1e6, "achieved": pipe_bytes / pipe_s / 1e9, "frac": pipe_bytes / pipe_s / 1e9 / HBM_PEAK_GBS},
-                      "sweep": {"algorithmic_bytes": 16.0 * npts, "us": sweep_s * 1e6, "achieved": 16.0 * npts / sweep_s / 1e9, "frac": 16.0 * npts / sweep_s / 1e9 / HBM_PEAK_GBS}}
+                      "sweep": {"what": "k_sweep: f alone, 4 B per point, + the inside mask (SURVEY 8d: 'store f only and say so'): compute-bound on the field, not a stream",
+                                "algorithmic_bytes": 4.125 * npts, "us": sweep_s * 1e6, "achieved": 4.125 * npts / sweep_s / 1e9, "frac": 4.125 * npts / sweep_s / 1e9 / HBM_PEAK_GBS},
+                      "sweep_and_xyzf_grid": {"what": "k_sweep + k_grid_xyzf: the float4 (x, y, z, f) grid fb_poly_read_grid / readBackVoxelGridSamples return, materialised on request "
+                                                      "(16 B per point written, 4 read)", "algorithmic_bytes": 24.125 * npts, "us": grid_s * 1e6,
+                                              "achieved": 24.125 * npts / grid_s / 1e9, "frac": 24.125 * npts / grid_s / 1e9 / HBM_PEAK_GBS,
+                                              "mvoxels_per_s": npts / grid_s / 1e6}}
     out = {"field_roofline": field_roofline, "field_mvoxels_per_s": npts / pipe_s / 1e6, "field_sweep_mvoxels_per_s": npts / sweep_s / 1e6, "field_grid": list(dims),
-           "field_sweep_gbs": npts * 16 / sweep_s / 1e9, "field_pipeline_us": pipe_s * 1e6, "field_tets": int(p.counts.n_tets),
+           "field_sweep_gbs": npts * 4.125 / sweep_s / 1e9, "field_sweep_bytes_per_point": "4 (f) + 1 bit (inside); the 16-byte (x, y, z, f) grid on request: field_roofline.sweep_and_xyzf_grid",
+           "field_pipeline_us": pipe_s * 1e6, "field_tets": int(p.counts.n_tets),
            "field_surface_us": surf_s * 1e6, "field_surface_vertices": int(p.counts.n_surface_vertices),
            "field_surface_triangles": int(p.counts.n_surface_indices) // 3,
-           "field_pipeline": "sweep (float4 per point) + edge/cell classification + scans + tet-mesh vertices and 6 tets per included cell"}
+           "field_pipeline": "sweep (f per point + inside mask) + edge/cell classification + scans + tet-mesh vertices and 6 tets per included cell"}
     if cpu:
         # bounded CPU sample: the oracle's scalar sweep + classification + tet emission on a 256x256x24 slab through the
         # sphere's equator (1 core), scaled to points/s; the reference CPU polygonizer is TBB-parallel over cores

@@ -376,7 +376,7 @@ __device__ __forceinline__ unsigned int div_by(unsigned int n, const FastDiv f) 
 template <bool CULL, int SEM>
 __global__ __launch_bounds__(kPB) void k_sweep(Grid G, FastDiv dxy, FastDiv dx, const Instr* __restrict__ prog, int n_instr, int n_prims, int depth,
                                                const float* __restrict__ prims, const float* __restrict__ mtx, const float* __restrict__ pbox,
-                                               const float* __restrict__ cbox, float4* __restrict__ grid, unsigned long long* __restrict__ inside) {
+                                               const float* __restrict__ cbox, float* __restrict__ fout, unsigned long long* __restrict__ inside) {
   extern __shared__ float stack[];
   // kSweepPts consecutive 256-point runs per block: every store instruction of a wave is still one contiguous 1 KiB
   // float4 segment and every ballot one aligned 64-point word of the inside mask
@@ -412,13 +412,29 @@ __global__ __launch_bounds__(kPB) void k_sweep(Grid G, FastDiv dxy, FastDiv dx, 
       const float y = G.lo[1] + G.cellsize * (float)iy;
       const float z = G.lo[2] + G.cellsize * (float)(iz + (unsigned int)G.z0);
       const float f = eval_field_t<CULL, SEM>(prog, n_instr, n_prims, prims, mtx, x, y, z, stack + threadIdx.x, sb);
-      if (grid) { const v4f o = {x, y, z, f}; __builtin_nontemporal_store(o, (v4f*)&grid[gid]); }  // streamed once: 49 vs 56 us
+      // f alone (round 5): 4 bytes per point where rounds 1-4 wrote the float4 (x, y, z, f) the API returns -- 268 MB at 256^3 that
+      // no stage of the tet path reads (classification reads the inside mask, emission computes positions from indices) and the
+      // surface path needs only for f at the two ends of a crossed edge.  fb_poly_read_grid materialises the float4 grid on demand.
+      if (fout) __builtin_nontemporal_store(f, &fout[gid]);
       in = f >= kIso;  // inside test of Polygonizer.cl:1367,1599 and Polygonizer.cpp:1052
     }
     const unsigned long long b = __ballot(in);
     if ((threadIdx.x & 63) == 0 && gid < ((G.n_points + 63) & ~63LL)) inside[gid >> 6] = b;
   }
   (void)depth;
+}
+
+// the float4 (x, y, z, f) grid of the API (readBackVoxelGridSamples, OclPolygonizer.cpp:1651-1694) from the stored field values:
+// positions by the sweep's own expression, so the result is what the sweep used to store, bit for bit
+__global__ __launch_bounds__(kPB) void k_grid_xyzf(Grid G, FastDiv dxy, FastDiv dx, const float* __restrict__ fval, float4* __restrict__ grid) {
+  const long long gid = (long long)blockIdx.x * kPB + threadIdx.x;
+  if (gid >= G.n_points) return;
+  const unsigned int gx = (unsigned int)G.g[0], gxy = gx * (unsigned int)G.g[1];
+  const unsigned int g32 = (unsigned int)gid;
+  const unsigned int iz = div_by(g32, dxy), rem = g32 - iz * gxy;
+  const unsigned int iy = div_by(rem, dx), ix = rem - iy * gx;
+  const v4f o = {G.lo[0] + G.cellsize * (float)ix, G.lo[1] + G.cellsize * (float)iy, G.lo[2] + G.cellsize * (float)(iz + (unsigned int)G.z0), fval[gid]};
+  __builtin_nontemporal_store(o, (v4f*)&grid[gid]);
 }
 
 // ComputeFieldArray (Polygonizer.cl:1262-1286)
@@ -820,6 +836,8 @@ __global__ __launch_bounds__(kPB) void k_tet_vertices(Grid G, FastDiv dxy, FastD
   __syncthreads();
   total = 3u * sbase[kVW];
   float* out = xyz + 3 * (size_t)first;
+  // (round 5: 16-byte stores for the body of the range -- up to three floats singly until the address is aligned, then a float4 per lane --
+  // measured 29.2 us against 26.3 for this form at 256^3: the kernel waits on its two barriers per 1,024 points, not on the store width)
   for (unsigned int i = threadIdx.x; i < total; i += kPB) out[i] = stage[i];
 }
 
@@ -1041,7 +1059,7 @@ template <int SEM>
 __global__ __launch_bounds__(kPB) void k_surface_vertices(Grid G, long long nv, const unsigned long long* __restrict__ elist,
                                                           const Instr* __restrict__ prog, int n_instr, int n_prims,
                                                           const float* __restrict__ prims, const float* __restrict__ mtx, const float* __restrict__ cbox,
-                                                          const float4* __restrict__ grid, const unsigned long long* __restrict__ vinc,
+                                                          const float* __restrict__ fval, const unsigned long long* __restrict__ vinc,
                                                           const unsigned int* __restrict__ vbase, float* __restrict__ pos, float* __restrict__ nrm,
                                                           uint2* __restrict__ ends, float* __restrict__ frac) {
   extern __shared__ float stack[];
@@ -1052,7 +1070,16 @@ __global__ __launch_bounds__(kPB) void k_surface_vertices(Grid G, long long nv, 
   const long long p = (long long)(ent >> 2);
   const int axis = (int)(ent & 3ULL);
   const long long nb = p + (axis == 0 ? 1LL : (axis == 1 ? (long long)G.g[0] : (long long)G.g[0] * G.g[1]));
-  const float4 va = grid[p], vb = grid[nb];
+  // the two ends of the edge: f as the sweep stored it, positions by the sweep's own expression (what the float4 grid held, bit for bit)
+  const long long gxl = G.g[0], gxyl = gxl * G.g[1];
+  const long long piz = p / gxyl, prem = p - piz * gxyl, piy = prem / gxl, pix = prem - piy * gxl;
+  float4 va, vb;
+  va.x = G.lo[0] + G.cellsize * (float)(unsigned int)pix; va.y = G.lo[1] + G.cellsize * (float)(unsigned int)piy;
+  va.z = G.lo[2] + G.cellsize * (float)((unsigned int)piz + (unsigned int)G.z0); va.w = fval[p];
+  vb.x = axis == 0 ? G.lo[0] + G.cellsize * (float)((unsigned int)pix + 1u) : va.x;
+  vb.y = axis == 1 ? G.lo[1] + G.cellsize * (float)((unsigned int)piy + 1u) : va.y;
+  vb.z = axis == 2 ? G.lo[2] + G.cellsize * (float)((unsigned int)piz + 1u + (unsigned int)G.z0) : va.z;
+  vb.w = fval[nb];
   const float t = (kIso - va.w) / (vb.w - va.w);
   const float x = va.x + t * (vb.x - va.x), y = va.y + t * (vb.y - va.y), z = va.z + t * (vb.z - va.z);
   float* stk = stack + threadIdx.x;
@@ -1272,7 +1299,9 @@ struct fb_poly_s {
   Grid G;
   int gz_total = 0;  // point planes of the whole grid this one is a slab of (= G.g[2] for a grid of its own)
   bool have_grid = false, classified = false, tetra = false, materialized = false;
-  DevBuf<float4> grid;
+  DevBuf<float> fval;    // the field at every grid point, as k_sweep stores it
+  DevBuf<float4> grid;   // (x, y, z, f) per point: materialised by fb_poly_read_grid only
+  bool grid_current = false;
   DevBuf<unsigned long long> inside, cinc, vinc, lastx, lasty, lastz, valid, crossx, crossy, crossz, firstx, firsty, firstz;
   DevBuf<uint4> block_sums;                // k_classify -> k_ranks: included cells, tet vertices, crossed edges, surface cells per workgroup
   long long n_words = 0;
@@ -1692,14 +1721,27 @@ void support_boxes(fb_poly_s* h) {
 
 size_t stack_bytes(const fb_poly_s* h) { return (size_t)std::max(1, h->depth) * kPB * sizeof(float); }
 
+// the float4 grid of the API from the stored field values, once per sweep
+int materialize_grid(fb_poly_s* h) {
+  if (h->grid_current) return FB_OK;
+  const Grid& G = h->G;
+  FB_TRY(h->grid.alloc((size_t)G.n_points));
+  hipLaunchKernelGGL(k_grid_xyzf, dim3((unsigned)((G.n_points + kPB - 1) / kPB)), dim3(kPB), 0, h->stream, G, fast_div((unsigned int)G.g[0] * (unsigned int)G.g[1]),
+                     fast_div((unsigned int)G.g[0]), h->fval.p, h->grid.p);
+  FB_HIP(hipGetLastError());
+  h->grid_current = true;
+  return FB_OK;
+}
+
 int do_sweep(fb_poly_s* h, bool store_grid) {
   const Grid& G = h->G;
+  h->grid_current = false;
   const int blocks = (int)((G.n_points + (long long)kPB * kSweepPts - 1) / ((long long)kPB * kSweepPts));
   // with one or two primitives the box test costs more than it can save (sphere at 256^3: 66 vs 50 us)
 #define FB_SWEEP(CULL, SEM)                                                                                                                             \
   hipLaunchKernelGGL((k_sweep<CULL, SEM>), dim3(blocks), dim3(kPB), stack_bytes(h), h->stream, G, fast_div((unsigned int)G.g[0] * (unsigned int)G.g[1]),                  \
                      fast_div((unsigned int)G.g[0]), h->d_prog.p, (int)h->prog.size(), h->n_prims, h->depth, \
-                     h->d_prims.p, h->d_mtx.p, h->d_pbox.p, h->d_cbox.p, store_grid ? h->grid.p : nullptr, h->inside.p)
+                     h->d_prims.p, h->d_mtx.p, h->d_pbox.p, h->d_cbox.p, store_grid ? h->fval.p : nullptr, h->inside.p)
   const bool cull = h->n_prims > 2;
   switch (h->sem) {
     case SEM_CPU_BOX: if (cull) FB_SWEEP(true, SEM_CPU_BOX); else FB_SWEEP(false, SEM_CPU_BOX); break;
@@ -1726,7 +1768,8 @@ int set_grid(fb_poly_s* h, const float lo[3], float cellsize, const int dims[3],
   if (G.n_points >= (1LL << 31)) return fail(FB_EINVAL, "grid too large");
   h->G = G;
   const size_t pw = (size_t)((G.n_points + 63) / 64);
-  FB_TRY(h->grid.alloc((size_t)G.n_points));
+  FB_TRY(h->fval.alloc((size_t)G.n_points));
+  h->grid_current = false;
   DevBuf<unsigned long long>* masks[] = {&h->inside, &h->cinc, &h->vinc, &h->lastx, &h->lasty, &h->lastz, &h->valid, &h->crossx, &h->crossy, &h->crossz,
                                          &h->surf, &h->firstx, &h->firsty, &h->firstz};
   for (auto* m : masks) FB_TRY(m->alloc(pw + 1));
@@ -1826,7 +1869,7 @@ int do_surface_emit(fb_poly_s* h) {
   FB_HIP(hipGetLastError());
   if (nv > 0) {
     FB_LAUNCH_SEM(h, k_surface_vertices, dim3((int)((nv + kPB - 1) / kPB)), dim3(kPB), stack_bytes(h), G, nv, h->elist.p, h->d_prog.p,
-                  (int)h->prog.size(), h->n_prims, h->d_prims.p, h->d_mtx.p, h->d_cbox.p, h->grid.p, h->vinc.p, h->vbase.p, h->sv.p, h->sn.p, h->sends.p, h->sfrac.p);
+                  (int)h->prog.size(), h->n_prims, h->d_prims.p, h->d_mtx.p, h->d_cbox.p, h->fval.p, h->vinc.p, h->vbase.p, h->sv.p, h->sn.p, h->sends.p, h->sfrac.p);
     FB_HIP(hipGetLastError());
   }
   if (ntri > 0) {
@@ -2065,6 +2108,7 @@ int fb_poly_sweep(fb_poly_t h, float cellsize, int dims_out[3]) {
 int fb_poly_read_grid(fb_poly_t h, float* xyzf) {
   CHECK_POLY(h);
   if (!h->have_grid || !xyzf) return fail(FB_EINVAL, "no swept grid / null buffer");
+  FB_TRY(materialize_grid(h));
   return h->grid.download((float4*)xyzf, (size_t)h->G.n_points, h->stream);
 }
 
@@ -2303,6 +2347,23 @@ int fb_poly_time_pipeline(fb_poly_t h, int reps, double* sweep_seconds, double* 
   }
   if (sweep_seconds) *sweep_seconds = ms_s * 1e-3 / reps;
   if (pipeline_seconds) *pipeline_seconds = ms_p * 1e-3 / reps;
+  return FB_OK;
+}
+
+int fb_poly_time_grid(fb_poly_t h, int reps, double* sweep_and_grid_seconds) {
+  CHECK_POLY(h);
+  if (!h->have_grid || reps < 1 || !sweep_and_grid_seconds) return fail(FB_EINVAL, "sweep a grid once first");
+  FB_TRY(materialize_grid(h));  // (allocation outside the timed region)
+  FB_HIP(hipEventRecord(h->ev[0], h->stream));
+  for (int r = 0; r < reps; r++) {
+    FB_TRY(do_sweep(h, true));
+    FB_TRY(materialize_grid(h));
+  }
+  FB_HIP(hipEventRecord(h->ev[1], h->stream));
+  FB_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0;
+  FB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  *sweep_and_grid_seconds = ms * 1e-3 / reps;
   return FB_OK;
 }
 

@@ -189,6 +189,7 @@ def lib():
         "fb_poly_tetrahedralize": (C.c_int, [vp, C.POINTER(PolyCounts)]),
         "fb_poly_read_tetmesh": (C.c_int, [vp, _fp, _up]),
         "fb_poly_time_pipeline": (C.c_int, [vp, C.c_int, _dp, _dp]),
+        "fb_poly_time_grid": (C.c_int, [vp, C.c_int, _dp]),
         "fb_poly_time_stages": (C.c_int, [vp, C.c_int, _dp]),
         "fb_poly_surface": (C.c_int, [vp, C.POINTER(PolyCounts)]),
         "fb_poly_read_surface": (C.c_int, [vp, _fp, _fp, _up]),

@@ -216,6 +216,12 @@ class GpuPoly:
         _l.check(self._L.fb_poly_time_surface(self.h, reps, C.byref(a)))
         return a.value
 
+    def time_grid(self, reps=10):
+        """seconds per sweep + materialisation of the float4 grid fb_poly_read_grid returns"""
+        a = C.c_double(0)
+        _l.check(self._L.fb_poly_time_grid(self.h, reps, C.byref(a)))
+        return a.value
+
     def time_pipeline(self, reps=5):
         a, b = C.c_double(0), C.c_double(0)
         _l.check(self._L.fb_poly_time_pipeline(self.h, reps, C.byref(a), C.byref(b)))

@@ -488,6 +488,9 @@ int fb_poly_off_surface(fb_poly_t h, float len, float* xyzf_pairs);
 int fb_poly_time_surface(fb_poly_t h, int reps, double* seconds);
 /* average device seconds of one sweep / one classify+tetrahedralize pipeline on the current grid */
 int fb_poly_time_pipeline(fb_poly_t h, int reps, double* sweep_seconds, double* pipeline_seconds);
+/* the sweep followed by the float4 (x, y, z, f) grid fb_poly_read_grid returns (16 bytes per point; the sweep itself stores f alone, 4 bytes
+ * per point, and the grid is materialised only when it is asked for): SURVEY.md 8d's second figure */
+int fb_poly_time_grid(fb_poly_t h, int reps, double* sweep_and_grid_seconds);
 /* the same pipeline with HIP events between its stages (the events cost a little: fb_poly_time_pipeline is the rate to quote):
  * average device seconds of [0] the sweep, [1] classification + scans, [2] tet-mesh vertices, [3] tet elements (the dominant kernel:
  * 96 B written per included cell), [4] all of it */

@@ -12,3 +12,5 @@ s, t = p.time_pipeline(30)
 npts = n ** 3
 print("grid %d^3: sweep %.1f us (%.0f GB/s), pipeline %.1f us -> %.0f Mvoxels/s; tets %d verts %d" %
       (n, s * 1e6, npts * 16 / s / 1e9, t * 1e6, npts / t / 1e6, c.n_included_cells * 6, p.counts.n_tet_vertices))
+st = p.time_stages(10)
+print("stages us: sweep %.1f classify+scans %.1f vertices %.1f elements %.1f (all with events %.1f); sweep + xyzf grid %.1f us" % (st[0] * 1e6, st[1] * 1e6, st[2] * 1e6, st[3] * 1e6, st[4] * 1e6, p.time_grid(10) * 1e6))
