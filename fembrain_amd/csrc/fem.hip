@@ -60,6 +60,11 @@ struct fb_fem_s {
   DevBuf<uint32_t> inc, inc_slot;
   bool asm_tets = false;             // the assembly kernel in use
   int asm_lds = 0, asm_grid = 0, asm_max_width = 0;
+  DevBuf<int> pipe_wg_first;         // persistent solver: the deal of the slices to the workgroups balanced by slots (pipe_deal), empty: equal numbers
+  std::vector<int> pipe_wg_first_host;
+  DevBuf<int4> pipe_tasks;           // persistent solver: per workgroup and wavefront its share of the slices (helpers, pcg_pipe.hip.h PipeArgs)
+  int pipe_help_waves = 0;           // wavefronts launched beyond slices + service wavefront, for the helpers (0: none)
+  int pipe_n_help = 0, pipe_help_tasks = 0;  // most helper tasks of a workgroup; all of them
   int asm_wide = 0;                  // slices wider than the element-major kernel takes (kIncMaxWidth slots): the slot-major kernel assembles those
   bool asm_staged = false;           // k_assemble_tets_st (records staged in LDS, mass entries precomputed) instead of k_assemble_tets
   int asm_lds_st = 0, asm_grid_st = 0;
@@ -454,7 +459,59 @@ int setup_persist(fb_fem_s* h) {
   FB_HIP(hipGetDeviceProperties(&prop, h->prm.device));
   const int nb = std::min(kPipeMaxBlocks, ((h->cu_limit > 0 ? std::min(h->cu_limit, prop.multiProcessorCount) : prop.multiProcessorCount) / 8) * 8);
   const char* e = getenv("FEMBRAIN_PCG_PERSIST");
-  const int w = nb >= 8 ? ceil_div(ceil_div(P.n_slices, 8), nb / 8) : 0;
+  int w = nb >= 8 ? ceil_div(ceil_div(P.n_slices, 8), nb / 8) : 0;
+  // The deal of the slices to the workgroups.  Equal NUMBERS of slices per workgroup (pipe_slices) is equal work only where the slices are
+  // alike; on a mesh with hull nodes of 40-60 neighbours the workgroups of the hull stream 2.5 x the slots of the others and every
+  // iteration waits for them (606k-tet Delaunay probe: product 18 us there, 7.5 on average).  Where the fullest workgroup of the equal
+  // deal has a quarter more slots than the average, the slices of every XCD's share are dealt to its workgroups by SLOTS instead
+  // (contiguous runs still, at most 12 -- or 24 where the two-row kernel is the mesh's anyway -- slices each).  FEMBRAIN_PIPE_BALANCE=0/1.
+  h->pipe_wg_first_host.clear();
+  h->pipe_wg_first.release();
+  if (P.n_ranks == 1 && nb >= 8 && w >= 1 && w <= 2 * kPipeMaxWaves && !P.slice_off.empty()) {
+    const int per = nb / 8, chunk = ceil_div(P.n_slices, 8), cap = w <= kPipeMaxWaves ? kPipeMaxWaves : 2 * kPipeMaxWaves;
+    long long total = 0, worst = 0;
+    for (int b = 0; b < nb; b++) {
+      int first, count;
+      pipe_slices(P.n_slices, nb, b, &first, &count);
+      const long long sl = count > 0 ? P.slice_off[first + count] - P.slice_off[first] : 0;
+      total += sl;
+      worst = std::max(worst, sl);
+    }
+    const char* eb = getenv("FEMBRAIN_PIPE_BALANCE");
+    const bool want = eb ? atoi(eb) != 0 : (worst * nb * 4 > total * 5);
+    if (want) {
+      std::vector<int> tab((size_t)2 * nb + 2, 0);
+      int most = 0;
+      for (int x = 0; x < 8; x++) {
+        const int lo = std::min(x * chunk, P.n_slices), hi = std::min((x + 1) * chunk, P.n_slices);
+        int at = lo;
+        for (int j = 0; j < per; j++) {
+          const int b = x + 8 * j, left = per - j;
+          const long long rest = P.slice_off[hi] - P.slice_off[at];
+          const double target = (double)rest / left;
+          int n = 0;
+          long long cum = 0;
+          // at least what the workgroups behind cannot take, then slices while the run stays closer to its share than without the next one
+          const int must = std::max(0, (hi - at) - (left - 1) * cap);
+          while (at + n < hi && n < cap) {
+            const long long wd = P.slice_off[at + n + 1] - P.slice_off[at + n];
+            if (n >= must && left > 1 && (double)cum + 0.5 * (double)wd > target) break;
+            cum += wd;
+            n++;
+          }
+          tab[b] = at;
+          tab[(size_t)nb + 1 + b] = n;
+          at += n;
+          most = std::max(most, n);
+        }
+      }
+      tab[nb] = P.n_slices;
+      h->pipe_wg_first_host = tab;
+      FB_TRY(h->pipe_wg_first.upload(tab, s));
+      if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] persistent solver: slices dealt by slots (fullest workgroup of the equal deal: %lld slots, average %.1f); up to %d slices per workgroup\n", worst, (double)total / nb, most);
+      w = std::max(1, most);
+    }
+  }
   read_persist_timeout(h);
   const bool explicit_p = h->prm.pcg_variant == FB_PCG_PERSISTENT;
   const bool shard_opt = P.n_ranks > 1 && getenv("FEMBRAIN_SHARDED_PERSIST") && atoi(getenv("FEMBRAIN_SHARDED_PERSIST")) != 0;
@@ -492,6 +549,71 @@ int setup_persist(fb_fem_s* h) {
   h->pipe_wmax = h->pipe_rows == 2 ? 12 : (small ? 5 : (w <= 8 ? 8 : 12));
   // slots of every slice resident in LDS at least: the CU's kPipeLdsSlots dealt to the slices of a workgroup (k_pcg_pipe), at most 16 / 8 / 6
   h->pipe_klt = h->pipe_rows == 2 ? 0 : std::min(small ? 16 : (w <= 8 ? 8 : 6), kPipeLdsSlots / std::max(w, 1));
+  // Helpers for very wide slices (unsharded, one row per lane, Jacobi): the widest slice at least half again as wide as the average and
+  // wider than 24 slots.  A workgroup's wavefronts without a slice of their own -- those its neighbours' fuller deal leaves idle, and
+  // the ones launched for the purpose: the 12-wavefront instantiation then serves fewer than 9 slices per CU too -- take the upper halves of
+  // the longest streams, longest first, until none is left or no stream is longer than 2 x 8 slots.  FEMBRAIN_PIPE_HELPERS=0/1 overrides.
+  h->pipe_tasks.release();
+  h->pipe_help_waves = 0; h->pipe_n_help = 0; h->pipe_help_tasks = 0;
+  if (h->pipe_rows == 1 && !bj && !small && P.n_ranks == 1 && !P.slice_off.empty()) {
+    int mx = 0;
+    long long tot = 0;
+    for (int sl = 0; sl < P.n_slices; sl++) { const int wd = P.slice_off[sl + 1] - P.slice_off[sl]; mx = std::max(mx, wd); tot += wd; }
+    const double mean = P.n_slices ? (double)tot / P.n_slices : 0.0;
+    const char* eh = getenv("FEMBRAIN_PIPE_HELPERS");
+    const bool want_h = eh ? atoi(eh) != 0 : (mx > 24 && (double)mx >= 1.5 * mean);
+    if (want_h && w + 2 <= kPipeMaxWaves) {
+      const int help_waves = kPipeMaxWaves - w - 1;   // (the 12-wavefront kernel: slices, helpers, the service wavefront)
+      std::vector<int4> tasks((size_t)nb * kPipeTaskStride, make_int4(-1, 0, 0, 0));
+      int most = 0, all = 0;
+      for (int b = 0; b < nb; b++) {
+        int first, count;
+        pipe_deal(h->pipe_wg_first_host.empty() ? nullptr : h->pipe_wg_first_host.data(), P.n_slices, nb, b, &first, &count);
+        int4* tk = &tasks[(size_t)b * kPipeTaskStride];
+        // streams: (wavefront, slice, k0, k1); the LDS-resident slots are the owner's, so a stream is split above them
+        const int lds_slots = kPipeLdsSlots - kPipeHelpSlots;
+        const int lbase = std::min(6, lds_slots / std::max(count, 1)), lrem = lbase < 6 ? std::min(count, lds_slots - lbase * count) : 0;
+        struct Stream { int wave, slice, k0, k1, floor; };
+        std::vector<Stream> st;
+        for (int j = 0; j < count; j++) {
+          const int wd = P.slice_off[first + j + 1] - P.slice_off[first + j];
+          st.push_back({j, j, 0, wd, lbase + (j < lrem ? 1 : 0)});
+          tk[j] = make_int4(j, 0, wd, 0);
+        }
+        int n_h = 0;
+        for (int hw = count; hw < w + help_waves && n_h < kPipeMaxHelpers; hw++) {  // idle slice wavefronts first, then the extra ones
+          int best = -1, len = 0;
+          for (int i = 0; i < (int)st.size(); i++) {
+            const int l = st[i].k1 - std::max(st[i].k0, st[i].floor);  // what it streams
+            if (l > len) { len = l; best = i; }
+          }
+          const int min_len = getenv("FEMBRAIN_PIPE_HELP_MINLEN") ? atoi(getenv("FEMBRAIN_PIPE_HELP_MINLEN")) : 16;  // (development)
+          if (best < 0 || len < min_len) break;
+          const int lo = std::max(st[best].k0, st[best].floor), mid = lo + (st[best].k1 - lo + 1) / 2;
+          const Stream up = {hw, st[best].slice, mid, st[best].k1, mid};
+          st[best].k1 = mid;
+          st.push_back(up);
+          tk[hw] = make_int4(up.slice, up.k0, up.k1, n_h);
+          tk[up.slice].w |= 1 << n_h;  // the owner adds this helper's partial sums
+          n_h++;
+        }
+        for (const Stream& S : st) { tk[S.wave].y = S.k0; tk[S.wave].z = S.k1; }  // (ends moved by later splits)
+        if (const char* dbg = getenv("FEMBRAIN_PIPE_HELP_DEBUG")) {  // development: 1 = owners keep their whole slice, helpers get empty ranges (their zero sums are still added); 2 = owners keep it all and add nothing, helpers work for nothing
+          for (int j = 0; j < count; j++) { tk[j].z = P.slice_off[first + j + 1] - P.slice_off[first + j]; if (atoi(dbg) == 2) tk[j].w = 0; }
+          if (atoi(dbg) == 1) for (int hw = count; hw < kPipeTaskStride; hw++) if (tk[hw].x >= 0) tk[hw].y = tk[hw].z;
+        }
+        most = std::max(most, n_h);
+        all += n_h;
+      }
+      if (all > 0 || (eh && atoi(eh) == 2)) {  // (=2, development: the task table without a single helper)
+        FB_TRY(h->pipe_tasks.upload(tasks, s));
+        h->pipe_wmax = 12;
+        h->pipe_klt = std::min(6, (kPipeLdsSlots - kPipeHelpSlots) / std::max(w, 1));
+        h->pipe_help_waves = help_waves; h->pipe_n_help = most; h->pipe_help_tasks = all;
+        if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] persistent solver: %d helper tasks (at most %d per workgroup), widest slice %d slots, mean %.1f\n", all, most, mx, mean);
+      }
+    }
+  }
   FB_TRY(h->pipe_post.alloc((size_t)2 * nb * 4));
   zb.add(h->pipe_post);
   h->pipe_flag_extra = P.n_ranks > 1 ? kP2PMaxRanks : 0;
@@ -521,10 +643,10 @@ int setup_persist(fb_fem_s* h) {
   FB_TRY(h->pipe_stats.alloc(2));
   zb.add(h->pipe_stats);
   FB_TRY(zb.flush());
-  hipLaunchKernelGGL(k_slice_owner, dim3(ceil_div(nb, kBlock)), dim3(kBlock), 0, s, P.n_slices, nb, h->pipe_owner.p);
+  hipLaunchKernelGGL(k_slice_owner, dim3(ceil_div(nb, kBlock)), dim3(kBlock), 0, s, P.n_slices, nb, h->pipe_wg_first.p, h->pipe_owner.p);
   hipLaunchKernelGGL(k_slice_producers, dim3(ceil_div(std::max(1, P.n_slices), kWavesPerBlock)), dim3(kBlock), 0, s, P.n_slices, P.n_owned, h->slice_off.p, h->colidx.p,
                      h->pipe_owner.p, h->pipe_mask.p);
-  hipLaunchKernelGGL(k_wg_producers, dim3(ceil_div(nb, kBlock)), dim3(kBlock), 0, s, P.n_slices, nb, h->pipe_mask.p, poll_all ? 1 : 0, h->pipe_prod.p, h->pipe_prod_count.p,
+  hipLaunchKernelGGL(k_wg_producers, dim3(ceil_div(nb, kBlock)), dim3(kBlock), 0, s, P.n_slices, nb, h->pipe_wg_first.p, h->pipe_mask.p, poll_all ? 1 : 0, h->pipe_prod.p, h->pipe_prod_count.p,
                      h->pipe_prod_xcd.p, h->pipe_stats.p);
   FB_HIP(hipGetLastError());
   h->pipe_stats_pending = true;  // (the longest list is fetched when fb_fem_pcg_path asks)
@@ -1101,17 +1223,19 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   pa.timing = h->persist_timing.p;
   pa.planes = h->pipe_planes.p; pa.n_pad = h->shard_persist ? (size_t)ceil_div(h->plan.n_local, 64) * 64 : (size_t)h->plan.n_slices * 64;
   pa.pstate = h->pipe_state.p;
+  pa.tasks = h->pipe_tasks.p; pa.n_help = h->pipe_n_help;
+  pa.wg_first = h->pipe_wg_first.p;
   // LDS: the sync buffers, then KLT slots of every slice; the request is the whole 160 KB of a CU, so exactly one workgroup lands on each
   const size_t lds = 160 * 1024;
   // one wavefront more than slices where the instantiation has room: it collects the sums while the others multiply
   static const bool want_service = !(getenv("FEMBRAIN_PIPE_SERVICE_WAVE") && atoi(getenv("FEMBRAIN_PIPE_SERVICE_WAVE")) == 0);
   const int cwaves = h->pipe_rows == 2 ? ceil_div(h->persist_waves, 2) : h->persist_waves;  // wavefronts that own slices
-  pa.service = (h->shard_persist || want_service) && cwaves < h->pipe_wmax ? 1 : 0;
+  pa.service = (h->shard_persist || want_service) && cwaves + h->pipe_help_waves < h->pipe_wmax ? 1 : 0;
   // values of the first streamed slots pulled into L2 during the neighbour wait: pays where the product is bandwidth-bound (9 and more
   // slices per CU: -6 % per iteration at 1M tets; neutral at 1,000 slices).  FEMBRAIN_PIPE_PREFETCH=0..4 overrides.
   static const int prefetch = getenv("FEMBRAIN_PIPE_PREFETCH") ? std::max(0, std::min(4, atoi(getenv("FEMBRAIN_PIPE_PREFETCH")))) : -1;
   pa.prefetch_slots = prefetch >= 0 ? prefetch : (h->persist_waves >= 9 ? (h->pipe_rows == 2 ? 3 : 4) : 0);
-  const dim3 grid(h->persist_blocks), block(64 * (cwaves + pa.service));
+  const dim3 grid(h->persist_blocks), block(64 * (cwaves + h->pipe_help_waves + pa.service));  // slices | helpers | the service wavefront
   FB_HIP(hipEventRecord(h->ev_p[0], h->stream));
   ShardArgs sa;
   memset(&sa, 0, sizeof sa);
@@ -1157,6 +1281,7 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     if (h->c16) FB_PIPE2(true, false); else FB_PIPE2(false, false);
   } else if (pa.timing) {  // development build with the phase clocks: the 1M-tet configuration and the small one
     if (h->pipe_wmax == 12 && h->c16) FB_PIPE(true, 12, 6, true, false);
+    else if (h->pipe_wmax == 12) FB_PIPE(false, 12, 6, true, false);
     else if (h->pipe_wmax == 5 && h->c16) FB_PIPE(true, 5, 16, true, false);
     else if (h->pipe_wmax == 8 && h->c16) FB_PIPE(true, 8, 8, true, false);
     else if (h->pipe_wmax == 8) FB_PIPE(false, 8, 8, true, false);
@@ -3034,6 +3159,7 @@ int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches,
 }
 
 int fb_fem_persist_rearms(fb_fem_t h) { return h ? h->persist_rearms : 0; }
+int fb_fem_persist_helpers(fb_fem_t h) { return h && h->persist ? h->pipe_help_tasks : 0; }
 
 int fb_fem_persist_stats(fb_fem_t h, int* launches, double* seconds, long long* iterations) {
   if (!h) return fail(FB_EINVAL, "null FEM handle");

@@ -62,7 +62,19 @@ struct PipeArgs {
   double* planes;             // [2][3][n_pad]: the published vector as the gathers read it, x | y | z planes
   size_t n_pad;               // rows padded to whole slices
   double* pstate;             // [2] gamma_old, alpha_old between the launches of one solve
+  // Helpers (round 5): on a mesh with a few very wide slices (hull nodes of a Delaunay mesh: 59 slots against 19 on average) the product
+  // of an iteration is as slow as the widest slice of the slowest workgroup -- one wavefront streams a slice's slots one after the other
+  // (18 us against 7.5 on average on the 606k-tet probe, profiles/r05_delaunay_phase_table.txt).  Wavefronts without a slice of their own
+  // then take the upper part of a wide slice's slots: tasks[b][wv] = (slice of the workgroup, first slot, end slot, x) -- x = for the
+  // wavefront that OWNS the slice the bit mask of the helpers whose partial sums it adds (ascending: a fixed order), for a helper its
+  // number in the workgroup (its place in the LDS hand-over), slice -1 = no task.  nullptr: no helpers anywhere (every other mesh).
+  const int* wg_first;        // the deal of the slices to the workgroups balanced by slots (pipe_deal), or nullptr: equal numbers of slices
+  const int4* tasks;          // [n_blocks][kPipeTaskStride]
+  int n_help;                 // most helpers of any workgroup (0: none; LDS for their partial sums is set aside when > 0)
 };
+constexpr int kPipeTaskStride = 16;
+constexpr int kPipeMaxHelpers = 8;   // per workgroup
+constexpr int kPipeHelpSlots = 5;    // LDS wavefront-slots set aside for their partial sums (8 x 3 x 64 doubles = 12 KB)
 
 __device__ __forceinline__ void st_sc1_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1_u32(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -96,6 +108,15 @@ __host__ __device__ inline void pipe_slices(int n_slices, int n_blocks, int b, i
   *count = base + (j < rem ? 1 : 0);
 }
 
+// ... or, where the slices of a mesh differ much in width (hull nodes of a Delaunay mesh: 59 slots against 19 on average), from a table
+// the host has balanced by SLOTS (fem.hip setup_persist): a CU's product takes as long as the slots it streams, whoever streams them --
+// the workgroups of the hull took 18 us per product against 7.5 on average with an equal number of slices each (profiles/r05_delaunay_phase_table.txt).
+// wg_first: n_blocks + 1 first slices, ascending inside every XCD's share; nullptr: the formula above.
+__host__ __device__ inline void pipe_deal(const int* wg_first, int n_slices, int n_blocks, int b, int* first, int* count) {
+  if (wg_first) { *first = wg_first[b]; *count = wg_first[n_blocks + 1 + b]; }
+  else pipe_slices(n_slices, n_blocks, b, first, count);
+}
+
 // The workgroups whose rows the columns of a slice lie in: a bit mask over the (at most kPipeMaxBlocks = 256) workgroups, 8 words per
 // slice.  EXACT, where a column range per slice (rounds 2-3) gave a superset: one element that joins two distant nodes (a sliver on the hull of a Delaunay
 // mesh, a cut that was closed again) widens the range of its slice to "everyone" but adds ONE producer to the exact list.
@@ -122,23 +143,23 @@ __global__ __launch_bounds__(kBlock) void k_slice_producers(int n_slices, int n_
 }
 
 // owner[slice] = the workgroup pipe_slices gives it to (a thread per workgroup)
-__global__ __launch_bounds__(kBlock) void k_slice_owner(int n_slices, int nb, int* __restrict__ owner) {
+__global__ __launch_bounds__(kBlock) void k_slice_owner(int n_slices, int nb, const int* __restrict__ wg_first, int* __restrict__ owner) {
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= nb) return;
   int first, count;
-  pipe_slices(n_slices, nb, b, &first, &count);
+  pipe_deal(wg_first, n_slices, nb, b, &first, &count);
   for (int k = 0; k < count; k++) owner[first + k] = b;
 }
 
 // The producer list of every workgroup from the masks of its slices (a thread per workgroup; round 4: on the device, the host loop
 // with its download and three uploads was 0.2 ms of every re-sync): prod[b][0..cnt[b]) ascending, cnt[b] = -1 (poll everyone) beyond
 // kPipeMaxProducers, far[b] = a producer sits on another XCD, stats[0] = longest list, stats[1] = some workgroup polls everyone.
-__global__ __launch_bounds__(kBlock) void k_wg_producers(int n_slices, int nb, const unsigned int* __restrict__ mask, int poll_all, int* __restrict__ prod,
-                                                         int* __restrict__ cnt, int* __restrict__ far, int* __restrict__ stats) {
+__global__ __launch_bounds__(kBlock) void k_wg_producers(int n_slices, int nb, const int* __restrict__ wg_first, const unsigned int* __restrict__ mask, int poll_all,
+                                                         int* __restrict__ prod, int* __restrict__ cnt, int* __restrict__ far, int* __restrict__ stats) {
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= nb) return;
   int first, count;
-  pipe_slices(n_slices, nb, b, &first, &count);
+  pipe_deal(wg_first, n_slices, nb, b, &first, &count);
   unsigned int m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   for (int k = 0; k < count; k++)
 #pragma unroll
@@ -233,7 +254,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int first, count;
   if constexpr (SHARD) { first = sa.wg_range[blockIdx.x].x; count = sa.wg_range[blockIdx.x].y; }
-  else pipe_slices(sv.n_slices, nb, blockIdx.x, &first, &count);
+  else pipe_deal(pa.wg_first, sv.n_slices, nb, blockIdx.x, &first, &count);
   const bool spare = SHARD && wv == n_waves - 1;  // a shard's spare wavefront: sums, counters, proxy copies (it owns no slice)
   const bool live = wv < count && !spare;         // wave-uniform
   const int sl = first + wv;
@@ -263,7 +284,8 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     if constexpr (SHARD) { send_beg = sa.row_send_off[row]; send_end = sa.row_send_off[row + 1]; }
   }
   // LDS-resident part of the matrix: the first KL slots of this wave's slice, [klt_w][10][64] words (9 values + the column id)
-  const int lbase = min(KLT, kPipeLdsSlots / max(count, 1)), lrem = lbase < KLT ? min(count, kPipeLdsSlots - lbase * count) : 0;  // workgroup-uniform
+  const int lds_slots = kPipeLdsSlots - (pa.n_help > 0 ? kPipeHelpSlots : 0);
+  const int lbase = min(KLT, lds_slots / max(count, 1)), lrem = lbase < KLT ? min(count, lds_slots - lbase * count) : 0;  // workgroup-uniform
   const int klt_w = __builtin_amdgcn_readfirstlane(live ? lbase + (wv < lrem ? 1 : 0) : 0);
   const int KL = min(klt_w, width);
   unsigned int* lres = (unsigned int*)(lds + kPipeSyncDoubles) + (size_t)(wv * lbase + min(wv, lrem)) * 10 * 64 + lane;
@@ -275,6 +297,19 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
       lres[(k * 10 + 9) * 64] = (unsigned int)(C16 ? row + (int)cd[(size_t)k * 64] : ci[(size_t)k * 64]);
     }
   }
+  // this wavefront's task (helpers, see PipeArgs): the owner of a slice streams its slots up to own_k1 and adds the partial sums of the
+  // helpers in help_mask; a helper streams [hk0, hk1) of slice help_sl for the rows of that slice
+  const bool has_help = !SHARD && pa.tasks != nullptr;  // grid-uniform
+  double* ypart = (double*)((unsigned int*)(lds + kPipeSyncDoubles) + (size_t)(kPipeLdsSlots - kPipeHelpSlots) * 10 * 64);  // [helper][3][64]
+  // (every value below is wave-uniform and made so explicitly, outside any branch: scalar registers)
+  const int4 tk = has_help ? pa.tasks[(size_t)blockIdx.x * kPipeTaskStride + wv] : make_int4(-1, 0, 0, 0);
+  const bool helper = has_help && !live && !spare && tk.x >= 0;
+  const int own_k1 = __builtin_amdgcn_readfirstlane(has_help && live ? tk.z : width);
+  const unsigned int help_mask = (unsigned int)__builtin_amdgcn_readfirstlane(has_help && live ? tk.w : 0);
+  const int help_sl = __builtin_amdgcn_readfirstlane(helper ? first + tk.x : -1);
+  const int hk0 = __builtin_amdgcn_readfirstlane(helper ? tk.y : 0), hk1 = __builtin_amdgcn_readfirstlane(helper ? tk.z : 0);
+  const int help_idx = __builtin_amdgcn_readfirstlane(helper ? tk.w : 0);
+  const int help_so = __builtin_amdgcn_readfirstlane(sv.slice_off[help_sl < 0 ? 0 : help_sl]);
   // the producers of this workgroup's columns: one per lane of wavefront 0
   const int n_prod = pa.prod_count[blockIdx.x];
   int my_prod = -1;
@@ -326,13 +361,13 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     __syncthreads();
     lap(0);  // publish, drained
     if (post_sums) sums++;
-    if (wv != 0 && live && pa.prefetch_slots > 0 && width > klt_w) {
+    if (wv != 0 && live && pa.prefetch_slots > 0 && own_k1 > klt_w) {
       // idle until wavefront 0 has seen the neighbours' flags: the first streamed slots' values go to L2 meanwhile (measured at 1M
       // tets, us per iteration with 0 / 2 / 3 / 4 slots: 17.15 / 16.25 / 16.1 / 16.05; the same during the drain of the publish
       // stores instead delays the flag and loses: 16.85)
       int so_k = so + klt_w;
       asm volatile("" : "+s"(so_k));  // (opaque, as for the streamed loop below)
-      pipe_prefetch_values(min(pa.prefetch_slots, width - klt_w), ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float), vals);
+      pipe_prefetch_values(min(pa.prefetch_slots, own_k1 - klt_w), ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float), vals);
     }
     if constexpr (SHARD) {
       if (spare) shard_service_product(sa, BL, pa, pub, pl, nb, lane, send_mask, t_limit, bc, failed);
@@ -434,8 +469,8 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
           y2 += (double)__uint_as_float(lk[6 * 64]) * x0 + (double)__uint_as_float(lk[7 * 64]) * x1 + (double)__uint_as_float(lk[8 * 64]) * x2;
         }
       }
-      // the streamed slots: hand-pipelined loads (pcg_pipe_stream.hip.h)
-      const int n_str = width - klt_w;
+      // the streamed slots: hand-pipelined loads (pcg_pipe_stream.hip.h); those from own_k1 on are a helper's
+      const int n_str = own_k1 - klt_w;
       if (n_str > 0) {
         int so_k = so + klt_w;
         asm volatile("" : "+s"(so_k));  // opaque: keeps the two offsets below from being hoisted out of the solver loop into live registers
@@ -444,8 +479,29 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
                                C16 ? (const void*)sv.coldelta : (const void*)sv.colidx, pl, pl + pa.n_pad, pl + 2 * pa.n_pad, row, y0, y1, y2);
       }
     }
+    if (help_sl >= 0) {  // a helper: its share of another wavefront's slice, handed over through LDS (the owner adds it after the next barrier)
+      double h0 = 0, h1 = 0, h2 = 0;
+      int so_k = help_so + hk0;
+      asm volatile("" : "+s"(so_k));
+      if (hk1 > hk0)  // (the stream loads its first slots unconditionally: never with none)
+      pipe_stream_slots<C16>(hk1 - hk0, ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
+                             ((unsigned int)so_k * 64u + (unsigned int)lane) * (unsigned int)(C16 ? sizeof(short) : sizeof(int)), vals,
+                             C16 ? (const void*)sv.coldelta : (const void*)sv.colidx, pl, pl + pa.n_pad, pl + 2 * pa.n_pad, help_sl * 64 + lane, h0, h1, h2);
+      double* hp = ypart + (size_t)help_idx * 3 * 64 + lane;
+      hp[0] = h0; hp[64] = h1; hp[128] = h2;
+    }
     y[0] = y0; y[1] = y1; y[2] = y2;
     lap(2);  // product
+  };
+  // the helpers' partial sums of this wavefront's slice, in the order of their numbers (after a workgroup barrier that follows the product)
+  auto add_helpers = [&](double* y) {
+    unsigned int m = help_mask;
+    while (m) {
+      const int hi = __ffs((int)m) - 1;
+      m &= m - 1u;
+      const double* hp = ypart + (size_t)hi * 3 * 64 + lane;
+      y[0] += hp[0]; y[1] += hp[64]; y[2] += hp[128];
+    }
   };
 
   // this row's vectors stay here for the whole solve
@@ -522,6 +578,10 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     product(vin, y, phase == PH_ITER, phase != PH_ITER || unsettled);
     unsettled = phase != PH_ITER;  // (an iteration's sums sweep settles the next product's early acquire)
     if (failed) break;
+    if (has_help && phase != PH_ITER) {  // (an iteration's sweep of the sums has barriers of its own: the partial sums are added behind them)
+      __syncthreads();
+      add_helpers(y);
+    }
     if (phase == PH_WARM_X || phase == PH_REFRESH_X) {
       unsigned int d3 = 3u * (unsigned int)(rvalid ? row : 0);
       asm volatile("" : "+v"(d3));  // opaque: the address of b is formed here, not kept in two registers through the whole solve
@@ -593,6 +653,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     }
     lap(3);  // sweep of the sums
     if (uniform_flag(bc[2] != 0.0)) { failed = true; break; }  // a wait timed out somewhere: every workgroup leaves within one phase
+    if (has_help) add_helpers(y);  // (every path of the sweep ends in a workgroup barrier: the helpers' sums of this product are in LDS)
     gamma = uniform_f64(bc[0]);
     const double delta = uniform_f64(bc[1]);
     if (fresh) rho0 = gamma;

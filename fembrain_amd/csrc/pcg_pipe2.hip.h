@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int first, count;
   if constexpr (SHARD) { first = sa.wg_range[blockIdx.x].x; count = sa.wg_range[blockIdx.x].y; }
-  else pipe_slices(sv.n_slices, nb, blockIdx.x, &first, &count);
+  else pipe_deal(pa.wg_first, sv.n_slices, nb, blockIdx.x, &first, &count);
   const bool spare = SHARD && wv == n_waves - 1;  // a shard's spare wavefront: sums, counters, proxy copies (it owns no slice)
   bool live[2], rvalid[2];
   int row[2], so[2], width[2], send_beg[2], send_end[2];

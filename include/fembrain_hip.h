@@ -345,6 +345,10 @@ int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches,
  * again, and every re-sync re-arms it (sharded handles: at a re-sync only, the ranks switch together).  Returns how often this handle
  * was re-armed by the count. */
 int fb_fem_persist_rearms(fb_fem_t h);
+/* helper tasks of the persistent solver on this mesh (0: none): where a few slices are much wider than the rest (hull nodes of a Delaunay
+ * mesh), wavefronts without a slice of their own multiply the upper part of a wide slice's slots and hand the partial sums over in LDS
+ * (fembrain_amd/csrc/pcg_pipe.hip.h).  Chosen by the library from the slice widths; FEMBRAIN_PIPE_HELPERS=0/1 overrides. */
+int fb_fem_persist_helpers(fb_fem_t h);
 /* average device seconds of ONE persistent launch that starts a solve of the current system and is cut after n_iters
  * iterations (tolerance out of reach), HIP events on the handle's stream around the launch; the difference of two lengths
  * prices an iteration without the launch's fixed cost */

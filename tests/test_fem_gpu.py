@@ -1111,8 +1111,7 @@ def _persistent(monkeypatch, kernel, *a, c16=True, **kw):
 
 @pytest.mark.parametrize("n,c16,kernel", [(14, True, "k_pcg_pipe<float,c16,8,8>"), (14, False, "k_pcg_pipe<float,c32,8,8>"),
                                           (26, True, "k_pcg_pipe<float,c16,8,8>"), (26, False, "k_pcg_pipe<float,c32,8,8>"),
-                                          (14, True, "k_pcg_pipe<float,c16,5,16>"), (26, True, "k_pcg_pipe<float,c16,5,16>"), (26, False, "k_pcg_pipe<float,c32,5,16>"),
-                                          (33, True, "k_pcg_pipe<float,c16,5,16>")])
+                                          (14, True, "k_pcg_pipe<float,c16,5,16>"), (26, True, "k_pcg_pipe<float,c16,5,16>"), (26, False, "k_pcg_pipe<float,c32,5,16>")])
 def test_persistent_solver_against_the_oracle(gpu, monkeypatch, n, c16, kernel):
     """One and two slices per workgroup (2,744 / 17,576 nodes): the solution of a tight solve and three reference-load steps against
     the CPU oracle (CGSolver.cpp:129-190 restated), iteration counts within max(3, 2 %)."""
@@ -1148,6 +1147,88 @@ def test_persistent_solver_against_the_oracle(gpu, monkeypatch, n, c16, kernel):
     p = g.pcg_path()
     assert p["path"] == fl.FB_PCG_PATH_PERSISTENT and p["launches"] >= 4 and p["fallbacks"] == 0 and 0 < p["max_producers"] <= 64
     g.close()
+
+
+def _delaunay_lattice(m, seed=2):
+    """Delaunay tetrahedra of an m^3 lattice with jittered points: hull nodes with 40 and more neighbours next to interior nodes with 15"""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    g = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(float)
+    pts = (g + rng.uniform(-0.35, 0.35, size=g.shape)) * 0.1
+    t = Delaunay(pts).simplices.astype(np.int32)
+    vol = np.einsum("ij,ij->i", pts[t[:, 1]] - pts[t[:, 0]], np.cross(pts[t[:, 2]] - pts[t[:, 0]], pts[t[:, 3]] - pts[t[:, 0]])) / 6
+    keep = np.abs(vol) > 1e-9
+    t, vol = t[keep], vol[keep]
+    t[vol < 0] = t[vol < 0][:, [0, 2, 1, 3]]
+    return pts, np.ascontiguousarray(t), fixed_vertices_to_dofs(np.nonzero(g[:, 0] == 0)[0])
+
+
+@pytest.mark.parametrize("kind,m,force,minlen", [("cube", 14, "1", "4"), ("cube", 26, "1", "4"), ("delaunay", 16, "1", None), ("delaunay", 22, None, None)])
+def test_persistent_solver_with_helper_wavefronts(gpu, monkeypatch, kind, m, force, minlen):
+    """Round 5: where a few slices are much wider than the rest (hull nodes of a Delaunay mesh) wavefronts without a slice of their own
+    multiply the upper part of a wide slice's slots and hand the partial sums over in LDS (pcg_pipe.hip.h, PipeArgs::tasks), and the
+    slices are dealt to the workgroups by slots (PipeArgs::wg_first).  The library decides from the widths (delaunay 22) or is told
+    (FEMBRAIN_PIPE_HELPERS=1; on the well-conditioned cubes with streams as short as 4 slots, so that hundreds of helpers work).
+    Against the same kernel WITHOUT helpers: on the cubes the SAME iteration count and the solution to 1e-10 (only the order of three
+    additions per row differs); on the sliver meshes, whose pipelined recurrences answer every change of rounding with a few per cent
+    of iterations, within 4 % and to the solver's tolerance.  Against ITSELF cut into launches of 1, 7 and 30 iterations: bit for bit.
+    Against the two-launch solver: three steps to the parity tolerance of the step tests."""
+    if kind == "cube":
+        v, t, fixed = _cube(m)
+        load, eps = -10000.0, 1e-8
+    else:
+        v, t, fixed = _delaunay_lattice(m)
+        load, eps = -100.0, 1e-6
+    gm = _two_launch(monkeypatch, v, t, fixed)
+    monkeypatch.setenv("FEMBRAIN_PERSIST_MIN_WAVES", "1")
+    if force:
+        monkeypatch.setenv("FEMBRAIN_PIPE_HELPERS", force)
+    if minlen:
+        monkeypatch.setenv("FEMBRAIN_PIPE_HELP_MINLEN", minlen)
+    gp = FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT)
+    monkeypatch.delenv("FEMBRAIN_PIPE_HELP_MINLEN", raising=False)
+    monkeypatch.setenv("FEMBRAIN_PIPE_HELPERS", "0")
+    g0 = FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT)
+    monkeypatch.delenv("FEMBRAIN_PIPE_HELPERS")
+    L = fl.lib()
+    cnt = L.fb_fem_device_plan_get(gp.h, b"slice_off", None, 0)
+    so = np.zeros(cnt, np.int32)
+    L.fb_fem_device_plan_get(gp.h, b"slice_off", fl.iptr(so), cnt)
+    wd = np.diff(so)
+    # the library's own rule where it was left to decide: widest slice wider than 24 slots and half again as wide as the average
+    expect = True if force else bool(wd.max() > 24 and wd.max() >= 1.5 * wd.mean())
+    assert (L.fb_fem_persist_helpers(gp.h) > 0) == expect and L.fb_fem_persist_helpers(g0.h) == 0, (L.fb_fem_persist_helpers(gp.h), wd.max(), wd.mean(), gp.pcg_path())
+    if expect:
+        assert gp.pcg_path()["kernel"].startswith("k_pcg_pipe<float,") and gp.pcg_path()["kernel"].endswith(",12,6>")
+    for g in (gm, gp, g0):
+        g.set_uniform_force(1, load)
+    _, rhs = gm.system()
+    gp.system(); g0.system()
+    itp, xp = gp.pcg(rhs, eps=eps, max_iter=20000)
+    it0, x0 = g0.pcg(rhs, eps=eps, max_iter=20000)
+    assert gp.pcg_path()["path"] == fl.FB_PCG_PATH_PERSISTENT and gp.pcg_path()["fallbacks"] == 0 and it0 > 30
+    if kind == "cube":
+        assert itp == it0 and np.abs(xp - x0).max() <= 1e-10 * np.abs(x0).max(), (itp, it0)
+    else:
+        assert abs(itp - it0) <= 0.04 * it0 and np.abs(xp - x0).max() <= 2e-4 * np.abs(x0).max(), (itp, it0)
+    assert not xp[fixed].any()
+    for run in ("1", "7", "30"):
+        monkeypatch.setenv("FEMBRAIN_PERSIST_MAX_RUN", run)
+        itc, xc = gp.pcg(rhs, eps=eps, max_iter=20000)
+        assert itc == itp and np.array_equal(xc, xp), run
+    monkeypatch.delenv("FEMBRAIN_PERSIST_MAX_RUN")
+    for g in (gm, gp):
+        g.reset_to_rest()
+    for k in range(3):
+        its = []
+        for g in (gm, gp):
+            g.set_uniform_force(1, load)
+            its.append(g.do_timestep())
+        assert abs(its[0] - its[1]) <= max(3, (0.02 if kind == "cube" else 0.05) * its[0]), (k, its)
+        qa, qb = gm.get_q_state()[0], gp.get_q_state()[0]
+        assert np.abs(qa - qb).max() <= 2e-4 * np.abs(qa).max()
+    for g in (gm, gp, g0):
+        g.close()
 
 
 @pytest.mark.parametrize("n,kname", [(14, "k_pcg_pipe<float,c16,8,8>"), (31, "k_pcg_pipe<float,c16,8,8>"), (40, "k_pcg_pipe<float,c16,8,8>"),
