@@ -271,7 +271,7 @@ def cut_resync_leg(device, prec):
     from fembrain_amd.meshgen import apply_delta, synthetic_cut
     import torch
     v, t, fixed = workload_mesh("cube56", device)
-    names = {fl.FB_RESYNC_FULL: "full", fl.FB_RESYNC_DELTA_MERGED: "pair list updated", fl.FB_RESYNC_DELTA_REBUILT: "full builder from the device copy of the mesh"}
+    names = {fl.FB_RESYNC_FULL: "full", fl.FB_RESYNC_DELTA_MERGED: "plan updated from the plan", fl.FB_RESYNC_DELTA_REBUILT: "full builder from the device copy of the mesh"}
     g = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device, expect_cuts=True)   # (the caller of fb_fem_resync_delta says it will cut)
     ref = FemIntegrator(v, t, fixed, matrix_precision=prec, device=device)
 
@@ -343,12 +343,12 @@ def field_bench(device, cpu=True):
     ftraffic, fnote = None, "no PMC profile of the current kernel sources under profiles/"
     try:
         from fembrain_amd import lib as _fl
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r04_poly256_pmc.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r05_poly256_pmc.json")))
         if rec.get("kernel_source_sha256") == _fl.source_sha256("poly"):
             ftraffic = rec["kernels"]["k_tet_elements"]["bytes"]
-            fnote = "profiles/r04_poly256_pmc.json (2 x FETCH_SIZE + WRITE_SIZE of k_tet_elements, separate --pmc passes; same kernel sources)"
+            fnote = "profiles/r05_poly256_pmc.json (2 x FETCH_SIZE + WRITE_SIZE of k_tet_elements, separate --pmc passes; same kernel sources)"
         else:
-            fnote = "profiles/r04_poly256_pmc.json was recorded for other kernel sources: not reported"
+            fnote = "profiles/r05_poly256_pmc.json was recorded for other kernel sources: not reported"
     except Exception:  # noqa: BLE001
         pass
     elem_bytes = 96.0 * n_inc + npts / 64.0 * 24.0

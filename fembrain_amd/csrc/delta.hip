@@ -224,15 +224,25 @@ __global__ __launch_bounds__(kB) void k_oldrow(int n_old, int n_new_nodes, const
 }
 // rows of the fresh pairs, and the rows of the elements that go (their old nodes through the node map).  The fresh list is sorted by
 // row: one atomic per run of a row, not per entry (every entry of a row hits the same word: 99 us of same-address atomics at 1.1M tets)
-// appends the rows of the lanes with `mine` to the list: one atomic per wavefront (35 us of same-address atomics at 1.1M tets otherwise)
+// appends the rows of the threads with `mine` to the list: ONE atomic on the counter per workgroup (an atomic per first entry: 35 us of
+// same-address atomics at 1.1M tets; one per wavefront: still 3,400 of them on one address, 34 us).  Every thread of the workgroup calls it.
 __device__ __forceinline__ void append_rows(bool mine, int r, int* __restrict__ tlist, int* __restrict__ count) {
+  __shared__ int s_cnt[kB / 64], s_base;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const unsigned long long m = __ballot(mine);
-  if (!m) return;
-  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(count, __popcll(m));
-  base = __shfl(base, leader, 64);
-  if (mine) tlist[base + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
+  if (lane == 0) s_cnt[wv] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < kB / 64; w++) total += s_cnt[w];
+    s_base = total ? atomicAdd(count, total) : 0;
+  }
+  __syncthreads();
+  if (mine) {
+    int base = s_base;
+    for (int w = 0; w < wv; w++) base += s_cnt[w];
+    tlist[base + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
+  }
 }
 __global__ __launch_bounds__(kB) void k_touch(int n_fresh, const unsigned long long* __restrict__ fk, int n_gone, const int* __restrict__ removed, int n_removed,
                                               const int* __restrict__ changed, const int4* __restrict__ tets_old, const int* __restrict__ imap, int* __restrict__ touched,

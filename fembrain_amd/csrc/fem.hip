@@ -736,7 +736,7 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
     h->asm_tets = mw >= 2 && mw <= kIncMaxWidth && h->asm_lds <= lds_cu && h->asm_lds <= (int)prop.sharedMemPerBlock && !(e && !strcmp(e, "rows"));
     if (h->asm_tets) {
       FB_TRY(build_incidence_device(s, P.n_slices, P.n_owned, h->slice_off.p, h->colidx.p, h->slot_coff.p, h->slot_ccnt.p, h->contrib.p, h->tets.p, h->inc_off,
-                                    h->inc, h->inc_slot, h->plan_ws));
+                                    h->inc, h->inc_slot, h->plan_ws, P.n_ranks == 1));
       int per_cu = std::max(1, lds_cu / h->asm_lds);
       if (const char* pc = getenv("FEMBRAIN_ASM_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(pc)));  // development aid
       const int cus = std::max(8, (prop.multiProcessorCount / 8) * 8);

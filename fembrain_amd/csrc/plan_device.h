@@ -103,6 +103,7 @@ int plan_layout_from_csr(hipStream_t s, int n_nodes, const unsigned int* ucnt, b
 // The incidence list of a row is the contribution list of its diagonal block, so the ascending element order carries over.
 constexpr int kIncMaxWidth = 31;  // widest slice (in slots) the element-major assembly kernel takes
 int build_incidence_device(hipStream_t s, int n_slices, int n_owned, const int* slice_off, const int* colidx, const int* slot_coff, const int* slot_ccnt,
-                           const uint32_t* contrib, const int4* tets, DevBuf<int>& inc_off, DevBuf<uint32_t>& inc, DevBuf<uint32_t>& inc_slot, PlanWorkspace& ws);
+                           const uint32_t* contrib, const int4* tets, DevBuf<int>& inc_off, DevBuf<uint32_t>& inc, DevBuf<uint32_t>& inc_slot, PlanWorkspace& ws,
+                           bool ascending_columns);  // ascending_columns: the column ids of a row ascend (an unsharded plan): binary searches
 
 }  // namespace fb

@@ -311,7 +311,16 @@ __global__ __launch_bounds__(kB) void k_inc_heights(int n_slices, int n_owned, c
     for (int k = 0; k < width; k++)
       if (colidx[((size_t)so + k) * 64 + lane] == row) {  // the first such slot is the diagonal block (padding repeats the row id later)
         const int coff = slot_coff[so + k], ccnt = slot_ccnt[so + k];
-        while (cnt < ccnt && contrib[((size_t)coff + cnt) * 64 + lane] != 0xFFFFFFFFu) cnt++;
+        bool ended = false;
+        for (int t0 = 0; t0 < ccnt && !ended; t0 += 8) {  // (eight entries of the list in flight: one at a time was a chain of ~25 dependent loads)
+          uint32_t wd[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) wd[j] = t0 + j < ccnt ? contrib[((size_t)coff + t0 + j) * 64 + lane] : 0xFFFFFFFFu;
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            if (!ended && wd[j] != 0xFFFFFFFFu) cnt++; else ended = true;
+          }
+        }
         break;
       }
 #pragma unroll
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(kB) void k_inc_heights(int n_slices, int n_owned, c
 
 __global__ __launch_bounds__(kB) void k_inc_fill(int n_slices, int n_owned, const int* __restrict__ slice_off, const int* __restrict__ colidx, const int* __restrict__ slot_coff, const int* __restrict__ slot_ccnt,
                                                      const uint32_t* __restrict__ contrib, const int4* __restrict__ tets, const int* __restrict__ inc_off,
-                                                     uint32_t* __restrict__ inc, uint32_t* __restrict__ inc_slot) {
+                                                     uint32_t* __restrict__ inc, uint32_t* __restrict__ inc_slot, int ascending) {
   // the columns of the slice are searched 4 x (list length) times per row: staged in LDS once (the builder is called for
   // slices of at most kIncMaxWidth slots, the limit of the kernel that reads the lists)
   __shared__ int cols[kB / 64][kIncMaxWidth][64];
@@ -338,6 +347,12 @@ __global__ __launch_bounds__(kB) void k_inc_fill(int n_slices, int n_owned, cons
     if (row < n_owned && kd < 0 && c == row) kd = k;
   }
   const int coff = kd >= 0 ? slot_coff[so + kd] : 0, ccnt = kd >= 0 ? slot_ccnt[so + kd] : 0;
+  // the real blocks of the lane's row: ascending columns, then padding (the row id again).  Their number, so that the four searches per
+  // list entry below are binary (round 5: the linear walk over up to 31 slots made this kernel 375 us of a re-sync at 1.1M tets)
+  // (ascending: an unsharded plan.  A shard orders a row by GLOBAL column while the ids here are local -- halo nodes of a lower rank come first
+  // and carry the larger local ids -- so it keeps the linear walk.)
+  int len = width > 0 ? 1 : 0;
+  while (ascending && len < width && cols[wv][len][lane] > cols[wv][len - 1][lane]) len++;
   for (int t = 0; t < height; t++) {
     uint32_t w = kNoContrib, sl = 0;
     if (t < ccnt) {
@@ -348,9 +363,16 @@ __global__ __launch_bounds__(kB) void k_inc_fill(int n_slices, int n_owned, cons
         const int4 tt = tets[e];
         const int id[4] = {tt.x, tt.y, tt.z, tt.w};
         for (int j = 0; j < 4; j++) {
-          int k = 0;
-          while (k < width && cols[wv][k][lane] != id[j]) k++;  // found by construction; the first match is the real block
-          sl |= (uint32_t)(k & 255) << (8 * j);
+          int lo = 0, hi = len;  // (found by construction: node j of an element on this row is a column of the row)
+          if (ascending) {
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (cols[wv][mid][lane] < id[j]) lo = mid + 1; else hi = mid;
+            }
+          } else {
+            while (lo < width && cols[wv][lo][lane] != id[j]) lo++;  // the first match is the real block
+          }
+          sl |= (uint32_t)(lo & 255) << (8 * j);
         }
       }
     }
@@ -536,7 +558,7 @@ int device_partition(hipStream_t s, int n_tets, DevBuf<int4>& tets, int n_global
 }
 
 int build_incidence_device(hipStream_t s, int n_slices, int n_owned, const int* slice_off, const int* colidx, const int* slot_coff, const int* slot_ccnt,
-                           const uint32_t* contrib, const int4* tets, DevBuf<int>& inc_off, DevBuf<uint32_t>& inc, DevBuf<uint32_t>& inc_slot, PlanWorkspace& W) {
+                           const uint32_t* contrib, const int4* tets, DevBuf<int>& inc_off, DevBuf<uint32_t>& inc, DevBuf<uint32_t>& inc_slot, PlanWorkspace& W, bool ascending_columns) {
   FB_TRY(W.width.reserve((size_t)n_slices + 1));
   FB_HIP(hipMemsetAsync(W.width.p, 0, sizeof(int) * ((size_t)n_slices + 1), s));
   const dim3 sg((unsigned)((n_slices + kB / 64 - 1) / (kB / 64)));
@@ -551,7 +573,7 @@ int build_incidence_device(hipStream_t s, int n_slices, int n_owned, const int* 
   FB_TRY(inc_off.download(&rows, 1, s, (size_t)n_slices));
   FB_TRY(inc.alloc(std::max<size_t>(1, (size_t)rows * 64)));
   FB_TRY(inc_slot.alloc(std::max<size_t>(1, (size_t)rows * 64)));
-  hipLaunchKernelGGL(k_inc_fill, sg, dim3(kB), 0, s, n_slices, n_owned, slice_off, colidx, slot_coff, slot_ccnt, contrib, tets, inc_off.p, inc.p, inc_slot.p);
+  hipLaunchKernelGGL(k_inc_fill, sg, dim3(kB), 0, s, n_slices, n_owned, slice_off, colidx, slot_coff, slot_ccnt, contrib, tets, inc_off.p, inc.p, inc_slot.p, ascending_columns ? 1 : 0);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
