@@ -200,15 +200,15 @@ int fb_fem_resync_sharded(fb_fem_t h, int n_nodes, const double* xyz, int n_tets
  *   new_xyz[3 n_new_nodes]    rest positions of nodes appended behind the last one (ids n_nodes, n_nodes + 1, ...)
  *   fixed_dofs                the whole constrained-DOF list of the new mesh, as fb_fem_resync takes it
  * The element list and the rest positions stay on the device; the result is the state fb_fem_resync would leave with the whole new
- * mesh (state reset).  Where the handle still holds the sorted pair list its plan was built from, that list is updated instead of
- * built and sorted again: for a handle in the caller's node order the plan is bit for bit the full rebuild's; a renumbered handle
+ * mesh (state reset).  The plan is updated from the plan (block pattern with the pairs of every block, contribution table:
+ * fembrain_amd/csrc/delta.hip) instead of built and sorted again: for a handle in the caller's node order the plan is bit for bit the full rebuild's; a renumbered handle
  * (fb_fem_renumbering) puts the new nodes into its slab order under the cell size the order was made with, where a full rebuild
  * would derive a new cell size -- same pattern and values in the caller's ids, roundings of sums aside.  Otherwise (and with
  * FEMBRAIN_RESYNC_DELTA=rebuild) the full builder runs from the device copy of the new mesh.  fb_fem_resync_path: what the last
  * re-sync of the handle did.  Unsharded handles with a device-built plan only (FB_EINVAL otherwise); a bad id is refused before
  * anything changes; after a failure further in the handle is unusable until a full fb_fem_resync succeeds. */
 #define FB_RESYNC_FULL 0           /* fb_fem_create / fb_fem_resync: whole mesh from the host */
-#define FB_RESYNC_DELTA_MERGED 1   /* fb_fem_resync_delta: pair list updated */
+#define FB_RESYNC_DELTA_MERGED 1   /* fb_fem_resync_delta: the plan updated from the plan */
 #define FB_RESYNC_DELTA_REBUILT 2  /* fb_fem_resync_delta: full builder from the device copy of the mesh */
 int fb_fem_resync_delta(fb_fem_t h, int n_removed, const int* removed, int n_changed, const int* changed_ids, const int* changed_nodes,
                         int n_added, const int* added_tets, int n_new_nodes, const double* new_xyz, int n_fixed_dofs, const int* fixed_dofs);
