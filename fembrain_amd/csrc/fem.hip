@@ -247,6 +247,17 @@ int handle_slack(const fb_fem_s* h, int n_nodes, int n_tets) {
   return std::max(2, std::min(32, (int)std::ceil(f * 16.0)));
 }
 
+// FB_MATRIX_AUTO: fp32 values from 2 slices per CU on (setup_persist's `w`, the persistent solver's range) and where the persistent solver is
+// asked for by name; fp64 below (include/fembrain_hip.h).  A shard decides by the WHOLE mesh, so that the sharded and the unsharded handle
+// of one mesh store the same values; the sharded persistent solver, asked for through the environment, needs fp32 as the unsharded one does.
+bool auto_matrix_f64(const fb_fem_s* h, int n_nodes, int n_ranks) {
+  const int cus = h->cu_limit > 0 ? std::min(h->cu_limit, h->n_cu_device) : h->n_cu_device;
+  const int nb = std::min(kPipeMaxBlocks, (cus / 8) * 8);
+  const int w = nb >= 8 ? ceil_div(ceil_div(ceil_div(n_nodes, 64), 8), nb / 8) : 0;
+  const bool shard_persist_asked = n_ranks > 1 && getenv("FEMBRAIN_SHARDED_PERSIST") && atoi(getenv("FEMBRAIN_SHARDED_PERSIST")) != 0;
+  return h->prm.pcg_variant != FB_PCG_PERSISTENT && !shard_persist_asked && w < 2;
+}
+
 constexpr int kFreshOrderPercent = 2;
 int fresh_order_percent() {
   const char* e = getenv("FEMBRAIN_FRESH_ORDER_PERCENT");
@@ -1789,17 +1800,7 @@ int build(fb_fem_s* h, int n_nodes, const double* xyz, int n_tets, const int* te
           int rank, const int* splits, const DeviceTetMesh* dm = nullptr) {
   drop_graph(h);  // the buffers it refers to are about to be replaced
   SlackScope slack(handle_slack(h, n_nodes, n_tets));
-  if (h->prm.matrix_precision == FB_MATRIX_AUTO) {
-    // fp32 values from 2 slices per CU on (setup_persist's `w`, the persistent solver's range), on shards, and where the persistent
-    // solver is asked for by name; fp64 below (include/fembrain_hip.h, FB_MATRIX_AUTO)
-    const int cus = h->cu_limit > 0 ? std::min(h->cu_limit, h->n_cu_device) : h->n_cu_device;
-    const int nb = std::min(kPipeMaxBlocks, (cus / 8) * 8);
-    const int w = nb >= 8 ? ceil_div(ceil_div(ceil_div(n_nodes, 64), 8), nb / 8) : 0;
-    // (a shard decides by the WHOLE mesh, so that the sharded and the unsharded handle of one mesh store the same values; the sharded
-    // persistent solver, asked for through the environment, needs fp32 as the unsharded one does)
-    const bool shard_persist_asked = n_ranks > 1 && getenv("FEMBRAIN_SHARDED_PERSIST") && atoi(getenv("FEMBRAIN_SHARDED_PERSIST")) != 0;
-    h->f64 = h->prm.pcg_variant != FB_PCG_PERSISTENT && !shard_persist_asked && w < 2;
-  }
+  if (h->prm.matrix_precision == FB_MATRIX_AUTO) h->f64 = auto_matrix_f64(h, n_nodes, n_ranks);
   h->last_resync_path = FB_RESYNC_FULL;
   h->csr_ready = false;
   h->span_stale = false;
@@ -2450,6 +2451,9 @@ int resync_delta(fb_fem_s* h, int n_removed, const int* removed, int n_changed, 
   // than the order was built for, the change gets a fresh order (FEMBRAIN_FRESH_ORDER_PERCENT overrides: the tests keep the merged
   // path busy with larger changes)
   if (merge && h->ren.active && (long long)n_new * 100 > (long long)h->ren_nodes_at_build * (100 + fresh_order_percent())) merge = false;
+  // FB_MATRIX_AUTO is decided again at every re-sync: a mesh that has grown across the size rule gets its values in the other width,
+  // which the full builder allocates
+  if (merge && h->prm.matrix_precision == FB_MATRIX_AUTO && auto_matrix_f64(h, n_new, 1) != h->f64) merge = false;
   const int mode = renumber_mode(h);
   int span = -1;
   double mean = 0.0;
