@@ -2523,7 +2523,6 @@ int resync_delta(fb_fem_s* h, int n_removed, const int* removed, int n_changed, 
   Dp.slice_off = &D.slice_off2; Dp.colidx = &h->colidx; Dp.slot_coff = &D.slot_coff2; Dp.slot_ccnt = &h->slot_ccnt; Dp.contrib = &D.contrib2;
   Dp.bptr = &D.bptr2; Dp.bcol = &D.bcol2; Dp.blk_slot = &D.blk_slot2; Dp.coldelta = &h->coldelta; Dp.ucnt_keep = &D.ucnt2;
   h->csr_ready = false;
-  W.sorted.valid = false;
   FB_TRY(delta_plan(s, D, old_plan, h->tets_next.p, h->tets.p, n_new, Dp, W));  // (tets_next: the old list, swapped out above)
   h->slice_off.swap(D.slice_off2); h->slot_coff.swap(D.slot_coff2); h->contrib.swap(D.contrib2);
   h->d_bptr.swap(D.bptr2); h->d_bcol.swap(D.bcol2); h->d_blk_slot.swap(D.blk_slot2); h->d_ucnt.swap(D.ucnt2);

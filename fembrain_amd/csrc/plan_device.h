@@ -9,16 +9,6 @@
 
 namespace fb {
 
-// The sorted (row, column) -> contribution list the last unsharded plan was built from, left in the workspace (keys_s / vals_s):
-// fb_fem_resync_delta (delta.hip) updates it -- drops the pairs of removed elements, merges in those of new ones -- instead of sorting
-// 16 pairs per element again.  narrow: 32-bit keys row << cb | (col - row + span); else 64-bit keys row << col_bits | col.
-struct SortedPairs {
-  bool valid = false, narrow = false;
-  int cb = 0, span = 0, col_bits = 0;
-  long long n_pairs = 0;
-  int n_nodes = 0, n_tets = 0;
-};
-
 // temporaries of the builder, kept by the caller between builds (a re-sync after every cut would otherwise spend more time
 // in hipMalloc / hipFree of ~700 MB than in the kernels)
 struct PlanWorkspace {
@@ -32,14 +22,12 @@ struct PlanWorkspace {
   DevBuf<int> picked, splits, idsel;       // device_partition: selected ids (+ count at the end), node ranges, kept element ids
   DevBuf<unsigned char> keep;              // device_partition: element has an owned node
   DevBuf<int4> tetsel;                     // device_partition: the kept elements (swapped with the handle's buffer)
-  SortedPairs sorted;
   size_t bytes() const {  // what is really held: capacities, not the sizes in use
     return nodeflag.cap + sendmask.cap * 8 + picked.cap * 4 + idsel.cap * 4 + keep.cap + tetsel.cap * 16 + keys.cap * 8 + keys_s.cap * 8 + ukeys.cap * 8 + vals.cap * 4 + vals_s.cap * 4 +
            ucnt.cap * 4 + cstart.cap * 4 + nruns.cap * 4 + width.cap * 4 + flags.cap * 4 + temp.cap;
   }
   void release() {
     keys.release(); keys_s.release(); ukeys.release(); vals.release(); vals_s.release(); ucnt.release(); cstart.release(); nruns.release();
-    sorted = SortedPairs();
     width.release(); flags.release(); temp.release(); nodeflag.release(); sendmask.release(); picked.release(); splits.release(); idsel.release(); keep.release(); tetsel.release();
   }
 };
@@ -90,8 +78,6 @@ int device_partition(hipStream_t s, int n_tets, DevBuf<int4>& tets, int n_global
 // span >= 0: the widest element of the list (largest id difference inside a tet, renumber.h) when the caller has measured it -- lets the sort use 32-bit keys
 int build_plan_device(hipStream_t s, int n_nodes, int n_tets, const int4* d_tets, DevicePlan& out, PlanWorkspace& ws, const PlanShard* shard = nullptr, int span = -1);
 
-// the rest of the builder from the sorted pair list W.sorted describes (unsharded)
-int plan_from_sorted_pairs(hipStream_t s, DevicePlan& out, PlanWorkspace& ws);
 // SELL-64 layout, slot table and list heights of the pattern in out.bptr / out.bcol with `ucnt` pairs per block (the diagonal block's count
 // includes its marker): fills slice_off, colidx, blk_slot, coldelta, slot_ccnt, slot_coff and n_slices, n_slots, n_crows, deltas_fit16,
 // slice_off_host.  The second half of the builder; delta.hip calls it on the pattern it has updated.  Synchronises the stream.

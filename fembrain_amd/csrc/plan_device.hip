@@ -353,15 +353,23 @@ __global__ __launch_bounds__(kB) void k_inc_fill(int n_slices, int n_owned, cons
   // and carry the larger local ids -- so it keeps the linear walk.)
   int len = width > 0 ? 1 : 0;
   while (ascending && len < width && cols[wv][len][lane] > cols[wv][len - 1][lane]) len++;
-  for (int t = 0; t < height; t++) {
-    uint32_t w = kNoContrib, sl = 0;
-    if (t < ccnt) {
-      const uint32_t c = contrib[((size_t)coff + t) * 64 + lane];
-      if (c != 0xFFFFFFFFu) {
-        const uint32_t e = c >> 4, i = (c >> 2) & 3;
+  // four list entries at a time: their words, then their elements' node ids, in flight together (one entry after the other was a chain
+  // of two dependent loads per entry: 113 us of every re-sync at 1.1M tets)
+  for (int t0 = 0; t0 < height; t0 += 4) {
+    uint32_t c[4];
+    int4 tt[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) c[u] = t0 + u < ccnt ? contrib[((size_t)coff + t0 + u) * 64 + lane] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < 4; u++) tt[u] = c[u] != 0xFFFFFFFFu ? tets[c[u] >> 4] : make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (t0 + u >= height) break;  // wave-uniform
+      uint32_t w = kNoContrib, sl = 0;
+      if (c[u] != 0xFFFFFFFFu) {
+        const uint32_t e = c[u] >> 4, i = (c[u] >> 2) & 3;
         w = (e << 2) | i;
-        const int4 tt = tets[e];
-        const int id[4] = {tt.x, tt.y, tt.z, tt.w};
+        const int id[4] = {tt[u].x, tt[u].y, tt[u].z, tt[u].w};
         for (int j = 0; j < 4; j++) {
           int lo = 0, hi = len;  // (found by construction: node j of an element on this row is a column of the row)
           if (ascending) {
@@ -375,9 +383,9 @@ __global__ __launch_bounds__(kB) void k_inc_fill(int n_slices, int n_owned, cons
           sl |= (uint32_t)(lo & 255) << (8 * j);
         }
       }
+      inc[((size_t)io + t0 + u) * 64 + lane] = w;
+      inc_slot[((size_t)io + t0 + u) * 64 + lane] = sl;
     }
-    inc[((size_t)io + t) * 64 + lane] = w;
-    inc_slot[((size_t)io + t) * 64 + lane] = sl;
   }
 }
 
@@ -633,19 +641,7 @@ int build_plan_device(hipStream_t s, int n_nodes_local, int n_tets, const int4* 
     FB_TRY(temp.reserve(std::max<size_t>(bytes, 16)));
     FB_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n_pairs, 0u, key_bits, s));
   }
-  // (kept in the workspace for a later fb_fem_resync_delta: delta.hip updates the sorted list instead of sorting again)
-  W.sorted = SortedPairs();
-  W.sorted.valid = !shard; W.sorted.narrow = narrow; W.sorted.cb = cb32; W.sorted.span = span; W.sorted.col_bits = geom.col_bits;
-  W.sorted.n_pairs = n_pairs; W.sorted.n_nodes = n_nodes; W.sorted.n_tets = n_tets;
   return plan_from_sorted(s, n_nodes, n_pairs, n_valid, narrow, cb32, span, geom, shard, D, W);
-}
-
-int plan_from_sorted_pairs(hipStream_t s, DevicePlan& D, PlanWorkspace& W) {
-  const SortedPairs& S = W.sorted;
-  if (!S.valid) return fail(FB_EINVAL, "internal: no sorted pair list in the workspace");
-  PairGeom geom;
-  geom.n_rows = S.n_nodes; geom.node_lo = 0; geom.halo = nullptr; geom.col_bits = S.col_bits;
-  return plan_from_sorted(s, S.n_nodes, S.n_pairs, S.n_pairs, S.narrow, S.cb, S.span, geom, nullptr, D, W);
 }
 
 // The plan from the sorted pair list in W.keys_s / W.vals_s (stage 3 of the header comment)
