@@ -1264,6 +1264,14 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     hipLaunchKernelGGL((k_pcg_pipe<float, C16, WMAX, KLT, TIMING, SHARD>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p,       \
                        (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);          \
   } while (0)
+#define FB_PIPE_HELP(C16, TIMING)                                                                                                                     \
+  do {                                                                                                                                                \
+    FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe<float, C16, 12, 6, TIMING, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                               (int)lds));                                                                                                           \
+    hipLaunchKernelGGL((k_pcg_pipe<float, C16, 12, 6, TIMING, false, false, true>), grid, block, lds, h->stream, sell_view(h),                       \
+                       (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, \
+                       h->st.p, pa, sa);                                                                                                             \
+  } while (0)
 #define FB_PIPE_BJ(C16, WMAX, KLT)                                                                                                                     \
   do {                                                                                                                                                \
     FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe<float, C16, WMAX, KLT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
@@ -1290,6 +1298,9 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     else FB_PIPE(false, 12, 6, false, true);
   } else if (h->pipe_rows == 2) {
     if (h->c16) FB_PIPE2(true, false); else FB_PIPE2(false, false);
+  } else if (h->pipe_tasks.p) {  // helper wavefronts (setup_persist): the (12, 6) kernel compiled with them
+    if (pa.timing) { if (h->c16) FB_PIPE_HELP(true, true); else FB_PIPE_HELP(false, true); }
+    else { if (h->c16) FB_PIPE_HELP(true, false); else FB_PIPE_HELP(false, false); }
   } else if (pa.timing) {  // development build with the phase clocks: the 1M-tet configuration and the small one
     if (h->pipe_wmax == 12 && h->c16) FB_PIPE(true, 12, 6, true, false);
     else if (h->pipe_wmax == 12) FB_PIPE(false, 12, 6, true, false);
@@ -1302,6 +1313,7 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   else { if (h->c16) FB_PIPE(true, 12, 6, false, false); else FB_PIPE(false, 12, 6, false, false); }
 #undef FB_PIPE2
 #undef FB_PIPE_BJ
+#undef FB_PIPE_HELP
 #undef FB_PIPE
   FB_HIP(hipGetLastError());
   FB_HIP(hipEventRecord(h->ev_p[1], h->stream));

@@ -245,7 +245,10 @@ namespace fb {
 // stored into its box, the sums go through the rank level; 32-bit column words, write-through stores.  sa is not read otherwise.
 // BJ (FB_PCG_BLOCK_JACOBI, opt-in and not part of the reference): the preconditioner is the inverse of the row's 3x3 diagonal block
 // instead of 1/diag -- `invdiag` then points at 9 doubles per row (symmetric: 6 are loaded).  The Jacobi instantiations do not change.
-template <typename MT, bool C16, int WMAX, int KLT, bool TIMING, bool SHARD, bool BJ = false>
+// HELP: the instantiation with helper wavefronts (PipeArgs::tasks).  A template parameter, not a run-time test: with the helpers' second
+// copy of the streamed product compiled in, the kernel of the headline mesh -- which has none -- ran 3 % slower (16.2 against 15.7 us per
+// iteration on one box, tools/ab_r4 in round 5); with HELP = false nothing of it is there.
+template <typename MT, bool C16, int WMAX, int KLT, bool TIMING, bool SHARD, bool BJ = false, bool HELP = false>
 __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo,
                                                         const double* __restrict__ invdiag, const double* __restrict__ bvec, double* __restrict__ xg,
                                                         double* __restrict__ rg, double* __restrict__ wg, double* __restrict__ zg,
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
                                                         ShardArgs sa) {
   static_assert(!SHARD || (!C16 && !TIMING), "a shard's columns are 32-bit local ids; the phase clocks are built for the unsharded kernel");
   static_assert(!BJ || (!SHARD && !TIMING), "block-Jacobi is for unsharded handles");
+  static_assert(!HELP || (!SHARD && !BJ), "helper wavefronts: unsharded handles, the Jacobi preconditioner");
   static_assert(sizeof(MT) == 4, "k_pcg_pipe keeps part of the matrix in LDS as fp32 words and streams the rest as fp32");
   extern __shared__ double lds[];  // the request is padded so that one workgroup fills a CU
   double* wsum = lds;                          // [2][16] wave sums
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     if constexpr (SHARD) { send_beg = sa.row_send_off[row]; send_end = sa.row_send_off[row + 1]; }
   }
   // LDS-resident part of the matrix: the first KL slots of this wave's slice, [klt_w][10][64] words (9 values + the column id)
-  const int lds_slots = kPipeLdsSlots - (pa.n_help > 0 ? kPipeHelpSlots : 0);
+  const int lds_slots = kPipeLdsSlots - (HELP ? kPipeHelpSlots : 0);
   const int lbase = min(KLT, lds_slots / max(count, 1)), lrem = lbase < KLT ? min(count, lds_slots - lbase * count) : 0;  // workgroup-uniform
   const int klt_w = __builtin_amdgcn_readfirstlane(live ? lbase + (wv < lrem ? 1 : 0) : 0);
   const int KL = min(klt_w, width);
@@ -309,17 +313,21 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
   }
   // this wavefront's task (helpers, see PipeArgs): the owner of a slice streams its slots up to own_k1 and adds the partial sums of the
   // helpers in help_mask; a helper streams [hk0, hk1) of slice help_sl for the rows of that slice
-  const bool has_help = !SHARD && pa.tasks != nullptr;  // grid-uniform
+  // (every value below is wave-uniform and made so explicitly, outside any branch: scalar registers.  Without HELP they are constants and the
+  // kernel is the round-4 one.)
   double* ypart = (double*)((unsigned int*)(lds + kPipeSyncDoubles) + (size_t)(kPipeLdsSlots - kPipeHelpSlots) * 10 * 64);  // [helper][3][64]
-  // (every value below is wave-uniform and made so explicitly, outside any branch: scalar registers)
-  const int4 tk = has_help ? pa.tasks[(size_t)blockIdx.x * kPipeTaskStride + wv] : make_int4(-1, 0, 0, 0);
-  const bool helper = has_help && !live && !spare && tk.x >= 0;
-  const int own_k1 = __builtin_amdgcn_readfirstlane(has_help && live ? tk.z : width);
-  const unsigned int help_mask = (unsigned int)__builtin_amdgcn_readfirstlane(has_help && live ? tk.w : 0);
-  const int help_sl = __builtin_amdgcn_readfirstlane(helper ? first + tk.x : -1);
-  const int hk0 = __builtin_amdgcn_readfirstlane(helper ? tk.y : 0), hk1 = __builtin_amdgcn_readfirstlane(helper ? tk.z : 0);
-  const int help_idx = __builtin_amdgcn_readfirstlane(helper ? tk.w : 0);
-  const int help_so = __builtin_amdgcn_readfirstlane(sv.slice_off[help_sl < 0 ? 0 : help_sl]);
+  int own_k1 = width, help_sl = -1, hk0 = 0, hk1 = 0, help_idx = 0, help_so = 0;
+  unsigned int help_mask = 0u;
+  if constexpr (HELP) {
+    const int4 tk = pa.tasks[(size_t)blockIdx.x * kPipeTaskStride + wv];
+    const bool helper = !live && !spare && tk.x >= 0;
+    own_k1 = __builtin_amdgcn_readfirstlane(live ? tk.z : width);
+    help_mask = (unsigned int)__builtin_amdgcn_readfirstlane(live ? tk.w : 0);
+    help_sl = __builtin_amdgcn_readfirstlane(helper ? first + tk.x : -1);
+    hk0 = __builtin_amdgcn_readfirstlane(helper ? tk.y : 0); hk1 = __builtin_amdgcn_readfirstlane(helper ? tk.z : 0);
+    help_idx = __builtin_amdgcn_readfirstlane(helper ? tk.w : 0);
+    help_so = __builtin_amdgcn_readfirstlane(sv.slice_off[help_sl < 0 ? 0 : help_sl]);
+  }
   // the producers of this workgroup's columns: one per lane of wavefront 0
   const int n_prod = pa.prod_count[blockIdx.x];
   int my_prod = -1;
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
                                C16 ? (const void*)sv.coldelta : (const void*)sv.colidx, pl, pl + pa.n_pad, pl + 2 * pa.n_pad, row, y0, y1, y2);
       }
     }
-    if (help_sl >= 0) {  // a helper: its share of another wavefront's slice, handed over through LDS (the owner adds it after the next barrier)
+    if constexpr (HELP) if (help_sl >= 0) {  // a helper: its share of another wavefront's slice, handed over through LDS (the owner adds it after the next barrier)
       double h0 = 0, h1 = 0, h2 = 0;
       int so_k = help_so + hk0;
       asm volatile("" : "+s"(so_k));
@@ -588,7 +596,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     product(vin, y, phase == PH_ITER, phase != PH_ITER || unsettled);
     unsettled = phase != PH_ITER;  // (an iteration's sums sweep settles the next product's early acquire)
     if (failed) break;
-    if (has_help && phase != PH_ITER) {  // (an iteration's sweep of the sums has barriers of its own: the partial sums are added behind them)
+    if constexpr (HELP) if (phase != PH_ITER) {  // (an iteration's sweep of the sums has barriers of its own: the partial sums are added behind them)
       __syncthreads();
       add_helpers(y);
     }
@@ -663,7 +671,7 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     }
     lap(3);  // sweep of the sums
     if (uniform_flag(bc[2] != 0.0)) { failed = true; break; }  // a wait timed out somewhere: every workgroup leaves within one phase
-    if (has_help) add_helpers(y);  // (every path of the sweep ends in a workgroup barrier: the helpers' sums of this product are in LDS)
+    if constexpr (HELP) add_helpers(y);  // (every path of the sweep ends in a workgroup barrier: the helpers' sums of this product are in LDS)
     gamma = uniform_f64(bc[0]);
     const double delta = uniform_f64(bc[1]);
     if (fresh) rho0 = gamma;
