@@ -65,7 +65,10 @@ struct fb_fem_s {
   DevBuf<int4> pipe_tasks;           // persistent solver: per workgroup and wavefront its share of the slices (helpers, pcg_pipe.hip.h PipeArgs)
   int pipe_help_waves = 0;           // wavefronts launched beyond slices + service wavefront, for the helpers (0: none)
   int pipe_n_help = 0, pipe_help_tasks = 0;  // most helper tasks of a workgroup; all of them
-  int asm_wide = 0;                  // slices wider than the element-major kernel takes (kIncMaxWidth slots): the slot-major kernel assembles those
+  int asm_wide = 0;                  // slices wider than the element-major kernel takes (kIncMaxWidth slots): k_assemble_wide assembles those
+  int asm_wide_slots = 0, asm_wide_grid = 0;  // the widest of them; workgroups of k_assemble_wide (each with a scratch area of asm_wide_slots slots)
+  DevBuf<int> wide_list;             // their slice numbers
+  DevBuf<double> wide_scratch;
   bool asm_staged = false;           // k_assemble_tets_st (records staged in LDS, mass entries precomputed) instead of k_assemble_tets
   int asm_lds_st = 0, asm_grid_st = 0;
   bool mass_valid = false;           // h->mblk holds the mass entries of the current rest data (k_mass_blocks)
@@ -732,12 +735,22 @@ int upload_plan(fb_fem_s* h, const double* xyz_global, const float* xyz_device =
     // FEMBRAIN_ASM_KERNEL=rows keeps the slot-major kernel (same result bit for bit, tests/test_fem_gpu.py)
     // (the widest slice the element-major kernels take, and how many are wider: those few go to the slot-major kernel -- one hub node
     // used to send the whole mesh there)
-    int mw = 0, n_wide = 0;
+    int mw = 0, n_wide = 0, widest = 0;
+    std::vector<int> wide;
     for (int sl = 0; sl < P.n_slices; sl++) {
       const int wsl = P.slice_off[sl + 1] - P.slice_off[sl];
-      if (wsl > kIncMaxWidth) n_wide++; else mw = std::max(mw, wsl);
+      if (wsl > kIncMaxWidth) { n_wide++; widest = std::max(widest, wsl); wide.push_back(sl); } else mw = std::max(mw, wsl);
     }
     h->asm_wide = n_wide;
+    h->asm_wide_slots = widest;
+    h->asm_wide_grid = 0;
+    if (n_wide > 0) {  // k_assemble_wide: one workgroup per wide slice while their scratch areas stay under 64 MB, fewer (each taking several) beyond
+      const size_t area = (size_t)widest * kWideTerms * 64;  // doubles
+      h->asm_wide_grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_wide, ((size_t)64 << 20) / (area * sizeof(double))));
+      if (const char* wg = getenv("FEMBRAIN_ASM_WIDE_GRID")) h->asm_wide_grid = std::max(1, std::min(h->asm_wide_grid, atoi(wg)));  // (tests: several slices per workgroup)
+      FB_TRY(h->wide_list.upload(wide, s));
+      FB_TRY(h->wide_scratch.alloc(area * (size_t)h->asm_wide_grid));
+    }
     hipDeviceProp_t prop;
     FB_HIP(hipGetDeviceProperties(&prop, h->prm.device));
     const int lds_cu = (int)std::min<size_t>(std::max<size_t>(prop.maxSharedMemoryPerMultiProcessor, prop.sharedMemPerBlock), 160 * 1024);  // gfx950: 160 KB per CU
@@ -899,12 +912,12 @@ int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const doub
       if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->side = nullptr; }
       for (auto& e : h->ev_side) if (h->side && !e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); }
     }
-    wide_beside = h->side && h->ev_side[0] && h->ev_side[1];
+    wide_beside = h->side && h->ev_side[0] && h->ev_side[1] && !getenv("FEMBRAIN_ASM_WIDE_ROWS");
     if (wide_beside) {
       FB_HIP(hipEventRecord(h->ev_side[0], h->stream));  // (the records and element forces of this assembly are complete)
       FB_HIP(hipStreamWaitEvent(h->side, h->ev_side[0], 0));
-      hipLaunchKernelGGL(k_assemble_rows<MT>, dim3(h->grid), dim3(kBlock), 0, h->side, sell_view(h), h->slot_coff.p, h->slot_ccnt.p,
-                         h->contrib.p, (const MT*)h->rec.p, h->fe.p, o, ap, (const MT*)h->kcorr.p, h->asm_max_width);
+      hipLaunchKernelGGL(k_assemble_wide<MT>, dim3(h->asm_wide_grid), dim3(kWideBlock), 0, h->side, sell_view(h), h->wide_list.p, h->asm_wide, h->asm_wide_slots,
+                         h->wide_scratch.p, h->slot_coff.p, h->slot_ccnt.p, h->contrib.p, (const MT*)h->rec.p, h->fe.p, o, ap, (const MT*)h->kcorr.p);
       FB_HIP(hipGetLastError());
       FB_HIP(hipEventRecord(h->ev_side[1], h->side));
     }
@@ -967,8 +980,12 @@ int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const doub
   } else if (wide_pass) {
     AsmOut<MT> ow = o;
     ow.mblk_in = nullptr;
-    hipLaunchKernelGGL(k_assemble_rows<MT>, dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), h->slot_coff.p, h->slot_ccnt.p,
-                       h->contrib.p, (const MT*)h->rec.p, h->fe.p, ow, ap, (const MT*)h->kcorr.p, h->asm_max_width);
+    if (getenv("FEMBRAIN_ASM_WIDE_ROWS"))  // development aid: the one-wavefront-per-slice form (same bits)
+      hipLaunchKernelGGL(k_assemble_rows<MT>, dim3(h->grid), dim3(kBlock), 0, h->stream, sell_view(h), h->slot_coff.p, h->slot_ccnt.p,
+                         h->contrib.p, (const MT*)h->rec.p, h->fe.p, ow, ap, (const MT*)h->kcorr.p, h->asm_max_width);
+    else
+      hipLaunchKernelGGL(k_assemble_wide<MT>, dim3(h->asm_wide_grid), dim3(kWideBlock), 0, h->stream, sell_view(h), h->wide_list.p, h->asm_wide, h->asm_wide_slots,
+                         h->wide_scratch.p, h->slot_coff.p, h->slot_ccnt.p, h->contrib.p, (const MT*)h->rec.p, h->fe.p, ow, ap, (const MT*)h->kcorr.p);
   }
   FB_HIP(hipGetLastError());
   return FB_OK;

@@ -557,6 +557,136 @@ __global__ __launch_bounds__(kBlock) void k_assemble_rows(SellView sv, const int
   }
 }
 
+// The slices too wide for the element-major kernels (hub nodes; hull nodes of a Delaunay mesh with 40-60 neighbours), one WORKGROUP per
+// slice.  k_assemble_rows gives such a slice to one wavefront, which walks its slots one latency-bound contribution list after the other
+// (0.8 ms for a 59-slot slice: the whole assembly of the 606k-tet probe waited for it).  Here the slots are dealt to the workgroup's
+// wavefronts: each sums the blocks of its slots (the same operations in the same order as k_assemble_rows), forms what the a7 algebra
+// needs of them -- the block's terms of t, the stored values u, the mass entry; element forces and contribution count where the column is
+// the row -- and leaves it in a scratch area of HBM ([slot][kWideTerms][64] doubles per workgroup, read back from L2); then wavefront 0
+// runs the order-dependent part (the running sums over the slots, the diagonal block) over the finished terms: no gather left in it.
+// Sums and their order are k_assemble_rows': same bits (tests/test_fem_gpu.py).
+constexpr int kWideTerms = 20;   // per slot and lane: t terms 0..2, qacc terms 3..5, u 6..14, m 15, contribution count 16, element forces 17..19
+constexpr int kWideBlock = 512;
+template <typename MT>
+__global__ __launch_bounds__(kWideBlock) void k_assemble_wide(SellView sv, const int* __restrict__ wide_list, int n_wide, int max_slots, double* __restrict__ scratch,
+                                                              const int* __restrict__ slot_coff, const int* __restrict__ slot_ccnt,
+                                                              const uint32_t* __restrict__ contrib, const MT* __restrict__ rec, const double* __restrict__ fe,
+                                                              AsmOut<MT> o, AsmParams ap, const MT* __restrict__ kcorr) {
+  __shared__ int next_slot;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* sc = scratch + (size_t)blockIdx.x * max_slots * kWideTerms * 64 + lane;
+  for (int wi = blockIdx.x; wi < n_wide; wi += gridDim.x) {
+    const int s = wide_list[wi];
+    const int row = s * 64 + lane;
+    const bool rvalid = row < sv.n_owned;
+    const int so = sv.slice_off[s], width = min(sv.slice_off[s + 1] - so, max_slots);
+    uint8_t ma[3] = {1, 1, 1};
+    if (rvalid && ap.apply_mask) { ma[0] = o.dofmask[3 * (size_t)row]; ma[1] = o.dofmask[3 * (size_t)row + 1]; ma[2] = o.dofmask[3 * (size_t)row + 2]; }
+    if (threadIdx.x == 0) next_slot = 0;
+    __syncthreads();
+    // the slots go to whichever wavefront is free (which one sums a block does not touch its bits): the slot of the diagonal blocks has
+    // ten times the contributions of the others
+    for (;;) {
+      int k = 0;
+      if (lane == 0) k = atomicAdd(&next_slot, 1);
+      k = __builtin_amdgcn_readfirstlane(k);
+      if (k >= width) break;
+      const int slot = so + k;
+      const int col = sv.colidx[(size_t)slot * 64 + lane];
+      const int colp = k > 0 ? sv.colidx[(size_t)(slot - 1) * 64 + lane] : -1;
+      const int coff = slot_coff[slot], ccnt = slot_ccnt[slot];
+      // a slot whose column is the row: the diagonal block if the slot before it has another column, else padding after the row's last
+      // block (the rule of RowAlgebra::is_diag: padding repeats the row id behind the blocks, whose columns are distinct)
+      const bool diag = rvalid && col == row && colp != row;
+      double K[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      double m = 0.0, fi[3] = {0.0, 0.0, 0.0};
+      int nc = 0;
+      typedef MT mt4 __attribute__((ext_vector_type(4)));
+      constexpr int kG = 8;  // (k_assemble_rows: 4; one wavefront in eight is on the long list here, and it alone sets the time)
+      for (int t0 = 0; t0 < ccnt; t0 += kG) {
+        uint32_t cw[kG];
+#pragma unroll
+        for (int u = 0; u < kG; u++) cw[u] = (t0 + u < ccnt) ? contrib[((size_t)coff + t0 + u) * 64 + lane] : 0xFFFFFFFFu;
+        mt4 rI[kG], rJ[kG];
+#pragma unroll
+        for (int u = 0; u < kG; u++) {
+          const uint32_t c = cw[u] == 0xFFFFFFFFu ? 0u : cw[u];
+          const mt4* r = (const mt4*)(rec + 16 * (size_t)(c >> 4));
+          rI[u] = r[(c >> 2) & 3];
+          rJ[u] = r[c & 3];
+        }
+#pragma unroll
+        for (int u = 0; u < kG; u++) {
+          const uint32_t c = cw[u];
+          if (c == 0xFFFFFFFFu) continue;
+          nc++;
+          const uint32_t e = c >> 4;
+          const int i = (c >> 2) & 3, j = c & 3;
+          const mt4 ri = rI[u], rj = rJ[u];
+          const double ci[3] = {(double)ri.x, (double)ri.y, (double)ri.z};
+          const double cj[3] = {(double)rj.x, (double)rj.y, (double)rj.z};
+          add_contribution<MT>(K, m, ci, cj, (double)ri.w, i, j, e, ap, kcorr);
+          if (diag) {
+            const double* f = fe + 12 * (size_t)e + 3 * i;
+            fi[0] += f[0]; fi[1] += f[1]; fi[2] += f[2];
+          }
+        }
+      }
+      RowGather g;
+      g.load(o, ap, col);
+      double* t = sc + (size_t)k * kWideTerms * 64;
+      MT* out = o.vals + (size_t)slot * 9 * 64 + lane;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        t[a * 64] = ap.g_k * (K[3 * a] * g.qv[0] + K[3 * a + 1] * g.qv[1] + K[3 * a + 2] * g.qv[2]) + ap.g_m * m * g.qv[a];
+        t[(3 + a) * 64] = ap.g_a * m * g.qa[a];
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          const MT u = (MT)(ap.s_k * K[3 * a + b] + (a == b ? ap.s_m * m : 0.0));
+          t[(6 + 3 * a + b) * 64] = (double)u;
+          if (!diag) out[(3 * a + b) * 64] = (ma[a] && g.mb[b]) ? u : (MT)0;
+        }
+        t[(17 + a) * 64] = fi[a];
+      }
+      t[15 * 64] = m;
+      t[16 * 64] = (double)nc;
+    }
+    __syncthreads();  // (the terms of every slot are written: block-wide barrier = release + acquire at workgroup scope, and a workgroup is on one CU)
+    if (wave == 0) {
+      RowAlgebra<MT> ra;
+      ra.begin(o, ap, row, rvalid);
+      int kdiag = -1;
+#pragma unroll 4
+      for (int k = 0; k < width; k++) {  // no gather and no branch around a load: the terms of several slots are in flight together
+        const int col = sv.colidx[(size_t)(so + k) * 64 + lane];
+        const double* t = sc + (size_t)k * kWideTerms * 64;
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = t[q * 64];
+        const bool diag = ra.is_diag(row, col, rvalid);
+#pragma unroll
+        for (int a = 0; a < 3; a++) ra.ta[a] += v[a];
+        if (o.qacc) {
+#pragma unroll
+          for (int a = 0; a < 3; a++) ra.ta[a] += v[3 + a];
+        }
+        ra.msum += v[15];
+        kdiag = diag ? k : kdiag;
+#pragma unroll
+        for (int q = 0; q < 9; q++) ra.off[q] = diag ? ra.off[q] : ra.off[q] + v[6 + q];
+      }
+      if (kdiag >= 0) {
+        const double* t = sc + (size_t)kdiag * kWideTerms * 64;
+        ra.kd = so + kdiag; ra.nd = (int)t[16 * 64];
+#pragma unroll
+        for (int a = 0; a < 3; a++) ra.fi[a] = t[(17 + a) * 64];
+      }
+      ra.finish(o, ap, s, lane, row, rvalid);
+    }
+    __syncthreads();  // (the scratch area and the slot counter are the next slice's)
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Element-major assembly.  k_assemble_rows walks a row slot by slot, so the 16 contributions of an element reach for its 64-B
 // record at 16 different times and every one of them misses L2 (an XCD's records are 8 MB at 1M tets).  Here a row's ELEMENTS

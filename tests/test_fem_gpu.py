@@ -935,18 +935,31 @@ def _jittered_lattice():
     return pts, t, fixed_vertices_to_dofs(np.nonzero(g[:, 0] == 0)[0])
 
 
-@pytest.mark.parametrize("case", ["cube14", "cube14_f64", "cube14_tangent", "cube14_newmark", "cube14_block_jacobi", "beam3", "jitter", "jitter_f64", "hub"])
+@pytest.mark.parametrize("case", ["cube14", "cube14_f64", "cube14_tangent", "cube14_newmark", "cube14_block_jacobi", "beam3", "jitter", "jitter_f64", "hub",
+                                  "hub_f64", "hub_tangent", "hub_newmark", "hub_block_jacobi", "hub_delaunay", "hub_delaunay_three_workgroups"])
 def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, monkeypatch, case):
     """k_assemble_tets_st / k_assemble_tets (lane walks its row's elements, blocks accumulated in LDS) against k_assemble_rows (FEMBRAIN_ASM_KERNEL=rows):
     raw f and K at a seeded displacement, Keff and rhs of a step, the states after two steps -- all bit for bit, for both matrix
     widths, the exact tangent, the Newmark step and the block-Jacobi inverse blocks; a mesh with a row wider than 32 slots keeps the
-    slot-major kernel by itself"""
+    slot-major kernel by itself.  hub*: the slices wider than 31 slots go through k_assemble_wide (a workgroup per slice, slots dealt to its
+    wavefronts, the running sums by one of them) -- the same bits again, also when one workgroup takes all of them in turn"""
     kw = {}
+    hub = case.startswith("hub")
+    if case == "hub_delaunay_three_workgroups":
+        monkeypatch.setenv("FEMBRAIN_ASM_WIDE_GRID", "3")
     if case == "beam3":
         g0 = np.load(os.path.join(GOLD, "fem_beam3.npz"))
         v, t, fixed = g0["verts"], g0["tets"], fixed_vertices_to_dofs(g0["fixed_vertices"])
-    elif case == "hub":
-        v, t, fixed = _wide_mesh()
+    elif hub:
+        v, t, fixed = _delaunay_lattice(12) if "delaunay" in case else _wide_mesh()       # (delaunay: dozens of hull slices of 32..60 slots)
+        if case.endswith("f64"):
+            kw["matrix_precision"] = fl.FB_MATRIX_F64
+        if case.endswith("tangent"):
+            kw["exact_tangent"] = True
+        if case.endswith("newmark"):
+            kw["integrator"] = fl.FB_INTEGRATOR_NEWMARK
+        if case.endswith("block_jacobi"):
+            kw["pcg_variant"] = fl.FB_PCG_BLOCK_JACOBI
     elif case.startswith("jitter"):
         v, t, fixed = _jittered_lattice()
         if case.endswith("f64"):
@@ -972,13 +985,13 @@ def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, mo
         g = FemIntegrator(v, t, fixed, **kw)
         # (a hub node makes ONE slice too wide for the element-major kernel: that slice alone goes through the slot-major kernel, round 5)
         assert fl.lib().fb_fem_assembly_kernel(g.h) == (0 if kern == "rows" else (2 if kern == "tets" and staged else 1))
-        assert (fl.lib().fb_fem_assembly_wide_slices(g.h) > 0) == (case == "hub" and kern != "rows")
+        assert (fl.lib().fb_fem_assembly_wide_slices(g.h) > 0) == (hub and kern != "rows")
         f, K = g.assemble(u)
         its = []
         for k in range(2):
             if k:
                 g.rebuild_elements()     # (the rest data again: the mass entries are formed again with it)
-            g.set_uniform_force(1, -2000.0 if case not in ("hub", "jitter", "jitter_f64") else -1.0)
+            g.set_uniform_force(1, -2000.0 if not hub and case not in ("jitter", "jitter_f64") else -1.0)
             its.append(g.do_timestep())
         Keff, rhs = g.system()
         out.append((f, K, its, Keff, rhs, g.get_q_state()[0], g.mass()))
