@@ -576,55 +576,91 @@ int setup_persist(fb_fem_s* h) {
     const double mean = P.n_slices ? (double)tot / P.n_slices : 0.0;
     const char* eh = getenv("FEMBRAIN_PIPE_HELPERS");
     const bool want_h = eh ? atoi(eh) != 0 : (mx > 24 && (double)mx >= 1.5 * mean);
-    if (want_h && w + 2 <= kPipeMaxWaves) {
-      const int help_waves = kPipeMaxWaves - w - 1;   // (the 12-wavefront kernel: slices, helpers, the service wavefront)
+    if (want_h && w <= kPipeMaxWaves) {
+      const int help_waves = std::max(0, kPipeMaxWaves - w - 1);   // (the 12-wavefront kernel: slices, helpers, the service wavefront)
       std::vector<int4> tasks((size_t)nb * kPipeTaskStride, make_int4(-1, 0, 0, 0));
-      int most = 0, all = 0;
+      int most = 0, all = 0, deepest = 0;
+      const int min_len = getenv("FEMBRAIN_PIPE_HELP_MINLEN") ? atoi(getenv("FEMBRAIN_PIPE_HELP_MINLEN")) : 16;  // (development)
+      // FEMBRAIN_PIPE_LDS_BY_WIDTH=1 (measured and NOT the default): the workgroup's LDS dealt to its slices by width instead of in equal
+      // shares, so that every wavefront streams about the same number of slots (the 27-slot slices of a cut among slices of 15 would keep 17
+      // here instead of 5).  It is slower -- cut cube 21.9 against 20.1 us per iteration, Delaunay probe 22.0 against 18.6: a resident slot
+      // still gathers its x entries from L2 / the fabric, and the compiled loop over resident slots has 6 slots' gathers in flight where
+      // the hand-written stream never drains; on these meshes the product waits for gathers, not for matrix bytes.
+      const bool even_share = !(getenv("FEMBRAIN_PIPE_LDS_BY_WIDTH") && atoi(getenv("FEMBRAIN_PIPE_LDS_BY_WIDTH")) != 0);
       for (int b = 0; b < nb; b++) {
         int first, count;
         pipe_deal(h->pipe_wg_first_host.empty() ? nullptr : h->pipe_wg_first_host.data(), P.n_slices, nb, b, &first, &count);
         int4* tk = &tasks[(size_t)b * kPipeTaskStride];
-        // streams: (wavefront, slice, k0, k1); the LDS-resident slots are the owner's, so a stream is split above them
-        const int lds_slots = kPipeLdsSlots - kPipeHelpSlots;
-        const int lbase = std::min(6, lds_slots / std::max(count, 1)), lrem = lbase < 6 ? std::min(count, lds_slots - lbase * count) : 0;
+        std::vector<int> wd(count), res(count);
+        for (int j = 0; j < count; j++) wd[j] = P.slice_off[first + j + 1] - P.slice_off[first + j];
+        // LDS-resident slots: equal shares (the plain kernel's deal), or by width: the lowest level L with sum_j max(0, wd_j - L) <= the
+        // workgroup's wavefront-slots -- every slice then streams min(wd, L) slots -- and what is left over one more for the first slices that
+        // still stream.  First with the helpers' hand-over area set aside; a workgroup that gets no helper is dealt again with all of it.
+        auto deal_lds = [&](int lds_slots) {
+          if (even_share) {
+            const int lbase = std::min(6, lds_slots / std::max(count, 1)), lrem = lbase < 6 ? std::min(count, lds_slots - lbase * count) : 0;
+            for (int j = 0; j < count; j++) res[j] = std::min(wd[j], lbase + (j < lrem ? 1 : 0));
+            return;
+          }
+          int L = 0, widest = 0;
+          for (int j = 0; j < count; j++) widest = std::max(widest, wd[j]);
+          for (L = 0; L <= widest; L++) {
+            int sum = 0;
+            for (int j = 0; j < count; j++) sum += std::max(0, wd[j] - L);
+            if (sum <= lds_slots) break;
+          }
+          int used = 0;
+          for (int j = 0; j < count; j++) { res[j] = std::max(0, wd[j] - L); used += res[j]; }
+          for (int j = 0; j < count && used < lds_slots; j++) if (res[j] < wd[j]) { res[j]++; used++; }
+        };
         struct Stream { int wave, slice, k0, k1, floor; };
         std::vector<Stream> st;
-        for (int j = 0; j < count; j++) {
-          const int wd = P.slice_off[first + j + 1] - P.slice_off[first + j];
-          st.push_back({j, j, 0, wd, lbase + (j < lrem ? 1 : 0)});
-          tk[j] = make_int4(j, 0, wd, 0);
-        }
         int n_h = 0;
-        for (int hw = count; hw < w + help_waves && n_h < kPipeMaxHelpers; hw++) {  // idle slice wavefronts first, then the extra ones
-          int best = -1, len = 0;
-          for (int i = 0; i < (int)st.size(); i++) {
-            const int l = st[i].k1 - std::max(st[i].k0, st[i].floor);  // what it streams
-            if (l > len) { len = l; best = i; }
+        auto deal_streams = [&]() {
+          st.clear();
+          n_h = 0;
+          for (int j = 0; j < kPipeTaskStride; j++) tk[j] = make_int4(-1, 0, 0, 0);
+          for (int j = 0; j < count; j++) st.push_back({j, j, 0, wd[j], res[j]});
+          std::vector<unsigned> mask(count, 0u);
+          for (int hw = count; hw < w + help_waves && n_h < kPipeMaxHelpers; hw++) {  // idle slice wavefronts first, then the extra ones
+            int best = -1, len = 0;
+            for (int i = 0; i < (int)st.size(); i++) {
+              const int l = st[i].k1 - std::max(st[i].k0, st[i].floor);  // what it streams
+              if (l > len) { len = l; best = i; }
+            }
+            if (best < 0 || len < min_len) break;
+            const int lo = std::max(st[best].k0, st[best].floor), mid = lo + (st[best].k1 - lo + 1) / 2;
+            const Stream up = {hw, st[best].slice, mid, st[best].k1, mid};
+            st[best].k1 = mid;
+            st.push_back(up);
+            tk[hw] = make_int4(up.slice, up.k0, up.k1, n_h);
+            mask[up.slice] |= 1u << n_h;  // the owner adds this helper's partial sums
+            n_h++;
           }
-          const int min_len = getenv("FEMBRAIN_PIPE_HELP_MINLEN") ? atoi(getenv("FEMBRAIN_PIPE_HELP_MINLEN")) : 16;  // (development)
-          if (best < 0 || len < min_len) break;
-          const int lo = std::max(st[best].k0, st[best].floor), mid = lo + (st[best].k1 - lo + 1) / 2;
-          const Stream up = {hw, st[best].slice, mid, st[best].k1, mid};
-          st[best].k1 = mid;
-          st.push_back(up);
-          tk[hw] = make_int4(up.slice, up.k0, up.k1, n_h);
-          tk[up.slice].w |= 1 << n_h;  // the owner adds this helper's partial sums
-          n_h++;
-        }
-        for (const Stream& S : st) { tk[S.wave].y = S.k0; tk[S.wave].z = S.k1; }  // (ends moved by later splits)
+          for (const Stream& S : st) {
+            if (S.wave < count) tk[S.wave] = make_int4(res[S.wave], 0, S.k1, (int)mask[S.wave]);  // owner: resident slots, (their place: below), end of its own stream, its helpers
+            else { tk[S.wave].y = S.k0; tk[S.wave].z = S.k1; }                                   // (ends moved by later splits)
+          }
+          int at = 0;
+          for (int j = 0; j < count; j++) { tk[j].y = at; at += res[j]; }
+        };
+        deal_lds(kPipeLdsSlots - kPipeHelpSlots);
+        deal_streams();
+        if (n_h == 0) { deal_lds(kPipeLdsSlots); deal_streams(); }
+        for (int j = 0; j < count; j++) deepest = std::max(deepest, res[j]);
         if (const char* dbg = getenv("FEMBRAIN_PIPE_HELP_DEBUG")) {  // development: 1 = owners keep their whole slice, helpers get empty ranges (their zero sums are still added); 2 = owners keep it all and add nothing, helpers work for nothing
-          for (int j = 0; j < count; j++) { tk[j].z = P.slice_off[first + j + 1] - P.slice_off[first + j]; if (atoi(dbg) == 2) tk[j].w = 0; }
+          for (int j = 0; j < count; j++) { tk[j].z = wd[j]; if (atoi(dbg) == 2) tk[j].w = 0; }
           if (atoi(dbg) == 1) for (int hw = count; hw < kPipeTaskStride; hw++) if (tk[hw].x >= 0) tk[hw].y = tk[hw].z;
         }
         most = std::max(most, n_h);
         all += n_h;
       }
-      if (all > 0 || (eh && atoi(eh) == 2)) {  // (=2, development: the task table without a single helper)
+      if (all > 0 || deepest > 6 || (eh && atoi(eh) == 2)) {  // (=2, development: the task table without a single helper)
         FB_TRY(h->pipe_tasks.upload(tasks, s));
         h->pipe_wmax = 12;
-        h->pipe_klt = std::min(6, (kPipeLdsSlots - kPipeHelpSlots) / std::max(w, 1));
+        h->pipe_klt = deepest;
         h->pipe_help_waves = help_waves; h->pipe_n_help = most; h->pipe_help_tasks = all;
-        if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] persistent solver: %d helper tasks (at most %d per workgroup), widest slice %d slots, mean %.1f\n", all, most, mx, mean);
+        if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] persistent solver: %d helper tasks (at most %d per workgroup), widest slice %d slots, mean %.1f, up to %d slots of a slice in LDS\n", all, most, mx, mean, deepest);
       }
     }
   }

@@ -65,9 +65,11 @@ struct PipeArgs {
   // Helpers (round 5): on a mesh with a few very wide slices (hull nodes of a Delaunay mesh: 59 slots against 19 on average) the product
   // of an iteration is as slow as the widest slice of the slowest workgroup -- one wavefront streams a slice's slots one after the other
   // (18 us against 7.5 on average on the 606k-tet probe, profiles/r05_delaunay_phase_table.txt).  Wavefronts without a slice of their own
-  // then take the upper part of a wide slice's slots: tasks[b][wv] = (slice of the workgroup, first slot, end slot, x) -- x = for the
-  // wavefront that OWNS the slice the bit mask of the helpers whose partial sums it adds (ascending: a fixed order), for a helper its
-  // number in the workgroup (its place in the LDS hand-over), slice -1 = no task.  nullptr: no helpers anywhere (every other mesh).
+  // then take the upper part of a wide slice's slots.  tasks[b][wv] of a HELPER = (slice of the workgroup, first slot, end slot, its number
+  // in the workgroup = its place in the LDS hand-over), slice -1 = no task; of the wavefront that OWNS a slice = (slots of the slice resident
+  // in LDS, where in LDS (in wavefront-slots), end of what it streams itself, bit mask of the helpers whose partial sums it adds -- ascending:
+  // a fixed order).  The resident slots of a workgroup are dealt by WIDTH (fem.hip, setup_persist): the slices stream equal numbers of slots
+  // as far as the LDS goes, where the plain kernel gives every slice the same share.  nullptr: the plain kernel (every regular mesh).
   const int* wg_first;        // the deal of the slices to the workgroups balanced by slots (pipe_deal), or nullptr: equal numbers of slices
   const int4* tasks;          // [n_blocks][kPipeTaskStride]
   int n_help;                 // most helpers of any workgroup (0: none; LDS for their partial sums is set aside when > 0)
@@ -298,11 +300,20 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     if constexpr (SHARD) { send_beg = sa.row_send_off[row]; send_end = sa.row_send_off[row + 1]; }
   }
   // LDS-resident part of the matrix: the first KL slots of this wave's slice, [klt_w][10][64] words (9 values + the column id)
-  const int lds_slots = kPipeLdsSlots - (HELP ? kPipeHelpSlots : 0);
-  const int lbase = min(KLT, lds_slots / max(count, 1)), lrem = lbase < KLT ? min(count, lds_slots - lbase * count) : 0;  // workgroup-uniform
-  const int klt_w = __builtin_amdgcn_readfirstlane(live ? lbase + (wv < lrem ? 1 : 0) : 0);
+  // (HELP: how many and where is the plan's decision, PipeArgs::tasks -- a slice of 27 slots among slices of 15 keeps 17 of them here, so
+  // that every wavefront of the workgroup streams about the same number: an iteration ends with the slowest wavefront)
+  int klt_w, lres_at;
+  if constexpr (HELP) {
+    const int4 tk = pa.tasks[(size_t)blockIdx.x * kPipeTaskStride + wv];
+    klt_w = __builtin_amdgcn_readfirstlane(live ? tk.x : 0);
+    lres_at = __builtin_amdgcn_readfirstlane(live ? tk.y : 0);
+  } else {
+    const int lbase = min(KLT, kPipeLdsSlots / max(count, 1)), lrem = lbase < KLT ? min(count, kPipeLdsSlots - lbase * count) : 0;  // workgroup-uniform
+    klt_w = __builtin_amdgcn_readfirstlane(live ? lbase + (wv < lrem ? 1 : 0) : 0);
+    lres_at = wv * lbase + min(wv, lrem);
+  }
   const int KL = min(klt_w, width);
-  unsigned int* lres = (unsigned int*)(lds + kPipeSyncDoubles) + (size_t)(wv * lbase + min(wv, lrem)) * 10 * 64 + lane;
+  unsigned int* lres = (unsigned int*)(lds + kPipeSyncDoubles) + (size_t)lres_at * 10 * 64 + lane;
   if (sizeof(MT) == 4) {
     for (int k = 0; k < KL; k++) {
       const MT* vk = v + (size_t)k * 9 * 64;
@@ -485,6 +496,25 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
           y0 += (double)__uint_as_float(lk[0 * 64]) * x0 + (double)__uint_as_float(lk[1 * 64]) * x1 + (double)__uint_as_float(lk[2 * 64]) * x2;
           y1 += (double)__uint_as_float(lk[3 * 64]) * x0 + (double)__uint_as_float(lk[4 * 64]) * x1 + (double)__uint_as_float(lk[5 * 64]) * x2;
           y2 += (double)__uint_as_float(lk[6 * 64]) * x0 + (double)__uint_as_float(lk[7 * 64]) * x1 + (double)__uint_as_float(lk[8 * 64]) * x2;
+        }
+        if constexpr (HELP) {  // (a wide slice's share may be longer than the unroll bound: further groups of KLT, the gathers of a group in flight together)
+          for (int kb = KLT; kb < KL; kb += KLT) {
+            double gx[KLT][3];
+#pragma unroll
+            for (int j = 0; j < KLT; j++) {
+              const int k = min(kb + j, KL - 1);  // (past the end: the last slot again, not used)
+              const double* xp = pl + (size_t)lres[((size_t)k * 10 + 9) * 64];
+              gx[j][0] = xp[0]; gx[j][1] = xp[pa.n_pad]; gx[j][2] = xp[2 * pa.n_pad];
+            }
+#pragma unroll
+            for (int j = 0; j < KLT; j++) if (kb + j < KL) {
+              const unsigned int* lk = lres + (size_t)(kb + j) * 10 * 64;
+              const double x0 = gx[j][0], x1 = gx[j][1], x2 = gx[j][2];
+              y0 += (double)__uint_as_float(lk[0 * 64]) * x0 + (double)__uint_as_float(lk[1 * 64]) * x1 + (double)__uint_as_float(lk[2 * 64]) * x2;
+              y1 += (double)__uint_as_float(lk[3 * 64]) * x0 + (double)__uint_as_float(lk[4 * 64]) * x1 + (double)__uint_as_float(lk[5 * 64]) * x2;
+              y2 += (double)__uint_as_float(lk[6 * 64]) * x0 + (double)__uint_as_float(lk[7 * 64]) * x1 + (double)__uint_as_float(lk[8 * 64]) * x2;
+            }
+          }
         }
       }
       // the streamed slots: hand-pipelined loads (pcg_pipe_stream.hip.h); those from own_k1 on are a helper's

@@ -103,6 +103,8 @@ def main():
         so = np.zeros(cnt, np.int32)
         g._L.fb_fem_device_plan_get(g.h, b"slice_off", fl.iptr(so), cnt)
         w = np.diff(so)
+        if os.environ.get("PROBE_DUMP"):
+            np.save(os.path.join(os.environ["PROBE_DUMP"], "widths_%s.npy" % row["case"][:1]), w)
         row["slice_widths"] = dict(slices=int(len(w)), max=int(w.max()), mean=float(w.mean()), wider_than_31=int((w > 31).sum()), p50=int(np.percentile(w, 50)), p99=int(np.percentile(w, 99)))
         t0 = time.time()
         for _ in range(5):
