@@ -652,6 +652,8 @@ int setup_persist(fb_fem_s* h) {
           for (int j = 0; j < count; j++) { tk[j].z = wd[j]; if (atoi(dbg) == 2) tk[j].w = 0; }
           if (atoi(dbg) == 1) for (int hw = count; hw < kPipeTaskStride; hw++) if (tk[hw].x >= 0) tk[hw].y = tk[hw].z;
         }
+        if (const char* tr = getenv("FEMBRAIN_PIPE_TRUNCATE"))  // development, WRONG RESULTS: owners stop n slots short of their slice -- what an iteration would cost with that many fewer streamed slots per slice (half storage)
+          for (int j = 0; j < count; j++) tk[j].z = std::max(tk[j].x, tk[j].z - atoi(tr));
         most = std::max(most, n_h);
         all += n_h;
       }

@@ -1,7 +1,9 @@
 // k_pcg_pipe2: the persistent pipelined Jacobi-PCG of pcg_pipe.hip.h for 13..24 slices per CU (1.2M..2.2M tets on 256 CUs), where
 // the registers of a CU no longer hold the state of one wavefront per slice.  Same recurrences, same hand-offs, same arithmetic
 // per row; what differs:
-//   * a wavefront owns TWO slices (lane = two rows, `h` = 0 / 1): slices first + 2 wv and first + 2 wv + 1 of its workgroup;
+//   * a wavefront owns up to TWO slices (lane = two rows, `h` = 0 / 1): slices first + wv and first + wv + (slice wavefronts) of its
+//     workgroup -- a workgroup with 13 slices keeps twelve wavefronts busy, one of them with two slices (round 5; it used to give
+//     wavefront wv the slices 2 wv and 2 wv + 1: six and a half busy wavefronts, and two wide slices of a cut on one of them);
 //   * r, w, s and 1/diag of both rows stay in registers (48 per lane); x, p, z and the low part of the diagonal block live in
 //     LDS (24 words per row: 147 KB for 12 wavefronts) -- they are touched once per iteration, in the recurrences;
 //   * no slot of the matrix is LDS-resident (the LDS holds vectors instead): every slot is streamed by the assembly loop.
@@ -38,8 +40,9 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
   int row[2], so[2], width[2], send_beg[2], send_end[2];
 #pragma unroll
   for (int h = 0; h < 2; h++) {
-    live[h] = 2 * wv + h < count && !spare;  // wave-uniform
-    const int sl = first + 2 * wv + h;
+    const int jl = wv + h * (n_waves - (SHARD ? 1 : 0));  // (the slice wavefronts: all, or all but a shard's spare one)
+    live[h] = jl < count && !spare;  // wave-uniform
+    const int sl = first + jl;
     row[h] = sl * 64 + lane;
     rvalid[h] = live[h] && row[h] < sv.n_owned;
     int o = 0, wd = 0;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
   for (int h = 0; h < 2; h++) {
     float m6[6] = {0, 0, 0, 0, 0, 0};
     if (rvalid[h]) {
-      const float* l = dlo + (size_t)(first + 2 * wv + h) * 9 * 64 + lane;
+      const float* l = dlo + (size_t)(row[h] >> 6) * 9 * 64 + lane;
       m6[0] = l[0 * 64]; m6[1] = l[1 * 64]; m6[2] = l[2 * 64]; m6[3] = l[4 * 64]; m6[4] = l[5 * 64]; m6[5] = l[8 * 64];
 #pragma unroll
       for (int a = 0; a < 3; a++) iv[h][a] = invdiag[3 * (size_t)row[h] + a];
