@@ -38,8 +38,13 @@ constexpr int kPipeMaxWaves = 12;    // wavefronts (= slices) per workgroup
 constexpr int kPipeMaxBlocks = 256;  // workgroups = CUs
 constexpr int kPipeSyncDoubles = 2 * 16 + 2 * kPipeMaxBlocks + 8;  // LDS in front of the resident values: wave sums | gathered sums | broadcast
 constexpr int kPipeMaxProducers = 64;
-constexpr int kPipeLdsSlots = 60;     // wavefront-slots of 10 x 64 words that fit the CU's 160 KB beside the sync buffers
-static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)kPipeLdsSlots * 10 * 64 * 4 <= 160 * 1024, "LDS budget of k_pcg_pipe");
+// LDS-resident slots of the matrix: 9 values and the column per lane.  With 32-bit columns a wavefront-slot is 10 x 64 words = 2,560 B and 62 fit
+// the CU's 160 KB beside the sync buffers; with 16-bit column differences (C16) it is 9 x 64 words + 64 halfwords = 2,432 B and 65 fit (round 5;
+// rounds 3-4: 60 slots of 2,560 B either way -- a streamed slot of a slice costs 1.0 us per iteration at 1M tets).
+constexpr int pipe_slot_bytes(bool c16) { return c16 ? 9 * 256 + 128 : 10 * 256; }
+constexpr int pipe_lds_slots(bool c16) { return c16 ? 65 : 62; }
+static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)pipe_lds_slots(false) * pipe_slot_bytes(false) <= 160 * 1024, "LDS budget of k_pcg_pipe");
+static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)pipe_lds_slots(true) * pipe_slot_bytes(true) <= 160 * 1024, "LDS budget of k_pcg_pipe<c16>");
 
 struct PipeArgs {
   unsigned long long* post;   // [2][n_blocks][4] granules: (hi, lo) of gamma, delta, each | sequence << 32
@@ -76,7 +81,8 @@ struct PipeArgs {
 };
 constexpr int kPipeTaskStride = 16;
 constexpr int kPipeMaxHelpers = 8;   // per workgroup
-constexpr int kPipeHelpSlots = 5;    // LDS wavefront-slots set aside for their partial sums (8 x 3 x 64 doubles = 12 KB)
+constexpr int pipe_help_slots(bool c16) { return c16 ? 6 : 5; }  // LDS wavefront-slots set aside for their partial sums (8 x 3 x 64 doubles = 12,288 B, at the end of the slots)
+static_assert(pipe_help_slots(true) * pipe_slot_bytes(true) >= kPipeMaxHelpers * 3 * 64 * 8 && pipe_help_slots(false) * pipe_slot_bytes(false) >= kPipeMaxHelpers * 3 * 64 * 8, "helpers' hand-over area");
 
 __device__ __forceinline__ void st_sc1_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1_u32(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -238,9 +244,9 @@ namespace fb {
 // WMAX: wavefronts per workgroup the instantiation is bounded for (512 registers per lane and SIMD are shared by
 // ceil(WMAX / 4) wavefronts).  LDS-resident part of the matrix: the first slots of every slice (9 values + the column id per lane)
 // are loaded into LDS ONCE per launch -- the matrix does not change during a solve; slots beyond are streamed every product as in
-// k_spmv.  The CU's LDS holds kPipeLdsSlots = 60 wavefront-slots (2,560 B each) beside the sync buffers; a workgroup deals them
+// k_spmv.  The CU's LDS holds pipe_lds_slots() = 62 / 65 wavefront-slots beside the sync buffers; a workgroup deals them
 // to its `count` live wavefronts, count-th part each and the remainder one more for the first ones (11 slices: 5 slots each and a
-// sixth for five of them; 10 slices: 6 each), at most KLT per wavefront (the unroll bound of the LDS loop).
+// sixth for seven of them; 10 slices: 6 each), at most KLT per wavefront (the unroll bound of the LDS loop).
 // TIMING: the development build with per-phase clocks (FEMBRAIN_PERSIST_TIMING=1).
 // SHARD: the kernel of a sharded handle (pcg_shard_box.hip.h; "k_pcg_pipe_shard<WMAX,KLT>" in fb_fem_pcg_path): the slices come from the
 // plan's deal (sa.wg_range), the last wavefront is the spare one (sums, counters, proxy copies), rows a neighbour rank gathers are also
@@ -308,25 +314,35 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     klt_w = __builtin_amdgcn_readfirstlane(live ? tk.x : 0);
     lres_at = __builtin_amdgcn_readfirstlane(live ? tk.y : 0);
   } else {
-    const int lbase = min(KLT, kPipeLdsSlots / max(count, 1)), lrem = lbase < KLT ? min(count, kPipeLdsSlots - lbase * count) : 0;  // workgroup-uniform
+    constexpr int kSlots = pipe_lds_slots(C16);
+    const int lbase = min(KLT, kSlots / max(count, 1)), lrem = lbase < KLT ? min(count, kSlots - lbase * count) : 0;  // workgroup-uniform
     klt_w = __builtin_amdgcn_readfirstlane(live ? lbase + (wv < lrem ? 1 : 0) : 0);
     lres_at = wv * lbase + min(wv, lrem);
   }
   const int KL = min(klt_w, width);
-  unsigned int* lres = (unsigned int*)(lds + kPipeSyncDoubles) + (size_t)lres_at * 10 * 64 + lane;
+  // this wavefront's part: C16 [klt_w][9][64] value words, then [klt_w][64] column differences (halfwords); else [klt_w][10][64] words, the tenth the column
+  constexpr int kValWords = C16 ? 9 : 10;
+  char* lwave = (char*)(lds + kPipeSyncDoubles) + (size_t)lres_at * pipe_slot_bytes(C16);
+  unsigned int* lres = (unsigned int*)lwave + lane;
+  short* lcd = (short*)(lwave + (size_t)klt_w * 9 * 256) + lane;  // (C16)
+  auto lds_col = [&](int k) -> unsigned int {
+    if constexpr (C16) return (unsigned int)(row + (int)lcd[k * 64]);
+    else return lres[(k * 10 + 9) * 64];
+  };
   if (sizeof(MT) == 4) {
     for (int k = 0; k < KL; k++) {
       const MT* vk = v + (size_t)k * 9 * 64;
 #pragma unroll
-      for (int j = 0; j < 9; j++) lres[(k * 10 + j) * 64] = __float_as_uint((float)vk[j * 64]);
-      lres[(k * 10 + 9) * 64] = (unsigned int)(C16 ? row + (int)cd[(size_t)k * 64] : ci[(size_t)k * 64]);
+      for (int j = 0; j < 9; j++) lres[(k * kValWords + j) * 64] = __float_as_uint((float)vk[j * 64]);
+      if constexpr (C16) lcd[k * 64] = cd[(size_t)k * 64];
+      else lres[(k * 10 + 9) * 64] = (unsigned int)ci[(size_t)k * 64];
     }
   }
   // this wavefront's task (helpers, see PipeArgs): the owner of a slice streams its slots up to own_k1 and adds the partial sums of the
   // helpers in help_mask; a helper streams [hk0, hk1) of slice help_sl for the rows of that slice
   // (every value below is wave-uniform and made so explicitly, outside any branch: scalar registers.  Without HELP they are constants and the
   // kernel is the round-4 one.)
-  double* ypart = (double*)((unsigned int*)(lds + kPipeSyncDoubles) + (size_t)(kPipeLdsSlots - kPipeHelpSlots) * 10 * 64);  // [helper][3][64]
+  double* ypart = (double*)((char*)(lds + kPipeSyncDoubles) + (size_t)(pipe_lds_slots(C16) - pipe_help_slots(C16)) * pipe_slot_bytes(C16));  // [helper][3][64]
   int own_k1 = width, help_sl = -1, hk0 = 0, hk1 = 0, help_idx = 0, help_so = 0;
   unsigned int help_mask = 0u;
   if constexpr (HELP) {
@@ -475,13 +491,13 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
         double gx[KLT][3];
 #pragma unroll
         for (int k = 0; k < KLT; k++) {
-          const unsigned int col = k < KL ? lres[((size_t)k * 10 + 9) * 64] : 0u;
+          const unsigned int col = k < KL ? lds_col(k) : 0u;
           const double* xp = pl + (size_t)col;
           gx[k][0] = k < KL ? xp[0] : 0.0; gx[k][1] = k < KL ? xp[pa.n_pad] : 0.0; gx[k][2] = k < KL ? xp[2 * pa.n_pad] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < KLT; k++) if (k < KL) {
-          const unsigned int* lk = lres + (size_t)k * 10 * 64;
+          const unsigned int* lk = lres + (size_t)k * kValWords * 64;
           const double x0 = gx[k][0], x1 = gx[k][1], x2 = gx[k][2];
           y0 += (double)__uint_as_float(lk[0 * 64]) * x0 + (double)__uint_as_float(lk[1 * 64]) * x1 + (double)__uint_as_float(lk[2 * 64]) * x2;
           y1 += (double)__uint_as_float(lk[3 * 64]) * x0 + (double)__uint_as_float(lk[4 * 64]) * x1 + (double)__uint_as_float(lk[5 * 64]) * x2;
@@ -490,8 +506,8 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
       } else if (sizeof(MT) == 4) {
 #pragma unroll
         for (int k = 0; k < KLT; k++) if (k < KL) {  // LDS-resident slots
-          const unsigned int* lk = lres + (size_t)k * 10 * 64;
-          const double* xp = pl + (size_t)lk[9 * 64];
+          const unsigned int* lk = lres + (size_t)k * kValWords * 64;
+          const double* xp = pl + (size_t)lds_col(k);
           const double x0 = xp[0], x1 = xp[pa.n_pad], x2 = xp[2 * pa.n_pad];
           y0 += (double)__uint_as_float(lk[0 * 64]) * x0 + (double)__uint_as_float(lk[1 * 64]) * x1 + (double)__uint_as_float(lk[2 * 64]) * x2;
           y1 += (double)__uint_as_float(lk[3 * 64]) * x0 + (double)__uint_as_float(lk[4 * 64]) * x1 + (double)__uint_as_float(lk[5 * 64]) * x2;
@@ -503,12 +519,12 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
 #pragma unroll
             for (int j = 0; j < KLT; j++) {
               const int k = min(kb + j, KL - 1);  // (past the end: the last slot again, not used)
-              const double* xp = pl + (size_t)lres[((size_t)k * 10 + 9) * 64];
+              const double* xp = pl + (size_t)lds_col(k);
               gx[j][0] = xp[0]; gx[j][1] = xp[pa.n_pad]; gx[j][2] = xp[2 * pa.n_pad];
             }
 #pragma unroll
             for (int j = 0; j < KLT; j++) if (kb + j < KL) {
-              const unsigned int* lk = lres + (size_t)(kb + j) * 10 * 64;
+              const unsigned int* lk = lres + (size_t)(kb + j) * kValWords * 64;
               const double x0 = gx[j][0], x1 = gx[j][1], x2 = gx[j][2];
               y0 += (double)__uint_as_float(lk[0 * 64]) * x0 + (double)__uint_as_float(lk[1 * 64]) * x1 + (double)__uint_as_float(lk[2 * 64]) * x2;
               y1 += (double)__uint_as_float(lk[3 * 64]) * x0 + (double)__uint_as_float(lk[4 * 64]) * x1 + (double)__uint_as_float(lk[5 * 64]) * x2;
