@@ -68,6 +68,7 @@ struct fb_fem_s {
   int asm_wide = 0;                  // slices wider than the element-major kernel takes (kIncMaxWidth slots): k_assemble_wide assembles those
   int asm_wide_slots = 0, asm_wide_grid = 0;  // the widest of them; workgroups of k_assemble_wide (each with a scratch area of asm_wide_slots slots)
   DevBuf<int> wide_list;             // their slice numbers
+  DevBuf<double> res_all;            // Newmark, several Newton iterations: the residual of every DOF (AsmOut::res_all)
   DevBuf<double> wide_scratch;
   bool asm_staged = false;           // k_assemble_tets_st (records staged in LDS, mass entries precomputed) instead of k_assemble_tets
   int asm_lds_st = 0, asm_grid_st = 0;
@@ -938,6 +939,11 @@ int launch_rows(fb_fem_s* h, const AsmParams& ap, const double* qvel, const doub
   AsmOut<MT> o;
   o.dofmask = h->dofmask.p; o.nodemask = h->nodemask.p; o.qvel = qvel; o.fext = fext; o.qacc = qacc; o.vals = (MT*)h->vals.p; o.dlo = (MT*)h->dlo.p; o.mblk_out = mblk_out;
   o.fint_out = fint_out; o.rhs = rhs; o.invdiag = invdiag;
+  o.res_all = nullptr;
+  if (rhs && h->prm.integrator == FB_INTEGRATOR_NEWMARK && h->nm_max_newton > 1) {  // (kept between calls: alloc is a no-op while the size fits)
+    FB_TRY(h->res_all.alloc((size_t)3 * h->plan.n_local + 2));
+    o.res_all = h->res_all.p;
+  }
   o.invblk = invdiag && h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI ? h->invblk.p : nullptr;
   o.mblk_in = nullptr;
   // The few slices too wide for the element-major kernel (hub nodes, hull nodes of a Delaunay mesh): the slot-major kernel on those only,
@@ -2726,12 +2732,12 @@ int newmark_step(fb_fem_s* h, fb_step_info* info) {
   do {
     FB_HIP(hipEventRecord(h->ev[0], s));
     FB_TRY(assemble_system(h));
-    // Newton error test on the residual.  DEVIATION (parity unpinned): the sum runs over the FREE DOFs -- the rows of the
-    // clamped ones are identity rows here and their right-hand side is 0 -- where implicitNewmarkSparse.cpp:258-262 sums qresidual over
-    // all r DOFs before RemoveRows, reaction forces at the clamps included; with clamped nodes and max_newton > 1 the loop can
-    // therefore stop an iteration earlier than the reference's.  FemBrain runs one Newton iteration (Deformable.cpp:205-214).
+    // Newton error test on the residual, summed over ALL DOFs as implicitNewmarkSparse.cpp:258-262 does before RemoveRows -- the reaction
+    // forces at the clamped DOFs included: the assembly leaves the unmasked residual in res_all beside the right-hand side (whose clamped
+    // rows are 0, identity rows here).  (Rounds 2-4 summed the right-hand side, i.e. the free DOFs only, and could stop an iteration early.)
+    // FemBrain itself runs one Newton iteration (Deformable.cpp:205-214).
     if (h->nm_max_newton > 1) {
-      hipLaunchKernelGGL(k_sumsq, dim3(1), dim3(kBlock), 0, s, (size_t)n, h->rhs.p, h->scal.p + 4);
+      hipLaunchKernelGGL(k_sumsq, dim3(1), dim3(kBlock), 0, s, (size_t)n, h->res_all.p, h->scal.p + 4);
       FB_HIP(hipGetLastError());
       double err = 0.0;
       FB_HIP(hipMemcpyAsync(&err, h->scal.p + 4, sizeof err, hipMemcpyDeviceToHost, s));
@@ -2769,6 +2775,7 @@ int newmark_step(fb_fem_s* h, fb_step_info* info) {
     info->rho = fin.rho[fin.iter & 1];
     info->pcg_path = h->last_pcg_path;
     info->persist_fallbacks = h->persist_fallbacks;
+    info->newton_iterations = newton;
   }
   if (!ok) return fail(FB_ESOLVER, "PCG sparse solver returned non-zero exit status %d", -total);
   return FB_OK;
@@ -2818,6 +2825,7 @@ int fb_fem_step(fb_fem_t h, fb_step_info* info) {
     info->rho = fin.rho[fin.iter & 1];
     info->pcg_path = h->last_pcg_path;
     info->persist_fallbacks = h->persist_fallbacks;
+    info->newton_iterations = 1;
   }
   if (!ok) return fail(FB_ESOLVER, "PCG sparse solver returned non-zero exit status %d", iters);
   return FB_OK;

@@ -339,6 +339,7 @@ struct AsmOut {
   const double* mblk_in;  // k_assemble_tets_st: the per-block mass entries (k_mass_blocks), [slot][64]
   double* fint_out;
   double* rhs;
+  double* res_all;  // (Newmark with several Newton iterations) the residual of EVERY DOF, the reaction forces at the clamped ones included: what implicitNewmarkSparse.cpp:258-262 sums
   double* invdiag;
   double* invblk;
 };
@@ -460,6 +461,7 @@ struct RowAlgebra {
         const size_t d = 3 * (size_t)row + a;
         if (o.fint_out) o.fint_out[d] = fi[a];
         if (o.rhs) o.rhs[d] = ma[a] ? ap.rhs_scale * (ta[a] + fi[a] - o.fext[d]) : 0.0;
+        if (o.res_all) o.res_all[d] = ap.rhs_scale * (ta[a] + fi[a] - o.fext[d]);
         if (o.invdiag) o.invdiag[d] = 1.0 / dg[a];
       }
       if (o.invblk) {  // FB_PCG_BLOCK_JACOBI: the inverse of the row's 3x3 diagonal block (symmetric; identity on clamped DOFs)
@@ -999,6 +1001,7 @@ __device__ __forceinline__ void tets_algebra(double* acc, const double* facc, co
     const double fi = facc[A * 64 + lane];
     if (o.fint_out) o.fint_out[d] = fi;
     if (o.rhs) o.rhs[d] = ma[A] ? ap.rhs_scale * (ta + fi - o.fext[d]) : 0.0;
+    if (o.res_all) o.res_all[d] = ap.rhs_scale * (ta + fi - o.fext[d]);
     if (o.invdiag) o.invdiag[d] = 1.0 / dg;
   }
 }

@@ -45,7 +45,7 @@ class FemParams(C.Structure):
 class StepInfo(C.Structure):
     _fields_ = [("cg_iterations", C.c_int), ("converged", C.c_int), ("assembly_seconds", C.c_double),
                 ("solve_seconds", C.c_double), ("rho0", C.c_double), ("rho", C.c_double), ("pcg_path", C.c_int),
-                ("persist_fallbacks", C.c_int)]
+                ("persist_fallbacks", C.c_int), ("newton_iterations", C.c_int)]
 
 
 class PolyCounts(C.Structure):

@@ -236,6 +236,7 @@ typedef struct fb_step_info {
   double rho0, rho;       /* initial / final sum r^2 / diag */
   int pcg_path;           /* FB_PCG_PATH_*: which solver form ran the (last) solve of this step */
   int persist_fallbacks;  /* solves of this handle so far that a timed-out persistent launch handed to the two-launch form */
+  int newton_iterations;  /* FB_INTEGRATOR_NEWMARK: linear solves of this step (implicitNewmarkSparse.cpp:201-379, numIter); 1 otherwise */
 } fb_step_info;
 #define FB_PCG_PATH_TWO_LAUNCH 0  /* k_spmv + k_cg_fused per iteration (or the literal / block-Jacobi sequences) */
 #define FB_PCG_PATH_PERSISTENT 1  /* the persistent launch (FB_PCG_PERSISTENT) */
@@ -259,9 +260,9 @@ int fb_fem_set_internal_force_scaling(fb_fem_t h, double factor);
 int fb_fem_set_cg(fb_fem_t h, double eps, int max_iter);
 /* Newmark parameters (implicitNewmarkSparse.h: NewmarkBeta 0.25, NewmarkGamma 0.5; IntegratorBase: maxIterations 1, epsilon
  * 1e-6): the Newton loop stops when |residual|^2 / |first residual|^2 < epsilon^2 or after max_newton_iterations.  Each Newton
- * iteration is one assembly + one PCG solve that -- as in the reference -- starts from the previous solution.  Deviation: the error
- * quotient is taken over the free DOFs (the reference includes the reaction forces at the clamped ones, implicitNewmarkSparse.cpp:
- * 258-262), so with max_newton_iterations > 1 the loop may stop earlier; unsharded handles only for more than one iteration. */
+ * iteration is one assembly + one PCG solve that -- as in the reference -- starts from the previous solution.  The residual is summed
+ * over ALL DOFs, the reaction forces at the clamped ones included (implicitNewmarkSparse.cpp:258-262; rounds 2-4 summed the free DOFs
+ * only).  Unsharded handles only for more than one iteration (the quotient is a global sum). */
 int fb_fem_set_newmark(fb_fem_t h, double beta, double gamma, int max_newton_iterations, double epsilon);
 /* IntegratorBaseSparse::setConstrainedDOF (integratorBaseSparse.cpp:73-87) -- takes effect at the next step
  * (the mask is applied when Keff is formed, so unlike the reference no stale systemMatrix can survive) */
