@@ -312,7 +312,7 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   // cross-rank chain (drain -> counter -> proxy copy -> flag; ~4.5 us between two processes on one MI355X) EVERY iteration, and the
   // whole grid ends up at its pace.  So it is dealt fewer slices ("relief", FEMBRAIN_SHARD_RELIEF=n, default 35 % of the
   // slices per CU): its shorter product absorbs the wait.
-  static const int relief_env = getenv("FEMBRAIN_SHARD_RELIEF") ? atoi(getenv("FEMBRAIN_SHARD_RELIEF")) : -1;
+  const int relief_env = getenv("FEMBRAIN_SHARD_RELIEF") ? atoi(getenv("FEMBRAIN_SHARD_RELIEF")) : -1;
   std::vector<int2> wg_range((size_t)nb, make_int2(0, 0));   // first slice and slice count of every workgroup
   // Default (profiles/r04_remote_delay.json: two and four ranks on CU shares of one GPU, remote signals delayed by 0 / 1 / 2 / 5 us): relief
   // pays where FEW workgroups gather halo rows -- 1M tets on two ranks, 2 of 28 planes per rank: 18.5 against 20.6 us per iteration, and
@@ -493,7 +493,13 @@ int setup_persist(fb_fem_s* h) {
       worst = std::max(worst, sl);
     }
     const char* eb = getenv("FEMBRAIN_PIPE_BALANCE");
-    const bool want = eb ? atoi(eb) != 0 : (worst * nb * 4 > total * 5);
+    // (a fullest workgroup a quarter above the average -- or 15 % above it on a mesh whose widest slice is half again as wide as the mean:
+    // the 56^3 cube after one cut, 200 slots against 171, 20.2 -> 19.3 us per iteration.  Forced on a uniform mesh the deal by slots is
+    // SLOWER, 16.4 against 15.6 at 1M tets: some workgroups then hold 12 slices and a smaller LDS share each.)
+    int widest = 0;
+    for (int sl = 0; sl < P.n_slices; sl++) widest = std::max(widest, P.slice_off[sl + 1] - P.slice_off[sl]);
+    const bool uneven = P.n_slices > 0 && (long long)widest * 2 * P.n_slices >= 3 * (long long)P.slice_off[P.n_slices];
+    const bool want = eb ? atoi(eb) != 0 : (worst * nb * 4 > total * 5 || (uneven && w <= kPipeMaxWaves && worst * nb * 100 > total * 115));  // (the two-row kernel at 13 slices per CU: 28.7 with the equal deal, 29.9 by slots)
     if (want) {
       std::vector<int> tab((size_t)2 * nb + 2, 0);
       int most = 0;
@@ -540,7 +546,7 @@ int setup_persist(fb_fem_s* h) {
   const bool eligible = !h->f64 && nb >= 8 && w >= 1 && (P.n_ranks == 1 ? w <= 2 * kPipeMaxWaves : (shard_opt && w <= 2 * (kPipeMaxWaves - 1)));  // (sharded: the spare wavefront leaves 11 for slices, two rows per lane from 12 slices on)
   // (us per iteration, two-launch vs persistent, on MI355X: 7.83 / 7.87 at 125 slices = 1 per CU, 8.74 / 8.74 at 308 and 8.98 / 8.64 at 466
   // = 2 per CU, 10.9 / 8.8 at 614 = 3 per CU, 14.0 / 10.3 at 792, 15.8 / 8.9 at 1,000, 27.4 / 15.75 at 2,744 = 1M tets)
-  static const int min_w = getenv("FEMBRAIN_PERSIST_MIN_WAVES") ? atoi(getenv("FEMBRAIN_PERSIST_MIN_WAVES")) : 2;
+  const int min_w = getenv("FEMBRAIN_PERSIST_MIN_WAVES") ? atoi(getenv("FEMBRAIN_PERSIST_MIN_WAVES")) : 2;
   // FB_PCG_BLOCK_JACOBI (opt-in, outside parity): the one-row persistent kernel with the block preconditioner, same rule
   const bool bj = h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI;
   const bool rows2_forced = getenv("FEMBRAIN_PERSIST_ROWS") && atoi(getenv("FEMBRAIN_PERSIST_ROWS")) == 2;
@@ -1301,12 +1307,12 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   // LDS: the sync buffers, then KLT slots of every slice; the request is the whole 160 KB of a CU, so exactly one workgroup lands on each
   const size_t lds = 160 * 1024;
   // one wavefront more than slices where the instantiation has room: it collects the sums while the others multiply
-  static const bool want_service = !(getenv("FEMBRAIN_PIPE_SERVICE_WAVE") && atoi(getenv("FEMBRAIN_PIPE_SERVICE_WAVE")) == 0);
+  const bool want_service = !(getenv("FEMBRAIN_PIPE_SERVICE_WAVE") && atoi(getenv("FEMBRAIN_PIPE_SERVICE_WAVE")) == 0);
   const int cwaves = h->pipe_rows == 2 ? ceil_div(h->persist_waves, 2) : h->persist_waves;  // wavefronts that own slices
   pa.service = (h->shard_persist || want_service) && cwaves + h->pipe_help_waves < h->pipe_wmax ? 1 : 0;
   // values of the first streamed slots pulled into L2 during the neighbour wait: pays where the product is bandwidth-bound (9 and more
   // slices per CU: -6 % per iteration at 1M tets; neutral at 1,000 slices).  FEMBRAIN_PIPE_PREFETCH=0..4 overrides.
-  static const int prefetch = getenv("FEMBRAIN_PIPE_PREFETCH") ? std::max(0, std::min(4, atoi(getenv("FEMBRAIN_PIPE_PREFETCH")))) : -1;
+  const int prefetch = getenv("FEMBRAIN_PIPE_PREFETCH") ? std::max(0, std::min(4, atoi(getenv("FEMBRAIN_PIPE_PREFETCH")))) : -1;
   pa.prefetch_slots = prefetch >= 0 ? prefetch : (h->persist_waves >= 9 ? (h->pipe_rows == 2 ? 3 : 4) : 0);
   const dim3 grid(h->persist_blocks), block(64 * (cwaves + h->pipe_help_waves + pa.service));  // slices | helpers | the service wavefront
   FB_HIP(hipEventRecord(h->ev_p[0], h->stream));

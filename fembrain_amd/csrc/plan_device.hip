@@ -705,7 +705,7 @@ static int plan_from_sorted(hipStream_t s, int n_nodes, long long n_pairs, long 
   FB_TRY(D.contrib->alloc(std::max<size_t>(1, (size_t)D.n_crows * kSliceRows)));
   const int n_slices = D.n_slices;
   const dim3 sg((unsigned)((n_slices + kB / 64 - 1) / (kB / 64)));
-  static const bool direct = getenv("FEMBRAIN_PLAN_CONTRIB") && !strcmp(getenv("FEMBRAIN_PLAN_CONTRIB"), "direct");  // development aid: the round-1 kernel
+  const bool direct = getenv("FEMBRAIN_PLAN_CONTRIB") && !strcmp(getenv("FEMBRAIN_PLAN_CONTRIB"), "direct");  // development aid: the round-1 kernel
   if (direct) {
     hipLaunchKernelGGL(k_plan_contrib, sg, dim3(kB), 0, s, n_nodes, n_slices, D.bptr->p, D.bcol->p, ucnt.p, cstart.p, vals_s.p, D.slice_off->p, D.slot_coff->p,
                        D.slot_ccnt->p, D.contrib->p);

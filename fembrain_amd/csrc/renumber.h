@@ -65,7 +65,7 @@ constexpr int kSigmaMaxCount = 1023;  // element counts are clipped to 10 bits o
 // producers (poll-all: 25.2 instead of 22.5 us per iteration) while a 1M-tet cut mesh gained either way.  A function of the node
 // count only, so that the host restatement (host_slab_order) agrees without a device.  FEMBRAIN_SIGMA_WINDOW overrides (development).
 inline int sigma_window(int n_nodes) {
-  static const char* e = getenv("FEMBRAIN_SIGMA_WINDOW");
+  const char* e = getenv("FEMBRAIN_SIGMA_WINDOW");
   if (e && atoi(e) >= 64) return (atoi(e) / 64) * 64;
   int per = ((n_nodes + 63) / 64) / 256;
   per = per < 4 ? 4 : (per > 32 ? 32 : per);

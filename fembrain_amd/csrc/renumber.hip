@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kB) void k_scatter_nodes(long long n, int width, co
 
 // the slab order alone pads by more than a tenth: 64 x the largest count of every slice against the sum of the counts
 bool sigma_wanted(int n_nodes, long long padded, long long used) {
-  static const char* e = getenv("FEMBRAIN_SIGMA");  // 0 / 1: never / always (development)
+  const char* e = getenv("FEMBRAIN_SIGMA");  // 0 / 1: never / always (development)
   if (e) return atoi(e) != 0;
   return n_nodes >= kRenumberMinNodes && padded > 0 && 10 * (padded - used) > padded;  // (small meshes are all surface, and no one waits for them)
 }
