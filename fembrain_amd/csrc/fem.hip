@@ -358,7 +358,7 @@ int setup_persist_shard_local(fb_fem_s* h, int nb, int w) {
   w = Q;
   h->pipe_rows = w < kPipeMaxWaves ? 1 : 2;   // 12..22 slices per CU: two rows per lane (k_pcg_pipe2_shard)
   h->pipe_wmax = h->pipe_rows == 2 ? 12 : (w < 8 ? 8 : 12);   // (one wavefront more than slices / slice pairs: the spare one serves the proxies and the sums)
-  h->pipe_klt = h->pipe_rows == 2 ? 0 : std::min(h->pipe_wmax == 8 ? 8 : 6, pipe_lds_slots(false) / std::max(w, 1));  // (a shard's columns are 32-bit)
+  h->pipe_klt = h->pipe_rows == 2 ? std::min(kPipe2Klt, pipe2_lds_slots(w, false) / std::max(w, 1)) : std::min(h->pipe_wmax == 8 ? 8 : 6, pipe_lds_slots(false) / std::max(w, 1));  // (a shard's columns are 32-bit)
   h->persist_blocks = nb; h->persist_waves = w;
   h->sh_relief = relief;
   h->pipe_flag_extra = kP2PMaxRanks * kShardProxies;
@@ -570,7 +570,7 @@ int setup_persist(fb_fem_s* h) {
   h->pipe_wmax = h->pipe_rows == 2 ? 12 : (small ? 5 : (w <= 8 ? 8 : 12));
   // slots of every slice resident in LDS at least: the CU's 62 / 65 (16-bit columns) wavefront-slots dealt to the slices of a workgroup (k_pcg_pipe), at most 16 / 8 / 6
   const int lds_all = pipe_lds_slots(h->c16 != 0), lds_help = pipe_help_slots(h->c16 != 0);
-  h->pipe_klt = h->pipe_rows == 2 ? 0 : std::min(small ? 16 : (w <= 8 ? 8 : 6), lds_all / std::max(w, 1));
+  h->pipe_klt = h->pipe_rows == 2 ? std::min(kPipe2Klt, pipe2_lds_slots(w, h->c16 != 0) / std::max(w, 1)) : std::min(small ? 16 : (w <= 8 ? 8 : 6), lds_all / std::max(w, 1));
   // Helpers for very wide slices (unsharded, one row per lane, Jacobi): the widest slice at least half again as wide as the average and
   // wider than 24 slots.  A workgroup's wavefronts without a slice of their own -- those its neighbours' fuller deal leaves idle, and
   // the ones launched for the purpose: the 12-wavefront instantiation then serves fewer than 9 slices per CU too -- take the upper halves of

@@ -6,8 +6,10 @@
 //     wavefront wv the slices 2 wv and 2 wv + 1: six and a half busy wavefronts, and two wide slices of a cut on one of them);
 //   * r, w, s and 1/diag of both rows stay in registers (48 per lane); x, p, z and the low part of the diagonal block live in
 //     LDS (24 words per row: 147 KB for 12 wavefronts) -- they are touched once per iteration, in the recurrences;
-//   * no slot of the matrix is LDS-resident (the LDS holds vectors instead): every slot is streamed by the assembly loop.
-// So an iteration moves the whole matrix (111 MB per million tets) where k_pcg_pipe moves two thirds of it; it replaces the
+//   * the vectors of a workgroup's slices take 6 KB each; what they leave of the CU's 160 KB holds the first slots of every slice, as in
+//     k_pcg_pipe (round 5: 30 wavefront-slots at 13 slices per CU, 2 at 24; rounds 3-4 reserved 24 vector areas whatever the count and
+//     streamed every slot).
+// So an iteration moves nearly the whole matrix (111 MB per million tets) where k_pcg_pipe moves two thirds of it; it replaces the
 // two-launch iteration (k_spmv + k_cg_fused: +46 MB of vector traffic per million tets and two kernel boundaries) in that range.
 #pragma once
 #include "pcg_pipe.hip.h"
@@ -15,6 +17,14 @@
 namespace fb {
 
 constexpr int kPipe2LdsWordsPerRow = 24;  // x[3], p[3], z[3] as doubles (18 words) + 6 floats of the diagonal block's low part
+constexpr int kPipe2SliceBytes = kPipe2LdsWordsPerRow * 64 * 4;  // the vector area of one slice
+constexpr int kPipe2Klt = 4;               // most LDS-resident slots per slice (the unroll bound of the LDS loop)
+// LDS-resident slots a workgroup with `count` slices has room for: the sync buffers, count + 1 vector areas (the last one is the dump of
+// the wavefronts' unused row sets), the rest in wavefront-slots
+__host__ __device__ constexpr int pipe2_lds_slots(int count, bool c16) {
+  return (160 * 1024 - (int)sizeof(double) * kPipeSyncDoubles - (count + 1) * kPipe2SliceBytes) / pipe_slot_bytes(c16) > 0
+             ? (160 * 1024 - (int)sizeof(double) * kPipeSyncDoubles - (count + 1) * kPipe2SliceBytes) / pipe_slot_bytes(c16) : 0;
+}
 
 // SHARD: the kernel of a sharded handle ("k_pcg_pipe2_shard" in fb_fem_pcg_path; pcg_shard_box.hip.h) -- as for k_pcg_pipe
 template <bool C16, bool SHARD>
@@ -37,11 +47,12 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
   else pipe_deal(pa.wg_first, sv.n_slices, nb, blockIdx.x, &first, &count);
   const bool spare = SHARD && wv == n_waves - 1;  // a shard's spare wavefront: sums, counters, proxy copies (it owns no slice)
   bool live[2], rvalid[2];
-  int row[2], so[2], width[2], send_beg[2], send_end[2];
+  int row[2], so[2], width[2], send_beg[2], send_end[2], jls[2];
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const int jl = wv + h * (n_waves - (SHARD ? 1 : 0));  // (the slice wavefronts: all, or all but a shard's spare one)
     live[h] = jl < count && !spare;  // wave-uniform
+    jls[h] = live[h] ? jl : count;   // (the place of its vectors in LDS; `count` = the dump)
     const int sl = first + jl;
     row[h] = sl * 64 + lane;
     rvalid[h] = live[h] && row[h] < sv.n_owned;
@@ -53,9 +64,33 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
   }
   // LDS of this wavefront and row set h: nine doubles (x, p, z: k = 0..8) then six floats (low diagonal part) per lane, each as a
   // plane of 64 lanes -- 24 words per row, conflict-free
-  char* lbase = (char*)(lds + kPipeSyncDoubles) + (size_t)wv * 2 * kPipe2LdsWordsPerRow * 64 * 4;
-  auto lds_d = [&](int h, int k) -> double* { return (double*)(lbase + (size_t)h * kPipe2LdsWordsPerRow * 256 + (size_t)k * 512) + lane; };
-  auto lds_f = [&](int h, int k) -> float* { return (float*)(lbase + (size_t)h * kPipe2LdsWordsPerRow * 256 + 9 * 512 + (size_t)k * 256) + lane; };
+  // (the areas of the workgroup's slices lie one after the other, slice j at j; a row set without a slice -- the recurrences below run
+  // over both row sets unconditionally -- reads and writes the dump area behind them, zeros from every wavefront that does)
+  char* lbase = (char*)(lds + kPipeSyncDoubles);
+  auto lds_d = [&](int h, int k) -> double* { return (double*)(lbase + (size_t)jls[h] * kPipe2SliceBytes + (size_t)k * 512) + lane; };
+  auto lds_f = [&](int h, int k) -> float* { return (float*)(lbase + (size_t)jls[h] * kPipe2SliceBytes + 9 * 512 + (size_t)k * 256) + lane; };
+  // LDS-resident part of the matrix: what the vector areas leave, dealt to the slices as in k_pcg_pipe (count-th part each, the remainder
+  // one more for the first ones, at most kPipe2Klt); C16: [klt][9][64] value words then [klt][64] column differences, else [klt][10][64] words
+  constexpr int kValWords = C16 ? 9 : 10;
+  const int pool = pipe2_lds_slots(count, C16);
+  const int pbase = min(kPipe2Klt, pool / max(count, 1)), prem = pbase < kPipe2Klt ? min(count, pool - pbase * count) : 0;  // workgroup-uniform
+  int klt[2], KL[2];
+  char* lres[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    klt[h] = __builtin_amdgcn_readfirstlane(live[h] ? pbase + (jls[h] < prem ? 1 : 0) : 0);
+    KL[h] = min(klt[h], width[h]);
+    lres[h] = lbase + (size_t)(count + 1) * kPipe2SliceBytes + (size_t)(jls[h] * pbase + min(jls[h], prem)) * pipe_slot_bytes(C16);
+    unsigned int* lv = (unsigned int*)lres[h] + lane;
+    short* lc = (short*)(lres[h] + (size_t)klt[h] * 9 * 256) + lane;
+    for (int k = 0; k < KL[h]; k++) {
+      const float* vk = vals + ((size_t)so[h] + k) * 9 * 64 + lane;
+#pragma unroll
+      for (int j = 0; j < 9; j++) lv[(k * kValWords + j) * 64] = __float_as_uint(vk[j * 64]);
+      if constexpr (C16) lc[k * 64] = sv.coldelta[((size_t)so[h] + k) * 64 + lane];
+      else lv[(k * 10 + 9) * 64] = (unsigned int)sv.colidx[((size_t)so[h] + k) * 64 + lane];
+    }
+  }
   double iv[2][3] = {{0, 0, 0}, {0, 0, 0}};
 #pragma unroll
   for (int h = 0; h < 2; h++) {
@@ -100,10 +135,10 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (post_sums) sums++;
-    if (wv != 0 && live[0] && pa.prefetch_slots > 0 && width[0] > 0) {
-      int so_k = so[0];
+    if (wv != 0 && live[0] && pa.prefetch_slots > 0 && width[0] > KL[0]) {
+      int so_k = so[0] + KL[0];
       asm volatile("" : "+s"(so_k));
-      pipe_prefetch_values(min(pa.prefetch_slots, width[0]), ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float), vals);
+      pipe_prefetch_values(min(pa.prefetch_slots, width[0] - KL[0]), ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float), vals);
     }
     if constexpr (SHARD) {
       if (spare) shard_service_product(sa, BL, pa, pub, pl, nb, lane, send_mask, t_limit, bc, failed);
@@ -161,10 +196,25 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
         y1 = l01 * vin[h][0] + l11 * vin[h][1] + l12 * vin[h][2];
         y2 = l02 * vin[h][0] + l12 * vin[h][1] + l22 * vin[h][2];
       }
-      if (live[h] && width[h] > 0) {
-        int so_k = so[h];
+      if (live[h]) {  // LDS-resident slots
+        const unsigned int* lv = (const unsigned int*)lres[h] + lane;
+        const short* lc = (const short*)(lres[h] + (size_t)klt[h] * 9 * 256) + lane;
+#pragma unroll
+        for (int k = 0; k < kPipe2Klt; k++) if (k < KL[h]) {
+          const unsigned int* lk = lv + (size_t)k * kValWords * 64;
+          unsigned int col;
+          if constexpr (C16) col = (unsigned int)(row[h] + (int)lc[k * 64]); else col = lk[9 * 64];
+          const double* xp = pl + (size_t)col;
+          const double x0 = xp[0], x1 = xp[pa.n_pad], x2 = xp[2 * pa.n_pad];
+          y0 += (double)__uint_as_float(lk[0 * 64]) * x0 + (double)__uint_as_float(lk[1 * 64]) * x1 + (double)__uint_as_float(lk[2 * 64]) * x2;
+          y1 += (double)__uint_as_float(lk[3 * 64]) * x0 + (double)__uint_as_float(lk[4 * 64]) * x1 + (double)__uint_as_float(lk[5 * 64]) * x2;
+          y2 += (double)__uint_as_float(lk[6 * 64]) * x0 + (double)__uint_as_float(lk[7 * 64]) * x1 + (double)__uint_as_float(lk[8 * 64]) * x2;
+        }
+      }
+      if (live[h] && width[h] > KL[h]) {
+        int so_k = so[h] + KL[h];
         asm volatile("" : "+s"(so_k));
-        pipe_stream_slots<C16>(width[h], ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
+        pipe_stream_slots<C16>(width[h] - KL[h], ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
                                ((unsigned int)so_k * 64u + (unsigned int)lane) * (unsigned int)(C16 ? sizeof(short) : sizeof(int)), vals,
                                C16 ? (const void*)sv.coldelta : (const void*)sv.colidx, pl, pl + pa.n_pad, pl + 2 * pa.n_pad, row[h], y0, y1, y2);
       }

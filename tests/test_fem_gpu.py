@@ -1414,7 +1414,9 @@ def test_default_handle_between_1M_and_2M_tets_against_the_reference_built_golde
     g = FemIntegrator(v, t, fixed)
     monkeypatch.delenv("FEMBRAIN_SPMV_C16", raising=False)
     on, waves, wgs, slots = g.persist_info()
-    assert on and waves == slices_per_cu and wgs == 256 and slots == 0 and g.pcg_path()["kernel"] == kernel
+    # (round 5: what the vectors of the workgroup's slices leave of the 160 KB holds the first slots of every slice: 1 at 14 slices per CU, 0 at 24)
+    pool = (160 * 1024 - 4416 - (slices_per_cu + 1) * 6144) // (2432 if c16 else 2560)
+    assert on and waves == slices_per_cu and wgs == 256 and slots == min(4, pool // slices_per_cu) and slots == (1 if n == 60 else 0) and g.pcg_path()["kernel"] == kernel
     _check_against_big_golden(g, gold)
     p = g.pcg_path()
     assert p["path"] == fl.FB_PCG_PATH_PERSISTENT and p["launches"] == 1 and p["fallbacks"] == 0
