@@ -64,6 +64,9 @@ struct fb_fem_s {
   std::vector<int> pipe_wg_first_host;
   DevBuf<int4> pipe_tasks;           // persistent solver: per workgroup and wavefront its share of the slices (helpers, pcg_pipe.hip.h PipeArgs)
   int pipe_help_waves = 0;           // wavefronts launched beyond slices + service wavefront, for the helpers (0: none)
+  DevBuf<unsigned long long> pipe_lines;  // k_gather_lines' three sums
+  bool pipe_xyz = false;             // the published vector node by node instead of in planes (irregular meshes; k_pcg_pipe<..., XYZ>)
+  double pipe_gather_lines[2] = {0, 0};  // cache lines a slot's gathers touch on average: three planes | 24-byte records (k_gather_lines; 0: not measured)
   int pipe_n_help = 0, pipe_help_tasks = 0;  // most helper tasks of a workgroup; all of them
   int asm_wide = 0;                  // slices wider than the element-major kernel takes (kIncMaxWidth slots): k_assemble_wide assembles those
   int asm_wide_slots = 0, asm_wide_grid = 0;  // the widest of them; workgroups of k_assemble_wide (each with a scratch area of asm_wide_slots slots)
@@ -584,7 +587,27 @@ int setup_persist(fb_fem_s* h) {
     const double mean = P.n_slices ? (double)tot / P.n_slices : 0.0;
     const char* eh = getenv("FEMBRAIN_PIPE_HELPERS");
     const bool want_h = eh ? atoi(eh) != 0 : (mx > 24 && (double)mx >= 1.5 * mean);
-    if (want_h && w <= kPipeMaxWaves) {
+    // Where do the columns of a slot lie?  On a structured mesh the 64 rows of a slice have consecutive columns and a gather touches 4 lines
+    // of each of the three planes of the published vector; on an unstructured one it touches ~50 of each, and a vector stored node by node
+    // (24-byte records) costs half of those.  Sampled on the device (every 8th slice), decided here: node by node where the planes cost 30 lines
+    // and more per slot and half again the records' (606k-tet Delaunay probe: 80 against 44 lines, 18.9 -> 16.4 us per iteration; the cube
+    // after a cut: 19 against 15, and there the planes are the faster form, 19.4 against 20.6, each load touching 4 lines instead of 12).  FEMBRAIN_PIPE_XYZ=0/1 overrides.  (The table-driven instantiation carries the layout.)
+    bool want_xyz = false;
+    h->pipe_gather_lines[0] = h->pipe_gather_lines[1] = 0.0;
+    if (w <= kPipeMaxWaves && P.n_local < (1 << 24) && h->colidx.p) {
+      FB_TRY(h->pipe_lines.alloc(4));
+      FB_HIP(hipMemsetAsync(h->pipe_lines.p, 0, 4 * sizeof(unsigned long long), s));
+      hipLaunchKernelGGL(k_gather_lines, dim3(64), dim3(256), 0, s, P.n_slices, 8, h->slice_off.p, h->colidx.p, h->pipe_lines.p);
+      FB_HIP(hipGetLastError());
+      unsigned long long got[3] = {0, 0, 0};
+      FB_HIP(hipMemcpyAsync(got, h->pipe_lines.p, sizeof got, hipMemcpyDeviceToHost, s));
+      FB_HIP(hipStreamSynchronize(s));
+      if (got[2]) { h->pipe_gather_lines[0] = 3.0 * (double)got[0] / (double)got[2]; h->pipe_gather_lines[1] = (double)got[1] / (double)got[2]; }
+      const char* ex = getenv("FEMBRAIN_PIPE_XYZ");
+      want_xyz = ex ? atoi(ex) != 0 : (got[2] && h->pipe_gather_lines[0] >= 30.0 && h->pipe_gather_lines[0] >= 1.5 * h->pipe_gather_lines[1]);
+    }
+    h->pipe_xyz = false;
+    if ((want_h || want_xyz) && w <= kPipeMaxWaves) {
       const int help_waves = std::max(0, kPipeMaxWaves - w - 1);   // (the 12-wavefront kernel: slices, helpers, the service wavefront)
       std::vector<int4> tasks((size_t)nb * kPipeTaskStride, make_int4(-1, 0, 0, 0));
       int most = 0, all = 0, deepest = 0;
@@ -630,7 +653,7 @@ int setup_persist(fb_fem_s* h) {
           for (int j = 0; j < kPipeTaskStride; j++) tk[j] = make_int4(-1, 0, 0, 0);
           for (int j = 0; j < count; j++) st.push_back({j, j, 0, wd[j], res[j]});
           std::vector<unsigned> mask(count, 0u);
-          for (int hw = count; hw < w + help_waves && n_h < kPipeMaxHelpers; hw++) {  // idle slice wavefronts first, then the extra ones
+          for (int hw = count; want_h && hw < w + help_waves && n_h < kPipeMaxHelpers; hw++) {  // idle slice wavefronts first, then the extra ones
             int best = -1, len = 0;
             for (int i = 0; i < (int)st.size(); i++) {
               const int l = st[i].k1 - std::max(st[i].k0, st[i].floor);  // what it streams
@@ -665,12 +688,13 @@ int setup_persist(fb_fem_s* h) {
         most = std::max(most, n_h);
         all += n_h;
       }
-      if (all > 0 || deepest > 6 || (eh && atoi(eh) == 2)) {  // (=2, development: the task table without a single helper)
+      if (all > 0 || deepest > 6 || want_xyz || (eh && atoi(eh) == 2)) {  // (=2, development: the task table without a single helper)
         FB_TRY(h->pipe_tasks.upload(tasks, s));
         h->pipe_wmax = 12;
         h->pipe_klt = deepest;
         h->pipe_help_waves = help_waves; h->pipe_n_help = most; h->pipe_help_tasks = all;
-        if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] persistent solver: %d helper tasks (at most %d per workgroup), widest slice %d slots, mean %.1f, up to %d slots of a slice in LDS\n", all, most, mx, mean, deepest);
+        h->pipe_xyz = want_xyz;
+        if (getenv("FEMBRAIN_TIMING")) fprintf(stderr, "[fembrain] persistent solver: %d helper tasks (at most %d per workgroup), widest slice %d slots, mean %.1f, up to %d slots of a slice in LDS; a slot's gathers touch %.1f lines in planes, %.1f node by node -> %s\n", all, most, mx, mean, deepest, h->pipe_gather_lines[0], h->pipe_gather_lines[1], want_xyz ? "node by node" : "planes");
       }
     }
   }
@@ -1332,11 +1356,11 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     hipLaunchKernelGGL((k_pcg_pipe<float, C16, WMAX, KLT, TIMING, SHARD>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p,       \
                        (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);          \
   } while (0)
-#define FB_PIPE_HELP(C16, TIMING)                                                                                                                     \
+#define FB_PIPE_HELP(C16, TIMING, XYZ)                                                                                                                \
   do {                                                                                                                                                \
-    FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe<float, C16, 12, 6, TIMING, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+    FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe<float, C16, 12, 6, TIMING, false, false, true, XYZ>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                (int)lds));                                                                                                           \
-    hipLaunchKernelGGL((k_pcg_pipe<float, C16, 12, 6, TIMING, false, false, true>), grid, block, lds, h->stream, sell_view(h),                       \
+    hipLaunchKernelGGL((k_pcg_pipe<float, C16, 12, 6, TIMING, false, false, true, XYZ>), grid, block, lds, h->stream, sell_view(h),                  \
                        (const float*)h->vals.p, (const float*)h->dlo.p, h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, \
                        h->st.p, pa, sa);                                                                                                             \
   } while (0)
@@ -1367,8 +1391,13 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
   } else if (h->pipe_rows == 2) {
     if (h->c16) FB_PIPE2(true, false); else FB_PIPE2(false, false);
   } else if (h->pipe_tasks.p) {  // helper wavefronts (setup_persist): the (12, 6) kernel compiled with them
-    if (pa.timing) { if (h->c16) FB_PIPE_HELP(true, true); else FB_PIPE_HELP(false, true); }
-    else { if (h->c16) FB_PIPE_HELP(true, false); else FB_PIPE_HELP(false, false); }
+    if (h->pipe_xyz) {  // (the published vector node by node)
+      if (pa.timing) { if (h->c16) FB_PIPE_HELP(true, true, true); else FB_PIPE_HELP(false, true, true); }
+      else { if (h->c16) FB_PIPE_HELP(true, false, true); else FB_PIPE_HELP(false, false, true); }
+    } else {
+      if (pa.timing) { if (h->c16) FB_PIPE_HELP(true, true, false); else FB_PIPE_HELP(false, true, false); }
+      else { if (h->c16) FB_PIPE_HELP(true, false, false); else FB_PIPE_HELP(false, false, false); }
+    }
   } else if (pa.timing) {  // development build with the phase clocks: the 1M-tet configuration and the small one
     if (h->pipe_wmax == 12 && h->c16) FB_PIPE(true, 12, 6, true, false);
     else if (h->pipe_wmax == 12) FB_PIPE(false, 12, 6, true, false);
@@ -3245,6 +3274,11 @@ int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches,
 
 int fb_fem_persist_rearms(fb_fem_t h) { return h ? h->persist_rearms : 0; }
 int fb_fem_persist_helpers(fb_fem_t h) { return h && h->persist ? h->pipe_help_tasks : 0; }
+int fb_fem_persist_gather(fb_fem_t h, double* lines_planes, double* lines_records) {
+  if (lines_planes) *lines_planes = h && h->persist ? h->pipe_gather_lines[0] : 0.0;
+  if (lines_records) *lines_records = h && h->persist ? h->pipe_gather_lines[1] : 0.0;
+  return h && h->persist && h->pipe_xyz ? 1 : 0;
+}
 
 int fb_fem_persist_stats(fb_fem_t h, int* launches, double* seconds, long long* iterations) {
   if (!h) return fail(FB_EINVAL, "null FEM handle");

@@ -237,6 +237,35 @@ __device__ __forceinline__ void pipe_collect_posts(const PipeArgs& pa, unsigned 
   }
 }
 
+// How many cache lines the gathers of a slot touch, planes against node-by-node storage of the gathered vector (sampled: every `step`-th
+// slice, all its slots; a wavefront per slot).  out[0] += distinct 128-byte lines of one plane (x 3 planes = the lines a slot fetches),
+// out[1] += distinct lines of the 24-byte records, out[2] += 1.
+__global__ __launch_bounds__(256) void k_gather_lines(int n_slices, int step, const int* __restrict__ slice_off, const int* __restrict__ colidx,
+                                                      unsigned long long* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * blockDim.x) >> 6);
+  unsigned long long planes = 0, records = 0, slots = 0;
+  for (int s = wave * step; s < n_slices; s += n_waves * step) {
+    for (int slot = slice_off[s]; slot < slice_off[s + 1]; slot++) {
+      const unsigned int col = (unsigned int)colidx[(size_t)slot * 64 + lane];
+      const unsigned int kp = col >> 4, k0 = (col * 24u) >> 7, k1 = (col * 24u + 23u) >> 7;
+      bool first_p = true, first_0 = true, first_1 = k1 != k0;
+      for (int l = 0; l < 64; l++) {  // (is there an earlier lane with the same line?)
+        const unsigned int op = __builtin_amdgcn_readlane(kp, l), o0 = __builtin_amdgcn_readlane(k0, l), o1 = __builtin_amdgcn_readlane(k1, l);
+        if (l < lane) {
+          first_p = first_p && op != kp;
+          first_0 = first_0 && o0 != k0 && o1 != k0;
+          first_1 = first_1 && o0 != k1 && o1 != k1;
+        }
+      }
+      planes += __popcll(__ballot(first_p));
+      records += __popcll(__ballot(first_0)) + __popcll(__ballot(first_1));
+      slots++;
+    }
+  }
+  if (lane == 0 && slots) { atomicAdd(out, planes); atomicAdd(out + 1, records); atomicAdd(out + 2, slots); }
+}
+
 }  // namespace fb
 #include "pcg_shard_box.hip.h"
 namespace fb {
@@ -256,7 +285,7 @@ namespace fb {
 // HELP: the instantiation with helper wavefronts (PipeArgs::tasks).  A template parameter, not a run-time test: with the helpers' second
 // copy of the streamed product compiled in, the kernel of the headline mesh -- which has none -- ran 3 % slower (16.2 against 15.7 us per
 // iteration on one box, tools/ab_r4 in round 5); with HELP = false nothing of it is there.
-template <typename MT, bool C16, int WMAX, int KLT, bool TIMING, bool SHARD, bool BJ = false, bool HELP = false>
+template <typename MT, bool C16, int WMAX, int KLT, bool TIMING, bool SHARD, bool BJ = false, bool HELP = false, bool XYZ = false>
 __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* __restrict__ vals, const MT* __restrict__ dlo,
                                                         const double* __restrict__ invdiag, const double* __restrict__ bvec, double* __restrict__ xg,
                                                         double* __restrict__ rg, double* __restrict__ wg, double* __restrict__ zg,
@@ -383,16 +412,22 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(my_xcc));
     if (threadIdx.x == 0) st_sc1_u32(pa.xcc + blockIdx.x, ((pub + 1u) << 4) | my_xcc);  // (visible before this workgroup's first flag: product() drains before it flags)
   }
+  // XYZ: the published vector lies node by node (x, y, z side by side) instead of in three planes -- for irregular meshes, whose gathers
+  // of a slot touch 64 different cache lines per plane: one line per lane instead of three (pcg_pipe_stream.hip.h).  606k-tet Delaunay
+  // probe 18.6 -> 16.4 us per iteration; the cube after a cut, whose columns are mostly consecutive, 19.4 -> 20.6 (each of the three loads
+  // of a slot then touches 12 lines instead of 4), so setup_persist decides from the columns (k_gather_lines).
+  static_assert(!XYZ || HELP, "the node-by-node vector comes with the table-driven instantiation");
+  const size_t xs = XYZ ? 1 : pa.n_pad, cs = XYZ ? 3 : 1;  // strides of a component and of a column in the published vector
   auto publish = [&](const double* vin) {
     pub++;
     double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
     if (rvalid) {
       if (through) {
 #pragma unroll
-        for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * pa.n_pad + (size_t)row, vin[a]);
+        for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * xs + cs * (size_t)row, vin[a]);
       } else {
 #pragma unroll
-        for (int a = 0; a < 3; a++) pl[a * pa.n_pad + (size_t)row] = vin[a];
+        for (int a = 0; a < 3; a++) pl[a * xs + cs * (size_t)row] = vin[a];
       }
       if constexpr (SHARD) shard_send_row(sa, BL, pub, send_beg, send_end, vin);
     }
@@ -492,8 +527,8 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
 #pragma unroll
         for (int k = 0; k < KLT; k++) {
           const unsigned int col = k < KL ? lds_col(k) : 0u;
-          const double* xp = pl + (size_t)col;
-          gx[k][0] = k < KL ? xp[0] : 0.0; gx[k][1] = k < KL ? xp[pa.n_pad] : 0.0; gx[k][2] = k < KL ? xp[2 * pa.n_pad] : 0.0;
+          const double* xp = pl + cs * (size_t)col;
+          gx[k][0] = k < KL ? xp[0] : 0.0; gx[k][1] = k < KL ? xp[xs] : 0.0; gx[k][2] = k < KL ? xp[2 * xs] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < KLT; k++) if (k < KL) {
@@ -507,8 +542,8 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
 #pragma unroll
         for (int k = 0; k < KLT; k++) if (k < KL) {  // LDS-resident slots
           const unsigned int* lk = lres + (size_t)k * kValWords * 64;
-          const double* xp = pl + (size_t)lds_col(k);
-          const double x0 = xp[0], x1 = xp[pa.n_pad], x2 = xp[2 * pa.n_pad];
+          const double* xp = pl + cs * (size_t)lds_col(k);
+          const double x0 = xp[0], x1 = xp[xs], x2 = xp[2 * xs];
           y0 += (double)__uint_as_float(lk[0 * 64]) * x0 + (double)__uint_as_float(lk[1 * 64]) * x1 + (double)__uint_as_float(lk[2 * 64]) * x2;
           y1 += (double)__uint_as_float(lk[3 * 64]) * x0 + (double)__uint_as_float(lk[4 * 64]) * x1 + (double)__uint_as_float(lk[5 * 64]) * x2;
           y2 += (double)__uint_as_float(lk[6 * 64]) * x0 + (double)__uint_as_float(lk[7 * 64]) * x1 + (double)__uint_as_float(lk[8 * 64]) * x2;
@@ -519,8 +554,8 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
 #pragma unroll
             for (int j = 0; j < KLT; j++) {
               const int k = min(kb + j, KL - 1);  // (past the end: the last slot again, not used)
-              const double* xp = pl + (size_t)lds_col(k);
-              gx[j][0] = xp[0]; gx[j][1] = xp[pa.n_pad]; gx[j][2] = xp[2 * pa.n_pad];
+              const double* xp = pl + cs * (size_t)lds_col(k);
+              gx[j][0] = xp[0]; gx[j][1] = xp[xs]; gx[j][2] = xp[2 * xs];
             }
 #pragma unroll
             for (int j = 0; j < KLT; j++) if (kb + j < KL) {
@@ -538,9 +573,9 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
       if (n_str > 0) {
         int so_k = so + klt_w;
         asm volatile("" : "+s"(so_k));  // opaque: keeps the two offsets below from being hoisted out of the solver loop into live registers
-        pipe_stream_slots<C16>(n_str, ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
+        pipe_stream_slots<C16, XYZ>(n_str, ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
                                ((unsigned int)so_k * 64u + (unsigned int)lane) * (unsigned int)(C16 ? sizeof(short) : sizeof(int)), vals,
-                               C16 ? (const void*)sv.coldelta : (const void*)sv.colidx, pl, pl + pa.n_pad, pl + 2 * pa.n_pad, row, y0, y1, y2);
+                               C16 ? (const void*)sv.coldelta : (const void*)sv.colidx, pl, pl + xs, pl + 2 * xs, row, y0, y1, y2);
       }
     }
     if constexpr (HELP) if (help_sl >= 0) {  // a helper: its share of another wavefront's slice, handed over through LDS (the owner adds it after the next barrier)
@@ -548,9 +583,9 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
       int so_k = help_so + hk0;
       asm volatile("" : "+s"(so_k));
       if (hk1 > hk0)  // (the stream loads its first slots unconditionally: never with none)
-      pipe_stream_slots<C16>(hk1 - hk0, ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
+      pipe_stream_slots<C16, XYZ>(hk1 - hk0, ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
                              ((unsigned int)so_k * 64u + (unsigned int)lane) * (unsigned int)(C16 ? sizeof(short) : sizeof(int)), vals,
-                             C16 ? (const void*)sv.coldelta : (const void*)sv.colidx, pl, pl + pa.n_pad, pl + 2 * pa.n_pad, help_sl * 64 + lane, h0, h1, h2);
+                             C16 ? (const void*)sv.coldelta : (const void*)sv.colidx, pl, pl + xs, pl + 2 * xs, help_sl * 64 + lane, h0, h1, h2);
       double* hp = ypart + (size_t)help_idx * 3 * 64 + lane;
       hp[0] = h0; hp[64] = h1; hp[128] = h2;
     }

@@ -44,12 +44,22 @@ namespace fb {
 // read when a load is issued), then the three gathers
 #define FBP_GOFF16(c) "v_add_u32_e32 v122, %[row], " c "\n\t" "v_lshlrev_b32_e32 v122, 3, v122\n\t"
 #define FBP_GOFF32(c) "v_lshlrev_b32_e32 v122, 3, " c "\n\t"
+// the same for a gathered vector stored node by node (x, y, z of a node side by side, 24 bytes apart; the three "planes" are then the
+// same array at +0, +8, +16 bytes): an irregular mesh's 64 columns of a slot lie in 64 different cache lines, and with planes in 3 x 64
+#define FBP_GOFF16X(c) "v_add_u32_e32 v122, %[row], " c "\n\t" "v_mul_u32_u24_e32 v122, 24, v122\n\t"
+#define FBP_GOFF32X(c) "v_mul_u32_u24_e32 v122, 24, " c "\n\t"
 #define FBP_GATHER(g0, g1, g2)                                             \
   "global_load_dwordx2 " g0 ", v122, %[spl0]\n\t"                          \
   "global_load_dwordx2 " g1 ", v122, %[spl1]\n\t"                          \
   "global_load_dwordx2 " g2 ", v122, %[spl2]\n\t"
 #define FBP_GATHER_A FBP_GATHER("v[124:125]", "v[126:127]", "v[128:129]")
 #define FBP_GATHER_B FBP_GATHER("v[130:131]", "v[132:133]", "v[134:135]")
+// node-by-node vector: x and y of the column in one 16-byte load, z in a second one (two loads per slot instead of three)
+#define FBP_GATHERX(g01, g2)                                               \
+  "global_load_dwordx4 " g01 ", v122, %[spl0]\n\t"                         \
+  "global_load_dwordx2 " g2 ", v122, %[spl0] offset:16\n\t"
+#define FBP_GATHERX_A FBP_GATHERX("v[124:127]", "v[128:129]")
+#define FBP_GATHERX_B FBP_GATHERX("v[130:133]", "v[134:135]")
 #define FBP_ROW(y, a, b, c, x0, x1, x2)                                    \
   "v_cvt_f64_f32_e32 v[120:121], " a "\n\t"                                \
   "v_cvt_f64_f32_e32 v[122:123], " b "\n\t"                                \
@@ -70,12 +80,14 @@ namespace fb {
   FBP_ROW("%[y2]", "v151", "v152", "v153", "v[130:131]", "v[132:133]", "v[134:135]")
 // One slot with two or more to follow / with one to follow / the last one; X = the set computed from, Y = the other set.
 // cX holds C(k) (consumed), cY holds C(k+1).
-#define FBP_FULL(LOADC, GOFF, cX, cY, LOADV_Y, GATHER_Y, COMPUTE_X)        \
-  LOADC(cX) LOADV_Y "s_waitcnt vmcnt(22)\n\t" GOFF(cY) GATHER_Y "s_waitcnt vmcnt(13)\n\t" COMPUTE_X
-#define FBP_PENULT(GOFF, cY, LOADV_Y, GATHER_Y, COMPUTE_X)                 \
-  LOADV_Y "s_waitcnt vmcnt(21)\n\t" GOFF(cY) GATHER_Y "s_waitcnt vmcnt(12)\n\t" COMPUTE_X
+// (W1..W4: the four counts above for three gathers per slot, "22" "13" "21" "12"; one less each with two)
+#define FBP_FULL(LOADC, GOFF, cX, cY, LOADV_Y, GATHER_Y, COMPUTE_X, W1, W2) \
+  LOADC(cX) LOADV_Y "s_waitcnt vmcnt(" W1 ")\n\t" GOFF(cY) GATHER_Y "s_waitcnt vmcnt(" W2 ")\n\t" COMPUTE_X
+#define FBP_PENULT(GOFF, cY, LOADV_Y, GATHER_Y, COMPUTE_X, W3, W4)         \
+  LOADV_Y "s_waitcnt vmcnt(" W3 ")\n\t" GOFF(cY) GATHER_Y "s_waitcnt vmcnt(" W4 ")\n\t" COMPUTE_X
 #define FBP_LAST(COMPUTE_X) "s_waitcnt vmcnt(0)\n\t" COMPUTE_X
-#define FBP_BODY(LOADC, GOFF)                                                                                   \
+#define FBP_BODY(LOADC, GOFF) FBP_BODYG(LOADC, GOFF, FBP_GATHER_A, FBP_GATHER_B, "22", "13", "21", "12")
+#define FBP_BODYG(LOADC, GOFF, GATHER_A, GATHER_B, W1, W2, W3, W4)                                                                                 \
   /* the scalar operands may have been written by a vector instruction (v_readlane / v_readfirstlane) just before: a vector   \
      memory instruction reading such a register needs 5 wait states, and the compiler does not look into this text */         \
   "s_nop 4\n\t"                                                                                                 \
@@ -91,23 +103,23 @@ namespace fb {
   FBP_LOADV_A                                                                                                   \
   "s_waitcnt vmcnt(9)\n"                                                                                        \
   ".Lfbp_g0_%=:\n\t"                                                                                            \
-  GOFF("v154") FBP_GATHER_A                                                                                     \
+  GOFF("v154") GATHER_A                                                                                     \
   /* even slot: compute from A */                                                                               \
   ".Lfbp_even_%=:\n\t"                                                                                          \
   "s_cmp_lt_i32 %[n], 3\n\t"                                                                                    \
   "s_cbranch_scc1 .Lfbp_even_tail_%=\n\t"                                                                       \
-  FBP_FULL(LOADC, GOFF, "v154", "v155", FBP_LOADV_B, FBP_GATHER_B, FBP_COMPUTE_A)                               \
+  FBP_FULL(LOADC, GOFF, "v154", "v155", FBP_LOADV_B, GATHER_B, FBP_COMPUTE_A, W1, W2)                               \
   "s_sub_i32 %[n], %[n], 1\n\t"                                                                                 \
   /* odd slot: compute from B */                                                                                \
   "s_cmp_lt_i32 %[n], 3\n\t"                                                                                    \
   "s_cbranch_scc1 .Lfbp_odd_tail_%=\n\t"                                                                        \
-  FBP_FULL(LOADC, GOFF, "v155", "v154", FBP_LOADV_A, FBP_GATHER_A, FBP_COMPUTE_B)                               \
+  FBP_FULL(LOADC, GOFF, "v155", "v154", FBP_LOADV_A, GATHER_A, FBP_COMPUTE_B, W1, W2)                               \
   "s_sub_i32 %[n], %[n], 1\n\t"                                                                                 \
   "s_branch .Lfbp_even_%=\n"                                                                                    \
   ".Lfbp_even_tail_%=:\n\t"                                                                                     \
   "s_cmp_lt_i32 %[n], 2\n\t"                                                                                    \
   "s_cbranch_scc1 .Lfbp_even_last_%=\n\t"                                                                       \
-  FBP_PENULT(GOFF, "v155", FBP_LOADV_B, FBP_GATHER_B, FBP_COMPUTE_A)                                            \
+  FBP_PENULT(GOFF, "v155", FBP_LOADV_B, GATHER_B, FBP_COMPUTE_A, W3, W4)                                            \
   FBP_LAST(FBP_COMPUTE_B)                                                                                       \
   "s_branch .Lfbp_end_%=\n"                                                                                     \
   ".Lfbp_even_last_%=:\n\t"                                                                                     \
@@ -116,7 +128,7 @@ namespace fb {
   ".Lfbp_odd_tail_%=:\n\t"                                                                                      \
   "s_cmp_lt_i32 %[n], 2\n\t"                                                                                    \
   "s_cbranch_scc1 .Lfbp_odd_last_%=\n\t"                                                                        \
-  FBP_PENULT(GOFF, "v154", FBP_LOADV_A, FBP_GATHER_A, FBP_COMPUTE_B)                                            \
+  FBP_PENULT(GOFF, "v154", FBP_LOADV_A, GATHER_A, FBP_COMPUTE_B, W3, W4)                                            \
   FBP_LAST(FBP_COMPUTE_A)                                                                                       \
   "s_branch .Lfbp_end_%=\n"                                                                                     \
   ".Lfbp_odd_last_%=:\n\t"                                                                                      \
@@ -169,12 +181,23 @@ __device__ __forceinline__ void pipe_prefetch_values(int n, unsigned int voff, c
                : FBP_CLOBBERS);
 }
 
-template <bool C16>
+// XYZ: the gathered vector is stored node by node (pl1 = pl0 + 1, pl2 = pl0 + 2 doubles; columns below 2^24) instead of in three planes
+template <bool C16, bool XYZ = false>
 __device__ __forceinline__ void pipe_stream_slots(int n, unsigned int voff, unsigned int coff, const float* vals, const void* cols, const double* pl0,
                                                   const double* pl1, const double* pl2, int row, double& y0, double& y1, double& y2) {
   vals = scalar_ptr(vals); cols = scalar_ptr(cols); pl0 = scalar_ptr(pl0); pl1 = scalar_ptr(pl1); pl2 = scalar_ptr(pl2);
   n = __builtin_amdgcn_readfirstlane(n);
-  if (C16) {
+  if (C16 && XYZ) {
+    asm volatile(FBP_BODYG(FBP_LOADC16, FBP_GOFF16X, FBP_GATHERX_A, FBP_GATHERX_B, "21", "12", "20", "11")
+                 : [y0] "+v"(y0), [y1] "+v"(y1), [y2] "+v"(y2), [voff] "+v"(voff), [coff] "+v"(coff), [n] "+s"(n)
+                 : [svals] "s"(vals), [scols] "s"(cols), [spl0] "s"(pl0), [spl1] "s"(pl1), [spl2] "s"(pl2), [row] "v"(row)
+                 : FBP_CLOBBERS);
+  } else if (XYZ) {
+    asm volatile(FBP_BODYG(FBP_LOADC32, FBP_GOFF32X, FBP_GATHERX_A, FBP_GATHERX_B, "21", "12", "20", "11")
+                 : [y0] "+v"(y0), [y1] "+v"(y1), [y2] "+v"(y2), [voff] "+v"(voff), [coff] "+v"(coff), [n] "+s"(n)
+                 : [svals] "s"(vals), [scols] "s"(cols), [spl0] "s"(pl0), [spl1] "s"(pl1), [spl2] "s"(pl2), [row] "v"(row)
+                 : FBP_CLOBBERS);
+  } else if (C16) {
     asm volatile(FBP_BODY(FBP_LOADC16, FBP_GOFF16)
                  : [y0] "+v"(y0), [y1] "+v"(y1), [y2] "+v"(y2), [voff] "+v"(voff), [coff] "+v"(coff), [n] "+s"(n)
                  : [svals] "s"(vals), [scols] "s"(cols), [spl0] "s"(pl0), [spl1] "s"(pl1), [spl2] "s"(pl2), [row] "v"(row)

@@ -305,6 +305,12 @@ class FemIntegrator:
         on = self._L.fb_fem_persist_info(self.h, C.byref(w), C.byref(b), C.byref(k))
         return bool(on == 1), w.value, b.value, k.value
 
+    def persist_gather(self):
+        """(published vector node by node?, cache lines a slot's gathers touch in planes, in 24-byte records) -- fb_fem_persist_gather"""
+        a, b = C.c_double(0), C.c_double(0)
+        on = self._L.fb_fem_persist_gather(self.h, C.byref(a), C.byref(b))
+        return bool(on), a.value, b.value
+
     def pcg_path(self):
         """What ran: dict(path = FB_PCG_PATH_* of the last solve, kernel = the persistent instantiation this handle launches or '',
         launches, fallbacks, max_producers)"""

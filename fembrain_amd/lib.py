@@ -170,6 +170,7 @@ def lib():
         "fb_fem_set_exchange_mode": (C.c_int, [vp, C.c_int]),
         "fb_fem_persist_rearms": (C.c_int, [vp]),
         "fb_fem_persist_helpers": (C.c_int, [vp]),
+        "fb_fem_persist_gather": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "fb_fem_renumbering": (C.c_int, [vp, _ip, _ip]),
         "fb_fem_owned_nodes": (C.c_int, [vp, _ip]),
         "fb_fem_halo_info": (C.c_int, [vp, _ip, _ip]),

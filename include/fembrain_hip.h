@@ -350,6 +350,12 @@ int fb_fem_persist_rearms(fb_fem_t h);
  * mesh), wavefronts without a slice of their own multiply the upper part of a wide slice's slots and hand the partial sums over in LDS
  * (fembrain_amd/csrc/pcg_pipe.hip.h).  Chosen by the library from the slice widths; FEMBRAIN_PIPE_HELPERS=0/1 overrides. */
 int fb_fem_persist_helpers(fb_fem_t h);
+/* How the persistent solver lays out the vector its products gather from: 1 = node by node (x, y, z of a node side by side), 0 = three
+ * planes.  Decided from the mesh: lines_planes / lines_records (either may be NULL) receive the cache lines the gathers of one matrix slot
+ * touch on average in the two forms, sampled on the device when the handle was (re)built -- structured meshes ~12-20 / ~12-15 (planes: each
+ * load touches 4 lines), unstructured ones ~80 / ~44 (node by node: 606k-tet Delaunay probe 18.9 -> 16.2 us per PCG iteration).  0 / 0 where
+ * it was not measured (handles outside the one-row persistent kernel's range).  FEMBRAIN_PIPE_XYZ=0/1 overrides. */
+int fb_fem_persist_gather(fb_fem_t h, double* lines_planes, double* lines_records);
 /* average device seconds of ONE persistent launch that starts a solve of the current system and is cut after n_iters
  * iterations (tolerance out of reach), HIP events on the handle's stream around the launch; the difference of two lengths
  * prices an iteration without the launch's fixed cost */

@@ -1162,6 +1162,35 @@ def test_persistent_solver_against_the_oracle(gpu, monkeypatch, n, c16, kernel):
     g.close()
 
 
+@pytest.mark.parametrize("kind,m", [("cube", 20), ("delaunay", 16), ("delaunay", 22)])
+def test_published_vector_node_by_node_gives_the_same_iterates(gpu, monkeypatch, kind, m):
+    """Round 5: on a mesh whose columns are scattered the persistent solver publishes the vector its products gather from node by node
+    (x, y, z side by side: one cache line per lane and slot instead of three; k_pcg_pipe<..., XYZ>, two gathers per slot in the hand-written
+    stream instead of three).  The library decides from the lines the gathers touch (fb_fem_persist_gather); forced both ways here
+    (FEMBRAIN_PIPE_XYZ) on the same task table: the sums and their order are the same, so iterations and solution are -- bit for bit, also
+    across launch cuts."""
+    v, t, fixed = _cube(m) if kind == "cube" else _delaunay_lattice(m)
+    monkeypatch.setenv("FEMBRAIN_PERSIST_MIN_WAVES", "1")
+    out = []
+    for xyz in ("1", "0"):
+        monkeypatch.setenv("FEMBRAIN_PIPE_XYZ", xyz)
+        g = FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT, matrix_precision=fl.FB_MATRIX_F32)
+        assert g.persist_gather()[0] == (xyz == "1") and g.persist_gather()[1] > 0
+        g.set_uniform_force(1, -100.0)
+        _, rhs = g.system()
+        it, x = g.pcg(rhs, eps=1e-6, max_iter=20000)
+        assert g.pcg_path()["path"] == fl.FB_PCG_PATH_PERSISTENT and g.pcg_path()["fallbacks"] == 0 and it > 30
+        if xyz == "1":
+            for run in ("1", "7"):
+                monkeypatch.setenv("FEMBRAIN_PERSIST_MAX_RUN", run)
+                itc, xc = g.pcg(rhs, eps=1e-6, max_iter=20000)
+                assert itc == it and np.array_equal(xc, x), run
+            monkeypatch.delenv("FEMBRAIN_PERSIST_MAX_RUN")
+        out.append((it, x))
+        g.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+
+
 def _delaunay_lattice(m, seed=2):
     """Delaunay tetrahedra of an m^3 lattice with jittered points: hull nodes with 40 and more neighbours next to interior nodes with 15"""
     from scipy.spatial import Delaunay
@@ -1224,6 +1253,11 @@ def test_persistent_solver_with_helper_wavefronts(gpu, monkeypatch, kind, m, for
     else:       # (these meshes are small: whole slices resident, more slots than the unrolled loop takes; helpers only where something is still streamed)
         assert gp.persist_info()[3] > 6 and g0.persist_info()[3] <= 8, (gp.persist_info(), g0.persist_info())
     deep = n_help == 0
+    # (round 5: where the columns of a slot are scattered the published vector lies node by node -- decided from the cache lines the gathers
+    # touch, sampled on the device: the Delaunay lattices yes, the cubes no; both forms give the same sums in the same order)
+    xyz, lp, lr = gp.persist_gather()
+    assert lp > 0 and lr > 0 and xyz == (kind == "delaunay" and lp >= 30 and lp >= 1.5 * lr), (xyz, lp, lr)
+    assert not (kind == "cube" and xyz), (kind, m, xyz, lp, lr)   # (these lattices are small: 27-30 lines against 21-23, planes; the 91,125-node probe has 80 against 44)
     if expect:
         assert gp.pcg_path()["kernel"].startswith("k_pcg_pipe<float,") and gp.pcg_path()["kernel"].endswith(",12,6>")
     for g in (gm, gp, g0):

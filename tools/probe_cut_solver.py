@@ -35,5 +35,5 @@ for cut in range(3):
     print(json.dumps(dict(cuts=cut, nodes=len(v), tets=len(t), kernel=g.pcg_path()["kernel"], iterations=its, us_per_iteration=us, renumbering=g.renumbering(),
                           slices=int(len(w)), slots=int(so[-1]), blocks=int(nnz), padding=round(float(so[-1]) * 64 / nnz - 1, 3),
                           widths=dict(max=int(w.max()), mean=round(float(w.mean()), 2), p50=int(np.percentile(w, 50)), p90=int(np.percentile(w, 90)), p99=int(np.percentile(w, 99))),
-                          spmv_mb=round(g.spmv_bytes() / 1e6, 1), persist=g.persist_info() if hasattr(g, "persist_info") else None)), flush=True)
+                          spmv_mb=round(g.spmv_bytes() / 1e6, 1), persist=g.persist_info(), gather=g.persist_gather())), flush=True)
     g.close()

@@ -95,7 +95,7 @@ def main():
             its.append(it)
             us.append(g.last.solve_seconds / max(it, 1) * 1e6)
         row["renumbering"] = g.renumbering()
-        row.update(iterations=its, us_per_iteration=[round(u, 2) for u in us], path=g.pcg_path(), persist=g.persist_info(),
+        row.update(iterations=its, us_per_iteration=[round(u, 2) for u in us], path=g.pcg_path(), persist=g.persist_info(), gather=g.persist_gather(),
                    spmv_mb=round(g.spmv_bytes() / 1e6, 1), spmv_us=round(g.time_spmv(50) * 1e6, 2),
                    assembly_us=round(g.time_assembly(10) * 1e6, 1), assembly_kernel=int(g._L.fb_fem_assembly_kernel(g.h)))
         # widths of the SELL slices (the element-major assembly takes up to 31 slots; wider slices went to the slot-major kernel)
