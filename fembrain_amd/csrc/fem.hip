@@ -66,6 +66,7 @@ struct fb_fem_s {
   int pipe_help_waves = 0;           // wavefronts launched beyond slices + service wavefront, for the helpers (0: none)
   DevBuf<unsigned long long> pipe_lines;  // k_gather_lines' three sums
   bool pipe_xyz = false;             // the published vector node by node instead of in planes (irregular meshes; k_pcg_pipe<..., XYZ>)
+  int pipe_lines_nodes = 0;          // nodes of the plan the counts below were taken on
   double pipe_gather_lines[2] = {0, 0};  // cache lines a slot's gathers touch on average: three planes | 24-byte records (k_gather_lines; 0: not measured)
   int pipe_n_help = 0, pipe_help_tasks = 0;  // most helper tasks of a workgroup; all of them
   int asm_wide = 0;                  // slices wider than the element-major kernel takes (kIncMaxWidth slots): k_assemble_wide assembles those
@@ -593,8 +594,17 @@ int setup_persist(fb_fem_s* h) {
     // and more per slot and half again the records' (606k-tet Delaunay probe: 80 against 44 lines, 18.9 -> 16.4 us per iteration; the cube
     // after a cut: 19 against 15, and there the planes are the faster form, 19.4 against 20.6, each load touching 4 lines instead of 12).  FEMBRAIN_PIPE_XYZ=0/1 overrides.  (The table-driven instantiation carries the layout.)
     bool want_xyz = false;
-    h->pipe_gather_lines[0] = h->pipe_gather_lines[1] = 0.0;
-    if (w <= kPipeMaxWaves && P.n_local < (1 << 24) && h->colidx.p) {
+    // (a re-sync that changes the mesh by a few per cent keeps the counts of the plan before it: the read-back is a host wait)
+    const bool keep_lines = h->pipe_gather_lines[0] > 0.0 && h->pipe_lines_nodes > 0 && std::abs(P.n_local - h->pipe_lines_nodes) * 20 <= h->pipe_lines_nodes;
+    if (keep_lines) {
+      const char* ex = getenv("FEMBRAIN_PIPE_XYZ");
+      want_xyz = w <= kPipeMaxWaves && P.n_local < (1 << 24) &&
+                 (ex ? atoi(ex) != 0 : (h->pipe_gather_lines[0] >= 30.0 && h->pipe_gather_lines[0] >= 1.5 * h->pipe_gather_lines[1]));
+    } else {
+      h->pipe_gather_lines[0] = h->pipe_gather_lines[1] = 0.0;
+      h->pipe_lines_nodes = 0;
+    }
+    if (!keep_lines && w <= kPipeMaxWaves && P.n_local < (1 << 24) && h->colidx.p) {
       FB_TRY(h->pipe_lines.alloc(4));
       FB_HIP(hipMemsetAsync(h->pipe_lines.p, 0, 4 * sizeof(unsigned long long), s));
       hipLaunchKernelGGL(k_gather_lines, dim3(64), dim3(256), 0, s, P.n_slices, 8, h->slice_off.p, h->colidx.p, h->pipe_lines.p);
@@ -602,7 +612,7 @@ int setup_persist(fb_fem_s* h) {
       unsigned long long got[3] = {0, 0, 0};
       FB_HIP(hipMemcpyAsync(got, h->pipe_lines.p, sizeof got, hipMemcpyDeviceToHost, s));
       FB_HIP(hipStreamSynchronize(s));
-      if (got[2]) { h->pipe_gather_lines[0] = 3.0 * (double)got[0] / (double)got[2]; h->pipe_gather_lines[1] = (double)got[1] / (double)got[2]; }
+      if (got[2]) { h->pipe_gather_lines[0] = 3.0 * (double)got[0] / (double)got[2]; h->pipe_gather_lines[1] = (double)got[1] / (double)got[2]; h->pipe_lines_nodes = P.n_local; }
       const char* ex = getenv("FEMBRAIN_PIPE_XYZ");
       want_xyz = ex ? atoi(ex) != 0 : (got[2] && h->pipe_gather_lines[0] >= 30.0 && h->pipe_gather_lines[0] >= 1.5 * h->pipe_gather_lines[1]);
     }
