@@ -581,13 +581,13 @@ int setup_persist(fb_fem_s* h) {
   // the longest streams, longest first, until none is left or no stream is longer than 2 x 8 slots.  FEMBRAIN_PIPE_HELPERS=0/1 overrides.
   h->pipe_tasks.release();
   h->pipe_help_waves = 0; h->pipe_n_help = 0; h->pipe_help_tasks = 0;
-  if (h->pipe_rows == 1 && !bj && !small && P.n_ranks == 1 && !P.slice_off.empty()) {
+  if (!bj && !small && P.n_ranks == 1 && !P.slice_off.empty()) {  // (one row per lane: helpers and layout; two rows per lane: the layout)
     int mx = 0;
     long long tot = 0;
     for (int sl = 0; sl < P.n_slices; sl++) { const int wd = P.slice_off[sl + 1] - P.slice_off[sl]; mx = std::max(mx, wd); tot += wd; }
     const double mean = P.n_slices ? (double)tot / P.n_slices : 0.0;
     const char* eh = getenv("FEMBRAIN_PIPE_HELPERS");
-    const bool want_h = eh ? atoi(eh) != 0 : (mx > 24 && (double)mx >= 1.5 * mean);
+    const bool want_h = h->pipe_rows == 1 && (eh ? atoi(eh) != 0 : (mx > 24 && (double)mx >= 1.5 * mean));
     // Where do the columns of a slot lie?  On a structured mesh the 64 rows of a slice have consecutive columns and a gather touches 4 lines
     // of each of the three planes of the published vector; on an unstructured one it touches ~50 of each, and a vector stored node by node
     // (24-byte records) costs half of those.  Sampled on the device (every 8th slice), decided here: node by node where the planes cost 30 lines
@@ -598,13 +598,13 @@ int setup_persist(fb_fem_s* h) {
     const bool keep_lines = h->pipe_gather_lines[0] > 0.0 && h->pipe_lines_nodes > 0 && std::abs(P.n_local - h->pipe_lines_nodes) * 20 <= h->pipe_lines_nodes;
     if (keep_lines) {
       const char* ex = getenv("FEMBRAIN_PIPE_XYZ");
-      want_xyz = w <= kPipeMaxWaves && P.n_local < (1 << 24) &&
+      want_xyz = P.n_local < (1 << 24) &&
                  (ex ? atoi(ex) != 0 : (h->pipe_gather_lines[0] >= 30.0 && h->pipe_gather_lines[0] >= 1.5 * h->pipe_gather_lines[1]));
     } else {
       h->pipe_gather_lines[0] = h->pipe_gather_lines[1] = 0.0;
       h->pipe_lines_nodes = 0;
     }
-    if (!keep_lines && w <= kPipeMaxWaves && P.n_local < (1 << 24) && h->colidx.p) {
+    if (!keep_lines && P.n_local < (1 << 24) && h->colidx.p) {
       FB_TRY(h->pipe_lines.alloc(4));
       FB_HIP(hipMemsetAsync(h->pipe_lines.p, 0, 4 * sizeof(unsigned long long), s));
       hipLaunchKernelGGL(k_gather_lines, dim3(64), dim3(256), 0, s, P.n_slices, 8, h->slice_off.p, h->colidx.p, h->pipe_lines.p);
@@ -616,8 +616,8 @@ int setup_persist(fb_fem_s* h) {
       const char* ex = getenv("FEMBRAIN_PIPE_XYZ");
       want_xyz = ex ? atoi(ex) != 0 : (got[2] && h->pipe_gather_lines[0] >= 30.0 && h->pipe_gather_lines[0] >= 1.5 * h->pipe_gather_lines[1]);
     }
-    h->pipe_xyz = false;
-    if ((want_h || want_xyz) && w <= kPipeMaxWaves) {
+    h->pipe_xyz = h->pipe_rows == 2 && want_xyz;  // (the two-row kernel: a template parameter; the one-row kernel: with its task table, below)
+    if (h->pipe_rows == 1 && (want_h || want_xyz) && w <= kPipeMaxWaves) {
       const int help_waves = std::max(0, kPipeMaxWaves - w - 1);   // (the 12-wavefront kernel: slices, helpers, the service wavefront)
       std::vector<int4> tasks((size_t)nb * kPipeTaskStride, make_int4(-1, 0, 0, 0));
       int most = 0, all = 0, deepest = 0;
@@ -1381,10 +1381,10 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     hipLaunchKernelGGL((k_pcg_pipe<float, C16, WMAX, KLT, false, false, true>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p,  \
                        (const float*)h->dlo.p, h->invblk.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);           \
   } while (0)
-#define FB_PIPE2(C16, SHARD)                                                                                                                          \
+#define FB_PIPE2(C16, SHARD, XYZ)                                                                                                                     \
   do {                                                                                                                                                \
-    FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe2<C16, SHARD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-    hipLaunchKernelGGL((k_pcg_pipe2<C16, SHARD>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p,        \
+    FB_HIP(hipFuncSetAttribute((const void*)k_pcg_pipe2<C16, SHARD, XYZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+    hipLaunchKernelGGL((k_pcg_pipe2<C16, SHARD, XYZ>), grid, block, lds, h->stream, sell_view(h), (const float*)h->vals.p, (const float*)h->dlo.p,   \
                        h->invdiag.p, b, h->x.p, h->r.p, h->Ad.p, h->pipe_z.p, h->pipe_s.p, h->d.p, h->st.p, pa, sa);                                  \
   } while (0)
   static_assert(sizeof(double) * kPipeSyncDoubles + (size_t)kPipeMaxWaves * 2 * kPipe2LdsWordsPerRow * 64 * 4 <= 160 * 1024, "LDS budget of k_pcg_pipe2");
@@ -1395,11 +1395,12 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     if (h->pipe_wmax == 8) { if (h->c16) FB_PIPE_BJ(true, 8, 8); else FB_PIPE_BJ(false, 8, 8); }
     else { if (h->c16) FB_PIPE_BJ(true, 12, 6); else FB_PIPE_BJ(false, 12, 6); }
   } else if (h->shard_persist) {
-    if (h->pipe_rows == 2) FB_PIPE2(false, true);
+    if (h->pipe_rows == 2) FB_PIPE2(false, true, false);
     else if (h->pipe_wmax == 8) FB_PIPE(false, 8, 8, false, true);
     else FB_PIPE(false, 12, 6, false, true);
   } else if (h->pipe_rows == 2) {
-    if (h->c16) FB_PIPE2(true, false); else FB_PIPE2(false, false);
+    if (h->pipe_xyz) { if (h->c16) FB_PIPE2(true, false, true); else FB_PIPE2(false, false, true); }
+    else { if (h->c16) FB_PIPE2(true, false, false); else FB_PIPE2(false, false, false); }
   } else if (h->pipe_tasks.p) {  // helper wavefronts (setup_persist): the (12, 6) kernel compiled with them
     if (h->pipe_xyz) {  // (the published vector node by node)
       if (pa.timing) { if (h->c16) FB_PIPE_HELP(true, true, true); else FB_PIPE_HELP(false, true, true); }

@@ -27,13 +27,15 @@ __host__ __device__ constexpr int pipe2_lds_slots(int count, bool c16) {
 }
 
 // SHARD: the kernel of a sharded handle ("k_pcg_pipe2_shard" in fb_fem_pcg_path; pcg_shard_box.hip.h) -- as for k_pcg_pipe
-template <bool C16, bool SHARD>
+// XYZ: the published vector node by node instead of in planes (pcg_pipe.hip.h; unstructured meshes, unsharded handles)
+template <bool C16, bool SHARD, bool XYZ = false>
 __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, const float* __restrict__ vals, const float* __restrict__ dlo,
                                                                   const double* __restrict__ invdiag, const double* __restrict__ bvec,
                                                                   double* __restrict__ xg, double* __restrict__ rg, double* __restrict__ wg,
                                                                   double* __restrict__ zg, double* __restrict__ sg, double* __restrict__ pg,
                                                                   CGState* __restrict__ st, PipeArgs pa, ShardArgs sa) {
   static_assert(!SHARD || !C16, "a shard's columns are 32-bit local ids");
+  static_assert(!SHARD || !XYZ, "a shard publishes planes");
   extern __shared__ double lds[];
   double* wsum = lds;                          // [2][16] wave sums
   double* gath = lds + 32;                     // [2][kPipeMaxBlocks] all workgroups' sums
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
 
   // (publish / product: as in k_pcg_pipe, for the two rows of the lane; write-through stores always -- the plain-store form is
   // for the latency-bound small systems)
+  const size_t xs = XYZ ? 1 : pa.n_pad, cs = XYZ ? 3 : 1;  // strides of a component and of a column in the published vector
   auto publish = [&](const double vin[2][3]) {
     pub++;
     double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
     for (int h = 0; h < 2; h++)
       if (rvalid[h]) {
 #pragma unroll
-        for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * pa.n_pad + (size_t)row[h], vin[h][a]);
+        for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * xs + cs * (size_t)row[h], vin[h][a]);
         if constexpr (SHARD) shard_send_row(sa, BL, pub, send_beg[h], send_end[h], vin[h]);
       }
   };
@@ -204,8 +207,8 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
           const unsigned int* lk = lv + (size_t)k * kValWords * 64;
           unsigned int col;
           if constexpr (C16) col = (unsigned int)(row[h] + (int)lc[k * 64]); else col = lk[9 * 64];
-          const double* xp = pl + (size_t)col;
-          const double x0 = xp[0], x1 = xp[pa.n_pad], x2 = xp[2 * pa.n_pad];
+          const double* xp = pl + cs * (size_t)col;
+          const double x0 = xp[0], x1 = xp[xs], x2 = xp[2 * xs];
           y0 += (double)__uint_as_float(lk[0 * 64]) * x0 + (double)__uint_as_float(lk[1 * 64]) * x1 + (double)__uint_as_float(lk[2 * 64]) * x2;
           y1 += (double)__uint_as_float(lk[3 * 64]) * x0 + (double)__uint_as_float(lk[4 * 64]) * x1 + (double)__uint_as_float(lk[5 * 64]) * x2;
           y2 += (double)__uint_as_float(lk[6 * 64]) * x0 + (double)__uint_as_float(lk[7 * 64]) * x1 + (double)__uint_as_float(lk[8 * 64]) * x2;
@@ -214,9 +217,9 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
       if (live[h] && width[h] > KL[h]) {
         int so_k = so[h] + KL[h];
         asm volatile("" : "+s"(so_k));
-        pipe_stream_slots<C16>(width[h] - KL[h], ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
+        pipe_stream_slots<C16, XYZ>(width[h] - KL[h], ((unsigned int)so_k * 9u * 64u + (unsigned int)lane) * (unsigned int)sizeof(float),
                                ((unsigned int)so_k * 64u + (unsigned int)lane) * (unsigned int)(C16 ? sizeof(short) : sizeof(int)), vals,
-                               C16 ? (const void*)sv.coldelta : (const void*)sv.colidx, pl, pl + pa.n_pad, pl + 2 * pa.n_pad, row[h], y0, y1, y2);
+                               C16 ? (const void*)sv.coldelta : (const void*)sv.colidx, pl, pl + xs, pl + 2 * xs, row[h], y0, y1, y2);
       }
       y[h][0] = y0; y[h][1] = y1; y[h][2] = y2;
     }

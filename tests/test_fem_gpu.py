@@ -1162,8 +1162,8 @@ def test_persistent_solver_against_the_oracle(gpu, monkeypatch, n, c16, kernel):
     g.close()
 
 
-@pytest.mark.parametrize("kind,m", [("cube", 20), ("delaunay", 16), ("delaunay", 22)])
-def test_published_vector_node_by_node_gives_the_same_iterates(gpu, monkeypatch, kind, m):
+@pytest.mark.parametrize("kind,m,rows", [("cube", 20, 1), ("delaunay", 16, 1), ("delaunay", 22, 1), ("cube", 20, 2), ("delaunay", 22, 2)])
+def test_published_vector_node_by_node_gives_the_same_iterates(gpu, monkeypatch, kind, m, rows):
     """Round 5: on a mesh whose columns are scattered the persistent solver publishes the vector its products gather from node by node
     (x, y, z side by side: one cache line per lane and slot instead of three; k_pcg_pipe<..., XYZ>, two gathers per slot in the hand-written
     stream instead of three).  The library decides from the lines the gathers touch (fb_fem_persist_gather); forced both ways here
@@ -1171,6 +1171,8 @@ def test_published_vector_node_by_node_gives_the_same_iterates(gpu, monkeypatch,
     across launch cuts."""
     v, t, fixed = _cube(m) if kind == "cube" else _delaunay_lattice(m)
     monkeypatch.setenv("FEMBRAIN_PERSIST_MIN_WAVES", "1")
+    if rows == 2:
+        monkeypatch.setenv("FEMBRAIN_PERSIST_ROWS", "2")          # (the two-row kernel, k_pcg_pipe2<..., XYZ>, on a mesh far below its range)
     out = []
     for xyz in ("1", "0"):
         monkeypatch.setenv("FEMBRAIN_PIPE_XYZ", xyz)
@@ -1180,6 +1182,7 @@ def test_published_vector_node_by_node_gives_the_same_iterates(gpu, monkeypatch,
         _, rhs = g.system()
         it, x = g.pcg(rhs, eps=1e-6, max_iter=20000)
         assert g.pcg_path()["path"] == fl.FB_PCG_PATH_PERSISTENT and g.pcg_path()["fallbacks"] == 0 and it > 30
+        assert g.pcg_path()["kernel"].startswith("k_pcg_pipe2<" if rows == 2 else "k_pcg_pipe<")
         if xyz == "1":
             for run in ("1", "7"):
                 monkeypatch.setenv("FEMBRAIN_PERSIST_MAX_RUN", run)
