@@ -229,6 +229,46 @@ def numbering_leg(device, prec):
             "resync_ms_all": [round(x, 3) for x in rs]}
 
 
+def unstructured_leg(device, prec, m=45):
+    """an UNSTRUCTURED mesh -- Delaunay tetrahedra of a jittered 45^3 lattice in random node order (606k tets, hull nodes
+    with 40-60 neighbours; fembrain_amd.meshgen.delaunay_jittered) -- the class of every TetGen mesh the reference ships and of every mesh
+    after a cut.  Reported: the solver kernel and its us per PCG iteration, how the gathered vector is laid out and why (cache lines per
+    slot), one assembly, the slice widths."""
+    from fembrain_amd import lib as fl
+    from fembrain_amd.fem import FemIntegrator
+    from fembrain_amd.meshgen import delaunay_jittered, fixed_vertices_to_dofs
+    v, t, fv = delaunay_jittered(m)
+    g = FemIntegrator(v, t, fixed_vertices_to_dofs(fv), matrix_precision=prec, device=device)
+    its, solve = [], 0.0
+    for k in range(3):
+        g.reset_to_rest()
+        g.set_uniform_force(1, -100.0)
+        it = g.do_timestep()
+        if k:
+            its.append(it)
+            solve += g.last.solve_seconds
+    asm = g.time_assembly(10)
+    L = g._L
+    cnt = L.fb_fem_device_plan_get(g.h, b"slice_off", None, 0)
+    so = np.zeros(cnt, np.int32)
+    L.fb_fem_device_plan_get(g.h, b"slice_off", fl.iptr(so), cnt)
+    w = np.diff(so)
+    xyz, lp, lr = g.persist_gather()
+    on, sc, si = g.renumbering()
+    path = g.pcg_path()
+    out = {"workload": "Delaunay tetrahedra of a jittered %d^3 lattice, nodes in random order: %d nodes, %d tets" % (m, len(v), len(t)),
+           "renumbered": bool(on), "widest_element_internal_order": si, "pcg_kernel": path["kernel"], "max_producers_per_workgroup": path["max_producers"],
+           "helper_tasks": int(L.fb_fem_persist_helpers(g.h)),
+           "gathered_vector": {"layout": "node by node (24-byte records)" if xyz else "three planes", "cache_lines_per_slot_planes": round(lp, 1),
+                               "cache_lines_per_slot_records": round(lr, 1)},
+           "cg_iterations": [int(i) for i in its], "us_per_cg_iteration": solve / max(sum(its), 1) * 1e6,
+           "assembly_us": asm * 1e6, "assembly_kernel": int(L.fb_fem_assembly_kernel(g.h)), "assembly_wide_slices": int(L.fb_fem_assembly_wide_slices(g.h)),
+           "slice_widths": {"slices": int(len(w)), "max": int(w.max()), "mean": round(float(w.mean()), 2), "wider_than_31": int((w > 31).sum())},
+           "spmv_mb": g.spmv_bytes() / 1e6}
+    g.close()
+    return out
+
+
 def block_jacobi_leg(device, prec, steps=5):
     """the headline mesh with the OPT-IN 3x3 block-Jacobi preconditioner (FB_PCG_BLOCK_JACOBI, not the reference's
     preconditioner, outside every parity claim and never part of `value`) inside the same persistent kernel (k_pcg_pipe<.., BJ>):
@@ -974,6 +1014,9 @@ def main():
             leg, why = stage("leg: scrambled node order", lambda: numbering_leg(device, prec), optional=True)
             if out is not None:
                 out["cube56_scrambled"] = leg if leg else {"error": why}
+            leg, why = stage("leg: unstructured mesh", lambda: unstructured_leg(device, prec), optional=True)
+            if out is not None:
+                out["delaunay606k"] = leg if leg else {"error": why}
             leg, why = stage("leg: re-sync after a cut", lambda: cut_resync_leg(device, prec), optional=True)
             if out is not None:
                 out["cut_resync"] = leg if leg else {"error": why}

@@ -491,3 +491,20 @@ def test_synthetic_cut_and_apply_delta_describe_the_same_mesh():
         kept[d["removed"]] = False
         kept[d["changed_ids"]] = False
         assert np.array_equal(t2[: kept.sum() + len(d["changed_ids"])][~np.isin(np.nonzero(np.ones(len(t), bool) & ~np.isin(np.arange(len(t)), d["removed"]))[0], d["changed_ids"])], t[kept])
+
+
+def test_unstructured_mesh_generator_gives_positive_elements_and_uneven_valences():
+    """fembrain_amd.meshgen.delaunay_jittered (bench.py's `delaunay606k` leg, tools/probe_numbering.py case d): every element positively
+    oriented, every node used, a fixed slab, and the valences of an unstructured mesh -- hull nodes with several times the neighbours of
+    an interior node; the same seed gives the same mesh"""
+    from fembrain_amd.meshgen import delaunay_jittered
+    v, t, f = delaunay_jittered(10)
+    assert v.shape == (1000, 3) and t.dtype == np.int32 and t.min() == 0 and t.max() == 999 and len(np.unique(t)) == 1000
+    vol = np.einsum("ij,ij->i", v[t[:, 1]] - v[t[:, 0]], np.cross(v[t[:, 2]] - v[t[:, 0]], v[t[:, 3]] - v[t[:, 0]])) / 6
+    assert (vol > 0).all() and abs(vol.sum() - ((v.max(0) - v.min(0)).prod())) < 0.2 * vol.sum()
+    assert 0 < len(f) < 200 and (v[f, 0] < 0.1).all()
+    pairs = np.unique(np.sort(np.concatenate([t[:, [i, j]] for i in range(4) for j in range(i + 1, 4)]), axis=1), axis=0)
+    val = np.bincount(pairs.ravel(), minlength=1000)
+    assert val.max() >= 2 * np.median(val)
+    v2, t2, f2 = delaunay_jittered(10)
+    assert np.array_equal(v, v2) and np.array_equal(t, t2) and np.array_equal(f, f2)

@@ -58,17 +58,9 @@ def cases(n):
     yield "c_surface_first", *relabel(v, t, fx, new_of_old)
     if os.environ.get("PROBE_DELAUNAY", "1") != "0":
         # (d) an UNSTRUCTURED mesh: Delaunay tetrahedra of a jittered grid (no grid order to find again), nodes in random order
-        from scipy.spatial import Delaunay
-        m = max(8, int(round(n * 0.8)))
-        g = np.stack(np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float64)
-        pts = (g + rng.uniform(-0.35, 0.35, size=g.shape)) * 0.1
-        pts = pts[rng.permutation(len(pts))]
-        tt = Delaunay(pts).simplices.astype(np.int32)
-        vol = np.einsum("ij,ij->i", pts[tt[:, 1]] - pts[tt[:, 0]], np.cross(pts[tt[:, 2]] - pts[tt[:, 0]], pts[tt[:, 3]] - pts[tt[:, 0]])) / 6
-        tt = tt[np.abs(vol) > 1e-6 * 1e-3]
-        neg = vol[np.abs(vol) > 1e-6 * 1e-3] < 0
-        tt[neg] = tt[neg][:, [0, 2, 1, 3]]
-        yield "d_delaunay_jittered_random_order", pts, np.ascontiguousarray(tt), np.nonzero(pts[:, 0] < 0.1)[0].astype(np.int32)
+        from fembrain_amd.meshgen import delaunay_jittered
+        pts, tt, fxd = delaunay_jittered(max(8, int(round(n * 0.8))))
+        yield "d_delaunay_jittered_random_order", pts, tt, fxd
 
 
 def main():
