@@ -53,6 +53,15 @@ def run(name, v, t, fixed, steps, load):
 for n, steps in ((34, 150), (40, 150), (52, 80), (56, 80), (60, 40), (73, 20)):
     run("cube%d" % n, *cube(n), steps, -10000.0)
 run("delaunay60k", *delaunay(60000), 60, -50.0)
+# round 5: the table-driven instantiation with helpers and the node-by-node vector (606k-tet jittered lattice), the two-row kernel with the
+# node-by-node vector (1.44M tets), the cube after a cut (slices dealt by slots, idle wavefronts helping at 12 slices per CU)
+from fembrain_amd.meshgen import delaunay_jittered, synthetic_cut  # noqa: E402
+for m, steps in ((45, 30), (60, 10)):
+    dv, dt_, dfv = delaunay_jittered(m)
+    run("jittered%d" % m, dv, dt_, fixed_vertices_to_dofs(dfv), steps, -100.0)
+cv, ct, cf = cube(56)
+cv, ct, _ = synthetic_cut(cv, ct, axis=1, where=0.23)
+run("cube56_cut", cv, ct, cf, 30, -10000.0)
 # two handles alternating on one device: their persistent launches serialise on their streams' turns, none may starve the other
 a, b = FemIntegrator(*cube(40)), FemIntegrator(*cube(44))
 for k in range(100):
