@@ -628,6 +628,9 @@ int setup_persist(fb_fem_s* h) {
       // still gathers its x entries from L2 / the fabric, and the compiled loop over resident slots has 6 slots' gathers in flight where
       // the hand-written stream never drains; on these meshes the product waits for gathers, not for matrix bytes.
       const bool even_share = !(getenv("FEMBRAIN_PIPE_LDS_BY_WIDTH") && atoi(getenv("FEMBRAIN_PIPE_LDS_BY_WIDTH")) != 0);
+      // (with the node-by-node vector a resident slot's gathers cost a third of the lines, and slices that keep up to 12 slots in LDS instead
+      // of 6 pay: sliver-free unstructured probe 16.2 -> 14.4 us per iteration, Delaunay probe 16.25 -> 15.9; 18 buys nothing more)
+      const int lds_cap = want_xyz ? 12 : 6;
       for (int b = 0; b < nb; b++) {
         int first, count;
         pipe_deal(h->pipe_wg_first_host.empty() ? nullptr : h->pipe_wg_first_host.data(), P.n_slices, nb, b, &first, &count);
@@ -639,7 +642,10 @@ int setup_persist(fb_fem_s* h) {
         // still stream.  First with the helpers' hand-over area set aside; a workgroup that gets no helper is dealt again with all of it.
         auto deal_lds = [&](int lds_slots) {
           if (even_share) {
-            const int lbase = std::min(6, lds_slots / std::max(count, 1)), lrem = lbase < 6 ? std::min(count, lds_slots - lbase * count) : 0;
+            // (most slots of a slice in LDS: the unroll bound of the plain kernel, 6 -- or FEMBRAIN_PIPE_LDS_CAP, development: further groups of
+            // six run in the table-driven kernel's second loop)
+            const int cap = getenv("FEMBRAIN_PIPE_LDS_CAP") ? std::max(1, atoi(getenv("FEMBRAIN_PIPE_LDS_CAP"))) : lds_cap;
+            const int lbase = std::min(cap, lds_slots / std::max(count, 1)), lrem = lbase < cap ? std::min(count, lds_slots - lbase * count) : 0;
             for (int j = 0; j < count; j++) res[j] = std::min(wd[j], lbase + (j < lrem ? 1 : 0));
             return;
           }

@@ -40,10 +40,12 @@ def fixed_vertices_to_dofs(fixed_vertices):
     return (3 * v[:, None] + np.arange(3, dtype=np.int32)[None, :]).reshape(-1).astype(np.int32)
 
 
-def delaunay_jittered(m, jitter=0.35, cellsize=0.1, seed=12345, shuffle=True):
+def delaunay_jittered(m, jitter=0.35, cellsize=0.1, seed=12345, shuffle=True, max_edge=None):
     """An UNSTRUCTURED synthetic mesh: Delaunay tetrahedra (scipy) of an m^3 lattice whose points are moved by up to `jitter` cells, nodes
     in random order (no grid order to find again); slivers dropped, elements oriented positively.  Hull nodes get 40-60 neighbours where an
-    interior node has ~15: what a TetGen mesh of a body looks like to the solver.  Returns (vertices, tets, fixed vertices = the slab x < one cell)."""
+    interior node has ~15: what a TetGen mesh of a body looks like to the solver.  max_edge (in cells): also drop the elements with a longer
+    edge -- the flat hull elements that join far-apart hull points, which a quality mesher would not produce.
+    Returns (vertices, tets, fixed vertices = the slab x < one cell)."""
     from scipy.spatial import Delaunay
     rng = np.random.default_rng(seed)
     g = np.stack(np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float64)
@@ -53,6 +55,12 @@ def delaunay_jittered(m, jitter=0.35, cellsize=0.1, seed=12345, shuffle=True):
     tt = Delaunay(pts).simplices.astype(np.int32)
     vol = np.einsum("ij,ij->i", pts[tt[:, 1]] - pts[tt[:, 0]], np.cross(pts[tt[:, 2]] - pts[tt[:, 0]], pts[tt[:, 3]] - pts[tt[:, 0]])) / 6
     keep = np.abs(vol) > 1e-6 * cellsize ** 3
+    if max_edge is not None:
+        longest = np.zeros(len(tt))
+        for i in range(4):
+            for j in range(i + 1, 4):
+                longest = np.maximum(longest, np.linalg.norm(pts[tt[:, i]] - pts[tt[:, j]], axis=1))
+        keep &= longest <= max_edge * cellsize
     tt, vol = tt[keep], vol[keep]
     tt[vol < 0] = tt[vol < 0][:, [0, 2, 1, 3]]
     return pts, np.ascontiguousarray(tt), np.nonzero(pts[:, 0] < cellsize)[0].astype(np.int32)

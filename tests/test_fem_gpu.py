@@ -1167,10 +1167,12 @@ def test_published_vector_node_by_node_gives_the_same_iterates(gpu, monkeypatch,
     """Round 5: on a mesh whose columns are scattered the persistent solver publishes the vector its products gather from node by node
     (x, y, z side by side: one cache line per lane and slot instead of three; k_pcg_pipe<..., XYZ>, two gathers per slot in the hand-written
     stream instead of three).  The library decides from the lines the gathers touch (fb_fem_persist_gather); forced both ways here
-    (FEMBRAIN_PIPE_XYZ) on the same task table: the sums and their order are the same, so iterations and solution are -- bit for bit, also
-    across launch cuts."""
+    (FEMBRAIN_PIPE_XYZ), helpers off (their partial sums would be cut at other slots: with the node-by-node vector a slice keeps up to 12
+    slots in LDS instead of 6): the sums of a row and their order are the same, so iterations and solution are -- bit for bit, also across
+    launch cuts, against the plain kernel with planes."""
     v, t, fixed = _cube(m) if kind == "cube" else _delaunay_lattice(m)
     monkeypatch.setenv("FEMBRAIN_PERSIST_MIN_WAVES", "1")
+    monkeypatch.setenv("FEMBRAIN_PIPE_HELPERS", "0")
     if rows == 2:
         monkeypatch.setenv("FEMBRAIN_PERSIST_ROWS", "2")          # (the two-row kernel, k_pcg_pipe2<..., XYZ>, on a mesh far below its range)
     out = []
@@ -1178,6 +1180,8 @@ def test_published_vector_node_by_node_gives_the_same_iterates(gpu, monkeypatch,
         monkeypatch.setenv("FEMBRAIN_PIPE_XYZ", xyz)
         g = FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT, matrix_precision=fl.FB_MATRIX_F32)
         assert g.persist_gather()[0] == (xyz == "1") and g.persist_gather()[1] > 0
+        if rows == 1:
+            assert (g.persist_info()[3] > 8) == (xyz == "1"), g.persist_info()      # (these meshes have a slice or two per CU: 12 slots against 8)
         g.set_uniform_force(1, -100.0)
         _, rhs = g.system()
         it, x = g.pcg(rhs, eps=1e-6, max_iter=20000)

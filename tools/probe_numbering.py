@@ -59,7 +59,7 @@ def cases(n):
     if os.environ.get("PROBE_DELAUNAY", "1") != "0":
         # (d) an UNSTRUCTURED mesh: Delaunay tetrahedra of a jittered grid (no grid order to find again), nodes in random order
         from fembrain_amd.meshgen import delaunay_jittered
-        pts, tt, fxd = delaunay_jittered(max(8, int(round(n * 0.8))))
+        pts, tt, fxd = delaunay_jittered(max(8, int(round(n * 0.8))), max_edge=float(os.environ["PROBE_MAX_EDGE"]) if os.environ.get("PROBE_MAX_EDGE") else None)
         yield "d_delaunay_jittered_random_order", pts, tt, fxd
 
 
