@@ -88,6 +88,12 @@ __device__ __forceinline__ void st_sc1_u64(unsigned long long* p, unsigned long 
 __device__ __forceinline__ void st_sc1_u32(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned int ld_sc1_u32(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a node's three doubles (24 consecutive bytes, 8-byte aligned) in two stores instead of three, write-through like st_sc1_f64
+__device__ __forceinline__ void st_sc1_xyz(double* p, double x, double y, double z) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2 xy = {x, y};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %0, %2, off offset:16 sc1" : : "v"(p), "v"(xy), "v"(z) : "memory");
+}
 // one 16-byte sc1 load, waited for (a poll of four flags / two granules in one request)
 __device__ __forceinline__ uint4 ld_sc1_u128(const void* p) {
   uint4 v;
@@ -422,7 +428,9 @@ __global__ __launch_bounds__(64 * WMAX) void k_pcg_pipe(SellView sv, const MT* _
     pub++;
     double* pl = pa.planes + (size_t)(pub & 1u) * 3 * pa.n_pad;
     if (rvalid) {
-      if (through) {
+      if (XYZ && through) {
+        st_sc1_xyz(pl + 3 * (size_t)row, vin[0], vin[1], vin[2]);
+      } else if (through) {
 #pragma unroll
         for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * xs + cs * (size_t)row, vin[a]);
       } else {
