@@ -128,8 +128,12 @@ __global__ __launch_bounds__(64 * kPipeMaxWaves) void k_pcg_pipe2(SellView sv, c
 #pragma unroll
     for (int h = 0; h < 2; h++)
       if (rvalid[h]) {
+        if constexpr (XYZ) {
+          st_sc1_xyz(pl + 3 * (size_t)row[h], vin[h][0], vin[h][1], vin[h][2]);
+        } else {
 #pragma unroll
-        for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * xs + cs * (size_t)row[h], vin[h][a]);
+          for (int a = 0; a < 3; a++) st_sc1_f64(pl + a * xs + cs * (size_t)row[h], vin[h][a]);
+        }
         if constexpr (SHARD) shard_send_row(sa, BL, pub, send_beg[h], send_end[h], vin[h]);
       }
   };
