@@ -936,7 +936,7 @@ def _jittered_lattice():
 
 
 @pytest.mark.parametrize("case", ["cube14", "cube14_f64", "cube14_tangent", "cube14_newmark", "cube14_block_jacobi", "beam3", "jitter", "jitter_f64", "hub",
-                                  "hub_f64", "hub_tangent", "hub_newmark", "hub_block_jacobi", "hub_delaunay", "hub_delaunay_three_workgroups"])
+                                  "hub_f64", "hub_tangent", "hub_newmark", "hub_newmark3", "hub_block_jacobi", "hub_delaunay", "hub_delaunay_three_workgroups"])
 def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, monkeypatch, case):
     """k_assemble_tets_st / k_assemble_tets (lane walks its row's elements, blocks accumulated in LDS) against k_assemble_rows (FEMBRAIN_ASM_KERNEL=rows):
     raw f and K at a seeded displacement, Keff and rhs of a step, the states after two steps -- all bit for bit, for both matrix
@@ -956,7 +956,7 @@ def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, mo
             kw["matrix_precision"] = fl.FB_MATRIX_F64
         if case.endswith("tangent"):
             kw["exact_tangent"] = True
-        if case.endswith("newmark"):
+        if case.endswith("newmark") or case.endswith("newmark3"):
             kw["integrator"] = fl.FB_INTEGRATOR_NEWMARK
         if case.endswith("block_jacobi"):
             kw["pcg_variant"] = fl.FB_PCG_BLOCK_JACOBI
@@ -986,6 +986,8 @@ def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, mo
         # (a hub node makes ONE slice too wide for the element-major kernel: that slice alone goes through the slot-major kernel, round 5)
         assert fl.lib().fb_fem_assembly_kernel(g.h) == (0 if kern == "rows" else (2 if kern == "tets" and staged else 1))
         assert (fl.lib().fb_fem_assembly_wide_slices(g.h) > 0) == (hub and kern != "rows")
+        if case.endswith("newmark3"):    # (several Newton iterations: every kernel also leaves the residual of ALL DOFs for the error quotient)
+            g.set_newmark(0.25, 0.5, 3, 0.5)
         f, K = g.assemble(u)
         its = []
         for k in range(2):
@@ -993,6 +995,7 @@ def test_element_major_assembly_writes_the_bits_of_the_slot_major_kernel(gpu, mo
                 g.rebuild_elements()     # (the rest data again: the mass entries are formed again with it)
             g.set_uniform_force(1, -2000.0 if not hub and case not in ("jitter", "jitter_f64") else -1.0)
             its.append(g.do_timestep())
+            its.append(g.last.newton_iterations)
         Keff, rhs = g.system()
         out.append((f, K, its, Keff, rhs, g.get_q_state()[0], g.mass()))
         g.close()

@@ -69,6 +69,8 @@ def _worker(rank, world, shm_name, n, variant, steps, q, p2p=0, quit_early=False
         own = g.owned_nodes()
         dofs = (3 * own[:, None].astype(np.int64) + np.arange(3)[None, :]).reshape(-1)
         info = (bool(g.renumbering()[0]),) + tuple(g.halo_info())
+        if os.environ.get("FEMBRAIN_TEST_REPORT_WIDE") == "1":    # (test_sharded_mesh_with_hull_slices_wider_than_the_element_major_kernel_takes)
+            info = info + (int(L.fb_fem_assembly_kernel(g.h)), int(L.fb_fem_assembly_wide_slices(g.h)))
         q.put((rank, its, qq[dofs].copy(), vv[dofs].copy(), dofs, info))
         g.close()
         L.fb_comm_destroy(comm)
@@ -255,6 +257,16 @@ def test_auto_node_order_on_shards_gives_slabs_without_being_asked(gpu, world, p
     ranks and a halo of a plane or two; the steps gathered through fb_fem_owned_nodes equal the unsharded handle's."""
     info = _run_sharded(world, 0, p2p, 1012)
     assert all(on and nbr <= 2 and halo <= 2 * (144 + 13) for on, halo, nbr in info), info
+
+
+def test_sharded_mesh_with_hull_slices_wider_than_the_element_major_kernel_takes(gpu, monkeypatch):
+    """Round 5: the Delaunay mesh of 4,000 random points on 2 ranks.  Hull nodes have 40 and more neighbours, so some slices of a shard
+    are wider than the 31 slots the element-major assembly kernel takes: those go to k_assemble_wide (a workgroup per slice) beside it, on
+    a shard as on an unsharded handle -- the two steps equal the unsharded handle's (checked by _run_sharded), the element-major kernel
+    is the one in use and at least one rank has such slices."""
+    monkeypatch.setenv("FEMBRAIN_TEST_REPORT_WIDE", "1")
+    info = _run_sharded(2, 0, 0, -4000)
+    assert all(kern in (1, 2) for *_, kern, wide in info) and any(wide > 0 for *_, kern, wide in info), info
 
 
 def test_auto_node_order_on_an_unstructured_mesh(gpu):
