@@ -1333,6 +1333,14 @@ bool host_finished(const CGState& s) {
 
 // One launch of the pipelined persistent solver (pcg_pipe.hip.h): `start` 1 = new solve from x = 0, 2 = new solve from the x in
 // memory, 0 = continue; at most n_iters iterations
+// 9 or 10 slices per CU in the plain 12-wavefront kernel: the LDS has room for 7 slots of a slice (65 / 9), one more than the (12, 6)
+// instantiation's unroll bound takes -- the (12, 7) instantiation is the same kernel with that bound (unsharded Jacobi handles without the
+// task table; FEMBRAIN_PIPE_KLT7=0 keeps (12, 6))
+static bool pipe_klt7(const fb_fem_s* h) {
+  const char* e = getenv("FEMBRAIN_PIPE_KLT7");
+  return h->persist && !h->shard_persist && h->pipe_rows == 1 && h->pipe_wmax == 12 && !h->pipe_tasks.p && h->prm.pcg_variant != FB_PCG_BLOCK_JACOBI &&
+         (h->persist_waves == 9 || h->persist_waves == 10) && !getenv("FEMBRAIN_PERSIST_TIMING") && !(e && atoi(e) == 0);
+}
 int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps, int max_iter) {
   PipeArgs pa;
   pa.post = h->pipe_post.p; pa.flags = h->pipe_flags.p; pa.error = h->pipe_flags.p + h->persist_blocks + h->pipe_flag_extra + 4; pa.seqs = h->pipe_flags.p + h->persist_blocks + h->pipe_flag_extra + 8;
@@ -1424,6 +1432,7 @@ int launch_pipe(fb_fem_s* h, const double* b, int start, int n_iters, double eps
     else return fail(FB_EINVAL, "FEMBRAIN_PERSIST_TIMING is built for one row per lane: (12, 6) and (5, 16) with 16-bit column words, (8, 8)");
   } else if (h->pipe_wmax == 5) { if (h->c16) FB_PIPE(true, 5, 16, false, false); else FB_PIPE(false, 5, 16, false, false); }
   else if (h->pipe_wmax == 8) { if (h->c16) FB_PIPE(true, 8, 8, false, false); else FB_PIPE(false, 8, 8, false, false); }
+  else if (pipe_klt7(h)) { if (h->c16) FB_PIPE(true, 12, 7, false, false); else FB_PIPE(false, 12, 7, false, false); }
   else { if (h->c16) FB_PIPE(true, 12, 6, false, false); else FB_PIPE(false, 12, 6, false, false); }
 #undef FB_PIPE2
 #undef FB_PIPE_BJ
@@ -3273,7 +3282,7 @@ int fb_fem_pcg_path(fb_fem_t h, char* name, int name_len, int* persist_launches,
     else if (h->persist && h->shard_persist) snprintf(name, name_len, "k_pcg_pipe_shard<%d,%d>", h->pipe_wmax, h->pipe_wmax == 8 ? 8 : 6);
     else if (h->persist && h->pipe_rows == 2) snprintf(name, name_len, "k_pcg_pipe2<%s>", h->c16 ? "c16" : "c32");
     else if (h->persist)
-      snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d%s>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_wmax == 5 ? 16 : (h->pipe_wmax == 8 ? 8 : 6),
+      snprintf(name, name_len, "k_pcg_pipe<float,%s,%d,%d%s>", h->c16 ? "c16" : "c32", h->pipe_wmax, h->pipe_wmax == 5 ? 16 : (h->pipe_wmax == 8 ? 8 : (pipe_klt7(h) ? 7 : 6)),
                h->prm.pcg_variant == FB_PCG_BLOCK_JACOBI ? ",bj" : "");
     else name[0] = 0;
   }

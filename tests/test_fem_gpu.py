@@ -1467,6 +1467,33 @@ def test_default_handle_between_1M_and_2M_tets_against_the_reference_built_golde
     g.close()
 
 
+@pytest.mark.parametrize("n,slices_per_cu", [(52, 9), (54, 10)])
+def test_nine_and_ten_slices_per_cu_keep_seven_slots_of_a_slice_in_lds(gpu, monkeypatch, n, slices_per_cu):
+    """Round 5: at 9 and 10 slices per CU the LDS has room for 7 slots of a slice, one more than the (12, 6) instantiation's loop takes;
+    k_pcg_pipe<float,c16,12,7> is the same kernel with that bound (52^3: 13.6 -> 13.0 us per iteration).  The sums of a row do not depend
+    on where its slots live: iterations and state bit for bit those of (12, 6) (FEMBRAIN_PIPE_KLT7=0), launch cuts included."""
+    v, t, fixed = _cube(n)
+    out = []
+    for k7 in ("1", "0"):
+        monkeypatch.setenv("FEMBRAIN_PIPE_KLT7", k7)
+        g = FemIntegrator(v, t, fixed)
+        on, waves, wgs, slots = g.persist_info()
+        assert on and waves == slices_per_cu and g.pcg_path()["kernel"] == "k_pcg_pipe<float,c16,12,%d>" % (7 if k7 == "1" else 6)
+        g.set_uniform_force(1, -10000.0)
+        it = g.do_timestep()
+        q = g.get_q_state()[0]
+        if k7 == "1":
+            g.reset_to_rest()
+            monkeypatch.setenv("FEMBRAIN_PERSIST_MAX_RUN", "400")
+            g.set_uniform_force(1, -10000.0)
+            assert g.do_timestep() == it and np.array_equal(g.get_q_state()[0], q)
+            monkeypatch.delenv("FEMBRAIN_PERSIST_MAX_RUN")
+        assert g.pcg_path()["fallbacks"] == 0 and g.last.pcg_path == fl.FB_PCG_PATH_PERSISTENT
+        out.append((it, q))
+        g.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+
+
 def test_persistent_solver_limits_are_refused_not_degraded(gpu, monkeypatch):
     """FB_PCG_PERSISTENT asked for explicitly where it cannot run is an error, not a silent other solver: fp64 storage, more than 24
     slices per CU.  The default (FB_PCG_MERGED) falls to the two-launch solver there and says so."""
