@@ -118,6 +118,7 @@ class HipIntegrator {
   double GetForceAssemblyTime() const { return info_.assembly_seconds; }
   double GetSystemSolveTime() const { return info_.solve_seconds; }
   int GetLastIterations() const { return info_.cg_iterations; }
+  int GetLastNewtonIterations() const { return info_.newton_iterations; }  // (Newmark: linear solves of the last step; 1 otherwise)
   int FloorCollision(double floorY, double restitution) {
     int n = 0;
     check(fb_fem_floor_collision(h_, floorY, restitution, &n));
