@@ -503,7 +503,9 @@ int setup_persist(fb_fem_s* h) {
     int widest = 0;
     for (int sl = 0; sl < P.n_slices; sl++) widest = std::max(widest, P.slice_off[sl + 1] - P.slice_off[sl]);
     const bool uneven = P.n_slices > 0 && (long long)widest * 2 * P.n_slices >= 3 * (long long)P.slice_off[P.n_slices];
-    const bool want = eb ? atoi(eb) != 0 : (worst * nb * 4 > total * 5 || (uneven && w <= kPipeMaxWaves && worst * nb * 100 > total * 115));  // (the two-row kernel at 13 slices per CU: 28.7 with the equal deal, 29.9 by slots)
+    // (uneven WIDTHS only: on a small uniform mesh the fullest workgroup is a quarter above the average because it holds 2 slices where others
+    // hold 1, which no deal changes -- and dealt by slots such a mesh was 2-5 % slower: 27^3 cube 8.65 -> 8.86 us per iteration, ventricle.blob 8.28 -> 8.62)
+    const bool want = eb ? atoi(eb) != 0 : (uneven && (worst * nb * 4 > total * 5 || (w <= kPipeMaxWaves && worst * nb * 100 > total * 115)));  // (the two-row kernel at 13 slices per CU: 28.7 with the equal deal, 29.9 by slots)
     if (want) {
       std::vector<int> tab((size_t)2 * nb + 2, 0);
       int most = 0;
