@@ -632,7 +632,9 @@ int setup_persist(fb_fem_s* h) {
       const bool even_share = !(getenv("FEMBRAIN_PIPE_LDS_BY_WIDTH") && atoi(getenv("FEMBRAIN_PIPE_LDS_BY_WIDTH")) != 0);
       // (with the node-by-node vector a resident slot's gathers cost a third of the lines, and slices that keep up to 12 slots in LDS instead
       // of 6 pay: sliver-free unstructured probe 16.2 -> 14.4 us per iteration, Delaunay probe 16.25 -> 15.9; 18 buys nothing more)
-      const int lds_cap = want_xyz ? 12 : 6;
+      // -- from 6 slices per CU on: with fewer, idle wavefronts split the streams (helpers) and a long LDS loop in the owner only delays them:
+      // 27,000 / 46,656 / 64,000-node lattices 11.0 / 12.2 / 13.5 us per iteration with 6 slots against 12.9 / 13.4 / 14.1 with 12
+      const int lds_cap = want_xyz && w >= 6 ? 12 : 6;
       for (int b = 0; b < nb; b++) {
         int first, count;
         pipe_deal(h->pipe_wg_first_host.empty() ? nullptr : h->pipe_wg_first_host.data(), P.n_slices, nb, b, &first, &count);
