@@ -1181,6 +1181,8 @@ def test_published_vector_node_by_node_gives_the_same_iterates(gpu, monkeypatch,
     out = []
     for xyz in ("1", "0"):
         monkeypatch.setenv("FEMBRAIN_PIPE_XYZ", xyz)
+        # (12 LDS slots of a slice is the library's choice from 6 slices per CU on; asked for here, on meshes of a slice or two per CU)
+        monkeypatch.setenv("FEMBRAIN_PIPE_LDS_CAP", "12" if xyz == "1" else "6")
         g = FemIntegrator(v, t, fixed, pcg_variant=fl.FB_PCG_PERSISTENT, matrix_precision=fl.FB_MATRIX_F32)
         assert g.persist_gather()[0] == (xyz == "1") and g.persist_gather()[1] > 0
         if rows == 1:
